@@ -1,0 +1,1083 @@
+/*
+ * oracle/h264_enc_oracle.c -- TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (see h264_oracle.h).
+ *
+ * Scalar CPU restatement of the encoder path that replaces the reference's
+ * `x264enc speed-preset=2 key-int-max=60 name=venc_kbps` pipeline token
+ * (/root/reference/pipeline/generic/x264_superfast_camlink:5; instantiated by
+ * /root/reference/src/io/pipeline_loader.c:59; bitrate driven through
+ * /root/reference/src/gst/encoder_control.c:53).  The reference tree contains no codec
+ * arithmetic, so every function cites the clause of ITU-T H.264 (04/2017 numbering) it
+ * restates, or says "encoder choice" where the standard leaves the encoder free.
+ *
+ * Stream shape: Constrained Baseline, CAVLC, one slice per picture, IDR every `gop`
+ * pictures, P pictures with one reference, macroblock types I16x16 (I pictures) and
+ * P_L0_16x16 / P_Skip (P pictures), integer-pel motion, in-loop deblocking on.
+ */
+#include "h264_oracle.h"
+#include "h264_tables_enc.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CLIP3(lo, hi, v) ((v) < (lo) ? (lo) : ((v) > (hi) ? (hi) : (v)))
+static inline int clip1(int v) { return CLIP3(0, 255, v); }
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+#define MAX_LEVEL 2047 /* keeps level_prefix <= 15 (Baseline, 9.2.2.1) */
+
+/* ================================================================== bit writer */
+typedef struct {
+    uint8_t *buf;
+    size_t cap, pos;
+    uint64_t acc;
+    int nbits;
+    int overflow;
+} bw_t;
+
+static void bw_init(bw_t *b, uint8_t *buf, size_t cap) {
+    b->buf = buf; b->cap = cap; b->pos = 0; b->acc = 0; b->nbits = 0; b->overflow = 0;
+}
+static void bw_put(bw_t *b, int n, uint32_t v) {
+    if (n == 0) return;
+    b->acc = (b->acc << n) | (v & (n == 32 ? 0xFFFFFFFFu : ((1u << n) - 1)));
+    b->nbits += n;
+    while (b->nbits >= 8) {
+        b->nbits -= 8;
+        if (b->pos < b->cap) b->buf[b->pos++] = (uint8_t)(b->acc >> b->nbits);
+        else b->overflow = 1;
+    }
+}
+/* 9.1 Exp-Golomb */
+int orc_ue_bits(uint32_t v, uint32_t *code) {
+    uint32_t k = v + 1;
+    int len = 0;
+    while ((k >> len) > 1) len++;
+    if (code) *code = k;
+    return 2 * len + 1;
+}
+static void bw_ue(bw_t *b, uint32_t v) {
+    uint32_t code;
+    int n = orc_ue_bits(v, &code);
+    if (n > 32) { bw_put(b, n - 32, 0); n = 32; }
+    bw_put(b, n, code);
+}
+static void bw_se(bw_t *b, int v) { bw_ue(b, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+static void bw_trailing(bw_t *b) { /* 7.3.2.11 rbsp_trailing_bits */
+    bw_put(b, 1, 1);
+    if (b->nbits) bw_put(b, 8 - b->nbits, 0);
+}
+
+/* 7.4.1.1 emulation prevention: 00 00 {00,01,02,03} -> 00 00 03 xx */
+size_t orc_nal_escape(const uint8_t *rbsp, size_t n, uint8_t *out, size_t cap) {
+    size_t o = 0;
+    int zeros = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (zeros >= 2 && rbsp[i] <= 3) {
+            if (o < cap) out[o] = 3;
+            o++;
+            zeros = 0;
+        }
+        if (o < cap) out[o] = rbsp[i];
+        o++;
+        zeros = rbsp[i] == 0 ? zeros + 1 : 0;
+    }
+    return o;
+}
+/* Annex B start code + NAL header + escaped payload.  Returns bytes written (0 = no room). */
+static size_t write_nal(uint8_t *out, size_t cap, int ref_idc, int type, const uint8_t *rbsp, size_t n) {
+    if (cap < 5) return 0;
+    out[0] = 0; out[1] = 0; out[2] = 0; out[3] = 1;
+    out[4] = (uint8_t)((ref_idc << 5) | type);
+    size_t e = orc_nal_escape(rbsp, n, out + 5, cap - 5);
+    if (e > cap - 5) return 0;
+    return 5 + e;
+}
+
+/* ================================================================== VLC tables */
+typedef struct { uint8_t len; uint16_t bits; } vlc_t;
+static vlc_t t_coeff_token[4][17][4];
+static vlc_t t_coeff_token_cdc[5][4];
+static vlc_t t_total_zeros[15][16];
+static vlc_t t_total_zeros_cdc[3][4];
+static vlc_t t_run_before[7][15];
+static int tables_ready;
+
+static vlc_t parse_vlc(const char *s) {
+    vlc_t v = {0, 0};
+    if (!s) return v;
+    for (; *s; s++) { v.bits = (uint16_t)((v.bits << 1) | (*s == '1')); v.len++; }
+    return v;
+}
+static void init_tables(void) {
+    if (tables_ready) return;
+    for (int t = 0; t < 3; t++)
+        for (int c = 0; c < 17; c++)
+            for (int o = 0; o < 4; o++) t_coeff_token[t][c][o] = parse_vlc(k_coeff_token_str[t][c][o]);
+    /* nC >= 8: 6-bit FLC (Table 9-5 last column) */
+    for (int c = 0; c < 17; c++)
+        for (int o = 0; o < 4; o++) {
+            vlc_t v = {0, 0};
+            if (c == 0 && o == 0) { v.len = 6; v.bits = 3; }
+            else if (c > 0 && o <= c && o < 4) { v.len = 6; v.bits = (uint16_t)(((c - 1) << 2) | o); }
+            t_coeff_token[3][c][o] = v;
+        }
+    for (int c = 0; c < 5; c++)
+        for (int o = 0; o < 4; o++) t_coeff_token_cdc[c][o] = parse_vlc(k_coeff_token_cdc_str[c][o]);
+    for (int i = 0; i < 15; i++)
+        for (int z = 0; z < 16; z++) t_total_zeros[i][z] = parse_vlc(k_total_zeros_str[i][z]);
+    for (int i = 0; i < 3; i++)
+        for (int z = 0; z < 4; z++) t_total_zeros_cdc[i][z] = parse_vlc(k_total_zeros_cdc_str[i][z]);
+    for (int i = 0; i < 7; i++)
+        for (int r = 0; r < 15; r++) t_run_before[i][r] = parse_vlc(k_run_before_str[i][r]);
+    tables_ready = 1;
+}
+
+/* FNV-1a checksums of the tables, for the KAT in tests/ */
+static uint32_t fnv(uint32_t h, const void *p, size_t n) {
+    const uint8_t *b = (const uint8_t *)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 16777619u; }
+    return h;
+}
+uint32_t orc_table_checksum(int which) {
+    init_tables();
+    uint32_t h = 2166136261u;
+    switch (which) {
+    case 0: for (int t = 0; t < 4; t++) for (int c = 0; c < 17; c++) for (int o = 0; o < 4; o++) {
+                h = fnv(h, &t_coeff_token[t][c][o].len, 1); h = fnv(h, &t_coeff_token[t][c][o].bits, 2); } break;
+    case 1: for (int c = 0; c < 5; c++) for (int o = 0; o < 4; o++) {
+                h = fnv(h, &t_coeff_token_cdc[c][o].len, 1); h = fnv(h, &t_coeff_token_cdc[c][o].bits, 2); } break;
+    case 2: for (int i = 0; i < 15; i++) for (int z = 0; z < 16; z++) {
+                h = fnv(h, &t_total_zeros[i][z].len, 1); h = fnv(h, &t_total_zeros[i][z].bits, 2); } break;
+    case 3: for (int i = 0; i < 3; i++) for (int z = 0; z < 4; z++) {
+                h = fnv(h, &t_total_zeros_cdc[i][z].len, 1); h = fnv(h, &t_total_zeros_cdc[i][z].bits, 2); } break;
+    case 4: for (int i = 0; i < 7; i++) for (int r = 0; r < 15; r++) {
+                h = fnv(h, &t_run_before[i][r].len, 1); h = fnv(h, &t_run_before[i][r].bits, 2); } break;
+    case 5: h = fnv(h, k_cbp_to_codenum_intra, 48); h = fnv(h, k_cbp_to_codenum_inter, 48); break;
+    case 6: h = fnv(h, k_zigzag4, 16); h = fnv(h, k_blk_x, 16); h = fnv(h, k_blk_y, 16); break;
+    case 7: h = fnv(h, k_dequant_v, sizeof k_dequant_v); h = fnv(h, k_quant_mf, sizeof k_quant_mf); break;
+    case 8: h = fnv(h, k_chroma_qp, 52); break;
+    case 9: h = fnv(h, k_alpha, 52); h = fnv(h, k_beta, 52); h = fnv(h, k_tc0, sizeof k_tc0); break;
+    case 10: h = fnv(h, k_me_lambda, 52); break;
+    default: return 0;
+    }
+    return h;
+}
+/* raw access for the cross-check against the decoder's transcription */
+int orc_enc_vlc(int table, int a, int b, int c, int *len, int *bits) {
+    init_tables();
+    vlc_t v = {0, 0};
+    switch (table) {
+    case 0: if (a < 4 && b < 17 && c < 4) v = t_coeff_token[a][b][c]; break;
+    case 1: if (b < 5 && c < 4) v = t_coeff_token_cdc[b][c]; break;
+    case 2: if (b < 15 && c < 16) v = t_total_zeros[b][c]; break;
+    case 3: if (b < 3 && c < 4) v = t_total_zeros_cdc[b][c]; break;
+    case 4: if (b < 7 && c < 15) v = t_run_before[b][c]; break;
+    default: break;
+    }
+    *len = v.len; *bits = v.bits;
+    return v.len != 0;
+}
+int orc_enc_cbp_codenum(int intra, int cbp) { return intra ? k_cbp_to_codenum_intra[cbp] : k_cbp_to_codenum_inter[cbp]; }
+int orc_me_lambda(int qp) { return k_me_lambda[CLIP3(0, 51, qp)]; }
+
+/* ================================================================== transforms */
+static inline int pos_class(int pos) { /* pos = y*4+x */
+    int x = pos & 3, y = pos >> 2;
+    if (!(x & 1) && !(y & 1)) return 0;
+    if ((x & 1) && (y & 1)) return 1;
+    return 2;
+}
+/* forward 4x4 core transform Y = Cf X Cf^T (encoder side of 8.5.12) */
+void orc_fdct4(const int16_t in[16], int16_t out[16]) {
+    int tmp[16];
+    for (int i = 0; i < 4; i++) {
+        int a = in[i * 4 + 0], b = in[i * 4 + 1], c = in[i * 4 + 2], d = in[i * 4 + 3];
+        int s03 = a + d, d03 = a - d, s12 = b + c, d12 = b - c;
+        tmp[i * 4 + 0] = s03 + s12;
+        tmp[i * 4 + 1] = 2 * d03 + d12;
+        tmp[i * 4 + 2] = s03 - s12;
+        tmp[i * 4 + 3] = d03 - 2 * d12;
+    }
+    for (int j = 0; j < 4; j++) {
+        int a = tmp[0 * 4 + j], b = tmp[1 * 4 + j], c = tmp[2 * 4 + j], d = tmp[3 * 4 + j];
+        int s03 = a + d, d03 = a - d, s12 = b + c, d12 = b - c;
+        out[0 * 4 + j] = (int16_t)(s03 + s12);
+        out[1 * 4 + j] = (int16_t)(2 * d03 + d12);
+        out[2 * 4 + j] = (int16_t)(s03 - s12);
+        out[3 * 4 + j] = (int16_t)(d03 - 2 * d12);
+    }
+}
+/* 8.5.12.2 inverse 4x4 transform (rows, then columns), (x+32)>>6, add to prediction.
+ * `step` is the byte distance between horizontally adjacent samples (2 for NV12 chroma). */
+static void idct4_add_step(const int32_t d[16], uint8_t *dst, int stride, int step) {
+    int f[16];
+    for (int i = 0; i < 4; i++) {
+        int e0 = d[i * 4 + 0] + d[i * 4 + 2];
+        int e1 = d[i * 4 + 0] - d[i * 4 + 2];
+        int e2 = (d[i * 4 + 1] >> 1) - d[i * 4 + 3];
+        int e3 = d[i * 4 + 1] + (d[i * 4 + 3] >> 1);
+        f[i * 4 + 0] = e0 + e3; f[i * 4 + 1] = e1 + e2;
+        f[i * 4 + 2] = e1 - e2; f[i * 4 + 3] = e0 - e3;
+    }
+    for (int j = 0; j < 4; j++) {
+        int g0 = f[0 * 4 + j] + f[2 * 4 + j];
+        int g1 = f[0 * 4 + j] - f[2 * 4 + j];
+        int g2 = (f[1 * 4 + j] >> 1) - f[3 * 4 + j];
+        int g3 = f[1 * 4 + j] + (f[3 * 4 + j] >> 1);
+        int h[4] = {g0 + g3, g1 + g2, g1 - g2, g0 - g3};
+        for (int i = 0; i < 4; i++) {
+            uint8_t *p = dst + (size_t)i * stride + j * step;
+            *p = (uint8_t)clip1(*p + ((h[i] + 32) >> 6));
+        }
+    }
+}
+void orc_idct4_add(const int32_t d[16], uint8_t *dst, int stride) { idct4_add_step(d, dst, stride, 1); }
+/* encoder choice: dead-zone quantiser, f = 2^qbits/3 intra, /6 inter; |level| <= MAX_LEVEL */
+int orc_quant4(int coef, int qp, int pos, int intra) {
+    int qbits = 15 + qp / 6;
+    int f = (1 << qbits) / (intra ? 3 : 6);
+    int mf = k_quant_mf[qp % 6][pos_class(pos)];
+    int l = (int)(((int64_t)iabs(coef) * mf + f) >> qbits);
+    if (l > MAX_LEVEL) l = MAX_LEVEL;
+    return coef < 0 ? -l : l;
+}
+static int quant_dc(int coef, int qp, int intra) { /* luma-DC / chroma-DC: one more bit */
+    int qbits = 16 + qp / 6;
+    int f = (1 << qbits) / (intra ? 3 : 6);
+    int mf = k_quant_mf[qp % 6][0];
+    int l = (int)(((int64_t)iabs(coef) * mf + f) >> qbits);
+    if (l > MAX_LEVEL) l = MAX_LEVEL;
+    return coef < 0 ? -l : l;
+}
+/* 8.5.12.1 with flat scaling lists: d = (c * LevelScale4x4) scaled by qP/6; flat lists make
+ * LevelScale = 16*v, and the <<(qP/6-4) / rounded >> forms both reduce to (c*v) << (qP/6). */
+int orc_dequant4(int level, int qp, int pos) {
+    return (level * k_dequant_v[qp % 6][pos_class(pos)]) << (qp / 6);
+}
+
+/* residual of one 4x4 block -> levels in zig-zag order; returns 1 if any level (from `first`) != 0 */
+static int tq_block(const int16_t res[16], int qp, int intra, int first, int16_t lev_zz[16], int16_t *dc_out) {
+    int16_t co[16];
+    orc_fdct4(res, co);
+    if (dc_out) *dc_out = co[0];
+    int nz = 0;
+    for (int k = 0; k < 16; k++) {
+        if (k < first) { lev_zz[k] = 0; continue; }
+        int pos = k_zigzag4[k];
+        int l = orc_quant4(co[pos], qp, pos, intra);
+        lev_zz[k] = (int16_t)l;
+        nz |= l != 0;
+    }
+    return nz;
+}
+/* levels (zig-zag) -> scaled coefficients d[] in raster order; `dc` overrides d[0] when have_dc */
+static void dq_block(const int16_t lev_zz[16], int qp, int first, int have_dc, int dc, int32_t d[16]) {
+    for (int k = 0; k < 16; k++) {
+        int pos = k_zigzag4[k];
+        d[pos] = k < first ? 0 : orc_dequant4(lev_zz[k], qp, pos);
+    }
+    if (have_dc) d[0] = dc;
+}
+
+/* ================================================================== motion search */
+static inline int mv_bits(int v_int) { /* se(v) length of the quarter-pel value 4*v_int */
+    int q = 4 * v_int;
+    uint32_t k = q > 0 ? (uint32_t)(2 * q - 1) : (uint32_t)(-2 * q);
+    return orc_ue_bits(k, NULL);
+}
+/* Encoder choice (the standard does not constrain motion search).  For each macroblock:
+ * candidates (dx,dy) in [-range,range]^2 whose 16x16 block lies inside the coded picture;
+ * cost = SAD + lambda(qp) * (bits(se(4dx)) + bits(se(4dy)));
+ * winner = lowest cost, then lowest |dx|+|dy|, then lowest dy, then lowest dx. */
+void orc_me_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mbw, int mbh,
+                  int range, int qp, orc_mbinfo_t *mbi, int threads) {
+    const int W = mbw * 16, H = mbh * 16;
+    const int lambda = orc_me_lambda(qp);
+    (void)threads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (int my = 0; my < mbh; my++) {
+        for (int mx = 0; mx < mbw; mx++) {
+            int x0 = mx * 16, y0 = my * 16;
+            int dx_lo = -range < -x0 ? -x0 : -range, dx_hi = range > W - 16 - x0 ? W - 16 - x0 : range;
+            int dy_lo = -range < -y0 ? -y0 : -range, dy_hi = range > H - 16 - y0 ? H - 16 - y0 : range;
+            uint32_t best_cost = 0xFFFFFFFFu;
+            int best_dx = 0, best_dy = 0;
+            const uint8_t *c = cur_y + (size_t)y0 * stride + x0;
+            for (int dy = dy_lo; dy <= dy_hi; dy++) {
+                for (int dx = dx_lo; dx <= dx_hi; dx++) {
+                    const uint8_t *r = ref_y + (size_t)(y0 + dy) * stride + x0 + dx;
+                    uint32_t sad = 0;
+                    for (int y = 0; y < 16; y++)
+                        for (int x = 0; x < 16; x++) sad += (uint32_t)iabs(c[y * stride + x] - r[y * stride + x]);
+                    uint32_t cost = sad + (uint32_t)(lambda * (mv_bits(dx) + mv_bits(dy)));
+                    int better = 0;
+                    if (cost < best_cost) better = 1;
+                    else if (cost == best_cost) {
+                        int m = iabs(dx) + iabs(dy), bm = iabs(best_dx) + iabs(best_dy);
+                        if (m < bm) better = 1;
+                        else if (m == bm && (dy < best_dy || (dy == best_dy && dx < best_dx))) better = 1;
+                    }
+                    if (better) { best_cost = cost; best_dx = dx; best_dy = dy; }
+                }
+            }
+            orc_mbinfo_t *m = &mbi[my * mbw + mx];
+            m->mvx = (int16_t)best_dx; m->mvy = (int16_t)best_dy; m->cost = best_cost;
+        }
+    }
+}
+
+/* ================================================================== chroma helpers */
+/* NV12 interleaved chroma: plane c (0 = Cb, 1 = Cr) sample (x,y) lives at uv[y*stride + 2x + c] */
+#define UV(p, stride, x, y, c) ((p)[(size_t)(y) * (stride) + 2 * (x) + (c)])
+
+/* shared by intra and inter: transform/quant/reconstruct the two 8x8 chroma blocks of one
+ * macroblock, given the prediction already written into rec_uv.  8.5.11 (chroma DC 2x2),
+ * 8.5.12; Table 8-15 for QPc. */
+static void chroma_tq_recon(const uint8_t *src_uv, uint8_t *rec_uv, int stride, int cx0, int cy0,
+                            int qp, int intra, int16_t *lev, uint32_t *nzmask) {
+    int qpc = k_chroma_qp[CLIP3(0, 51, qp)];
+    for (int c = 0; c < 2; c++) {
+        int16_t dc[4];
+        int16_t *ldc = lev + ORC_L_CDC + 4 * c;
+        for (int b = 0; b < 4; b++) {
+            int bx = (b & 1) * 4, by = (b >> 1) * 4;
+            int16_t res[16];
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++)
+                    res[y * 4 + x] = (int16_t)(UV(src_uv, stride, cx0 + bx + x, cy0 + by + y, c) -
+                                               UV(rec_uv, stride, cx0 + bx + x, cy0 + by + y, c));
+            int16_t *l = lev + ORC_L_CAC + (4 * c + b) * 16;
+            if (tq_block(res, qpc, intra, 1, l, &dc[b])) *nzmask |= 1u << (16 + 4 * c + b);
+        }
+        /* forward 2x2 Hadamard of the four DCs (raster order), then quantise */
+        int f0 = dc[0] + dc[1] + dc[2] + dc[3];
+        int f1 = dc[0] - dc[1] + dc[2] - dc[3];
+        int f2 = dc[0] + dc[1] - dc[2] - dc[3];
+        int f3 = dc[0] - dc[1] - dc[2] + dc[3];
+        ldc[0] = (int16_t)quant_dc(f0, qpc, intra);
+        ldc[1] = (int16_t)quant_dc(f1, qpc, intra);
+        ldc[2] = (int16_t)quant_dc(f2, qpc, intra);
+        ldc[3] = (int16_t)quant_dc(f3, qpc, intra);
+        if (ldc[0] | ldc[1] | ldc[2] | ldc[3]) *nzmask |= (c ? ORC_NZ_CRDC : ORC_NZ_CBDC);
+    }
+    /* 7.3.5: chroma AC levels are only transmitted when coded_block_pattern chroma == 2,
+     * which this encoder sets when any AC level of either plane is non-zero. */
+    for (int c = 0; c < 2; c++) {
+        const int16_t *ldc = lev + ORC_L_CDC + 4 * c;
+        /* 8.5.11.1/2: c = [[l0,l1],[l2,l3]], f = H c H, dcC = ((f*LevelScale(0,0)) << (qP/6)) >> 5 */
+        int g0 = ldc[0] + ldc[1] + ldc[2] + ldc[3];
+        int g1 = ldc[0] - ldc[1] + ldc[2] - ldc[3];
+        int g2 = ldc[0] + ldc[1] - ldc[2] - ldc[3];
+        int g3 = ldc[0] - ldc[1] - ldc[2] + ldc[3];
+        int ls = 16 * k_dequant_v[qpc % 6][0];
+        int dcv[4] = {((g0 * ls) << (qpc / 6)) >> 5, ((g1 * ls) << (qpc / 6)) >> 5,
+                      ((g2 * ls) << (qpc / 6)) >> 5, ((g3 * ls) << (qpc / 6)) >> 5};
+        for (int b = 0; b < 4; b++) {
+            int bx = (b & 1) * 4, by = (b >> 1) * 4;
+            int32_t d[16];
+            dq_block(lev + ORC_L_CAC + (4 * c + b) * 16, qpc, 1, 1, dcv[b], d);
+            idct4_add_step(d, &UV(rec_uv, stride, cx0 + bx, cy0 + by, c), stride, 2);
+        }
+    }
+}
+
+/* ================================================================== inter (P) picture */
+/* 8.4.2.2.1 integer sample fetch + 8.4.2.2.2 chroma bilinear (xFrac,yFrac in {0,4} for
+ * integer luma vectors); 8.4.1.4: chroma vector = luma vector, units of 1/8 chroma sample. */
+static void mc_mb(const uint8_t *ref_y, const uint8_t *ref_uv, uint8_t *rec_y, uint8_t *rec_uv,
+                  int stride, int W, int H, int x0, int y0, int mvx, int mvy) {
+    for (int y = 0; y < 16; y++)
+        for (int x = 0; x < 16; x++) {
+            int sx = CLIP3(0, W - 1, x0 + x + mvx), sy = CLIP3(0, H - 1, y0 + y + mvy);
+            rec_y[(size_t)(y0 + y) * stride + x0 + x] = ref_y[(size_t)sy * stride + sx];
+        }
+    int cw = W / 2, ch = H / 2, cx0 = x0 / 2, cy0 = y0 / 2;
+    int mvcx = 4 * mvx, mvcy = 4 * mvy; /* quarter luma units == 1/8 chroma units */
+    int xi = mvcx >> 3, yi = mvcy >> 3, xf = mvcx & 7, yf = mvcy & 7;
+    for (int c = 0; c < 2; c++)
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++) {
+                int ax = CLIP3(0, cw - 1, cx0 + x + xi), bx = CLIP3(0, cw - 1, cx0 + x + xi + 1);
+                int ay = CLIP3(0, ch - 1, cy0 + y + yi), cy = CLIP3(0, ch - 1, cy0 + y + yi + 1);
+                int A = UV(ref_uv, stride, ax, ay, c), B = UV(ref_uv, stride, bx, ay, c);
+                int C = UV(ref_uv, stride, ax, cy, c), D = UV(ref_uv, stride, bx, cy, c);
+                UV(rec_uv, stride, cx0 + x, cy0 + y, c) =
+                    (uint8_t)(((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6);
+            }
+}
+
+void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y,
+                     const uint8_t *ref_uv, uint8_t *rec_y, uint8_t *rec_uv, int stride,
+                     int mbw, int mbh, int qp, orc_mbinfo_t *mbi, int16_t *levels) {
+    const int W = mbw * 16, H = mbh * 16;
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            orc_mbinfo_t *m = &mbi[my * mbw + mx];
+            int16_t *lev = levels + (size_t)(my * mbw + mx) * ORC_LEVELS_PER_MB;
+            memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
+            int x0 = mx * 16, y0 = my * 16;
+            m->mb_type = 1; m->i16_mode = 0; m->chroma_mode = 0; m->qp = (uint8_t)qp; m->nzmask = 0;
+            mc_mb(ref_y, ref_uv, rec_y, rec_uv, stride, W, H, x0, y0, m->mvx, m->mvy);
+            for (int b = 0; b < 16; b++) {
+                int bx = x0 + k_blk_x[b], by = y0 + k_blk_y[b];
+                int16_t res[16];
+                for (int y = 0; y < 4; y++)
+                    for (int x = 0; x < 4; x++)
+                        res[y * 4 + x] = (int16_t)(src_y[(size_t)(by + y) * stride + bx + x] -
+                                                   rec_y[(size_t)(by + y) * stride + bx + x]);
+                if (tq_block(res, qp, 0, 0, lev + ORC_L_LUMA + b * 16, NULL)) m->nzmask |= 1u << b;
+            }
+            for (int b = 0; b < 16; b++) {
+                if (!(m->nzmask & (1u << b))) continue;
+                int32_t d[16];
+                dq_block(lev + ORC_L_LUMA + b * 16, qp, 0, 0, 0, d);
+                orc_idct4_add(d, rec_y + (size_t)(y0 + k_blk_y[b]) * stride + x0 + k_blk_x[b], stride);
+            }
+            chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 0, lev, &m->nzmask);
+        }
+}
+
+/* ================================================================== intra (I) picture */
+/* 8.3.3 Intra_16x16 prediction, written into out[256] */
+static void pred16(const uint8_t *rec_y, int stride, int x0, int y0, int mode, int has_top, int has_left,
+                   uint8_t out[256]) {
+    const uint8_t *p = rec_y + (size_t)y0 * stride + x0;
+    if (mode == 0) { /* vertical 8.3.3.1 */
+        for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) out[y * 16 + x] = p[-stride + x];
+    } else if (mode == 1) { /* horizontal 8.3.3.2 */
+        for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) out[y * 16 + x] = p[y * stride - 1];
+    } else if (mode == 2) { /* DC 8.3.3.3 */
+        int s = 0, v;
+        if (has_top) for (int x = 0; x < 16; x++) s += p[-stride + x];
+        if (has_left) for (int y = 0; y < 16; y++) s += p[y * stride - 1];
+        if (has_top && has_left) v = (s + 16) >> 5;
+        else if (has_top || has_left) v = (s + 8) >> 4;
+        else v = 128;
+        memset(out, v, 256);
+    } else { /* plane 8.3.3.4 */
+        int Hh = 0, Vv = 0;
+        for (int i = 0; i < 8; i++) {
+            Hh += (i + 1) * (p[-stride + 8 + i] - p[-stride + 6 - i]);
+            Vv += (i + 1) * (p[(8 + i) * stride - 1] - p[(6 - i) * stride - 1]);
+        }
+        int a = 16 * (p[15 * stride - 1] + p[-stride + 15]);
+        int b = (5 * Hh + 32) >> 6, c = (5 * Vv + 32) >> 6;
+        for (int y = 0; y < 16; y++)
+            for (int x = 0; x < 16; x++) out[y * 16 + x] = (uint8_t)clip1((a + b * (x - 7) + c * (y - 7) + 16) >> 5);
+    }
+}
+/* 8.3.4 chroma prediction for one plane, out[64] */
+static void pred_chroma(const uint8_t *rec_uv, int stride, int cx0, int cy0, int c, int mode, int has_top,
+                        int has_left, uint8_t out[64]) {
+#define T(x) UV(rec_uv, stride, cx0 + (x), cy0 - 1, c)
+#define L(y) UV(rec_uv, stride, cx0 - 1, cy0 + (y), c)
+    if (mode == 0) { /* DC 8.3.4.1-3, per 4x4 chroma block */
+        for (int b = 0; b < 4; b++) {
+            int bx = (b & 1) * 4, by = (b >> 1) * 4, v;
+            int st = 0, sl = 0;
+            if (has_top) for (int i = 0; i < 4; i++) st += T(bx + i);
+            if (has_left) for (int i = 0; i < 4; i++) sl += L(by + i);
+            if (b == 0 || b == 3) {
+                if (has_top && has_left) v = (st + sl + 4) >> 3;
+                else if (has_top) v = (st + 2) >> 2;
+                else if (has_left) v = (sl + 2) >> 2;
+                else v = 128;
+            } else if (b == 1) {
+                if (has_top) v = (st + 2) >> 2;
+                else if (has_left) v = (sl + 2) >> 2;
+                else v = 128;
+            } else {
+                if (has_left) v = (sl + 2) >> 2;
+                else if (has_top) v = (st + 2) >> 2;
+                else v = 128;
+            }
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) out[(by + y) * 8 + bx + x] = (uint8_t)v;
+        }
+    } else if (mode == 1) { /* horizontal */
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) out[y * 8 + x] = L(y);
+    } else if (mode == 2) { /* vertical */
+        for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) out[y * 8 + x] = T(x);
+    } else { /* plane 8.3.4.4, xCF = yCF = 0 */
+        int Hh = 0, Vv = 0;
+        for (int i = 0; i < 4; i++) {
+            Hh += (i + 1) * (T(4 + i) - T(2 - i));
+            Vv += (i + 1) * (L(4 + i) - L(2 - i));
+        }
+        int a = 16 * (L(7) + T(7));
+        int b = (34 * Hh + 32) >> 6, cc = (34 * Vv + 32) >> 6;
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++) out[y * 8 + x] = (uint8_t)clip1((a + b * (x - 3) + cc * (y - 3) + 16) >> 5);
+    }
+#undef T
+#undef L
+}
+
+/* Mode decision is an encoder choice: lowest SAD(source, prediction) among the modes whose
+ * neighbours exist; ties go to the lowest mode number.  Chroma decides on Cb+Cr jointly. */
+void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
+                     uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
+                     orc_mbinfo_t *mbi, int16_t *levels) {
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            orc_mbinfo_t *m = &mbi[my * mbw + mx];
+            int16_t *lev = levels + (size_t)(my * mbw + mx) * ORC_LEVELS_PER_MB;
+            memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
+            int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0;
+            m->mb_type = 0; m->mvx = 0; m->mvy = 0; m->qp = (uint8_t)qp; m->nzmask = 0;
+            /* --- luma mode */
+            uint8_t pred[256], best_pred[256];
+            uint32_t best = 0xFFFFFFFFu; int best_mode = 2;
+            for (int mode = 0; mode < 4; mode++) {
+                if (mode == 0 && !has_top) continue;
+                if (mode == 1 && !has_left) continue;
+                if (mode == 3 && !(has_top && has_left)) continue;
+                pred16(rec_y, stride, x0, y0, mode, has_top, has_left, pred);
+                uint32_t sad = 0;
+                for (int y = 0; y < 16; y++)
+                    for (int x = 0; x < 16; x++) sad += (uint32_t)iabs(src_y[(size_t)(y0 + y) * stride + x0 + x] - pred[y * 16 + x]);
+                if (sad < best) { best = sad; best_mode = mode; memcpy(best_pred, pred, 256); }
+            }
+            m->i16_mode = (uint8_t)best_mode;
+            uint32_t luma_sad = best;
+            /* --- chroma mode */
+            uint8_t cp[2][64], best_cp[2][64];
+            best = 0xFFFFFFFFu; int best_cmode = 0;
+            for (int mode = 0; mode < 4; mode++) {
+                if (mode == 1 && !has_left) continue;
+                if (mode == 2 && !has_top) continue;
+                if (mode == 3 && !(has_top && has_left)) continue;
+                uint32_t sad = 0;
+                for (int c = 0; c < 2; c++) {
+                    pred_chroma(rec_uv, stride, x0 / 2, y0 / 2, c, mode, has_top, has_left, cp[c]);
+                    for (int y = 0; y < 8; y++)
+                        for (int x = 0; x < 8; x++) sad += (uint32_t)iabs(UV(src_uv, stride, x0 / 2 + x, y0 / 2 + y, c) - cp[c][y * 8 + x]);
+                }
+                if (sad < best) { best = sad; best_cmode = mode; memcpy(best_cp, cp, sizeof cp); }
+            }
+            m->chroma_mode = (uint8_t)best_cmode;
+            m->cost = luma_sad + best;
+            /* --- luma residual: 16 x (4x4 core), DCs through the 4x4 Hadamard (8.5.10 inverse) */
+            int16_t dcs[16]; /* raster over 4x4 blocks: index (by/4)*4 + bx/4 */
+            for (int b = 0; b < 16; b++) {
+                int bx = k_blk_x[b], by = k_blk_y[b];
+                int16_t res[16], dc;
+                for (int y = 0; y < 4; y++)
+                    for (int x = 0; x < 4; x++)
+                        res[y * 4 + x] = (int16_t)(src_y[(size_t)(y0 + by + y) * stride + x0 + bx + x] - best_pred[(by + y) * 16 + bx + x]);
+                if (tq_block(res, qp, 1, 1, lev + ORC_L_LUMA + b * 16, &dc)) m->nzmask |= 1u << b;
+                dcs[(by / 4) * 4 + bx / 4] = dc;
+            }
+            /* forward Hadamard, halved with rounding (encoder choice), then DC quantiser */
+            int t[16], hd[16];
+            for (int i = 0; i < 4; i++) {
+                int a = dcs[i * 4], b = dcs[i * 4 + 1], c = dcs[i * 4 + 2], d = dcs[i * 4 + 3];
+                t[i * 4 + 0] = a + b + c + d; t[i * 4 + 1] = a + b - c - d;
+                t[i * 4 + 2] = a - b - c + d; t[i * 4 + 3] = a - b + c - d;
+            }
+            for (int j = 0; j < 4; j++) {
+                int a = t[j], b = t[4 + j], c = t[8 + j], d = t[12 + j];
+                hd[j] = (a + b + c + d + 1) >> 1; hd[4 + j] = (a + b - c - d + 1) >> 1;
+                hd[8 + j] = (a - b - c + d + 1) >> 1; hd[12 + j] = (a - b + c - d + 1) >> 1;
+            }
+            int16_t *ldc = lev + ORC_L_LDC;
+            for (int k = 0; k < 16; k++) {
+                ldc[k] = (int16_t)quant_dc(hd[k_zigzag4[k]], qp, 1);
+                if (ldc[k]) m->nzmask |= ORC_NZ_LDC;
+            }
+            /* 7.3.5.3: Intra16x16 AC levels are sent for all 16 blocks or none (cbp luma 15/0) */
+            /* --- luma reconstruction: 8.5.10 (DC) then 8.5.12 per block */
+            int cm[16], f[16], dcy[16];
+            for (int k = 0; k < 16; k++) cm[k_zigzag4[k]] = ldc[k];
+            for (int i = 0; i < 4; i++) {
+                int a = cm[i * 4], b = cm[i * 4 + 1], c = cm[i * 4 + 2], d = cm[i * 4 + 3];
+                t[i * 4 + 0] = a + b + c + d; t[i * 4 + 1] = a + b - c - d;
+                t[i * 4 + 2] = a - b - c + d; t[i * 4 + 3] = a - b + c - d;
+            }
+            for (int j = 0; j < 4; j++) {
+                int a = t[j], b = t[4 + j], c = t[8 + j], d = t[12 + j];
+                f[j] = a + b + c + d; f[4 + j] = a + b - c - d;
+                f[8 + j] = a - b - c + d; f[12 + j] = a - b + c - d;
+            }
+            int ls = 16 * k_dequant_v[qp % 6][0];
+            for (int k = 0; k < 16; k++)
+                dcy[k] = qp >= 36 ? (f[k] * ls) << (qp / 6 - 6) : (f[k] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+            for (int y = 0; y < 16; y++) memcpy(rec_y + (size_t)(y0 + y) * stride + x0, best_pred + y * 16, 16);
+            for (int b = 0; b < 16; b++) {
+                int bx = k_blk_x[b], by = k_blk_y[b];
+                int32_t d[16];
+                dq_block(lev + ORC_L_LUMA + b * 16, qp, 1, 1, dcy[(by / 4) * 4 + bx / 4], d);
+                orc_idct4_add(d, rec_y + (size_t)(y0 + by) * stride + x0 + bx, stride);
+            }
+            /* --- chroma */
+            for (int c = 0; c < 2; c++)
+                for (int y = 0; y < 8; y++)
+                    for (int x = 0; x < 8; x++) UV(rec_uv, stride, x0 / 2 + x, y0 / 2 + y, c) = best_cp[c][y * 8 + x];
+            chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 1, lev, &m->nzmask);
+        }
+}
+
+/* ================================================================== deblocking (8.7) */
+/* one line of samples across an edge: p[0..3] going away from the edge on one side, q likewise */
+static void filter_line(uint8_t *pix, int dstep, int bS, int qp_p, int qp_q, int chroma) {
+    if (bS == 0) return;
+    int qpav = (qp_p + qp_q + 1) >> 1;
+    int indexA = CLIP3(0, 51, qpav), indexB = CLIP3(0, 51, qpav); /* FilterOffsetA = FilterOffsetB = 0 */
+    int alpha = k_alpha[indexA], beta = k_beta[indexB];
+    int p0 = pix[-1 * dstep], p1 = pix[-2 * dstep], p2 = pix[-3 * dstep];
+    int q0 = pix[0], q1 = pix[1 * dstep], q2 = pix[2 * dstep];
+    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    if (bS < 4) { /* 8.7.2.3 */
+        int tc0 = k_tc0[indexA][bS - 1];
+        int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
+        int tc = chroma ? tc0 + 1 : tc0 + (ap < beta) + (aq < beta);
+        int delta = CLIP3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        pix[-1 * dstep] = (uint8_t)clip1(p0 + delta);
+        pix[0] = (uint8_t)clip1(q0 - delta);
+        if (!chroma) {
+            if (ap < beta) pix[-2 * dstep] = (uint8_t)(p1 + CLIP3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1));
+            if (aq < beta) pix[1 * dstep] = (uint8_t)(q1 + CLIP3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1));
+        }
+    } else { /* 8.7.2.4 */
+        if (chroma) {
+            pix[-1 * dstep] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+            pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+        } else {
+            int p3 = pix[-4 * dstep], q3 = pix[3 * dstep];
+            int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
+            int small = iabs(p0 - q0) < ((alpha >> 2) + 2);
+            if (ap < beta && small) {
+                pix[-1 * dstep] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+                pix[-2 * dstep] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
+                pix[-3 * dstep] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+            } else pix[-1 * dstep] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+            if (aq < beta && small) {
+                pix[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+                pix[1 * dstep] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
+                pix[2 * dstep] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+            } else pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+        }
+    }
+}
+/* 8.7.2.1 boundary strength between the 4x4 luma blocks at raster positions (bxp,byp) of
+ * macroblock mp and (bxq,byq) of macroblock mq (frame pictures, one reference picture). */
+static int blk_has_coef(const orc_mbinfo_t *m, int bx4, int by4) {
+    static const uint8_t raster_to_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+    int b = raster_to_blk[by4 * 4 + bx4];
+    if (m->mb_type == 0) return 1; /* intra handled before this is consulted */
+    return (m->nzmask >> b) & 1;
+}
+static int bs_of(const orc_mbinfo_t *mp, int bxp, int byp, const orc_mbinfo_t *mq, int bxq, int byq, int mb_edge) {
+    if (mp->mb_type == 0 || mq->mb_type == 0) return mb_edge ? 4 : 3;
+    if (blk_has_coef(mp, bxp, byp) || blk_has_coef(mq, bxq, byq)) return 2;
+    if (iabs(4 * mp->mvx - 4 * mq->mvx) >= 4 || iabs(4 * mp->mvy - 4 * mq->mvy) >= 4) return 1;
+    return 0;
+}
+void orc_deblock_frame(uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mbh,
+                       const orc_mbinfo_t *mbi) {
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            const orc_mbinfo_t *m = &mbi[my * mbw + mx];
+            int x0 = mx * 16, y0 = my * 16;
+            int qpc_q = k_chroma_qp[m->qp];
+            /* vertical edges, left to right */
+            for (int e = 0; e < 4; e++) {
+                if (e == 0 && mx == 0) continue;
+                const orc_mbinfo_t *mp = e == 0 ? m - 1 : m;
+                int qpc_p = k_chroma_qp[mp->qp];
+                for (int k = 0; k < 16; k++) {
+                    int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 2, m, e, k >> 2, e == 0);
+                    filter_line(rec_y + (size_t)(y0 + k) * stride + x0 + 4 * e, 1, bS, mp->qp, m->qp, 0);
+                }
+                if ((e & 1) == 0) /* chroma edges at chroma x = 0 and 4 */
+                    for (int c = 0; c < 2; c++)
+                        for (int k = 0; k < 8; k++) {
+                            int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 1, m, e, k >> 1, e == 0);
+                            filter_line(&UV(rec_uv, stride, x0 / 2 + 2 * e, y0 / 2 + k, c), 2, bS, qpc_p, qpc_q, 1);
+                        }
+            }
+            /* horizontal edges, top to bottom */
+            for (int e = 0; e < 4; e++) {
+                if (e == 0 && my == 0) continue;
+                const orc_mbinfo_t *mp = e == 0 ? m - mbw : m;
+                int qpc_p = k_chroma_qp[mp->qp];
+                for (int k = 0; k < 16; k++) {
+                    int bS = bs_of(mp, k >> 2, e == 0 ? 3 : e - 1, m, k >> 2, e, e == 0);
+                    filter_line(rec_y + (size_t)(y0 + 4 * e) * stride + x0 + k, stride, bS, mp->qp, m->qp, 0);
+                }
+                if ((e & 1) == 0)
+                    for (int c = 0; c < 2; c++)
+                        for (int k = 0; k < 8; k++) {
+                            int bS = bs_of(mp, k >> 1, e == 0 ? 3 : e - 1, m, k >> 1, e, e == 0);
+                            filter_line(&UV(rec_uv, stride, x0 / 2 + k, y0 / 2 + 2 * e, c), stride, bS, qpc_p, qpc_q, 1);
+                        }
+            }
+        }
+}
+
+/* ================================================================== CAVLC (9.2) */
+/* One residual block: coef[0..maxnum-1] in scan order.  Returns TotalCoeff. */
+static int cavlc_block(bw_t *bw, const int16_t *coef, int maxnum, int nC) {
+    int idx[16], n = 0;
+    for (int i = 0; i < maxnum; i++) if (coef[i]) idx[n++] = i;
+    int total = n, t1 = 0;
+    for (int i = n - 1; i >= 0 && t1 < 3; i--) {
+        if (coef[idx[i]] == 1 || coef[idx[i]] == -1) t1++;
+        else break;
+    }
+    vlc_t tok;
+    if (nC < 0) tok = t_coeff_token_cdc[total][t1];
+    else tok = t_coeff_token[nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3][total][t1];
+    bw_put(bw, tok.len, tok.bits);
+    if (!total) return 0;
+    for (int i = 0; i < t1; i++) bw_put(bw, 1, coef[idx[n - 1 - i]] < 0); /* trailing_ones_sign_flag */
+    /* 9.2.2.1 levels, highest frequency first */
+    int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
+    for (int i = n - 1 - t1; i >= 0; i--) {
+        int lv = coef[idx[i]];
+        int code = lv > 0 ? 2 * lv - 2 : -2 * lv - 1; /* levelCode */
+        if (i == n - 1 - t1 && t1 < 3) code -= 2;
+        if (suffix_len == 0) {
+            if (code < 14) bw_put(bw, code + 1, 1);
+            else if (code < 30) { bw_put(bw, 15, 1); bw_put(bw, 4, (uint32_t)(code - 14)); }
+            else { bw_put(bw, 16, 1); bw_put(bw, 12, (uint32_t)(code - 30)); }
+        } else {
+            if (code < (15 << suffix_len)) {
+                bw_put(bw, (code >> suffix_len) + 1, 1);
+                bw_put(bw, suffix_len, (uint32_t)(code & ((1 << suffix_len) - 1)));
+            } else { bw_put(bw, 16, 1); bw_put(bw, 12, (uint32_t)(code - (15 << suffix_len))); }
+        }
+        if (suffix_len == 0) suffix_len = 1;
+        if (iabs(lv) > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+    }
+    /* total_zeros */
+    int zeros_left = idx[n - 1] + 1 - total;
+    if (total < maxnum) {
+        vlc_t tz = maxnum == 4 ? t_total_zeros_cdc[total - 1][zeros_left] : t_total_zeros[total - 1][zeros_left];
+        bw_put(bw, tz.len, tz.bits);
+    }
+    /* run_before, highest frequency first, not for the last (lowest) coefficient */
+    for (int i = n - 1; i > 0 && zeros_left > 0; i--) {
+        int run = idx[i] - idx[i - 1] - 1;
+        vlc_t rb = t_run_before[(zeros_left > 7 ? 7 : zeros_left) - 1][run];
+        bw_put(bw, rb.len, rb.bits);
+        zeros_left -= run;
+    }
+    return total;
+}
+
+static int median3(int a, int b, int c) {
+    int mn = a < b ? a : b, mx = a < b ? b : a;
+    return c < mn ? mn : (c > mx ? mx : c);
+}
+/* 8.4.1.3 motion vector prediction for a 16x16 partition with refIdx 0 (quarter-pel units
+ * are not needed: vectors are compared/added as integer-pel*4 by the caller).
+ * type[] : -1 unavailable, 0 intra (refIdx -1), 1 inter (refIdx 0). */
+static void mv_pred16(const orc_mbinfo_t *mbi, int mbw, int mx, int my, int *px, int *py) {
+    int avA = mx > 0, avB = my > 0, avC = my > 0 && mx + 1 < mbw, avD = mx > 0 && my > 0;
+    const orc_mbinfo_t *A = avA ? &mbi[my * mbw + mx - 1] : NULL;
+    const orc_mbinfo_t *B = avB ? &mbi[(my - 1) * mbw + mx] : NULL;
+    const orc_mbinfo_t *C = avC ? &mbi[(my - 1) * mbw + mx + 1] : (avD ? &mbi[(my - 1) * mbw + mx - 1] : NULL);
+    int rA = A && A->mb_type == 1, rB = B && B->mb_type == 1, rC = C && C->mb_type == 1; /* refIdx == 0 */
+    int ax = rA ? A->mvx : 0, ay = rA ? A->mvy : 0;
+    int bx = rB ? B->mvx : 0, by = rB ? B->mvy : 0;
+    int cx = rC ? C->mvx : 0, cy = rC ? C->mvy : 0;
+    if (!B && !C && A) { *px = ax; *py = ay; return; } /* only A available */
+    if (rA + rB + rC == 1) {
+        if (rA) { *px = ax; *py = ay; }
+        else if (rB) { *px = bx; *py = by; }
+        else { *px = cx; *py = cy; }
+        return;
+    }
+    *px = median3(ax, bx, cx);
+    *py = median3(ay, by, cy);
+}
+/* 8.4.1.1 P_Skip vector */
+static void mv_pred_skip(const orc_mbinfo_t *mbi, int mbw, int mx, int my, int *px, int *py) {
+    *px = 0; *py = 0;
+    if (mx == 0 || my == 0) return;
+    const orc_mbinfo_t *A = &mbi[my * mbw + mx - 1], *B = &mbi[(my - 1) * mbw + mx];
+    if (A->mb_type == 1 && A->mvx == 0 && A->mvy == 0) return;
+    if (B->mb_type == 1 && B->mvx == 0 && B->mvy == 0) return;
+    mv_pred16(mbi, mbw, mx, my, px, py);
+}
+
+static int level_idc_for(int mbw, int mbh, int fps_num, int fps_den) {
+    /* Table A-1: {level_idc, MaxMBPS, MaxFS} */
+    static const int lv[][3] = {{10, 1485, 99},      {11, 3000, 396},     {12, 6000, 396},    {13, 11880, 396},
+                                {20, 11880, 396},    {21, 19800, 792},    {22, 20250, 1620},  {30, 40500, 1620},
+                                {31, 108000, 3600},  {32, 216000, 5120},  {40, 245760, 8192}, {42, 522240, 8704},
+                                {50, 589824, 22080}, {51, 983040, 36864}, {52, 2073600, 36864}};
+    int64_t fs = (int64_t)mbw * mbh;
+    int64_t mbps = (fs * fps_num + fps_den - 1) / fps_den;
+    for (size_t i = 0; i < sizeof lv / sizeof lv[0]; i++)
+        if (fs <= lv[i][2] && mbps <= lv[i][1] && mbw * mbw <= 8 * lv[i][2] && mbh * mbh <= 8 * lv[i][2]) return lv[i][0];
+    return 52;
+}
+
+/* 7.3.2.1 SPS + 7.3.2.2 PPS, Annex B.  Constrained Baseline (profile_idc 66, set0+set1). */
+size_t orc_write_headers(uint8_t *out, size_t cap, int width, int height, int fps_num, int fps_den) {
+    init_tables();
+    uint8_t rb[128];
+    bw_t b;
+    int mbw = (width + 15) / 16, mbh = (height + 15) / 16;
+    bw_init(&b, rb, sizeof rb);
+    bw_put(&b, 8, 66);                 /* profile_idc */
+    bw_put(&b, 8, 0xC0);               /* constraint_set0,1 = 1 */
+    bw_put(&b, 8, (uint32_t)level_idc_for(mbw, mbh, fps_num, fps_den));
+    bw_ue(&b, 0);                      /* seq_parameter_set_id */
+    bw_ue(&b, 4);                      /* log2_max_frame_num_minus4 -> 8 bits */
+    bw_ue(&b, 2);                      /* pic_order_cnt_type */
+    bw_ue(&b, 1);                      /* max_num_ref_frames */
+    bw_put(&b, 1, 0);                  /* gaps_in_frame_num_value_allowed_flag */
+    bw_ue(&b, (uint32_t)(mbw - 1));
+    bw_ue(&b, (uint32_t)(mbh - 1));
+    bw_put(&b, 1, 1);                  /* frame_mbs_only_flag */
+    bw_put(&b, 1, 1);                  /* direct_8x8_inference_flag */
+    int crop_r = (mbw * 16 - width) / 2, crop_b = (mbh * 16 - height) / 2;
+    if (crop_r || crop_b) {
+        bw_put(&b, 1, 1);
+        bw_ue(&b, 0); bw_ue(&b, (uint32_t)crop_r); bw_ue(&b, 0); bw_ue(&b, (uint32_t)crop_b);
+    } else bw_put(&b, 1, 0);
+    bw_put(&b, 1, 1);                  /* vui_parameters_present_flag (E.1.1) */
+    bw_put(&b, 1, 0);                  /* aspect_ratio_info_present_flag */
+    bw_put(&b, 1, 0);                  /* overscan_info_present_flag */
+    bw_put(&b, 1, 0);                  /* video_signal_type_present_flag */
+    bw_put(&b, 1, 0);                  /* chroma_loc_info_present_flag */
+    bw_put(&b, 1, 1);                  /* timing_info_present_flag */
+    bw_put(&b, 32, (uint32_t)fps_den); /* num_units_in_tick */
+    bw_put(&b, 32, (uint32_t)(2 * fps_num)); /* time_scale */
+    bw_put(&b, 1, 1);                  /* fixed_frame_rate_flag */
+    bw_put(&b, 1, 0);                  /* nal_hrd_parameters_present_flag */
+    bw_put(&b, 1, 0);                  /* vcl_hrd_parameters_present_flag */
+    bw_put(&b, 1, 0);                  /* pic_struct_present_flag */
+    bw_put(&b, 1, 1);                  /* bitstream_restriction_flag */
+    bw_put(&b, 1, 1);                  /* motion_vectors_over_pic_boundaries_flag */
+    bw_ue(&b, 0);                      /* max_bytes_per_pic_denom */
+    bw_ue(&b, 0);                      /* max_bits_per_mb_denom */
+    bw_ue(&b, 10);                     /* log2_max_mv_length_horizontal */
+    bw_ue(&b, 10);                     /* log2_max_mv_length_vertical */
+    bw_ue(&b, 0);                      /* max_num_reorder_frames */
+    bw_ue(&b, 1);                      /* max_dec_frame_buffering */
+    bw_trailing(&b);
+    size_t n = write_nal(out, cap, 3, 7, rb, b.pos);
+    if (!n) return 0;
+    bw_init(&b, rb, sizeof rb);
+    bw_ue(&b, 0);                      /* pic_parameter_set_id */
+    bw_ue(&b, 0);                      /* seq_parameter_set_id */
+    bw_put(&b, 1, 0);                  /* entropy_coding_mode_flag: CAVLC */
+    bw_put(&b, 1, 0);                  /* bottom_field_pic_order_in_frame_present_flag */
+    bw_ue(&b, 0);                      /* num_slice_groups_minus1 */
+    bw_ue(&b, 0);                      /* num_ref_idx_l0_default_active_minus1 */
+    bw_ue(&b, 0);                      /* num_ref_idx_l1_default_active_minus1 */
+    bw_put(&b, 1, 0);                  /* weighted_pred_flag */
+    bw_put(&b, 2, 0);                  /* weighted_bipred_idc */
+    bw_se(&b, 0);                      /* pic_init_qp_minus26 */
+    bw_se(&b, 0);                      /* pic_init_qs_minus26 */
+    bw_se(&b, 0);                      /* chroma_qp_index_offset */
+    bw_put(&b, 1, 1);                  /* deblocking_filter_control_present_flag */
+    bw_put(&b, 1, 0);                  /* constrained_intra_pred_flag */
+    bw_put(&b, 1, 0);                  /* redundant_pic_cnt_present_flag */
+    bw_trailing(&b);
+    size_t m = write_nal(out + n, cap - n, 3, 8, rb, b.pos);
+    if (!m) return 0;
+    return n + m;
+}
+
+/* 7.3.3 slice header + 7.3.4 slice data + 7.3.5 macroblock layer, one slice per picture. */
+size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, int frame_num,
+                       int idr_pic_id, int qp, const orc_mbinfo_t *mbi, const int16_t *levels) {
+    init_tables();
+    int nmb = mbw * mbh;
+    size_t rcap = (size_t)nmb * 1024 + 256; /* > 3200 bits/MB worst case (A.3.1) */
+    uint8_t *rb = (uint8_t *)malloc(rcap);
+    uint8_t *tc_l = (uint8_t *)calloc((size_t)nmb, 16); /* TotalCoeff per luma blkIdx   */
+    uint8_t *tc_c = (uint8_t *)calloc((size_t)nmb, 8);  /* per chroma AC block (Cb 0-3, Cr 4-7) */
+    if (!rb || !tc_l || !tc_c) { free(rb); free(tc_l); free(tc_c); return 0; }
+    bw_t b;
+    bw_init(&b, rb, rcap);
+    bw_ue(&b, 0);                                 /* first_mb_in_slice */
+    bw_ue(&b, is_idr ? 7 : 5);                    /* slice_type: all slices of the picture I / P */
+    bw_ue(&b, 0);                                 /* pic_parameter_set_id */
+    bw_put(&b, 8, (uint32_t)(frame_num & 0xFF));  /* frame_num, log2_max_frame_num = 8 */
+    if (is_idr) bw_ue(&b, (uint32_t)idr_pic_id);
+    if (!is_idr) bw_put(&b, 1, 0);                /* num_ref_idx_active_override_flag */
+    if (!is_idr) bw_put(&b, 1, 0);                /* ref_pic_list_modification_flag_l0 */
+    if (is_idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); } /* no_output_of_prior_pics, long_term_reference */
+    else bw_put(&b, 1, 0);                        /* adaptive_ref_pic_marking_mode_flag */
+    bw_se(&b, qp - 26);                           /* slice_qp_delta */
+    bw_ue(&b, 0);                                 /* disable_deblocking_filter_idc */
+    bw_se(&b, 0);                                 /* slice_alpha_c0_offset_div2 */
+    bw_se(&b, 0);                                 /* slice_beta_offset_div2 */
+
+    static const uint8_t blk_raster[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* blkIdx -> by*4+bx */
+    static const uint8_t raster_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* by*4+bx -> blkIdx */
+    int skip_run = 0, prev_qp = qp;
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            int mbn = my * mbw + mx;
+            const orc_mbinfo_t *m = &mbi[mbn];
+            const int16_t *lev = levels + (size_t)mbn * ORC_LEVELS_PER_MB;
+            int cbp_luma = 0, cbp_chroma = 0;
+            if (m->mb_type == 0) cbp_luma = (m->nzmask & 0xFFFF) ? 15 : 0;
+            else for (int g = 0; g < 4; g++) if ((m->nzmask >> (4 * g)) & 0xF) cbp_luma |= 1 << g;
+            if (m->nzmask & 0x00FF0000u) cbp_chroma = 2;
+            else if (m->nzmask & (ORC_NZ_CBDC | ORC_NZ_CRDC)) cbp_chroma = 1;
+
+            if (!is_idr && m->mb_type == 1) {
+                int sx, sy;
+                mv_pred_skip(mbi, mbw, mx, my, &sx, &sy);
+                if (cbp_luma == 0 && cbp_chroma == 0 && m->mvx == sx && m->mvy == sy) { skip_run++; continue; }
+            }
+            if (!is_idr) { bw_ue(&b, (uint32_t)skip_run); skip_run = 0; }
+            if (m->mb_type == 0) {
+                int t = 1 + m->i16_mode + 4 * cbp_chroma + (cbp_luma ? 12 : 0); /* Table 7-11 */
+                bw_ue(&b, (uint32_t)(is_idr ? t : t + 5));
+                bw_ue(&b, m->chroma_mode);                                        /* intra_chroma_pred_mode */
+            } else {
+                bw_ue(&b, 0); /* P_L0_16x16 */
+                int px, py;
+                mv_pred16(mbi, mbw, mx, my, &px, &py);
+                bw_se(&b, 4 * (m->mvx - px));
+                bw_se(&b, 4 * (m->mvy - py));
+                bw_ue(&b, k_cbp_to_codenum_inter[cbp_chroma * 16 + cbp_luma]);
+            }
+            if (m->mb_type == 0 || cbp_luma || cbp_chroma) {
+                bw_se(&b, m->qp - prev_qp); /* mb_qp_delta */
+                prev_qp = m->qp;
+            }
+            /* neighbour TotalCoeff lookup, 9.2.1 */
+#define NC_LUMA(bx, by, out)                                                                        \
+    do {                                                                                            \
+        int na = -1, nb = -1;                                                                       \
+        if ((bx) > 0) na = tc_l[mbn * 16 + raster_blk[(by) * 4 + (bx) - 1]];                         \
+        else if (mx > 0) na = tc_l[(mbn - 1) * 16 + raster_blk[(by) * 4 + 3]];                      \
+        if ((by) > 0) nb = tc_l[mbn * 16 + raster_blk[((by) - 1) * 4 + (bx)]];                       \
+        else if (my > 0) nb = tc_l[(mbn - mbw) * 16 + raster_blk[12 + (bx)]];                       \
+        (out) = (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));    \
+    } while (0)
+            if (m->mb_type == 0) {
+                int nC;
+                NC_LUMA(0, 0, nC);
+                cavlc_block(&b, lev + ORC_L_LDC, 16, nC);
+            }
+            for (int blk = 0; blk < 16; blk++) {
+                if (!(cbp_luma & (1 << (blk >> 2)))) continue;
+                int bx = blk_raster[blk] & 3, by = blk_raster[blk] >> 2, nC;
+                NC_LUMA(bx, by, nC);
+                int tc = m->mb_type == 0 ? cavlc_block(&b, lev + ORC_L_LUMA + blk * 16 + 1, 15, nC)
+                                         : cavlc_block(&b, lev + ORC_L_LUMA + blk * 16, 16, nC);
+                tc_l[mbn * 16 + blk] = (uint8_t)tc;
+            }
+            if (cbp_chroma) {
+                cavlc_block(&b, lev + ORC_L_CDC, 4, -1);
+                cavlc_block(&b, lev + ORC_L_CDC + 4, 4, -1);
+            }
+            if (cbp_chroma == 2)
+                for (int c = 0; c < 2; c++)
+                    for (int blk = 0; blk < 4; blk++) {
+                        int bx = blk & 1, by = blk >> 1, na = -1, nb = -1, nC;
+                        if (bx > 0) na = tc_c[mbn * 8 + 4 * c + blk - 1];
+                        else if (mx > 0) na = tc_c[(mbn - 1) * 8 + 4 * c + by * 2 + 1];
+                        if (by > 0) nb = tc_c[mbn * 8 + 4 * c + blk - 2];
+                        else if (my > 0) nb = tc_c[(mbn - mbw) * 8 + 4 * c + 2 + bx];
+                        nC = (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));
+                        tc_c[mbn * 8 + 4 * c + blk] = (uint8_t)cavlc_block(&b, lev + ORC_L_CAC + (4 * c + blk) * 16 + 1, 15, nC);
+                    }
+#undef NC_LUMA
+        }
+    if (!is_idr && skip_run) bw_ue(&b, (uint32_t)skip_run);
+    bw_trailing(&b);
+    size_t n = b.overflow ? 0 : write_nal(out, cap, is_idr ? 3 : 2, is_idr ? 5 : 1, rb, b.pos);
+    free(rb); free(tc_l); free(tc_c);
+    return n;
+}
+
+/* ================================================================== encoder wrapper */
+struct orc_enc {
+    int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads;
+    int frames_since_idr, idr_count, have_ref;
+    uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv;
+    int cur; /* index of the surface holding the last reconstructed picture */
+    orc_mbinfo_t *mbi;
+    int16_t *levels;
+};
+
+orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop, int me_range, int threads) {
+    if (width < 16 || height < 16 || (width & 1) || (height & 1) || gop < 1) return NULL;
+    init_tables();
+    orc_enc_t *e = (orc_enc_t *)calloc(1, sizeof *e);
+    if (!e) return NULL;
+    e->width = width; e->height = height;
+    e->mbw = (width + 15) / 16; e->mbh = (height + 15) / 16; e->stride = e->mbw * 16;
+    e->fps_num = fps_num; e->fps_den = fps_den; e->gop = gop; e->me_range = me_range; e->threads = threads;
+    size_t ysz = (size_t)e->stride * e->mbh * 16, csz = ysz / 2;
+    e->src_y = (uint8_t *)malloc(ysz); e->src_uv = (uint8_t *)malloc(csz);
+    e->pre_y = (uint8_t *)malloc(ysz); e->pre_uv = (uint8_t *)malloc(csz);
+    for (int i = 0; i < 2; i++) { e->rec_y[i] = (uint8_t *)malloc(ysz); e->rec_uv[i] = (uint8_t *)malloc(csz); }
+    e->mbi = (orc_mbinfo_t *)calloc((size_t)e->mbw * e->mbh, sizeof(orc_mbinfo_t));
+    e->levels = (int16_t *)calloc((size_t)e->mbw * e->mbh * ORC_LEVELS_PER_MB, sizeof(int16_t));
+    return e;
+}
+void orc_enc_close(orc_enc_t *e) {
+    if (!e) return;
+    free(e->src_y); free(e->src_uv); free(e->pre_y); free(e->pre_uv);
+    for (int i = 0; i < 2; i++) { free(e->rec_y[i]); free(e->rec_uv[i]); }
+    free(e->mbi); free(e->levels); free(e);
+}
+/* copy the visible picture into the coded-size surface, replicating the last column/row */
+static void load_padded(orc_enc_t *e, const uint8_t *y, int ys, const uint8_t *uv, int uvs) {
+    int W = e->stride, H = e->mbh * 16;
+    for (int r = 0; r < H; r++) {
+        const uint8_t *s = y + (size_t)(r < e->height ? r : e->height - 1) * ys;
+        uint8_t *d = e->src_y + (size_t)r * W;
+        memcpy(d, s, (size_t)e->width);
+        for (int x = e->width; x < W; x++) d[x] = s[e->width - 1];
+    }
+    for (int r = 0; r < H / 2; r++) {
+        const uint8_t *s = uv + (size_t)(r < e->height / 2 ? r : e->height / 2 - 1) * uvs;
+        uint8_t *d = e->src_uv + (size_t)r * W;
+        memcpy(d, s, (size_t)e->width);
+        for (int x = e->width; x < W; x += 2) { d[x] = s[e->width - 2]; d[x + 1] = s[e->width - 1]; }
+    }
+}
+int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
+                  int qp, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len, int *is_idr) {
+    if (!e || qp < 0 || qp > 51) return -1;
+    int idr = force_idr || !e->have_ref || e->frames_since_idr >= e->gop;
+    if (idr) { e->frames_since_idr = 0; }
+    load_padded(e, y, y_stride, uv, uv_stride);
+    int nxt = e->cur ^ 1;
+    size_t ysz = (size_t)e->stride * e->mbh * 16;
+    if (idr)
+        orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
+    else {
+        orc_me_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, e->me_range, qp, e->mbi, e->threads);
+        orc_inter_frame(e->src_y, e->src_uv, e->rec_y[e->cur], e->rec_uv[e->cur], e->rec_y[nxt], e->rec_uv[nxt],
+                        e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
+    }
+    memcpy(e->pre_y, e->rec_y[nxt], ysz);
+    memcpy(e->pre_uv, e->rec_uv[nxt], ysz / 2);
+    orc_deblock_frame(e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, e->mbi);
+    size_t n = 0;
+    if (idr) {
+        n = orc_write_headers(out, out_cap, e->width, e->height, e->fps_num, e->fps_den);
+        if (!n) return -2;
+    }
+    size_t s = orc_write_slice(out + n, out_cap - n, e->mbw, e->mbh, idr, e->frames_since_idr, e->idr_count & 0xFFFF,
+                               qp, e->mbi, e->levels);
+    if (!s) return -2;
+    *out_len = n + s;
+    if (is_idr) *is_idr = idr;
+    if (idr) e->idr_count++;
+    e->frames_since_idr++;
+    e->cur = nxt; e->have_ref = 1;
+    return 0;
+}
+const uint8_t *orc_enc_recon_y(const orc_enc_t *e) { return e->rec_y[e->cur]; }
+const uint8_t *orc_enc_recon_uv(const orc_enc_t *e) { return e->rec_uv[e->cur]; }
+const uint8_t *orc_enc_prefilter_y(const orc_enc_t *e) { return e->pre_y; }
+const uint8_t *orc_enc_prefilter_uv(const orc_enc_t *e) { return e->pre_uv; }
+const orc_mbinfo_t *orc_enc_mbinfo(const orc_enc_t *e) { return e->mbi; }
+const int16_t *orc_enc_levels(const orc_enc_t *e) { return e->levels; }
+int orc_enc_mbw(const orc_enc_t *e) { return e->mbw; }
+int orc_enc_mbh(const orc_enc_t *e) { return e->mbh; }

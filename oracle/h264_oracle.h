@@ -1,0 +1,132 @@
+/*
+ * oracle/h264_oracle.h -- TEST INFRASTRUCTURE ONLY (CPU oracle for the H.264 hot path).
+ *
+ * PARITY UNPINNED at the codec boundary: the reference (CERALIVE/ceracoder) holds no
+ * codec arithmetic -- its encoder is the token `x264enc speed-preset=2 key-int-max=60`
+ * (/root/reference/pipeline/generic/x264_superfast_camlink:5, resolved by
+ * /root/reference/src/io/pipeline_loader.c:59) backed by the un-vendored, un-pinned
+ * libx264 -- and it has no golden bitstreams.  This oracle is a
+ * scalar restatement of ITU-T H.264 (sections cited per function) plus this repo's own
+ * non-normative encoder decisions (motion search rule, mode decision, quantiser dead
+ * zone).  It is pinned by (i) known-answer tests of every constant table and of the
+ * Exp-Golomb / emulation-prevention / transform identities, and (ii) an independently
+ * written decoder (h264_dec_oracle.c) whose output must equal the encoder's
+ * reconstruction bit for bit.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ */
+#ifndef H264_ORACLE_H
+#define H264_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-macroblock side record, 16 bytes (SURVEY.md section 8d "16 B/MB info"). */
+typedef struct {
+    int16_t mvx, mvy;     /* integer-pel luma motion vector (P macroblocks)            */
+    uint8_t mb_type;      /* 0 = I16x16, 1 = P_L0_16x16 (P_Skip is an entropy decision) */
+    uint8_t i16_mode;     /* Intra16x16PredMode 0 V, 1 H, 2 DC, 3 Plane                 */
+    uint8_t chroma_mode;  /* intra_chroma_pred_mode 0 DC, 1 H, 2 V, 3 Plane             */
+    uint8_t qp;           /* QP_Y of this macroblock                                    */
+    uint32_t nzmask;      /* b0-15 luma blkIdx (AC only for I16x16), b16-19 Cb AC,
+                             b20-23 Cr AC, b24 luma DC (I16x16), b25 Cb DC, b26 Cr DC   */
+    uint32_t cost;        /* motion-search cost (P) or intra SAD luma+chroma (I)        */
+} orc_mbinfo_t;
+
+/* Levels per macroblock, int16, coding (zig-zag) order:
+ *   [  0..255] luma blkIdx 0..15 x 16   ([0] of each block is 0 for I16x16)
+ *   [256..271] Intra16x16 DC levels
+ *   [272..275] Cb DC, [276..279] Cr DC
+ *   [280..407] chroma AC: Cb blk 0..3, Cr blk 0..3, x 16 ([0] unused = 0)      */
+#define ORC_LEVELS_PER_MB 408
+#define ORC_L_LUMA   0
+#define ORC_L_LDC    256
+#define ORC_L_CDC    272
+#define ORC_L_CAC    280
+
+#define ORC_NZ_LDC   (1u << 24)
+#define ORC_NZ_CBDC  (1u << 25)
+#define ORC_NZ_CRDC  (1u << 26)
+
+/* ---- stage functions (each is the checker for one HIP kernel) ------------------- */
+
+/* Full-search integer-pel SAD motion search, +-range, on coded-size luma planes.
+ * Writes mvx,mvy,cost of every macroblock. */
+void orc_me_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mbw, int mbh,
+                  int range, int qp, orc_mbinfo_t *mbi, int threads);
+
+/* P picture: motion compensation + residual + 4x4 transform/quant + normative
+ * dequant/inverse + reconstruction (pre-deblock) for every macroblock. */
+void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y,
+                     const uint8_t *ref_uv, uint8_t *rec_y, uint8_t *rec_uv, int stride,
+                     int mbw, int mbh, int qp, orc_mbinfo_t *mbi, int16_t *levels);
+
+/* I picture: Intra16x16 + chroma prediction, mode decision by SAD, transform/quant,
+ * reconstruction (pre-deblock), macroblocks in raster order. */
+void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
+                     uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
+                     orc_mbinfo_t *mbi, int16_t *levels);
+
+/* In-loop deblocking filter, in place, normative macroblock raster order (8.7). */
+void orc_deblock_frame(uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mbh,
+                       const orc_mbinfo_t *mbi);
+
+/* ---- whole-encoder wrapper ------------------------------------------------------ */
+typedef struct orc_enc orc_enc_t;
+
+orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop,
+                        int me_range, int threads);
+void orc_enc_close(orc_enc_t *e);
+/* Encode one NV12 frame at a caller-chosen QP.  Returns 0, or <0 on error. */
+int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv,
+                  int uv_stride, int qp, int force_idr, uint8_t *out, size_t out_cap,
+                  size_t *out_len, int *is_idr);
+/* Views into the last encoded frame (coded size, stride = 16*mbw). */
+const uint8_t *orc_enc_recon_y(const orc_enc_t *e);
+const uint8_t *orc_enc_recon_uv(const orc_enc_t *e);
+const uint8_t *orc_enc_prefilter_y(const orc_enc_t *e);
+const uint8_t *orc_enc_prefilter_uv(const orc_enc_t *e);
+const orc_mbinfo_t *orc_enc_mbinfo(const orc_enc_t *e);
+const int16_t *orc_enc_levels(const orc_enc_t *e);
+int orc_enc_mbw(const orc_enc_t *e);
+int orc_enc_mbh(const orc_enc_t *e);
+
+/* Parameter sets + slice entropy coding, usable on externally produced records
+ * (this is how the product's device output is turned into the expected bytes). */
+size_t orc_write_headers(uint8_t *out, size_t cap, int width, int height, int fps_num,
+                         int fps_den);
+size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr,
+                       int frame_num, int idr_pic_id, int qp, const orc_mbinfo_t *mbi,
+                       const int16_t *levels);
+
+/* ---- independent decoder (h264_dec_oracle.c) ------------------------------------ */
+typedef struct orc_dec orc_dec_t;
+orc_dec_t *orc_dec_open(void);
+void orc_dec_close(orc_dec_t *d);
+/* Feed one access unit (Annex B).  Returns number of pictures output (0/1), <0 error. */
+int orc_dec_decode(orc_dec_t *d, const uint8_t *au, size_t len);
+int orc_dec_width(const orc_dec_t *d);        /* cropped */
+int orc_dec_height(const orc_dec_t *d);
+int orc_dec_coded_width(const orc_dec_t *d);
+int orc_dec_coded_height(const orc_dec_t *d);
+const uint8_t *orc_dec_y(const orc_dec_t *d);  /* coded-size planes, stride = coded width */
+const uint8_t *orc_dec_uv(const orc_dec_t *d); /* interleaved CbCr                         */
+const char *orc_dec_error(const orc_dec_t *d);
+
+/* ---- small known-answer helpers exported for tests ------------------------------ */
+void orc_fdct4(const int16_t in[16], int16_t out[16]);
+void orc_idct4_add(const int32_t coef[16], uint8_t *dst, int stride);
+int orc_quant4(int coef, int qp, int pos, int intra);
+int orc_dequant4(int level, int qp, int pos);
+size_t orc_nal_escape(const uint8_t *rbsp, size_t n, uint8_t *out, size_t cap);
+int orc_ue_bits(uint32_t v, uint32_t *code);
+uint32_t orc_table_checksum(int which);
+int orc_me_lambda(int qp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

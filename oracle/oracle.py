@@ -1,0 +1,242 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE ONLY -- see h264_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle_h264.so")
+
+LEVELS_PER_MB = 408
+MBINFO_DTYPE = np.dtype(
+    [("mvx", "<i2"), ("mvy", "<i2"), ("mb_type", "u1"), ("i16_mode", "u1"), ("chroma_mode", "u1"),
+     ("qp", "u1"), ("nzmask", "<u4"), ("cost", "<u4")]
+)
+assert MBINFO_DTYPE.itemsize == 16
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("h264_enc_oracle.c", "h264_dec_oracle.c", "h264_oracle.h", "h264_tables_enc.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle_h264.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/src/core"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        u8p, i16p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.c_void_p
+        L.orc_enc_open.restype = vp
+        L.orc_enc_open.argtypes = [C.c_int] * 7
+        L.orc_enc_close.argtypes = [vp]
+        L.orc_enc_frame.restype = C.c_int
+        L.orc_enc_frame.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t,
+                                    C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        for n in ("recon_y", "recon_uv", "prefilter_y", "prefilter_uv", "mbinfo", "levels"):
+            f = getattr(L, "orc_enc_" + n)
+            f.restype = vp
+            f.argtypes = [vp]
+        L.orc_enc_mbw.argtypes = [vp]
+        L.orc_enc_mbh.argtypes = [vp]
+        L.orc_me_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orc_me_frame.restype = None
+        L.orc_inter_frame.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.orc_inter_frame.restype = None
+        L.orc_intra_frame.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.orc_intra_frame.restype = None
+        L.orc_deblock_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_deblock_frame.restype = None
+        L.orc_write_headers.restype = C.c_size_t
+        L.orc_write_headers.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_write_slice.restype = C.c_size_t
+        L.orc_write_slice.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.orc_dec_open.restype = vp
+        L.orc_dec_close.argtypes = [vp]
+        L.orc_dec_decode.argtypes = [vp, vp, C.c_size_t]
+        for n in ("width", "height", "coded_width", "coded_height"):
+            getattr(L, "orc_dec_" + n).argtypes = [vp]
+        L.orc_dec_y.restype = vp
+        L.orc_dec_y.argtypes = [vp]
+        L.orc_dec_uv.restype = vp
+        L.orc_dec_uv.argtypes = [vp]
+        L.orc_dec_error.restype = C.c_char_p
+        L.orc_dec_error.argtypes = [vp]
+        L.orc_fdct4.argtypes = [i16p, i16p]
+        L.orc_idct4_add.argtypes = [C.POINTER(C.c_int32), u8p, C.c_int]
+        L.orc_quant4.argtypes = [C.c_int] * 4
+        L.orc_dequant4.argtypes = [C.c_int] * 3
+        L.orc_nal_escape.restype = C.c_size_t
+        L.orc_nal_escape.argtypes = [vp, C.c_size_t, vp, C.c_size_t]
+        L.orc_ue_bits.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_table_checksum.restype = C.c_uint32
+        L.orc_table_checksum.argtypes = [C.c_int]
+        L.orc_me_lambda.argtypes = [C.c_int]
+        for n in ("orc_enc_vlc", "orc_dec_vlc"):
+            getattr(L, n).argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] * 2
+        L.orc_enc_cbp_codenum.argtypes = [C.c_int, C.c_int]
+        L.orc_dec_cbp.argtypes = [C.c_int, C.c_int]
+        L.orc_dec_const.argtypes = [C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _view(ptr, shape, dtype):
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    buf = (C.c_uint8 * n).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+class Encoder:
+    """Whole-encoder oracle: one NV12 frame + QP in, Annex-B access unit + stage outputs out."""
+
+    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1):
+        self.L = lib()
+        self.h = self.L.orc_enc_open(width, height, fps, 1, gop, me_range, threads)
+        if not self.h:
+            raise ValueError("orc_enc_open failed")
+        self.width, self.height = width, height
+        self.mbw, self.mbh = self.L.orc_enc_mbw(self.h), self.L.orc_enc_mbh(self.h)
+        self._out = np.empty(self.mbw * self.mbh * 1024 + 4096, np.uint8)
+
+    def encode(self, y, uv, qp, force_idr=False):
+        y = np.ascontiguousarray(y, np.uint8)
+        uv = np.ascontiguousarray(uv, np.uint8)
+        assert y.shape == (self.height, self.width) and uv.shape == (self.height // 2, self.width)
+        n, idr = C.c_size_t(0), C.c_int(0)
+        r = self.L.orc_enc_frame(self.h, _ptr(y), self.width, _ptr(uv), self.width, qp, int(force_idr),
+                                 _ptr(self._out), self._out.size, C.byref(n), C.byref(idr))
+        if r:
+            raise RuntimeError("orc_enc_frame -> %d" % r)
+        return bytes(self._out[: n.value]), bool(idr.value)
+
+    def _plane(self, fn, rows):
+        return _view(fn(self.h), (rows, self.mbw * 16), np.uint8).copy()
+
+    @property
+    def recon_y(self):
+        return self._plane(self.L.orc_enc_recon_y, self.mbh * 16)
+
+    @property
+    def recon_uv(self):
+        return self._plane(self.L.orc_enc_recon_uv, self.mbh * 8)
+
+    @property
+    def prefilter_y(self):
+        return self._plane(self.L.orc_enc_prefilter_y, self.mbh * 16)
+
+    @property
+    def prefilter_uv(self):
+        return self._plane(self.L.orc_enc_prefilter_uv, self.mbh * 8)
+
+    @property
+    def mbinfo(self):
+        return _view(self.L.orc_enc_mbinfo(self.h), (self.mbh * self.mbw,), MBINFO_DTYPE).copy()
+
+    @property
+    def levels(self):
+        return _view(self.L.orc_enc_levels(self.h), (self.mbh * self.mbw, LEVELS_PER_MB), np.int16).copy()
+
+    def close(self):
+        if self.h:
+            self.L.orc_enc_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class Decoder:
+    def __init__(self):
+        self.L = lib()
+        self.h = self.L.orc_dec_open()
+
+    def decode(self, au):
+        buf = np.frombuffer(au, np.uint8)
+        r = self.L.orc_dec_decode(self.h, _ptr(buf), buf.size)
+        if r < 0:
+            raise RuntimeError("oracle decoder: " + self.L.orc_dec_error(self.h).decode())
+        if r == 0:
+            return None
+        cw, ch = self.L.orc_dec_coded_width(self.h), self.L.orc_dec_coded_height(self.h)
+        y = _view(self.L.orc_dec_y(self.h), (ch, cw), np.uint8).copy()
+        uv = _view(self.L.orc_dec_uv(self.h), (ch // 2, cw), np.uint8).copy()
+        return y, uv
+
+    @property
+    def size(self):
+        return self.L.orc_dec_width(self.h), self.L.orc_dec_height(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.orc_dec_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def me_frame(cur_y, ref_y, rng, qp, threads=1):
+    L = lib()
+    H, W = cur_y.shape
+    mbi = np.zeros((H // 16) * (W // 16), MBINFO_DTYPE)
+    L.orc_me_frame(_ptr(np.ascontiguousarray(cur_y)), _ptr(np.ascontiguousarray(ref_y)), W, W // 16, H // 16, rng, qp,
+                   _ptr(mbi), threads)
+    return mbi
+
+
+def inter_frame(src_y, src_uv, ref_y, ref_uv, mbi, qp):
+    L = lib()
+    H, W = src_y.shape
+    rec_y, rec_uv = np.zeros_like(src_y), np.zeros_like(src_uv)
+    mbi = mbi.copy()
+    lev = np.zeros((mbi.size, LEVELS_PER_MB), np.int16)
+    L.orc_inter_frame(_ptr(src_y), _ptr(src_uv), _ptr(ref_y), _ptr(ref_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16,
+                      H // 16, qp, _ptr(mbi), _ptr(lev))
+    return rec_y, rec_uv, mbi, lev
+
+
+def intra_frame(src_y, src_uv, qp):
+    L = lib()
+    H, W = src_y.shape
+    rec_y, rec_uv = np.zeros_like(src_y), np.zeros_like(src_uv)
+    mbi = np.zeros((H // 16) * (W // 16), MBINFO_DTYPE)
+    lev = np.zeros((mbi.size, LEVELS_PER_MB), np.int16)
+    L.orc_intra_frame(_ptr(src_y), _ptr(src_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16, H // 16, qp, _ptr(mbi), _ptr(lev))
+    return rec_y, rec_uv, mbi, lev
+
+
+def deblock_frame(rec_y, rec_uv, mbi):
+    L = lib()
+    H, W = rec_y.shape
+    y, uv = rec_y.copy(), rec_uv.copy()
+    L.orc_deblock_frame(_ptr(y), _ptr(uv), W, W // 16, H // 16, _ptr(np.ascontiguousarray(mbi)))
+    return y, uv
+
+
+def write_headers(width, height, fps):
+    L = lib()
+    out = np.empty(256, np.uint8)
+    n = L.orc_write_headers(_ptr(out), out.size, width, height, fps, 1)
+    return bytes(out[:n])
+
+
+def write_slice(mbw, mbh, is_idr, frame_num, idr_pic_id, qp, mbi, levels):
+    L = lib()
+    out = np.empty(mbw * mbh * 1024 + 4096, np.uint8)
+    n = L.orc_write_slice(_ptr(out), out.size, mbw, mbh, int(is_idr), frame_num, idr_pic_id, qp,
+                          _ptr(np.ascontiguousarray(mbi)), _ptr(np.ascontiguousarray(levels)))
+    if not n:
+        raise RuntimeError("orc_write_slice failed")
+    return bytes(out[:n])
