@@ -1,0 +1,382 @@
+/*
+ * h264_host.c -- host side of the encoder: Annex-B writer, parameter sets, CAVLC slice
+ * coding.  north_star keeps entropy coding on the host thread; the device hands over one
+ * 16-byte record and 408 int16 levels per macroblock (mi355enc_dev.h).
+ *
+ * Produces what the reference's graph expects from its encoder element: `video/x-h264,
+ * stream-format=byte-stream, alignment=au`, SPS+PPS in band before every IDR so that
+ * `h264parse config-interval=-1` (/root/reference/pipeline/generic/x264_superfast_camlink:6)
+ * passes it through.  Clause numbers refer to ITU-T H.264.
+ */
+#include "h264_host.h"
+
+#include <emmintrin.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "h264_vlc_tables.h"
+
+/* Table 9-4 (inter column), coded_block_pattern -> codeNum, ChromaArrayType 1 */
+static const uint8_t cbp_inter_code[48] = {0,  2,  3,  7,  4,  8,  17, 13, 5,  18, 9,  14, 10, 15, 16, 11,
+                                           1,  32, 33, 36, 34, 37, 44, 40, 35, 45, 38, 41, 39, 42, 43, 19,
+                                           6,  24, 25, 20, 26, 21, 46, 28, 27, 47, 22, 29, 23, 30, 31, 12};
+static const uint8_t blk_to_raster[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+
+/* ------------------------------------------------------------------ bit sink */
+typedef struct {
+    uint8_t *p, *end;
+    uint64_t acc; /* bits are collected at the low end */
+    int n;        /* valid bits in acc (< 32 after every put) */
+    int overflow;
+} bits_t;
+
+static inline void bits_init(bits_t *b, uint8_t *buf, size_t cap) { b->p = buf; b->end = buf + cap; b->acc = 0; b->n = 0; b->overflow = 0; }
+static inline void bits_put(bits_t *b, int len, uint32_t v) { /* len 0..32, v < 2^len */
+    b->acc = (b->acc << len) | v;
+    b->n += len;
+    if (b->n >= 32) {
+        b->n -= 32;
+        uint32_t w = (uint32_t)(b->acc >> b->n);
+        if (b->end - b->p >= 4) { b->p[0] = (uint8_t)(w >> 24); b->p[1] = (uint8_t)(w >> 16); b->p[2] = (uint8_t)(w >> 8); b->p[3] = (uint8_t)w; b->p += 4; }
+        else b->overflow = 1;
+    }
+}
+static inline void bits_ue(bits_t *b, uint32_t v) {
+    uint32_t k = v + 1;
+    int len = 31 - __builtin_clz(k);
+    bits_put(b, len, 0);
+    bits_put(b, len + 1, k);
+}
+static inline void bits_se(bits_t *b, int v) { bits_ue(b, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+static size_t bits_finish(bits_t *b, uint8_t *base) { /* rbsp_trailing_bits + byte flush */
+    bits_put(b, 1, 1);
+    if (b->n & 7) bits_put(b, 8 - (b->n & 7), 0);
+    while (b->n > 0) {
+        b->n -= 8;
+        if (b->p < b->end) *b->p++ = (uint8_t)(b->acc >> b->n);
+        else b->overflow = 1;
+    }
+    return (size_t)(b->p - base);
+}
+
+/* start code + header + payload with emulation prevention (7.4.1.1); 0 when out of room */
+static size_t emit_nal(uint8_t *out, size_t cap, int ref_idc, int type, const uint8_t *rbsp, size_t n) {
+    if (cap < 5) return 0;
+    uint8_t *o = out, *oe = out + cap;
+    *o++ = 0; *o++ = 0; *o++ = 0; *o++ = 1;
+    *o++ = (uint8_t)((ref_idc << 5) | type);
+    int zeros = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t v = rbsp[i];
+        if (zeros >= 2 && v <= 3) {
+            if (o >= oe) return 0;
+            *o++ = 3;
+            zeros = 0;
+        }
+        if (o >= oe) return 0;
+        *o++ = v;
+        zeros = v ? 0 : zeros + 1;
+    }
+    return (size_t)(o - out);
+}
+
+/* ------------------------------------------------------------------ parameter sets */
+static int pick_level(int mbw, int mbh, int fps_num, int fps_den) { /* Table A-1 */
+    static const int t[][3] = {{10, 1485, 99},      {11, 3000, 396},     {12, 6000, 396},    {13, 11880, 396},
+                               {20, 11880, 396},    {21, 19800, 792},    {22, 20250, 1620},  {30, 40500, 1620},
+                               {31, 108000, 3600},  {32, 216000, 5120},  {40, 245760, 8192}, {42, 522240, 8704},
+                               {50, 589824, 22080}, {51, 983040, 36864}, {52, 2073600, 36864}};
+    long long fs = (long long)mbw * mbh, rate = (fs * fps_num + fps_den - 1) / fps_den;
+    for (unsigned i = 0; i < sizeof t / sizeof t[0]; i++)
+        if (fs <= t[i][2] && rate <= t[i][1] && mbw * mbw <= 8 * t[i][2] && mbh * mbh <= 8 * t[i][2]) return t[i][0];
+    return 52;
+}
+
+size_t h264_write_headers(uint8_t *out, size_t cap, int width, int height, int fps_num, int fps_den) {
+    uint8_t rb[160];
+    bits_t b;
+    const int mbw = (width + 15) / 16, mbh = (height + 15) / 16;
+    /* 7.3.2.1.1 seq_parameter_set_data: Constrained Baseline */
+    bits_init(&b, rb, sizeof rb);
+    bits_put(&b, 8, 66);
+    bits_put(&b, 8, 0xC0);
+    bits_put(&b, 8, (uint32_t)pick_level(mbw, mbh, fps_num, fps_den));
+    bits_ue(&b, 0);
+    bits_ue(&b, 4); /* log2_max_frame_num_minus4 */
+    bits_ue(&b, 2); /* pic_order_cnt_type 2: output order = decoding order */
+    bits_ue(&b, 1); /* max_num_ref_frames */
+    bits_put(&b, 1, 0);
+    bits_ue(&b, (uint32_t)(mbw - 1));
+    bits_ue(&b, (uint32_t)(mbh - 1));
+    bits_put(&b, 1, 1); /* frame_mbs_only_flag */
+    bits_put(&b, 1, 1); /* direct_8x8_inference_flag */
+    const int cr = (mbw * 16 - width) / 2, cb = (mbh * 16 - height) / 2;
+    if (cr || cb) { bits_put(&b, 1, 1); bits_ue(&b, 0); bits_ue(&b, (uint32_t)cr); bits_ue(&b, 0); bits_ue(&b, (uint32_t)cb); }
+    else bits_put(&b, 1, 0);
+    bits_put(&b, 1, 1);  /* vui_parameters_present_flag */
+    bits_put(&b, 4, 0);  /* aspect_ratio, overscan, video_signal_type, chroma_loc: absent */
+    bits_put(&b, 1, 1);  /* timing_info_present_flag */
+    bits_put(&b, 16, (uint32_t)fps_den >> 16); bits_put(&b, 16, (uint32_t)fps_den & 0xFFFF);
+    bits_put(&b, 16, (uint32_t)(2 * fps_num) >> 16); bits_put(&b, 16, (uint32_t)(2 * fps_num) & 0xFFFF);
+    bits_put(&b, 1, 1);  /* fixed_frame_rate_flag */
+    bits_put(&b, 3, 0);  /* nal_hrd, vcl_hrd, pic_struct: absent */
+    bits_put(&b, 1, 1);  /* bitstream_restriction_flag */
+    bits_put(&b, 1, 1);  /* motion_vectors_over_pic_boundaries_flag */
+    bits_ue(&b, 0); bits_ue(&b, 0); bits_ue(&b, 10); bits_ue(&b, 10);
+    bits_ue(&b, 0); /* max_num_reorder_frames */
+    bits_ue(&b, 1); /* max_dec_frame_buffering */
+    size_t n = bits_finish(&b, rb);
+    size_t a = emit_nal(out, cap, 3, 7, rb, n);
+    if (!a || b.overflow) return 0;
+    /* 7.3.2.2 pic_parameter_set_rbsp */
+    bits_init(&b, rb, sizeof rb);
+    bits_ue(&b, 0); bits_ue(&b, 0);
+    bits_put(&b, 1, 0); /* CAVLC */
+    bits_put(&b, 1, 0);
+    bits_ue(&b, 0); bits_ue(&b, 0); bits_ue(&b, 0);
+    bits_put(&b, 3, 0); /* weighted_pred_flag, weighted_bipred_idc */
+    bits_se(&b, 0); bits_se(&b, 0); bits_se(&b, 0);
+    bits_put(&b, 1, 1); /* deblocking_filter_control_present_flag */
+    bits_put(&b, 2, 0); /* constrained_intra_pred_flag, redundant_pic_cnt_present_flag */
+    n = bits_finish(&b, rb);
+    size_t c = emit_nal(out + a, cap - a, 3, 8, rb, n);
+    if (!c || b.overflow) return 0;
+    return a + c;
+}
+
+/* ------------------------------------------------------------------ residual block (9.2) */
+/* coef: 16 int16 in scan order, 16-byte aligned group; `skip_first` drops coef[0]
+ * (Intra16x16 AC / chroma AC: maxNumCoeff 15).  Returns TotalCoeff. */
+static inline int put_block16(bits_t *b, const int16_t *coef, int skip_first, int nC) {
+    __m128i z = _mm_setzero_si128();
+    __m128i lo = _mm_loadu_si128((const __m128i *)coef), hi = _mm_loadu_si128((const __m128i *)(coef + 8));
+    unsigned zm = (unsigned)_mm_movemask_epi8(_mm_packs_epi16(_mm_cmpeq_epi16(lo, z), _mm_cmpeq_epi16(hi, z)));
+    unsigned nzm = ~zm & 0xFFFFu; /* bit k: coef[k] != 0 */
+    if (skip_first) nzm >>= 1, coef++;
+    const int maxnum = skip_first ? 15 : 16;
+    const int total = __builtin_popcount(nzm);
+    const int cls = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3;
+    if (!total) { bits_put(b, vlc_coeff_token[cls][0][0].len, vlc_coeff_token[cls][0][0].bits); return 0; }
+    int idx[16], n = 0;
+    for (unsigned m = nzm; m; m &= m - 1) idx[n++] = __builtin_ctz(m);
+    int t1 = 0;
+    for (int i = n - 1; i >= 0 && t1 < 3; i--) {
+        int v = coef[idx[i]];
+        if (v == 1 || v == -1) t1++;
+        else break;
+    }
+    bits_put(b, vlc_coeff_token[cls][total][t1].len, vlc_coeff_token[cls][total][t1].bits);
+    uint32_t signs = 0;
+    for (int i = 0; i < t1; i++) signs = (signs << 1) | (coef[idx[n - 1 - i]] < 0);
+    bits_put(b, t1, signs);
+    int sl = (total > 10 && t1 < 3) ? 1 : 0;
+    for (int i = n - 1 - t1; i >= 0; i--) {
+        int lv = coef[idx[i]], av = lv < 0 ? -lv : lv;
+        int code = 2 * av - 2 + (lv < 0);
+        if (i == n - 1 - t1 && t1 < 3) code -= 2;
+        if (sl == 0) {
+            if (code < 14) bits_put(b, code + 1, 1);
+            else if (code < 30) { bits_put(b, 15, 1); bits_put(b, 4, (uint32_t)(code - 14)); }
+            else { bits_put(b, 16, 1); bits_put(b, 12, (uint32_t)(code - 30)); }
+            sl = 1;
+        } else if (code < (15 << sl)) {
+            bits_put(b, (code >> sl) + 1, 1);
+            bits_put(b, sl, (uint32_t)code & ((1u << sl) - 1));
+        } else { bits_put(b, 16, 1); bits_put(b, 12, (uint32_t)(code - (15 << sl))); }
+        if (av > (3 << (sl - 1)) && sl < 6) sl++;
+    }
+    int zl = idx[n - 1] + 1 - total;
+    if (total < maxnum) bits_put(b, vlc_total_zeros[total - 1][zl].len, vlc_total_zeros[total - 1][zl].bits);
+    for (int i = n - 1; i > 0 && zl > 0; i--) {
+        int run = idx[i] - idx[i - 1] - 1;
+        const vlc_t *v = &vlc_run_before[(zl > 7 ? 7 : zl) - 1][run];
+        bits_put(b, v->len, v->bits);
+        zl -= run;
+    }
+    return total;
+}
+static inline void put_chroma_dc(bits_t *b, const int16_t *coef) { /* 4 coefficients, nC = -1 */
+    int idx[4], n = 0;
+    for (int i = 0; i < 4; i++) if (coef[i]) idx[n++] = i;
+    int t1 = 0;
+    for (int i = n - 1; i >= 0 && t1 < 3; i--) {
+        if (coef[idx[i]] == 1 || coef[idx[i]] == -1) t1++;
+        else break;
+    }
+    bits_put(b, vlc_coeff_token_cdc[n][t1].len, vlc_coeff_token_cdc[n][t1].bits);
+    if (!n) return;
+    for (int i = 0; i < t1; i++) bits_put(b, 1, coef[idx[n - 1 - i]] < 0);
+    int sl = 0;
+    for (int i = n - 1 - t1; i >= 0; i--) {
+        int lv = coef[idx[i]], av = lv < 0 ? -lv : lv;
+        int code = 2 * av - 2 + (lv < 0);
+        if (i == n - 1 - t1 && t1 < 3) code -= 2;
+        if (sl == 0) {
+            if (code < 14) bits_put(b, code + 1, 1);
+            else if (code < 30) { bits_put(b, 15, 1); bits_put(b, 4, (uint32_t)(code - 14)); }
+            else { bits_put(b, 16, 1); bits_put(b, 12, (uint32_t)(code - 30)); }
+            sl = 1;
+        } else if (code < (15 << sl)) {
+            bits_put(b, (code >> sl) + 1, 1);
+            bits_put(b, sl, (uint32_t)code & ((1u << sl) - 1));
+        } else { bits_put(b, 16, 1); bits_put(b, 12, (uint32_t)(code - (15 << sl))); }
+        if (av > (3 << (sl - 1)) && sl < 6) sl++;
+    }
+    int zl = idx[n - 1] + 1 - n;
+    if (n < 4) bits_put(b, vlc_total_zeros_cdc[n - 1][zl].len, vlc_total_zeros_cdc[n - 1][zl].bits);
+    for (int i = n - 1; i > 0 && zl > 0; i--) {
+        int run = idx[i] - idx[i - 1] - 1;
+        const vlc_t *v = &vlc_run_before[zl - 1][run];
+        bits_put(b, v->len, v->bits);
+        zl -= run;
+    }
+}
+
+/* ------------------------------------------------------------------ motion vector prediction */
+static inline int med3(int a, int b, int c) {
+    int lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+}
+/* 8.4.1.3 for a 16x16 partition, refIdx 0, single slice: A left, B top, C top-right else top-left */
+static inline void predict_mv(const mb_info_t *mbi, int mbw, int mx, int my, int *px, int *py) {
+    const mb_info_t *m = mbi + (size_t)my * mbw + mx;
+    const mb_info_t *A = mx > 0 ? m - 1 : NULL, *B = my > 0 ? m - mbw : NULL;
+    const mb_info_t *C = my > 0 ? (mx + 1 < mbw ? m - mbw + 1 : (mx > 0 ? m - mbw - 1 : NULL)) : NULL;
+    const int ra = A && A->mb_type == 1, rb = B && B->mb_type == 1, rc = C && C->mb_type == 1;
+    const int ax = ra ? A->mvx : 0, ay = ra ? A->mvy : 0, bx = rb ? B->mvx : 0, by = rb ? B->mvy : 0;
+    const int cx = rc ? C->mvx : 0, cy = rc ? C->mvy : 0;
+    if (!B && !C && A) { *px = ax; *py = ay; return; }
+    if (ra + rb + rc == 1) {
+        *px = ra ? ax : rb ? bx : cx;
+        *py = ra ? ay : rb ? by : cy;
+        return;
+    }
+    *px = med3(ax, bx, cx);
+    *py = med3(ay, by, cy);
+}
+
+/* ------------------------------------------------------------------ slice */
+struct h264_writer {
+    int mbw, mbh;
+    uint8_t *rbsp; size_t rbsp_cap;
+    uint8_t *tc_l; /* TotalCoeff per luma 4x4 in raster order, 16 per macroblock */
+    uint8_t *tc_c; /* per chroma AC block: Cb 0-3, Cr 4-7 */
+};
+
+h264_writer_t *h264_writer_new(int mbw, int mbh) {
+    h264_writer_t *w = (h264_writer_t *)calloc(1, sizeof *w);
+    if (!w) return NULL;
+    w->mbw = mbw; w->mbh = mbh;
+    w->rbsp_cap = (size_t)mbw * mbh * 1024 + 1024;
+    w->rbsp = (uint8_t *)malloc(w->rbsp_cap);
+    w->tc_l = (uint8_t *)malloc((size_t)mbw * mbh * 16);
+    w->tc_c = (uint8_t *)malloc((size_t)mbw * mbh * 8);
+    if (!w->rbsp || !w->tc_l || !w->tc_c) { h264_writer_free(w); return NULL; }
+    return w;
+}
+void h264_writer_free(h264_writer_t *w) {
+    if (!w) return;
+    free(w->rbsp); free(w->tc_l); free(w->tc_c); free(w);
+}
+size_t h264_max_au_bytes(int mbw, int mbh) { return (size_t)mbw * mbh * 1536 + 4096; }
+
+static inline int ctx_luma(const h264_writer_t *w, int mbn, int mx, int my, int bx, int by) {
+    const uint8_t *t = w->tc_l + (size_t)mbn * 16;
+    int na = -1, nb = -1;
+    if (bx) na = t[by * 4 + bx - 1];
+    else if (mx) na = t[-16 + by * 4 + 3];
+    if (by) nb = t[(by - 1) * 4 + bx];
+    else if (my) nb = t[-16 * w->mbw + 12 + bx];
+    return (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));
+}
+static inline int ctx_chroma(const h264_writer_t *w, int mbn, int mx, int my, int c, int bx, int by) {
+    const uint8_t *t = w->tc_c + (size_t)mbn * 8 + 4 * c;
+    int na = -1, nb = -1;
+    if (bx) na = t[by * 2];
+    else if (mx) na = t[-8 + by * 2 + 1];
+    if (by) nb = t[bx];
+    else if (my) nb = t[-8 * w->mbw + 2 + bx];
+    return (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));
+}
+
+size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
+                        int slice_qp, const mb_info_t *mbi, const int16_t *levels) {
+    const int mbw = w->mbw, mbh = w->mbh, nmb = mbw * mbh;
+    bits_t b;
+    bits_init(&b, w->rbsp, w->rbsp_cap);
+    memset(w->tc_l, 0, (size_t)nmb * 16);
+    memset(w->tc_c, 0, (size_t)nmb * 8);
+    /* 7.3.3 slice_header */
+    bits_ue(&b, 0);
+    bits_ue(&b, is_idr ? 7 : 5);
+    bits_ue(&b, 0);
+    bits_put(&b, 8, (uint32_t)frame_num & 0xFF);
+    if (is_idr) bits_ue(&b, (uint32_t)idr_pic_id);
+    if (!is_idr) bits_put(&b, 2, 0);  /* num_ref_idx_active_override_flag, ref_pic_list_modification_flag_l0 */
+    if (is_idr) bits_put(&b, 2, 0);   /* no_output_of_prior_pics_flag, long_term_reference_flag */
+    else bits_put(&b, 1, 0);          /* adaptive_ref_pic_marking_mode_flag */
+    bits_se(&b, slice_qp - 26);
+    bits_ue(&b, 0);                   /* disable_deblocking_filter_idc */
+    bits_se(&b, 0); bits_se(&b, 0);
+    /* 7.3.4 slice_data */
+    int skip = 0, prev_qp = slice_qp;
+    for (int my = 0, mbn = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++, mbn++) {
+            const mb_info_t *m = mbi + mbn;
+            const int16_t *lv = levels + (size_t)mbn * MB_LEVELS;
+            const uint32_t nz = m->nzmask;
+            const int intra = m->mb_type == 0;
+            int cbp_l = 0;
+            if (intra) cbp_l = (nz & 0xFFFF) ? 15 : 0;
+            else cbp_l = ((nz & 0x000F) ? 1 : 0) | ((nz & 0x00F0) ? 2 : 0) | ((nz & 0x0F00) ? 4 : 0) | ((nz & 0xF000) ? 8 : 0);
+            const int cbp_c = (nz & 0x00FF0000u) ? 2 : ((nz & (NZ_CBDC | NZ_CRDC)) ? 1 : 0);
+            if (!intra) {
+                int px, py;
+                predict_mv(mbi, mbw, mx, my, &px, &py);
+                if (!cbp_l && !cbp_c) { /* 8.4.1.1: P_Skip when the vector equals the inferred one */
+                    int sx = px, sy = py;
+                    if (!mx || !my) sx = sy = 0;
+                    else {
+                        const mb_info_t *A = m - 1, *B = m - mbw;
+                        if ((A->mb_type == 1 && !A->mvx && !A->mvy) || (B->mb_type == 1 && !B->mvx && !B->mvy)) sx = sy = 0;
+                    }
+                    if (m->mvx == sx && m->mvy == sy) { skip++; continue; }
+                }
+                bits_ue(&b, (uint32_t)skip); skip = 0;
+                bits_ue(&b, 0); /* P_L0_16x16 */
+                bits_se(&b, 4 * (m->mvx - px));
+                bits_se(&b, 4 * (m->mvy - py));
+                bits_ue(&b, cbp_inter_code[cbp_c * 16 + cbp_l]);
+            } else {
+                if (!is_idr) { bits_ue(&b, (uint32_t)skip); skip = 0; }
+                int t = 1 + m->i16_mode + 4 * cbp_c + (cbp_l ? 12 : 0); /* Table 7-11 */
+                bits_ue(&b, (uint32_t)(is_idr ? t : t + 5));
+                bits_ue(&b, m->chroma_mode);
+            }
+            if (intra || cbp_l || cbp_c) { bits_se(&b, (int)m->qp - prev_qp); prev_qp = m->qp; }
+            uint8_t *tl = w->tc_l + (size_t)mbn * 16;
+            if (intra) put_block16(&b, lv + L_LDC, 0, ctx_luma(w, mbn, mx, my, 0, 0));
+            if (cbp_l)
+                for (int blk = 0; blk < 16; blk++) {
+                    if (!(cbp_l & (1 << (blk >> 2)))) continue;
+                    const int r = blk_to_raster[blk], bx = r & 3, by = r >> 2;
+                    const int nC = ctx_luma(w, mbn, mx, my, bx, by);
+                    if ((nz >> blk) & 1) tl[r] = (uint8_t)put_block16(&b, lv + L_LUMA + blk * 16, intra, nC);
+                    else { const int cls = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3; bits_put(&b, vlc_coeff_token[cls][0][0].len, vlc_coeff_token[cls][0][0].bits); }
+                }
+            if (cbp_c) {
+                put_chroma_dc(&b, lv + L_CDC);
+                put_chroma_dc(&b, lv + L_CDC + 4);
+                if (cbp_c == 2)
+                    for (int c = 0; c < 2; c++)
+                        for (int blk = 0; blk < 4; blk++) {
+                            const int nC = ctx_chroma(w, mbn, mx, my, c, blk & 1, blk >> 1);
+                            w->tc_c[(size_t)mbn * 8 + 4 * c + blk] = (uint8_t)put_block16(&b, lv + L_CAC + (4 * c + blk) * 16, 1, nC);
+                        }
+            }
+        }
+    if (!is_idr && skip) bits_ue(&b, (uint32_t)skip);
+    size_t n = bits_finish(&b, w->rbsp);
+    if (b.overflow) return 0;
+    return emit_nal(out, cap, is_idr ? 3 : 2, is_idr ? 5 : 1, w->rbsp, n);
+}

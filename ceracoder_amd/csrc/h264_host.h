@@ -1,0 +1,42 @@
+/* Host-side bitstream writer of libmi355enc (internal). */
+#ifndef H264_HOST_H
+#define H264_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mi355enc_dev.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct h264_writer h264_writer_t;
+h264_writer_t *h264_writer_new(int mbw, int mbh);
+void h264_writer_free(h264_writer_t *w);
+size_t h264_max_au_bytes(int mbw, int mbh);
+/* SPS + PPS (Annex B).  Returns bytes written, 0 if `cap` is too small. */
+size_t h264_write_headers(uint8_t *out, size_t cap, int width, int height, int fps_num, int fps_den);
+/* One slice NAL covering the whole picture.  Returns bytes written, 0 if out of room. */
+size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
+                        int slice_qp, const mb_info_t *mbi, const int16_t *levels);
+
+/* ---- rate control (ratecontrol.c): one QP per picture from a bits/s setpoint ---- */
+typedef struct {
+    double fps;
+    int gop, qp_min, qp_max;
+    double target_bps;
+    double cplx_i, cplx_p;     /* bits * qstep of recent I / P pictures          */
+    double fullness;           /* virtual buffer: produced - budgeted bits        */
+    int last_qp_i, last_qp_p;
+    int frames_in_gop;
+    int have_i, have_p;
+} rc_state_t;
+void rc_init(rc_state_t *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max);
+void rc_set_bitrate(rc_state_t *rc, uint32_t bps);
+int rc_pick_qp(rc_state_t *rc, int is_idr);
+void rc_update(rc_state_t *rc, int is_idr, int qp, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

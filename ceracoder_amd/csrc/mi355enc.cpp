@@ -1,0 +1,488 @@
+// mi355enc.cpp -- C-ABI shim (include/mi355enc.h) over the HIP kernels: owns device
+// surfaces, the stream, the captured launch graphs, the picture pipeline and rate control.
+//
+// Per picture, on one HIP stream:
+//   [H2D source] -> ctx upload -> IDR: intra wavefront (x+y diagonals)
+//                                 P  : me_kernel -> inter_kernel
+//                -> deblock wavefront (x+2y diagonals) -> D2H {mb records, levels} -> event
+// and on the host, when the event has fired: CAVLC slice coding (h264_host.c).
+// With pipeline_depth = 1 the host codes picture n while the device works on n+1.
+#include "../../include/mi355enc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "h264_host.h"
+#include "mi355enc_dev.h"
+
+#define HIPCHK(expr)                                                                                 \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            fprintf(stderr, "mi355enc: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MI355ENC_ERR_HIP;                                                                 \
+        }                                                                                            \
+    } while (0)
+
+static const uint8_t k_lambda[52] = {1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  2,  2,
+                                     2,  2,  3,  3,  3,  4,  4,  4,  5,  6,  6,  7,  8,  9,  10, 11, 13, 14,
+                                     16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91};
+
+#define NSLOT 2
+#define SURF_PAD 256 /* bytes past each surface: unaligned-pair loads may touch 4 bytes beyond */
+
+struct slot_t {
+    frame_ctx_t *h_ctx;   // pinned
+    mb_info_t *h_mbi;     // pinned
+    int16_t *h_levels;    // pinned
+    uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
+    hipEvent_t done, ev[6];
+    int is_idr, qp, frame_num, idr_pic_id, rec_index;
+    int64_t pts;
+};
+
+struct mi355enc {
+    mi355enc_cfg_t cfg;
+    int mbw, mbh, W, H, nmb;
+    size_t ysz, csz;
+    hipStream_t stream;
+    frame_ctx_t *d_ctx;
+    mb_info_t *d_mbi;
+    int16_t *d_levels;
+    uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
+    slot_t slot[NSLOT];
+    int head, tail, pending;
+    int cur, have_ref, frames_since_idr, idr_count, last_collected_rec;
+    slot_t *last_slot;
+    hipGraphExec_t g_intra, g_deblock;
+    h264_writer_t *writer;
+    rc_state_t rc;
+    std::atomic<uint32_t> want_bps;
+    std::atomic<int> fixed_qp;
+    mi355enc_stats_t st;
+};
+
+static double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+extern "C" {
+
+int mi355enc_abi_version(void) { return MI355ENC_ABI_VERSION; }
+
+const char *mi355enc_strerror(int code) {
+    switch (code) {
+    case MI355ENC_OK: return "ok";
+    case MI355ENC_ERR_ARG: return "invalid argument";
+    case MI355ENC_ERR_NO_DEVICE: return "no usable HIP device (this encoder has no CPU fallback)";
+    case MI355ENC_ERR_HIP: return "HIP runtime error";
+    case MI355ENC_ERR_NOMEM: return "out of memory";
+    case MI355ENC_ERR_OVERFLOW: return "output buffer too small";
+    case MI355ENC_ERR_STATE: return "call order violated";
+    default: return "unknown error";
+    }
+}
+
+void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num, int fps_den) {
+    memset(c, 0, sizeof *c);
+    c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
+    c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0;
+}
+
+static void launch_intra_all(mi355enc_t *h) {
+    int n = k_intra_diags(h->mbw, h->mbh);
+    for (int d = 0; d < n; d++) k_launch_intra_diag(h->d_ctx, h->mbw, h->mbh, d, h->stream);
+}
+static void launch_deblock_all(mi355enc_t *h) {
+    int n = k_deblock_diags(h->mbw, h->mbh);
+    for (int d = 0; d < n; d++) k_launch_deblock_diag(h->d_ctx, h->mbw, h->mbh, d, h->stream);
+}
+static int build_graph(mi355enc_t *h, int which, hipGraphExec_t *out) {
+    hipGraph_t g;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    if (which == 0) launch_intra_all(h); else launch_deblock_all(h);
+    HIPCHK(hipStreamEndCapture(h->stream, &g));
+    HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(g));
+    return 0;
+}
+static int run_intra(mi355enc_t *h) {
+    if (h->cfg.use_graphs) {
+        if (!h->g_intra) { int r = build_graph(h, 0, &h->g_intra); if (r) return r; }
+        HIPCHK(hipGraphLaunch(h->g_intra, h->stream));
+    } else launch_intra_all(h);
+    return 0;
+}
+static int run_deblock(mi355enc_t *h) {
+    if (h->cfg.use_graphs) {
+        if (!h->g_deblock) { int r = build_graph(h, 1, &h->g_deblock); if (r) return r; }
+        HIPCHK(hipGraphLaunch(h->g_deblock, h->stream));
+    } else launch_deblock_all(h);
+    return 0;
+}
+
+int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
+    if (!cfg || !out) return MI355ENC_ERR_ARG;
+    *out = nullptr;
+    if (cfg->width < 16 || cfg->height < 16 || cfg->width > 8192 || cfg->height > 8192 || (cfg->width & 1) || (cfg->height & 1) ||
+        cfg->fps_num <= 0 || cfg->fps_den <= 0 || cfg->gop < 1 || cfg->me_range < 1 || cfg->me_range > 16 ||
+        cfg->pipeline_depth < 0 || cfg->pipeline_depth > NSLOT - 1 || cfg->fixed_qp > 51) {
+        fprintf(stderr, "mi355enc: invalid configuration\n");
+        return MI355ENC_ERR_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || cfg->device_id < 0 || cfg->device_id >= ndev) {
+        fprintf(stderr, "mi355enc: no usable HIP device (count=%d, device-id=%d, %s); this encoder has no CPU path\n", ndev,
+                cfg->device_id, e == hipSuccess ? "ok" : hipGetErrorString(e));
+        return MI355ENC_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(cfg->device_id));
+    mi355enc_t *h = new (std::nothrow) mi355enc();
+    if (!h) return MI355ENC_ERR_NOMEM;
+    memset((void *)&h->cfg, 0, sizeof h->cfg);
+    h->cfg = *cfg;
+    if (h->cfg.qp_min <= 0 && h->cfg.qp_max <= 0) { h->cfg.qp_min = 10; h->cfg.qp_max = 51; }
+    if (h->cfg.qp_max > 51) h->cfg.qp_max = 51;
+    if (h->cfg.qp_min < 0) h->cfg.qp_min = 0;
+    h->mbw = (cfg->width + 15) / 16; h->mbh = (cfg->height + 15) / 16;
+    h->W = h->mbw * 16; h->H = h->mbh * 16; h->nmb = h->mbw * h->mbh;
+    h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
+    h->head = h->tail = h->pending = 0;
+    h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
+    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr;
+    memset(&h->st, 0, sizeof h->st);
+    h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
+    h->fixed_qp.store(cfg->fixed_qp);
+    *out = h; // from here on close() cleans up partial state
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&h->d_ctx, sizeof(frame_ctx_t)));
+    HIPCHK(hipMalloc((void **)&h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t)));
+    HIPCHK(hipMalloc((void **)&h->d_levels, (size_t)h->nmb * MB_LEVELS * sizeof(int16_t)));
+    HIPCHK(hipMemsetAsync(h->d_mbi, 0, (size_t)h->nmb * sizeof(mb_info_t), h->stream));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc((void **)&h->d_rec_y[i], h->ysz + SURF_PAD));
+        HIPCHK(hipMalloc((void **)&h->d_rec_uv[i], h->csz + SURF_PAD));
+        HIPCHK(hipMemsetAsync(h->d_rec_y[i], 0, h->ysz + SURF_PAD, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_rec_uv[i], 0, h->csz + SURF_PAD, h->stream));
+    }
+    if (cfg->keep_prefilter) {
+        HIPCHK(hipMalloc((void **)&h->d_pre_y, h->ysz));
+        HIPCHK(hipMalloc((void **)&h->d_pre_uv, h->csz));
+    }
+    for (int i = 0; i < NSLOT; i++) {
+        slot_t *s = &h->slot[i];
+        memset(s, 0, sizeof *s);
+        HIPCHK(hipHostMalloc((void **)&s->h_ctx, sizeof(frame_ctx_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&s->h_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&s->h_levels, (size_t)h->nmb * MB_LEVELS * sizeof(int16_t), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&s->d_src_y, h->ysz + SURF_PAD));
+        HIPCHK(hipMalloc((void **)&s->d_src_uv, h->csz + SURF_PAD));
+        HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+        for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&s->ev[k]));
+    }
+    h->writer = h264_writer_new(h->mbw, h->mbh);
+    if (!h->writer) return MI355ENC_ERR_NOMEM;
+    rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
+
+void mi355enc_close(mi355enc_t *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->g_intra) (void)hipGraphExecDestroy(h->g_intra);
+    if (h->g_deblock) (void)hipGraphExecDestroy(h->g_deblock);
+    for (int i = 0; i < NSLOT; i++) {
+        slot_t *s = &h->slot[i];
+        if (s->h_ctx) (void)hipHostFree(s->h_ctx);
+        if (s->h_mbi) (void)hipHostFree(s->h_mbi);
+        if (s->h_levels) (void)hipHostFree(s->h_levels);
+        if (s->d_src_y) (void)hipFree(s->d_src_y);
+        if (s->d_src_uv) (void)hipFree(s->d_src_uv);
+        if (s->done) (void)hipEventDestroy(s->done);
+        for (int k = 0; k < 6; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
+    }
+    for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
+    if (h->d_pre_y) (void)hipFree(h->d_pre_y);
+    if (h->d_pre_uv) (void)hipFree(h->d_pre_uv);
+    if (h->d_ctx) (void)hipFree(h->d_ctx);
+    if (h->d_mbi) (void)hipFree(h->d_mbi);
+    if (h->d_levels) (void)hipFree(h->d_levels);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    h264_writer_free(h->writer);
+    delete h;
+}
+
+int mi355enc_set_bitrate(mi355enc_t *h, uint32_t bps) {
+    if (!h) return MI355ENC_ERR_ARG;
+    h->want_bps.store(bps < 1000 ? 1000 : bps, std::memory_order_relaxed);
+    return MI355ENC_OK;
+}
+uint32_t mi355enc_get_bitrate(const mi355enc_t *h) { return h ? h->want_bps.load(std::memory_order_relaxed) : 0; }
+int mi355enc_set_fixed_qp(mi355enc_t *h, int qp) {
+    if (!h || qp > 51) return MI355ENC_ERR_ARG;
+    h->fixed_qp.store(qp < 0 ? -1 : qp, std::memory_order_relaxed);
+    return MI355ENC_OK;
+}
+int mi355enc_pending(const mi355enc_t *h) { return h ? h->pending : 0; }
+size_t mi355enc_max_au_bytes(const mi355enc_t *h) { return h ? h264_max_au_bytes(h->mbw, h->mbh) : 0; }
+int mi355enc_mb_width(const mi355enc_t *h) { return h ? h->mbw : 0; }
+int mi355enc_mb_height(const mi355enc_t *h) { return h ? h->mbh : 0; }
+
+// Enqueue every device step of one picture whose source is described by (src_y, src_uv, src_stride).
+static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride,
+                           int64_t pts, int force_idr) {
+    const int idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop;
+    if (idr) h->frames_since_idr = 0;
+    // rate control: latch the setpoint written by the control thread, pick this picture's QP
+    rc_set_bitrate(&h->rc, h->want_bps.load(std::memory_order_relaxed));
+    int fq = h->fixed_qp.load(std::memory_order_relaxed);
+    const int qp = fq >= 0 ? fq : rc_pick_qp(&h->rc, idr);
+    const int nxt = h->cur ^ 1;
+    frame_ctx_t *c = s->h_ctx;
+    c->src_y = src_y; c->src_uv = src_uv; c->src_stride = src_stride;
+    c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
+    c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
+    c->mbi = h->d_mbi; c->levels = h->d_levels;
+    c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp];
+    HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
+    const int prof = h->cfg.profile_events;
+    if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
+    if (idr) {
+        int r = run_intra(h); if (r) return r;
+        if (prof) { HIPCHK(hipEventRecord(s->ev[1], h->stream)); HIPCHK(hipEventRecord(s->ev[2], h->stream)); }
+    } else {
+        k_launch_me(h->d_ctx, h->mbw, h->mbh, h->stream);
+        if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
+        k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
+        if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
+    }
+    if (h->d_pre_y) {
+        HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
+        if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
+    }
+    { int r = run_deblock(h); if (r) return r; }
+    if (prof) HIPCHK(hipEventRecord(s->ev[3], h->stream));
+    HIPCHK(hipMemcpyAsync(s->h_mbi, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(s->h_levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    if (prof) HIPCHK(hipEventRecord(s->ev[4], h->stream));
+    HIPCHK(hipEventRecord(s->done, h->stream));
+    s->is_idr = idr; s->qp = qp; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
+    s->pts = pts; s->rec_index = nxt;
+    if (idr) h->idr_count++;
+    h->frames_since_idr++;
+    h->cur = nxt; h->have_ref = 1;
+    h->head = (h->head + 1) % NSLOT; h->pending++;
+    return MI355ENC_OK;
+}
+
+int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride, int64_t pts, int force_idr) {
+    if (!h || !y || !uv || y_stride < h->cfg.width || uv_stride < h->cfg.width) return MI355ENC_ERR_ARG;
+    if (h->pending > h->cfg.pipeline_depth) return MI355ENC_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[h->head];
+    const int w = h->cfg.width, ht = h->cfg.height;
+    HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, y, y_stride, w, ht, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, h->stream));
+    if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, h->stream);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+}
+
+int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const void *d_uv, int uv_stride, int64_t pts, int force_idr) {
+    if (!h || !d_y || !d_uv || y_stride < h->cfg.width || uv_stride < h->cfg.width) return MI355ENC_ERR_ARG;
+    if (h->pending > h->cfg.pipeline_depth) return MI355ENC_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[h->head];
+    const int w = h->cfg.width, ht = h->cfg.height;
+    const bool direct = w == h->W && y_stride == uv_stride && (y_stride & 15) == 0 && (((uintptr_t)d_y | (uintptr_t)d_uv) & 15) == 0;
+    if (direct) return enqueue_picture(h, s, (const uint8_t *)d_y, (const uint8_t *)d_uv, y_stride, pts, force_idr);
+    HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, d_y, y_stride, w, ht, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, d_uv, uv_stride, w, ht / 2, hipMemcpyDeviceToDevice, h->stream));
+    if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, h->stream);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+}
+
+int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_len, int *is_keyframe, int64_t *pts, int *qp) {
+    if (!h || !out || !out_len) return MI355ENC_ERR_ARG;
+    if (h->pending <= 0) return MI355ENC_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[h->tail];
+    double t0 = now_ms();
+    HIPCHK(hipEventSynchronize(s->done));
+    double t1 = now_ms();
+    h->st.ms_wait += t1 - t0;
+    size_t n = 0;
+    if (s->is_idr) {
+        n = h264_write_headers(out, out_cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den);
+        if (!n) return MI355ENC_ERR_OVERFLOW;
+    }
+    size_t m = h264_write_slice(h->writer, out + n, out_cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels);
+    if (!m) return MI355ENC_ERR_OVERFLOW;
+    h->st.ms_entropy += now_ms() - t1;
+    *out_len = n + m;
+    if (is_keyframe) *is_keyframe = s->is_idr;
+    if (pts) *pts = s->pts;
+    if (qp) *qp = s->qp;
+    rc_update(&h->rc, s->is_idr, s->qp, n + m);
+    if (h->cfg.profile_events) {
+        float a = 0, b = 0, c = 0, tot = 0;
+        (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
+        (void)hipEventElapsedTime(&b, s->ev[1], s->ev[2]);
+        (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
+        (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]);
+        if (s->is_idr) { h->st.ms_intra += a; h->st.n_intra++; }
+        else { h->st.ms_me += a; h->st.n_me++; h->st.ms_inter += b; h->st.n_inter++; }
+        h->st.ms_deblock += c; h->st.n_deblock++;
+        h->st.ms_total_gpu += tot;
+    }
+    h->st.frames++; h->st.idr_frames += s->is_idr; h->st.bytes += n + m;
+    h->st.last_qp = (uint32_t)s->qp; h->st.last_bytes = (uint32_t)(n + m); h->st.target_bps = h->want_bps.load();
+    h->last_slot = s; h->last_collected_rec = s->rec_index;
+    h->tail = (h->tail + 1) % NSLOT; h->pending--;
+    return MI355ENC_OK;
+}
+
+int mi355enc_encode(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride, int64_t pts, int force_idr,
+                    uint8_t *out, size_t out_cap, size_t *out_len, int *is_keyframe) {
+    if (!h) return MI355ENC_ERR_ARG;
+    if (h->pending) return MI355ENC_ERR_STATE;
+    int r = mi355enc_submit(h, y, y_stride, uv, uv_stride, pts, force_idr);
+    if (r) return r;
+    return mi355enc_collect(h, out, out_cap, out_len, is_keyframe, nullptr, nullptr);
+}
+
+int mi355enc_get_stats(mi355enc_t *h, mi355enc_stats_t *st) {
+    if (!h || !st) return MI355ENC_ERR_ARG;
+    *st = h->st;
+    st->target_bps = h->want_bps.load();
+    return MI355ENC_OK;
+}
+void mi355enc_reset_stats(mi355enc_t *h) { if (h) memset(&h->st, 0, sizeof h->st); }
+
+int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
+    if (!h || !dst) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const void *src = nullptr; size_t need = 0; bool host = false;
+    switch (what) {
+    case MI355ENC_FETCH_RECON_Y: src = h->d_rec_y[h->last_collected_rec]; need = h->ysz; break;
+    case MI355ENC_FETCH_RECON_UV: src = h->d_rec_uv[h->last_collected_rec]; need = h->csz; break;
+    case MI355ENC_FETCH_PREFILTER_Y: src = h->d_pre_y; need = h->ysz; break;
+    case MI355ENC_FETCH_PREFILTER_UV: src = h->d_pre_uv; need = h->csz; break;
+    case MI355ENC_FETCH_MBINFO: src = h->last_slot ? h->last_slot->h_mbi : nullptr; need = (size_t)h->nmb * sizeof(mb_info_t); host = true; break;
+    case MI355ENC_FETCH_LEVELS: src = h->last_slot ? h->last_slot->h_levels : nullptr; need = (size_t)h->nmb * MB_LEVELS * 2; host = true; break;
+    default: return MI355ENC_ERR_ARG;
+    }
+    if (!src) return MI355ENC_ERR_STATE;
+    if (n < need) return MI355ENC_ERR_OVERFLOW;
+    if (host) { memcpy(dst, src, need); return MI355ENC_OK; }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
+    return MI355ENC_OK;
+}
+
+// ---------------------------------------------------------------- single-stage entry points
+static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
+    if (h->pending) return MI355ENC_ERR_STATE;
+    slot_t *s = &h->slot[0];
+    frame_ctx_t *c = s->h_ctx;
+    c->src_y = src_is_staging ? s->d_src_y : nullptr; c->src_uv = src_is_staging ? s->d_src_uv : nullptr; c->src_stride = h->W;
+    c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
+    c->mbi = h->d_mbi; c->levels = h->d_levels; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp];
+    HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_out) {
+    if (!h || !cur_y || !ref_y || !mbinfo_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, cur_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    int r = stage_ctx(h, qp, true); if (r) return r;
+    k_launch_me(h->d_ctx, h->mbw, h->mbh, h->stream);
+    HIPCHK(hipMemcpyAsync(mbinfo_out, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
+int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv,
+                         int qp, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels) {
+    if (!h || !src_y || !src_uv || !ref_y || !ref_uv || !mbinfo_inout || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rec_uv[0], ref_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
+    int r = stage_ctx(h, qp, true); if (r) return r;
+    k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
+    HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
+int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out, uint8_t *rec_y,
+                         uint8_t *rec_uv, int16_t *levels) {
+    if (!h || !src_y || !src_uv || !mbinfo_out || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    int r = stage_ctx(h, qp, true); if (r) return r;
+    r = run_intra(h); if (r) return r;
+    HIPCHK(hipMemcpyAsync(mbinfo_out, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
+int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const void *mbinfo) {
+    if (!h || !rec_y || !rec_uv || !mbinfo) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->d_rec_y[1], rec_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rec_uv[1], rec_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
+    int r = stage_ctx(h, 26, false); if (r) return r;
+    r = run_deblock(h); if (r) return r;
+    HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
+int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
+    if (!h || !avg_ms || iters < 1 || stage < 0 || stage > 3) return MI355ENC_ERR_ARG;
+    if (h->pending) return MI355ENC_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[0];
+    // make sure the device context is valid: reuse the last one uploaded; if none, build a stage context
+    if (!h->have_ref) { int r = stage_ctx(h, 26, true); if (r) return r; }
+    for (int warm = 0; warm < 2; warm++) {
+        if (warm) HIPCHK(hipEventRecord(s->ev[0], h->stream));
+        for (int i = 0; i < (warm ? iters : 1); i++) {
+            if (stage == 0) k_launch_me(h->d_ctx, h->mbw, h->mbh, h->stream);
+            else if (stage == 1) k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
+            else if (stage == 2) { int r = run_intra(h); if (r) return r; }
+            else { int r = run_deblock(h); if (r) return r; }
+        }
+        if (warm) HIPCHK(hipEventRecord(s->ev[1], h->stream));
+    }
+    HIPCHK(hipEventSynchronize(s->ev[1]));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+    *avg_ms = (double)ms / iters;
+    return MI355ENC_OK;
+}
+
+} // extern "C"

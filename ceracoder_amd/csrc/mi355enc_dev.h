@@ -1,0 +1,60 @@
+/* Internal: types shared by the host orchestration (mi355enc.cpp), the host entropy coder
+ * (h264_host.c) and the HIP kernels (mi355enc_kernels.hip).  Not part of the C ABI. */
+#ifndef MI355ENC_DEV_H
+#define MI355ENC_DEV_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 16-byte per-macroblock record (DESIGN.md "HBM layout") */
+typedef struct {
+    int16_t mvx, mvy;     /* integer-pel luma motion vector                         */
+    uint8_t mb_type;      /* 0 I16x16, 1 P_L0_16x16                                 */
+    uint8_t i16_mode;     /* 0 V 1 H 2 DC 3 Plane                                   */
+    uint8_t chroma_mode;  /* 0 DC 1 H 2 V 3 Plane                                   */
+    uint8_t qp;
+    uint32_t nzmask;      /* b0-15 luma blkIdx, b16-23 chroma AC, b24 luma DC, b25 Cb DC, b26 Cr DC */
+    uint32_t cost;
+} mb_info_t;
+
+#define MB_LEVELS 408
+#define L_LUMA 0
+#define L_LDC 256
+#define L_CDC 272
+#define L_CAC 280
+#define NZ_LDC (1u << 24)
+#define NZ_CBDC (1u << 25)
+#define NZ_CRDC (1u << 26)
+
+/* Device-resident description of the picture being encoded; kernels read it through one
+ * pointer so that the per-picture launch sequence can be replayed as a hipGraph. */
+typedef struct {
+    const uint8_t *src_y, *src_uv; /* source NV12 (visible rows only; rows clamp to vis_h-1) */
+    const uint8_t *ref_y, *ref_uv; /* previous reconstructed, deblocked picture (coded size) */
+    uint8_t *rec_y, *rec_uv;       /* picture being reconstructed (coded size)               */
+    mb_info_t *mbi;
+    int16_t *levels;
+    int32_t src_stride;            /* bytes per source luma row (= chroma row, NV12)          */
+    int32_t stride;                /* coded-surface stride = 16*mbw                           */
+    int32_t mbw, mbh, vis_h;
+    int32_t qp, me_range, lambda;
+} frame_ctx_t;
+
+#ifdef __cplusplus
+}
+#endif
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+/* launchers (mi355enc_kernels.hip); all asynchronous on `s` */
+void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
+void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
+void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
+void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
+void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s);
+int k_intra_diags(int mbw, int mbh);
+int k_deblock_diags(int mbw, int mbh);
+#endif
+#endif

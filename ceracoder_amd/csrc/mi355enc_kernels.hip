@@ -1,0 +1,832 @@
+// mi355enc_kernels.hip -- hand-written HIP kernels for gfx950 (CDNA4, wave64).
+//
+// The per-macroblock hot path that the reference delegates to libx264 behind its
+// `x264enc` pipeline token (/root/reference/pipeline/generic/x264_superfast_camlink:5):
+//   me_kernel        full-search SAD motion estimation            (encoder choice)
+//   inter_kernel     MC + residual + 4x4 T/Q + dequant/IDCT + recon (H.264 8.4.2.2, 8.5)
+//   intra_kernel     Intra16x16 + chroma prediction, T/Q, recon     (H.264 8.3.3, 8.3.4, 8.5)
+//   deblock_kernel   in-loop deblocking filter                      (H.264 8.7)
+// Integer arithmetic throughout (u8 samples, 16-bit levels, 32-bit accumulators): results
+// must equal oracle/h264_enc_oracle.c byte for byte.  No MFMA: nothing here is a dense
+// contraction; the SAD inner loop is v_qsad_pk_u16_u8 on an LDS-staged search window.
+#include "mi355enc_dev.h"
+
+#define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------ constant tables
+__constant__ uint16_t c_mf[6][3] = {{13107, 5243, 8066}, {11916, 4660, 7490}, {10082, 4194, 6554},
+                                    {9362, 3647, 5825},  {8192, 3355, 5243},  {7282, 2893, 4559}};
+__constant__ uint8_t c_v[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+__constant__ uint8_t c_qpc[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+                                  18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
+                                  34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+__constant__ uint8_t c_alpha[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,   0,   0,   0,   0,   0,   0,   0,   4,   4,
+                                    5,  6,  7,  8,  9,  10, 12, 13, 15,  17,  20,  22,  25,  28,  32,  36,  40,  45,
+                                    50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255};
+__constant__ uint8_t c_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  0,  0,  0,  0,  2,  2,
+                                   2, 3, 3, 3, 3, 4, 4, 4, 6,  6,  7,  7,  8,  8,  9,  9,  10, 10,
+                                   11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18};
+__constant__ uint8_t c_tc0[52][3] = {
+    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},
+    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 1},
+    {0, 0, 1},   {0, 0, 1},   {0, 0, 1},   {0, 1, 1},   {0, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},
+    {1, 1, 2},   {1, 1, 2},   {1, 1, 2},   {1, 1, 2},   {1, 2, 3},   {1, 2, 3},   {2, 2, 3},   {2, 2, 4},   {2, 3, 4},
+    {2, 3, 4},   {3, 3, 5},   {3, 4, 6},   {3, 4, 6},   {4, 5, 7},   {4, 5, 8},   {4, 6, 9},   {5, 7, 10},  {6, 8, 11},
+    {6, 8, 13},  {7, 10, 14}, {8, 11, 16}, {9, 12, 18}, {10, 13, 20}, {11, 15, 23}, {13, 17, 25}};
+
+DEV int iabs(int v) { return v < 0 ? -v : v; }
+DEV int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+DEV int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+DEV int blkx(int b) { return ((b & 1) << 2) | ((b & 4) << 1); }        // luma4x4BlkIdx -> x offset (6.4.3)
+DEV int blky(int b) { return ((b & 2) << 1) | ((b & 8)); }             // luma4x4BlkIdx -> y offset
+
+// XCD-aware block remap: consecutive logical tiles land on the same XCD (blocks are dealt
+// round-robin over the 8 XCDs), so neighbouring strips share one L2.  Bijective for any n.
+DEV int xcd_remap(int wg, int n) {
+    int q = n >> 3, r = n & 7, k = wg & 7;
+    return k * q + (k < r ? k : r) + (wg >> 3);
+}
+
+// =================================================================== motion search
+// One workgroup = 8 horizontally adjacent macroblocks of one macroblock row, 4 waves.
+// The 48 x 160 luma search window (+-16 around the strip) is staged once in LDS; each
+// 32-lane half-wave owns one macroblock: lane l < 27 owns the candidates
+//   dy in [-16 + 11*(l/9), +11)   x   dx in [-16 + 4*(l%9), +4)
+// and accumulates them with v_qsad_pk_u16_u8 (4 SADs of 4 pixels per instruction),
+// re-using each window row for the 11 dy it serves.  The (cost,dy,dx) minimum is then
+// reduced over the half-wave with cross-lane shuffles.
+#define ME_MBS 8
+#define ME_ROWS 48
+#define ME_STRIDE 59 /* words; 11*59 mod 32 = 9 -> the three dy-groups hit disjoint banks */
+
+DEV unsigned long long qsad(unsigned lo, unsigned hi, unsigned cur, unsigned long long acc) {
+    unsigned long long src = ((unsigned long long)hi << 32) | lo;
+    return __builtin_amdgcn_qsad_pk_u16_u8(src, cur, acc);
+}
+DEV int mv_bits(int v) { // bits of se(4v): 1 for 0, else 7 + 2*floor(log2|v|)
+    int a = iabs(v);
+    return a == 0 ? 1 : 7 + 2 * (31 - __clz(a));
+}
+
+__global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__ ctx) {
+    __shared__ unsigned win[ME_ROWS * ME_STRIDE];
+    const int stride = ctx->stride, mbw = ctx->mbw, mbh = ctx->mbh;
+    const int W = mbw * 16, H = mbh * 16;
+    const int strips = (mbw + ME_MBS - 1) / ME_MBS;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int my = tile / strips, sx = tile - my * strips;
+    const int t = threadIdx.x;
+    const uint8_t *__restrict__ ref = ctx->ref_y;
+
+    // ---- stage the window: 48 rows x 10 uint4 (coalesced 16 B per lane)
+    for (int i = t; i < ME_ROWS * 10; i += 256) {
+        int row = i / 10, q = i - row * 10;
+        int gy = my * 16 - 16 + row, gx = sx * (ME_MBS * 16) - 16 + 16 * q;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *(const uint4 *)(ref + (size_t)gy * stride + gx);
+        unsigned *d = &win[row * ME_STRIDE + 4 * q];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (t < ME_ROWS) win[t * ME_STRIDE + 40] = 0;
+
+    const int lane = t & 63, wave = t >> 6, half = lane >> 5, l = lane & 31;
+    const int m = wave * 2 + half;
+    const int mx = sx * ME_MBS + m;
+    const bool active = l < 27 && mx < mbw;
+    const int g = l < 27 ? l / 9 : 0, dxg = l < 27 ? l % 9 : 0;
+    const int mxc = mx < mbw ? mx : mbw - 1;
+
+    // ---- current macroblock: 16 rows x 4 words, identical in every lane of the half-wave
+    unsigned c[16][4];
+    {
+        const uint8_t *__restrict__ src = ctx->src_y;
+        const int ss = ctx->src_stride, vh = ctx->vis_h;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int sy = my * 16 + r;
+            sy = sy < vh ? sy : vh - 1;
+            uint4 v = *(const uint4 *)(src + (size_t)sy * ss + mxc * 16);
+            c[r][0] = v.x; c[r][1] = v.y; c[r][2] = v.z; c[r][3] = v.w;
+        }
+    }
+    __syncthreads();
+
+    unsigned long long acc[11];
+#pragma unroll
+    for (int d = 0; d < 11; d++) acc[d] = 0;
+    const unsigned *wp = &win[(11 * g) * ME_STRIDE + 4 * m + dxg];
+#pragma unroll
+    for (int j = 0; j < 26; j++) {
+        unsigned w0 = wp[j * ME_STRIDE + 0], w1 = wp[j * ME_STRIDE + 1], w2 = wp[j * ME_STRIDE + 2];
+        unsigned w3 = wp[j * ME_STRIDE + 3], w4 = wp[j * ME_STRIDE + 4];
+#pragma unroll
+        for (int d = 0; d < 11; d++) {
+            const int r = j - d;
+            if (r >= 0 && r < 16) {
+                acc[d] = qsad(w0, w1, c[r][0], acc[d]);
+                acc[d] = qsad(w1, w2, c[r][1], acc[d]);
+                acc[d] = qsad(w2, w3, c[r][2], acc[d]);
+                acc[d] = qsad(w3, w4, c[r][3], acc[d]);
+            }
+        }
+    }
+
+    // ---- cost = SAD + lambda*(bits(dx)+bits(dy)); key = cost<<12 | (dy+16)<<6 | (dx+16)
+    const int R = ctx->me_range, lambda = ctx->lambda;
+    const int x0 = mxc * 16, y0 = my * 16;
+    const int dx_lo = -R < -x0 ? -x0 : -R, dx_hi = R > W - 16 - x0 ? W - 16 - x0 : R;
+    const int dy_lo = -R < -y0 ? -y0 : -R, dy_hi = R > H - 16 - y0 ? H - 16 - y0 : R;
+    const unsigned INVALID = 0x40000000u;
+    unsigned bo[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        int dx = -16 + 4 * dxg + o;
+        bo[o] = (dx >= dx_lo && dx <= dx_hi && active) ? (((unsigned)(lambda * mv_bits(dx)) << 12) | (unsigned)(dx + 16)) : INVALID;
+    }
+    unsigned best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 0; d < 11; d++) {
+        int dy = -16 + 11 * g + d;
+        unsigned bd = (dy >= dy_lo && dy <= dy_hi) ? (((unsigned)(lambda * mv_bits(dy)) << 12) | ((unsigned)(dy + 16) << 6)) : INVALID;
+        unsigned lo = (unsigned)acc[d], hi = (unsigned)(acc[d] >> 32);
+        unsigned k0 = ((lo << 16) >> 4) + bd + bo[0];
+        unsigned k1 = ((lo & 0xFFFF0000u) >> 4) + bd + bo[1];
+        unsigned k2 = ((hi << 16) >> 4) + bd + bo[2];
+        unsigned k3 = ((hi & 0xFFFF0000u) >> 4) + bd + bo[3];
+        unsigned ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
+        ka = ka < kb ? ka : kb;
+        best = best < ka ? best : ka;
+    }
+    // ---- half-wave (32-lane) minimum
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        unsigned o = (unsigned)__shfl_xor((int)best, s, 32);
+        best = best < o ? best : o;
+    }
+    if (l == 0 && mx < mbw) {
+        mb_info_t *mb = &ctx->mbi[my * mbw + mx];
+        mb->mvx = (int16_t)((int)(best & 63) - 16);
+        mb->mvy = (int16_t)((int)((best >> 6) & 63) - 16);
+        mb->cost = best >> 12;
+    }
+}
+
+// =================================================================== 4x4 transform helpers
+// All operate on int x[16] in raster order (index y*4+x); loops are fully unrolled so the
+// arrays stay in registers.
+DEV void fdct4(int *x) { // Y = Cf X Cf^T
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int a = x[i * 4], b = x[i * 4 + 1], c = x[i * 4 + 2], d = x[i * 4 + 3];
+        int s03 = a + d, d03 = a - d, s12 = b + c, d12 = b - c;
+        x[i * 4] = s03 + s12; x[i * 4 + 1] = 2 * d03 + d12; x[i * 4 + 2] = s03 - s12; x[i * 4 + 3] = d03 - 2 * d12;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int a = x[j], b = x[4 + j], c = x[8 + j], d = x[12 + j];
+        int s03 = a + d, d03 = a - d, s12 = b + c, d12 = b - c;
+        x[j] = s03 + s12; x[4 + j] = 2 * d03 + d12; x[8 + j] = s03 - s12; x[12 + j] = d03 - 2 * d12;
+    }
+}
+DEV void idct4(int *d) { // 8.5.12.2: rows then columns, (x+32)>>6; result = residual
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int e0 = d[i * 4] + d[i * 4 + 2], e1 = d[i * 4] - d[i * 4 + 2];
+        int e2 = (d[i * 4 + 1] >> 1) - d[i * 4 + 3], e3 = d[i * 4 + 1] + (d[i * 4 + 3] >> 1);
+        d[i * 4] = e0 + e3; d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = e1 - e2; d[i * 4 + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int g0 = d[j] + d[8 + j], g1 = d[j] - d[8 + j];
+        int g2 = (d[4 + j] >> 1) - d[12 + j], g3 = d[4 + j] + (d[12 + j] >> 1);
+        d[j] = (g0 + g3 + 32) >> 6; d[4 + j] = (g1 + g2 + 32) >> 6; d[8 + j] = (g1 - g2 + 32) >> 6; d[12 + j] = (g0 - g3 + 32) >> 6;
+    }
+}
+// 8.5.6 zig-zag: scan position -> raster index, packed one nibble per entry
+DEV constexpr int zz(int k) { return (int)((0xFEB7ADC963258410ull >> (4 * k)) & 15); }
+DEV constexpr int pos_class(int p) { // 0: (even,even)  1: (odd,odd)  2: mixed
+    return ((p & 1) == 0 && (p & 4) == 0) ? 0 : (((p & 1) && (p & 4)) ? 1 : 2);
+}
+DEV int quant1(int coef, int mf, int f, int qbits) { // dead-zone quantiser, |level| <= 2047
+    int a = iabs(coef);
+    int l = (a * mf + f) >> qbits;
+    l = l > 2047 ? 2047 : l;
+    return coef < 0 ? -l : l;
+}
+struct qparams { int mf[3], v[3], qbits, f, shift; };
+DEV qparams make_q(int qp, bool intra) {
+    qparams q;
+    int m = qp % 6;
+    q.mf[0] = c_mf[m][0]; q.mf[1] = c_mf[m][1]; q.mf[2] = c_mf[m][2];
+    q.v[0] = c_v[m][0]; q.v[1] = c_v[m][1]; q.v[2] = c_v[m][2];
+    q.qbits = 15 + qp / 6;
+    q.f = (1 << q.qbits) / (intra ? 3 : 6);
+    q.shift = qp / 6;
+    return q;
+}
+// coef[] (raster, after fdct4) -> lev[] (zig-zag order) and coef[] := dequantised (raster).
+// Scan positions below `first` are forced to zero.  Returns true if any level != 0.
+template <int FIRST>
+DEV bool quant_dequant(int *coef, int *lev, const qparams &q) {
+    bool nz = false;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int p = zz(k), cl = pos_class(p);
+        int l = k < FIRST ? 0 : quant1(coef[p], q.mf[cl], q.f, q.qbits);
+        lev[k] = l;
+        nz |= l != 0;
+        coef[p] = (l * q.v[cl]) << q.shift;
+    }
+    return nz;
+}
+DEV void store_levels(int16_t *dst, const int *lev) { // 16 int16 = two 16-byte stores
+    uint4 a, b;
+    a.x = (lev[0] & 0xFFFF) | (lev[1] << 16); a.y = (lev[2] & 0xFFFF) | (lev[3] << 16);
+    a.z = (lev[4] & 0xFFFF) | (lev[5] << 16); a.w = (lev[6] & 0xFFFF) | (lev[7] << 16);
+    b.x = (lev[8] & 0xFFFF) | (lev[9] << 16); b.y = (lev[10] & 0xFFFF) | (lev[11] << 16);
+    b.z = (lev[12] & 0xFFFF) | (lev[13] << 16); b.w = (lev[14] & 0xFFFF) | (lev[15] << 16);
+    ((uint4 *)dst)[0] = a; ((uint4 *)dst)[1] = b;
+}
+DEV unsigned pack4(int a, int b, int c, int d) { return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24); }
+DEV int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 255); }
+
+// Chroma of one macroblock, run by 8 consecutive lanes (cl = 0..7: plane c = cl>>2, block b = cl&3).
+// pred[16]: prediction of this lane's 4x4 block.  Handles the 2x2 DC Hadamard across the four
+// lanes of a plane with shuffles (8.5.11), writes levels + reconstruction, returns the AC flag
+// in bit 0 and the plane's DC flag in bit 1.
+DEV int chroma_block(const frame_ctx_t *ctx, int mbn, int cx0, int cy0, int cl, const int *pred, int qp, bool intra) {
+    const int c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
+    const int qpc = c_qpc[qp];
+    const qparams q = make_q(qpc, intra);
+    int x[16], lev[16];
+    {
+        const uint8_t *__restrict__ s = ctx->src_uv;
+        const int ss = ctx->src_stride, vh2 = ctx->vis_h >> 1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int sy = cy0 + by + r;
+            sy = sy < vh2 ? sy : vh2 - 1;
+            uint2 w = *(const uint2 *)(s + (size_t)sy * ss + 2 * (cx0 + bx));
+            unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
+            x[r * 4 + 0] = (int)(lo & 255) - pred[r * 4 + 0];
+            x[r * 4 + 1] = (int)((lo >> 16) & 255) - pred[r * 4 + 1];
+            x[r * 4 + 2] = (int)(hi & 255) - pred[r * 4 + 2];
+            x[r * 4 + 3] = (int)((hi >> 16) & 255) - pred[r * 4 + 3];
+        }
+    }
+    fdct4(x);
+    const int dc = x[0];
+    bool nz_ac = quant_dequant<1>(x, lev, q);
+    // forward 2x2 Hadamard over the plane's four lanes; lane b keeps element b
+    int d1 = __shfl_xor(dc, 1, 4), d2 = __shfl_xor(dc, 2, 4), d3 = __shfl_xor(dc, 3, 4);
+    // with e0..e3 the values of blocks 0..3: this lane holds e_b = dc, e_{b^1} = d1, e_{b^2} = d2, e_{b^3} = d3
+    int fb;
+    {
+        int e[4]; // e_k = DC of block k (this lane holds e_b; partners arrive by shuffle)
+        e[b] = dc; e[b ^ 1] = d1; e[b ^ 2] = d2; e[b ^ 3] = d3;
+        int f0 = e[0] + e[1] + e[2] + e[3], f1 = e[0] - e[1] + e[2] - e[3];
+        int f2 = e[0] + e[1] - e[2] - e[3], f3 = e[0] - e[1] - e[2] + e[3];
+        fb = b == 0 ? f0 : b == 1 ? f1 : b == 2 ? f2 : f3;
+    }
+    const int ldc = quant1(fb, q.mf[0], 2 * q.f, q.qbits + 1);
+    // inverse: g = H l H over the four DC levels, dcC = ((g*LevelScale(0,0)) << (qP/6)) >> 5
+    int l1 = __shfl_xor(ldc, 1, 4), l2 = __shfl_xor(ldc, 2, 4), l3 = __shfl_xor(ldc, 3, 4);
+    int gl[4];
+    gl[b] = ldc; gl[b ^ 1] = l1; gl[b ^ 2] = l2; gl[b ^ 3] = l3;
+    int g0 = gl[0] + gl[1] + gl[2] + gl[3], g1 = gl[0] - gl[1] + gl[2] - gl[3];
+    int g2 = gl[0] + gl[1] - gl[2] - gl[3], g3 = gl[0] - gl[1] - gl[2] + gl[3];
+    int gb = b == 0 ? g0 : b == 1 ? g1 : b == 2 ? g2 : g3;
+    x[0] = ((gb * 16 * q.v[0]) << q.shift) >> 5;
+    const bool nz_dc = (gl[0] | gl[1] | gl[2] | gl[3]) != 0;
+    idct4(x);
+    // levels
+    int16_t *lv = ctx->levels + (size_t)mbn * MB_LEVELS;
+    store_levels(lv + L_CAC + (4 * c + b) * 16, lev);
+    lv[L_CDC + 4 * c + b] = (int16_t)ldc;
+    // reconstruction: this lane owns every other byte of 8-byte row segments
+    uint8_t *__restrict__ rec = ctx->rec_uv;
+    const int st = ctx->stride;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint8_t *p = rec + (size_t)(cy0 + by + r) * st + 2 * (cx0 + bx) + c;
+#pragma unroll
+        for (int i = 0; i < 4; i++) p[2 * i] = (uint8_t)clip255(pred[r * 4 + i] + x[r * 4 + i]);
+    }
+    return (nz_ac ? 1 : 0) | (nz_dc ? 2 : 0);
+}
+
+// =================================================================== inter (P) macroblocks
+// One wave = two macroblocks.  Lanes 0-31: one 4x4 luma block each (MB = lane>>4);
+// lanes 32-47: one 4x4 chroma block each (MB = (lane-32)>>3); lanes 48-63 idle.
+__global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restrict__ ctx) {
+    const int mbw = ctx->mbw, nmb = mbw * ctx->mbh, stride = ctx->stride, qp = ctx->qp;
+    const int W = mbw * 16, H = ctx->mbh * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    const bool is_luma = lane < 32, is_chroma = lane >= 32 && lane < 48;
+    const int sel = is_luma ? lane >> 4 : (is_chroma ? (lane - 32) >> 3 : 0);
+    int mbn = pair * 2 + sel;
+    const bool mb_ok = mbn < nmb;
+    if (!mb_ok) mbn = nmb - 1;
+    const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
+    const mb_info_t info = ctx->mbi[mbn];
+    const int mvx = clip3(-x0, W - 16 - x0, info.mvx), mvy = clip3(-y0, H - 16 - y0, info.mvy);
+    int flags = 0; // bit0: AC/any nonzero, bit1: chroma DC nonzero
+    if (is_luma && mb_ok) {
+        const int b = lane & 15, bx = blkx(b), by = blky(b);
+        const qparams q = make_q(qp, false);
+        int x[16], pr[16], lev[16];
+        const uint8_t *__restrict__ s = ctx->src_y;
+        const uint8_t *__restrict__ rf = ctx->ref_y;
+        const int ss = ctx->src_stride, vh = ctx->vis_h;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int sy = y0 + by + r;
+            sy = sy < vh ? sy : vh - 1;
+            unsigned sw = *(const unsigned *)(s + (size_t)sy * ss + x0 + bx);
+            size_t a = (size_t)(y0 + by + r + mvy) * stride + (x0 + bx + mvx);
+            const unsigned *ap = (const unsigned *)(rf + (a & ~(size_t)3));
+            unsigned pw = __builtin_amdgcn_alignbyte(ap[1], ap[0], (unsigned)(a & 3));
+#pragma unroll
+            for (int i = 0; i < 4; i++) { pr[r * 4 + i] = byte_of(pw, i); x[r * 4 + i] = byte_of(sw, i) - pr[r * 4 + i]; }
+        }
+        fdct4(x);
+        bool nz = quant_dequant<0>(x, lev, q);
+        store_levels(ctx->levels + (size_t)mbn * MB_LEVELS + L_LUMA + b * 16, lev);
+        idct4(x);
+        uint8_t *__restrict__ rec = ctx->rec_y;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            *(unsigned *)(rec + (size_t)(y0 + by + r) * stride + x0 + bx) =
+                pack4(clip255(pr[r * 4] + x[r * 4]), clip255(pr[r * 4 + 1] + x[r * 4 + 1]),
+                      clip255(pr[r * 4 + 2] + x[r * 4 + 2]), clip255(pr[r * 4 + 3] + x[r * 4 + 3]));
+        flags = nz ? 1 : 0;
+    }
+    if (is_chroma) { // all 16 lanes run (shuffles inside); stores are predicated by mb_ok via mbn clamp
+        const int cl = (lane - 32) & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
+        const int cx0 = x0 >> 1, cy0 = y0 >> 1, cw = W >> 1, ch = H >> 1;
+        // 8.4.2.2.2: chroma vector = luma vector in 1/8 sample units -> fraction 0 or 4
+        const int xi = mvx >> 1, yi = mvy >> 1, xf = (mvx & 1) * 4, yf = (mvy & 1) * 4;
+        const uint8_t *__restrict__ rf = ctx->ref_uv;
+        int smp[5][5];
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            int yy = clip3(0, ch - 1, cy0 + by + r + yi);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                int xx = clip3(0, cw - 1, cx0 + bx + i + xi);
+                smp[r][i] = rf[(size_t)yy * stride + 2 * xx + c];
+            }
+        }
+        int pr[16];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                pr[r * 4 + i] = ((8 - xf) * (8 - yf) * smp[r][i] + xf * (8 - yf) * smp[r][i + 1] +
+                                 (8 - xf) * yf * smp[r + 1][i] + xf * yf * smp[r + 1][i + 1] + 32) >> 6;
+        if (mb_ok) flags = chroma_block(ctx, mbn, cx0, cy0, cl, pr, qp, false);
+        else { // keep the shuffles of partner lanes well-defined
+            (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
+            (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
+        }
+    }
+    const unsigned long long any = __ballot(flags & 1), dcm = __ballot(flags & 2);
+    if ((lane == 0 || lane == 16) && mb_ok) {
+        const int s2 = lane >> 4;
+        unsigned nzm = (unsigned)((any >> (16 * s2)) & 0xFFFF) | ((unsigned)((any >> (32 + 8 * s2)) & 0xFF) << 16);
+        if ((dcm >> (32 + 8 * s2)) & 0x0F) nzm |= NZ_CBDC;
+        if ((dcm >> (32 + 8 * s2)) & 0xF0) nzm |= NZ_CRDC;
+        mb_info_t *mb = &ctx->mbi[mbn];
+        mb->mb_type = 1; mb->i16_mode = 0; mb->chroma_mode = 0; mb->qp = (uint8_t)qp; mb->nzmask = nzm;
+    }
+    // luma DC levels are unused by P macroblocks but part of the record: keep them zero
+    if (is_luma && mb_ok && (lane & 15) < 2) {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        ((uint4 *)(ctx->levels + (size_t)mbn * MB_LEVELS + L_LDC))[lane & 15] = z;
+    }
+}
+
+// =================================================================== intra (I) macroblocks
+// One wave per macroblock, launched once per anti-diagonal x + y = diag (left, top and
+// top-left neighbours are then complete).  Lanes 0-15: luma 4x4 blocks; lanes 16-23: chroma.
+DEV int wave16_sum(int v) {
+#pragma unroll
+    for (int s = 8; s >= 1; s >>= 1) v += __shfl_xor(v, s, 16);
+    return v;
+}
+__global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
+    __shared__ int sh_top[2][3][17], sh_left[2][3][17]; // [unused][plane 0=Y,1=Cb,2=Cr][-1..15]
+    __shared__ int sh_dc[16], sh_ldc[16];
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, qp = ctx->qp;
+    const int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
+    const int my = y_lo + blockIdx.x, mx = diag - my;
+    const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
+    const bool has_top = my > 0, has_left = mx > 0;
+    const int lane = threadIdx.x;
+    uint8_t *__restrict__ ry = ctx->rec_y;
+    uint8_t *__restrict__ ruv = ctx->rec_uv;
+    // ---- neighbours into LDS: index i+1 holds sample i, index 0 holds the corner (-1)
+    int (*top)[17] = sh_top[0];
+    int (*left)[17] = sh_left[0];
+    if (lane < 17) {
+        int i = lane - 1;
+        top[0][lane] = has_top && (i >= 0 || has_left) ? ry[(size_t)(y0 - 1) * stride + x0 + i] : 0;
+        left[0][lane] = has_left && (i >= 0 || has_top) ? ry[(size_t)(y0 + i) * stride + x0 - 1] : 0;
+    } else if (lane >= 32 && lane < 32 + 18) {
+        int c = (lane - 32) / 9, i = (lane - 32) % 9 - 1;
+        top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? ruv[(size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c] : 0;
+        left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? ruv[(size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c] : 0;
+    }
+    __syncthreads();
+#define TOP(p, i) top[p][(i) + 1]
+#define LEFT(p, i) left[p][(i) + 1]
+    const bool is_luma = lane < 16, is_chroma = lane >= 16 && lane < 24;
+    const unsigned BIG = 0x10000000u;
+    int pred[16];
+    int flags = 0, mode = 0;
+    unsigned sad_sel = 0;
+    if (is_luma) {
+        const int b = lane, bx = blkx(b), by = blky(b);
+        // source block
+        int src[16];
+        {
+            const uint8_t *__restrict__ s = ctx->src_y;
+            const int ss = ctx->src_stride, vh = ctx->vis_h;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int sy = y0 + by + r;
+                sy = sy < vh ? sy : vh - 1;
+                unsigned sw = *(const unsigned *)(s + (size_t)sy * ss + x0 + bx);
+#pragma unroll
+                for (int i = 0; i < 4; i++) src[r * 4 + i] = byte_of(sw, i);
+            }
+        }
+        // DC value and plane parameters (8.3.3.3, 8.3.3.4) -- every lane computes the same numbers
+        int st = 0, sl = 0, Hh = 0, Vv = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { st += TOP(0, i); sl += LEFT(0, i); }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            Hh += (i + 1) * (TOP(0, 8 + i) - TOP(0, 6 - i));
+            Vv += (i + 1) * (LEFT(0, 8 + i) - LEFT(0, 6 - i));
+        }
+        const int dcv = (has_top && has_left) ? (st + sl + 16) >> 5 : has_top ? (st + 8) >> 4 : has_left ? (sl + 8) >> 4 : 128;
+        const int pa = 16 * (LEFT(0, 15) + TOP(0, 15)), pb = (5 * Hh + 32) >> 6, pc = (5 * Vv + 32) >> 6;
+        unsigned sad[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int sv = src[r * 4 + i];
+                sad[0] += iabs(sv - TOP(0, bx + i));
+                sad[1] += iabs(sv - LEFT(0, by + r));
+                sad[2] += iabs(sv - dcv);
+                sad[3] += iabs(sv - clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5));
+            }
+        unsigned tot[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) tot[k] = (unsigned)wave16_sum((int)sad[k]);
+        if (!has_top) tot[0] = BIG;
+        if (!has_left) tot[1] = BIG;
+        if (!(has_top && has_left)) tot[3] = BIG;
+        unsigned best = tot[0]; mode = 0;
+        if (tot[1] < best) { best = tot[1]; mode = 1; }
+        if (tot[2] < best) { best = tot[2]; mode = 2; }
+        if (tot[3] < best) { best = tot[3]; mode = 3; }
+        sad_sel = best;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                pred[r * 4 + i] = mode == 0 ? TOP(0, bx + i) : mode == 1 ? LEFT(0, by + r) : mode == 2 ? dcv
+                                  : clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5);
+        // ---- residual, core transform, DC through the 4x4 Hadamard
+        const qparams q = make_q(qp, true);
+        int x[16], lev[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = src[k] - pred[k];
+        fdct4(x);
+        sh_dc[(by >> 2) * 4 + (bx >> 2)] = x[0];
+        bool nz = quant_dequant<1>(x, lev, q);
+        store_levels(ctx->levels + (size_t)mbn * MB_LEVELS + L_LUMA + b * 16, lev);
+        flags = nz ? 1 : 0;
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the 16 DC writes have landed (same wave)
+        __builtin_amdgcn_wave_barrier();
+        // lane p = raster position (i,j): hd = (M X M^T + 1) >> 1, M = [[1,1,1,1],[1,1,-1,-1],[1,-1,-1,1],[1,-1,1,-1]]
+        const int pi = lane >> 2, pj = lane & 3;
+        const int Mi[4] = {1, pi < 2 ? 1 : -1, (pi == 0 || pi == 3) ? 1 : -1, (pi & 1) ? -1 : 1};
+        const int Mj[4] = {1, pj < 2 ? 1 : -1, (pj == 0 || pj == 3) ? 1 : -1, (pj & 1) ? -1 : 1};
+        int acc = 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; c2++) acc += Mi[a] * Mj[c2] * sh_dc[a * 4 + c2];
+        const int hd = (acc + 1) >> 1;
+        const int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
+        sh_ldc[lane] = ldc;
+        // zig-zag position of raster index `lane` (inverse of zz)
+        int kz = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (zz(k) == lane) kz = k;
+        ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + kz] = (int16_t)ldc;
+        if (ldc) flags |= 2;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        // inverse for this lane's own block position (by/4, bx/4): f = M c M^T, then 8.5.10 scaling
+        {
+            const int bi = by >> 2, bj = bx >> 2;
+            const int Ni[4] = {1, bi < 2 ? 1 : -1, (bi == 0 || bi == 3) ? 1 : -1, (bi & 1) ? -1 : 1};
+            const int Nj[4] = {1, bj < 2 ? 1 : -1, (bj == 0 || bj == 3) ? 1 : -1, (bj & 1) ? -1 : 1};
+            int f = 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) f += Ni[a] * Nj[c2] * sh_ldc[a * 4 + c2];
+            const int ls = 16 * q.v[0];
+            x[0] = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+        }
+        idct4(x);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            *(unsigned *)(ry + (size_t)(y0 + by + r) * stride + x0 + bx) =
+                pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
+                      clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3]));
+    } else if (lane < 32) { // lanes 16-31 form one shuffle group; 16-23 do chroma, 24-31 pad with zeros
+        const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
+        const int p = 1 + c;
+        int src[16];
+        {
+            const uint8_t *__restrict__ s = ctx->src_uv;
+            const int ss = ctx->src_stride, vh2 = ctx->vis_h >> 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int sy = cy0 + by + r;
+                sy = sy < vh2 ? sy : vh2 - 1;
+                uint2 w = *(const uint2 *)(s + (size_t)sy * ss + 2 * (cx0 + bx));
+                unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
+                src[r * 4 + 0] = (int)(lo & 255); src[r * 4 + 1] = (int)((lo >> 16) & 255);
+                src[r * 4 + 2] = (int)(hi & 255); src[r * 4 + 3] = (int)((hi >> 16) & 255);
+            }
+        }
+        // DC of this 4x4 block (8.3.4.1-3)
+        int st = 0, sl = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { st += TOP(p, bx + i); sl += LEFT(p, by + i); }
+        int dcv;
+        {
+            bool ut = has_top, ul = has_left;
+            if (b == 1 && has_top) ul = false;
+            if (b == 2 && has_left) ut = false;
+            dcv = (ut && ul) ? (st + sl + 4) >> 3 : ut ? (st + 2) >> 2 : ul ? (sl + 2) >> 2 : 128;
+        }
+        int Hh = 0, Vv = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            Hh += (i + 1) * (TOP(p, 4 + i) - TOP(p, 2 - i));
+            Vv += (i + 1) * (LEFT(p, 4 + i) - LEFT(p, 2 - i));
+        }
+        const int pa = 16 * (LEFT(p, 7) + TOP(p, 7)), pb = (34 * Hh + 32) >> 6, pc = (34 * Vv + 32) >> 6;
+        unsigned sad[4] = {0, 0, 0, 0};
+        if (is_chroma) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    int sv = src[r * 4 + i];
+                    sad[0] += iabs(sv - dcv);
+                    sad[1] += iabs(sv - LEFT(p, by + r));
+                    sad[2] += iabs(sv - TOP(p, bx + i));
+                    sad[3] += iabs(sv - clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5));
+                }
+        }
+        unsigned tot[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) tot[k] = (unsigned)wave16_sum((int)sad[k]);
+        if (!has_left) tot[1] = BIG;
+        if (!has_top) tot[2] = BIG;
+        if (!(has_top && has_left)) tot[3] = BIG;
+        unsigned best = tot[0]; mode = 0;
+        if (tot[1] < best) { best = tot[1]; mode = 1; }
+        if (tot[2] < best) { best = tot[2]; mode = 2; }
+        if (tot[3] < best) { best = tot[3]; mode = 3; }
+        sad_sel = best;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                pred[r * 4 + i] = mode == 0 ? dcv : mode == 1 ? LEFT(p, by + r) : mode == 2 ? TOP(p, bx + i)
+                                  : clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5);
+        if (is_chroma) flags = chroma_block(ctx, mbn, cx0, cy0, cl, pred, qp, true);
+        else {
+            (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
+            (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
+        }
+    }
+#undef TOP
+#undef LEFT
+    const unsigned long long any = __ballot(flags & 1), dcm = __ballot(flags & 2);
+    const int cmode = __shfl(mode, 16), csad = __shfl((int)sad_sel, 16);
+    if (lane == 0) {
+        unsigned nzm = (unsigned)(any & 0xFFFF) | ((unsigned)((any >> 16) & 0xFF) << 16);
+        if (dcm & 0xFFFF) nzm |= NZ_LDC;
+        if ((dcm >> 16) & 0x0F) nzm |= NZ_CBDC;
+        if ((dcm >> 16) & 0xF0) nzm |= NZ_CRDC;
+        mb_info_t mb;
+        mb.mvx = 0; mb.mvy = 0; mb.mb_type = 0; mb.i16_mode = (uint8_t)mode; mb.chroma_mode = (uint8_t)cmode;
+        mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = sad_sel + (unsigned)csad;
+        ctx->mbi[mbn] = mb;
+    }
+}
+
+// =================================================================== deblocking (8.7)
+DEV void filter_line(uint8_t *pix, int step, int bS, int qp_p, int qp_q, bool chroma) {
+    if (bS == 0) return;
+    const int idx = clip3(0, 51, (qp_p + qp_q + 1) >> 1);
+    const int alpha = c_alpha[idx], beta = c_beta[idx];
+    const int p0 = pix[-step], p1 = pix[-2 * step], q0 = pix[0], q1 = pix[step];
+    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    if (chroma) {
+        if (bS < 4) {
+            const int tc = c_tc0[idx][bS - 1] + 1;
+            const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+            pix[-step] = (uint8_t)clip255(p0 + dl); pix[0] = (uint8_t)clip255(q0 - dl);
+        } else {
+            pix[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2); pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+        }
+        return;
+    }
+    const int p2 = pix[-3 * step], q2 = pix[2 * step];
+    const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
+    if (bS < 4) {
+        const int tc0 = c_tc0[idx][bS - 1];
+        const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+        const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        pix[-step] = (uint8_t)clip255(p0 + dl); pix[0] = (uint8_t)clip255(q0 - dl);
+        const int avg = (p0 + q0 + 1) >> 1;
+        if (ap) pix[-2 * step] = (uint8_t)(p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1));
+        if (aq) pix[step] = (uint8_t)(q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1));
+    } else {
+        const int p3 = pix[-4 * step], q3 = pix[3 * step];
+        const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        if (ap && small) {
+            pix[-step] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+            pix[-2 * step] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
+            pix[-3 * step] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+        } else pix[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+        if (aq && small) {
+            pix[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+            pix[step] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
+            pix[2 * step] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+        } else pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+    }
+}
+DEV int has_coef(const mb_info_t &m, int bx4, int by4) { // (bx4,by4) raster 4x4 position -> blkIdx bit
+    const int b = ((by4 >> 1) << 3) | ((bx4 >> 1) << 2) | ((by4 & 1) << 1) | (bx4 & 1);
+    return (m.nzmask >> b) & 1;
+}
+DEV int bs_of(const mb_info_t &mp, int bxp, int byp, const mb_info_t &mq, int bxq, int byq, bool mb_edge) {
+    if (mp.mb_type == 0 || mq.mb_type == 0) return mb_edge ? 4 : 3;
+    if (has_coef(mp, bxp, byp) || has_coef(mq, bxq, byq)) return 2;
+    if (iabs(mp.mvx - mq.mvx) >= 1 || iabs(mp.mvy - mq.mvy) >= 1) return 1; // >= 4 quarter samples
+    return 0;
+}
+// One wave per macroblock, launched once per wavefront x + 2y = diag: then the left, top and
+// top-right macroblocks (everything the raster-order process of 8.7 has touched before this
+// macroblock that overlaps its support) are complete, and same-diagonal tiles are disjoint.
+#define TLS 24 /* LDS tile row stride in bytes */
+__global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
+    __shared__ __attribute__((aligned(16))) uint8_t tl[20 * TLS]; // luma rows y0-4..y0+15, cols x0-4..x0+15
+    __shared__ __attribute__((aligned(16))) uint8_t tc[10 * TLS]; // chroma rows cy0-2..cy0+7, bytes 2*(cx0-2)..2*(cx0+8)
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
+    int y_lo = diag - (mbw - 1);
+    y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    const int my = y_lo + blockIdx.x, mx = diag - 2 * my;
+    if (my >= mbh || mx < 0 || mx >= mbw) return;
+    const int x0 = mx * 16, y0 = my * 16, cy0 = y0 >> 1;
+    const int lane = threadIdx.x;
+    uint8_t *__restrict__ ry = ctx->rec_y;
+    uint8_t *__restrict__ ruv = ctx->rec_uv;
+    const mb_info_t cur = ctx->mbi[my * mbw + mx];
+    const mb_info_t lft = ctx->mbi[my * mbw + (mx > 0 ? mx - 1 : mx)];
+    const mb_info_t upp = ctx->mbi[(my > 0 ? my - 1 : my) * mbw + mx];
+    // ---- load tiles (skipping the corner, which this macroblock neither reads nor writes)
+    for (int i = lane; i < 100; i += 64) {
+        int r = i / 5, q = i - r * 5;
+        int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
+        if (gy >= 0 && gx >= 0 && !(r < 4 && q == 0))
+            *(unsigned *)&tl[r * TLS + 4 * q] = *(const unsigned *)(ry + (size_t)gy * stride + gx);
+    }
+    if (lane < 50) {
+        int r = lane / 5, q = lane - r * 5;
+        int gy = cy0 - 2 + r, gb = x0 - 4 + 4 * q; // chroma byte offset 2*cx0 = x0
+        if (gy >= 0 && gb >= 0 && !(r < 2 && q == 0))
+            *(unsigned *)&tc[r * TLS + 4 * q] = *(const unsigned *)(ruv + (size_t)gy * stride + gb);
+    }
+    __syncthreads();
+    const int qpc_c = c_qpc[cur.qp], qpc_l = c_qpc[lft.qp], qpc_u = c_qpc[upp.qp];
+    // ---- vertical edges, left to right
+    if (lane < 16) {
+        const int k = lane;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (e == 0 && mx == 0) continue;
+            const mb_info_t &mp = e == 0 ? lft : cur;
+            int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 2, cur, e, k >> 2, e == 0);
+            filter_line(&tl[(4 + k) * TLS + 4 + 4 * e], 1, bS, mp.qp, cur.qp, false);
+        }
+    } else if (lane < 24) {
+        const int k = lane - 16;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            if (e == 0 && mx == 0) continue;
+            const mb_info_t &mp = e == 0 ? lft : cur;
+            int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 1, cur, e, k >> 1, e == 0);
+#pragma unroll
+            for (int c = 0; c < 2; c++) filter_line(&tc[(2 + k) * TLS + 4 + 4 * e + c], 2, bS, e == 0 ? qpc_l : qpc_c, qpc_c, true);
+        }
+    }
+    __syncthreads();
+    // ---- horizontal edges, top to bottom
+    if (lane < 16) {
+        const int k = lane;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (e == 0 && my == 0) continue;
+            const mb_info_t &mp = e == 0 ? upp : cur;
+            int bS = bs_of(mp, k >> 2, e == 0 ? 3 : e - 1, cur, k >> 2, e, e == 0);
+            filter_line(&tl[(4 + 4 * e) * TLS + 4 + k], TLS, bS, mp.qp, cur.qp, false);
+        }
+    } else if (lane < 24) {
+        const int k = lane - 16;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            if (e == 0 && my == 0) continue;
+            const mb_info_t &mp = e == 0 ? upp : cur;
+            int bS = bs_of(mp, k >> 1, e == 0 ? 3 : e - 1, cur, k >> 1, e, e == 0);
+#pragma unroll
+            for (int c = 0; c < 2; c++) filter_line(&tc[(2 + 2 * e) * TLS + 4 + 2 * k + c], TLS, bS, e == 0 ? qpc_u : qpc_c, qpc_c, true);
+        }
+    }
+    __syncthreads();
+    // ---- write back
+    for (int i = lane; i < 100; i += 64) {
+        int r = i / 5, q = i - r * 5;
+        int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
+        if (gy >= 0 && gx >= 0 && !(r < 4 && q == 0))
+            *(unsigned *)(ry + (size_t)gy * stride + gx) = *(const unsigned *)&tl[r * TLS + 4 * q];
+    }
+    if (lane < 50) {
+        int r = lane / 5, q = lane - r * 5;
+        int gy = cy0 - 2 + r, gb = x0 - 4 + 4 * q;
+        if (gy >= 0 && gb >= 0 && !(r < 2 && q == 0))
+            *(unsigned *)(ruv + (size_t)gy * stride + gb) = *(const unsigned *)&tc[r * TLS + 4 * q];
+    }
+}
+
+// =================================================================== staging helper
+// Replicate the last visible column/row into the coded-size margin of a staged source surface.
+__global__ void pad_kernel(uint8_t *y, uint8_t *uv, int stride, int vw, int vh, int W, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nY = W * H;
+    if (i < nY) {
+        int r = i / W, c = i - r * W;
+        if (r >= vh || c >= vw) y[(size_t)r * stride + c] = y[(size_t)(r < vh ? r : vh - 1) * stride + (c < vw ? c : vw - 1)];
+    } else if (i < nY + nY / 2) {
+        int j = i - nY, r = j / W, c = j - r * W;
+        if (r >= vh / 2 || c >= vw) {
+            int sc = c < vw ? c : vw - 2 + (c & 1);
+            uv[(size_t)r * stride + c] = uv[(size_t)(r < vh / 2 ? r : vh / 2 - 1) * stride + sc];
+        }
+    }
+}
+
+// =================================================================== launchers
+int k_intra_diags(int mbw, int mbh) { return mbw + mbh - 1; }
+int k_deblock_diags(int mbw, int mbh) { return mbw + 2 * (mbh - 1); }
+
+void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
+    int strips = (mbw + ME_MBS - 1) / ME_MBS;
+    hipLaunchKernelGGL(me_kernel, dim3(strips * mbh), dim3(256), 0, s, d_ctx);
+}
+void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
+    int pairs = (mbw * mbh + 1) / 2;
+    hipLaunchKernelGGL(inter_kernel, dim3((pairs + 3) / 4), dim3(256), 0, s, d_ctx);
+}
+void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s) {
+    int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
+    int y_hi = diag < mbh - 1 ? diag : mbh - 1;
+    if (y_hi < y_lo) return;
+    hipLaunchKernelGGL(intra_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
+}
+void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s) {
+    int y_lo = diag - (mbw - 1);
+    y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    int y_hi = diag / 2 < mbh - 1 ? diag / 2 : mbh - 1;
+    if (y_hi < y_lo) return;
+    hipLaunchKernelGGL(deblock_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
+}
+void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s) {
+    int n = W * H + W * H / 2;
+    hipLaunchKernelGGL(pad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, uv, stride, vis_w, vis_h, W, H);
+}

@@ -1,0 +1,218 @@
+"""ctypes mirror of include/mi355enc.h -- plumbing only: every call below is one C-ABI call.
+
+The library is the product; there is no Python or CPU fallback.  If libmi355enc.so is
+missing or no HIP device is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355enc.so")
+
+LEVELS_PER_MB = 408
+MBINFO_DTYPE = np.dtype(
+    [("mvx", "<i2"), ("mvy", "<i2"), ("mb_type", "u1"), ("i16_mode", "u1"), ("chroma_mode", "u1"),
+     ("qp", "u1"), ("nzmask", "<u4"), ("cost", "<u4")]
+)
+
+FETCH_RECON_Y, FETCH_RECON_UV, FETCH_PREFILTER_Y, FETCH_PREFILTER_UV, FETCH_MBINFO, FETCH_LEVELS = range(6)
+STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK = range(4)
+
+EXPORTS = [
+    "mi355enc_abi_version", "mi355enc_strerror", "mi355enc_default_cfg", "mi355enc_open", "mi355enc_close",
+    "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_encode", "mi355enc_submit",
+    "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
+    "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
+    "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_deblock", "mi355enc_time_stage",
+]
+
+
+class Cfg(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
+                ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
+                ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("idr_frames", C.c_uint64), ("bytes", C.c_uint64), ("last_qp", C.c_uint32),
+                ("last_bytes", C.c_uint32), ("target_bps", C.c_uint32), ("ms_me", C.c_double), ("ms_inter", C.c_double),
+                ("ms_intra", C.c_double), ("ms_deblock", C.c_double), ("ms_total_gpu", C.c_double), ("n_me", C.c_uint64),
+                ("n_inter", C.c_uint64), ("n_intra", C.c_uint64), ("n_deblock", C.c_uint64), ("ms_entropy", C.c_double),
+                ("ms_wait", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libmi355enc.so not built (run `python -c 'import __graft_entry__ as g; g.build()'`)")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.mi355enc_strerror.restype = C.c_char_p
+        L.mi355enc_strerror.argtypes = [C.c_int]
+        L.mi355enc_default_cfg.restype = None
+        L.mi355enc_default_cfg.argtypes = [C.POINTER(Cfg), C.c_int, C.c_int, C.c_int, C.c_int]
+        L.mi355enc_open.argtypes = [C.POINTER(Cfg), C.POINTER(vp)]
+        L.mi355enc_close.restype = None
+        L.mi355enc_close.argtypes = [vp]
+        L.mi355enc_set_bitrate.argtypes = [vp, C.c_uint32]
+        L.mi355enc_get_bitrate.restype = C.c_uint32
+        L.mi355enc_get_bitrate.argtypes = [vp]
+        L.mi355enc_set_fixed_qp.argtypes = [vp, C.c_int]
+        L.mi355enc_encode.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int, vp, C.c_size_t,
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.mi355enc_submit.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int]
+        L.mi355enc_submit_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int]
+        L.mi355enc_pending.argtypes = [vp]
+        L.mi355enc_collect.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        L.mi355enc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        L.mi355enc_reset_stats.restype = None
+        L.mi355enc_reset_stats.argtypes = [vp]
+        L.mi355enc_max_au_bytes.restype = C.c_size_t
+        L.mi355enc_max_au_bytes.argtypes = [vp]
+        L.mi355enc_fetch.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        L.mi355enc_mb_width.argtypes = [vp]
+        L.mi355enc_mb_height.argtypes = [vp]
+        L.mi355enc_stage_me.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.mi355enc_stage_inter.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
+        L.mi355enc_time_stage.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+class EncoderError(RuntimeError):
+    pass
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Encoder:
+    """One H.264 stream on one GPU.  Arguments mirror the element's properties
+    (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
+
+    def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1):
+        self.L = load()
+        cfg = Cfg()
+        self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
+        cfg.gop, cfg.bitrate_bps, cfg.device_id, cfg.fixed_qp, cfg.me_range = gop, bitrate_bps, device_id, fixed_qp, me_range
+        cfg.pipeline_depth, cfg.profile_events, cfg.use_graphs, cfg.keep_prefilter = (
+            pipeline_depth, int(profile_events), int(use_graphs), int(keep_prefilter))
+        self.h = C.c_void_p()
+        self._chk(self.L.mi355enc_open(C.byref(cfg), C.byref(self.h)), "open", close_on_fail=True)
+        self.width, self.height = width, height
+        self.mbw, self.mbh = self.L.mi355enc_mb_width(self.h), self.L.mi355enc_mb_height(self.h)
+        self._out = np.empty(self.L.mi355enc_max_au_bytes(self.h), np.uint8)
+
+    def _chk(self, r, what, close_on_fail=False):
+        if r != 0:
+            msg = self.L.mi355enc_strerror(r).decode()
+            if close_on_fail and self.h:
+                self.L.mi355enc_close(self.h)
+                self.h = None
+            raise EncoderError("mi355enc_%s: %s (%d)" % (what, msg, r))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi355enc_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_bitrate(self, bps):
+        self._chk(self.L.mi355enc_set_bitrate(self.h, int(bps)), "set_bitrate")
+
+    def set_fixed_qp(self, qp):
+        self._chk(self.L.mi355enc_set_fixed_qp(self.h, int(qp)), "set_fixed_qp")
+
+    def encode(self, y, uv, pts=0, force_idr=False):
+        y = np.ascontiguousarray(y, np.uint8)
+        uv = np.ascontiguousarray(uv, np.uint8)
+        n, key = C.c_size_t(0), C.c_int(0)
+        self._chk(self.L.mi355enc_encode(self.h, _p(y), y.strides[0], _p(uv), uv.strides[0], pts, int(force_idr),
+                                         _p(self._out), self._out.size, C.byref(n), C.byref(key)), "encode")
+        return bytes(self._out[: n.value]), bool(key.value)
+
+    def submit(self, y, uv, pts=0, force_idr=False):
+        y = np.ascontiguousarray(y, np.uint8)
+        uv = np.ascontiguousarray(uv, np.uint8)
+        self._chk(self.L.mi355enc_submit(self.h, _p(y), y.strides[0], _p(uv), uv.strides[0], pts, int(force_idr)), "submit")
+
+    def submit_device(self, y_ptr, y_stride, uv_ptr, uv_stride, pts=0, force_idr=False):
+        self._chk(self.L.mi355enc_submit_device(self.h, y_ptr, y_stride, uv_ptr, uv_stride, pts, int(force_idr)), "submit_device")
+
+    def collect(self, copy=True):
+        n, key, pts, qp = C.c_size_t(0), C.c_int(0), C.c_int64(0), C.c_int(0)
+        self._chk(self.L.mi355enc_collect(self.h, _p(self._out), self._out.size, C.byref(n), C.byref(key), C.byref(pts),
+                                          C.byref(qp)), "collect")
+        au = bytes(self._out[: n.value]) if copy else n.value
+        return au, bool(key.value), pts.value, qp.value
+
+    @property
+    def pending(self):
+        return self.L.mi355enc_pending(self.h)
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.mi355enc_get_stats(self.h, C.byref(s)), "get_stats")
+        return s
+
+    def reset_stats(self):
+        self.L.mi355enc_reset_stats(self.h)
+
+    def fetch(self, what):
+        H, W, n = self.mbh * 16, self.mbw * 16, self.mbw * self.mbh
+        if what in (FETCH_RECON_Y, FETCH_PREFILTER_Y):
+            a = np.empty((H, W), np.uint8)
+        elif what in (FETCH_RECON_UV, FETCH_PREFILTER_UV):
+            a = np.empty((H // 2, W), np.uint8)
+        elif what == FETCH_MBINFO:
+            a = np.empty(n, MBINFO_DTYPE)
+        else:
+            a = np.empty((n, LEVELS_PER_MB), np.int16)
+        self._chk(self.L.mi355enc_fetch(self.h, what, _p(a), a.nbytes), "fetch")
+        return a
+
+    # ---- single-stage entry points (coded-size host planes)
+    def stage_me(self, cur_y, ref_y, qp):
+        mbi = np.zeros(self.mbw * self.mbh, MBINFO_DTYPE)
+        self._chk(self.L.mi355enc_stage_me(self.h, _p(np.ascontiguousarray(cur_y)), _p(np.ascontiguousarray(ref_y)), qp, _p(mbi)), "stage_me")
+        return mbi
+
+    def stage_inter(self, src_y, src_uv, ref_y, ref_uv, mbi, qp):
+        mbi = np.ascontiguousarray(mbi).copy()
+        rec_y, rec_uv = np.empty_like(src_y), np.empty_like(src_uv)
+        lev = np.empty((mbi.size, LEVELS_PER_MB), np.int16)
+        self._chk(self.L.mi355enc_stage_inter(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)),
+                                              _p(np.ascontiguousarray(ref_y)), _p(np.ascontiguousarray(ref_uv)), qp, _p(mbi),
+                                              _p(rec_y), _p(rec_uv), _p(lev)), "stage_inter")
+        return rec_y, rec_uv, mbi, lev
+
+    def stage_intra(self, src_y, src_uv, qp):
+        mbi = np.zeros(self.mbw * self.mbh, MBINFO_DTYPE)
+        rec_y, rec_uv = np.empty_like(src_y), np.empty_like(src_uv)
+        lev = np.empty((mbi.size, LEVELS_PER_MB), np.int16)
+        self._chk(self.L.mi355enc_stage_intra(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)), qp,
+                                              _p(mbi), _p(rec_y), _p(rec_uv), _p(lev)), "stage_intra")
+        return rec_y, rec_uv, mbi, lev
+
+    def stage_deblock(self, rec_y, rec_uv, mbi):
+        y, uv = np.ascontiguousarray(rec_y).copy(), np.ascontiguousarray(rec_uv).copy()
+        self._chk(self.L.mi355enc_stage_deblock(self.h, _p(y), _p(uv), _p(np.ascontiguousarray(mbi))), "stage_deblock")
+        return y, uv
+
+    def time_stage(self, stage, iters=20):
+        ms = C.c_double(0)
+        self._chk(self.L.mi355enc_time_stage(self.h, stage, iters, C.byref(ms)), "time_stage")
+        return ms.value

@@ -1,0 +1,133 @@
+/*
+ * include/mi355enc.h -- C ABI of the MI355X-native H.264 encoder (libmi355enc.so).
+ *
+ * This is the drop-in boundary under ceracoder's GStreamer graph.  It replaces what the
+ * reference obtains from the third-party `x264enc` element named in its pipeline text
+ * (/root/reference/pipeline/generic/x264_superfast_camlink:5,
+ *  /root/reference/pipeline/generic/x264_superfast_v4l_mjpeg_720p30:6,
+ *  /root/reference/bindings/typescript/src/pipeline/generic-builder.ts:50-55),
+ * instantiated by gst_parse_launch at /root/reference/src/io/pipeline_loader.c:59.
+ * The reference has no FFI of its own for this path: the binding a maintainer adds is the
+ * GStreamer element in ceracoder_amd/csrc/gstmi355h264enc.c, which
+ * calls exactly these entry points.
+ *
+ * Conventions follow the reference's C modules (int return, 0 = ok, negative = error,
+ * message on stderr; cf. /root/reference/src/gst/encoder_control.h:42-50,
+ * /root/reference/src/net/srt_client.c:40-55): no exceptions, no abort(), plain pointers
+ * and sizes only.  There is NO CPU fallback: without a usable HIP device
+ * mi355enc_open() fails with MI355ENC_ERR_NO_DEVICE.
+ */
+#ifndef MI355ENC_H
+#define MI355ENC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355ENC_ABI_VERSION 1
+
+enum {
+    MI355ENC_OK = 0,
+    MI355ENC_ERR_ARG = -1,        /* bad argument / unsupported geometry            */
+    MI355ENC_ERR_NO_DEVICE = -2,  /* no HIP device, or device-id out of range       */
+    MI355ENC_ERR_HIP = -3,        /* a HIP runtime call failed (text on stderr)     */
+    MI355ENC_ERR_NOMEM = -4,
+    MI355ENC_ERR_OVERFLOW = -5,   /* caller's output buffer too small               */
+    MI355ENC_ERR_STATE = -6,      /* call order violated (e.g. collect with nothing pending) */
+};
+
+typedef struct mi355enc mi355enc_t; /* opaque; owns all device memory, streams, graphs */
+
+typedef struct {
+    int width, height;        /* visible picture, even, 16..8192                          */
+    int fps_num, fps_den;
+    int gop;                  /* IDR period; x264enc `key-int-max` (pipelines pass 60)     */
+    int me_range;             /* full-search radius in integer pels, 1..16                 */
+    uint32_t bitrate_bps;     /* initial target; what encoder_control.c:53 later rewrites  */
+    int device_id;            /* HIP device ordinal (one stream per GPU)        */
+    int fixed_qp;             /* >= 0: constant QP, rate control off (tests, bench); -1: CBR */
+    int qp_min, qp_max;       /* rate-control clamp; 0,0 -> defaults 10..51                */
+    int pipeline_depth;       /* 0: encode() returns this frame's AU; 1: host entropy coding
+                                 of frame n overlaps device work of frame n+1             */
+    int profile_events;       /* 1: bracket every kernel stage with HIP events (stats)    */
+    int use_graphs;           /* 1: replay the per-picture launch sequence as a hipGraph  */
+    int keep_prefilter;       /* 1: keep a copy of the picture before deblocking (tests)  */
+} mi355enc_cfg_t;
+
+typedef struct {
+    uint64_t frames, idr_frames, bytes;
+    uint32_t last_qp, last_bytes, target_bps;
+    /* accumulated device time per stage in ms and launch counts (profile_events=1) */
+    double ms_me, ms_inter, ms_intra, ms_deblock, ms_total_gpu;
+    uint64_t n_me, n_inter, n_intra, n_deblock;
+    double ms_entropy;        /* host CAVLC wall time */
+    double ms_wait;           /* host time blocked on the device */
+} mi355enc_stats_t;
+
+/* Fill cfg with the defaults of the element (gop 60, me_range 16, 2048 kbit/s like x264enc). */
+void mi355enc_default_cfg(mi355enc_cfg_t *cfg, int width, int height, int fps_num, int fps_den);
+
+int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out);
+void mi355enc_close(mi355enc_t *h);
+
+/* Thread-safe against a concurrent encode (atomic store, latched at the next picture);
+ * never touches the GPU.  Mirrors g_object_set(elem, "bps", v) at encoder_control.c:53. */
+int mi355enc_set_bitrate(mi355enc_t *h, uint32_t bps);
+uint32_t mi355enc_get_bitrate(const mi355enc_t *h);
+/* Constant-QP override for the next pictures (tests/bench); -1 returns to rate control. */
+int mi355enc_set_fixed_qp(mi355enc_t *h, int qp);
+
+/* Synchronous: one NV12 picture in host memory -> one Annex-B access unit
+ * (SPS+PPS precede every IDR).  Borrowed input, caller-owned output. */
+int mi355enc_encode(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
+                    int64_t pts, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len,
+                    int *is_keyframe);
+
+/* Split form.  submit() enqueues all device work of a picture and returns; collect()
+ * entropy-codes the oldest submitted picture.  At most pipeline_depth+1 pictures may be
+ * outstanding.  submit_device() takes planes already resident in this GPU's memory
+ * (the bench's timed region; they must stay valid until the matching collect()). */
+int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
+                    int64_t pts, int force_idr);
+int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const void *d_uv,
+                           int uv_stride, int64_t pts, int force_idr);
+int mi355enc_pending(const mi355enc_t *h);
+int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_len, int *is_keyframe,
+                     int64_t *pts, int *qp);
+
+int mi355enc_get_stats(mi355enc_t *h, mi355enc_stats_t *st);
+void mi355enc_reset_stats(mi355enc_t *h);
+size_t mi355enc_max_au_bytes(const mi355enc_t *h);
+const char *mi355enc_strerror(int code);
+int mi355enc_abi_version(void);
+
+/* ---- inspection of the last collected picture (parity tests) ----------------------
+ * Copies device state to host: coded-size planes (stride = 16*mb_width), the 16-byte
+ * per-macroblock records and the 408 int16 levels per macroblock (layout: DESIGN.md). */
+enum { MI355ENC_FETCH_RECON_Y = 0, MI355ENC_FETCH_RECON_UV = 1, MI355ENC_FETCH_PREFILTER_Y = 2,
+       MI355ENC_FETCH_PREFILTER_UV = 3, MI355ENC_FETCH_MBINFO = 4, MI355ENC_FETCH_LEVELS = 5 };
+int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t dst_bytes);
+int mi355enc_mb_width(const mi355enc_t *h);
+int mi355enc_mb_height(const mi355enc_t *h);
+
+/* ---- single-stage entry points (parity tests; same kernels the encoder launches) ----
+ * All planes are host pointers to coded-size (multiple-of-16) surfaces with stride 16*mbw;
+ * mbinfo is mbw*mbh 16-byte records, levels mbw*mbh*408 int16. */
+int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_out);
+int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y,
+                         const uint8_t *ref_uv, int qp, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv,
+                         int16_t *levels);
+int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out,
+                         uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
+int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const void *mbinfo);
+/* Time `iters` back-to-back launches of one stage on the handle's stream with HIP events;
+ * stage: 0 ME, 1 inter, 2 intra (whole wavefront), 3 deblock (whole wavefront).
+ * Uses whatever the handle's surfaces currently hold.  Returns average ms per launch. */
+int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

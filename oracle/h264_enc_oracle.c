@@ -288,7 +288,7 @@ static inline int mv_bits(int v_int) { /* se(v) length of the quarter-pel value 
 /* Encoder choice (the standard does not constrain motion search).  For each macroblock:
  * candidates (dx,dy) in [-range,range]^2 whose 16x16 block lies inside the coded picture;
  * cost = SAD + lambda(qp) * (bits(se(4dx)) + bits(se(4dy)));
- * winner = lowest cost, then lowest |dx|+|dy|, then lowest dy, then lowest dx. */
+ * winner = lowest cost, then lowest dy, then lowest dx (i.e. first in raster scan). */
 void orc_me_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mbw, int mbh,
                   int range, int qp, orc_mbinfo_t *mbi, int threads) {
     const int W = mbw * 16, H = mbh * 16;
@@ -310,13 +310,7 @@ void orc_me_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mb
                     for (int y = 0; y < 16; y++)
                         for (int x = 0; x < 16; x++) sad += (uint32_t)iabs(c[y * stride + x] - r[y * stride + x]);
                     uint32_t cost = sad + (uint32_t)(lambda * (mv_bits(dx) + mv_bits(dy)));
-                    int better = 0;
-                    if (cost < best_cost) better = 1;
-                    else if (cost == best_cost) {
-                        int m = iabs(dx) + iabs(dy), bm = iabs(best_dx) + iabs(best_dy);
-                        if (m < bm) better = 1;
-                        else if (m == bm && (dy < best_dy || (dy == best_dy && dx < best_dx))) better = 1;
-                    }
+                    int better = cost < best_cost; /* scan order dy then dx resolves ties */
                     if (better) { best_cost = cost; best_dx = dx; best_dy = dy; }
                 }
             }

@@ -1,0 +1,165 @@
+"""GPU parity: every HIP kernel and the whole encoder against the CPU oracle, bit-exact.
+All calls go through the C ABI (include/mi355enc.h) via ceracoder_amd.enc."""
+import numpy as np
+import pytest
+
+from tests.util import first_diff, frames, mbinfo_equal
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(64, 48), (176, 144), (320, 180), (1280, 720)]
+
+
+@pytest.fixture(scope="module")
+def E():
+    from ceracoder_amd import enc
+    return enc
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("qp", [20, 34])
+def test_me_kernel_matches_oracle(E, oracle, w, h, qp):
+    f = frames(w, h, 2)
+    cur, ref = f[1][0], f[0][0]
+    e = E.Encoder(cur.shape[1], cur.shape[0], fixed_qp=qp)
+    dev = e.stage_me(cur, ref, qp)
+    orc = oracle.me_frame(cur, ref, 16, qp, threads=8)
+    for fld in ("mvx", "mvy", "cost"):
+        assert np.array_equal(dev[fld], orc[fld]), (fld, first_diff(dev[fld], orc[fld]))
+    e.close()
+
+
+def test_me_kernel_ties_and_flat(E, oracle):
+    """Flat and periodic content: many equal SADs -> the (cost, dy, dx) tie-break decides."""
+    H, W = 96, 160
+    flat = np.full((H, W), 77, np.uint8)
+    x = np.arange(W)[None, :] + np.zeros((H, 1), int)
+    per = ((x % 8) * 20 + 30).astype(np.uint8)
+    e = E.Encoder(W, H, fixed_qp=26)
+    for cur, ref in ((flat, flat), (per, per), (per, np.roll(per, 3, axis=1)), (flat, per)):
+        dev, orc = e.stage_me(cur, ref, 26), oracle.me_frame(cur, ref, 16, 26)
+        assert mbinfo_equal(dev, orc, ("mvx", "mvy", "cost"))
+    e.close()
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("qp", [0, 18, 30, 51])
+def test_inter_kernel_matches_oracle(E, oracle, w, h, qp):
+    f = frames(w, h, 2)
+    (cy, cuv), (ry, ruv) = f[1][:2], f[0][:2]
+    mbi = oracle.me_frame(cy, ry, 16, qp, threads=8)
+    o_y, o_uv, o_mbi, o_lev = oracle.inter_frame(cy, cuv, ry, ruv, mbi, qp)
+    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp)
+    d_y, d_uv, d_mbi, d_lev = e.stage_inter(cy, cuv, ry, ruv, mbi, qp)
+    assert np.array_equal(d_lev, o_lev), first_diff(d_lev, o_lev)
+    assert np.array_equal(d_y, o_y), first_diff(d_y, o_y)
+    assert np.array_equal(d_uv, o_uv), first_diff(d_uv, o_uv)
+    assert mbinfo_equal(d_mbi, o_mbi, ("mvx", "mvy", "mb_type", "qp", "nzmask"))
+    e.close()
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("qp", [0, 12, 28, 40, 51])
+def test_intra_kernel_matches_oracle(E, oracle, w, h, qp):
+    cy, cuv = frames(w, h, 1)[0][:2]
+    o_y, o_uv, o_mbi, o_lev = oracle.intra_frame(cy, cuv, qp)
+    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp)
+    d_y, d_uv, d_mbi, d_lev = e.stage_intra(cy, cuv, qp)
+    assert mbinfo_equal(d_mbi, o_mbi, ("i16_mode", "chroma_mode", "cost")), \
+        [(f, first_diff(d_mbi[f], o_mbi[f])) for f in ("i16_mode", "chroma_mode", "cost")]
+    assert np.array_equal(d_lev, o_lev), first_diff(d_lev, o_lev)
+    assert np.array_equal(d_y, o_y), first_diff(d_y, o_y)
+    assert np.array_equal(d_uv, o_uv), first_diff(d_uv, o_uv)
+    assert mbinfo_equal(d_mbi, o_mbi, ("mb_type", "qp", "nzmask", "mvx", "mvy"))
+    e.close()
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("qp", [16, 30, 44, 51])
+def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp):
+    """Feed the oracle's own pre-filter pictures (one I, one P) and records to the HIP filter."""
+    oe = oracle.Encoder(w, h, gop=60, threads=8)
+    e = E.Encoder((w + 15) // 16 * 16, (h + 15) // 16 * 16, fixed_qp=qp)
+    for _, _, y, uv in frames(w, h, 2):
+        oe.encode(y, uv, qp)
+        d_y, d_uv = e.stage_deblock(oe.prefilter_y, oe.prefilter_uv, oe.mbinfo)
+        assert np.array_equal(d_y, oe.recon_y), first_diff(d_y, oe.recon_y)
+        assert np.array_equal(d_uv, oe.recon_uv), first_diff(d_uv, oe.recon_uv)
+    e.close()
+
+
+@pytest.mark.parametrize("w,h,n", [(64, 48, 9), (176, 144, 7), (322, 182, 5), (1280, 720, 4), (1920, 1080, 3)])
+@pytest.mark.parametrize("graphs", [True, False])
+def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs):
+    """Whole path: identical access units, identical reconstruction, and the independent
+    decoder reproduces both."""
+    qps = [30, 28, 33, 24, 40, 26, 30, 51, 10]
+    e = E.Encoder(w, h, gop=4, fixed_qp=30, use_graphs=graphs, keep_prefilter=True)
+    oe = oracle.Encoder(w, h, gop=4, threads=8)
+    dec = oracle.Decoder()
+    for i, (_, _, y, uv) in enumerate(frames(w, h, n)):
+        qp = qps[i % len(qps)]
+        e.set_fixed_qp(qp)
+        au, key = e.encode(y, uv, pts=i)
+        ref_au, ref_key = oe.encode(y, uv, qp)
+        assert key == ref_key
+        assert np.array_equal(e.fetch(E.FETCH_PREFILTER_Y), oe.prefilter_y), ("prefilter", i)
+        assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y), ("recon", i, first_diff(e.fetch(E.FETCH_RECON_Y), oe.recon_y))
+        assert np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv), ("recon uv", i)
+        assert au == ref_au, ("bitstream", i, len(au), len(ref_au))
+        dy, duv = dec.decode(au)
+        assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv)
+    assert dec.size == (w, h)
+    e.close()
+
+
+def test_pipelined_submit_collect_equals_sync(E, oracle):
+    """pipeline_depth=1 (entropy coding overlapped with the next picture) yields the same stream."""
+    w, h, n = 320, 192, 8
+    fr = frames(w, h, n)
+    a = E.Encoder(w, h, gop=5, fixed_qp=29)
+    b = E.Encoder(w, h, gop=5, fixed_qp=29, pipeline_depth=1)
+    sync = [a.encode(y, uv)[0] for _, _, y, uv in fr]
+    piped = []
+    for i, (_, _, y, uv) in enumerate(fr):
+        b.submit(y, uv, pts=i)
+        if b.pending == 2:
+            piped.append(b.collect())
+    while b.pending:
+        piped.append(b.collect())
+    assert [p[0] for p in piped] == sync
+    assert [p[2] for p in piped] == list(range(n))
+    a.close(); b.close()
+
+
+def test_noise_worst_case_roundtrip(E, oracle):
+    """S3 (i.i.d. noise) at low QP: maximum-size levels, escape codes, every block coded."""
+    w, h = 176, 144
+    e = E.Encoder(w, h, gop=3, fixed_qp=4)
+    oe = oracle.Encoder(w, h, gop=3, threads=8)
+    dec = oracle.Decoder()
+    for i, (_, _, y, uv) in enumerate(frames(w, h, 4, kind="s3")):
+        qp = [4, 0, 8, 2][i]
+        e.set_fixed_qp(qp)
+        au, _ = e.encode(y, uv)
+        assert au == oe.encode(y, uv, qp)[0]
+        dy, duv = dec.decode(au)
+        assert np.array_equal(dy, e.fetch(E.FETCH_RECON_Y)) and np.array_equal(duv, e.fetch(E.FETCH_RECON_UV))
+    e.close()
+
+
+def test_rate_control_tracks_setpoint_within_one_gop(E):
+    """M4: after a step on the bitrate property the mean rate over the next GOP is within 10 %."""
+    w, h, fps, gop = 640, 368, 30, 30
+    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=2_000_000)
+    sizes = []
+    fr = frames(w, h, 4 * gop)
+    for i, (_, _, y, uv) in enumerate(fr):
+        if i == 2 * gop:
+            e.set_bitrate(1_000_000)
+        sizes.append(len(e.encode(y, uv)[0]))
+    rate = lambda a, b: sum(sizes[a:b]) * 8 * fps / (b - a)
+    assert abs(rate(gop, 2 * gop) - 2_000_000) / 2_000_000 < 0.10, rate(gop, 2 * gop)
+    assert abs(rate(2 * gop, 3 * gop) - 1_000_000) / 1_000_000 < 0.10, rate(2 * gop, 3 * gop)
+    assert abs(rate(3 * gop, 4 * gop) - 1_000_000) / 1_000_000 < 0.10, rate(3 * gop, 4 * gop)
+    e.close()

@@ -1,0 +1,35 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from ceracoder_amd import synth
+
+
+def pad_planes(y, uv):
+    """Replicate the last row/column up to the coded (multiple-of-16) size, as the encoder does."""
+    h, w = y.shape
+    H, W = (h + 15) // 16 * 16, (w + 15) // 16 * 16
+    yp = np.empty((H, W), np.uint8)
+    yp[:h, :w] = y
+    yp[:h, w:] = y[:, w - 1:w]
+    yp[h:, :] = yp[h - 1:h, :]
+    up = np.empty((H // 2, W), np.uint8)
+    up[:h // 2, :w] = uv
+    for x in range(w, W, 2):
+        up[:h // 2, x] = uv[:, w - 2]
+        up[:h // 2, x + 1] = uv[:, w - 1]
+    up[h // 2:, :] = up[h // 2 - 1:h // 2, :]
+    return yp, up
+
+
+def frames(w, h, n, kind="s2"):
+    gen = synth.s2_frames(w, h, n) if kind == "s2" else synth.s3_frames(w, h, n)
+    return [pad_planes(y, uv) + (y, uv) for y, uv in gen]
+
+
+def mbinfo_equal(a, b, fields):
+    return all(np.array_equal(a[f], b[f]) for f in fields)
+
+
+def first_diff(a, b):
+    d = np.argwhere(np.asarray(a) != np.asarray(b))
+    return None if len(d) == 0 else (tuple(d[0]), len(d))
