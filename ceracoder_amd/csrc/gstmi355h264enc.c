@@ -1,0 +1,289 @@
+/*
+ * gstmi355h264enc.c -- GStreamer element `mi355h264enc`: the drop-in for the `x264enc`
+ * token of ceracoder's pipeline files
+ * (/root/reference/pipeline/generic/x264_superfast_camlink:5:
+ *      `x264enc speed-preset=2 key-int-max=60 name=venc_kbps`).
+ *
+ * Contract taken from the reference:
+ *  - found by NAME, not type: `venc_bps` (value in bit/s) is tried first, then `venc_kbps`
+ *    (value / 1000)                       /root/reference/src/gst/encoder_control.c:29-32
+ *  - the property the binary writes is "bps"        .../encoder_control.c:53
+ *    (README/docs call it "bitrate": /root/reference/README.md:256) -> both exist here and
+ *    alias one target; "bitrate" is kbit/s with x264enc's default 2048
+ *  - first write happens in state NULL, before PLAYING /root/reference/src/ceracoder.c:515-518
+ *  - later writes come from the GLib main thread every <= 20 ms while the streaming thread
+ *    encodes                                         /root/reference/src/ceracoder.c:266-295
+ *  - upstream zeroes DTS and smooths PTS             /root/reference/src/ceracoder.c:371-423
+ *    -> output DTS = PTS, no reordering
+ *  - errors go to the bus; the app exits on ERROR    /root/reference/src/ceracoder.c:425-438
+ * API level: GStreamer 1.14 (GstVideoEncoder).  Plain C; the device is reached only
+ * through the C ABI in include/mi355enc.h.  There is no CPU path: without a HIP device the
+ * element posts an ERROR when it leaves READY.
+ */
+#include <gst/gst.h>
+#include <gst/video/gstvideoencoder.h>
+#include <gst/video/video.h>
+#include <string.h>
+
+#include "../../include/mi355enc.h"
+
+#define PACKAGE "ceracoder-amd"
+#define VERSION "0.1.0"
+
+GST_DEBUG_CATEGORY_STATIC(mi355_debug);
+#define GST_CAT_DEFAULT mi355_debug
+
+typedef struct {
+    GstVideoEncoder parent;
+    /* properties (guarded by the object lock; bitrate is additionally forwarded atomically) */
+    guint bps;          /* bit/s */
+    guint key_int_max;
+    gint device_id, me_range, qp, pipeline_depth, speed_preset;
+    gboolean stats;
+    /* streaming state */
+    mi355enc_t *enc;
+    GstVideoCodecState *input_state;
+    gsize max_au;
+} GstMi355H264Enc;
+typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
+
+#define GST_TYPE_MI355H264ENC (gst_mi355h264enc_get_type())
+#define GST_MI355H264ENC(o) (G_TYPE_CHECK_INSTANCE_CAST((o), GST_TYPE_MI355H264ENC, GstMi355H264Enc))
+G_DEFINE_TYPE(GstMi355H264Enc, gst_mi355h264enc, GST_TYPE_VIDEO_ENCODER)
+
+enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME_RANGE, PROP_QP, PROP_PIPELINE_DEPTH,
+       PROP_SPEED_PRESET, PROP_STATS };
+
+static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
+    GST_STATIC_CAPS("video/x-raw, format=(string)NV12, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
+static GstStaticPadTemplate src_tmpl = GST_STATIC_PAD_TEMPLATE("src", GST_PAD_SRC, GST_PAD_ALWAYS,
+    GST_STATIC_CAPS("video/x-h264, stream-format=(string)byte-stream, alignment=(string)au, profile=(string)constrained-baseline, "
+                    "width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
+
+/* x264enc's speed-preset enum, accepted so that an x264enc line converts by changing only the factory name */
+static GType speed_preset_type(void) {
+    static GType t = 0;
+    static const GEnumValue v[] = {{0, "No preset", "None"}, {1, "ultrafast", "ultrafast"}, {2, "superfast", "superfast"},
+                                   {3, "veryfast", "veryfast"}, {4, "faster", "faster"}, {5, "fast", "fast"}, {6, "medium", "medium"},
+                                   {7, "slow", "slow"}, {8, "slower", "slower"}, {9, "veryslow", "veryslow"}, {10, "placebo", "placebo"},
+                                   {0, NULL, NULL}};
+    if (!t) t = g_enum_register_static("GstMi355H264EncPreset", v);
+    return t;
+}
+
+static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *ps) {
+    GstMi355H264Enc *s = GST_MI355H264ENC(obj);
+    GST_OBJECT_LOCK(s);
+    switch (id) {
+    case PROP_BPS: s->bps = g_value_get_uint(val); if (s->enc) mi355enc_set_bitrate(s->enc, s->bps); break;
+    case PROP_BITRATE: s->bps = g_value_get_uint(val) * 1000u; if (s->enc) mi355enc_set_bitrate(s->enc, s->bps); break;
+    case PROP_KEY_INT_MAX: s->key_int_max = g_value_get_uint(val); break;
+    case PROP_DEVICE_ID: s->device_id = g_value_get_int(val); break;
+    case PROP_ME_RANGE: s->me_range = g_value_get_int(val); break;
+    case PROP_QP: s->qp = g_value_get_int(val); if (s->enc) mi355enc_set_fixed_qp(s->enc, s->qp); break;
+    case PROP_PIPELINE_DEPTH: s->pipeline_depth = g_value_get_int(val); break;
+    case PROP_SPEED_PRESET: s->speed_preset = g_value_get_enum(val); break;
+    case PROP_STATS: s->stats = g_value_get_boolean(val); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
+    }
+    GST_OBJECT_UNLOCK(s);
+}
+static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
+    GstMi355H264Enc *s = GST_MI355H264ENC(obj);
+    GST_OBJECT_LOCK(s);
+    switch (id) {
+    case PROP_BPS: g_value_set_uint(val, s->bps); break;
+    case PROP_BITRATE: g_value_set_uint(val, s->bps / 1000u); break;
+    case PROP_KEY_INT_MAX: g_value_set_uint(val, s->key_int_max); break;
+    case PROP_DEVICE_ID: g_value_set_int(val, s->device_id); break;
+    case PROP_ME_RANGE: g_value_set_int(val, s->me_range); break;
+    case PROP_QP: g_value_set_int(val, s->qp); break;
+    case PROP_PIPELINE_DEPTH: g_value_set_int(val, s->pipeline_depth); break;
+    case PROP_SPEED_PRESET: g_value_set_enum(val, s->speed_preset); break;
+    case PROP_STATS: g_value_set_boolean(val, s->stats); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
+    }
+    GST_OBJECT_UNLOCK(s);
+}
+
+static void close_encoder(GstMi355H264Enc *s) {
+    mi355enc_t *e;
+    GST_OBJECT_LOCK(s);
+    e = s->enc; s->enc = NULL;
+    GST_OBJECT_UNLOCK(s);
+    if (e) {
+        if (s->stats) {
+            mi355enc_stats_t st;
+            if (mi355enc_get_stats(e, &st) == 0)
+                g_printerr("{\"element\":\"mi355h264enc\",\"frames\":%" G_GUINT64_FORMAT ",\"idr\":%" G_GUINT64_FORMAT ",\"bytes\":%" G_GUINT64_FORMAT
+                           ",\"ms_entropy\":%.3f,\"ms_wait\":%.3f,\"last_qp\":%u}\n", st.frames, st.idr_frames, st.bytes, st.ms_entropy, st.ms_wait, st.last_qp);
+        }
+        mi355enc_close(e);
+    }
+}
+static gboolean enc_stop(GstVideoEncoder *ve) {
+    GstMi355H264Enc *s = GST_MI355H264ENC(ve);
+    close_encoder(s);
+    if (s->input_state) { gst_video_codec_state_unref(s->input_state); s->input_state = NULL; }
+    return TRUE;
+}
+static gboolean enc_start(GstVideoEncoder *ve) {
+    (void)ve;
+    return TRUE; /* geometry is unknown until set_format; the device is opened there, still before data flows */
+}
+
+static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
+    GstMi355H264Enc *s = GST_MI355H264ENC(ve);
+    GstVideoInfo *vi = &state->info;
+    mi355enc_cfg_t cfg;
+    mi355enc_t *e = NULL;
+    int fn = GST_VIDEO_INFO_FPS_N(vi), fd = GST_VIDEO_INFO_FPS_D(vi);
+    if (fn <= 0 || fd <= 0) { fn = 30; fd = 1; } /* variable framerate: rate control assumes 30 */
+    close_encoder(s);
+    mi355enc_default_cfg(&cfg, GST_VIDEO_INFO_WIDTH(vi), GST_VIDEO_INFO_HEIGHT(vi), fn, fd);
+    GST_OBJECT_LOCK(s);
+    cfg.gop = s->key_int_max ? (int)s->key_int_max : 250;
+    cfg.me_range = s->me_range; cfg.bitrate_bps = s->bps; cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
+    cfg.pipeline_depth = s->pipeline_depth;
+    GST_OBJECT_UNLOCK(s);
+    int r = mi355enc_open(&cfg, &e);
+    if (r != MI355ENC_OK) {
+        if (e) mi355enc_close(e);
+        GST_ELEMENT_ERROR(s, LIBRARY, INIT, ("mi355h264enc: cannot open the MI355X encoder: %s", mi355enc_strerror(r)),
+                          ("mi355enc_open(%dx%d, device-id=%d) returned %d", cfg.width, cfg.height, cfg.device_id, r));
+        return FALSE;
+    }
+    GST_OBJECT_LOCK(s);
+    s->enc = e;
+    mi355enc_set_bitrate(e, s->bps); /* a write that raced with open() must not be lost */
+    GST_OBJECT_UNLOCK(s);
+    s->max_au = mi355enc_max_au_bytes(e);
+    if (s->input_state) gst_video_codec_state_unref(s->input_state);
+    s->input_state = gst_video_codec_state_ref(state);
+    GstCaps *caps = gst_caps_new_simple("video/x-h264", "stream-format", G_TYPE_STRING, "byte-stream", "alignment", G_TYPE_STRING, "au",
+                                        "profile", G_TYPE_STRING, "constrained-baseline", NULL);
+    GstVideoCodecState *out = gst_video_encoder_set_output_state(ve, caps, state);
+    gst_video_codec_state_unref(out);
+    if (cfg.pipeline_depth > 0) {
+        GstClockTime d = gst_util_uint64_scale(GST_SECOND, (guint64)fd * cfg.pipeline_depth, fn);
+        gst_video_encoder_set_latency(ve, d, d);
+    }
+    return gst_video_encoder_negotiate(ve);
+}
+
+/* entropy-code the oldest submitted picture into `frame` and push it */
+static GstFlowReturn collect_into(GstMi355H264Enc *s, GstVideoCodecFrame *frame) {
+    GstVideoEncoder *ve = GST_VIDEO_ENCODER(s);
+    GstMapInfo map;
+    size_t len = 0;
+    int key = 0;
+    GstFlowReturn fr = gst_video_encoder_allocate_output_frame(ve, frame, s->max_au);
+    if (fr != GST_FLOW_OK) { gst_video_encoder_finish_frame(ve, frame); return fr; }
+    if (!gst_buffer_map(frame->output_buffer, &map, GST_MAP_WRITE)) { gst_video_encoder_finish_frame(ve, frame); return GST_FLOW_ERROR; }
+    int r = mi355enc_collect(s->enc, map.data, map.size, &len, &key, NULL, NULL);
+    gst_buffer_unmap(frame->output_buffer, &map);
+    if (r != MI355ENC_OK) {
+        GST_ELEMENT_ERROR(s, STREAM, ENCODE, ("mi355h264enc: encode failed: %s", mi355enc_strerror(r)), ("mi355enc_collect returned %d", r));
+        gst_buffer_replace(&frame->output_buffer, NULL);
+        gst_video_encoder_finish_frame(ve, frame);
+        return GST_FLOW_ERROR;
+    }
+    gst_buffer_set_size(frame->output_buffer, (gssize)len);
+    if (key) GST_VIDEO_CODEC_FRAME_SET_SYNC_POINT(frame);
+    else GST_VIDEO_CODEC_FRAME_UNSET_SYNC_POINT(frame);
+    frame->dts = frame->pts; /* no reordering; upstream forces DTS to 0 (ceracoder.c:377) */
+    return gst_video_encoder_finish_frame(ve, frame);
+}
+
+static GstFlowReturn enc_handle_frame(GstVideoEncoder *ve, GstVideoCodecFrame *frame) {
+    GstMi355H264Enc *s = GST_MI355H264ENC(ve);
+    GstVideoFrame vf;
+    if (!s->enc || !s->input_state) { gst_video_encoder_finish_frame(ve, frame); return GST_FLOW_NOT_NEGOTIATED; }
+    if (!gst_video_frame_map(&vf, &s->input_state->info, frame->input_buffer, GST_MAP_READ)) {
+        gst_video_encoder_finish_frame(ve, frame);
+        return GST_FLOW_ERROR;
+    }
+    int r = mi355enc_submit(s->enc, GST_VIDEO_FRAME_PLANE_DATA(&vf, 0), GST_VIDEO_FRAME_PLANE_STRIDE(&vf, 0),
+                            GST_VIDEO_FRAME_PLANE_DATA(&vf, 1), GST_VIDEO_FRAME_PLANE_STRIDE(&vf, 1), (int64_t)frame->pts,
+                            GST_VIDEO_CODEC_FRAME_IS_FORCE_KEYFRAME(frame) ? 1 : 0);
+    gst_video_frame_unmap(&vf); /* submit() has copied the planes to the device (stream-ordered from pageable memory) */
+    if (r != MI355ENC_OK) {
+        GST_ELEMENT_ERROR(s, STREAM, ENCODE, ("mi355h264enc: submit failed: %s", mi355enc_strerror(r)), ("mi355enc_submit returned %d", r));
+        gst_video_encoder_finish_frame(ve, frame);
+        return GST_FLOW_ERROR;
+    }
+    GstFlowReturn fr = GST_FLOW_OK;
+    if (mi355enc_pending(s->enc) > s->pipeline_depth) {
+        GstVideoCodecFrame *old = gst_video_encoder_get_oldest_frame(ve);
+        if (old) fr = collect_into(s, old); /* finish_frame() consumes the reference */
+    }
+    gst_video_codec_frame_unref(frame);
+    return fr;
+}
+static GstFlowReturn drain(GstMi355H264Enc *s, gboolean push) {
+    GstVideoEncoder *ve = GST_VIDEO_ENCODER(s);
+    GstFlowReturn fr = GST_FLOW_OK;
+    while (s->enc && mi355enc_pending(s->enc) > 0) {
+        GstVideoCodecFrame *old = gst_video_encoder_get_oldest_frame(ve);
+        if (!old) break;
+        if (push) fr = collect_into(s, old);
+        else {
+            size_t n = 0;
+            guint8 *tmp = g_malloc(s->max_au);
+            mi355enc_collect(s->enc, tmp, s->max_au, &n, NULL, NULL, NULL);
+            g_free(tmp);
+            gst_video_encoder_finish_frame(ve, old); /* no output buffer: dropped */
+        }
+        if (fr != GST_FLOW_OK) break;
+    }
+    return fr;
+}
+static GstFlowReturn enc_finish(GstVideoEncoder *ve) { return drain(GST_MI355H264ENC(ve), TRUE); }
+static gboolean enc_flush(GstVideoEncoder *ve) { drain(GST_MI355H264ENC(ve), FALSE); return TRUE; }
+static gboolean enc_propose_allocation(GstVideoEncoder *ve, GstQuery *q) {
+    gst_query_add_allocation_meta(q, GST_VIDEO_META_API_TYPE, NULL);
+    return GST_VIDEO_ENCODER_CLASS(gst_mi355h264enc_parent_class)->propose_allocation(ve, q);
+}
+static void finalize(GObject *obj) {
+    enc_stop(GST_VIDEO_ENCODER(obj));
+    G_OBJECT_CLASS(gst_mi355h264enc_parent_class)->finalize(obj);
+}
+
+static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
+    GObjectClass *g = G_OBJECT_CLASS(k);
+    GstElementClass *e = GST_ELEMENT_CLASS(k);
+    GstVideoEncoderClass *v = GST_VIDEO_ENCODER_CLASS(k);
+    const GParamFlags F = (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS | GST_PARAM_MUTABLE_PLAYING);
+    g->set_property = set_property; g->get_property = get_property; g->finalize = finalize;
+    g_object_class_install_property(g, PROP_BPS, g_param_spec_uint("bps", "Bitrate (bit/s)",
+        "Target bitrate in bit/s; the property ceracoder's encoder_control writes (use with name=venc_bps)", 1000, 1000000000, 2048000, F));
+    g_object_class_install_property(g, PROP_BITRATE, g_param_spec_uint("bitrate", "Bitrate (kbit/s)",
+        "Target bitrate in kbit/s (x264enc-compatible alias of bps)", 1, 1000000, 2048, F));
+    g_object_class_install_property(g, PROP_KEY_INT_MAX, g_param_spec_uint("key-int-max", "Key-frame interval",
+        "Maximal distance between two IDR pictures (0 = 250)", 0, 100000, 60, F));
+    g_object_class_install_property(g, PROP_DEVICE_ID, g_param_spec_int("device-id", "HIP device", "GPU ordinal (one stream per GPU)", 0, 63, 0, F));
+    g_object_class_install_property(g, PROP_ME_RANGE, g_param_spec_int("me-range", "Motion search range", "Full-search radius, integer pels", 1, 16, 16, F));
+    g_object_class_install_property(g, PROP_QP, g_param_spec_int("qp", "Constant QP", "-1: rate control on; 0..51: constant quantiser", -1, 51, -1, F));
+    g_object_class_install_property(g, PROP_PIPELINE_DEPTH, g_param_spec_int("pipeline-depth", "Pipeline depth",
+        "0: output each picture before taking the next; 1: overlap host entropy coding with the next picture (+1 frame latency)", 0, 1, 0, F));
+    g_object_class_install_property(g, PROP_SPEED_PRESET, g_param_spec_enum("speed-preset", "Speed preset",
+        "Accepted for x264enc pipeline compatibility; ignored", speed_preset_type(), 6, F));
+    g_object_class_install_property(g, PROP_STATS, g_param_spec_boolean("stats", "Print stats", "Print a JSON line with counters when the encoder closes", FALSE, F));
+    gst_element_class_add_static_pad_template(e, &sink_tmpl);
+    gst_element_class_add_static_pad_template(e, &src_tmpl);
+    gst_element_class_set_static_metadata(e, "MI355X H.264 encoder", "Codec/Encoder/Video/Hardware",
+        "H.264 (Constrained Baseline) encoder on AMD Instinct MI355X via hand-written HIP kernels", "ceracoder-amd");
+    v->start = enc_start; v->stop = enc_stop; v->set_format = enc_set_format; v->handle_frame = enc_handle_frame;
+    v->finish = enc_finish; v->flush = enc_flush; v->propose_allocation = enc_propose_allocation;
+}
+static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
+    s->bps = 2048000; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
+    s->stats = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
+}
+
+static gboolean plugin_init(GstPlugin *p) {
+    GST_DEBUG_CATEGORY_INIT(mi355_debug, "mi355h264enc", 0, "MI355X H.264 encoder");
+    return gst_element_register(p, "mi355h264enc", GST_RANK_NONE, GST_TYPE_MI355H264ENC);
+}
+GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, mi355h264enc, "MI355X-native H.264 encoder for ceracoder", plugin_init, VERSION,
+                  "LGPL", PACKAGE, "https://github.com/CERALIVE/ceracoder")

@@ -485,4 +485,29 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
     return MI355ENC_OK;
 }
 
+// ---------------------------------------------------------------- host-only stages
+int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!out || !out_len || width < 16 || height < 16 || fps_num <= 0 || fps_den <= 0) return MI355ENC_ERR_ARG;
+    size_t n = h264_write_headers(out, cap, width, height, fps_num, fps_den);
+    if (!n) return MI355ENC_ERR_OVERFLOW;
+    *out_len = n;
+    return MI355ENC_OK;
+}
+int mi355enc_host_write_slice(int mbw, int mbh, int is_idr, int frame_num, int idr_pic_id, int qp, const void *mbinfo,
+                              const int16_t *levels, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!out || !out_len || !mbinfo || !levels || mbw < 1 || mbh < 1 || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    h264_writer_t *w = h264_writer_new(mbw, mbh);
+    if (!w) return MI355ENC_ERR_NOMEM;
+    size_t n = h264_write_slice(w, out, cap, is_idr, frame_num, idr_pic_id, qp, (const mb_info_t *)mbinfo, levels);
+    h264_writer_free(w);
+    if (!n) return MI355ENC_ERR_OVERFLOW;
+    *out_len = n;
+    return MI355ENC_OK;
+}
+static_assert(sizeof(rc_state_t) <= MI355ENC_RC_BYTES, "MI355ENC_RC_BYTES too small");
+void mi355enc_rc_init(void *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max) { rc_init((rc_state_t *)rc, fps, gop, bps, qp_min, qp_max); }
+void mi355enc_rc_set_bitrate(void *rc, uint32_t bps) { rc_set_bitrate((rc_state_t *)rc, bps); }
+int mi355enc_rc_pick_qp(void *rc, int is_idr) { return rc_pick_qp((rc_state_t *)rc, is_idr); }
+void mi355enc_rc_update(void *rc, int is_idr, int qp, size_t bytes) { rc_update((rc_state_t *)rc, is_idr, qp, bytes); }
+
 } // extern "C"

@@ -14,25 +14,35 @@
 #define DEV __device__ __forceinline__
 
 // ------------------------------------------------------------------ constant tables
-__constant__ uint16_t c_mf[6][3] = {{13107, 5243, 8066}, {11916, 4660, 7490}, {10082, 4194, 6554},
-                                    {9362, 3647, 5825},  {8192, 3355, 5243},  {7282, 2893, 4559}};
-__constant__ uint8_t c_v[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
-__constant__ uint8_t c_qpc[52] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
-                                  18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
-                                  34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
-__constant__ uint8_t c_alpha[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,   0,   0,   0,   0,   0,   0,   0,   4,   4,
-                                    5,  6,  7,  8,  9,  10, 12, 13, 15,  17,  20,  22,  25,  28,  32,  36,  40,  45,
-                                    50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255};
-__constant__ uint8_t c_beta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  0,  0,  0,  0,  2,  2,
-                                   2, 3, 3, 3, 3, 4, 4, 4, 6,  6,  7,  7,  8,  8,  9,  9,  10, 10,
-                                   11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18};
-__constant__ uint8_t c_tc0[52][3] = {
-    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},
-    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 1},
-    {0, 0, 1},   {0, 0, 1},   {0, 0, 1},   {0, 1, 1},   {0, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},
-    {1, 1, 2},   {1, 1, 2},   {1, 1, 2},   {1, 1, 2},   {1, 2, 3},   {1, 2, 3},   {2, 2, 3},   {2, 2, 4},   {2, 3, 4},
-    {2, 3, 4},   {3, 3, 5},   {3, 4, 6},   {3, 4, 6},   {4, 5, 7},   {4, 5, 8},   {4, 6, 9},   {5, 7, 10},  {6, 8, 11},
-    {6, 8, 13},  {7, 10, 14}, {8, 11, 16}, {9, 12, 18}, {10, 13, 20}, {11, 15, 23}, {13, 17, 25}};
+// One blob so that the latency-critical wavefront kernels can stage it in LDS with a single
+// round of loads (a table lookup through global memory costs a full L2 round trip each).
+struct dev_tables {
+    uint8_t alpha[52], beta[52], tc0[52][3], qpc[52]; // Tables 8-16, 8-17, 8-15
+    uint16_t mf[6][3];                                // encoder quantiser multipliers
+    uint8_t v[6][3];                                  // 8.5.9 normAdjust4x4
+    uint8_t pad[2];
+};
+static_assert(sizeof(dev_tables) % 4 == 0, "dev_tables is copied as dwords");
+#define TAB_DWORDS ((int)(sizeof(dev_tables) / 4))
+__device__ const dev_tables g_tab = {
+    {0,  0,  0,  0,  0,  0,  0,  0,  0,   0,   0,   0,   0,   0,   0,   0,   4,   4,
+     5,  6,  7,  8,  9,  10, 12, 13, 15,  17,  20,  22,  25,  28,  32,  36,  40,  45,
+     50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  0,  0,  0,  0,  2,  2,
+     2, 3, 3, 3, 3, 4, 4, 4, 6,  6,  7,  7,  8,  8,  9,  9,  10, 10,
+     11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18},
+    {{0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},
+     {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 1},
+     {0, 0, 1},   {0, 0, 1},   {0, 0, 1},   {0, 1, 1},   {0, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},
+     {1, 1, 2},   {1, 1, 2},   {1, 1, 2},   {1, 1, 2},   {1, 2, 3},   {1, 2, 3},   {2, 2, 3},   {2, 2, 4},   {2, 3, 4},
+     {2, 3, 4},   {3, 3, 5},   {3, 4, 6},   {3, 4, 6},   {4, 5, 7},   {4, 5, 8},   {4, 6, 9},   {5, 7, 10},  {6, 8, 11},
+     {6, 8, 13},  {7, 10, 14}, {8, 11, 16}, {9, 12, 18}, {10, 13, 20}, {11, 15, 23}, {13, 17, 25}},
+    {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+     18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
+     34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39},
+    {{13107, 5243, 8066}, {11916, 4660, 7490}, {10082, 4194, 6554}, {9362, 3647, 5825}, {8192, 3355, 5243}, {7282, 2893, 4559}},
+    {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}},
+    {0, 0}};
 
 DEV int iabs(int v) { return v < 0 ? -v : v; }
 DEV int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -214,11 +224,11 @@ DEV int quant1(int coef, int mf, int f, int qbits) { // dead-zone quantiser, |le
     return coef < 0 ? -l : l;
 }
 struct qparams { int mf[3], v[3], qbits, f, shift; };
-DEV qparams make_q(int qp, bool intra) {
+DEV qparams make_q(const dev_tables *T, int qp, bool intra) {
     qparams q;
     int m = qp % 6;
-    q.mf[0] = c_mf[m][0]; q.mf[1] = c_mf[m][1]; q.mf[2] = c_mf[m][2];
-    q.v[0] = c_v[m][0]; q.v[1] = c_v[m][1]; q.v[2] = c_v[m][2];
+    q.mf[0] = T->mf[m][0]; q.mf[1] = T->mf[m][1]; q.mf[2] = T->mf[m][2];
+    q.v[0] = T->v[m][0]; q.v[1] = T->v[m][1]; q.v[2] = T->v[m][2];
     q.qbits = 15 + qp / 6;
     q.f = (1 << q.qbits) / (intra ? 3 : 6);
     q.shift = qp / 6;
@@ -254,10 +264,10 @@ DEV int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 255); }
 // pred[16]: prediction of this lane's 4x4 block.  Handles the 2x2 DC Hadamard across the four
 // lanes of a plane with shuffles (8.5.11), writes levels + reconstruction, returns the AC flag
 // in bit 0 and the plane's DC flag in bit 1.
-DEV int chroma_block(const frame_ctx_t *ctx, int mbn, int cx0, int cy0, int cl, const int *pred, int qp, bool intra) {
+DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int cx0, int cy0, int cl, const int *pred, int qp, bool intra) {
     const int c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
-    const int qpc = c_qpc[qp];
-    const qparams q = make_q(qpc, intra);
+    const int qpc = T->qpc[qp];
+    const qparams q = make_q(T, qpc, intra);
     int x[16], lev[16];
     {
         const uint8_t *__restrict__ s = ctx->src_uv;
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
     int flags = 0; // bit0: AC/any nonzero, bit1: chroma DC nonzero
     if (is_luma && mb_ok) {
         const int b = lane & 15, bx = blkx(b), by = blky(b);
-        const qparams q = make_q(qp, false);
+        const qparams q = make_q(&g_tab, qp, false);
         int x[16], pr[16], lev[16];
         const uint8_t *__restrict__ s = ctx->src_y;
         const uint8_t *__restrict__ rf = ctx->ref_y;
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
             for (int i = 0; i < 4; i++)
                 pr[r * 4 + i] = ((8 - xf) * (8 - yf) * smp[r][i] + xf * (8 - yf) * smp[r][i + 1] +
                                  (8 - xf) * yf * smp[r + 1][i] + xf * yf * smp[r + 1][i + 1] + 32) >> 6;
-        if (mb_ok) flags = chroma_block(ctx, mbn, cx0, cy0, cl, pr, qp, false);
+        if (mb_ok) flags = chroma_block(ctx, &g_tab, mbn, cx0, cy0, cl, pr, qp, false);
         else { // keep the shuffles of partner lanes well-defined
             (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
             (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
@@ -416,9 +426,11 @@ DEV int wave16_sum(int v) {
     return v;
 }
 __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
-    __shared__ int sh_top[2][3][17], sh_left[2][3][17]; // [unused][plane 0=Y,1=Cb,2=Cr][-1..15]
+    __shared__ int sh_top[3][17], sh_left[3][17]; // [plane 0=Y,1=Cb,2=Cr][-1..15]
     __shared__ int sh_dc[16], sh_ldc[16];
-    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, qp = ctx->qp;
+    __shared__ unsigned tabw[TAB_DWORDS];
+    const dev_tables *T = (const dev_tables *)tabw;
+    const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
     const int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
     const int my = y_lo + blockIdx.x, mx = diag - my;
     const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
@@ -426,33 +438,26 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     const int lane = threadIdx.x;
     uint8_t *__restrict__ ry = ctx->rec_y;
     uint8_t *__restrict__ ruv = ctx->rec_uv;
-    // ---- neighbours into LDS: index i+1 holds sample i, index 0 holds the corner (-1)
-    int (*top)[17] = sh_top[0];
-    int (*left)[17] = sh_left[0];
-    if (lane < 17) {
-        int i = lane - 1;
-        top[0][lane] = has_top && (i >= 0 || has_left) ? ry[(size_t)(y0 - 1) * stride + x0 + i] : 0;
-        left[0][lane] = has_left && (i >= 0 || has_top) ? ry[(size_t)(y0 + i) * stride + x0 - 1] : 0;
-    } else if (lane >= 32 && lane < 32 + 18) {
-        int c = (lane - 32) / 9, i = (lane - 32) % 9 - 1;
+    const bool is_luma = lane < 16, is_chroma = lane >= 16 && lane < 24;
+    // ---- every global load is issued up front: tables, neighbours, this lane's source block
+    for (int i = lane; i < TAB_DWORDS; i += 64) tabw[i] = ((const unsigned *)&g_tab)[i];
+    int (*top)[17] = sh_top;
+    int (*left)[17] = sh_left;
+    if (lane >= 24 && lane < 24 + 17) { // lanes 24-40: luma neighbours; index i+1 holds sample i, index 0 the corner
+        int i = lane - 24 - 1;
+        top[0][i + 1] = has_top && (i >= 0 || has_left) ? ry[(size_t)(y0 - 1) * stride + x0 + i] : 0;
+        left[0][i + 1] = has_left && (i >= 0 || has_top) ? ry[(size_t)(y0 + i) * stride + x0 - 1] : 0;
+    } else if (lane >= 41 && lane < 41 + 18) { // lanes 41-58: chroma neighbours
+        int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
         top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? ruv[(size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c] : 0;
         left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? ruv[(size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c] : 0;
     }
-    __syncthreads();
-#define TOP(p, i) top[p][(i) + 1]
-#define LEFT(p, i) left[p][(i) + 1]
-    const bool is_luma = lane < 16, is_chroma = lane >= 16 && lane < 24;
-    const unsigned BIG = 0x10000000u;
-    int pred[16];
-    int flags = 0, mode = 0;
-    unsigned sad_sel = 0;
-    if (is_luma) {
-        const int b = lane, bx = blkx(b), by = blky(b);
-        // source block
-        int src[16];
-        {
+    int src[16];
+    if (lane < 24) {
+        const int ss = ctx->src_stride;
+        if (is_luma) {
             const uint8_t *__restrict__ s = ctx->src_y;
-            const int ss = ctx->src_stride, vh = ctx->vis_h;
+            const int bx = blkx(lane), by = blky(lane), vh = ctx->vis_h;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 int sy = y0 + by + r;
@@ -461,7 +466,29 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
 #pragma unroll
                 for (int i = 0; i < 4; i++) src[r * 4 + i] = byte_of(sw, i);
             }
+        } else {
+            const uint8_t *__restrict__ s = ctx->src_uv;
+            const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4, vh2 = ctx->vis_h >> 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int sy = cy0 + by + r;
+                sy = sy < vh2 ? sy : vh2 - 1;
+                uint2 w = *(const uint2 *)(s + (size_t)sy * ss + 2 * (cx0 + bx));
+                unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
+                src[r * 4 + 0] = (int)(lo & 255); src[r * 4 + 1] = (int)((lo >> 16) & 255);
+                src[r * 4 + 2] = (int)(hi & 255); src[r * 4 + 3] = (int)((hi >> 16) & 255);
+            }
         }
+    }
+    __syncthreads();
+#define TOP(p, i) top[p][(i) + 1]
+#define LEFT(p, i) left[p][(i) + 1]
+    const unsigned BIG = 0x10000000u;
+    int pred[16];
+    int flags = 0, mode = 0;
+    unsigned sad_sel = 0;
+    if (is_luma) {
+        const int b = lane, bx = blkx(b), by = blky(b);
         // DC value and plane parameters (8.3.3.3, 8.3.3.4) -- every lane computes the same numbers
         int st = 0, sl = 0, Hh = 0, Vv = 0;
 #pragma unroll
@@ -502,7 +529,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
                 pred[r * 4 + i] = mode == 0 ? TOP(0, bx + i) : mode == 1 ? LEFT(0, by + r) : mode == 2 ? dcv
                                   : clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5);
         // ---- residual, core transform, DC through the 4x4 Hadamard
-        const qparams q = make_q(qp, true);
+        const qparams q = make_q(T, qp, true);
         int x[16], lev[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = src[k] - pred[k];
@@ -555,20 +582,6 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     } else if (lane < 32) { // lanes 16-31 form one shuffle group; 16-23 do chroma, 24-31 pad with zeros
         const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
         const int p = 1 + c;
-        int src[16];
-        {
-            const uint8_t *__restrict__ s = ctx->src_uv;
-            const int ss = ctx->src_stride, vh2 = ctx->vis_h >> 1;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int sy = cy0 + by + r;
-                sy = sy < vh2 ? sy : vh2 - 1;
-                uint2 w = *(const uint2 *)(s + (size_t)sy * ss + 2 * (cx0 + bx));
-                unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
-                src[r * 4 + 0] = (int)(lo & 255); src[r * 4 + 1] = (int)((lo >> 16) & 255);
-                src[r * 4 + 2] = (int)(hi & 255); src[r * 4 + 3] = (int)((hi >> 16) & 255);
-            }
-        }
         // DC of this 4x4 block (8.3.4.1-3)
         int st = 0, sl = 0;
 #pragma unroll
@@ -617,7 +630,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
             for (int i = 0; i < 4; i++)
                 pred[r * 4 + i] = mode == 0 ? dcv : mode == 1 ? LEFT(p, by + r) : mode == 2 ? TOP(p, bx + i)
                                   : clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5);
-        if (is_chroma) flags = chroma_block(ctx, mbn, cx0, cy0, cl, pred, qp, true);
+        if (is_chroma) flags = chroma_block(ctx, T, mbn, cx0, cy0, cl, pred, qp, true);
         else {
             (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
             (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
@@ -640,15 +653,15 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
 }
 
 // =================================================================== deblocking (8.7)
-DEV void filter_line(uint8_t *pix, int step, int bS, int qp_p, int qp_q, bool chroma) {
+DEV void filter_line(const dev_tables *T, uint8_t *pix, int step, int bS, int qp_p, int qp_q, bool chroma) {
     if (bS == 0) return;
     const int idx = clip3(0, 51, (qp_p + qp_q + 1) >> 1);
-    const int alpha = c_alpha[idx], beta = c_beta[idx];
+    const int alpha = T->alpha[idx], beta = T->beta[idx];
     const int p0 = pix[-step], p1 = pix[-2 * step], q0 = pix[0], q1 = pix[step];
     if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
     if (chroma) {
         if (bS < 4) {
-            const int tc = c_tc0[idx][bS - 1] + 1;
+            const int tc = T->tc0[idx][bS - 1] + 1;
             const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
             pix[-step] = (uint8_t)clip255(p0 + dl); pix[0] = (uint8_t)clip255(q0 - dl);
         } else {
@@ -659,7 +672,7 @@ DEV void filter_line(uint8_t *pix, int step, int bS, int qp_p, int qp_q, bool ch
     const int p2 = pix[-3 * step], q2 = pix[2 * step];
     const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
     if (bS < 4) {
-        const int tc0 = c_tc0[idx][bS - 1];
+        const int tc0 = T->tc0[idx][bS - 1];
         const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
         const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
         pix[-step] = (uint8_t)clip255(p0 + dl); pix[0] = (uint8_t)clip255(q0 - dl);
@@ -698,6 +711,8 @@ DEV int bs_of(const mb_info_t &mp, int bxp, int byp, const mb_info_t &mq, int bx
 __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
     __shared__ __attribute__((aligned(16))) uint8_t tl[20 * TLS]; // luma rows y0-4..y0+15, cols x0-4..x0+15
     __shared__ __attribute__((aligned(16))) uint8_t tc[10 * TLS]; // chroma rows cy0-2..cy0+7, bytes 2*(cx0-2)..2*(cx0+8)
+    __shared__ unsigned tabw[TAB_DWORDS];
+    const dev_tables *T = (const dev_tables *)tabw;
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
     int y_lo = diag - (mbw - 1);
     y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
@@ -710,6 +725,8 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
     const mb_info_t cur = ctx->mbi[my * mbw + mx];
     const mb_info_t lft = ctx->mbi[my * mbw + (mx > 0 ? mx - 1 : mx)];
     const mb_info_t upp = ctx->mbi[(my > 0 ? my - 1 : my) * mbw + mx];
+    // ---- every global load of this macroblock is issued here, before the first wait
+    for (int i = lane; i < TAB_DWORDS; i += 64) tabw[i] = ((const unsigned *)&g_tab)[i];
     // ---- load tiles (skipping the corner, which this macroblock neither reads nor writes)
     for (int i = lane; i < 100; i += 64) {
         int r = i / 5, q = i - r * 5;
@@ -724,7 +741,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
             *(unsigned *)&tc[r * TLS + 4 * q] = *(const unsigned *)(ruv + (size_t)gy * stride + gb);
     }
     __syncthreads();
-    const int qpc_c = c_qpc[cur.qp], qpc_l = c_qpc[lft.qp], qpc_u = c_qpc[upp.qp];
+    const int qpc_c = T->qpc[cur.qp], qpc_l = T->qpc[lft.qp], qpc_u = T->qpc[upp.qp];
     // ---- vertical edges, left to right
     if (lane < 16) {
         const int k = lane;
@@ -733,7 +750,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
             if (e == 0 && mx == 0) continue;
             const mb_info_t &mp = e == 0 ? lft : cur;
             int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 2, cur, e, k >> 2, e == 0);
-            filter_line(&tl[(4 + k) * TLS + 4 + 4 * e], 1, bS, mp.qp, cur.qp, false);
+            filter_line(T, &tl[(4 + k) * TLS + 4 + 4 * e], 1, bS, mp.qp, cur.qp, false);
         }
     } else if (lane < 24) {
         const int k = lane - 16;
@@ -743,7 +760,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
             const mb_info_t &mp = e == 0 ? lft : cur;
             int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 1, cur, e, k >> 1, e == 0);
 #pragma unroll
-            for (int c = 0; c < 2; c++) filter_line(&tc[(2 + k) * TLS + 4 + 4 * e + c], 2, bS, e == 0 ? qpc_l : qpc_c, qpc_c, true);
+            for (int c = 0; c < 2; c++) filter_line(T, &tc[(2 + k) * TLS + 4 + 4 * e + c], 2, bS, e == 0 ? qpc_l : qpc_c, qpc_c, true);
         }
     }
     __syncthreads();
@@ -755,7 +772,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
             if (e == 0 && my == 0) continue;
             const mb_info_t &mp = e == 0 ? upp : cur;
             int bS = bs_of(mp, k >> 2, e == 0 ? 3 : e - 1, cur, k >> 2, e, e == 0);
-            filter_line(&tl[(4 + 4 * e) * TLS + 4 + k], TLS, bS, mp.qp, cur.qp, false);
+            filter_line(T, &tl[(4 + 4 * e) * TLS + 4 + k], TLS, bS, mp.qp, cur.qp, false);
         }
     } else if (lane < 24) {
         const int k = lane - 16;
@@ -765,7 +782,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
             const mb_info_t &mp = e == 0 ? upp : cur;
             int bS = bs_of(mp, k >> 1, e == 0 ? 3 : e - 1, cur, k >> 1, e, e == 0);
 #pragma unroll
-            for (int c = 0; c < 2; c++) filter_line(&tc[(2 + 2 * e) * TLS + 4 + 2 * k + c], TLS, bS, e == 0 ? qpc_u : qpc_c, qpc_c, true);
+            for (int c = 0; c < 2; c++) filter_line(T, &tc[(2 + 2 * e) * TLS + 4 + 2 * k + c], TLS, bS, e == 0 ? qpc_u : qpc_c, qpc_c, true);
         }
     }
     __syncthreads();

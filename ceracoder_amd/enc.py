@@ -26,6 +26,8 @@ EXPORTS = [
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
     "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_deblock", "mi355enc_time_stage",
+    "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
+    "mi355enc_rc_pick_qp", "mi355enc_rc_update",
 ]
 
 
@@ -85,8 +87,55 @@ def load():
         L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
         L.mi355enc_time_stage.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.mi355enc_host_write_headers.argtypes = [C.c_int] * 4 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi355enc_host_write_slice.argtypes = [C.c_int] * 6 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi355enc_rc_init.restype = None
+        L.mi355enc_rc_init.argtypes = [vp, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_int]
+        L.mi355enc_rc_set_bitrate.restype = None
+        L.mi355enc_rc_set_bitrate.argtypes = [vp, C.c_uint32]
+        L.mi355enc_rc_pick_qp.argtypes = [vp, C.c_int]
+        L.mi355enc_rc_update.restype = None
+        L.mi355enc_rc_update.argtypes = [vp, C.c_int, C.c_int, C.c_size_t]
         _lib = L
     return _lib
+
+
+def host_write_headers(width, height, fps_num, fps_den=1):
+    L = load()
+    out, n = np.empty(256, np.uint8), C.c_size_t(0)
+    r = L.mi355enc_host_write_headers(width, height, fps_num, fps_den, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+    if r:
+        raise RuntimeError("mi355enc_host_write_headers: %d" % r)
+    return bytes(out[: n.value])
+
+
+def host_write_slice(mbw, mbh, is_idr, frame_num, idr_pic_id, qp, mbinfo, levels):
+    L = load()
+    out, n = np.empty(mbw * mbh * 1536 + 4096, np.uint8), C.c_size_t(0)
+    mbinfo, levels = np.ascontiguousarray(mbinfo), np.ascontiguousarray(levels, np.int16)
+    r = L.mi355enc_host_write_slice(mbw, mbh, int(is_idr), frame_num, idr_pic_id, qp, mbinfo.ctypes.data_as(C.c_void_p),
+                                    levels.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+    if r:
+        raise RuntimeError("mi355enc_host_write_slice: %d" % r)
+    return bytes(out[: n.value])
+
+
+class RateControl:
+    """The encoder's rate-control model by itself (host logic; no device)."""
+
+    def __init__(self, fps, gop, bps, qp_min=10, qp_max=51):
+        self.L = load()
+        self.buf = (C.c_uint8 * 128)()
+        self.L.mi355enc_rc_init(self.buf, float(fps), gop, bps, qp_min, qp_max)
+
+    def set_bitrate(self, bps):
+        self.L.mi355enc_rc_set_bitrate(self.buf, int(bps))
+
+    def pick_qp(self, is_idr):
+        return self.L.mi355enc_rc_pick_qp(self.buf, int(is_idr))
+
+    def update(self, is_idr, qp, nbytes):
+        self.L.mi355enc_rc_update(self.buf, int(is_idr), qp, nbytes)
 
 
 class EncoderError(RuntimeError):

@@ -127,6 +127,20 @@ int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const
  * Uses whatever the handle's surfaces currently hold.  Returns average ms per launch. */
 int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms);
 
+
+/* ---- host-only stages (no device needed; what collect() runs after the D2H copy) ----
+ * SPS+PPS, and one CAVLC slice NAL from macroblock records + levels.  *out_len = bytes. */
+int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den, uint8_t *out, size_t out_cap, size_t *out_len);
+int mi355enc_host_write_slice(int mb_width, int mb_height, int is_idr, int frame_num, int idr_pic_id, int slice_qp,
+                              const void *mbinfo, const int16_t *levels, uint8_t *out, size_t out_cap, size_t *out_len);
+/* Rate-control model on its own: feed (is_idr, produced bytes) per picture, get the next QP.
+ * rc is an opaque block of MI355ENC_RC_BYTES bytes owned by the caller. */
+#define MI355ENC_RC_BYTES 128
+void mi355enc_rc_init(void *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max);
+void mi355enc_rc_set_bitrate(void *rc, uint32_t bps);
+int mi355enc_rc_pick_qp(void *rc, int is_idr);
+void mi355enc_rc_update(void *rc, int is_idr, int qp, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

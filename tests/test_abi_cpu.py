@@ -1,0 +1,145 @@
+"""The C-ABI library: loads, exports every symbol include/mi355enc.h declares, fails loudly
+without a device, and its host-only stages (CAVLC slice writer, parameter sets, rate
+control) agree with the oracle.  No GPU compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ceracoder_amd import enc as E
+from ceracoder_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mi355enc.h")).read()
+    declared = sorted(set(re.findall(r"\b(mi355enc_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    L = C.CDLL(E.LIB_PATH)
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(E.EXPORTS) == declared, set(declared) ^ set(E.EXPORTS)
+    assert L.mi355enc_abi_version() == 1
+
+
+def test_error_strings_and_defaults():
+    L = E.load()
+    assert L.mi355enc_strerror(0) == b"ok"
+    assert b"no CPU fallback" in L.mi355enc_strerror(-2)
+    cfg = E.Cfg()
+    L.mi355enc_default_cfg(C.byref(cfg), 1920, 1080, 60, 1)
+    assert (cfg.gop, cfg.me_range, cfg.bitrate_bps, cfg.fixed_qp) == (60, 16, 2048000, -1)  # x264enc default 2048 kbit/s
+
+
+def test_open_rejects_bad_geometry():
+    L = E.load()
+    for w, h in ((8, 8), (17, 16), (16384, 16)):
+        cfg = E.Cfg()
+        L.mi355enc_default_cfg(C.byref(cfg), w, h, 30, 1)
+        hnd = C.c_void_p()
+        assert L.mi355enc_open(C.byref(cfg), C.byref(hnd)) == -1
+        assert not hnd.value
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful where no HIP device exists")
+def test_no_device_fails_loudly_no_cpu_fallback():
+    with pytest.raises(E.EncoderError, match="no usable HIP device"):
+        E.Encoder(320, 192)
+
+
+def test_host_headers_equal_oracle(oracle):
+    for w, h, fps in ((64, 48, 30), (1280, 720, 30), (1920, 1080, 60), (3840, 2160, 60), (50, 34, 25)):
+        assert E.host_write_headers(w, h, fps) == oracle.write_headers(w, h, fps)
+
+
+@pytest.mark.parametrize("w,h,qp", [(64, 48, 30), (176, 144, 8), (176, 144, 44), (320, 180, 24)])
+def test_host_cavlc_equals_oracle_on_real_pictures(oracle, w, h, qp):
+    """Feed the oracle's records/levels of an IDR and three P pictures to the product's slice writer."""
+    oe = oracle.Encoder(w, h, gop=4, threads=4)
+    for i, (y, uv) in enumerate(synth.s2_frames(w, h, 4)):
+        au, idr = oe.encode(y, uv, qp)
+        mine = E.host_write_slice(oe.mbw, oe.mbh, idr, i % 4, 0, qp, oe.mbinfo, oe.levels)
+        hdr = oracle.write_headers(w, h, 60) if idr else b""
+        assert hdr + mine == au, (i, len(mine), len(au))
+
+
+def test_host_cavlc_equals_oracle_on_random_levels(oracle):
+    """Adversarial levels: long runs, escape-coded magnitudes, every nC class, all cbp values."""
+    rng = np.random.default_rng(7)
+    mbw, mbh = 5, 4
+    n = mbw * mbh
+    for trial in range(30):
+        is_idr = trial % 3 == 0
+        mbi = np.zeros(n, E.MBINFO_DTYPE)
+        lev = np.zeros((n, E.LEVELS_PER_MB), np.int16)
+        dens = [0.02, 0.2, 0.6, 1.0][trial % 4]
+        mag = [1, 3, 40, 2047][(trial // 4) % 4]
+        for m in range(n):
+            intra = is_idr or rng.random() < 0.2
+            mbi[m]["mb_type"] = 0 if intra else 1
+            mbi[m]["qp"] = 30
+            mbi[m]["i16_mode"], mbi[m]["chroma_mode"] = rng.integers(0, 4), rng.integers(0, 4)
+            mbi[m]["mvx"], mbi[m]["mvy"] = (0, 0) if intra else (rng.integers(-16, 17), rng.integers(-16, 17))
+            nz = 0
+            for b in range(16):
+                if rng.random() < 0.7:
+                    v = (rng.random(16) < dens) * rng.integers(-mag, mag + 1, 16)
+                    if intra:
+                        v[0] = 0
+                    lev[m, b * 16:(b + 1) * 16] = v
+                    nz |= int(v.any()) << b
+            if intra:
+                v = (rng.random(16) < dens) * rng.integers(-mag, mag + 1, 16)
+                lev[m, 256:272] = v
+                nz |= int(v.any()) << 24
+            for c in range(2):
+                v = (rng.random(4) < dens) * rng.integers(-mag, mag + 1, 4)
+                lev[m, 272 + 4 * c:276 + 4 * c] = v
+                nz |= int(v.any()) << (25 + c)
+                for b in range(4):
+                    if rng.random() < 0.5:
+                        v = (rng.random(16) < dens) * rng.integers(-mag, mag + 1, 16)
+                        v[0] = 0
+                        o = 280 + (4 * c + b) * 16
+                        lev[m, o:o + 16] = v
+                        nz |= int(v.any()) << (16 + 4 * c + b)
+            mbi[m]["nzmask"] = nz
+        a = E.host_write_slice(mbw, mbh, is_idr, trial % 256, trial, 30, mbi, lev)
+        b = oracle.write_slice(mbw, mbh, is_idr, trial % 256, trial, 30, mbi, lev)
+        assert a == b, trial
+
+
+def test_rate_control_model_converges_and_follows_steps():
+    """Host logic only: synthetic pictures whose size is C/qstep; after a step on the setpoint the
+    mean rate over the following GOP must be within 10 %."""
+    fps, gop = 60, 60
+    rc = E.RateControl(fps, gop, 6_000_000)
+    rng = np.random.default_rng(3)
+    sizes = []
+    for i in range(6 * gop):
+        if i == 2 * gop:
+            rc.set_bitrate(3_000_000)
+        if i == 4 * gop:
+            rc.set_bitrate(1_000_000)  # a deep emergency drop (floor is 300 kbit/s, bitrate_control.h:30)
+        idr = i % gop == 0
+        qp = rc.pick_qp(idr)
+        assert 10 <= qp <= 51
+        cplx = (9e6 if idr else 1.2e6) * (1 + 0.1 * rng.standard_normal())
+        nbytes = max(40, int(cplx / 2 ** ((qp - 4) / 6) / 8))
+        rc.update(idr, qp, nbytes)
+        sizes.append(nbytes)
+    rate = lambda g: sum(sizes[g * gop:(g + 1) * gop]) * 8 * fps / gop
+    assert abs(rate(1) - 6e6) / 6e6 < 0.10, rate(1)
+    assert abs(rate(3) - 3e6) / 3e6 < 0.10, rate(3)
+    assert abs(rate(5) - 1e6) / 1e6 < 0.10, rate(5)

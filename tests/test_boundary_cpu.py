@@ -1,0 +1,91 @@
+"""The drop-in boundary exercised by the reference's own code (compiled unmodified into
+oracle/_ref): pipeline text -> gst_parse_launch -> element found by name -> "bps" written in
+state NULL (ceracoder.c:514-518).  Golden bitrate scripts come from the reference balancer."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def gst_env():
+    env = dict(os.environ)
+    env.update(GST_PLUGIN_SYSTEM_PATH="/opt/conda/lib/gstreamer-1.0", GST_PLUGIN_SCANNER="/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner",
+               GST_REGISTRY="/tmp/ceracoder_amd_gst_registry.bin", GST_PLUGIN_PATH=os.path.join(ROOT, "ceracoder_amd", "gst-plugins"),
+               LD_PRELOAD="/usr/lib/x86_64-linux-gnu/libstdc++.so.6")
+    return env
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+needs_gst = pytest.mark.skipif(not os.path.exists("/opt/conda/bin/gst-inspect-1.0"), reason="GStreamer 1.14 of this image not found")
+
+
+def test_golden_balancer_scripts_match_survey():
+    """SURVEY.md 8c lists what the reference's balancer prints for test_integration.c:151-225."""
+    def kbps(name):
+        return [int(l.split()[1]) // 1000 for l in open(os.path.join(GOLD, name))]
+    assert kbps("balancer_adaptive.txt") == [6000] * 10 + [5300] * 10 + [5500, 5500, 5700, 5700, 5900, 5900] + [6000] * 9
+    assert kbps("balancer_aimd.txt") == [6000] * 10 + [4500, 3300, 2500, 1800, 1400, 1000, 800, 600, 500, 500] + \
+        [500, 500, 600, 600, 600, 600, 700, 700, 700, 700, 800, 800, 800, 800, 900]
+    assert kbps("balancer_fixed.txt") == [6000] * 35
+    ts = [int(l.split()[0]) for l in open(os.path.join(GOLD, "balancer_adaptive.txt"))]
+    assert ts[:10] == list(range(500, 5001, 500)) and ts[10] == 5250 and ts[-1] == 15000
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/core"), reason="reference tree only exists in the build container")
+def test_golden_balancer_scripts_regenerate_identically():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for algo in ("adaptive", "aimd", "fixed"):
+        out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "gen_balancer_script"), algo], capture_output=True, text=True, check=True).stdout
+        assert out == open(os.path.join(GOLD, "balancer_%s.txt" % algo)).read()
+
+
+@needs_gst
+def test_plugin_registers_with_expected_properties():
+    out = subprocess.run(["/opt/conda/bin/gst-inspect-1.0", "mi355h264enc"], env=gst_env(), capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for needle in ("bps ", "bitrate ", "key-int-max", "device-id", "speed-preset", "video/x-h264", "byte-stream", "NV12"):
+        assert needle in out.stdout, needle
+
+
+@needs_gst
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,div", [("venc_bps", 1), ("venc_kbps", 1000)])
+def test_reference_encoder_control_drives_bps_in_null_state(tmp_path, name, div):
+    """encoder_control.c finds the element by name and writes "bps" before PLAYING; the element must
+    hold the value.  (Named venc_kbps the reference divides by 1000 -- documented, not recommended.)"""
+    pf = tmp_path / "pipe"
+    pf.write_text("videotestsrc num-buffers=3 ! video/x-raw,width=320,height=192,framerate=30/1,format=NV12 ! "
+                  "mi355h264enc key-int-max=30 speed-preset=superfast name=%s ! appsink name=appsink sync=false\n" % name)
+    script = tmp_path / "script"
+    script.write_text("0 4300000\n")
+    r = subprocess.run([HARNESS, str(pf), str(tmp_path / "out.bin"), str(script)], env=gst_env(), capture_output=True, text=True, timeout=120)
+    info = json.loads([l for l in r.stderr.splitlines() if l.startswith("{\"encoder_found\"")][0])
+    assert info == {"encoder_found": 1, "bitrate_div": div, "bps_after_null_state_write": 4300000 // div}
+    if _has_gpu():
+        assert r.returncode == 0, r.stderr
+        assert json.loads(r.stdout.splitlines()[-1])["samples"] == 3
+    else:  # no device: a bus ERROR from the element, never a silent CPU encode
+        assert r.returncode == 3 and "no usable HIP device" in r.stderr, r.stderr
+
+
+def test_pipeline_files_name_the_element_like_the_reference():
+    """The swap point is one token: same line shape as pipeline/generic/x264_superfast_*:5-6."""
+    d = os.path.join(ROOT, "pipeline", "mi355x")
+    files = sorted(os.listdir(d))
+    assert "h264_test_pattern_1080p60" in files and "h264_test_pattern_2160p60" in files and "h264_test_pattern_720p30" in files
+    for f in files:
+        text = open(os.path.join(d, f)).read()
+        assert "mi355h264enc" in text and "name=venc_bps" in text and "appsink name=appsink" in text, f
+        assert "x264enc" not in text
