@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--fixed-qp", type=int, default=-1)
     ap.add_argument("--depth", type=int, default=1)
+    ap.add_argument("--deblock-mode", type=int, default=0)
     args = ap.parse_args()
 
     import torch
@@ -106,7 +107,7 @@ def main():
     fbytes = frames.stride(0)
 
     e = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
-                  pipeline_depth=args.depth, profile_events=True, use_graphs=not args.no_graphs)
+                  pipeline_depth=args.depth, profile_events=True, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode)
 
     def run(n, first_index):
         qps, nbytes = [], 0

@@ -56,6 +56,9 @@ struct mi355enc {
     mb_info_t *d_mbi;
     int16_t *d_levels;
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
+    unsigned *d_progress; // [2*bands] strip counters of the band deblocker, then one error word
+    unsigned *h_err;      // pinned mirror of the error word
+    int n_progress;
     slot_t slot[NSLOT];
     int head, tail, pending;
     int cur, have_ref, frames_since_idr, idr_count, last_collected_rec;
@@ -94,7 +97,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0;
 }
 
 static void launch_intra_all(mi355enc_t *h) {
@@ -122,6 +125,12 @@ static int run_intra(mi355enc_t *h) {
     return 0;
 }
 static int run_deblock(mi355enc_t *h) {
+    if (h->cfg.deblock_mode == 0) {
+        HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(h->n_progress + 1) * sizeof(unsigned), h->stream));
+        k_launch_deblock_band(h->d_ctx, h->mbh, h->d_progress, h->d_progress + h->n_progress, h->stream);
+        HIPCHK(hipMemcpyAsync(h->h_err, h->d_progress + h->n_progress, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        return 0;
+    }
     if (h->cfg.use_graphs) {
         if (!h->g_deblock) { int r = build_graph(h, 1, &h->g_deblock); if (r) return r; }
         HIPCHK(hipGraphLaunch(h->g_deblock, h->stream));
@@ -158,7 +167,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
-    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr;
+    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->h_err = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
     h->fixed_qp.store(cfg->fixed_qp);
@@ -174,6 +183,10 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMemsetAsync(h->d_rec_y[i], 0, h->ysz + SURF_PAD, h->stream));
         HIPCHK(hipMemsetAsync(h->d_rec_uv[i], 0, h->csz + SURF_PAD, h->stream));
     }
+    h->n_progress = 2 * k_deblock_bands(h->mbh);
+    HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(h->n_progress + 1) * sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void **)&h->h_err, sizeof(unsigned), hipHostMallocDefault));
+    *h->h_err = 0;
     if (cfg->keep_prefilter) {
         HIPCHK(hipMalloc((void **)&h->d_pre_y, h->ysz));
         HIPCHK(hipMalloc((void **)&h->d_pre_uv, h->csz));
@@ -215,6 +228,8 @@ void mi355enc_close(mi355enc_t *h) {
     for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
     if (h->d_pre_y) (void)hipFree(h->d_pre_y);
     if (h->d_pre_uv) (void)hipFree(h->d_pre_uv);
+    if (h->d_progress) (void)hipFree(h->d_progress);
+    if (h->h_err) (void)hipHostFree(h->h_err);
     if (h->d_ctx) (void)hipFree(h->d_ctx);
     if (h->d_mbi) (void)hipFree(h->d_mbi);
     if (h->d_levels) (void)hipFree(h->d_levels);
@@ -323,6 +338,10 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     HIPCHK(hipEventSynchronize(s->done));
     double t1 = now_ms();
     h->st.ms_wait += t1 - t0;
+    if (*h->h_err) {
+        fprintf(stderr, "mi355enc: deblocking wavefront timed out waiting for a neighbouring band (device error word %u)\n", *h->h_err);
+        return MI355ENC_ERR_HIP;
+    }
     size_t n = 0;
     if (s->is_idr) {
         n = h264_write_headers(out, out_cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den);

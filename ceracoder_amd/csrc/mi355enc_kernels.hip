@@ -801,6 +801,279 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
     }
 }
 
+// =================================================================== deblocking, persistent form
+// One kernel per picture instead of one launch per wavefront.  A workgroup owns a band of
+// DB_R macroblock rows: wave r < DB_R filters the LUMA of row band*DB_R + r, wave DB_R + r the
+// CHROMA of the same row (the two planes share nothing but the bS inputs).  All waves advance in
+// lock-step, one workgroup barrier per step; at step t row r handles macroblock x = t - 2r, which
+// is exactly the x + 2y wavefront, so the ordering argument of deblock_kernel carries over.
+// Hand-offs never touch global memory inside a band:
+//   left strip   (4 columns)  : stays in the wave's own LDS tile between steps
+//   bottom strip (4 rows)     : LDS ring of 4 macroblocks, written by row r, read by row r+1 two
+//                               steps later (after row r patched columns 13-15 at step t+1)
+// Between bands the bottom strips of the last row travel through global memory with `sc1`
+// (agent-scope, L1-bypassing) stores/loads and one monotonic progress counter per band and
+// plane (MI355X_MICROARCH.md, "Valid forms": all handed-off bytes stored sc1 by one wave,
+// `s_waitcnt vmcnt(0)`, then the sc1 counter store; consumer polls with sc1 loads and reads the
+// bytes with sc1 loads).  A band waits only on the band above it, so the wait graph is acyclic;
+// every spin is bounded and reports through ctx-independent `err`.
+#define DB_R 4
+#define DB_TS 32 /* tile row stride; column c of the macroblock lives at byte 16 + c, the left strip at 12..15 */
+#define DB_SPIN_MAX (1 << 20)
+
+struct db_luma_lds { uint8_t t[20 * DB_TS]; unsigned ring[4][16]; };   // rows -4..15
+struct db_chroma_lds { uint8_t t[10 * DB_TS]; unsigned ring[4][8]; };  // rows -2..7
+
+DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// one luma line across an edge, samples in registers
+DEV void edge_luma(const dev_tables *T, int &p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int &q3, int bS, int qpav) {
+    (void)p3; (void)q3;
+    const int alpha = T->alpha[qpav], beta = T->beta[qpav];
+    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
+    if (bS < 4) {
+        const int tc0 = T->tc0[qpav][bS - 1];
+        const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+        const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        const int avg = (p0 + q0 + 1) >> 1;
+        const int np1 = ap ? p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) : p1;
+        const int nq1 = aq ? q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) : q1;
+        p0 = clip255(p0 + dl); q0 = clip255(q0 - dl); p1 = np1; q1 = nq1;
+    } else {
+        const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        int np0, np1 = p1, np2 = p2, nq0, nq1 = q1, nq2 = q2;
+        if (ap && small) {
+            np0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3; np1 = (p2 + p1 + p0 + q0 + 2) >> 2; np2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+        } else np0 = (2 * p1 + p0 + q1 + 2) >> 2;
+        if (aq && small) {
+            nq0 = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3; nq1 = (p0 + q0 + q1 + q2 + 2) >> 2; nq2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+        } else nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
+        p0 = np0; p1 = np1; p2 = np2; q0 = nq0; q1 = nq1; q2 = nq2;
+    }
+}
+DEV void edge_chroma(const dev_tables *T, int p1, int &p0, int &q0, int q1, int bS, int qpav) {
+    const int alpha = T->alpha[qpav], beta = T->beta[qpav];
+    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    if (bS < 4) {
+        const int tc = T->tc0[qpav][bS - 1] + 1;
+        const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        p0 = clip255(p0 + dl); q0 = clip255(q0 - dl);
+    } else {
+        const int np0 = (2 * p1 + p0 + q1 + 2) >> 2, nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
+        p0 = np0; q0 = nq0;
+    }
+}
+
+struct db_args { const frame_ctx_t *ctx; unsigned *progress; unsigned *err; };
+
+// wait until the band above has published the bottom strips of macroblocks 0..need-1
+DEV void db_wait(unsigned *progress, unsigned *err, int idx, int need) {
+    int spins = 0;
+    while ((int)ld_sc1(&progress[idx]) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(err))) { st_sc1(err, 1u); break; } // bounded; once tripped, nobody waits again
+    }
+}
+
+__global__ __launch_bounds__(2 * DB_R * 64) void deblock_band_kernel(db_args a) {
+    __shared__ __attribute__((aligned(16))) db_luma_lds LL[DB_R];
+    __shared__ __attribute__((aligned(16))) db_chroma_lds CL[DB_R];
+    __shared__ unsigned tabw[TAB_DWORDS];
+    const dev_tables *T = (const dev_tables *)tabw;
+    const frame_ctx_t *__restrict__ ctx = a.ctx;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
+    const int band = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool chroma = wave >= DB_R;
+    const int r = chroma ? wave - DB_R : wave;
+    const int my = band * DB_R + r;
+    const bool row_ok = my < mbh;
+    const bool last_row = my == mbh - 1;
+    // the row whose bottom strips feed the next band (none if this band holds the picture's last row)
+    const bool feeds_next = row_ok && r == DB_R - 1 && !last_row;
+    const bool fed_by_prev = row_ok && r == 0 && band > 0;
+    for (int i = threadIdx.x; i < TAB_DWORDS; i += 2 * DB_R * 64) tabw[i] = ((const unsigned *)&g_tab)[i];
+    uint8_t *__restrict__ plane = chroma ? ctx->rec_uv : ctx->rec_y;
+    const int rows_mb = chroma ? 8 : 16, strip = chroma ? 2 : 4; // rows per macroblock, rows per hand-off strip
+    const size_t row0 = (size_t)my * rows_mb;                     // first plane row of this macroblock row
+    uint8_t *tile = chroma ? CL[r].t : LL[r].t;
+    unsigned *ring = chroma ? &CL[r].ring[0][0] : &LL[r].ring[0][0];
+    const unsigned *ring_up = r > 0 ? (chroma ? &CL[r - 1].ring[0][0] : &LL[r - 1].ring[0][0]) : nullptr;
+    const int ring_n = chroma ? 8 : 16;                            // dwords per ring slot
+    const int pidx = 2 * band + (chroma ? 1 : 0);
+    const mb_info_t *__restrict__ mbi = ctx->mbi;
+
+    // prefetch registers: this lane's row of the next macroblock, and the records it needs
+    uint4 pre = make_uint4(0, 0, 0, 0);
+    mb_info_t cur, lft, upp;
+    cur.mb_type = lft.mb_type = upp.mb_type = 1; cur.qp = lft.qp = upp.qp = 0; cur.nzmask = lft.nzmask = upp.nzmask = 0;
+    cur.mvx = cur.mvy = lft.mvx = lft.mvy = upp.mvx = upp.mvy = 0;
+    mb_info_t nxt_cur = cur, nxt_upp = cur;
+    if (row_ok) {
+        if (lane < rows_mb) pre = *(const uint4 *)(plane + (row0 + lane) * stride);
+        nxt_cur = mbi[my * mbw];
+        if (my > 0) nxt_upp = mbi[(my - 1) * mbw];
+    }
+    const int nsteps = mbw + 2 * (DB_R - 1);
+    for (int t = 0; t < nsteps; t++) {
+        const int x = t - 2 * r;
+        const bool act = row_ok && x >= 0 && x < mbw;
+        if (act && fed_by_prev && lane == 0) db_wait(a.progress, a.err, pidx - 2, x + 1);
+        __syncthreads();
+        if (!act) continue;
+        lft = cur; cur = nxt_cur; upp = nxt_upp;
+        const int x0b = x * 16; // byte offset of the macroblock in a plane row (luma: 16 px, chroma: 8 px x 2 planes)
+        // ---- (a) own rows into the tile
+        if (lane < rows_mb) *(uint4 *)&tile[(lane + strip) * DB_TS + 16] = pre;
+        // ---- (b) top strip: LDS ring of the row above, or global (sc1) across a band boundary
+        if (my > 0 && lane < strip * 4) {
+            const int sr = lane >> 2, q = lane & 3;
+            unsigned v;
+            if (r > 0) v = ring_up[(x & 3) * ring_n + lane];
+            else v = ld_sc1((const unsigned *)(plane + (row0 - strip + sr) * stride + x0b + 4 * q));
+            *(unsigned *)&tile[sr * DB_TS + 16 + 4 * q] = v;
+        }
+        // ---- prefetch the next macroblock while this one is filtered
+        if (x + 1 < mbw) {
+            if (lane < rows_mb) pre = *(const uint4 *)(plane + (row0 + lane) * stride + x0b + 16);
+            nxt_cur = mbi[my * mbw + x + 1];
+            if (my > 0) nxt_upp = mbi[(my - 1) * mbw + x + 1];
+        }
+        WAVE_SYNC();
+        if (!chroma) {
+            // ---- (e) vertical edges: lane k < 16 owns picture row k of the macroblock
+            if (lane < 16) {
+                const int k = lane;
+                unsigned w5[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 4) * DB_TS + 12 + 4 * i];
+                int px[20];
+#pragma unroll
+                for (int i = 0; i < 20; i++) px[i] = byte_of(w5[i >> 2], i & 3);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (e == 0 && x == 0) continue;
+                    const mb_info_t &mp = e == 0 ? lft : cur;
+                    const int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 2, cur, e, k >> 2, e == 0);
+                    if (bS) edge_luma(T, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6],
+                                      px[4 * e + 7], bS, clip3(0, 51, (mp.qp + cur.qp + 1) >> 1));
+                }
+#pragma unroll
+                for (int i = 0; i < 5; i++)
+                    *(unsigned *)&tile[(k + 4) * DB_TS + 12 + 4 * i] = pack4(px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]);
+            }
+            WAVE_SYNC();
+            // ---- (g) horizontal edges: lane k < 16 owns picture column k
+            if (lane < 16) {
+                const int k = lane;
+                int px[20];
+#pragma unroll
+                for (int i = 0; i < 20; i++) px[i] = tile[i * DB_TS + 16 + k];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (e == 0 && my == 0) continue;
+                    const mb_info_t &mp = e == 0 ? upp : cur;
+                    const int bS = bs_of(mp, k >> 2, e == 0 ? 3 : e - 1, cur, k >> 2, e, e == 0);
+                    if (bS) edge_luma(T, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6],
+                                      px[4 * e + 7], bS, clip3(0, 51, (mp.qp + cur.qp + 1) >> 1));
+                }
+#pragma unroll
+                for (int i = 1; i < 19; i++) tile[i * DB_TS + 16 + k] = (uint8_t)px[i];
+            }
+        } else {
+            const int qc = T->qpc[cur.qp], ql = T->qpc[lft.qp], qu = T->qpc[upp.qp];
+            // ---- vertical edges: lane k < 8 owns chroma row k (both planes, interleaved bytes)
+            if (lane < 8) {
+                const int k = lane;
+                unsigned w5[5];
+#pragma unroll
+                for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 2) * DB_TS + 12 + 4 * i];
+                int b[20];
+#pragma unroll
+                for (int i = 0; i < 20; i++) b[i] = byte_of(w5[i >> 2], i & 3);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    if (e == 0 && x == 0) continue;
+                    const mb_info_t &mp = e == 0 ? lft : cur;
+                    const int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 1, cur, e, k >> 1, e == 0);
+                    if (bS) {
+                        const int qa = (e == 0 ? (ql + qc + 1) >> 1 : qc);
+#pragma unroll
+                        for (int c = 0; c < 2; c++) // q0 of plane c sits at byte 4 + 4e + c; neighbours 2 bytes apart
+                            edge_chroma(T, b[4 * e + c], b[4 * e + 2 + c], b[4 * e + 4 + c], b[4 * e + 6 + c], bS, qa);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 5; i++)
+                    *(unsigned *)&tile[(k + 2) * DB_TS + 12 + 4 * i] = pack4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
+            }
+            WAVE_SYNC();
+            // ---- horizontal edges: lane j < 16 owns byte column j (8 samples x 2 planes)
+            if (lane < 16) {
+                const int j = lane;
+                int b[10];
+#pragma unroll
+                for (int i = 0; i < 10; i++) b[i] = tile[i * DB_TS + 16 + j];
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    if (e == 0 && my == 0) continue;
+                    const mb_info_t &mp = e == 0 ? upp : cur;
+                    const int bS = bs_of(mp, j >> 2, e == 0 ? 3 : e - 1, cur, j >> 2, e, e == 0);
+                    if (bS) edge_chroma(T, b[2 * e], b[2 * e + 1], b[2 * e + 2], b[2 * e + 3], bS, e == 0 ? (qu + qc + 1) >> 1 : qc);
+                }
+#pragma unroll
+                for (int i = 1; i < 9; i++) tile[i * DB_TS + 16 + j] = (uint8_t)b[i];
+            }
+        }
+        WAVE_SYNC();
+        // ---- (i) final samples leave for global memory (plain stores; nobody inside this launch reads them back)
+        {
+            const int keep = last_row ? rows_mb : rows_mb - strip; // rows below go through the ring instead
+            // region A: rows 0..keep-1, byte columns -4..11 (dword 0 is the left strip, final now)
+            if (lane < 4 * rows_mb) {
+                const int rr = lane >> 2, q = lane & 3;
+                if (rr < keep && !(q == 0 && x == 0))
+                    *(unsigned *)(plane + (row0 + rr) * stride + x0b - 4 + 4 * q) = *(const unsigned *)&tile[(rr + strip) * DB_TS + 12 + 4 * q];
+            }
+            // region B: last macroblock of the row: columns 12..15 have no right neighbour to wait for
+            if (x == mbw - 1 && lane < keep)
+                *(unsigned *)(plane + (row0 + lane) * stride + x0b + 12) = *(const unsigned *)&tile[(lane + strip) * DB_TS + 28];
+            // region C: the strip of the row above is final after this macroblock's top edge
+            if (my > 0 && lane < strip * 4) {
+                const int sr = lane >> 2, q = lane & 3;
+                *(unsigned *)(plane + (row0 - strip + sr) * stride + x0b + 4 * q) = *(const unsigned *)&tile[sr * DB_TS + 16 + 4 * q];
+            }
+        }
+        // ---- (j) bottom strip -> ring (and patch columns 12..15 of the previous macroblock's strip)
+        if (!last_row) {
+            if (lane < strip * 4) {
+                const int sr = lane >> 2, q = lane & 3;
+                ring[(x & 3) * ring_n + lane] = *(const unsigned *)&tile[(rows_mb + sr) * DB_TS + 16 + 4 * q];
+            } else if (lane < strip * 5 && x > 0) {
+                const int sr = lane - strip * 4;
+                ring[((x - 1) & 3) * ring_n + sr * 4 + 3] = *(const unsigned *)&tile[(rows_mb + sr) * DB_TS + 12];
+            }
+            if (feeds_next) { // publish finished strips to the band below: macroblock x-1 now, and x too at the row's end
+                WAVE_SYNC();
+                const int first = x > 0 ? x - 1 : x, lastp = (x == mbw - 1) ? x : x - 1;
+                for (int m = first; m <= lastp; m++)
+                    if (lane < strip * 4) {
+                        const int sr = lane >> 2, q = lane & 3;
+                        st_sc1((unsigned *)(plane + (row0 + rows_mb - strip + sr) * stride + m * 16 + 4 * q), ring[(m & 3) * ring_n + lane]);
+                    }
+                if (lastp >= first) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) st_sc1(&a.progress[pidx], (unsigned)(lastp + 1));
+                }
+            }
+        }
+        // ---- (k) right strip becomes the next macroblock's left strip
+        if (lane < rows_mb) *(unsigned *)&tile[(lane + strip) * DB_TS + 12] = *(const unsigned *)&tile[(lane + strip) * DB_TS + 28];
+    }
+}
+
 // =================================================================== staging helper
 // Replicate the last visible column/row into the coded-size margin of a staged source surface.
 __global__ void pad_kernel(uint8_t *y, uint8_t *uv, int stride, int vw, int vh, int W, int H) {
@@ -843,6 +1116,13 @@ void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag,
     if (y_hi < y_lo) return;
     hipLaunchKernelGGL(deblock_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
 }
+void k_launch_deblock_band(const frame_ctx_t *d_ctx, int mbh, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
+    int bands = (mbh + DB_R - 1) / DB_R;
+    db_args a;
+    a.ctx = d_ctx; a.progress = d_progress; a.err = d_err;
+    hipLaunchKernelGGL(deblock_band_kernel, dim3(bands), dim3(2 * DB_R * 64), 0, s, a);
+}
+int k_deblock_bands(int mbh) { return (mbh + DB_R - 1) / DB_R; }
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s) {
     int n = W * H + W * H / 2;
     hipLaunchKernelGGL(pad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, uv, stride, vis_w, vis_h, W, H);

@@ -74,12 +74,14 @@ def test_intra_kernel_matches_oracle(E, oracle, w, h, qp):
     e.close()
 
 
-@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("w,h", SIZES + [(48, 272), (1920, 1080)])
 @pytest.mark.parametrize("qp", [16, 30, 44, 51])
-def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp):
-    """Feed the oracle's own pre-filter pictures (one I, one P) and records to the HIP filter."""
+@pytest.mark.parametrize("mode", [0, 1])
+def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp, mode):
+    """Feed the oracle's own pre-filter pictures (one I, one P) and records to the HIP filter
+    (mode 0: persistent band-wavefront kernel; mode 1: one launch per x+2y wavefront)."""
     oe = oracle.Encoder(w, h, gop=60, threads=8)
-    e = E.Encoder((w + 15) // 16 * 16, (h + 15) // 16 * 16, fixed_qp=qp)
+    e = E.Encoder((w + 15) // 16 * 16, (h + 15) // 16 * 16, fixed_qp=qp, deblock_mode=mode)
     for _, _, y, uv in frames(w, h, 2):
         oe.encode(y, uv, qp)
         d_y, d_uv = e.stage_deblock(oe.prefilter_y, oe.prefilter_uv, oe.mbinfo)
@@ -89,12 +91,12 @@ def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp):
 
 
 @pytest.mark.parametrize("w,h,n", [(64, 48, 9), (176, 144, 7), (322, 182, 5), (1280, 720, 4), (1920, 1080, 3)])
-@pytest.mark.parametrize("graphs", [True, False])
-def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs):
+@pytest.mark.parametrize("graphs,mode", [(True, 0), (False, 0), (True, 1)])
+def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode):
     """Whole path: identical access units, identical reconstruction, and the independent
     decoder reproduces both."""
     qps = [30, 28, 33, 24, 40, 26, 30, 51, 10]
-    e = E.Encoder(w, h, gop=4, fixed_qp=30, use_graphs=graphs, keep_prefilter=True)
+    e = E.Encoder(w, h, gop=4, fixed_qp=30, use_graphs=graphs, keep_prefilter=True, deblock_mode=mode)
     oe = oracle.Encoder(w, h, gop=4, threads=8)
     dec = oracle.Decoder()
     for i, (_, _, y, uv) in enumerate(frames(w, h, n)):
