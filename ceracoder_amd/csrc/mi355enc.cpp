@@ -183,7 +183,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMemsetAsync(h->d_rec_y[i], 0, h->ysz + SURF_PAD, h->stream));
         HIPCHK(hipMemsetAsync(h->d_rec_uv[i], 0, h->csz + SURF_PAD, h->stream));
     }
-    h->n_progress = 2 * k_deblock_bands(h->mbh);
+    h->n_progress = k_deblock_bands(h->mbh);
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&h->h_err, sizeof(unsigned), hipHostMallocDefault));
     *h->h_err = 0;

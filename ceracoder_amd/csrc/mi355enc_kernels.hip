@@ -44,6 +44,39 @@ __device__ const dev_tables g_tab = {
     {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}},
     {0, 0}};
 
+
+// ------------------------------------------------------------------ global-memory accessors
+// Pointers read out of frame_ctx_t are generic; plain dereferences would become flat_load/
+// flat_store, which count against BOTH vmcnt and lgkmcnt -- every LDS wait would then also
+// wait for the outstanding HBM load.  These force global_* instructions.
+#define GAS __attribute__((address_space(1)))
+DEV unsigned ldg8(const void *p) { return *(const GAS uint8_t *)p; }
+DEV unsigned ldg32(const void *p) { return *(const GAS unsigned *)p; }
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+DEV uint2 ldg64(const void *p) { const v2u v = *(const GAS v2u *)p; return make_uint2(v.x, v.y); }
+DEV uint2 ldg64x(const void *p) { return make_uint2(*(const GAS unsigned *)p, *((const GAS unsigned *)p + 1)); } // 4-byte aligned pair
+DEV uint4 ldg128(const void *p) { const v4u v = *(const GAS v4u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+DEV void stg8(void *p, unsigned v) { *(GAS uint8_t *)p = (uint8_t)v; }
+DEV void stg16(void *p, int v) { *(GAS int16_t *)p = (int16_t)v; }
+DEV void stg32(void *p, unsigned v) { *(GAS unsigned *)p = v; }
+DEV void stg128(void *p, uint4 v) { v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(GAS v4u *)p = t; }
+DEV mb_info_t unpack_mbinfo(const uint4 r) {
+    mb_info_t m;
+    m.mvx = (int16_t)(r.x & 0xFFFF); m.mvy = (int16_t)(r.x >> 16);
+    m.mb_type = (uint8_t)(r.y & 255); m.i16_mode = (uint8_t)((r.y >> 8) & 255); m.chroma_mode = (uint8_t)((r.y >> 16) & 255); m.qp = (uint8_t)(r.y >> 24);
+    m.nzmask = r.z; m.cost = r.w;
+    return m;
+}
+DEV mb_info_t ld_mbinfo(const mb_info_t *p) { return unpack_mbinfo(ldg128(p)); } // one 16-byte load instead of four partial ones
+DEV void st_mbinfo(mb_info_t *p, const mb_info_t &m) {
+    uint4 r;
+    r.x = ((unsigned)(uint16_t)m.mvx) | ((unsigned)(uint16_t)m.mvy << 16);
+    r.y = (unsigned)m.mb_type | ((unsigned)m.i16_mode << 8) | ((unsigned)m.chroma_mode << 16) | ((unsigned)m.qp << 24);
+    r.z = m.nzmask; r.w = m.cost;
+    stg128(p, r);
+}
+
 DEV int iabs(int v) { return v < 0 ? -v : v; }
 DEV int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 DEV int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
@@ -93,7 +126,7 @@ __global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__
         int row = i / 10, q = i - row * 10;
         int gy = my * 16 - 16 + row, gx = sx * (ME_MBS * 16) - 16 + 16 * q;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *(const uint4 *)(ref + (size_t)gy * stride + gx);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ldg128(ref + (size_t)gy * stride + gx);
         unsigned *d = &win[row * ME_STRIDE + 4 * q];
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -115,7 +148,7 @@ __global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__
         for (int r = 0; r < 16; r++) {
             int sy = my * 16 + r;
             sy = sy < vh ? sy : vh - 1;
-            uint4 v = *(const uint4 *)(src + (size_t)sy * ss + mxc * 16);
+            uint4 v = ldg128(src + (size_t)sy * ss + mxc * 16);
             c[r][0] = v.x; c[r][1] = v.y; c[r][2] = v.z; c[r][3] = v.w;
         }
     }
@@ -175,9 +208,9 @@ __global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__
     }
     if (l == 0 && mx < mbw) {
         mb_info_t *mb = &ctx->mbi[my * mbw + mx];
-        mb->mvx = (int16_t)((int)(best & 63) - 16);
-        mb->mvy = (int16_t)((int)((best >> 6) & 63) - 16);
-        mb->cost = best >> 12;
+        const int bx_ = (int)(best & 63) - 16, by_ = (int)((best >> 6) & 63) - 16;
+        stg32(&mb->mvx, ((unsigned)(uint16_t)bx_) | ((unsigned)(uint16_t)by_ << 16));
+        stg32(&mb->cost, best >> 12);
     }
 }
 
@@ -255,7 +288,7 @@ DEV void store_levels(int16_t *dst, const int *lev) { // 16 int16 = two 16-byte 
     a.z = (lev[4] & 0xFFFF) | (lev[5] << 16); a.w = (lev[6] & 0xFFFF) | (lev[7] << 16);
     b.x = (lev[8] & 0xFFFF) | (lev[9] << 16); b.y = (lev[10] & 0xFFFF) | (lev[11] << 16);
     b.z = (lev[12] & 0xFFFF) | (lev[13] << 16); b.w = (lev[14] & 0xFFFF) | (lev[15] << 16);
-    ((uint4 *)dst)[0] = a; ((uint4 *)dst)[1] = b;
+    stg128(dst, a); stg128(dst + 8, b);
 }
 DEV unsigned pack4(int a, int b, int c, int d) { return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24); }
 DEV int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 255); }
@@ -276,7 +309,7 @@ DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int c
         for (int r = 0; r < 4; r++) {
             int sy = cy0 + by + r;
             sy = sy < vh2 ? sy : vh2 - 1;
-            uint2 w = *(const uint2 *)(s + (size_t)sy * ss + 2 * (cx0 + bx));
+            uint2 w = ldg64(s + (size_t)sy * ss + 2 * (cx0 + bx));
             unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
             x[r * 4 + 0] = (int)(lo & 255) - pred[r * 4 + 0];
             x[r * 4 + 1] = (int)((lo >> 16) & 255) - pred[r * 4 + 1];
@@ -312,7 +345,7 @@ DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int c
     // levels
     int16_t *lv = ctx->levels + (size_t)mbn * MB_LEVELS;
     store_levels(lv + L_CAC + (4 * c + b) * 16, lev);
-    lv[L_CDC + 4 * c + b] = (int16_t)ldc;
+    stg16(&lv[L_CDC + 4 * c + b], ldc);
     // reconstruction: this lane owns every other byte of 8-byte row segments
     uint8_t *__restrict__ rec = ctx->rec_uv;
     const int st = ctx->stride;
@@ -320,7 +353,7 @@ DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int c
     for (int r = 0; r < 4; r++) {
         uint8_t *p = rec + (size_t)(cy0 + by + r) * st + 2 * (cx0 + bx) + c;
 #pragma unroll
-        for (int i = 0; i < 4; i++) p[2 * i] = (uint8_t)clip255(pred[r * 4 + i] + x[r * 4 + i]);
+        for (int i = 0; i < 4; i++) stg8(p + 2 * i, (unsigned)clip255(pred[r * 4 + i] + x[r * 4 + i]));
     }
     return (nz_ac ? 1 : 0) | (nz_dc ? 2 : 0);
 }
@@ -339,7 +372,7 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
     const bool mb_ok = mbn < nmb;
     if (!mb_ok) mbn = nmb - 1;
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
-    const mb_info_t info = ctx->mbi[mbn];
+    const mb_info_t info = ld_mbinfo(&ctx->mbi[mbn]);
     const int mvx = clip3(-x0, W - 16 - x0, info.mvx), mvy = clip3(-y0, H - 16 - y0, info.mvy);
     int flags = 0; // bit0: AC/any nonzero, bit1: chroma DC nonzero
     if (is_luma && mb_ok) {
@@ -353,10 +386,10 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
         for (int r = 0; r < 4; r++) {
             int sy = y0 + by + r;
             sy = sy < vh ? sy : vh - 1;
-            unsigned sw = *(const unsigned *)(s + (size_t)sy * ss + x0 + bx);
+            unsigned sw = ldg32(s + (size_t)sy * ss + x0 + bx);
             size_t a = (size_t)(y0 + by + r + mvy) * stride + (x0 + bx + mvx);
-            const unsigned *ap = (const unsigned *)(rf + (a & ~(size_t)3));
-            unsigned pw = __builtin_amdgcn_alignbyte(ap[1], ap[0], (unsigned)(a & 3));
+            const uint2 apw = ldg64x(rf + (a & ~(size_t)3));
+            unsigned pw = __builtin_amdgcn_alignbyte(apw.y, apw.x, (unsigned)(a & 3));
 #pragma unroll
             for (int i = 0; i < 4; i++) { pr[r * 4 + i] = byte_of(pw, i); x[r * 4 + i] = byte_of(sw, i) - pr[r * 4 + i]; }
         }
@@ -367,9 +400,9 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
         uint8_t *__restrict__ rec = ctx->rec_y;
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            *(unsigned *)(rec + (size_t)(y0 + by + r) * stride + x0 + bx) =
-                pack4(clip255(pr[r * 4] + x[r * 4]), clip255(pr[r * 4 + 1] + x[r * 4 + 1]),
-                      clip255(pr[r * 4 + 2] + x[r * 4 + 2]), clip255(pr[r * 4 + 3] + x[r * 4 + 3]));
+            stg32(rec + (size_t)(y0 + by + r) * stride + x0 + bx,
+                  pack4(clip255(pr[r * 4] + x[r * 4]), clip255(pr[r * 4 + 1] + x[r * 4 + 1]),
+                        clip255(pr[r * 4 + 2] + x[r * 4 + 2]), clip255(pr[r * 4 + 3] + x[r * 4 + 3])));
         flags = nz ? 1 : 0;
     }
     if (is_chroma) { // all 16 lanes run (shuffles inside); stores are predicated by mb_ok via mbn clamp
@@ -385,7 +418,7 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
 #pragma unroll
             for (int i = 0; i < 5; i++) {
                 int xx = clip3(0, cw - 1, cx0 + bx + i + xi);
-                smp[r][i] = rf[(size_t)yy * stride + 2 * xx + c];
+                smp[r][i] = (int)ldg8(rf + (size_t)yy * stride + 2 * xx + c);
             }
         }
         int pr[16];
@@ -408,12 +441,13 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
         if ((dcm >> (32 + 8 * s2)) & 0x0F) nzm |= NZ_CBDC;
         if ((dcm >> (32 + 8 * s2)) & 0xF0) nzm |= NZ_CRDC;
         mb_info_t *mb = &ctx->mbi[mbn];
-        mb->mb_type = 1; mb->i16_mode = 0; mb->chroma_mode = 0; mb->qp = (uint8_t)qp; mb->nzmask = nzm;
+        stg32(&mb->mb_type, 1u | ((unsigned)qp << 24)); // mb_type 1, modes 0, qp
+        stg32(&mb->nzmask, nzm);
     }
     // luma DC levels are unused by P macroblocks but part of the record: keep them zero
     if (is_luma && mb_ok && (lane & 15) < 2) {
         uint4 z = make_uint4(0, 0, 0, 0);
-        ((uint4 *)(ctx->levels + (size_t)mbn * MB_LEVELS + L_LDC))[lane & 15] = z;
+        stg128(ctx->levels + (size_t)mbn * MB_LEVELS + L_LDC + 8 * (lane & 15), z);
     }
 }
 
@@ -445,12 +479,12 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     int (*left)[17] = sh_left;
     if (lane >= 24 && lane < 24 + 17) { // lanes 24-40: luma neighbours; index i+1 holds sample i, index 0 the corner
         int i = lane - 24 - 1;
-        top[0][i + 1] = has_top && (i >= 0 || has_left) ? ry[(size_t)(y0 - 1) * stride + x0 + i] : 0;
-        left[0][i + 1] = has_left && (i >= 0 || has_top) ? ry[(size_t)(y0 + i) * stride + x0 - 1] : 0;
+        top[0][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ry + (size_t)(y0 - 1) * stride + x0 + i) : 0;
+        left[0][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ry + (size_t)(y0 + i) * stride + x0 - 1) : 0;
     } else if (lane >= 41 && lane < 41 + 18) { // lanes 41-58: chroma neighbours
         int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
-        top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? ruv[(size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c] : 0;
-        left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? ruv[(size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c] : 0;
+        top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c) : 0;
+        left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c) : 0;
     }
     int src[16];
     if (lane < 24) {
@@ -462,7 +496,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
             for (int r = 0; r < 4; r++) {
                 int sy = y0 + by + r;
                 sy = sy < vh ? sy : vh - 1;
-                unsigned sw = *(const unsigned *)(s + (size_t)sy * ss + x0 + bx);
+                unsigned sw = ldg32(s + (size_t)sy * ss + x0 + bx);
 #pragma unroll
                 for (int i = 0; i < 4; i++) src[r * 4 + i] = byte_of(sw, i);
             }
@@ -473,7 +507,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
             for (int r = 0; r < 4; r++) {
                 int sy = cy0 + by + r;
                 sy = sy < vh2 ? sy : vh2 - 1;
-                uint2 w = *(const uint2 *)(s + (size_t)sy * ss + 2 * (cx0 + bx));
+                uint2 w = ldg64(s + (size_t)sy * ss + 2 * (cx0 + bx));
                 unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
                 src[r * 4 + 0] = (int)(lo & 255); src[r * 4 + 1] = (int)((lo >> 16) & 255);
                 src[r * 4 + 2] = (int)(hi & 255); src[r * 4 + 3] = (int)((hi >> 16) & 255);
@@ -556,7 +590,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
         int kz = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) if (zz(k) == lane) kz = k;
-        ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + kz] = (int16_t)ldc;
+        stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + kz], ldc);
         if (ldc) flags |= 2;
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
@@ -576,9 +610,9 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
         idct4(x);
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            *(unsigned *)(ry + (size_t)(y0 + by + r) * stride + x0 + bx) =
-                pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
-                      clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3]));
+            stg32(ry + (size_t)(y0 + by + r) * stride + x0 + bx,
+                  pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
+                        clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3])));
     } else if (lane < 32) { // lanes 16-31 form one shuffle group; 16-23 do chroma, 24-31 pad with zeros
         const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
         const int p = 1 + c;
@@ -648,7 +682,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
         mb_info_t mb;
         mb.mvx = 0; mb.mvy = 0; mb.mb_type = 0; mb.i16_mode = (uint8_t)mode; mb.chroma_mode = (uint8_t)cmode;
         mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = sad_sel + (unsigned)csad;
-        ctx->mbi[mbn] = mb;
+        st_mbinfo(&ctx->mbi[mbn], mb);
     }
 }
 
@@ -722,9 +756,9 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
     const int lane = threadIdx.x;
     uint8_t *__restrict__ ry = ctx->rec_y;
     uint8_t *__restrict__ ruv = ctx->rec_uv;
-    const mb_info_t cur = ctx->mbi[my * mbw + mx];
-    const mb_info_t lft = ctx->mbi[my * mbw + (mx > 0 ? mx - 1 : mx)];
-    const mb_info_t upp = ctx->mbi[(my > 0 ? my - 1 : my) * mbw + mx];
+    const mb_info_t cur = ld_mbinfo(&ctx->mbi[my * mbw + mx]);
+    const mb_info_t lft = ld_mbinfo(&ctx->mbi[my * mbw + (mx > 0 ? mx - 1 : mx)]);
+    const mb_info_t upp = ld_mbinfo(&ctx->mbi[(my > 0 ? my - 1 : my) * mbw + mx]);
     // ---- every global load of this macroblock is issued here, before the first wait
     for (int i = lane; i < TAB_DWORDS; i += 64) tabw[i] = ((const unsigned *)&g_tab)[i];
     // ---- load tiles (skipping the corner, which this macroblock neither reads nor writes)
@@ -732,13 +766,13 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
         int r = i / 5, q = i - r * 5;
         int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
         if (gy >= 0 && gx >= 0 && !(r < 4 && q == 0))
-            *(unsigned *)&tl[r * TLS + 4 * q] = *(const unsigned *)(ry + (size_t)gy * stride + gx);
+            *(unsigned *)&tl[r * TLS + 4 * q] = ldg32(ry + (size_t)gy * stride + gx);
     }
     if (lane < 50) {
         int r = lane / 5, q = lane - r * 5;
         int gy = cy0 - 2 + r, gb = x0 - 4 + 4 * q; // chroma byte offset 2*cx0 = x0
         if (gy >= 0 && gb >= 0 && !(r < 2 && q == 0))
-            *(unsigned *)&tc[r * TLS + 4 * q] = *(const unsigned *)(ruv + (size_t)gy * stride + gb);
+            *(unsigned *)&tc[r * TLS + 4 * q] = ldg32(ruv + (size_t)gy * stride + gb);
     }
     __syncthreads();
     const int qpc_c = T->qpc[cur.qp], qpc_l = T->qpc[lft.qp], qpc_u = T->qpc[upp.qp];
@@ -791,13 +825,13 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
         int r = i / 5, q = i - r * 5;
         int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
         if (gy >= 0 && gx >= 0 && !(r < 4 && q == 0))
-            *(unsigned *)(ry + (size_t)gy * stride + gx) = *(const unsigned *)&tl[r * TLS + 4 * q];
+            stg32(ry + (size_t)gy * stride + gx, *(const unsigned *)&tl[r * TLS + 4 * q]);
     }
     if (lane < 50) {
         int r = lane / 5, q = lane - r * 5;
         int gy = cy0 - 2 + r, gb = x0 - 4 + 4 * q;
         if (gy >= 0 && gb >= 0 && !(r < 2 && q == 0))
-            *(unsigned *)(ruv + (size_t)gy * stride + gb) = *(const unsigned *)&tc[r * TLS + 4 * q];
+            stg32(ruv + (size_t)gy * stride + gb, *(const unsigned *)&tc[r * TLS + 4 * q]);
     }
 }
 
@@ -818,24 +852,36 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 // bytes with sc1 loads).  A band waits only on the band above it, so the wait graph is acyclic;
 // every spin is bounded and reports through ctx-independent `err`.
 #define DB_R 4
+static_assert(DB_R == 4, "the I/O wave maps lane>>4 to the band's rows");
 #define DB_TS 32 /* tile row stride; column c of the macroblock lives at byte 16 + c, the left strip at 12..15 */
 #define DB_SPIN_MAX (1 << 20)
 
 struct db_luma_lds { uint8_t t[20 * DB_TS]; unsigned ring[4][16]; };   // rows -4..15
 struct db_chroma_lds { uint8_t t[10 * DB_TS]; unsigned ring[4][8]; };  // rows -2..7
 
-DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// workgroup barrier that drains LDS traffic only: global loads (prefetch) and stores stay in flight
+#define BAND_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// one luma line across an edge, samples in registers
-DEV void edge_luma(const dev_tables *T, int &p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int &q3, int bS, int qpav) {
+// filter parameters of one edge class (left / top / inner), looked up once per macroblock
+struct edge_par { int alpha, beta, tc0[3]; };
+DEV edge_par make_par(const dev_tables *T, int qpav) {
+    edge_par p;
+    p.alpha = T->alpha[qpav]; p.beta = T->beta[qpav];
+    p.tc0[0] = T->tc0[qpav][0]; p.tc0[1] = T->tc0[qpav][1]; p.tc0[2] = T->tc0[qpav][2];
+    return p;
+}
+DEV int tc0_of(const edge_par &P, int bS) { return bS == 1 ? P.tc0[0] : bS == 2 ? P.tc0[1] : P.tc0[2]; }
+// one luma line across an edge, samples in registers (8.7.2.3 / 8.7.2.4)
+DEV void edge_luma(const edge_par &P, int &p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int &q3, int bS) {
     (void)p3; (void)q3;
-    const int alpha = T->alpha[qpav], beta = T->beta[qpav];
-    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    const int alpha = P.alpha, beta = P.beta;
+    if (bS == 0 || !(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
     const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
     if (bS < 4) {
-        const int tc0 = T->tc0[qpav][bS - 1];
+        const int tc0 = tc0_of(P, bS);
         const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
         const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
         const int avg = (p0 + q0 + 1) >> 1;
@@ -854,11 +900,10 @@ DEV void edge_luma(const dev_tables *T, int &p3, int &p2, int &p1, int &p0, int 
         p0 = np0; p1 = np1; p2 = np2; q0 = nq0; q1 = nq1; q2 = nq2;
     }
 }
-DEV void edge_chroma(const dev_tables *T, int p1, int &p0, int &q0, int q1, int bS, int qpav) {
-    const int alpha = T->alpha[qpav], beta = T->beta[qpav];
-    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+DEV void edge_chroma(const edge_par &P, int p1, int &p0, int &q0, int q1, int bS) {
+    if (bS == 0 || !(iabs(p0 - q0) < P.alpha && iabs(p1 - p0) < P.beta && iabs(q1 - q0) < P.beta)) return;
     if (bS < 4) {
-        const int tc = T->tc0[qpav][bS - 1] + 1;
+        const int tc = tc0_of(P, bS) + 1;
         const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
         p0 = clip255(p0 + dl); q0 = clip255(q0 - dl);
     } else {
@@ -878,23 +923,104 @@ DEV void db_wait(unsigned *progress, unsigned *err, int idx, int need) {
     }
 }
 
-__global__ __launch_bounds__(2 * DB_R * 64) void deblock_band_kernel(db_args a) {
+// What the I/O wave stages in LDS for one macroblock row and one step.
+struct db_stage {
+    uint4 luma[16], chroma[8]; // the macroblock's unfiltered rows
+    uint4 cur, top;            // raw mb_info_t of the macroblock and of the one above it
+    uint4 strip_l[4], strip_c[2]; // bottom strip of the band above (first row of a band only)
+};
+
+// Work-group layout: waves 0..DB_R-1 filter LUMA of rows band*DB_R + r, waves DB_R..2*DB_R-1 the
+// CHROMA of the same rows, wave 2*DB_R is the I/O wave.  The compute waves touch global memory
+// only with fire-and-forget stores; every load (macroblock rows, records, strips of the band
+// above) is issued by the I/O wave two steps ahead and handed over through LDS, and the I/O
+// wave also publishes finished strips to the band below -- so all `s_waitcnt vmcnt` stalls sit
+// on a wave that has a whole step of slack, never on the dependency chain.
+__global__ __launch_bounds__((2 * DB_R + 1) * 64) void deblock_band_kernel(db_args a) {
     __shared__ __attribute__((aligned(16))) db_luma_lds LL[DB_R];
     __shared__ __attribute__((aligned(16))) db_chroma_lds CL[DB_R];
+    __shared__ __attribute__((aligned(16))) db_stage ST[2][DB_R];
     __shared__ unsigned tabw[TAB_DWORDS];
     const dev_tables *T = (const dev_tables *)tabw;
     const frame_ctx_t *__restrict__ ctx = a.ctx;
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
     const int band = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool chroma = wave >= DB_R;
-    const int r = chroma ? wave - DB_R : wave;
+    const bool io = wave == 2 * DB_R;
+    const bool chroma = !io && wave >= DB_R;
+    const int r = io ? 0 : (chroma ? wave - DB_R : wave);
+    for (int i = threadIdx.x; i < TAB_DWORDS; i += (2 * DB_R + 1) * 64) tabw[i] = ((const unsigned *)&g_tab)[i];
+    const int nsteps = mbw + 2 * (DB_R - 1); // compute steps; iteration j runs compute step j-2
+    const int niter = mbw + 2 * DB_R + 3;
+    const mb_info_t *__restrict__ mbi = ctx->mbi;
+
+    if (io) {
+        // ------------------------------------------------------------------ I/O wave
+        uint8_t *__restrict__ py = ctx->rec_y;
+        uint8_t *__restrict__ pc = ctx->rec_uv;
+        const int lr = lane >> 4, li = lane & 15;          // this lane serves row lr of the band, item li
+        const int my = band * DB_R + lr;
+        const bool row_ok = my < mbh;
+        const bool fed = row_ok && lr == 0 && band > 0;     // first row of a band: strips come from the band above
+        const int last_r = (mbh - 1 - band * DB_R) < (DB_R - 1) ? -1 : DB_R - 1; // feeding row, or -1 if this band holds the last row
+        const bool feeds = last_r >= 0 && (band * DB_R + last_r) != mbh - 1;
+        const size_t fy = (size_t)(band * DB_R + DB_R - 1) * 16 + 12, fc = (size_t)(band * DB_R + DB_R - 1) * 8 + 6; // strip rows of the feeding row
+        uint4 vA = make_uint4(0, 0, 0, 0), vB = make_uint4(0, 0, 0, 0);
+        bool haveA = false;
+        int flag_due = 0;
+        unsigned avail = 0;
+        for (int j = 0; j < niter; j++) {
+            BAND_BARRIER();
+            // (1) everything this wave issued one iteration ago has had a whole step to land
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (feeds && flag_due && lane == 0) st_sc1(&a.progress[band], (unsigned)flag_due);
+            // (2) hand the data loaded during iteration j-1 (for compute step j-1) over through LDS
+            if (haveA) {
+                db_stage *S = &ST[(j - 1) & 1][lr];
+                S->luma[li] = vA;
+                if (li < 8) S->chroma[li] = vB;
+                else if (li == 8) S->cur = vB;
+                else if (li == 9) S->top = vB;
+                else if (li < 14) S->strip_l[li - 10] = vB;
+                else S->strip_c[li - 14] = vB;
+            }
+            // (3) issue the loads for compute step j (runs at iteration j+2)
+            {
+                const int x = j - 2 * lr;
+                haveA = row_ok && x >= 0 && x < mbw && j < nsteps;
+                if (haveA) {
+                    // `avail` was read one iteration ago (landed under the vmcnt(0) above): in steady state no poll is needed here
+                    if (fed && (int)avail < x + 1) db_wait(a.progress, a.err, band - 1, x + 1);
+                    vA = ldg128(py + ((size_t)my * 16 + li) * stride + x * 16);
+                    if (li < 8) vB = ldg128(pc + ((size_t)my * 8 + li) * stride + x * 16);
+                    else if (li == 8) vB = ldg128(&mbi[my * mbw + x]);
+                    else if (li == 9) vB = my > 0 ? ldg128(&mbi[(my - 1) * mbw + x]) : make_uint4(0, 1u, 0, 0);
+                    else if (fed) {
+                        const uint8_t *sp = li < 14 ? py + ((size_t)my * 16 - 4 + (li - 10)) * stride + x * 16
+                                                    : pc + ((size_t)my * 8 - 2 + (li - 14)) * stride + x * 16;
+                        vB.x = ld_sc1((const unsigned *)sp); vB.y = ld_sc1((const unsigned *)sp + 1);
+                        vB.z = ld_sc1((const unsigned *)sp + 2); vB.w = ld_sc1((const unsigned *)sp + 3);
+                    }
+                }
+                if (fed) avail = ld_sc1(&a.progress[band - 1]); // for the next iteration; costs nothing here
+            }
+            // (4) publish the strip that became final when compute step j-3 finished: macroblock j - 2*DB_R - 2 of the feeding row
+            if (feeds) {
+                const int m = j - 2 * DB_R - 2;
+                if (m >= 0 && m < mbw) {
+                    if (lane < 16) st_sc1((unsigned *)(py + (fy + (lane >> 2)) * stride + m * 16 + 4 * (lane & 3)), LL[DB_R - 1].ring[m & 3][lane]);
+                    else if (lane < 24) st_sc1((unsigned *)(pc + (fc + ((lane - 16) >> 2)) * stride + m * 16 + 4 * (lane & 3)), CL[DB_R - 1].ring[m & 3][lane - 16]);
+                    flag_due = m + 1;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
     const int my = band * DB_R + r;
     const bool row_ok = my < mbh;
     const bool last_row = my == mbh - 1;
-    // the row whose bottom strips feed the next band (none if this band holds the picture's last row)
-    const bool feeds_next = row_ok && r == DB_R - 1 && !last_row;
     const bool fed_by_prev = row_ok && r == 0 && band > 0;
-    for (int i = threadIdx.x; i < TAB_DWORDS; i += 2 * DB_R * 64) tabw[i] = ((const unsigned *)&g_tab)[i];
     uint8_t *__restrict__ plane = chroma ? ctx->rec_uv : ctx->rec_y;
     const int rows_mb = chroma ? 8 : 16, strip = chroma ? 2 : 4; // rows per macroblock, rows per hand-off strip
     const size_t row0 = (size_t)my * rows_mb;                     // first plane row of this macroblock row
@@ -902,50 +1028,47 @@ __global__ __launch_bounds__(2 * DB_R * 64) void deblock_band_kernel(db_args a) 
     unsigned *ring = chroma ? &CL[r].ring[0][0] : &LL[r].ring[0][0];
     const unsigned *ring_up = r > 0 ? (chroma ? &CL[r - 1].ring[0][0] : &LL[r - 1].ring[0][0]) : nullptr;
     const int ring_n = chroma ? 8 : 16;                            // dwords per ring slot
-    const int pidx = 2 * band + (chroma ? 1 : 0);
-    const mb_info_t *__restrict__ mbi = ctx->mbi;
-
-    // prefetch registers: this lane's row of the next macroblock, and the records it needs
-    uint4 pre = make_uint4(0, 0, 0, 0);
     mb_info_t cur, lft, upp;
     cur.mb_type = lft.mb_type = upp.mb_type = 1; cur.qp = lft.qp = upp.qp = 0; cur.nzmask = lft.nzmask = upp.nzmask = 0;
     cur.mvx = cur.mvy = lft.mvx = lft.mvy = upp.mvx = upp.mvy = 0;
-    mb_info_t nxt_cur = cur, nxt_upp = cur;
-    if (row_ok) {
-        if (lane < rows_mb) pre = *(const uint4 *)(plane + (row0 + lane) * stride);
-        nxt_cur = mbi[my * mbw];
-        if (my > 0) nxt_upp = mbi[(my - 1) * mbw];
-    }
-    const int nsteps = mbw + 2 * (DB_R - 1);
-    for (int t = 0; t < nsteps; t++) {
-        const int x = t - 2 * r;
-        const bool act = row_ok && x >= 0 && x < mbw;
-        if (act && fed_by_prev && lane == 0) db_wait(a.progress, a.err, pidx - 2, x + 1);
-        __syncthreads();
+    for (int j = 0; j < niter; j++) {
+        const int t = j - 2, x = t - 2 * r;
+        const bool act = row_ok && t >= 0 && t < nsteps && x >= 0 && x < mbw;
+        BAND_BARRIER();
         if (!act) continue;
-        lft = cur; cur = nxt_cur; upp = nxt_upp;
+        const db_stage *S = &ST[t & 1][r];
+        lft = cur; cur = unpack_mbinfo(S->cur); upp = unpack_mbinfo(S->top);
         const int x0b = x * 16; // byte offset of the macroblock in a plane row (luma: 16 px, chroma: 8 px x 2 planes)
         // ---- (a) own rows into the tile
-        if (lane < rows_mb) *(uint4 *)&tile[(lane + strip) * DB_TS + 16] = pre;
-        // ---- (b) top strip: LDS ring of the row above, or global (sc1) across a band boundary
+        if (lane < rows_mb) *(uint4 *)&tile[(lane + strip) * DB_TS + 16] = chroma ? S->chroma[lane] : S->luma[lane];
+        // ---- (b) top strip: LDS ring of the row above, or the staged strip of the band above
         if (my > 0 && lane < strip * 4) {
-            const int sr = lane >> 2, q = lane & 3;
             unsigned v;
-            if (r > 0) v = ring_up[(x & 3) * ring_n + lane];
-            else v = ld_sc1((const unsigned *)(plane + (row0 - strip + sr) * stride + x0b + 4 * q));
-            *(unsigned *)&tile[sr * DB_TS + 16 + 4 * q] = v;
+            if (fed_by_prev) v = chroma ? ((const unsigned *)S->strip_c)[lane] : ((const unsigned *)S->strip_l)[lane];
+            else v = ring_up[(x & 3) * ring_n + lane];
+            *(unsigned *)&tile[(lane >> 2) * DB_TS + 16 + 4 * (lane & 3)] = v;
         }
-        // ---- prefetch the next macroblock while this one is filtered
-        if (x + 1 < mbw) {
-            if (lane < rows_mb) pre = *(const uint4 *)(plane + (row0 + lane) * stride + x0b + 16);
-            nxt_cur = mbi[my * mbw + x + 1];
-            if (my > 0) nxt_upp = mbi[(my - 1) * mbw + x + 1];
+        // ---- boundary strengths of the whole macroblock at once: lane l < 32 owns (dir = l>>4, edge = (l>>2)&3, segment = l&3)
+        int bsv = 0;
+        if (lane < 32) {
+            const int dir = lane >> 4, e = (lane >> 2) & 3, sg = lane & 3;
+            if (dir == 0) { if (!(e == 0 && x == 0)) bsv = bs_of(e == 0 ? lft : cur, e == 0 ? 3 : e - 1, sg, cur, e, sg, e == 0); }
+            else if (!(e == 0 && my == 0)) bsv = bs_of(e == 0 ? upp : cur, sg, e == 0 ? 3 : e - 1, cur, sg, e, e == 0);
         }
+        const unsigned long long bm = __ballot(bsv != 0) & (chroma ? 0x0F0F0F0Full : 0xFFFFFFFFull); // chroma filters edges 0 and 2 only
+        const bool anyV = (bm & 0xFFFFull) != 0, anyH = (bm >> 16) != 0; // wave-uniform
+        // this lane's strengths for both passes (luma: line k -> segment k>>2; chroma rows: k>>1, chroma byte columns: j>>2)
+        const int segV = chroma ? (lane >> 1) & 3 : (lane >> 2) & 3, segH = (lane >> 2) & 3;
+        int bsV[4], bsH[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { bsV[e] = __shfl(bsv, e * 4 + segV); bsH[e] = __shfl(bsv, 16 + e * 4 + segH); }
         WAVE_SYNC();
         if (!chroma) {
+            const edge_par PI = make_par(T, cur.qp);
             // ---- (e) vertical edges: lane k < 16 owns picture row k of the macroblock
-            if (lane < 16) {
+            if (anyV && lane < 16) {
                 const int k = lane;
+                const edge_par PL = make_par(T, clip3(0, 51, (lft.qp + cur.qp + 1) >> 1));
                 unsigned w5[5];
 #pragma unroll
                 for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 4) * DB_TS + 12 + 4 * i];
@@ -953,40 +1076,35 @@ __global__ __launch_bounds__(2 * DB_R * 64) void deblock_band_kernel(db_args a) 
 #pragma unroll
                 for (int i = 0; i < 20; i++) px[i] = byte_of(w5[i >> 2], i & 3);
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (e == 0 && x == 0) continue;
-                    const mb_info_t &mp = e == 0 ? lft : cur;
-                    const int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 2, cur, e, k >> 2, e == 0);
-                    if (bS) edge_luma(T, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6],
-                                      px[4 * e + 7], bS, clip3(0, 51, (mp.qp + cur.qp + 1) >> 1));
-                }
+                for (int e = 0; e < 4; e++)
+                    edge_luma(e == 0 ? PL : PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6],
+                              px[4 * e + 7], bsV[e]);
 #pragma unroll
                 for (int i = 0; i < 5; i++)
                     *(unsigned *)&tile[(k + 4) * DB_TS + 12 + 4 * i] = pack4(px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]);
             }
             WAVE_SYNC();
             // ---- (g) horizontal edges: lane k < 16 owns picture column k
-            if (lane < 16) {
+            if (anyH && lane < 16) {
                 const int k = lane;
+                const edge_par PT = make_par(T, clip3(0, 51, (upp.qp + cur.qp + 1) >> 1));
                 int px[20];
 #pragma unroll
                 for (int i = 0; i < 20; i++) px[i] = tile[i * DB_TS + 16 + k];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    if (e == 0 && my == 0) continue;
-                    const mb_info_t &mp = e == 0 ? upp : cur;
-                    const int bS = bs_of(mp, k >> 2, e == 0 ? 3 : e - 1, cur, k >> 2, e, e == 0);
-                    if (bS) edge_luma(T, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6],
-                                      px[4 * e + 7], bS, clip3(0, 51, (mp.qp + cur.qp + 1) >> 1));
-                }
+                for (int e = 0; e < 4; e++)
+                    edge_luma(e == 0 ? PT : PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6],
+                              px[4 * e + 7], bsH[e]);
 #pragma unroll
                 for (int i = 1; i < 19; i++) tile[i * DB_TS + 16 + k] = (uint8_t)px[i];
             }
         } else {
-            const int qc = T->qpc[cur.qp], ql = T->qpc[lft.qp], qu = T->qpc[upp.qp];
+            const int qc = T->qpc[cur.qp];
+            const edge_par PI = make_par(T, qc);
             // ---- vertical edges: lane k < 8 owns chroma row k (both planes, interleaved bytes)
-            if (lane < 8) {
+            if (anyV && lane < 8) {
                 const int k = lane;
+                const edge_par PL = make_par(T, (T->qpc[lft.qp] + qc + 1) >> 1);
                 unsigned w5[5];
 #pragma unroll
                 for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 2) * DB_TS + 12 + 4 * i];
@@ -994,37 +1112,26 @@ __global__ __launch_bounds__(2 * DB_R * 64) void deblock_band_kernel(db_args a) 
 #pragma unroll
                 for (int i = 0; i < 20; i++) b[i] = byte_of(w5[i >> 2], i & 3);
 #pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    if (e == 0 && x == 0) continue;
-                    const mb_info_t &mp = e == 0 ? lft : cur;
-                    const int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 1, cur, e, k >> 1, e == 0);
-                    if (bS) {
-                        const int qa = (e == 0 ? (ql + qc + 1) >> 1 : qc);
+                for (int e = 0; e < 4; e += 2)
 #pragma unroll
-                        for (int c = 0; c < 2; c++) // q0 of plane c sits at byte 4 + 4e + c; neighbours 2 bytes apart
-                            edge_chroma(T, b[4 * e + c], b[4 * e + 2 + c], b[4 * e + 4 + c], b[4 * e + 6 + c], bS, qa);
-                    }
-                }
+                    for (int c = 0; c < 2; c++) // q0 of plane c sits at byte 4 + 4e + c; neighbours 2 bytes apart
+                        edge_chroma(e == 0 ? PL : PI, b[4 * e + c], b[4 * e + 2 + c], b[4 * e + 4 + c], b[4 * e + 6 + c], bsV[e]);
 #pragma unroll
                 for (int i = 0; i < 5; i++)
                     *(unsigned *)&tile[(k + 2) * DB_TS + 12 + 4 * i] = pack4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
             }
             WAVE_SYNC();
             // ---- horizontal edges: lane j < 16 owns byte column j (8 samples x 2 planes)
-            if (lane < 16) {
-                const int j = lane;
+            if (anyH && lane < 16) {
+                const int jc = lane;
+                const edge_par PT = make_par(T, (T->qpc[upp.qp] + qc + 1) >> 1);
                 int b[10];
 #pragma unroll
-                for (int i = 0; i < 10; i++) b[i] = tile[i * DB_TS + 16 + j];
+                for (int i = 0; i < 10; i++) b[i] = tile[i * DB_TS + 16 + jc];
 #pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    if (e == 0 && my == 0) continue;
-                    const mb_info_t &mp = e == 0 ? upp : cur;
-                    const int bS = bs_of(mp, j >> 2, e == 0 ? 3 : e - 1, cur, j >> 2, e, e == 0);
-                    if (bS) edge_chroma(T, b[2 * e], b[2 * e + 1], b[2 * e + 2], b[2 * e + 3], bS, e == 0 ? (qu + qc + 1) >> 1 : qc);
-                }
+                for (int e = 0; e < 4; e += 2) edge_chroma(e == 0 ? PT : PI, b[2 * e], b[2 * e + 1], b[2 * e + 2], b[2 * e + 3], bsH[e]);
 #pragma unroll
-                for (int i = 1; i < 9; i++) tile[i * DB_TS + 16 + j] = (uint8_t)b[i];
+                for (int i = 1; i < 9; i++) tile[i * DB_TS + 16 + jc] = (uint8_t)b[i];
             }
         }
         WAVE_SYNC();
@@ -1035,15 +1142,15 @@ __global__ __launch_bounds__(2 * DB_R * 64) void deblock_band_kernel(db_args a) 
             if (lane < 4 * rows_mb) {
                 const int rr = lane >> 2, q = lane & 3;
                 if (rr < keep && !(q == 0 && x == 0))
-                    *(unsigned *)(plane + (row0 + rr) * stride + x0b - 4 + 4 * q) = *(const unsigned *)&tile[(rr + strip) * DB_TS + 12 + 4 * q];
+                    stg32(plane + (row0 + rr) * stride + x0b - 4 + 4 * q, *(const unsigned *)&tile[(rr + strip) * DB_TS + 12 + 4 * q]);
             }
             // region B: last macroblock of the row: columns 12..15 have no right neighbour to wait for
             if (x == mbw - 1 && lane < keep)
-                *(unsigned *)(plane + (row0 + lane) * stride + x0b + 12) = *(const unsigned *)&tile[(lane + strip) * DB_TS + 28];
+                stg32(plane + (row0 + lane) * stride + x0b + 12, *(const unsigned *)&tile[(lane + strip) * DB_TS + 28]);
             // region C: the strip of the row above is final after this macroblock's top edge
             if (my > 0 && lane < strip * 4) {
                 const int sr = lane >> 2, q = lane & 3;
-                *(unsigned *)(plane + (row0 - strip + sr) * stride + x0b + 4 * q) = *(const unsigned *)&tile[sr * DB_TS + 16 + 4 * q];
+                stg32(plane + (row0 - strip + sr) * stride + x0b + 4 * q, *(const unsigned *)&tile[sr * DB_TS + 16 + 4 * q]);
             }
         }
         // ---- (j) bottom strip -> ring (and patch columns 12..15 of the previous macroblock's strip)
@@ -1054,19 +1161,6 @@ __global__ __launch_bounds__(2 * DB_R * 64) void deblock_band_kernel(db_args a) 
             } else if (lane < strip * 5 && x > 0) {
                 const int sr = lane - strip * 4;
                 ring[((x - 1) & 3) * ring_n + sr * 4 + 3] = *(const unsigned *)&tile[(rows_mb + sr) * DB_TS + 12];
-            }
-            if (feeds_next) { // publish finished strips to the band below: macroblock x-1 now, and x too at the row's end
-                WAVE_SYNC();
-                const int first = x > 0 ? x - 1 : x, lastp = (x == mbw - 1) ? x : x - 1;
-                for (int m = first; m <= lastp; m++)
-                    if (lane < strip * 4) {
-                        const int sr = lane >> 2, q = lane & 3;
-                        st_sc1((unsigned *)(plane + (row0 + rows_mb - strip + sr) * stride + m * 16 + 4 * q), ring[(m & 3) * ring_n + lane]);
-                    }
-                if (lastp >= first) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) st_sc1(&a.progress[pidx], (unsigned)(lastp + 1));
-                }
             }
         }
         // ---- (k) right strip becomes the next macroblock's left strip
@@ -1120,7 +1214,7 @@ void k_launch_deblock_band(const frame_ctx_t *d_ctx, int mbh, unsigned *d_progre
     int bands = (mbh + DB_R - 1) / DB_R;
     db_args a;
     a.ctx = d_ctx; a.progress = d_progress; a.err = d_err;
-    hipLaunchKernelGGL(deblock_band_kernel, dim3(bands), dim3(2 * DB_R * 64), 0, s, a);
+    hipLaunchKernelGGL(deblock_band_kernel, dim3(bands), dim3((2 * DB_R + 1) * 64), 0, s, a);
 }
 int k_deblock_bands(int mbh) { return (mbh + DB_R - 1) / DB_R; }
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s) {
