@@ -91,16 +91,21 @@ DEV int xcd_remap(int wg, int n) {
 }
 
 // =================================================================== motion search
-// One workgroup = 8 horizontally adjacent macroblocks of one macroblock row, 4 waves.
-// The 48 x 160 luma search window (+-16 around the strip) is staged once in LDS; each
-// 32-lane half-wave owns one macroblock: lane l < 27 owns the candidates
-//   dy in [-16 + 11*(l/9), +11)   x   dx in [-16 + 4*(l%9), +4)
-// and accumulates them with v_qsad_pk_u16_u8 (4 SADs of 4 pixels per instruction),
-// re-using each window row for the 11 dy it serves.  The (cost,dy,dx) minimum is then
-// reduced over the half-wave with cross-lane shuffles.
-#define ME_MBS 8
-#define ME_ROWS 48
-#define ME_STRIDE 59 /* words; 11*59 mod 32 = 9 -> the three dy-groups hit disjoint banks */
+// One workgroup = ME_MBS horizontally adjacent macroblocks of one macroblock row, one wave per
+// macroblock.  The 48 x (16*ME_MBS+32) luma search window (+-16 around the strip) is staged once in
+// LDS.  Lane l < 63 of a wave owns the candidates
+//   dy in [-16 + 5*(l/9), +5)   x   dx in [-16 + 4*(l%9), +4)
+// (7 x 9 tiles cover 35 x 36 >= 33 x 33; 85 % of the computed SADs are real candidates) and
+// accumulates them with v_qsad_pk_u16_u8 -- four 4-pixel SADs per instruction -- re-using each
+// window row for the 5 dy it serves.  The (cost, dy, dx) minimum is reduced over the wave with
+// cross-lane shuffles.
+#ifndef ME_MBS
+#define ME_MBS 4
+#endif
+#define ME_WQ (ME_MBS + 2)      /* uint4 per window row: 16*ME_MBS + 32 bytes */
+#define ME_ROWS 50   /* 48 real rows + 2 that only masked candidates (dy = 17, 18) ever touch */
+#define ME_STRIDE 53 /* words; 5*53 mod 32 = 9 -> consecutive dy-groups start 9 banks apart */
+#define ME_K 5       /* dy per lane */
 
 DEV unsigned long long qsad(unsigned lo, unsigned hi, unsigned cur, unsigned long long acc) {
     unsigned long long src = ((unsigned long long)hi << 32) | lo;
@@ -111,7 +116,7 @@ DEV int mv_bits(int v) { // bits of se(4v): 1 for 0, else 7 + 2*floor(log2|v|)
     return a == 0 ? 1 : 7 + 2 * (31 - __clz(a));
 }
 
-__global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__ ctx) {
+__global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t *__restrict__ ctx) {
     __shared__ unsigned win[ME_ROWS * ME_STRIDE];
     const int stride = ctx->stride, mbw = ctx->mbw, mbh = ctx->mbh;
     const int W = mbw * 16, H = mbh * 16;
@@ -122,24 +127,24 @@ __global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__
     const uint8_t *__restrict__ ref = ctx->ref_y;
 
     // ---- stage the window: 48 rows x 10 uint4 (coalesced 16 B per lane)
-    for (int i = t; i < ME_ROWS * 10; i += 256) {
-        int row = i / 10, q = i - row * 10;
+    for (int i = t; i < 48 * ME_WQ; i += 64 * ME_MBS) {
+        int row = i / ME_WQ, q = i - row * ME_WQ;
         int gy = my * 16 - 16 + row, gx = sx * (ME_MBS * 16) - 16 + 16 * q;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ldg128(ref + (size_t)gy * stride + gx);
         unsigned *d = &win[row * ME_STRIDE + 4 * q];
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    if (t < ME_ROWS) win[t * ME_STRIDE + 40] = 0;
+    if (t < ME_ROWS) win[t * ME_STRIDE + 4 * ME_WQ] = 0;
+    if (t < 2 * (4 * ME_WQ + 1)) win[(48 + t / (4 * ME_WQ + 1)) * ME_STRIDE + t % (4 * ME_WQ + 1)] = 0;
 
-    const int lane = t & 63, wave = t >> 6, half = lane >> 5, l = lane & 31;
-    const int m = wave * 2 + half;
+    const int lane = t & 63, m = t >> 6;
     const int mx = sx * ME_MBS + m;
-    const bool active = l < 27 && mx < mbw;
-    const int g = l < 27 ? l / 9 : 0, dxg = l < 27 ? l % 9 : 0;
+    const bool active = lane < 63 && mx < mbw;
+    const int g = lane < 63 ? lane / 9 : 0, dxg = lane < 63 ? lane % 9 : 0;
     const int mxc = mx < mbw ? mx : mbw - 1;
 
-    // ---- current macroblock: 16 rows x 4 words, identical in every lane of the half-wave
+    // ---- current macroblock: 16 rows x 4 words, identical in every lane of the wave
     unsigned c[16][4];
     {
         const uint8_t *__restrict__ src = ctx->src_y;
@@ -154,16 +159,22 @@ __global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__
     }
     __syncthreads();
 
-    unsigned long long acc[11];
+    unsigned long long acc[ME_K];
 #pragma unroll
-    for (int d = 0; d < 11; d++) acc[d] = 0;
-    const unsigned *wp = &win[(11 * g) * ME_STRIDE + 4 * m + dxg];
+    for (int d = 0; d < ME_K; d++) acc[d] = 0;
+    const unsigned *wp = &win[(ME_K * g) * ME_STRIDE + 4 * m + dxg];
+    // one window row ahead in registers; sched_barrier keeps the compiler from hoisting all 100 LDS
+    // reads to the top (which costs > 200 VGPRs and halves the occupancy)
+    unsigned w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
 #pragma unroll
-    for (int j = 0; j < 26; j++) {
-        unsigned w0 = wp[j * ME_STRIDE + 0], w1 = wp[j * ME_STRIDE + 1], w2 = wp[j * ME_STRIDE + 2];
-        unsigned w3 = wp[j * ME_STRIDE + 3], w4 = wp[j * ME_STRIDE + 4];
+    for (int j = 0; j < 16 + ME_K - 1; j++) {
+        unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0;
+        if (j + 1 < 16 + ME_K - 1) {
+            n0 = wp[(j + 1) * ME_STRIDE + 0]; n1 = wp[(j + 1) * ME_STRIDE + 1]; n2 = wp[(j + 1) * ME_STRIDE + 2];
+            n3 = wp[(j + 1) * ME_STRIDE + 3]; n4 = wp[(j + 1) * ME_STRIDE + 4];
+        }
 #pragma unroll
-        for (int d = 0; d < 11; d++) {
+        for (int d = 0; d < ME_K; d++) {
             const int r = j - d;
             if (r >= 0 && r < 16) {
                 acc[d] = qsad(w0, w1, c[r][0], acc[d]);
@@ -172,6 +183,10 @@ __global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__
                 acc[d] = qsad(w3, w4, c[r][3], acc[d]);
             }
         }
+        // pin this row's SADs here (pure intrinsics would otherwise sink below all the LDS reads)
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
+        __builtin_amdgcn_sched_barrier(0);
+        w0 = n0; w1 = n1; w2 = n2; w3 = n3; w4 = n4;
     }
 
     // ---- cost = SAD + lambda*(bits(dx)+bits(dy)); key = cost<<12 | (dy+16)<<6 | (dx+16)
@@ -188,8 +203,8 @@ __global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__
     }
     unsigned best = 0xFFFFFFFFu;
 #pragma unroll
-    for (int d = 0; d < 11; d++) {
-        int dy = -16 + 11 * g + d;
+    for (int d = 0; d < ME_K; d++) {
+        int dy = -16 + ME_K * g + d;
         unsigned bd = (dy >= dy_lo && dy <= dy_hi) ? (((unsigned)(lambda * mv_bits(dy)) << 12) | ((unsigned)(dy + 16) << 6)) : INVALID;
         unsigned lo = (unsigned)acc[d], hi = (unsigned)(acc[d] >> 32);
         unsigned k0 = ((lo << 16) >> 4) + bd + bo[0];
@@ -200,13 +215,13 @@ __global__ __launch_bounds__(256) void me_kernel(const frame_ctx_t *__restrict__
         ka = ka < kb ? ka : kb;
         best = best < ka ? best : ka;
     }
-    // ---- half-wave (32-lane) minimum
+    // ---- wave-wide minimum
 #pragma unroll
-    for (int s = 16; s >= 1; s >>= 1) {
-        unsigned o = (unsigned)__shfl_xor((int)best, s, 32);
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        unsigned o = (unsigned)__shfl_xor((int)best, sft, 64);
         best = best < o ? best : o;
     }
-    if (l == 0 && mx < mbw) {
+    if (lane == 0 && mx < mbw) {
         mb_info_t *mb = &ctx->mbi[my * mbw + mx];
         const int bx_ = (int)(best & 63) - 16, by_ = (int)((best >> 6) & 63) - 16;
         stg32(&mb->mvx, ((unsigned)(uint16_t)bx_) | ((unsigned)(uint16_t)by_ << 16));
@@ -1191,7 +1206,7 @@ int k_deblock_diags(int mbw, int mbh) { return mbw + 2 * (mbh - 1); }
 
 void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
     int strips = (mbw + ME_MBS - 1) / ME_MBS;
-    hipLaunchKernelGGL(me_kernel, dim3(strips * mbh), dim3(256), 0, s, d_ctx);
+    hipLaunchKernelGGL(me_kernel, dim3(strips * mbh), dim3(64 * ME_MBS), 0, s, d_ctx);
 }
 void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
     int pairs = (mbw * mbh + 1) / 2;
