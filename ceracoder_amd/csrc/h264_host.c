@@ -344,8 +344,8 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
                 }
                 bits_ue(&b, (uint32_t)skip); skip = 0;
                 bits_ue(&b, 0); /* P_L0_16x16 */
-                bits_se(&b, 4 * (m->mvx - px));
-                bits_se(&b, 4 * (m->mvy - py));
+                bits_se(&b, m->mvx - px); /* mvd_l0: vectors are kept in quarter-sample units */
+                bits_se(&b, m->mvy - py);
                 bits_ue(&b, cbp_inter_code[cbp_c * 16 + cbp_l]);
             } else {
                 if (!is_idr) { bits_ue(&b, (uint32_t)skip); skip = 0; }

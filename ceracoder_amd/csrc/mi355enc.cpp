@@ -97,7 +97,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1;
 }
 
 static void launch_intra_all(mi355enc_t *h) {
@@ -280,6 +280,8 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     } else {
         k_launch_me(h->d_ctx, h->mbw, h->mbh, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
+        if (h->cfg.subpel) k_launch_subpel(h->d_ctx, h->mbw, h->mbh, h->stream);
+        if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
         k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
     }
@@ -356,9 +358,9 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     if (qp) *qp = s->qp;
     rc_update(&h->rc, s->is_idr, s->qp, n + m);
     if (h->cfg.profile_events) {
-        float a = 0, b = 0, c = 0, tot = 0;
+        float a = 0, b = 0, c = 0, tot = 0, sp = 0;
         (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
-        (void)hipEventElapsedTime(&b, s->ev[1], s->ev[2]);
+        if (!s->is_idr) { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[2]); h->st.ms_subpel += sp; }
         (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
         (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]);
         if (s->is_idr) { h->st.ms_intra += a; h->st.n_intra++; }
@@ -434,6 +436,18 @@ int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y,
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }
+int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_inout) {
+    if (!h || !cur_y || !ref_y || !mbinfo_inout || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, cur_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
+    int r = stage_ctx(h, qp, true); if (r) return r;
+    k_launch_subpel(h->d_ctx, h->mbw, h->mbh, h->stream);
+    HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
 int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv,
                          int qp, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels) {
     if (!h || !src_y || !src_uv || !ref_y || !ref_uv || !mbinfo_inout || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
@@ -481,7 +495,7 @@ int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const
     return MI355ENC_OK;
 }
 int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
-    if (!h || !avg_ms || iters < 1 || stage < 0 || stage > 3) return MI355ENC_ERR_ARG;
+    if (!h || !avg_ms || iters < 1 || stage < 0 || stage > 4) return MI355ENC_ERR_ARG;
     if (h->pending) return MI355ENC_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[0];
@@ -493,6 +507,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
             if (stage == 0) k_launch_me(h->d_ctx, h->mbw, h->mbh, h->stream);
             else if (stage == 1) k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
             else if (stage == 2) { int r = run_intra(h); if (r) return r; }
+            else if (stage == 4) k_launch_subpel(h->d_ctx, h->mbw, h->mbh, h->stream);
             else { int r = run_deblock(h); if (r) return r; }
         }
         if (warm) HIPCHK(hipEventRecord(s->ev[1], h->stream));

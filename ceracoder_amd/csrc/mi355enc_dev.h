@@ -10,7 +10,7 @@ extern "C" {
 
 /* 16-byte per-macroblock record (DESIGN.md "HBM layout") */
 typedef struct {
-    int16_t mvx, mvy;     /* integer-pel luma motion vector                         */
+    int16_t mvx, mvy;     /* luma motion vector, quarter-sample units               */
     uint8_t mb_type;      /* 0 I16x16, 1 P_L0_16x16                                 */
     uint8_t i16_mode;     /* 0 V 1 H 2 DC 3 Plane                                   */
     uint8_t chroma_mode;  /* 0 DC 1 H 2 V 3 Plane                                   */
@@ -50,6 +50,7 @@ typedef struct {
 #include <hip/hip_runtime.h>
 /* launchers (mi355enc_kernels.hip); all asynchronous on `s` */
 void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
+void k_launch_subpel(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
 void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
 void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);

@@ -77,6 +77,10 @@ DEV void st_mbinfo(mb_info_t *p, const mb_info_t &m) {
     stg128(p, r);
 }
 
+// workgroup barrier that drains LDS traffic only: global loads (prefetch) and stores stay in flight
+#define BAND_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 DEV int iabs(int v) { return v < 0 ? -v : v; }
 DEV int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 DEV int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t *__re
     if (lane == 0 && mx < mbw) {
         mb_info_t *mb = &ctx->mbi[my * mbw + mx];
         const int bx_ = (int)(best & 63) - 16, by_ = (int)((best >> 6) & 63) - 16;
-        stg32(&mb->mvx, ((unsigned)(uint16_t)bx_) | ((unsigned)(uint16_t)by_ << 16));
+        stg32(&mb->mvx, ((unsigned)(uint16_t)(4 * bx_)) | ((unsigned)(uint16_t)(4 * by_) << 16)); // quarter-sample units
         stg32(&mb->cost, best >> 12);
     }
 }
@@ -373,6 +377,150 @@ DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int c
     return (nz_ac ? 1 : 0) | (nz_dc ? 2 : 0);
 }
 
+// =================================================================== sub-sample refinement
+// One wave per macroblock.  Around the integer winner (ix, iy) the wave builds, in LDS, the
+// integer samples G and the three half-sample planes of 8.4.2.2.1 (b: horizontal 6-tap,
+// h: vertical 6-tap, j: centre, 6-tap over the unrounded horizontal intermediates) on an
+// 18 x 18 (+1) grid; every quarter-sample candidate is then the rounded average of two plane
+// entries (Table 8-12).  Two rounds (step 2, then step 1) of the 8 neighbours, visited in
+// (dy, dx) raster order, strictly-lower cost wins -- the oracle's orc_subpel_frame.
+#define SP_GS 24 /* G row stride (23 used) */
+#define SP_PS 20 /* plane row stride (18/19 used) */
+struct sp_lds {
+    uint8_t G[23 * SP_GS];     // rows iy-3 .. iy+19, cols ix-3 .. ix+19
+    int16_t B1[23 * 18];       // unrounded horizontal half samples: rows iy-3 .. iy+19, cols ix-1 .. ix+16
+    uint8_t b[19 * SP_PS];     // rows iy-1 .. iy+17, cols ix-1 .. ix+16
+    uint8_t h[18 * SP_PS];     // rows iy-1 .. iy+16, cols ix-1 .. ix+17
+    uint8_t j[18 * SP_PS];     // rows iy-1 .. iy+16, cols ix-1 .. ix+16
+};
+DEV int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+DEV int mvq_bits(int q) { // bits of se(q)
+    unsigned k = q > 0 ? (unsigned)(2 * q - 1) : (unsigned)(-2 * q);
+    return 2 * (31 - __clz((int)(k + 1))) + 1;
+}
+// value of the luma sample at plane position (X, Y) (plane coordinates: 0 = ix-1 / iy-1) and fraction (fx, fy)
+DEV int sp_sample(const sp_lds *L, int X, int Y, int fx, int fy) {
+#define SG(x, y) ((int)L->G[((y) + 2) * SP_GS + (x) + 2])
+#define SB(x, y) ((int)L->b[(y) * SP_PS + (x)])
+#define SH(x, y) ((int)L->h[(y) * SP_PS + (x)])
+#define SJ(x, y) ((int)L->j[(y) * SP_PS + (x)])
+    if (fy == 0) {
+        if (fx == 0) return SG(X, Y);
+        return fx == 2 ? SB(X, Y) : fx == 1 ? (SG(X, Y) + SB(X, Y) + 1) >> 1 : (SG(X + 1, Y) + SB(X, Y) + 1) >> 1;
+    }
+    if (fx == 0) return fy == 2 ? SH(X, Y) : fy == 1 ? (SG(X, Y) + SH(X, Y) + 1) >> 1 : (SG(X, Y + 1) + SH(X, Y) + 1) >> 1;
+    if ((fx & 1) && (fy & 1)) return ((fy == 1 ? SB(X, Y) : SB(X, Y + 1)) + (fx == 1 ? SH(X, Y) : SH(X + 1, Y)) + 1) >> 1;
+    if (fx == 2 && fy == 2) return SJ(X, Y);
+    if (fx == 2) return ((fy == 1 ? SB(X, Y) : SB(X, Y + 1)) + SJ(X, Y) + 1) >> 1;
+    return ((fx == 1 ? SH(X, Y) : SH(X + 1, Y)) + SJ(X, Y) + 1) >> 1;
+#undef SG
+#undef SB
+#undef SH
+#undef SJ
+}
+__global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t *__restrict__ ctx) {
+    __shared__ __attribute__((aligned(16))) sp_lds LD[4];
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int mbn = blockIdx.x * 4 + wave;
+    const bool ok = mbn < mbw * mbh;
+    if (!ok) mbn = mbw * mbh - 1;
+    const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
+    sp_lds *L = &LD[wave];
+    const mb_info_t info = ld_mbinfo(&ctx->mbi[mbn]);
+    const int ix = x0 + (info.mvx >> 2), iy = y0 + (info.mvy >> 2); // integer winner (vector is a multiple of 4 here)
+    const uint8_t *__restrict__ ref = ctx->ref_y;
+    // ---- G with the picture extended by coordinate clamping (8.4.2.2.1)
+    for (int i = lane; i < 23 * 23; i += 64) {
+        int r = i / 23, c = i - r * 23;
+        int yy = clip3(0, H - 1, iy - 3 + r), xx = clip3(0, W - 1, ix - 3 + c);
+        L->G[r * SP_GS + c] = (uint8_t)ldg8(ref + (size_t)yy * stride + xx);
+    }
+    // current macroblock: lane owns row lane>>2, columns 4*(lane&3) .. +3
+    const int pr = lane >> 2, pc = (lane & 3) * 4;
+    unsigned curw;
+    {
+        int sy = y0 + pr;
+        sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
+        curw = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + x0 + pc);
+    }
+    WAVE_SYNC();
+    // ---- horizontal half samples (unrounded B1, rounded b)
+    for (int i = lane; i < 23 * 18; i += 64) {
+        int r = i / 18, c = i - r * 18; // position x = ix-1+c -> G column c+2; taps at G columns c .. c+5
+        const uint8_t *g = &L->G[r * SP_GS + c];
+        int v = tap6(g[0], g[1], g[2], g[3], g[4], g[5]);
+        L->B1[r * 18 + c] = (int16_t)v;
+        if (r >= 2 && r < 21) L->b[(r - 2) * SP_PS + c] = (uint8_t)clip255((v + 16) >> 5);
+    }
+    // ---- vertical half samples h: rows iy-1 .. iy+16 (G rows 2..19), cols ix-1 .. ix+17 (G cols 2..20)
+    for (int i = lane; i < 18 * 19; i += 64) {
+        int r = i / 19, c = i - r * 19;
+        const uint8_t *g = &L->G[r * SP_GS + c + 2]; // taps at G rows r .. r+5
+        int v = tap6(g[0], g[SP_GS], g[2 * SP_GS], g[3 * SP_GS], g[4 * SP_GS], g[5 * SP_GS]);
+        L->h[r * SP_PS + c] = (uint8_t)clip255((v + 16) >> 5);
+    }
+    WAVE_SYNC();
+    // ---- centre samples j: vertical 6-tap over B1
+    for (int i = lane; i < 18 * 18; i += 64) {
+        int r = i / 18, c = i - r * 18;
+        const int16_t *q = &L->B1[r * 18 + c];
+        int v = tap6(q[0], q[18], q[36], q[54], q[72], q[90]);
+        L->j[r * SP_PS + c] = (uint8_t)clip255((v + 512) >> 10);
+    }
+    WAVE_SYNC();
+    // ---- two refinement rounds
+    const int lambda = ctx->lambda;
+    int bqx = info.mvx, bqy = info.mvy;
+    unsigned best = info.cost;
+#pragma unroll 1
+    for (int step = 2; step >= 1; step--) {
+        const int cqx = bqx, cqy = bqy;
+#pragma unroll 1
+        for (int k = 0; k < 9; k++) {
+            if (k == 4) continue;
+            const int qx = cqx + (k % 3 - 1) * step, qy = cqy + (k / 3 - 1) * step;
+            const int ox = qx - info.mvx, oy = qy - info.mvy;               // -3 .. 3 relative to the integer winner
+            const int X = 1 + (ox >> 2) + pc, Y = 1 + (oy >> 2) + pr;       // plane coordinates of this lane's first pixel
+            const int fx = ox & 3, fy = oy & 3;
+            unsigned sad = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) sad += (unsigned)iabs(byte_of(curw, i) - sp_sample(L, X + i, Y, fx, fy));
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) sad += (unsigned)__shfl_xor((int)sad, sft, 64);
+            const unsigned cost = sad + (unsigned)(lambda * (mvq_bits(qx) + mvq_bits(qy)));
+            if (cost < best) { best = cost; bqx = qx; bqy = qy; }
+        }
+    }
+    if (lane == 0 && ok) {
+        mb_info_t *mb = &ctx->mbi[mbn];
+        stg32(&mb->mvx, ((unsigned)(uint16_t)bqx) | ((unsigned)(uint16_t)bqy << 16));
+        stg32(&mb->cost, best);
+    }
+}
+
+// 8.4.2.2.1 for one sample out of a clamped 9 x 9 neighbourhood held in registers:
+// n[r][c] is the integer sample at (X - 2 + c, Y - 2 + r) of the block's first pixel; (i, jj) selects the pixel.
+DEV int qpel_from9(const int (*n)[9], int i, int jj, int fx, int fy) {
+#define N(dx, dy) n[jj + 2 + (dy)][i + 2 + (dx)]
+#define HB1(dx, dy) tap6(N((dx) - 2, dy), N((dx) - 1, dy), N(dx, dy), N((dx) + 1, dy), N((dx) + 2, dy), N((dx) + 3, dy))
+#define VH1(dx, dy) tap6(N(dx, (dy) - 2), N(dx, (dy) - 1), N(dx, dy), N(dx, (dy) + 1), N(dx, (dy) + 2), N(dx, (dy) + 3))
+    const int G = N(0, 0);
+    if (!fx && !fy) return G;
+    const int b = clip255((HB1(0, 0) + 16) >> 5), h = clip255((VH1(0, 0) + 16) >> 5);
+    if (!fy) return fx == 2 ? b : fx == 1 ? (G + b + 1) >> 1 : (N(1, 0) + b + 1) >> 1;
+    if (!fx) return fy == 2 ? h : fy == 1 ? (G + h + 1) >> 1 : (N(0, 1) + h + 1) >> 1;
+    const int m = clip255((VH1(1, 0) + 16) >> 5), s = clip255((HB1(0, 1) + 16) >> 5);
+    if ((fx & 1) && (fy & 1)) return ((fy == 1 ? b : s) + (fx == 1 ? h : m) + 1) >> 1;
+    const int j = clip255((tap6(HB1(0, -2), HB1(0, -1), HB1(0, 0), HB1(0, 1), HB1(0, 2), HB1(0, 3)) + 512) >> 10);
+    if (fx == 2 && fy == 2) return j;
+    if (fx == 2) return ((fy == 1 ? b : s) + j + 1) >> 1;
+    return ((fx == 1 ? h : m) + j + 1) >> 1;
+#undef N
+#undef HB1
+#undef VH1
+}
+
 // =================================================================== inter (P) macroblocks
 // One wave = two macroblocks.  Lanes 0-31: one 4x4 luma block each (MB = lane>>4);
 // lanes 32-47: one 4x4 chroma block each (MB = (lane-32)>>3); lanes 48-63 idle.
@@ -388,7 +536,8 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
     if (!mb_ok) mbn = nmb - 1;
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
     const mb_info_t info = ld_mbinfo(&ctx->mbi[mbn]);
-    const int mvx = clip3(-x0, W - 16 - x0, info.mvx), mvy = clip3(-y0, H - 16 - y0, info.mvy);
+    // quarter-sample vector; the clamp only guards against garbage records (real vectors are far inside it)
+    const int mvx = clip3(-4 * (x0 + 24), 4 * (W - x0 + 8), info.mvx), mvy = clip3(-4 * (y0 + 24), 4 * (H - y0 + 8), info.mvy);
     int flags = 0; // bit0: AC/any nonzero, bit1: chroma DC nonzero
     if (is_luma && mb_ok) {
         const int b = lane & 15, bx = blkx(b), by = blky(b);
@@ -397,16 +546,36 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
         const uint8_t *__restrict__ s = ctx->src_y;
         const uint8_t *__restrict__ rf = ctx->ref_y;
         const int ss = ctx->src_stride, vh = ctx->vis_h;
+        const int fx = mvx & 3, fy = mvy & 3, X = x0 + bx + (mvx >> 2), Y = y0 + by + (mvy >> 2);
+        if (fx == 0 && fy == 0 && X >= 0 && Y >= 0 && X + 4 <= W && Y + 4 <= H) { // whole-sample vector, block inside the picture
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                size_t a = (size_t)(Y + r) * stride + X;
+                const uint2 apw = ldg64x(rf + (a & ~(size_t)3));
+                unsigned pw = __builtin_amdgcn_alignbyte(apw.y, apw.x, (unsigned)(a & 3));
+#pragma unroll
+                for (int i = 0; i < 4; i++) pr[r * 4 + i] = byte_of(pw, i);
+            }
+        } else { // 8.4.2.2.1: 6-tap / averaged samples from a 9 x 9 neighbourhood, picture extended by clamping
+            int n[9][9];
+#pragma unroll
+            for (int r = 0; r < 9; r++) {
+                const int yy = clip3(0, H - 1, Y - 2 + r);
+#pragma unroll
+                for (int c2 = 0; c2 < 9; c2++) n[r][c2] = (int)ldg8(rf + (size_t)yy * stride + clip3(0, W - 1, X - 2 + c2));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) pr[r * 4 + i] = qpel_from9(n, i, r, fx, fy);
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             int sy = y0 + by + r;
             sy = sy < vh ? sy : vh - 1;
             unsigned sw = ldg32(s + (size_t)sy * ss + x0 + bx);
-            size_t a = (size_t)(y0 + by + r + mvy) * stride + (x0 + bx + mvx);
-            const uint2 apw = ldg64x(rf + (a & ~(size_t)3));
-            unsigned pw = __builtin_amdgcn_alignbyte(apw.y, apw.x, (unsigned)(a & 3));
 #pragma unroll
-            for (int i = 0; i < 4; i++) { pr[r * 4 + i] = byte_of(pw, i); x[r * 4 + i] = byte_of(sw, i) - pr[r * 4 + i]; }
+            for (int i = 0; i < 4; i++) x[r * 4 + i] = byte_of(sw, i) - pr[r * 4 + i];
         }
         fdct4(x);
         bool nz = quant_dequant<0>(x, lev, q);
@@ -423,8 +592,8 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
     if (is_chroma) { // all 16 lanes run (shuffles inside); stores are predicated by mb_ok via mbn clamp
         const int cl = (lane - 32) & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
         const int cx0 = x0 >> 1, cy0 = y0 >> 1, cw = W >> 1, ch = H >> 1;
-        // 8.4.2.2.2: chroma vector = luma vector in 1/8 sample units -> fraction 0 or 4
-        const int xi = mvx >> 1, yi = mvy >> 1, xf = (mvx & 1) * 4, yf = (mvy & 1) * 4;
+        // 8.4.1.4 / 8.4.2.2.2: the chroma vector is the luma vector read in 1/8 chroma-sample units
+        const int xi = mvx >> 3, yi = mvy >> 3, xf = mvx & 7, yf = mvy & 7;
         const uint8_t *__restrict__ rf = ctx->ref_uv;
         int smp[5][5];
 #pragma unroll
@@ -750,7 +919,7 @@ DEV int has_coef(const mb_info_t &m, int bx4, int by4) { // (bx4,by4) raster 4x4
 DEV int bs_of(const mb_info_t &mp, int bxp, int byp, const mb_info_t &mq, int bxq, int byq, bool mb_edge) {
     if (mp.mb_type == 0 || mq.mb_type == 0) return mb_edge ? 4 : 3;
     if (has_coef(mp, bxp, byp) || has_coef(mq, bxq, byq)) return 2;
-    if (iabs(mp.mvx - mq.mvx) >= 1 || iabs(mp.mvy - mq.mvy) >= 1) return 1; // >= 4 quarter samples
+    if (iabs(mp.mvx - mq.mvx) >= 4 || iabs(mp.mvy - mq.mvy) >= 4) return 1; // quarter-sample units
     return 0;
 }
 // One wave per macroblock, launched once per wavefront x + 2y = diag: then the left, top and
@@ -876,9 +1045,6 @@ struct db_chroma_lds { uint8_t t[10 * DB_TS]; unsigned ring[4][8]; };  // rows -
 
 DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// workgroup barrier that drains LDS traffic only: global loads (prefetch) and stores stay in flight
-#define BAND_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // filter parameters of one edge class (left / top / inner), looked up once per macroblock
 struct edge_par { int alpha, beta, tc0[3]; };
@@ -1207,6 +1373,9 @@ int k_deblock_diags(int mbw, int mbh) { return mbw + 2 * (mbh - 1); }
 void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
     int strips = (mbw + ME_MBS - 1) / ME_MBS;
     hipLaunchKernelGGL(me_kernel, dim3(strips * mbh), dim3(64 * ME_MBS), 0, s, d_ctx);
+}
+void k_launch_subpel(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
+    hipLaunchKernelGGL(subpel_kernel, dim3((mbw * mbh + 3) / 4), dim3(256), 0, s, d_ctx);
 }
 void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
     int pairs = (mbw * mbh + 1) / 2;

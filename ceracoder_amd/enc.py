@@ -18,14 +18,14 @@ MBINFO_DTYPE = np.dtype(
 )
 
 FETCH_RECON_Y, FETCH_RECON_UV, FETCH_PREFILTER_Y, FETCH_PREFILTER_UV, FETCH_MBINFO, FETCH_LEVELS = range(6)
-STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK = range(4)
+STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK, STAGE_SUBPEL = range(5)
 
 EXPORTS = [
     "mi355enc_abi_version", "mi355enc_strerror", "mi355enc_default_cfg", "mi355enc_open", "mi355enc_close",
     "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_encode", "mi355enc_submit",
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
-    "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_deblock", "mi355enc_time_stage",
+    "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_deblock", "mi355enc_time_stage",
     "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
     "mi355enc_rc_pick_qp", "mi355enc_rc_update",
 ]
@@ -35,13 +35,13 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
                 ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
-                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("deblock_mode", C.c_int)]
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("idr_frames", C.c_uint64), ("bytes", C.c_uint64), ("last_qp", C.c_uint32),
                 ("last_bytes", C.c_uint32), ("target_bps", C.c_uint32), ("ms_me", C.c_double), ("ms_inter", C.c_double),
-                ("ms_intra", C.c_double), ("ms_deblock", C.c_double), ("ms_total_gpu", C.c_double), ("n_me", C.c_uint64),
+                ("ms_intra", C.c_double), ("ms_deblock", C.c_double), ("ms_total_gpu", C.c_double), ("ms_subpel", C.c_double), ("n_me", C.c_uint64),
                 ("n_inter", C.c_uint64), ("n_intra", C.c_uint64), ("n_deblock", C.c_uint64), ("ms_entropy", C.c_double),
                 ("ms_wait", C.c_double)]
 
@@ -83,6 +83,7 @@ def load():
         L.mi355enc_mb_width.argtypes = [vp]
         L.mi355enc_mb_height.argtypes = [vp]
         L.mi355enc_stage_me.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.mi355enc_stage_subpel.argtypes = [vp, vp, vp, C.c_int, vp]
         L.mi355enc_stage_inter.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
@@ -151,7 +152,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
@@ -159,6 +160,7 @@ class Encoder:
         cfg.pipeline_depth, cfg.profile_events, cfg.use_graphs, cfg.keep_prefilter = (
             pipeline_depth, int(profile_events), int(use_graphs), int(keep_prefilter))
         cfg.deblock_mode = deblock_mode
+        cfg.subpel = int(subpel)
         self.h = C.c_void_p()
         self._chk(self.L.mi355enc_open(C.byref(cfg), C.byref(self.h)), "open", close_on_fail=True)
         self.width, self.height = width, height
@@ -238,6 +240,11 @@ class Encoder:
     def stage_me(self, cur_y, ref_y, qp):
         mbi = np.zeros(self.mbw * self.mbh, MBINFO_DTYPE)
         self._chk(self.L.mi355enc_stage_me(self.h, _p(np.ascontiguousarray(cur_y)), _p(np.ascontiguousarray(ref_y)), qp, _p(mbi)), "stage_me")
+        return mbi
+
+    def stage_subpel(self, cur_y, ref_y, mbi, qp):
+        mbi = np.ascontiguousarray(mbi).copy()
+        self._chk(self.L.mi355enc_stage_subpel(self.h, _p(np.ascontiguousarray(cur_y)), _p(np.ascontiguousarray(ref_y)), qp, _p(mbi)), "stage_subpel")
         return mbi
 
     def stage_inter(self, src_y, src_uv, ref_y, ref_uv, mbi, qp):

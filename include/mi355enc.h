@@ -54,6 +54,7 @@ typedef struct {
     int profile_events;       /* 1: bracket every kernel stage with HIP events (stats)    */
     int use_graphs;           /* 1: replay the per-picture launch sequence as a hipGraph  */
     int keep_prefilter;       /* 1: keep a copy of the picture before deblocking (tests)  */
+    int subpel;               /* 1 (default): half- then quarter-sample refinement after the integer search */
     int deblock_mode;         /* 0: persistent band-wavefront kernel (one launch per picture);
                                  1: one launch per x+2y wavefront (reference implementation) */
 } mi355enc_cfg_t;
@@ -63,6 +64,7 @@ typedef struct {
     uint32_t last_qp, last_bytes, target_bps;
     /* accumulated device time per stage in ms and launch counts (profile_events=1) */
     double ms_me, ms_inter, ms_intra, ms_deblock, ms_total_gpu;
+    double ms_subpel;
     uint64_t n_me, n_inter, n_intra, n_deblock;
     double ms_entropy;        /* host CAVLC wall time */
     double ms_wait;           /* host time blocked on the device */
@@ -118,6 +120,8 @@ int mi355enc_mb_height(const mi355enc_t *h);
  * All planes are host pointers to coded-size (multiple-of-16) surfaces with stride 16*mbw;
  * mbinfo is mbw*mbh 16-byte records, levels mbw*mbh*408 int16. */
 int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_out);
+/* refine the integer vectors in mbinfo (mvx, mvy in quarter-sample units, cost) in place */
+int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_inout);
 int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y,
                          const uint8_t *ref_uv, int qp, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv,
                          int16_t *levels);
@@ -125,7 +129,7 @@ int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
                          uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
 int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const void *mbinfo);
 /* Time `iters` back-to-back launches of one stage on the handle's stream with HIP events;
- * stage: 0 ME, 1 inter, 2 intra (whole wavefront), 3 deblock (whole wavefront).
+ * stage: 0 ME, 1 inter, 2 intra (whole wavefront), 3 deblock (whole wavefront), 4 sub-sample refinement.
  * Uses whatever the handle's surfaces currently hold.  Returns average ms per launch. */
 int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms);
 

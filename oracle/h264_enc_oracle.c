@@ -315,7 +315,7 @@ void orc_me_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mb
                 }
             }
             orc_mbinfo_t *m = &mbi[my * mbw + mx];
-            m->mvx = (int16_t)best_dx; m->mvy = (int16_t)best_dy; m->cost = best_cost;
+            m->mvx = (int16_t)(4 * best_dx); m->mvy = (int16_t)(4 * best_dy); m->cost = best_cost; /* quarter-sample units */
         }
     }
 }
@@ -376,18 +376,44 @@ static void chroma_tq_recon(const uint8_t *src_uv, uint8_t *rec_uv, int stride, 
 }
 
 /* ================================================================== inter (P) picture */
-/* 8.4.2.2.1 integer sample fetch + 8.4.2.2.2 chroma bilinear (xFrac,yFrac in {0,4} for
- * integer luma vectors); 8.4.1.4: chroma vector = luma vector, units of 1/8 chroma sample. */
+/* 8.4.2.2.1 luma sample interpolation (6-tap half samples, averaged quarter samples) with the
+ * reference picture extended by coordinate clamping, written from Figure 8-4 / Table 8-12. */
+static inline int ref_at(const uint8_t *p, int stride, int W, int H, int x, int y) {
+    return p[(size_t)CLIP3(0, H - 1, y) * stride + CLIP3(0, W - 1, x)];
+}
+static inline int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+static int half_h(const uint8_t *p, int stride, int W, int H, int x, int y) { /* b1 at the right of (x,y) */
+    return tap6(ref_at(p, stride, W, H, x - 2, y), ref_at(p, stride, W, H, x - 1, y), ref_at(p, stride, W, H, x, y),
+                ref_at(p, stride, W, H, x + 1, y), ref_at(p, stride, W, H, x + 2, y), ref_at(p, stride, W, H, x + 3, y));
+}
+static int half_v(const uint8_t *p, int stride, int W, int H, int x, int y) { /* h1 below (x,y) */
+    return tap6(ref_at(p, stride, W, H, x, y - 2), ref_at(p, stride, W, H, x, y - 1), ref_at(p, stride, W, H, x, y),
+                ref_at(p, stride, W, H, x, y + 1), ref_at(p, stride, W, H, x, y + 2), ref_at(p, stride, W, H, x, y + 3));
+}
+static int luma_qpel(const uint8_t *p, int stride, int W, int H, int x, int y, int fx, int fy) {
+    int G = ref_at(p, stride, W, H, x, y);
+    if (!fx && !fy) return G;
+    int b = clip1((half_h(p, stride, W, H, x, y) + 16) >> 5), h = clip1((half_v(p, stride, W, H, x, y) + 16) >> 5);
+    if (!fy) return fx == 2 ? b : fx == 1 ? (G + b + 1) >> 1 : (ref_at(p, stride, W, H, x + 1, y) + b + 1) >> 1;
+    if (!fx) return fy == 2 ? h : fy == 1 ? (G + h + 1) >> 1 : (ref_at(p, stride, W, H, x, y + 1) + h + 1) >> 1;
+    int m = clip1((half_v(p, stride, W, H, x + 1, y) + 16) >> 5), s = clip1((half_h(p, stride, W, H, x, y + 1) + 16) >> 5);
+    if ((fx & 1) && (fy & 1)) return ((fy == 1 ? b : s) + (fx == 1 ? h : m) + 1) >> 1; /* e, g, p, r */
+    int j = clip1((tap6(half_h(p, stride, W, H, x, y - 2), half_h(p, stride, W, H, x, y - 1), half_h(p, stride, W, H, x, y),
+                        half_h(p, stride, W, H, x, y + 1), half_h(p, stride, W, H, x, y + 2), half_h(p, stride, W, H, x, y + 3)) + 512) >> 10);
+    if (fx == 2 && fy == 2) return j;
+    if (fx == 2) return ((fy == 1 ? b : s) + j + 1) >> 1;  /* f, q */
+    return ((fx == 1 ? h : m) + j + 1) >> 1;               /* i, k */
+}
+/* prediction of one macroblock for the quarter-sample vector (mvx, mvy); 8.4.1.4: the chroma
+ * vector equals the luma vector, read in units of 1/8 chroma sample (8.4.2.2.2 bilinear). */
 static void mc_mb(const uint8_t *ref_y, const uint8_t *ref_uv, uint8_t *rec_y, uint8_t *rec_uv,
                   int stride, int W, int H, int x0, int y0, int mvx, int mvy) {
     for (int y = 0; y < 16; y++)
-        for (int x = 0; x < 16; x++) {
-            int sx = CLIP3(0, W - 1, x0 + x + mvx), sy = CLIP3(0, H - 1, y0 + y + mvy);
-            rec_y[(size_t)(y0 + y) * stride + x0 + x] = ref_y[(size_t)sy * stride + sx];
-        }
+        for (int x = 0; x < 16; x++)
+            rec_y[(size_t)(y0 + y) * stride + x0 + x] =
+                (uint8_t)luma_qpel(ref_y, stride, W, H, x0 + x + (mvx >> 2), y0 + y + (mvy >> 2), mvx & 3, mvy & 3);
     int cw = W / 2, ch = H / 2, cx0 = x0 / 2, cy0 = y0 / 2;
-    int mvcx = 4 * mvx, mvcy = 4 * mvy; /* quarter luma units == 1/8 chroma units */
-    int xi = mvcx >> 3, yi = mvcy >> 3, xf = mvcx & 7, yf = mvcy & 7;
+    int xi = mvx >> 3, yi = mvy >> 3, xf = mvx & 7, yf = mvy & 7;
     for (int c = 0; c < 2; c++)
         for (int y = 0; y < 8; y++)
             for (int x = 0; x < 8; x++) {
@@ -398,6 +424,40 @@ static void mc_mb(const uint8_t *ref_y, const uint8_t *ref_uv, uint8_t *rec_y, u
                 UV(rec_uv, stride, cx0 + x, cy0 + y, c) =
                     (uint8_t)(((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6);
             }
+}
+
+/* Encoder choice: sub-sample refinement of the integer vectors found by orc_me_frame.
+ * Two rounds around the current best vector, step 2 (half sample) then step 1 (quarter sample):
+ * the 8 neighbours are visited in (dy, dx) raster order and replace the best only when strictly
+ * cheaper.  cost = SAD(source, interpolated reference) + lambda * (bits(se(mvx)) + bits(se(mvy))). */
+static inline int mvq_bits(int q) { return orc_ue_bits(q > 0 ? (uint32_t)(2 * q - 1) : (uint32_t)(-2 * q), NULL); }
+void orc_subpel_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mbw, int mbh, int qp,
+                      orc_mbinfo_t *mbi, int threads) {
+    const int W = mbw * 16, H = mbh * 16, lambda = orc_me_lambda(qp);
+    (void)threads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            orc_mbinfo_t *m = &mbi[my * mbw + mx];
+            int x0 = mx * 16, y0 = my * 16, bx = m->mvx, by = m->mvy;
+            uint32_t best = m->cost;
+            for (int step = 2; step >= 1; step--) {
+                int cx = bx, cy = by;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (!dx && !dy) continue;
+                        int qx = cx + dx * step, qy = cy + dy * step;
+                        uint32_t sad = 0;
+                        for (int y = 0; y < 16; y++)
+                            for (int x = 0; x < 16; x++)
+                                sad += (uint32_t)iabs(cur_y[(size_t)(y0 + y) * stride + x0 + x] -
+                                                      luma_qpel(ref_y, stride, W, H, x0 + x + (qx >> 2), y0 + y + (qy >> 2), qx & 3, qy & 3));
+                        uint32_t cost = sad + (uint32_t)(lambda * (mvq_bits(qx) + mvq_bits(qy)));
+                        if (cost < best) { best = cost; bx = qx; by = qy; }
+                    }
+            }
+            m->mvx = (int16_t)bx; m->mvy = (int16_t)by; m->cost = best;
+        }
 }
 
 void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y,
@@ -663,7 +723,7 @@ static int blk_has_coef(const orc_mbinfo_t *m, int bx4, int by4) {
 static int bs_of(const orc_mbinfo_t *mp, int bxp, int byp, const orc_mbinfo_t *mq, int bxq, int byq, int mb_edge) {
     if (mp->mb_type == 0 || mq->mb_type == 0) return mb_edge ? 4 : 3;
     if (blk_has_coef(mp, bxp, byp) || blk_has_coef(mq, bxq, byq)) return 2;
-    if (iabs(4 * mp->mvx - 4 * mq->mvx) >= 4 || iabs(4 * mp->mvy - 4 * mq->mvy) >= 4) return 1;
+    if (iabs(mp->mvx - mq->mvx) >= 4 || iabs(mp->mvy - mq->mvy) >= 4) return 1; /* quarter-sample units */
     return 0;
 }
 void orc_deblock_frame(uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mbh,
@@ -931,8 +991,8 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
                 bw_ue(&b, 0); /* P_L0_16x16 */
                 int px, py;
                 mv_pred16(mbi, mbw, mx, my, &px, &py);
-                bw_se(&b, 4 * (m->mvx - px));
-                bw_se(&b, 4 * (m->mvy - py));
+                bw_se(&b, m->mvx - px); /* mvd_l0, quarter-sample units */
+                bw_se(&b, m->mvy - py);
                 bw_ue(&b, k_cbp_to_codenum_inter[cbp_chroma * 16 + cbp_luma]);
             }
             if (m->mb_type == 0 || cbp_luma || cbp_chroma) {
@@ -988,7 +1048,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
 
 /* ================================================================== encoder wrapper */
 struct orc_enc {
-    int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads;
+    int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads, subpel;
     int frames_since_idr, idr_count, have_ref;
     uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv;
     int cur; /* index of the surface holding the last reconstructed picture */
@@ -1003,7 +1063,7 @@ orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop
     if (!e) return NULL;
     e->width = width; e->height = height;
     e->mbw = (width + 15) / 16; e->mbh = (height + 15) / 16; e->stride = e->mbw * 16;
-    e->fps_num = fps_num; e->fps_den = fps_den; e->gop = gop; e->me_range = me_range; e->threads = threads;
+    e->fps_num = fps_num; e->fps_den = fps_den; e->gop = gop; e->me_range = me_range; e->threads = threads; e->subpel = 1;
     size_t ysz = (size_t)e->stride * e->mbh * 16, csz = ysz / 2;
     e->src_y = (uint8_t *)malloc(ysz); e->src_uv = (uint8_t *)malloc(csz);
     e->pre_y = (uint8_t *)malloc(ysz); e->pre_uv = (uint8_t *)malloc(csz);
@@ -1046,6 +1106,7 @@ int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *u
         orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
     else {
         orc_me_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, e->me_range, qp, e->mbi, e->threads);
+        if (e->subpel) orc_subpel_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, qp, e->mbi, e->threads);
         orc_inter_frame(e->src_y, e->src_uv, e->rec_y[e->cur], e->rec_uv[e->cur], e->rec_y[nxt], e->rec_uv[nxt],
                         e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
     }
@@ -1067,6 +1128,7 @@ int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *u
     e->cur = nxt; e->have_ref = 1;
     return 0;
 }
+void orc_enc_set_subpel(orc_enc_t *e, int on) { e->subpel = on; }
 const uint8_t *orc_enc_recon_y(const orc_enc_t *e) { return e->rec_y[e->cur]; }
 const uint8_t *orc_enc_recon_uv(const orc_enc_t *e) { return e->rec_uv[e->cur]; }
 const uint8_t *orc_enc_prefilter_y(const orc_enc_t *e) { return e->pre_y; }

@@ -26,7 +26,7 @@ extern "C" {
 
 /* Per-macroblock side record, 16 bytes (SURVEY.md section 8d "16 B/MB info"). */
 typedef struct {
-    int16_t mvx, mvy;     /* integer-pel luma motion vector (P macroblocks)            */
+    int16_t mvx, mvy;     /* luma motion vector, quarter-sample units (P macroblocks)  */
     uint8_t mb_type;      /* 0 = I16x16, 1 = P_L0_16x16 (P_Skip is an entropy decision) */
     uint8_t i16_mode;     /* Intra16x16PredMode 0 V, 1 H, 2 DC, 3 Plane                 */
     uint8_t chroma_mode;  /* intra_chroma_pred_mode 0 DC, 1 H, 2 V, 3 Plane             */
@@ -54,9 +54,13 @@ typedef struct {
 /* ---- stage functions (each is the checker for one HIP kernel) ------------------- */
 
 /* Full-search integer-pel SAD motion search, +-range, on coded-size luma planes.
- * Writes mvx,mvy,cost of every macroblock. */
+ * Writes mvx,mvy (quarter-sample units, multiples of 4) and cost of every macroblock. */
 void orc_me_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mbw, int mbh,
                   int range, int qp, orc_mbinfo_t *mbi, int threads);
+
+/* Half- then quarter-sample refinement of the vectors left by orc_me_frame (mvx,mvy,cost updated). */
+void orc_subpel_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mbw, int mbh, int qp,
+                      orc_mbinfo_t *mbi, int threads);
 
 /* P picture: motion compensation + residual + 4x4 transform/quant + normative
  * dequant/inverse + reconstruction (pre-deblock) for every macroblock. */
@@ -80,6 +84,7 @@ typedef struct orc_enc orc_enc_t;
 orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop,
                         int me_range, int threads);
 void orc_enc_close(orc_enc_t *e);
+void orc_enc_set_subpel(orc_enc_t *e, int on); /* default on */
 /* Encode one NV12 frame at a caller-chosen QP.  Returns 0, or <0 on error. */
 int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv,
                   int uv_stride, int qp, int force_idr, uint8_t *out, size_t out_cap,

@@ -50,6 +50,10 @@ def lib():
         L.orc_enc_mbh.argtypes = [vp]
         L.orc_me_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
         L.orc_me_frame.restype = None
+        L.orc_subpel_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orc_subpel_frame.restype = None
+        L.orc_enc_set_subpel.argtypes = [vp, C.c_int]
+        L.orc_enc_set_subpel.restype = None
         L.orc_inter_frame.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.orc_inter_frame.restype = None
         L.orc_intra_frame.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -103,11 +107,12 @@ def _view(ptr, shape, dtype):
 class Encoder:
     """Whole-encoder oracle: one NV12 frame + QP in, Annex-B access unit + stage outputs out."""
 
-    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1):
+    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True):
         self.L = lib()
         self.h = self.L.orc_enc_open(width, height, fps, 1, gop, me_range, threads)
         if not self.h:
             raise ValueError("orc_enc_open failed")
+        self.L.orc_enc_set_subpel(self.h, int(subpel))
         self.width, self.height = width, height
         self.mbw, self.mbh = self.L.orc_enc_mbw(self.h), self.L.orc_enc_mbh(self.h)
         self._out = np.empty(self.mbw * self.mbh * 1024 + 4096, np.uint8)
@@ -193,6 +198,14 @@ def me_frame(cur_y, ref_y, rng, qp, threads=1):
     mbi = np.zeros((H // 16) * (W // 16), MBINFO_DTYPE)
     L.orc_me_frame(_ptr(np.ascontiguousarray(cur_y)), _ptr(np.ascontiguousarray(ref_y)), W, W // 16, H // 16, rng, qp,
                    _ptr(mbi), threads)
+    return mbi
+
+
+def subpel_frame(cur_y, ref_y, mbi, qp, threads=1):
+    L = lib()
+    H, W = cur_y.shape
+    mbi = np.ascontiguousarray(mbi).copy()
+    L.orc_subpel_frame(_ptr(np.ascontiguousarray(cur_y)), _ptr(np.ascontiguousarray(ref_y)), W, W // 16, H // 16, qp, _ptr(mbi), threads)
     return mbi
 
 

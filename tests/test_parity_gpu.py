@@ -29,6 +29,22 @@ def test_me_kernel_matches_oracle(E, oracle, w, h, qp):
     e.close()
 
 
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("qp", [18, 36])
+def test_subpel_kernel_matches_oracle(E, oracle, w, h, qp):
+    """Half/quarter-sample refinement (6-tap planes in LDS) against orc_subpel_frame, incl. picture borders."""
+    f = frames(w, h, 2)
+    cur, ref = f[1][0], f[0][0]
+    mbi = oracle.me_frame(cur, ref, 16, qp, threads=8)
+    orc = oracle.subpel_frame(cur, ref, mbi, qp, threads=8)
+    e = E.Encoder(cur.shape[1], cur.shape[0], fixed_qp=qp)
+    dev = e.stage_subpel(cur, ref, mbi, qp)
+    for fld in ("mvx", "mvy", "cost"):
+        assert np.array_equal(dev[fld], orc[fld]), (fld, first_diff(dev[fld], orc[fld]))
+    assert (orc["mvx"] % 4 != 0).any() or (orc["mvy"] % 4 != 0).any()  # the refinement really moved something
+    e.close()
+
+
 def test_me_kernel_ties_and_flat(E, oracle):
     """Flat and periodic content: many equal SADs -> the (cost, dy, dx) tie-break decides."""
     H, W = 96, 160
@@ -44,10 +60,13 @@ def test_me_kernel_ties_and_flat(E, oracle):
 
 @pytest.mark.parametrize("w,h", SIZES)
 @pytest.mark.parametrize("qp", [0, 18, 30, 51])
-def test_inter_kernel_matches_oracle(E, oracle, w, h, qp):
+@pytest.mark.parametrize("sub", [False, True])
+def test_inter_kernel_matches_oracle(E, oracle, w, h, qp, sub):
     f = frames(w, h, 2)
     (cy, cuv), (ry, ruv) = f[1][:2], f[0][:2]
     mbi = oracle.me_frame(cy, ry, 16, qp, threads=8)
+    if sub:
+        mbi = oracle.subpel_frame(cy, ry, mbi, qp, threads=8)
     o_y, o_uv, o_mbi, o_lev = oracle.inter_frame(cy, cuv, ry, ruv, mbi, qp)
     e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp)
     d_y, d_uv, d_mbi, d_lev = e.stage_inter(cy, cuv, ry, ruv, mbi, qp)
@@ -91,13 +110,13 @@ def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp, mode):
 
 
 @pytest.mark.parametrize("w,h,n", [(64, 48, 9), (176, 144, 7), (322, 182, 5), (1280, 720, 4), (1920, 1080, 3)])
-@pytest.mark.parametrize("graphs,mode", [(True, 0), (False, 0), (True, 1)])
-def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode):
+@pytest.mark.parametrize("graphs,mode,sub", [(True, 0, True), (False, 0, False), (True, 1, True)])
+def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub):
     """Whole path: identical access units, identical reconstruction, and the independent
     decoder reproduces both."""
     qps = [30, 28, 33, 24, 40, 26, 30, 51, 10]
-    e = E.Encoder(w, h, gop=4, fixed_qp=30, use_graphs=graphs, keep_prefilter=True, deblock_mode=mode)
-    oe = oracle.Encoder(w, h, gop=4, threads=8)
+    e = E.Encoder(w, h, gop=4, fixed_qp=30, use_graphs=graphs, keep_prefilter=True, deblock_mode=mode, subpel=sub)
+    oe = oracle.Encoder(w, h, gop=4, threads=8, subpel=sub)
     dec = oracle.Decoder()
     for i, (_, _, y, uv) in enumerate(frames(w, h, n)):
         qp = qps[i % len(qps)]
