@@ -129,6 +129,29 @@ def main():
     dt, (qps, nbytes) = ranks.timed(lambda: run(args.steps, args.warmup), sync=torch.cuda.synchronize)
     st = e.stats()
 
+    extra = {}
+    if rank == 0:
+        # Untimed extras.  (1) quality of the last picture: encoder reconstruction vs its source (luma PSNR).
+        from ceracoder_amd import synth
+        last = frames_np[bounce(args.warmup + args.steps - 1, args.unique)]
+        rec = e.fetch(E.FETCH_RECON_Y)[:height, :width]
+        extra["psnr_y_last_picture_db"] = round(synth.psnr(last[:height], rec), 2)
+        # (2) per-picture latency of the synchronous path an element in a live graph uses (pipeline_depth 0):
+        # host NV12 in -> H2D -> kernels -> D2H -> CAVLC -> access unit out, PCIe included.
+        lat_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0)
+        lat = []
+        for i in range(150):
+            f = frames_np[bounce(i, args.unique)]
+            t0 = time.perf_counter()
+            lat_enc.encode(f[:height], f[height:], pts=i)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat_enc.close()
+        lat = np.sort(np.array(lat[30:]))
+        extra["latency_ms"] = {"p50": round(float(lat[len(lat) // 2]), 3), "p95": round(float(lat[int(len(lat) * 0.95)]), 3),
+                               "path": "pipeline_depth=0: host NV12 -> H2D -> GPU -> D2H -> host CAVLC -> AU (the element's handle_frame); "
+                                       "appsink->SRT segment not measurable here (no libsrt / mpegtsmux in the image)",
+                               "host_input_frames_per_s": round(1e3 / float(lat.mean()), 1)}
+
     if rank == 0:
         # HBM traffic of the kernels comes from separate rocprofv3 --pmc passes (cannot be collected from inside this
         # process); the committed summary of the latest pass for this workload is attached for cross-checking.
@@ -164,10 +187,11 @@ def main():
             "dtype": "u8", "data": "synthetic (S2: panning texture + 12 moving rectangles, seed 0x5EED), resident in HBM",
             "config": {"workload": args.workload, "width": width, "height": height, "fps_nominal": fps, "gop": gop,
                        "rate_control": "cbr %d bit/s" % bps if args.fixed_qp < 0 else "fixed qp %d" % args.fixed_qp,
-                       "me": "full search +-16 integer-pel SAD", "streams_per_gpu": 1, "parallelism": "%d independent streams" % world,
+                       "me": "full search +-16 integer-pel SAD + half/quarter-sample refinement", "streams_per_gpu": 1, "parallelism": "%d independent streams" % world,
                        "pipeline_depth": args.depth},
             "roofline": roof,
             "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "inter": round(st.ms_inter / max(1, st.n_inter), 4),
+                                     "subpel": round(st.ms_subpel / max(1, st.n_me), 4),
                                      "intra_wavefront": round(st.ms_intra / max(1, st.n_intra), 4),
                                      "deblock_wavefront": round(st.ms_deblock / max(1, st.n_deblock), 4),
                                      "gpu_total": round(st.ms_total_gpu / max(1, st.frames), 4),
@@ -175,6 +199,7 @@ def main():
                                      "host_wait": round(st.ms_wait / max(1, st.frames), 4)},
             "bitrate_out_bps": round(nbytes * 8 * fps / args.steps), "mean_qp": round(float(np.mean(qps)), 2),
         }
+        out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, width, height, fps, gop, qps)
         print(json.dumps(out), flush=True)

@@ -42,7 +42,7 @@ struct slot_t {
     mb_info_t *h_mbi;     // pinned
     int16_t *h_levels;    // pinned
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
-    hipEvent_t done, ev[6];
+    hipEvent_t done, gpu_done, ev[6];
     int is_idr, qp, frame_num, idr_pic_id, rec_index;
     int64_t pts;
 };
@@ -53,8 +53,10 @@ struct mi355enc {
     size_t ysz, csz;
     hipStream_t stream;
     frame_ctx_t *d_ctx;
-    mb_info_t *d_mbi;
-    int16_t *d_levels;
+    mb_info_t *d_mbi, *d_mbi_set[2];     // two record/level sets: the D2H of picture n overlaps the kernels of n+1
+    int16_t *d_levels, *d_levels_set[2];
+    hipStream_t cstream;                 // copy stream for the D2H hand-over
+    uint64_t n_submitted;
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
     unsigned *d_progress; // [2*bands] strip counters of the band deblocker, then one error word
     unsigned *h_err;      // pinned mirror of the error word
@@ -128,7 +130,6 @@ static int run_deblock(mi355enc_t *h) {
     if (h->cfg.deblock_mode == 0) {
         HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(h->n_progress + 1) * sizeof(unsigned), h->stream));
         k_launch_deblock_band(h->d_ctx, h->mbh, h->d_progress, h->d_progress + h->n_progress, h->stream);
-        HIPCHK(hipMemcpyAsync(h->h_err, h->d_progress + h->n_progress, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         return 0;
     }
     if (h->cfg.use_graphs) {
@@ -168,15 +169,20 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->h_err = nullptr;
+    h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
     h->fixed_qp.store(cfg->fixed_qp);
     *out = h; // from here on close() cleans up partial state
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&h->d_ctx, sizeof(frame_ctx_t)));
-    HIPCHK(hipMalloc((void **)&h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t)));
-    HIPCHK(hipMalloc((void **)&h->d_levels, (size_t)h->nmb * MB_LEVELS * sizeof(int16_t)));
-    HIPCHK(hipMemsetAsync(h->d_mbi, 0, (size_t)h->nmb * sizeof(mb_info_t), h->stream));
+    HIPCHK(hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc((void **)&h->d_mbi_set[i], (size_t)h->nmb * sizeof(mb_info_t)));
+        HIPCHK(hipMalloc((void **)&h->d_levels_set[i], (size_t)h->nmb * MB_LEVELS * sizeof(int16_t)));
+        HIPCHK(hipMemsetAsync(h->d_mbi_set[i], 0, (size_t)h->nmb * sizeof(mb_info_t), h->stream));
+    }
+    h->d_mbi = h->d_mbi_set[0]; h->d_levels = h->d_levels_set[0]; h->n_submitted = 0;
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&h->d_rec_y[i], h->ysz + SURF_PAD));
         HIPCHK(hipMalloc((void **)&h->d_rec_uv[i], h->csz + SURF_PAD));
@@ -200,6 +206,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMalloc((void **)&s->d_src_y, h->ysz + SURF_PAD));
         HIPCHK(hipMalloc((void **)&s->d_src_uv, h->csz + SURF_PAD));
         HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->gpu_done, hipEventDisableTiming));
         for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&s->ev[k]));
     }
     h->writer = h264_writer_new(h->mbw, h->mbh);
@@ -223,6 +230,7 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->d_src_y) (void)hipFree(s->d_src_y);
         if (s->d_src_uv) (void)hipFree(s->d_src_uv);
         if (s->done) (void)hipEventDestroy(s->done);
+        if (s->gpu_done) (void)hipEventDestroy(s->gpu_done);
         for (int k = 0; k < 6; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
     }
     for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
@@ -231,8 +239,8 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->h_err) (void)hipHostFree(h->h_err);
     if (h->d_ctx) (void)hipFree(h->d_ctx);
-    if (h->d_mbi) (void)hipFree(h->d_mbi);
-    if (h->d_levels) (void)hipFree(h->d_levels);
+    for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
+    if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h264_writer_free(h->writer);
     delete h;
@@ -268,7 +276,8 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     c->src_y = src_y; c->src_uv = src_uv; c->src_stride = src_stride;
     c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
     c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
-    c->mbi = h->d_mbi; c->levels = h->d_levels;
+    const int set = (int)(h->n_submitted & 1);
+    c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set];
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp];
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
@@ -292,10 +301,15 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     }
     { int r = run_deblock(h); if (r) return r; }
     if (prof) HIPCHK(hipEventRecord(s->ev[3], h->stream));
-    HIPCHK(hipMemcpyAsync(s->h_mbi, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(s->h_levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
-    if (prof) HIPCHK(hipEventRecord(s->ev[4], h->stream));
-    HIPCHK(hipEventRecord(s->done, h->stream));
+    // hand-over on the copy stream, so the next picture's kernels (other record/level set) need not wait for PCIe
+    HIPCHK(hipEventRecord(s->gpu_done, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
+    HIPCHK(hipMemcpyAsync(s->h_mbi, h->d_mbi_set[set], (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->cstream));
+    HIPCHK(hipMemcpyAsync(s->h_levels, h->d_levels_set[set], (size_t)h->nmb * MB_LEVELS * sizeof(int16_t), hipMemcpyDeviceToHost, h->cstream));
+    if (h->cfg.deblock_mode == 0) HIPCHK(hipMemcpyAsync(h->h_err, h->d_progress + h->n_progress, sizeof(unsigned), hipMemcpyDeviceToHost, h->cstream));
+    if (prof) HIPCHK(hipEventRecord(s->ev[4], h->cstream));
+    HIPCHK(hipEventRecord(s->done, h->cstream));
+    h->n_submitted++;
     s->is_idr = idr; s->qp = qp; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
     s->pts = pts; s->rec_index = nxt;
     if (idr) h->idr_count++;
@@ -420,6 +434,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     frame_ctx_t *c = s->h_ctx;
     c->src_y = src_is_staging ? s->d_src_y : nullptr; c->src_uv = src_is_staging ? s->d_src_uv : nullptr; c->src_stride = h->W;
     c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
+    HIPCHK(hipStreamSynchronize(h->cstream));
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp];
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
