@@ -11,6 +11,7 @@
 #include "h264_host.h"
 
 #include <emmintrin.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -20,7 +21,11 @@
 static const uint8_t cbp_inter_code[48] = {0,  2,  3,  7,  4,  8,  17, 13, 5,  18, 9,  14, 10, 15, 16, 11,
                                            1,  32, 33, 36, 34, 37, 44, 40, 35, 45, 38, 41, 39, 42, 43, 19,
                                            6,  24, 25, 20, 26, 21, 46, 28, 27, 47, 22, 29, 23, 30, 31, 12};
-static const uint8_t blk_to_raster[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+static const uint8_t blk_to_raster[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* self-inverse */
+/* Table 9-4 (intra column) */
+static const uint8_t cbp_intra_code[48] = {3,  29, 30, 17, 31, 18, 37, 8,  32, 38, 19, 9,  20, 10, 11, 2,
+                                           16, 33, 34, 21, 35, 22, 39, 4,  36, 40, 23, 5,  24, 6,  7,  1,
+                                           41, 42, 43, 25, 44, 26, 46, 12, 45, 47, 27, 13, 28, 14, 15, 0};
 
 /* ------------------------------------------------------------------ bit sink */
 typedef struct {
@@ -325,9 +330,9 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
             const mb_info_t *m = mbi + mbn;
             const int16_t *lv = levels + (size_t)mbn * MB_LEVELS;
             const uint32_t nz = m->nzmask;
-            const int intra = m->mb_type == 0;
+            const int intra = m->mb_type != 1, i16 = m->mb_type == 0;
             int cbp_l = 0;
-            if (intra) cbp_l = (nz & 0xFFFF) ? 15 : 0;
+            if (i16) cbp_l = (nz & 0xFFFF) ? 15 : 0;
             else cbp_l = ((nz & 0x000F) ? 1 : 0) | ((nz & 0x00F0) ? 2 : 0) | ((nz & 0x0F00) ? 4 : 0) | ((nz & 0xF000) ? 8 : 0);
             const int cbp_c = (nz & 0x00FF0000u) ? 2 : ((nz & (NZ_CBDC | NZ_CRDC)) ? 1 : 0);
             if (!intra) {
@@ -349,19 +354,36 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
                 bits_ue(&b, cbp_inter_code[cbp_c * 16 + cbp_l]);
             } else {
                 if (!is_idr) { bits_ue(&b, (uint32_t)skip); skip = 0; }
-                int t = 1 + m->i16_mode + 4 * cbp_c + (cbp_l ? 12 : 0); /* Table 7-11 */
-                bits_ue(&b, (uint32_t)(is_idr ? t : t + 5));
-                bits_ue(&b, m->chroma_mode);
+                if (i16) {
+                    int t = 1 + m->i16_mode + 4 * cbp_c + (cbp_l ? 12 : 0); /* Table 7-11 */
+                    bits_ue(&b, (uint32_t)(is_idr ? t : t + 5));
+                    bits_ue(&b, m->chroma_mode);
+                } else { /* I_NxN: sixteen Intra_4x4 modes, each predicted from the blocks left and above (8.3.1.1) */
+                    bits_ue(&b, is_idr ? 0u : 5u);
+                    for (int blk = 0; blk < 16; blk++) {
+                        const int r = blk_to_raster[blk], bx = r & 3, by = r >> 2;
+                        int ma = -1, mb_ = -1;
+                        if (bx) ma = lv[L_LDC + blk_to_raster[by * 4 + bx - 1]];
+                        else if (mx) ma = m[-1].mb_type == 2 ? lv[-MB_LEVELS + L_LDC + blk_to_raster[by * 4 + 3]] : 2;
+                        if (by) mb_ = lv[L_LDC + blk_to_raster[(by - 1) * 4 + bx]];
+                        else if (my) mb_ = m[-mbw].mb_type == 2 ? lv[-(ptrdiff_t)mbw * MB_LEVELS + L_LDC + blk_to_raster[12 + bx]] : 2;
+                        const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode = lv[L_LDC + blk];
+                        if (mode == pm) bits_put(&b, 1, 1);
+                        else bits_put(&b, 4, (uint32_t)(mode < pm ? mode : mode - 1)); /* flag 0 + 3-bit rem */
+                    }
+                    bits_ue(&b, m->chroma_mode);
+                    bits_ue(&b, cbp_intra_code[cbp_c * 16 + cbp_l]);
+                }
             }
-            if (intra || cbp_l || cbp_c) { bits_se(&b, (int)m->qp - prev_qp); prev_qp = m->qp; }
+            if (i16 || cbp_l || cbp_c) { bits_se(&b, (int)m->qp - prev_qp); prev_qp = m->qp; }
             uint8_t *tl = w->tc_l + (size_t)mbn * 16;
-            if (intra) put_block16(&b, lv + L_LDC, 0, ctx_luma(w, mbn, mx, my, 0, 0));
+            if (i16) put_block16(&b, lv + L_LDC, 0, ctx_luma(w, mbn, mx, my, 0, 0));
             if (cbp_l)
                 for (int blk = 0; blk < 16; blk++) {
                     if (!(cbp_l & (1 << (blk >> 2)))) continue;
                     const int r = blk_to_raster[blk], bx = r & 3, by = r >> 2;
                     const int nC = ctx_luma(w, mbn, mx, my, bx, by);
-                    if ((nz >> blk) & 1) tl[r] = (uint8_t)put_block16(&b, lv + L_LUMA + blk * 16, intra, nC);
+                    if ((nz >> blk) & 1) tl[r] = (uint8_t)put_block16(&b, lv + L_LUMA + blk * 16, i16, nC);
                     else { const int cls = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3; bits_put(&b, vlc_coeff_token[cls][0][0].len, vlc_coeff_token[cls][0][0].bits); }
                 }
             if (cbp_c) {

@@ -99,7 +99,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1;
 }
 
 static void launch_intra_all(mi355enc_t *h) {
@@ -279,7 +279,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     const int set = (int)(h->n_submitted & 1);
     c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set];
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
-    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp];
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     const int prof = h->cfg.profile_events;
     if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
@@ -436,7 +436,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
     HIPCHK(hipStreamSynchronize(h->cstream));
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
-    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp];
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     return 0;
 }

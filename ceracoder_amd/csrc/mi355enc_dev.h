@@ -11,7 +11,7 @@ extern "C" {
 /* 16-byte per-macroblock record (DESIGN.md "HBM layout") */
 typedef struct {
     int16_t mvx, mvy;     /* luma motion vector, quarter-sample units               */
-    uint8_t mb_type;      /* 0 I16x16, 1 P_L0_16x16                                 */
+    uint8_t mb_type;      /* 0 I16x16, 1 P_L0_16x16, 2 I4x4 (modes in levels[L_LDC..]) */
     uint8_t i16_mode;     /* 0 V 1 H 2 DC 3 Plane                                   */
     uint8_t chroma_mode;  /* 0 DC 1 H 2 V 3 Plane                                   */
     uint8_t qp;
@@ -40,6 +40,7 @@ typedef struct {
     int32_t stride;                /* coded-surface stride = 16*mbw                           */
     int32_t mbw, mbh, vis_h;
     int32_t qp, me_range, lambda;
+    int32_t i4x4;                  /* try Intra_4x4 in I pictures */
 } frame_ctx_t;
 
 #ifdef __cplusplus

@@ -57,6 +57,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 DEV uint2 ldg64(const void *p) { const v2u v = *(const GAS v2u *)p; return make_uint2(v.x, v.y); }
 DEV uint2 ldg64x(const void *p) { return make_uint2(*(const GAS unsigned *)p, *((const GAS unsigned *)p + 1)); } // 4-byte aligned pair
 DEV uint4 ldg128(const void *p) { const v4u v = *(const GAS v4u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+DEV int ldg16(const void *p) { return *(const GAS int16_t *)p; }
 DEV void stg8(void *p, unsigned v) { *(GAS uint8_t *)p = (uint8_t)v; }
 DEV void stg16(void *p, int v) { *(GAS int16_t *)p = (int16_t)v; }
 DEV void stg32(void *p, unsigned v) { *(GAS unsigned *)p = v; }
@@ -647,6 +648,9 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     __shared__ int sh_top[3][17], sh_left[3][17]; // [plane 0=Y,1=Cb,2=Cr][-1..15]
     __shared__ int sh_dc[16], sh_ldc[16];
     __shared__ unsigned tabw[TAB_DWORDS];
+    __shared__ __attribute__((aligned(4))) uint8_t T4[17 * 24]; // Intra_4x4: reconstructed samples incl. the row above / column left
+    __shared__ __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
+    __shared__ int sh_mode4[16], sh_nbm[8];
     const dev_tables *T = (const dev_tables *)tabw;
     const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
     const int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
@@ -669,6 +673,18 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
         int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
         top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c) : 0;
         left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c) : 0;
+    }
+    if (lane < 8) { // Intra_4x4 modes of the neighbouring macroblocks' border blocks: -1 unavailable, 2 unless that MB is I4x4
+        const bool isl = lane < 4;
+        const int k = lane & 3, nb = isl ? mbn - 1 : mbn - mbw;
+        int v = -1;
+        if (isl ? has_left : has_top) {
+            const int blk = isl ? (k == 0 ? 5 : k == 1 ? 7 : k == 2 ? 13 : 15) : (k == 0 ? 10 : k == 1 ? 11 : k == 2 ? 14 : 15);
+            const unsigned ty = ldg8(&ctx->mbi[nb].mb_type);
+            const int md = ldg16(ctx->levels + (size_t)nb * MB_LEVELS + L_LDC + blk);
+            v = ty == 2 ? md : 2;
+        }
+        sh_nbm[lane] = v;
     }
     int src[16];
     if (lane < 24) {
@@ -746,6 +762,125 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
             for (int i = 0; i < 4; i++)
                 pred[r * 4 + i] = mode == 0 ? TOP(0, bx + i) : mode == 1 ? LEFT(0, by + r) : mode == 2 ? dcv
                                   : clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5);
+        // source macroblock to LDS for the per-pixel Intra_4x4 pass
+#pragma unroll
+        for (int r = 0; r < 4; r++) *(unsigned *)&S4[(by + r) * 16 + bx] = pack4(src[r * 4], src[r * 4 + 1], src[r * 4 + 2], src[r * 4 + 3]);
+    }
+    // ================================================================ Intra_4x4 attempt (8.3.1)
+    // Blocks are visited along bx + 2*by (all their prediction sources are then reconstructed); up to
+    // two blocks per step, 16 lanes each, lane = one pixel.  Transforms run across lanes by shuffles.
+    bool use_i4 = false;
+    unsigned nz4 = 0;
+    if (ctx->i4x4) {
+        const unsigned cost16 = (unsigned)__shfl((int)sad_sel, 0);
+        if (lane < 17) T4[lane] = (uint8_t)TOP(0, lane - 1);
+        else if (lane < 33) T4[(lane - 16) * 24] = (uint8_t)LEFT(0, lane - 17);
+        const int half = (lane >> 4) & 1, px = lane & 3, py = (lane >> 2) & 3;
+        const qparams q4 = make_q(T, qp, true);
+        const int lam = ctx->lambda;
+        const int cl4 = (!(px & 1) && !(py & 1)) ? 0 : ((px & 1) && (py & 1)) ? 1 : 2;
+        const int mf4 = cl4 == 0 ? q4.mf[0] : cl4 == 1 ? q4.mf[1] : q4.mf[2], v4 = cl4 == 0 ? q4.v[0] : cl4 == 1 ? q4.v[1] : q4.v[2];
+        const int kz4 = (int)((0xFEA9DB83C7426510ull >> (4 * (py * 4 + px))) & 15); // raster -> zig-zag position
+        unsigned cost4 = 0;
+        WAVE_SYNC();
+#pragma unroll 1
+        for (int s4 = 0; s4 < 10; s4++) {
+            const int by_lo = s4 > 3 ? (s4 - 2) >> 1 : 0, by_hi = (s4 >> 1) < 3 ? (s4 >> 1) : 3;
+            const bool two = by_lo + 1 <= by_hi;
+            const bool valid = lane < 32 && (half == 0 || two);
+            const int by = (valid && half) ? by_lo + 1 : by_lo, bx = s4 - 2 * by;
+            const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1); // blkIdx
+            const bool up = by > 0 || has_top, lf = bx > 0 || has_left;
+            const bool ul = (bx > 0 && by > 0) ? true : bx > 0 ? has_top : by > 0 ? has_left : (has_top && has_left);
+            // top-right samples exist when that block precedes this one in decoding order (or lies in the row above);
+            // block 5 (3,0) never uses them: its two modes that would read the macroblock above-right are not tried
+            const int trb = by > 0 && bx < 3 ? ((((by - 1) >> 1) << 3) | (((bx + 1) >> 1) << 2) | (((by - 1) & 1) << 1) | ((bx + 1) & 1)) : 99;
+            const bool ur = by == 0 ? (bx < 3 && has_top) : (bx < 3 && trb < b);
+            const int emax = ur ? 8 : 4;
+            const uint8_t *tb = &T4[(by * 4) * 24 + bx * 4];
+            auto E = [&](int i) -> int { // ... l1 l0 | corner | t0 t1 ... t7
+                i = i > emax ? emax : i;
+                return i < 0 ? (int)tb[(-i) * 24] : (int)tb[i];
+            };
+            const int ma = bx > 0 ? sh_mode4[by * 4 + bx - 1] : sh_nbm[by], mb_ = by > 0 ? sh_mode4[(by - 1) * 4 + bx] : sh_nbm[4 + bx];
+            const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
+            const int sv = S4[(by * 4 + py) * 16 + bx * 4 + px];
+            const int sumT = E(1) + E(2) + E(3) + E(4), sumL = E(-1) + E(-2) + E(-3) + E(-4);
+            const int dc4 = (up && lf) ? (sumT + sumL + 4) >> 3 : lf ? (sumL + 2) >> 2 : up ? (sumT + 2) >> 2 : 128;
+            unsigned best = BIG; int bmode = 2, bpred = dc4;
+#pragma unroll
+            for (int md = 0; md < 9; md++) {
+                int pv;
+                if (md == 0) pv = E(px + 1);
+                else if (md == 1) pv = E(-(py + 1));
+                else if (md == 2) pv = dc4;
+                else if (md == 3) pv = (px == 3 && py == 3) ? (E(7) + 3 * E(8) + 2) >> 2 : (E(px + py + 1) + 2 * E(px + py + 2) + E(px + py + 3) + 2) >> 2;
+                else if (md == 4) pv = (E(px - py - 1) + 2 * E(px - py) + E(px - py + 1) + 2) >> 2;
+                else if (md == 5) {
+                    const int z = 2 * px - py, k = px - (py >> 1);
+                    pv = (z >= 0 && !(z & 1)) ? (E(k) + E(k + 1) + 1) >> 1 : z >= 0 ? (E(k - 1) + 2 * E(k) + E(k + 1) + 2) >> 2
+                         : z == -1 ? (E(-1) + 2 * E(0) + E(1) + 2) >> 2 : (E(-py) + 2 * E(-py + 1) + E(-py + 2) + 2) >> 2;
+                } else if (md == 6) {
+                    const int z = 2 * py - px, k = py - (px >> 1);
+                    pv = (z >= 0 && !(z & 1)) ? (E(-k) + E(-k - 1) + 1) >> 1 : z >= 0 ? (E(-k + 1) + 2 * E(-k) + E(-k - 1) + 2) >> 2
+                         : z == -1 ? (E(-1) + 2 * E(0) + E(1) + 2) >> 2 : (E(px) + 2 * E(px - 1) + E(px - 2) + 2) >> 2;
+                } else if (md == 7) {
+                    const int k = px + (py >> 1);
+                    pv = !(py & 1) ? (E(k + 1) + E(k + 2) + 1) >> 1 : (E(k + 1) + 2 * E(k + 2) + E(k + 3) + 2) >> 2;
+                } else {
+                    const int z = px + 2 * py, k = py + (px >> 1);
+                    pv = z > 5 ? E(-4) : z == 5 ? (E(-3) + 3 * E(-4) + 2) >> 2 : !(z & 1) ? (E(-(k + 1)) + E(-(k + 2)) + 1) >> 1
+                         : (E(-(k + 1)) + 2 * E(-(k + 2)) + E(-(k + 3)) + 2) >> 2;
+                }
+                const bool need_up = md == 0 || md == 3 || md == 7, need_left = md == 1 || md == 8, need_all = md >= 4 && md <= 6;
+                const bool okm = !((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul)) || (b == 5 && (md == 3 || md == 7)));
+                const unsigned sad = (unsigned)wave16_sum(iabs(sv - pv));
+                const unsigned cst = okm ? sad + (unsigned)(lam * (md == pm ? 1 : 4)) : BIG;
+                if (cst < best) { best = cst; bmode = md; bpred = pv; }
+            }
+            // residual -> 4x4 core transform across the 16 lanes (rows, then columns)
+            const int res = sv - bpred;
+            const int rbase = lane & ~3, cbase = lane & ~12;
+            int a0 = __shfl(res, rbase, 64), a1 = __shfl(res, rbase + 1, 64), a2 = __shfl(res, rbase + 2, 64), a3 = __shfl(res, rbase + 3, 64);
+            int tr = px == 0 ? a0 + a1 + a2 + a3 : px == 1 ? 2 * a0 + a1 - a2 - 2 * a3 : px == 2 ? a0 - a1 - a2 + a3 : a0 - 2 * a1 + 2 * a2 - a3;
+            a0 = __shfl(tr, cbase, 64); a1 = __shfl(tr, cbase + 4, 64); a2 = __shfl(tr, cbase + 8, 64); a3 = __shfl(tr, cbase + 12, 64);
+            const int coef = py == 0 ? a0 + a1 + a2 + a3 : py == 1 ? 2 * a0 + a1 - a2 - 2 * a3 : py == 2 ? a0 - a1 - a2 + a3 : a0 - 2 * a1 + 2 * a2 - a3;
+            const int lv4 = quant1(coef, mf4, q4.f, q4.qbits);
+            // 8.5.12: scale, inverse transform (rows then columns), round
+            const int dq = (lv4 * v4) << q4.shift;
+            a0 = __shfl(dq, rbase, 64); a1 = __shfl(dq, rbase + 1, 64); a2 = __shfl(dq, rbase + 2, 64); a3 = __shfl(dq, rbase + 3, 64);
+            {
+                const int e0 = a0 + a2, e1 = a0 - a2, e2 = (a1 >> 1) - a3, e3 = a1 + (a3 >> 1);
+                tr = px == 0 ? e0 + e3 : px == 1 ? e1 + e2 : px == 2 ? e1 - e2 : e0 - e3;
+            }
+            a0 = __shfl(tr, cbase, 64); a1 = __shfl(tr, cbase + 4, 64); a2 = __shfl(tr, cbase + 8, 64); a3 = __shfl(tr, cbase + 12, 64);
+            int rr;
+            {
+                const int e0 = a0 + a2, e1 = a0 - a2, e2 = (a1 >> 1) - a3, e3 = a1 + (a3 >> 1);
+                rr = py == 0 ? e0 + e3 : py == 1 ? e1 + e2 : py == 2 ? e1 - e2 : e0 - e3;
+            }
+            const int recp = clip255(bpred + ((rr + 32) >> 6));
+            const unsigned long long bal = __ballot(valid && lv4 != 0);
+            const int b0 = ((by_lo >> 1) << 3) | (((s4 - 2 * by_lo) >> 1) << 2) | ((by_lo & 1) << 1) | ((s4 - 2 * by_lo) & 1);
+            if (bal & 0xFFFFull) nz4 |= 1u << b0;
+            if (two) {
+                const int by1 = by_lo + 1, bx1 = s4 - 2 * by1, b1 = ((by1 >> 1) << 3) | ((bx1 >> 1) << 2) | ((by1 & 1) << 1) | (bx1 & 1);
+                if (bal & 0xFFFF0000ull) nz4 |= 1u << b1;
+            }
+            cost4 += (unsigned)__shfl((int)best, 0, 64) + (two ? (unsigned)__shfl((int)best, 16, 64) : 0u);
+            if (valid) {
+                T4[(by * 4 + py + 1) * 24 + bx * 4 + px + 1] = (uint8_t)recp;
+                stg8(ry + (size_t)(y0 + by * 4 + py) * stride + x0 + bx * 4 + px, (unsigned)recp);
+                stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + b * 16 + kz4], lv4);
+                if ((lane & 15) == 0) { sh_mode4[by * 4 + bx] = bmode; stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + b], bmode); }
+            }
+            WAVE_SYNC();
+        }
+        use_i4 = cost4 + (unsigned)(32 * lam) < cost16;
+        if (use_i4) sad_sel = cost4 + (unsigned)(32 * lam); // lane 0 reports it
+    }
+    if (is_luma && !use_i4) {
+        const int b = lane, bx = blkx(b), by = blky(b);
         // ---- residual, core transform, DC through the 4x4 Hadamard
         const qparams q = make_q(T, qp, true);
         int x[16], lev[16];
@@ -797,7 +932,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
             stg32(ry + (size_t)(y0 + by + r) * stride + x0 + bx,
                   pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
                         clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3])));
-    } else if (lane < 32) { // lanes 16-31 form one shuffle group; 16-23 do chroma, 24-31 pad with zeros
+    } else if (!is_luma && lane < 32) { // lanes 16-31 form one shuffle group; 16-23 do chroma, 24-31 pad with zeros
         const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
         const int p = 1 + c;
         // DC of this 4x4 block (8.3.4.1-3)
@@ -859,12 +994,12 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     const unsigned long long any = __ballot(flags & 1), dcm = __ballot(flags & 2);
     const int cmode = __shfl(mode, 16), csad = __shfl((int)sad_sel, 16);
     if (lane == 0) {
-        unsigned nzm = (unsigned)(any & 0xFFFF) | ((unsigned)((any >> 16) & 0xFF) << 16);
-        if (dcm & 0xFFFF) nzm |= NZ_LDC;
+        unsigned nzm = (use_i4 ? nz4 : (unsigned)(any & 0xFFFF)) | ((unsigned)((any >> 16) & 0xFF) << 16);
+        if (!use_i4 && (dcm & 0xFFFF)) nzm |= NZ_LDC;
         if ((dcm >> 16) & 0x0F) nzm |= NZ_CBDC;
         if ((dcm >> 16) & 0xF0) nzm |= NZ_CRDC;
         mb_info_t mb;
-        mb.mvx = 0; mb.mvy = 0; mb.mb_type = 0; mb.i16_mode = (uint8_t)mode; mb.chroma_mode = (uint8_t)cmode;
+        mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)mode; mb.chroma_mode = (uint8_t)cmode;
         mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = sad_sel + (unsigned)csad;
         st_mbinfo(&ctx->mbi[mbn], mb);
     }
@@ -917,7 +1052,7 @@ DEV int has_coef(const mb_info_t &m, int bx4, int by4) { // (bx4,by4) raster 4x4
     return (m.nzmask >> b) & 1;
 }
 DEV int bs_of(const mb_info_t &mp, int bxp, int byp, const mb_info_t &mq, int bxq, int byq, bool mb_edge) {
-    if (mp.mb_type == 0 || mq.mb_type == 0) return mb_edge ? 4 : 3;
+    if (mp.mb_type != 1 || mq.mb_type != 1) return mb_edge ? 4 : 3; // 0 (I16x16) and 2 (I4x4) are intra
     if (has_coef(mp, bxp, byp) || has_coef(mq, bxq, byq)) return 2;
     if (iabs(mp.mvx - mq.mvx) >= 4 || iabs(mp.mvy - mq.mvy) >= 4) return 1; // quarter-sample units
     return 0;

@@ -54,6 +54,7 @@ typedef struct {
     int profile_events;       /* 1: bracket every kernel stage with HIP events (stats)    */
     int use_graphs;           /* 1: replay the per-picture launch sequence as a hipGraph  */
     int keep_prefilter;       /* 1: keep a copy of the picture before deblocking (tests)  */
+    int i4x4;                 /* 1 (default): try Intra_4x4 besides Intra_16x16 in I pictures */
     int subpel;               /* 1 (default): half- then quarter-sample refinement after the integer search */
     int deblock_mode;         /* 0: persistent band-wavefront kernel (one launch per picture);
                                  1: one launch per x+2y wavefront (reference implementation) */

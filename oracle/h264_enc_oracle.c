@@ -566,6 +566,106 @@ static void pred_chroma(const uint8_t *rec_uv, int stride, int cx0, int cy0, int
 #undef L
 }
 
+static int g_orc_i4x4 = 1; /* encoder switch: try Intra_4x4 in I pictures */
+void orc_set_i4x4(int on) { g_orc_i4x4 = on; }
+/* 8.3.1.2 Intra_4x4 sample prediction.  e[0..12]: e[0] = p[-1,-1], e[1..8] = p[0..7,-1], e[9..12] = p[-1,0..3]. */
+static void pred4x4(const int e[13], int mode, int has_up, int has_left, uint8_t out[16]) {
+    const int *t = e + 1, *l = e + 9, c = e[0];
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++) {
+            int v;
+            switch (mode) {
+            case 0: v = t[x]; break;
+            case 1: v = l[y]; break;
+            case 2:
+                if (has_up && has_left) v = (t[0] + t[1] + t[2] + t[3] + l[0] + l[1] + l[2] + l[3] + 4) >> 3;
+                else if (has_left) v = (l[0] + l[1] + l[2] + l[3] + 2) >> 2;
+                else if (has_up) v = (t[0] + t[1] + t[2] + t[3] + 2) >> 2;
+                else v = 128;
+                break;
+            case 3: v = (x == 3 && y == 3) ? (t[6] + 3 * t[7] + 2) >> 2 : (t[x + y] + 2 * t[x + y + 1] + t[x + y + 2] + 2) >> 2; break;
+#define EDGE(i) ((i) < 0 ? l[-(i) - 1] : (i) == 0 ? c : t[(i) - 1]) /* ... l1 l0 c t0 t1 ... */
+            case 4: v = (EDGE(x - y - 1) + 2 * EDGE(x - y) + EDGE(x - y + 1) + 2) >> 2; break;
+            case 5: {
+                int z = 2 * x - y, k = x - (y >> 1);
+                if (z >= 0 && !(z & 1)) v = (EDGE(k) + EDGE(k + 1) + 1) >> 1;
+                else if (z >= 0) v = (EDGE(k - 1) + 2 * EDGE(k) + EDGE(k + 1) + 2) >> 2;
+                else if (z == -1) v = (l[0] + 2 * c + t[0] + 2) >> 2;
+                else v = (EDGE(-y) + 2 * EDGE(-y + 1) + EDGE(-y + 2) + 2) >> 2;
+                break; }
+            case 6: {
+                int z = 2 * y - x, k = y - (x >> 1);
+                if (z >= 0 && !(z & 1)) v = (EDGE(-k) + EDGE(-k - 1) + 1) >> 1;
+                else if (z >= 0) v = (EDGE(-k + 1) + 2 * EDGE(-k) + EDGE(-k - 1) + 2) >> 2;
+                else if (z == -1) v = (l[0] + 2 * c + t[0] + 2) >> 2;
+                else v = (EDGE(x) + 2 * EDGE(x - 1) + EDGE(x - 2) + 2) >> 2;
+                break; }
+#undef EDGE
+            case 7: v = !(y & 1) ? (t[x + (y >> 1)] + t[x + (y >> 1) + 1] + 1) >> 1
+                                 : (t[x + (y >> 1)] + 2 * t[x + (y >> 1) + 1] + t[x + (y >> 1) + 2] + 2) >> 2; break;
+            default: {
+                int z = x + 2 * y, k = y + (x >> 1);
+                if (z > 5) v = l[3];
+                else if (z == 5) v = (l[2] + 3 * l[3] + 2) >> 2;
+                else if (!(z & 1)) v = (l[k] + l[k + 1] + 1) >> 1;
+                else v = (l[k] + 2 * l[k + 1] + l[k + 2] + 2) >> 2;
+                break; }
+            }
+            out[y * 4 + x] = (uint8_t)v;
+        }
+}
+/* Intra_4x4 coding of one macroblock into rec_y (encoder choice of modes: lowest
+ * SAD + lambda * (mode == predicted ? 1 : 4); ties to the lowest mode; block 5 never uses the two
+ * modes that read the top-right macroblock, which keeps the x+y wavefront of the device valid).
+ * Modes go to lev[ORC_L_LDC + blkIdx].  Returns the summed cost. */
+static uint32_t intra4x4_mb(const uint8_t *src_y, uint8_t *rec_y, int stride, int mbw, int mx, int my, int qp, int lambda,
+                            const orc_mbinfo_t *mbi, const int16_t *levels, int16_t *lev, uint32_t *nzmask) {
+    static const uint8_t raster_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+    const int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0, has_tr = my > 0 && mx + 1 < mbw;
+    const orc_mbinfo_t *m = &mbi[my * mbw + mx];
+    uint32_t total = 0;
+    int modes[16]; /* by blkIdx */
+    for (int b = 0; b < 16; b++) {
+        const int bx = k_blk_x[b] >> 2, by = k_blk_y[b] >> 2, X = x0 + 4 * bx, Y = y0 + 4 * by;
+        const int up = by > 0 || has_top, lf = bx > 0 || has_left;
+        const int ul = (bx > 0 && by > 0) ? 1 : bx > 0 ? has_top : by > 0 ? has_left : (has_top && has_left);
+        int ur;
+        if (by == 0) ur = bx < 3 ? has_top : has_tr;
+        else ur = bx < 3 && raster_blk[(by - 1) * 4 + bx + 1] < b;
+        int e[13];
+        e[0] = ul ? rec_y[(size_t)(Y - 1) * stride + X - 1] : 0;
+        for (int i = 0; i < 4; i++) { e[1 + i] = up ? rec_y[(size_t)(Y - 1) * stride + X + i] : 0; e[9 + i] = lf ? rec_y[(size_t)(Y + i) * stride + X - 1] : 0; }
+        for (int i = 4; i < 8; i++) e[1 + i] = ur ? rec_y[(size_t)(Y - 1) * stride + X + i] : e[4];
+        /* 8.3.1.1 predicted mode */
+        int ma = -1, mb_ = -1;
+        if (bx > 0) ma = modes[raster_blk[by * 4 + bx - 1]];
+        else if (has_left) ma = m[-1].mb_type == 2 ? levels[(size_t)(my * mbw + mx - 1) * ORC_LEVELS_PER_MB + ORC_L_LDC + raster_blk[by * 4 + 3]] : 2;
+        if (by > 0) mb_ = modes[raster_blk[(by - 1) * 4 + bx]];
+        else if (has_top) mb_ = m[-mbw].mb_type == 2 ? levels[(size_t)((my - 1) * mbw + mx) * ORC_LEVELS_PER_MB + ORC_L_LDC + raster_blk[12 + bx]] : 2;
+        const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
+        uint8_t pred[16], best_pred[16];
+        uint32_t best = 0xFFFFFFFFu; int best_mode = 2;
+        for (int mode = 0; mode < 9; mode++) {
+            const int need_up = mode == 0 || mode == 3 || mode == 7, need_left = mode == 1 || mode == 8, need_all = mode >= 4 && mode <= 6;
+            if ((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul))) continue;
+            if (b == 5 && (mode == 3 || mode == 7)) continue; /* would read the macroblock above-right */
+            pred4x4(e, mode, up, lf, pred);
+            uint32_t cost = (uint32_t)(lambda * (mode == pm ? 1 : 4));
+            for (int i = 0; i < 16; i++) cost += (uint32_t)iabs(src_y[(size_t)(Y + (i >> 2)) * stride + X + (i & 3)] - pred[i]);
+            if (cost < best) { best = cost; best_mode = mode; memcpy(best_pred, pred, 16); }
+        }
+        modes[b] = best_mode; lev[ORC_L_LDC + b] = (int16_t)best_mode; total += best;
+        int16_t res[16];
+        for (int i = 0; i < 16; i++) res[i] = (int16_t)(src_y[(size_t)(Y + (i >> 2)) * stride + X + (i & 3)] - best_pred[i]);
+        if (tq_block(res, qp, 1, 0, lev + ORC_L_LUMA + b * 16, NULL)) *nzmask |= 1u << b;
+        for (int i = 0; i < 16; i++) rec_y[(size_t)(Y + (i >> 2)) * stride + X + (i & 3)] = best_pred[i];
+        int32_t d[16];
+        dq_block(lev + ORC_L_LUMA + b * 16, qp, 0, 0, 0, d);
+        orc_idct4_add(d, rec_y + (size_t)Y * stride + X, stride);
+    }
+    return total;
+}
+
 /* Mode decision is an encoder choice: lowest SAD(source, prediction) among the modes whose
  * neighbours exist; ties go to the lowest mode number.  Chroma decides on Cb+Cr jointly. */
 void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
@@ -593,6 +693,14 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
             }
             m->i16_mode = (uint8_t)best_mode;
             uint32_t luma_sad = best;
+            /* --- Intra 4x4 candidate (writes rec_y and the luma levels); kept when strictly cheaper */
+            int use_i4 = 0;
+            if (g_orc_i4x4) {
+                uint32_t nz4 = 0;
+                uint32_t cost4 = intra4x4_mb(src_y, rec_y, stride, mbw, mx, my, qp, orc_me_lambda(qp), mbi, levels, lev, &nz4);
+                if (cost4 + (uint32_t)(32 * orc_me_lambda(qp)) < luma_sad) { use_i4 = 1; /* 32 lambda: the extra header bits of I_NxN */ m->mb_type = 2; m->i16_mode = 0; m->nzmask = nz4; luma_sad = cost4 + (uint32_t)(32 * orc_me_lambda(qp)); }
+                else { memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t)); }
+            }
             /* --- chroma mode */
             uint8_t cp[2][64], best_cp[2][64];
             best = 0xFFFFFFFFu; int best_cmode = 0;
@@ -610,6 +718,7 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
             }
             m->chroma_mode = (uint8_t)best_cmode;
             m->cost = luma_sad + best;
+            if (!use_i4) {
             /* --- luma residual: 16 x (4x4 core), DCs through the 4x4 Hadamard (8.5.10 inverse) */
             int16_t dcs[16]; /* raster over 4x4 blocks: index (by/4)*4 + bx/4 */
             for (int b = 0; b < 16; b++) {
@@ -662,6 +771,7 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
                 dq_block(lev + ORC_L_LUMA + b * 16, qp, 1, 1, dcy[(by / 4) * 4 + bx / 4], d);
                 orc_idct4_add(d, rec_y + (size_t)(y0 + by) * stride + x0 + bx, stride);
             }
+            } /* !use_i4 */
             /* --- chroma */
             for (int c = 0; c < 2; c++)
                 for (int y = 0; y < 8; y++)
@@ -717,11 +827,11 @@ static void filter_line(uint8_t *pix, int dstep, int bS, int qp_p, int qp_q, int
 static int blk_has_coef(const orc_mbinfo_t *m, int bx4, int by4) {
     static const uint8_t raster_to_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
     int b = raster_to_blk[by4 * 4 + bx4];
-    if (m->mb_type == 0) return 1; /* intra handled before this is consulted */
+    if (m->mb_type != 1) return 1; /* intra handled before this is consulted */
     return (m->nzmask >> b) & 1;
 }
 static int bs_of(const orc_mbinfo_t *mp, int bxp, int byp, const orc_mbinfo_t *mq, int bxq, int byq, int mb_edge) {
-    if (mp->mb_type == 0 || mq->mb_type == 0) return mb_edge ? 4 : 3;
+    if (mp->mb_type != 1 || mq->mb_type != 1) return mb_edge ? 4 : 3; /* mb_type 0 (I16x16) and 2 (I4x4) are intra */
     if (blk_has_coef(mp, bxp, byp) || blk_has_coef(mq, bxq, byq)) return 2;
     if (iabs(mp->mvx - mq->mvx) >= 4 || iabs(mp->mvy - mq->mvy) >= 4) return 1; /* quarter-sample units */
     return 0;
@@ -972,7 +1082,8 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
             const orc_mbinfo_t *m = &mbi[mbn];
             const int16_t *lev = levels + (size_t)mbn * ORC_LEVELS_PER_MB;
             int cbp_luma = 0, cbp_chroma = 0;
-            if (m->mb_type == 0) cbp_luma = (m->nzmask & 0xFFFF) ? 15 : 0;
+            const int intra = m->mb_type != 1, i16 = m->mb_type == 0;
+            if (i16) cbp_luma = (m->nzmask & 0xFFFF) ? 15 : 0;
             else for (int g = 0; g < 4; g++) if ((m->nzmask >> (4 * g)) & 0xF) cbp_luma |= 1 << g;
             if (m->nzmask & 0x00FF0000u) cbp_chroma = 2;
             else if (m->nzmask & (ORC_NZ_CBDC | ORC_NZ_CRDC)) cbp_chroma = 1;
@@ -983,10 +1094,25 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
                 if (cbp_luma == 0 && cbp_chroma == 0 && m->mvx == sx && m->mvy == sy) { skip_run++; continue; }
             }
             if (!is_idr) { bw_ue(&b, (uint32_t)skip_run); skip_run = 0; }
-            if (m->mb_type == 0) {
+            if (i16) {
                 int t = 1 + m->i16_mode + 4 * cbp_chroma + (cbp_luma ? 12 : 0); /* Table 7-11 */
                 bw_ue(&b, (uint32_t)(is_idr ? t : t + 5));
                 bw_ue(&b, m->chroma_mode);                                        /* intra_chroma_pred_mode */
+            } else if (intra) { /* I_NxN (Intra_4x4): 7.3.5.1 mb_pred */
+                static const uint8_t rb[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* raster -> blkIdx (self-inverse) */
+                bw_ue(&b, is_idr ? 0u : 5u);
+                for (int blk = 0; blk < 16; blk++) {
+                    int bx = rb[blk] & 3, by = rb[blk] >> 2, ma = -1, mb_ = -1;
+                    if (bx > 0) ma = lev[ORC_L_LDC + rb[by * 4 + bx - 1]];
+                    else if (mx > 0) ma = m[-1].mb_type == 2 ? lev[-ORC_LEVELS_PER_MB + ORC_L_LDC + rb[by * 4 + 3]] : 2;
+                    if (by > 0) mb_ = lev[ORC_L_LDC + rb[(by - 1) * 4 + bx]];
+                    else if (my > 0) mb_ = m[-mbw].mb_type == 2 ? lev[-(ptrdiff_t)mbw * ORC_LEVELS_PER_MB + ORC_L_LDC + rb[12 + bx]] : 2;
+                    int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode = lev[ORC_L_LDC + blk];
+                    if (mode == pm) bw_put(&b, 1, 1);
+                    else { bw_put(&b, 1, 0); bw_put(&b, 3, (uint32_t)(mode < pm ? mode : mode - 1)); }
+                }
+                bw_ue(&b, m->chroma_mode);
+                bw_ue(&b, k_cbp_to_codenum_intra[cbp_chroma * 16 + cbp_luma]);
             } else {
                 bw_ue(&b, 0); /* P_L0_16x16 */
                 int px, py;
@@ -995,7 +1121,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
                 bw_se(&b, m->mvy - py);
                 bw_ue(&b, k_cbp_to_codenum_inter[cbp_chroma * 16 + cbp_luma]);
             }
-            if (m->mb_type == 0 || cbp_luma || cbp_chroma) {
+            if (i16 || cbp_luma || cbp_chroma) {
                 bw_se(&b, m->qp - prev_qp); /* mb_qp_delta */
                 prev_qp = m->qp;
             }
@@ -1009,7 +1135,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
         else if (my > 0) nb = tc_l[(mbn - mbw) * 16 + raster_blk[12 + (bx)]];                       \
         (out) = (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));    \
     } while (0)
-            if (m->mb_type == 0) {
+            if (i16) {
                 int nC;
                 NC_LUMA(0, 0, nC);
                 cavlc_block(&b, lev + ORC_L_LDC, 16, nC);
@@ -1018,7 +1144,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
                 if (!(cbp_luma & (1 << (blk >> 2)))) continue;
                 int bx = blk_raster[blk] & 3, by = blk_raster[blk] >> 2, nC;
                 NC_LUMA(bx, by, nC);
-                int tc = m->mb_type == 0 ? cavlc_block(&b, lev + ORC_L_LUMA + blk * 16 + 1, 15, nC)
+                int tc = i16 ? cavlc_block(&b, lev + ORC_L_LUMA + blk * 16 + 1, 15, nC)
                                          : cavlc_block(&b, lev + ORC_L_LUMA + blk * 16, 16, nC);
                 tc_l[mbn * 16 + blk] = (uint8_t)tc;
             }

@@ -27,7 +27,8 @@ extern "C" {
 /* Per-macroblock side record, 16 bytes (SURVEY.md section 8d "16 B/MB info"). */
 typedef struct {
     int16_t mvx, mvy;     /* luma motion vector, quarter-sample units (P macroblocks)  */
-    uint8_t mb_type;      /* 0 = I16x16, 1 = P_L0_16x16 (P_Skip is an entropy decision) */
+    uint8_t mb_type;      /* 0 = I16x16, 1 = P_L0_16x16 (P_Skip is an entropy decision),
+                             2 = I4x4 (its 16 modes sit in levels[ORC_L_LDC + blkIdx])    */
     uint8_t i16_mode;     /* Intra16x16PredMode 0 V, 1 H, 2 DC, 3 Plane                 */
     uint8_t chroma_mode;  /* intra_chroma_pred_mode 0 DC, 1 H, 2 V, 3 Plane             */
     uint8_t qp;           /* QP_Y of this macroblock                                    */
@@ -73,6 +74,8 @@ void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t 
 void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
                      uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
                      orc_mbinfo_t *mbi, int16_t *levels);
+
+void orc_set_i4x4(int on); /* process-wide: try Intra_4x4 besides Intra_16x16 (default on) */
 
 /* In-loop deblocking filter, in place, normative macroblock raster order (8.7). */
 void orc_deblock_frame(uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mbh,

@@ -54,6 +54,8 @@ def lib():
         L.orc_subpel_frame.restype = None
         L.orc_enc_set_subpel.argtypes = [vp, C.c_int]
         L.orc_enc_set_subpel.restype = None
+        L.orc_set_i4x4.argtypes = [C.c_int]
+        L.orc_set_i4x4.restype = None
         L.orc_inter_frame.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.orc_inter_frame.restype = None
         L.orc_intra_frame.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -218,6 +220,11 @@ def inter_frame(src_y, src_uv, ref_y, ref_uv, mbi, qp):
     L.orc_inter_frame(_ptr(src_y), _ptr(src_uv), _ptr(ref_y), _ptr(ref_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16,
                       H // 16, qp, _ptr(mbi), _ptr(lev))
     return rec_y, rec_uv, mbi, lev
+
+
+def set_i4x4(on):
+    """Process-wide oracle switch (default on): try Intra_4x4 in I pictures."""
+    lib().orc_set_i4x4(int(on))
 
 
 def intra_frame(src_y, src_uv, qp):

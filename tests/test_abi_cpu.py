@@ -87,7 +87,8 @@ def test_host_cavlc_equals_oracle_on_random_levels(oracle):
         mag = [1, 3, 40, 2047][(trial // 4) % 4]
         for m in range(n):
             intra = is_idr or rng.random() < 0.2
-            mbi[m]["mb_type"] = 0 if intra else 1
+            i4 = intra and rng.random() < 0.5
+            mbi[m]["mb_type"] = (2 if i4 else 0) if intra else 1
             mbi[m]["qp"] = 30
             mbi[m]["i16_mode"], mbi[m]["chroma_mode"] = rng.integers(0, 4), rng.integers(0, 4)
             mbi[m]["mvx"], mbi[m]["mvy"] = (0, 0) if intra else (rng.integers(-16, 17), rng.integers(-16, 17))
@@ -95,11 +96,14 @@ def test_host_cavlc_equals_oracle_on_random_levels(oracle):
             for b in range(16):
                 if rng.random() < 0.7:
                     v = (rng.random(16) < dens) * rng.integers(-mag, mag + 1, 16)
-                    if intra:
+                    if intra and not i4:
                         v[0] = 0
                     lev[m, b * 16:(b + 1) * 16] = v
                     nz |= int(v.any()) << b
-            if intra:
+            if i4:
+                lev[m, 256:272] = rng.integers(0, 9, 16)  # the sixteen Intra_4x4 modes
+                mbi[m]["i16_mode"] = 0
+            elif intra:
                 v = (rng.random(16) < dens) * rng.integers(-mag, mag + 1, 16)
                 lev[m, 256:272] = v
                 nz |= int(v.any()) << 24

@@ -79,13 +79,20 @@ def test_inter_kernel_matches_oracle(E, oracle, w, h, qp, sub):
 
 @pytest.mark.parametrize("w,h", SIZES)
 @pytest.mark.parametrize("qp", [0, 12, 28, 40, 51])
-def test_intra_kernel_matches_oracle(E, oracle, w, h, qp):
+@pytest.mark.parametrize("i4", [True, False])
+def test_intra_kernel_matches_oracle(E, oracle, w, h, qp, i4):
     cy, cuv = frames(w, h, 1)[0][:2]
-    o_y, o_uv, o_mbi, o_lev = oracle.intra_frame(cy, cuv, qp)
-    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp)
+    oracle.set_i4x4(i4)
+    try:
+        o_y, o_uv, o_mbi, o_lev = oracle.intra_frame(cy, cuv, qp)
+    finally:
+        oracle.set_i4x4(True)
+    if i4:
+        assert (o_mbi["mb_type"] == 2).any() or qp >= 40
+    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp, i4x4=i4)
     d_y, d_uv, d_mbi, d_lev = e.stage_intra(cy, cuv, qp)
-    assert mbinfo_equal(d_mbi, o_mbi, ("i16_mode", "chroma_mode", "cost")), \
-        [(f, first_diff(d_mbi[f], o_mbi[f])) for f in ("i16_mode", "chroma_mode", "cost")]
+    assert mbinfo_equal(d_mbi, o_mbi, ("mb_type", "i16_mode", "chroma_mode", "cost")), \
+        [(f, first_diff(d_mbi[f], o_mbi[f])) for f in ("mb_type", "i16_mode", "chroma_mode", "cost")]
     assert np.array_equal(d_lev, o_lev), first_diff(d_lev, o_lev)
     assert np.array_equal(d_y, o_y), first_diff(d_y, o_y)
     assert np.array_equal(d_uv, o_uv), first_diff(d_uv, o_uv)
