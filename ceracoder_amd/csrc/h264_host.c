@@ -97,16 +97,17 @@ static int pick_level(int mbw, int mbh, int fps_num, int fps_den) { /* Table A-1
     return 52;
 }
 
-size_t h264_write_headers(uint8_t *out, size_t cap, int width, int height, int fps_num, int fps_den) {
+size_t h264_write_headers(uint8_t *out, size_t cap, int width, int height, int fps_num, int fps_den, int t8) {
     uint8_t rb[160];
     bits_t b;
     const int mbw = (width + 15) / 16, mbh = (height + 15) / 16;
     /* 7.3.2.1.1 seq_parameter_set_data: Constrained Baseline */
     bits_init(&b, rb, sizeof rb);
-    bits_put(&b, 8, 66);
-    bits_put(&b, 8, 0xC0);
+    bits_put(&b, 8, t8 ? 100u : 66u);  /* High when the 8x8 transform is on, else Constrained Baseline */
+    bits_put(&b, 8, t8 ? 0x00u : 0xC0u);
     bits_put(&b, 8, (uint32_t)pick_level(mbw, mbh, fps_num, fps_den));
     bits_ue(&b, 0);
+    if (t8) { bits_ue(&b, 1); bits_ue(&b, 0); bits_ue(&b, 0); bits_put(&b, 2, 0); } /* 4:2:0, 8 bit, no bypass, flat scaling */
     bits_ue(&b, 4); /* log2_max_frame_num_minus4 */
     bits_ue(&b, 2); /* pic_order_cnt_type 2: output order = decoding order */
     bits_ue(&b, 1); /* max_num_ref_frames */
@@ -143,6 +144,7 @@ size_t h264_write_headers(uint8_t *out, size_t cap, int width, int height, int f
     bits_se(&b, 0); bits_se(&b, 0); bits_se(&b, 0);
     bits_put(&b, 1, 1); /* deblocking_filter_control_present_flag */
     bits_put(&b, 2, 0); /* constrained_intra_pred_flag, redundant_pic_cnt_present_flag */
+    if (t8) { bits_put(&b, 2, 2); bits_se(&b, 0); } /* transform_8x8_mode_flag = 1, pic_scaling_matrix_present_flag = 0, second_chroma_qp_index_offset */
     n = bits_finish(&b, rb);
     size_t c = emit_nal(out + a, cap - a, 3, 8, rb, n);
     if (!c || b.overflow) return 0;
@@ -262,16 +264,16 @@ static inline void predict_mv(const mb_info_t *mbi, int mbw, int mx, int my, int
 
 /* ------------------------------------------------------------------ slice */
 struct h264_writer {
-    int mbw, mbh;
+    int mbw, mbh, t8;
     uint8_t *rbsp; size_t rbsp_cap;
     uint8_t *tc_l; /* TotalCoeff per luma 4x4 in raster order, 16 per macroblock */
     uint8_t *tc_c; /* per chroma AC block: Cb 0-3, Cr 4-7 */
 };
 
-h264_writer_t *h264_writer_new(int mbw, int mbh) {
+h264_writer_t *h264_writer_new(int mbw, int mbh, int t8) {
     h264_writer_t *w = (h264_writer_t *)calloc(1, sizeof *w);
     if (!w) return NULL;
-    w->mbw = mbw; w->mbh = mbh;
+    w->mbw = mbw; w->mbh = mbh; w->t8 = t8;
     w->rbsp_cap = (size_t)mbw * mbh * 1024 + 1024;
     w->rbsp = (uint8_t *)malloc(w->rbsp_cap);
     w->tc_l = (uint8_t *)malloc((size_t)mbw * mbh * 16);
@@ -352,6 +354,7 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
                 bits_se(&b, m->mvx - px); /* mvd_l0: vectors are kept in quarter-sample units */
                 bits_se(&b, m->mvy - py);
                 bits_ue(&b, cbp_inter_code[cbp_c * 16 + cbp_l]);
+                if (w->t8 && cbp_l) bits_put(&b, 1, (nz & NZ_T8) ? 1u : 0u); /* transform_size_8x8_flag */
             } else {
                 if (!is_idr) { bits_ue(&b, (uint32_t)skip); skip = 0; }
                 if (i16) {
@@ -360,6 +363,7 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
                     bits_ue(&b, m->chroma_mode);
                 } else { /* I_NxN: sixteen Intra_4x4 modes, each predicted from the blocks left and above (8.3.1.1) */
                     bits_ue(&b, is_idr ? 0u : 5u);
+                    if (w->t8) bits_put(&b, 1, 0); /* transform_size_8x8_flag: Intra_4x4, not Intra_8x8 */
                     for (int blk = 0; blk < 16; blk++) {
                         const int r = blk_to_raster[blk], bx = r & 3, by = r >> 2;
                         int ma = -1, mb_ = -1;

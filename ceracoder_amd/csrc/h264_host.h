@@ -11,11 +11,11 @@ extern "C" {
 #endif
 
 typedef struct h264_writer h264_writer_t;
-h264_writer_t *h264_writer_new(int mbw, int mbh);
+h264_writer_t *h264_writer_new(int mbw, int mbh, int transform8x8);
 void h264_writer_free(h264_writer_t *w);
 size_t h264_max_au_bytes(int mbw, int mbh);
 /* SPS + PPS (Annex B).  Returns bytes written, 0 if `cap` is too small. */
-size_t h264_write_headers(uint8_t *out, size_t cap, int width, int height, int fps_num, int fps_den);
+size_t h264_write_headers(uint8_t *out, size_t cap, int width, int height, int fps_num, int fps_den, int transform8x8);
 /* One slice NAL covering the whole picture.  Returns bytes written, 0 if out of room. */
 size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                         int slice_qp, const mb_info_t *mbi, const int16_t *levels);

@@ -99,7 +99,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0;
 }
 
 static void launch_intra_all(mi355enc_t *h) {
@@ -209,7 +209,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipEventCreateWithFlags(&s->gpu_done, hipEventDisableTiming));
         for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&s->ev[k]));
     }
-    h->writer = h264_writer_new(h->mbw, h->mbh);
+    h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
     if (!h->writer) return MI355ENC_ERR_NOMEM;
     rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -279,7 +279,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     const int set = (int)(h->n_submitted & 1);
     c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set];
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
-    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4;
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     const int prof = h->cfg.profile_events;
     if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
@@ -360,7 +360,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     }
     size_t n = 0;
     if (s->is_idr) {
-        n = h264_write_headers(out, out_cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den);
+        n = h264_write_headers(out, out_cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den, h->cfg.transform8x8);
         if (!n) return MI355ENC_ERR_OVERFLOW;
     }
     size_t m = h264_write_slice(h->writer, out + n, out_cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels);
@@ -436,7 +436,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
     HIPCHK(hipStreamSynchronize(h->cstream));
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
-    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4;
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     return 0;
 }
@@ -535,17 +535,17 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
 }
 
 // ---------------------------------------------------------------- host-only stages
-int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den, uint8_t *out, size_t cap, size_t *out_len) {
+int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den, int t8, uint8_t *out, size_t cap, size_t *out_len) {
     if (!out || !out_len || width < 16 || height < 16 || fps_num <= 0 || fps_den <= 0) return MI355ENC_ERR_ARG;
-    size_t n = h264_write_headers(out, cap, width, height, fps_num, fps_den);
+    size_t n = h264_write_headers(out, cap, width, height, fps_num, fps_den, t8);
     if (!n) return MI355ENC_ERR_OVERFLOW;
     *out_len = n;
     return MI355ENC_OK;
 }
-int mi355enc_host_write_slice(int mbw, int mbh, int is_idr, int frame_num, int idr_pic_id, int qp, const void *mbinfo,
+int mi355enc_host_write_slice(int mbw, int mbh, int is_idr, int frame_num, int idr_pic_id, int qp, int t8, const void *mbinfo,
                               const int16_t *levels, uint8_t *out, size_t cap, size_t *out_len) {
     if (!out || !out_len || !mbinfo || !levels || mbw < 1 || mbh < 1 || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
-    h264_writer_t *w = h264_writer_new(mbw, mbh);
+    h264_writer_t *w = h264_writer_new(mbw, mbh, t8);
     if (!w) return MI355ENC_ERR_NOMEM;
     size_t n = h264_write_slice(w, out, cap, is_idr, frame_num, idr_pic_id, qp, (const mb_info_t *)mbinfo, levels);
     h264_writer_free(w);

@@ -27,6 +27,7 @@ typedef struct {
 #define NZ_LDC (1u << 24)
 #define NZ_CBDC (1u << 25)
 #define NZ_CRDC (1u << 26)
+#define NZ_T8 (1u << 27) /* transform_size_8x8_flag of a P macroblock */
 
 /* Device-resident description of the picture being encoded; kernels read it through one
  * pointer so that the per-picture launch sequence can be replayed as a hipGraph. */
@@ -41,6 +42,7 @@ typedef struct {
     int32_t mbw, mbh, vis_h;
     int32_t qp, me_range, lambda;
     int32_t i4x4;                  /* try Intra_4x4 in I pictures */
+    int32_t t8;                    /* P macroblocks use the 8x8 transform (High profile stream) */
 } frame_ctx_t;
 
 #ifdef __cplusplus

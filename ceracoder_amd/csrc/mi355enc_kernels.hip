@@ -21,6 +21,9 @@ struct dev_tables {
     uint16_t mf[6][3];                                // encoder quantiser multipliers
     uint8_t v[6][3];                                  // 8.5.9 normAdjust4x4
     uint8_t pad[2];
+    uint16_t mf8[6][6];                               // 8x8 quantiser multipliers
+    uint8_t v8[6][6];                                 // 8.5.9 normAdjust8x8
+    uint8_t izz8[64];                                 // 8x8 zig-zag, raster position -> scan index
 };
 static_assert(sizeof(dev_tables) % 4 == 0, "dev_tables is copied as dwords");
 #define TAB_DWORDS ((int)(sizeof(dev_tables) / 4))
@@ -42,7 +45,11 @@ __device__ const dev_tables g_tab = {
      34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39},
     {{13107, 5243, 8066}, {11916, 4660, 7490}, {10082, 4194, 6554}, {9362, 3647, 5825}, {8192, 3355, 5243}, {7282, 2893, 4559}},
     {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}},
-    {0, 0}};
+    {0, 0},
+    {{13107, 11428, 20972, 12222, 16777, 15481}, {11916, 10826, 19174, 11058, 14980, 14290}, {10082, 8943, 15978, 9675, 12710, 11985},
+     {9362, 8228, 14913, 8931, 11984, 11259},    {8192, 7346, 13159, 7740, 10486, 9777},     {7282, 6428, 11570, 6830, 9118, 8640}},
+    {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31}, {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}},
+    {0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63}};
 
 
 // ------------------------------------------------------------------ global-memory accessors
@@ -522,6 +529,56 @@ DEV int qpel_from9(const int (*n)[9], int i, int jj, int fx, int fy) {
 #undef VH1
 }
 
+// 8-point transforms of the High-profile 8x8 residual path: forward (encoder side) and 8.5.13 inverse
+DEV void fdct8_1d(int *v) {
+    const int s07 = v[0] + v[7], s16 = v[1] + v[6], s25 = v[2] + v[5], s34 = v[3] + v[4];
+    const int a0 = s07 + s34, a1 = s16 + s25, a2 = s07 - s34, a3 = s16 - s25;
+    const int d07 = v[0] - v[7], d16 = v[1] - v[6], d25 = v[2] - v[5], d34 = v[3] - v[4];
+    const int a4 = d16 + d25 + (d07 + (d07 >> 1)), a5 = d07 - d34 - (d25 + (d25 >> 1));
+    const int a6 = d07 + d34 - (d16 + (d16 >> 1)), a7 = d16 - d25 + (d34 + (d34 >> 1));
+    v[0] = a0 + a1; v[1] = a4 + (a7 >> 2); v[2] = a2 + (a3 >> 1); v[3] = a5 + (a6 >> 2);
+    v[4] = a0 - a1; v[5] = a6 - (a5 >> 2); v[6] = (a2 >> 1) - a3; v[7] = (a4 >> 2) - a7;
+}
+DEV void idct8_1d(int *v) {
+    const int a0 = v[0] + v[4], a2 = v[0] - v[4], a4 = (v[2] >> 1) - v[6], a6 = (v[6] >> 1) + v[2];
+    const int b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
+    const int a1 = -v[3] + v[5] - v[7] - (v[7] >> 1), a3 = v[1] + v[7] - v[3] - (v[3] >> 1);
+    const int a5 = -v[1] + v[7] + v[5] + (v[5] >> 1), a7 = v[3] + v[5] + v[1] + (v[1] >> 1);
+    const int b1 = (a7 >> 2) + a1, b3 = a3 + (a5 >> 2), b5 = (a3 >> 2) - a5, b7 = a7 - (a1 >> 2);
+    v[0] = b0 + b7; v[1] = b2 + b5; v[2] = b4 + b3; v[3] = b6 + b1;
+    v[4] = b6 - b1; v[5] = b4 - b3; v[6] = b2 - b5; v[7] = b0 - b7;
+}
+DEV int pos_class8(int y, int x) { // 8.5.9
+    if (!(y & 3) && !(x & 3)) return 0;
+    if ((y & 1) && (x & 1)) return 1;
+    if ((y & 3) == 2 && (x & 3) == 2) return 2;
+    if ((!(y & 3) && (x & 1)) || ((y & 1) && !(x & 3))) return 3;
+    if ((!(y & 3) && (x & 3) == 2) || ((y & 3) == 2 && !(x & 3))) return 4;
+    return 5;
+}
+// 8.4.2.2.1 for one sample out of a clamped neighbourhood with NC columns held in registers:
+// n[r][c] is the integer sample at (X - 2 + c, Y - 2 + r) of the region's first pixel; (i, jj) selects the pixel.
+template <int NC>
+DEV int qpel_nb(const int (*n)[NC], int i, int jj, int fx, int fy) {
+#define N(dx, dy) n[jj + 2 + (dy)][i + 2 + (dx)]
+#define HB1(dx, dy) tap6(N((dx) - 2, dy), N((dx) - 1, dy), N(dx, dy), N((dx) + 1, dy), N((dx) + 2, dy), N((dx) + 3, dy))
+#define VH1(dx, dy) tap6(N(dx, (dy) - 2), N(dx, (dy) - 1), N(dx, dy), N(dx, (dy) + 1), N(dx, (dy) + 2), N(dx, (dy) + 3))
+    const int G = N(0, 0);
+    if (!fx && !fy) return G;
+    const int b = clip255((HB1(0, 0) + 16) >> 5), h = clip255((VH1(0, 0) + 16) >> 5);
+    if (!fy) return fx == 2 ? b : fx == 1 ? (G + b + 1) >> 1 : (N(1, 0) + b + 1) >> 1;
+    if (!fx) return fy == 2 ? h : fy == 1 ? (G + h + 1) >> 1 : (N(0, 1) + h + 1) >> 1;
+    const int m = clip255((VH1(1, 0) + 16) >> 5), s = clip255((HB1(0, 1) + 16) >> 5);
+    if ((fx & 1) && (fy & 1)) return ((fy == 1 ? b : s) + (fx == 1 ? h : m) + 1) >> 1;
+    const int j = clip255((tap6(HB1(0, -2), HB1(0, -1), HB1(0, 0), HB1(0, 1), HB1(0, 2), HB1(0, 3)) + 512) >> 10);
+    if (fx == 2 && fy == 2) return j;
+    if (fx == 2) return ((fy == 1 ? b : s) + j + 1) >> 1;
+    return ((fx == 1 ? h : m) + j + 1) >> 1;
+#undef N
+#undef HB1
+#undef VH1
+}
+
 // =================================================================== inter (P) macroblocks
 // One wave = two macroblocks.  Lanes 0-31: one 4x4 luma block each (MB = lane>>4);
 // lanes 32-47: one 4x4 chroma block each (MB = (lane-32)>>3); lanes 48-63 idle.
@@ -540,7 +597,136 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
     // quarter-sample vector; the clamp only guards against garbage records (real vectors are far inside it)
     const int mvx = clip3(-4 * (x0 + 24), 4 * (W - x0 + 8), info.mvx), mvy = clip3(-4 * (y0 + 24), 4 * (H - y0 + 8), info.mvy);
     int flags = 0; // bit0: AC/any nonzero, bit1: chroma DC nonzero
-    if (is_luma && mb_ok) {
+    __shared__ int t8tile[4][8][64]; // [wave][8x8 block of the wave's two macroblocks][8x8], used only by the 8x8 transform path
+    const bool t8 = ctx->t8 != 0;
+    if (t8) { // High profile: every P macroblock through the 8x8 transform.  Four lanes per 8x8 block, two rows each;
+              // the separable passes alternate rows/columns through a per-block LDS tile (same-wave traffic only).
+        int pr8[2][8], rs[2][8], cw[2][8];
+        unsigned submask = 0; // non-zero 4x4 "sub-blocks" (scan positions 4k+j) this lane has seen
+        int *tile = t8tile[wave][(lane >> 2) & 7];
+        const int i8 = (lane >> 2) & 3, j = lane & 3;
+        const int bx8 = x0 + (i8 & 1) * 8, by8 = y0 + (i8 >> 1) * 8;
+        const int m6 = qp % 6, k6 = qp / 6;
+        if (is_luma && mb_ok) {
+            const uint8_t *__restrict__ s = ctx->src_y;
+            const uint8_t *__restrict__ rf = ctx->ref_y;
+            const int ss = ctx->src_stride, vh = ctx->vis_h;
+            const int fx = mvx & 3, fy = mvy & 3, X = bx8 + (mvx >> 2), Y = by8 + 2 * j + (mvy >> 2);
+            if (fx == 0 && fy == 0 && X >= 0 && Y >= 0 && X + 8 <= W && Y + 2 <= H) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    size_t a = (size_t)(Y + r) * stride + X;
+                    const unsigned *ap = (const unsigned *)(rf + (a & ~(size_t)3));
+                    const unsigned w0 = ldg32(ap), w1 = ldg32(ap + 1), w2 = ldg32(ap + 2);
+                    const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)(a & 3)), hi = __builtin_amdgcn_alignbyte(w2, w1, (unsigned)(a & 3));
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { pr8[r][i] = byte_of(lo, i); pr8[r][4 + i] = byte_of(hi, i); }
+                }
+            } else {
+                int n[7][13];
+#pragma unroll
+                for (int r = 0; r < 7; r++) {
+                    const int yy = clip3(0, H - 1, Y - 2 + r);
+#pragma unroll
+                    for (int c2 = 0; c2 < 13; c2++) n[r][c2] = (int)ldg8(rf + (size_t)yy * stride + clip3(0, W - 1, X - 2 + c2));
+                }
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) pr8[r][i] = qpel_nb<13>(n, i, r, fx, fy);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                int sy = by8 + 2 * j + r;
+                sy = sy < vh ? sy : vh - 1;
+                const uint2 sw = ldg64(s + (size_t)sy * ss + bx8);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { rs[r][i] = byte_of(sw.x, i) - pr8[r][i]; rs[r][4 + i] = byte_of(sw.y, i) - pr8[r][4 + i]; }
+                fdct8_1d(rs[r]);
+#pragma unroll
+                for (int i = 0; i < 8; i++) tile[(2 * j + r) * 8 + i] = rs[r][i];
+            }
+        }
+        WAVE_SYNC();
+        if (is_luma && mb_ok) { // columns 2j, 2j+1: second forward pass, quantise, scale
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) cw[c2][r] = tile[r * 8 + 2 * j + c2];
+                fdct8_1d(cw[c2]);
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int xx = 2 * j + c2, cl = pos_class8(r, xx);
+                    const int qbits = 16 + k6, f = (1 << qbits) / 6;
+                    const int a = iabs(cw[c2][r]);
+                    int l = (int)(((long long)a * g_tab.mf8[m6][cl] + f) >> qbits);
+                    l = l > 2047 ? 2047 : l;
+                    l = cw[c2][r] < 0 ? -l : l;
+                    const int kk = g_tab.izz8[r * 8 + xx];
+                    stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + (4 * i8 + (kk & 3)) * 16 + (kk >> 2)], l);
+                    if (l) submask |= 1u << (kk & 3);
+                    const int ls = 16 * g_tab.v8[m6][cl];
+                    cw[c2][r] = qp >= 36 ? (l * ls) << (k6 - 6) : (l * ls + (1 << (5 - k6))) >> (6 - k6);
+                }
+            }
+        }
+        WAVE_SYNC();
+        if (is_luma && mb_ok) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) tile[r * 8 + 2 * j + c2] = cw[c2][r];
+        }
+        // the 4-bit sub-block mask of the 8x8 block: OR over its four lanes
+        submask |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)submask, 0xB1, 0xF, 0xF, false);
+        submask |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)submask, 0x4E, 0xF, 0xF, false);
+        WAVE_SYNC();
+        if (is_luma && mb_ok) { // 8.5.13: rows first ...
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) rs[r][i] = tile[(2 * j + r) * 8 + i];
+                idct8_1d(rs[r]);
+            }
+        }
+        WAVE_SYNC();
+        if (is_luma && mb_ok) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) tile[(2 * j + r) * 8 + i] = rs[r][i];
+        }
+        WAVE_SYNC();
+        if (is_luma && mb_ok) { // ... then columns, rounding
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+#pragma unroll
+                for (int r = 0; r < 8; r++) cw[c2][r] = tile[r * 8 + 2 * j + c2];
+                idct8_1d(cw[c2]);
+            }
+        }
+        WAVE_SYNC();
+        if (is_luma && mb_ok) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+                for (int r = 0; r < 8; r++) tile[r * 8 + 2 * j + c2] = (cw[c2][r] + 32) >> 6;
+        }
+        WAVE_SYNC();
+        if (is_luma && mb_ok) {
+            uint8_t *__restrict__ rec = ctx->rec_y;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                int o[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = clip255(pr8[r][i] + tile[(2 * j + r) * 8 + i]);
+                uint8_t *dst = rec + (size_t)(by8 + 2 * j + r) * stride + bx8;
+                stg32(dst, pack4(o[0], o[1], o[2], o[3]));
+                stg32(dst + 4, pack4(o[4], o[5], o[6], o[7]));
+            }
+            flags = (submask >> j) & 1; // lane 4*i8 + j reports sub-block j, which is blkIdx 4*i8 + j
+        }
+    } else if (is_luma && mb_ok) {
         const int b = lane & 15, bx = blkx(b), by = blky(b);
         const qparams q = make_q(&g_tab, qp, false);
         int x[16], pr[16], lev[16];
@@ -625,6 +811,7 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
         unsigned nzm = (unsigned)((any >> (16 * s2)) & 0xFFFF) | ((unsigned)((any >> (32 + 8 * s2)) & 0xFF) << 16);
         if ((dcm >> (32 + 8 * s2)) & 0x0F) nzm |= NZ_CBDC;
         if ((dcm >> (32 + 8 * s2)) & 0xF0) nzm |= NZ_CRDC;
+        if (t8 && (nzm & 0xFFFF)) nzm |= NZ_T8; // transform_size_8x8_flag exists only with luma cbp != 0
         mb_info_t *mb = &ctx->mbi[mbn];
         stg32(&mb->mb_type, 1u | ((unsigned)qp << 24)); // mb_type 1, modes 0, qp
         stg32(&mb->nzmask, nzm);
@@ -639,11 +826,16 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
 // =================================================================== intra (I) macroblocks
 // One wave per macroblock, launched once per anti-diagonal x + y = diag (left, top and
 // top-left neighbours are then complete).  Lanes 0-15: luma 4x4 blocks; lanes 16-23: chroma.
+// sum over each row of 16 lanes, result in every lane: four DPP adds (no LDS crossbar round trips)
 DEV int wave16_sum(int v) {
-#pragma unroll
-    for (int s = 8; s >= 1; s >>= 1) v += __shfl_xor(v, s, 16);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false); // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // quad_perm:[1,0,3,2]
     return v;
 }
+// value of lane k of this lane's quad (k = 0..3), and of row r of this lane's column in a 4x4 tile laid out on 16 lanes
+template <int K> DEV int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, false); }
 __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
     __shared__ int sh_top[3][17], sh_left[3][17]; // [plane 0=Y,1=Cb,2=Cr][-1..15]
     __shared__ int sh_dc[16], sh_ldc[16];
@@ -840,15 +1032,15 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
             }
             // residual -> 4x4 core transform across the 16 lanes (rows, then columns)
             const int res = sv - bpred;
-            const int rbase = lane & ~3, cbase = lane & ~12;
-            int a0 = __shfl(res, rbase, 64), a1 = __shfl(res, rbase + 1, 64), a2 = __shfl(res, rbase + 2, 64), a3 = __shfl(res, rbase + 3, 64);
+            const int cbase = lane & ~12;
+            int a0 = quad_bcast<0>(res), a1 = quad_bcast<1>(res), a2 = quad_bcast<2>(res), a3 = quad_bcast<3>(res);
             int tr = px == 0 ? a0 + a1 + a2 + a3 : px == 1 ? 2 * a0 + a1 - a2 - 2 * a3 : px == 2 ? a0 - a1 - a2 + a3 : a0 - 2 * a1 + 2 * a2 - a3;
             a0 = __shfl(tr, cbase, 64); a1 = __shfl(tr, cbase + 4, 64); a2 = __shfl(tr, cbase + 8, 64); a3 = __shfl(tr, cbase + 12, 64);
             const int coef = py == 0 ? a0 + a1 + a2 + a3 : py == 1 ? 2 * a0 + a1 - a2 - 2 * a3 : py == 2 ? a0 - a1 - a2 + a3 : a0 - 2 * a1 + 2 * a2 - a3;
             const int lv4 = quant1(coef, mf4, q4.f, q4.qbits);
             // 8.5.12: scale, inverse transform (rows then columns), round
             const int dq = (lv4 * v4) << q4.shift;
-            a0 = __shfl(dq, rbase, 64); a1 = __shfl(dq, rbase + 1, 64); a2 = __shfl(dq, rbase + 2, 64); a3 = __shfl(dq, rbase + 3, 64);
+            a0 = quad_bcast<0>(dq); a1 = quad_bcast<1>(dq); a2 = quad_bcast<2>(dq); a3 = quad_bcast<3>(dq);
             {
                 const int e0 = a0 + a2, e1 = a0 - a2, e2 = (a1 >> 1) - a3, e3 = a1 + (a3 >> 1);
                 tr = px == 0 ? e0 + e3 : px == 1 ? e1 + e2 : px == 2 ? e1 - e2 : e0 - e3;
@@ -1049,6 +1241,7 @@ DEV void filter_line(const dev_tables *T, uint8_t *pix, int step, int bS, int qp
 }
 DEV int has_coef(const mb_info_t &m, int bx4, int by4) { // (bx4,by4) raster 4x4 position -> blkIdx bit
     const int b = ((by4 >> 1) << 3) | ((bx4 >> 1) << 2) | ((by4 & 1) << 1) | (bx4 & 1);
+    if (m.nzmask & NZ_T8) return ((m.nzmask >> (b & ~3)) & 0xF) != 0; // 8.7.2.1: the 8x8 block containing the sample
     return (m.nzmask >> b) & 1;
 }
 DEV int bs_of(const mb_info_t &mp, int bxp, int byp, const mb_info_t &mq, int bxq, int byq, bool mb_edge) {
@@ -1100,7 +1293,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
         const int k = lane;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            if (e == 0 && mx == 0) continue;
+            if ((e == 0 && mx == 0) || ((cur.nzmask & NZ_T8) && (e & 1))) continue; // 8x8 transform: edges 1, 3 are not block edges
             const mb_info_t &mp = e == 0 ? lft : cur;
             int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 2, cur, e, k >> 2, e == 0);
             filter_line(T, &tl[(4 + k) * TLS + 4 + 4 * e], 1, bS, mp.qp, cur.qp, false);
@@ -1122,7 +1315,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
         const int k = lane;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            if (e == 0 && my == 0) continue;
+            if ((e == 0 && my == 0) || ((cur.nzmask & NZ_T8) && (e & 1))) continue;
             const mb_info_t &mp = e == 0 ? upp : cur;
             int bS = bs_of(mp, k >> 2, e == 0 ? 3 : e - 1, cur, k >> 2, e, e == 0);
             filter_line(T, &tl[(4 + 4 * e) * TLS + 4 + k], TLS, bS, mp.qp, cur.qp, false);
@@ -1368,7 +1561,8 @@ __global__ __launch_bounds__((2 * DB_R + 1) * 64) void deblock_band_kernel(db_ar
         int bsv = 0;
         if (lane < 32) {
             const int dir = lane >> 4, e = (lane >> 2) & 3, sg = lane & 3;
-            if (dir == 0) { if (!(e == 0 && x == 0)) bsv = bs_of(e == 0 ? lft : cur, e == 0 ? 3 : e - 1, sg, cur, e, sg, e == 0); }
+            if ((cur.nzmask & NZ_T8) && (e & 1)) bsv = 0; // 8x8 transform: luma edges 1 and 3 are not block edges
+            else if (dir == 0) { if (!(e == 0 && x == 0)) bsv = bs_of(e == 0 ? lft : cur, e == 0 ? 3 : e - 1, sg, cur, e, sg, e == 0); }
             else if (!(e == 0 && my == 0)) bsv = bs_of(e == 0 ? upp : cur, sg, e == 0 ? 3 : e - 1, cur, sg, e, e == 0);
         }
         const unsigned long long bm = __ballot(bsv != 0) & (chroma ? 0x0F0F0F0Full : 0xFFFFFFFFull); // chroma filters edges 0 and 2 only

@@ -35,7 +35,7 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
                 ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
-                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int)]
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -88,8 +88,8 @@ def load():
         L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
         L.mi355enc_time_stage.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
-        L.mi355enc_host_write_headers.argtypes = [C.c_int] * 4 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
-        L.mi355enc_host_write_slice.argtypes = [C.c_int] * 6 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi355enc_host_write_headers.argtypes = [C.c_int] * 5 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi355enc_host_write_slice.argtypes = [C.c_int] * 7 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_rc_init.restype = None
         L.mi355enc_rc_init.argtypes = [vp, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_int]
         L.mi355enc_rc_set_bitrate.restype = None
@@ -101,20 +101,20 @@ def load():
     return _lib
 
 
-def host_write_headers(width, height, fps_num, fps_den=1):
+def host_write_headers(width, height, fps_num, fps_den=1, transform8x8=False):
     L = load()
     out, n = np.empty(256, np.uint8), C.c_size_t(0)
-    r = L.mi355enc_host_write_headers(width, height, fps_num, fps_den, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+    r = L.mi355enc_host_write_headers(width, height, fps_num, fps_den, int(transform8x8), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
     if r:
         raise RuntimeError("mi355enc_host_write_headers: %d" % r)
     return bytes(out[: n.value])
 
 
-def host_write_slice(mbw, mbh, is_idr, frame_num, idr_pic_id, qp, mbinfo, levels):
+def host_write_slice(mbw, mbh, is_idr, frame_num, idr_pic_id, qp, mbinfo, levels, transform8x8=False):
     L = load()
     out, n = np.empty(mbw * mbh * 1536 + 4096, np.uint8), C.c_size_t(0)
     mbinfo, levels = np.ascontiguousarray(mbinfo), np.ascontiguousarray(levels, np.int16)
-    r = L.mi355enc_host_write_slice(mbw, mbh, int(is_idr), frame_num, idr_pic_id, qp, mbinfo.ctypes.data_as(C.c_void_p),
+    r = L.mi355enc_host_write_slice(mbw, mbh, int(is_idr), frame_num, idr_pic_id, qp, int(transform8x8), mbinfo.ctypes.data_as(C.c_void_p),
                                     levels.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
     if r:
         raise RuntimeError("mi355enc_host_write_slice: %d" % r)
@@ -152,7 +152,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
@@ -162,6 +162,7 @@ class Encoder:
         cfg.deblock_mode = deblock_mode
         cfg.subpel = int(subpel)
         cfg.i4x4 = int(i4x4)
+        cfg.transform8x8 = int(transform8x8)
         self.h = C.c_void_p()
         self._chk(self.L.mi355enc_open(C.byref(cfg), C.byref(self.h)), "open", close_on_fail=True)
         self.width, self.height = width, height

@@ -54,6 +54,7 @@ typedef struct {
     int profile_events;       /* 1: bracket every kernel stage with HIP events (stats)    */
     int use_graphs;           /* 1: replay the per-picture launch sequence as a hipGraph  */
     int keep_prefilter;       /* 1: keep a copy of the picture before deblocking (tests)  */
+    int transform8x8;         /* 1: High-profile stream, P macroblocks use the 8x8 transform; 0 (default): Constrained Baseline */
     int i4x4;                 /* 1 (default): try Intra_4x4 besides Intra_16x16 in I pictures */
     int subpel;               /* 1 (default): half- then quarter-sample refinement after the integer search */
     int deblock_mode;         /* 0: persistent band-wavefront kernel (one launch per picture);
@@ -137,8 +138,9 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms);
 
 /* ---- host-only stages (no device needed; what collect() runs after the D2H copy) ----
  * SPS+PPS, and one CAVLC slice NAL from macroblock records + levels.  *out_len = bytes. */
-int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den, uint8_t *out, size_t out_cap, size_t *out_len);
-int mi355enc_host_write_slice(int mb_width, int mb_height, int is_idr, int frame_num, int idr_pic_id, int slice_qp,
+int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den, int transform8x8, uint8_t *out, size_t out_cap,
+                                size_t *out_len);
+int mi355enc_host_write_slice(int mb_width, int mb_height, int is_idr, int frame_num, int idr_pic_id, int slice_qp, int transform8x8,
                               const void *mbinfo, const int16_t *levels, uint8_t *out, size_t out_cap, size_t *out_len);
 /* Rate-control model on its own: feed (is_idr, produced bytes) per picture, get the next QP.
  * rc is an opaque block of MI355ENC_RC_BYTES bytes owned by the caller. */

@@ -149,6 +149,7 @@ typedef struct {
     uint8_t i4mode[16]; /* raster */
     uint16_t coded;   /* luma 4x4 blocks with non-zero levels, raster bit */
     int8_t dbf_idc, dbf_a, dbf_b;
+    int8_t t8;        /* transform_size_8x8_flag */
 } dmb_t;
 
 struct orc_dec {
@@ -156,7 +157,7 @@ struct orc_dec {
     int have_sps, mbw, mbh, crop_l, crop_r, crop_t, crop_b, log2_fn, poc_type, log2_poc_lsb;
     int delta_pic_order_always_zero;
     /* PPS */
-    int have_pps, pic_init_qp, cqp_off, dbf_present, constrained_intra, redundant_cnt, num_ref_default, bottom_field_poc;
+    int have_pps, pic_init_qp, cqp_off, dbf_present, constrained_intra, redundant_cnt, num_ref_default, bottom_field_poc, t8_mode;
     uint8_t *cur_y, *cur_uv, *ref_y, *ref_uv;
     int have_ref, pic_open, n_slices;
     dmb_t *mb;
@@ -251,10 +252,11 @@ static int parse_pps(orc_dec_t *d) {
     d->constrained_intra = (int)rd_bit(d);
     d->redundant_cnt = (int)rd_bit(d);
     if (d->rb_fail) return fail(d, "PPS truncated");
+    d->t8_mode = 0;
     if (more_data(d)) {
-        if (rd_bit(d)) return fail(d, "transform_8x8_mode unsupported");
+        d->t8_mode = (int)rd_bit(d);
         if (rd_bit(d)) return fail(d, "scaling matrices unsupported");
-        rd_se(d);
+        if (rd_se(d) != d->cqp_off) return fail(d, "second_chroma_qp_index_offset != chroma_qp_index_offset unsupported");
     }
     d->have_pps = 1;
     return 0;
@@ -353,6 +355,41 @@ static void scale4x4(const int16_t *lev, int first, int qp, int c[4][4]) {
         c[y][x] = (w * ls_at(qp, x, y) * 16 << (qp / 6)) >> 4;
     }
 }
+
+/* ---------------------------------------------------------------- 8x8 residual (High profile) */
+static const uint8_t D_ls8[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+                                    {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+static int ls8_class(int x, int y) { /* 8.5.9 */
+    if (x % 4 == 0 && y % 4 == 0) return 0;
+    if (x % 2 == 1 && y % 2 == 1) return 1;
+    if (x % 4 == 2 && y % 4 == 2) return 2;
+    if ((x % 4 == 0 && y % 2 == 1) || (x % 2 == 1 && y % 4 == 0)) return 3;
+    if ((x % 4 == 0 && y % 4 == 2) || (x % 4 == 2 && y % 4 == 0)) return 4;
+    return 5;
+}
+/* Figure 6-?? 8x8 zig-zag generated by walking the anti-diagonals (not transcribed): scan index -> (x, y) */
+static void zz8_xy(int k, int *px, int *py) {
+    int x = 0, y = 0;
+    for (int i = 0; i < k; i++) {
+        if (((x + y) & 1) == 0) { /* moving up-right */
+            if (x == 7) y++; else if (y == 0) x++; else { x++; y--; }
+        } else {                  /* moving down-left */
+            if (y == 7) x++; else if (x == 0) y++; else { x--; y++; }
+        }
+    }
+    *px = x; *py = y;
+}
+static void inv8_1d(const int *s, int st, int *o, int ot) { /* 8.5.13 */
+    int e0 = s[0] + s[4 * st], e1 = -s[3 * st] + s[5 * st] - s[7 * st] - (s[7 * st] >> 1);
+    int e2 = s[0] - s[4 * st], e3 = s[st] + s[7 * st] - s[3 * st] - (s[3 * st] >> 1);
+    int e4 = (s[2 * st] >> 1) - s[6 * st], e5 = -s[st] + s[7 * st] + s[5 * st] + (s[5 * st] >> 1);
+    int e6 = s[2 * st] + (s[6 * st] >> 1), e7 = s[3 * st] + s[5 * st] + s[st] + (s[st] >> 1);
+    int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
+    int f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
+    o[0] = f0 + f7; o[ot] = f2 + f5; o[2 * ot] = f4 + f3; o[3 * ot] = f6 + f1;
+    o[4 * ot] = f6 - f1; o[5 * ot] = f4 - f3; o[6 * ot] = f2 - f5; o[7 * ot] = f0 - f7;
+}
+int orc_dec_zz8(int k) { int x, y; zz8_xy(k, &x, &y); return y * 8 + x; }
 
 /* ---------------------------------------------------------------- neighbour availability */
 static int mb_avail(const orc_dec_t *d, int mx, int my, int slice) {
@@ -611,7 +648,7 @@ static int decode_chroma_residual(orc_dec_t *d, int mx, int my, int slice, int c
 static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skipped, int *qp) {
     dmb_t *m = &d->mb[my * d->mbw + mx];
     memset(m->tc_l, 0, 16); memset(m->tc_c, 0, 8); memset(m->i4mode, 2, 16);
-    m->slice = (int16_t)slice; m->coded = 0; m->is_i4 = 0; m->mvx = m->mvy = 0;
+    m->slice = (int16_t)slice; m->coded = 0; m->is_i4 = 0; m->mvx = m->mvy = 0; m->t8 = 0;
     if (skipped) {
         int px, py; predict_mv(d, mx, my, slice, 1, &px, &py);
         m->mvx = (int16_t)px; m->mvy = (int16_t)py;
@@ -632,9 +669,10 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
         inter_pred_mb(d, mx, my, m->mvx, m->mvy);
         unsigned k = rd_ue(d); if (k > 47) return fail(d, "cbp codeNum %u", k);
         cbp = D_cbp_inter[k];
+        if (d->t8_mode && (cbp & 15)) m->t8 = (int8_t)rd_bit(d);
     } else {
         m->kind = 0;
-        if (t == 0) m->is_i4 = 1;
+        if (t == 0) { m->is_i4 = 1; if (d->t8_mode && rd_bit(d)) return fail(d, "Intra_8x8 unsupported"); }
         else if (t <= 24) { i16 = 1; i16mode = (t - 1) & 3; cbp = (((t - 1) >> 2) % 3) << 4 | (t > 12 ? 15 : 0); }
         else return fail(d, "I_PCM / mb_type %d unsupported", t);
         if (m->is_i4) {
@@ -685,6 +723,36 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
             for (int x = 0; x < 4; x++)
                 dcy[y * 4 + x] = q >= 36 ? (f[y][x] * ls) << (q / 6 - 6) : (f[y][x] * ls + (1 << (5 - q / 6))) >> (6 - q / 6);
     }
+    if (m->t8) { /* 7.3.5.3.2: each 8x8 block arrives as four interleaved 4x4 CAVLC blocks; 8.5.13 reconstruction */
+        for (int i8 = 0; i8 < 4; i8++) {
+            if (!(cbp & (1 << i8))) continue;
+            int lev8[64], any = 0;
+            memset(lev8, 0, sizeof lev8);
+            for (int j = 0; j < 4; j++) {
+                int b = 4 * i8 + j, bx = D_blkx[b], by = D_blky[b];
+                int16_t l[16];
+                int n = residual_block(d, l, 16, ctx_nC(d, mx, my, slice, 0, bx, by));
+                if (n < 0) return fail(d, "luma 8x8 residual at MB %d,%d", mx, my);
+                m->tc_l[by * 4 + bx] = (uint8_t)n;
+                any |= n;
+                for (int k = 0; k < 16; k++) lev8[4 * k + j] = l[k];
+            }
+            if (!any) continue;
+            for (int j = 0; j < 4; j++) m->coded |= (uint16_t)(1u << (D_blky[4 * i8 + j] * 4 + D_blkx[4 * i8 + j])); /* 8x8 granularity */
+            int c8[64], t8[64], r8[64];
+            memset(c8, 0, sizeof c8);
+            for (int k = 0; k < 64; k++) {
+                int x, y; zz8_xy(k, &x, &y);
+                int ls = 16 * D_ls8[q % 6][ls8_class(x, y)];
+                c8[y * 8 + x] = q >= 36 ? (lev8[k] * ls) << (q / 6 - 6) : (lev8[k] * ls + (1 << (5 - q / 6))) >> (6 - q / 6);
+            }
+            for (int y = 0; y < 8; y++) inv8_1d(c8 + 8 * y, 1, t8 + 8 * y, 1);
+            for (int x = 0; x < 8; x++) inv8_1d(t8 + x, 8, r8 + x, 8);
+            int X = mx * 16 + (i8 & 1) * 8, Y = my * 16 + (i8 >> 1) * 8;
+            for (int y = 0; y < 8; y++)
+                for (int x = 0; x < 8; x++) DY(d, X + x, Y + y) = (uint8_t)u8clip(DY(d, X + x, Y + y) + ((r8[y * 8 + x] + 32) >> 6));
+        }
+    } else
     for (int b = 0; b < 16; b++) {
         int bx = D_blkx[b], by = D_blky[b], X = mx * 16 + bx * 4, Y = my * 16 + by * 4;
         if (m->is_i4) {
@@ -781,6 +849,7 @@ static void deblock_picture(orc_dec_t *d) {
                     }
                     for (int k = 0; k < 16; k++) {
                         int seg = k >> 2;
+                        if (Q->t8 && (e & 1)) break; /* 8.7: with transform_size_8x8_flag only 8x8 block edges are filtered */
                         int qi = dir ? e * 4 + seg : seg * 4 + e;
                         int pi = e ? (dir ? (e - 1) * 4 + seg : seg * 4 + e - 1) : (dir ? 12 + seg : seg * 4 + 3);
                         int bS = strength(P, pi, Q, qi, e == 0);

@@ -255,6 +255,90 @@ int orc_dequant4(int level, int qp, int pos) {
     return (level * k_dequant_v[qp % 6][pos_class(pos)]) << (qp / 6);
 }
 
+/* ================================================================== 8x8 transform (High profile) */
+static int g_orc_t8 = 0; /* process-wide: transform_8x8_mode (High profile stream, 8x8 transform for P macroblocks) */
+void orc_set_transform8x8(int on) { g_orc_t8 = on; }
+int orc_get_transform8x8(void) { return g_orc_t8; }
+/* 8.5.6 8x8 zig-zag (frame) scan: scan position -> raster index y*8+x */
+static const uint8_t k_zigzag8[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                      41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                      30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+/* 8.5.9 normAdjust8x8 v(m, class) */
+static const uint8_t k_dequant8_v[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31},
+                                           {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+/* encoder multipliers: round(2^24 / (v * g(class))), g = squared norms of the 8x8 basis {64, 81.5625, 25, 72.25, 40, 45.15625} */
+static const uint16_t k_quant8_mf[6][6] = {{13107, 11428, 20972, 12222, 16777, 15481}, {11916, 10826, 19174, 11058, 14980, 14290},
+                                           {10082, 8943, 15978, 9675, 12710, 11985},   {9362, 8228, 14913, 8931, 11984, 11259},
+                                           {8192, 7346, 13159, 7740, 10486, 9777},     {7282, 6428, 11570, 6830, 9118, 8640}};
+static inline int pos_class8(int pos) { /* pos = y*8+x (symmetric in x,y) */
+    int i = pos >> 3, j = pos & 7;
+    if (i % 4 == 0 && j % 4 == 0) return 0;
+    if ((i & 1) && (j & 1)) return 1;
+    if (i % 4 == 2 && j % 4 == 2) return 2;
+    if ((i % 4 == 0 && (j & 1)) || ((i & 1) && j % 4 == 0)) return 3;
+    if ((i % 4 == 0 && j % 4 == 2) || (i % 4 == 2 && j % 4 == 0)) return 4;
+    return 5;
+}
+static void fdct8_1d(const int *s, int st, int *d, int dt) { /* encoder-side 8-point transform matching 8.5.13's inverse */
+    int s07 = s[0] + s[7 * st], s16 = s[st] + s[6 * st], s25 = s[2 * st] + s[5 * st], s34 = s[3 * st] + s[4 * st];
+    int a0 = s07 + s34, a1 = s16 + s25, a2 = s07 - s34, a3 = s16 - s25;
+    int d07 = s[0] - s[7 * st], d16 = s[st] - s[6 * st], d25 = s[2 * st] - s[5 * st], d34 = s[3 * st] - s[4 * st];
+    int a4 = d16 + d25 + (d07 + (d07 >> 1)), a5 = d07 - d34 - (d25 + (d25 >> 1));
+    int a6 = d07 + d34 - (d16 + (d16 >> 1)), a7 = d16 - d25 + (d34 + (d34 >> 1));
+    d[0] = a0 + a1; d[dt] = a4 + (a7 >> 2); d[2 * dt] = a2 + (a3 >> 1); d[3 * dt] = a5 + (a6 >> 2);
+    d[4 * dt] = a0 - a1; d[5 * dt] = a6 - (a5 >> 2); d[6 * dt] = (a2 >> 1) - a3; d[7 * dt] = (a4 >> 2) - a7;
+}
+static void idct8_1d(const int *s, int st, int *d, int dt) { /* 8.5.13 one-dimensional inverse */
+    int a0 = s[0] + s[4 * st], a2 = s[0] - s[4 * st], a4 = (s[2 * st] >> 1) - s[6 * st], a6 = (s[6 * st] >> 1) + s[2 * st];
+    int b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
+    int a1 = -s[3 * st] + s[5 * st] - s[7 * st] - (s[7 * st] >> 1), a3 = s[st] + s[7 * st] - s[3 * st] - (s[3 * st] >> 1);
+    int a5 = -s[st] + s[7 * st] + s[5 * st] + (s[5 * st] >> 1), a7 = s[3 * st] + s[5 * st] + s[st] + (s[st] >> 1);
+    int b1 = (a7 >> 2) + a1, b3 = a3 + (a5 >> 2), b5 = (a3 >> 2) - a5, b7 = a7 - (a1 >> 2);
+    d[0] = b0 + b7; d[dt] = b2 + b5; d[2 * dt] = b4 + b3; d[3 * dt] = b6 + b1;
+    d[4 * dt] = b6 - b1; d[5 * dt] = b4 - b3; d[6 * dt] = b2 - b5; d[7 * dt] = b0 - b7;
+}
+void orc_fdct8(const int in[64], int out[64]) { /* rows, then columns */
+    int t[64];
+    for (int i = 0; i < 8; i++) fdct8_1d(in + 8 * i, 1, t + 8 * i, 1);
+    for (int j = 0; j < 8; j++) fdct8_1d(t + j, 8, out + j, 8);
+}
+void orc_idct8(const int in[64], int out[64]) { /* 8.5.13: each row, then each column; caller rounds with (x + 32) >> 6 */
+    int t[64];
+    for (int i = 0; i < 8; i++) idct8_1d(in + 8 * i, 1, t + 8 * i, 1);
+    for (int j = 0; j < 8; j++) idct8_1d(t + j, 8, out + j, 8);
+}
+int orc_quant8(int coef, int qp, int pos, int intra) {
+    int qbits = 16 + qp / 6, f = (1 << qbits) / (intra ? 3 : 6);
+    int l = (int)(((int64_t)iabs(coef) * k_quant8_mf[qp % 6][pos_class8(pos)] + f) >> qbits);
+    if (l > MAX_LEVEL) l = MAX_LEVEL;
+    return coef < 0 ? -l : l;
+}
+int orc_dequant8(int level, int qp, int pos) { /* 8.5.13 scaling with flat lists: LevelScale8x8 = 16 * normAdjust8x8 */
+    int ls = 16 * k_dequant8_v[qp % 6][pos_class8(pos)];
+    return qp >= 36 ? (level * ls) << (qp / 6 - 6) : (level * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+}
+int orc_zigzag8(int k) { return k_zigzag8[k]; }
+/* One 8x8 luma block of an inter macroblock: transform, quantise, reconstruct in place over the prediction.
+ * Levels are stored de-interleaved the way CAVLC transmits them (7.3.5.3.2): 4x4 "block" 4*i8+j holds
+ * scan positions 4k+j, k = 0..15.  Returns the 4-bit mask of non-zero sub-blocks. */
+static int tq8_block(const uint8_t *src, uint8_t *rec, int stride, int qp, int16_t *lev4 /* 4 x 16 */) {
+    int res[64], co[64], dq[64], out[64], mask = 0;
+    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) res[y * 8 + x] = src[(size_t)y * stride + x] - rec[(size_t)y * stride + x];
+    orc_fdct8(res, co);
+    for (int k = 0; k < 64; k++) {
+        int pos = k_zigzag8[k], l = orc_quant8(co[pos], qp, pos, 0);
+        lev4[(k & 3) * 16 + (k >> 2)] = (int16_t)l;
+        if (l) mask |= 1 << (k & 3);
+        dq[pos] = orc_dequant8(l, qp, pos);
+    }
+    if (mask) {
+        orc_idct8(dq, out);
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++) rec[(size_t)y * stride + x] = (uint8_t)clip1(rec[(size_t)y * stride + x] + ((out[y * 8 + x] + 32) >> 6));
+    }
+    return mask;
+}
+
 /* residual of one 4x4 block -> levels in zig-zag order; returns 1 if any level (from `first`) != 0 */
 static int tq_block(const int16_t res[16], int qp, int intra, int first, int16_t lev_zz[16], int16_t *dc_out) {
     int16_t co[16];
@@ -472,6 +556,14 @@ void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t 
             int x0 = mx * 16, y0 = my * 16;
             m->mb_type = 1; m->i16_mode = 0; m->chroma_mode = 0; m->qp = (uint8_t)qp; m->nzmask = 0;
             mc_mb(ref_y, ref_uv, rec_y, rec_uv, stride, W, H, x0, y0, m->mvx, m->mvy);
+            if (g_orc_t8) { /* encoder choice: every P_L0_16x16 macroblock uses the 8x8 transform when the stream allows it */
+                for (int i8 = 0; i8 < 4; i8++) {
+                    size_t o = (size_t)(y0 + (i8 >> 1) * 8) * stride + x0 + (i8 & 1) * 8;
+                    int mk = tq8_block(src_y + o, rec_y + o, stride, qp, lev + ORC_L_LUMA + i8 * 64);
+                    m->nzmask |= (uint32_t)mk << (4 * i8);
+                }
+                if (m->nzmask & 0xFFFF) m->nzmask |= ORC_NZ_T8; /* transform_size_8x8_flag is only sent (and only matters) with luma cbp != 0 */
+            } else {
             for (int b = 0; b < 16; b++) {
                 int bx = x0 + k_blk_x[b], by = y0 + k_blk_y[b];
                 int16_t res[16];
@@ -486,6 +578,7 @@ void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t 
                 int32_t d[16];
                 dq_block(lev + ORC_L_LUMA + b * 16, qp, 0, 0, 0, d);
                 orc_idct4_add(d, rec_y + (size_t)(y0 + k_blk_y[b]) * stride + x0 + k_blk_x[b], stride);
+            }
             }
             chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 0, lev, &m->nzmask);
         }
@@ -828,6 +921,7 @@ static int blk_has_coef(const orc_mbinfo_t *m, int bx4, int by4) {
     static const uint8_t raster_to_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
     int b = raster_to_blk[by4 * 4 + bx4];
     if (m->mb_type != 1) return 1; /* intra handled before this is consulted */
+    if (m->nzmask & ORC_NZ_T8) return ((m->nzmask >> (b & ~3)) & 0xF) != 0; /* 8.7.2.1: the 8x8 block containing the sample */
     return (m->nzmask >> b) & 1;
 }
 static int bs_of(const orc_mbinfo_t *mp, int bxp, int byp, const orc_mbinfo_t *mq, int bxq, int byq, int mb_edge) {
@@ -844,10 +938,12 @@ void orc_deblock_frame(uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int
             int x0 = mx * 16, y0 = my * 16;
             int qpc_q = k_chroma_qp[m->qp];
             /* vertical edges, left to right */
+            const int t8 = (m->nzmask & ORC_NZ_T8) != 0; /* transform_size_8x8_flag: luma edges 1 and 3 are not transform edges */
             for (int e = 0; e < 4; e++) {
                 if (e == 0 && mx == 0) continue;
                 const orc_mbinfo_t *mp = e == 0 ? m - 1 : m;
                 int qpc_p = k_chroma_qp[mp->qp];
+                if (!(t8 && (e & 1)))
                 for (int k = 0; k < 16; k++) {
                     int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 2, m, e, k >> 2, e == 0);
                     filter_line(rec_y + (size_t)(y0 + k) * stride + x0 + 4 * e, 1, bS, mp->qp, m->qp, 0);
@@ -864,6 +960,7 @@ void orc_deblock_frame(uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int
                 if (e == 0 && my == 0) continue;
                 const orc_mbinfo_t *mp = e == 0 ? m - mbw : m;
                 int qpc_p = k_chroma_qp[mp->qp];
+                if (!(t8 && (e & 1)))
                 for (int k = 0; k < 16; k++) {
                     int bS = bs_of(mp, k >> 2, e == 0 ? 3 : e - 1, m, k >> 2, e, e == 0);
                     filter_line(rec_y + (size_t)(y0 + 4 * e) * stride + x0 + k, stride, bS, mp->qp, m->qp, 0);
@@ -985,10 +1082,11 @@ size_t orc_write_headers(uint8_t *out, size_t cap, int width, int height, int fp
     bw_t b;
     int mbw = (width + 15) / 16, mbh = (height + 15) / 16;
     bw_init(&b, rb, sizeof rb);
-    bw_put(&b, 8, 66);                 /* profile_idc */
-    bw_put(&b, 8, 0xC0);               /* constraint_set0,1 = 1 */
+    bw_put(&b, 8, g_orc_t8 ? 100 : 66); /* profile_idc: High when the 8x8 transform is enabled, else (Constrained) Baseline */
+    bw_put(&b, 8, g_orc_t8 ? 0x00 : 0xC0); /* constraint_set0,1 = 1 for Constrained Baseline */
     bw_put(&b, 8, (uint32_t)level_idc_for(mbw, mbh, fps_num, fps_den));
     bw_ue(&b, 0);                      /* seq_parameter_set_id */
+    if (g_orc_t8) { bw_ue(&b, 1); bw_ue(&b, 0); bw_ue(&b, 0); bw_put(&b, 2, 0); } /* chroma_format_idc 1, 8-bit, no bypass, no scaling matrix */
     bw_ue(&b, 4);                      /* log2_max_frame_num_minus4 -> 8 bits */
     bw_ue(&b, 2);                      /* pic_order_cnt_type */
     bw_ue(&b, 1);                      /* max_num_ref_frames */
@@ -1041,6 +1139,7 @@ size_t orc_write_headers(uint8_t *out, size_t cap, int width, int height, int fp
     bw_put(&b, 1, 1);                  /* deblocking_filter_control_present_flag */
     bw_put(&b, 1, 0);                  /* constrained_intra_pred_flag */
     bw_put(&b, 1, 0);                  /* redundant_pic_cnt_present_flag */
+    if (g_orc_t8) { bw_put(&b, 1, 1); bw_put(&b, 1, 0); bw_se(&b, 0); } /* transform_8x8_mode_flag, no pic scaling matrix, second_chroma_qp_index_offset */
     bw_trailing(&b);
     size_t m = write_nal(out + n, cap - n, 3, 8, rb, b.pos);
     if (!m) return 0;
@@ -1101,6 +1200,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
             } else if (intra) { /* I_NxN (Intra_4x4): 7.3.5.1 mb_pred */
                 static const uint8_t rb[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* raster -> blkIdx (self-inverse) */
                 bw_ue(&b, is_idr ? 0u : 5u);
+                if (g_orc_t8) bw_put(&b, 1, 0); /* transform_size_8x8_flag: Intra_4x4, not Intra_8x8 */
                 for (int blk = 0; blk < 16; blk++) {
                     int bx = rb[blk] & 3, by = rb[blk] >> 2, ma = -1, mb_ = -1;
                     if (bx > 0) ma = lev[ORC_L_LDC + rb[by * 4 + bx - 1]];
@@ -1120,6 +1220,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
                 bw_se(&b, m->mvx - px); /* mvd_l0, quarter-sample units */
                 bw_se(&b, m->mvy - py);
                 bw_ue(&b, k_cbp_to_codenum_inter[cbp_chroma * 16 + cbp_luma]);
+                if (g_orc_t8 && cbp_luma) bw_put(&b, 1, (m->nzmask & ORC_NZ_T8) ? 1 : 0); /* transform_size_8x8_flag */
             }
             if (i16 || cbp_luma || cbp_chroma) {
                 bw_se(&b, m->qp - prev_qp); /* mb_qp_delta */

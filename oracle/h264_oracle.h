@@ -51,6 +51,7 @@ typedef struct {
 #define ORC_NZ_LDC   (1u << 24)
 #define ORC_NZ_CBDC  (1u << 25)
 #define ORC_NZ_CRDC  (1u << 26)
+#define ORC_NZ_T8    (1u << 27) /* P macroblock coded with the 8x8 transform (transform_size_8x8_flag) */
 
 /* ---- stage functions (each is the checker for one HIP kernel) ------------------- */
 
@@ -75,6 +76,13 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
                      uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
                      orc_mbinfo_t *mbi, int16_t *levels);
 
+void orc_set_transform8x8(int on); /* process-wide: High-profile stream, 8x8 transform for P macroblocks (default off) */
+int orc_get_transform8x8(void);
+void orc_fdct8(const int in[64], int out[64]);
+void orc_idct8(const int in[64], int out[64]);
+int orc_quant8(int coef, int qp, int pos, int intra);
+int orc_dequant8(int level, int qp, int pos);
+int orc_zigzag8(int k);
 void orc_set_i4x4(int on); /* process-wide: try Intra_4x4 besides Intra_16x16 (default on) */
 
 /* In-loop deblocking filter, in place, normative macroblock raster order (8.7). */

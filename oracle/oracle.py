@@ -54,6 +54,14 @@ def lib():
         L.orc_subpel_frame.restype = None
         L.orc_enc_set_subpel.argtypes = [vp, C.c_int]
         L.orc_enc_set_subpel.restype = None
+        L.orc_set_transform8x8.argtypes = [C.c_int]
+        L.orc_set_transform8x8.restype = None
+        L.orc_fdct8.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_idct8.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_quant8.argtypes = [C.c_int] * 4
+        L.orc_dequant8.argtypes = [C.c_int] * 3
+        L.orc_zigzag8.argtypes = [C.c_int]
+        L.orc_dec_zz8.argtypes = [C.c_int]
         L.orc_set_i4x4.argtypes = [C.c_int]
         L.orc_set_i4x4.restype = None
         L.orc_inter_frame.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -220,6 +228,11 @@ def inter_frame(src_y, src_uv, ref_y, ref_uv, mbi, qp):
     L.orc_inter_frame(_ptr(src_y), _ptr(src_uv), _ptr(ref_y), _ptr(ref_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16,
                       H // 16, qp, _ptr(mbi), _ptr(lev))
     return rec_y, rec_uv, mbi, lev
+
+
+def set_transform8x8(on):
+    """Process-wide oracle switch (default off): High-profile stream, 8x8 transform for P macroblocks."""
+    lib().orc_set_transform8x8(int(on))
 
 
 def set_i4x4(on):

@@ -74,6 +74,23 @@ def test_host_cavlc_equals_oracle_on_real_pictures(oracle, w, h, qp):
         assert hdr + mine == au, (i, len(mine), len(au))
 
 
+@pytest.mark.parametrize("w,h,qp", [(176, 144, 22), (320, 180, 34)])
+def test_host_cavlc_high_profile_equals_oracle(oracle, w, h, qp):
+    """transform8x8: High-profile parameter sets and transform_size_8x8_flag from the product's writer."""
+    oracle.set_transform8x8(True)
+    try:
+        oe = oracle.Encoder(w, h, gop=4, threads=4)
+        for i, (y, uv) in enumerate(synth.s2_frames(w, h, 4)):
+            au, idr = oe.encode(y, uv, qp)
+            mine = E.host_write_slice(oe.mbw, oe.mbh, idr, i % 4, 0, qp, oe.mbinfo, oe.levels, transform8x8=True)
+            hdr = E.host_write_headers(w, h, 60, transform8x8=True) if idr else b""
+            assert hdr + mine == au, (i, len(mine), len(au))
+            if not idr:
+                assert ((oe.mbinfo["nzmask"] >> 27) & 1).any()
+    finally:
+        oracle.set_transform8x8(False)
+
+
 def test_host_cavlc_equals_oracle_on_random_levels(oracle):
     """Adversarial levels: long runs, escape-coded magnitudes, every nC class, all cbp values."""
     rng = np.random.default_rng(7)

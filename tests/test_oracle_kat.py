@@ -142,3 +142,33 @@ def test_me_lambda_monotone(oracle):
     L = oracle.lib()
     lam = [L.orc_me_lambda(q) for q in range(52)]
     assert lam == sorted(lam) and lam[0] == 1 and lam[51] == 91
+
+
+def test_8x8_transform_tables_are_mutually_consistent(oracle):
+    """High-profile 8x8 path: the forward/inverse pair, normAdjust8x8 and the quantiser multipliers were
+    transcribed separately; they only fit together if all are right: MF * V * g(class) == 2^24 where g is the
+    squared basis norm measured through the oracle's own fdct8(idct8(.)), and the zig-zag table (encoder:
+    transcribed; decoder: generated by walking anti-diagonals) must agree."""
+    L = oracle.lib()
+    I64 = C.c_int * 64
+    g = np.zeros((8, 8))
+    for p in range(64):
+        d = I64(); d[p] = 1 << 16
+        r, c = I64(), I64()
+        L.orc_idct8(d, r); L.orc_fdct8(r, c)
+        g[p // 8, p % 8] = c[p] / float(1 << 16)
+    assert np.allclose(sorted(set(np.round(g.ravel(), 2))), [25.0, 40.0, 45.16, 64.0, 72.25, 81.56], atol=0.011)
+    for qp in range(6):
+        for p in range(64):
+            v = L.orc_dequant8(1, 36 + qp, p) // 16          # LevelScale8x8 / 16 at qP/6 == 6 (no shift)
+            mf = 16 * L.orc_quant8(1 << 12, qp, p, 0)         # (2^12 * MF + f) >> 16 ~ MF / 16 (levels clamp at 2047)
+            assert abs(mf * v * g[p // 8, p % 8] - 2 ** 24) < 2 ** 24 * 0.012, (qp, p, mf, v)
+    assert [L.orc_zigzag8(k) for k in range(64)] == [L.orc_dec_zz8(k) for k in range(64)]
+    assert sorted(L.orc_zigzag8(k) for k in range(64)) == list(range(64))
+    rng = np.random.default_rng(5)
+    for _ in range(20):  # near-identity at qp 0
+        x = rng.integers(-255, 256, 64)
+        c = I64(); L.orc_fdct8(I64(*x), c)
+        dq = I64(*[L.orc_dequant8(L.orc_quant8(c[p], 0, p, 0), 0, p) for p in range(64)])
+        r = I64(); L.orc_idct8(dq, r)
+        assert np.abs((np.array(r[:]) + 32 >> 6) - x).max() <= 2

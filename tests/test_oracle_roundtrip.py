@@ -35,6 +35,18 @@ def test_encoder_recon_equals_decoder_output(oracle, w, h, qp):
     run(oracle, w, h, 6, [qp])
 
 
+@pytest.mark.parametrize("qp", [0, 14, 30, 44])
+def test_high_profile_8x8_transform_roundtrip(oracle, qp):
+    """transform_8x8_mode on: High-profile SPS/PPS, transform_size_8x8_flag, 8x8 CAVLC interleave, 8.5.13 inverse,
+    deblocking without edges 1/3 -- the independent decoder must still reproduce the encoder bit for bit."""
+    oracle.set_transform8x8(True)
+    try:
+        run(oracle, 176, 144, 6, [qp], gop=5)
+        run(oracle, 50, 34, 4, [qp, 51 - qp // 2], gop=3, kind="s3")
+    finally:
+        oracle.set_transform8x8(False)
+
+
 def test_varying_qp_and_noise(oracle):
     run(oracle, 96, 80, 8, [51, 0, 30, 12, 44, 3], gop=3, kind="s3")
 

@@ -141,6 +141,31 @@ def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub):
     e.close()
 
 
+@pytest.mark.parametrize("w,h,n", [(64, 48, 6), (176, 144, 6), (322, 182, 5), (1280, 720, 3)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_high_profile_8x8_transform_equals_oracle(E, oracle, w, h, n, mode):
+    """transform8x8=1: P macroblocks through the 8x8 transform kernel path, deblocking with 8x8 block edges."""
+    oracle.set_transform8x8(True)
+    try:
+        e = E.Encoder(w, h, gop=4, fixed_qp=30, transform8x8=True, keep_prefilter=True, deblock_mode=mode)
+        oe = oracle.Encoder(w, h, gop=4, threads=8)
+        dec = oracle.Decoder()
+        for i, (_, _, y, uv) in enumerate(frames(w, h, n)):
+            qp = [30, 12, 40, 24, 2, 50][i % 6]
+            e.set_fixed_qp(qp)
+            au, _ = e.encode(y, uv, pts=i)
+            ref_au, _ = oe.encode(y, uv, qp)
+            assert np.array_equal(e.fetch(E.FETCH_LEVELS), oe.levels), ("levels", i, first_diff(e.fetch(E.FETCH_LEVELS), oe.levels))
+            assert np.array_equal(e.fetch(E.FETCH_PREFILTER_Y), oe.prefilter_y), ("prefilter", i)
+            assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y), ("recon", i, first_diff(e.fetch(E.FETCH_RECON_Y), oe.recon_y))
+            assert au == ref_au, ("bitstream", i)
+            dy, duv = dec.decode(au)
+            assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv)
+        e.close()
+    finally:
+        oracle.set_transform8x8(False)
+
+
 def test_pipelined_submit_collect_equals_sync(E, oracle):
     """pipeline_depth=1 (entropy coding overlapped with the next picture) yields the same stream."""
     w, h, n = 320, 192, 8
