@@ -39,7 +39,7 @@ typedef struct {
     guint bps;          /* bit/s */
     guint key_int_max;
     gint device_id, me_range, qp, pipeline_depth, speed_preset;
-    gboolean stats;
+    gboolean stats, dct8x8;
     /* streaming state */
     mi355enc_t *enc;
     GstVideoCodecState *input_state;
@@ -52,12 +52,12 @@ typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 G_DEFINE_TYPE(GstMi355H264Enc, gst_mi355h264enc, GST_TYPE_VIDEO_ENCODER)
 
 enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME_RANGE, PROP_QP, PROP_PIPELINE_DEPTH,
-       PROP_SPEED_PRESET, PROP_STATS };
+       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8 };
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-raw, format=(string)NV12, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
 static GstStaticPadTemplate src_tmpl = GST_STATIC_PAD_TEMPLATE("src", GST_PAD_SRC, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS("video/x-h264, stream-format=(string)byte-stream, alignment=(string)au, profile=(string)constrained-baseline, "
+    GST_STATIC_CAPS("video/x-h264, stream-format=(string)byte-stream, alignment=(string)au, profile=(string){ constrained-baseline, high }, "
                     "width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
 
 /* x264enc's speed-preset enum, accepted so that an x264enc line converts by changing only the factory name */
@@ -84,6 +84,7 @@ static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *
     case PROP_PIPELINE_DEPTH: s->pipeline_depth = g_value_get_int(val); break;
     case PROP_SPEED_PRESET: s->speed_preset = g_value_get_enum(val); break;
     case PROP_STATS: s->stats = g_value_get_boolean(val); break;
+    case PROP_DCT8X8: s->dct8x8 = g_value_get_boolean(val); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -101,6 +102,7 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     case PROP_PIPELINE_DEPTH: g_value_set_int(val, s->pipeline_depth); break;
     case PROP_SPEED_PRESET: g_value_set_enum(val, s->speed_preset); break;
     case PROP_STATS: g_value_set_boolean(val, s->stats); break;
+    case PROP_DCT8X8: g_value_set_boolean(val, s->dct8x8); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -144,7 +146,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     GST_OBJECT_LOCK(s);
     cfg.gop = s->key_int_max ? (int)s->key_int_max : 250;
     cfg.me_range = s->me_range; cfg.bitrate_bps = s->bps; cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
-    cfg.pipeline_depth = s->pipeline_depth;
+    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0;
     GST_OBJECT_UNLOCK(s);
     int r = mi355enc_open(&cfg, &e);
     if (r != MI355ENC_OK) {
@@ -161,7 +163,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     if (s->input_state) gst_video_codec_state_unref(s->input_state);
     s->input_state = gst_video_codec_state_ref(state);
     GstCaps *caps = gst_caps_new_simple("video/x-h264", "stream-format", G_TYPE_STRING, "byte-stream", "alignment", G_TYPE_STRING, "au",
-                                        "profile", G_TYPE_STRING, "constrained-baseline", NULL);
+                                        "profile", G_TYPE_STRING, cfg.transform8x8 ? "high" : "constrained-baseline", NULL);
     GstVideoCodecState *out = gst_video_encoder_set_output_state(ve, caps, state);
     gst_video_codec_state_unref(out);
     if (cfg.pipeline_depth > 0) {
@@ -268,6 +270,8 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
         "0: output each picture before taking the next; 1: overlap host entropy coding with the next picture (+1 frame latency)", 0, 1, 0, F));
     g_object_class_install_property(g, PROP_SPEED_PRESET, g_param_spec_enum("speed-preset", "Speed preset",
         "Accepted for x264enc pipeline compatibility; ignored", speed_preset_type(), 6, F));
+    g_object_class_install_property(g, PROP_DCT8X8, g_param_spec_boolean("dct8x8", "8x8 transform",
+        "Adaptive spatial transform size as in x264enc: High-profile stream, P macroblocks use the 8x8 transform", FALSE, F));
     g_object_class_install_property(g, PROP_STATS, g_param_spec_boolean("stats", "Print stats", "Print a JSON line with counters when the encoder closes", FALSE, F));
     gst_element_class_add_static_pad_template(e, &sink_tmpl);
     gst_element_class_add_static_pad_template(e, &src_tmpl);
@@ -278,7 +282,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->bps = 2048000; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
-    s->stats = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
+    s->stats = FALSE; s->dct8x8 = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
 }
 
 static gboolean plugin_init(GstPlugin *p) {

@@ -166,6 +166,63 @@ def test_high_profile_8x8_transform_equals_oracle(E, oracle, w, h, n, mode):
         oracle.set_transform8x8(False)
 
 
+@pytest.mark.parametrize("w,h", [(16, 16), (32, 16), (16, 48), (18, 18), (4096, 32)])
+def test_degenerate_geometries(E, oracle, w, h):
+    """Single macroblock, single row/column, non-multiple-of-16, and the widest row the caps allow."""
+    e = E.Encoder(w, h, gop=3, fixed_qp=27)
+    oe = oracle.Encoder(w, h, gop=3, threads=4)
+    dec = oracle.Decoder()
+    for i, (_, _, y, uv) in enumerate(frames(w, h, 5)):
+        au, _ = e.encode(y, uv, pts=i)
+        assert au == oe.encode(y, uv, 27)[0], i
+        dy, duv = dec.decode(au)
+        assert np.array_equal(dy, e.fetch(E.FETCH_RECON_Y)) and np.array_equal(duv, e.fetch(E.FETCH_RECON_UV))
+    assert dec.size == (w, h)
+    e.close()
+
+
+@pytest.mark.parametrize("rng", [1, 5, 8])
+def test_me_range_property(E, oracle, rng):
+    """me-range < 16: candidates outside the range are masked, the rest of the kernel is unchanged."""
+    f = frames(320, 192, 2)
+    cur, ref = f[1][0], f[0][0]
+    e = E.Encoder(320, 192, fixed_qp=30, me_range=rng)
+    dev, orc = e.stage_me(cur, ref, 30), oracle.me_frame(cur, ref, rng, 30, threads=4)
+    assert mbinfo_equal(dev, orc, ("mvx", "mvy", "cost"))
+    assert np.abs(dev["mvx"]).max() <= 4 * rng and np.abs(dev["mvy"]).max() <= 4 * rng
+    e.close()
+
+
+def test_2160p_one_gop_head_equals_oracle(E, oracle):
+    """BASELINE config 4 geometry at full size: IDR + P, bit-exact (32 400 macroblocks, 34 deblock bands)."""
+    w, h = 3840, 2160
+    e = E.Encoder(w, h, gop=60, fixed_qp=32)
+    oe = oracle.Encoder(w, h, gop=60, threads=16)
+    for i, (_, _, y, uv) in enumerate(frames(w, h, 2)):
+        au, _ = e.encode(y, uv, pts=i)
+        assert au == oe.encode(y, uv, 32)[0], i
+        assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y)
+    e.close()
+
+
+def test_full_size_stream_properties_1080p(E, oracle):
+    """Size-independent properties at the benchmark geometry over two GOPs with rate control on: every access unit
+    decodes with the independent decoder to exactly the encoder's reconstruction (drift-free closed loop), IDR cadence
+    and parameter sets are where the element promises them, and PSNR stays sane."""
+    from ceracoder_amd import synth
+    w, h, gop = 1920, 1080, 12
+    e = E.Encoder(w, h, gop=gop, bitrate_bps=12_000_000, fps=60)
+    dec = oracle.Decoder()
+    for i, (y, uv) in enumerate(synth.s2_frames(w, h, 2 * gop + 1)):
+        au, key = e.encode(y, uv, pts=i)
+        assert key == (i % gop == 0)
+        assert (au[:5] == b"\x00\x00\x00\x01\x67") == key
+        dy, duv = dec.decode(au)
+        assert np.array_equal(dy, e.fetch(E.FETCH_RECON_Y)) and np.array_equal(duv, e.fetch(E.FETCH_RECON_UV)), i
+        assert synth.psnr(y, dy[:h, :w]) > 24.0
+    e.close()
+
+
 def test_pipelined_submit_collect_equals_sync(E, oracle):
     """pipeline_depth=1 (entropy coding overlapped with the next picture) yields the same stream."""
     w, h, n = 320, 192, 8
