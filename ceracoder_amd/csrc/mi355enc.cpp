@@ -58,6 +58,7 @@ struct mi355enc {
     hipStream_t cstream;                 // copy stream for the D2H hand-over
     uint64_t n_submitted;
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
+    uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
     unsigned *d_progress; // [2*bands] strip counters of the band deblocker, then one error word
     unsigned *h_err;      // pinned mirror of the error word
     int n_progress;
@@ -120,6 +121,7 @@ static int build_graph(mi355enc_t *h, int which, hipGraphExec_t *out) {
     return 0;
 }
 static int run_intra(mi355enc_t *h) {
+    k_launch_intra_analyse(h->d_ctx, h->mbw, h->mbh, h->stream); // open-loop mode analysis: one flat launch
     if (h->cfg.use_graphs) {
         if (!h->g_intra) { int r = build_graph(h, 0, &h->g_intra); if (r) return r; }
         HIPCHK(hipGraphLaunch(h->g_intra, h->stream));
@@ -168,7 +170,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
-    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->h_err = nullptr;
+    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->h_err = nullptr; h->d_isad = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -189,6 +191,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMemsetAsync(h->d_rec_y[i], 0, h->ysz + SURF_PAD, h->stream));
         HIPCHK(hipMemsetAsync(h->d_rec_uv[i], 0, h->csz + SURF_PAD, h->stream));
     }
+    HIPCHK(hipMalloc((void **)&h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t)));
     h->n_progress = k_deblock_bands(h->mbh);
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&h->h_err, sizeof(unsigned), hipHostMallocDefault));
@@ -236,6 +239,7 @@ void mi355enc_close(mi355enc_t *h) {
     for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
     if (h->d_pre_y) (void)hipFree(h->d_pre_y);
     if (h->d_pre_uv) (void)hipFree(h->d_pre_uv);
+    if (h->d_isad) (void)hipFree(h->d_isad);
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->h_err) (void)hipHostFree(h->h_err);
     if (h->d_ctx) (void)hipFree(h->d_ctx);
@@ -277,7 +281,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
     c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
     const int set = (int)(h->n_submitted & 1);
-    c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set];
+    c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set]; c->isad = h->d_isad;
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
@@ -435,7 +439,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     c->src_y = src_is_staging ? s->d_src_y : nullptr; c->src_uv = src_is_staging ? s->d_src_uv : nullptr; c->src_stride = h->W;
     c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
     HIPCHK(hipStreamSynchronize(h->cstream));
-    c->mbi = h->d_mbi; c->levels = h->d_levels; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
+    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     return 0;
@@ -493,6 +497,17 @@ int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
     HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
+int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, uint16_t *isad_out) {
+    if (!h || !src_y || !src_uv || !isad_out) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    int r = stage_ctx(h, 26, true); if (r) return r;
+    k_launch_intra_analyse(h->d_ctx, h->mbw, h->mbh, h->stream);
+    HIPCHK(hipMemcpyAsync(isad_out, h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }

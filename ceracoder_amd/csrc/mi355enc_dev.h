@@ -20,6 +20,7 @@ typedef struct {
 } mb_info_t;
 
 #define MB_LEVELS 408
+#define ISAD_PER_MB 152
 #define L_LUMA 0
 #define L_LDC 256
 #define L_CDC 272
@@ -37,6 +38,7 @@ typedef struct {
     uint8_t *rec_y, *rec_uv;       /* picture being reconstructed (coded size)               */
     mb_info_t *mbi;
     int16_t *levels;
+    uint16_t *isad;                /* intra analysis: 152 u16 per macroblock {i16[4], chroma[4], i4[16][9]}, 0xFFFF = mode unavailable */
     int32_t src_stride;            /* bytes per source luma row (= chroma row, NV12)          */
     int32_t stride;                /* coded-surface stride = 16*mbw                           */
     int32_t mbw, mbh, vis_h;
@@ -55,6 +57,7 @@ typedef struct {
 void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
 void k_launch_subpel(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
 void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
+void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
 void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
 void k_launch_deblock_band(const frame_ctx_t *d_ctx, int mbh, unsigned *d_progress, unsigned *d_err, hipStream_t s);

@@ -823,9 +823,6 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
     }
 }
 
-// =================================================================== intra (I) macroblocks
-// One wave per macroblock, launched once per anti-diagonal x + y = diag (left, top and
-// top-left neighbours are then complete).  Lanes 0-15: luma 4x4 blocks; lanes 16-23: chroma.
 // sum over each row of 16 lanes, result in every lane: four DPP adds (no LDS crossbar round trips)
 DEV int wave16_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); // row_ror:8
@@ -836,13 +833,208 @@ DEV int wave16_sum(int v) {
 }
 // value of lane k of this lane's quad (k = 0..3), and of row r of this lane's column in a 4x4 tile laid out on 16 lanes
 template <int K> DEV int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, false); }
+
+// =================================================================== intra analysis (open loop)
+// SAD of every intra candidate of every macroblock, with predictions built from the SOURCE picture's
+// neighbouring samples: no macroblock depends on another, so this is one flat launch (one wave per
+// macroblock) instead of work inside the reconstruction wavefront.  Oracle: orc_intra_analyse.
+DEV int wave16_min(int v) {
+    int o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); v = v < o ? v : o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false); v = v < o ? v : o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  v = v < o ? v : o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  v = v < o ? v : o;
+    return v;
+}
+// one Intra_4x4 prediction sample (8.3.1.2) for pixel (px,py); E(i): ... l1 l0 | corner | t0 .. t7 with the
+// top-right substitution already applied; dc4: the block's DC value
+template <typename EF>
+DEV int pred4_px(int md, int px, int py, EF E, int dc4) {
+    if (md == 0) return E(px + 1);
+    if (md == 1) return E(-(py + 1));
+    if (md == 2) return dc4;
+    if (md == 3) return (px == 3 && py == 3) ? (E(7) + 3 * E(8) + 2) >> 2 : (E(px + py + 1) + 2 * E(px + py + 2) + E(px + py + 3) + 2) >> 2;
+    if (md == 4) return (E(px - py - 1) + 2 * E(px - py) + E(px - py + 1) + 2) >> 2;
+    if (md == 5) {
+        const int z = 2 * px - py, k = px - (py >> 1);
+        return (z >= 0 && !(z & 1)) ? (E(k) + E(k + 1) + 1) >> 1 : z >= 0 ? (E(k - 1) + 2 * E(k) + E(k + 1) + 2) >> 2
+               : z == -1 ? (E(-1) + 2 * E(0) + E(1) + 2) >> 2 : (E(-py) + 2 * E(-py + 1) + E(-py + 2) + 2) >> 2;
+    }
+    if (md == 6) {
+        const int z = 2 * py - px, k = py - (px >> 1);
+        return (z >= 0 && !(z & 1)) ? (E(-k) + E(-k - 1) + 1) >> 1 : z >= 0 ? (E(-k + 1) + 2 * E(-k) + E(-k - 1) + 2) >> 2
+               : z == -1 ? (E(-1) + 2 * E(0) + E(1) + 2) >> 2 : (E(px) + 2 * E(px - 1) + E(px - 2) + 2) >> 2;
+    }
+    if (md == 7) {
+        const int k = px + (py >> 1);
+        return !(py & 1) ? (E(k + 1) + E(k + 2) + 1) >> 1 : (E(k + 1) + 2 * E(k + 2) + E(k + 3) + 2) >> 2;
+    }
+    const int z = px + 2 * py, k = py + (px >> 1);
+    return z > 5 ? E(-4) : z == 5 ? (E(-3) + 3 * E(-4) + 2) >> 2 : !(z & 1) ? (E(-(k + 1)) + E(-(k + 2)) + 1) >> 1
+           : (E(-(k + 1)) + 2 * E(-(k + 2)) + E(-(k + 3)) + 2) >> 2;
+}
+DEV bool mode4_ok(int b, int md, bool up, bool lf, bool ul) {
+    const bool need_up = md == 0 || md == 3 || md == 7, need_left = md == 1 || md == 8, need_all = md >= 4 && md <= 6;
+    return !((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul)) || (b == 5 && (md == 3 || md == 7)));
+}
+#define IA_S 24 /* luma tile stride: row 0 = y -1, col 0 = x -1 */
+__global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *__restrict__ ctx) {
+    __shared__ __attribute__((aligned(4))) uint8_t SL[4][17 * IA_S];
+    __shared__ __attribute__((aligned(4))) uint8_t SC[4][2][9 * 12]; // [plane][row 0 = y -1][col 0 = x -1]
+    const int mbw = ctx->mbw, nmb = mbw * ctx->mbh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int mbn = blockIdx.x * 4 + wave;
+    const bool ok = mbn < nmb;
+    if (!ok) mbn = nmb - 1;
+    const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
+    const bool has_top = my > 0, has_left = mx > 0;
+    const uint8_t *__restrict__ sy = ctx->src_y;
+    const uint8_t *__restrict__ suv = ctx->src_uv;
+    const int ss = ctx->src_stride, vh = ctx->vis_h, vh2 = vh >> 1;
+    uint8_t *S = SL[wave];
+    // ---- source tile with its one-sample apron (rows beyond the visible picture repeat the last row, like every source read)
+    {
+        const int r = lane >> 2, q = lane & 3; // interior: 16 rows x 4 dwords
+        int yy = y0 + r; yy = yy < vh ? yy : vh - 1;
+        const unsigned w = ldg32(sy + (size_t)yy * ss + x0 + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; i++) S[(r + 1) * IA_S + 1 + 4 * q + i] = (uint8_t)byte_of(w, i);
+        if (lane < 17) { // top row incl. corner
+            const int x = lane - 1;
+            int yt = y0 - 1; yt = yt < vh ? yt : vh - 1;
+            S[lane] = (has_top && (x >= 0 || has_left)) ? (uint8_t)ldg8(sy + (size_t)yt * ss + x0 + x) : 0;
+        } else if (lane < 33) { // left column
+            int yl = y0 + lane - 17; yl = yl < vh ? yl : vh - 1;
+            S[(lane - 16) * IA_S] = has_left ? (uint8_t)ldg8(sy + (size_t)yl * ss + x0 - 1) : 0;
+        }
+        // chroma: interior 8 rows x 16 bytes (both planes interleaved) = 32 dwords
+        if (lane < 32) {
+            const int cr = lane >> 2, cq = lane & 3;
+            int yc = cy0 + cr; yc = yc < vh2 ? yc : vh2 - 1;
+            const unsigned cwd = ldg32(suv + (size_t)yc * ss + 2 * cx0 + 4 * cq);
+            SC[wave][0][(cr + 1) * 12 + 1 + 2 * cq] = (uint8_t)byte_of(cwd, 0); SC[wave][1][(cr + 1) * 12 + 1 + 2 * cq] = (uint8_t)byte_of(cwd, 1);
+            SC[wave][0][(cr + 1) * 12 + 2 + 2 * cq] = (uint8_t)byte_of(cwd, 2); SC[wave][1][(cr + 1) * 12 + 2 + 2 * cq] = (uint8_t)byte_of(cwd, 3);
+        } else if (lane < 32 + 18) { // top rows incl. corner, both planes
+            const int c = (lane - 32) / 9, x = (lane - 32) % 9 - 1;
+            int yt = cy0 - 1; yt = yt < vh2 ? yt : vh2 - 1;
+            SC[wave][c][x + 1] = (has_top && (x >= 0 || has_left)) ? (uint8_t)ldg8(suv + (size_t)yt * ss + 2 * (cx0 + x) + c) : 0;
+        } else if (lane < 32 + 18 + 14) { // left columns, rows 0..6 of both planes (row 7 below)
+            const int c = (lane - 50) / 7, y = (lane - 50) % 7;
+            int yl = cy0 + y; yl = yl < vh2 ? yl : vh2 - 1;
+            SC[wave][c][(y + 1) * 12] = has_left ? (uint8_t)ldg8(suv + (size_t)yl * ss + 2 * (cx0 - 1) + c) : 0;
+        }
+        if (lane < 2) {
+            int yl = cy0 + 7; yl = yl < vh2 ? yl : vh2 - 1;
+            SC[wave][lane][8 * 12] = has_left ? (uint8_t)ldg8(suv + (size_t)yl * ss + 2 * (cx0 - 1) + lane) : 0;
+        }
+    }
+    WAVE_SYNC();
+    uint16_t *out = ctx->isad + (size_t)mbn * ISAD_PER_MB;
+    const unsigned NA = 0xFFFFu;
+    // ---- Intra_16x16: lane = row lane>>2, columns 4*(lane&3)..+3
+    {
+        const int tl = lane < 16 ? S[lane + 1] : 0, ll = lane < 16 ? S[(lane + 1) * IA_S] : 0;
+        const int st = __shfl(wave16_sum(tl), 0), sl = __shfl(wave16_sum(ll), 0);
+        int hterm = 0, vterm = 0;
+        if (lane < 8) {
+            hterm = (lane + 1) * ((int)S[8 + lane + 1] - (int)S[6 - lane + 1]);                 // x' = lane: p[8+x',-1] - p[6-x',-1] (6-7 = -1 is the corner, col 0)
+            vterm = (lane + 1) * ((int)S[(8 + lane + 1) * IA_S] - (int)S[(6 - lane + 1) * IA_S]);
+        }
+        const int Hh = __shfl(wave16_sum(hterm), 0), Vv = __shfl(wave16_sum(vterm), 0);
+        const int dcv = (has_top && has_left) ? (st + sl + 16) >> 5 : has_top ? (st + 8) >> 4 : has_left ? (sl + 8) >> 4 : 128;
+        const int pa = 16 * ((int)S[16 * IA_S] + (int)S[16]), pb = (5 * Hh + 32) >> 6, pc = (5 * Vv + 32) >> 6;
+        const int r = lane >> 2, c0 = (lane & 3) * 4;
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int sv = S[(r + 1) * IA_S + c0 + i + 1];
+            s0 += iabs(sv - (int)S[c0 + i + 1]);
+            s1 += iabs(sv - (int)S[(r + 1) * IA_S]);
+            s2 += iabs(sv - dcv);
+            s3 += iabs(sv - clip255((pa + pb * (c0 + i - 7) + pc * (r - 7) + 16) >> 5));
+        }
+        int packed01 = wave16_sum(s0 | (s1 << 16)), packed23 = wave16_sum(s2 | (s3 << 16)); // row sums <= 16*255 fit 16 bits each
+        packed01 += __shfl_xor(packed01, 16); packed23 += __shfl_xor(packed23, 16); // 32 lanes: <= 8160
+        const unsigned a01 = (unsigned)packed01, a23 = (unsigned)packed23;
+        const unsigned o01 = (unsigned)__shfl_xor(packed01, 32), o23 = (unsigned)__shfl_xor(packed23, 32);
+        const unsigned t0 = (a01 & 0xFFFF) + (o01 & 0xFFFF), t1 = (a01 >> 16) + (o01 >> 16), t2 = (a23 & 0xFFFF) + (o23 & 0xFFFF), t3 = (a23 >> 16) + (o23 >> 16);
+        if (lane == 0 && ok) {
+            stg16(out + 0, (int)(has_top ? t0 : NA)); stg16(out + 1, (int)(has_left ? t1 : NA));
+            stg16(out + 2, (int)t2); stg16(out + 3, (int)((has_top && has_left) ? t3 : NA));
+        }
+    }
+    // ---- chroma 8x8 (both planes): lane = plane lane>>5, row (lane>>2)&7, columns 2*(lane&3)..+1
+    {
+        const int c = lane >> 5, r = (lane >> 2) & 7, c0 = (lane & 3) * 2;
+        const uint8_t *P = SC[wave][c];
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int Hh = 0, Vv = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { Hh += (i + 1) * ((int)P[4 + i + 1] - (int)P[2 - i + 1]); Vv += (i + 1) * ((int)P[(4 + i + 1) * 12] - (int)P[(2 - i + 1) * 12]); }
+        const int pa = 16 * ((int)P[8 * 12] + (int)P[8]), pb = (34 * Hh + 32) >> 6, pc = (34 * Vv + 32) >> 6;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int x = c0 + i, sv = P[(r + 1) * 12 + x + 1];
+            const int qx = x >> 2, qy = r >> 2; // 8.3.4.1-3 DC per 4x4 quadrant
+            int stq = 0, slq = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { stq += P[qx * 4 + k + 1]; slq += P[(qy * 4 + k + 1) * 12]; }
+            bool ut = has_top, ul = has_left;
+            if (qx == 1 && qy == 0 && has_top) ul = false;
+            if (qx == 0 && qy == 1 && has_left) ut = false;
+            const int dcv = (ut && ul) ? (stq + slq + 4) >> 3 : ut ? (stq + 2) >> 2 : ul ? (slq + 2) >> 2 : 128;
+            s0 += iabs(sv - dcv);
+            s1 += iabs(sv - (int)P[(r + 1) * 12]);
+            s2 += iabs(sv - (int)P[x + 1]);
+            s3 += iabs(sv - clip255((pa + pb * (x - 3) + pc * (r - 3) + 16) >> 5));
+        }
+        int p01 = wave16_sum(s0 | (s1 << 16)), p23 = wave16_sum(s2 | (s3 << 16));
+        p01 += __shfl_xor(p01, 16); p23 += __shfl_xor(p23, 16);
+        const unsigned a01 = (unsigned)p01, a23 = (unsigned)p23, o01 = (unsigned)__shfl_xor(p01, 32), o23 = (unsigned)__shfl_xor(p23, 32);
+        const unsigned t0 = (a01 & 0xFFFF) + (o01 & 0xFFFF), t1 = (a01 >> 16) + (o01 >> 16), t2 = (a23 & 0xFFFF) + (o23 & 0xFFFF), t3 = (a23 >> 16) + (o23 >> 16);
+        if (lane == 0 && ok) {
+            stg16(out + 4, (int)t0); stg16(out + 5, (int)(has_left ? t1 : NA));
+            stg16(out + 6, (int)(has_top ? t2 : NA)); stg16(out + 7, (int)((has_top && has_left) ? t3 : NA));
+        }
+    }
+    // ---- Intra_4x4: four blocks at a time, 16 lanes (pixels) each
+    {
+        const int px = lane & 3, py = (lane >> 2) & 3;
+#pragma unroll 1
+        for (int rnd = 0; rnd < 4; rnd++) {
+            const int b = rnd * 4 + (lane >> 4);
+            const int bx = blkx(b) >> 2, by = blky(b) >> 2;
+            const bool up = by > 0 || has_top, lf = bx > 0 || has_left;
+            const bool ul = (bx > 0 && by > 0) ? true : bx > 0 ? has_top : by > 0 ? has_left : (has_top && has_left);
+            const int trb = by > 0 && bx < 3 ? ((((by - 1) >> 1) << 3) | (((bx + 1) >> 1) << 2) | (((by - 1) & 1) << 1) | ((bx + 1) & 1)) : 99;
+            const bool ur = by == 0 ? (bx < 3 && has_top) : (bx < 3 && trb < b);
+            const int emax = ur ? 8 : 4;
+            const uint8_t *tb = &S[(by * 4) * IA_S + bx * 4];
+            auto E = [&](int i) -> int { i = i > emax ? emax : i; return i < 0 ? (int)tb[(-i) * IA_S] : (int)tb[i]; };
+            const int sv = S[(by * 4 + py + 1) * IA_S + bx * 4 + px + 1];
+            const int sumT = E(1) + E(2) + E(3) + E(4), sumL = E(-1) + E(-2) + E(-3) + E(-4);
+            const int dc4 = (up && lf) ? (sumT + sumL + 4) >> 3 : lf ? (sumL + 2) >> 2 : up ? (sumT + 2) >> 2 : 128;
+#pragma unroll
+            for (int md = 0; md < 9; md++) {
+                const int sad = wave16_sum(iabs(sv - pred4_px(md, px, py, E, dc4)));
+                if ((lane & 15) == 0 && ok) stg16(out + 8 + b * 9 + md, (int)(mode4_ok(b, md, up, lf, ul) ? (unsigned)sad : NA));
+            }
+        }
+    }
+}
+
+// =================================================================== intra (I) macroblocks
+// One wave per macroblock, launched once per anti-diagonal x + y = diag (left, top and
+// top-left neighbours are then complete).  Lanes 0-15: luma 4x4 blocks; lanes 16-23: chroma.
 __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
-    __shared__ int sh_top[3][17], sh_left[3][17]; // [plane 0=Y,1=Cb,2=Cr][-1..15]
+    __shared__ int sh_top[3][17], sh_left[3][17]; // reconstructed neighbours [plane 0=Y,1=Cb,2=Cr][-1..15]
     __shared__ int sh_dc[16], sh_ldc[16];
     __shared__ unsigned tabw[TAB_DWORDS];
     __shared__ __attribute__((aligned(4))) uint8_t T4[17 * 24]; // Intra_4x4: reconstructed samples incl. the row above / column left
     __shared__ __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
     __shared__ int sh_mode4[16], sh_nbm[8];
+    __shared__ unsigned sh_isadw[ISAD_PER_MB / 2];              // this macroblock's analysed SADs
+    const uint16_t *isad = (const uint16_t *)sh_isadw;
     const dev_tables *T = (const dev_tables *)tabw;
     const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
     const int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
@@ -853,8 +1045,13 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     uint8_t *__restrict__ ry = ctx->rec_y;
     uint8_t *__restrict__ ruv = ctx->rec_uv;
     const bool is_luma = lane < 16, is_chroma = lane >= 16 && lane < 24;
-    // ---- every global load is issued up front: tables, neighbours, this lane's source block
+    // ---- every global load is issued up front: tables, analysed SADs, neighbours, neighbour modes, this lane's source block
     for (int i = lane; i < TAB_DWORDS; i += 64) tabw[i] = ((const unsigned *)&g_tab)[i];
+    {
+        const unsigned *gi = (const unsigned *)(ctx->isad + (size_t)mbn * ISAD_PER_MB);
+        sh_isadw[lane] = ldg32(gi + lane);
+        if (lane < ISAD_PER_MB / 2 - 64) sh_isadw[64 + lane] = ldg32(gi + 64 + lane);
+    }
     int (*top)[17] = sh_top;
     int (*left)[17] = sh_left;
     if (lane >= 24 && lane < 24 + 17) { // lanes 24-40: luma neighbours; index i+1 holds sample i, index 0 the corner
@@ -891,6 +1088,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
                 unsigned sw = ldg32(s + (size_t)sy * ss + x0 + bx);
 #pragma unroll
                 for (int i = 0; i < 4; i++) src[r * 4 + i] = byte_of(sw, i);
+                *(unsigned *)&S4[(by + r) * 16 + bx] = sw;
             }
         } else {
             const uint8_t *__restrict__ s = ctx->src_uv;
@@ -910,70 +1108,55 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
 #define TOP(p, i) top[p][(i) + 1]
 #define LEFT(p, i) left[p][(i) + 1]
     const unsigned BIG = 0x10000000u;
-    int pred[16];
-    int flags = 0, mode = 0;
-    unsigned sad_sel = 0;
-    if (is_luma) {
-        const int b = lane, bx = blkx(b), by = blky(b);
-        // DC value and plane parameters (8.3.3.3, 8.3.3.4) -- every lane computes the same numbers
-        int st = 0, sl = 0, Hh = 0, Vv = 0;
+    const int lam = ctx->lambda;
+    // ---- decisions from the analysed SADs (oracle: orc_intra_frame).  Lowest SAD, ties to the lowest mode.
+    int mode16 = 0, cmode = 0;
+    unsigned cost16 = BIG, costc = BIG;
 #pragma unroll
-        for (int i = 0; i < 16; i++) { st += TOP(0, i); sl += LEFT(0, i); }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            Hh += (i + 1) * (TOP(0, 8 + i) - TOP(0, 6 - i));
-            Vv += (i + 1) * (LEFT(0, 8 + i) - LEFT(0, 6 - i));
-        }
-        const int dcv = (has_top && has_left) ? (st + sl + 16) >> 5 : has_top ? (st + 8) >> 4 : has_left ? (sl + 8) >> 4 : 128;
-        const int pa = 16 * (LEFT(0, 15) + TOP(0, 15)), pb = (5 * Hh + 32) >> 6, pc = (5 * Vv + 32) >> 6;
-        unsigned sad[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int sv = src[r * 4 + i];
-                sad[0] += iabs(sv - TOP(0, bx + i));
-                sad[1] += iabs(sv - LEFT(0, by + r));
-                sad[2] += iabs(sv - dcv);
-                sad[3] += iabs(sv - clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5));
-            }
-        unsigned tot[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) tot[k] = (unsigned)wave16_sum((int)sad[k]);
-        if (!has_top) tot[0] = BIG;
-        if (!has_left) tot[1] = BIG;
-        if (!(has_top && has_left)) tot[3] = BIG;
-        unsigned best = tot[0]; mode = 0;
-        if (tot[1] < best) { best = tot[1]; mode = 1; }
-        if (tot[2] < best) { best = tot[2]; mode = 2; }
-        if (tot[3] < best) { best = tot[3]; mode = 3; }
-        sad_sel = best;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                pred[r * 4 + i] = mode == 0 ? TOP(0, bx + i) : mode == 1 ? LEFT(0, by + r) : mode == 2 ? dcv
-                                  : clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5);
-        // source macroblock to LDS for the per-pixel Intra_4x4 pass
-#pragma unroll
-        for (int r = 0; r < 4; r++) *(unsigned *)&S4[(by + r) * 16 + bx] = pack4(src[r * 4], src[r * 4 + 1], src[r * 4 + 2], src[r * 4 + 3]);
+    for (int k = 0; k < 4; k++) {
+        const unsigned a = isad[k], c = isad[4 + k];
+        if (a != 0xFFFFu && a < cost16) { cost16 = a; mode16 = k; }
+        if (c != 0xFFFFu && c < costc) { costc = c; cmode = k; }
     }
-    // ================================================================ Intra_4x4 attempt (8.3.1)
-    // Blocks are visited along bx + 2*by (all their prediction sources are then reconstructed); up to
-    // two blocks per step, 16 lanes each, lane = one pixel.  Transforms run across lanes by shuffles.
     bool use_i4 = false;
-    unsigned nz4 = 0;
-    if (ctx->i4x4) {
-        const unsigned cost16 = (unsigned)__shfl((int)sad_sel, 0);
+    unsigned nz4 = 0, cost_luma = cost16;
+    if (ctx->i4x4) { // Intra_4x4 modes block by block: SAD + lambda * (mode == predicted ? 1 : 4); blocks visited along bx + 2*by
+        unsigned cost4 = 0;
+        const int half = (lane >> 4) & 1, cand = lane & 15;
+#pragma unroll 1
+        for (int s4 = 0; s4 < 10; s4++) {
+            const int by_lo = s4 > 3 ? (s4 - 2) >> 1 : 0, by_hi = (s4 >> 1) < 3 ? (s4 >> 1) : 3;
+            const bool two = by_lo + 1 <= by_hi;
+            const bool valid = lane < 32 && (half == 0 || two);
+            const int by = (valid && half) ? by_lo + 1 : by_lo, bx = s4 - 2 * by;
+            const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1);
+            const int ma = bx > 0 ? sh_mode4[by * 4 + bx - 1] : sh_nbm[by], mb_ = by > 0 ? sh_mode4[(by - 1) * 4 + bx] : sh_nbm[4 + bx];
+            const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
+            unsigned key = 0x7FFFFFFFu;
+            if (cand < 9) {
+                const unsigned sd = isad[8 + b * 9 + cand];
+                if (sd != 0xFFFFu) key = ((sd + (unsigned)(lam * (cand == pm ? 1 : 4))) << 4) | (unsigned)cand;
+            }
+            key = (unsigned)wave16_min((int)key);
+            if (valid && cand == 0) sh_mode4[by * 4 + bx] = (int)(key & 15);
+            cost4 += (unsigned)__shfl((int)(key >> 4), 0, 64) + (two ? (unsigned)__shfl((int)(key >> 4), 16, 64) : 0u);
+            WAVE_SYNC();
+        }
+        use_i4 = cost4 + (unsigned)(32 * lam) < cost16;
+        if (use_i4) cost_luma = cost4 + (unsigned)(32 * lam);
+    }
+    int pred[16];
+    int flags = 0;
+    if (use_i4) {
+        // ================================================================ Intra_4x4 reconstruction (8.3.1.2 + 8.5)
+        // Same block order; up to two blocks per step, 16 lanes each, lane = one pixel; transforms across lanes.
         if (lane < 17) T4[lane] = (uint8_t)TOP(0, lane - 1);
         else if (lane < 33) T4[(lane - 16) * 24] = (uint8_t)LEFT(0, lane - 17);
         const int half = (lane >> 4) & 1, px = lane & 3, py = (lane >> 2) & 3;
         const qparams q4 = make_q(T, qp, true);
-        const int lam = ctx->lambda;
         const int cl4 = (!(px & 1) && !(py & 1)) ? 0 : ((px & 1) && (py & 1)) ? 1 : 2;
         const int mf4 = cl4 == 0 ? q4.mf[0] : cl4 == 1 ? q4.mf[1] : q4.mf[2], v4 = cl4 == 0 ? q4.v[0] : cl4 == 1 ? q4.v[1] : q4.v[2];
         const int kz4 = (int)((0xFEA9DB83C7426510ull >> (4 * (py * 4 + px))) & 15); // raster -> zig-zag position
-        unsigned cost4 = 0;
         WAVE_SYNC();
 #pragma unroll 1
         for (int s4 = 0; s4 < 10; s4++) {
@@ -983,53 +1166,16 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
             const int by = (valid && half) ? by_lo + 1 : by_lo, bx = s4 - 2 * by;
             const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1); // blkIdx
             const bool up = by > 0 || has_top, lf = bx > 0 || has_left;
-            const bool ul = (bx > 0 && by > 0) ? true : bx > 0 ? has_top : by > 0 ? has_left : (has_top && has_left);
-            // top-right samples exist when that block precedes this one in decoding order (or lies in the row above);
-            // block 5 (3,0) never uses them: its two modes that would read the macroblock above-right are not tried
             const int trb = by > 0 && bx < 3 ? ((((by - 1) >> 1) << 3) | (((bx + 1) >> 1) << 2) | (((by - 1) & 1) << 1) | ((bx + 1) & 1)) : 99;
             const bool ur = by == 0 ? (bx < 3 && has_top) : (bx < 3 && trb < b);
             const int emax = ur ? 8 : 4;
             const uint8_t *tb = &T4[(by * 4) * 24 + bx * 4];
-            auto E = [&](int i) -> int { // ... l1 l0 | corner | t0 t1 ... t7
-                i = i > emax ? emax : i;
-                return i < 0 ? (int)tb[(-i) * 24] : (int)tb[i];
-            };
-            const int ma = bx > 0 ? sh_mode4[by * 4 + bx - 1] : sh_nbm[by], mb_ = by > 0 ? sh_mode4[(by - 1) * 4 + bx] : sh_nbm[4 + bx];
-            const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
+            auto E = [&](int i) -> int { i = i > emax ? emax : i; return i < 0 ? (int)tb[(-i) * 24] : (int)tb[i]; };
+            const int bmode = sh_mode4[by * 4 + bx];
             const int sv = S4[(by * 4 + py) * 16 + bx * 4 + px];
             const int sumT = E(1) + E(2) + E(3) + E(4), sumL = E(-1) + E(-2) + E(-3) + E(-4);
             const int dc4 = (up && lf) ? (sumT + sumL + 4) >> 3 : lf ? (sumL + 2) >> 2 : up ? (sumT + 2) >> 2 : 128;
-            unsigned best = BIG; int bmode = 2, bpred = dc4;
-#pragma unroll
-            for (int md = 0; md < 9; md++) {
-                int pv;
-                if (md == 0) pv = E(px + 1);
-                else if (md == 1) pv = E(-(py + 1));
-                else if (md == 2) pv = dc4;
-                else if (md == 3) pv = (px == 3 && py == 3) ? (E(7) + 3 * E(8) + 2) >> 2 : (E(px + py + 1) + 2 * E(px + py + 2) + E(px + py + 3) + 2) >> 2;
-                else if (md == 4) pv = (E(px - py - 1) + 2 * E(px - py) + E(px - py + 1) + 2) >> 2;
-                else if (md == 5) {
-                    const int z = 2 * px - py, k = px - (py >> 1);
-                    pv = (z >= 0 && !(z & 1)) ? (E(k) + E(k + 1) + 1) >> 1 : z >= 0 ? (E(k - 1) + 2 * E(k) + E(k + 1) + 2) >> 2
-                         : z == -1 ? (E(-1) + 2 * E(0) + E(1) + 2) >> 2 : (E(-py) + 2 * E(-py + 1) + E(-py + 2) + 2) >> 2;
-                } else if (md == 6) {
-                    const int z = 2 * py - px, k = py - (px >> 1);
-                    pv = (z >= 0 && !(z & 1)) ? (E(-k) + E(-k - 1) + 1) >> 1 : z >= 0 ? (E(-k + 1) + 2 * E(-k) + E(-k - 1) + 2) >> 2
-                         : z == -1 ? (E(-1) + 2 * E(0) + E(1) + 2) >> 2 : (E(px) + 2 * E(px - 1) + E(px - 2) + 2) >> 2;
-                } else if (md == 7) {
-                    const int k = px + (py >> 1);
-                    pv = !(py & 1) ? (E(k + 1) + E(k + 2) + 1) >> 1 : (E(k + 1) + 2 * E(k + 2) + E(k + 3) + 2) >> 2;
-                } else {
-                    const int z = px + 2 * py, k = py + (px >> 1);
-                    pv = z > 5 ? E(-4) : z == 5 ? (E(-3) + 3 * E(-4) + 2) >> 2 : !(z & 1) ? (E(-(k + 1)) + E(-(k + 2)) + 1) >> 1
-                         : (E(-(k + 1)) + 2 * E(-(k + 2)) + E(-(k + 3)) + 2) >> 2;
-                }
-                const bool need_up = md == 0 || md == 3 || md == 7, need_left = md == 1 || md == 8, need_all = md >= 4 && md <= 6;
-                const bool okm = !((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul)) || (b == 5 && (md == 3 || md == 7)));
-                const unsigned sad = (unsigned)wave16_sum(iabs(sv - pv));
-                const unsigned cst = okm ? sad + (unsigned)(lam * (md == pm ? 1 : 4)) : BIG;
-                if (cst < best) { best = cst; bmode = md; bpred = pv; }
-            }
+            const int bpred = pred4_px(bmode, px, py, E, dc4);
             // residual -> 4x4 core transform across the 16 lanes (rows, then columns)
             const int res = sv - bpred;
             const int cbase = lane & ~12;
@@ -1059,21 +1205,33 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
                 const int by1 = by_lo + 1, bx1 = s4 - 2 * by1, b1 = ((by1 >> 1) << 3) | ((bx1 >> 1) << 2) | ((by1 & 1) << 1) | (bx1 & 1);
                 if (bal & 0xFFFF0000ull) nz4 |= 1u << b1;
             }
-            cost4 += (unsigned)__shfl((int)best, 0, 64) + (two ? (unsigned)__shfl((int)best, 16, 64) : 0u);
             if (valid) {
                 T4[(by * 4 + py + 1) * 24 + bx * 4 + px + 1] = (uint8_t)recp;
                 stg8(ry + (size_t)(y0 + by * 4 + py) * stride + x0 + bx * 4 + px, (unsigned)recp);
                 stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + b * 16 + kz4], lv4);
-                if ((lane & 15) == 0) { sh_mode4[by * 4 + bx] = bmode; stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + b], bmode); }
+                if ((lane & 15) == 0) stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + b], bmode);
             }
             WAVE_SYNC();
         }
-        use_i4 = cost4 + (unsigned)(32 * lam) < cost16;
-        if (use_i4) sad_sel = cost4 + (unsigned)(32 * lam); // lane 0 reports it
-    }
-    if (is_luma && !use_i4) {
-        const int b = lane, bx = blkx(b), by = blky(b);
-        // ---- residual, core transform, DC through the 4x4 Hadamard
+    } else if (is_luma) {
+        // ================================================================ Intra_16x16 reconstruction (8.3.3 + 8.5.10)
+        const int b = lane, bx = blkx(b), by = blky(b), mode = mode16;
+        int st = 0, sl = 0, Hh = 0, Vv = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { st += TOP(0, i); sl += LEFT(0, i); }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            Hh += (i + 1) * (TOP(0, 8 + i) - TOP(0, 6 - i));
+            Vv += (i + 1) * (LEFT(0, 8 + i) - LEFT(0, 6 - i));
+        }
+        const int dcv = (has_top && has_left) ? (st + sl + 16) >> 5 : has_top ? (st + 8) >> 4 : has_left ? (sl + 8) >> 4 : 128;
+        const int pa = 16 * (LEFT(0, 15) + TOP(0, 15)), pb = (5 * Hh + 32) >> 6, pc = (5 * Vv + 32) >> 6;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                pred[r * 4 + i] = mode == 0 ? TOP(0, bx + i) : mode == 1 ? LEFT(0, by + r) : mode == 2 ? dcv
+                                  : clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5);
         const qparams q = make_q(T, qp, true);
         int x[16], lev[16];
 #pragma unroll
@@ -1083,8 +1241,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
         bool nz = quant_dequant<1>(x, lev, q);
         store_levels(ctx->levels + (size_t)mbn * MB_LEVELS + L_LUMA + b * 16, lev);
         flags = nz ? 1 : 0;
-        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): the 16 DC writes have landed (same wave)
-        __builtin_amdgcn_wave_barrier();
+        WAVE_SYNC();
         // lane p = raster position (i,j): hd = (M X M^T + 1) >> 1, M = [[1,1,1,1],[1,1,-1,-1],[1,-1,-1,1],[1,-1,1,-1]]
         const int pi = lane >> 2, pj = lane & 3;
         const int Mi[4] = {1, pi < 2 ? 1 : -1, (pi == 0 || pi == 3) ? 1 : -1, (pi & 1) ? -1 : 1};
@@ -1097,16 +1254,13 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
         const int hd = (acc + 1) >> 1;
         const int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
         sh_ldc[lane] = ldc;
-        // zig-zag position of raster index `lane` (inverse of zz)
-        int kz = 0;
+        int kz = 0; // zig-zag position of raster index `lane` (inverse of zz)
 #pragma unroll
         for (int k = 0; k < 16; k++) if (zz(k) == lane) kz = k;
         stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + kz], ldc);
         if (ldc) flags |= 2;
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        // inverse for this lane's own block position (by/4, bx/4): f = M c M^T, then 8.5.10 scaling
-        {
+        WAVE_SYNC();
+        { // inverse for this lane's own block position (by/4, bx/4): f = M c M^T, then 8.5.10 scaling
             const int bi = by >> 2, bj = bx >> 2;
             const int Ni[4] = {1, bi < 2 ? 1 : -1, (bi == 0 || bi == 3) ? 1 : -1, (bi & 1) ? -1 : 1};
             const int Nj[4] = {1, bj < 2 ? 1 : -1, (bj == 0 || bj == 3) ? 1 : -1, (bj & 1) ? -1 : 1};
@@ -1124,14 +1278,14 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
             stg32(ry + (size_t)(y0 + by + r) * stride + x0 + bx,
                   pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
                         clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3])));
-    } else if (!is_luma && lane < 32) { // lanes 16-31 form one shuffle group; 16-23 do chroma, 24-31 pad with zeros
+    }
+    if (!is_luma && lane < 32) { // lanes 16-31 form one shuffle group for chroma_block; 16-23 carry the 8 chroma blocks
         const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
         const int p = 1 + c;
-        // DC of this 4x4 block (8.3.4.1-3)
         int st = 0, sl = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) { st += TOP(p, bx + i); sl += LEFT(p, by + i); }
-        int dcv;
+        int dcv; // DC of this 4x4 block (8.3.4.1-3)
         {
             bool ut = has_top, ul = has_left;
             if (b == 1 && has_top) ul = false;
@@ -1145,35 +1299,11 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
             Vv += (i + 1) * (LEFT(p, 4 + i) - LEFT(p, 2 - i));
         }
         const int pa = 16 * (LEFT(p, 7) + TOP(p, 7)), pb = (34 * Hh + 32) >> 6, pc = (34 * Vv + 32) >> 6;
-        unsigned sad[4] = {0, 0, 0, 0};
-        if (is_chroma) {
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    int sv = src[r * 4 + i];
-                    sad[0] += iabs(sv - dcv);
-                    sad[1] += iabs(sv - LEFT(p, by + r));
-                    sad[2] += iabs(sv - TOP(p, bx + i));
-                    sad[3] += iabs(sv - clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5));
-                }
-        }
-        unsigned tot[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) tot[k] = (unsigned)wave16_sum((int)sad[k]);
-        if (!has_left) tot[1] = BIG;
-        if (!has_top) tot[2] = BIG;
-        if (!(has_top && has_left)) tot[3] = BIG;
-        unsigned best = tot[0]; mode = 0;
-        if (tot[1] < best) { best = tot[1]; mode = 1; }
-        if (tot[2] < best) { best = tot[2]; mode = 2; }
-        if (tot[3] < best) { best = tot[3]; mode = 3; }
-        sad_sel = best;
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int i = 0; i < 4; i++)
-                pred[r * 4 + i] = mode == 0 ? dcv : mode == 1 ? LEFT(p, by + r) : mode == 2 ? TOP(p, bx + i)
+                pred[r * 4 + i] = cmode == 0 ? dcv : cmode == 1 ? LEFT(p, by + r) : cmode == 2 ? TOP(p, bx + i)
                                   : clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5);
         if (is_chroma) flags = chroma_block(ctx, T, mbn, cx0, cy0, cl, pred, qp, true);
         else {
@@ -1184,15 +1314,14 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
 #undef TOP
 #undef LEFT
     const unsigned long long any = __ballot(flags & 1), dcm = __ballot(flags & 2);
-    const int cmode = __shfl(mode, 16), csad = __shfl((int)sad_sel, 16);
     if (lane == 0) {
         unsigned nzm = (use_i4 ? nz4 : (unsigned)(any & 0xFFFF)) | ((unsigned)((any >> 16) & 0xFF) << 16);
         if (!use_i4 && (dcm & 0xFFFF)) nzm |= NZ_LDC;
         if ((dcm >> 16) & 0x0F) nzm |= NZ_CBDC;
         if ((dcm >> 16) & 0xF0) nzm |= NZ_CRDC;
         mb_info_t mb;
-        mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)mode; mb.chroma_mode = (uint8_t)cmode;
-        mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = sad_sel + (unsigned)csad;
+        mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)mode16; mb.chroma_mode = (uint8_t)cmode;
+        mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = cost_luma + costc;
         st_mbinfo(&ctx->mbi[mbn], mb);
     }
 }
@@ -1709,6 +1838,9 @@ void k_launch_subpel(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) 
 void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
     int pairs = (mbw * mbh + 1) / 2;
     hipLaunchKernelGGL(inter_kernel, dim3((pairs + 3) / 4), dim3(256), 0, s, d_ctx);
+}
+void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
+    hipLaunchKernelGGL(intra_analyse_kernel, dim3((mbw * mbh + 3) / 4), dim3(256), 0, s, d_ctx);
 }
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s) {
     int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;

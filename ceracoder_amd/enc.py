@@ -25,7 +25,7 @@ EXPORTS = [
     "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_encode", "mi355enc_submit",
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
-    "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_deblock", "mi355enc_time_stage",
+    "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_deblock", "mi355enc_time_stage",
     "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
     "mi355enc_rc_pick_qp", "mi355enc_rc_update",
 ]
@@ -86,6 +86,7 @@ def load():
         L.mi355enc_stage_subpel.argtypes = [vp, vp, vp, C.c_int, vp]
         L.mi355enc_stage_inter.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.mi355enc_stage_intra_analyse.argtypes = [vp, vp, vp, vp]
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
         L.mi355enc_time_stage.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mi355enc_host_write_headers.argtypes = [C.c_int] * 5 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -265,6 +266,11 @@ class Encoder:
         self._chk(self.L.mi355enc_stage_intra(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)), qp,
                                               _p(mbi), _p(rec_y), _p(rec_uv), _p(lev)), "stage_intra")
         return rec_y, rec_uv, mbi, lev
+
+    def stage_intra_analyse(self, src_y, src_uv):
+        out = np.empty((self.mbw * self.mbh, 152), np.uint16)
+        self._chk(self.L.mi355enc_stage_intra_analyse(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)), _p(out)), "stage_intra_analyse")
+        return out
 
     def stage_deblock(self, rec_y, rec_uv, mbi):
         y, uv = np.ascontiguousarray(rec_y).copy(), np.ascontiguousarray(rec_uv).copy()

@@ -129,6 +129,8 @@ int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
                          int16_t *levels);
 int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out,
                          uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
+/* open-loop intra analysis only: 152 uint16 per macroblock {i16[4], chroma[4], i4[16][9]}, 0xFFFF = mode unavailable */
+int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, uint16_t *isad_out);
 int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const void *mbinfo);
 /* Time `iters` back-to-back launches of one stage on the handle's stream with HIP events;
  * stage: 0 ME, 1 inter, 2 intra (whole wavefront), 3 deblock (whole wavefront), 4 sub-sample refinement.

@@ -707,111 +707,155 @@ static void pred4x4(const int e[13], int mode, int has_up, int has_left, uint8_t
             out[y * 4 + x] = (uint8_t)v;
         }
 }
-/* Intra_4x4 coding of one macroblock into rec_y (encoder choice of modes: lowest
- * SAD + lambda * (mode == predicted ? 1 : 4); ties to the lowest mode; block 5 never uses the two
- * modes that read the top-right macroblock, which keeps the x+y wavefront of the device valid).
- * Modes go to lev[ORC_L_LDC + blkIdx].  Returns the summed cost. */
-static uint32_t intra4x4_mb(const uint8_t *src_y, uint8_t *rec_y, int stride, int mbw, int mx, int my, int qp, int lambda,
-                            const orc_mbinfo_t *mbi, const int16_t *levels, int16_t *lev, uint32_t *nzmask) {
+/* ---- Intra analysis (encoder choice).  Mode decisions are "open loop": every candidate prediction is
+ * built from the SOURCE picture's neighbouring samples, so all macroblocks (and all sixteen 4x4 blocks of a
+ * macroblock) can be analysed independently -- the device does this in one fully parallel kernel -- while the
+ * reconstruction that follows uses the normative reconstructed neighbours with the modes chosen here.
+ * 0xFFFF marks a mode whose neighbours do not exist (or, for block 5, that would read the macroblock
+ * above-right, which would break the device's x+y wavefront). */
+static void e13_from(const uint8_t *p, int stride, int X, int Y, int up, int lf, int ul, int ur, int e[13]) {
+    e[0] = ul ? p[(size_t)(Y - 1) * stride + X - 1] : 0;
+    for (int i = 0; i < 4; i++) { e[1 + i] = up ? p[(size_t)(Y - 1) * stride + X + i] : 0; e[9 + i] = lf ? p[(size_t)(Y + i) * stride + X - 1] : 0; }
+    for (int i = 4; i < 8; i++) e[1 + i] = ur ? p[(size_t)(Y - 1) * stride + X + i] : e[4];
+}
+static void blk4_avail(int b, int has_top, int has_left, int has_tr, int *up, int *lf, int *ul, int *ur) {
     static const uint8_t raster_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
-    const int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0, has_tr = my > 0 && mx + 1 < mbw;
+    const int bx = k_blk_x[b] >> 2, by = k_blk_y[b] >> 2;
+    *up = by > 0 || has_top; *lf = bx > 0 || has_left;
+    *ul = (bx > 0 && by > 0) ? 1 : bx > 0 ? has_top : by > 0 ? has_left : (has_top && has_left);
+    *ur = by == 0 ? (bx < 3 ? has_top : has_tr) : (bx < 3 && raster_blk[(by - 1) * 4 + bx + 1] < b);
+}
+static int mode4_ok(int b, int mode, int up, int lf, int ul) {
+    const int need_up = mode == 0 || mode == 3 || mode == 7, need_left = mode == 1 || mode == 8, need_all = mode >= 4 && mode <= 6;
+    if ((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul))) return 0;
+    return !(b == 5 && (mode == 3 || mode == 7));
+}
+void orc_intra_analyse(const uint8_t *src_y, const uint8_t *src_uv, int stride, int mbw, int mbh, orc_isad_t *out) {
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            orc_isad_t *o = &out[my * mbw + mx];
+            const int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0, has_tr = my > 0 && mx + 1 < mbw;
+            uint8_t pred[256], cp[64];
+            for (int mode = 0; mode < 4; mode++) {
+                o->i16[mode] = 0xFFFF;
+                if ((mode == 0 && !has_top) || (mode == 1 && !has_left) || (mode == 3 && !(has_top && has_left))) continue;
+                pred16(src_y, stride, x0, y0, mode, has_top, has_left, pred);
+                uint32_t sad = 0;
+                for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) sad += (uint32_t)iabs(src_y[(size_t)(y0 + y) * stride + x0 + x] - pred[y * 16 + x]);
+                o->i16[mode] = (uint16_t)sad;
+            }
+            for (int mode = 0; mode < 4; mode++) {
+                o->chroma[mode] = 0xFFFF;
+                if ((mode == 1 && !has_left) || (mode == 2 && !has_top) || (mode == 3 && !(has_top && has_left))) continue;
+                uint32_t sad = 0;
+                for (int c = 0; c < 2; c++) {
+                    pred_chroma(src_uv, stride, x0 / 2, y0 / 2, c, mode, has_top, has_left, cp);
+                    for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) sad += (uint32_t)iabs(UV(src_uv, stride, x0 / 2 + x, y0 / 2 + y, c) - cp[y * 8 + x]);
+                }
+                o->chroma[mode] = (uint16_t)sad;
+            }
+            for (int b = 0; b < 16; b++) {
+                const int X = x0 + k_blk_x[b], Y = y0 + k_blk_y[b];
+                int up, lf, ul, ur, e[13];
+                blk4_avail(b, has_top, has_left, has_tr, &up, &lf, &ul, &ur);
+                e13_from(src_y, stride, X, Y, up, lf, ul, ur, e);
+                for (int mode = 0; mode < 9; mode++) {
+                    o->i4[b][mode] = 0xFFFF;
+                    if (!mode4_ok(b, mode, up, lf, ul)) continue;
+                    uint8_t p4[16];
+                    pred4x4(e, mode, up, lf, p4);
+                    uint32_t sad = 0;
+                    for (int i = 0; i < 16; i++) sad += (uint32_t)iabs(src_y[(size_t)(Y + (i >> 2)) * stride + X + (i & 3)] - p4[i]);
+                    o->i4[b][mode] = (uint16_t)sad;
+                }
+            }
+        }
+}
+static int argmin_u16(const uint16_t *v, int n, uint32_t *best) {
+    int bi = 0; uint32_t b = 0xFFFFFFFFu;
+    for (int i = 0; i < n; i++) if (v[i] != 0xFFFF && v[i] < b) { b = v[i]; bi = i; }
+    *best = b;
+    return bi;
+}
+/* Intra_4x4 modes of one macroblock from the analysed SADs: per block lowest SAD + lambda * (mode == predicted ? 1 : 4),
+ * ties to the lowest mode; the predicted mode follows 8.3.1.1.  Modes go to lev[ORC_L_LDC + blkIdx]. */
+static uint32_t intra4x4_choose(const orc_isad_t *sad, int mbw, int mx, int my, int lambda, const orc_mbinfo_t *mbi,
+                                const int16_t *levels, int16_t *lev) {
+    static const uint8_t raster_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
     const orc_mbinfo_t *m = &mbi[my * mbw + mx];
     uint32_t total = 0;
-    int modes[16]; /* by blkIdx */
     for (int b = 0; b < 16; b++) {
-        const int bx = k_blk_x[b] >> 2, by = k_blk_y[b] >> 2, X = x0 + 4 * bx, Y = y0 + 4 * by;
-        const int up = by > 0 || has_top, lf = bx > 0 || has_left;
-        const int ul = (bx > 0 && by > 0) ? 1 : bx > 0 ? has_top : by > 0 ? has_left : (has_top && has_left);
-        int ur;
-        if (by == 0) ur = bx < 3 ? has_top : has_tr;
-        else ur = bx < 3 && raster_blk[(by - 1) * 4 + bx + 1] < b;
-        int e[13];
-        e[0] = ul ? rec_y[(size_t)(Y - 1) * stride + X - 1] : 0;
-        for (int i = 0; i < 4; i++) { e[1 + i] = up ? rec_y[(size_t)(Y - 1) * stride + X + i] : 0; e[9 + i] = lf ? rec_y[(size_t)(Y + i) * stride + X - 1] : 0; }
-        for (int i = 4; i < 8; i++) e[1 + i] = ur ? rec_y[(size_t)(Y - 1) * stride + X + i] : e[4];
-        /* 8.3.1.1 predicted mode */
+        const int bx = k_blk_x[b] >> 2, by = k_blk_y[b] >> 2;
         int ma = -1, mb_ = -1;
-        if (bx > 0) ma = modes[raster_blk[by * 4 + bx - 1]];
-        else if (has_left) ma = m[-1].mb_type == 2 ? levels[(size_t)(my * mbw + mx - 1) * ORC_LEVELS_PER_MB + ORC_L_LDC + raster_blk[by * 4 + 3]] : 2;
-        if (by > 0) mb_ = modes[raster_blk[(by - 1) * 4 + bx]];
-        else if (has_top) mb_ = m[-mbw].mb_type == 2 ? levels[(size_t)((my - 1) * mbw + mx) * ORC_LEVELS_PER_MB + ORC_L_LDC + raster_blk[12 + bx]] : 2;
+        if (bx > 0) ma = lev[ORC_L_LDC + raster_blk[by * 4 + bx - 1]];
+        else if (mx > 0) ma = m[-1].mb_type == 2 ? levels[(size_t)(my * mbw + mx - 1) * ORC_LEVELS_PER_MB + ORC_L_LDC + raster_blk[by * 4 + 3]] : 2;
+        if (by > 0) mb_ = lev[ORC_L_LDC + raster_blk[(by - 1) * 4 + bx]];
+        else if (my > 0) mb_ = m[-mbw].mb_type == 2 ? levels[(size_t)((my - 1) * mbw + mx) * ORC_LEVELS_PER_MB + ORC_L_LDC + raster_blk[12 + bx]] : 2;
         const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
-        uint8_t pred[16], best_pred[16];
         uint32_t best = 0xFFFFFFFFu; int best_mode = 2;
         for (int mode = 0; mode < 9; mode++) {
-            const int need_up = mode == 0 || mode == 3 || mode == 7, need_left = mode == 1 || mode == 8, need_all = mode >= 4 && mode <= 6;
-            if ((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul))) continue;
-            if (b == 5 && (mode == 3 || mode == 7)) continue; /* would read the macroblock above-right */
-            pred4x4(e, mode, up, lf, pred);
-            uint32_t cost = (uint32_t)(lambda * (mode == pm ? 1 : 4));
-            for (int i = 0; i < 16; i++) cost += (uint32_t)iabs(src_y[(size_t)(Y + (i >> 2)) * stride + X + (i & 3)] - pred[i]);
-            if (cost < best) { best = cost; best_mode = mode; memcpy(best_pred, pred, 16); }
+            if (sad->i4[b][mode] == 0xFFFF) continue;
+            uint32_t cost = sad->i4[b][mode] + (uint32_t)(lambda * (mode == pm ? 1 : 4));
+            if (cost < best) { best = cost; best_mode = mode; }
         }
-        modes[b] = best_mode; lev[ORC_L_LDC + b] = (int16_t)best_mode; total += best;
+        lev[ORC_L_LDC + b] = (int16_t)best_mode;
+        total += best;
+    }
+    return total;
+}
+/* reconstruction of an Intra_4x4 macroblock with the modes in lev[ORC_L_LDC..] (8.3.1.2 + 8.5) */
+static void intra4x4_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int mbw, int mx, int my, int qp, int16_t *lev, uint32_t *nzmask) {
+    const int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0, has_tr = my > 0 && mx + 1 < mbw;
+    for (int b = 0; b < 16; b++) {
+        const int X = x0 + k_blk_x[b], Y = y0 + k_blk_y[b];
+        int up, lf, ul, ur, e[13];
+        blk4_avail(b, has_top, has_left, has_tr, &up, &lf, &ul, &ur);
+        e13_from(rec_y, stride, X, Y, up, lf, ul, ur, e);
+        uint8_t p4[16];
+        pred4x4(e, lev[ORC_L_LDC + b], up, lf, p4);
         int16_t res[16];
-        for (int i = 0; i < 16; i++) res[i] = (int16_t)(src_y[(size_t)(Y + (i >> 2)) * stride + X + (i & 3)] - best_pred[i]);
+        for (int i = 0; i < 16; i++) res[i] = (int16_t)(src_y[(size_t)(Y + (i >> 2)) * stride + X + (i & 3)] - p4[i]);
         if (tq_block(res, qp, 1, 0, lev + ORC_L_LUMA + b * 16, NULL)) *nzmask |= 1u << b;
-        for (int i = 0; i < 16; i++) rec_y[(size_t)(Y + (i >> 2)) * stride + X + (i & 3)] = best_pred[i];
+        for (int i = 0; i < 16; i++) rec_y[(size_t)(Y + (i >> 2)) * stride + X + (i & 3)] = p4[i];
         int32_t d[16];
         dq_block(lev + ORC_L_LUMA + b * 16, qp, 0, 0, 0, d);
         orc_idct4_add(d, rec_y + (size_t)Y * stride + X, stride);
     }
-    return total;
 }
 
-/* Mode decision is an encoder choice: lowest SAD(source, prediction) among the modes whose
- * neighbours exist; ties go to the lowest mode number.  Chroma decides on Cb+Cr jointly. */
+/* I picture.  Analysis (above) on source neighbours, then per macroblock in raster order: Intra_16x16 mode =
+ * lowest SAD (ties to the lowest mode number), chroma likewise on Cb+Cr jointly, Intra_4x4 modes by
+ * intra4x4_choose; I_NxN is taken when its cost + 32 lambda (its extra header bits) is strictly lower. */
 void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
                      uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
                      orc_mbinfo_t *mbi, int16_t *levels) {
+    orc_isad_t *isad = (orc_isad_t *)malloc((size_t)mbw * mbh * sizeof(orc_isad_t));
+    orc_intra_analyse(src_y, src_uv, stride, mbw, mbh, isad);
+    const int lambda = orc_me_lambda(qp);
     for (int my = 0; my < mbh; my++)
         for (int mx = 0; mx < mbw; mx++) {
             orc_mbinfo_t *m = &mbi[my * mbw + mx];
+            const orc_isad_t *sad = &isad[my * mbw + mx];
             int16_t *lev = levels + (size_t)(my * mbw + mx) * ORC_LEVELS_PER_MB;
             memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
             int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0;
             m->mb_type = 0; m->mvx = 0; m->mvy = 0; m->qp = (uint8_t)qp; m->nzmask = 0;
-            /* --- luma mode */
-            uint8_t pred[256], best_pred[256];
-            uint32_t best = 0xFFFFFFFFu; int best_mode = 2;
-            for (int mode = 0; mode < 4; mode++) {
-                if (mode == 0 && !has_top) continue;
-                if (mode == 1 && !has_left) continue;
-                if (mode == 3 && !(has_top && has_left)) continue;
-                pred16(rec_y, stride, x0, y0, mode, has_top, has_left, pred);
-                uint32_t sad = 0;
-                for (int y = 0; y < 16; y++)
-                    for (int x = 0; x < 16; x++) sad += (uint32_t)iabs(src_y[(size_t)(y0 + y) * stride + x0 + x] - pred[y * 16 + x]);
-                if (sad < best) { best = sad; best_mode = mode; memcpy(best_pred, pred, 256); }
-            }
+            uint32_t luma_sad, chroma_sad;
+            const int best_mode = argmin_u16(sad->i16, 4, &luma_sad);
+            const int best_cmode = argmin_u16(sad->chroma, 4, &chroma_sad);
             m->i16_mode = (uint8_t)best_mode;
-            uint32_t luma_sad = best;
-            /* --- Intra 4x4 candidate (writes rec_y and the luma levels); kept when strictly cheaper */
+            m->chroma_mode = (uint8_t)best_cmode;
             int use_i4 = 0;
             if (g_orc_i4x4) {
-                uint32_t nz4 = 0;
-                uint32_t cost4 = intra4x4_mb(src_y, rec_y, stride, mbw, mx, my, qp, orc_me_lambda(qp), mbi, levels, lev, &nz4);
-                if (cost4 + (uint32_t)(32 * orc_me_lambda(qp)) < luma_sad) { use_i4 = 1; /* 32 lambda: the extra header bits of I_NxN */ m->mb_type = 2; m->i16_mode = 0; m->nzmask = nz4; luma_sad = cost4 + (uint32_t)(32 * orc_me_lambda(qp)); }
-                else { memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t)); }
+                uint32_t cost4 = intra4x4_choose(sad, mbw, mx, my, lambda, mbi, levels, lev);
+                if (cost4 + (uint32_t)(32 * lambda) < luma_sad) { use_i4 = 1; m->mb_type = 2; m->i16_mode = 0; luma_sad = cost4 + (uint32_t)(32 * lambda); }
+                else memset(lev + ORC_L_LDC, 0, 16 * sizeof(int16_t));
             }
-            /* --- chroma mode */
-            uint8_t cp[2][64], best_cp[2][64];
-            best = 0xFFFFFFFFu; int best_cmode = 0;
-            for (int mode = 0; mode < 4; mode++) {
-                if (mode == 1 && !has_left) continue;
-                if (mode == 2 && !has_top) continue;
-                if (mode == 3 && !(has_top && has_left)) continue;
-                uint32_t sad = 0;
-                for (int c = 0; c < 2; c++) {
-                    pred_chroma(rec_uv, stride, x0 / 2, y0 / 2, c, mode, has_top, has_left, cp[c]);
-                    for (int y = 0; y < 8; y++)
-                        for (int x = 0; x < 8; x++) sad += (uint32_t)iabs(UV(src_uv, stride, x0 / 2 + x, y0 / 2 + y, c) - cp[c][y * 8 + x]);
-                }
-                if (sad < best) { best = sad; best_cmode = mode; memcpy(best_cp, cp, sizeof cp); }
-            }
-            m->chroma_mode = (uint8_t)best_cmode;
-            m->cost = luma_sad + best;
-            if (!use_i4) {
+            m->cost = luma_sad + chroma_sad;
+            if (use_i4) intra4x4_recon(src_y, rec_y, stride, mbw, mx, my, qp, lev, &m->nzmask);
+            else {
+            uint8_t best_pred[256];
+            pred16(rec_y, stride, x0, y0, best_mode, has_top, has_left, best_pred);
             /* --- luma residual: 16 x (4x4 core), DCs through the 4x4 Hadamard (8.5.10 inverse) */
             int16_t dcs[16]; /* raster over 4x4 blocks: index (by/4)*4 + bx/4 */
             for (int b = 0; b < 16; b++) {
@@ -865,12 +909,16 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
                 orc_idct4_add(d, rec_y + (size_t)(y0 + by) * stride + x0 + bx, stride);
             }
             } /* !use_i4 */
-            /* --- chroma */
-            for (int c = 0; c < 2; c++)
+            /* --- chroma: prediction from the reconstructed neighbours with the analysed mode */
+            for (int c = 0; c < 2; c++) {
+                uint8_t cp[64];
+                pred_chroma(rec_uv, stride, x0 / 2, y0 / 2, c, best_cmode, has_top, has_left, cp);
                 for (int y = 0; y < 8; y++)
-                    for (int x = 0; x < 8; x++) UV(rec_uv, stride, x0 / 2 + x, y0 / 2 + y, c) = best_cp[c][y * 8 + x];
+                    for (int x = 0; x < 8; x++) UV(rec_uv, stride, x0 / 2 + x, y0 / 2 + y, c) = cp[y * 8 + x];
+            }
             chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 1, lev, &m->nzmask);
         }
+    free(isad);
 }
 
 /* ================================================================== deblocking (8.7) */

@@ -70,6 +70,10 @@ void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t 
                      const uint8_t *ref_uv, uint8_t *rec_y, uint8_t *rec_uv, int stride,
                      int mbw, int mbh, int qp, orc_mbinfo_t *mbi, int16_t *levels);
 
+/* SADs of every intra candidate measured against predictions built from SOURCE neighbours (0xFFFF: mode not available). */
+typedef struct { uint16_t i16[4], chroma[4], i4[16][9]; } orc_isad_t; /* 304 bytes per macroblock */
+void orc_intra_analyse(const uint8_t *src_y, const uint8_t *src_uv, int stride, int mbw, int mbh, orc_isad_t *out);
+
 /* I picture: Intra16x16 + chroma prediction, mode decision by SAD, transform/quant,
  * reconstruction (pre-deblock), macroblocks in raster order. */
 void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,

@@ -66,6 +66,8 @@ def lib():
         L.orc_set_i4x4.restype = None
         L.orc_inter_frame.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.orc_inter_frame.restype = None
+        L.orc_intra_analyse.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_intra_analyse.restype = None
         L.orc_intra_frame.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.orc_intra_frame.restype = None
         L.orc_deblock_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -228,6 +230,15 @@ def inter_frame(src_y, src_uv, ref_y, ref_uv, mbi, qp):
     L.orc_inter_frame(_ptr(src_y), _ptr(src_uv), _ptr(ref_y), _ptr(ref_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16,
                       H // 16, qp, _ptr(mbi), _ptr(lev))
     return rec_y, rec_uv, mbi, lev
+
+
+def intra_analyse(src_y, src_uv):
+    """SADs of all intra candidates against source-neighbour predictions: (n_mb, 152) uint16, 0xFFFF = unavailable."""
+    L = lib()
+    H, W = src_y.shape
+    out = np.empty(((H // 16) * (W // 16), 152), np.uint16)
+    L.orc_intra_analyse(_ptr(np.ascontiguousarray(src_y)), _ptr(np.ascontiguousarray(src_uv)), W, W // 16, H // 16, _ptr(out))
+    return out
 
 
 def set_transform8x8(on):

@@ -77,6 +77,18 @@ def test_inter_kernel_matches_oracle(E, oracle, w, h, qp, sub):
     e.close()
 
 
+@pytest.mark.parametrize("w,h", SIZES + [(16, 16), (1920, 1088)])
+def test_intra_analyse_kernel_matches_oracle(E, oracle, w, h):
+    """Open-loop intra analysis (one flat launch): SAD of every I16 / chroma / I4x4 candidate, 152 u16 per macroblock."""
+    cy, cuv = frames(w, h, 1)[0][:2]
+    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=30)
+    dev, orc = e.stage_intra_analyse(cy, cuv), oracle.intra_analyse(cy, cuv)
+    assert np.array_equal(dev[:, :4], orc[:, :4]), ("i16", first_diff(dev[:, :4], orc[:, :4]))
+    assert np.array_equal(dev[:, 4:8], orc[:, 4:8]), ("chroma", first_diff(dev[:, 4:8], orc[:, 4:8]))
+    assert np.array_equal(dev[:, 8:], orc[:, 8:]), ("i4", first_diff(dev[:, 8:], orc[:, 8:]))
+    e.close()
+
+
 @pytest.mark.parametrize("w,h", SIZES)
 @pytest.mark.parametrize("qp", [0, 12, 28, 40, 51])
 @pytest.mark.parametrize("i4", [True, False])
