@@ -1504,14 +1504,14 @@ DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS uns
 DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // filter parameters of one edge class (left / top / inner), looked up once per macroblock
-struct edge_par { int alpha, beta, tc0[3]; };
+struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
 DEV edge_par make_par(const dev_tables *T, int qpav) {
     edge_par p;
     p.alpha = T->alpha[qpav]; p.beta = T->beta[qpav];
-    p.tc0[0] = T->tc0[qpav][0]; p.tc0[1] = T->tc0[qpav][1]; p.tc0[2] = T->tc0[qpav][2];
+    p.tc0 = (unsigned)T->tc0[qpav][0] | ((unsigned)T->tc0[qpav][1] << 8) | ((unsigned)T->tc0[qpav][2] << 16);
     return p;
 }
-DEV int tc0_of(const edge_par &P, int bS) { return bS == 1 ? P.tc0[0] : bS == 2 ? P.tc0[1] : P.tc0[2]; }
+DEV int tc0_of(const edge_par &P, int bS) { return (int)((P.tc0 >> (8 * (bS - 1))) & 0xFF); }
 // one luma line across an edge, samples in registers (8.7.2.3 / 8.7.2.4)
 DEV void edge_luma(const edge_par &P, int &p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int &q3, int bS) {
     (void)p3; (void)q3;
