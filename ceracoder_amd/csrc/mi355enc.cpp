@@ -58,6 +58,7 @@ struct mi355enc {
     hipStream_t cstream;                 // copy stream for the D2H hand-over
     uint64_t n_submitted;
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
+    uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock (deblock_mode 2)
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
     unsigned *d_progress; // [2*bands] strip counters of the band deblocker, then one error word
     unsigned *h_err;      // pinned mirror of the error word
@@ -129,7 +130,11 @@ static int run_intra(mi355enc_t *h) {
     return 0;
 }
 static int run_deblock(mi355enc_t *h) {
-    if (h->cfg.deblock_mode == 0) {
+    if (h->cfg.deblock_mode == 2) {
+        k_launch_deblock_band16(h->d_ctx, h->mbw, h->mbh, h->d_progress, h->n_progress + 1, h->d_progress + h->n_progress, h->stream);
+        HIPCHK(hipGetLastError());
+        return 0;
+    } else if (h->cfg.deblock_mode == 0) {
         HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(h->n_progress + 1) * sizeof(unsigned), h->stream));
         k_launch_deblock_band(h->d_ctx, h->mbh, h->d_progress, h->d_progress + h->n_progress, h->stream);
         return 0;
@@ -170,7 +175,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
-    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->h_err = nullptr; h->d_isad = nullptr;
+    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->h_err = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -192,7 +197,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMemsetAsync(h->d_rec_uv[i], 0, h->csz + SURF_PAD, h->stream));
     }
     HIPCHK(hipMalloc((void **)&h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t)));
-    h->n_progress = k_deblock_bands(h->mbh);
+    HIPCHK(hipMalloc((void **)&h->d_dbrec, (size_t)h->nmb * 64));
+    h->n_progress = k_deblock_bands(h->mbh) > 2 * k_deblock_bands16(h->mbh) ? k_deblock_bands(h->mbh) : 2 * k_deblock_bands16(h->mbh);
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&h->h_err, sizeof(unsigned), hipHostMallocDefault));
     *h->h_err = 0;
@@ -240,6 +246,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_pre_y) (void)hipFree(h->d_pre_y);
     if (h->d_pre_uv) (void)hipFree(h->d_pre_uv);
     if (h->d_isad) (void)hipFree(h->d_isad);
+    if (h->d_dbrec) (void)hipFree(h->d_dbrec);
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->h_err) (void)hipHostFree(h->h_err);
     if (h->d_ctx) (void)hipFree(h->d_ctx);
@@ -281,7 +288,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
     c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
     const int set = (int)(h->n_submitted & 1);
-    c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set]; c->isad = h->d_isad;
+    c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set]; c->isad = h->d_isad; c->dbrec = h->d_dbrec;
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
@@ -310,7 +317,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
     HIPCHK(hipMemcpyAsync(s->h_mbi, h->d_mbi_set[set], (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->cstream));
     HIPCHK(hipMemcpyAsync(s->h_levels, h->d_levels_set[set], (size_t)h->nmb * MB_LEVELS * sizeof(int16_t), hipMemcpyDeviceToHost, h->cstream));
-    if (h->cfg.deblock_mode == 0) HIPCHK(hipMemcpyAsync(h->h_err, h->d_progress + h->n_progress, sizeof(unsigned), hipMemcpyDeviceToHost, h->cstream));
+    if (h->cfg.deblock_mode != 1) HIPCHK(hipMemcpyAsync(h->h_err, h->d_progress + h->n_progress, sizeof(unsigned), hipMemcpyDeviceToHost, h->cstream));
     if (prof) HIPCHK(hipEventRecord(s->ev[4], h->cstream));
     HIPCHK(hipEventRecord(s->done, h->cstream));
     h->n_submitted++;
@@ -421,6 +428,7 @@ int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
     case MI355ENC_FETCH_PREFILTER_UV: src = h->d_pre_uv; need = h->csz; break;
     case MI355ENC_FETCH_MBINFO: src = h->last_slot ? h->last_slot->h_mbi : nullptr; need = (size_t)h->nmb * sizeof(mb_info_t); host = true; break;
     case MI355ENC_FETCH_LEVELS: src = h->last_slot ? h->last_slot->h_levels : nullptr; need = (size_t)h->nmb * MB_LEVELS * 2; host = true; break;
+    case 100: src = h->d_dbrec; need = (size_t)h->nmb * 64; break; /* debug: deblocking records of the last mode-2 launch */
     default: return MI355ENC_ERR_ARG;
     }
     if (!src) return MI355ENC_ERR_STATE;
@@ -439,7 +447,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     c->src_y = src_is_staging ? s->d_src_y : nullptr; c->src_uv = src_is_staging ? s->d_src_uv : nullptr; c->src_stride = h->W;
     c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
     HIPCHK(hipStreamSynchronize(h->cstream));
-    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
+    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     return 0;

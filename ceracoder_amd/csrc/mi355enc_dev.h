@@ -39,6 +39,7 @@ typedef struct {
     mb_info_t *mbi;
     int16_t *levels;
     uint16_t *isad;                /* intra analysis: 152 u16 per macroblock {i16[4], chroma[4], i4[16][9]}, 0xFFFF = mode unavailable */
+    uint8_t *dbrec;                /* deblocking: 64 B per macroblock {bS nibbles V, H; alpha/beta/tc0 of 6 edge classes} */
     int32_t src_stride;            /* bytes per source luma row (= chroma row, NV12)          */
     int32_t stride;                /* coded-surface stride = 16*mbw                           */
     int32_t mbw, mbh, vis_h;
@@ -62,6 +63,8 @@ void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, h
 void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
 void k_launch_deblock_band(const frame_ctx_t *d_ctx, int mbh, unsigned *d_progress, unsigned *d_err, hipStream_t s);
 int k_deblock_bands(int mbh);
+int k_deblock_bands16(int mbh);
+void k_launch_deblock_band16(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, unsigned *d_err, hipStream_t s);
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s);
 int k_intra_diags(int mbw, int mbh);
 int k_deblock_diags(int mbw, int mbh);

@@ -1807,6 +1807,276 @@ __global__ __launch_bounds__((2 * DB_R + 1) * 64) void deblock_band_kernel(db_ar
     }
 }
 
+// =================================================================== deblocking, 16-row bands in x + y order
+// Third form of the same filter.  Two observations shorten the dependency chain further:
+//  (1) Boundary strengths and the alpha/beta/tc0 triples depend only on the macroblock records,
+//      so a flat kernel (deblock_prep_kernel) computes them for the whole picture up front:
+//      64 bytes per macroblock {bS nibbles V/H, six packed parameter pairs}.
+//  (2) x + 2y is sufficient but not necessary.  Macroblock (x, y) only conflicts with its
+//      top-right neighbour (x+1, y-1) on the 3x3 corner of (x, y-1) that the neighbour's left
+//      edge (a VERTICAL edge, first thing it filters) and this macroblock's top edge (a
+//      HORIZONTAL edge, filtered after all vertical ones) both touch.  If every row filters its
+//      vertical edges, all rows meet at one barrier, and then every row filters its horizontal
+//      edges, (x, y) and (x+1, y-1) can share a step: the order x + y with ONE barrier per step
+//      reproduces the raster-order result (mbw + mbh - 1 steps instead of mbw + 2(mbh - 1)).
+// A wave serves four macroblock rows (16 lanes each: one lane per picture line / column), so a
+// workgroup of 4 luma + 4 chroma waves owns a band of 16 rows and only every 16th row boundary
+// crosses global memory (sc1 strips + progress counter, as in deblock_band_kernel).  Each lane
+// group prefetches its next macroblock one step ahead into registers and lands it in LDS after
+// the step's arithmetic, immediately before the step's own stores are issued, so the only
+// `s_waitcnt vmcnt(0)` on the chain waits for loads that have had a whole step to arrive.
+#define D3_ROWS 16
+#define D3_TS 52 /* tile row stride (13 dwords: the 16 lines of a group fall on 16 different banks) */
+struct d3_luma { uint8_t t[20 * D3_TS]; unsigned ring[4][16]; unsigned rec[16]; };   // 1360 B = 340 dwords (20 mod 32)
+struct d3_chroma { uint8_t t[10 * D3_TS]; unsigned ring[4][8]; unsigned rec[16]; };  // 712 B = 178 dwords (18 mod 32)
+#define DBREC_BYTES 64
+
+DEV unsigned pack_par_ab(const dev_tables *T, int idx) { return (unsigned)T->alpha[idx] | ((unsigned)T->beta[idx] << 8); }
+DEV unsigned pack_par_tc(const dev_tables *T, int idx) { return (unsigned)T->tc0[idx][0] | ((unsigned)T->tc0[idx][1] << 8) | ((unsigned)T->tc0[idx][2] << 16); }
+DEV edge_par par_of(unsigned ab, unsigned tc) { edge_par p; p.alpha = (int)(ab & 255); p.beta = (int)(ab >> 8); p.tc0 = tc; return p; }
+
+// One thread per macroblock: words 0-1 bS of the vertical edges (nibble 4*edge + segment), 2-3 of
+// the horizontal edges, then {alpha|beta<<8, tc0 bytes} for luma left / top / inner and chroma
+// left / top / inner.  Edges that are not filtered (picture border, 8x8-transform inner edges) get bS 0.
+// Also clears the band progress counters of the launch that follows.
+__global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t *__restrict__ ctx, unsigned *__restrict__ progress, int nprog) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nprog) progress[i] = 0;
+    const int mbw = ctx->mbw, mbh = ctx->mbh;
+    if (i >= mbw * mbh) return;
+    const dev_tables *T = &g_tab;
+    const int my = i / mbw, mx = i - my * mbw;
+    const mb_info_t cur = ld_mbinfo(&ctx->mbi[i]);
+    const mb_info_t lft = ld_mbinfo(&ctx->mbi[mx > 0 ? i - 1 : i]);
+    const mb_info_t upp = ld_mbinfo(&ctx->mbi[my > 0 ? i - mbw : i]);
+    const bool t8 = (cur.nzmask & NZ_T8) != 0;
+    unsigned w[16];
+    unsigned long long bv = 0, bh = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++) {
+            int v = 0, h = 0;
+            if (!(t8 && (e & 1))) {
+                if (!(e == 0 && mx == 0)) v = bs_of(e == 0 ? lft : cur, e == 0 ? 3 : e - 1, sg, cur, e, sg, e == 0);
+                if (!(e == 0 && my == 0)) h = bs_of(e == 0 ? upp : cur, sg, e == 0 ? 3 : e - 1, cur, sg, e, e == 0);
+            }
+            bv |= (unsigned long long)v << (4 * (e * 4 + sg));
+            bh |= (unsigned long long)h << (4 * (e * 4 + sg));
+        }
+    w[0] = (unsigned)bv; w[1] = (unsigned)(bv >> 32); w[2] = (unsigned)bh; w[3] = (unsigned)(bh >> 32);
+    const int il = clip3(0, 51, (lft.qp + cur.qp + 1) >> 1), it = clip3(0, 51, (upp.qp + cur.qp + 1) >> 1), ii = cur.qp;
+    const int qc = T->qpc[cur.qp], cl = (T->qpc[lft.qp] + qc + 1) >> 1, ct = (T->qpc[upp.qp] + qc + 1) >> 1;
+    w[4] = pack_par_ab(T, il); w[5] = pack_par_tc(T, il); w[6] = pack_par_ab(T, it); w[7] = pack_par_tc(T, it);
+    w[8] = pack_par_ab(T, ii); w[9] = pack_par_tc(T, ii); w[10] = pack_par_ab(T, cl); w[11] = pack_par_tc(T, cl);
+    w[12] = pack_par_ab(T, ct); w[13] = pack_par_tc(T, ct); w[14] = pack_par_ab(T, qc); w[15] = pack_par_tc(T, qc);
+    uint8_t *o = ctx->dbrec + (size_t)i * DBREC_BYTES;
+#pragma unroll
+    for (int q = 0; q < 4; q++) stg128(o + 16 * q, make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]));
+}
+
+typedef v4u v4u_a4 __attribute__((aligned(4)));
+DEV void stg128u(void *p, unsigned a, unsigned b, unsigned c, unsigned d) { v4u t; t.x = a; t.y = b; t.z = c; t.w = d; *(GAS v4u_a4 *)p = t; } // 4-byte aligned
+DEV int db_wait_get(unsigned *progress, unsigned *err, int need) {
+    int spins = 0, v;
+    while ((v = (int)ld_sc1(progress)) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(err))) { st_sc1(err, 1u); return 0x7FFFFFFF; } // bounded; once tripped, nobody waits again
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(512) void deblock_band16_kernel(db_args a) {
+    __shared__ __attribute__((aligned(16))) d3_luma LL[D3_ROWS];
+    __shared__ __attribute__((aligned(16))) d3_chroma CL[D3_ROWS];
+    const frame_ctx_t *__restrict__ ctx = a.ctx;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
+    const int band = blockIdx.x, nb = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool chroma = wave >= 4;
+    const int g = lane >> 4, k = lane & 15, r = 4 * (wave & 3) + g, my = band * D3_ROWS + r;
+    const bool row_ok = my < mbh, last_row = my == mbh - 1;
+    const bool fed = row_ok && r == 0 && band > 0;
+    const bool feeds = row_ok && r == D3_ROWS - 1 && !last_row;
+    unsigned *prog_up = a.progress + (chroma ? nb : 0) + (band > 0 ? band - 1 : 0), *prog_my = a.progress + (chroma ? nb : 0) + band;
+    const int rows_mb = chroma ? 8 : 16, strip = chroma ? 2 : 4, ring_n = chroma ? 8 : 16;
+    uint8_t *__restrict__ plane = chroma ? ctx->rec_uv : ctx->rec_y;
+    const uint8_t *__restrict__ dbrec = ctx->dbrec;
+    const size_t row0 = (size_t)my * rows_mb;
+    uint8_t *tile = chroma ? CL[r].t : LL[r].t;
+    unsigned *ring = chroma ? &CL[r].ring[0][0] : &LL[r].ring[0][0];
+    const unsigned *ring_up = chroma ? &CL[r > 0 ? r - 1 : 0].ring[0][0] : &LL[r > 0 ? r - 1 : 0].ring[0][0];
+    unsigned *recw = chroma ? CL[r].rec : LL[r].rec;
+    const int keep = last_row ? rows_mb : rows_mb - strip; // rows stored by this row itself; the strip below goes through the ring
+    uint4 own = make_uint4(0, 0, 0, 0), recv = make_uint4(0, 0, 0, 0);
+    unsigned stripv = 0, strip_next = 0;
+    int avail = 0, avail_next = 0;
+    const int nsteps = mbw + D3_ROWS + 2;
+    for (int t = 0; t < nsteps; t++) {
+        const int x = t - 1 - r, xn = x + 1;
+#if defined(D3_VARIANT) && (D3_VARIANT & 1)
+        BAND_BARRIER();
+#endif
+        const bool act = row_ok && x >= 0 && x < mbw;
+        const bool pf = row_ok && xn >= 0 && xn < mbw;
+        const bool pub = feeds && x >= 1 && x <= mbw;         // strip of macroblock x-1 becomes final in this step's vertical phase
+        const int x0b = x * 16;
+        // ---- A. prefetch macroblock x+1 (rows, record, strip of the band above)
+        if (pf) {
+            if (fed) {
+                if (avail < xn + 1) avail = db_wait_get(prog_up, a.err, xn + 1);
+                if (k < strip * 4) strip_next = ld_sc1((const unsigned *)(plane + (row0 - strip + (k >> 2)) * stride + xn * 16 + 4 * (k & 3)));
+                avail_next = (int)ld_sc1(prog_up);
+            }
+            if (k < rows_mb) own = ldg128(plane + (row0 + k) * stride + xn * 16);
+            if (k >= 12) recv = ldg128(dbrec + ((size_t)my * mbw + xn) * DBREC_BYTES + 16 * (k - 12));
+        }
+        unsigned bhl = 0, bhh = 0, ptab = 0, pttc = 0, piab = 0, pitc = 0;
+        // ---- B. vertical edges
+        if (act) {
+            const unsigned bvl = recw[0], bvh = recw[1];
+            bhl = recw[2]; bhh = recw[3];
+            const int o = chroma ? 10 : 4;
+            const unsigned plab = recw[o], pltc = recw[o + 1];
+            ptab = recw[o + 2]; pttc = recw[o + 3]; piab = recw[o + 4]; pitc = recw[o + 5];
+#if defined(D3_VARIANT) && (D3_VARIANT & 8)
+            if ((bvl | bvh) && !chroma) {
+#else
+            if (bvl | bvh) {
+#endif
+                if (!chroma) {
+                    const int sh = 4 * (k >> 2);
+                    const edge_par PL = par_of(plab, pltc), PI = par_of(piab, pitc);
+                    unsigned w5[5];
+#pragma unroll
+                    for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 4) * D3_TS + 12 + 4 * i];
+                    int px[20];
+#pragma unroll
+                    for (int i = 0; i < 20; i++) px[i] = byte_of(w5[i >> 2], i & 3);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int bS = (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15);
+                        edge_luma(e == 0 ? PL : PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS);
+                    }
+                    const unsigned l0 = pack4(px[0], px[1], px[2], px[3]);
+                    *(unsigned *)&tile[(k + 4) * D3_TS + 12] = l0;
+#pragma unroll
+                    for (int i = 1; i < 5; i++) *(unsigned *)&tile[(k + 4) * D3_TS + 12 + 4 * i] = pack4(px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]);
+                    if (k >= 12 && x > 0 && !last_row) ring[((x - 1) & 3) * 16 + (k - 12) * 4 + 3] = l0; // columns 12..15 of the previous macroblock's strip
+                } else {
+#if defined(D3_VARIANT) && (D3_VARIANT & 2)
+                    if (k < 8) {
+                        const int sh = 4 * (k >> 1);
+                        const edge_par PL = par_of(plab, pltc), PI = par_of(piab, pitc);
+                        unsigned w5[5];
+#pragma unroll
+                        for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 2) * D3_TS + 12 + 4 * i];
+                        int b[20];
+#pragma unroll
+                        for (int i = 0; i < 20; i++) b[i] = byte_of(w5[i >> 2], i & 3);
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2)
+#pragma unroll
+                            for (int c = 0; c < 2; c++) {
+                                const int bS = (int)(((e == 0 ? bvl : bvh) >> sh) & 15);
+                                edge_chroma(e == 0 ? PL : PI, b[4 * e + c], b[4 * e + 2 + c], b[4 * e + 4 + c], b[4 * e + 6 + c], bS);
+                            }
+#pragma unroll
+                        for (int i = 0; i < 5; i++) *(unsigned *)&tile[(k + 2) * D3_TS + 12 + 4 * i] = pack4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
+                    }
+#else
+                    const int kk = k & 7, c = k >> 3, sh = 4 * (kk >> 1);
+                    const edge_par PL = par_of(plab, pltc), PI = par_of(piab, pitc);
+                    uint8_t *b = &tile[(kk + 2) * D3_TS + 12 + c];
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) { // samples of plane c sit 2 bytes apart; q0 at byte 4 + 4e
+                        const int bS = (int)(((e == 0 ? bvl : bvh) >> sh) & 15);
+                        int p1 = b[4 * e], p0 = b[4 * e + 2], q0 = b[4 * e + 4], q1 = b[4 * e + 6];
+                        edge_chroma(e == 0 ? PL : PI, p1, p0, q0, q1, bS);
+                        b[4 * e + 2] = (uint8_t)p0; b[4 * e + 4] = (uint8_t)q0;
+                    }
+#endif
+                    WAVE_SYNC();
+                    if (k >= 6 && k < 8 && x > 0 && !last_row) ring[((x - 1) & 3) * 8 + (k - 6) * 4 + 3] = *(const unsigned *)&tile[(k + 2) * D3_TS + 12];
+                }
+            }
+        }
+        // ---- the strip of macroblock x-1 is final now: hand it to the band below
+        if (pub) {
+            WAVE_SYNC();
+            if (k < strip * 4)
+                st_sc1((unsigned *)(plane + (row0 + rows_mb - strip + (k >> 2)) * stride + (x - 1) * 16 + 4 * (k & 3)), ring[((x - 1) & 3) * ring_n + k]);
+        }
+        // ---- C. the one barrier of the step: every vertical edge of this step precedes every horizontal edge
+        BAND_BARRIER();
+        unsigned sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sb = 0;
+        uint4 sc = make_uint4(0, 0, 0, 0);
+        // ---- D. horizontal edges
+        if (act) {
+            if (my > 0 && k < strip * 4) *(unsigned *)&tile[(k >> 2) * D3_TS + 16 + 4 * (k & 3)] = fed ? stripv : ring_up[(x & 3) * ring_n + k];
+            WAVE_SYNC();
+#if defined(D3_VARIANT) && (D3_VARIANT & 4)
+            if ((bhl | bhh) && !chroma) {
+#else
+            if (bhl | bhh) {
+#endif
+                const int sh = 4 * (k >> 2);
+                const edge_par PT = par_of(ptab, pttc), PI = par_of(piab, pitc);
+                if (!chroma) {
+                    int px[20];
+#pragma unroll
+                    for (int i = 0; i < 20; i++) px[i] = tile[i * D3_TS + 16 + k];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int bS = (int)(((e < 2 ? bhl : bhh) >> (16 * (e & 1) + sh)) & 15);
+                        edge_luma(e == 0 ? PT : PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS);
+                    }
+#pragma unroll
+                    for (int i = 1; i < 19; i++) tile[i * D3_TS + 16 + k] = (uint8_t)px[i];
+                } else {
+                    int b[10];
+#pragma unroll
+                    for (int i = 0; i < 10; i++) b[i] = tile[i * D3_TS + 16 + k];
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int bS = (int)(((e == 0 ? bhl : bhh) >> sh) & 15);
+                        edge_chroma(e == 0 ? PT : PI, b[2 * e], b[2 * e + 1], b[2 * e + 2], b[2 * e + 3], bS);
+                    }
+#pragma unroll
+                    for (int i = 1; i < 9; i++) tile[i * D3_TS + 16 + k] = (uint8_t)b[i];
+                }
+            }
+            WAVE_SYNC();
+            // bottom strip -> ring (read by the row below after the next barrier)
+            if (!last_row && k < strip * 4) ring[(x & 3) * ring_n + k] = *(const unsigned *)&tile[(rows_mb + (k >> 2)) * D3_TS + 16 + 4 * (k & 3)];
+            // final samples into registers: row k, byte columns -4..11 (the left strip is final now), and the strip of the row above
+            if (k < rows_mb) {
+                unsigned *rp = (unsigned *)&tile[(k + strip) * D3_TS + 12];
+                sa0 = rp[0]; sa1 = rp[1]; sa2 = rp[2]; sa3 = rp[3]; sb = rp[4];
+                rp[0] = sb; // right strip becomes the next macroblock's left strip
+            }
+            if (my > 0 && k < strip) { const unsigned *tp = (const unsigned *)&tile[k * D3_TS + 16]; sc = make_uint4(tp[0], tp[1], tp[2], tp[3]); }
+        }
+        // ---- E. land the prefetch (issued a whole step ago) before this step's stores queue up behind it
+        if (pf || pub) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (pub && k == 0) st_sc1(prog_my, (unsigned)x);
+        if (pf) {
+            if (k < rows_mb) { unsigned *d = (unsigned *)&tile[(k + strip) * D3_TS + 16]; d[0] = own.x; d[1] = own.y; d[2] = own.z; d[3] = own.w; }
+            if (k >= 12) { unsigned *d = &recw[4 * (k - 12)]; d[0] = recv.x; d[1] = recv.y; d[2] = recv.z; d[3] = recv.w; }
+            stripv = strip_next; avail = avail_next;
+        }
+        // ---- F. stores (nobody inside this launch reads them back)
+        if (act) {
+            if (k < keep) {
+                uint8_t *dst = plane + (row0 + k) * stride + x0b;
+                if (x > 0) stg128u(dst - 4, sa0, sa1, sa2, sa3);
+                else { stg32(dst, sa1); stg32(dst + 4, sa2); stg32(dst + 8, sa3); }
+                if (x == mbw - 1) stg32(dst + 12, sb); // no right neighbour will patch columns 12..15
+            }
+            if (my > 0 && k < strip) stg128(plane + (row0 - strip + k) * stride + x0b, sc); // the strip of the row above is final after this top edge
+        }
+    }
+}
+
 // =================================================================== staging helper
 // Replicate the last visible column/row into the coded-size margin of a staged source surface.
 __global__ void pad_kernel(uint8_t *y, uint8_t *uv, int stride, int vw, int vh, int W, int H) {
@@ -1862,6 +2132,14 @@ void k_launch_deblock_band(const frame_ctx_t *d_ctx, int mbh, unsigned *d_progre
     hipLaunchKernelGGL(deblock_band_kernel, dim3(bands), dim3((2 * DB_R + 1) * 64), 0, s, a);
 }
 int k_deblock_bands(int mbh) { return (mbh + DB_R - 1) / DB_R; }
+int k_deblock_bands16(int mbh) { return (mbh + D3_ROWS - 1) / D3_ROWS; }
+// prep + 16-row bands; `d_progress` holds 2 * bands counters (luma, chroma) followed by the error word at d_err
+void k_launch_deblock_band16(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, unsigned *d_err, hipStream_t s) {
+    db_args a;
+    a.ctx = d_ctx; a.progress = d_progress; a.err = d_err;
+    hipLaunchKernelGGL(deblock_prep_kernel, dim3((mbw * mbh + 255) / 256), dim3(256), 0, s, d_ctx, d_progress, nprog);
+    hipLaunchKernelGGL(deblock_band16_kernel, dim3(k_deblock_bands16(mbh)), dim3(512), 0, s, a);
+}
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s) {
     int n = W * H + W * H / 2;
     hipLaunchKernelGGL(pad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, uv, stride, vis_w, vis_h, W, H);

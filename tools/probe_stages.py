@@ -6,7 +6,7 @@ import numpy as np
 from ceracoder_amd import enc as E, synth
 
 for (w, h) in ((1920, 64), (1920, 128), (1920, 256), (1920, 1088), (3840, 2160)):
-    for mode in (0, 1):
+    for mode in (0, 2):
         e = E.Encoder(w, h, gop=60, fixed_qp=int(os.environ.get("QP", "40")), deblock_mode=mode)
         fr = list(synth.s2_frames(w, h, 3))
         e.encode(*fr[0])
