@@ -4,7 +4,7 @@
 // Per picture, on one HIP stream:
 //   [H2D source] -> ctx upload -> IDR: intra wavefront (x+y diagonals)
 //                                 P  : me_kernel -> inter_kernel
-//                -> deblock wavefront (x+2y diagonals) -> D2H {mb records, levels} -> event
+//                -> deblock (prep + persistent band kernel) -> D2H {mb records, levels} -> event
 // and on the host, when the event has fired: CAVLC slice coding (h264_host.c).
 // With pipeline_depth = 1 the host codes picture n while the device works on n+1.
 #include "../../include/mi355enc.h"
@@ -58,7 +58,7 @@ struct mi355enc {
     hipStream_t cstream;                 // copy stream for the D2H hand-over
     uint64_t n_submitted;
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
-    uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock (deblock_mode 2)
+    uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
     unsigned *d_progress; // [2*bands] strip counters of the band deblocker, then one error word
     unsigned *h_err;      // pinned mirror of the error word
@@ -130,13 +130,9 @@ static int run_intra(mi355enc_t *h) {
     return 0;
 }
 static int run_deblock(mi355enc_t *h) {
-    if (h->cfg.deblock_mode == 2) {
+    if (h->cfg.deblock_mode == 0) { // prep kernel (also clears the progress counters) + persistent 16-row band kernel
         k_launch_deblock_band16(h->d_ctx, h->mbw, h->mbh, h->d_progress, h->n_progress + 1, h->d_progress + h->n_progress, h->stream);
         HIPCHK(hipGetLastError());
-        return 0;
-    } else if (h->cfg.deblock_mode == 0) {
-        HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(h->n_progress + 1) * sizeof(unsigned), h->stream));
-        k_launch_deblock_band(h->d_ctx, h->mbh, h->d_progress, h->d_progress + h->n_progress, h->stream);
         return 0;
     }
     if (h->cfg.use_graphs) {
@@ -198,7 +194,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     }
     HIPCHK(hipMalloc((void **)&h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t)));
     HIPCHK(hipMalloc((void **)&h->d_dbrec, (size_t)h->nmb * 64));
-    h->n_progress = k_deblock_bands(h->mbh) > 2 * k_deblock_bands16(h->mbh) ? k_deblock_bands(h->mbh) : 2 * k_deblock_bands16(h->mbh);
+    h->n_progress = 2 * k_deblock_bands16(h->mbh);
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void **)&h->h_err, sizeof(unsigned), hipHostMallocDefault));
     *h->h_err = 0;
@@ -317,7 +313,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
     HIPCHK(hipMemcpyAsync(s->h_mbi, h->d_mbi_set[set], (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->cstream));
     HIPCHK(hipMemcpyAsync(s->h_levels, h->d_levels_set[set], (size_t)h->nmb * MB_LEVELS * sizeof(int16_t), hipMemcpyDeviceToHost, h->cstream));
-    if (h->cfg.deblock_mode != 1) HIPCHK(hipMemcpyAsync(h->h_err, h->d_progress + h->n_progress, sizeof(unsigned), hipMemcpyDeviceToHost, h->cstream));
+    if (h->cfg.deblock_mode == 0) HIPCHK(hipMemcpyAsync(h->h_err, h->d_progress + h->n_progress, sizeof(unsigned), hipMemcpyDeviceToHost, h->cstream));
     if (prof) HIPCHK(hipEventRecord(s->ev[4], h->cstream));
     HIPCHK(hipEventRecord(s->done, h->cstream));
     h->n_submitted++;
@@ -428,7 +424,6 @@ int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
     case MI355ENC_FETCH_PREFILTER_UV: src = h->d_pre_uv; need = h->csz; break;
     case MI355ENC_FETCH_MBINFO: src = h->last_slot ? h->last_slot->h_mbi : nullptr; need = (size_t)h->nmb * sizeof(mb_info_t); host = true; break;
     case MI355ENC_FETCH_LEVELS: src = h->last_slot ? h->last_slot->h_levels : nullptr; need = (size_t)h->nmb * MB_LEVELS * 2; host = true; break;
-    case 100: src = h->d_dbrec; need = (size_t)h->nmb * 64; break; /* debug: deblocking records of the last mode-2 launch */
     default: return MI355ENC_ERR_ARG;
     }
     if (!src) return MI355ENC_ERR_STATE;

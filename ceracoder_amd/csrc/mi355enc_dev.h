@@ -61,8 +61,6 @@ void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
 void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
 void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
-void k_launch_deblock_band(const frame_ctx_t *d_ctx, int mbh, unsigned *d_progress, unsigned *d_err, hipStream_t s);
-int k_deblock_bands(int mbh);
 int k_deblock_bands16(int mbh);
 void k_launch_deblock_band16(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, unsigned *d_err, hipStream_t s);
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s);

@@ -1476,339 +1476,15 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
     }
 }
 
-// =================================================================== deblocking, persistent form
-// One kernel per picture instead of one launch per wavefront.  A workgroup owns a band of
-// DB_R macroblock rows: wave r < DB_R filters the LUMA of row band*DB_R + r, wave DB_R + r the
-// CHROMA of the same row (the two planes share nothing but the bS inputs).  All waves advance in
-// lock-step, one workgroup barrier per step; at step t row r handles macroblock x = t - 2r, which
-// is exactly the x + 2y wavefront, so the ordering argument of deblock_kernel carries over.
-// Hand-offs never touch global memory inside a band:
-//   left strip   (4 columns)  : stays in the wave's own LDS tile between steps
-//   bottom strip (4 rows)     : LDS ring of 4 macroblocks, written by row r, read by row r+1 two
-//                               steps later (after row r patched columns 13-15 at step t+1)
-// Between bands the bottom strips of the last row travel through global memory with `sc1`
-// (agent-scope, L1-bypassing) stores/loads and one monotonic progress counter per band and
-// plane (MI355X_MICROARCH.md, "Valid forms": all handed-off bytes stored sc1 by one wave,
-// `s_waitcnt vmcnt(0)`, then the sc1 counter store; consumer polls with sc1 loads and reads the
-// bytes with sc1 loads).  A band waits only on the band above it, so the wait graph is acyclic;
-// every spin is bounded and reports through ctx-independent `err`.
-#define DB_R 4
-static_assert(DB_R == 4, "the I/O wave maps lane>>4 to the band's rows");
-#define DB_TS 32 /* tile row stride; column c of the macroblock lives at byte 16 + c, the left strip at 12..15 */
+// ------------------------------------------------------------------ shared by the persistent band kernel
 #define DB_SPIN_MAX (1 << 20)
-
-struct db_luma_lds { uint8_t t[20 * DB_TS]; unsigned ring[4][16]; };   // rows -4..15
-struct db_chroma_lds { uint8_t t[10 * DB_TS]; unsigned ring[4][8]; };  // rows -2..7
-
 DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// filter parameters of one edge class (left / top / inner), looked up once per macroblock
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-DEV edge_par make_par(const dev_tables *T, int qpav) {
-    edge_par p;
-    p.alpha = T->alpha[qpav]; p.beta = T->beta[qpav];
-    p.tc0 = (unsigned)T->tc0[qpav][0] | ((unsigned)T->tc0[qpav][1] << 8) | ((unsigned)T->tc0[qpav][2] << 16);
-    return p;
-}
-DEV int tc0_of(const edge_par &P, int bS) { return (int)((P.tc0 >> (8 * (bS - 1))) & 0xFF); }
-// one luma line across an edge, samples in registers (8.7.2.3 / 8.7.2.4)
-DEV void edge_luma(const edge_par &P, int &p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int &q3, int bS) {
-    (void)p3; (void)q3;
-    const int alpha = P.alpha, beta = P.beta;
-    if (bS == 0 || !(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
-    const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
-    if (bS < 4) {
-        const int tc0 = tc0_of(P, bS);
-        const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
-        const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-        const int avg = (p0 + q0 + 1) >> 1;
-        const int np1 = ap ? p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) : p1;
-        const int nq1 = aq ? q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) : q1;
-        p0 = clip255(p0 + dl); q0 = clip255(q0 - dl); p1 = np1; q1 = nq1;
-    } else {
-        const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
-        int np0, np1 = p1, np2 = p2, nq0, nq1 = q1, nq2 = q2;
-        if (ap && small) {
-            np0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3; np1 = (p2 + p1 + p0 + q0 + 2) >> 2; np2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-        } else np0 = (2 * p1 + p0 + q1 + 2) >> 2;
-        if (aq && small) {
-            nq0 = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3; nq1 = (p0 + q0 + q1 + q2 + 2) >> 2; nq2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-        } else nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-        p0 = np0; p1 = np1; p2 = np2; q0 = nq0; q1 = nq1; q2 = nq2;
-    }
-}
-DEV void edge_chroma(const edge_par &P, int p1, int &p0, int &q0, int q1, int bS) {
-    if (bS == 0 || !(iabs(p0 - q0) < P.alpha && iabs(p1 - p0) < P.beta && iabs(q1 - q0) < P.beta)) return;
-    if (bS < 4) {
-        const int tc = tc0_of(P, bS) + 1;
-        const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-        p0 = clip255(p0 + dl); q0 = clip255(q0 - dl);
-    } else {
-        const int np0 = (2 * p1 + p0 + q1 + 2) >> 2, nq0 = (2 * q1 + q0 + p1 + 2) >> 2;
-        p0 = np0; q0 = nq0;
-    }
-}
-
 struct db_args { const frame_ctx_t *ctx; unsigned *progress; unsigned *err; };
 
-// wait until the band above has published the bottom strips of macroblocks 0..need-1
-DEV void db_wait(unsigned *progress, unsigned *err, int idx, int need) {
-    int spins = 0;
-    while ((int)ld_sc1(&progress[idx]) < need) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(err))) { st_sc1(err, 1u); break; } // bounded; once tripped, nobody waits again
-    }
-}
-
-// What the I/O wave stages in LDS for one macroblock row and one step.
-struct db_stage {
-    uint4 luma[16], chroma[8]; // the macroblock's unfiltered rows
-    uint4 cur, top;            // raw mb_info_t of the macroblock and of the one above it
-    uint4 strip_l[4], strip_c[2]; // bottom strip of the band above (first row of a band only)
-};
-
-// Work-group layout: waves 0..DB_R-1 filter LUMA of rows band*DB_R + r, waves DB_R..2*DB_R-1 the
-// CHROMA of the same rows, wave 2*DB_R is the I/O wave.  The compute waves touch global memory
-// only with fire-and-forget stores; every load (macroblock rows, records, strips of the band
-// above) is issued by the I/O wave two steps ahead and handed over through LDS, and the I/O
-// wave also publishes finished strips to the band below -- so all `s_waitcnt vmcnt` stalls sit
-// on a wave that has a whole step of slack, never on the dependency chain.
-__global__ __launch_bounds__((2 * DB_R + 1) * 64) void deblock_band_kernel(db_args a) {
-    __shared__ __attribute__((aligned(16))) db_luma_lds LL[DB_R];
-    __shared__ __attribute__((aligned(16))) db_chroma_lds CL[DB_R];
-    __shared__ __attribute__((aligned(16))) db_stage ST[2][DB_R];
-    __shared__ unsigned tabw[TAB_DWORDS];
-    const dev_tables *T = (const dev_tables *)tabw;
-    const frame_ctx_t *__restrict__ ctx = a.ctx;
-    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
-    const int band = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool io = wave == 2 * DB_R;
-    const bool chroma = !io && wave >= DB_R;
-    const int r = io ? 0 : (chroma ? wave - DB_R : wave);
-    for (int i = threadIdx.x; i < TAB_DWORDS; i += (2 * DB_R + 1) * 64) tabw[i] = ((const unsigned *)&g_tab)[i];
-    const int nsteps = mbw + 2 * (DB_R - 1); // compute steps; iteration j runs compute step j-2
-    const int niter = mbw + 2 * DB_R + 3;
-    const mb_info_t *__restrict__ mbi = ctx->mbi;
-
-    if (io) {
-        // ------------------------------------------------------------------ I/O wave
-        uint8_t *__restrict__ py = ctx->rec_y;
-        uint8_t *__restrict__ pc = ctx->rec_uv;
-        const int lr = lane >> 4, li = lane & 15;          // this lane serves row lr of the band, item li
-        const int my = band * DB_R + lr;
-        const bool row_ok = my < mbh;
-        const bool fed = row_ok && lr == 0 && band > 0;     // first row of a band: strips come from the band above
-        const int last_r = (mbh - 1 - band * DB_R) < (DB_R - 1) ? -1 : DB_R - 1; // feeding row, or -1 if this band holds the last row
-        const bool feeds = last_r >= 0 && (band * DB_R + last_r) != mbh - 1;
-        const size_t fy = (size_t)(band * DB_R + DB_R - 1) * 16 + 12, fc = (size_t)(band * DB_R + DB_R - 1) * 8 + 6; // strip rows of the feeding row
-        uint4 vA = make_uint4(0, 0, 0, 0), vB = make_uint4(0, 0, 0, 0);
-        bool haveA = false;
-        int flag_due = 0;
-        unsigned avail = 0;
-        for (int j = 0; j < niter; j++) {
-            BAND_BARRIER();
-            // (1) everything this wave issued one iteration ago has had a whole step to land
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (feeds && flag_due && lane == 0) st_sc1(&a.progress[band], (unsigned)flag_due);
-            // (2) hand the data loaded during iteration j-1 (for compute step j-1) over through LDS
-            if (haveA) {
-                db_stage *S = &ST[(j - 1) & 1][lr];
-                S->luma[li] = vA;
-                if (li < 8) S->chroma[li] = vB;
-                else if (li == 8) S->cur = vB;
-                else if (li == 9) S->top = vB;
-                else if (li < 14) S->strip_l[li - 10] = vB;
-                else S->strip_c[li - 14] = vB;
-            }
-            // (3) issue the loads for compute step j (runs at iteration j+2)
-            {
-                const int x = j - 2 * lr;
-                haveA = row_ok && x >= 0 && x < mbw && j < nsteps;
-                if (haveA) {
-                    // `avail` was read one iteration ago (landed under the vmcnt(0) above): in steady state no poll is needed here
-                    if (fed && (int)avail < x + 1) db_wait(a.progress, a.err, band - 1, x + 1);
-                    vA = ldg128(py + ((size_t)my * 16 + li) * stride + x * 16);
-                    if (li < 8) vB = ldg128(pc + ((size_t)my * 8 + li) * stride + x * 16);
-                    else if (li == 8) vB = ldg128(&mbi[my * mbw + x]);
-                    else if (li == 9) vB = my > 0 ? ldg128(&mbi[(my - 1) * mbw + x]) : make_uint4(0, 1u, 0, 0);
-                    else if (fed) {
-                        const uint8_t *sp = li < 14 ? py + ((size_t)my * 16 - 4 + (li - 10)) * stride + x * 16
-                                                    : pc + ((size_t)my * 8 - 2 + (li - 14)) * stride + x * 16;
-                        vB.x = ld_sc1((const unsigned *)sp); vB.y = ld_sc1((const unsigned *)sp + 1);
-                        vB.z = ld_sc1((const unsigned *)sp + 2); vB.w = ld_sc1((const unsigned *)sp + 3);
-                    }
-                }
-                if (fed) avail = ld_sc1(&a.progress[band - 1]); // for the next iteration; costs nothing here
-            }
-            // (4) publish the strip that became final when compute step j-3 finished: macroblock j - 2*DB_R - 2 of the feeding row
-            if (feeds) {
-                const int m = j - 2 * DB_R - 2;
-                if (m >= 0 && m < mbw) {
-                    if (lane < 16) st_sc1((unsigned *)(py + (fy + (lane >> 2)) * stride + m * 16 + 4 * (lane & 3)), LL[DB_R - 1].ring[m & 3][lane]);
-                    else if (lane < 24) st_sc1((unsigned *)(pc + (fc + ((lane - 16) >> 2)) * stride + m * 16 + 4 * (lane & 3)), CL[DB_R - 1].ring[m & 3][lane - 16]);
-                    flag_due = m + 1;
-                }
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- compute waves
-    const int my = band * DB_R + r;
-    const bool row_ok = my < mbh;
-    const bool last_row = my == mbh - 1;
-    const bool fed_by_prev = row_ok && r == 0 && band > 0;
-    uint8_t *__restrict__ plane = chroma ? ctx->rec_uv : ctx->rec_y;
-    const int rows_mb = chroma ? 8 : 16, strip = chroma ? 2 : 4; // rows per macroblock, rows per hand-off strip
-    const size_t row0 = (size_t)my * rows_mb;                     // first plane row of this macroblock row
-    uint8_t *tile = chroma ? CL[r].t : LL[r].t;
-    unsigned *ring = chroma ? &CL[r].ring[0][0] : &LL[r].ring[0][0];
-    const unsigned *ring_up = r > 0 ? (chroma ? &CL[r - 1].ring[0][0] : &LL[r - 1].ring[0][0]) : nullptr;
-    const int ring_n = chroma ? 8 : 16;                            // dwords per ring slot
-    mb_info_t cur, lft, upp;
-    cur.mb_type = lft.mb_type = upp.mb_type = 1; cur.qp = lft.qp = upp.qp = 0; cur.nzmask = lft.nzmask = upp.nzmask = 0;
-    cur.mvx = cur.mvy = lft.mvx = lft.mvy = upp.mvx = upp.mvy = 0;
-    for (int j = 0; j < niter; j++) {
-        const int t = j - 2, x = t - 2 * r;
-        const bool act = row_ok && t >= 0 && t < nsteps && x >= 0 && x < mbw;
-        BAND_BARRIER();
-        if (!act) continue;
-        const db_stage *S = &ST[t & 1][r];
-        lft = cur; cur = unpack_mbinfo(S->cur); upp = unpack_mbinfo(S->top);
-        const int x0b = x * 16; // byte offset of the macroblock in a plane row (luma: 16 px, chroma: 8 px x 2 planes)
-        // ---- (a) own rows into the tile
-        if (lane < rows_mb) *(uint4 *)&tile[(lane + strip) * DB_TS + 16] = chroma ? S->chroma[lane] : S->luma[lane];
-        // ---- (b) top strip: LDS ring of the row above, or the staged strip of the band above
-        if (my > 0 && lane < strip * 4) {
-            unsigned v;
-            if (fed_by_prev) v = chroma ? ((const unsigned *)S->strip_c)[lane] : ((const unsigned *)S->strip_l)[lane];
-            else v = ring_up[(x & 3) * ring_n + lane];
-            *(unsigned *)&tile[(lane >> 2) * DB_TS + 16 + 4 * (lane & 3)] = v;
-        }
-        // ---- boundary strengths of the whole macroblock at once: lane l < 32 owns (dir = l>>4, edge = (l>>2)&3, segment = l&3)
-        int bsv = 0;
-        if (lane < 32) {
-            const int dir = lane >> 4, e = (lane >> 2) & 3, sg = lane & 3;
-            if ((cur.nzmask & NZ_T8) && (e & 1)) bsv = 0; // 8x8 transform: luma edges 1 and 3 are not block edges
-            else if (dir == 0) { if (!(e == 0 && x == 0)) bsv = bs_of(e == 0 ? lft : cur, e == 0 ? 3 : e - 1, sg, cur, e, sg, e == 0); }
-            else if (!(e == 0 && my == 0)) bsv = bs_of(e == 0 ? upp : cur, sg, e == 0 ? 3 : e - 1, cur, sg, e, e == 0);
-        }
-        const unsigned long long bm = __ballot(bsv != 0) & (chroma ? 0x0F0F0F0Full : 0xFFFFFFFFull); // chroma filters edges 0 and 2 only
-        const bool anyV = (bm & 0xFFFFull) != 0, anyH = (bm >> 16) != 0; // wave-uniform
-        // this lane's strengths for both passes (luma: line k -> segment k>>2; chroma rows: k>>1, chroma byte columns: j>>2)
-        const int segV = chroma ? (lane >> 1) & 3 : (lane >> 2) & 3, segH = (lane >> 2) & 3;
-        int bsV[4], bsH[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) { bsV[e] = __shfl(bsv, e * 4 + segV); bsH[e] = __shfl(bsv, 16 + e * 4 + segH); }
-        WAVE_SYNC();
-        if (!chroma) {
-            const edge_par PI = make_par(T, cur.qp);
-            // ---- (e) vertical edges: lane k < 16 owns picture row k of the macroblock
-            if (anyV && lane < 16) {
-                const int k = lane;
-                const edge_par PL = make_par(T, clip3(0, 51, (lft.qp + cur.qp + 1) >> 1));
-                unsigned w5[5];
-#pragma unroll
-                for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 4) * DB_TS + 12 + 4 * i];
-                int px[20];
-#pragma unroll
-                for (int i = 0; i < 20; i++) px[i] = byte_of(w5[i >> 2], i & 3);
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    edge_luma(e == 0 ? PL : PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6],
-                              px[4 * e + 7], bsV[e]);
-#pragma unroll
-                for (int i = 0; i < 5; i++)
-                    *(unsigned *)&tile[(k + 4) * DB_TS + 12 + 4 * i] = pack4(px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]);
-            }
-            WAVE_SYNC();
-            // ---- (g) horizontal edges: lane k < 16 owns picture column k
-            if (anyH && lane < 16) {
-                const int k = lane;
-                const edge_par PT = make_par(T, clip3(0, 51, (upp.qp + cur.qp + 1) >> 1));
-                int px[20];
-#pragma unroll
-                for (int i = 0; i < 20; i++) px[i] = tile[i * DB_TS + 16 + k];
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    edge_luma(e == 0 ? PT : PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6],
-                              px[4 * e + 7], bsH[e]);
-#pragma unroll
-                for (int i = 1; i < 19; i++) tile[i * DB_TS + 16 + k] = (uint8_t)px[i];
-            }
-        } else {
-            const int qc = T->qpc[cur.qp];
-            const edge_par PI = make_par(T, qc);
-            // ---- vertical edges: lane k < 8 owns chroma row k (both planes, interleaved bytes)
-            if (anyV && lane < 8) {
-                const int k = lane;
-                const edge_par PL = make_par(T, (T->qpc[lft.qp] + qc + 1) >> 1);
-                unsigned w5[5];
-#pragma unroll
-                for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 2) * DB_TS + 12 + 4 * i];
-                int b[20];
-#pragma unroll
-                for (int i = 0; i < 20; i++) b[i] = byte_of(w5[i >> 2], i & 3);
-#pragma unroll
-                for (int e = 0; e < 4; e += 2)
-#pragma unroll
-                    for (int c = 0; c < 2; c++) // q0 of plane c sits at byte 4 + 4e + c; neighbours 2 bytes apart
-                        edge_chroma(e == 0 ? PL : PI, b[4 * e + c], b[4 * e + 2 + c], b[4 * e + 4 + c], b[4 * e + 6 + c], bsV[e]);
-#pragma unroll
-                for (int i = 0; i < 5; i++)
-                    *(unsigned *)&tile[(k + 2) * DB_TS + 12 + 4 * i] = pack4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
-            }
-            WAVE_SYNC();
-            // ---- horizontal edges: lane j < 16 owns byte column j (8 samples x 2 planes)
-            if (anyH && lane < 16) {
-                const int jc = lane;
-                const edge_par PT = make_par(T, (T->qpc[upp.qp] + qc + 1) >> 1);
-                int b[10];
-#pragma unroll
-                for (int i = 0; i < 10; i++) b[i] = tile[i * DB_TS + 16 + jc];
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) edge_chroma(e == 0 ? PT : PI, b[2 * e], b[2 * e + 1], b[2 * e + 2], b[2 * e + 3], bsH[e]);
-#pragma unroll
-                for (int i = 1; i < 9; i++) tile[i * DB_TS + 16 + jc] = (uint8_t)b[i];
-            }
-        }
-        WAVE_SYNC();
-        // ---- (i) final samples leave for global memory (plain stores; nobody inside this launch reads them back)
-        {
-            const int keep = last_row ? rows_mb : rows_mb - strip; // rows below go through the ring instead
-            // region A: rows 0..keep-1, byte columns -4..11 (dword 0 is the left strip, final now)
-            if (lane < 4 * rows_mb) {
-                const int rr = lane >> 2, q = lane & 3;
-                if (rr < keep && !(q == 0 && x == 0))
-                    stg32(plane + (row0 + rr) * stride + x0b - 4 + 4 * q, *(const unsigned *)&tile[(rr + strip) * DB_TS + 12 + 4 * q]);
-            }
-            // region B: last macroblock of the row: columns 12..15 have no right neighbour to wait for
-            if (x == mbw - 1 && lane < keep)
-                stg32(plane + (row0 + lane) * stride + x0b + 12, *(const unsigned *)&tile[(lane + strip) * DB_TS + 28]);
-            // region C: the strip of the row above is final after this macroblock's top edge
-            if (my > 0 && lane < strip * 4) {
-                const int sr = lane >> 2, q = lane & 3;
-                stg32(plane + (row0 - strip + sr) * stride + x0b + 4 * q, *(const unsigned *)&tile[sr * DB_TS + 16 + 4 * q]);
-            }
-        }
-        // ---- (j) bottom strip -> ring (and patch columns 12..15 of the previous macroblock's strip)
-        if (!last_row) {
-            if (lane < strip * 4) {
-                const int sr = lane >> 2, q = lane & 3;
-                ring[(x & 3) * ring_n + lane] = *(const unsigned *)&tile[(rows_mb + sr) * DB_TS + 16 + 4 * q];
-            } else if (lane < strip * 5 && x > 0) {
-                const int sr = lane - strip * 4;
-                ring[((x - 1) & 3) * ring_n + sr * 4 + 3] = *(const unsigned *)&tile[(rows_mb + sr) * DB_TS + 12];
-            }
-        }
-        // ---- (k) right strip becomes the next macroblock's left strip
-        if (lane < rows_mb) *(unsigned *)&tile[(lane + strip) * DB_TS + 12] = *(const unsigned *)&tile[(lane + strip) * DB_TS + 28];
-    }
-}
-
-// =================================================================== deblocking, 16-row bands in x + y order
-// Third form of the same filter.  Two observations shorten the dependency chain further:
+// =================================================================== deblocking, persistent: 16-row bands in x + y order
+// One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
 //  (1) Boundary strengths and the alpha/beta/tc0 triples depend only on the macroblock records,
 //      so a flat kernel (deblock_prep_kernel) computes them for the whole picture up front:
 //      64 bytes per macroblock {bS nibbles V/H, six packed parameter pairs}.
@@ -1821,7 +1497,11 @@ __global__ __launch_bounds__((2 * DB_R + 1) * 64) void deblock_band_kernel(db_ar
 //      reproduces the raster-order result (mbw + mbh - 1 steps instead of mbw + 2(mbh - 1)).
 // A wave serves four macroblock rows (16 lanes each: one lane per picture line / column), so a
 // workgroup of 4 luma + 4 chroma waves owns a band of 16 rows and only every 16th row boundary
-// crosses global memory (sc1 strips + progress counter, as in deblock_band_kernel).  Each lane
+// crosses global memory: the bottom strip of a band's last row is stored with `sc1` (agent scope,
+// L1-bypassing) stores, `s_waitcnt vmcnt(0)`, then an sc1 store of a monotonic progress counter per band and
+// plane; the band below polls the counter with sc1 loads and reads the strip with sc1 loads
+// (MI355X_MICROARCH.md, "Valid forms").  A band waits only on the band above it, so the wait graph is
+// acyclic; every spin is bounded and reports through `err`.  Each lane
 // group prefetches its next macroblock one step ahead into registers and lands it in LDS after
 // the step's arithmetic, immediately before the step's own stores are issued, so the only
 // `s_waitcnt vmcnt(0)` on the chain waits for loads that have had a whole step to arrive.
@@ -1886,40 +1566,94 @@ DEV int db_wait_get(unsigned *progress, unsigned *err, int need) {
     return v;
 }
 
-__global__ __launch_bounds__(512) void deblock_band16_kernel(db_args a) {
-    __shared__ __attribute__((aligned(16))) d3_luma LL[D3_ROWS];
-    __shared__ __attribute__((aligned(16))) d3_chroma CL[D3_ROWS];
+// Branch-free forms of the edge filters (8.7.2.3 / 8.7.2.4): every lane computes both candidates and
+// selects, so a step costs the same few dozen VALU instructions whatever the lanes decide -- the
+// early-outs of edge_luma() only pay when a whole wave agrees, which the uniform `any4` / ballot
+// tests outside keep.  Samples are 0..255, so |a - b| is one v_sad_u8.
+DEV int adiff(int a, int b) { return (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)b, 0u); }
+template <bool MBEDGE>
+DEV void edge_luma2(const edge_par &P, int p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int q3, int bS, bool any4) {
+    const int alpha = P.alpha, beta = P.beta;
+    const int d = adiff(p0, q0);
+    const bool f = (bS != 0) & (d < alpha) & (adiff(p1, p0) < beta) & (adiff(q1, q0) < beta);
+    const bool ap = adiff(p2, p0) < beta, aq = adiff(q2, q0) < beta;
+    const int tc0 = (int)((P.tc0 >> (8 * ((bS - 1) & 3))) & 0xFF); // bS 0 or 4 read a don't-care byte
+    const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+    const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    const int avg = (p0 + q0 + 1) >> 1;
+    int np1 = p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1);
+    int nq1 = q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
+    int np0 = clip255(p0 + dl), nq0 = clip255(q0 - dl);
+    int np2 = p2, nq2 = q2;
+    bool wp1 = ap, wq1 = aq;
+    if (MBEDGE && any4) { // bS 4 exists only on macroblock edges, and only if some lane of the wave is intra
+        const bool s4 = bS == 4, small = d < ((alpha >> 2) + 2);
+        const bool sp = ap & small, sq = aq & small;
+        const int sp0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
+        const int sq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+        const int sp1 = (p2 + p1 + p0 + q0 + 2) >> 2, sp2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+        const int sq1 = (p0 + q0 + q1 + q2 + 2) >> 2, sq2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+        np0 = s4 ? sp0 : np0; nq0 = s4 ? sq0 : nq0; np1 = s4 ? sp1 : np1; nq1 = s4 ? sq1 : nq1;
+        wp1 = s4 ? sp : ap; wq1 = s4 ? sq : aq;
+        np2 = (s4 & sp) ? sp2 : p2; nq2 = (s4 & sq) ? sq2 : q2;
+    }
+    p0 = f ? np0 : p0; q0 = f ? nq0 : q0;
+    p1 = (f & wp1) ? np1 : p1; q1 = (f & wq1) ? nq1 : q1;
+    p2 = f ? np2 : p2; q2 = f ? nq2 : q2;
+}
+DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int bS) {
+    const bool f = (bS != 0) & (adiff(p0, q0) < P.alpha) & (adiff(p1, p0) < P.beta) & (adiff(q1, q0) < P.beta);
+    const int tc = (int)((P.tc0 >> (8 * ((bS - 1) & 3))) & 0xFF) + 1;
+    const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    const bool s4 = bS == 4;
+    const int np0 = s4 ? (2 * p1 + p0 + q1 + 2) >> 2 : clip255(p0 + dl);
+    const int nq0 = s4 ? (2 * q1 + q0 + p1 + 2) >> 2 : clip255(q0 - dl);
+    p0 = f ? np0 : p0; q0 = f ? nq0 : q0;
+}
+
+// One workgroup = one band of 16 macroblock rows of ONE plane (blocks [0, nb): luma, [nb, 2nb):
+// chroma -- the planes share nothing but the records, and on separate CUs neither steals issue
+// slots from the other's dependency chain).  4 waves, one per SIMD; a wave serves four rows, 16
+// lanes each.
+template <bool CHROMA>
+DEV void band16_body(const db_args a, const int band, const int nb, uint8_t *lds) {
+    constexpr int rows_mb = CHROMA ? 8 : 16, strip = CHROMA ? 2 : 4, ring_n = CHROMA ? 8 : 16;
+    constexpr int ROW_LDS = CHROMA ? (int)sizeof(d3_chroma) : (int)sizeof(d3_luma);
     const frame_ctx_t *__restrict__ ctx = a.ctx;
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
-    const int band = blockIdx.x, nb = gridDim.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool chroma = wave >= 4;
-    const int g = lane >> 4, k = lane & 15, r = 4 * (wave & 3) + g, my = band * D3_ROWS + r;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, k = lane & 15, r = 4 * wave + g, my = band * D3_ROWS + r;
     const bool row_ok = my < mbh, last_row = my == mbh - 1;
     const bool fed = row_ok && r == 0 && band > 0;
     const bool feeds = row_ok && r == D3_ROWS - 1 && !last_row;
-    unsigned *prog_up = a.progress + (chroma ? nb : 0) + (band > 0 ? band - 1 : 0), *prog_my = a.progress + (chroma ? nb : 0) + band;
-    const int rows_mb = chroma ? 8 : 16, strip = chroma ? 2 : 4, ring_n = chroma ? 8 : 16;
-    uint8_t *__restrict__ plane = chroma ? ctx->rec_uv : ctx->rec_y;
+    unsigned *prog_up = a.progress + (CHROMA ? nb : 0) + (band > 0 ? band - 1 : 0), *prog_my = a.progress + (CHROMA ? nb : 0) + band;
+    uint8_t *__restrict__ plane = CHROMA ? ctx->rec_uv : ctx->rec_y;
     const uint8_t *__restrict__ dbrec = ctx->dbrec;
     const size_t row0 = (size_t)my * rows_mb;
-    uint8_t *tile = chroma ? CL[r].t : LL[r].t;
-    unsigned *ring = chroma ? &CL[r].ring[0][0] : &LL[r].ring[0][0];
-    const unsigned *ring_up = chroma ? &CL[r > 0 ? r - 1 : 0].ring[0][0] : &LL[r > 0 ? r - 1 : 0].ring[0][0];
-    unsigned *recw = chroma ? CL[r].rec : LL[r].rec;
+    uint8_t *tile = lds + r * ROW_LDS;                                     // d3_luma / d3_chroma of this row: t, ring, rec
+    unsigned *ring = (unsigned *)(tile + (CHROMA ? 10 : 20) * D3_TS);
+    unsigned *recw = ring + 4 * ring_n;
+    const unsigned *ring_up = (const unsigned *)(lds + (r > 0 ? r - 1 : 0) * ROW_LDS + (CHROMA ? 10 : 20) * D3_TS);
     const int keep = last_row ? rows_mb : rows_mb - strip; // rows stored by this row itself; the strip below goes through the ring
     uint4 own = make_uint4(0, 0, 0, 0), recv = make_uint4(0, 0, 0, 0);
     unsigned stripv = 0, strip_next = 0;
     int avail = 0, avail_next = 0;
     const int nsteps = mbw + D3_ROWS + 2;
+#ifdef D3_PROF
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0, tm1;
+#define D3_TICK(i) do { tm1 = __builtin_readcyclecounter(); pc[i] += tm1 - tm0; tm0 = tm1; } while (0)
+#else
+#define D3_TICK(i) do { } while (0)
+#endif
     for (int t = 0; t < nsteps; t++) {
         const int x = t - 1 - r, xn = x + 1;
-#if defined(D3_VARIANT) && (D3_VARIANT & 1)
-        BAND_BARRIER();
-#endif
         const bool act = row_ok && x >= 0 && x < mbw;
         const bool pf = row_ok && xn >= 0 && xn < mbw;
         const bool pub = feeds && x >= 1 && x <= mbw;         // strip of macroblock x-1 becomes final in this step's vertical phase
         const int x0b = x * 16;
+#ifdef D3_PROF
+        tm0 = __builtin_readcyclecounter();
+#endif
         // ---- A. prefetch macroblock x+1 (rows, record, strip of the band above)
         if (pf) {
             if (fed) {
@@ -1930,71 +1664,49 @@ __global__ __launch_bounds__(512) void deblock_band16_kernel(db_args a) {
             if (k < rows_mb) own = ldg128(plane + (row0 + k) * stride + xn * 16);
             if (k >= 12) recv = ldg128(dbrec + ((size_t)my * mbw + xn) * DBREC_BYTES + 16 * (k - 12));
         }
-        unsigned bhl = 0, bhh = 0, ptab = 0, pttc = 0, piab = 0, pitc = 0;
-        // ---- B. vertical edges
-        if (act) {
-            const unsigned bvl = recw[0], bvh = recw[1];
-            bhl = recw[2]; bhh = recw[3];
-            const int o = chroma ? 10 : 4;
-            const unsigned plab = recw[o], pltc = recw[o + 1];
-            ptab = recw[o + 2]; pttc = recw[o + 3]; piab = recw[o + 4]; pitc = recw[o + 5];
-#if defined(D3_VARIANT) && (D3_VARIANT & 8)
-            if ((bvl | bvh) && !chroma) {
-#else
-            if (bvl | bvh) {
-#endif
-                if (!chroma) {
-                    const int sh = 4 * (k >> 2);
-                    const edge_par PL = par_of(plab, pltc), PI = par_of(piab, pitc);
-                    unsigned w5[5];
+        D3_TICK(0);
+        // ---- B. vertical edges.  All LDS reads of the phase are issued together (one round trip).
+        const unsigned bvl = act ? recw[0] : 0u, bvh = act ? recw[1] : 0u, bhl = act ? recw[2] : 0u, bhh = act ? recw[3] : 0u;
+        constexpr int o = CHROMA ? 10 : 4;
+        const edge_par PL = par_of(recw[o], recw[o + 1]), PT = par_of(recw[o + 2], recw[o + 3]), PI = par_of(recw[o + 4], recw[o + 5]);
+        if (!CHROMA) {
+            unsigned w5[5];
 #pragma unroll
-                    for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 4) * D3_TS + 12 + 4 * i];
-                    int px[20];
+            for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 4) * D3_TS + 12 + 4 * i];
+            if (__ballot((bvl | bvh) != 0)) {
+                const int sh = 4 * (k >> 2);
+                int px[20];
 #pragma unroll
-                    for (int i = 0; i < 20; i++) px[i] = byte_of(w5[i >> 2], i & 3);
+                for (int i = 0; i < 20; i++) px[i] = byte_of(w5[i >> 2], i & 3);
+                {
+                    const int bS = (int)((bvl >> sh) & 15);
+                    const unsigned long long nz = __ballot(bS != 0);
+                    if (nz) edge_luma2<true>(PL, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], bS, __ballot(bS == 4) != 0);
+                }
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int bS = (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15);
-                        edge_luma(e == 0 ? PL : PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS);
-                    }
+                for (int e = 1; e < 4; e++) {
+                    const int bS = (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15);
+                    if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
+                }
+                if (act) {
                     const unsigned l0 = pack4(px[0], px[1], px[2], px[3]);
                     *(unsigned *)&tile[(k + 4) * D3_TS + 12] = l0;
 #pragma unroll
                     for (int i = 1; i < 5; i++) *(unsigned *)&tile[(k + 4) * D3_TS + 12 + 4 * i] = pack4(px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]);
                     if (k >= 12 && x > 0 && !last_row) ring[((x - 1) & 3) * 16 + (k - 12) * 4 + 3] = l0; // columns 12..15 of the previous macroblock's strip
-                } else {
-#if defined(D3_VARIANT) && (D3_VARIANT & 2)
-                    if (k < 8) {
-                        const int sh = 4 * (k >> 1);
-                        const edge_par PL = par_of(plab, pltc), PI = par_of(piab, pitc);
-                        unsigned w5[5];
+                }
+            }
+        } else {
+            const int kk = k & 7, c = k >> 3, sh = 4 * (kk >> 1);
+            uint8_t *b = &tile[(kk + 2) * D3_TS + 12 + c]; // samples of plane c sit 2 bytes apart; q0 of edge e at byte 4 + 4e
+            int s[8];
 #pragma unroll
-                        for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 2) * D3_TS + 12 + 4 * i];
-                        int b[20];
-#pragma unroll
-                        for (int i = 0; i < 20; i++) b[i] = byte_of(w5[i >> 2], i & 3);
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2)
-#pragma unroll
-                            for (int c = 0; c < 2; c++) {
-                                const int bS = (int)(((e == 0 ? bvl : bvh) >> sh) & 15);
-                                edge_chroma(e == 0 ? PL : PI, b[4 * e + c], b[4 * e + 2 + c], b[4 * e + 4 + c], b[4 * e + 6 + c], bS);
-                            }
-#pragma unroll
-                        for (int i = 0; i < 5; i++) *(unsigned *)&tile[(k + 2) * D3_TS + 12 + 4 * i] = pack4(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]);
-                    }
-#else
-                    const int kk = k & 7, c = k >> 3, sh = 4 * (kk >> 1);
-                    const edge_par PL = par_of(plab, pltc), PI = par_of(piab, pitc);
-                    uint8_t *b = &tile[(kk + 2) * D3_TS + 12 + c];
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) { // samples of plane c sit 2 bytes apart; q0 at byte 4 + 4e
-                        const int bS = (int)(((e == 0 ? bvl : bvh) >> sh) & 15);
-                        int p1 = b[4 * e], p0 = b[4 * e + 2], q0 = b[4 * e + 4], q1 = b[4 * e + 6];
-                        edge_chroma(e == 0 ? PL : PI, p1, p0, q0, q1, bS);
-                        b[4 * e + 2] = (uint8_t)p0; b[4 * e + 4] = (uint8_t)q0;
-                    }
-#endif
+            for (int i = 0; i < 8; i++) s[i] = b[2 * i];
+            if (__ballot((bvl | bvh) != 0)) {
+                edge_chroma2(PL, s[0], s[1], s[2], s[3], (int)((bvl >> sh) & 15));
+                edge_chroma2(PI, s[4], s[5], s[6], s[7], (int)((bvh >> sh) & 15));
+                if (act) {
+                    b[2] = (uint8_t)s[1]; b[4] = (uint8_t)s[2]; b[10] = (uint8_t)s[5]; b[12] = (uint8_t)s[6];
                     WAVE_SYNC();
                     if (k >= 6 && k < 8 && x > 0 && !last_row) ring[((x - 1) & 3) * 8 + (k - 6) * 4 + 3] = *(const unsigned *)&tile[(k + 2) * D3_TS + 12];
                 }
@@ -2006,46 +1718,50 @@ __global__ __launch_bounds__(512) void deblock_band16_kernel(db_args a) {
             if (k < strip * 4)
                 st_sc1((unsigned *)(plane + (row0 + rows_mb - strip + (k >> 2)) * stride + (x - 1) * 16 + 4 * (k & 3)), ring[((x - 1) & 3) * ring_n + k]);
         }
+        D3_TICK(1);
         // ---- C. the one barrier of the step: every vertical edge of this step precedes every horizontal edge
         BAND_BARRIER();
+        D3_TICK(2);
         unsigned sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sb = 0;
         uint4 sc = make_uint4(0, 0, 0, 0);
         // ---- D. horizontal edges
-        if (act) {
-            if (my > 0 && k < strip * 4) *(unsigned *)&tile[(k >> 2) * D3_TS + 16 + 4 * (k & 3)] = fed ? stripv : ring_up[(x & 3) * ring_n + k];
-            WAVE_SYNC();
-#if defined(D3_VARIANT) && (D3_VARIANT & 4)
-            if ((bhl | bhh) && !chroma) {
-#else
-            if (bhl | bhh) {
-#endif
-                const int sh = 4 * (k >> 2);
-                const edge_par PT = par_of(ptab, pttc), PI = par_of(piab, pitc);
-                if (!chroma) {
-                    int px[20];
+        if (act && my > 0 && k < strip * 4) *(unsigned *)&tile[(k >> 2) * D3_TS + 16 + 4 * (k & 3)] = fed ? stripv : ring_up[(x & 3) * ring_n + k];
+        WAVE_SYNC();
+        {
+            const int sh = 4 * (k >> 2);
+            if (!CHROMA) {
+                int px[20];
 #pragma unroll
-                    for (int i = 0; i < 20; i++) px[i] = tile[i * D3_TS + 16 + k];
+                for (int i = 0; i < 20; i++) px[i] = tile[i * D3_TS + 16 + k];
+                if (__ballot((bhl | bhh) != 0)) {
+                    {
+                        const int bS = (int)((bhl >> sh) & 15);
+                        if (__ballot(bS != 0)) edge_luma2<true>(PT, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], bS, __ballot(bS == 4) != 0);
+                    }
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
+                    for (int e = 1; e < 4; e++) {
                         const int bS = (int)(((e < 2 ? bhl : bhh) >> (16 * (e & 1) + sh)) & 15);
-                        edge_luma(e == 0 ? PT : PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS);
+                        if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
                     }
+                    if (act) {
 #pragma unroll
-                    for (int i = 1; i < 19; i++) tile[i * D3_TS + 16 + k] = (uint8_t)px[i];
-                } else {
-                    int b[10];
-#pragma unroll
-                    for (int i = 0; i < 10; i++) b[i] = tile[i * D3_TS + 16 + k];
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        const int bS = (int)(((e == 0 ? bhl : bhh) >> sh) & 15);
-                        edge_chroma(e == 0 ? PT : PI, b[2 * e], b[2 * e + 1], b[2 * e + 2], b[2 * e + 3], bS);
+                        for (int i = 1; i < 19; i++) tile[i * D3_TS + 16 + k] = (uint8_t)px[i];
                     }
+                }
+            } else {
+                int b[8];
 #pragma unroll
-                    for (int i = 1; i < 9; i++) tile[i * D3_TS + 16 + k] = (uint8_t)b[i];
+                for (int i = 0; i < 8; i++) b[i] = tile[i * D3_TS + 16 + k];
+                if (__ballot((bhl | bhh) != 0)) {
+                    edge_chroma2(PT, b[0], b[1], b[2], b[3], (int)((bhl >> sh) & 15));
+                    edge_chroma2(PI, b[4], b[5], b[6], b[7], (int)((bhh >> sh) & 15));
+                    if (act) { tile[1 * D3_TS + 16 + k] = (uint8_t)b[1]; tile[2 * D3_TS + 16 + k] = (uint8_t)b[2]; tile[5 * D3_TS + 16 + k] = (uint8_t)b[5]; tile[6 * D3_TS + 16 + k] = (uint8_t)b[6]; }
                 }
             }
-            WAVE_SYNC();
+        }
+        WAVE_SYNC();
+        D3_TICK(3);
+        if (act) {
             // bottom strip -> ring (read by the row below after the next barrier)
             if (!last_row && k < strip * 4) ring[(x & 3) * ring_n + k] = *(const unsigned *)&tile[(rows_mb + (k >> 2)) * D3_TS + 16 + 4 * (k & 3)];
             // final samples into registers: row k, byte columns -4..11 (the left strip is final now), and the strip of the row above
@@ -2056,8 +1772,14 @@ __global__ __launch_bounds__(512) void deblock_band16_kernel(db_args a) {
             }
             if (my > 0 && k < strip) { const unsigned *tp = (const unsigned *)&tile[k * D3_TS + 16]; sc = make_uint4(tp[0], tp[1], tp[2], tp[3]); }
         }
+        D3_TICK(4);
         // ---- E. land the prefetch (issued a whole step ago) before this step's stores queue up behind it
-        if (pf || pub) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Unconditional, and the prefetched registers are "used" right here in uniform control flow: the compiler's
+        // wait-count bookkeeping then knows that no load into them is pending when the stores below are issued.  Without
+        // this it re-waits vmcnt(0) at the top of the next step (before overwriting them) -- i.e. for those stores.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(own.x), "v"(own.y), "v"(own.z), "v"(own.w), "v"(recv.x), "v"(recv.y), "v"(recv.z), "v"(recv.w), "v"(strip_next), "v"(avail_next));
+        D3_TICK(5);
         if (pub && k == 0) st_sc1(prog_my, (unsigned)x);
         if (pf) {
             if (k < rows_mb) { unsigned *d = (unsigned *)&tile[(k + strip) * D3_TS + 16]; d[0] = own.x; d[1] = own.y; d[2] = own.z; d[3] = own.w; }
@@ -2074,7 +1796,21 @@ __global__ __launch_bounds__(512) void deblock_band16_kernel(db_args a) {
             }
             if (my > 0 && k < strip) stg128(plane + (row0 - strip + k) * stride + x0b, sc); // the strip of the row above is final after this top edge
         }
+        D3_TICK(6);
     }
+#ifdef D3_PROF
+    if (lane == 0 && (wave == 0 || wave == 3) && band < 2) {
+        unsigned *o = (unsigned *)(ctx->dbrec) + (((CHROMA ? 2 : 0) + band) * 2 + (wave ? 1 : 0)) * 8; // debug build only: overwrites the first records after use
+        for (int i = 0; i < 8; i++) o[i] = (unsigned)(pc[i] >> 0);
+    }
+#endif
+}
+
+__global__ __launch_bounds__(256) void deblock_band16_kernel(db_args a) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[D3_ROWS * sizeof(d3_luma)];
+    const int nb = gridDim.x >> 1;
+    if ((int)blockIdx.x < nb) band16_body<false>(a, blockIdx.x, nb, lds);
+    else band16_body<true>(a, blockIdx.x - nb, nb, lds);
 }
 
 // =================================================================== staging helper
@@ -2125,20 +1861,13 @@ void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag,
     if (y_hi < y_lo) return;
     hipLaunchKernelGGL(deblock_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
 }
-void k_launch_deblock_band(const frame_ctx_t *d_ctx, int mbh, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
-    int bands = (mbh + DB_R - 1) / DB_R;
-    db_args a;
-    a.ctx = d_ctx; a.progress = d_progress; a.err = d_err;
-    hipLaunchKernelGGL(deblock_band_kernel, dim3(bands), dim3((2 * DB_R + 1) * 64), 0, s, a);
-}
-int k_deblock_bands(int mbh) { return (mbh + DB_R - 1) / DB_R; }
 int k_deblock_bands16(int mbh) { return (mbh + D3_ROWS - 1) / D3_ROWS; }
 // prep + 16-row bands; `d_progress` holds 2 * bands counters (luma, chroma) followed by the error word at d_err
 void k_launch_deblock_band16(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, unsigned *d_err, hipStream_t s) {
     db_args a;
     a.ctx = d_ctx; a.progress = d_progress; a.err = d_err;
     hipLaunchKernelGGL(deblock_prep_kernel, dim3((mbw * mbh + 255) / 256), dim3(256), 0, s, d_ctx, d_progress, nprog);
-    hipLaunchKernelGGL(deblock_band16_kernel, dim3(k_deblock_bands16(mbh)), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(deblock_band16_kernel, dim3(2 * k_deblock_bands16(mbh)), dim3(256), 0, s, a);
 }
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s) {
     int n = W * H + W * H / 2;

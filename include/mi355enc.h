@@ -57,8 +57,8 @@ typedef struct {
     int transform8x8;         /* 1: High-profile stream, P macroblocks use the 8x8 transform; 0 (default): Constrained Baseline */
     int i4x4;                 /* 1 (default): try Intra_4x4 besides Intra_16x16 in I pictures */
     int subpel;               /* 1 (default): half- then quarter-sample refinement after the integer search */
-    int deblock_mode;         /* 0: persistent band-wavefront kernel (one launch per picture);
-                                 1: one launch per x+2y wavefront (reference implementation) */
+    int deblock_mode;         /* 0: boundary-strength prep kernel + persistent 16-row band kernel (x+y order);
+                                 1: one launch per x+2y wavefront (plain form, kept as a cross-check) */
 } mi355enc_cfg_t;
 
 typedef struct {

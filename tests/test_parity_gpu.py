@@ -114,11 +114,11 @@ def test_intra_kernel_matches_oracle(E, oracle, w, h, qp, i4):
 
 @pytest.mark.parametrize("w,h", SIZES + [(48, 272), (64, 256), (80, 528), (1920, 1080)])
 @pytest.mark.parametrize("qp", [16, 30, 44, 51])
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1])
 def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp, mode):
     """Feed the oracle's own pre-filter pictures (one I, one P) and records to the HIP filter
-    (mode 0: persistent 4-row band kernel, x+2y; mode 1: one launch per x+2y wavefront;
-    mode 2: prep kernel + 16-row bands in x+y order with one barrier per step)."""
+    (mode 0: prep kernel + persistent 16-row bands in x+y order with one barrier per step;
+    mode 1: one launch per x+2y wavefront, the plain form kept as a cross-check)."""
     oe = oracle.Encoder(w, h, gop=60, threads=8)
     e = E.Encoder((w + 15) // 16 * 16, (h + 15) // 16 * 16, fixed_qp=qp, deblock_mode=mode)
     for _, _, y, uv in frames(w, h, 2):
@@ -130,7 +130,7 @@ def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp, mode):
 
 
 @pytest.mark.parametrize("w,h,n", [(64, 48, 9), (176, 144, 7), (322, 182, 5), (1280, 720, 4), (1920, 1080, 3)])
-@pytest.mark.parametrize("graphs,mode,sub", [(True, 0, True), (False, 0, False), (True, 1, True), (True, 2, True)])
+@pytest.mark.parametrize("graphs,mode,sub", [(True, 0, True), (False, 0, False), (True, 1, True)])
 def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub):
     """Whole path: identical access units, identical reconstruction, and the independent
     decoder reproduces both."""
@@ -155,7 +155,7 @@ def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub):
 
 
 @pytest.mark.parametrize("w,h,n", [(64, 48, 6), (176, 144, 6), (322, 182, 5), (1280, 720, 3)])
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1])
 def test_high_profile_8x8_transform_equals_oracle(E, oracle, w, h, n, mode):
     """transform8x8=1: P macroblocks through the 8x8 transform kernel path, deblocking with 8x8 block edges."""
     oracle.set_transform8x8(True)

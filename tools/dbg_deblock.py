@@ -21,10 +21,3 @@ for n, (_, _, y, uv) in enumerate(frames(w, h, 2)):
         print("qp", set(oe.mbinfo["qp"].tolist()), "types", set(oe.mbinfo["mb_type"].tolist()))
         for name, a in (("pre", oe.prefilter_uv), ("exp", oe.recon_uv), ("got", d_uv)):
             print(name); print(a[r0:r1, c0:c1])
-    if n == 0 and mode == 2:
-        import ctypes as C
-        buf = np.zeros((e.mbw * e.mbh, 16), np.uint32)
-        rc = e.L.mi355enc_fetch(e.h, 100, buf.ctypes.data_as(C.c_void_p), buf.nbytes)
-        print("dbrec rc", rc)
-        for j in range(16):
-            print("w%d" % j, sorted(set(hex(v) for v in buf[:, j].tolist())))
