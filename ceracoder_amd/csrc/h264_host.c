@@ -268,6 +268,7 @@ struct h264_writer {
     uint8_t *rbsp; size_t rbsp_cap;
     uint8_t *tc_l; /* TotalCoeff per luma 4x4 in raster order, 16 per macroblock */
     uint8_t *tc_c; /* per chroma AC block: Cb 0-3, Cr 4-7 */
+    uint8_t *i4m;  /* Intra4x4PredMode per luma4x4BlkIdx, 16 per macroblock (valid where mb_type == 2) */
 };
 
 h264_writer_t *h264_writer_new(int mbw, int mbh, int t8) {
@@ -278,12 +279,13 @@ h264_writer_t *h264_writer_new(int mbw, int mbh, int t8) {
     w->rbsp = (uint8_t *)malloc(w->rbsp_cap);
     w->tc_l = (uint8_t *)malloc((size_t)mbw * mbh * 16);
     w->tc_c = (uint8_t *)malloc((size_t)mbw * mbh * 8);
-    if (!w->rbsp || !w->tc_l || !w->tc_c) { h264_writer_free(w); return NULL; }
+    w->i4m = (uint8_t *)malloc((size_t)mbw * mbh * 16);
+    if (!w->rbsp || !w->tc_l || !w->tc_c || !w->i4m) { h264_writer_free(w); return NULL; }
     return w;
 }
 void h264_writer_free(h264_writer_t *w) {
     if (!w) return;
-    free(w->rbsp); free(w->tc_l); free(w->tc_c); free(w);
+    free(w->rbsp); free(w->tc_l); free(w->tc_c); free(w->i4m); free(w);
 }
 size_t h264_max_au_bytes(int mbw, int mbh) { return (size_t)mbw * mbh * 1536 + 4096; }
 
@@ -306,8 +308,13 @@ static inline int ctx_chroma(const h264_writer_t *w, int mbn, int mx, int my, in
     return (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));
 }
 
-size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
-                        int slice_qp, const mb_info_t *mbi, const int16_t *levels) {
+/* One implementation for both level layouts.  dense: 408 int16 per macroblock (mi355enc_dev.h).  packed: the stream
+ * written by levels_pack_kernel -- per macroblock, 32-byte blocks [I4x4 modes if mb_type == 2][I16x16 DC if NZ_LDC]
+ * [luma block b for each set bit b][chroma DC if NZ_CBDC|NZ_CRDC][chroma AC block i for each set bit 16+i]; blocks that
+ * are absent are all-zero by construction and read from k_zero_block. */
+static const int16_t k_zero_block[16] __attribute__((aligned(32))) = {0};
+static size_t write_slice_impl(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
+                               int slice_qp, const mb_info_t *mbi, const int16_t *levels, const int16_t *packed) {
     const int mbw = w->mbw, mbh = w->mbh, nmb = mbw * mbh;
     bits_t b;
     bits_init(&b, w->rbsp, w->rbsp_cap);
@@ -330,9 +337,23 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
     for (int my = 0, mbn = 0; my < mbh; my++)
         for (int mx = 0; mx < mbw; mx++, mbn++) {
             const mb_info_t *m = mbi + mbn;
-            const int16_t *lv = levels + (size_t)mbn * MB_LEVELS;
             const uint32_t nz = m->nzmask;
             const int intra = m->mb_type != 1, i16 = m->mb_type == 0;
+            const int16_t *p_modes, *p_ldc, *p_cdc, *p_luma[16], *p_cac[8];
+            if (packed) {
+                p_modes = m->mb_type == 2 ? packed : k_zero_block; if (m->mb_type == 2) packed += 16;
+                p_ldc = (nz & NZ_LDC) ? packed : k_zero_block; if (nz & NZ_LDC) packed += 16;
+                for (int i = 0; i < 16; i++) { if ((nz >> i) & 1) { p_luma[i] = packed; packed += 16; } else p_luma[i] = k_zero_block; }
+                p_cdc = (nz & (NZ_CBDC | NZ_CRDC)) ? packed : k_zero_block; if (nz & (NZ_CBDC | NZ_CRDC)) packed += 16;
+                for (int i = 0; i < 8; i++) { if ((nz >> (16 + i)) & 1) { p_cac[i] = packed; packed += 16; } else p_cac[i] = k_zero_block; }
+            } else {
+                const int16_t *lv = levels + (size_t)mbn * MB_LEVELS;
+                p_modes = p_ldc = lv + L_LDC; p_cdc = lv + L_CDC;
+                for (int i = 0; i < 16; i++) p_luma[i] = lv + L_LUMA + i * 16;
+                for (int i = 0; i < 8; i++) p_cac[i] = lv + L_CAC + i * 16;
+            }
+            uint8_t *im = w->i4m + (size_t)mbn * 16;
+            if (m->mb_type == 2) for (int i = 0; i < 16; i++) im[i] = (uint8_t)p_modes[i];
             int cbp_l = 0;
             if (i16) cbp_l = (nz & 0xFFFF) ? 15 : 0;
             else cbp_l = ((nz & 0x000F) ? 1 : 0) | ((nz & 0x00F0) ? 2 : 0) | ((nz & 0x0F00) ? 4 : 0) | ((nz & 0xF000) ? 8 : 0);
@@ -367,11 +388,11 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
                     for (int blk = 0; blk < 16; blk++) {
                         const int r = blk_to_raster[blk], bx = r & 3, by = r >> 2;
                         int ma = -1, mb_ = -1;
-                        if (bx) ma = lv[L_LDC + blk_to_raster[by * 4 + bx - 1]];
-                        else if (mx) ma = m[-1].mb_type == 2 ? lv[-MB_LEVELS + L_LDC + blk_to_raster[by * 4 + 3]] : 2;
-                        if (by) mb_ = lv[L_LDC + blk_to_raster[(by - 1) * 4 + bx]];
-                        else if (my) mb_ = m[-mbw].mb_type == 2 ? lv[-(ptrdiff_t)mbw * MB_LEVELS + L_LDC + blk_to_raster[12 + bx]] : 2;
-                        const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode = lv[L_LDC + blk];
+                        if (bx) ma = im[blk_to_raster[by * 4 + bx - 1]];
+                        else if (mx) ma = m[-1].mb_type == 2 ? im[-16 + blk_to_raster[by * 4 + 3]] : 2;
+                        if (by) mb_ = im[blk_to_raster[(by - 1) * 4 + bx]];
+                        else if (my) mb_ = m[-mbw].mb_type == 2 ? im[-(ptrdiff_t)mbw * 16 + blk_to_raster[12 + bx]] : 2;
+                        const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode = im[blk];
                         if (mode == pm) bits_put(&b, 1, 1);
                         else bits_put(&b, 4, (uint32_t)(mode < pm ? mode : mode - 1)); /* flag 0 + 3-bit rem */
                     }
@@ -381,23 +402,23 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
             }
             if (i16 || cbp_l || cbp_c) { bits_se(&b, (int)m->qp - prev_qp); prev_qp = m->qp; }
             uint8_t *tl = w->tc_l + (size_t)mbn * 16;
-            if (i16) put_block16(&b, lv + L_LDC, 0, ctx_luma(w, mbn, mx, my, 0, 0));
+            if (i16) put_block16(&b, p_ldc, 0, ctx_luma(w, mbn, mx, my, 0, 0));
             if (cbp_l)
                 for (int blk = 0; blk < 16; blk++) {
                     if (!(cbp_l & (1 << (blk >> 2)))) continue;
                     const int r = blk_to_raster[blk], bx = r & 3, by = r >> 2;
                     const int nC = ctx_luma(w, mbn, mx, my, bx, by);
-                    if ((nz >> blk) & 1) tl[r] = (uint8_t)put_block16(&b, lv + L_LUMA + blk * 16, i16, nC);
+                    if ((nz >> blk) & 1) tl[r] = (uint8_t)put_block16(&b, p_luma[blk], i16, nC);
                     else { const int cls = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3; bits_put(&b, vlc_coeff_token[cls][0][0].len, vlc_coeff_token[cls][0][0].bits); }
                 }
             if (cbp_c) {
-                put_chroma_dc(&b, lv + L_CDC);
-                put_chroma_dc(&b, lv + L_CDC + 4);
+                put_chroma_dc(&b, p_cdc);
+                put_chroma_dc(&b, p_cdc + 4);
                 if (cbp_c == 2)
                     for (int c = 0; c < 2; c++)
                         for (int blk = 0; blk < 4; blk++) {
                             const int nC = ctx_chroma(w, mbn, mx, my, c, blk & 1, blk >> 1);
-                            w->tc_c[(size_t)mbn * 8 + 4 * c + blk] = (uint8_t)put_block16(&b, lv + L_CAC + (4 * c + blk) * 16, 1, nC);
+                            w->tc_c[(size_t)mbn * 8 + 4 * c + blk] = (uint8_t)put_block16(&b, p_cac[4 * c + blk], 1, nC);
                         }
             }
         }
@@ -405,4 +426,12 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
     size_t n = bits_finish(&b, w->rbsp);
     if (b.overflow) return 0;
     return emit_nal(out, cap, is_idr ? 3 : 2, is_idr ? 5 : 1, w->rbsp, n);
+}
+size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
+                        int slice_qp, const mb_info_t *mbi, const int16_t *levels) {
+    return write_slice_impl(w, out, cap, is_idr, frame_num, idr_pic_id, slice_qp, mbi, levels, NULL);
+}
+size_t h264_write_slice_packed(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
+                               int slice_qp, const mb_info_t *mbi, const int16_t *packed) {
+    return write_slice_impl(w, out, cap, is_idr, frame_num, idr_pic_id, slice_qp, mbi, NULL, packed);
 }

@@ -40,10 +40,11 @@ static const uint8_t k_lambda[52] = {1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1, 
 struct slot_t {
     frame_ctx_t *h_ctx;   // pinned
     mb_info_t *h_mbi;     // pinned
-    int16_t *h_levels;    // pinned
+    int16_t *h_levels;    // pinned: packed level stream, written by levels_pack_kernel over PCIe (no D2H copy)
+    unsigned *h_hdr;      // pinned: [0] blocks in the stream, [1] error word of the band deblocker
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
     hipEvent_t done, gpu_done, ev[6];
-    int is_idr, qp, frame_num, idr_pic_id, rec_index;
+    int is_idr, qp, frame_num, idr_pic_id, rec_index, set;
     int64_t pts;
 };
 
@@ -61,7 +62,7 @@ struct mi355enc {
     uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
     unsigned *d_progress; // [2*bands] strip counters of the band deblocker, then one error word
-    unsigned *h_err;      // pinned mirror of the error word
+    unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
     int n_progress;
     slot_t slot[NSLOT];
     int head, tail, pending;
@@ -171,7 +172,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
-    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->h_err = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr;
+    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -196,8 +197,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_dbrec, (size_t)h->nmb * 64));
     h->n_progress = 2 * k_deblock_bands16(h->mbh);
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(h->n_progress + 1) * sizeof(unsigned)));
-    HIPCHK(hipHostMalloc((void **)&h->h_err, sizeof(unsigned), hipHostMallocDefault));
-    *h->h_err = 0;
+    HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
+    HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
     if (cfg->keep_prefilter) {
         HIPCHK(hipMalloc((void **)&h->d_pre_y, h->ysz));
         HIPCHK(hipMalloc((void **)&h->d_pre_uv, h->csz));
@@ -207,7 +208,9 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         memset(s, 0, sizeof *s);
         HIPCHK(hipHostMalloc((void **)&s->h_ctx, sizeof(frame_ctx_t), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&s->h_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&s->h_levels, (size_t)h->nmb * MB_LEVELS * sizeof(int16_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&s->h_levels, (size_t)h->nmb * PACK_BLOCKS_MAX * 32, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&s->h_hdr, 4 * sizeof(unsigned), hipHostMallocDefault));
+        s->h_hdr[0] = s->h_hdr[1] = 0;
         HIPCHK(hipMalloc((void **)&s->d_src_y, h->ysz + SURF_PAD));
         HIPCHK(hipMalloc((void **)&s->d_src_uv, h->csz + SURF_PAD));
         HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
@@ -232,6 +235,7 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->h_ctx) (void)hipHostFree(s->h_ctx);
         if (s->h_mbi) (void)hipHostFree(s->h_mbi);
         if (s->h_levels) (void)hipHostFree(s->h_levels);
+        if (s->h_hdr) (void)hipHostFree(s->h_hdr);
         if (s->d_src_y) (void)hipFree(s->d_src_y);
         if (s->d_src_uv) (void)hipFree(s->d_src_uv);
         if (s->done) (void)hipEventDestroy(s->done);
@@ -244,7 +248,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_isad) (void)hipFree(h->d_isad);
     if (h->d_dbrec) (void)hipFree(h->d_dbrec);
     if (h->d_progress) (void)hipFree(h->d_progress);
-    if (h->h_err) (void)hipHostFree(h->h_err);
+    if (h->d_off) (void)hipFree(h->d_off);
     if (h->d_ctx) (void)hipFree(h->d_ctx);
     for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
@@ -301,24 +305,23 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
     }
+    // Hand-over on the second stream as soon as records and levels are final (they do not depend on deblocking): the
+    // device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
+    HIPCHK(hipEventRecord(s->gpu_done, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
+    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, h->d_progress + h->n_progress, h->cstream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->done, h->cstream));
     if (h->d_pre_y) {
         HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
     }
     { int r = run_deblock(h); if (r) return r; }
-    if (prof) HIPCHK(hipEventRecord(s->ev[3], h->stream));
-    // hand-over on the copy stream, so the next picture's kernels (other record/level set) need not wait for PCIe
-    HIPCHK(hipEventRecord(s->gpu_done, h->stream));
-    HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
-    HIPCHK(hipMemcpyAsync(s->h_mbi, h->d_mbi_set[set], (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->cstream));
-    HIPCHK(hipMemcpyAsync(s->h_levels, h->d_levels_set[set], (size_t)h->nmb * MB_LEVELS * sizeof(int16_t), hipMemcpyDeviceToHost, h->cstream));
-    if (h->cfg.deblock_mode == 0) HIPCHK(hipMemcpyAsync(h->h_err, h->d_progress + h->n_progress, sizeof(unsigned), hipMemcpyDeviceToHost, h->cstream));
-    if (prof) HIPCHK(hipEventRecord(s->ev[4], h->cstream));
-    HIPCHK(hipEventRecord(s->done, h->cstream));
+    if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
     h->n_submitted++;
     s->is_idr = idr; s->qp = qp; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
-    s->pts = pts; s->rec_index = nxt;
+    s->pts = pts; s->rec_index = nxt; s->set = set;
     if (idr) h->idr_count++;
     h->frames_since_idr++;
     h->cur = nxt; h->have_ref = 1;
@@ -361,8 +364,8 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     HIPCHK(hipEventSynchronize(s->done));
     double t1 = now_ms();
     h->st.ms_wait += t1 - t0;
-    if (*h->h_err) {
-        fprintf(stderr, "mi355enc: deblocking wavefront timed out waiting for a neighbouring band (device error word %u)\n", *h->h_err);
+    if (s->h_hdr[1]) { // sticky: set by a band of an earlier picture's deblocking launch that gave up waiting
+        fprintf(stderr, "mi355enc: deblocking wavefront timed out waiting for a neighbouring band (device error word %u)\n", s->h_hdr[1]);
         return MI355ENC_ERR_HIP;
     }
     size_t n = 0;
@@ -370,7 +373,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
         n = h264_write_headers(out, out_cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den, h->cfg.transform8x8);
         if (!n) return MI355ENC_ERR_OVERFLOW;
     }
-    size_t m = h264_write_slice(h->writer, out + n, out_cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels);
+    size_t m = h264_write_slice_packed(h->writer, out + n, out_cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels);
     if (!m) return MI355ENC_ERR_OVERFLOW;
     h->st.ms_entropy += now_ms() - t1;
     *out_len = n + m;
@@ -380,6 +383,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     rc_update(&h->rc, s->is_idr, s->qp, n + m);
     if (h->cfg.profile_events) {
         float a = 0, b = 0, c = 0, tot = 0, sp = 0;
+        HIPCHK(hipEventSynchronize(s->ev[4])); // the access unit is ready before deblocking ends; the stage timers are not
         (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
         if (!s->is_idr) { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[2]); h->st.ms_subpel += sp; }
         (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
@@ -423,7 +427,7 @@ int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
     case MI355ENC_FETCH_PREFILTER_Y: src = h->d_pre_y; need = h->ysz; break;
     case MI355ENC_FETCH_PREFILTER_UV: src = h->d_pre_uv; need = h->csz; break;
     case MI355ENC_FETCH_MBINFO: src = h->last_slot ? h->last_slot->h_mbi : nullptr; need = (size_t)h->nmb * sizeof(mb_info_t); host = true; break;
-    case MI355ENC_FETCH_LEVELS: src = h->last_slot ? h->last_slot->h_levels : nullptr; need = (size_t)h->nmb * MB_LEVELS * 2; host = true; break;
+    case MI355ENC_FETCH_LEVELS: src = h->last_slot ? h->d_levels_set[h->last_slot->set] : nullptr; need = (size_t)h->nmb * MB_LEVELS * 2; break; // dense, from HBM
     default: return MI355ENC_ERR_ARG;
     }
     if (!src) return MI355ENC_ERR_STATE;

@@ -29,6 +29,7 @@ typedef struct {
 #define NZ_CBDC (1u << 25)
 #define NZ_CRDC (1u << 26)
 #define NZ_T8 (1u << 27) /* transform_size_8x8_flag of a P macroblock */
+#define PACK_BLOCKS_MAX 27 /* 32-byte blocks a macroblock can contribute to the packed level stream */
 
 /* Device-resident description of the picture being encoded; kernels read it through one
  * pointer so that the per-picture launch sequence can be replayed as a hipGraph. */
@@ -65,6 +66,8 @@ int k_deblock_bands16(int mbh);
 void k_launch_deblock_band16(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, unsigned *d_err, hipStream_t s);
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s);
 int k_intra_diags(int mbw, int mbh);
+void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,
+                   unsigned *h_hdr, const unsigned *d_err, hipStream_t s);
 int k_deblock_diags(int mbw, int mbh);
 #endif
 #endif

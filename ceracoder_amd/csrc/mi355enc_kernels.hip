@@ -1813,6 +1813,72 @@ __global__ __launch_bounds__(256) void deblock_band16_kernel(db_args a) {
     else band16_body<true>(a, blockIdx.x - nb, nb, lds);
 }
 
+// =================================================================== hand-over to the host entropy coder
+// The kernels above leave 408 int16 per macroblock in HBM; at streaming bit rates almost all of
+// them are zero.  Instead of copying the dense array over PCIe (6.6 MB per 1080p picture) the
+// device packs what the CAVLC writer will actually read, in the order it reads it, straight into
+// the pinned host buffer: per macroblock, 32-byte blocks
+//     [Intra4x4 modes, if mb_type == 2] [Intra16x16 DC, if NZ_LDC] [luma blkIdx b for every set bit b of nzmask]
+//     [chroma DC (Cb 4 + Cr 4), if NZ_CBDC | NZ_CRDC] [chroma AC block i for every set bit 16 + i]
+// The host walks the stream with a running pointer and needs no per-macroblock offsets.
+#define PACK_CAND 27
+DEV int pack_count(unsigned nz, unsigned mb_type) {
+    return __popc(nz & 0x01FFFFFFu) + ((nz & (NZ_CBDC | NZ_CRDC)) ? 1 : 0) + (mb_type == 2 ? 1 : 0);
+}
+// exclusive prefix sum of the block counts: one workgroup, thread t owns a run of consecutive macroblocks
+__global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__restrict__ mbi, int nmb, unsigned *__restrict__ off,
+                                                           unsigned *__restrict__ hdr, const unsigned *__restrict__ err) {
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x, per = (nmb + 1023) / 1024, base = tid * per;
+    unsigned mine = 0;
+    for (int i = 0; i < per; i++) {
+        const int mb = base + i;
+        if (mb < nmb) { const uint4 r = ldg128(&mbi[mb]); mine += (unsigned)pack_count(r.z, r.y & 255); }
+    }
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned v = __shfl_up(incl, d); if ((tid & 63) >= d) incl += v; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    unsigned before = 0;
+    for (int w = 0; w < (tid >> 6); w++) before += wsum[w];
+    unsigned run = before + incl - mine;
+    for (int i = 0; i < per; i++) {
+        const int mb = base + i;
+        if (mb < nmb) { off[mb] = run; const uint4 r = ldg128(&mbi[mb]); run += (unsigned)pack_count(r.z, r.y & 255); }
+    }
+    if (tid == 1023) { hdr[0] = run; hdr[1] = ldg32(err); } // total blocks; sticky error word of the band deblocker
+}
+// one wave per macroblock: lane c < 27 is one candidate block of the stream order above
+__global__ __launch_bounds__(256) void levels_pack_kernel(const mb_info_t *__restrict__ mbi, const int16_t *__restrict__ levels, int nmb,
+                                                          const unsigned *__restrict__ off, mb_info_t *__restrict__ h_mbi, int16_t *__restrict__ h_packed) {
+    const int mb = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+    if (mb >= nmb) return;
+    const uint4 r = ldg128(&mbi[mb]);
+    const unsigned nz = r.z, type = r.y & 255;
+    bool present = false;
+    int src = 0; // int16 offset inside the macroblock's 408 levels
+    if (c == 0) { present = type == 2; src = L_LDC; }
+    else if (c == 1) { present = (nz & NZ_LDC) != 0; src = L_LDC; }
+    else if (c < 18) { present = (nz >> (c - 2)) & 1; src = L_LUMA + (c - 2) * 16; }
+    else if (c == 18) { present = (nz & (NZ_CBDC | NZ_CRDC)) != 0; src = L_CDC; }
+    else if (c < PACK_CAND) { present = (nz >> (16 + c - 19)) & 1; src = L_CAC + (c - 19) * 16; }
+    const unsigned long long m = __ballot(present);
+    if (present) {
+        const int rank = __popcll(m & ((1ull << c) - 1));
+        const int16_t *sp = levels + (size_t)mb * MB_LEVELS + src;
+        int16_t *dp = h_packed + ((size_t)ldg32(&off[mb]) + rank) * 16;
+        const uint4 a = ldg128(sp), b = ldg128(sp + 8);
+        stg128(dp, a); stg128(dp + 8, b);
+    }
+    if (c == PACK_CAND) stg128(&h_mbi[mb], r);
+}
+void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,
+                   unsigned *h_hdr, const unsigned *d_err, hipStream_t s) {
+    hipLaunchKernelGGL(levels_scan_kernel, dim3(1), dim3(1024), 0, s, d_mbi, nmb, d_off, h_hdr, d_err);
+    hipLaunchKernelGGL(levels_pack_kernel, dim3((nmb + 3) / 4), dim3(256), 0, s, d_mbi, d_levels, nmb, d_off, h_mbi, h_packed);
+}
+
 // =================================================================== staging helper
 // Replicate the last visible column/row into the coded-size margin of a staged source surface.
 __global__ void pad_kernel(uint8_t *y, uint8_t *uv, int stride, int vw, int vh, int W, int H) {
