@@ -180,7 +180,12 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     *out = h; // from here on close() cleans up partial state
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&h->d_ctx, sizeof(frame_ctx_t)));
-    HIPCHK(hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+    { // The hand-over stream gets its own priority level: HIP then backs it with a different hardware queue, so its
+      // kernels run beside the persistent deblocking kernel instead of queueing behind it.
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
+    }
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&h->d_mbi_set[i], (size_t)h->nmb * sizeof(mb_info_t)));
         HIPCHK(hipMalloc((void **)&h->d_levels_set[i], (size_t)h->nmb * MB_LEVELS * sizeof(int16_t)));
@@ -305,13 +310,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
     }
-    // Hand-over on the second stream as soon as records and levels are final (they do not depend on deblocking): the
-    // device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
-    HIPCHK(hipEventRecord(s->gpu_done, h->stream));
-    HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
-    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, h->d_progress + h->n_progress, h->cstream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s->done, h->cstream));
+    HIPCHK(hipEventRecord(s->gpu_done, h->stream)); // records and levels are final here; they do not depend on deblocking
     if (h->d_pre_y) {
         HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
@@ -319,6 +318,12 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     }
     { int r = run_deblock(h); if (r) return r; }
     if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
+    // Hand-over on the second stream, enqueued after the deblocking launch so that it cannot be dispatched ahead of it:
+    // the device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
+    HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
+    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, h->d_progress + h->n_progress, h->cstream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->done, h->cstream));
     h->n_submitted++;
     s->is_idr = idr; s->qp = qp; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
     s->pts = pts; s->rec_index = nxt; s->set = set;

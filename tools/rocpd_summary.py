@@ -22,7 +22,7 @@ print("\n".join(lines))
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write("\n".join(lines) + "\n")
 # timeline of the last full picture that starts with me_kernel
-idx = [i for i, (k, s, e) in enumerate(rows) if names.get(k, "").startswith("me_kernel")]
+idx = [i for i, (k, s, e) in enumerate(rows) if "me_kernel" in names.get(k, "")]
 if len(idx) > 3:
     a, b = idx[-3], idx[-2]
     t0 = rows[a][1]
