@@ -28,8 +28,6 @@ WORKLOADS = {
     "2160p_ippp": (3840, 2160, 60, 60, 20_000_000),  # configs[3]
     "720p_ippp": (1280, 720, 30, 60, 6_000_000),     # configs[0] geometry
 }
-# algorithmic bytes of the motion-search kernel = cur luma + ref luma + 8 B/MB
-ME_BYTES_PER_PIXEL = 2.03125
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 
 
@@ -163,23 +161,35 @@ def main():
         except Exception:
             prof = None
         P = coded(width) * coded(height)
-        me_bytes = ME_BYTES_PER_PIXEL * P
-        me_ms = st.ms_me / st.n_me if st.n_me else None
-        roof = None
-        if me_ms:
-            ach = me_bytes / (me_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "me_kernel", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": (prof or {}).get("me_kernel", {}).get("hbm_bytes_per_launch_corrected"),
-                    "avg_launch_us": round(me_ms * 1e3, 2), "algorithmic_bytes_per_launch": int(me_bytes), "launches": int(st.n_me),
-                    "kernel_trace_avg_us": (prof or {}).get("me_kernel", {}).get("kernel_trace_avg_us"),
-                    "note": "full search is bound by the SAD issue rate (~142 T abs-diff/s chip-wide, tools/ubench_sad.hip), not by HBM: "
-                            "1089*P abs-diffs -> >=17.6 us @1080p, i.e. <=3% of the HBM roofline for any exhaustive SAD search"}
-        else:  # I-only workload: the dominant kernel is the intra wavefront (6.0625 B/pixel)
-            ms = st.ms_intra / st.n_intra
-            ach = 6.0625 * P / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "intra_kernel wavefront", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_us": round(ms * 1e3, 2),
-                    "algorithmic_bytes_per_launch": int(6.0625 * P), "launches": int(st.n_intra)}
+        # SURVEY.md 8(d) algorithmic bytes per launch (P = coded luma pixels); sub-pel refinement is not in the survey's
+        # table: cur luma P + reference window P + 16 B/MB record read and written = 2.125 P.
+        ALG = {"me_kernel": 2.03125, "subpel_kernel": 2.125, "inter_kernel": 7.5625, "intra (analyse + x+y wavefront)": 6.0625,
+               "deblock (prep + band16 kernel)": 3.0625}
+        per = {"me_kernel": (st.ms_me, st.n_me), "subpel_kernel": (st.ms_subpel, st.n_me), "inter_kernel": (st.ms_inter, st.n_inter),
+               "intra (analyse + x+y wavefront)": (st.ms_intra, st.n_intra), "deblock (prep + band16 kernel)": (st.ms_deblock, st.n_deblock)}
+        bound = {"me_kernel": "VALU SAD issue rate (~142 T abs-diff/s chip-wide, tools/ubench_sad.hip): 1089*P abs-diffs -> >=17.6 us @1080p",
+                 "subpel_kernel": "LDS-staged 6-tap planes, latency/LDS", "inter_kernel": "launch + byte stores of interleaved chroma",
+                 "intra (analyse + x+y wavefront)": "dependency chain: mbw+mbh-1 dependent launches (hipGraph)",
+                 "deblock (prep + band16 kernel)": "dependency chain of the normative filter order: ~mbw+mbh dependent steps of ~1.5 us inside one persistent launch"}
+        pmc_name = {"me_kernel": "me_kernel", "deblock (prep + band16 kernel)": "deblock_band16_kernel"}
+        kernels = []
+        for name, (ms, n) in per.items():
+            if not n:
+                continue
+            us = ms / n * 1e3
+            ach = ALG[name] * P / (us * 1e-6) / 1e9
+            pk = (prof or {}).get(pmc_name.get(name, ""), {})
+            kernels.append({"kernel": name, "launches": int(n), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": int(ALG[name] * P),
+                            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                            "traffic": pk.get("hbm_bytes_per_launch_corrected"), "kernel_trace_avg_us": pk.get("kernel_trace_avg_us"),
+                            "time_share": round(ms / max(1e-9, st.ms_total_gpu), 4), "bounded_by": bound[name]})
+        kernels.sort(key=lambda k: -k["time_share"])
+        dom = kernels[0]
+        roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                "launches": dom["launches"], "kernel_trace_avg_us": dom["kernel_trace_avg_us"], "time_share": dom["time_share"],
+                "note": "dominant kernel by GPU time; " + dom["bounded_by"] + ". Every kernel of the path is listed in roofline_kernels "
+                        "(the motion search north_star names is 'me_kernel')."}
         out = {
             "metric": "1080p H.264 encoded frames/sec per GPU" if args.workload.startswith("1080p") else "H.264 encoded frames/sec per GPU",
             "value": round(world * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,6 +200,7 @@ def main():
                        "me": "full search +-16 integer-pel SAD + half/quarter-sample refinement", "streams_per_gpu": 1, "parallelism": "%d independent streams" % world,
                        "pipeline_depth": args.depth},
             "roofline": roof,
+            "roofline_kernels": kernels,
             "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "inter": round(st.ms_inter / max(1, st.n_inter), 4),
                                      "subpel": round(st.ms_subpel / max(1, st.n_me), 4),
                                      "intra_wavefront": round(st.ms_intra / max(1, st.n_intra), 4),

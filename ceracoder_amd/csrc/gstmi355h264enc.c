@@ -285,9 +285,11 @@ static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->stats = FALSE; s->dct8x8 = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
 }
 
+GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */
 static gboolean plugin_init(GstPlugin *p) {
     GST_DEBUG_CATEGORY_INIT(mi355_debug, "mi355h264enc", 0, "MI355X H.264 encoder");
-    return gst_element_register(p, "mi355h264enc", GST_RANK_NONE, GST_TYPE_MI355H264ENC);
+    return gst_element_register(p, "mi355h264enc", GST_RANK_NONE, GST_TYPE_MI355H264ENC) &&
+           gst_element_register(p, "mi355tsmux", GST_RANK_NONE, gst_mi355tsmux_get_type());
 }
 GST_PLUGIN_DEFINE(GST_VERSION_MAJOR, GST_VERSION_MINOR, mi355h264enc, "MI355X-native H.264 encoder for ceracoder", plugin_init, VERSION,
                   "LGPL", PACKAGE, "https://github.com/CERALIVE/ceracoder")

@@ -10,14 +10,23 @@
  *             instead of SRT statistics; libsrt is not in this image)
  *   :425-438  bus watch: ERROR / EOS stop the loop
  * Output file: records {u32 length, u64 pts_ns, bytes} per appsink sample.
+ * Latency: t0 = buffer enters the encoder's sink pad (pad probe), t1 = the
+ * sample reaches new_buf_cb, t2 = the last 1316-byte datagram of that sample has been sent.  The
+ * sender regroups samples into 7 x 188-byte payloads like /root/reference/src/ceracoder.c:297-339
+ * does for srt_send, but over UDP to a loopback socket (libsrt is absent: the t2 - t1 segment is
+ * "UDP loopback, same packetisation", not SRT).
  *
  * usage: ref_harness PIPELINE_FILE OUT_FILE [SCRIPT_FILE]     (script lines: "<ms> <bps>")
  */
+#include <arpa/inet.h>
 #include <gst/app/gstappsink.h>
 #include <gst/gst.h>
+#include <netinet/in.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/socket.h>
+#include <unistd.h>
 
 #include "encoder_control.h"
 #include "pipeline_loader.h"
@@ -33,15 +42,81 @@ static struct { long ms; int bps; } script[4096];
 static int script_n, script_i;
 static gint64 t_start;
 
+/* ---- latency bookkeeping */
+#define LAT_RING 256
+#define LAT_MAX 65536
+#define PKT_SIZE (188 * 7)
+static struct { guint64 pts; gint64 t0; } lat_ring[LAT_RING];
+static unsigned lat_head;
+static GMutex lat_lock;
+static float lat_enc[LAT_MAX], lat_send[LAT_MAX];
+static unsigned lat_n;
+static int udp_tx = -1, udp_rx = -1;
+static struct sockaddr_in udp_dst;
+static unsigned char pkt[PKT_SIZE];
+static int pkt_len;
+static guint64 n_datagrams;
+
+static GstPadProbeReturn enc_sink_probe(GstPad *pad, GstPadProbeInfo *info, gpointer user) {
+    (void)pad; (void)user;
+    GstBuffer *b = GST_PAD_PROBE_INFO_BUFFER(info);
+    if (b) {
+        g_mutex_lock(&lat_lock);
+        lat_ring[lat_head % LAT_RING].pts = GST_BUFFER_PTS(b);
+        lat_ring[lat_head % LAT_RING].t0 = g_get_monotonic_time();
+        lat_head++;
+        g_mutex_unlock(&lat_lock);
+    }
+    return GST_PAD_PROBE_OK;
+}
+static void udp_open(void) {
+    udp_rx = socket(AF_INET, SOCK_DGRAM, 0);
+    udp_tx = socket(AF_INET, SOCK_DGRAM, 0);
+    if (udp_rx < 0 || udp_tx < 0) { udp_tx = -1; return; }
+    struct sockaddr_in a;
+    memset(&a, 0, sizeof a);
+    a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK); a.sin_port = 0;
+    socklen_t al = sizeof a;
+    if (bind(udp_rx, (struct sockaddr *)&a, sizeof a) || getsockname(udp_rx, (struct sockaddr *)&a, &al)) { udp_tx = -1; return; }
+    udp_dst = a; /* datagrams pile up in (and overflow) the never-read receive buffer; the sender does not care */
+}
+static void send_regrouped(const unsigned char *data, size_t n) {
+    while (n) {
+        size_t k = (size_t)(PKT_SIZE - pkt_len) < n ? (size_t)(PKT_SIZE - pkt_len) : n;
+        memcpy(pkt + pkt_len, data, k);
+        pkt_len += (int)k; data += k; n -= k;
+        if (pkt_len == PKT_SIZE) {
+            if (udp_tx >= 0) (void)sendto(udp_tx, pkt, PKT_SIZE, 0, (struct sockaddr *)&udp_dst, sizeof udp_dst);
+            n_datagrams++;
+            pkt_len = 0;
+        }
+    }
+}
+static int cmp_float(const void *a, const void *b) { float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }
+static void print_pct(const char *name, float *v, unsigned n) {
+    if (!n) { printf(",\"%s\":null", name); return; }
+    qsort(v, n, sizeof *v, cmp_float);
+    printf(",\"%s\":{\"p50\":%.3f,\"p95\":%.3f,\"max\":%.3f,\"n\":%u}", name, v[n / 2], v[(unsigned)(n * 0.95)], v[n - 1], n);
+}
+
 static GstFlowReturn new_buf_cb(GstAppSink *sink, gpointer user) {
     (void)user;
     GstSample *sample = gst_app_sink_pull_sample(sink);
     if (!sample) return GST_FLOW_OK;
     GstBuffer *buf = gst_sample_get_buffer(sample);
     GstMapInfo map;
+    const gint64 t1 = g_get_monotonic_time();
     if (gst_buffer_map(buf, &map, GST_MAP_READ)) {
         guint32 len = (guint32)map.size;
         guint64 pts = GST_BUFFER_PTS(buf);
+        send_regrouped(map.data, map.size);
+        const gint64 t2 = g_get_monotonic_time();
+        gint64 t0 = -1;
+        g_mutex_lock(&lat_lock);
+        for (unsigned i = 0; i < LAT_RING && i < lat_head; i++)
+            if (lat_ring[(lat_head - 1 - i) % LAT_RING].pts == pts) { t0 = lat_ring[(lat_head - 1 - i) % LAT_RING].t0; break; }
+        g_mutex_unlock(&lat_lock);
+        if (t0 >= 0 && lat_n < LAT_MAX) { lat_enc[lat_n] = (float)((t1 - t0) / 1e3); lat_send[lat_n] = (float)((t2 - t1) / 1e3); lat_n++; }
         fwrite(&len, 4, 1, out); fwrite(&pts, 8, 1, out); fwrite(map.data, 1, map.size, out);
         n_samples++; n_bytes += map.size;
         gst_buffer_unmap(buf, &map);
@@ -95,6 +170,11 @@ int main(int argc, char **argv) {
     guint bps_prop = 0;
     if (have_enc) g_object_get(G_OBJECT(enc.element), "bps", &bps_prop, NULL);
     fprintf(stderr, "{\"encoder_found\":%d,\"bitrate_div\":%d,\"bps_after_null_state_write\":%u}\n", have_enc, enc.bitrate_div, bps_prop);
+    if (have_enc) {
+        GstPad *sp = gst_element_get_static_pad(enc.element, "sink");
+        if (sp) { gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_BUFFER, enc_sink_probe, NULL, NULL); gst_object_unref(sp); }
+    }
+    udp_open();
     GstElement *sink = gst_bin_get_by_name(GST_BIN(pipeline), "appsink");
     if (!sink) { fprintf(stderr, "no element named appsink\n"); return 2; }
     GstAppSinkCallbacks cbs = {NULL, NULL, new_buf_cb, {0}};
@@ -106,7 +186,14 @@ int main(int argc, char **argv) {
     double secs = (g_get_monotonic_time() - t_start) / 1e6;
     gst_element_set_state(GST_ELEMENT(pipeline), GST_STATE_NULL);
     fclose(out);
-    printf("{\"samples\":%" G_GUINT64_FORMAT ",\"bytes\":%" G_GUINT64_FORMAT ",\"seconds\":%.3f,\"setpoints_applied\":%d}\n", n_samples, n_bytes, secs, script_i);
+    printf("{\"samples\":%" G_GUINT64_FORMAT ",\"bytes\":%" G_GUINT64_FORMAT ",\"seconds\":%.3f,\"setpoints_applied\":%d,\"datagrams_1316\":%" G_GUINT64_FORMAT,
+           n_samples, n_bytes, secs, script_i, n_datagrams);
+    unsigned skip = lat_n > 90 ? 60 : 0; /* discard the first GOP (warm-up) when the run is long enough */
+    print_pct("ms_encoder_sink_to_appsink", lat_enc + skip, lat_n - skip);
+    print_pct("ms_appsink_to_last_udp_send", lat_send + skip, lat_n - skip);
+    printf("}\n");
+    if (udp_tx >= 0) close(udp_tx);
+    if (udp_rx >= 0) close(udp_rx);
     pipeline_file_unload(&pf);
     return exit_code;
 }

@@ -64,3 +64,31 @@ def test_balancer_script_drives_bitrate_through_reference_encoder_control(tmp_pa
     assert abs(rate(60, 150) - 6.0e6) / 6.0e6 < 0.10, rate(60, 150)
     assert abs(rate(165, 225) - 5.3e6) / 5.3e6 < 0.12, rate(165, 225)
     assert abs(rate(330, 450) - 6.0e6) / 6.0e6 < 0.10, rate(330, 450)
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
+def test_ts_pipeline_demuxes_and_decodes(tmp_path, oracle):
+    """pipeline/mi355x/ts_test_pattern_720p30: ... ! mi355h264enc ! mi355tsmux ! appsink -- the plugins-bad-free tail
+    (SURVEY 8f N4).  The harness regroups the packets into 1316-byte datagrams like new_buf_cb; an independent
+    demultiplexer and the independent decoder must recover every picture."""
+    from tests.tsdemux import demux
+    out = tmp_path / "out.bin"
+    r = subprocess.run([HARNESS, os.path.join(ROOT, "pipeline", "mi355x", "ts_test_pattern_720p30"), str(out)], env=gst_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    summary = json.loads(r.stdout.splitlines()[-1])
+    assert summary["samples"] == 150
+    recs = read_records(str(out))
+    ts = b"".join(a for _, a in recs)
+    assert summary["datagrams_1316"] == len(ts) // 1316
+    d = demux(ts)
+    assert len(d["pes"]) == 150 and len(d["pat"]) >= 5
+    assert [p["pts"] for p in d["pes"]] == [90000 + (pts // 100000 * 9 + pts % 100000 * 9 // 100000) for pts, _ in recs]
+    dec = oracle.Decoder()
+    for i, p in enumerate(d["pes"]):
+        data = bytes(p["data"])
+        assert data[:6] == b"\x00\x00\x00\x01\x09\xF0" and p["rai"] == (i % 30 == 0)
+        y, uv = dec.decode(data[6:])
+    assert dec.size == (1280, 720)
+    lat = summary["ms_encoder_sink_to_appsink"]
+    assert lat["n"] >= 60 and 0 < lat["p50"] < 50, lat
