@@ -55,7 +55,7 @@ enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME
        PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8 };
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS("video/x-raw, format=(string)NV12, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
+    GST_STATIC_CAPS("video/x-raw, format=(string){ NV12, I420, YUY2, UYVY }, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
 static GstStaticPadTemplate src_tmpl = GST_STATIC_PAD_TEMPLATE("src", GST_PAD_SRC, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-h264, stream-format=(string)byte-stream, alignment=(string)au, profile=(string){ constrained-baseline, high }, "
                     "width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
@@ -205,9 +205,22 @@ static GstFlowReturn enc_handle_frame(GstVideoEncoder *ve, GstVideoCodecFrame *f
         gst_video_encoder_finish_frame(ve, frame);
         return GST_FLOW_ERROR;
     }
-    int r = mi355enc_submit(s->enc, GST_VIDEO_FRAME_PLANE_DATA(&vf, 0), GST_VIDEO_FRAME_PLANE_STRIDE(&vf, 0),
-                            GST_VIDEO_FRAME_PLANE_DATA(&vf, 1), GST_VIDEO_FRAME_PLANE_STRIDE(&vf, 1), (int64_t)frame->pts,
-                            GST_VIDEO_CODEC_FRAME_IS_FORCE_KEYFRAME(frame) ? 1 : 0);
+    /* NV12 goes in as is; I420 (x264enc's native format) and packed 4:2:2 are converted on the device, so the
+     * `videoconvert` in front of the encoder (pipeline/generic/x264_superfast_camlink:4) degenerates to a pass-through */
+    int fmt = MI355ENC_FMT_NV12;
+    switch (GST_VIDEO_INFO_FORMAT(&s->input_state->info)) {
+    case GST_VIDEO_FORMAT_I420: fmt = MI355ENC_FMT_I420; break;
+    case GST_VIDEO_FORMAT_YUY2: fmt = MI355ENC_FMT_YUY2; break;
+    case GST_VIDEO_FORMAT_UYVY: fmt = MI355ENC_FMT_UYVY; break;
+    default: break;
+    }
+    const uint8_t *planes[3] = {NULL, NULL, NULL};
+    int strides[3] = {0, 0, 0};
+    for (guint i = 0; i < GST_VIDEO_FRAME_N_PLANES(&vf) && i < 3; i++) {
+        planes[i] = GST_VIDEO_FRAME_PLANE_DATA(&vf, i);
+        strides[i] = GST_VIDEO_FRAME_PLANE_STRIDE(&vf, i);
+    }
+    int r = mi355enc_submit_fmt(s->enc, fmt, planes, strides, (int64_t)frame->pts, GST_VIDEO_CODEC_FRAME_IS_FORCE_KEYFRAME(frame) ? 1 : 0);
     gst_video_frame_unmap(&vf); /* submit() has copied the planes to the device (stream-ordered from pageable memory) */
     if (r != MI355ENC_OK) {
         GST_ELEMENT_ERROR(s, STREAM, ENCODE, ("mi355h264enc: submit failed: %s", mi355enc_strerror(r)), ("mi355enc_submit returned %d", r));

@@ -43,6 +43,7 @@ struct slot_t {
     int16_t *h_levels;    // pinned: packed level stream, written by levels_pack_kernel over PCIe (no D2H copy)
     unsigned *h_hdr;      // pinned: [0] blocks in the stream, [1] error word of the band deblocker
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
+    uint8_t *d_raw;              // staging of non-NV12 input before the conversion kernel (allocated on first use)
     hipEvent_t done, gpu_done, ev[6];
     int is_idr, qp, frame_num, idr_pic_id, rec_index, set;
     int64_t pts;
@@ -243,6 +244,7 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->h_hdr) (void)hipHostFree(s->h_hdr);
         if (s->d_src_y) (void)hipFree(s->d_src_y);
         if (s->d_src_uv) (void)hipFree(s->d_src_uv);
+        if (s->d_raw) (void)hipFree(s->d_raw);
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->gpu_done) (void)hipEventDestroy(s->gpu_done);
         for (int k = 0; k < 6; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
@@ -344,6 +346,52 @@ int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
     HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, h->stream));
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, h->stream);
     return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+}
+
+// Upload the planes of a non-NV12 picture tightly into the slot's raw staging buffer and convert into its NV12 staging surfaces.
+static int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const planes[3], const int strides[3]) {
+    const int w = h->cfg.width, ht = h->cfg.height;
+    if (fmt < MI355ENC_FMT_I420 || fmt > MI355ENC_FMT_UYVY || !planes || !strides || !planes[0]) return MI355ENC_ERR_ARG;
+    if (!s->d_raw) HIPCHK(hipMalloc((void **)&s->d_raw, (size_t)(2 * h->W + 32) * h->H + 64));
+    if (fmt == MI355ENC_FMT_I420) {
+        if (!planes[1] || !planes[2] || strides[0] < w || strides[1] < w / 2 || strides[2] < w / 2) return MI355ENC_ERR_ARG;
+        const int r0 = (w + 15) & ~15, r1 = (w / 2 + 15) & ~15;
+        uint8_t *dy = s->d_raw, *du = dy + (size_t)r0 * ht, *dv = du + (size_t)r1 * (ht / 2);
+        HIPCHK(hipMemcpy2DAsync(dy, r0, planes[0], strides[0], w, ht, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpy2DAsync(du, r1, planes[1], strides[1], w / 2, ht / 2, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpy2DAsync(dv, r1, planes[2], strides[2], w / 2, ht / 2, hipMemcpyHostToDevice, h->stream));
+        if (k_launch_csc(fmt, dy, du, dv, r0, r1, r1, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, h->stream)) return MI355ENC_ERR_ARG;
+    } else {
+        if (strides[0] < 2 * w) return MI355ENC_ERR_ARG;
+        const int r0 = (2 * w + 15) & ~15;
+        HIPCHK(hipMemcpy2DAsync(s->d_raw, r0, planes[0], strides[0], 2 * w, ht, hipMemcpyHostToDevice, h->stream));
+        if (k_launch_csc(fmt, s->d_raw, nullptr, nullptr, r0, 0, 0, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, h->stream)) return MI355ENC_ERR_ARG;
+    }
+    HIPCHK(hipGetLastError());
+    return MI355ENC_OK;
+}
+
+int mi355enc_submit_fmt(mi355enc_t *h, int fmt, const uint8_t *const planes[3], const int strides[3], int64_t pts, int force_idr) {
+    if (!h || !planes || !strides) return MI355ENC_ERR_ARG;
+    if (fmt == MI355ENC_FMT_NV12) return mi355enc_submit(h, planes[0], strides[0], planes[1], strides[1], pts, force_idr);
+    if (h->pending > h->cfg.pipeline_depth) return MI355ENC_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[h->head];
+    int r = upload_and_convert(h, s, fmt, planes, strides);
+    if (r) return r;
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+}
+
+int mi355enc_stage_csc(mi355enc_t *h, int fmt, const uint8_t *const planes[3], const int strides[3], uint8_t *out_y, uint8_t *out_uv) {
+    if (!h || !out_y || !out_uv || h->pending) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[0];
+    int r = upload_and_convert(h, s, fmt, planes, strides);
+    if (r) return r;
+    HIPCHK(hipMemcpyAsync(out_y, s->d_src_y, h->ysz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(out_uv, s->d_src_uv, h->csz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
 }
 
 int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const void *d_uv, int uv_stride, int64_t pts, int force_idr) {

@@ -1935,6 +1935,97 @@ void k_launch_deblock_band16(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigne
     hipLaunchKernelGGL(deblock_prep_kernel, dim3((mbw * mbh + 255) / 256), dim3(256), 0, s, d_ctx, d_progress, nprog);
     hipLaunchKernelGGL(deblock_band16_kernel, dim3(2 * k_deblock_bands16(mbh)), dim3(256), 0, s, a);
 }
+// =================================================================== input conversion to NV12
+// Replaces the `videoconvert` hop of the reference's pipelines for the raw formats its sources deliver
+// (/root/reference/pipeline/generic/x264_superfast_camlink:4: v4l2src ... ! videoconvert ! x264enc): planar I420
+// (jpegdec, videotestsrc) and packed 4:2:2 YUY2 / UYVY (capture cards).  One thread converts an 8 x 2 luma patch and
+// its 4 chroma pairs: every global access is an aligned 8- or 16-byte word, reads and writes are contiguous per
+// row, so the kernel runs at copy speed (pure HBM traffic: 1.5 P in + 1.5 P out for I420, 2 P + 1.5 P for 4:2:2).
+// 4:2:2 -> 4:2:0 takes the rounded mean of the two chroma rows.  The coded-size margin (width/height not a
+// multiple of 16) is filled by clamping the source coordinate, so no separate padding pass is needed.
+struct csc_args {
+    const uint8_t *p0, *p1, *p2; // I420: Y, U, V planes; packed formats: p0 only
+    int s0, s1, s2;              // their strides in bytes
+    uint8_t *dy, *duv;           // NV12 destination, coded size W x H, stride W
+    int vw, vh, W, H;            // visible and coded size
+};
+DEV unsigned avg4(unsigned a, unsigned b) { // per-byte (a + b + 1) >> 1 without carries between bytes
+    return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu);
+}
+template <int FMT> // 1 I420, 2 YUY2 (Y0 U Y1 V), 3 UYVY (U Y0 V Y1)
+__global__ __launch_bounds__(256) void csc_kernel(csc_args a) {
+    const int tx = blockIdx.x * 256 + threadIdx.x, per_row = a.W >> 3, rows2 = a.H >> 1;
+    if (tx >= per_row * rows2) return;
+    const int ry = tx / per_row, cx = tx - ry * per_row; // output luma rows 2ry, 2ry+1; luma columns 8cx..8cx+7
+    // visible width is even; a patch is either fully visible, or clamped per byte through the slow path
+    const int x0 = cx * 8;
+    const bool fast = x0 + 8 <= a.vw && (a.s0 & 7) == 0 && (((uintptr_t)a.p0) & 7) == 0;
+    uint2 yrow[2];
+    unsigned uvw[2]; // chroma of this patch: 4 (U,V) pairs = 8 bytes
+    if (FMT == 1) {
+        const int cy = (2 * ry < a.vh ? 2 * ry : a.vh - 2) >> 1;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int sy = 2 * ry + r < a.vh ? 2 * ry + r : a.vh - 1;
+            const uint8_t *sp = a.p0 + (size_t)sy * a.s0;
+            if (fast) yrow[r] = ldg64(sp + x0);
+            else {
+                unsigned w[2] = {0, 0};
+                for (int i = 0; i < 8; i++) { const int sx = x0 + i < a.vw ? x0 + i : a.vw - 1; w[i >> 2] |= ldg8(sp + sx) << (8 * (i & 3)); }
+                yrow[r] = make_uint2(w[0], w[1]);
+            }
+        }
+        unsigned u = 0, v = 0;
+        const uint8_t *up = a.p1 + (size_t)cy * a.s1, *vp = a.p2 + (size_t)cy * a.s2;
+        const int cw = a.vw >> 1;
+        if (cx * 4 + 4 <= cw && ((a.s1 | a.s2) & 3) == 0 && ((((uintptr_t)a.p1) | ((uintptr_t)a.p2)) & 3) == 0) { u = ldg32(up + cx * 4); v = ldg32(vp + cx * 4); }
+        else
+            for (int i = 0; i < 4; i++) { const int sx = cx * 4 + i < cw ? cx * 4 + i : cw - 1; u |= ldg8(up + sx) << (8 * i); v |= ldg8(vp + sx) << (8 * i); }
+        uvw[0] = (u & 0xFF) | ((v & 0xFF) << 8) | ((u & 0xFF00) << 8) | ((v & 0xFF00) << 16);
+        uvw[1] = ((u >> 16) & 0xFF) | (((v >> 16) & 0xFF) << 8) | (((u >> 24) & 0xFF) << 16) | ((v >> 24) << 24);
+    } else {
+        unsigned c[2][2]; // per source row: 4 (U,V) pairs
+        const int base = 2 * ry < a.vh ? 2 * ry : a.vh - 2; // margin rows repeat the last chroma row (mean of the last two source rows)
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int sy = base + r;
+            const uint8_t *sp = a.p0 + (size_t)sy * a.s0;
+            unsigned w[4];
+            if (fast && (a.s0 & 15) == 0 && (((uintptr_t)a.p0) & 15) == 0) { const uint4 q = ldg128(sp + 2 * x0); w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
+            else
+                for (int i = 0; i < 4; i++) { const int sx = x0 + 2 * i < a.vw ? x0 + 2 * i : a.vw - 2; w[i] = ldg8(sp + 2 * sx) | (ldg8(sp + 2 * sx + 1) << 8) | (ldg8(sp + 2 * sx + 2) << 16) | (ldg8(sp + 2 * sx + 3) << 24); }
+            unsigned yy[2] = {0, 0}, cc[2] = {0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; i++) { // one macropixel: 2 luma + (U,V)
+                const unsigned m = w[i];
+                const unsigned y1 = FMT == 2 ? (m >> 16) & 0xFF : m >> 24;
+                const unsigned y0 = x0 + 2 * i >= a.vw ? y1 : (FMT == 2 ? m & 0xFF : (m >> 8) & 0xFF); // margin: the last visible sample, not the last pair
+                const unsigned u = FMT == 2 ? (m >> 8) & 0xFF : m & 0xFF, v = FMT == 2 ? m >> 24 : (m >> 16) & 0xFF;
+                yy[i >> 1] |= (y0 | (y1 << 8)) << (16 * (i & 1));
+                cc[i >> 1] |= (u | (v << 8)) << (16 * (i & 1));
+            }
+            yrow[r] = make_uint2(yy[0], yy[1]);
+            c[r][0] = cc[0]; c[r][1] = cc[1];
+        }
+        if (2 * ry >= a.vh) yrow[0] = yrow[1]; // ... and the last luma row
+        uvw[0] = avg4(c[0][0], c[1][0]); uvw[1] = avg4(c[0][1], c[1][1]);
+    }
+    v2u t;
+    t.x = yrow[0].x; t.y = yrow[0].y; *(GAS v2u *)(a.dy + (size_t)(2 * ry) * a.W + x0) = t;
+    t.x = yrow[1].x; t.y = yrow[1].y; *(GAS v2u *)(a.dy + (size_t)(2 * ry + 1) * a.W + x0) = t;
+    t.x = uvw[0]; t.y = uvw[1]; *(GAS v2u *)(a.duv + (size_t)ry * a.W + x0) = t;
+}
+int k_launch_csc(int fmt, const uint8_t *p0, const uint8_t *p1, const uint8_t *p2, int s0, int s1, int s2, uint8_t *dy, uint8_t *duv,
+                 int vw, int vh, int W, int H, hipStream_t s) {
+    csc_args a;
+    a.p0 = p0; a.p1 = p1; a.p2 = p2; a.s0 = s0; a.s1 = s1; a.s2 = s2; a.dy = dy; a.duv = duv; a.vw = vw; a.vh = vh; a.W = W; a.H = H;
+    const int n = (W >> 3) * (H >> 1);
+    if (fmt == 1) hipLaunchKernelGGL(csc_kernel<1>, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    else if (fmt == 2) hipLaunchKernelGGL(csc_kernel<2>, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    else if (fmt == 3) hipLaunchKernelGGL(csc_kernel<3>, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    else return -1;
+    return 0;
+}
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s) {
     int n = W * H + W * H / 2;
     hipLaunchKernelGGL(pad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, uv, stride, vis_w, vis_h, W, H);

@@ -18,6 +18,7 @@ MBINFO_DTYPE = np.dtype(
 )
 
 FETCH_RECON_Y, FETCH_RECON_UV, FETCH_PREFILTER_Y, FETCH_PREFILTER_UV, FETCH_MBINFO, FETCH_LEVELS = range(6)
+FMT_NV12, FMT_I420, FMT_YUY2, FMT_UYVY = range(4)
 STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK, STAGE_SUBPEL = range(5)
 
 EXPORTS = [
@@ -25,7 +26,7 @@ EXPORTS = [
     "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_encode", "mi355enc_submit",
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
-    "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_deblock", "mi355enc_time_stage",
+    "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_stage_deblock", "mi355enc_time_stage",
     "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
     "mi355enc_rc_pick_qp", "mi355enc_rc_update",
 ]
@@ -88,6 +89,8 @@ def load():
         L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_intra_analyse.argtypes = [vp, vp, vp, vp]
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
+        L.mi355enc_submit_fmt.argtypes = [vp, C.c_int, vp, vp, C.c_int64, C.c_int]
+        L.mi355enc_stage_csc.argtypes = [vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_time_stage.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mi355enc_host_write_headers.argtypes = [C.c_int] * 5 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_write_slice.argtypes = [C.c_int] * 7 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -203,6 +206,24 @@ class Encoder:
         y = np.ascontiguousarray(y, np.uint8)
         uv = np.ascontiguousarray(uv, np.uint8)
         self._chk(self.L.mi355enc_submit(self.h, _p(y), y.strides[0], _p(uv), uv.strides[0], pts, int(force_idr)), "submit")
+
+    def _planes(self, planes):
+        arrs = [np.ascontiguousarray(a, np.uint8) for a in planes]
+        pp = (C.c_void_p * 3)(*([a.ctypes.data for a in arrs] + [None] * (3 - len(arrs))))
+        ss = (C.c_int * 3)(*([a.strides[0] for a in arrs] + [0] * (3 - len(arrs))))
+        return arrs, pp, ss
+
+    def submit_fmt(self, fmt, planes, pts=0, force_idr=False):
+        """fmt: FMT_I420 (planes Y, U, V), FMT_YUY2 / FMT_UYVY (one packed plane, 2 bytes per pixel), FMT_NV12 (Y, UV)."""
+        arrs, pp, ss = self._planes(planes)
+        self._chk(self.L.mi355enc_submit_fmt(self.h, fmt, pp, ss, pts, int(force_idr)), "submit_fmt")
+
+    def stage_csc(self, fmt, planes):
+        arrs, pp, ss = self._planes(planes)
+        oy = np.empty((self.mbh * 16, self.mbw * 16), np.uint8)
+        ouv = np.empty((self.mbh * 8, self.mbw * 16), np.uint8)
+        self._chk(self.L.mi355enc_stage_csc(self.h, fmt, pp, ss, _p(oy), _p(ouv)), "stage_csc")
+        return oy, ouv
 
     def submit_device(self, y_ptr, y_stride, uv_ptr, uv_stride, pts=0, force_idr=False):
         self._chk(self.L.mi355enc_submit_device(self.h, y_ptr, y_stride, uv_ptr, uv_stride, pts, int(force_idr)), "submit_device")

@@ -97,6 +97,13 @@ int mi355enc_encode(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
  * (the bench's timed region; they must stay valid until the matching collect()). */
 int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
                     int64_t pts, int force_idr);
+/* Raw input formats other than NV12 are converted on the device (no `videoconvert` hop): I420 (planes Y, U, V), and
+ * packed 4:2:2 YUY2 / UYVY (plane 0 only; chroma rows are averaged pairwise with rounding to reach 4:2:0). */
+enum { MI355ENC_FMT_NV12 = 0, MI355ENC_FMT_I420 = 1, MI355ENC_FMT_YUY2 = 2, MI355ENC_FMT_UYVY = 3 };
+/* like mi355enc_submit, from host memory in `fmt`; planes[]/strides[]: as many entries as the format has planes */
+int mi355enc_submit_fmt(mi355enc_t *h, int fmt, const uint8_t *const planes[3], const int strides[3], int64_t pts, int force_idr);
+/* conversion stage alone (tests): writes the coded-size NV12 surfaces (16*mbw x 16*mbh luma, then interleaved chroma) */
+int mi355enc_stage_csc(mi355enc_t *h, int fmt, const uint8_t *const planes[3], const int strides[3], uint8_t *out_y, uint8_t *out_uv);
 int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const void *d_uv,
                            int uv_stride, int64_t pts, int force_idr);
 int mi355enc_pending(const mi355enc_t *h);

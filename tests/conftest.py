@@ -17,3 +17,9 @@ def oracle():
     from oracle import oracle as O
     O.lib()
     return O
+
+
+@pytest.fixture(scope="session")
+def E():
+    from ceracoder_amd import enc
+    return enc

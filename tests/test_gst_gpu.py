@@ -92,3 +92,26 @@ def test_ts_pipeline_demuxes_and_decodes(tmp_path, oracle):
     assert dec.size == (1280, 720)
     lat = summary["ms_encoder_sink_to_appsink"]
     assert lat["n"] >= 60 and 0 < lat["p50"] < 50, lat
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
+@pytest.mark.parametrize("fmt", ["I420", "YUY2", "UYVY"])
+def test_element_takes_raw_formats_without_videoconvert(tmp_path, oracle, fmt):
+    """The reference's graphs put `videoconvert` in front of the encoder; with I420 / packed 4:2:2 accepted directly
+    (device-side conversion) the same graph negotiates without a CPU conversion.  The stream must decode to the
+    videotestsrc picture."""
+    pf = tmp_path / "pipe"
+    pf.write_text("videotestsrc num-buffers=12 ! video/x-raw,width=320,height=180,framerate=30/1,format=%s ! "
+                  "mi355h264enc key-int-max=30 qp=24 name=venc_bps ! appsink name=appsink sync=false\n" % fmt)
+    out = tmp_path / "out.bin"
+    r = subprocess.run([HARNESS, str(pf), str(out)], env=gst_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = read_records(str(out))
+    assert len(recs) == 12
+    dec = oracle.Decoder()
+    for _, au in recs:
+        y, uv = dec.decode(au)
+    assert dec.size == (320, 180)
+    # SMPTE bars: the left-most bar is white or light grey, the 7th blue (Y ~ 35); chroma of the blue bar: Cb high, Cr low
+    assert float(y[20:100, 5:35].mean()) > 150 and float(y[20:100, 280:310].mean()) < 70
+    assert float(uv[10:50, 280:310:2].mean()) > 170 and float(uv[10:50, 281:311:2].mean()) < 128

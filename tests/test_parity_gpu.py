@@ -10,12 +10,6 @@ pytestmark = pytest.mark.gpu
 SIZES = [(64, 48), (176, 144), (320, 180), (1280, 720)]
 
 
-@pytest.fixture(scope="module")
-def E():
-    from ceracoder_amd import enc
-    return enc
-
-
 @pytest.mark.parametrize("w,h", SIZES)
 @pytest.mark.parametrize("qp", [20, 34])
 def test_me_kernel_matches_oracle(E, oracle, w, h, qp):
