@@ -585,12 +585,16 @@ int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const
     return MI355ENC_OK;
 }
 int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
-    if (!h || !avg_ms || iters < 1 || stage < 0 || stage > 4) return MI355ENC_ERR_ARG;
+    if (!h || !avg_ms || iters < 1 || stage < 0 || stage > 7) return MI355ENC_ERR_ARG;
     if (h->pending) return MI355ENC_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[0];
     // make sure the device context is valid: reuse the last one uploaded; if none, build a stage context
     if (!h->have_ref) { int r = stage_ctx(h, 26, true); if (r) return r; }
+    if (stage >= 5 && !s->d_raw) { // input conversion (5 I420, 6 YUY2, 7 UYVY): any bytes will do as a source
+        HIPCHK(hipMalloc((void **)&s->d_raw, (size_t)(2 * h->W + 32) * h->H + 64));
+        HIPCHK(hipMemsetAsync(s->d_raw, 0x55, (size_t)(2 * h->W + 32) * h->H + 64, h->stream));
+    }
     for (int warm = 0; warm < 2; warm++) {
         if (warm) HIPCHK(hipEventRecord(s->ev[0], h->stream));
         for (int i = 0; i < (warm ? iters : 1); i++) {
@@ -598,6 +602,11 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
             else if (stage == 1) k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
             else if (stage == 2) { int r = run_intra(h); if (r) return r; }
             else if (stage == 4) k_launch_subpel(h->d_ctx, h->mbw, h->mbh, h->stream);
+            else if (stage >= 5) {
+                const int w = h->cfg.width, ht = h->cfg.height, r0 = stage == 5 ? (w + 15) & ~15 : (2 * w + 15) & ~15, r1 = (w / 2 + 15) & ~15;
+                const uint8_t *p0 = s->d_raw, *p1 = p0 + (size_t)r0 * ht, *p2 = p1 + (size_t)r1 * (ht / 2);
+                k_launch_csc(stage - 4, p0, p1, p2, r0, r1, r1, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, h->stream);
+            }
             else { int r = run_deblock(h); if (r) return r; }
         }
         if (warm) HIPCHK(hipEventRecord(s->ev[1], h->stream));

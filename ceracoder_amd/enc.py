@@ -19,7 +19,7 @@ MBINFO_DTYPE = np.dtype(
 
 FETCH_RECON_Y, FETCH_RECON_UV, FETCH_PREFILTER_Y, FETCH_PREFILTER_UV, FETCH_MBINFO, FETCH_LEVELS = range(6)
 FMT_NV12, FMT_I420, FMT_YUY2, FMT_UYVY = range(4)
-STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK, STAGE_SUBPEL = range(5)
+STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK, STAGE_SUBPEL, STAGE_CSC_I420, STAGE_CSC_YUY2, STAGE_CSC_UYVY = range(8)
 
 EXPORTS = [
     "mi355enc_abi_version", "mi355enc_strerror", "mi355enc_default_cfg", "mi355enc_open", "mi355enc_close",

@@ -140,12 +140,13 @@ int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
 int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, uint16_t *isad_out);
 int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const void *mbinfo);
 /* Time `iters` back-to-back launches of one stage on the handle's stream with HIP events;
- * stage: 0 ME, 1 inter, 2 intra (whole wavefront), 3 deblock (whole wavefront), 4 sub-sample refinement.
+ * stage: 0 ME, 1 inter, 2 intra (whole wavefront), 3 deblock (whole wavefront), 4 sub-sample refinement,
+ * 5 / 6 / 7 input conversion from I420 / YUY2 / UYVY.
  * Uses whatever the handle's surfaces currently hold.  Returns average ms per launch. */
 int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms);
 
 
-/* ---- host-only stages (no device needed; what collect() runs after the D2H copy) ----
+/* ---- host-only stages (no device needed; what collect() runs once the packed hand-over has landed) ----
  * SPS+PPS, and one CAVLC slice NAL from macroblock records + levels.  *out_len = bytes. */
 int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den, int transform8x8, uint8_t *out, size_t out_cap,
                                 size_t *out_len);

@@ -20,3 +20,11 @@ for (w, h) in ((1920, 64), (1920, 128), (1920, 256), (1920, 1088), (3840, 2160))
         print("%4dx%-4d mode %d: deblock I %.3f ms  P %.3f ms (%d wavefront steps, %.2f / %.2f us per step) | intra %.3f ms | me %.1f us inter %.1f us"
               % (w, h, mode, t_i, t_p, steps, t_i * 1e3 / steps, t_p * 1e3 / steps, t_intra, t_me * 1e3, t_inter * 1e3), flush=True)
         e.close()
+
+for (w, h) in ((1920, 1080), (3840, 2160)):
+    e = E.Encoder(w, h, fixed_qp=30)
+    P = e.mbw * e.mbh * 256
+    for name, stg, bpp in (("I420", E.STAGE_CSC_I420, 3.0), ("YUY2", E.STAGE_CSC_YUY2, 3.5), ("UYVY", E.STAGE_CSC_UYVY, 3.5)):
+        t = e.time_stage(stg, 200)
+        print("%dx%d csc %s -> NV12: %.2f us, %.0f GB/s algorithmic (%.1f B/pixel)" % (w, h, name, t * 1e3, bpp * P / (t * 1e-3) / 1e9, bpp), flush=True)
+    e.close()
