@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--fixed-qp", type=int, default=-1)
     ap.add_argument("--depth", type=int, default=1)
     ap.add_argument("--deblock-mode", type=int, default=0)
+    ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     args = ap.parse_args()
 
     import torch
@@ -105,7 +106,8 @@ def main():
     fbytes = frames.stride(0)
 
     e = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
-                  pipeline_depth=args.depth, profile_events=True, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode)
+                  pipeline_depth=args.depth, profile_events=True, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
+                  transform8x8=bool(args.dct8x8))
 
     def run(n, first_index):
         qps, nbytes = [], 0
@@ -198,7 +200,7 @@ def main():
             "config": {"workload": args.workload, "width": width, "height": height, "fps_nominal": fps, "gop": gop,
                        "rate_control": "cbr %d bit/s" % bps if args.fixed_qp < 0 else "fixed qp %d" % args.fixed_qp,
                        "me": "full search +-16 integer-pel SAD + half/quarter-sample refinement", "streams_per_gpu": 1, "parallelism": "%d independent streams" % world,
-                       "pipeline_depth": args.depth},
+                       "pipeline_depth": args.depth, "dct8x8": bool(args.dct8x8)},
             "roofline": roof,
             "roofline_kernels": kernels,
             "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "inter": round(st.ms_inter / max(1, st.n_inter), 4),

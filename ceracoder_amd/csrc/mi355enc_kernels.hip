@@ -1639,11 +1639,15 @@ DEV void band16_body(const db_args a, const int band, const int nb, uint8_t *lds
     unsigned stripv = 0, strip_next = 0;
     int avail = 0, avail_next = 0;
     const int nsteps = mbw + D3_ROWS + 2;
-#ifdef D3_PROF
+#if defined(D3_PROF) && D3_PROF == 1 /* debug builds only: per-phase cycle counters (perturbs: every tick drains lgkmcnt) */
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0, tm1;
 #define D3_TICK(i) do { tm1 = __builtin_readcyclecounter(); pc[i] += tm1 - tm0; tm0 = tm1; } while (0)
 #else
 #define D3_TICK(i) do { } while (0)
+#endif
+#if defined(D3_PROF) && D3_PROF == 2 /* whole loop only */
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long loop_t0 = __builtin_readcyclecounter();
 #endif
     for (int t = 0; t < nsteps; t++) {
         const int x = t - 1 - r, xn = x + 1;
@@ -1651,7 +1655,7 @@ DEV void band16_body(const db_args a, const int band, const int nb, uint8_t *lds
         const bool pf = row_ok && xn >= 0 && xn < mbw;
         const bool pub = feeds && x >= 1 && x <= mbw;         // strip of macroblock x-1 becomes final in this step's vertical phase
         const int x0b = x * 16;
-#ifdef D3_PROF
+#if defined(D3_PROF) && D3_PROF == 1
         tm0 = __builtin_readcyclecounter();
 #endif
         // ---- A. prefetch macroblock x+1 (rows, record, strip of the band above)
@@ -1798,6 +1802,9 @@ DEV void band16_body(const db_args a, const int band, const int nb, uint8_t *lds
         }
         D3_TICK(6);
     }
+#if defined(D3_PROF) && D3_PROF == 2
+    pc[7] = __builtin_readcyclecounter() - loop_t0; pc[6] = (unsigned long long)nsteps;
+#endif
 #ifdef D3_PROF
     if (lane == 0 && (wave == 0 || wave == 3) && band < 2) {
         unsigned *o = (unsigned *)(ctx->dbrec) + (((CHROMA ? 2 : 0) + band) * 2 + (wave ? 1 : 0)) * 8; // debug build only: overwrites the first records after use

@@ -164,3 +164,31 @@ def test_rate_control_model_converges_and_follows_steps():
     assert abs(rate(1) - 6e6) / 6e6 < 0.10, rate(1)
     assert abs(rate(3) - 3e6) / 3e6 < 0.10, rate(3)
     assert abs(rate(5) - 1e6) / 1e6 < 0.10, rate(5)
+
+
+@pytest.mark.parametrize("delay", [0, 1])
+def test_rate_control_emergency_drop_lands_within_a_few_pictures(delay):
+    """the balancer's emergency drops (/root/reference/src/core/bitrate_control.c:176-199 cut the
+    setpoint towards min_bitrate in one 20 ms tick) must show in the stream within a few pictures, not a GOP.
+    delay=1 models pipeline_depth=1, where picture n is coded before the size of picture n-1 is known."""
+    fps, gop = 60, 60
+    rc = E.RateControl(fps, gop, 6_000_000)
+    rng = np.random.default_rng(5)
+    sizes, pend = [], []
+    drop_at = 2 * gop + 17
+    for i in range(4 * gop):
+        if i == drop_at:
+            rc.set_bitrate(500_000)
+        idr = i % gop == 0
+        qp = rc.pick_qp(idr)
+        cplx = (9e6 if idr else 1.2e6) * (1 + 0.1 * rng.standard_normal())
+        nbytes = max(40, int(cplx / 2 ** ((qp - 4) / 6) / 8))
+        pend.append((idr, qp, nbytes))
+        if len(pend) > delay:
+            rc.update(*pend.pop(0))
+        sizes.append(nbytes)
+    per_frame = 500_000 / fps / 8
+    # within 3 pictures (4 with one picture of feedback delay) P pictures are at most 1.5x the new per-picture budget ...
+    assert all(s < 1.5 * per_frame for s in sizes[drop_at + 3 + delay:drop_at + 20]), sizes[drop_at:drop_at + 8]
+    # ... and the half second after the drop carries no more than 1.3x the new rate
+    assert sum(sizes[drop_at + 2:drop_at + 32]) * 8 * fps / 30 < 1.3 * 500_000

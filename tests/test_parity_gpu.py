@@ -280,3 +280,26 @@ def test_rate_control_tracks_setpoint_within_one_gop(E):
     assert abs(rate(2 * gop, 3 * gop) - 1_000_000) / 1_000_000 < 0.10, rate(2 * gop, 3 * gop)
     assert abs(rate(3 * gop, 4 * gop) - 1_000_000) / 1_000_000 < 0.10, rate(3 * gop, 4 * gop)
     e.close()
+
+
+@pytest.mark.parametrize("depth", [0, 1])
+def test_rate_control_emergency_drop_on_the_device(E, depth):
+    """N3: a 4x cut of the setpoint between two key frames shows in the access-unit sizes within a few pictures
+    (pipeline_depth 1 adds one picture of feedback delay)."""
+    w, h, fps, gop = 640, 368, 30, 60
+    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=2_400_000, pipeline_depth=depth)
+    sizes, drop_at = [], 75
+    fr = frames(w, h, 120)
+    for i, (_, _, y, uv) in enumerate(fr):
+        if i == drop_at:
+            e.set_bitrate(600_000)
+        e.submit(y, uv, pts=i)
+        if e.pending > depth:
+            sizes.append(len(e.collect()[0]))
+    while e.pending:
+        sizes.append(len(e.collect()[0]))
+    per_frame = 600_000 / fps / 8
+    assert np.mean(sizes[drop_at - 10:drop_at]) > 2.5 * per_frame          # it really was running at the old rate
+    assert max(sizes[drop_at + 3 + depth:drop_at + 25]) < 1.6 * per_frame, sizes[drop_at:drop_at + 8]
+    assert sum(sizes[drop_at + 2:drop_at + 32]) * 8 * fps / 30 < 1.3 * 600_000
+    e.close()
