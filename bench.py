@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--fixed-qp", type=int, default=-1)
     ap.add_argument("--depth", type=int, default=1)
     ap.add_argument("--deblock-mode", type=int, default=0)
+    ap.add_argument("--sample", type=int, default=7, help="stage timers (HIP events) on every k-th picture; each event record costs ~5 us of queue time")
+    ap.add_argument("--overlap", type=int, default=0, help="1: overlapped two-stream schedule for P pictures")
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     args = ap.parse_args()
 
@@ -106,8 +108,8 @@ def main():
     fbytes = frames.stride(0)
 
     e = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
-                  pipeline_depth=args.depth, profile_events=True, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                  transform8x8=bool(args.dct8x8))
+                  pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
+                  transform8x8=bool(args.dct8x8), overlap=bool(args.overlap))
 
     def run(n, first_index):
         qps, nbytes = [], 0
@@ -167,29 +169,37 @@ def main():
         # table: cur luma P + reference window P + 16 B/MB record read and written = 2.125 P.
         ALG = {"me_kernel": 2.03125, "subpel_kernel": 2.125, "inter_kernel": 7.5625, "intra (analyse + x+y wavefront)": 6.0625,
                "deblock (prep + band16 kernel)": 3.0625}
+        db_p = (st.ms_deblock - st.ms_deblock_idr, st.n_deblock - st.n_deblock_idr) if st.n_deblock > st.n_deblock_idr else (st.ms_deblock, st.n_deblock)
         per = {"me_kernel": (st.ms_me, st.n_me), "subpel_kernel": (st.ms_subpel, st.n_me), "inter_kernel": (st.ms_inter, st.n_inter),
-               "intra (analyse + x+y wavefront)": (st.ms_intra, st.n_intra), "deblock (prep + band16 kernel)": (st.ms_deblock, st.n_deblock)}
+               "intra (analyse + x+y wavefront)": (st.ms_intra, st.n_intra), "deblock (prep + band16 kernel)": db_p}
         bound = {"me_kernel": "VALU SAD issue rate (~142 T abs-diff/s chip-wide, tools/ubench_sad.hip): 1089*P abs-diffs -> >=17.6 us @1080p",
                  "subpel_kernel": "LDS-staged 6-tap planes, latency/LDS", "inter_kernel": "launch + byte stores of interleaved chroma",
                  "intra (analyse + x+y wavefront)": "dependency chain: mbw+mbh-1 dependent launches (hipGraph)",
                  "deblock (prep + band16 kernel)": "dependency chain of the normative filter order: ~mbw+mbh dependent steps of ~1.5 us inside one persistent launch"}
         pmc_name = {"me_kernel": "me_kernel", "deblock (prep + band16 kernel)": "deblock_band16_kernel"}
         kernels = []
+        n_idr, n_p = int(st.idr_frames), int(st.frames - st.idr_frames)
+        weight = {"me_kernel": n_p, "subpel_kernel": n_p, "inter_kernel": n_p, "intra (analyse + x+y wavefront)": n_idr,
+                  "deblock (prep + band16 kernel)": n_idr + n_p}  # pictures of the timed region each kernel ran in (timers are sampled)
+        db_i_avg = st.ms_deblock_idr / st.n_deblock_idr if st.n_deblock_idr else 0.0
+        if n_p and st.n_deblock_idr:  # deblocking of P pictures is the roofline entry; IDR pictures are added to the total separately
+            weight["deblock (prep + band16 kernel)"] = n_p
+        est_total = (sum(weight[k] * (ms / n) for k, (ms, n) in per.items() if n) + (n_idr * db_i_avg if n_p else 0.0)) or 1e-9
         for name, (ms, n) in per.items():
             if not n:
                 continue
             us = ms / n * 1e3
             ach = ALG[name] * P / (us * 1e-6) / 1e9
             pk = (prof or {}).get(pmc_name.get(name, ""), {})
-            kernels.append({"kernel": name, "launches": int(n), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": int(ALG[name] * P),
+            kernels.append({"kernel": name, "launches_timed": int(n), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": int(ALG[name] * P),
                             "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                             "traffic": pk.get("hbm_bytes_per_launch_corrected"), "kernel_trace_avg_us": pk.get("kernel_trace_avg_us"),
-                            "time_share": round(ms / max(1e-9, st.ms_total_gpu), 4), "bounded_by": bound[name]})
+                            "time_share": round(weight[name] * (ms / n) / est_total, 4), "bounded_by": bound[name]})
         kernels.sort(key=lambda k: -k["time_share"])
         dom = kernels[0]
         roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
                 "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                "launches": dom["launches"], "kernel_trace_avg_us": dom["kernel_trace_avg_us"], "time_share": dom["time_share"],
+                "launches": dom["launches_timed"], "kernel_trace_avg_us": dom["kernel_trace_avg_us"], "time_share": dom["time_share"],
                 "note": "dominant kernel by GPU time; " + dom["bounded_by"] + ". Every kernel of the path is listed in roofline_kernels "
                         "(the motion search north_star names is 'me_kernel')."}
         out = {
@@ -206,8 +216,8 @@ def main():
             "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "inter": round(st.ms_inter / max(1, st.n_inter), 4),
                                      "subpel": round(st.ms_subpel / max(1, st.n_me), 4),
                                      "intra_wavefront": round(st.ms_intra / max(1, st.n_intra), 4),
-                                     "deblock_wavefront": round(st.ms_deblock / max(1, st.n_deblock), 4),
-                                     "gpu_total": round(st.ms_total_gpu / max(1, st.frames), 4),
+                                     "deblock_wavefront": round(db_p[0] / max(1, db_p[1]), 4), "deblock_wavefront_idr": round(db_i_avg, 4),
+                                     "gpu_total": round(est_total / max(1, st.frames), 4),
                                      "host_cavlc": round(st.ms_entropy / max(1, st.frames), 4),
                                      "host_wait": round(st.ms_wait / max(1, st.frames), 4)},
             "bitrate_out_bps": round(nbytes * 8 * fps / args.steps), "mean_qp": round(float(np.mean(qps)), 2),

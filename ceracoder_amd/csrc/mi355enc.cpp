@@ -44,7 +44,9 @@ struct slot_t {
     unsigned *h_hdr;      // pinned: [0] blocks in the stream, [1] error word of the band deblocker
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
     uint8_t *d_raw;              // staging of non-NV12 input before the conversion kernel (allocated on first use)
-    hipEvent_t done, gpu_done, ev[6];
+    hipEvent_t done, gpu_done, ev[12];
+    hipEvent_t ev_up, ev_top, ev_prep, ev_a; // cross-stream edges of the overlapped schedule (enqueue_picture)
+    int overlapped, prof;
     int is_idr, qp, frame_num, idr_pic_id, rec_index, set;
     int64_t pts;
 };
@@ -53,8 +55,11 @@ struct mi355enc {
     mi355enc_cfg_t cfg;
     int mbw, mbh, W, H, nmb;
     size_t ysz, csz;
-    hipStream_t stream;
-    frame_ctx_t *d_ctx;
+    hipStream_t stream;                  // main compute stream
+    hipStream_t astream;                 // second compute stream: uploads, the upper part of P pictures, the upper deblocking bands
+    frame_ctx_t *d_ctx, *d_ctx2[2];      // one context per picture parity (two pictures are in flight on the device); d_ctx = d_ctx2[0]
+    slot_t *prev_slot;                   // slot of the picture enqueued last
+    int ov_bands_a, ov_rows_top;         // overlapped schedule: bands [0, ov_bands_a) / rows [0, ov_rows_top) form the upper part; 0 = off
     mb_info_t *d_mbi, *d_mbi_set[2];     // two record/level sets: the D2H of picture n overlaps the kernels of n+1
     int16_t *d_levels, *d_levels_set[2];
     hipStream_t cstream;                 // copy stream for the D2H hand-over
@@ -69,7 +74,7 @@ struct mi355enc {
     int head, tail, pending;
     int cur, have_ref, frames_since_idr, idr_count, last_collected_rec;
     slot_t *last_slot;
-    hipGraphExec_t g_intra, g_deblock;
+    hipGraphExec_t g_intra[2], g_deblock[2]; // per context
     h264_writer_t *writer;
     rc_state_t rc;
     std::atomic<uint32_t> want_bps;
@@ -103,44 +108,46 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0;
 }
 
-static void launch_intra_all(mi355enc_t *h) {
+static void launch_intra_all(mi355enc_t *h, int ci) {
     int n = k_intra_diags(h->mbw, h->mbh);
-    for (int d = 0; d < n; d++) k_launch_intra_diag(h->d_ctx, h->mbw, h->mbh, d, h->stream);
+    for (int d = 0; d < n; d++) k_launch_intra_diag(h->d_ctx2[ci], h->mbw, h->mbh, d, h->stream);
 }
-static void launch_deblock_all(mi355enc_t *h) {
+static void launch_deblock_all(mi355enc_t *h, int ci) {
     int n = k_deblock_diags(h->mbw, h->mbh);
-    for (int d = 0; d < n; d++) k_launch_deblock_diag(h->d_ctx, h->mbw, h->mbh, d, h->stream);
+    for (int d = 0; d < n; d++) k_launch_deblock_diag(h->d_ctx2[ci], h->mbw, h->mbh, d, h->stream);
 }
-static int build_graph(mi355enc_t *h, int which, hipGraphExec_t *out) {
+static int build_graph(mi355enc_t *h, int which, int ci, hipGraphExec_t *out) {
     hipGraph_t g;
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    if (which == 0) launch_intra_all(h); else launch_deblock_all(h);
+    if (which == 0) launch_intra_all(h, ci); else launch_deblock_all(h, ci);
     HIPCHK(hipStreamEndCapture(h->stream, &g));
     HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
     HIPCHK(hipGraphDestroy(g));
     return 0;
 }
-static int run_intra(mi355enc_t *h) {
-    k_launch_intra_analyse(h->d_ctx, h->mbw, h->mbh, h->stream); // open-loop mode analysis: one flat launch
+static int run_intra(mi355enc_t *h, int ci) {
+    k_launch_intra_analyse(h->d_ctx2[ci], h->mbw, h->mbh, h->stream); // open-loop mode analysis: one flat launch
     if (h->cfg.use_graphs) {
-        if (!h->g_intra) { int r = build_graph(h, 0, &h->g_intra); if (r) return r; }
-        HIPCHK(hipGraphLaunch(h->g_intra, h->stream));
-    } else launch_intra_all(h);
+        if (!h->g_intra[ci]) { int r = build_graph(h, 0, ci, &h->g_intra[ci]); if (r) return r; }
+        HIPCHK(hipGraphLaunch(h->g_intra[ci], h->stream));
+    } else launch_intra_all(h, ci);
     return 0;
 }
-static int run_deblock(mi355enc_t *h) {
+// whole picture on the main stream
+static int run_deblock(mi355enc_t *h, int ci) {
     if (h->cfg.deblock_mode == 0) { // prep kernel (also clears the progress counters) + persistent 16-row band kernel
-        k_launch_deblock_band16(h->d_ctx, h->mbw, h->mbh, h->d_progress, h->n_progress + 1, h->d_progress + h->n_progress, h->stream);
+        k_launch_deblock_prep(h->d_ctx2[ci], h->mbw, h->mbh, h->d_progress, h->n_progress, h->stream);
+        k_launch_deblock_bands(h->d_ctx2[ci], h->mbh, 0, k_deblock_bands16(h->mbh), h->d_progress, h->d_progress + h->n_progress, h->stream);
         HIPCHK(hipGetLastError());
         return 0;
     }
     if (h->cfg.use_graphs) {
-        if (!h->g_deblock) { int r = build_graph(h, 1, &h->g_deblock); if (r) return r; }
-        HIPCHK(hipGraphLaunch(h->g_deblock, h->stream));
-    } else launch_deblock_all(h);
+        if (!h->g_deblock[ci]) { int r = build_graph(h, 1, ci, &h->g_deblock[ci]); if (r) return r; }
+        HIPCHK(hipGraphLaunch(h->g_deblock[ci], h->stream));
+    } else launch_deblock_all(h, ci);
     return 0;
 }
 
@@ -173,19 +180,22 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
-    h->g_intra = nullptr; h->g_deblock = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr;
+    h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->astream = nullptr; h->prev_slot = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->ov_bands_a = h->ov_rows_top = 0; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
     h->fixed_qp.store(cfg->fixed_qp);
     *out = h; // from here on close() cleans up partial state
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&h->d_ctx, sizeof(frame_ctx_t)));
+    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
+    h->d_ctx = h->d_ctx2[0];
     { // The hand-over stream gets its own priority level: HIP then backs it with a different hardware queue, so its
       // kernels run beside the persistent deblocking kernel instead of queueing behind it.
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->astream, hipStreamNonBlocking, lo)); // a third level; correctness never depends on it (see enqueue_picture)
     }
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&h->d_mbi_set[i], (size_t)h->nmb * sizeof(mb_info_t)));
@@ -221,21 +231,38 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMalloc((void **)&s->d_src_uv, h->csz + SURF_PAD));
         HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->gpu_done, hipEventDisableTiming));
-        for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&s->ev[k]));
+        for (int k = 0; k < 12; k++) HIPCHK(hipEventCreate(&s->ev[k]));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_top, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_prep, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_a, hipEventDisableTiming));
+    }
+    { // Overlapped schedule for P pictures (deblock_mode 0 only): choose how many upper bands go to the second stream so that the
+      // time the lower bands keep running after them (~18 steps of ~1.6 us per band) roughly matches the upper part's flat kernels
+      // (~12 ns per macroblock for search + refinement + transform).
+        const int nb = k_deblock_bands16(h->mbh);
+        int best_k = 0; double best_v = 0;
+        for (int k = 1; k <= nb - 2; k++) { // k bands above, at least two below
+            int rows = 16 * k - 3;
+            double win = (nb - k) * 18 * 1.6, top = 0.012 * h->mbw * rows, v = win < top ? win : top;
+            if (v > best_v) { best_v = v; best_k = k; }
+        }
+        if (h->cfg.overlap && h->cfg.deblock_mode == 0 && best_k > 0) { h->ov_bands_a = best_k; h->ov_rows_top = 16 * best_k - 3; }
     }
     h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
     if (!h->writer) return MI355ENC_ERR_NOMEM;
     rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->astream));
     return MI355ENC_OK;
 }
 
 void mi355enc_close(mi355enc_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device_id);
+    if (h->astream) (void)hipStreamSynchronize(h->astream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->g_intra) (void)hipGraphExecDestroy(h->g_intra);
-    if (h->g_deblock) (void)hipGraphExecDestroy(h->g_deblock);
+    for (int i = 0; i < 2; i++) { if (h->g_intra[i]) (void)hipGraphExecDestroy(h->g_intra[i]); if (h->g_deblock[i]) (void)hipGraphExecDestroy(h->g_deblock[i]); }
     for (int i = 0; i < NSLOT; i++) {
         slot_t *s = &h->slot[i];
         if (s->h_ctx) (void)hipHostFree(s->h_ctx);
@@ -247,7 +274,11 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->d_raw) (void)hipFree(s->d_raw);
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->gpu_done) (void)hipEventDestroy(s->gpu_done);
-        for (int k = 0; k < 6; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
+        for (int k = 0; k < 12; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
+        if (s->ev_up) (void)hipEventDestroy(s->ev_up);
+        if (s->ev_top) (void)hipEventDestroy(s->ev_top);
+        if (s->ev_prep) (void)hipEventDestroy(s->ev_prep);
+        if (s->ev_a) (void)hipEventDestroy(s->ev_a);
     }
     for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
     if (h->d_pre_y) (void)hipFree(h->d_pre_y);
@@ -256,9 +287,10 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_dbrec) (void)hipFree(h->d_dbrec);
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->d_off) (void)hipFree(h->d_off);
-    if (h->d_ctx) (void)hipFree(h->d_ctx);
+    for (int i = 0; i < 2; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
     for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
+    if (h->astream) (void)hipStreamDestroy(h->astream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h264_writer_free(h->writer);
     delete h;
@@ -280,7 +312,27 @@ size_t mi355enc_max_au_bytes(const mi355enc_t *h) { return h ? h264_max_au_bytes
 int mi355enc_mb_width(const mi355enc_t *h) { return h ? h->mbw : 0; }
 int mi355enc_mb_height(const mi355enc_t *h) { return h ? h->mbh : 0; }
 
-// Enqueue every device step of one picture whose source is described by (src_y, src_uv, src_stride).
+// Which stream carries the uploads of the next picture: the second stream if that picture will use the overlapped schedule.
+static bool next_overlaps(const mi355enc_t *h, int force_idr) {
+    const bool idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop;
+    return !idr && h->ov_bands_a > 0;
+}
+static hipStream_t upload_stream(const mi355enc_t *h, int force_idr) { return next_overlaps(h, force_idr) ? h->astream : h->stream; }
+
+// Enqueue every device step of one picture whose source is described by (src_y, src_uv, src_stride).  Anything the
+// caller uploaded for this picture was enqueued on `astream`.
+//
+// Sequential schedule (IDR pictures, deblock_mode 1, small pictures, overlap off), all on `stream`:
+//     ctx -> intra | me, subpel, inter -> prep -> all bands
+// Overlapped schedule (P pictures): the kernels of a P picture only need the reference rows around their own rows, and the
+// band deblocker of the previous picture finishes top-down.  With A = bands [0, ka) and TOP = macroblock rows [0, 16 ka - 3):
+//     astream:  ... A(n-1) | ctx(n), TOP(n): me, subpel, inter | wait prep(n) | A(n) | ctx(n+1), TOP(n+1) ...
+//     stream :  ... B(n-1) | wait ctx(n), A(n-1) | BOT(n): me, subpel, inter | wait TOP(n) | prep(n) | B(n) | ...
+// TOP(n) follows A(n-1) in stream order, and its search + interpolation window ends inside the rows A(n-1) has finalised
+// (the last 3 rows of A are left to BOT for that reason).  B(n)'s first band spin-waits on A(n)'s last band like any band on
+// the one above; A(n) is always submitted before B(n), so even if both streams shared one hardware queue the wait could not
+// deadlock (it would merely find the counters already complete).  Records and levels are final after `inter`, so the pack
+// kernels start on `cstream` there, as before.
 static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride,
                            int64_t pts, int force_idr) {
     const int idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop;
@@ -290,48 +342,86 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     int fq = h->fixed_qp.load(std::memory_order_relaxed);
     const int qp = fq >= 0 ? fq : rc_pick_qp(&h->rc, idr);
     const int nxt = h->cur ^ 1;
-    frame_ctx_t *c = s->h_ctx;
+    const int set = (int)(h->n_submitted & 1), ci = set;
+    frame_ctx_t *c = s->h_ctx, *dctx = h->d_ctx2[ci];
     c->src_y = src_y; c->src_uv = src_uv; c->src_stride = src_stride;
     c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
     c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
-    const int set = (int)(h->n_submitted & 1);
     c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set]; c->isad = h->d_isad; c->dbrec = h->d_dbrec;
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
-    HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
-    const int prof = h->cfg.profile_events;
-    if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
+    // stage timers: an event record costs ~5 us of queue time, so profile_events = k samples every k-th picture (IDR pictures always)
+    const int prof = h->cfg.profile_events > 0 && (idr || h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
+    const bool ov = !idr && h->ov_bands_a > 0;
+    const int nb = k_deblock_bands16(h->mbh), R = h->ov_rows_top;
+    slot_t *prev = h->prev_slot;
+    unsigned *d_err = h->d_progress + h->n_progress;
+    if (ov) { // uploads of this picture (source planes by the caller, the context here) go through astream, behind the previous picture's A
+        if (prev && !prev->overlapped) HIPCHK(hipStreamWaitEvent(h->astream, prev->ev_a, 0)); // after a sequential picture: its deblocking ran on `stream`
+        HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->astream));
+        HIPCHK(hipEventRecord(s->ev_up, h->astream));
+        HIPCHK(hipStreamWaitEvent(h->stream, s->ev_up, 0));
+    } else HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
+    if (prev && prev->overlapped) HIPCHK(hipStreamWaitEvent(h->stream, prev->ev_a, 0)); // A(n-1) ran on astream; B(n-1) precedes us in stream order
     if (idr) {
-        int r = run_intra(h); if (r) return r;
-        if (prof) { HIPCHK(hipEventRecord(s->ev[1], h->stream)); HIPCHK(hipEventRecord(s->ev[2], h->stream)); }
-    } else {
-        k_launch_me(h->d_ctx, h->mbw, h->mbh, h->stream);
+        if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
+        int r = run_intra(h, ci); if (r) return r;
         if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
-        if (h->cfg.subpel) k_launch_subpel(h->d_ctx, h->mbw, h->mbh, h->stream);
+    } else {
+        if (ov) { // TOP on astream
+            if (prof) HIPCHK(hipEventRecord(s->ev[6], h->astream));
+            k_launch_me(dctx, h->mbw, 0, R, h->astream);
+            if (prof) HIPCHK(hipEventRecord(s->ev[7], h->astream));
+            if (h->cfg.subpel) k_launch_subpel(dctx, h->mbw, 0, R, h->astream);
+            if (prof) HIPCHK(hipEventRecord(s->ev[8], h->astream));
+            k_launch_inter(dctx, h->mbw, 0, R, h->astream);
+            if (prof) HIPCHK(hipEventRecord(s->ev[9], h->astream));
+            HIPCHK(hipEventRecord(s->ev_top, h->astream));
+        }
+        const int r0 = ov ? R : 0;
+        if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
+        k_launch_me(dctx, h->mbw, r0, h->mbh, h->stream);
+        if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
+        if (h->cfg.subpel) k_launch_subpel(dctx, h->mbw, r0, h->mbh, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
-        k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
-        if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
+        k_launch_inter(dctx, h->mbw, r0, h->mbh, h->stream);
+        if (prof) HIPCHK(hipEventRecord(s->ev[11], h->stream));
+        if (ov) HIPCHK(hipStreamWaitEvent(h->stream, s->ev_top, 0));
     }
+    if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->gpu_done, h->stream)); // records and levels are final here; they do not depend on deblocking
     if (h->d_pre_y) {
         HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
     }
-    { int r = run_deblock(h); if (r) return r; }
+    if (ov) {
+        k_launch_deblock_prep(dctx, h->mbw, h->mbh, h->d_progress, h->n_progress, h->stream);
+        HIPCHK(hipEventRecord(s->ev_prep, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->astream, s->ev_prep, 0));
+        k_launch_deblock_bands(dctx, h->mbh, 0, h->ov_bands_a, h->d_progress, d_err, h->astream);   // A first ...
+        HIPCHK(hipEventRecord(s->ev_a, h->astream));
+        if (prof) HIPCHK(hipEventRecord(s->ev[10], h->astream));
+        k_launch_deblock_bands(dctx, h->mbh, h->ov_bands_a, nb, h->d_progress, d_err, h->stream);  // ... then B
+        HIPCHK(hipGetLastError());
+    } else {
+        int r = run_deblock(h, ci); if (r) return r;
+        if (h->ov_bands_a > 0) HIPCHK(hipEventRecord(s->ev_a, h->stream)); // only a later overlapped picture waits on it
+    }
     if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
-    // Hand-over on the second stream, enqueued after the deblocking launch so that it cannot be dispatched ahead of it:
+    // Hand-over on the third stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:
     // the device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
     HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
-    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, h->d_progress + h->n_progress, h->cstream);
+    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, d_err, h->cstream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->done, h->cstream));
     h->n_submitted++;
     s->is_idr = idr; s->qp = qp; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
-    s->pts = pts; s->rec_index = nxt; s->set = set;
+    s->pts = pts; s->rec_index = nxt; s->set = set; s->overlapped = ov ? 1 : 0; s->prof = prof;
     if (idr) h->idr_count++;
     h->frames_since_idr++;
-    h->cur = nxt; h->have_ref = 1;
+    h->cur = nxt; h->have_ref = 1; h->prev_slot = s;
     h->head = (h->head + 1) % NSLOT; h->pending++;
     return MI355ENC_OK;
 }
@@ -342,14 +432,15 @@ int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[h->head];
     const int w = h->cfg.width, ht = h->cfg.height;
-    HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, y, y_stride, w, ht, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, h->stream));
-    if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, h->stream);
+    hipStream_t up = upload_stream(h, force_idr);
+    HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, y, y_stride, w, ht, hipMemcpyHostToDevice, up));
+    HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, up));
+    if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
     return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }
 
 // Upload the planes of a non-NV12 picture tightly into the slot's raw staging buffer and convert into its NV12 staging surfaces.
-static int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const planes[3], const int strides[3]) {
+static int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const planes[3], const int strides[3], hipStream_t up) {
     const int w = h->cfg.width, ht = h->cfg.height;
     if (fmt < MI355ENC_FMT_I420 || fmt > MI355ENC_FMT_UYVY || !planes || !strides || !planes[0]) return MI355ENC_ERR_ARG;
     if (!s->d_raw) HIPCHK(hipMalloc((void **)&s->d_raw, (size_t)(2 * h->W + 32) * h->H + 64));
@@ -357,15 +448,15 @@ static int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *
         if (!planes[1] || !planes[2] || strides[0] < w || strides[1] < w / 2 || strides[2] < w / 2) return MI355ENC_ERR_ARG;
         const int r0 = (w + 15) & ~15, r1 = (w / 2 + 15) & ~15;
         uint8_t *dy = s->d_raw, *du = dy + (size_t)r0 * ht, *dv = du + (size_t)r1 * (ht / 2);
-        HIPCHK(hipMemcpy2DAsync(dy, r0, planes[0], strides[0], w, ht, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpy2DAsync(du, r1, planes[1], strides[1], w / 2, ht / 2, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpy2DAsync(dv, r1, planes[2], strides[2], w / 2, ht / 2, hipMemcpyHostToDevice, h->stream));
-        if (k_launch_csc(fmt, dy, du, dv, r0, r1, r1, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, h->stream)) return MI355ENC_ERR_ARG;
+        HIPCHK(hipMemcpy2DAsync(dy, r0, planes[0], strides[0], w, ht, hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpy2DAsync(du, r1, planes[1], strides[1], w / 2, ht / 2, hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpy2DAsync(dv, r1, planes[2], strides[2], w / 2, ht / 2, hipMemcpyHostToDevice, up));
+        if (k_launch_csc(fmt, dy, du, dv, r0, r1, r1, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, up)) return MI355ENC_ERR_ARG;
     } else {
         if (strides[0] < 2 * w) return MI355ENC_ERR_ARG;
         const int r0 = (2 * w + 15) & ~15;
-        HIPCHK(hipMemcpy2DAsync(s->d_raw, r0, planes[0], strides[0], 2 * w, ht, hipMemcpyHostToDevice, h->stream));
-        if (k_launch_csc(fmt, s->d_raw, nullptr, nullptr, r0, 0, 0, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, h->stream)) return MI355ENC_ERR_ARG;
+        HIPCHK(hipMemcpy2DAsync(s->d_raw, r0, planes[0], strides[0], 2 * w, ht, hipMemcpyHostToDevice, up));
+        if (k_launch_csc(fmt, s->d_raw, nullptr, nullptr, r0, 0, 0, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, up)) return MI355ENC_ERR_ARG;
     }
     HIPCHK(hipGetLastError());
     return MI355ENC_OK;
@@ -377,7 +468,7 @@ int mi355enc_submit_fmt(mi355enc_t *h, int fmt, const uint8_t *const planes[3], 
     if (h->pending > h->cfg.pipeline_depth) return MI355ENC_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[h->head];
-    int r = upload_and_convert(h, s, fmt, planes, strides);
+    int r = upload_and_convert(h, s, fmt, planes, strides, upload_stream(h, force_idr));
     if (r) return r;
     return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }
@@ -386,7 +477,7 @@ int mi355enc_stage_csc(mi355enc_t *h, int fmt, const uint8_t *const planes[3], c
     if (!h || !out_y || !out_uv || h->pending) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[0];
-    int r = upload_and_convert(h, s, fmt, planes, strides);
+    int r = upload_and_convert(h, s, fmt, planes, strides, h->stream);
     if (r) return r;
     HIPCHK(hipMemcpyAsync(out_y, s->d_src_y, h->ysz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(out_uv, s->d_src_uv, h->csz, hipMemcpyDeviceToHost, h->stream));
@@ -400,11 +491,12 @@ int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const v
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[h->head];
     const int w = h->cfg.width, ht = h->cfg.height;
+    hipStream_t up = upload_stream(h, force_idr);
     const bool direct = w == h->W && y_stride == uv_stride && (y_stride & 15) == 0 && (((uintptr_t)d_y | (uintptr_t)d_uv) & 15) == 0;
     if (direct) return enqueue_picture(h, s, (const uint8_t *)d_y, (const uint8_t *)d_uv, y_stride, pts, force_idr);
-    HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, d_y, y_stride, w, ht, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, d_uv, uv_stride, w, ht / 2, hipMemcpyDeviceToDevice, h->stream));
-    if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, h->stream);
+    HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, d_y, y_stride, w, ht, hipMemcpyDeviceToDevice, up));
+    HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, d_uv, uv_stride, w, ht / 2, hipMemcpyDeviceToDevice, up));
+    if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
     return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }
 
@@ -434,17 +526,25 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     if (pts) *pts = s->pts;
     if (qp) *qp = s->qp;
     rc_update(&h->rc, s->is_idr, s->qp, n + m);
-    if (h->cfg.profile_events) {
-        float a = 0, b = 0, c = 0, tot = 0, sp = 0;
+    if (s->prof) {
+        float a = 0, b = 0, c = 0, tot = 0, sp = 0, t = 0;
         HIPCHK(hipEventSynchronize(s->ev[4])); // the access unit is ready before deblocking ends; the stage timers are not
+        if (s->overlapped) HIPCHK(hipEventSynchronize(s->ev[10]));
         (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
-        if (!s->is_idr) { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[2]); h->st.ms_subpel += sp; }
+        if (!s->is_idr) { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
+        if (s->overlapped) { // the upper part ran on the other stream: kernel times add up
+            (void)hipEventElapsedTime(&t, s->ev[6], s->ev[7]); a += t;
+            (void)hipEventElapsedTime(&t, s->ev[7], s->ev[8]); sp += t;
+            (void)hipEventElapsedTime(&t, s->ev[8], s->ev[9]); b += t;
+        }
         (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
-        (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]);
+        if (s->overlapped) { (void)hipEventElapsedTime(&t, s->ev[2], s->ev[10]); if (t > c) c = t; (void)hipEventElapsedTime(&tot, s->ev[6], s->ev[4]); }
+        else (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]);
         if (s->is_idr) { h->st.ms_intra += a; h->st.n_intra++; }
-        else { h->st.ms_me += a; h->st.n_me++; h->st.ms_inter += b; h->st.n_inter++; }
+        else { h->st.ms_me += a; h->st.n_me++; h->st.ms_inter += b; h->st.n_inter++; h->st.ms_subpel += sp; }
         h->st.ms_deblock += c; h->st.n_deblock++;
-        h->st.ms_total_gpu += tot;
+        if (s->is_idr) { h->st.ms_deblock_idr += c; h->st.n_deblock_idr++; }
+        h->st.ms_total_gpu += tot; h->st.n_total_gpu++;
     }
     h->st.frames++; h->st.idr_frames += s->is_idr; h->st.bytes += n + m;
     h->st.last_qp = (uint32_t)s->qp; h->st.last_bytes = (uint32_t)(n + m); h->st.target_bps = h->want_bps.load();
@@ -487,6 +587,7 @@ int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
     if (!src) return MI355ENC_ERR_STATE;
     if (n < need) return MI355ENC_ERR_OVERFLOW;
     if (host) { memcpy(dst, src, need); return MI355ENC_OK; }
+    HIPCHK(hipStreamSynchronize(h->astream));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
     return MI355ENC_OK;
@@ -500,6 +601,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     c->src_y = src_is_staging ? s->d_src_y : nullptr; c->src_uv = src_is_staging ? s->d_src_uv : nullptr; c->src_stride = h->W;
     c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
     HIPCHK(hipStreamSynchronize(h->cstream));
+    HIPCHK(hipStreamSynchronize(h->astream));
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
@@ -511,7 +613,7 @@ int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y,
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, cur_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    k_launch_me(h->d_ctx, h->mbw, h->mbh, h->stream);
+    k_launch_me(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
     HIPCHK(hipMemcpyAsync(mbinfo_out, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
@@ -523,7 +625,7 @@ int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *re
     HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    k_launch_subpel(h->d_ctx, h->mbw, h->mbh, h->stream);
+    k_launch_subpel(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
     HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
@@ -538,7 +640,7 @@ int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
     HIPCHK(hipMemcpyAsync(h->d_rec_uv[0], ref_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
+    k_launch_inter(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
     HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
@@ -553,7 +655,7 @@ int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    r = run_intra(h); if (r) return r;
+    r = run_intra(h, 0); if (r) return r;
     HIPCHK(hipMemcpyAsync(mbinfo_out, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
@@ -579,7 +681,7 @@ int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const
     HIPCHK(hipMemcpyAsync(h->d_rec_uv[1], rec_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, 26, false); if (r) return r;
-    r = run_deblock(h); if (r) return r;
+    r = run_deblock(h, 0); if (r) return r;
     HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -599,16 +701,16 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
     for (int warm = 0; warm < 2; warm++) {
         if (warm) HIPCHK(hipEventRecord(s->ev[0], h->stream));
         for (int i = 0; i < (warm ? iters : 1); i++) {
-            if (stage == 0) k_launch_me(h->d_ctx, h->mbw, h->mbh, h->stream);
-            else if (stage == 1) k_launch_inter(h->d_ctx, h->mbw, h->mbh, h->stream);
-            else if (stage == 2) { int r = run_intra(h); if (r) return r; }
-            else if (stage == 4) k_launch_subpel(h->d_ctx, h->mbw, h->mbh, h->stream);
+            if (stage == 0) k_launch_me(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
+            else if (stage == 1) k_launch_inter(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
+            else if (stage == 2) { int r = run_intra(h, 0); if (r) return r; }
+            else if (stage == 4) k_launch_subpel(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage >= 5) {
                 const int w = h->cfg.width, ht = h->cfg.height, r0 = stage == 5 ? (w + 15) & ~15 : (2 * w + 15) & ~15, r1 = (w / 2 + 15) & ~15;
                 const uint8_t *p0 = s->d_raw, *p1 = p0 + (size_t)r0 * ht, *p2 = p1 + (size_t)r1 * (ht / 2);
                 k_launch_csc(stage - 4, p0, p1, p2, r0, r1, r1, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, h->stream);
             }
-            else { int r = run_deblock(h); if (r) return r; }
+            else { int r = run_deblock(h, 0); if (r) return r; }
         }
         if (warm) HIPCHK(hipEventRecord(s->ev[1], h->stream));
     }

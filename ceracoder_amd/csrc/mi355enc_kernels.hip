@@ -128,13 +128,13 @@ DEV int mv_bits(int v) { // bits of se(4v): 1 for 0, else 7 + 2*floor(log2|v|)
     return a == 0 ? 1 : 7 + 2 * (31 - __clz(a));
 }
 
-__global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t *__restrict__ ctx) {
+__global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t *__restrict__ ctx, int row0) {
     __shared__ unsigned win[ME_ROWS * ME_STRIDE];
     const int stride = ctx->stride, mbw = ctx->mbw, mbh = ctx->mbh;
     const int W = mbw * 16, H = mbh * 16;
     const int strips = (mbw + ME_MBS - 1) / ME_MBS;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int my = tile / strips, sx = tile - my * strips;
+    const int my = row0 + tile / strips, sx = tile % strips; // the launch covers macroblock rows row0 .. row0 + gridDim.x / strips - 1
     const int t = threadIdx.x;
     const uint8_t *__restrict__ ref = ctx->ref_y;
 
@@ -392,6 +392,14 @@ DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int c
 // 18 x 18 (+1) grid; every quarter-sample candidate is then the rounded average of two plane
 // entries (Table 8-12).  Two rounds (step 2, then step 1) of the 8 neighbours, visited in
 // (dy, dx) raster order, strictly-lower cost wins -- the oracle's orc_subpel_frame.
+// sum over the 16 lanes of a DPP row (every lane receives it)
+DEV int wave16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false); // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // quad_perm:[1,0,3,2]
+    return v;
+}
 #define SP_GS 24 /* G row stride (23 used) */
 #define SP_PS 20 /* plane row stride (18/19 used) */
 struct sp_lds {
@@ -400,50 +408,68 @@ struct sp_lds {
     uint8_t b[19 * SP_PS];     // rows iy-1 .. iy+17, cols ix-1 .. ix+16
     uint8_t h[18 * SP_PS];     // rows iy-1 .. iy+16, cols ix-1 .. ix+17
     uint8_t j[18 * SP_PS];     // rows iy-1 .. iy+16, cols ix-1 .. ix+16
+    uint8_t pad[16];           // lds4() may read one word past the last sample of a plane
 };
 DEV int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
 DEV int mvq_bits(int q) { // bits of se(q)
     unsigned k = q > 0 ? (unsigned)(2 * q - 1) : (unsigned)(-2 * q);
     return 2 * (31 - __clz((int)(k + 1))) + 1;
 }
-// value of the luma sample at plane position (X, Y) (plane coordinates: 0 = ix-1 / iy-1) and fraction (fx, fy)
-DEV int sp_sample(const sp_lds *L, int X, int Y, int fx, int fy) {
-#define SG(x, y) ((int)L->G[((y) + 2) * SP_GS + (x) + 2])
-#define SB(x, y) ((int)L->b[(y) * SP_PS + (x)])
-#define SH(x, y) ((int)L->h[(y) * SP_PS + (x)])
-#define SJ(x, y) ((int)L->j[(y) * SP_PS + (x)])
+// four horizontally adjacent bytes of an LDS plane starting at byte offset `o` (any alignment): two aligned words + one v_alignbyte
+DEV unsigned lds4(const uint8_t *plane, int o) {
+    const unsigned *w = (const unsigned *)(plane + (o & ~3));
+    return __builtin_amdgcn_alignbyte(w[1], w[0], (unsigned)(o & 3));
+}
+DEV unsigned avg4(unsigned a, unsigned b) { return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu); } // per byte (a + b + 1) >> 1
+// the four luma samples at plane positions (X..X+3, Y) (plane coordinates: 0 = ix-1 / iy-1) and fraction (fx, fy), one per byte
+// (8.4.2.2.1, Table 8-12).  fx, fy are wave-uniform, so the case analysis costs no divergence.
+DEV unsigned sp_sample4(const sp_lds *L, int X, int Y, int fx, int fy) {
+#define SG(x, y) lds4(L->G, ((y) + 2) * SP_GS + (x) + 2)
+#define SB(x, y) lds4(L->b, (y) * SP_PS + (x))
+#define SH(x, y) lds4(L->h, (y) * SP_PS + (x))
+#define SJ(x, y) lds4(L->j, (y) * SP_PS + (x))
     if (fy == 0) {
         if (fx == 0) return SG(X, Y);
-        return fx == 2 ? SB(X, Y) : fx == 1 ? (SG(X, Y) + SB(X, Y) + 1) >> 1 : (SG(X + 1, Y) + SB(X, Y) + 1) >> 1;
+        return fx == 2 ? SB(X, Y) : fx == 1 ? avg4(SG(X, Y), SB(X, Y)) : avg4(SG(X + 1, Y), SB(X, Y));
     }
-    if (fx == 0) return fy == 2 ? SH(X, Y) : fy == 1 ? (SG(X, Y) + SH(X, Y) + 1) >> 1 : (SG(X, Y + 1) + SH(X, Y) + 1) >> 1;
-    if ((fx & 1) && (fy & 1)) return ((fy == 1 ? SB(X, Y) : SB(X, Y + 1)) + (fx == 1 ? SH(X, Y) : SH(X + 1, Y)) + 1) >> 1;
+    if (fx == 0) return fy == 2 ? SH(X, Y) : fy == 1 ? avg4(SG(X, Y), SH(X, Y)) : avg4(SG(X, Y + 1), SH(X, Y));
+    if ((fx & 1) && (fy & 1)) return avg4(fy == 1 ? SB(X, Y) : SB(X, Y + 1), fx == 1 ? SH(X, Y) : SH(X + 1, Y));
     if (fx == 2 && fy == 2) return SJ(X, Y);
-    if (fx == 2) return ((fy == 1 ? SB(X, Y) : SB(X, Y + 1)) + SJ(X, Y) + 1) >> 1;
-    return ((fx == 1 ? SH(X, Y) : SH(X + 1, Y)) + SJ(X, Y) + 1) >> 1;
+    if (fx == 2) return avg4(fy == 1 ? SB(X, Y) : SB(X, Y + 1), SJ(X, Y));
+    return avg4(fx == 1 ? SH(X, Y) : SH(X + 1, Y), SJ(X, Y));
 #undef SG
 #undef SB
 #undef SH
 #undef SJ
 }
-__global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t *__restrict__ ctx) {
+__global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t *__restrict__ ctx, int mb0, int mb1) {
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int mbn = blockIdx.x * 4 + wave;
-    const bool ok = mbn < mbw * mbh;
-    if (!ok) mbn = mbw * mbh - 1;
+    int mbn = mb0 + blockIdx.x * 4 + wave; // the launch covers macroblocks mb0 .. mb1-1
+    const bool ok = mbn < mb1;
+    if (!ok) mbn = mb1 - 1;
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
     sp_lds *L = &LD[wave];
     const mb_info_t info = ld_mbinfo(&ctx->mbi[mbn]);
     const int ix = x0 + (info.mvx >> 2), iy = y0 + (info.mvy >> 2); // integer winner (vector is a multiple of 4 here)
     const uint8_t *__restrict__ ref = ctx->ref_y;
-    // ---- G with the picture extended by coordinate clamping (8.4.2.2.1)
-    for (int i = lane; i < 23 * 23; i += 64) {
-        int r = i / 23, c = i - r * 23;
-        int yy = clip3(0, H - 1, iy - 3 + r), xx = clip3(0, W - 1, ix - 3 + c);
-        L->G[r * SP_GS + c] = (uint8_t)ldg8(ref + (size_t)yy * stride + xx);
-    }
+    // ---- G with the picture extended by coordinate clamping (8.4.2.2.1).  Window fully inside the picture (the usual
+    // case, wave-uniform): 23 rows x 7 aligned words, shifted into place with v_alignbyte; otherwise byte by byte.
+    if (ix - 3 >= 0 && iy - 3 >= 0 && ((ix - 3) & ~3) + 28 <= W && iy + 19 < H) {
+        const int a = (ix - 3) & 3;
+        const uint8_t *base = ref + (size_t)(iy - 3) * stride + ((ix - 3) & ~3);
+        for (int i = lane; i < 23 * 6; i += 64) {
+            const int r = i / 6, d = i - r * 6;
+            const unsigned w0 = ldg32(base + (size_t)r * stride + 4 * d), w1 = ldg32(base + (size_t)r * stride + 4 * d + 4);
+            *(unsigned *)&L->G[r * SP_GS + 4 * d] = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)a);
+        }
+    } else
+        for (int i = lane; i < 23 * 23; i += 64) {
+            int r = i / 23, c = i - r * 23;
+            int yy = clip3(0, H - 1, iy - 3 + r), xx = clip3(0, W - 1, ix - 3 + c);
+            L->G[r * SP_GS + c] = (uint8_t)ldg8(ref + (size_t)yy * stride + xx);
+        }
     // current macroblock: lane owns row lane>>2, columns 4*(lane&3) .. +3
     const int pr = lane >> 2, pc = (lane & 3) * 4;
     unsigned curw;
@@ -477,25 +503,37 @@ __global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t *__restri
         L->j[r * SP_PS + c] = (uint8_t)clip255((v + 512) >> 10);
     }
     WAVE_SYNC();
-    // ---- two refinement rounds
+    // ---- two refinement rounds (half, then quarter).  The 8 candidates of a round are scored together: per lane one
+    // v_sad_u8 over its 4 pixels each, two 16-bit partial sums per register (64 lanes x 1020 < 65536), one wave reduction
+    // for all of them; then the candidates are compared in scan order with a strict `<`, as the oracle does.
     const int lambda = ctx->lambda;
     int bqx = info.mvx, bqy = info.mvy;
     unsigned best = info.cost;
 #pragma unroll 1
     for (int step = 2; step >= 1; step--) {
         const int cqx = bqx, cqy = bqy;
-#pragma unroll 1
-        for (int k = 0; k < 9; k++) {
-            if (k == 4) continue;
+        unsigned acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c8 = 0; c8 < 8; c8++) {
+            const int k = c8 < 4 ? c8 : c8 + 1;
             const int qx = cqx + (k % 3 - 1) * step, qy = cqy + (k / 3 - 1) * step;
             const int ox = qx - info.mvx, oy = qy - info.mvy;               // -3 .. 3 relative to the integer winner
             const int X = 1 + (ox >> 2) + pc, Y = 1 + (oy >> 2) + pr;       // plane coordinates of this lane's first pixel
-            const int fx = ox & 3, fy = oy & 3;
-            unsigned sad = 0;
+            const unsigned sad = __builtin_amdgcn_sad_u8(curw, sp_sample4(L, X, Y, ox & 3, oy & 3), 0u);
+            acc[c8 >> 1] |= sad << (16 * (c8 & 1));
+        }
 #pragma unroll
-            for (int i = 0; i < 4; i++) sad += (unsigned)iabs(byte_of(curw, i) - sp_sample(L, X + i, Y, fx, fy));
+        for (int q = 0; q < 4; q++) {
+            int v = wave16_sum((int)acc[q]);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[q] = (unsigned)v;
+        }
 #pragma unroll
-            for (int sft = 32; sft >= 1; sft >>= 1) sad += (unsigned)__shfl_xor((int)sad, sft, 64);
+        for (int c8 = 0; c8 < 8; c8++) {
+            const int k = c8 < 4 ? c8 : c8 + 1;
+            const int qx = cqx + (k % 3 - 1) * step, qy = cqy + (k / 3 - 1) * step;
+            const unsigned sad = (acc[c8 >> 1] >> (16 * (c8 & 1))) & 0xFFFFu;
             const unsigned cost = sad + (unsigned)(lambda * (mvq_bits(qx) + mvq_bits(qy)));
             if (cost < best) { best = cost; bqx = qx; bqy = qy; }
         }
@@ -582,16 +620,16 @@ DEV int qpel_nb(const int (*n)[NC], int i, int jj, int fx, int fy) {
 // =================================================================== inter (P) macroblocks
 // One wave = two macroblocks.  Lanes 0-31: one 4x4 luma block each (MB = lane>>4);
 // lanes 32-47: one 4x4 chroma block each (MB = (lane-32)>>3); lanes 48-63 idle.
-__global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restrict__ ctx) {
-    const int mbw = ctx->mbw, nmb = mbw * ctx->mbh, stride = ctx->stride, qp = ctx->qp;
+__global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restrict__ ctx, int mb0, int mb1) {
+    const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
     const int W = mbw * 16, H = ctx->mbh * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.x * 4 + wave;
     const bool is_luma = lane < 32, is_chroma = lane >= 32 && lane < 48;
     const int sel = is_luma ? lane >> 4 : (is_chroma ? (lane - 32) >> 3 : 0);
-    int mbn = pair * 2 + sel;
-    const bool mb_ok = mbn < nmb;
-    if (!mb_ok) mbn = nmb - 1;
+    int mbn = mb0 + pair * 2 + sel; // the launch covers macroblocks mb0 .. mb1-1
+    const bool mb_ok = mbn < mb1;
+    if (!mb_ok) mbn = mb1 - 1;
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
     const mb_info_t info = ld_mbinfo(&ctx->mbi[mbn]);
     // quarter-sample vector; the clamp only guards against garbage records (real vectors are far inside it)
@@ -824,13 +862,6 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restric
 }
 
 // sum over each row of 16 lanes, result in every lane: four DPP adds (no LDS crossbar round trips)
-DEV int wave16_sum(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); // row_ror:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false); // row_ror:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm:[2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // quad_perm:[1,0,3,2]
-    return v;
-}
 // value of lane k of this lane's quad (k = 0..3), and of row r of this lane's column in a 4x4 tile laid out on 16 lanes
 template <int K> DEV int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, false); }
 
@@ -1481,7 +1512,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { const frame_ctx_t *ctx; unsigned *progress; unsigned *err; };
+struct db_args { const frame_ctx_t *ctx; unsigned *progress; unsigned *err; int band0, nb_total; }; // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: 16-row bands in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -1815,9 +1846,9 @@ DEV void band16_body(const db_args a, const int band, const int nb, uint8_t *lds
 
 __global__ __launch_bounds__(256) void deblock_band16_kernel(db_args a) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[D3_ROWS * sizeof(d3_luma)];
-    const int nb = gridDim.x >> 1;
-    if ((int)blockIdx.x < nb) band16_body<false>(a, blockIdx.x, nb, lds);
-    else band16_body<true>(a, blockIdx.x - nb, nb, lds);
+    const int nl = gridDim.x >> 1;
+    if ((int)blockIdx.x < nl) band16_body<false>(a, a.band0 + blockIdx.x, a.nb_total, lds);
+    else band16_body<true>(a, a.band0 + blockIdx.x - nl, a.nb_total, lds);
 }
 
 // =================================================================== hand-over to the host entropy coder
@@ -1907,16 +1938,18 @@ __global__ void pad_kernel(uint8_t *y, uint8_t *uv, int stride, int vw, int vh, 
 int k_intra_diags(int mbw, int mbh) { return mbw + mbh - 1; }
 int k_deblock_diags(int mbw, int mbh) { return mbw + 2 * (mbh - 1); }
 
-void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
+// The three P-picture kernels take a macroblock-row range [row0, row1): the host overlaps the upper part of picture n+1
+// with the tail of picture n's deblocking (mi355enc.cpp, enqueue_picture).
+void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int row0, int row1, hipStream_t s) {
     int strips = (mbw + ME_MBS - 1) / ME_MBS;
-    hipLaunchKernelGGL(me_kernel, dim3(strips * mbh), dim3(64 * ME_MBS), 0, s, d_ctx);
+    if (row1 > row0) hipLaunchKernelGGL(me_kernel, dim3(strips * (row1 - row0)), dim3(64 * ME_MBS), 0, s, d_ctx, row0);
 }
-void k_launch_subpel(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
-    hipLaunchKernelGGL(subpel_kernel, dim3((mbw * mbh + 3) / 4), dim3(256), 0, s, d_ctx);
+void k_launch_subpel(const frame_ctx_t *d_ctx, int mbw, int row0, int row1, hipStream_t s) {
+    if (row1 > row0) hipLaunchKernelGGL(subpel_kernel, dim3((mbw * (row1 - row0) + 3) / 4), dim3(256), 0, s, d_ctx, row0 * mbw, row1 * mbw);
 }
-void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
-    int pairs = (mbw * mbh + 1) / 2;
-    hipLaunchKernelGGL(inter_kernel, dim3((pairs + 3) / 4), dim3(256), 0, s, d_ctx);
+void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int row0, int row1, hipStream_t s) {
+    int pairs = (mbw * (row1 - row0) + 1) / 2;
+    if (row1 > row0) hipLaunchKernelGGL(inter_kernel, dim3((pairs + 3) / 4), dim3(256), 0, s, d_ctx, row0 * mbw, row1 * mbw);
 }
 void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
     hipLaunchKernelGGL(intra_analyse_kernel, dim3((mbw * mbh + 3) / 4), dim3(256), 0, s, d_ctx);
@@ -1935,12 +1968,16 @@ void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag,
     hipLaunchKernelGGL(deblock_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
 }
 int k_deblock_bands16(int mbh) { return (mbh + D3_ROWS - 1) / D3_ROWS; }
-// prep + 16-row bands; `d_progress` holds 2 * bands counters (luma, chroma) followed by the error word at d_err
-void k_launch_deblock_band16(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, unsigned *d_err, hipStream_t s) {
-    db_args a;
-    a.ctx = d_ctx; a.progress = d_progress; a.err = d_err;
+// `d_progress` holds 2 * bands counters (luma, chroma) followed by the sticky error word at d_err.  The prep kernel clears
+// the counters; the band kernel may be launched in several pieces (bands [band0, band1)): a band only ever waits for the
+// band above it, so pieces may run concurrently on different streams as long as the upper piece is submitted first.
+void k_launch_deblock_prep(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, hipStream_t s) {
     hipLaunchKernelGGL(deblock_prep_kernel, dim3((mbw * mbh + 255) / 256), dim3(256), 0, s, d_ctx, d_progress, nprog);
-    hipLaunchKernelGGL(deblock_band16_kernel, dim3(2 * k_deblock_bands16(mbh)), dim3(256), 0, s, a);
+}
+void k_launch_deblock_bands(const frame_ctx_t *d_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
+    db_args a;
+    a.ctx = d_ctx; a.progress = d_progress; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh);
+    if (band1 > band0) hipLaunchKernelGGL(deblock_band16_kernel, dim3(2 * (band1 - band0)), dim3(256), 0, s, a);
 }
 // =================================================================== input conversion to NV12
 // Replaces the `videoconvert` hop of the reference's pipelines for the raw formats its sources deliver
@@ -1956,9 +1993,6 @@ struct csc_args {
     uint8_t *dy, *duv;           // NV12 destination, coded size W x H, stride W
     int vw, vh, W, H;            // visible and coded size
 };
-DEV unsigned avg4(unsigned a, unsigned b) { // per-byte (a + b + 1) >> 1 without carries between bytes
-    return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu);
-}
 template <int FMT> // 1 I420, 2 YUY2 (Y0 U Y1 V), 3 UYVY (U Y0 V Y1)
 __global__ __launch_bounds__(256) void csc_kernel(csc_args a) {
     const int tx = blockIdx.x * 256 + threadIdx.x, per_row = a.W >> 3, rows2 = a.H >> 1;

@@ -36,7 +36,7 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
                 ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
-                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int)]
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("overlap", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -44,7 +44,7 @@ class Stats(C.Structure):
                 ("last_bytes", C.c_uint32), ("target_bps", C.c_uint32), ("ms_me", C.c_double), ("ms_inter", C.c_double),
                 ("ms_intra", C.c_double), ("ms_deblock", C.c_double), ("ms_total_gpu", C.c_double), ("ms_subpel", C.c_double), ("n_me", C.c_uint64),
                 ("n_inter", C.c_uint64), ("n_intra", C.c_uint64), ("n_deblock", C.c_uint64), ("ms_entropy", C.c_double),
-                ("ms_wait", C.c_double)]
+                ("ms_wait", C.c_double), ("n_total_gpu", C.c_uint64), ("ms_deblock_idr", C.c_double), ("n_deblock_idr", C.c_uint64)]
 
 
 _lib = None
@@ -156,7 +156,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, overlap=False):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
@@ -164,6 +164,7 @@ class Encoder:
         cfg.pipeline_depth, cfg.profile_events, cfg.use_graphs, cfg.keep_prefilter = (
             pipeline_depth, int(profile_events), int(use_graphs), int(keep_prefilter))
         cfg.deblock_mode = deblock_mode
+        cfg.overlap = int(overlap)
         cfg.subpel = int(subpel)
         cfg.i4x4 = int(i4x4)
         cfg.transform8x8 = int(transform8x8)

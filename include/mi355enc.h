@@ -51,7 +51,9 @@ typedef struct {
     int qp_min, qp_max;       /* rate-control clamp; 0,0 -> defaults 10..51                */
     int pipeline_depth;       /* 0: encode() returns this frame's AU; 1: host entropy coding
                                  of frame n overlaps device work of frame n+1             */
-    int profile_events;       /* 1: bracket every kernel stage with HIP events (stats)    */
+    int profile_events;       /* k > 0: bracket the kernel stages of every k-th picture (and every IDR) with HIP events
+                                 for the stage statistics; an event record costs ~5 us of queue time, so k = 1 slows
+                                 the stream by several per cent */
     int use_graphs;           /* 1: replay the per-picture launch sequence as a hipGraph  */
     int keep_prefilter;       /* 1: keep a copy of the picture before deblocking (tests)  */
     int transform8x8;         /* 1: High-profile stream, P macroblocks use the 8x8 transform; 0 (default): Constrained Baseline */
@@ -59,17 +61,23 @@ typedef struct {
     int subpel;               /* 1 (default): half- then quarter-sample refinement after the integer search */
     int deblock_mode;         /* 0: boundary-strength prep kernel + persistent 16-row band kernel (x+y order);
                                  1: one launch per x+2y wavefront (plain form, kept as a cross-check) */
+    int overlap;              /* 1: start the upper rows of a P picture on a second stream while the lower bands of the previous
+                                 picture are still being deblocked (bit-identical output; measured neutral in r01 because the split
+                                 launches sit at their latency floor -- see DESIGN.md); 0 (default): one picture after the other */
 } mi355enc_cfg_t;
 
 typedef struct {
     uint64_t frames, idr_frames, bytes;
     uint32_t last_qp, last_bytes, target_bps;
-    /* accumulated device time per stage in ms and launch counts (profile_events=1) */
+    /* accumulated device time per stage in ms and sample counts (profile_events > 0) */
     double ms_me, ms_inter, ms_intra, ms_deblock, ms_total_gpu;
     double ms_subpel;
     uint64_t n_me, n_inter, n_intra, n_deblock;
     double ms_entropy;        /* host CAVLC wall time */
     double ms_wait;           /* host time blocked on the device */
+    uint64_t n_total_gpu;     /* pictures sampled into ms_total_gpu */
+    double ms_deblock_idr;    /* the part of ms_deblock / n_deblock that came from IDR pictures */
+    uint64_t n_deblock_idr;
 } mi355enc_stats_t;
 
 /* Fill cfg with the defaults of the element (gop 60, me_range 16, 2048 kbit/s like x264enc). */
