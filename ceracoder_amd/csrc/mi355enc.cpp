@@ -66,6 +66,7 @@ struct mi355enc {
     uint64_t n_submitted;
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
     uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock
+    uint8_t *d_idec;      // intra decisions, IDEC_BYTES per macroblock
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
     unsigned *d_progress; // [2*bands] strip counters of the band deblocker, then one error word
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
@@ -181,7 +182,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->astream = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->ov_bands_a = h->ov_rows_top = 0; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->ov_bands_a = h->ov_rows_top = 0; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -211,6 +212,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     }
     HIPCHK(hipMalloc((void **)&h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t)));
     HIPCHK(hipMalloc((void **)&h->d_dbrec, (size_t)h->nmb * 64));
+    HIPCHK(hipMalloc((void **)&h->d_idec, (size_t)h->nmb * IDEC_BYTES + 16));
     h->n_progress = 2 * k_deblock_bands16(h->mbh);
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
@@ -285,6 +287,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_pre_uv) (void)hipFree(h->d_pre_uv);
     if (h->d_isad) (void)hipFree(h->d_isad);
     if (h->d_dbrec) (void)hipFree(h->d_dbrec);
+    if (h->d_idec) (void)hipFree(h->d_idec);
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->d_off) (void)hipFree(h->d_off);
     for (int i = 0; i < 2; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
@@ -347,7 +350,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     c->src_y = src_y; c->src_uv = src_uv; c->src_stride = src_stride;
     c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
     c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
-    c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set]; c->isad = h->d_isad; c->dbrec = h->d_dbrec;
+    c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set]; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec;
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     // stage timers: an event record costs ~5 us of queue time, so profile_events = k samples every k-th picture (IDR pictures always)
@@ -602,7 +605,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
     HIPCHK(hipStreamSynchronize(h->cstream));
     HIPCHK(hipStreamSynchronize(h->astream));
-    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
+    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     return 0;
@@ -663,14 +666,15 @@ int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }
-int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, uint16_t *isad_out) {
-    if (!h || !src_y || !src_uv || !isad_out) return MI355ENC_ERR_ARG;
+int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, uint16_t *isad_out, void *idec_out) {
+    if (!h || !src_y || !src_uv || !isad_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
-    int r = stage_ctx(h, 26, true); if (r) return r;
+    int r = stage_ctx(h, qp, true); if (r) return r;
     k_launch_intra_analyse(h->d_ctx, h->mbw, h->mbh, h->stream);
     HIPCHK(hipMemcpyAsync(isad_out, h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    if (idec_out) HIPCHK(hipMemcpyAsync(idec_out, h->d_idec, (size_t)h->nmb * IDEC_BYTES, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }

@@ -21,6 +21,7 @@ typedef struct {
 
 #define MB_LEVELS 408
 #define ISAD_PER_MB 152
+#define IDEC_BYTES 24 /* intra decisions per macroblock: u8 modes4[16] (by blkIdx); u8 mode16, cmode, use_i4, 0; u32 cost */
 #define L_LUMA 0
 #define L_LDC 256
 #define L_CDC 272
@@ -40,6 +41,7 @@ typedef struct {
     mb_info_t *mbi;
     int16_t *levels;
     uint16_t *isad;                /* intra analysis: 152 u16 per macroblock {i16[4], chroma[4], i4[16][9]}, 0xFFFF = mode unavailable */
+    uint8_t *idec;                 /* intra decisions of intra_analyse_kernel, IDEC_BYTES per macroblock */
     uint8_t *dbrec;                /* deblocking: 64 B per macroblock {bS nibbles V, H; alpha/beta/tc0 of 6 edge classes} */
     int32_t src_stride;            /* bytes per source luma row (= chroma row, NV12)          */
     int32_t stride;                /* coded-surface stride = 16*mbw                           */

@@ -910,6 +910,8 @@ DEV bool mode4_ok(int b, int md, bool up, bool lf, bool ul) {
 }
 #define IA_S 24 /* luma tile stride: row 0 = y -1, col 0 = x -1 */
 __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *__restrict__ ctx) {
+    __shared__ uint16_t sh_sad[4][ISAD_PER_MB]; // this wave's macroblock: the same 152 values that go to ctx->isad
+    __shared__ int sh_m4[4][16];                // Intra_4x4 modes chosen so far, raster order
     __shared__ __attribute__((aligned(4))) uint8_t SL[4][17 * IA_S];
     __shared__ __attribute__((aligned(4))) uint8_t SC[4][2][9 * 12]; // [plane][row 0 = y -1][col 0 = x -1]
     const int mbw = ctx->mbw, nmb = mbw * ctx->mbh;
@@ -990,8 +992,9 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *_
         const unsigned o01 = (unsigned)__shfl_xor(packed01, 32), o23 = (unsigned)__shfl_xor(packed23, 32);
         const unsigned t0 = (a01 & 0xFFFF) + (o01 & 0xFFFF), t1 = (a01 >> 16) + (o01 >> 16), t2 = (a23 & 0xFFFF) + (o23 & 0xFFFF), t3 = (a23 >> 16) + (o23 >> 16);
         if (lane == 0 && ok) {
-            stg16(out + 0, (int)(has_top ? t0 : NA)); stg16(out + 1, (int)(has_left ? t1 : NA));
-            stg16(out + 2, (int)t2); stg16(out + 3, (int)((has_top && has_left) ? t3 : NA));
+            const unsigned v0 = has_top ? t0 : NA, v1 = has_left ? t1 : NA, v3 = (has_top && has_left) ? t3 : NA;
+            stg16(out + 0, (int)v0); stg16(out + 1, (int)v1); stg16(out + 2, (int)t2); stg16(out + 3, (int)v3);
+            sh_sad[wave][0] = (uint16_t)v0; sh_sad[wave][1] = (uint16_t)v1; sh_sad[wave][2] = (uint16_t)t2; sh_sad[wave][3] = (uint16_t)v3;
         }
     }
     // ---- chroma 8x8 (both planes): lane = plane lane>>5, row (lane>>2)&7, columns 2*(lane&3)..+1
@@ -1024,8 +1027,9 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *_
         const unsigned a01 = (unsigned)p01, a23 = (unsigned)p23, o01 = (unsigned)__shfl_xor(p01, 32), o23 = (unsigned)__shfl_xor(p23, 32);
         const unsigned t0 = (a01 & 0xFFFF) + (o01 & 0xFFFF), t1 = (a01 >> 16) + (o01 >> 16), t2 = (a23 & 0xFFFF) + (o23 & 0xFFFF), t3 = (a23 >> 16) + (o23 >> 16);
         if (lane == 0 && ok) {
-            stg16(out + 4, (int)t0); stg16(out + 5, (int)(has_left ? t1 : NA));
-            stg16(out + 6, (int)(has_top ? t2 : NA)); stg16(out + 7, (int)((has_top && has_left) ? t3 : NA));
+            const unsigned v1 = has_left ? t1 : NA, v2 = has_top ? t2 : NA, v3 = (has_top && has_left) ? t3 : NA;
+            stg16(out + 4, (int)t0); stg16(out + 5, (int)v1); stg16(out + 6, (int)v2); stg16(out + 7, (int)v3);
+            sh_sad[wave][4] = (uint16_t)t0; sh_sad[wave][5] = (uint16_t)v1; sh_sad[wave][6] = (uint16_t)v2; sh_sad[wave][7] = (uint16_t)v3;
         }
     }
     // ---- Intra_4x4: four blocks at a time, 16 lanes (pixels) each
@@ -1048,8 +1052,68 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *_
 #pragma unroll
             for (int md = 0; md < 9; md++) {
                 const int sad = wave16_sum(iabs(sv - pred4_px(md, px, py, E, dc4)));
-                if ((lane & 15) == 0 && ok) stg16(out + 8 + b * 9 + md, (int)(mode4_ok(b, md, up, lf, ul) ? (unsigned)sad : NA));
+                if ((lane & 15) == 0) {
+                    const unsigned v = mode4_ok(b, md, up, lf, ul) ? (unsigned)sad : NA;
+                    if (ok) stg16(out + 8 + b * 9 + md, (int)v);
+                    sh_sad[wave][8 + b * 9 + md] = (uint16_t)v;
+                }
             }
+        }
+    }
+    // ---- decisions (oracle: orc_intra_decide): nothing outside this macroblock is needed, so they are taken here, in
+    // the flat launch, and the reconstruction wavefront only reads the 24-byte result.
+    WAVE_SYNC();
+    {
+        const uint16_t *isad = sh_sad[wave];
+        const unsigned BIG = 0x10000000u;
+        const int lam = ctx->lambda;
+        int mode16 = 0, cmode = 0;
+        unsigned cost16 = BIG, costc = BIG;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned a = isad[q], c = isad[4 + q];
+            if (a != 0xFFFFu && a < cost16) { cost16 = a; mode16 = q; }
+            if (c != 0xFFFFu && c < costc) { costc = c; cmode = q; }
+        }
+        bool use_i4 = false;
+        unsigned cost_luma = cost16;
+        if (ctx->i4x4) { // Intra_4x4 modes block by block: SAD + lambda * (mode == expected ? 1 : 4); blocks visited along bx + 2*by
+            unsigned cost4 = 0;
+            const int half = (lane >> 4) & 1, cand = lane & 15;
+            int (*m4)[16] = &sh_m4[wave];
+#pragma unroll 1
+            for (int s4 = 0; s4 < 10; s4++) {
+                const int by_lo = s4 > 3 ? (s4 - 2) >> 1 : 0, by_hi = (s4 >> 1) < 3 ? (s4 >> 1) : 3;
+                const bool two = by_lo + 1 <= by_hi;
+                const bool valid = lane < 32 && (half == 0 || two);
+                const int by = (valid && half) ? by_lo + 1 : by_lo, bx = s4 - 2 * by;
+                const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1);
+                const int ma = bx > 0 ? (*m4)[by * 4 + bx - 1] : (has_left ? 2 : -1), mb_ = by > 0 ? (*m4)[(by - 1) * 4 + bx] : (has_top ? 2 : -1);
+                const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
+                unsigned key = 0x7FFFFFFFu;
+                if (cand < 9) {
+                    const unsigned sd = isad[8 + b * 9 + cand];
+                    if (sd != 0xFFFFu) key = ((sd + (unsigned)(lam * (cand == pm ? 1 : 4))) << 4) | (unsigned)cand;
+                }
+                key = (unsigned)wave16_min((int)key);
+                if (valid && cand == 0) (*m4)[by * 4 + bx] = (int)(key & 15);
+                cost4 += (unsigned)__shfl((int)(key >> 4), 0, 64) + (two ? (unsigned)__shfl((int)(key >> 4), 16, 64) : 0u);
+                WAVE_SYNC();
+            }
+            use_i4 = cost4 + (unsigned)(32 * lam) < cost16;
+            if (use_i4) cost_luma = cost4 + (unsigned)(32 * lam);
+        }
+        if (lane < 6 && ok) { // 24-byte record {u8 modes4[16] by blkIdx; u8 mode16, cmode, use_i4, 0; u32 cost}
+            unsigned w = 0;
+            if (lane < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int bb = lane * 4 + i, r = (blky(bb) >> 2) * 4 + (blkx(bb) >> 2);
+                    w |= (ctx->i4x4 ? (unsigned)sh_m4[wave][r] & 0xFF : 0u) << (8 * i);
+                }
+            } else if (lane == 4) w = (unsigned)mode16 | ((unsigned)cmode << 8) | ((use_i4 ? 1u : 0u) << 16);
+            else w = cost_luma + costc;
+            stg32(ctx->idec + (size_t)mbn * IDEC_BYTES + 4 * lane, w);
         }
     }
 }
@@ -1063,9 +1127,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     __shared__ unsigned tabw[TAB_DWORDS];
     __shared__ __attribute__((aligned(4))) uint8_t T4[17 * 24]; // Intra_4x4: reconstructed samples incl. the row above / column left
     __shared__ __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
-    __shared__ int sh_mode4[16], sh_nbm[8];
-    __shared__ unsigned sh_isadw[ISAD_PER_MB / 2];              // this macroblock's analysed SADs
-    const uint16_t *isad = (const uint16_t *)sh_isadw;
+    __shared__ int sh_mode4[16];
     const dev_tables *T = (const dev_tables *)tabw;
     const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
     const int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
@@ -1078,11 +1140,8 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     const bool is_luma = lane < 16, is_chroma = lane >= 16 && lane < 24;
     // ---- every global load is issued up front: tables, analysed SADs, neighbours, neighbour modes, this lane's source block
     for (int i = lane; i < TAB_DWORDS; i += 64) tabw[i] = ((const unsigned *)&g_tab)[i];
-    {
-        const unsigned *gi = (const unsigned *)(ctx->isad + (size_t)mbn * ISAD_PER_MB);
-        sh_isadw[lane] = ldg32(gi + lane);
-        if (lane < ISAD_PER_MB / 2 - 64) sh_isadw[64 + lane] = ldg32(gi + 64 + lane);
-    }
+    const uint4 dec0 = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES);              // modes4[16]
+    const uint2 dec1 = ldg64(ctx->idec + (size_t)mbn * IDEC_BYTES + 16);          // mode16, cmode, use_i4 | cost
     int (*top)[17] = sh_top;
     int (*left)[17] = sh_left;
     if (lane >= 24 && lane < 24 + 17) { // lanes 24-40: luma neighbours; index i+1 holds sample i, index 0 the corner
@@ -1093,18 +1152,6 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
         int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
         top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c) : 0;
         left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c) : 0;
-    }
-    if (lane < 8) { // Intra_4x4 modes of the neighbouring macroblocks' border blocks: -1 unavailable, 2 unless that MB is I4x4
-        const bool isl = lane < 4;
-        const int k = lane & 3, nb = isl ? mbn - 1 : mbn - mbw;
-        int v = -1;
-        if (isl ? has_left : has_top) {
-            const int blk = isl ? (k == 0 ? 5 : k == 1 ? 7 : k == 2 ? 13 : 15) : (k == 0 ? 10 : k == 1 ? 11 : k == 2 ? 14 : 15);
-            const unsigned ty = ldg8(&ctx->mbi[nb].mb_type);
-            const int md = ldg16(ctx->levels + (size_t)nb * MB_LEVELS + L_LDC + blk);
-            v = ty == 2 ? md : 2;
-        }
-        sh_nbm[lane] = v;
     }
     int src[16];
     if (lane < 24) {
@@ -1138,44 +1185,16 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     __syncthreads();
 #define TOP(p, i) top[p][(i) + 1]
 #define LEFT(p, i) left[p][(i) + 1]
-    const unsigned BIG = 0x10000000u;
-    const int lam = ctx->lambda;
-    // ---- decisions from the analysed SADs (oracle: orc_intra_frame).  Lowest SAD, ties to the lowest mode.
-    int mode16 = 0, cmode = 0;
-    unsigned cost16 = BIG, costc = BIG;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const unsigned a = isad[k], c = isad[4 + k];
-        if (a != 0xFFFFu && a < cost16) { cost16 = a; mode16 = k; }
-        if (c != 0xFFFFu && c < costc) { costc = c; cmode = k; }
+    // ---- decisions were taken by intra_analyse_kernel (oracle: orc_intra_decide)
+    const int mode16 = (int)(dec1.x & 255), cmode = (int)((dec1.x >> 8) & 255);
+    const bool use_i4 = ((dec1.x >> 16) & 255) != 0;
+    unsigned nz4 = 0;
+    if (use_i4 && lane < 16) { // raster order for the reconstruction loop
+        const int bb = ((lane >> 3) << 3) | (((lane & 3) >> 1) << 2) | (((lane >> 2) & 1) << 1) | (lane & 1); // raster (by = lane>>2, bx = lane&3) -> blkIdx
+        const unsigned w = bb < 4 ? dec0.x : bb < 8 ? dec0.y : bb < 12 ? dec0.z : dec0.w;
+        sh_mode4[lane] = (int)((w >> (8 * (bb & 3))) & 255);
     }
-    bool use_i4 = false;
-    unsigned nz4 = 0, cost_luma = cost16;
-    if (ctx->i4x4) { // Intra_4x4 modes block by block: SAD + lambda * (mode == predicted ? 1 : 4); blocks visited along bx + 2*by
-        unsigned cost4 = 0;
-        const int half = (lane >> 4) & 1, cand = lane & 15;
-#pragma unroll 1
-        for (int s4 = 0; s4 < 10; s4++) {
-            const int by_lo = s4 > 3 ? (s4 - 2) >> 1 : 0, by_hi = (s4 >> 1) < 3 ? (s4 >> 1) : 3;
-            const bool two = by_lo + 1 <= by_hi;
-            const bool valid = lane < 32 && (half == 0 || two);
-            const int by = (valid && half) ? by_lo + 1 : by_lo, bx = s4 - 2 * by;
-            const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1);
-            const int ma = bx > 0 ? sh_mode4[by * 4 + bx - 1] : sh_nbm[by], mb_ = by > 0 ? sh_mode4[(by - 1) * 4 + bx] : sh_nbm[4 + bx];
-            const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
-            unsigned key = 0x7FFFFFFFu;
-            if (cand < 9) {
-                const unsigned sd = isad[8 + b * 9 + cand];
-                if (sd != 0xFFFFu) key = ((sd + (unsigned)(lam * (cand == pm ? 1 : 4))) << 4) | (unsigned)cand;
-            }
-            key = (unsigned)wave16_min((int)key);
-            if (valid && cand == 0) sh_mode4[by * 4 + bx] = (int)(key & 15);
-            cost4 += (unsigned)__shfl((int)(key >> 4), 0, 64) + (two ? (unsigned)__shfl((int)(key >> 4), 16, 64) : 0u);
-            WAVE_SYNC();
-        }
-        use_i4 = cost4 + (unsigned)(32 * lam) < cost16;
-        if (use_i4) cost_luma = cost4 + (unsigned)(32 * lam);
-    }
+    WAVE_SYNC();
     int pred[16];
     int flags = 0;
     if (use_i4) {
@@ -1352,7 +1371,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
         if ((dcm >> 16) & 0xF0) nzm |= NZ_CRDC;
         mb_info_t mb;
         mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)mode16; mb.chroma_mode = (uint8_t)cmode;
-        mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = cost_luma + costc;
+        mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = dec1.y;
         st_mbinfo(&ctx->mbi[mbn], mb);
     }
 }

@@ -19,6 +19,7 @@ MBINFO_DTYPE = np.dtype(
 
 FETCH_RECON_Y, FETCH_RECON_UV, FETCH_PREFILTER_Y, FETCH_PREFILTER_UV, FETCH_MBINFO, FETCH_LEVELS = range(6)
 FMT_NV12, FMT_I420, FMT_YUY2, FMT_UYVY = range(4)
+IDEC = np.dtype([("modes4", "u1", (16,)), ("mode16", "u1"), ("cmode", "u1"), ("use_i4", "u1"), ("pad", "u1"), ("cost", "<u4")])
 STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK, STAGE_SUBPEL, STAGE_CSC_I420, STAGE_CSC_YUY2, STAGE_CSC_UYVY = range(8)
 
 EXPORTS = [
@@ -87,7 +88,7 @@ def load():
         L.mi355enc_stage_subpel.argtypes = [vp, vp, vp, C.c_int, vp]
         L.mi355enc_stage_inter.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
-        L.mi355enc_stage_intra_analyse.argtypes = [vp, vp, vp, vp]
+        L.mi355enc_stage_intra_analyse.argtypes = [vp, vp, vp, C.c_int, vp, vp]
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
         L.mi355enc_submit_fmt.argtypes = [vp, C.c_int, vp, vp, C.c_int64, C.c_int]
         L.mi355enc_stage_csc.argtypes = [vp, C.c_int, vp, vp, vp, vp]
@@ -289,10 +290,11 @@ class Encoder:
                                               _p(mbi), _p(rec_y), _p(rec_uv), _p(lev)), "stage_intra")
         return rec_y, rec_uv, mbi, lev
 
-    def stage_intra_analyse(self, src_y, src_uv):
+    def stage_intra_analyse(self, src_y, src_uv, qp=30):
         out = np.empty((self.mbw * self.mbh, 152), np.uint16)
-        self._chk(self.L.mi355enc_stage_intra_analyse(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)), _p(out)), "stage_intra_analyse")
-        return out
+        dec = np.zeros(self.mbw * self.mbh, IDEC)
+        self._chk(self.L.mi355enc_stage_intra_analyse(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)), qp, _p(out), _p(dec)), "stage_intra_analyse")
+        return out, dec
 
     def stage_deblock(self, rec_y, rec_uv, mbi):
         y, uv = np.ascontiguousarray(rec_y).copy(), np.ascontiguousarray(rec_uv).copy()

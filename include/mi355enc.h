@@ -144,8 +144,10 @@ int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
                          int16_t *levels);
 int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out,
                          uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
-/* open-loop intra analysis only: 152 uint16 per macroblock {i16[4], chroma[4], i4[16][9]}, 0xFFFF = mode unavailable */
-int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, uint16_t *isad_out);
+/* open-loop intra analysis only: 152 uint16 per macroblock {i16[4], chroma[4], i4[16][9]}, 0xFFFF = mode unavailable; and
+ * (idec_out may be NULL) the decisions taken from them at `qp`: 24 bytes per macroblock {u8 modes4[16] by luma4x4BlkIdx;
+ * u8 mode16, chroma mode, use_i4, 0; u32 cost} */
+int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, uint16_t *isad_out, void *idec_out);
 int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const void *mbinfo);
 /* Time `iters` back-to-back launches of one stage on the handle's stream with HIP events;
  * stage: 0 ME, 1 inter, 2 intra (whole wavefront), 3 deblock (whole wavefront), 4 sub-sample refinement,

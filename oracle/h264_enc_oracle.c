@@ -777,20 +777,18 @@ static int argmin_u16(const uint16_t *v, int n, uint32_t *best) {
     *best = b;
     return bi;
 }
-/* Intra_4x4 modes of one macroblock from the analysed SADs: per block lowest SAD + lambda * (mode == predicted ? 1 : 4),
- * ties to the lowest mode; the predicted mode follows 8.3.1.1.  Modes go to lev[ORC_L_LDC + blkIdx]. */
-static uint32_t intra4x4_choose(const orc_isad_t *sad, int mbw, int mx, int my, int lambda, const orc_mbinfo_t *mbi,
-                                const int16_t *levels, int16_t *lev) {
+/* Intra_4x4 modes of one macroblock from the analysed SADs: per block lowest SAD + lambda * (mode == expected ? 1 : 4),
+ * ties to the lowest mode.  "expected" follows 8.3.1.1 inside the macroblock; blocks on the left / top border take DC (2)
+ * for the neighbouring macroblock's block whatever that macroblock chose, so the decision needs nothing outside the
+ * macroblock and all macroblocks can be decided at once (the entropy coder still codes against the true predicted mode).
+ * Modes go to lev[ORC_L_LDC + blkIdx]. */
+static uint32_t intra4x4_choose(const orc_isad_t *sad, int mx, int my, int lambda, int16_t *lev) {
     static const uint8_t raster_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
-    const orc_mbinfo_t *m = &mbi[my * mbw + mx];
     uint32_t total = 0;
     for (int b = 0; b < 16; b++) {
         const int bx = k_blk_x[b] >> 2, by = k_blk_y[b] >> 2;
-        int ma = -1, mb_ = -1;
-        if (bx > 0) ma = lev[ORC_L_LDC + raster_blk[by * 4 + bx - 1]];
-        else if (mx > 0) ma = m[-1].mb_type == 2 ? levels[(size_t)(my * mbw + mx - 1) * ORC_LEVELS_PER_MB + ORC_L_LDC + raster_blk[by * 4 + 3]] : 2;
-        if (by > 0) mb_ = lev[ORC_L_LDC + raster_blk[(by - 1) * 4 + bx]];
-        else if (my > 0) mb_ = m[-mbw].mb_type == 2 ? levels[(size_t)((my - 1) * mbw + mx) * ORC_LEVELS_PER_MB + ORC_L_LDC + raster_blk[12 + bx]] : 2;
+        const int ma = bx > 0 ? lev[ORC_L_LDC + raster_blk[by * 4 + bx - 1]] : (mx > 0 ? 2 : -1);
+        const int mb_ = by > 0 ? lev[ORC_L_LDC + raster_blk[(by - 1) * 4 + bx]] : (my > 0 ? 2 : -1);
         const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
         uint32_t best = 0xFFFFFFFFu; int best_mode = 2;
         for (int mode = 0; mode < 9; mode++) {
@@ -802,6 +800,28 @@ static uint32_t intra4x4_choose(const orc_isad_t *sad, int mbw, int mx, int my, 
         total += best;
     }
     return total;
+}
+/* Every mode decision of an I picture from the analysed SADs (no reconstructed sample is involved): Intra_16x16 mode =
+ * lowest SAD (ties to the lowest mode number), chroma likewise on Cb+Cr jointly, Intra_4x4 modes by intra4x4_choose;
+ * I_NxN is taken when its cost + 32 lambda (its extra header bits) is strictly lower. */
+void orc_intra_decide(const orc_isad_t *isad, int mbw, int mbh, int qp, int i4x4, orc_idec_t *out) {
+    const int lambda = orc_me_lambda(qp);
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            const orc_isad_t *sad = &isad[my * mbw + mx];
+            orc_idec_t *d = &out[my * mbw + mx];
+            uint32_t luma_sad, chroma_sad;
+            int16_t lev[ORC_LEVELS_PER_MB];
+            memset(d, 0, sizeof *d);
+            d->mode16 = (uint8_t)argmin_u16(sad->i16, 4, &luma_sad);
+            d->cmode = (uint8_t)argmin_u16(sad->chroma, 4, &chroma_sad);
+            if (i4x4) {
+                uint32_t cost4 = intra4x4_choose(sad, mx, my, lambda, lev);
+                if (cost4 + (uint32_t)(32 * lambda) < luma_sad) { d->use_i4 = 1; luma_sad = cost4 + (uint32_t)(32 * lambda); }
+                for (int b = 0; b < 16; b++) d->modes4[b] = (uint8_t)lev[ORC_L_LDC + b];
+            }
+            d->cost = luma_sad + chroma_sad;
+        }
 }
 /* reconstruction of an Intra_4x4 macroblock with the modes in lev[ORC_L_LDC..] (8.3.1.2 + 8.5) */
 static void intra4x4_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int mbw, int mx, int my, int qp, int16_t *lev, uint32_t *nzmask) {
@@ -823,35 +843,28 @@ static void intra4x4_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int
     }
 }
 
-/* I picture.  Analysis (above) on source neighbours, then per macroblock in raster order: Intra_16x16 mode =
- * lowest SAD (ties to the lowest mode number), chroma likewise on Cb+Cr jointly, Intra_4x4 modes by
- * intra4x4_choose; I_NxN is taken when its cost + 32 lambda (its extra header bits) is strictly lower. */
+/* I picture.  Analysis and decisions (above) need only the source picture; then per macroblock in raster order the
+ * reconstruction with the chosen modes. */
 void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
                      uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
                      orc_mbinfo_t *mbi, int16_t *levels) {
     orc_isad_t *isad = (orc_isad_t *)malloc((size_t)mbw * mbh * sizeof(orc_isad_t));
+    orc_idec_t *idec = (orc_idec_t *)malloc((size_t)mbw * mbh * sizeof(orc_idec_t));
     orc_intra_analyse(src_y, src_uv, stride, mbw, mbh, isad);
-    const int lambda = orc_me_lambda(qp);
+    orc_intra_decide(isad, mbw, mbh, qp, g_orc_i4x4, idec);
     for (int my = 0; my < mbh; my++)
         for (int mx = 0; mx < mbw; mx++) {
             orc_mbinfo_t *m = &mbi[my * mbw + mx];
-            const orc_isad_t *sad = &isad[my * mbw + mx];
+            const orc_idec_t *dec = &idec[my * mbw + mx];
             int16_t *lev = levels + (size_t)(my * mbw + mx) * ORC_LEVELS_PER_MB;
             memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
             int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0;
             m->mb_type = 0; m->mvx = 0; m->mvy = 0; m->qp = (uint8_t)qp; m->nzmask = 0;
-            uint32_t luma_sad, chroma_sad;
-            const int best_mode = argmin_u16(sad->i16, 4, &luma_sad);
-            const int best_cmode = argmin_u16(sad->chroma, 4, &chroma_sad);
-            m->i16_mode = (uint8_t)best_mode;
+            const int best_mode = dec->mode16, best_cmode = dec->cmode, use_i4 = dec->use_i4;
+            m->i16_mode = (uint8_t)(use_i4 ? 0 : best_mode);
             m->chroma_mode = (uint8_t)best_cmode;
-            int use_i4 = 0;
-            if (g_orc_i4x4) {
-                uint32_t cost4 = intra4x4_choose(sad, mbw, mx, my, lambda, mbi, levels, lev);
-                if (cost4 + (uint32_t)(32 * lambda) < luma_sad) { use_i4 = 1; m->mb_type = 2; m->i16_mode = 0; luma_sad = cost4 + (uint32_t)(32 * lambda); }
-                else memset(lev + ORC_L_LDC, 0, 16 * sizeof(int16_t));
-            }
-            m->cost = luma_sad + chroma_sad;
+            if (use_i4) { m->mb_type = 2; for (int b = 0; b < 16; b++) lev[ORC_L_LDC + b] = dec->modes4[b]; }
+            m->cost = dec->cost;
             if (use_i4) intra4x4_recon(src_y, rec_y, stride, mbw, mx, my, qp, lev, &m->nzmask);
             else {
             uint8_t best_pred[256];
@@ -919,6 +932,7 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
             chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 1, lev, &m->nzmask);
         }
     free(isad);
+    free(idec);
 }
 
 /* ================================================================== deblocking (8.7) */

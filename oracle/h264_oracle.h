@@ -73,6 +73,9 @@ void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t 
 /* SADs of every intra candidate measured against predictions built from SOURCE neighbours (0xFFFF: mode not available). */
 typedef struct { uint16_t i16[4], chroma[4], i4[16][9]; } orc_isad_t; /* 304 bytes per macroblock */
 void orc_intra_analyse(const uint8_t *src_y, const uint8_t *src_uv, int stride, int mbw, int mbh, orc_isad_t *out);
+/* Mode decisions of an I picture from those SADs alone: 16 bytes per macroblock (layout shared with the device) */
+typedef struct { uint8_t modes4[16]; uint8_t mode16, cmode, use_i4, pad; uint32_t cost; } orc_idec_t; /* 24 bytes */
+void orc_intra_decide(const orc_isad_t *isad, int mbw, int mbh, int qp, int i4x4, orc_idec_t *out);
 
 /* I picture: Intra16x16 + chroma prediction, mode decision by SAD, transform/quant,
  * reconstruction (pre-deblock), macroblocks in raster order. */

@@ -68,6 +68,8 @@ def lib():
         L.orc_inter_frame.restype = None
         L.orc_intra_analyse.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
         L.orc_intra_analyse.restype = None
+        L.orc_intra_decide.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_intra_decide.restype = None
         L.orc_intra_frame.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.orc_intra_frame.restype = None
         L.orc_deblock_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
@@ -238,6 +240,17 @@ def intra_analyse(src_y, src_uv):
     H, W = src_y.shape
     out = np.empty(((H // 16) * (W // 16), 152), np.uint16)
     L.orc_intra_analyse(_ptr(np.ascontiguousarray(src_y)), _ptr(np.ascontiguousarray(src_uv)), W, W // 16, H // 16, _ptr(out))
+    return out
+
+
+IDEC = np.dtype([("modes4", "u1", (16,)), ("mode16", "u1"), ("cmode", "u1"), ("use_i4", "u1"), ("pad", "u1"), ("cost", "<u4")])
+
+
+def intra_decide(isad, mbw, mbh, qp, i4x4=True):
+    """Mode decisions of an I picture from the analysed SADs alone: structured array (n_mb,) of IDEC."""
+    L = lib()
+    out = np.zeros(mbw * mbh, IDEC)
+    L.orc_intra_decide(_ptr(np.ascontiguousarray(isad)), mbw, mbh, qp, int(i4x4), _ptr(out))
     return out
 
 

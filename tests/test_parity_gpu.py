@@ -73,14 +73,19 @@ def test_inter_kernel_matches_oracle(E, oracle, w, h, qp, sub):
 
 @pytest.mark.parametrize("w,h", SIZES + [(16, 16), (1920, 1088)])
 def test_intra_analyse_kernel_matches_oracle(E, oracle, w, h):
-    """Open-loop intra analysis (one flat launch): SAD of every I16 / chroma / I4x4 candidate, 152 u16 per macroblock."""
+    """Open-loop intra analysis (one flat launch): SAD of every I16 / chroma / I4x4 candidate, 152 u16 per macroblock,
+    and the mode decisions taken from them (24 bytes per macroblock)."""
     cy, cuv = frames(w, h, 1)[0][:2]
-    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=30)
-    dev, orc = e.stage_intra_analyse(cy, cuv), oracle.intra_analyse(cy, cuv)
-    assert np.array_equal(dev[:, :4], orc[:, :4]), ("i16", first_diff(dev[:, :4], orc[:, :4]))
-    assert np.array_equal(dev[:, 4:8], orc[:, 4:8]), ("chroma", first_diff(dev[:, 4:8], orc[:, 4:8]))
-    assert np.array_equal(dev[:, 8:], orc[:, 8:]), ("i4", first_diff(dev[:, 8:], orc[:, 8:]))
-    e.close()
+    for qp, i4 in ((30, True), (12, True), (44, False)):
+        e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp, i4x4=i4)
+        (dev, ddec), orc = e.stage_intra_analyse(cy, cuv, qp), oracle.intra_analyse(cy, cuv)
+        assert np.array_equal(dev[:, :4], orc[:, :4]), ("i16", first_diff(dev[:, :4], orc[:, :4]))
+        assert np.array_equal(dev[:, 4:8], orc[:, 4:8]), ("chroma", first_diff(dev[:, 4:8], orc[:, 4:8]))
+        assert np.array_equal(dev[:, 8:], orc[:, 8:]), ("i4", first_diff(dev[:, 8:], orc[:, 8:]))
+        odec = oracle.intra_decide(orc, cy.shape[1] // 16, cy.shape[0] // 16, qp, i4)
+        for f in ("mode16", "cmode", "use_i4", "cost", "modes4"):
+            assert np.array_equal(ddec[f], odec[f]), (f, qp, i4, first_diff(ddec[f], odec[f]))
+        e.close()
 
 
 @pytest.mark.parametrize("w,h", SIZES)
