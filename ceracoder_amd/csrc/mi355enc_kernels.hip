@@ -1121,7 +1121,9 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *_
 // =================================================================== intra (I) macroblocks
 // One wave per macroblock, launched once per anti-diagonal x + y = diag (left, top and
 // top-left neighbours are then complete).  Lanes 0-15: luma 4x4 blocks; lanes 16-23: chroma.
-__global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
+// Two waves per macroblock: wave 0 reconstructs luma, wave 1 chroma -- the planes share nothing after the decisions.
+__global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
+    __shared__ unsigned sh_cflags[2]; // chroma wave -> luma wave: ballots of its blocks' AC / DC flags
     __shared__ int sh_top[3][17], sh_left[3][17]; // reconstructed neighbours [plane 0=Y,1=Cb,2=Cr][-1..15]
     __shared__ int sh_dc[16], sh_ldc[16];
     __shared__ unsigned tabw[TAB_DWORDS];
@@ -1134,27 +1136,27 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     const int my = y_lo + blockIdx.x, mx = diag - my;
     const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
     const bool has_top = my > 0, has_left = mx > 0;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint8_t *__restrict__ ry = ctx->rec_y;
     uint8_t *__restrict__ ruv = ctx->rec_uv;
-    const bool is_luma = lane < 16, is_chroma = lane >= 16 && lane < 24;
+    const bool is_luma = wave == 0 && lane < 16, is_chroma = wave == 1 && lane >= 16 && lane < 24;
     // ---- every global load is issued up front: tables, analysed SADs, neighbours, neighbour modes, this lane's source block
-    for (int i = lane; i < TAB_DWORDS; i += 64) tabw[i] = ((const unsigned *)&g_tab)[i];
+    for (int i = threadIdx.x; i < TAB_DWORDS; i += 128) tabw[i] = ((const unsigned *)&g_tab)[i];
     const uint4 dec0 = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES);              // modes4[16]
     const uint2 dec1 = ldg64(ctx->idec + (size_t)mbn * IDEC_BYTES + 16);          // mode16, cmode, use_i4 | cost
     int (*top)[17] = sh_top;
     int (*left)[17] = sh_left;
-    if (lane >= 24 && lane < 24 + 17) { // lanes 24-40: luma neighbours; index i+1 holds sample i, index 0 the corner
+    if (wave == 0 && lane >= 24 && lane < 24 + 17) { // wave 0, lanes 24-40: luma neighbours; index i+1 holds sample i, index 0 the corner
         int i = lane - 24 - 1;
         top[0][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ry + (size_t)(y0 - 1) * stride + x0 + i) : 0;
         left[0][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ry + (size_t)(y0 + i) * stride + x0 - 1) : 0;
-    } else if (lane >= 41 && lane < 41 + 18) { // lanes 41-58: chroma neighbours
+    } else if (wave == 1 && lane >= 41 && lane < 41 + 18) { // wave 1, lanes 41-58: chroma neighbours
         int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
         top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c) : 0;
         left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c) : 0;
     }
     int src[16];
-    if (lane < 24) {
+    if (is_luma || is_chroma) {
         const int ss = ctx->src_stride;
         if (is_luma) {
             const uint8_t *__restrict__ s = ctx->src_y;
@@ -1189,7 +1191,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     const int mode16 = (int)(dec1.x & 255), cmode = (int)((dec1.x >> 8) & 255);
     const bool use_i4 = ((dec1.x >> 16) & 255) != 0;
     unsigned nz4 = 0;
-    if (use_i4 && lane < 16) { // raster order for the reconstruction loop
+    if (use_i4 && wave == 0 && lane < 16) { // raster order for the reconstruction loop
         const int bb = ((lane >> 3) << 3) | (((lane & 3) >> 1) << 2) | (((lane >> 2) & 1) << 1) | (lane & 1); // raster (by = lane>>2, bx = lane&3) -> blkIdx
         const unsigned w = bb < 4 ? dec0.x : bb < 8 ? dec0.y : bb < 12 ? dec0.z : dec0.w;
         sh_mode4[lane] = (int)((w >> (8 * (bb & 3))) & 255);
@@ -1197,7 +1199,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
     WAVE_SYNC();
     int pred[16];
     int flags = 0;
-    if (use_i4) {
+    if (use_i4 && wave == 0) {
         // ================================================================ Intra_4x4 reconstruction (8.3.1.2 + 8.5)
         // Same block order; up to two blocks per step, 16 lanes each, lane = one pixel; transforms across lanes.
         if (lane < 17) T4[lane] = (uint8_t)TOP(0, lane - 1);
@@ -1329,7 +1331,7 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
                   pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
                         clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3])));
     }
-    if (!is_luma && lane < 32) { // lanes 16-31 form one shuffle group for chroma_block; 16-23 carry the 8 chroma blocks
+    if (wave == 1 && lane >= 16 && lane < 32) { // lanes 16-31 form one shuffle group for chroma_block; 16-23 carry the 8 chroma blocks
         const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
         const int p = 1 + c;
         int st = 0, sl = 0;
@@ -1364,11 +1366,14 @@ __global__ __launch_bounds__(64) void intra_kernel(const frame_ctx_t *__restrict
 #undef TOP
 #undef LEFT
     const unsigned long long any = __ballot(flags & 1), dcm = __ballot(flags & 2);
-    if (lane == 0) {
-        unsigned nzm = (use_i4 ? nz4 : (unsigned)(any & 0xFFFF)) | ((unsigned)((any >> 16) & 0xFF) << 16);
+    if (wave == 1 && lane == 0) { sh_cflags[0] = (unsigned)((any >> 16) & 0xFF); sh_cflags[1] = (unsigned)((dcm >> 16) & 0xFF); }
+    __syncthreads();
+    if (wave == 0 && lane == 0) {
+        const unsigned cany = sh_cflags[0], cdc = sh_cflags[1];
+        unsigned nzm = (use_i4 ? nz4 : (unsigned)(any & 0xFFFF)) | (cany << 16);
         if (!use_i4 && (dcm & 0xFFFF)) nzm |= NZ_LDC;
-        if ((dcm >> 16) & 0x0F) nzm |= NZ_CBDC;
-        if ((dcm >> 16) & 0xF0) nzm |= NZ_CRDC;
+        if (cdc & 0x0F) nzm |= NZ_CBDC;
+        if (cdc & 0xF0) nzm |= NZ_CRDC;
         mb_info_t mb;
         mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)mode16; mb.chroma_mode = (uint8_t)cmode;
         mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = dec1.y;
@@ -1977,7 +1982,7 @@ void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, h
     int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
     int y_hi = diag < mbh - 1 ? diag : mbh - 1;
     if (y_hi < y_lo) return;
-    hipLaunchKernelGGL(intra_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
+    hipLaunchKernelGGL(intra_kernel, dim3(y_hi - y_lo + 1), dim3(128), 0, s, d_ctx, diag);
 }
 void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s) {
     int y_lo = diag - (mbw - 1);
