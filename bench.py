@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--depth", type=int, default=1)
     ap.add_argument("--deblock-mode", type=int, default=0)
     ap.add_argument("--sample", type=int, default=7, help="stage timers (HIP events) on every k-th picture; each event record costs ~5 us of queue time")
+    ap.add_argument("--cavlc-threads", type=int, default=1, help="host threads coding one slice row-parallel (bit-identical output)")
     ap.add_argument("--overlap", type=int, default=0, help="1: overlapped two-stream schedule for P pictures")
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     args = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
 
     e = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                   pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                  transform8x8=bool(args.dct8x8), overlap=bool(args.overlap))
+                  transform8x8=bool(args.dct8x8), overlap=bool(args.overlap), cavlc_threads=args.cavlc_threads)
 
     def run(n, first_index):
         qps, nbytes = [], 0
@@ -140,7 +141,7 @@ def main():
         extra["psnr_y_last_picture_db"] = round(synth.psnr(last[:height], rec), 2)
         # (2) per-picture latency of the synchronous path an element in a live graph uses (pipeline_depth 0):
         # host NV12 in -> H2D -> kernels -> D2H -> CAVLC -> access unit out, PCIe included.
-        lat_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0)
+        lat_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads)
         lat = []
         for i in range(150):
             f = frames_np[bounce(i, args.unique)]
@@ -210,7 +211,7 @@ def main():
             "config": {"workload": args.workload, "width": width, "height": height, "fps_nominal": fps, "gop": gop,
                        "rate_control": "cbr %d bit/s" % bps if args.fixed_qp < 0 else "fixed qp %d" % args.fixed_qp,
                        "me": "full search +-16 integer-pel SAD + half/quarter-sample refinement", "streams_per_gpu": 1, "parallelism": "%d independent streams" % world,
-                       "pipeline_depth": args.depth, "dct8x8": bool(args.dct8x8)},
+                       "pipeline_depth": args.depth, "dct8x8": bool(args.dct8x8), "cavlc_threads": args.cavlc_threads},
             "roofline": roof,
             "roofline_kernels": kernels,
             "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "inter": round(st.ms_inter / max(1, st.n_inter), 4),

@@ -40,6 +40,7 @@ typedef struct {
     guint key_int_max;
     gint device_id, me_range, qp, pipeline_depth, speed_preset;
     gboolean stats, dct8x8;
+    gint threads;
     /* streaming state */
     mi355enc_t *enc;
     GstVideoCodecState *input_state;
@@ -52,7 +53,7 @@ typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 G_DEFINE_TYPE(GstMi355H264Enc, gst_mi355h264enc, GST_TYPE_VIDEO_ENCODER)
 
 enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME_RANGE, PROP_QP, PROP_PIPELINE_DEPTH,
-       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8 };
+       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS };
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-raw, format=(string){ NV12, I420, YUY2, UYVY }, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
@@ -85,6 +86,7 @@ static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *
     case PROP_SPEED_PRESET: s->speed_preset = g_value_get_enum(val); break;
     case PROP_STATS: s->stats = g_value_get_boolean(val); break;
     case PROP_DCT8X8: s->dct8x8 = g_value_get_boolean(val); break;
+    case PROP_THREADS: s->threads = g_value_get_int(val); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -103,6 +105,7 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     case PROP_SPEED_PRESET: g_value_set_enum(val, s->speed_preset); break;
     case PROP_STATS: g_value_set_boolean(val, s->stats); break;
     case PROP_DCT8X8: g_value_set_boolean(val, s->dct8x8); break;
+    case PROP_THREADS: g_value_set_int(val, s->threads); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -146,7 +149,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     GST_OBJECT_LOCK(s);
     cfg.gop = s->key_int_max ? (int)s->key_int_max : 250;
     cfg.me_range = s->me_range; cfg.bitrate_bps = s->bps; cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
-    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0;
+    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 1;
     GST_OBJECT_UNLOCK(s);
     int r = mi355enc_open(&cfg, &e);
     if (r != MI355ENC_OK) {
@@ -283,6 +286,8 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
         "0: output each picture before taking the next; 1: overlap host entropy coding with the next picture (+1 frame latency)", 0, 1, 0, F));
     g_object_class_install_property(g, PROP_SPEED_PRESET, g_param_spec_enum("speed-preset", "Speed preset",
         "Accepted for x264enc pipeline compatibility; ignored", speed_preset_type(), 6, F));
+    g_object_class_install_property(g, PROP_THREADS, g_param_spec_int("threads", "Entropy-coding threads",
+        "Host threads that code one slice row-parallel (bit-identical output); like x264enc's property of the same name, 0/1 = streaming thread only", 0, 64, 1, F));
     g_object_class_install_property(g, PROP_DCT8X8, g_param_spec_boolean("dct8x8", "8x8 transform",
         "Adaptive spatial transform size as in x264enc: High-profile stream, P macroblocks use the 8x8 transform", FALSE, F));
     g_object_class_install_property(g, PROP_STATS, g_param_spec_boolean("stats", "Print stats", "Print a JSON line with counters when the encoder closes", FALSE, F));
@@ -295,7 +300,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->bps = 2048000; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
-    s->stats = FALSE; s->dct8x8 = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
+    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 1; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
 }
 
 GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */

@@ -11,6 +11,7 @@
 #include "h264_host.h"
 
 #include <emmintrin.h>
+#include <pthread.h>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
@@ -269,6 +270,7 @@ struct h264_writer {
     uint8_t *tc_l; /* TotalCoeff per luma 4x4 in raster order, 16 per macroblock */
     uint8_t *tc_c; /* per chroma AC block: Cb 0-3, Cr 4-7 */
     uint8_t *i4m;  /* Intra4x4PredMode per luma4x4BlkIdx, 16 per macroblock (valid where mb_type == 2) */
+    struct cavlc_pool *pool; /* row-parallel coding (h264_writer_set_threads); NULL = everything on the calling thread */
 };
 
 h264_writer_t *h264_writer_new(int mbw, int mbh, int t8) {
@@ -283,8 +285,10 @@ h264_writer_t *h264_writer_new(int mbw, int mbh, int t8) {
     if (!w->rbsp || !w->tc_l || !w->tc_c || !w->i4m) { h264_writer_free(w); return NULL; }
     return w;
 }
+static void cavlc_pool_free(struct cavlc_pool *p);
 void h264_writer_free(h264_writer_t *w) {
     if (!w) return;
+    if (w->pool) cavlc_pool_free(w->pool);
     free(w->rbsp); free(w->tc_l); free(w->tc_c); free(w->i4m); free(w);
 }
 size_t h264_max_au_bytes(int mbw, int mbh) { return (size_t)mbw * mbh * 1536 + 4096; }
@@ -313,28 +317,35 @@ static inline int ctx_chroma(const h264_writer_t *w, int mbn, int mx, int my, in
  * [luma block b for each set bit b][chroma DC if NZ_CBDC|NZ_CRDC][chroma AC block i for each set bit 16+i]; blocks that
  * are absent are all-zero by construction and read from k_zero_block. */
 static const int16_t k_zero_block[16] __attribute__((aligned(32))) = {0};
-static size_t write_slice_impl(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
-                               int slice_qp, const mb_info_t *mbi, const int16_t *levels, const int16_t *packed) {
-    const int mbw = w->mbw, mbh = w->mbh, nmb = mbw * mbh;
-    bits_t b;
-    bits_init(&b, w->rbsp, w->rbsp_cap);
-    memset(w->tc_l, 0, (size_t)nmb * 16);
-    memset(w->tc_c, 0, (size_t)nmb * 8);
-    /* 7.3.3 slice_header */
-    bits_ue(&b, 0);
-    bits_ue(&b, is_idr ? 7 : 5);
-    bits_ue(&b, 0);
-    bits_put(&b, 8, (uint32_t)frame_num & 0xFF);
-    if (is_idr) bits_ue(&b, (uint32_t)idr_pic_id);
-    if (!is_idr) bits_put(&b, 2, 0);  /* num_ref_idx_active_override_flag, ref_pic_list_modification_flag_l0 */
-    if (is_idr) bits_put(&b, 2, 0);   /* no_output_of_prior_pics_flag, long_term_reference_flag */
-    else bits_put(&b, 1, 0);          /* adaptive_ref_pic_marking_mode_flag */
-    bits_se(&b, slice_qp - 26);
-    bits_ue(&b, 0);                   /* disable_deblocking_filter_idc */
-    bits_se(&b, 0); bits_se(&b, 0);
-    /* 7.3.4 slice_data */
-    int skip = 0, prev_qp = slice_qp;
-    for (int my = 0, mbn = 0; my < mbh; my++)
+static void slice_header(bits_t *bp, int is_idr, int frame_num, int idr_pic_id, int slice_qp) { /* 7.3.3 */
+    bits_ue(bp, 0);
+    bits_ue(bp, is_idr ? 7 : 5);
+    bits_ue(bp, 0);
+    bits_put(bp, 8, (uint32_t)frame_num & 0xFF);
+    if (is_idr) bits_ue(bp, (uint32_t)idr_pic_id);
+    if (!is_idr) bits_put(bp, 2, 0);  /* num_ref_idx_active_override_flag, ref_pic_list_modification_flag_l0 */
+    if (is_idr) bits_put(bp, 2, 0);   /* no_output_of_prior_pics_flag, long_term_reference_flag */
+    else bits_put(bp, 1, 0);          /* adaptive_ref_pic_marking_mode_flag */
+    bits_se(bp, slice_qp - 26);
+    bits_ue(bp, 0);                   /* disable_deblocking_filter_idc */
+    bits_se(bp, 0); bits_se(bp, 0);
+}
+/* What a range of macroblock rows leaves open at its two ends (P slices): the mb_skip_run before its first coded
+ * macroblock is NOT written when `defer_first_run` is set -- the caller that concatenates ranges writes
+ * ue(skips pending from earlier ranges + lead_skip) -- and the run after its last coded macroblock is returned. */
+typedef struct { int has_coded, lead_skip, trail_skip; } rows_result_t;
+
+/* 7.3.4 slice_data for macroblock rows [row0, row1).  The neighbour state (tc_l, tc_c, i4m of row row0-1) must be in
+ * place.  `packed` points at the first block of row0 in the packed stream (or is NULL: dense levels). */
+static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1, int is_idr, int slice_qp, const mb_info_t *mbi,
+                               const int16_t *levels, const int16_t *packed, int defer_first_run) {
+    const int mbw = w->mbw;
+    bits_t b = *bp;
+    rows_result_t res = {0, 0, 0};
+    memset(w->tc_l + (size_t)row0 * mbw * 16, 0, (size_t)(row1 - row0) * mbw * 16);
+    memset(w->tc_c + (size_t)row0 * mbw * 8, 0, (size_t)(row1 - row0) * mbw * 8);
+    int skip = 0, prev_qp = slice_qp; /* one QP per picture: mb_qp_delta is 0 wherever it is sent, whatever the range */
+    for (int my = row0, mbn = row0 * mbw; my < row1; my++)
         for (int mx = 0; mx < mbw; mx++, mbn++) {
             const mb_info_t *m = mbi + mbn;
             const uint32_t nz = m->nzmask;
@@ -370,14 +381,16 @@ static size_t write_slice_impl(h264_writer_t *w, uint8_t *out, size_t cap, int i
                     }
                     if (m->mvx == sx && m->mvy == sy) { skip++; continue; }
                 }
-                bits_ue(&b, (uint32_t)skip); skip = 0;
+                if (defer_first_run && !res.has_coded) res.lead_skip = skip; else bits_ue(&b, (uint32_t)skip);
+                skip = 0; res.has_coded = 1;
                 bits_ue(&b, 0); /* P_L0_16x16 */
                 bits_se(&b, m->mvx - px); /* mvd_l0: vectors are kept in quarter-sample units */
                 bits_se(&b, m->mvy - py);
                 bits_ue(&b, cbp_inter_code[cbp_c * 16 + cbp_l]);
                 if (w->t8 && cbp_l) bits_put(&b, 1, (nz & NZ_T8) ? 1u : 0u); /* transform_size_8x8_flag */
             } else {
-                if (!is_idr) { bits_ue(&b, (uint32_t)skip); skip = 0; }
+                if (!is_idr) { if (defer_first_run && !res.has_coded) res.lead_skip = skip; else bits_ue(&b, (uint32_t)skip); skip = 0; }
+                res.has_coded = 1;
                 if (i16) {
                     int t = 1 + m->i16_mode + 4 * cbp_c + (cbp_l ? 12 : 0); /* Table 7-11 */
                     bits_ue(&b, (uint32_t)(is_idr ? t : t + 5));
@@ -422,11 +435,179 @@ static size_t write_slice_impl(h264_writer_t *w, uint8_t *out, size_t cap, int i
                         }
             }
         }
-    if (!is_idr && skip) bits_ue(&b, (uint32_t)skip);
+    if (!res.has_coded) res.lead_skip = skip; else res.trail_skip = skip;
+    *bp = b;
+    return res;
+}
+
+/* Neighbour state of one macroblock row from the packed stream, without coding it: TotalCoeff of every coded luma /
+ * chroma-AC block and the Intra_4x4 modes -- what the row below reads through ctx_luma / ctx_chroma / the mode predictor. */
+static void fill_ctx_row(h264_writer_t *w, int row, const mb_info_t *mbi, const int16_t *packed) {
+    const int mbw = w->mbw;
+    const __m128i z = _mm_setzero_si128();
+    for (int mx = 0, mbn = row * mbw; mx < mbw; mx++, mbn++) {
+        const mb_info_t *m = mbi + mbn;
+        const uint32_t nz = m->nzmask;
+        uint8_t *tl = w->tc_l + (size_t)mbn * 16, *tc = w->tc_c + (size_t)mbn * 8, *im = w->i4m + (size_t)mbn * 16;
+        memset(tl, 0, 16); memset(tc, 0, 8);
+        if (m->mb_type == 2) { for (int i = 0; i < 16; i++) im[i] = (uint8_t)packed[i]; packed += 16; }
+        if (nz & NZ_LDC) packed += 16;
+        const int ac_only = m->mb_type == 0; /* Intra16x16: coefficient 0 travels in the DC block */
+        for (int i = 0; i < 16; i++)
+            if ((nz >> i) & 1) {
+                __m128i lo = _mm_loadu_si128((const __m128i *)packed), hi = _mm_loadu_si128((const __m128i *)(packed + 8));
+                unsigned nzm = ~(unsigned)_mm_movemask_epi8(_mm_packs_epi16(_mm_cmpeq_epi16(lo, z), _mm_cmpeq_epi16(hi, z))) & 0xFFFFu;
+                if (ac_only) nzm >>= 1;
+                tl[blk_to_raster[i]] = (uint8_t)__builtin_popcount(nzm);
+                packed += 16;
+            }
+        if (nz & (NZ_CBDC | NZ_CRDC)) packed += 16;
+        for (int i = 0; i < 8; i++)
+            if ((nz >> (16 + i)) & 1) {
+                __m128i lo = _mm_loadu_si128((const __m128i *)packed), hi = _mm_loadu_si128((const __m128i *)(packed + 8));
+                unsigned nzm = ~(unsigned)_mm_movemask_epi8(_mm_packs_epi16(_mm_cmpeq_epi16(lo, z), _mm_cmpeq_epi16(hi, z))) & 0xFFFFu;
+                tc[i] = (uint8_t)__builtin_popcount(nzm >> 1);
+                packed += 16;
+            }
+    }
+}
+
+static size_t write_slice_impl(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
+                               int slice_qp, const mb_info_t *mbi, const int16_t *levels, const int16_t *packed) {
+    bits_t b;
+    bits_init(&b, w->rbsp, w->rbsp_cap);
+    slice_header(&b, is_idr, frame_num, idr_pic_id, slice_qp);
+    rows_result_t r = code_rows(w, &b, 0, w->mbh, is_idr, slice_qp, mbi, levels, packed, 0);
+    const int tail = r.has_coded ? r.trail_skip : r.lead_skip;
+    if (!is_idr && tail) bits_ue(&b, (uint32_t)tail);
     size_t n = bits_finish(&b, w->rbsp);
     if (b.overflow) return 0;
     return emit_nal(out, cap, is_idr ? 3 : 2, is_idr ? 5 : 1, w->rbsp, n);
 }
+
+/* ------------------------------------------------------------------ row-parallel CAVLC
+ * The slice stays ONE slice: ranges of macroblock rows are coded concurrently into private bit buffers and concatenated
+ * bit-exactly.  That works because nothing in CAVLC depends on the bits before a macroblock, only on neighbour DATA:
+ *   - nC contexts and Intra_4x4 mode prediction read the row above -> each worker first derives that row's TotalCoeff /
+ *     modes from the packed stream (fill_ctx_row), it does not wait for the worker that codes it;
+ *   - motion-vector prediction and P_Skip inference read records only;
+ *   - mb_qp_delta is 0 everywhere (one QP per picture);
+ *   - mb_skip_run crosses range boundaries -> the first run of a range is left to the stitcher.
+ * Each worker owns a private h264_writer (context arrays + bit buffer): no shared mutable state. */
+typedef struct {
+    h264_writer_t *w;          /* private writer */
+    int row0, row1;
+    bits_t bits;
+    rows_result_t res;
+} cavlc_job_t;
+struct cavlc_pool {
+    int n;                     /* workers including the calling thread */
+    pthread_t *th;
+    cavlc_job_t *job;
+    pthread_mutex_t mu;
+    pthread_cond_t cv_go, cv_done;
+    unsigned long long generation;
+    int remaining, stop;
+    /* per call */
+    int is_idr, slice_qp;
+    const mb_info_t *mbi;
+    const int16_t *packed;
+    const uint32_t *row_off;
+};
+static void cavlc_run_job(struct cavlc_pool *p, int k) {
+    cavlc_job_t *j = &p->job[k];
+    bits_init(&j->bits, j->w->rbsp, j->w->rbsp_cap);
+    if (j->row1 <= j->row0) { j->res.has_coded = 0; j->res.lead_skip = 0; j->res.trail_skip = 0; return; }
+    if (j->row0 > 0) fill_ctx_row(j->w, j->row0 - 1, p->mbi, p->packed + (size_t)p->row_off[j->row0 - 1] * 16);
+    j->res = code_rows(j->w, &j->bits, j->row0, j->row1, p->is_idr, p->slice_qp, p->mbi, NULL, p->packed + (size_t)p->row_off[j->row0] * 16, 1);
+}
+typedef struct { struct cavlc_pool *p; int k; } cavlc_arg_t;
+static void *cavlc_thread(void *arg) {
+    cavlc_arg_t a = *(cavlc_arg_t *)arg;
+    free(arg);
+    unsigned long long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&a.p->mu);
+        while (!a.p->stop && a.p->generation == seen) pthread_cond_wait(&a.p->cv_go, &a.p->mu);
+        if (a.p->stop) { pthread_mutex_unlock(&a.p->mu); return NULL; }
+        seen = a.p->generation;
+        pthread_mutex_unlock(&a.p->mu);
+        cavlc_run_job(a.p, a.k);
+        pthread_mutex_lock(&a.p->mu);
+        if (--a.p->remaining == 0) pthread_cond_signal(&a.p->cv_done);
+        pthread_mutex_unlock(&a.p->mu);
+    }
+}
+static void cavlc_pool_free(struct cavlc_pool *p) {
+    if (!p) return;
+    pthread_mutex_lock(&p->mu); p->stop = 1; pthread_cond_broadcast(&p->cv_go); pthread_mutex_unlock(&p->mu);
+    for (int k = 1; k < p->n; k++) if (p->th[k]) pthread_join(p->th[k], NULL);
+    for (int k = 0; k < p->n; k++) if (p->job[k].w) { p->job[k].w->pool = NULL; h264_writer_free(p->job[k].w); }
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_go); pthread_cond_destroy(&p->cv_done);
+    free(p->th); free(p->job); free(p);
+}
+int h264_writer_set_threads(h264_writer_t *w, int threads) {
+    if (!w) return -1;
+    if (w->pool) { cavlc_pool_free(w->pool); w->pool = NULL; }
+    if (threads > w->mbh) threads = w->mbh;
+    if (threads <= 1) return 0;
+    struct cavlc_pool *p = (struct cavlc_pool *)calloc(1, sizeof *p);
+    if (!p) return -1;
+    p->n = threads;
+    p->th = (pthread_t *)calloc((size_t)threads, sizeof *p->th);
+    p->job = (cavlc_job_t *)calloc((size_t)threads, sizeof *p->job);
+    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv_go, NULL); pthread_cond_init(&p->cv_done, NULL);
+    int ok = p->th && p->job;
+    for (int k = 0; ok && k < threads; k++) { p->job[k].w = h264_writer_new(w->mbw, w->mbh, w->t8); ok = p->job[k].w != NULL; }
+    for (int k = 1; ok && k < threads; k++) {
+        cavlc_arg_t *a = (cavlc_arg_t *)malloc(sizeof *a);
+        if (!a) { ok = 0; break; }
+        a->p = p; a->k = k;
+        if (pthread_create(&p->th[k], NULL, cavlc_thread, a)) { free(a); p->th[k] = 0; ok = 0; }
+    }
+    if (!ok) { cavlc_pool_free(p); return -1; }
+    w->pool = p;
+    return 0;
+}
+static void bits_append(bits_t *dst, const bits_t *src, const uint8_t *base) { /* everything `src` has collected so far */
+    const uint8_t *q = base;
+    for (; q + 4 <= src->p; q += 4) bits_put(dst, 32, ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]);
+    for (; q < src->p; q++) bits_put(dst, 8, *q);
+    if (src->n) bits_put(dst, src->n, (uint32_t)(src->acc & ((1ull << src->n) - 1)));
+    if (src->overflow) dst->overflow = 1;
+}
+size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
+                                    int slice_qp, const mb_info_t *mbi, const int16_t *packed, const uint32_t *row_off) {
+    struct cavlc_pool *p = w->pool;
+    if (!p || !row_off) return write_slice_impl(w, out, cap, is_idr, frame_num, idr_pic_id, slice_qp, mbi, NULL, packed);
+    p->is_idr = is_idr; p->slice_qp = slice_qp; p->mbi = mbi; p->packed = packed; p->row_off = row_off;
+    for (int k = 0; k < p->n; k++) { p->job[k].row0 = (int)((long long)w->mbh * k / p->n); p->job[k].row1 = (int)((long long)w->mbh * (k + 1) / p->n); }
+    pthread_mutex_lock(&p->mu);
+    p->remaining = p->n - 1; p->generation++;
+    pthread_cond_broadcast(&p->cv_go);
+    pthread_mutex_unlock(&p->mu);
+    cavlc_run_job(p, 0);
+    pthread_mutex_lock(&p->mu);
+    while (p->remaining) pthread_cond_wait(&p->cv_done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+    bits_t b;
+    bits_init(&b, w->rbsp, w->rbsp_cap);
+    slice_header(&b, is_idr, frame_num, idr_pic_id, slice_qp);
+    int pending = 0;
+    for (int k = 0; k < p->n; k++) {
+        const cavlc_job_t *j = &p->job[k];
+        if (j->res.has_coded) {
+            if (!is_idr) bits_ue(&b, (uint32_t)(pending + j->res.lead_skip));
+            bits_append(&b, &j->bits, j->w->rbsp);
+            pending = j->res.trail_skip;
+        } else pending += j->res.lead_skip;
+    }
+    if (!is_idr && pending) bits_ue(&b, (uint32_t)pending);
+    size_t n = bits_finish(&b, w->rbsp);
+    if (b.overflow) return 0;
+    return emit_nal(out, cap, is_idr ? 3 : 2, is_idr ? 5 : 1, w->rbsp, n);
+}
+
 size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                         int slice_qp, const mb_info_t *mbi, const int16_t *levels) {
     return write_slice_impl(w, out, cap, is_idr, frame_num, idr_pic_id, slice_qp, mbi, levels, NULL);

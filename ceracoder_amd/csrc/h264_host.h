@@ -23,6 +23,13 @@ size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, 
 size_t h264_write_slice_packed(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                                int slice_qp, const mb_info_t *mbi, const int16_t *packed);
 
+/* Row-parallel coding of the same single slice: `threads` workers (the caller is one of them) code ranges of macroblock
+ * rows concurrently and the result is concatenated bit-exactly.  row_off[r] = index of the first 32-byte block of
+ * macroblock row r in the packed stream (written by the device's scan kernel).  threads <= 1: everything on the caller. */
+int h264_writer_set_threads(h264_writer_t *w, int threads);
+size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
+                                    int slice_qp, const mb_info_t *mbi, const int16_t *packed, const uint32_t *row_off);
+
 /* ---- rate control (ratecontrol.c): one QP per picture from a bits/s setpoint ---- */
 typedef struct {
     double fps;

@@ -41,7 +41,7 @@ struct slot_t {
     frame_ctx_t *h_ctx;   // pinned
     mb_info_t *h_mbi;     // pinned
     int16_t *h_levels;    // pinned: packed level stream, written by levels_pack_kernel over PCIe (no D2H copy)
-    unsigned *h_hdr;      // pinned: [0] blocks in the stream, [1] error word of the band deblocker
+    unsigned *h_hdr;      // pinned: [0] blocks in the stream, [1] error word of the band deblocker, [2 + r] first block of macroblock row r
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
     uint8_t *d_raw;              // staging of non-NV12 input before the conversion kernel (allocated on first use)
     hipEvent_t done, gpu_done, ev[12];
@@ -109,7 +109,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0; c->cavlc_threads = 1;
 }
 
 static void launch_intra_all(mi355enc_t *h, int ci) {
@@ -227,7 +227,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipHostMalloc((void **)&s->h_ctx, sizeof(frame_ctx_t), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&s->h_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&s->h_levels, (size_t)h->nmb * PACK_BLOCKS_MAX * 32, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&s->h_hdr, 4 * sizeof(unsigned), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&s->h_hdr, (size_t)(2 + h->mbh) * sizeof(unsigned), hipHostMallocDefault));
         s->h_hdr[0] = s->h_hdr[1] = 0;
         HIPCHK(hipMalloc((void **)&s->d_src_y, h->ysz + SURF_PAD));
         HIPCHK(hipMalloc((void **)&s->d_src_uv, h->csz + SURF_PAD));
@@ -253,6 +253,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     }
     h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
     if (!h->writer) return MI355ENC_ERR_NOMEM;
+    if (h->cfg.cavlc_threads > 1 && h264_writer_set_threads(h->writer, h->cfg.cavlc_threads)) return MI355ENC_ERR_NOMEM;
     rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipStreamSynchronize(h->astream));
@@ -416,7 +417,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     // Hand-over on the third stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:
     // the device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
     HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
-    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, d_err, h->cstream);
+    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, d_err, h->cstream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->done, h->cstream));
     h->n_submitted++;
@@ -521,7 +522,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
         n = h264_write_headers(out, out_cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den, h->cfg.transform8x8);
         if (!n) return MI355ENC_ERR_OVERFLOW;
     }
-    size_t m = h264_write_slice_packed(h->writer, out + n, out_cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels);
+    size_t m = h264_write_slice_packed_rows(h->writer, out + n, out_cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels, s->h_hdr + 2);
     if (!m) return MI355ENC_ERR_OVERFLOW;
     h->st.ms_entropy += now_ms() - t1;
     *out_len = n + m;
@@ -743,6 +744,36 @@ int mi355enc_host_write_slice(int mbw, int mbh, int is_idr, int frame_num, int i
     if (!n) return MI355ENC_ERR_OVERFLOW;
     *out_len = n;
     return MI355ENC_OK;
+}
+// Host statement of what levels_pack_kernel + levels_scan_kernel hand over (same block order), then the slice writer on
+// `threads` host threads: lets the row-parallel coder be checked against the dense single-thread one without a device.
+int mi355enc_host_write_slice_packed(int mbw, int mbh, int is_idr, int frame_num, int idr_pic_id, int qp, int t8, int threads, const void *mbinfo,
+                                     const int16_t *levels, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!out || !out_len || !mbinfo || !levels || mbw < 1 || mbh < 1 || qp < 0 || qp > 51 || threads < 1) return MI355ENC_ERR_ARG;
+    const mb_info_t *mbi = (const mb_info_t *)mbinfo;
+    const size_t nmb = (size_t)mbw * mbh;
+    int16_t *packed = (int16_t *)malloc(nmb * PACK_BLOCKS_MAX * 32 + 32);
+    uint32_t *row_off = (uint32_t *)malloc((size_t)mbh * sizeof(uint32_t));
+    h264_writer_t *w = h264_writer_new(mbw, mbh, t8);
+    int rc = MI355ENC_ERR_NOMEM;
+    if (packed && row_off && w && h264_writer_set_threads(w, threads) == 0) {
+        size_t nblk = 0;
+        for (size_t mb = 0; mb < nmb; mb++) {
+            const uint32_t nz = mbi[mb].nzmask;
+            const int16_t *lv = levels + mb * MB_LEVELS;
+            if (mb % mbw == 0) row_off[mb / mbw] = (uint32_t)nblk;
+            if (mbi[mb].mb_type == 2) memcpy(packed + 16 * nblk++, lv + L_LDC, 32);
+            if (nz & NZ_LDC) memcpy(packed + 16 * nblk++, lv + L_LDC, 32);
+            for (int i = 0; i < 16; i++) if ((nz >> i) & 1) memcpy(packed + 16 * nblk++, lv + L_LUMA + 16 * i, 32);
+            if (nz & (NZ_CBDC | NZ_CRDC)) memcpy(packed + 16 * nblk++, lv + L_CDC, 32);
+            for (int i = 0; i < 8; i++) if ((nz >> (16 + i)) & 1) memcpy(packed + 16 * nblk++, lv + L_CAC + 16 * i, 32);
+        }
+        size_t n = h264_write_slice_packed_rows(w, out, cap, is_idr, frame_num, idr_pic_id, qp, mbi, packed, row_off);
+        rc = n ? MI355ENC_OK : MI355ENC_ERR_OVERFLOW;
+        *out_len = n;
+    }
+    h264_writer_free(w); free(packed); free(row_off);
+    return rc;
 }
 static_assert(sizeof(rc_state_t) <= MI355ENC_RC_BYTES, "MI355ENC_RC_BYTES too small");
 void mi355enc_rc_init(void *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max) { rc_init((rc_state_t *)rc, fps, gop, bps, qp_min, qp_max); }

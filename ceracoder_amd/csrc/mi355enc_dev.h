@@ -71,7 +71,7 @@ void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int
 int k_intra_diags(int mbw, int mbh);
 int k_launch_csc(int fmt, const uint8_t *p0, const uint8_t *p1, const uint8_t *p2, int s0, int s1, int s2, uint8_t *dy, uint8_t *duv,
                  int vw, int vh, int W, int H, hipStream_t s);
-void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,
+void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, int mbw, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,
                    unsigned *h_hdr, const unsigned *d_err, hipStream_t s);
 int k_deblock_diags(int mbw, int mbh);
 #endif

@@ -1888,7 +1888,7 @@ DEV int pack_count(unsigned nz, unsigned mb_type) {
     return __popc(nz & 0x01FFFFFFu) + ((nz & (NZ_CBDC | NZ_CRDC)) ? 1 : 0) + (mb_type == 2 ? 1 : 0);
 }
 // exclusive prefix sum of the block counts: one workgroup, thread t owns a run of consecutive macroblocks
-__global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__restrict__ mbi, int nmb, unsigned *__restrict__ off,
+__global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__restrict__ mbi, int nmb, int mbw, unsigned *__restrict__ off,
                                                            unsigned *__restrict__ hdr, const unsigned *__restrict__ err) {
     __shared__ unsigned wsum[16];
     const int tid = threadIdx.x, per = (nmb + 1023) / 1024, base = tid * per;
@@ -1907,7 +1907,11 @@ __global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__re
     unsigned run = before + incl - mine;
     for (int i = 0; i < per; i++) {
         const int mb = base + i;
-        if (mb < nmb) { off[mb] = run; const uint4 r = ldg128(&mbi[mb]); run += (unsigned)pack_count(r.z, r.y & 255); }
+        if (mb < nmb) {
+            off[mb] = run;
+            if (mb % mbw == 0) hdr[2 + mb / mbw] = run; // where each macroblock row starts: lets the host code rows in parallel
+            const uint4 r = ldg128(&mbi[mb]); run += (unsigned)pack_count(r.z, r.y & 255);
+        }
     }
     if (tid == 1023) { hdr[0] = run; hdr[1] = ldg32(err); } // total blocks; sticky error word of the band deblocker
 }
@@ -1935,9 +1939,9 @@ __global__ __launch_bounds__(256) void levels_pack_kernel(const mb_info_t *__res
     }
     if (c == PACK_CAND) stg128(&h_mbi[mb], r);
 }
-void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,
+void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, int mbw, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,
                    unsigned *h_hdr, const unsigned *d_err, hipStream_t s) {
-    hipLaunchKernelGGL(levels_scan_kernel, dim3(1), dim3(1024), 0, s, d_mbi, nmb, d_off, h_hdr, d_err);
+    hipLaunchKernelGGL(levels_scan_kernel, dim3(1), dim3(1024), 0, s, d_mbi, nmb, mbw, d_off, h_hdr, d_err);
     hipLaunchKernelGGL(levels_pack_kernel, dim3((nmb + 3) / 4), dim3(256), 0, s, d_mbi, d_levels, nmb, d_off, h_mbi, h_packed);
 }
 

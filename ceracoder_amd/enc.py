@@ -27,7 +27,7 @@ EXPORTS = [
     "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_encode", "mi355enc_submit",
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
-    "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_stage_deblock", "mi355enc_time_stage",
+    "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
     "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
     "mi355enc_rc_pick_qp", "mi355enc_rc_update",
 ]
@@ -37,7 +37,7 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
                 ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
-                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("overlap", C.c_int)]
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("overlap", C.c_int), ("cavlc_threads", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -95,6 +95,7 @@ def load():
         L.mi355enc_time_stage.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mi355enc_host_write_headers.argtypes = [C.c_int] * 5 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_write_slice.argtypes = [C.c_int] * 7 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi355enc_host_write_slice_packed.argtypes = [C.c_int] * 8 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_rc_init.restype = None
         L.mi355enc_rc_init.argtypes = [vp, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_int]
         L.mi355enc_rc_set_bitrate.restype = None
@@ -123,6 +124,17 @@ def host_write_slice(mbw, mbh, is_idr, frame_num, idr_pic_id, qp, mbinfo, levels
                                     levels.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
     if r:
         raise RuntimeError("mi355enc_host_write_slice: %d" % r)
+    return bytes(out[: n.value])
+
+
+def host_write_slice_packed(mbw, mbh, is_idr, frame_num, idr_pic_id, qp, mbinfo, levels, threads=1, transform8x8=False):
+    L = load()
+    out, n = np.empty(mbw * mbh * 1536 + 4096, np.uint8), C.c_size_t(0)
+    mbinfo, levels = np.ascontiguousarray(mbinfo), np.ascontiguousarray(levels, np.int16)
+    r = L.mi355enc_host_write_slice_packed(mbw, mbh, int(is_idr), frame_num, idr_pic_id, qp, int(transform8x8), int(threads), mbinfo.ctypes.data_as(C.c_void_p),
+                                           levels.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), out.size, C.byref(n))
+    if r:
+        raise RuntimeError("mi355enc_host_write_slice_packed: %d" % r)
     return bytes(out[: n.value])
 
 
@@ -157,7 +169,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, overlap=False):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, overlap=False, cavlc_threads=1):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
@@ -166,6 +178,7 @@ class Encoder:
             pipeline_depth, int(profile_events), int(use_graphs), int(keep_prefilter))
         cfg.deblock_mode = deblock_mode
         cfg.overlap = int(overlap)
+        cfg.cavlc_threads = int(cavlc_threads)
         cfg.subpel = int(subpel)
         cfg.i4x4 = int(i4x4)
         cfg.transform8x8 = int(transform8x8)

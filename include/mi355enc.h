@@ -64,6 +64,8 @@ typedef struct {
     int overlap;              /* 1: start the upper rows of a P picture on a second stream while the lower bands of the previous
                                  picture are still being deblocked (bit-identical output; measured neutral in r01 because the split
                                  launches sit at their latency floor -- see DESIGN.md); 0 (default): one picture after the other */
+    int cavlc_threads;        /* host threads that code the slice (ranges of macroblock rows, concatenated bit-exactly into the
+                                 same single slice); 1 (default): the calling thread only */
 } mi355enc_cfg_t;
 
 typedef struct {
@@ -162,6 +164,9 @@ int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den,
                                 size_t *out_len);
 int mi355enc_host_write_slice(int mb_width, int mb_height, int is_idr, int frame_num, int idr_pic_id, int slice_qp, int transform8x8,
                               const void *mbinfo, const int16_t *levels, uint8_t *out, size_t out_cap, size_t *out_len);
+/* the same slice through the packed hand-over format and `threads` row-parallel host threads (bit-identical result) */
+int mi355enc_host_write_slice_packed(int mbw, int mbh, int is_idr, int frame_num, int idr_pic_id, int qp, int t8, int threads, const void *mbinfo,
+                                     const int16_t *levels, uint8_t *out, size_t cap, size_t *out_len);
 /* Rate-control model on its own: feed (is_idr, produced bytes) per picture, get the next QP.
  * rc is an opaque block of MI355ENC_RC_BYTES bytes owned by the caller. */
 #define MI355ENC_RC_BYTES 128

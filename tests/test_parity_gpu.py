@@ -129,12 +129,12 @@ def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp, mode):
 
 
 @pytest.mark.parametrize("w,h,n", [(64, 48, 9), (176, 144, 7), (322, 182, 5), (1280, 720, 4), (1920, 1080, 3)])
-@pytest.mark.parametrize("graphs,mode,sub,ov", [(True, 0, True, False), (False, 0, False, False), (True, 1, True, False), (True, 0, True, True)])
-def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub, ov):
+@pytest.mark.parametrize("graphs,mode,sub,ov,thr", [(True, 0, True, False, 1), (False, 0, False, False, 3), (True, 1, True, False, 1), (True, 0, True, True, 4)])
+def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub, ov, thr):
     """Whole path: identical access units, identical reconstruction, and the independent
     decoder reproduces both."""
     qps = [30, 28, 33, 24, 40, 26, 30, 51, 10]
-    e = E.Encoder(w, h, gop=4, fixed_qp=30, use_graphs=graphs, keep_prefilter=True, deblock_mode=mode, subpel=sub, overlap=ov)
+    e = E.Encoder(w, h, gop=4, fixed_qp=30, use_graphs=graphs, keep_prefilter=True, deblock_mode=mode, subpel=sub, overlap=ov, cavlc_threads=thr)
     oe = oracle.Encoder(w, h, gop=4, threads=8, subpel=sub)
     dec = oracle.Decoder()
     for i, (_, _, y, uv) in enumerate(frames(w, h, n)):
