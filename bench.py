@@ -70,6 +70,31 @@ def cpu_baseline(frames_np, width, height, fps, gop, qps, budget_s=20.0):
                       "x264enc is not installed on this image), OpenMP motion search on %d threads, rest scalar" % (n, threads)}
 
 
+def gst_latency(width, height, fps, gop, bps, dev, seconds=4):
+    """M2 as SURVEY 8d defines it: a LIVE source at the nominal frame rate through the element in a real GStreamer graph,
+    stamped at the encoder's sink pad, at the appsink callback and after the last 1316-byte datagram (UDP loopback; libsrt
+    is not in the image).  Uses the product's own probe (ceracoder_amd/mi355_gst_probe), nothing of oracle/."""
+    import subprocess
+    probe = os.path.join(ROOT, "ceracoder_amd", "mi355_gst_probe")
+    if not (os.path.exists(probe) and os.path.exists("/opt/conda/lib/gstreamer-1.0")):
+        return {"unavailable": "GStreamer 1.14 of this image or the probe binary not found"}
+    env = dict(os.environ)
+    env.update(GST_PLUGIN_SYSTEM_PATH="/opt/conda/lib/gstreamer-1.0", GST_PLUGIN_SCANNER="/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner",
+               GST_REGISTRY="/tmp/ceracoder_amd_gst_registry_bench.bin", GST_PLUGIN_PATH=os.path.join(ROOT, "ceracoder_amd", "gst-plugins"),
+               LD_PRELOAD="/usr/lib/x86_64-linux-gnu/libstdc++.so.6")
+    desc = ("videotestsrc is-live=true num-buffers=%d pattern=smpte horizontal-speed=5 ! video/x-raw,width=%d,height=%d,framerate=%d/1,format=NV12 ! queue ! "
+            "mi355h264enc key-int-max=%d bps=%d device-id=%d name=venc_bps ! mi355tsmux ! appsink name=appsink sync=false"
+            % (seconds * fps, width, height, fps, gop, bps, dev))
+    try:
+        r = subprocess.run([probe, desc], env=env, capture_output=True, text=True, timeout=60 + 3 * seconds)
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # the headline number must not depend on this extra
+        return {"unavailable": "probe failed: %s" % e}
+    out["path"] = ("live videotestsrc (scrolling SMPTE bars) %dx%d@%d -> mi355h264enc -> mi355tsmux -> appsink -> 7x188-byte datagrams over UDP loopback "
+                   "(same packetisation as ceracoder.c new_buf_cb; not SRT)" % (width, height, fps))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +103,7 @@ def main():
     ap.add_argument("--workload", default="1080p_ippp", choices=sorted(WORKLOADS))
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pictures kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gst-latency", action="store_true", help="skip the live GStreamer latency probe (M2)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--fixed-qp", type=int, default=-1)
     ap.add_argument("--depth", type=int, default=1)
@@ -154,6 +180,9 @@ def main():
                                "path": "pipeline_depth=0: host NV12 -> H2D -> GPU -> D2H -> host CAVLC -> AU (the element's handle_frame); "
                                        "appsink->SRT segment not measurable here (no libsrt / mpegtsmux in the image)",
                                "host_input_frames_per_s": round(1e3 / float(lat.mean()), 1)}
+
+    if rank == 0 and world == 1 and not args.no_gst_latency:
+        extra["latency_gst_ms"] = gst_latency(width, height, fps, gop, bps, dev)
 
     if rank == 0:
         # HBM traffic of the kernels comes from separate rocprofv3 --pmc passes (cannot be collected from inside this

@@ -1,0 +1,136 @@
+/*
+ * mi355_gst_probe.c -- product-side latency probe for the metric "appsink -> SRT p50 frame latency"
+ * (BASELINE.json).  Runs a gst-launch style description that must contain an element named
+ * `venc_bps` (the encoder) and one named `appsink`, and stamps every buffer three times:
+ *   t0  buffer enters the encoder's sink pad            (pad probe)
+ *   t1  the muxed sample reaches the appsink callback   (what /root/reference/src/ceracoder.c:297 new_buf_cb receives)
+ *   t2  the last 1316-byte datagram of that sample has been handed to the socket
+ * The sender regroups samples into 7 x 188-byte payloads exactly like new_buf_cb does for srt_send
+ * (/root/reference/src/ceracoder.c:48-51,313-332) but over UDP to a loopback socket: libsrt is not in this image, so
+ * t2 - t1 is "UDP loopback, same packetisation", not SRT.  Prints one JSON line.
+ *
+ * usage: mi355_gst_probe "PIPELINE DESCRIPTION"
+ */
+#include <arpa/inet.h>
+#include <gst/app/gstappsink.h>
+#include <gst/gst.h>
+#include <netinet/in.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#define RING 512
+#define MAXN 65536
+#define PKT (188 * 7)
+
+static GMainLoop *loop;
+static struct { guint64 pts; gint64 t0; } ring[RING];
+static unsigned head;
+static GMutex lock;
+static float l_enc[MAXN], l_send[MAXN];
+static unsigned n_lat;
+static guint64 n_samples, n_bytes, n_dgrams;
+static int tx = -1, rx = -1, exit_code;
+static struct sockaddr_in dst;
+static unsigned char pkt[PKT];
+static int pkt_len;
+
+static GstPadProbeReturn on_enc_sink(GstPad *pad, GstPadProbeInfo *info, gpointer u) {
+    (void)pad; (void)u;
+    GstBuffer *b = GST_PAD_PROBE_INFO_BUFFER(info);
+    if (b) {
+        g_mutex_lock(&lock);
+        ring[head % RING].pts = GST_BUFFER_PTS(b); ring[head % RING].t0 = g_get_monotonic_time(); head++;
+        g_mutex_unlock(&lock);
+    }
+    return GST_PAD_PROBE_OK;
+}
+static void send_regrouped(const unsigned char *d, size_t n) {
+    while (n) {
+        size_t k = (size_t)(PKT - pkt_len) < n ? (size_t)(PKT - pkt_len) : n;
+        memcpy(pkt + pkt_len, d, k);
+        pkt_len += (int)k; d += k; n -= k;
+        if (pkt_len == PKT) {
+            if (tx >= 0) (void)sendto(tx, pkt, PKT, 0, (struct sockaddr *)&dst, sizeof dst);
+            n_dgrams++; pkt_len = 0;
+        }
+    }
+}
+static GstFlowReturn on_sample(GstAppSink *sink, gpointer u) {
+    (void)u;
+    GstSample *s = gst_app_sink_pull_sample(sink);
+    if (!s) return GST_FLOW_OK;
+    const gint64 t1 = g_get_monotonic_time();
+    GstBuffer *b = gst_sample_get_buffer(s);
+    GstMapInfo m;
+    if (gst_buffer_map(b, &m, GST_MAP_READ)) {
+        send_regrouped(m.data, m.size);
+        const gint64 t2 = g_get_monotonic_time();
+        const guint64 pts = GST_BUFFER_PTS(b);
+        gint64 t0 = -1;
+        g_mutex_lock(&lock);
+        for (unsigned i = 0; i < RING && i < head; i++)
+            if (ring[(head - 1 - i) % RING].pts == pts) { t0 = ring[(head - 1 - i) % RING].t0; break; }
+        g_mutex_unlock(&lock);
+        if (t0 >= 0 && n_lat < MAXN) { l_enc[n_lat] = (float)((t1 - t0) / 1e3); l_send[n_lat] = (float)((t2 - t1) / 1e3); n_lat++; }
+        n_samples++; n_bytes += m.size;
+        gst_buffer_unmap(b, &m);
+    }
+    gst_sample_unref(s);
+    return GST_FLOW_OK;
+}
+static gboolean on_bus(GstBus *bus, GstMessage *msg, gpointer u) {
+    (void)bus; (void)u;
+    if (GST_MESSAGE_TYPE(msg) == GST_MESSAGE_ERROR) {
+        GError *e = NULL; gchar *dbg = NULL;
+        gst_message_parse_error(msg, &e, &dbg);
+        fprintf(stderr, "gstreamer error: %s (%s)\n", e->message, dbg ? dbg : "");
+        g_error_free(e); g_free(dbg);
+        exit_code = 3; g_main_loop_quit(loop);
+    } else if (GST_MESSAGE_TYPE(msg) == GST_MESSAGE_EOS) g_main_loop_quit(loop);
+    return TRUE;
+}
+static int cmpf(const void *a, const void *b) { float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }
+static void pct(const char *name, float *v, unsigned n) {
+    if (!n) { printf(",\"%s\":null", name); return; }
+    qsort(v, n, sizeof *v, cmpf);
+    printf(",\"%s\":{\"p50\":%.3f,\"p95\":%.3f,\"max\":%.3f,\"n\":%u}", name, v[n / 2], v[(unsigned)(n * 0.95)], v[n - 1], n);
+}
+int main(int argc, char **argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s \"PIPELINE\"\n", argv[0]); return 2; }
+    gst_init(&argc, &argv);
+    GError *err = NULL;
+    GstElement *pipe = gst_parse_launch(argv[1], &err);
+    if (!pipe) { fprintf(stderr, "parse error: %s\n", err ? err->message : "?"); return 2; }
+    GstElement *enc = gst_bin_get_by_name(GST_BIN(pipe), "venc_bps"), *sink = gst_bin_get_by_name(GST_BIN(pipe), "appsink");
+    if (!enc || !sink) { fprintf(stderr, "the description needs elements named venc_bps and appsink\n"); return 2; }
+    GstPad *sp = gst_element_get_static_pad(enc, "sink");
+    gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_BUFFER, on_enc_sink, NULL, NULL);
+    gst_object_unref(sp);
+    rx = socket(AF_INET, SOCK_DGRAM, 0); tx = socket(AF_INET, SOCK_DGRAM, 0);
+    struct sockaddr_in a; memset(&a, 0, sizeof a);
+    a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    socklen_t al = sizeof a;
+    if (rx < 0 || tx < 0 || bind(rx, (struct sockaddr *)&a, sizeof a) || getsockname(rx, (struct sockaddr *)&a, &al)) tx = -1;
+    dst = a; /* the receive buffer is never read: datagrams are dropped there, the sender does not care */
+    GstAppSinkCallbacks cb = {NULL, NULL, on_sample, {0}};
+    gst_app_sink_set_callbacks(GST_APP_SINK(sink), &cb, NULL, NULL);
+    loop = g_main_loop_new(NULL, FALSE);
+    GstBus *bus = gst_element_get_bus(pipe);
+    gst_bus_add_watch(bus, on_bus, NULL);
+    const gint64 t_start = g_get_monotonic_time();
+    gst_element_set_state(pipe, GST_STATE_PLAYING);
+    g_main_loop_run(loop);
+    const double secs = (g_get_monotonic_time() - t_start) / 1e6;
+    gst_element_set_state(pipe, GST_STATE_NULL);
+    printf("{\"samples\":%" G_GUINT64_FORMAT ",\"bytes\":%" G_GUINT64_FORMAT ",\"seconds\":%.3f,\"datagrams_1316\":%" G_GUINT64_FORMAT, n_samples, n_bytes, secs, n_dgrams);
+    const unsigned skip = n_lat > 90 ? 60 : 0; /* discard the first GOP (warm-up) */
+    pct("ms_encoder_sink_to_appsink", l_enc + skip, n_lat - skip);
+    pct("ms_appsink_to_last_udp_send", l_send + skip, n_lat - skip);
+    printf("}\n");
+    if (tx >= 0) close(tx);
+    if (rx >= 0) close(rx);
+    return exit_code;
+}

@@ -89,3 +89,20 @@ def test_pipeline_files_name_the_element_like_the_reference():
         text = open(os.path.join(d, f)).read()
         assert "mi355h264enc" in text and "name=venc_bps" in text and "appsink name=appsink" in text, f
         assert "x264enc" not in text
+
+
+@needs_gst
+def test_latency_probe_runs_the_graph_and_fails_loudly_without_a_device():
+    """ceracoder_amd/mi355_gst_probe (bench.py's M2 leg): parses a description, needs the two named elements, and on a
+    machine without a HIP device ends with the element's bus ERROR instead of producing samples."""
+    probe = os.path.join(ROOT, "ceracoder_amd", "mi355_gst_probe")
+    assert os.path.exists(probe), "run __graft_entry__.build()"
+    r = subprocess.run([probe, "videotestsrc num-buffers=2 ! fakesink"], env=gst_env(), capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "venc_bps" in r.stderr
+    desc = ("videotestsrc num-buffers=3 ! video/x-raw,width=320,height=192,framerate=30/1,format=I420 ! mi355h264enc name=venc_bps ! "
+            "mi355tsmux ! appsink name=appsink sync=false")
+    r = subprocess.run([probe, desc], env=gst_env(), capture_output=True, text=True, timeout=120)
+    if _has_gpu():
+        assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1])["samples"] == 3, r.stderr
+    else:
+        assert r.returncode == 3 and "no usable HIP device" in r.stderr, r.stderr
