@@ -95,6 +95,27 @@ def gst_latency(width, height, fps, gop, bps, dev, seconds=4):
     return out
 
 
+def third_party_probe():
+    """x264enc / an H.264 decoder / ffmpeg on the box would allow an x264 baseline and a third-party decode of
+    our stream.  They are not part of this image; record what is (not) there instead of failing."""
+    import shutil
+    import subprocess
+    found = {"ffmpeg": bool(shutil.which("ffmpeg")), "x264": bool(shutil.which("x264"))}
+    insp = "/opt/conda/bin/gst-inspect-1.0" if os.path.exists("/opt/conda/bin/gst-inspect-1.0") else shutil.which("gst-inspect-1.0")
+    for el in ("x264enc", "avdec_h264", "h264parse", "mpegtsmux"):
+        ok = False
+        if insp:
+            try:
+                env = dict(os.environ, GST_PLUGIN_SYSTEM_PATH="/opt/conda/lib/gstreamer-1.0", GST_REGISTRY="/tmp/ceracoder_amd_gst_registry_bench.bin",
+                           GST_PLUGIN_SCANNER="/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner")
+                ok = subprocess.run([insp, "--exists", el], env=env, capture_output=True, timeout=30).returncode == 0
+            except Exception:
+                ok = False
+        found[el] = ok
+    found["note"] = ("x264enc absent: cpu_baseline is this repo's own CPU restatement, not x264" if not found["x264enc"] else "x264enc present")
+    return found
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +204,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_gst_latency:
         extra["latency_gst_ms"] = gst_latency(width, height, fps, gop, bps, dev)
+        extra["third_party"] = third_party_probe()
 
     if rank == 0:
         # HBM traffic of the kernels comes from separate rocprofv3 --pmc passes (cannot be collected from inside this
