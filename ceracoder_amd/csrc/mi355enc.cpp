@@ -137,11 +137,11 @@ static int run_intra(mi355enc_t *h, int ci) {
     } else launch_intra_all(h, ci);
     return 0;
 }
-// whole picture on the main stream
-static int run_deblock(mi355enc_t *h, int ci) {
+// whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
+static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
     if (h->cfg.deblock_mode == 0) { // prep kernel (also clears the progress counters) + persistent 16-row band kernel
-        k_launch_deblock_prep(h->d_ctx2[ci], h->mbw, h->mbh, h->d_progress, h->n_progress, h->stream);
-        k_launch_deblock_bands(h->d_ctx2[ci], h->mbh, 0, k_deblock_bands16(h->mbh), h->d_progress, h->d_progress + h->n_progress, h->stream);
+        k_launch_deblock_prep(hc, h->mbw, h->mbh, h->d_progress, h->n_progress, h->stream);
+        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), h->d_progress, h->d_progress + h->n_progress, h->stream);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -360,12 +360,15 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     const int nb = k_deblock_bands16(h->mbh), R = h->ov_rows_top;
     slot_t *prev = h->prev_slot;
     unsigned *d_err = h->d_progress + h->n_progress;
-    if (ov) { // uploads of this picture (source planes by the caller, the context here) go through astream, behind the previous picture's A
+    // The P-picture kernels and the band deblocker take the context by value; only the kernels replayed from a hipGraph
+    // (intra wavefront, deblock_mode 1) read the device copy, so only those pictures pay for an upload.
+    const bool need_dctx = idr || h->cfg.deblock_mode != 0;
+    if (ov) { // uploads of this picture (source planes, by the caller) go through astream, behind the previous picture's A
         if (prev && !prev->overlapped) HIPCHK(hipStreamWaitEvent(h->astream, prev->ev_a, 0)); // after a sequential picture: its deblocking ran on `stream`
-        HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->astream));
+        if (need_dctx) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->astream));
         HIPCHK(hipEventRecord(s->ev_up, h->astream));
         HIPCHK(hipStreamWaitEvent(h->stream, s->ev_up, 0));
-    } else HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
+    } else if (need_dctx) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     if (prev && prev->overlapped) HIPCHK(hipStreamWaitEvent(h->stream, prev->ev_a, 0)); // A(n-1) ran on astream; B(n-1) precedes us in stream order
     if (idr) {
         if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
@@ -374,21 +377,21 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     } else {
         if (ov) { // TOP on astream
             if (prof) HIPCHK(hipEventRecord(s->ev[6], h->astream));
-            k_launch_me(dctx, h->mbw, 0, R, h->astream);
+            k_launch_me(c, h->mbw, 0, R, h->astream);
             if (prof) HIPCHK(hipEventRecord(s->ev[7], h->astream));
-            if (h->cfg.subpel) k_launch_subpel(dctx, h->mbw, 0, R, h->astream);
+            if (h->cfg.subpel) k_launch_subpel(c, h->mbw, 0, R, h->astream);
             if (prof) HIPCHK(hipEventRecord(s->ev[8], h->astream));
-            k_launch_inter(dctx, h->mbw, 0, R, h->astream);
+            k_launch_inter(c, h->mbw, 0, R, h->astream);
             if (prof) HIPCHK(hipEventRecord(s->ev[9], h->astream));
             HIPCHK(hipEventRecord(s->ev_top, h->astream));
         }
         const int r0 = ov ? R : 0;
         if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
-        k_launch_me(dctx, h->mbw, r0, h->mbh, h->stream);
+        k_launch_me(c, h->mbw, r0, h->mbh, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
-        if (h->cfg.subpel) k_launch_subpel(dctx, h->mbw, r0, h->mbh, h->stream);
+        if (h->cfg.subpel) k_launch_subpel(c, h->mbw, r0, h->mbh, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
-        k_launch_inter(dctx, h->mbw, r0, h->mbh, h->stream);
+        k_launch_inter(c, h->mbw, r0, h->mbh, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[11], h->stream));
         if (ov) HIPCHK(hipStreamWaitEvent(h->stream, s->ev_top, 0));
     }
@@ -401,16 +404,16 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
     }
     if (ov) {
-        k_launch_deblock_prep(dctx, h->mbw, h->mbh, h->d_progress, h->n_progress, h->stream);
+        k_launch_deblock_prep(c, h->mbw, h->mbh, h->d_progress, h->n_progress, h->stream);
         HIPCHK(hipEventRecord(s->ev_prep, h->stream));
         HIPCHK(hipStreamWaitEvent(h->astream, s->ev_prep, 0));
-        k_launch_deblock_bands(dctx, h->mbh, 0, h->ov_bands_a, h->d_progress, d_err, h->astream);   // A first ...
+        k_launch_deblock_bands(c, h->mbh, 0, h->ov_bands_a, h->d_progress, d_err, h->astream);   // A first ...
         HIPCHK(hipEventRecord(s->ev_a, h->astream));
         if (prof) HIPCHK(hipEventRecord(s->ev[10], h->astream));
-        k_launch_deblock_bands(dctx, h->mbh, h->ov_bands_a, nb, h->d_progress, d_err, h->stream);  // ... then B
+        k_launch_deblock_bands(c, h->mbh, h->ov_bands_a, nb, h->d_progress, d_err, h->stream);  // ... then B
         HIPCHK(hipGetLastError());
     } else {
-        int r = run_deblock(h, ci); if (r) return r;
+        int r = run_deblock(h, ci, c); if (r) return r;
         if (h->ov_bands_a > 0) HIPCHK(hipEventRecord(s->ev_a, h->stream)); // only a later overlapped picture waits on it
     }
     if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
@@ -617,7 +620,7 @@ int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y,
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, cur_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    k_launch_me(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
+    k_launch_me(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
     HIPCHK(hipMemcpyAsync(mbinfo_out, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
@@ -629,7 +632,7 @@ int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *re
     HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    k_launch_subpel(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
+    k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
     HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
@@ -644,7 +647,7 @@ int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
     HIPCHK(hipMemcpyAsync(h->d_rec_uv[0], ref_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    k_launch_inter(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
+    k_launch_inter(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
     HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
@@ -686,7 +689,7 @@ int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const
     HIPCHK(hipMemcpyAsync(h->d_rec_uv[1], rec_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, 26, false); if (r) return r;
-    r = run_deblock(h, 0); if (r) return r;
+    r = run_deblock(h, 0, h->slot[0].h_ctx); if (r) return r;
     HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -697,8 +700,12 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
     if (h->pending) return MI355ENC_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[0];
-    // make sure the device context is valid: reuse the last one uploaded; if none, build a stage context
+    // a valid context in both places: the last picture's host copy (slot 0) re-uploaded, or a fresh stage context
     if (!h->have_ref) { int r = stage_ctx(h, 26, true); if (r) return r; }
+    else {
+        HIPCHK(hipStreamSynchronize(h->astream));
+        HIPCHK(hipMemcpyAsync(h->d_ctx, s->h_ctx, sizeof(frame_ctx_t), hipMemcpyHostToDevice, h->stream));
+    }
     if (stage >= 5 && !s->d_raw) { // input conversion (5 I420, 6 YUY2, 7 UYVY): any bytes will do as a source
         HIPCHK(hipMalloc((void **)&s->d_raw, (size_t)(2 * h->W + 32) * h->H + 64));
         HIPCHK(hipMemsetAsync(s->d_raw, 0x55, (size_t)(2 * h->W + 32) * h->H + 64, h->stream));
@@ -706,16 +713,16 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
     for (int warm = 0; warm < 2; warm++) {
         if (warm) HIPCHK(hipEventRecord(s->ev[0], h->stream));
         for (int i = 0; i < (warm ? iters : 1); i++) {
-            if (stage == 0) k_launch_me(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
-            else if (stage == 1) k_launch_inter(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
+            if (stage == 0) k_launch_me(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
+            else if (stage == 1) k_launch_inter(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 2) { int r = run_intra(h, 0); if (r) return r; }
-            else if (stage == 4) k_launch_subpel(h->d_ctx, h->mbw, 0, h->mbh, h->stream);
+            else if (stage == 4) k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage >= 5) {
                 const int w = h->cfg.width, ht = h->cfg.height, r0 = stage == 5 ? (w + 15) & ~15 : (2 * w + 15) & ~15, r1 = (w / 2 + 15) & ~15;
                 const uint8_t *p0 = s->d_raw, *p1 = p0 + (size_t)r0 * ht, *p2 = p1 + (size_t)r1 * (ht / 2);
                 k_launch_csc(stage - 4, p0, p1, p2, r0, r1, r1, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, h->stream);
             }
-            else { int r = run_deblock(h, 0); if (r) return r; }
+            else { int r = run_deblock(h, 0, h->slot[0].h_ctx); if (r) return r; }
         }
         if (warm) HIPCHK(hipEventRecord(s->ev[1], h->stream));
     }

@@ -57,16 +57,17 @@ typedef struct {
 
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
-/* launchers (mi355enc_kernels.hip); all asynchronous on `s` */
-void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int row0, int row1, hipStream_t s);
-void k_launch_subpel(const frame_ctx_t *d_ctx, int mbw, int row0, int row1, hipStream_t s);
-void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int row0, int row1, hipStream_t s);
+/* launchers (mi355enc_kernels.hip); all asynchronous on `s`.  h_ctx: HOST copy of the context, passed to the kernel by value
+ * (kernarg segment); d_ctx: device copy, for the kernels that are replayed from a hipGraph. */
+void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
+void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
+void k_launch_inter(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
 void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
 int k_deblock_bands16(int mbh);
-void k_launch_deblock_prep(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, hipStream_t s);
-void k_launch_deblock_bands(const frame_ctx_t *d_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, hipStream_t s);
+void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, hipStream_t s);
+void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, hipStream_t s);
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s);
 int k_intra_diags(int mbw, int mbh);
 int k_launch_csc(int fmt, const uint8_t *p0, const uint8_t *p1, const uint8_t *p2, int s0, int s1, int s2, uint8_t *dy, uint8_t *duv,

@@ -128,7 +128,8 @@ DEV int mv_bits(int v) { // bits of se(4v): 1 for 0, else 7 + 2*floor(log2|v|)
     return a == 0 ? 1 : 7 + 2 * (31 - __clz(a));
 }
 
-__global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t *__restrict__ ctx, int row0) {
+__global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, int row0) { // context by value: lives in the kernarg segment, no per-picture upload
+    const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ unsigned win[ME_ROWS * ME_STRIDE];
     const int stride = ctx->stride, mbw = ctx->mbw, mbh = ctx->mbh;
     const int W = mbw * 16, H = mbh * 16;
@@ -442,7 +443,8 @@ DEV unsigned sp_sample4(const sp_lds *L, int X, int Y, int fx, int fy) {
 #undef SH
 #undef SJ
 }
-__global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t *__restrict__ ctx, int mb0, int mb1) {
+__global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t cv, int mb0, int mb1) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -620,7 +622,8 @@ DEV int qpel_nb(const int (*n)[NC], int i, int jj, int fx, int fy) {
 // =================================================================== inter (P) macroblocks
 // One wave = two macroblocks.  Lanes 0-31: one 4x4 luma block each (MB = lane>>4);
 // lanes 32-47: one 4x4 chroma block each (MB = (lane-32)>>3); lanes 48-63 idle.
-__global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t *__restrict__ ctx, int mb0, int mb1) {
+__global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t cv, int mb0, int mb1) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
     const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
     const int W = mbw * 16, H = ctx->mbh * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1536,7 +1539,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { const frame_ctx_t *ctx; unsigned *progress; unsigned *err; int band0, nb_total; }; // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; int band0, nb_total; }; // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: 16-row bands in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -1574,7 +1577,8 @@ DEV edge_par par_of(unsigned ab, unsigned tc) { edge_par p; p.alpha = (int)(ab &
 // the horizontal edges, then {alpha|beta<<8, tc0 bytes} for luma left / top / inner and chroma
 // left / top / inner.  Edges that are not filtered (picture border, 8x8-transform inner edges) get bS 0.
 // Also clears the band progress counters of the launch that follows.
-__global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t *__restrict__ ctx, unsigned *__restrict__ progress, int nprog) {
+__global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv, unsigned *__restrict__ progress, int nprog) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < nprog) progress[i] = 0;
     const int mbw = ctx->mbw, mbh = ctx->mbh;
@@ -1671,10 +1675,10 @@ DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int b
 // slots from the other's dependency chain).  4 waves, one per SIMD; a wave serves four rows, 16
 // lanes each.
 template <bool CHROMA>
-DEV void band16_body(const db_args a, const int band, const int nb, uint8_t *lds) {
+DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *lds) {
     constexpr int rows_mb = CHROMA ? 8 : 16, strip = CHROMA ? 2 : 4, ring_n = CHROMA ? 8 : 16;
     constexpr int ROW_LDS = CHROMA ? (int)sizeof(d3_chroma) : (int)sizeof(d3_luma);
-    const frame_ctx_t *__restrict__ ctx = a.ctx;
+    const frame_ctx_t *__restrict__ ctx = &a.ctx;
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, k = lane & 15, r = 4 * wave + g, my = band * D3_ROWS + r;
@@ -1968,16 +1972,16 @@ int k_deblock_diags(int mbw, int mbh) { return mbw + 2 * (mbh - 1); }
 
 // The three P-picture kernels take a macroblock-row range [row0, row1): the host overlaps the upper part of picture n+1
 // with the tail of picture n's deblocking (mi355enc.cpp, enqueue_picture).
-void k_launch_me(const frame_ctx_t *d_ctx, int mbw, int row0, int row1, hipStream_t s) {
+void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
     int strips = (mbw + ME_MBS - 1) / ME_MBS;
-    if (row1 > row0) hipLaunchKernelGGL(me_kernel, dim3(strips * (row1 - row0)), dim3(64 * ME_MBS), 0, s, d_ctx, row0);
+    if (row1 > row0) hipLaunchKernelGGL(me_kernel, dim3(strips * (row1 - row0)), dim3(64 * ME_MBS), 0, s, *h_ctx, row0);
 }
-void k_launch_subpel(const frame_ctx_t *d_ctx, int mbw, int row0, int row1, hipStream_t s) {
-    if (row1 > row0) hipLaunchKernelGGL(subpel_kernel, dim3((mbw * (row1 - row0) + 3) / 4), dim3(256), 0, s, d_ctx, row0 * mbw, row1 * mbw);
+void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
+    if (row1 > row0) hipLaunchKernelGGL(subpel_kernel, dim3((mbw * (row1 - row0) + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw);
 }
-void k_launch_inter(const frame_ctx_t *d_ctx, int mbw, int row0, int row1, hipStream_t s) {
+void k_launch_inter(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
     int pairs = (mbw * (row1 - row0) + 1) / 2;
-    if (row1 > row0) hipLaunchKernelGGL(inter_kernel, dim3((pairs + 3) / 4), dim3(256), 0, s, d_ctx, row0 * mbw, row1 * mbw);
+    if (row1 > row0) hipLaunchKernelGGL(inter_kernel, dim3((pairs + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw);
 }
 void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
     hipLaunchKernelGGL(intra_analyse_kernel, dim3((mbw * mbh + 3) / 4), dim3(256), 0, s, d_ctx);
@@ -1999,12 +2003,12 @@ int k_deblock_bands16(int mbh) { return (mbh + D3_ROWS - 1) / D3_ROWS; }
 // `d_progress` holds 2 * bands counters (luma, chroma) followed by the sticky error word at d_err.  The prep kernel clears
 // the counters; the band kernel may be launched in several pieces (bands [band0, band1)): a band only ever waits for the
 // band above it, so pieces may run concurrently on different streams as long as the upper piece is submitted first.
-void k_launch_deblock_prep(const frame_ctx_t *d_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, hipStream_t s) {
-    hipLaunchKernelGGL(deblock_prep_kernel, dim3((mbw * mbh + 255) / 256), dim3(256), 0, s, d_ctx, d_progress, nprog);
+void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, hipStream_t s) {
+    hipLaunchKernelGGL(deblock_prep_kernel, dim3((mbw * mbh + 255) / 256), dim3(256), 0, s, *h_ctx, d_progress, nprog);
 }
-void k_launch_deblock_bands(const frame_ctx_t *d_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
+void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
     db_args a;
-    a.ctx = d_ctx; a.progress = d_progress; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh);
+    a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh);
     if (band1 > band0) hipLaunchKernelGGL(deblock_band16_kernel, dim3(2 * (band1 - band0)), dim3(256), 0, s, a);
 }
 // =================================================================== input conversion to NV12
