@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""dev tool: where does deblock mode N differ from the oracle?  python tools/dbg_deblock.py W H QP MODE"""
+"""dev tool: where does deblock mode N differ from the oracle?  python tests/devtools/dbg_deblock.py W H QP MODE"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from ceracoder_amd import enc as E
 from oracle import oracle as O

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """dev tool: long CBR run with bitrate changes; every access unit is decoded by the independent decoder and the
-decoder's picture must equal the encoder's reconstruction every `check` pictures.  python tools/soak.py W H N"""
+decoder's picture must equal the encoder's reconstruction every `check` pictures.  python tests/devtools/soak.py W H N"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from ceracoder_amd import enc as E, synth
 from oracle import oracle as O
