@@ -325,7 +325,7 @@ DEV int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 255); }
 // pred[16]: prediction of this lane's 4x4 block.  Handles the 2x2 DC Hadamard across the four
 // lanes of a plane with shuffles (8.5.11), writes levels + reconstruction, returns the AC flag
 // in bit 0 and the plane's DC flag in bit 1.
-DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int cx0, int cy0, int cl, const int *pred, int qp, bool intra) {
+DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int cx0, int cy0, int cl, const int *pred, int qp, bool intra, uint8_t *lrec = nullptr) {
     const int c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
     const int qpc = T->qpc[qp];
     const qparams q = make_q(T, qpc, intra);
@@ -381,7 +381,11 @@ DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int c
     for (int r = 0; r < 4; r++) {
         uint8_t *p = rec + (size_t)(cy0 + by + r) * st + 2 * (cx0 + bx) + c;
 #pragma unroll
-        for (int i = 0; i < 4; i++) stg8(p + 2 * i, (unsigned)clip255(pred[r * 4 + i] + x[r * 4 + i]));
+        for (int i = 0; i < 4; i++) {
+            const unsigned v = (unsigned)clip255(pred[r * 4 + i] + x[r * 4 + i]);
+            stg8(p + 2 * i, v);
+            if (lrec) lrec[(by + r) * 16 + 2 * (bx + i) + c] = (uint8_t)v; // 8 x 16 interleaved tile in LDS for the persistent intra kernel
+        }
     }
     return (nz_ac ? 1 : 0) | (nz_dc ? 2 : 0);
 }
@@ -1124,40 +1128,38 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *_
 // =================================================================== intra (I) macroblocks
 // One wave per macroblock, launched once per anti-diagonal x + y = diag (left, top and
 // top-left neighbours are then complete).  Lanes 0-15: luma 4x4 blocks; lanes 16-23: chroma.
-// Two waves per macroblock: wave 0 reconstructs luma, wave 1 chroma -- the planes share nothing after the decisions.
-__global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
-    __shared__ unsigned sh_cflags[2]; // chroma wave -> luma wave: ballots of its blocks' AC / DC flags
-    __shared__ int sh_top[3][17], sh_left[3][17]; // reconstructed neighbours [plane 0=Y,1=Cb,2=Cr][-1..15]
-    __shared__ int sh_dc[16], sh_ldc[16];
-    __shared__ unsigned tabw[TAB_DWORDS];
-    __shared__ __attribute__((aligned(4))) uint8_t T4[17 * 24]; // Intra_4x4: reconstructed samples incl. the row above / column left
-    __shared__ __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
-    __shared__ int sh_mode4[16];
-    const dev_tables *T = (const dev_tables *)tabw;
+// Per-macroblock working set of the intra reconstruction, in LDS.  Filled by the caller: top / left (reconstructed
+// neighbours, [plane 0 = Y, 1 = Cb, 2 = Cr][index i + 1 holds sample i, index 0 the corner]).  Produced for the neighbours
+// to the right and below (persistent kernel): bottom rows into a 4-deep ring, the right column.
+struct intra_lds {
+    int top[3][17], left[3][17];
+    int dc[16], ldc[16];
+    __attribute__((aligned(4))) uint8_t T4[17 * 24]; // Intra_4x4: reconstructed samples incl. the row above / column left
+    __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
+    __attribute__((aligned(4))) uint8_t crec[8 * 16]; // reconstructed chroma, interleaved Cb Cr (OUT only)
+    int mode4[16];
+    unsigned cflags[2];                               // chroma wave -> luma wave: ballots of its blocks' AC / DC flags
+    unsigned cseq;                                    // ... valid once this equals macroblock number + 1
+    __attribute__((aligned(4))) uint8_t bot_y[4][16], bot_c[4][16];
+    __attribute__((aligned(4))) uint8_t right_y[16], right_c[2][8];
+    int corner[3];                                    // bottom-right sample of the macroblock before the one in right_*: the next corner
+};
+
+// Reconstruction of one intra macroblock by two waves (wave 0 luma, wave 1 chroma; the planes share nothing after the
+// decisions).  Needs L->top / L->left in place and visible; dec0/dec1: the 24-byte decision of intra_analyse_kernel.
+template <bool OUT>
+DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, intra_lds *L, const int mx, const int my, const int wave, const int lane,
+                       const uint4 dec0, const uint2 dec1) {
+    int (*top)[17] = L->top;
+    int (*left)[17] = L->left;
+    int *sh_dc = L->dc, *sh_ldc = L->ldc, *sh_mode4 = L->mode4;
+    uint8_t *T4 = L->T4, *S4 = L->S4;
     const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
-    const int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
-    const int my = y_lo + blockIdx.x, mx = diag - my;
     const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
     const bool has_top = my > 0, has_left = mx > 0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint8_t *__restrict__ ry = ctx->rec_y;
-    uint8_t *__restrict__ ruv = ctx->rec_uv;
     const bool is_luma = wave == 0 && lane < 16, is_chroma = wave == 1 && lane >= 16 && lane < 24;
-    // ---- every global load is issued up front: tables, analysed SADs, neighbours, neighbour modes, this lane's source block
-    for (int i = threadIdx.x; i < TAB_DWORDS; i += 128) tabw[i] = ((const unsigned *)&g_tab)[i];
-    const uint4 dec0 = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES);              // modes4[16]
-    const uint2 dec1 = ldg64(ctx->idec + (size_t)mbn * IDEC_BYTES + 16);          // mode16, cmode, use_i4 | cost
-    int (*top)[17] = sh_top;
-    int (*left)[17] = sh_left;
-    if (wave == 0 && lane >= 24 && lane < 24 + 17) { // wave 0, lanes 24-40: luma neighbours; index i+1 holds sample i, index 0 the corner
-        int i = lane - 24 - 1;
-        top[0][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ry + (size_t)(y0 - 1) * stride + x0 + i) : 0;
-        left[0][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ry + (size_t)(y0 + i) * stride + x0 - 1) : 0;
-    } else if (wave == 1 && lane >= 41 && lane < 41 + 18) { // wave 1, lanes 41-58: chroma neighbours
-        int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
-        top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c) : 0;
-        left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c) : 0;
-    }
+    const int slot = mx & 3;
     int src[16];
     if (is_luma || is_chroma) {
         const int ss = ctx->src_stride;
@@ -1187,7 +1189,6 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
             }
         }
     }
-    __syncthreads();
 #define TOP(p, i) top[p][(i) + 1]
 #define LEFT(p, i) left[p][(i) + 1]
     // ---- decisions were taken by intra_analyse_kernel (oracle: orc_intra_decide)
@@ -1268,6 +1269,7 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
             }
             WAVE_SYNC();
         }
+        if (OUT && lane < 16) { L->bot_y[slot][lane] = T4[16 * 24 + lane + 1]; L->right_y[lane] = T4[(lane + 1) * 24 + 16]; }
     } else if (is_luma) {
         // ================================================================ Intra_16x16 reconstruction (8.3.3 + 8.5.10)
         const int b = lane, bx = blkx(b), by = blky(b), mode = mode16;
@@ -1329,10 +1331,15 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
         }
         idct4(x);
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            stg32(ry + (size_t)(y0 + by + r) * stride + x0 + bx,
-                  pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
-                        clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3])));
+        for (int r = 0; r < 4; r++) {
+            const unsigned rw = pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
+                                      clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3]));
+            stg32(ry + (size_t)(y0 + by + r) * stride + x0 + bx, rw);
+            if (OUT) {
+                if (by == 12 && r == 3) *(unsigned *)&L->bot_y[slot][bx] = rw;
+                if (bx == 12) L->right_y[by + r] = (uint8_t)(rw >> 24);
+            }
+        }
     }
     if (wave == 1 && lane >= 16 && lane < 32) { // lanes 16-31 form one shuffle group for chroma_block; 16-23 carry the 8 chroma blocks
         const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
@@ -1360,7 +1367,7 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
             for (int i = 0; i < 4; i++)
                 pred[r * 4 + i] = cmode == 0 ? dcv : cmode == 1 ? LEFT(p, by + r) : cmode == 2 ? TOP(p, bx + i)
                                   : clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5);
-        if (is_chroma) flags = chroma_block(ctx, T, mbn, cx0, cy0, cl, pred, qp, true);
+        if (is_chroma) flags = chroma_block(ctx, T, mbn, cx0, cy0, cl, pred, qp, true, OUT ? L->crec : nullptr);
         else {
             (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
             (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
@@ -1369,10 +1376,22 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
 #undef TOP
 #undef LEFT
     const unsigned long long any = __ballot(flags & 1), dcm = __ballot(flags & 2);
-    if (wave == 1 && lane == 0) { sh_cflags[0] = (unsigned)((any >> 16) & 0xFF); sh_cflags[1] = (unsigned)((dcm >> 16) & 0xFF); }
-    __syncthreads();
-    if (wave == 0 && lane == 0) {
-        const unsigned cany = sh_cflags[0], cdc = sh_cflags[1];
+    if (wave == 1) {
+        if (OUT) {
+            WAVE_SYNC();
+            if (lane >= 16 && lane < 32) {
+                const int i = lane - 16;
+                L->bot_c[slot][i] = L->crec[7 * 16 + i];
+                L->right_c[i >> 3][i & 7] = L->crec[(i & 7) * 16 + 14 + (i >> 3)];
+            }
+        }
+        if (lane == 0) {
+            L->cflags[0] = (unsigned)((any >> 16) & 0xFF); L->cflags[1] = (unsigned)((dcm >> 16) & 0xFF);
+            __hip_atomic_store(&L->cseq, (unsigned)mbn + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else if (lane == 0) { // the luma wave writes the record once the chroma wave's flags are in (both waves are resident: plain spin)
+        while (__hip_atomic_load(&L->cseq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)mbn + 1u) __builtin_amdgcn_s_sleep(1);
+        const unsigned cany = L->cflags[0], cdc = L->cflags[1];
         unsigned nzm = (use_i4 ? nz4 : (unsigned)(any & 0xFFFF)) | (cany << 16);
         if (!use_i4 && (dcm & 0xFFFF)) nzm |= NZ_LDC;
         if (cdc & 0x0F) nzm |= NZ_CBDC;
@@ -1382,6 +1401,37 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
         mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = dec1.y;
         st_mbinfo(&ctx->mbi[mbn], mb);
     }
+}
+
+// One launch per anti-diagonal x + y (replayed as a hipGraph): neighbours come from the reconstructed picture in global
+// memory.  intra_mode 1; kept as the plain form and cross-check of the persistent kernel below.
+__global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
+    __shared__ intra_lds LD;
+    __shared__ unsigned tabw[TAB_DWORDS];
+    const dev_tables *T = (const dev_tables *)tabw;
+    const int mbw = ctx->mbw, stride = ctx->stride;
+    const int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
+    const int my = y_lo + blockIdx.x, mx = diag - my;
+    const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
+    const bool has_top = my > 0, has_left = mx > 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t *__restrict__ ry = ctx->rec_y;
+    const uint8_t *__restrict__ ruv = ctx->rec_uv;
+    for (int i = threadIdx.x; i < TAB_DWORDS; i += 128) tabw[i] = ((const unsigned *)&g_tab)[i];
+    if (threadIdx.x == 0) LD.cseq = 0;
+    const uint4 dec0 = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES);              // modes4[16]
+    const uint2 dec1 = ldg64(ctx->idec + (size_t)mbn * IDEC_BYTES + 16);          // mode16, cmode, use_i4 | cost
+    if (wave == 0 && lane >= 24 && lane < 24 + 17) { // wave 0, lanes 24-40: luma neighbours; index i+1 holds sample i, index 0 the corner
+        int i = lane - 24 - 1;
+        LD.top[0][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ry + (size_t)(y0 - 1) * stride + x0 + i) : 0;
+        LD.left[0][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ry + (size_t)(y0 + i) * stride + x0 - 1) : 0;
+    } else if (wave == 1 && lane >= 41 && lane < 41 + 18) { // wave 1, lanes 41-58: chroma neighbours
+        int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
+        LD.top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c) : 0;
+        LD.left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c) : 0;
+    }
+    __syncthreads();
+    intra_compute<false>(ctx, T, &LD, mx, my, wave, lane, dec0, dec1);
 }
 
 // =================================================================== deblocking (8.7)
