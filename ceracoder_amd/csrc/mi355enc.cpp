@@ -69,6 +69,7 @@ struct mi355enc {
     uint8_t *d_idec;      // intra decisions, IDEC_BYTES per macroblock
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
     unsigned *d_progress; // [2*bands] strip counters of the band deblocker, then one error word
+    unsigned *d_iprogress; // progress counters of the persistent intra kernel, one per band
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
     int n_progress;
     slot_t slot[NSLOT];
@@ -109,7 +110,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0; c->cavlc_threads = 1;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0; c->cavlc_threads = 1; c->intra_mode = 0;
 }
 
 static void launch_intra_all(mi355enc_t *h, int ci) {
@@ -129,8 +130,13 @@ static int build_graph(mi355enc_t *h, int which, int ci, hipGraphExec_t *out) {
     HIPCHK(hipGraphDestroy(g));
     return 0;
 }
-static int run_intra(mi355enc_t *h, int ci) {
-    k_launch_intra_analyse(h->d_ctx2[ci], h->mbw, h->mbh, h->stream); // open-loop mode analysis: one flat launch
+static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
+    k_launch_intra_analyse(h->d_ctx2[ci], h->mbw, h->mbh, h->stream); // open-loop mode analysis + decisions: one flat launch
+    if (h->cfg.intra_mode == 0) { // persistent band kernel
+        k_launch_intra_band(hc, h->mbh, h->d_iprogress, h->d_progress + h->n_progress, h->stream);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (h->cfg.use_graphs) {
         if (!h->g_intra[ci]) { int r = build_graph(h, 0, ci, &h->g_intra[ci]); if (r) return r; }
         HIPCHK(hipGraphLaunch(h->g_intra[ci], h->stream));
@@ -182,7 +188,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->astream = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->ov_bands_a = h->ov_rows_top = 0; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->ov_bands_a = h->ov_rows_top = 0; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -217,6 +223,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void **)&h->d_iprogress, (size_t)k_intra_bands(h->mbh) * sizeof(unsigned)));
     if (cfg->keep_prefilter) {
         HIPCHK(hipMalloc((void **)&h->d_pre_y, h->ysz));
         HIPCHK(hipMalloc((void **)&h->d_pre_uv, h->csz));
@@ -291,6 +298,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_idec) (void)hipFree(h->d_idec);
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->d_off) (void)hipFree(h->d_off);
+    if (h->d_iprogress) (void)hipFree(h->d_iprogress);
     for (int i = 0; i < 2; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
     for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
@@ -372,7 +380,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     if (prev && prev->overlapped) HIPCHK(hipStreamWaitEvent(h->stream, prev->ev_a, 0)); // A(n-1) ran on astream; B(n-1) precedes us in stream order
     if (idr) {
         if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
-        int r = run_intra(h, ci); if (r) return r;
+        int r = run_intra(h, ci, c); if (r) return r;
         if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
     } else {
         if (ov) { // TOP on astream
@@ -662,7 +670,7 @@ int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    r = run_intra(h, 0); if (r) return r;
+    r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r;
     HIPCHK(hipMemcpyAsync(mbinfo_out, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
@@ -715,7 +723,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
         for (int i = 0; i < (warm ? iters : 1); i++) {
             if (stage == 0) k_launch_me(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 1) k_launch_inter(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
-            else if (stage == 2) { int r = run_intra(h, 0); if (r) return r; }
+            else if (stage == 2) { int r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r; }
             else if (stage == 4) k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage >= 5) {
                 const int w = h->cfg.width, ht = h->cfg.height, r0 = stage == 5 ? (w + 15) & ~15 : (2 * w + 15) & ~15, r1 = (w / 2 + 15) & ~15;

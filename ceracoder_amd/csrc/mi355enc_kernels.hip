@@ -85,6 +85,22 @@ DEV void st_mbinfo(mb_info_t *p, const mb_info_t &m) {
     stg128(p, r);
 }
 
+// ------------------------------------------------------------------ cross-workgroup hand-off inside a persistent launch
+// Agent-scope (sc1, L1-bypassing) accesses for data one workgroup produces and another consumes while both run, and a bounded
+// wait on a monotonic progress counter (MI355X_MICROARCH.md, "Valid forms": producer stores the data sc1, s_waitcnt vmcnt(0),
+// then stores the counter sc1; consumer polls the counter and reads the data with sc1 loads).
+#define DB_SPIN_MAX (1 << 20)
+DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV int db_wait_get(unsigned *progress, unsigned *err, int need) {
+    int spins = 0, v;
+    while ((v = (int)ld_sc1(progress)) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(err))) { st_sc1(err, 1u); return 0x7FFFFFFF; } // bounded; once tripped, nobody waits again
+    }
+    return v;
+}
+
 // workgroup barrier that drains LDS traffic only: global loads (prefetch) and stores stay in flight
 #define BAND_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -325,7 +341,7 @@ DEV int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 255); }
 // pred[16]: prediction of this lane's 4x4 block.  Handles the 2x2 DC Hadamard across the four
 // lanes of a plane with shuffles (8.5.11), writes levels + reconstruction, returns the AC flag
 // in bit 0 and the plane's DC flag in bit 1.
-DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int cx0, int cy0, int cl, const int *pred, int qp, bool intra, uint8_t *lrec = nullptr) {
+DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int cx0, int cy0, int cl, const int *pred, int qp, bool intra, uint8_t *lrec = nullptr, const uint2 *presrc = nullptr) {
     const int c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
     const int qpc = T->qpc[qp];
     const qparams q = make_q(T, qpc, intra);
@@ -337,7 +353,7 @@ DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int c
         for (int r = 0; r < 4; r++) {
             int sy = cy0 + by + r;
             sy = sy < vh2 ? sy : vh2 - 1;
-            uint2 w = ldg64(s + (size_t)sy * ss + 2 * (cx0 + bx));
+            uint2 w = presrc ? presrc[r] : ldg64(s + (size_t)sy * ss + 2 * (cx0 + bx));
             unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
             x[r * 4 + 0] = (int)(lo & 255) - pred[r * 4 + 0];
             x[r * 4 + 1] = (int)((lo >> 16) & 255) - pred[r * 4 + 1];
@@ -1149,7 +1165,7 @@ struct intra_lds {
 // decisions).  Needs L->top / L->left in place and visible; dec0/dec1: the 24-byte decision of intra_analyse_kernel.
 template <bool OUT>
 DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, intra_lds *L, const int mx, const int my, const int wave, const int lane,
-                       const uint4 dec0, const uint2 dec1) {
+                       const uint4 dec0, const uint2 dec1, const uint2 *presrc = nullptr) { // presrc: this lane's source rows, loaded ahead (luma: .x of 4; chroma: 4 pairs)
     int (*top)[17] = L->top;
     int (*left)[17] = L->left;
     int *sh_dc = L->dc, *sh_ldc = L->ldc, *sh_mode4 = L->mode4;
@@ -1170,7 +1186,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             for (int r = 0; r < 4; r++) {
                 int sy = y0 + by + r;
                 sy = sy < vh ? sy : vh - 1;
-                unsigned sw = ldg32(s + (size_t)sy * ss + x0 + bx);
+                unsigned sw = presrc ? presrc[r].x : ldg32(s + (size_t)sy * ss + x0 + bx);
 #pragma unroll
                 for (int i = 0; i < 4; i++) src[r * 4 + i] = byte_of(sw, i);
                 *(unsigned *)&S4[(by + r) * 16 + bx] = sw;
@@ -1182,7 +1198,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             for (int r = 0; r < 4; r++) {
                 int sy = cy0 + by + r;
                 sy = sy < vh2 ? sy : vh2 - 1;
-                uint2 w = ldg64(s + (size_t)sy * ss + 2 * (cx0 + bx));
+                uint2 w = presrc ? presrc[r] : ldg64(s + (size_t)sy * ss + 2 * (cx0 + bx));
                 unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
                 src[r * 4 + 0] = (int)(lo & 255); src[r * 4 + 1] = (int)((lo >> 16) & 255);
                 src[r * 4 + 2] = (int)(hi & 255); src[r * 4 + 3] = (int)((hi >> 16) & 255);
@@ -1367,7 +1383,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             for (int i = 0; i < 4; i++)
                 pred[r * 4 + i] = cmode == 0 ? dcv : cmode == 1 ? LEFT(p, by + r) : cmode == 2 ? TOP(p, bx + i)
                                   : clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5);
-        if (is_chroma) flags = chroma_block(ctx, T, mbn, cx0, cy0, cl, pred, qp, true, OUT ? L->crec : nullptr);
+        if (is_chroma) flags = chroma_block(ctx, T, mbn, cx0, cy0, cl, pred, qp, true, OUT ? L->crec : nullptr, presrc);
         else {
             (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
             (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
@@ -1432,6 +1448,118 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
     }
     __syncthreads();
     intra_compute<false>(ctx, T, &LD, mx, my, wave, lane, dec0, dec1);
+}
+
+// Persistent form of the intra wavefront (intra_mode 0): one launch per picture.  A workgroup owns a band of IB_ROWS
+// macroblock rows, two waves per row (luma, chroma); all rows advance in lock-step, one barrier per step, row r handling
+// macroblock x = t - r at step t (x + y order: left, top-left and top neighbours are complete, and Intra_4x4 never looks
+// past its own macroblock's columns in the row above).  Neighbour samples never go through global memory inside a band:
+// the bottom row of a macroblock travels to the row below through a 4-deep LDS ring, its right column stays in the row's
+// own LDS for the next step.  Between bands the bottom rows of the last row are stored with `sc1` and announced through a
+// progress counter, exactly like the deblocking bands; the first row of a band prefetches them one step ahead.
+#define IB_ROWS 4
+struct ib_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; };
+
+__global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
+    __shared__ intra_lds LD[IB_ROWS];
+    __shared__ unsigned tabw[TAB_DWORDS];
+    __shared__ unsigned stage[2][8]; // first row of a band: the prefetched samples of the band above (luma, chroma), 5 dwords each
+    const dev_tables *T = (const dev_tables *)tabw;
+    const frame_ctx_t *__restrict__ ctx = &a.ctx;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
+    const int band = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = w >> 1, role = w & 1;
+    const int my = band * IB_ROWS + r;
+    const bool row_ok = my < mbh, has_top = my > 0;
+    const bool fed = row_ok && r == 0 && band > 0;                        // top samples come from the band above
+    const bool feeds = row_ok && r == IB_ROWS - 1 && my != mbh - 1;       // bottom rows go to the band below
+    intra_lds *L = &LD[r];
+    const intra_lds *Lup = &LD[r > 0 ? r - 1 : 0];
+    for (int i = threadIdx.x; i < TAB_DWORDS; i += IB_ROWS * 128) tabw[i] = ((const unsigned *)&g_tab)[i];
+    if (lane == 0 && role == 0) L->cseq = 0;
+    const uint8_t *__restrict__ ry = ctx->rec_y;
+    const uint8_t *__restrict__ ruv = ctx->rec_uv;
+    unsigned *prog_up = a.progress + (band > 0 ? band - 1 : 0), *prog_my = a.progress + band;
+    // the lanes that move neighbour samples: luma wave 24..40 (i = -1..15), chroma wave 41..58 (plane c, i = -1..7)
+    const bool mover = role == 0 ? (lane >= 24 && lane < 41) : (lane >= 41 && lane < 59);
+    const int mi = role == 0 ? lane - 25 : (lane - 41) % 9 - 1, mc = role == 0 ? 0 : (lane - 41) / 9;
+    // ... and the lanes that fetch for a fed row: 5 dwords starting 4 bytes left of the macroblock (the corner is byte 3 of dword 0)
+    const bool fetcher = fed && lane >= 24 && lane < 29;
+    const uint8_t *frow = role == 0 ? ry + (size_t)(my * 16 - 1) * stride : ruv + (size_t)(my * 8 - 1) * stride;
+    unsigned gpre = 0;
+    int avail = 0;
+    uint4 dec0n = make_uint4(0, 0, 0, 0);
+    uint2 dec1n = make_uint2(0, 0);
+    uint2 srcn[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)}; // this lane's source rows of the next macroblock
+    const bool src_luma = role == 0 && lane < 16, src_chroma = role == 1 && lane >= 16 && lane < 24;
+    const int nsteps = mbw + IB_ROWS + 1;
+    for (int t = -1; t < nsteps; t++) { // step -1 only prefetches for the first row
+        const int x = t - r, xn = x + 1;
+        const bool act = row_ok && x >= 0 && x < mbw;
+        const bool pf = row_ok && xn >= 0 && xn < mbw;
+        if (feeds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // both waves: the bottom rows stored in the previous step have landed
+        __syncthreads(); // the rings and right columns written in the previous step are visible
+        if (feeds && role == 0 && lane == 0 && x >= 1 && x <= mbw) st_sc1(prog_my, (unsigned)x); // ... announce them
+        // ---- land what was prefetched for this step, prefetch for the next one
+        const uint4 dec0 = dec0n;
+        const uint2 dec1 = dec1n;
+        const uint2 srcc[4] = {srcn[0], srcn[1], srcn[2], srcn[3]};
+        if (fed && act && lane >= 24 && lane < 29) stage[role][lane - 24] = gpre;
+        if (pf) {
+            const size_t mbn_n = (size_t)my * mbw + xn;
+            dec0n = ldg128(ctx->idec + mbn_n * IDEC_BYTES);
+            dec1n = ldg64(ctx->idec + mbn_n * IDEC_BYTES + 16);
+            if (src_luma) {
+                const int bx = blkx(lane), by = blky(lane), vh = ctx->vis_h;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { int sy = my * 16 + by + q; sy = sy < vh ? sy : vh - 1; srcn[q].x = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + xn * 16 + bx); }
+            } else if (src_chroma) {
+                const int cl = lane & 7, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4, vh2 = ctx->vis_h >> 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { int sy = my * 8 + by + q; sy = sy < vh2 ? sy : vh2 - 1; srcn[q] = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * (xn * 8 + bx)); }
+            }
+            if (fed) {
+                if (avail < xn + 1) avail = db_wait_get(prog_up, a.err, xn + 1);
+                if (fetcher) gpre = xn > 0 || lane > 24 ? ld_sc1((const unsigned *)(frow + xn * 16 - 4 + 4 * (lane - 24))) : 0u;
+            }
+        }
+        WAVE_SYNC();
+        if (act) {
+            // ---- neighbours of macroblock x into L->top / L->left
+            if (mover) {
+                const bool has_left = x > 0;
+                int tv = 0, lv = 0;
+                if (role == 0) {
+                    if (has_top && (mi >= 0 || has_left))
+                        tv = fed ? (int)((const uint8_t *)stage[0])[4 + mi] : (mi >= 0 ? (int)Lup->bot_y[x & 3][mi] : (int)Lup->bot_y[(x - 1) & 3][15]);
+                    if (has_left && (mi >= 0 || has_top)) lv = mi >= 0 ? (int)L->right_y[mi] : tv;
+                } else {
+                    if (has_top && (mi >= 0 || has_left))
+                        tv = fed ? (int)((const uint8_t *)stage[1])[4 + 2 * mi + mc] : (mi >= 0 ? (int)Lup->bot_c[x & 3][2 * mi + mc] : (int)Lup->bot_c[(x - 1) & 3][14 + mc]);
+                    if (has_left && (mi >= 0 || has_top)) lv = mi >= 0 ? (int)L->right_c[mc][mi] : tv;
+                }
+                L->top[role ? 1 + mc : 0][mi + 1] = tv;
+                L->left[role ? 1 + mc : 0][mi + 1] = lv;
+            }
+            WAVE_SYNC();
+            intra_compute<true>(ctx, T, L, x, my, role, lane, dec0, dec1, srcc);
+            // ---- last row of the band: its bottom rows go to the band below
+            if (feeds) {
+                WAVE_SYNC();
+                if (lane < 4) {
+                    if (role == 0) st_sc1((unsigned *)(ctx->rec_y + (size_t)(my * 16 + 15) * stride + x * 16) + lane, ((const unsigned *)L->bot_y[x & 3])[lane]);
+                    else st_sc1((unsigned *)(ctx->rec_uv + (size_t)(my * 8 + 7) * stride + x * 16) + lane, ((const unsigned *)L->bot_c[x & 3])[lane]);
+                }
+            }
+        }
+    }
+}
+int k_intra_bands(int mbh) { return (mbh + IB_ROWS - 1) / IB_ROWS; }
+// d_progress: one counter per band (cleared here), then the sticky error word
+void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
+    ib_args a;
+    a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err;
+    (void)hipMemsetAsync(d_progress, 0, (size_t)k_intra_bands(mbh) * sizeof(unsigned), s);
+    hipLaunchKernelGGL(intra_band_kernel, dim3(k_intra_bands(mbh)), dim3(IB_ROWS * 128), 0, s, a);
 }
 
 // =================================================================== deblocking (8.7)
@@ -1585,9 +1713,6 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 }
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
-#define DB_SPIN_MAX (1 << 20)
-DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
 struct db_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; int band0, nb_total; }; // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
@@ -1666,14 +1791,6 @@ __global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv,
 
 typedef v4u v4u_a4 __attribute__((aligned(4)));
 DEV void stg128u(void *p, unsigned a, unsigned b, unsigned c, unsigned d) { v4u t; t.x = a; t.y = b; t.z = c; t.w = d; *(GAS v4u_a4 *)p = t; } // 4-byte aligned
-DEV int db_wait_get(unsigned *progress, unsigned *err, int need) {
-    int spins = 0, v;
-    while ((v = (int)ld_sc1(progress)) < need) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(err))) { st_sc1(err, 1u); return 0x7FFFFFFF; } // bounded; once tripped, nobody waits again
-    }
-    return v;
-}
 
 // Branch-free forms of the edge filters (8.7.2.3 / 8.7.2.4): every lane computes both candidates and
 // selects, so a step costs the same few dozen VALU instructions whatever the lanes decide -- the

@@ -66,6 +66,8 @@ typedef struct {
                                  launches sit at their latency floor -- see DESIGN.md); 0 (default): one picture after the other */
     int cavlc_threads;        /* host threads that code the slice (ranges of macroblock rows, concatenated bit-exactly into the
                                  same single slice); 1 (default): the calling thread only */
+    int intra_mode;           /* 0 (default): persistent band kernel for the intra reconstruction wavefront; 1: one launch per
+                                 anti-diagonal replayed as a hipGraph (plain form, kept as a cross-check) */
 } mi355enc_cfg_t;
 
 typedef struct {

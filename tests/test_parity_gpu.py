@@ -88,10 +88,13 @@ def test_intra_analyse_kernel_matches_oracle(E, oracle, w, h):
         e.close()
 
 
-@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("w,h", SIZES + [(48, 272), (80, 528)])
 @pytest.mark.parametrize("qp", [0, 12, 28, 40, 51])
 @pytest.mark.parametrize("i4", [True, False])
-def test_intra_kernel_matches_oracle(E, oracle, w, h, qp, i4):
+@pytest.mark.parametrize("imode", [0, 1])
+def test_intra_kernel_matches_oracle(E, oracle, w, h, qp, i4, imode):
+    """imode 0: persistent band kernel (LDS hand-off inside a band, sc1 + progress counters between bands);
+    imode 1: one launch per anti-diagonal from a hipGraph."""
     cy, cuv = frames(w, h, 1)[0][:2]
     oracle.set_i4x4(i4)
     try:
@@ -100,7 +103,7 @@ def test_intra_kernel_matches_oracle(E, oracle, w, h, qp, i4):
         oracle.set_i4x4(True)
     if i4:
         assert (o_mbi["mb_type"] == 2).any() or qp >= 40
-    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp, i4x4=i4)
+    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp, i4x4=i4, intra_mode=imode)
     d_y, d_uv, d_mbi, d_lev = e.stage_intra(cy, cuv, qp)
     assert mbinfo_equal(d_mbi, o_mbi, ("mb_type", "i16_mode", "chroma_mode", "cost")), \
         [(f, first_diff(d_mbi[f], o_mbi[f])) for f in ("mb_type", "i16_mode", "chroma_mode", "cost")]
@@ -129,12 +132,12 @@ def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp, mode):
 
 
 @pytest.mark.parametrize("w,h,n", [(64, 48, 9), (176, 144, 7), (322, 182, 5), (1280, 720, 4), (1920, 1080, 3)])
-@pytest.mark.parametrize("graphs,mode,sub,ov,thr", [(True, 0, True, False, 1), (False, 0, False, False, 3), (True, 1, True, False, 1), (True, 0, True, True, 4)])
-def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub, ov, thr):
+@pytest.mark.parametrize("graphs,mode,sub,ov,thr,imode", [(True, 0, True, False, 1, 0), (False, 0, False, False, 3, 1), (True, 1, True, False, 1, 1), (True, 0, True, True, 4, 0)])
+def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub, ov, thr, imode):
     """Whole path: identical access units, identical reconstruction, and the independent
     decoder reproduces both."""
     qps = [30, 28, 33, 24, 40, 26, 30, 51, 10]
-    e = E.Encoder(w, h, gop=4, fixed_qp=30, use_graphs=graphs, keep_prefilter=True, deblock_mode=mode, subpel=sub, overlap=ov, cavlc_threads=thr)
+    e = E.Encoder(w, h, gop=4, fixed_qp=30, use_graphs=graphs, keep_prefilter=True, deblock_mode=mode, subpel=sub, overlap=ov, cavlc_threads=thr, intra_mode=imode)
     oe = oracle.Encoder(w, h, gop=4, threads=8, subpel=sub)
     dec = oracle.Decoder()
     for i, (_, _, y, uv) in enumerate(frames(w, h, n)):

@@ -1,12 +1,17 @@
-import sys
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""dev tool: intra wavefront time per picture for both forms, with and without Intra_4x4.  python tools/probe_intra.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ceracoder_amd import enc as E, synth
-for i4 in (True, False):
-    for qp in (24, 40):
-        e = E.Encoder(1920, 1080, gop=60, fixed_qp=qp, i4x4=i4)
-        fr = list(synth.s2_frames(1920, 1080, 1))
-        e.encode(*fr[0])
-        t = e.time_stage(E.STAGE_INTRA, 5)
-        mbi = e.fetch(E.FETCH_MBINFO)
-        print("i4x4=%s qp=%d: intra %.3f ms (%.2f us/step), I4 macroblocks %.0f%%" % (i4, qp, t, t * 1e3 / 187, 100.0 * (mbi["mb_type"] == 2).mean()), flush=True)
-        e.close()
+for (w, h) in ((1920, 64), (1920, 1080)):
+    for imode in (0, 1):
+        for i4, qp in ((True, 24), (True, 40), (False, 40)):
+            e = E.Encoder(w, h, gop=60, fixed_qp=qp, i4x4=i4, intra_mode=imode)
+            fr = list(synth.s2_frames(w, h, 1))
+            e.encode(*fr[0])
+            t = e.time_stage(E.STAGE_INTRA, 5)
+            mbi = e.fetch(E.FETCH_MBINFO)
+            steps = e.mbw + e.mbh - 1
+            print("%dx%d intra_mode %d i4x4=%s qp=%d: %.3f ms (%.2f us per x+y step), I4 macroblocks %.0f%%"
+                  % (w, h, imode, i4, qp, t, t * 1e3 / steps, 100.0 * (mbi["mb_type"] == 2).mean()), flush=True)
+            e.close()
