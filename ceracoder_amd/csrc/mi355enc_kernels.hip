@@ -338,6 +338,8 @@ DEV unsigned pack4(int a, int b, int c, int d) { return (unsigned)a | ((unsigned
 DEV int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 255); }
 
 // Chroma of one macroblock, run by 8 consecutive lanes (cl = 0..7: plane c = cl>>2, block b = cl&3).
+// value of lane (l ^ K) of this lane's quad, K = 1..3 (DPP quad_perm)
+template <int K> DEV int quad_xor(int v) { return __builtin_amdgcn_update_dpp(0, v, K == 1 ? 0xB1 : K == 2 ? 0x4E : 0x1B, 0xF, 0xF, false); }
 // pred[16]: prediction of this lane's 4x4 block.  Handles the 2x2 DC Hadamard across the four
 // lanes of a plane with shuffles (8.5.11), writes levels + reconstruction, returns the AC flag
 // in bit 0 and the plane's DC flag in bit 1.
@@ -365,7 +367,7 @@ DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int c
     const int dc = x[0];
     bool nz_ac = quant_dequant<1>(x, lev, q);
     // forward 2x2 Hadamard over the plane's four lanes; lane b keeps element b
-    int d1 = __shfl_xor(dc, 1, 4), d2 = __shfl_xor(dc, 2, 4), d3 = __shfl_xor(dc, 3, 4);
+    int d1 = quad_xor<1>(dc), d2 = quad_xor<2>(dc), d3 = quad_xor<3>(dc); // DPP quad_perm: the four blocks of a plane sit in one quad
     // with e0..e3 the values of blocks 0..3: this lane holds e_b = dc, e_{b^1} = d1, e_{b^2} = d2, e_{b^3} = d3
     int fb;
     {
@@ -377,7 +379,7 @@ DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int c
     }
     const int ldc = quant1(fb, q.mf[0], 2 * q.f, q.qbits + 1);
     // inverse: g = H l H over the four DC levels, dcC = ((g*LevelScale(0,0)) << (qP/6)) >> 5
-    int l1 = __shfl_xor(ldc, 1, 4), l2 = __shfl_xor(ldc, 2, 4), l3 = __shfl_xor(ldc, 3, 4);
+    int l1 = quad_xor<1>(ldc), l2 = quad_xor<2>(ldc), l3 = quad_xor<3>(ldc);
     int gl[4];
     gl[b] = ldc; gl[b ^ 1] = l1; gl[b ^ 2] = l2; gl[b ^ 3] = l3;
     int g0 = gl[0] + gl[1] + gl[2] + gl[3], g1 = gl[0] - gl[1] + gl[2] - gl[3];
@@ -860,11 +862,7 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t cv, int mb
             for (int i = 0; i < 4; i++)
                 pr[r * 4 + i] = ((8 - xf) * (8 - yf) * smp[r][i] + xf * (8 - yf) * smp[r][i + 1] +
                                  (8 - xf) * yf * smp[r + 1][i] + xf * yf * smp[r + 1][i + 1] + 32) >> 6;
-        if (mb_ok) flags = chroma_block(ctx, &g_tab, mbn, cx0, cy0, cl, pr, qp, false);
-        else { // keep the shuffles of partner lanes well-defined
-            (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
-            (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
-        }
+        if (mb_ok) flags = chroma_block(ctx, &g_tab, mbn, cx0, cy0, cl, pr, qp, false); // (a quad is one macroblock's plane: valid or not as a whole)
     }
     const unsigned long long any = __ballot(flags & 1), dcm = __ballot(flags & 2);
     if ((lane == 0 || lane == 16) && mb_ok) {
@@ -1289,22 +1287,28 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
     } else if (is_luma) {
         // ================================================================ Intra_16x16 reconstruction (8.3.3 + 8.5.10)
         const int b = lane, bx = blkx(b), by = blky(b), mode = mode16;
-        int st = 0, sl = 0, Hh = 0, Vv = 0;
+        // neighbour statistics once per macroblock, reduced over the 16 lanes (lane j holds top j / left j): sums for DC,
+        // the weighted sums of 8.3.3.4 for Plane (weights j - 7, and -8 for the corner)
+        const int tj = TOP(0, lane), lj = LEFT(0, lane), cor = TOP(0, -1);
+        const int st = wave16_sum(tj), sl = wave16_sum(lj);
+        if (mode == 0) { // wave-uniform: only the chosen predictor is evaluated
 #pragma unroll
-        for (int i = 0; i < 16; i++) { st += TOP(0, i); sl += LEFT(0, i); }
+            for (int i = 0; i < 4; i++) { const int t = TOP(0, bx + i); pred[i] = t; pred[4 + i] = t; pred[8 + i] = t; pred[12 + i] = t; }
+        } else if (mode == 1) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            Hh += (i + 1) * (TOP(0, 8 + i) - TOP(0, 6 - i));
-            Vv += (i + 1) * (LEFT(0, 8 + i) - LEFT(0, 6 - i));
+            for (int r = 0; r < 4; r++) { const int l = LEFT(0, by + r); pred[r * 4] = l; pred[r * 4 + 1] = l; pred[r * 4 + 2] = l; pred[r * 4 + 3] = l; }
+        } else if (mode == 2) {
+            const int dcv = (has_top && has_left) ? (st + sl + 16) >> 5 : has_top ? (st + 8) >> 4 : has_left ? (sl + 8) >> 4 : 128;
+#pragma unroll
+            for (int k = 0; k < 16; k++) pred[k] = dcv;
+        } else {
+            const int Hh = wave16_sum((lane - 7) * tj) - 8 * cor, Vv = wave16_sum((lane - 7) * lj) - 8 * cor;
+            const int pa = 16 * (LEFT(0, 15) + TOP(0, 15)), pb = (5 * Hh + 32) >> 6, pc = (5 * Vv + 32) >> 6;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) pred[r * 4 + i] = clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5);
         }
-        const int dcv = (has_top && has_left) ? (st + sl + 16) >> 5 : has_top ? (st + 8) >> 4 : has_left ? (sl + 8) >> 4 : 128;
-        const int pa = 16 * (LEFT(0, 15) + TOP(0, 15)), pb = (5 * Hh + 32) >> 6, pc = (5 * Vv + 32) >> 6;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                pred[r * 4 + i] = mode == 0 ? TOP(0, bx + i) : mode == 1 ? LEFT(0, by + r) : mode == 2 ? dcv
-                                  : clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5);
         const qparams q = make_q(T, qp, true);
         int x[16], lev[16];
 #pragma unroll
@@ -1327,9 +1331,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         const int hd = (acc + 1) >> 1;
         const int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
         sh_ldc[lane] = ldc;
-        int kz = 0; // zig-zag position of raster index `lane` (inverse of zz)
-#pragma unroll
-        for (int k = 0; k < 16; k++) if (zz(k) == lane) kz = k;
+        const int kz = (int)((0xFEA9DB83C7426510ull >> (4 * lane)) & 15); // zig-zag position of raster index `lane` (inverse of zz)
         stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + kz], ldc);
         if (ldc) flags |= 2;
         WAVE_SYNC();
@@ -1357,37 +1359,39 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             }
         }
     }
-    if (wave == 1 && lane >= 16 && lane < 32) { // lanes 16-31 form one shuffle group for chroma_block; 16-23 carry the 8 chroma blocks
+    if (is_chroma) { // wave 1, lanes 16-23: the 8 chroma blocks (a plane's four blocks in one DPP quad)
         const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
         const int p = 1 + c;
-        int st = 0, sl = 0;
+        if (cmode == 0) { // wave-uniform: only the chosen predictor is evaluated.  DC of this 4x4 block (8.3.4.1-3)
+            int st = 0, sl = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { st += TOP(p, bx + i); sl += LEFT(p, by + i); }
-        int dcv; // DC of this 4x4 block (8.3.4.1-3)
-        {
+            for (int i = 0; i < 4; i++) { st += TOP(p, bx + i); sl += LEFT(p, by + i); }
             bool ut = has_top, ul = has_left;
             if (b == 1 && has_top) ul = false;
             if (b == 2 && has_left) ut = false;
-            dcv = (ut && ul) ? (st + sl + 4) >> 3 : ut ? (st + 2) >> 2 : ul ? (sl + 2) >> 2 : 128;
+            const int dcv = (ut && ul) ? (st + sl + 4) >> 3 : ut ? (st + 2) >> 2 : ul ? (sl + 2) >> 2 : 128;
+#pragma unroll
+            for (int k = 0; k < 16; k++) pred[k] = dcv;
+        } else if (cmode == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int l = LEFT(p, by + r); pred[r * 4] = l; pred[r * 4 + 1] = l; pred[r * 4 + 2] = l; pred[r * 4 + 3] = l; }
+        } else if (cmode == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int t = TOP(p, bx + i); pred[i] = t; pred[4 + i] = t; pred[8 + i] = t; pred[12 + i] = t; }
+        } else {
+            int Hh = 0, Vv = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Hh += (i + 1) * (TOP(p, 4 + i) - TOP(p, 2 - i));
+                Vv += (i + 1) * (LEFT(p, 4 + i) - LEFT(p, 2 - i));
+            }
+            const int pa = 16 * (LEFT(p, 7) + TOP(p, 7)), pb = (34 * Hh + 32) >> 6, pc = (34 * Vv + 32) >> 6;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) pred[r * 4 + i] = clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5);
         }
-        int Hh = 0, Vv = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            Hh += (i + 1) * (TOP(p, 4 + i) - TOP(p, 2 - i));
-            Vv += (i + 1) * (LEFT(p, 4 + i) - LEFT(p, 2 - i));
-        }
-        const int pa = 16 * (LEFT(p, 7) + TOP(p, 7)), pb = (34 * Hh + 32) >> 6, pc = (34 * Vv + 32) >> 6;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                pred[r * 4 + i] = cmode == 0 ? dcv : cmode == 1 ? LEFT(p, by + r) : cmode == 2 ? TOP(p, bx + i)
-                                  : clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5);
         if (is_chroma) flags = chroma_block(ctx, T, mbn, cx0, cy0, cl, pred, qp, true, OUT ? L->crec : nullptr, presrc);
-        else {
-            (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
-            (void)__shfl_xor(0, 1, 4); (void)__shfl_xor(0, 2, 4); (void)__shfl_xor(0, 3, 4);
-        }
     }
 #undef TOP
 #undef LEFT
@@ -1492,6 +1496,10 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     uint2 srcn[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)}; // this lane's source rows of the next macroblock
     const bool src_luma = role == 0 && lane < 16, src_chroma = role == 1 && lane >= 16 && lane < 24;
     const int nsteps = mbw + IB_ROWS + 1;
+#ifdef IB_PROF /* debug builds: cycles inside intra_compute per wave, and of the whole loop, left in ctx->isad */
+    unsigned long long ib_cyc = 0, ib_n = 0;
+    const unsigned long long ib_l0 = __builtin_readcyclecounter();
+#endif
     for (int t = -1; t < nsteps; t++) { // step -1 only prefetches for the first row
         const int x = t - r, xn = x + 1;
         const bool act = row_ok && x >= 0 && x < mbw;
@@ -1541,7 +1549,13 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
                 L->left[role ? 1 + mc : 0][mi + 1] = lv;
             }
             WAVE_SYNC();
+#ifdef IB_PROF
+            const unsigned long long ib_t0 = __builtin_readcyclecounter();
+#endif
             intra_compute<true>(ctx, T, L, x, my, role, lane, dec0, dec1, srcc);
+#ifdef IB_PROF
+            ib_cyc += __builtin_readcyclecounter() - ib_t0; ib_n++;
+#endif
             // ---- last row of the band: its bottom rows go to the band below
             if (feeds) {
                 WAVE_SYNC();
@@ -1552,6 +1566,12 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
             }
         }
     }
+#ifdef IB_PROF
+    if (lane == 0 && band < 2) {
+        unsigned *o = (unsigned *)ctx->isad + (band * 8 + w) * 4;
+        o[0] = (unsigned)ib_cyc; o[1] = (unsigned)ib_n; o[2] = (unsigned)(__builtin_readcyclecounter() - ib_l0); o[3] = (unsigned)nsteps;
+    }
+#endif
 }
 int k_intra_bands(int mbh) { return (mbh + IB_ROWS - 1) / IB_ROWS; }
 // d_progress: one counter per band (cleared here), then the sticky error word
