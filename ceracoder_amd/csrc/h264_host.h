@@ -19,7 +19,7 @@ size_t h264_write_headers(uint8_t *out, size_t cap, int width, int height, int f
 /* One slice NAL covering the whole picture.  Returns bytes written, 0 if out of room. */
 size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                         int slice_qp, const mb_info_t *mbi, const int16_t *levels);
-/* same, from the packed level stream the device writes (mi355enc_kernels.hip, levels_pack_kernel) */
+/* same, from the packed level stream the device writes (k_handover.hip, levels_pack_kernel) */
 size_t h264_write_slice_packed(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                                int slice_qp, const mb_info_t *mbi, const int16_t *packed);
 

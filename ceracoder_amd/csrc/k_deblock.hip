@@ -1,0 +1,509 @@
+// k_deblock.hip -- in-loop deblocking filter (H.264 8.7): prep + persistent 16-row bands, and the per-diagonal form
+// Hand-written HIP for gfx950 (CDNA4, wave64); part of libmi355enc (see kernels_common.hpp).
+#include "kernels_common.hpp"
+
+// =================================================================== deblocking (8.7)
+DEV void filter_line(const dev_tables *T, uint8_t *pix, int step, int bS, int qp_p, int qp_q, bool chroma) {
+    if (bS == 0) return;
+    const int idx = clip3(0, 51, (qp_p + qp_q + 1) >> 1);
+    const int alpha = T->alpha[idx], beta = T->beta[idx];
+    const int p0 = pix[-step], p1 = pix[-2 * step], q0 = pix[0], q1 = pix[step];
+    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+    if (chroma) {
+        if (bS < 4) {
+            const int tc = T->tc0[idx][bS - 1] + 1;
+            const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+            pix[-step] = (uint8_t)clip255(p0 + dl); pix[0] = (uint8_t)clip255(q0 - dl);
+        } else {
+            pix[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2); pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+        }
+        return;
+    }
+    const int p2 = pix[-3 * step], q2 = pix[2 * step];
+    const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
+    if (bS < 4) {
+        const int tc0 = T->tc0[idx][bS - 1];
+        const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+        const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        pix[-step] = (uint8_t)clip255(p0 + dl); pix[0] = (uint8_t)clip255(q0 - dl);
+        const int avg = (p0 + q0 + 1) >> 1;
+        if (ap) pix[-2 * step] = (uint8_t)(p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1));
+        if (aq) pix[step] = (uint8_t)(q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1));
+    } else {
+        const int p3 = pix[-4 * step], q3 = pix[3 * step];
+        const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        if (ap && small) {
+            pix[-step] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+            pix[-2 * step] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
+            pix[-3 * step] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+        } else pix[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+        if (aq && small) {
+            pix[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+            pix[step] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
+            pix[2 * step] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+        } else pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+    }
+}
+DEV int has_coef(const mb_info_t &m, int bx4, int by4) { // (bx4,by4) raster 4x4 position -> blkIdx bit
+    const int b = ((by4 >> 1) << 3) | ((bx4 >> 1) << 2) | ((by4 & 1) << 1) | (bx4 & 1);
+    if (m.nzmask & NZ_T8) return ((m.nzmask >> (b & ~3)) & 0xF) != 0; // 8.7.2.1: the 8x8 block containing the sample
+    return (m.nzmask >> b) & 1;
+}
+DEV int bs_of(const mb_info_t &mp, int bxp, int byp, const mb_info_t &mq, int bxq, int byq, bool mb_edge) {
+    if (mp.mb_type != 1 || mq.mb_type != 1) return mb_edge ? 4 : 3; // 0 (I16x16) and 2 (I4x4) are intra
+    if (has_coef(mp, bxp, byp) || has_coef(mq, bxq, byq)) return 2;
+    if (iabs(mp.mvx - mq.mvx) >= 4 || iabs(mp.mvy - mq.mvy) >= 4) return 1; // quarter-sample units
+    return 0;
+}
+// One wave per macroblock, launched once per wavefront x + 2y = diag: then the left, top and
+// top-right macroblocks (everything the raster-order process of 8.7 has touched before this
+// macroblock that overlaps its support) are complete, and same-diagonal tiles are disjoint.
+#define TLS 24 /* LDS tile row stride in bytes */
+__global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
+    __shared__ __attribute__((aligned(16))) uint8_t tl[20 * TLS]; // luma rows y0-4..y0+15, cols x0-4..x0+15
+    __shared__ __attribute__((aligned(16))) uint8_t tc[10 * TLS]; // chroma rows cy0-2..cy0+7, bytes 2*(cx0-2)..2*(cx0+8)
+    __shared__ unsigned tabw[TAB_DWORDS];
+    const dev_tables *T = (const dev_tables *)tabw;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
+    int y_lo = diag - (mbw - 1);
+    y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    const int my = y_lo + blockIdx.x, mx = diag - 2 * my;
+    if (my >= mbh || mx < 0 || mx >= mbw) return;
+    const int x0 = mx * 16, y0 = my * 16, cy0 = y0 >> 1;
+    const int lane = threadIdx.x;
+    uint8_t *__restrict__ ry = ctx->rec_y;
+    uint8_t *__restrict__ ruv = ctx->rec_uv;
+    const mb_info_t cur = ld_mbinfo(&ctx->mbi[my * mbw + mx]);
+    const mb_info_t lft = ld_mbinfo(&ctx->mbi[my * mbw + (mx > 0 ? mx - 1 : mx)]);
+    const mb_info_t upp = ld_mbinfo(&ctx->mbi[(my > 0 ? my - 1 : my) * mbw + mx]);
+    // ---- every global load of this macroblock is issued here, before the first wait
+    for (int i = lane; i < TAB_DWORDS; i += 64) tabw[i] = ((const unsigned *)&g_tab)[i];
+    // ---- load tiles (skipping the corner, which this macroblock neither reads nor writes)
+    for (int i = lane; i < 100; i += 64) {
+        int r = i / 5, q = i - r * 5;
+        int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
+        if (gy >= 0 && gx >= 0 && !(r < 4 && q == 0))
+            *(unsigned *)&tl[r * TLS + 4 * q] = ldg32(ry + (size_t)gy * stride + gx);
+    }
+    if (lane < 50) {
+        int r = lane / 5, q = lane - r * 5;
+        int gy = cy0 - 2 + r, gb = x0 - 4 + 4 * q; // chroma byte offset 2*cx0 = x0
+        if (gy >= 0 && gb >= 0 && !(r < 2 && q == 0))
+            *(unsigned *)&tc[r * TLS + 4 * q] = ldg32(ruv + (size_t)gy * stride + gb);
+    }
+    __syncthreads();
+    const int qpc_c = T->qpc[cur.qp], qpc_l = T->qpc[lft.qp], qpc_u = T->qpc[upp.qp];
+    // ---- vertical edges, left to right
+    if (lane < 16) {
+        const int k = lane;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if ((e == 0 && mx == 0) || ((cur.nzmask & NZ_T8) && (e & 1))) continue; // 8x8 transform: edges 1, 3 are not block edges
+            const mb_info_t &mp = e == 0 ? lft : cur;
+            int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 2, cur, e, k >> 2, e == 0);
+            filter_line(T, &tl[(4 + k) * TLS + 4 + 4 * e], 1, bS, mp.qp, cur.qp, false);
+        }
+    } else if (lane < 24) {
+        const int k = lane - 16;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            if (e == 0 && mx == 0) continue;
+            const mb_info_t &mp = e == 0 ? lft : cur;
+            int bS = bs_of(mp, e == 0 ? 3 : e - 1, k >> 1, cur, e, k >> 1, e == 0);
+#pragma unroll
+            for (int c = 0; c < 2; c++) filter_line(T, &tc[(2 + k) * TLS + 4 + 4 * e + c], 2, bS, e == 0 ? qpc_l : qpc_c, qpc_c, true);
+        }
+    }
+    __syncthreads();
+    // ---- horizontal edges, top to bottom
+    if (lane < 16) {
+        const int k = lane;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if ((e == 0 && my == 0) || ((cur.nzmask & NZ_T8) && (e & 1))) continue;
+            const mb_info_t &mp = e == 0 ? upp : cur;
+            int bS = bs_of(mp, k >> 2, e == 0 ? 3 : e - 1, cur, k >> 2, e, e == 0);
+            filter_line(T, &tl[(4 + 4 * e) * TLS + 4 + k], TLS, bS, mp.qp, cur.qp, false);
+        }
+    } else if (lane < 24) {
+        const int k = lane - 16;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            if (e == 0 && my == 0) continue;
+            const mb_info_t &mp = e == 0 ? upp : cur;
+            int bS = bs_of(mp, k >> 1, e == 0 ? 3 : e - 1, cur, k >> 1, e, e == 0);
+#pragma unroll
+            for (int c = 0; c < 2; c++) filter_line(T, &tc[(2 + 2 * e) * TLS + 4 + 2 * k + c], TLS, bS, e == 0 ? qpc_u : qpc_c, qpc_c, true);
+        }
+    }
+    __syncthreads();
+    // ---- write back
+    for (int i = lane; i < 100; i += 64) {
+        int r = i / 5, q = i - r * 5;
+        int gy = y0 - 4 + r, gx = x0 - 4 + 4 * q;
+        if (gy >= 0 && gx >= 0 && !(r < 4 && q == 0))
+            stg32(ry + (size_t)gy * stride + gx, *(const unsigned *)&tl[r * TLS + 4 * q]);
+    }
+    if (lane < 50) {
+        int r = lane / 5, q = lane - r * 5;
+        int gy = cy0 - 2 + r, gb = x0 - 4 + 4 * q;
+        if (gy >= 0 && gb >= 0 && !(r < 2 && q == 0))
+            stg32(ruv + (size_t)gy * stride + gb, *(const unsigned *)&tc[r * TLS + 4 * q]);
+    }
+}
+
+// ------------------------------------------------------------------ shared by the persistent band kernel
+struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
+struct db_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; int band0, nb_total; }; // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+
+// =================================================================== deblocking, persistent: 16-row bands in x + y order
+// One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
+//  (1) Boundary strengths and the alpha/beta/tc0 triples depend only on the macroblock records,
+//      so a flat kernel (deblock_prep_kernel) computes them for the whole picture up front:
+//      64 bytes per macroblock {bS nibbles V/H, six packed parameter pairs}.
+//  (2) x + 2y is sufficient but not necessary.  Macroblock (x, y) only conflicts with its
+//      top-right neighbour (x+1, y-1) on the 3x3 corner of (x, y-1) that the neighbour's left
+//      edge (a VERTICAL edge, first thing it filters) and this macroblock's top edge (a
+//      HORIZONTAL edge, filtered after all vertical ones) both touch.  If every row filters its
+//      vertical edges, all rows meet at one barrier, and then every row filters its horizontal
+//      edges, (x, y) and (x+1, y-1) can share a step: the order x + y with ONE barrier per step
+//      reproduces the raster-order result (mbw + mbh - 1 steps instead of mbw + 2(mbh - 1)).
+// A wave serves four macroblock rows (16 lanes each: one lane per picture line / column), so a
+// workgroup of 4 luma + 4 chroma waves owns a band of 16 rows and only every 16th row boundary
+// crosses global memory: the bottom strip of a band's last row is stored with `sc1` (agent scope,
+// L1-bypassing) stores, `s_waitcnt vmcnt(0)`, then an sc1 store of a monotonic progress counter per band and
+// plane; the band below polls the counter with sc1 loads and reads the strip with sc1 loads
+// (MI355X_MICROARCH.md, "Valid forms").  A band waits only on the band above it, so the wait graph is
+// acyclic; every spin is bounded and reports through `err`.  Each lane
+// group prefetches its next macroblock one step ahead into registers and lands it in LDS after
+// the step's arithmetic, immediately before the step's own stores are issued, so the only
+// `s_waitcnt vmcnt(0)` on the chain waits for loads that have had a whole step to arrive.
+#define D3_ROWS 16
+#define D3_TS 52 /* tile row stride (13 dwords: the 16 lines of a group fall on 16 different banks) */
+struct d3_luma { uint8_t t[20 * D3_TS]; unsigned ring[4][16]; unsigned rec[16]; };   // 1360 B = 340 dwords (20 mod 32)
+struct d3_chroma { uint8_t t[10 * D3_TS]; unsigned ring[4][8]; unsigned rec[16]; };  // 712 B = 178 dwords (18 mod 32)
+#define DBREC_BYTES 64
+
+DEV unsigned pack_par_ab(const dev_tables *T, int idx) { return (unsigned)T->alpha[idx] | ((unsigned)T->beta[idx] << 8); }
+DEV unsigned pack_par_tc(const dev_tables *T, int idx) { return (unsigned)T->tc0[idx][0] | ((unsigned)T->tc0[idx][1] << 8) | ((unsigned)T->tc0[idx][2] << 16); }
+DEV edge_par par_of(unsigned ab, unsigned tc) { edge_par p; p.alpha = (int)(ab & 255); p.beta = (int)(ab >> 8); p.tc0 = tc; return p; }
+
+// One thread per macroblock: words 0-1 bS of the vertical edges (nibble 4*edge + segment), 2-3 of
+// the horizontal edges, then {alpha|beta<<8, tc0 bytes} for luma left / top / inner and chroma
+// left / top / inner.  Edges that are not filtered (picture border, 8x8-transform inner edges) get bS 0.
+// Also clears the band progress counters of the launch that follows.
+__global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv, unsigned *__restrict__ progress, int nprog) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nprog) progress[i] = 0;
+    const int mbw = ctx->mbw, mbh = ctx->mbh;
+    if (i >= mbw * mbh) return;
+    const dev_tables *T = &g_tab;
+    const int my = i / mbw, mx = i - my * mbw;
+    const mb_info_t cur = ld_mbinfo(&ctx->mbi[i]);
+    const mb_info_t lft = ld_mbinfo(&ctx->mbi[mx > 0 ? i - 1 : i]);
+    const mb_info_t upp = ld_mbinfo(&ctx->mbi[my > 0 ? i - mbw : i]);
+    const bool t8 = (cur.nzmask & NZ_T8) != 0;
+    unsigned w[16];
+    unsigned long long bv = 0, bh = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+        for (int sg = 0; sg < 4; sg++) {
+            int v = 0, h = 0;
+            if (!(t8 && (e & 1))) {
+                if (!(e == 0 && mx == 0)) v = bs_of(e == 0 ? lft : cur, e == 0 ? 3 : e - 1, sg, cur, e, sg, e == 0);
+                if (!(e == 0 && my == 0)) h = bs_of(e == 0 ? upp : cur, sg, e == 0 ? 3 : e - 1, cur, sg, e, e == 0);
+            }
+            bv |= (unsigned long long)v << (4 * (e * 4 + sg));
+            bh |= (unsigned long long)h << (4 * (e * 4 + sg));
+        }
+    w[0] = (unsigned)bv; w[1] = (unsigned)(bv >> 32); w[2] = (unsigned)bh; w[3] = (unsigned)(bh >> 32);
+    const int il = clip3(0, 51, (lft.qp + cur.qp + 1) >> 1), it = clip3(0, 51, (upp.qp + cur.qp + 1) >> 1), ii = cur.qp;
+    const int qc = T->qpc[cur.qp], cl = (T->qpc[lft.qp] + qc + 1) >> 1, ct = (T->qpc[upp.qp] + qc + 1) >> 1;
+    w[4] = pack_par_ab(T, il); w[5] = pack_par_tc(T, il); w[6] = pack_par_ab(T, it); w[7] = pack_par_tc(T, it);
+    w[8] = pack_par_ab(T, ii); w[9] = pack_par_tc(T, ii); w[10] = pack_par_ab(T, cl); w[11] = pack_par_tc(T, cl);
+    w[12] = pack_par_ab(T, ct); w[13] = pack_par_tc(T, ct); w[14] = pack_par_ab(T, qc); w[15] = pack_par_tc(T, qc);
+    uint8_t *o = ctx->dbrec + (size_t)i * DBREC_BYTES;
+#pragma unroll
+    for (int q = 0; q < 4; q++) stg128(o + 16 * q, make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]));
+}
+
+typedef v4u v4u_a4 __attribute__((aligned(4)));
+DEV void stg128u(void *p, unsigned a, unsigned b, unsigned c, unsigned d) { v4u t; t.x = a; t.y = b; t.z = c; t.w = d; *(GAS v4u_a4 *)p = t; } // 4-byte aligned
+
+// Branch-free forms of the edge filters (8.7.2.3 / 8.7.2.4): every lane computes both candidates and
+// selects, so a step costs the same few dozen VALU instructions whatever the lanes decide -- the
+// early-outs of edge_luma() only pay when a whole wave agrees, which the uniform `any4` / ballot
+// tests outside keep.  Samples are 0..255, so |a - b| is one v_sad_u8.
+DEV int adiff(int a, int b) { return (int)__builtin_amdgcn_sad_u8((unsigned)a, (unsigned)b, 0u); }
+template <bool MBEDGE>
+DEV void edge_luma2(const edge_par &P, int p3, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int q3, int bS, bool any4) {
+    const int alpha = P.alpha, beta = P.beta;
+    const int d = adiff(p0, q0);
+    const bool f = (bS != 0) & (d < alpha) & (adiff(p1, p0) < beta) & (adiff(q1, q0) < beta);
+    const bool ap = adiff(p2, p0) < beta, aq = adiff(q2, q0) < beta;
+    const int tc0 = (int)((P.tc0 >> (8 * ((bS - 1) & 3))) & 0xFF); // bS 0 or 4 read a don't-care byte
+    const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+    const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    const int avg = (p0 + q0 + 1) >> 1;
+    int np1 = p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1);
+    int nq1 = q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
+    int np0 = clip255(p0 + dl), nq0 = clip255(q0 - dl);
+    int np2 = p2, nq2 = q2;
+    bool wp1 = ap, wq1 = aq;
+    if (MBEDGE && any4) { // bS 4 exists only on macroblock edges, and only if some lane of the wave is intra
+        const bool s4 = bS == 4, small = d < ((alpha >> 2) + 2);
+        const bool sp = ap & small, sq = aq & small;
+        const int sp0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
+        const int sq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+        const int sp1 = (p2 + p1 + p0 + q0 + 2) >> 2, sp2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+        const int sq1 = (p0 + q0 + q1 + q2 + 2) >> 2, sq2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+        np0 = s4 ? sp0 : np0; nq0 = s4 ? sq0 : nq0; np1 = s4 ? sp1 : np1; nq1 = s4 ? sq1 : nq1;
+        wp1 = s4 ? sp : ap; wq1 = s4 ? sq : aq;
+        np2 = (s4 & sp) ? sp2 : p2; nq2 = (s4 & sq) ? sq2 : q2;
+    }
+    p0 = f ? np0 : p0; q0 = f ? nq0 : q0;
+    p1 = (f & wp1) ? np1 : p1; q1 = (f & wq1) ? nq1 : q1;
+    p2 = f ? np2 : p2; q2 = f ? nq2 : q2;
+}
+DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int bS) {
+    const bool f = (bS != 0) & (adiff(p0, q0) < P.alpha) & (adiff(p1, p0) < P.beta) & (adiff(q1, q0) < P.beta);
+    const int tc = (int)((P.tc0 >> (8 * ((bS - 1) & 3))) & 0xFF) + 1;
+    const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    const bool s4 = bS == 4;
+    const int np0 = s4 ? (2 * p1 + p0 + q1 + 2) >> 2 : clip255(p0 + dl);
+    const int nq0 = s4 ? (2 * q1 + q0 + p1 + 2) >> 2 : clip255(q0 - dl);
+    p0 = f ? np0 : p0; q0 = f ? nq0 : q0;
+}
+
+// One workgroup = one band of 16 macroblock rows of ONE plane (blocks [0, nb): luma, [nb, 2nb):
+// chroma -- the planes share nothing but the records, and on separate CUs neither steals issue
+// slots from the other's dependency chain).  4 waves, one per SIMD; a wave serves four rows, 16
+// lanes each.
+template <bool CHROMA>
+DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *lds) {
+    constexpr int rows_mb = CHROMA ? 8 : 16, strip = CHROMA ? 2 : 4, ring_n = CHROMA ? 8 : 16;
+    constexpr int ROW_LDS = CHROMA ? (int)sizeof(d3_chroma) : (int)sizeof(d3_luma);
+    const frame_ctx_t *__restrict__ ctx = &a.ctx;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, k = lane & 15, r = 4 * wave + g, my = band * D3_ROWS + r;
+    const bool row_ok = my < mbh, last_row = my == mbh - 1;
+    const bool fed = row_ok && r == 0 && band > 0;
+    const bool feeds = row_ok && r == D3_ROWS - 1 && !last_row;
+    unsigned *prog_up = a.progress + (CHROMA ? nb : 0) + (band > 0 ? band - 1 : 0), *prog_my = a.progress + (CHROMA ? nb : 0) + band;
+    uint8_t *__restrict__ plane = CHROMA ? ctx->rec_uv : ctx->rec_y;
+    const uint8_t *__restrict__ dbrec = ctx->dbrec;
+    const size_t row0 = (size_t)my * rows_mb;
+    uint8_t *tile = lds + r * ROW_LDS;                                     // d3_luma / d3_chroma of this row: t, ring, rec
+    unsigned *ring = (unsigned *)(tile + (CHROMA ? 10 : 20) * D3_TS);
+    unsigned *recw = ring + 4 * ring_n;
+    const unsigned *ring_up = (const unsigned *)(lds + (r > 0 ? r - 1 : 0) * ROW_LDS + (CHROMA ? 10 : 20) * D3_TS);
+    const int keep = last_row ? rows_mb : rows_mb - strip; // rows stored by this row itself; the strip below goes through the ring
+    uint4 own = make_uint4(0, 0, 0, 0), recv = make_uint4(0, 0, 0, 0);
+    unsigned stripv = 0, strip_next = 0;
+    int avail = 0, avail_next = 0;
+    const int nsteps = mbw + D3_ROWS + 2;
+#if defined(D3_PROF) && D3_PROF == 1 /* debug builds only: per-phase cycle counters (perturbs: every tick drains lgkmcnt) */
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tm0, tm1;
+#define D3_TICK(i) do { tm1 = __builtin_readcyclecounter(); pc[i] += tm1 - tm0; tm0 = tm1; } while (0)
+#else
+#define D3_TICK(i) do { } while (0)
+#endif
+#if defined(D3_PROF) && D3_PROF == 2 /* whole loop only */
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long loop_t0 = __builtin_readcyclecounter();
+#endif
+    for (int t = 0; t < nsteps; t++) {
+        const int x = t - 1 - r, xn = x + 1;
+        const bool act = row_ok && x >= 0 && x < mbw;
+        const bool pf = row_ok && xn >= 0 && xn < mbw;
+        const bool pub = feeds && x >= 1 && x <= mbw;         // strip of macroblock x-1 becomes final in this step's vertical phase
+        const int x0b = x * 16;
+#if defined(D3_PROF) && D3_PROF == 1
+        tm0 = __builtin_readcyclecounter();
+#endif
+        // ---- A. prefetch macroblock x+1 (rows, record, strip of the band above)
+        if (pf) {
+            if (fed) {
+                if (avail < xn + 1) avail = db_wait_get(prog_up, a.err, xn + 1);
+                if (k < strip * 4) strip_next = ld_sc1((const unsigned *)(plane + (row0 - strip + (k >> 2)) * stride + xn * 16 + 4 * (k & 3)));
+                avail_next = (int)ld_sc1(prog_up);
+            }
+            if (k < rows_mb) own = ldg128(plane + (row0 + k) * stride + xn * 16);
+            if (k >= 12) recv = ldg128(dbrec + ((size_t)my * mbw + xn) * DBREC_BYTES + 16 * (k - 12));
+        }
+        D3_TICK(0);
+        // ---- B. vertical edges.  All LDS reads of the phase are issued together (one round trip).
+        const unsigned bvl = act ? recw[0] : 0u, bvh = act ? recw[1] : 0u, bhl = act ? recw[2] : 0u, bhh = act ? recw[3] : 0u;
+        constexpr int o = CHROMA ? 10 : 4;
+        const edge_par PL = par_of(recw[o], recw[o + 1]), PT = par_of(recw[o + 2], recw[o + 3]), PI = par_of(recw[o + 4], recw[o + 5]);
+        if (!CHROMA) {
+            unsigned w5[5];
+#pragma unroll
+            for (int i = 0; i < 5; i++) w5[i] = *(const unsigned *)&tile[(k + 4) * D3_TS + 12 + 4 * i];
+            if (__ballot((bvl | bvh) != 0)) {
+                const int sh = 4 * (k >> 2);
+                int px[20];
+#pragma unroll
+                for (int i = 0; i < 20; i++) px[i] = byte_of(w5[i >> 2], i & 3);
+                {
+                    const int bS = (int)((bvl >> sh) & 15);
+                    const unsigned long long nz = __ballot(bS != 0);
+                    if (nz) edge_luma2<true>(PL, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], bS, __ballot(bS == 4) != 0);
+                }
+#pragma unroll
+                for (int e = 1; e < 4; e++) {
+                    const int bS = (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15);
+                    if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
+                }
+                if (act) {
+                    const unsigned l0 = pack4(px[0], px[1], px[2], px[3]);
+                    *(unsigned *)&tile[(k + 4) * D3_TS + 12] = l0;
+#pragma unroll
+                    for (int i = 1; i < 5; i++) *(unsigned *)&tile[(k + 4) * D3_TS + 12 + 4 * i] = pack4(px[4 * i], px[4 * i + 1], px[4 * i + 2], px[4 * i + 3]);
+                    if (k >= 12 && x > 0 && !last_row) ring[((x - 1) & 3) * 16 + (k - 12) * 4 + 3] = l0; // columns 12..15 of the previous macroblock's strip
+                }
+            }
+        } else {
+            const int kk = k & 7, c = k >> 3, sh = 4 * (kk >> 1);
+            uint8_t *b = &tile[(kk + 2) * D3_TS + 12 + c]; // samples of plane c sit 2 bytes apart; q0 of edge e at byte 4 + 4e
+            int s[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = b[2 * i];
+            if (__ballot((bvl | bvh) != 0)) {
+                edge_chroma2(PL, s[0], s[1], s[2], s[3], (int)((bvl >> sh) & 15));
+                edge_chroma2(PI, s[4], s[5], s[6], s[7], (int)((bvh >> sh) & 15));
+                if (act) {
+                    b[2] = (uint8_t)s[1]; b[4] = (uint8_t)s[2]; b[10] = (uint8_t)s[5]; b[12] = (uint8_t)s[6];
+                    WAVE_SYNC();
+                    if (k >= 6 && k < 8 && x > 0 && !last_row) ring[((x - 1) & 3) * 8 + (k - 6) * 4 + 3] = *(const unsigned *)&tile[(k + 2) * D3_TS + 12];
+                }
+            }
+        }
+        // ---- the strip of macroblock x-1 is final now: hand it to the band below
+        if (pub) {
+            WAVE_SYNC();
+            if (k < strip * 4)
+                st_sc1((unsigned *)(plane + (row0 + rows_mb - strip + (k >> 2)) * stride + (x - 1) * 16 + 4 * (k & 3)), ring[((x - 1) & 3) * ring_n + k]);
+        }
+        D3_TICK(1);
+        // ---- C. the one barrier of the step: every vertical edge of this step precedes every horizontal edge
+        BAND_BARRIER();
+        D3_TICK(2);
+        unsigned sa0 = 0, sa1 = 0, sa2 = 0, sa3 = 0, sb = 0;
+        uint4 sc = make_uint4(0, 0, 0, 0);
+        // ---- D. horizontal edges
+        if (act && my > 0 && k < strip * 4) *(unsigned *)&tile[(k >> 2) * D3_TS + 16 + 4 * (k & 3)] = fed ? stripv : ring_up[(x & 3) * ring_n + k];
+        WAVE_SYNC();
+        {
+            const int sh = 4 * (k >> 2);
+            if (!CHROMA) {
+                int px[20];
+#pragma unroll
+                for (int i = 0; i < 20; i++) px[i] = tile[i * D3_TS + 16 + k];
+                if (__ballot((bhl | bhh) != 0)) {
+                    {
+                        const int bS = (int)((bhl >> sh) & 15);
+                        if (__ballot(bS != 0)) edge_luma2<true>(PT, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], bS, __ballot(bS == 4) != 0);
+                    }
+#pragma unroll
+                    for (int e = 1; e < 4; e++) {
+                        const int bS = (int)(((e < 2 ? bhl : bhh) >> (16 * (e & 1) + sh)) & 15);
+                        if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
+                    }
+                    if (act) {
+#pragma unroll
+                        for (int i = 1; i < 19; i++) tile[i * D3_TS + 16 + k] = (uint8_t)px[i];
+                    }
+                }
+            } else {
+                int b[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) b[i] = tile[i * D3_TS + 16 + k];
+                if (__ballot((bhl | bhh) != 0)) {
+                    edge_chroma2(PT, b[0], b[1], b[2], b[3], (int)((bhl >> sh) & 15));
+                    edge_chroma2(PI, b[4], b[5], b[6], b[7], (int)((bhh >> sh) & 15));
+                    if (act) { tile[1 * D3_TS + 16 + k] = (uint8_t)b[1]; tile[2 * D3_TS + 16 + k] = (uint8_t)b[2]; tile[5 * D3_TS + 16 + k] = (uint8_t)b[5]; tile[6 * D3_TS + 16 + k] = (uint8_t)b[6]; }
+                }
+            }
+        }
+        WAVE_SYNC();
+        D3_TICK(3);
+        if (act) {
+            // bottom strip -> ring (read by the row below after the next barrier)
+            if (!last_row && k < strip * 4) ring[(x & 3) * ring_n + k] = *(const unsigned *)&tile[(rows_mb + (k >> 2)) * D3_TS + 16 + 4 * (k & 3)];
+            // final samples into registers: row k, byte columns -4..11 (the left strip is final now), and the strip of the row above
+            if (k < rows_mb) {
+                unsigned *rp = (unsigned *)&tile[(k + strip) * D3_TS + 12];
+                sa0 = rp[0]; sa1 = rp[1]; sa2 = rp[2]; sa3 = rp[3]; sb = rp[4];
+                rp[0] = sb; // right strip becomes the next macroblock's left strip
+            }
+            if (my > 0 && k < strip) { const unsigned *tp = (const unsigned *)&tile[k * D3_TS + 16]; sc = make_uint4(tp[0], tp[1], tp[2], tp[3]); }
+        }
+        D3_TICK(4);
+        // ---- E. land the prefetch (issued a whole step ago) before this step's stores queue up behind it
+        // Unconditional, and the prefetched registers are "used" right here in uniform control flow: the compiler's
+        // wait-count bookkeeping then knows that no load into them is pending when the stores below are issued.  Without
+        // this it re-waits vmcnt(0) at the top of the next step (before overwriting them) -- i.e. for those stores.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(own.x), "v"(own.y), "v"(own.z), "v"(own.w), "v"(recv.x), "v"(recv.y), "v"(recv.z), "v"(recv.w), "v"(strip_next), "v"(avail_next));
+        D3_TICK(5);
+        if (pub && k == 0) st_sc1(prog_my, (unsigned)x);
+        if (pf) {
+            if (k < rows_mb) { unsigned *d = (unsigned *)&tile[(k + strip) * D3_TS + 16]; d[0] = own.x; d[1] = own.y; d[2] = own.z; d[3] = own.w; }
+            if (k >= 12) { unsigned *d = &recw[4 * (k - 12)]; d[0] = recv.x; d[1] = recv.y; d[2] = recv.z; d[3] = recv.w; }
+            stripv = strip_next; avail = avail_next;
+        }
+        // ---- F. stores (nobody inside this launch reads them back)
+        if (act) {
+            if (k < keep) {
+                uint8_t *dst = plane + (row0 + k) * stride + x0b;
+                if (x > 0) stg128u(dst - 4, sa0, sa1, sa2, sa3);
+                else { stg32(dst, sa1); stg32(dst + 4, sa2); stg32(dst + 8, sa3); }
+                if (x == mbw - 1) stg32(dst + 12, sb); // no right neighbour will patch columns 12..15
+            }
+            if (my > 0 && k < strip) stg128(plane + (row0 - strip + k) * stride + x0b, sc); // the strip of the row above is final after this top edge
+        }
+        D3_TICK(6);
+    }
+#if defined(D3_PROF) && D3_PROF == 2
+    pc[7] = __builtin_readcyclecounter() - loop_t0; pc[6] = (unsigned long long)nsteps;
+#endif
+#ifdef D3_PROF
+    if (lane == 0 && (wave == 0 || wave == 3) && band < 2) {
+        unsigned *o = (unsigned *)(ctx->dbrec) + (((CHROMA ? 2 : 0) + band) * 2 + (wave ? 1 : 0)) * 8; // debug build only: overwrites the first records after use
+        for (int i = 0; i < 8; i++) o[i] = (unsigned)(pc[i] >> 0);
+    }
+#endif
+}
+
+__global__ __launch_bounds__(256) void deblock_band16_kernel(db_args a) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[D3_ROWS * sizeof(d3_luma)];
+    const int nl = gridDim.x >> 1;
+    if ((int)blockIdx.x < nl) band16_body<false>(a, a.band0 + blockIdx.x, a.nb_total, lds);
+    else band16_body<true>(a, a.band0 + blockIdx.x - nl, a.nb_total, lds);
+}
+
+// =================================================================== launchers
+int k_deblock_diags(int mbw, int mbh) { return mbw + 2 * (mbh - 1); }
+void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s) {
+    int y_lo = diag - (mbw - 1);
+    y_lo = y_lo > 0 ? (y_lo + 1) >> 1 : 0;
+    int y_hi = diag / 2 < mbh - 1 ? diag / 2 : mbh - 1;
+    if (y_hi < y_lo) return;
+    hipLaunchKernelGGL(deblock_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
+}
+int k_deblock_bands16(int mbh) { return (mbh + D3_ROWS - 1) / D3_ROWS; }
+// `d_progress` holds 2 * bands counters (luma, chroma) followed by the sticky error word at d_err.  The prep kernel clears
+// the counters; the band kernel may be launched in several pieces (bands [band0, band1)): a band only ever waits for the
+// band above it, so pieces may run concurrently on different streams as long as the upper piece is submitted first.
+void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, hipStream_t s) {
+    hipLaunchKernelGGL(deblock_prep_kernel, dim3((mbw * mbh + 255) / 256), dim3(256), 0, s, *h_ctx, d_progress, nprog);
+}
+void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
+    db_args a;
+    a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh);
+    if (band1 > band0) hipLaunchKernelGGL(deblock_band16_kernel, dim3(2 * (band1 - band0)), dim3(256), 0, s, a);
+}

@@ -1,0 +1,711 @@
+// k_intra.hip -- I pictures: open-loop analysis + decisions, reconstruction wavefront (persistent bands / per diagonal)
+// Hand-written HIP for gfx950 (CDNA4, wave64); part of libmi355enc (see kernels_common.hpp).
+#include "kernels_common.hpp"
+
+// =================================================================== intra analysis (open loop)
+// SAD of every intra candidate of every macroblock, with predictions built from the SOURCE picture's
+// neighbouring samples: no macroblock depends on another, so this is one flat launch (one wave per
+// macroblock) instead of work inside the reconstruction wavefront.  Oracle: orc_intra_analyse.
+DEV int wave16_min(int v) {
+    int o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); v = v < o ? v : o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false); v = v < o ? v : o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  v = v < o ? v : o;
+    o = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  v = v < o ? v : o;
+    return v;
+}
+// one Intra_4x4 prediction sample (8.3.1.2) for pixel (px,py); E(i): ... l1 l0 | corner | t0 .. t7 with the
+// top-right substitution already applied; dc4: the block's DC value
+template <typename EF>
+DEV int pred4_px(int md, int px, int py, EF E, int dc4) {
+    if (md == 0) return E(px + 1);
+    if (md == 1) return E(-(py + 1));
+    if (md == 2) return dc4;
+    if (md == 3) return (px == 3 && py == 3) ? (E(7) + 3 * E(8) + 2) >> 2 : (E(px + py + 1) + 2 * E(px + py + 2) + E(px + py + 3) + 2) >> 2;
+    if (md == 4) return (E(px - py - 1) + 2 * E(px - py) + E(px - py + 1) + 2) >> 2;
+    if (md == 5) {
+        const int z = 2 * px - py, k = px - (py >> 1);
+        return (z >= 0 && !(z & 1)) ? (E(k) + E(k + 1) + 1) >> 1 : z >= 0 ? (E(k - 1) + 2 * E(k) + E(k + 1) + 2) >> 2
+               : z == -1 ? (E(-1) + 2 * E(0) + E(1) + 2) >> 2 : (E(-py) + 2 * E(-py + 1) + E(-py + 2) + 2) >> 2;
+    }
+    if (md == 6) {
+        const int z = 2 * py - px, k = py - (px >> 1);
+        return (z >= 0 && !(z & 1)) ? (E(-k) + E(-k - 1) + 1) >> 1 : z >= 0 ? (E(-k + 1) + 2 * E(-k) + E(-k - 1) + 2) >> 2
+               : z == -1 ? (E(-1) + 2 * E(0) + E(1) + 2) >> 2 : (E(px) + 2 * E(px - 1) + E(px - 2) + 2) >> 2;
+    }
+    if (md == 7) {
+        const int k = px + (py >> 1);
+        return !(py & 1) ? (E(k + 1) + E(k + 2) + 1) >> 1 : (E(k + 1) + 2 * E(k + 2) + E(k + 3) + 2) >> 2;
+    }
+    const int z = px + 2 * py, k = py + (px >> 1);
+    return z > 5 ? E(-4) : z == 5 ? (E(-3) + 3 * E(-4) + 2) >> 2 : !(z & 1) ? (E(-(k + 1)) + E(-(k + 2)) + 1) >> 1
+           : (E(-(k + 1)) + 2 * E(-(k + 2)) + E(-(k + 3)) + 2) >> 2;
+}
+DEV bool mode4_ok(int b, int md, bool up, bool lf, bool ul) {
+    const bool need_up = md == 0 || md == 3 || md == 7, need_left = md == 1 || md == 8, need_all = md >= 4 && md <= 6;
+    return !((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul)) || (b == 5 && (md == 3 || md == 7)));
+}
+#define IA_S 24 /* luma tile stride: row 0 = y -1, col 0 = x -1 */
+__global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *__restrict__ ctx) {
+    __shared__ uint16_t sh_sad[4][ISAD_PER_MB]; // this wave's macroblock: the same 152 values that go to ctx->isad
+    __shared__ int sh_m4[4][16];                // Intra_4x4 modes chosen so far, raster order
+    __shared__ __attribute__((aligned(4))) uint8_t SL[4][17 * IA_S];
+    __shared__ __attribute__((aligned(4))) uint8_t SC[4][2][9 * 12]; // [plane][row 0 = y -1][col 0 = x -1]
+    const int mbw = ctx->mbw, nmb = mbw * ctx->mbh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int mbn = blockIdx.x * 4 + wave;
+    const bool ok = mbn < nmb;
+    if (!ok) mbn = nmb - 1;
+    const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
+    const bool has_top = my > 0, has_left = mx > 0;
+    const uint8_t *__restrict__ sy = ctx->src_y;
+    const uint8_t *__restrict__ suv = ctx->src_uv;
+    const int ss = ctx->src_stride, vh = ctx->vis_h, vh2 = vh >> 1;
+    uint8_t *S = SL[wave];
+    // ---- source tile with its one-sample apron (rows beyond the visible picture repeat the last row, like every source read)
+    {
+        const int r = lane >> 2, q = lane & 3; // interior: 16 rows x 4 dwords
+        int yy = y0 + r; yy = yy < vh ? yy : vh - 1;
+        const unsigned w = ldg32(sy + (size_t)yy * ss + x0 + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; i++) S[(r + 1) * IA_S + 1 + 4 * q + i] = (uint8_t)byte_of(w, i);
+        if (lane < 17) { // top row incl. corner
+            const int x = lane - 1;
+            int yt = y0 - 1; yt = yt < vh ? yt : vh - 1;
+            S[lane] = (has_top && (x >= 0 || has_left)) ? (uint8_t)ldg8(sy + (size_t)yt * ss + x0 + x) : 0;
+        } else if (lane < 33) { // left column
+            int yl = y0 + lane - 17; yl = yl < vh ? yl : vh - 1;
+            S[(lane - 16) * IA_S] = has_left ? (uint8_t)ldg8(sy + (size_t)yl * ss + x0 - 1) : 0;
+        }
+        // chroma: interior 8 rows x 16 bytes (both planes interleaved) = 32 dwords
+        if (lane < 32) {
+            const int cr = lane >> 2, cq = lane & 3;
+            int yc = cy0 + cr; yc = yc < vh2 ? yc : vh2 - 1;
+            const unsigned cwd = ldg32(suv + (size_t)yc * ss + 2 * cx0 + 4 * cq);
+            SC[wave][0][(cr + 1) * 12 + 1 + 2 * cq] = (uint8_t)byte_of(cwd, 0); SC[wave][1][(cr + 1) * 12 + 1 + 2 * cq] = (uint8_t)byte_of(cwd, 1);
+            SC[wave][0][(cr + 1) * 12 + 2 + 2 * cq] = (uint8_t)byte_of(cwd, 2); SC[wave][1][(cr + 1) * 12 + 2 + 2 * cq] = (uint8_t)byte_of(cwd, 3);
+        } else if (lane < 32 + 18) { // top rows incl. corner, both planes
+            const int c = (lane - 32) / 9, x = (lane - 32) % 9 - 1;
+            int yt = cy0 - 1; yt = yt < vh2 ? yt : vh2 - 1;
+            SC[wave][c][x + 1] = (has_top && (x >= 0 || has_left)) ? (uint8_t)ldg8(suv + (size_t)yt * ss + 2 * (cx0 + x) + c) : 0;
+        } else if (lane < 32 + 18 + 14) { // left columns, rows 0..6 of both planes (row 7 below)
+            const int c = (lane - 50) / 7, y = (lane - 50) % 7;
+            int yl = cy0 + y; yl = yl < vh2 ? yl : vh2 - 1;
+            SC[wave][c][(y + 1) * 12] = has_left ? (uint8_t)ldg8(suv + (size_t)yl * ss + 2 * (cx0 - 1) + c) : 0;
+        }
+        if (lane < 2) {
+            int yl = cy0 + 7; yl = yl < vh2 ? yl : vh2 - 1;
+            SC[wave][lane][8 * 12] = has_left ? (uint8_t)ldg8(suv + (size_t)yl * ss + 2 * (cx0 - 1) + lane) : 0;
+        }
+    }
+    WAVE_SYNC();
+    uint16_t *out = ctx->isad + (size_t)mbn * ISAD_PER_MB;
+    const unsigned NA = 0xFFFFu;
+    // ---- Intra_16x16: lane = row lane>>2, columns 4*(lane&3)..+3
+    {
+        const int tl = lane < 16 ? S[lane + 1] : 0, ll = lane < 16 ? S[(lane + 1) * IA_S] : 0;
+        const int st = __shfl(wave16_sum(tl), 0), sl = __shfl(wave16_sum(ll), 0);
+        int hterm = 0, vterm = 0;
+        if (lane < 8) {
+            hterm = (lane + 1) * ((int)S[8 + lane + 1] - (int)S[6 - lane + 1]);                 // x' = lane: p[8+x',-1] - p[6-x',-1] (6-7 = -1 is the corner, col 0)
+            vterm = (lane + 1) * ((int)S[(8 + lane + 1) * IA_S] - (int)S[(6 - lane + 1) * IA_S]);
+        }
+        const int Hh = __shfl(wave16_sum(hterm), 0), Vv = __shfl(wave16_sum(vterm), 0);
+        const int dcv = (has_top && has_left) ? (st + sl + 16) >> 5 : has_top ? (st + 8) >> 4 : has_left ? (sl + 8) >> 4 : 128;
+        const int pa = 16 * ((int)S[16 * IA_S] + (int)S[16]), pb = (5 * Hh + 32) >> 6, pc = (5 * Vv + 32) >> 6;
+        const int r = lane >> 2, c0 = (lane & 3) * 4;
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int sv = S[(r + 1) * IA_S + c0 + i + 1];
+            s0 += iabs(sv - (int)S[c0 + i + 1]);
+            s1 += iabs(sv - (int)S[(r + 1) * IA_S]);
+            s2 += iabs(sv - dcv);
+            s3 += iabs(sv - clip255((pa + pb * (c0 + i - 7) + pc * (r - 7) + 16) >> 5));
+        }
+        int packed01 = wave16_sum(s0 | (s1 << 16)), packed23 = wave16_sum(s2 | (s3 << 16)); // row sums <= 16*255 fit 16 bits each
+        packed01 += __shfl_xor(packed01, 16); packed23 += __shfl_xor(packed23, 16); // 32 lanes: <= 8160
+        const unsigned a01 = (unsigned)packed01, a23 = (unsigned)packed23;
+        const unsigned o01 = (unsigned)__shfl_xor(packed01, 32), o23 = (unsigned)__shfl_xor(packed23, 32);
+        const unsigned t0 = (a01 & 0xFFFF) + (o01 & 0xFFFF), t1 = (a01 >> 16) + (o01 >> 16), t2 = (a23 & 0xFFFF) + (o23 & 0xFFFF), t3 = (a23 >> 16) + (o23 >> 16);
+        if (lane == 0 && ok) {
+            const unsigned v0 = has_top ? t0 : NA, v1 = has_left ? t1 : NA, v3 = (has_top && has_left) ? t3 : NA;
+            stg16(out + 0, (int)v0); stg16(out + 1, (int)v1); stg16(out + 2, (int)t2); stg16(out + 3, (int)v3);
+            sh_sad[wave][0] = (uint16_t)v0; sh_sad[wave][1] = (uint16_t)v1; sh_sad[wave][2] = (uint16_t)t2; sh_sad[wave][3] = (uint16_t)v3;
+        }
+    }
+    // ---- chroma 8x8 (both planes): lane = plane lane>>5, row (lane>>2)&7, columns 2*(lane&3)..+1
+    {
+        const int c = lane >> 5, r = (lane >> 2) & 7, c0 = (lane & 3) * 2;
+        const uint8_t *P = SC[wave][c];
+        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int Hh = 0, Vv = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { Hh += (i + 1) * ((int)P[4 + i + 1] - (int)P[2 - i + 1]); Vv += (i + 1) * ((int)P[(4 + i + 1) * 12] - (int)P[(2 - i + 1) * 12]); }
+        const int pa = 16 * ((int)P[8 * 12] + (int)P[8]), pb = (34 * Hh + 32) >> 6, pc = (34 * Vv + 32) >> 6;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int x = c0 + i, sv = P[(r + 1) * 12 + x + 1];
+            const int qx = x >> 2, qy = r >> 2; // 8.3.4.1-3 DC per 4x4 quadrant
+            int stq = 0, slq = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { stq += P[qx * 4 + k + 1]; slq += P[(qy * 4 + k + 1) * 12]; }
+            bool ut = has_top, ul = has_left;
+            if (qx == 1 && qy == 0 && has_top) ul = false;
+            if (qx == 0 && qy == 1 && has_left) ut = false;
+            const int dcv = (ut && ul) ? (stq + slq + 4) >> 3 : ut ? (stq + 2) >> 2 : ul ? (slq + 2) >> 2 : 128;
+            s0 += iabs(sv - dcv);
+            s1 += iabs(sv - (int)P[(r + 1) * 12]);
+            s2 += iabs(sv - (int)P[x + 1]);
+            s3 += iabs(sv - clip255((pa + pb * (x - 3) + pc * (r - 3) + 16) >> 5));
+        }
+        int p01 = wave16_sum(s0 | (s1 << 16)), p23 = wave16_sum(s2 | (s3 << 16));
+        p01 += __shfl_xor(p01, 16); p23 += __shfl_xor(p23, 16);
+        const unsigned a01 = (unsigned)p01, a23 = (unsigned)p23, o01 = (unsigned)__shfl_xor(p01, 32), o23 = (unsigned)__shfl_xor(p23, 32);
+        const unsigned t0 = (a01 & 0xFFFF) + (o01 & 0xFFFF), t1 = (a01 >> 16) + (o01 >> 16), t2 = (a23 & 0xFFFF) + (o23 & 0xFFFF), t3 = (a23 >> 16) + (o23 >> 16);
+        if (lane == 0 && ok) {
+            const unsigned v1 = has_left ? t1 : NA, v2 = has_top ? t2 : NA, v3 = (has_top && has_left) ? t3 : NA;
+            stg16(out + 4, (int)t0); stg16(out + 5, (int)v1); stg16(out + 6, (int)v2); stg16(out + 7, (int)v3);
+            sh_sad[wave][4] = (uint16_t)t0; sh_sad[wave][5] = (uint16_t)v1; sh_sad[wave][6] = (uint16_t)v2; sh_sad[wave][7] = (uint16_t)v3;
+        }
+    }
+    // ---- Intra_4x4: four blocks at a time, 16 lanes (pixels) each
+    {
+        const int px = lane & 3, py = (lane >> 2) & 3;
+#pragma unroll 1
+        for (int rnd = 0; rnd < 4; rnd++) {
+            const int b = rnd * 4 + (lane >> 4);
+            const int bx = blkx(b) >> 2, by = blky(b) >> 2;
+            const bool up = by > 0 || has_top, lf = bx > 0 || has_left;
+            const bool ul = (bx > 0 && by > 0) ? true : bx > 0 ? has_top : by > 0 ? has_left : (has_top && has_left);
+            const int trb = by > 0 && bx < 3 ? ((((by - 1) >> 1) << 3) | (((bx + 1) >> 1) << 2) | (((by - 1) & 1) << 1) | ((bx + 1) & 1)) : 99;
+            const bool ur = by == 0 ? (bx < 3 && has_top) : (bx < 3 && trb < b);
+            const int emax = ur ? 8 : 4;
+            const uint8_t *tb = &S[(by * 4) * IA_S + bx * 4];
+            auto E = [&](int i) -> int { i = i > emax ? emax : i; return i < 0 ? (int)tb[(-i) * IA_S] : (int)tb[i]; };
+            const int sv = S[(by * 4 + py + 1) * IA_S + bx * 4 + px + 1];
+            const int sumT = E(1) + E(2) + E(3) + E(4), sumL = E(-1) + E(-2) + E(-3) + E(-4);
+            const int dc4 = (up && lf) ? (sumT + sumL + 4) >> 3 : lf ? (sumL + 2) >> 2 : up ? (sumT + 2) >> 2 : 128;
+#pragma unroll
+            for (int md = 0; md < 9; md++) {
+                const int sad = wave16_sum(iabs(sv - pred4_px(md, px, py, E, dc4)));
+                if ((lane & 15) == 0) {
+                    const unsigned v = mode4_ok(b, md, up, lf, ul) ? (unsigned)sad : NA;
+                    if (ok) stg16(out + 8 + b * 9 + md, (int)v);
+                    sh_sad[wave][8 + b * 9 + md] = (uint16_t)v;
+                }
+            }
+        }
+    }
+    // ---- decisions (oracle: orc_intra_decide): nothing outside this macroblock is needed, so they are taken here, in
+    // the flat launch, and the reconstruction wavefront only reads the 24-byte result.
+    WAVE_SYNC();
+    {
+        const uint16_t *isad = sh_sad[wave];
+        const unsigned BIG = 0x10000000u;
+        const int lam = ctx->lambda;
+        int mode16 = 0, cmode = 0;
+        unsigned cost16 = BIG, costc = BIG;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned a = isad[q], c = isad[4 + q];
+            if (a != 0xFFFFu && a < cost16) { cost16 = a; mode16 = q; }
+            if (c != 0xFFFFu && c < costc) { costc = c; cmode = q; }
+        }
+        bool use_i4 = false;
+        unsigned cost_luma = cost16;
+        if (ctx->i4x4) { // Intra_4x4 modes block by block: SAD + lambda * (mode == expected ? 1 : 4); blocks visited along bx + 2*by
+            unsigned cost4 = 0;
+            const int half = (lane >> 4) & 1, cand = lane & 15;
+            int (*m4)[16] = &sh_m4[wave];
+#pragma unroll 1
+            for (int s4 = 0; s4 < 10; s4++) {
+                const int by_lo = s4 > 3 ? (s4 - 2) >> 1 : 0, by_hi = (s4 >> 1) < 3 ? (s4 >> 1) : 3;
+                const bool two = by_lo + 1 <= by_hi;
+                const bool valid = lane < 32 && (half == 0 || two);
+                const int by = (valid && half) ? by_lo + 1 : by_lo, bx = s4 - 2 * by;
+                const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1);
+                const int ma = bx > 0 ? (*m4)[by * 4 + bx - 1] : (has_left ? 2 : -1), mb_ = by > 0 ? (*m4)[(by - 1) * 4 + bx] : (has_top ? 2 : -1);
+                const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
+                unsigned key = 0x7FFFFFFFu;
+                if (cand < 9) {
+                    const unsigned sd = isad[8 + b * 9 + cand];
+                    if (sd != 0xFFFFu) key = ((sd + (unsigned)(lam * (cand == pm ? 1 : 4))) << 4) | (unsigned)cand;
+                }
+                key = (unsigned)wave16_min((int)key);
+                if (valid && cand == 0) (*m4)[by * 4 + bx] = (int)(key & 15);
+                cost4 += (unsigned)__shfl((int)(key >> 4), 0, 64) + (two ? (unsigned)__shfl((int)(key >> 4), 16, 64) : 0u);
+                WAVE_SYNC();
+            }
+            use_i4 = cost4 + (unsigned)(32 * lam) < cost16;
+            if (use_i4) cost_luma = cost4 + (unsigned)(32 * lam);
+        }
+        if (lane < 6 && ok) { // 24-byte record {u8 modes4[16] by blkIdx; u8 mode16, cmode, use_i4, 0; u32 cost}
+            unsigned w = 0;
+            if (lane < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int bb = lane * 4 + i, r = (blky(bb) >> 2) * 4 + (blkx(bb) >> 2);
+                    w |= (ctx->i4x4 ? (unsigned)sh_m4[wave][r] & 0xFF : 0u) << (8 * i);
+                }
+            } else if (lane == 4) w = (unsigned)mode16 | ((unsigned)cmode << 8) | ((use_i4 ? 1u : 0u) << 16);
+            else w = cost_luma + costc;
+            stg32(ctx->idec + (size_t)mbn * IDEC_BYTES + 4 * lane, w);
+        }
+    }
+}
+
+// =================================================================== intra (I) macroblocks
+// One wave per macroblock, launched once per anti-diagonal x + y = diag (left, top and
+// top-left neighbours are then complete).  Lanes 0-15: luma 4x4 blocks; lanes 16-23: chroma.
+// Per-macroblock working set of the intra reconstruction, in LDS.  Filled by the caller: top / left (reconstructed
+// neighbours, [plane 0 = Y, 1 = Cb, 2 = Cr][index i + 1 holds sample i, index 0 the corner]).  Produced for the neighbours
+// to the right and below (persistent kernel): bottom rows into a 4-deep ring, the right column.
+struct intra_lds {
+    int top[3][17], left[3][17];
+    int dc[16], ldc[16];
+    __attribute__((aligned(4))) uint8_t T4[17 * 24]; // Intra_4x4: reconstructed samples incl. the row above / column left
+    __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
+    __attribute__((aligned(4))) uint8_t crec[8 * 16]; // reconstructed chroma, interleaved Cb Cr (OUT only)
+    int mode4[16];
+    unsigned cflags[2];                               // chroma wave -> luma wave: ballots of its blocks' AC / DC flags
+    unsigned cseq;                                    // ... valid once this equals macroblock number + 1
+    __attribute__((aligned(4))) uint8_t bot_y[4][16], bot_c[4][16];
+    __attribute__((aligned(4))) uint8_t right_y[16], right_c[2][8];
+    int corner[3];                                    // bottom-right sample of the macroblock before the one in right_*: the next corner
+};
+
+// Reconstruction of one intra macroblock by two waves (wave 0 luma, wave 1 chroma; the planes share nothing after the
+// decisions).  Needs L->top / L->left in place and visible; dec0/dec1: the 24-byte decision of intra_analyse_kernel.
+template <bool OUT>
+DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, intra_lds *L, const int mx, const int my, const int wave, const int lane,
+                       const uint4 dec0, const uint2 dec1, const uint2 *presrc = nullptr) { // presrc: this lane's source rows, loaded ahead (luma: .x of 4; chroma: 4 pairs)
+    int (*top)[17] = L->top;
+    int (*left)[17] = L->left;
+    int *sh_dc = L->dc, *sh_ldc = L->ldc, *sh_mode4 = L->mode4;
+    uint8_t *T4 = L->T4, *S4 = L->S4;
+    const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
+    const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
+    const bool has_top = my > 0, has_left = mx > 0;
+    uint8_t *__restrict__ ry = ctx->rec_y;
+    const bool is_luma = wave == 0 && lane < 16, is_chroma = wave == 1 && lane >= 16 && lane < 24;
+    const int slot = mx & 3;
+    int src[16];
+    if (is_luma || is_chroma) {
+        const int ss = ctx->src_stride;
+        if (is_luma) {
+            const uint8_t *__restrict__ s = ctx->src_y;
+            const int bx = blkx(lane), by = blky(lane), vh = ctx->vis_h;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int sy = y0 + by + r;
+                sy = sy < vh ? sy : vh - 1;
+                unsigned sw = presrc ? presrc[r].x : ldg32(s + (size_t)sy * ss + x0 + bx);
+#pragma unroll
+                for (int i = 0; i < 4; i++) src[r * 4 + i] = byte_of(sw, i);
+                *(unsigned *)&S4[(by + r) * 16 + bx] = sw;
+            }
+        } else {
+            const uint8_t *__restrict__ s = ctx->src_uv;
+            const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4, vh2 = ctx->vis_h >> 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int sy = cy0 + by + r;
+                sy = sy < vh2 ? sy : vh2 - 1;
+                uint2 w = presrc ? presrc[r] : ldg64(s + (size_t)sy * ss + 2 * (cx0 + bx));
+                unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
+                src[r * 4 + 0] = (int)(lo & 255); src[r * 4 + 1] = (int)((lo >> 16) & 255);
+                src[r * 4 + 2] = (int)(hi & 255); src[r * 4 + 3] = (int)((hi >> 16) & 255);
+            }
+        }
+    }
+#define TOP(p, i) top[p][(i) + 1]
+#define LEFT(p, i) left[p][(i) + 1]
+    // ---- decisions were taken by intra_analyse_kernel (oracle: orc_intra_decide)
+    const int mode16 = (int)(dec1.x & 255), cmode = (int)((dec1.x >> 8) & 255);
+    const bool use_i4 = ((dec1.x >> 16) & 255) != 0;
+    unsigned nz4 = 0;
+    if (use_i4 && wave == 0 && lane < 16) { // raster order for the reconstruction loop
+        const int bb = ((lane >> 3) << 3) | (((lane & 3) >> 1) << 2) | (((lane >> 2) & 1) << 1) | (lane & 1); // raster (by = lane>>2, bx = lane&3) -> blkIdx
+        const unsigned w = bb < 4 ? dec0.x : bb < 8 ? dec0.y : bb < 12 ? dec0.z : dec0.w;
+        sh_mode4[lane] = (int)((w >> (8 * (bb & 3))) & 255);
+    }
+    WAVE_SYNC();
+    int pred[16];
+    int flags = 0;
+    if (use_i4 && wave == 0) {
+        // ================================================================ Intra_4x4 reconstruction (8.3.1.2 + 8.5)
+        // Same block order; up to two blocks per step, 16 lanes each, lane = one pixel; transforms across lanes.
+        if (lane < 17) T4[lane] = (uint8_t)TOP(0, lane - 1);
+        else if (lane < 33) T4[(lane - 16) * 24] = (uint8_t)LEFT(0, lane - 17);
+        const int half = (lane >> 4) & 1, px = lane & 3, py = (lane >> 2) & 3;
+        const qparams q4 = make_q(T, qp, true);
+        const int cl4 = (!(px & 1) && !(py & 1)) ? 0 : ((px & 1) && (py & 1)) ? 1 : 2;
+        const int mf4 = cl4 == 0 ? q4.mf[0] : cl4 == 1 ? q4.mf[1] : q4.mf[2], v4 = cl4 == 0 ? q4.v[0] : cl4 == 1 ? q4.v[1] : q4.v[2];
+        const int kz4 = (int)((0xFEA9DB83C7426510ull >> (4 * (py * 4 + px))) & 15); // raster -> zig-zag position
+        WAVE_SYNC();
+#pragma unroll 1
+        for (int s4 = 0; s4 < 10; s4++) {
+            const int by_lo = s4 > 3 ? (s4 - 2) >> 1 : 0, by_hi = (s4 >> 1) < 3 ? (s4 >> 1) : 3;
+            const bool two = by_lo + 1 <= by_hi;
+            const bool valid = lane < 32 && (half == 0 || two);
+            const int by = (valid && half) ? by_lo + 1 : by_lo, bx = s4 - 2 * by;
+            const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1); // blkIdx
+            const bool up = by > 0 || has_top, lf = bx > 0 || has_left;
+            const int trb = by > 0 && bx < 3 ? ((((by - 1) >> 1) << 3) | (((bx + 1) >> 1) << 2) | (((by - 1) & 1) << 1) | ((bx + 1) & 1)) : 99;
+            const bool ur = by == 0 ? (bx < 3 && has_top) : (bx < 3 && trb < b);
+            const int emax = ur ? 8 : 4;
+            const uint8_t *tb = &T4[(by * 4) * 24 + bx * 4];
+            auto E = [&](int i) -> int { i = i > emax ? emax : i; return i < 0 ? (int)tb[(-i) * 24] : (int)tb[i]; };
+            const int bmode = sh_mode4[by * 4 + bx];
+            const int sv = S4[(by * 4 + py) * 16 + bx * 4 + px];
+            const int sumT = E(1) + E(2) + E(3) + E(4), sumL = E(-1) + E(-2) + E(-3) + E(-4);
+            const int dc4 = (up && lf) ? (sumT + sumL + 4) >> 3 : lf ? (sumL + 2) >> 2 : up ? (sumT + 2) >> 2 : 128;
+            const int bpred = pred4_px(bmode, px, py, E, dc4);
+            // residual -> 4x4 core transform across the 16 lanes (rows, then columns)
+            const int res = sv - bpred;
+            const int cbase = lane & ~12;
+            int a0 = quad_bcast<0>(res), a1 = quad_bcast<1>(res), a2 = quad_bcast<2>(res), a3 = quad_bcast<3>(res);
+            int tr = px == 0 ? a0 + a1 + a2 + a3 : px == 1 ? 2 * a0 + a1 - a2 - 2 * a3 : px == 2 ? a0 - a1 - a2 + a3 : a0 - 2 * a1 + 2 * a2 - a3;
+            a0 = __shfl(tr, cbase, 64); a1 = __shfl(tr, cbase + 4, 64); a2 = __shfl(tr, cbase + 8, 64); a3 = __shfl(tr, cbase + 12, 64);
+            const int coef = py == 0 ? a0 + a1 + a2 + a3 : py == 1 ? 2 * a0 + a1 - a2 - 2 * a3 : py == 2 ? a0 - a1 - a2 + a3 : a0 - 2 * a1 + 2 * a2 - a3;
+            const int lv4 = quant1(coef, mf4, q4.f, q4.qbits);
+            // 8.5.12: scale, inverse transform (rows then columns), round
+            const int dq = (lv4 * v4) << q4.shift;
+            a0 = quad_bcast<0>(dq); a1 = quad_bcast<1>(dq); a2 = quad_bcast<2>(dq); a3 = quad_bcast<3>(dq);
+            {
+                const int e0 = a0 + a2, e1 = a0 - a2, e2 = (a1 >> 1) - a3, e3 = a1 + (a3 >> 1);
+                tr = px == 0 ? e0 + e3 : px == 1 ? e1 + e2 : px == 2 ? e1 - e2 : e0 - e3;
+            }
+            a0 = __shfl(tr, cbase, 64); a1 = __shfl(tr, cbase + 4, 64); a2 = __shfl(tr, cbase + 8, 64); a3 = __shfl(tr, cbase + 12, 64);
+            int rr;
+            {
+                const int e0 = a0 + a2, e1 = a0 - a2, e2 = (a1 >> 1) - a3, e3 = a1 + (a3 >> 1);
+                rr = py == 0 ? e0 + e3 : py == 1 ? e1 + e2 : py == 2 ? e1 - e2 : e0 - e3;
+            }
+            const int recp = clip255(bpred + ((rr + 32) >> 6));
+            const unsigned long long bal = __ballot(valid && lv4 != 0);
+            const int b0 = ((by_lo >> 1) << 3) | (((s4 - 2 * by_lo) >> 1) << 2) | ((by_lo & 1) << 1) | ((s4 - 2 * by_lo) & 1);
+            if (bal & 0xFFFFull) nz4 |= 1u << b0;
+            if (two) {
+                const int by1 = by_lo + 1, bx1 = s4 - 2 * by1, b1 = ((by1 >> 1) << 3) | ((bx1 >> 1) << 2) | ((by1 & 1) << 1) | (bx1 & 1);
+                if (bal & 0xFFFF0000ull) nz4 |= 1u << b1;
+            }
+            if (valid) {
+                T4[(by * 4 + py + 1) * 24 + bx * 4 + px + 1] = (uint8_t)recp;
+                stg8(ry + (size_t)(y0 + by * 4 + py) * stride + x0 + bx * 4 + px, (unsigned)recp);
+                stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + b * 16 + kz4], lv4);
+                if ((lane & 15) == 0) stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + b], bmode);
+            }
+            WAVE_SYNC();
+        }
+        if (OUT && lane < 16) { L->bot_y[slot][lane] = T4[16 * 24 + lane + 1]; L->right_y[lane] = T4[(lane + 1) * 24 + 16]; }
+    } else if (is_luma) {
+        // ================================================================ Intra_16x16 reconstruction (8.3.3 + 8.5.10)
+        const int b = lane, bx = blkx(b), by = blky(b), mode = mode16;
+        // neighbour statistics once per macroblock, reduced over the 16 lanes (lane j holds top j / left j): sums for DC,
+        // the weighted sums of 8.3.3.4 for Plane (weights j - 7, and -8 for the corner)
+        const int tj = TOP(0, lane), lj = LEFT(0, lane), cor = TOP(0, -1);
+        const int st = wave16_sum(tj), sl = wave16_sum(lj);
+        if (mode == 0) { // wave-uniform: only the chosen predictor is evaluated
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int t = TOP(0, bx + i); pred[i] = t; pred[4 + i] = t; pred[8 + i] = t; pred[12 + i] = t; }
+        } else if (mode == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int l = LEFT(0, by + r); pred[r * 4] = l; pred[r * 4 + 1] = l; pred[r * 4 + 2] = l; pred[r * 4 + 3] = l; }
+        } else if (mode == 2) {
+            const int dcv = (has_top && has_left) ? (st + sl + 16) >> 5 : has_top ? (st + 8) >> 4 : has_left ? (sl + 8) >> 4 : 128;
+#pragma unroll
+            for (int k = 0; k < 16; k++) pred[k] = dcv;
+        } else {
+            const int Hh = wave16_sum((lane - 7) * tj) - 8 * cor, Vv = wave16_sum((lane - 7) * lj) - 8 * cor;
+            const int pa = 16 * (LEFT(0, 15) + TOP(0, 15)), pb = (5 * Hh + 32) >> 6, pc = (5 * Vv + 32) >> 6;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) pred[r * 4 + i] = clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5);
+        }
+        const qparams q = make_q(T, qp, true);
+        int x[16], lev[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = src[k] - pred[k];
+        fdct4(x);
+        sh_dc[(by >> 2) * 4 + (bx >> 2)] = x[0];
+        bool nz = quant_dequant<1>(x, lev, q);
+        store_levels(ctx->levels + (size_t)mbn * MB_LEVELS + L_LUMA + b * 16, lev);
+        flags = nz ? 1 : 0;
+        WAVE_SYNC();
+        // lane p = raster position (i,j): hd = (M X M^T + 1) >> 1, M = [[1,1,1,1],[1,1,-1,-1],[1,-1,-1,1],[1,-1,1,-1]]
+        const int pi = lane >> 2, pj = lane & 3;
+        const int Mi[4] = {1, pi < 2 ? 1 : -1, (pi == 0 || pi == 3) ? 1 : -1, (pi & 1) ? -1 : 1};
+        const int Mj[4] = {1, pj < 2 ? 1 : -1, (pj == 0 || pj == 3) ? 1 : -1, (pj & 1) ? -1 : 1};
+        int acc = 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; c2++) acc += Mi[a] * Mj[c2] * sh_dc[a * 4 + c2];
+        const int hd = (acc + 1) >> 1;
+        const int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
+        sh_ldc[lane] = ldc;
+        const int kz = (int)((0xFEA9DB83C7426510ull >> (4 * lane)) & 15); // zig-zag position of raster index `lane` (inverse of zz)
+        stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + kz], ldc);
+        if (ldc) flags |= 2;
+        WAVE_SYNC();
+        { // inverse for this lane's own block position (by/4, bx/4): f = M c M^T, then 8.5.10 scaling
+            const int bi = by >> 2, bj = bx >> 2;
+            const int Ni[4] = {1, bi < 2 ? 1 : -1, (bi == 0 || bi == 3) ? 1 : -1, (bi & 1) ? -1 : 1};
+            const int Nj[4] = {1, bj < 2 ? 1 : -1, (bj == 0 || bj == 3) ? 1 : -1, (bj & 1) ? -1 : 1};
+            int f = 0;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int c2 = 0; c2 < 4; c2++) f += Ni[a] * Nj[c2] * sh_ldc[a * 4 + c2];
+            const int ls = 16 * q.v[0];
+            x[0] = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+        }
+        idct4(x);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned rw = pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
+                                      clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3]));
+            stg32(ry + (size_t)(y0 + by + r) * stride + x0 + bx, rw);
+            if (OUT) {
+                if (by == 12 && r == 3) *(unsigned *)&L->bot_y[slot][bx] = rw;
+                if (bx == 12) L->right_y[by + r] = (uint8_t)(rw >> 24);
+            }
+        }
+    }
+    if (is_chroma) { // wave 1, lanes 16-23: the 8 chroma blocks (a plane's four blocks in one DPP quad)
+        const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
+        const int p = 1 + c;
+        if (cmode == 0) { // wave-uniform: only the chosen predictor is evaluated.  DC of this 4x4 block (8.3.4.1-3)
+            int st = 0, sl = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { st += TOP(p, bx + i); sl += LEFT(p, by + i); }
+            bool ut = has_top, ul = has_left;
+            if (b == 1 && has_top) ul = false;
+            if (b == 2 && has_left) ut = false;
+            const int dcv = (ut && ul) ? (st + sl + 4) >> 3 : ut ? (st + 2) >> 2 : ul ? (sl + 2) >> 2 : 128;
+#pragma unroll
+            for (int k = 0; k < 16; k++) pred[k] = dcv;
+        } else if (cmode == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int l = LEFT(p, by + r); pred[r * 4] = l; pred[r * 4 + 1] = l; pred[r * 4 + 2] = l; pred[r * 4 + 3] = l; }
+        } else if (cmode == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const int t = TOP(p, bx + i); pred[i] = t; pred[4 + i] = t; pred[8 + i] = t; pred[12 + i] = t; }
+        } else {
+            int Hh = 0, Vv = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                Hh += (i + 1) * (TOP(p, 4 + i) - TOP(p, 2 - i));
+                Vv += (i + 1) * (LEFT(p, 4 + i) - LEFT(p, 2 - i));
+            }
+            const int pa = 16 * (LEFT(p, 7) + TOP(p, 7)), pb = (34 * Hh + 32) >> 6, pc = (34 * Vv + 32) >> 6;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) pred[r * 4 + i] = clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5);
+        }
+        if (is_chroma) flags = chroma_block(ctx, T, mbn, cx0, cy0, cl, pred, qp, true, OUT ? L->crec : nullptr, presrc);
+    }
+#undef TOP
+#undef LEFT
+    const unsigned long long any = __ballot(flags & 1), dcm = __ballot(flags & 2);
+    if (wave == 1) {
+        if (OUT) {
+            WAVE_SYNC();
+            if (lane >= 16 && lane < 32) {
+                const int i = lane - 16;
+                L->bot_c[slot][i] = L->crec[7 * 16 + i];
+                L->right_c[i >> 3][i & 7] = L->crec[(i & 7) * 16 + 14 + (i >> 3)];
+            }
+        }
+        if (lane == 0) {
+            L->cflags[0] = (unsigned)((any >> 16) & 0xFF); L->cflags[1] = (unsigned)((dcm >> 16) & 0xFF);
+            __hip_atomic_store(&L->cseq, (unsigned)mbn + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else if (lane == 0) { // the luma wave writes the record once the chroma wave's flags are in (both waves are resident: plain spin)
+        while (__hip_atomic_load(&L->cseq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)mbn + 1u) __builtin_amdgcn_s_sleep(1);
+        const unsigned cany = L->cflags[0], cdc = L->cflags[1];
+        unsigned nzm = (use_i4 ? nz4 : (unsigned)(any & 0xFFFF)) | (cany << 16);
+        if (!use_i4 && (dcm & 0xFFFF)) nzm |= NZ_LDC;
+        if (cdc & 0x0F) nzm |= NZ_CBDC;
+        if (cdc & 0xF0) nzm |= NZ_CRDC;
+        mb_info_t mb;
+        mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)mode16; mb.chroma_mode = (uint8_t)cmode;
+        mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = dec1.y;
+        st_mbinfo(&ctx->mbi[mbn], mb);
+    }
+}
+
+// One launch per anti-diagonal x + y (replayed as a hipGraph): neighbours come from the reconstructed picture in global
+// memory.  intra_mode 1; kept as the plain form and cross-check of the persistent kernel below.
+__global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restrict__ ctx, int diag) {
+    __shared__ intra_lds LD;
+    __shared__ unsigned tabw[TAB_DWORDS];
+    const dev_tables *T = (const dev_tables *)tabw;
+    const int mbw = ctx->mbw, stride = ctx->stride;
+    const int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
+    const int my = y_lo + blockIdx.x, mx = diag - my;
+    const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
+    const bool has_top = my > 0, has_left = mx > 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t *__restrict__ ry = ctx->rec_y;
+    const uint8_t *__restrict__ ruv = ctx->rec_uv;
+    for (int i = threadIdx.x; i < TAB_DWORDS; i += 128) tabw[i] = ((const unsigned *)&g_tab)[i];
+    if (threadIdx.x == 0) LD.cseq = 0;
+    const uint4 dec0 = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES);              // modes4[16]
+    const uint2 dec1 = ldg64(ctx->idec + (size_t)mbn * IDEC_BYTES + 16);          // mode16, cmode, use_i4 | cost
+    if (wave == 0 && lane >= 24 && lane < 24 + 17) { // wave 0, lanes 24-40: luma neighbours; index i+1 holds sample i, index 0 the corner
+        int i = lane - 24 - 1;
+        LD.top[0][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ry + (size_t)(y0 - 1) * stride + x0 + i) : 0;
+        LD.left[0][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ry + (size_t)(y0 + i) * stride + x0 - 1) : 0;
+    } else if (wave == 1 && lane >= 41 && lane < 41 + 18) { // wave 1, lanes 41-58: chroma neighbours
+        int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
+        LD.top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c) : 0;
+        LD.left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c) : 0;
+    }
+    __syncthreads();
+    intra_compute<false>(ctx, T, &LD, mx, my, wave, lane, dec0, dec1);
+}
+
+// Persistent form of the intra wavefront (intra_mode 0): one launch per picture.  A workgroup owns a band of IB_ROWS
+// macroblock rows, two waves per row (luma, chroma); all rows advance in lock-step, one barrier per step, row r handling
+// macroblock x = t - r at step t (x + y order: left, top-left and top neighbours are complete, and Intra_4x4 never looks
+// past its own macroblock's columns in the row above).  Neighbour samples never go through global memory inside a band:
+// the bottom row of a macroblock travels to the row below through a 4-deep LDS ring, its right column stays in the row's
+// own LDS for the next step.  Between bands the bottom rows of the last row are stored with `sc1` and announced through a
+// progress counter, exactly like the deblocking bands; the first row of a band prefetches them one step ahead.
+#define IB_ROWS 4
+struct ib_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; };
+
+__global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
+    __shared__ intra_lds LD[IB_ROWS];
+    __shared__ unsigned tabw[TAB_DWORDS];
+    __shared__ unsigned stage[2][8]; // first row of a band: the prefetched samples of the band above (luma, chroma), 5 dwords each
+    const dev_tables *T = (const dev_tables *)tabw;
+    const frame_ctx_t *__restrict__ ctx = &a.ctx;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
+    const int band = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = w >> 1, role = w & 1;
+    const int my = band * IB_ROWS + r;
+    const bool row_ok = my < mbh, has_top = my > 0;
+    const bool fed = row_ok && r == 0 && band > 0;                        // top samples come from the band above
+    const bool feeds = row_ok && r == IB_ROWS - 1 && my != mbh - 1;       // bottom rows go to the band below
+    intra_lds *L = &LD[r];
+    const intra_lds *Lup = &LD[r > 0 ? r - 1 : 0];
+    for (int i = threadIdx.x; i < TAB_DWORDS; i += IB_ROWS * 128) tabw[i] = ((const unsigned *)&g_tab)[i];
+    if (lane == 0 && role == 0) L->cseq = 0;
+    const uint8_t *__restrict__ ry = ctx->rec_y;
+    const uint8_t *__restrict__ ruv = ctx->rec_uv;
+    unsigned *prog_up = a.progress + (band > 0 ? band - 1 : 0), *prog_my = a.progress + band;
+    // the lanes that move neighbour samples: luma wave 24..40 (i = -1..15), chroma wave 41..58 (plane c, i = -1..7)
+    const bool mover = role == 0 ? (lane >= 24 && lane < 41) : (lane >= 41 && lane < 59);
+    const int mi = role == 0 ? lane - 25 : (lane - 41) % 9 - 1, mc = role == 0 ? 0 : (lane - 41) / 9;
+    // ... and the lanes that fetch for a fed row: 5 dwords starting 4 bytes left of the macroblock (the corner is byte 3 of dword 0)
+    const bool fetcher = fed && lane >= 24 && lane < 29;
+    const uint8_t *frow = role == 0 ? ry + (size_t)(my * 16 - 1) * stride : ruv + (size_t)(my * 8 - 1) * stride;
+    unsigned gpre = 0;
+    int avail = 0;
+    uint4 dec0n = make_uint4(0, 0, 0, 0);
+    uint2 dec1n = make_uint2(0, 0);
+    uint2 srcn[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)}; // this lane's source rows of the next macroblock
+    const bool src_luma = role == 0 && lane < 16, src_chroma = role == 1 && lane >= 16 && lane < 24;
+    const int nsteps = mbw + IB_ROWS + 1;
+#ifdef IB_PROF /* debug builds: cycles inside intra_compute per wave, and of the whole loop, left in ctx->isad */
+    unsigned long long ib_cyc = 0, ib_n = 0;
+    const unsigned long long ib_l0 = __builtin_readcyclecounter();
+#endif
+    for (int t = -1; t < nsteps; t++) { // step -1 only prefetches for the first row
+        const int x = t - r, xn = x + 1;
+        const bool act = row_ok && x >= 0 && x < mbw;
+        const bool pf = row_ok && xn >= 0 && xn < mbw;
+        if (feeds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // both waves: the bottom rows stored in the previous step have landed
+        __syncthreads(); // the rings and right columns written in the previous step are visible
+        if (feeds && role == 0 && lane == 0 && x >= 1 && x <= mbw) st_sc1(prog_my, (unsigned)x); // ... announce them
+        // ---- land what was prefetched for this step, prefetch for the next one
+        const uint4 dec0 = dec0n;
+        const uint2 dec1 = dec1n;
+        const uint2 srcc[4] = {srcn[0], srcn[1], srcn[2], srcn[3]};
+        if (fed && act && lane >= 24 && lane < 29) stage[role][lane - 24] = gpre;
+        if (pf) {
+            const size_t mbn_n = (size_t)my * mbw + xn;
+            dec0n = ldg128(ctx->idec + mbn_n * IDEC_BYTES);
+            dec1n = ldg64(ctx->idec + mbn_n * IDEC_BYTES + 16);
+            if (src_luma) {
+                const int bx = blkx(lane), by = blky(lane), vh = ctx->vis_h;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { int sy = my * 16 + by + q; sy = sy < vh ? sy : vh - 1; srcn[q].x = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + xn * 16 + bx); }
+            } else if (src_chroma) {
+                const int cl = lane & 7, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4, vh2 = ctx->vis_h >> 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { int sy = my * 8 + by + q; sy = sy < vh2 ? sy : vh2 - 1; srcn[q] = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * (xn * 8 + bx)); }
+            }
+            if (fed) {
+                if (avail < xn + 1) avail = db_wait_get(prog_up, a.err, xn + 1);
+                if (fetcher) gpre = xn > 0 || lane > 24 ? ld_sc1((const unsigned *)(frow + xn * 16 - 4 + 4 * (lane - 24))) : 0u;
+            }
+        }
+        WAVE_SYNC();
+        if (act) {
+            // ---- neighbours of macroblock x into L->top / L->left
+            if (mover) {
+                const bool has_left = x > 0;
+                int tv = 0, lv = 0;
+                if (role == 0) {
+                    if (has_top && (mi >= 0 || has_left))
+                        tv = fed ? (int)((const uint8_t *)stage[0])[4 + mi] : (mi >= 0 ? (int)Lup->bot_y[x & 3][mi] : (int)Lup->bot_y[(x - 1) & 3][15]);
+                    if (has_left && (mi >= 0 || has_top)) lv = mi >= 0 ? (int)L->right_y[mi] : tv;
+                } else {
+                    if (has_top && (mi >= 0 || has_left))
+                        tv = fed ? (int)((const uint8_t *)stage[1])[4 + 2 * mi + mc] : (mi >= 0 ? (int)Lup->bot_c[x & 3][2 * mi + mc] : (int)Lup->bot_c[(x - 1) & 3][14 + mc]);
+                    if (has_left && (mi >= 0 || has_top)) lv = mi >= 0 ? (int)L->right_c[mc][mi] : tv;
+                }
+                L->top[role ? 1 + mc : 0][mi + 1] = tv;
+                L->left[role ? 1 + mc : 0][mi + 1] = lv;
+            }
+            WAVE_SYNC();
+#ifdef IB_PROF
+            const unsigned long long ib_t0 = __builtin_readcyclecounter();
+#endif
+            intra_compute<true>(ctx, T, L, x, my, role, lane, dec0, dec1, srcc);
+#ifdef IB_PROF
+            ib_cyc += __builtin_readcyclecounter() - ib_t0; ib_n++;
+#endif
+            // ---- last row of the band: its bottom rows go to the band below
+            if (feeds) {
+                WAVE_SYNC();
+                if (lane < 4) {
+                    if (role == 0) st_sc1((unsigned *)(ctx->rec_y + (size_t)(my * 16 + 15) * stride + x * 16) + lane, ((const unsigned *)L->bot_y[x & 3])[lane]);
+                    else st_sc1((unsigned *)(ctx->rec_uv + (size_t)(my * 8 + 7) * stride + x * 16) + lane, ((const unsigned *)L->bot_c[x & 3])[lane]);
+                }
+            }
+        }
+    }
+#ifdef IB_PROF
+    if (lane == 0 && band < 2) {
+        unsigned *o = (unsigned *)ctx->isad + (band * 8 + w) * 4;
+        o[0] = (unsigned)ib_cyc; o[1] = (unsigned)ib_n; o[2] = (unsigned)(__builtin_readcyclecounter() - ib_l0); o[3] = (unsigned)nsteps;
+    }
+#endif
+}
+int k_intra_bands(int mbh) { return (mbh + IB_ROWS - 1) / IB_ROWS; }
+// d_progress: one counter per band (cleared here), then the sticky error word
+void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
+    ib_args a;
+    a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err;
+    (void)hipMemsetAsync(d_progress, 0, (size_t)k_intra_bands(mbh) * sizeof(unsigned), s);
+    hipLaunchKernelGGL(intra_band_kernel, dim3(k_intra_bands(mbh)), dim3(IB_ROWS * 128), 0, s, a);
+}
+
+// =================================================================== launchers
+int k_intra_diags(int mbw, int mbh) { return mbw + mbh - 1; }
+void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
+    hipLaunchKernelGGL(intra_analyse_kernel, dim3((mbw * mbh + 3) / 4), dim3(256), 0, s, d_ctx);
+}
+void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s) {
+    int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
+    int y_hi = diag < mbh - 1 ? diag : mbh - 1;
+    if (y_hi < y_lo) return;
+    hipLaunchKernelGGL(intra_kernel, dim3(y_hi - y_lo + 1), dim3(128), 0, s, d_ctx, diag);
+}

@@ -1,0 +1,305 @@
+// k_motion.hip -- full-search motion estimation and sub-sample refinement
+// Hand-written HIP for gfx950 (CDNA4, wave64); part of libmi355enc (see kernels_common.hpp).
+#include "kernels_common.hpp"
+
+// =================================================================== motion search
+// One workgroup = ME_MBS horizontally adjacent macroblocks of one macroblock row, one wave per
+// macroblock.  The 48 x (16*ME_MBS+32) luma search window (+-16 around the strip) is staged once in
+// LDS.  Lane l < 63 of a wave owns the candidates
+//   dy in [-16 + 5*(l/9), +5)   x   dx in [-16 + 4*(l%9), +4)
+// (7 x 9 tiles cover 35 x 36 >= 33 x 33; 85 % of the computed SADs are real candidates) and
+// accumulates them with v_qsad_pk_u16_u8 -- four 4-pixel SADs per instruction -- re-using each
+// window row for the 5 dy it serves.  The (cost, dy, dx) minimum is reduced over the wave with
+// cross-lane shuffles.
+#ifndef ME_MBS
+#define ME_MBS 4
+#endif
+#define ME_WQ (ME_MBS + 2)      /* uint4 per window row: 16*ME_MBS + 32 bytes */
+#define ME_ROWS 50   /* 48 real rows + 2 that only masked candidates (dy = 17, 18) ever touch */
+#define ME_STRIDE 53 /* words; 5*53 mod 32 = 9 -> consecutive dy-groups start 9 banks apart */
+#define ME_K 5       /* dy per lane */
+
+DEV unsigned long long qsad(unsigned lo, unsigned hi, unsigned cur, unsigned long long acc) {
+    unsigned long long src = ((unsigned long long)hi << 32) | lo;
+    return __builtin_amdgcn_qsad_pk_u16_u8(src, cur, acc);
+}
+DEV int mv_bits(int v) { // bits of se(4v): 1 for 0, else 7 + 2*floor(log2|v|)
+    int a = iabs(v);
+    return a == 0 ? 1 : 7 + 2 * (31 - __clz(a));
+}
+
+__global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, int row0) { // context by value: lives in the kernarg segment, no per-picture upload
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    __shared__ unsigned win[ME_ROWS * ME_STRIDE];
+    const int stride = ctx->stride, mbw = ctx->mbw, mbh = ctx->mbh;
+    const int W = mbw * 16, H = mbh * 16;
+    const int strips = (mbw + ME_MBS - 1) / ME_MBS;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int my = row0 + tile / strips, sx = tile % strips; // the launch covers macroblock rows row0 .. row0 + gridDim.x / strips - 1
+    const int t = threadIdx.x;
+    const uint8_t *__restrict__ ref = ctx->ref_y;
+
+    // ---- stage the window: 48 rows x 10 uint4 (coalesced 16 B per lane)
+    for (int i = t; i < 48 * ME_WQ; i += 64 * ME_MBS) {
+        int row = i / ME_WQ, q = i - row * ME_WQ;
+        int gy = my * 16 - 16 + row, gx = sx * (ME_MBS * 16) - 16 + 16 * q;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ldg128(ref + (size_t)gy * stride + gx);
+        unsigned *d = &win[row * ME_STRIDE + 4 * q];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (t < ME_ROWS) win[t * ME_STRIDE + 4 * ME_WQ] = 0;
+    if (t < 2 * (4 * ME_WQ + 1)) win[(48 + t / (4 * ME_WQ + 1)) * ME_STRIDE + t % (4 * ME_WQ + 1)] = 0;
+
+    const int lane = t & 63, m = t >> 6;
+    const int mx = sx * ME_MBS + m;
+    const bool active = lane < 63 && mx < mbw;
+    const int g = lane < 63 ? lane / 9 : 0, dxg = lane < 63 ? lane % 9 : 0;
+    const int mxc = mx < mbw ? mx : mbw - 1;
+
+    // ---- current macroblock: 16 rows x 4 words, identical in every lane of the wave
+    unsigned c[16][4];
+    {
+        const uint8_t *__restrict__ src = ctx->src_y;
+        const int ss = ctx->src_stride, vh = ctx->vis_h;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int sy = my * 16 + r;
+            sy = sy < vh ? sy : vh - 1;
+            uint4 v = ldg128(src + (size_t)sy * ss + mxc * 16);
+            c[r][0] = v.x; c[r][1] = v.y; c[r][2] = v.z; c[r][3] = v.w;
+        }
+    }
+    __syncthreads();
+
+    unsigned long long acc[ME_K];
+#pragma unroll
+    for (int d = 0; d < ME_K; d++) acc[d] = 0;
+    const unsigned *wp = &win[(ME_K * g) * ME_STRIDE + 4 * m + dxg];
+    // one window row ahead in registers; sched_barrier keeps the compiler from hoisting all 100 LDS
+    // reads to the top (which costs > 200 VGPRs and halves the occupancy)
+    unsigned w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
+#pragma unroll
+    for (int j = 0; j < 16 + ME_K - 1; j++) {
+        unsigned n0 = 0, n1 = 0, n2 = 0, n3 = 0, n4 = 0;
+        if (j + 1 < 16 + ME_K - 1) {
+            n0 = wp[(j + 1) * ME_STRIDE + 0]; n1 = wp[(j + 1) * ME_STRIDE + 1]; n2 = wp[(j + 1) * ME_STRIDE + 2];
+            n3 = wp[(j + 1) * ME_STRIDE + 3]; n4 = wp[(j + 1) * ME_STRIDE + 4];
+        }
+#pragma unroll
+        for (int d = 0; d < ME_K; d++) {
+            const int r = j - d;
+            if (r >= 0 && r < 16) {
+                acc[d] = qsad(w0, w1, c[r][0], acc[d]);
+                acc[d] = qsad(w1, w2, c[r][1], acc[d]);
+                acc[d] = qsad(w2, w3, c[r][2], acc[d]);
+                acc[d] = qsad(w3, w4, c[r][3], acc[d]);
+            }
+        }
+        // pin this row's SADs here (pure intrinsics would otherwise sink below all the LDS reads)
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
+        __builtin_amdgcn_sched_barrier(0);
+        w0 = n0; w1 = n1; w2 = n2; w3 = n3; w4 = n4;
+    }
+
+    // ---- cost = SAD + lambda*(bits(dx)+bits(dy)); key = cost<<12 | (dy+16)<<6 | (dx+16)
+    const int R = ctx->me_range, lambda = ctx->lambda;
+    const int x0 = mxc * 16, y0 = my * 16;
+    const int dx_lo = -R < -x0 ? -x0 : -R, dx_hi = R > W - 16 - x0 ? W - 16 - x0 : R;
+    const int dy_lo = -R < -y0 ? -y0 : -R, dy_hi = R > H - 16 - y0 ? H - 16 - y0 : R;
+    const unsigned INVALID = 0x40000000u;
+    unsigned bo[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        int dx = -16 + 4 * dxg + o;
+        bo[o] = (dx >= dx_lo && dx <= dx_hi && active) ? (((unsigned)(lambda * mv_bits(dx)) << 12) | (unsigned)(dx + 16)) : INVALID;
+    }
+    unsigned best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 0; d < ME_K; d++) {
+        int dy = -16 + ME_K * g + d;
+        unsigned bd = (dy >= dy_lo && dy <= dy_hi) ? (((unsigned)(lambda * mv_bits(dy)) << 12) | ((unsigned)(dy + 16) << 6)) : INVALID;
+        unsigned lo = (unsigned)acc[d], hi = (unsigned)(acc[d] >> 32);
+        unsigned k0 = ((lo << 16) >> 4) + bd + bo[0];
+        unsigned k1 = ((lo & 0xFFFF0000u) >> 4) + bd + bo[1];
+        unsigned k2 = ((hi << 16) >> 4) + bd + bo[2];
+        unsigned k3 = ((hi & 0xFFFF0000u) >> 4) + bd + bo[3];
+        unsigned ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
+        ka = ka < kb ? ka : kb;
+        best = best < ka ? best : ka;
+    }
+    // ---- wave-wide minimum
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        unsigned o = (unsigned)__shfl_xor((int)best, sft, 64);
+        best = best < o ? best : o;
+    }
+    if (lane == 0 && mx < mbw) {
+        mb_info_t *mb = &ctx->mbi[my * mbw + mx];
+        const int bx_ = (int)(best & 63) - 16, by_ = (int)((best >> 6) & 63) - 16;
+        stg32(&mb->mvx, ((unsigned)(uint16_t)(4 * bx_)) | ((unsigned)(uint16_t)(4 * by_) << 16)); // quarter-sample units
+        stg32(&mb->cost, best >> 12);
+    }
+}
+
+// =================================================================== sub-sample refinement
+// One wave per macroblock.  Around the integer winner (ix, iy) the wave builds, in LDS, the
+// integer samples G and the three half-sample planes of 8.4.2.2.1 (b: horizontal 6-tap,
+// h: vertical 6-tap, j: centre, 6-tap over the unrounded horizontal intermediates) on an
+// 18 x 18 (+1) grid; every quarter-sample candidate is then the rounded average of two plane
+// entries (Table 8-12).  Two rounds (step 2, then step 1) of the 8 neighbours, visited in
+// (dy, dx) raster order, strictly-lower cost wins -- the oracle's orc_subpel_frame.
+#define SP_GS 24 /* G row stride (23 used) */
+#define SP_PS 20 /* plane row stride (18/19 used) */
+struct sp_lds {
+    uint8_t G[23 * SP_GS];     // rows iy-3 .. iy+19, cols ix-3 .. ix+19
+    int16_t B1[23 * 18];       // unrounded horizontal half samples: rows iy-3 .. iy+19, cols ix-1 .. ix+16
+    uint8_t b[19 * SP_PS];     // rows iy-1 .. iy+17, cols ix-1 .. ix+16
+    uint8_t h[18 * SP_PS];     // rows iy-1 .. iy+16, cols ix-1 .. ix+17
+    uint8_t j[18 * SP_PS];     // rows iy-1 .. iy+16, cols ix-1 .. ix+16
+    uint8_t pad[16];           // lds4() may read one word past the last sample of a plane
+};
+DEV int mvq_bits(int q) { // bits of se(q)
+    unsigned k = q > 0 ? (unsigned)(2 * q - 1) : (unsigned)(-2 * q);
+    return 2 * (31 - __clz((int)(k + 1))) + 1;
+}
+// four horizontally adjacent bytes of an LDS plane starting at byte offset `o` (any alignment): two aligned words + one v_alignbyte
+DEV unsigned lds4(const uint8_t *plane, int o) {
+    const unsigned *w = (const unsigned *)(plane + (o & ~3));
+    return __builtin_amdgcn_alignbyte(w[1], w[0], (unsigned)(o & 3));
+}
+// the four luma samples at plane positions (X..X+3, Y) (plane coordinates: 0 = ix-1 / iy-1) and fraction (fx, fy), one per byte
+// (8.4.2.2.1, Table 8-12).  fx, fy are wave-uniform, so the case analysis costs no divergence.
+DEV unsigned sp_sample4(const sp_lds *L, int X, int Y, int fx, int fy) {
+#define SG(x, y) lds4(L->G, ((y) + 2) * SP_GS + (x) + 2)
+#define SB(x, y) lds4(L->b, (y) * SP_PS + (x))
+#define SH(x, y) lds4(L->h, (y) * SP_PS + (x))
+#define SJ(x, y) lds4(L->j, (y) * SP_PS + (x))
+    if (fy == 0) {
+        if (fx == 0) return SG(X, Y);
+        return fx == 2 ? SB(X, Y) : fx == 1 ? avg4(SG(X, Y), SB(X, Y)) : avg4(SG(X + 1, Y), SB(X, Y));
+    }
+    if (fx == 0) return fy == 2 ? SH(X, Y) : fy == 1 ? avg4(SG(X, Y), SH(X, Y)) : avg4(SG(X, Y + 1), SH(X, Y));
+    if ((fx & 1) && (fy & 1)) return avg4(fy == 1 ? SB(X, Y) : SB(X, Y + 1), fx == 1 ? SH(X, Y) : SH(X + 1, Y));
+    if (fx == 2 && fy == 2) return SJ(X, Y);
+    if (fx == 2) return avg4(fy == 1 ? SB(X, Y) : SB(X, Y + 1), SJ(X, Y));
+    return avg4(fx == 1 ? SH(X, Y) : SH(X + 1, Y), SJ(X, Y));
+#undef SG
+#undef SB
+#undef SH
+#undef SJ
+}
+__global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t cv, int mb0, int mb1) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    __shared__ __attribute__((aligned(16))) sp_lds LD[4];
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int mbn = mb0 + blockIdx.x * 4 + wave; // the launch covers macroblocks mb0 .. mb1-1
+    const bool ok = mbn < mb1;
+    if (!ok) mbn = mb1 - 1;
+    const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
+    sp_lds *L = &LD[wave];
+    const mb_info_t info = ld_mbinfo(&ctx->mbi[mbn]);
+    const int ix = x0 + (info.mvx >> 2), iy = y0 + (info.mvy >> 2); // integer winner (vector is a multiple of 4 here)
+    const uint8_t *__restrict__ ref = ctx->ref_y;
+    // ---- G with the picture extended by coordinate clamping (8.4.2.2.1).  Window fully inside the picture (the usual
+    // case, wave-uniform): 23 rows x 7 aligned words, shifted into place with v_alignbyte; otherwise byte by byte.
+    if (ix - 3 >= 0 && iy - 3 >= 0 && ((ix - 3) & ~3) + 28 <= W && iy + 19 < H) {
+        const int a = (ix - 3) & 3;
+        const uint8_t *base = ref + (size_t)(iy - 3) * stride + ((ix - 3) & ~3);
+        for (int i = lane; i < 23 * 6; i += 64) {
+            const int r = i / 6, d = i - r * 6;
+            const unsigned w0 = ldg32(base + (size_t)r * stride + 4 * d), w1 = ldg32(base + (size_t)r * stride + 4 * d + 4);
+            *(unsigned *)&L->G[r * SP_GS + 4 * d] = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)a);
+        }
+    } else
+        for (int i = lane; i < 23 * 23; i += 64) {
+            int r = i / 23, c = i - r * 23;
+            int yy = clip3(0, H - 1, iy - 3 + r), xx = clip3(0, W - 1, ix - 3 + c);
+            L->G[r * SP_GS + c] = (uint8_t)ldg8(ref + (size_t)yy * stride + xx);
+        }
+    // current macroblock: lane owns row lane>>2, columns 4*(lane&3) .. +3
+    const int pr = lane >> 2, pc = (lane & 3) * 4;
+    unsigned curw;
+    {
+        int sy = y0 + pr;
+        sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
+        curw = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + x0 + pc);
+    }
+    WAVE_SYNC();
+    // ---- horizontal half samples (unrounded B1, rounded b)
+    for (int i = lane; i < 23 * 18; i += 64) {
+        int r = i / 18, c = i - r * 18; // position x = ix-1+c -> G column c+2; taps at G columns c .. c+5
+        const uint8_t *g = &L->G[r * SP_GS + c];
+        int v = tap6(g[0], g[1], g[2], g[3], g[4], g[5]);
+        L->B1[r * 18 + c] = (int16_t)v;
+        if (r >= 2 && r < 21) L->b[(r - 2) * SP_PS + c] = (uint8_t)clip255((v + 16) >> 5);
+    }
+    // ---- vertical half samples h: rows iy-1 .. iy+16 (G rows 2..19), cols ix-1 .. ix+17 (G cols 2..20)
+    for (int i = lane; i < 18 * 19; i += 64) {
+        int r = i / 19, c = i - r * 19;
+        const uint8_t *g = &L->G[r * SP_GS + c + 2]; // taps at G rows r .. r+5
+        int v = tap6(g[0], g[SP_GS], g[2 * SP_GS], g[3 * SP_GS], g[4 * SP_GS], g[5 * SP_GS]);
+        L->h[r * SP_PS + c] = (uint8_t)clip255((v + 16) >> 5);
+    }
+    WAVE_SYNC();
+    // ---- centre samples j: vertical 6-tap over B1
+    for (int i = lane; i < 18 * 18; i += 64) {
+        int r = i / 18, c = i - r * 18;
+        const int16_t *q = &L->B1[r * 18 + c];
+        int v = tap6(q[0], q[18], q[36], q[54], q[72], q[90]);
+        L->j[r * SP_PS + c] = (uint8_t)clip255((v + 512) >> 10);
+    }
+    WAVE_SYNC();
+    // ---- two refinement rounds (half, then quarter).  The 8 candidates of a round are scored together: per lane one
+    // v_sad_u8 over its 4 pixels each, two 16-bit partial sums per register (64 lanes x 1020 < 65536), one wave reduction
+    // for all of them; then the candidates are compared in scan order with a strict `<`, as the oracle does.
+    const int lambda = ctx->lambda;
+    int bqx = info.mvx, bqy = info.mvy;
+    unsigned best = info.cost;
+#pragma unroll 1
+    for (int step = 2; step >= 1; step--) {
+        const int cqx = bqx, cqy = bqy;
+        unsigned acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c8 = 0; c8 < 8; c8++) {
+            const int k = c8 < 4 ? c8 : c8 + 1;
+            const int qx = cqx + (k % 3 - 1) * step, qy = cqy + (k / 3 - 1) * step;
+            const int ox = qx - info.mvx, oy = qy - info.mvy;               // -3 .. 3 relative to the integer winner
+            const int X = 1 + (ox >> 2) + pc, Y = 1 + (oy >> 2) + pr;       // plane coordinates of this lane's first pixel
+            const unsigned sad = __builtin_amdgcn_sad_u8(curw, sp_sample4(L, X, Y, ox & 3, oy & 3), 0u);
+            acc[c8 >> 1] |= sad << (16 * (c8 & 1));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int v = wave16_sum((int)acc[q]);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[q] = (unsigned)v;
+        }
+#pragma unroll
+        for (int c8 = 0; c8 < 8; c8++) {
+            const int k = c8 < 4 ? c8 : c8 + 1;
+            const int qx = cqx + (k % 3 - 1) * step, qy = cqy + (k / 3 - 1) * step;
+            const unsigned sad = (acc[c8 >> 1] >> (16 * (c8 & 1))) & 0xFFFFu;
+            const unsigned cost = sad + (unsigned)(lambda * (mvq_bits(qx) + mvq_bits(qy)));
+            if (cost < best) { best = cost; bqx = qx; bqy = qy; }
+        }
+    }
+    if (lane == 0 && ok) {
+        mb_info_t *mb = &ctx->mbi[mbn];
+        stg32(&mb->mvx, ((unsigned)(uint16_t)bqx) | ((unsigned)(uint16_t)bqy << 16));
+        stg32(&mb->cost, best);
+    }
+}
+
+// =================================================================== launchers
+// The three P-picture kernels take a macroblock-row range [row0, row1): the host overlaps the upper part of picture n+1
+// with the tail of picture n's deblocking (mi355enc.cpp, enqueue_picture).
+void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
+    int strips = (mbw + ME_MBS - 1) / ME_MBS;
+    if (row1 > row0) hipLaunchKernelGGL(me_kernel, dim3(strips * (row1 - row0)), dim3(64 * ME_MBS), 0, s, *h_ctx, row0);
+}
+void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
+    if (row1 > row0) hipLaunchKernelGGL(subpel_kernel, dim3((mbw * (row1 - row0) + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw);
+}

@@ -1,0 +1,282 @@
+// kernels_common.hpp -- what every kernel translation unit of libmi355enc shares: the constant tables, global-memory
+// accessors that force global_* (not flat_*) instructions, the cross-workgroup hand-off primitives of the persistent
+// kernels, small integer / DPP helpers and the 4x4 transform + quantiser + chroma block code used by both the inter and
+// the intra path.  Everything is static / force-inlined: each .hip file is compiled on its own (no relocatable
+// device code).  Integer arithmetic throughout (u8 samples, 16-bit levels, 32-bit accumulators): results must equal
+// oracle/h264_enc_oracle.c byte for byte.  No MFMA: nothing on this path is a dense contraction.
+#ifndef MI355ENC_KERNELS_COMMON_HPP
+#define MI355ENC_KERNELS_COMMON_HPP
+#include "mi355enc_dev.h"
+
+#define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------ constant tables
+// One blob so that the latency-critical wavefront kernels can stage it in LDS with a single
+// round of loads (a table lookup through global memory costs a full L2 round trip each).
+struct dev_tables {
+    uint8_t alpha[52], beta[52], tc0[52][3], qpc[52]; // Tables 8-16, 8-17, 8-15
+    uint16_t mf[6][3];                                // encoder quantiser multipliers
+    uint8_t v[6][3];                                  // 8.5.9 normAdjust4x4
+    uint8_t pad[2];
+    uint16_t mf8[6][6];                               // 8x8 quantiser multipliers
+    uint8_t v8[6][6];                                 // 8.5.9 normAdjust8x8
+    uint8_t izz8[64];                                 // 8x8 zig-zag, raster position -> scan index
+};
+static_assert(sizeof(dev_tables) % 4 == 0, "dev_tables is copied as dwords");
+#define TAB_DWORDS ((int)(sizeof(dev_tables) / 4))
+static __device__ const dev_tables g_tab = {
+    {0,  0,  0,  0,  0,  0,  0,  0,  0,   0,   0,   0,   0,   0,   0,   0,   4,   4,
+     5,  6,  7,  8,  9,  10, 12, 13, 15,  17,  20,  22,  25,  28,  32,  36,  40,  45,
+     50, 56, 63, 71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  0,  0,  0,  0,  2,  2,
+     2, 3, 3, 3, 3, 4, 4, 4, 6,  6,  7,  7,  8,  8,  9,  9,  10, 10,
+     11, 11, 12, 12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18},
+    {{0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},
+     {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 1},
+     {0, 0, 1},   {0, 0, 1},   {0, 0, 1},   {0, 1, 1},   {0, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},
+     {1, 1, 2},   {1, 1, 2},   {1, 1, 2},   {1, 1, 2},   {1, 2, 3},   {1, 2, 3},   {2, 2, 3},   {2, 2, 4},   {2, 3, 4},
+     {2, 3, 4},   {3, 3, 5},   {3, 4, 6},   {3, 4, 6},   {4, 5, 7},   {4, 5, 8},   {4, 6, 9},   {5, 7, 10},  {6, 8, 11},
+     {6, 8, 13},  {7, 10, 14}, {8, 11, 16}, {9, 12, 18}, {10, 13, 20}, {11, 15, 23}, {13, 17, 25}},
+    {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17,
+     18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33,
+     34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39},
+    {{13107, 5243, 8066}, {11916, 4660, 7490}, {10082, 4194, 6554}, {9362, 3647, 5825}, {8192, 3355, 5243}, {7282, 2893, 4559}},
+    {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}},
+    {0, 0},
+    {{13107, 11428, 20972, 12222, 16777, 15481}, {11916, 10826, 19174, 11058, 14980, 14290}, {10082, 8943, 15978, 9675, 12710, 11985},
+     {9362, 8228, 14913, 8931, 11984, 11259},    {8192, 7346, 13159, 7740, 10486, 9777},     {7282, 6428, 11570, 6830, 9118, 8640}},
+    {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31}, {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}},
+    {0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63}};
+
+
+// ------------------------------------------------------------------ global-memory accessors
+// Pointers read out of frame_ctx_t are generic; plain dereferences would become flat_load/
+// flat_store, which count against BOTH vmcnt and lgkmcnt -- every LDS wait would then also
+// wait for the outstanding HBM load.  These force global_* instructions.
+#define GAS __attribute__((address_space(1)))
+DEV unsigned ldg8(const void *p) { return *(const GAS uint8_t *)p; }
+DEV unsigned ldg32(const void *p) { return *(const GAS unsigned *)p; }
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+DEV uint2 ldg64(const void *p) { const v2u v = *(const GAS v2u *)p; return make_uint2(v.x, v.y); }
+DEV uint2 ldg64x(const void *p) { return make_uint2(*(const GAS unsigned *)p, *((const GAS unsigned *)p + 1)); } // 4-byte aligned pair
+DEV uint4 ldg128(const void *p) { const v4u v = *(const GAS v4u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+DEV int ldg16(const void *p) { return *(const GAS int16_t *)p; }
+DEV void stg8(void *p, unsigned v) { *(GAS uint8_t *)p = (uint8_t)v; }
+DEV void stg16(void *p, int v) { *(GAS int16_t *)p = (int16_t)v; }
+DEV void stg32(void *p, unsigned v) { *(GAS unsigned *)p = v; }
+DEV void stg128(void *p, uint4 v) { v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(GAS v4u *)p = t; }
+DEV mb_info_t unpack_mbinfo(const uint4 r) {
+    mb_info_t m;
+    m.mvx = (int16_t)(r.x & 0xFFFF); m.mvy = (int16_t)(r.x >> 16);
+    m.mb_type = (uint8_t)(r.y & 255); m.i16_mode = (uint8_t)((r.y >> 8) & 255); m.chroma_mode = (uint8_t)((r.y >> 16) & 255); m.qp = (uint8_t)(r.y >> 24);
+    m.nzmask = r.z; m.cost = r.w;
+    return m;
+}
+DEV mb_info_t ld_mbinfo(const mb_info_t *p) { return unpack_mbinfo(ldg128(p)); } // one 16-byte load instead of four partial ones
+DEV void st_mbinfo(mb_info_t *p, const mb_info_t &m) {
+    uint4 r;
+    r.x = ((unsigned)(uint16_t)m.mvx) | ((unsigned)(uint16_t)m.mvy << 16);
+    r.y = (unsigned)m.mb_type | ((unsigned)m.i16_mode << 8) | ((unsigned)m.chroma_mode << 16) | ((unsigned)m.qp << 24);
+    r.z = m.nzmask; r.w = m.cost;
+    stg128(p, r);
+}
+
+// ------------------------------------------------------------------ cross-workgroup hand-off inside a persistent launch
+// Agent-scope (sc1, L1-bypassing) accesses for data one workgroup produces and another consumes while both run, and a bounded
+// wait on a monotonic progress counter (MI355X_MICROARCH.md, "Valid forms": producer stores the data sc1, s_waitcnt vmcnt(0),
+// then stores the counter sc1; consumer polls the counter and reads the data with sc1 loads).
+#define DB_SPIN_MAX (1 << 20)
+DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV int db_wait_get(unsigned *progress, unsigned *err, int need) {
+    int spins = 0, v;
+    while ((v = (int)ld_sc1(progress)) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(err))) { st_sc1(err, 1u); return 0x7FFFFFFF; } // bounded; once tripped, nobody waits again
+    }
+    return v;
+}
+
+// workgroup barrier that drains LDS traffic only: global loads (prefetch) and stores stay in flight
+#define BAND_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+DEV int iabs(int v) { return v < 0 ? -v : v; }
+DEV int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+DEV int clip255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+DEV int blkx(int b) { return ((b & 1) << 2) | ((b & 4) << 1); }        // luma4x4BlkIdx -> x offset (6.4.3)
+DEV int blky(int b) { return ((b & 2) << 1) | ((b & 8)); }             // luma4x4BlkIdx -> y offset
+
+// XCD-aware block remap: consecutive logical tiles land on the same XCD (blocks are dealt
+// round-robin over the 8 XCDs), so neighbouring strips share one L2.  Bijective for any n.
+DEV int xcd_remap(int wg, int n) {
+    int q = n >> 3, r = n & 7, k = wg & 7;
+    return k * q + (k < r ? k : r) + (wg >> 3);
+}
+
+// sum over the 16 lanes of a DPP row (every lane receives it)
+DEV int wave16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false); // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // quad_perm:[1,0,3,2]
+    return v;
+}
+// value of lane k of this lane's quad (k = 0..3), and of row r of this lane's column in a 4x4 tile laid out on 16 lanes
+template <int K> DEV int quad_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, false); }
+
+// =================================================================== 4x4 transform helpers
+// All operate on int x[16] in raster order (index y*4+x); loops are fully unrolled so the
+// arrays stay in registers.
+DEV void fdct4(int *x) { // Y = Cf X Cf^T
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int a = x[i * 4], b = x[i * 4 + 1], c = x[i * 4 + 2], d = x[i * 4 + 3];
+        int s03 = a + d, d03 = a - d, s12 = b + c, d12 = b - c;
+        x[i * 4] = s03 + s12; x[i * 4 + 1] = 2 * d03 + d12; x[i * 4 + 2] = s03 - s12; x[i * 4 + 3] = d03 - 2 * d12;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int a = x[j], b = x[4 + j], c = x[8 + j], d = x[12 + j];
+        int s03 = a + d, d03 = a - d, s12 = b + c, d12 = b - c;
+        x[j] = s03 + s12; x[4 + j] = 2 * d03 + d12; x[8 + j] = s03 - s12; x[12 + j] = d03 - 2 * d12;
+    }
+}
+DEV void idct4(int *d) { // 8.5.12.2: rows then columns, (x+32)>>6; result = residual
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int e0 = d[i * 4] + d[i * 4 + 2], e1 = d[i * 4] - d[i * 4 + 2];
+        int e2 = (d[i * 4 + 1] >> 1) - d[i * 4 + 3], e3 = d[i * 4 + 1] + (d[i * 4 + 3] >> 1);
+        d[i * 4] = e0 + e3; d[i * 4 + 1] = e1 + e2; d[i * 4 + 2] = e1 - e2; d[i * 4 + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int g0 = d[j] + d[8 + j], g1 = d[j] - d[8 + j];
+        int g2 = (d[4 + j] >> 1) - d[12 + j], g3 = d[4 + j] + (d[12 + j] >> 1);
+        d[j] = (g0 + g3 + 32) >> 6; d[4 + j] = (g1 + g2 + 32) >> 6; d[8 + j] = (g1 - g2 + 32) >> 6; d[12 + j] = (g0 - g3 + 32) >> 6;
+    }
+}
+// 8.5.6 zig-zag: scan position -> raster index, packed one nibble per entry
+DEV constexpr int zz(int k) { return (int)((0xFEB7ADC963258410ull >> (4 * k)) & 15); }
+DEV constexpr int pos_class(int p) { // 0: (even,even)  1: (odd,odd)  2: mixed
+    return ((p & 1) == 0 && (p & 4) == 0) ? 0 : (((p & 1) && (p & 4)) ? 1 : 2);
+}
+DEV int quant1(int coef, int mf, int f, int qbits) { // dead-zone quantiser, |level| <= 2047
+    int a = iabs(coef);
+    int l = (a * mf + f) >> qbits;
+    l = l > 2047 ? 2047 : l;
+    return coef < 0 ? -l : l;
+}
+struct qparams { int mf[3], v[3], qbits, f, shift; };
+DEV qparams make_q(const dev_tables *T, int qp, bool intra) {
+    qparams q;
+    int m = qp % 6;
+    q.mf[0] = T->mf[m][0]; q.mf[1] = T->mf[m][1]; q.mf[2] = T->mf[m][2];
+    q.v[0] = T->v[m][0]; q.v[1] = T->v[m][1]; q.v[2] = T->v[m][2];
+    q.qbits = 15 + qp / 6;
+    q.f = (1 << q.qbits) / (intra ? 3 : 6);
+    q.shift = qp / 6;
+    return q;
+}
+// coef[] (raster, after fdct4) -> lev[] (zig-zag order) and coef[] := dequantised (raster).
+// Scan positions below `first` are forced to zero.  Returns true if any level != 0.
+template <int FIRST>
+DEV bool quant_dequant(int *coef, int *lev, const qparams &q) {
+    bool nz = false;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int p = zz(k), cl = pos_class(p);
+        int l = k < FIRST ? 0 : quant1(coef[p], q.mf[cl], q.f, q.qbits);
+        lev[k] = l;
+        nz |= l != 0;
+        coef[p] = (l * q.v[cl]) << q.shift;
+    }
+    return nz;
+}
+DEV void store_levels(int16_t *dst, const int *lev) { // 16 int16 = two 16-byte stores
+    uint4 a, b;
+    a.x = (lev[0] & 0xFFFF) | (lev[1] << 16); a.y = (lev[2] & 0xFFFF) | (lev[3] << 16);
+    a.z = (lev[4] & 0xFFFF) | (lev[5] << 16); a.w = (lev[6] & 0xFFFF) | (lev[7] << 16);
+    b.x = (lev[8] & 0xFFFF) | (lev[9] << 16); b.y = (lev[10] & 0xFFFF) | (lev[11] << 16);
+    b.z = (lev[12] & 0xFFFF) | (lev[13] << 16); b.w = (lev[14] & 0xFFFF) | (lev[15] << 16);
+    stg128(dst, a); stg128(dst + 8, b);
+}
+DEV unsigned pack4(int a, int b, int c, int d) { return (unsigned)a | ((unsigned)b << 8) | ((unsigned)c << 16) | ((unsigned)d << 24); }
+DEV int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 255); }
+
+// Chroma of one macroblock, run by 8 consecutive lanes (cl = 0..7: plane c = cl>>2, block b = cl&3).
+// value of lane (l ^ K) of this lane's quad, K = 1..3 (DPP quad_perm)
+template <int K> DEV int quad_xor(int v) { return __builtin_amdgcn_update_dpp(0, v, K == 1 ? 0xB1 : K == 2 ? 0x4E : 0x1B, 0xF, 0xF, false); }
+// pred[16]: prediction of this lane's 4x4 block.  Handles the 2x2 DC Hadamard across the four
+// lanes of a plane with shuffles (8.5.11), writes levels + reconstruction, returns the AC flag
+// in bit 0 and the plane's DC flag in bit 1.
+DEV int chroma_block(const frame_ctx_t *ctx, const dev_tables *T, int mbn, int cx0, int cy0, int cl, const int *pred, int qp, bool intra, uint8_t *lrec = nullptr, const uint2 *presrc = nullptr) {
+    const int c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
+    const int qpc = T->qpc[qp];
+    const qparams q = make_q(T, qpc, intra);
+    int x[16], lev[16];
+    {
+        const uint8_t *__restrict__ s = ctx->src_uv;
+        const int ss = ctx->src_stride, vh2 = ctx->vis_h >> 1;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int sy = cy0 + by + r;
+            sy = sy < vh2 ? sy : vh2 - 1;
+            uint2 w = presrc ? presrc[r] : ldg64(s + (size_t)sy * ss + 2 * (cx0 + bx));
+            unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
+            x[r * 4 + 0] = (int)(lo & 255) - pred[r * 4 + 0];
+            x[r * 4 + 1] = (int)((lo >> 16) & 255) - pred[r * 4 + 1];
+            x[r * 4 + 2] = (int)(hi & 255) - pred[r * 4 + 2];
+            x[r * 4 + 3] = (int)((hi >> 16) & 255) - pred[r * 4 + 3];
+        }
+    }
+    fdct4(x);
+    const int dc = x[0];
+    bool nz_ac = quant_dequant<1>(x, lev, q);
+    // forward 2x2 Hadamard over the plane's four lanes; lane b keeps element b
+    int d1 = quad_xor<1>(dc), d2 = quad_xor<2>(dc), d3 = quad_xor<3>(dc); // DPP quad_perm: the four blocks of a plane sit in one quad
+    // with e0..e3 the values of blocks 0..3: this lane holds e_b = dc, e_{b^1} = d1, e_{b^2} = d2, e_{b^3} = d3
+    int fb;
+    {
+        int e[4]; // e_k = DC of block k (this lane holds e_b; partners arrive by shuffle)
+        e[b] = dc; e[b ^ 1] = d1; e[b ^ 2] = d2; e[b ^ 3] = d3;
+        int f0 = e[0] + e[1] + e[2] + e[3], f1 = e[0] - e[1] + e[2] - e[3];
+        int f2 = e[0] + e[1] - e[2] - e[3], f3 = e[0] - e[1] - e[2] + e[3];
+        fb = b == 0 ? f0 : b == 1 ? f1 : b == 2 ? f2 : f3;
+    }
+    const int ldc = quant1(fb, q.mf[0], 2 * q.f, q.qbits + 1);
+    // inverse: g = H l H over the four DC levels, dcC = ((g*LevelScale(0,0)) << (qP/6)) >> 5
+    int l1 = quad_xor<1>(ldc), l2 = quad_xor<2>(ldc), l3 = quad_xor<3>(ldc);
+    int gl[4];
+    gl[b] = ldc; gl[b ^ 1] = l1; gl[b ^ 2] = l2; gl[b ^ 3] = l3;
+    int g0 = gl[0] + gl[1] + gl[2] + gl[3], g1 = gl[0] - gl[1] + gl[2] - gl[3];
+    int g2 = gl[0] + gl[1] - gl[2] - gl[3], g3 = gl[0] - gl[1] - gl[2] + gl[3];
+    int gb = b == 0 ? g0 : b == 1 ? g1 : b == 2 ? g2 : g3;
+    x[0] = ((gb * 16 * q.v[0]) << q.shift) >> 5;
+    const bool nz_dc = (gl[0] | gl[1] | gl[2] | gl[3]) != 0;
+    idct4(x);
+    // levels
+    int16_t *lv = ctx->levels + (size_t)mbn * MB_LEVELS;
+    store_levels(lv + L_CAC + (4 * c + b) * 16, lev);
+    stg16(&lv[L_CDC + 4 * c + b], ldc);
+    // reconstruction: this lane owns every other byte of 8-byte row segments
+    uint8_t *__restrict__ rec = ctx->rec_uv;
+    const int st = ctx->stride;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint8_t *p = rec + (size_t)(cy0 + by + r) * st + 2 * (cx0 + bx) + c;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned v = (unsigned)clip255(pred[r * 4 + i] + x[r * 4 + i]);
+            stg8(p + 2 * i, v);
+            if (lrec) lrec[(by + r) * 16 + 2 * (bx + i) + c] = (uint8_t)v; // 8 x 16 interleaved tile in LDS for the persistent intra kernel
+        }
+    }
+    return (nz_ac ? 1 : 0) | (nz_dc ? 2 : 0);
+}
+
+// 6-tap filter of 8.4.2.2.1 (unrounded), and the rounded per-byte mean of two packed words
+DEV int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+DEV unsigned avg4(unsigned a, unsigned b) { return (a | b) - (((a ^ b) >> 1) & 0x7F7F7F7Fu); } // per byte (a + b + 1) >> 1
+#endif

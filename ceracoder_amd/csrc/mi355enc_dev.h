@@ -1,5 +1,5 @@
 /* Internal: types shared by the host orchestration (mi355enc.cpp), the host entropy coder
- * (h264_host.c) and the HIP kernels (mi355enc_kernels.hip).  Not part of the C ABI. */
+ * (h264_host.c) and the HIP kernels (k_*.hip, kernels_common.hpp).  Not part of the C ABI. */
 #ifndef MI355ENC_DEV_H
 #define MI355ENC_DEV_H
 #include <stdint.h>
@@ -57,7 +57,7 @@ typedef struct {
 
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
-/* launchers (mi355enc_kernels.hip); all asynchronous on `s`.  h_ctx: HOST copy of the context, passed to the kernel by value
+/* launchers (k_*.hip); all asynchronous on `s`.  h_ctx: HOST copy of the context, passed to the kernel by value
  * (kernarg segment); d_ctx: device copy, for the kernels that are replayed from a hipGraph. */
 void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);

@@ -1,5 +1,5 @@
 """oracle/csc.py -- TEST INFRASTRUCTURE ONLY: numpy restatement of the raw-format conversions the
-product does on the device (ceracoder_amd/csrc/mi355enc_kernels.hip, csc_kernel).
+product does on the device (ceracoder_amd/csrc/k_handover.hip, csc_kernel).
 
 PARITY UNPINNED: the reference converts with GStreamer's `videoconvert`
 (/root/reference/pipeline/generic/x264_superfast_camlink:4), which is not part of its tree; the
