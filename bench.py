@@ -130,10 +130,13 @@ def main():
     ap.add_argument("--depth", type=int, default=1)
     ap.add_argument("--deblock-mode", type=int, default=0)
     ap.add_argument("--sample", type=int, default=7, help="stage timers (HIP events) on every k-th picture; each event record costs ~5 us of queue time")
+    ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent streams encoded concurrently on each GPU (one host thread each); the headline configuration is 1")
     ap.add_argument("--cavlc-threads", type=int, default=1, help="host threads coding one slice row-parallel (bit-identical output)")
     ap.add_argument("--overlap", type=int, default=0, help="1: overlapped two-stream schedule for P pictures")
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     args = ap.parse_args()
+    if args.streams_per_gpu > 1:  # every encoder owns three HIP streams; the runtime's default of 4 hardware queues would serialise them
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
     from ceracoder_amd.multistream import Ranks
@@ -155,27 +158,46 @@ def main():
     base = frames.data_ptr()
     fbytes = frames.stride(0)
 
-    e = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
-                  pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                  transform8x8=bool(args.dct8x8), overlap=bool(args.overlap), cavlc_threads=args.cavlc_threads)
+    S = max(1, args.streams_per_gpu)
 
-    def run(n, first_index):
+    def make_encoder():
+        return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
+                         pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
+                         transform8x8=bool(args.dct8x8), overlap=bool(args.overlap), cavlc_threads=args.cavlc_threads)
+
+    encs = [make_encoder() for _ in range(S)]
+    e = encs[0]
+
+    def run_one(enc, n, first_index, shift):
         qps, nbytes = [], 0
         for i in range(n):
-            p = base + bounce(first_index + i, args.unique) * fbytes
-            e.submit_device(p, stride, p + height * stride, stride, pts=first_index + i)
-            if e.pending > args.depth:
-                sz, _, _, qp = e.collect(copy=False)
+            p = base + bounce(first_index + i + shift, args.unique) * fbytes
+            enc.submit_device(p, stride, p + height * stride, stride, pts=first_index + i)
+            if enc.pending > args.depth:
+                sz, _, _, qp = enc.collect(copy=False)
                 qps.append(qp)
                 nbytes += sz
-        while e.pending:
-            sz, _, _, qp = e.collect(copy=False)
+        while enc.pending:
+            sz, _, _, qp = enc.collect(copy=False)
             qps.append(qp)
             nbytes += sz
         return qps, nbytes
 
+    def run(n, first_index):
+        if S == 1:
+            return run_one(e, n, first_index, 0)
+        import threading  # one host thread per stream; the C ABI releases the GIL for the duration of every call
+        res = [None] * S
+        th = [threading.Thread(target=lambda k=k: res.__setitem__(k, run_one(encs[k], n, first_index, 5 * k))) for k in range(S)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return res[0][0], sum(r[1] for r in res)
+
     run(args.warmup, 0)
-    e.reset_stats()
+    for enc in encs:
+        enc.reset_stats()
     dt, (qps, nbytes) = ranks.timed(lambda: run(args.steps, args.warmup), sync=torch.cuda.synchronize)
     st = e.stats()
 
@@ -256,12 +278,12 @@ def main():
                         "(the motion search north_star names is 'me_kernel')."}
         out = {
             "metric": "1080p H.264 encoded frames/sec per GPU" if args.workload.startswith("1080p") else "H.264 encoded frames/sec per GPU",
-            "value": round(world * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(world * S * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / (S * args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic (S2: panning texture + 12 moving rectangles, seed 0x5EED), resident in HBM",
             "config": {"workload": args.workload, "width": width, "height": height, "fps_nominal": fps, "gop": gop,
                        "rate_control": "cbr %d bit/s" % bps if args.fixed_qp < 0 else "fixed qp %d" % args.fixed_qp,
-                       "me": "full search +-16 integer-pel SAD + half/quarter-sample refinement", "streams_per_gpu": 1, "parallelism": "%d independent streams" % world,
+                       "me": "full search +-16 integer-pel SAD + half/quarter-sample refinement", "streams_per_gpu": S, "parallelism": "%d independent streams" % (world * S),
                        "pipeline_depth": args.depth, "dct8x8": bool(args.dct8x8), "cavlc_threads": args.cavlc_threads},
             "roofline": roof,
             "roofline_kernels": kernels,
@@ -272,13 +294,14 @@ def main():
                                      "gpu_total": round(est_total / max(1, st.frames), 4),
                                      "host_cavlc": round(st.ms_entropy / max(1, st.frames), 4),
                                      "host_wait": round(st.ms_wait / max(1, st.frames), 4)},
-            "bitrate_out_bps": round(nbytes * 8 * fps / args.steps), "mean_qp": round(float(np.mean(qps)), 2),
+            "bitrate_out_bps": round(nbytes * 8 * fps / (S * args.steps)), "mean_qp": round(float(np.mean(qps)), 2),
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, width, height, fps, gop, qps)
         print(json.dumps(out), flush=True)
-    e.close()
+    for enc in encs:
+        enc.close()
     ranks.close()
 
 
