@@ -10,7 +10,7 @@ for (w, h) in ((1920, 64), (1920, 1088)):
     n = e.mbw * e.mbh
     y = np.random.default_rng(0).integers(0, 256, (h, w), dtype=np.uint8)
     uv = np.random.default_rng(1).integers(0, 256, (h // 2, w), dtype=np.uint8)
-    steps = e.mbw + 2 * (e.mbh - 1)
+    steps = e.mbw + e.mbh - 1  # x + y order of the band kernel (plus ~3 per band boundary)
     for name, typ, nz in (("idle", 1, 0), ("coded", 1, 0xFFFF), ("intra", 0, 0)):
         mbi = np.zeros(n, E.MBINFO_DTYPE)
         mbi["mb_type"], mbi["qp"], mbi["nzmask"] = typ, 30, nz
