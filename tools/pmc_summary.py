@@ -13,8 +13,11 @@ for line in csv.DictReader(open(stats_csv)):
 
 
 def short(name):
-    m = re.match(r"^(?:_Z\d+)?([A-Za-z_0-9]+?)(?:PK|7db_args|ILi|\.kd|\(|$)", name)
-    return m.group(1) if m else name
+    m = re.match(r"^_Z(\d+)", name)  # Itanium mangling: _Z<len><identifier>...
+    if m:
+        n = int(m.group(1))
+        return name[m.end():m.end() + n]
+    return re.sub(r"(\(.*|\.kd)$", "", name)
 
 
 def load(d, counter):
