@@ -268,6 +268,7 @@ struct intra_lds {
     __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
     __attribute__((aligned(4))) uint8_t crec[8 * 16]; // reconstructed chroma, interleaved Cb Cr (OUT only)
     int mode4[16];
+    __attribute__((aligned(4))) uint8_t z4[2 * 16];   // Intra_4x4: the neighbour line of the (up to two) blocks of a sub-step
     unsigned cflags[2];                               // chroma wave -> luma wave: ballots of its blocks' AC / DC flags
     unsigned cseq;                                    // ... valid once this equals macroblock number + 1
     __attribute__((aligned(4))) uint8_t bot_y[4][16], bot_c[4][16];
@@ -356,12 +357,24 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             const bool ur = by == 0 ? (bx < 3 && has_top) : (bx < 3 && trb < b);
             const int emax = ur ? 8 : 4;
             const uint8_t *tb = &T4[(by * 4) * 24 + bx * 4];
-            auto E = [&](int i) -> int { i = i > emax ? emax : i; return i < 0 ? (int)tb[(-i) * 24] : (int)tb[i]; };
+            // The 13 neighbours E(-4..8) (left column bottom-up, corner, top row with the top-right substitution) laid out as
+            // one line, both ends replicated: zb[j] = E(clamp(j - 5, -4, emax)).  Lane q of the block's 16 lanes builds
+            // entry q; every directional mode is then "copy / 2-tap / 3-tap at a table-given position of that line"
+            // (8.3.1.2.1-9 rewritten: T->i4tab[mode][pixel] = position + 5 | kind << 4).
+            const int q16 = lane & 15;
+            int ei = q16 - 5;
+            ei = ei < -4 ? -4 : (ei > emax ? emax : ei);
+            const int zv = ei < 0 ? (int)tb[(-ei) * 24] : (int)tb[ei];
+            uint8_t *zb = &L->z4[half * 16];
+            if (lane < 32) zb[q16] = (uint8_t)zv;
             const int bmode = sh_mode4[by * 4 + bx];
             const int sv = S4[(by * 4 + py) * 16 + bx * 4 + px];
-            const int sumT = E(1) + E(2) + E(3) + E(4), sumL = E(-1) + E(-2) + E(-3) + E(-4);
+            const int sumL = wave16_sum(q16 >= 1 && q16 <= 4 ? zv : 0), sumT = wave16_sum(q16 >= 6 && q16 <= 9 ? zv : 0);
             const int dc4 = (up && lf) ? (sumT + sumL + 4) >> 3 : lf ? (sumL + 2) >> 2 : up ? (sumT + 2) >> 2 : 128;
-            const int bpred = pred4_px(bmode, px, py, E, dc4);
+            WAVE_SYNC();
+            const int ent = T->i4tab[bmode * 16 + py * 4 + px], j0 = ent & 15, kind = ent >> 4;
+            const int za = zb[j0], zc = zb[j0 + 1], zd = zb[j0 + 2];
+            const int bpred = kind == 0 ? za : kind == 1 ? (za + zc + 1) >> 1 : kind == 2 ? (za + 2 * zc + zd + 2) >> 2 : dc4;
             // residual -> 4x4 core transform across the 16 lanes (rows, then columns)
             const int res = sv - bpred;
             const int cbase = lane & ~12;

@@ -21,6 +21,7 @@ struct dev_tables {
     uint16_t mf8[6][6];                               // 8x8 quantiser multipliers
     uint8_t v8[6][6];                                 // 8.5.9 normAdjust8x8
     uint8_t izz8[64];                                 // 8x8 zig-zag, raster position -> scan index
+    uint8_t i4tab[9 * 16];                            // Intra_4x4 predictors: [mode][pixel] = (position on the neighbour line + 5) | kind << 4 (k_intra.hip)
 };
 static_assert(sizeof(dev_tables) % 4 == 0, "dev_tables is copied as dwords");
 #define TAB_DWORDS ((int)(sizeof(dev_tables) / 4))
@@ -46,7 +47,16 @@ static __device__ const dev_tables g_tab = {
     {{13107, 11428, 20972, 12222, 16777, 15481}, {11916, 10826, 19174, 11058, 14980, 14290}, {10082, 8943, 15978, 9675, 12710, 11985},
      {9362, 8228, 14913, 8931, 11984, 11259},    {8192, 7346, 13159, 7740, 10486, 9777},     {7282, 6428, 11570, 6830, 9118, 8640}},
     {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26}, {26, 23, 42, 24, 33, 31}, {28, 25, 45, 26, 35, 33}, {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}},
-    {0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63}};
+    {0, 1, 5, 6, 14, 15, 27, 28, 2, 4, 7, 13, 16, 26, 29, 42, 3, 8, 12, 17, 25, 30, 41, 43, 9, 11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63},
+    {0x06, 0x07, 0x08, 0x09, 0x06, 0x07, 0x08, 0x09, 0x06, 0x07, 0x08, 0x09, 0x06, 0x07, 0x08, 0x09,   // 0 vertical: copy E(1 + x)
+     0x04, 0x04, 0x04, 0x04, 0x03, 0x03, 0x03, 0x03, 0x02, 0x02, 0x02, 0x02, 0x01, 0x01, 0x01, 0x01,   // 1 horizontal: copy E(-1 - y)
+     0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35, 0x35,   // 2 DC
+     0x26, 0x27, 0x28, 0x29, 0x27, 0x28, 0x29, 0x2A, 0x28, 0x29, 0x2A, 0x2B, 0x29, 0x2A, 0x2B, 0x2C,   // 3 diagonal down-left
+     0x24, 0x25, 0x26, 0x27, 0x23, 0x24, 0x25, 0x26, 0x22, 0x23, 0x24, 0x25, 0x21, 0x22, 0x23, 0x24,   // 4 diagonal down-right
+     0x15, 0x16, 0x17, 0x18, 0x24, 0x25, 0x26, 0x27, 0x23, 0x15, 0x16, 0x17, 0x22, 0x24, 0x25, 0x26,   // 5 vertical-right
+     0x14, 0x24, 0x25, 0x26, 0x13, 0x23, 0x14, 0x24, 0x12, 0x22, 0x13, 0x23, 0x11, 0x21, 0x12, 0x22,   // 6 horizontal-down
+     0x16, 0x17, 0x18, 0x19, 0x26, 0x27, 0x28, 0x29, 0x17, 0x18, 0x19, 0x1A, 0x27, 0x28, 0x29, 0x2A,   // 7 vertical-left
+     0x13, 0x22, 0x12, 0x21, 0x12, 0x21, 0x11, 0x20, 0x11, 0x20, 0x01, 0x01, 0x01, 0x01, 0x01, 0x01}}; // 8 horizontal-up
 
 
 // ------------------------------------------------------------------ global-memory accessors
