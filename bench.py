@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--sample", type=int, default=7, help="stage timers (HIP events) on every k-th picture; each event record costs ~5 us of queue time")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent streams encoded concurrently on each GPU (one host thread each); the headline configuration is 1")
     ap.add_argument("--cavlc-threads", type=int, default=1, help="host threads coding one slice row-parallel (bit-identical output)")
-    ap.add_argument("--overlap", type=int, default=0, help="1: overlapped two-stream schedule for P pictures")
+    ap.add_argument("--overlap", type=int, default=0, help="band-pipelined schedule for P pictures: 0 off, 1 default piece count (4), N >= 2 pieces")
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     args = ap.parse_args()
     if args.streams_per_gpu > 1:  # every encoder owns three HIP streams; the runtime's default of 4 hardware queues would serialise them
@@ -163,7 +163,7 @@ def main():
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                          pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                         transform8x8=bool(args.dct8x8), overlap=bool(args.overlap), cavlc_threads=args.cavlc_threads)
+                         transform8x8=bool(args.dct8x8), overlap=args.overlap, cavlc_threads=args.cavlc_threads)
 
     encs = [make_encoder() for _ in range(S)]
     e = encs[0]

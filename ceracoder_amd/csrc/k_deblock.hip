@@ -191,13 +191,16 @@ DEV edge_par par_of(unsigned ab, unsigned tc) { edge_par p; p.alpha = (int)(ab &
 // One thread per macroblock: words 0-1 bS of the vertical edges (nibble 4*edge + segment), 2-3 of
 // the horizontal edges, then {alpha|beta<<8, tc0 bytes} for luma left / top / inner and chroma
 // left / top / inner.  Edges that are not filtered (picture border, 8x8-transform inner edges) get bS 0.
-// Also clears the band progress counters of the launch that follows.
-__global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv, unsigned *__restrict__ progress, int nprog) {
+// Covers macroblocks [mb0, mb1); also zeroes two ranges of band progress counters (which ones: see the launch sites -- a
+// counter must be zero before any kernel that polls it can start, so a launch never clears counters its own picture's bands
+// are about to use unless everything else has been joined).
+__global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv, unsigned *__restrict__ clr_a, int n_a, unsigned *__restrict__ clr_b, int n_b, int mb0, int mb1) {
     const frame_ctx_t *__restrict__ ctx = &cv;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nprog) progress[i] = 0;
-    const int mbw = ctx->mbw, mbh = ctx->mbh;
-    if (i >= mbw * mbh) return;
+    const int j = blockIdx.x * 256 + threadIdx.x, i = mb0 + j;
+    if (j < n_a) clr_a[j] = 0;
+    if (j < n_b) clr_b[j] = 0;
+    const int mbw = ctx->mbw;
+    if (i >= mb1) return;
     const dev_tables *T = &g_tab;
     const int my = i / mbw, mx = i - my * mbw;
     const mb_info_t cur = ld_mbinfo(&ctx->mbi[i]);
@@ -499,8 +502,9 @@ int k_deblock_bands16(int mbh) { return (mbh + D3_ROWS - 1) / D3_ROWS; }
 // `d_progress` holds 2 * bands counters (luma, chroma) followed by the sticky error word at d_err.  The prep kernel clears
 // the counters; the band kernel may be launched in several pieces (bands [band0, band1)): a band only ever waits for the
 // band above it, so pieces may run concurrently on different streams as long as the upper piece is submitted first.
-void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_progress, int nprog, hipStream_t s) {
-    hipLaunchKernelGGL(deblock_prep_kernel, dim3((mbw * mbh + 255) / 256), dim3(256), 0, s, *h_ctx, d_progress, nprog);
+void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, unsigned *clr_a, int n_a, unsigned *clr_b, int n_b, hipStream_t s) {
+    const int n = (row1 - row0) * mbw, m = n > n_a ? (n > n_b ? n : n_b) : (n_a > n_b ? n_a : n_b);
+    if (m > 0) hipLaunchKernelGGL(deblock_prep_kernel, dim3((m + 255) / 256), dim3(256), 0, s, *h_ctx, clr_a, n_a, clr_b, n_b, row0 * mbw, row1 * mbw);
 }
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
     db_args a;

@@ -35,6 +35,7 @@ static const uint8_t k_lambda[52] = {1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1, 
                                      16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91};
 
 #define NSLOT 2
+#define MAX_PIECES 8
 #define SURF_PAD 256 /* bytes past each surface: unaligned-pair loads may touch 4 bytes beyond */
 
 struct slot_t {
@@ -45,8 +46,10 @@ struct slot_t {
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
     uint8_t *d_raw;              // staging of non-NV12 input before the conversion kernel (allocated on first use)
     hipEvent_t done, gpu_done, ev[12];
-    hipEvent_t ev_up, ev_top, ev_prep, ev_a; // cross-stream edges of the overlapped schedule (enqueue_picture)
-    int overlapped, prof;
+    hipEvent_t ev_up, ev_all;                  // uploads finished / every device step of a sequentially scheduled picture finished
+    hipEvent_t ev_fe[MAX_PIECES], ev_db[MAX_PIECES]; // band-pipelined schedule: piece p's records + reconstruction final / piece p deblocked
+    hipEvent_t pv[MAX_PIECES][6];              // stage timers of a sampled pipelined picture (created on first use)
+    int pipelined, prof;
     int is_idr, qp, frame_num, idr_pic_id, rec_index, set;
     int64_t pts;
 };
@@ -56,10 +59,11 @@ struct mi355enc {
     int mbw, mbh, W, H, nmb;
     size_t ysz, csz;
     hipStream_t stream;                  // main compute stream
-    hipStream_t astream;                 // second compute stream: uploads, the upper part of P pictures, the upper deblocking bands
+    hipStream_t astream;                 // low-priority stream: source uploads + colour conversion of the band-pipelined schedule
+    hipStream_t pstream[MAX_PIECES];     // band-pipelined schedule: one stream per piece of the picture; pstream[0] == stream
+    int npieces, piece_band[MAX_PIECES + 1]; // piece p owns deblocking bands [piece_band[p], piece_band[p+1]); npieces < 2: schedule off
     frame_ctx_t *d_ctx, *d_ctx2[2];      // one context per picture parity (two pictures are in flight on the device); d_ctx = d_ctx2[0]
     slot_t *prev_slot;                   // slot of the picture enqueued last
-    int ov_bands_a, ov_rows_top;         // overlapped schedule: bands [0, ov_bands_a) / rows [0, ov_rows_top) form the upper part; 0 = off
     mb_info_t *d_mbi, *d_mbi_set[2];     // two record/level sets: the D2H of picture n overlaps the kernels of n+1
     int16_t *d_levels, *d_levels_set[2];
     hipStream_t cstream;                 // copy stream for the D2H hand-over
@@ -68,7 +72,7 @@ struct mi355enc {
     uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock
     uint8_t *d_idec;      // intra decisions, IDEC_BYTES per macroblock
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
-    unsigned *d_progress; // [2*bands] strip counters of the band deblocker, then one error word
+    unsigned *d_progress; // two sets (picture parity) of [2*bands] strip counters of the band deblocker, then one error word
     unsigned *d_iprogress; // progress counters of the persistent intra kernel, one per band
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
     int n_progress;
@@ -113,6 +117,9 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0; c->cavlc_threads = 1; c->intra_mode = 0;
 }
 
+static unsigned *prog_set(const mi355enc_t *h, int set) { return h->d_progress + (size_t)set * h->n_progress; }
+static unsigned *err_word(const mi355enc_t *h) { return h->d_progress + 2 * (size_t)h->n_progress; }
+
 static void launch_intra_all(mi355enc_t *h, int ci) {
     int n = k_intra_diags(h->mbw, h->mbh);
     for (int d = 0; d < n; d++) k_launch_intra_diag(h->d_ctx2[ci], h->mbw, h->mbh, d, h->stream);
@@ -133,7 +140,7 @@ static int build_graph(mi355enc_t *h, int which, int ci, hipGraphExec_t *out) {
 static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
     k_launch_intra_analyse(h->d_ctx2[ci], h->mbw, h->mbh, h->stream); // open-loop mode analysis + decisions: one flat launch
     if (h->cfg.intra_mode == 0) { // persistent band kernel
-        k_launch_intra_band(hc, h->mbh, h->d_iprogress, h->d_progress + h->n_progress, h->stream);
+        k_launch_intra_band(hc, h->mbh, h->d_iprogress, err_word(h), h->stream);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -146,8 +153,9 @@ static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
 static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
     if (h->cfg.deblock_mode == 0) { // prep kernel (also clears the progress counters) + persistent 16-row band kernel
-        k_launch_deblock_prep(hc, h->mbw, h->mbh, h->d_progress, h->n_progress, h->stream);
-        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), h->d_progress, h->d_progress + h->n_progress, h->stream);
+        const int nb = k_deblock_bands16(h->mbh);
+        k_launch_deblock_prep(hc, h->mbw, 0, h->mbh, h->d_progress, 2 * h->n_progress, nullptr, 0, h->stream); // nothing else is in flight: clear both sets
+        k_launch_deblock_bands(hc, h->mbh, 0, nb, prog_set(h, ci), err_word(h), h->stream);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -188,7 +196,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->astream = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->ov_bands_a = h->ov_rows_top = 0; h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->npieces = 0; memset(h->pstream, 0, sizeof h->pstream); h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -220,8 +228,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_dbrec, (size_t)h->nmb * 64));
     HIPCHK(hipMalloc((void **)&h->d_idec, (size_t)h->nmb * IDEC_BYTES + 16));
     h->n_progress = 2 * k_deblock_bands16(h->mbh);
-    HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(h->n_progress + 1) * sizeof(unsigned)));
-    HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
+    HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
     HIPCHK(hipMalloc((void **)&h->d_iprogress, (size_t)k_intra_bands(h->mbh) * sizeof(unsigned)));
     if (cfg->keep_prefilter) {
@@ -242,21 +250,34 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipEventCreateWithFlags(&s->gpu_done, hipEventDisableTiming));
         for (int k = 0; k < 12; k++) HIPCHK(hipEventCreate(&s->ev[k]));
         HIPCHK(hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&s->ev_top, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&s->ev_prep, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&s->ev_a, hipEventDisableTiming));
-    }
-    { // Overlapped schedule for P pictures (deblock_mode 0 only): choose how many upper bands go to the second stream so that the
-      // time the lower bands keep running after them (~18 steps of ~1.6 us per band) roughly matches the upper part's flat kernels
-      // (~12 ns per macroblock for search + refinement + transform).
-        const int nb = k_deblock_bands16(h->mbh);
-        int best_k = 0; double best_v = 0;
-        for (int k = 1; k <= nb - 2; k++) { // k bands above, at least two below
-            int rows = 16 * k - 3;
-            double win = (nb - k) * 18 * 1.6, top = 0.012 * h->mbw * rows, v = win < top ? win : top;
-            if (v > best_v) { best_v = v; best_k = k; }
+        HIPCHK(hipEventCreateWithFlags(&s->ev_all, hipEventDisableTiming));
+        for (int k = 0; k < MAX_PIECES; k++) {
+            HIPCHK(hipEventCreateWithFlags(&s->ev_fe[k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&s->ev_db[k], hipEventDisableTiming));
         }
-        if (h->cfg.overlap && h->cfg.deblock_mode == 0 && best_k > 0) { h->ov_bands_a = best_k; h->ov_rows_top = 16 * best_k - 3; }
+    }
+    { // Band-pipelined schedule (deblock_mode 0): cut the picture into up to `overlap` pieces of whole deblocking bands, one stream
+      // each.  overlap = 1 asks for the default, 4: this many equal-priority streams still get a hardware queue each on a stock
+      // HIP runtime (tools/ubench_streams.hip), and pieces that shared a queue would serialise what the schedule overlaps.
+        const int nb = k_deblock_bands16(h->mbh);
+        int want = h->cfg.overlap <= 0 ? 0 : h->cfg.overlap == 1 ? 4 : h->cfg.overlap;
+        if (want > MAX_PIECES) want = MAX_PIECES;
+        if (want > nb) want = nb;
+        h->pstream[0] = h->stream;
+        if (want >= 2 && h->cfg.deblock_mode == 0) {
+            // the last `nb % want` pieces take one band more: the last band of a picture is usually short, and what bounds the
+            // picture rate is the largest sum of two neighbouring pieces' rows (see enqueue_picture)
+            const int base = nb / want, extra = nb % want;
+            h->piece_band[0] = 0;
+            for (int p = 0; p < want; p++) h->piece_band[p + 1] = h->piece_band[p] + base + (p >= want - extra ? 1 : 0);
+            // HIP keeps a pool of (by default 4) hardware queues per priority level and the application's own streams draw from
+            // the normal pool too, so the piece streams alternate between the normal and the high level: two pieces that
+            // shared a queue would run one after the other and undo the schedule.
+            int lo = 0, hi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            for (int p = 1; p < want; p++) HIPCHK(hipStreamCreateWithPriority(&h->pstream[p], hipStreamNonBlocking, (p & 1) ? hi : (lo + hi) / 2));
+            h->npieces = want;
+        }
     }
     h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
     if (!h->writer) return MI355ENC_ERR_NOMEM;
@@ -271,6 +292,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device_id);
     if (h->astream) (void)hipStreamSynchronize(h->astream);
+    for (int p = 1; p < h->npieces; p++) if (h->pstream[p]) { (void)hipStreamSynchronize(h->pstream[p]); (void)hipStreamDestroy(h->pstream[p]); }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 2; i++) { if (h->g_intra[i]) (void)hipGraphExecDestroy(h->g_intra[i]); if (h->g_deblock[i]) (void)hipGraphExecDestroy(h->g_deblock[i]); }
     for (int i = 0; i < NSLOT; i++) {
@@ -286,9 +308,12 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->gpu_done) (void)hipEventDestroy(s->gpu_done);
         for (int k = 0; k < 12; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
         if (s->ev_up) (void)hipEventDestroy(s->ev_up);
-        if (s->ev_top) (void)hipEventDestroy(s->ev_top);
-        if (s->ev_prep) (void)hipEventDestroy(s->ev_prep);
-        if (s->ev_a) (void)hipEventDestroy(s->ev_a);
+        if (s->ev_all) (void)hipEventDestroy(s->ev_all);
+        for (int k = 0; k < MAX_PIECES; k++) {
+            if (s->ev_fe[k]) (void)hipEventDestroy(s->ev_fe[k]);
+            if (s->ev_db[k]) (void)hipEventDestroy(s->ev_db[k]);
+            for (int q = 0; q < 6; q++) if (s->pv[k][q]) (void)hipEventDestroy(s->pv[k][q]);
+        }
     }
     for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
     if (h->d_pre_y) (void)hipFree(h->d_pre_y);
@@ -324,29 +349,58 @@ size_t mi355enc_max_au_bytes(const mi355enc_t *h) { return h ? h264_max_au_bytes
 int mi355enc_mb_width(const mi355enc_t *h) { return h ? h->mbw : 0; }
 int mi355enc_mb_height(const mi355enc_t *h) { return h ? h->mbh : 0; }
 
-// Which stream carries the uploads of the next picture: the second stream if that picture will use the overlapped schedule.
-static bool next_overlaps(const mi355enc_t *h, int force_idr) {
-    const bool idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop;
-    return !idr && h->ov_bands_a > 0;
+// Uploads (and the colour conversion) of a picture go through the low-priority stream when the band-pipelined schedule is on,
+// so that they never queue behind a deblocking kernel; enqueue_picture() makes every consumer wait for them.
+static int sync_compute(mi355enc_t *h) { // every stream that carries kernels of a picture (the hand-over stream aside)
+    HIPCHK(hipStreamSynchronize(h->astream));
+    for (int p = 1; p < h->npieces; p++) HIPCHK(hipStreamSynchronize(h->pstream[p]));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
 }
-static hipStream_t upload_stream(const mi355enc_t *h, int force_idr) { return next_overlaps(h, force_idr) ? h->astream : h->stream; }
+static hipStream_t upload_stream(const mi355enc_t *h) { return h->npieces >= 2 ? h->astream : h->stream; }
 
-// Enqueue every device step of one picture whose source is described by (src_y, src_uv, src_stride).  Anything the
-// caller uploaded for this picture was enqueued on `astream`.
+static int ensure_piece_timers(slot_t *s, int np) {
+    for (int p = 0; p < np; p++)
+        for (int q = 0; q < 6; q++)
+            if (!s->pv[p][q]) HIPCHK(hipEventCreate(&s->pv[p][q]));
+    return 0;
+}
+
+// Enqueue every device step of one picture whose source is described by (src_y, src_uv, src_stride).  Anything the caller
+// uploaded for this picture was enqueued on upload_stream().
 //
-// Sequential schedule (IDR pictures, deblock_mode 1, small pictures, overlap off), all on `stream`:
-//     ctx -> intra | me, subpel, inter -> prep -> all bands
-// Overlapped schedule (P pictures): the kernels of a P picture only need the reference rows around their own rows, and the
-// band deblocker of the previous picture finishes top-down.  With A = bands [0, ka) and TOP = macroblock rows [0, 16 ka - 3):
-//     astream:  ... A(n-1) | ctx(n), TOP(n): me, subpel, inter | wait prep(n) | A(n) | ctx(n+1), TOP(n+1) ...
-//     stream :  ... B(n-1) | wait ctx(n), A(n-1) | BOT(n): me, subpel, inter | wait TOP(n) | prep(n) | B(n) | ...
-// TOP(n) follows A(n-1) in stream order, and its search + interpolation window ends inside the rows A(n-1) has finalised
-// (the last 3 rows of A are left to BOT for that reason).  B(n)'s first band spin-waits on A(n)'s last band like any band on
-// the one above; A(n) is always submitted before B(n), so even if both streams shared one hardware queue the wait could not
-// deadlock (it would merely find the counters already complete).  Records and levels are final after `inter`, so the pack
-// kernels start on `cstream` there, as before.
+// Sequential schedule (IDR pictures, deblock_mode 1, overlap off), all on `stream`:
+//     intra | me, subpel, inter -> prep -> all bands                       pack (cstream) starts after intra / inter
+//
+// Band-pipelined schedule (P pictures, cfg.overlap): what bounds the picture rate is the dependency chain of the deblocking
+// filter, ~(mbw + mbh) steps per picture, during which a dozen workgroups are busy and the rest of the device idles -- while
+// the next picture's search only needs reference rows two macroblock rows below its own.  The picture is cut into pieces of
+// whole deblocking bands, piece p on stream p, each stream running for picture n
+//     wait db(n-1, p-1), db(n-1, p+1)           db(n-1, p) precedes in stream order
+//     me, subpel, inter over the piece's rows   -> event fe(n, p)        (the pack kernels on cstream wait for every fe)
+//     wait fe(n, p-1)                           prep reads the records of the row above
+//     prep + band kernel of the piece's bands   its first band spin-waits on the last band of piece p-1 like any band on
+//                                               the one above (k_deblock.hip); piece p-1 is always submitted first
+//     -> event db(n, p)
+// so piece p of picture n+1 starts when piece p+1 of picture n is done instead of when its last band is: consecutive
+// pictures overlap by all bands below p+1, and the search/transform kernels disappear behind the deblocking of the picture
+// before.  Why the waits suffice:
+//   * reference rows: rows r of piece p search lines up to 16 r + 35 (range 16 + 0.75 + 3 filter taps) and down to
+//     16 r - 20, i.e. inside pieces p-1 .. p+1 of the reference, which are final (the last lines the band below touches are
+//     the bottom 3 of a piece; the search stays 12 lines clear of piece p+1's bottom unless that piece is the last one);
+//   * the reconstruction of n+1 overwrites the plane picture n used as its reference: the readers of piece p's rows are the
+//     search kernels of pieces p-1, p, p+1 of picture n, all ahead of db(n, .) in their streams;
+//   * records / levels (two sets, by picture parity) of picture n-1 were consumed by pack (collect() returned before this
+//     submit) and by prep(n-1, p), prep(n-1, p+1), both ahead of db(n-1, .) which precede db(n, .) in stream order;
+//   * deblocking records are written by prep(n+1, p) after the band kernel of (n, p) in the same stream;
+//   * progress counters exist in two sets (picture parity).  A band kernel must never see a stale "complete" counter of the
+//     band above, and piece p+1 runs independently of piece p's prep kernel, so a piece cannot clear its own counters:
+//     prep(n, p) clears piece p's counters of the OTHER set, for picture n+1 -- their last reader, the band kernel of
+//     (n-1, p+1), is ahead of fe(n, p) via db(n-1, p+1), and their next reader (n+1, p+1) starts after db(n, p).
+//     Sequentially scheduled pictures have joined everything and clear both sets.
+// Correctness never depends on streams running concurrently: every spin-wait targets work submitted earlier.
 static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride,
-                           int64_t pts, int force_idr) {
+                           int64_t pts, int force_idr, bool uploaded) {
     const int idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop;
     if (idr) h->frames_since_idr = 0;
     // rate control: latch the setpoint written by the control thread, pick this picture's QP
@@ -364,76 +418,84 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     // stage timers: an event record costs ~5 us of queue time, so profile_events = k samples every k-th picture (IDR pictures always)
     const int prof = h->cfg.profile_events > 0 && (idr || h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
-    const bool ov = !idr && h->ov_bands_a > 0;
-    const int nb = k_deblock_bands16(h->mbh), R = h->ov_rows_top;
+    const int np = h->npieces;
+    const bool pl = !idr && np >= 2;
     slot_t *prev = h->prev_slot;
-    unsigned *d_err = h->d_progress + h->n_progress;
-    // The P-picture kernels and the band deblocker take the context by value; only the kernels replayed from a hipGraph
-    // (intra wavefront, deblock_mode 1) read the device copy, so only those pictures pay for an upload.
-    const bool need_dctx = idr || h->cfg.deblock_mode != 0;
-    if (ov) { // uploads of this picture (source planes, by the caller) go through astream, behind the previous picture's A
-        if (prev && !prev->overlapped) HIPCHK(hipStreamWaitEvent(h->astream, prev->ev_a, 0)); // after a sequential picture: its deblocking ran on `stream`
-        if (need_dctx) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->astream));
-        HIPCHK(hipEventRecord(s->ev_up, h->astream));
-        HIPCHK(hipStreamWaitEvent(h->stream, s->ev_up, 0));
-    } else if (need_dctx) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
-    if (prev && prev->overlapped) HIPCHK(hipStreamWaitEvent(h->stream, prev->ev_a, 0)); // A(n-1) ran on astream; B(n-1) precedes us in stream order
-    if (idr) {
-        if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
-        int r = run_intra(h, ci, c); if (r) return r;
-        if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
-    } else {
-        if (ov) { // TOP on astream
-            if (prof) HIPCHK(hipEventRecord(s->ev[6], h->astream));
-            k_launch_me(c, h->mbw, 0, R, h->astream);
-            if (prof) HIPCHK(hipEventRecord(s->ev[7], h->astream));
-            if (h->cfg.subpel) k_launch_subpel(c, h->mbw, 0, R, h->astream);
-            if (prof) HIPCHK(hipEventRecord(s->ev[8], h->astream));
-            k_launch_inter(c, h->mbw, 0, R, h->astream);
-            if (prof) HIPCHK(hipEventRecord(s->ev[9], h->astream));
-            HIPCHK(hipEventRecord(s->ev_top, h->astream));
+    const bool up_ev = uploaded && upload_stream(h) != h->stream;
+    if (up_ev) HIPCHK(hipEventRecord(s->ev_up, h->astream));
+    if (pl) {
+        const int nb = k_deblock_bands16(h->mbh);
+        if (prof) { int r = ensure_piece_timers(s, np); if (r) return r; }
+        for (int p = 0; p < np; p++) {
+            hipStream_t st = h->pstream[p];
+            const int b0 = h->piece_band[p], b1 = h->piece_band[p + 1];
+            const int r0 = 16 * b0, r1 = 16 * b1 < h->mbh ? 16 * b1 : h->mbh;
+            if (prev && prev->pipelined) {
+                if (p > 0) HIPCHK(hipStreamWaitEvent(st, prev->ev_db[p - 1], 0));
+                if (p + 1 < np) HIPCHK(hipStreamWaitEvent(st, prev->ev_db[p + 1], 0));
+            } else if (prev && p > 0) HIPCHK(hipStreamWaitEvent(st, prev->ev_all, 0)); // stream 0 carried the sequential picture itself
+            if (up_ev) HIPCHK(hipStreamWaitEvent(st, s->ev_up, 0));
+            if (prof) HIPCHK(hipEventRecord(s->pv[p][0], st));
+            k_launch_me(c, h->mbw, r0, r1, st);
+            if (prof) HIPCHK(hipEventRecord(s->pv[p][1], st));
+            if (h->cfg.subpel) k_launch_subpel(c, h->mbw, r0, r1, st);
+            if (prof) HIPCHK(hipEventRecord(s->pv[p][2], st));
+            k_launch_inter(c, h->mbw, r0, r1, st);
+            if (prof) HIPCHK(hipEventRecord(s->pv[p][3], st));
+            HIPCHK(hipEventRecord(s->ev_fe[p], st));
+            if (h->d_pre_y) {
+                HIPCHK(hipMemcpyAsync(h->d_pre_y + (size_t)r0 * 16 * h->W, h->d_rec_y[nxt] + (size_t)r0 * 16 * h->W, (size_t)(r1 - r0) * 16 * h->W, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(h->d_pre_uv + (size_t)r0 * 8 * h->W, h->d_rec_uv[nxt] + (size_t)r0 * 8 * h->W, (size_t)(r1 - r0) * 8 * h->W, hipMemcpyDeviceToDevice, st));
+            }
+            if (p > 0) HIPCHK(hipStreamWaitEvent(st, s->ev_fe[p - 1], 0));
+            if (prof) HIPCHK(hipEventRecord(s->pv[p][4], st));
+            k_launch_deblock_prep(c, h->mbw, r0, r1, prog_set(h, set ^ 1) + b0, b1 - b0, prog_set(h, set ^ 1) + nb + b0, b1 - b0, st); // clears for picture n+1 (below)
+            k_launch_deblock_bands(c, h->mbh, b0, b1, prog_set(h, set), err_word(h), st);
+            if (prof) HIPCHK(hipEventRecord(s->pv[p][5], st));
+            HIPCHK(hipEventRecord(s->ev_db[p], st));
+            HIPCHK(hipStreamWaitEvent(h->cstream, s->ev_fe[p], 0));
         }
-        const int r0 = ov ? R : 0;
-        if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
-        k_launch_me(c, h->mbw, r0, h->mbh, h->stream);
-        if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
-        if (h->cfg.subpel) k_launch_subpel(c, h->mbw, r0, h->mbh, h->stream);
-        if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
-        k_launch_inter(c, h->mbw, r0, h->mbh, h->stream);
-        if (prof) HIPCHK(hipEventRecord(s->ev[11], h->stream));
-        if (ov) HIPCHK(hipStreamWaitEvent(h->stream, s->ev_top, 0));
-    }
-    if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s->gpu_done, h->stream)); // records and levels are final here; they do not depend on deblocking
-    if (h->d_pre_y) {
-        HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
-        if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
-    }
-    if (ov) {
-        k_launch_deblock_prep(c, h->mbw, h->mbh, h->d_progress, h->n_progress, h->stream);
-        HIPCHK(hipEventRecord(s->ev_prep, h->stream));
-        HIPCHK(hipStreamWaitEvent(h->astream, s->ev_prep, 0));
-        k_launch_deblock_bands(c, h->mbh, 0, h->ov_bands_a, h->d_progress, d_err, h->astream);   // A first ...
-        HIPCHK(hipEventRecord(s->ev_a, h->astream));
-        if (prof) HIPCHK(hipEventRecord(s->ev[10], h->astream));
-        k_launch_deblock_bands(c, h->mbh, h->ov_bands_a, nb, h->d_progress, d_err, h->stream);  // ... then B
         HIPCHK(hipGetLastError());
     } else {
+        // The P-picture kernels and the band deblocker take the context by value; only the kernels replayed from a hipGraph
+        // (intra wavefront, deblock_mode 1) read the device copy, so only those pictures pay for an upload.
+        if (idr || h->cfg.deblock_mode != 0) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
+        if (prev && prev->pipelined)
+            for (int p = 1; p < np; p++) HIPCHK(hipStreamWaitEvent(h->stream, prev->ev_db[p], 0)); // join: piece 0 precedes in stream order
+        if (up_ev) HIPCHK(hipStreamWaitEvent(h->stream, s->ev_up, 0));
+        if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
+        if (idr) {
+            int r = run_intra(h, ci, c); if (r) return r;
+            if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
+        } else {
+            k_launch_me(c, h->mbw, 0, h->mbh, h->stream);
+            if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
+            if (h->cfg.subpel) k_launch_subpel(c, h->mbw, 0, h->mbh, h->stream);
+            if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
+            k_launch_inter(c, h->mbw, 0, h->mbh, h->stream);
+            if (prof) HIPCHK(hipEventRecord(s->ev[11], h->stream));
+        }
+        if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->gpu_done, h->stream)); // records and levels are final here; they do not depend on deblocking
+        if (h->d_pre_y) {
+            HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
+            if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
+        }
         int r = run_deblock(h, ci, c); if (r) return r;
-        if (h->ov_bands_a > 0) HIPCHK(hipEventRecord(s->ev_a, h->stream)); // only a later overlapped picture waits on it
+        if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
+        if (np >= 2) HIPCHK(hipEventRecord(s->ev_all, h->stream)); // only a later pipelined picture waits on it
+        HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
     }
-    if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
     // Hand-over on the third stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:
     // the device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
-    HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
-    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, d_err, h->cstream);
+    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, err_word(h), h->cstream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->done, h->cstream));
     h->n_submitted++;
     s->is_idr = idr; s->qp = qp; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
-    s->pts = pts; s->rec_index = nxt; s->set = set; s->overlapped = ov ? 1 : 0; s->prof = prof;
+    s->pts = pts; s->rec_index = nxt; s->set = set; s->pipelined = pl ? 1 : 0; s->prof = prof;
     if (idr) h->idr_count++;
     h->frames_since_idr++;
     h->cur = nxt; h->have_ref = 1; h->prev_slot = s;
@@ -447,11 +509,11 @@ int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[h->head];
     const int w = h->cfg.width, ht = h->cfg.height;
-    hipStream_t up = upload_stream(h, force_idr);
+    hipStream_t up = upload_stream(h);
     HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, y, y_stride, w, ht, hipMemcpyHostToDevice, up));
     HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, up));
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
-    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr, true);
 }
 
 // Upload the planes of a non-NV12 picture tightly into the slot's raw staging buffer and convert into its NV12 staging surfaces.
@@ -483,9 +545,9 @@ int mi355enc_submit_fmt(mi355enc_t *h, int fmt, const uint8_t *const planes[3], 
     if (h->pending > h->cfg.pipeline_depth) return MI355ENC_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[h->head];
-    int r = upload_and_convert(h, s, fmt, planes, strides, upload_stream(h, force_idr));
+    int r = upload_and_convert(h, s, fmt, planes, strides, upload_stream(h));
     if (r) return r;
-    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr, true);
 }
 
 int mi355enc_stage_csc(mi355enc_t *h, int fmt, const uint8_t *const planes[3], const int strides[3], uint8_t *out_y, uint8_t *out_uv) {
@@ -506,13 +568,13 @@ int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const v
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[h->head];
     const int w = h->cfg.width, ht = h->cfg.height;
-    hipStream_t up = upload_stream(h, force_idr);
+    hipStream_t up = upload_stream(h);
     const bool direct = w == h->W && y_stride == uv_stride && (y_stride & 15) == 0 && (((uintptr_t)d_y | (uintptr_t)d_uv) & 15) == 0;
-    if (direct) return enqueue_picture(h, s, (const uint8_t *)d_y, (const uint8_t *)d_uv, y_stride, pts, force_idr);
+    if (direct) return enqueue_picture(h, s, (const uint8_t *)d_y, (const uint8_t *)d_uv, y_stride, pts, force_idr, false);
     HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, d_y, y_stride, w, ht, hipMemcpyDeviceToDevice, up));
     HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, d_uv, uv_stride, w, ht / 2, hipMemcpyDeviceToDevice, up));
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
-    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr, true);
 }
 
 int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_len, int *is_keyframe, int64_t *pts, int *qp) {
@@ -543,18 +605,23 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     rc_update(&h->rc, s->is_idr, s->qp, n + m);
     if (s->prof) {
         float a = 0, b = 0, c = 0, tot = 0, sp = 0, t = 0;
-        HIPCHK(hipEventSynchronize(s->ev[4])); // the access unit is ready before deblocking ends; the stage timers are not
-        if (s->overlapped) HIPCHK(hipEventSynchronize(s->ev[10]));
-        (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
-        if (!s->is_idr) { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
-        if (s->overlapped) { // the upper part ran on the other stream: kernel times add up
-            (void)hipEventElapsedTime(&t, s->ev[6], s->ev[7]); a += t;
-            (void)hipEventElapsedTime(&t, s->ev[7], s->ev[8]); sp += t;
-            (void)hipEventElapsedTime(&t, s->ev[8], s->ev[9]); b += t;
+        if (s->pipelined) { // kernel times add up over the pieces; deblocking and the total are spans (the pieces run side by side)
+            const int np = h->npieces;
+            for (int p = 0; p < np; p++) HIPCHK(hipEventSynchronize(s->pv[p][5]));
+            for (int p = 0; p < np; p++) {
+                (void)hipEventElapsedTime(&t, s->pv[p][0], s->pv[p][1]); a += t;
+                (void)hipEventElapsedTime(&t, s->pv[p][1], s->pv[p][2]); sp += t;
+                (void)hipEventElapsedTime(&t, s->pv[p][2], s->pv[p][3]); b += t;
+                (void)hipEventElapsedTime(&t, s->pv[0][4], s->pv[p][5]); if (t > c) c = t;
+                (void)hipEventElapsedTime(&t, s->pv[0][0], s->pv[p][5]); if (t > tot) tot = t;
+            }
+        } else {
+            HIPCHK(hipEventSynchronize(s->ev[4])); // the access unit is ready before deblocking ends; the stage timers are not
+            (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
+            if (!s->is_idr) { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
+            (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
+            (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]);
         }
-        (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
-        if (s->overlapped) { (void)hipEventElapsedTime(&t, s->ev[2], s->ev[10]); if (t > c) c = t; (void)hipEventElapsedTime(&tot, s->ev[6], s->ev[4]); }
-        else (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]);
         if (s->is_idr) { h->st.ms_intra += a; h->st.n_intra++; }
         else { h->st.ms_me += a; h->st.n_me++; h->st.ms_inter += b; h->st.n_inter++; h->st.ms_subpel += sp; }
         h->st.ms_deblock += c; h->st.n_deblock++;
@@ -603,8 +670,7 @@ int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
     if (!src) return MI355ENC_ERR_STATE;
     if (n < need) return MI355ENC_ERR_OVERFLOW;
     if (host) { memcpy(dst, src, need); return MI355ENC_OK; }
-    HIPCHK(hipStreamSynchronize(h->astream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    { int r = sync_compute(h); if (r) return r; }
     HIPCHK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
     return MI355ENC_OK;
 }
@@ -617,7 +683,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     c->src_y = src_is_staging ? s->d_src_y : nullptr; c->src_uv = src_is_staging ? s->d_src_uv : nullptr; c->src_stride = h->W;
     c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
     HIPCHK(hipStreamSynchronize(h->cstream));
-    HIPCHK(hipStreamSynchronize(h->astream));
+    { int r = sync_compute(h); if (r) return r; }
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));

@@ -61,9 +61,13 @@ typedef struct {
     int subpel;               /* 1 (default): half- then quarter-sample refinement after the integer search */
     int deblock_mode;         /* 0: boundary-strength prep kernel + persistent 16-row band kernel (x+y order);
                                  1: one launch per x+2y wavefront (plain form, kept as a cross-check) */
-    int overlap;              /* 1: start the upper rows of a P picture on a second stream while the lower bands of the previous
-                                 picture are still being deblocked (bit-identical output; measured neutral in r01 because the split
-                                 launches sit at their latency floor -- see DESIGN.md); 0 (default): one picture after the other */
+    int overlap;              /* band-pipelined schedule for P pictures (deblock_mode 0): the picture is cut into pieces of whole
+                                 deblocking bands, one HIP stream each; piece p of picture n+1 (search, transform, deblocking)
+                                 starts as soon as pieces p-1..p+1 of picture n are deblocked, so consecutive pictures overlap on
+                                 the device instead of queueing behind the deblocking chain of the whole picture.  Bit-identical
+                                 output.  0 (default): one picture after the other; 1: default piece count (4, the number of
+                                 equal-priority streams a stock HIP runtime backs with separate hardware queues); N >= 2: N
+                                 pieces (useful with GPU_MAX_HW_QUEUES raised) */
     int cavlc_threads;        /* host threads that code the slice (ranges of macroblock rows, concatenated bit-exactly into the
                                  same single slice); 1 (default): the calling thread only */
     int intra_mode;           /* 0 (default): persistent band kernel for the intra reconstruction wavefront; 1: one launch per

@@ -132,7 +132,7 @@ def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp, mode):
 
 
 @pytest.mark.parametrize("w,h,n", [(64, 48, 9), (176, 144, 7), (322, 182, 5), (1280, 720, 4), (1920, 1080, 3)])
-@pytest.mark.parametrize("graphs,mode,sub,ov,thr,imode", [(True, 0, True, False, 1, 0), (False, 0, False, False, 3, 1), (True, 1, True, False, 1, 1), (True, 0, True, True, 4, 0)])
+@pytest.mark.parametrize("graphs,mode,sub,ov,thr,imode", [(True, 0, True, False, 1, 0), (False, 0, False, False, 3, 1), (True, 1, True, False, 1, 1), (True, 0, True, 1, 4, 0)])
 def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub, ov, thr, imode):
     """Whole path: identical access units, identical reconstruction, and the independent
     decoder reproduces both."""
@@ -255,6 +255,33 @@ def test_pipelined_submit_collect_equals_sync(E, oracle):
     assert [p[0] for p in piped] == sync
     assert [p[2] for p in piped] == list(range(n))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("w,h,n,ov", [(640, 528, 14, 1), (640, 528, 14, 2), (1280, 720, 9, 3), (1920, 1080, 9, 1), (1920, 1080, 7, 5), (320, 2064, 8, 8)])
+def test_band_pipelined_schedule_equals_oracle(E, oracle, w, h, n, ov):
+    """cfg.overlap: P pictures cut into pieces of deblocking bands on separate streams, consecutive pictures overlapping on
+    the device (piece p of picture n+1 starts when piece p+1 of picture n is deblocked).  Pictures are submitted back to
+    back (pipeline_depth=1, nothing fetched in between) so that the overlap really happens; every access unit and the
+    final reconstruction must equal the oracle's.  overlap=5/8: more pieces than the runtime has hardware queues."""
+    gop = 6
+    e = E.Encoder(w, h, gop=gop, fixed_qp=30, overlap=ov, pipeline_depth=1, cavlc_threads=2)
+    oe = oracle.Encoder(w, h, gop=gop, threads=8)
+    qps = [30, 26, 34, 22, 41, 28, 30]
+    got = []
+    for i, (_, _, y, uv) in enumerate(frames(w, h, n)):
+        e.set_fixed_qp(qps[i % len(qps)])
+        e.submit(y, uv, pts=i)
+        if e.pending == 2:
+            got.append(e.collect())
+    while e.pending:
+        got.append(e.collect())
+    for i, (_, _, y, uv) in enumerate(frames(w, h, n)):
+        ref_au, ref_key = oe.encode(y, uv, qps[i % len(qps)])
+        assert got[i][0] == ref_au, ("bitstream", i, len(got[i][0]), len(ref_au))
+        assert got[i][1] == ref_key
+    assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y), first_diff(e.fetch(E.FETCH_RECON_Y), oe.recon_y)
+    assert np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv)
+    e.close()
 
 
 def test_noise_worst_case_roundtrip(E, oracle):
