@@ -131,8 +131,11 @@ def main():
     ap.add_argument("--deblock-mode", type=int, default=0)
     ap.add_argument("--sample", type=int, default=7, help="stage timers (HIP events) on every k-th picture; each event record costs ~5 us of queue time")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent streams encoded concurrently on each GPU (one host thread each); the headline configuration is 1")
-    ap.add_argument("--cavlc-threads", type=int, default=1, help="host threads coding one slice row-parallel (bit-identical output)")
+    ap.add_argument("--cavlc-threads", type=int, default=0, help="host threads coding one slice row-parallel (bit-identical output); 0 = the encoder's default (automatic, at most 4)")
     ap.add_argument("--overlap", type=int, default=0, help="band-pipelined schedule for P pictures: 0 off, 1 default piece count (4), N >= 2 pieces")
+    ap.add_argument("--rate-script", default="auto", help="bitrate setpoints written to the encoder while it runs: 'none', or a balancer of the reference "
+                    "(adaptive|aimd|fixed: tests/golden/balancer_<name>.txt, generated from the reference's own balancer code); auto = adaptive for 1080p_ippp "
+                    "(BASELINE.json configs[2]: 'balancer driving the bitrate property'), none elsewhere")
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     args = ap.parse_args()
     if args.streams_per_gpu > 1:  # every encoder owns three HIP streams; the runtime's default of 4 hardware queues would serialise them
@@ -159,6 +162,24 @@ def main():
     fbytes = frames.stride(0)
 
     S = max(1, args.streams_per_gpu)
+    # The reference's control loop (src/ceracoder.c:237-264) writes a new setpoint every balancer tick; the committed script holds
+    # (time in ms, bit/s) pairs of one of its balancers for a scripted link, replayed here against stream time (picture index / fps).
+    script_name = args.rate_script if args.rate_script != "auto" else ("adaptive" if args.workload == "1080p_ippp" else "none")
+    script = []
+    if script_name != "none" and args.fixed_qp < 0:
+        here = os.path.dirname(os.path.abspath(__file__))
+        for line in open(os.path.join(here, "tests", "golden", "balancer_%s.txt" % script_name)):
+            t_ms, b = line.split()
+            script.append((int(t_ms), int(b)))
+    script_end = script[-1][0] if script else 0
+
+    def setpoint(index):  # the script repeats when the run is longer than it
+        t = (index * 1000 // fps) % script_end
+        cur = script[0][1]
+        for t_ms, b in script:
+            if t_ms <= t:
+                cur = b
+        return cur
 
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
@@ -169,8 +190,13 @@ def main():
     e = encs[0]
 
     def run_one(enc, n, first_index, shift):
-        qps, nbytes = [], 0
+        qps, nbytes, last_bps = [], 0, None
         for i in range(n):
+            if script:
+                b = setpoint(first_index + i)
+                if b != last_bps:
+                    enc.set_bitrate(b)
+                    last_bps = b
             p = base + bounce(first_index + i + shift, args.unique) * fbytes
             enc.submit_device(p, stride, p + height * stride, stride, pts=first_index + i)
             if enc.pending > args.depth:
@@ -282,9 +308,11 @@ def main():
             "ms_per_step": round(dt / (S * args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic (S2: panning texture + 12 moving rectangles, seed 0x5EED), resident in HBM",
             "config": {"workload": args.workload, "width": width, "height": height, "fps_nominal": fps, "gop": gop,
-                       "rate_control": "cbr %d bit/s" % bps if args.fixed_qp < 0 else "fixed qp %d" % args.fixed_qp,
+                       "rate_control": ("fixed qp %d" % args.fixed_qp) if args.fixed_qp >= 0 else ("cbr %d bit/s" % bps) if not script else
+                       "cbr, setpoint driven by the reference's '%s' balancer script (%d..%d kbit/s, tests/golden/balancer_%s.txt)" % (
+                           script_name, min(b for _, b in script) // 1000, max(b for _, b in script) // 1000, script_name),
                        "me": "full search +-16 integer-pel SAD + half/quarter-sample refinement", "streams_per_gpu": S, "parallelism": "%d independent streams" % (world * S),
-                       "pipeline_depth": args.depth, "dct8x8": bool(args.dct8x8), "cavlc_threads": args.cavlc_threads},
+                       "pipeline_depth": args.depth, "dct8x8": bool(args.dct8x8), "cavlc_threads": int(st.cavlc_threads)},
             "roofline": roof,
             "roofline_kernels": kernels,
             "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "inter": round(st.ms_inter / max(1, st.n_inter), 4),
@@ -294,7 +322,8 @@ def main():
                                      "gpu_total": round(est_total / max(1, st.frames), 4),
                                      "host_cavlc": round(st.ms_entropy / max(1, st.frames), 4),
                                      "host_wait": round(st.ms_wait / max(1, st.frames), 4)},
-            "bitrate_out_bps": round(nbytes * 8 * fps / (S * args.steps)), "mean_qp": round(float(np.mean(qps)), 2),
+            "bitrate_out_bps": round(nbytes * 8 * fps / (S * args.steps)),
+            "bitrate_setpoint_mean_bps": round(float(np.mean([setpoint(args.warmup + i) for i in range(args.steps)]))) if script else bps, "mean_qp": round(float(np.mean(qps)), 2),
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:

@@ -149,7 +149,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     GST_OBJECT_LOCK(s);
     cfg.gop = s->key_int_max ? (int)s->key_int_max : 250;
     cfg.me_range = s->me_range; cfg.bitrate_bps = s->bps; cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
-    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 1;
+    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0;
     GST_OBJECT_UNLOCK(s);
     int r = mi355enc_open(&cfg, &e);
     if (r != MI355ENC_OK) {
@@ -287,7 +287,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
     g_object_class_install_property(g, PROP_SPEED_PRESET, g_param_spec_enum("speed-preset", "Speed preset",
         "Accepted for x264enc pipeline compatibility; ignored", speed_preset_type(), 6, F));
     g_object_class_install_property(g, PROP_THREADS, g_param_spec_int("threads", "Entropy-coding threads",
-        "Host threads that code one slice row-parallel (bit-identical output); like x264enc's property of the same name, 0/1 = streaming thread only", 0, 64, 1, F));
+        "Host threads that code one slice row-parallel (bit-identical output); like x264enc's property of the same name, 0 = automatic (a quarter of the CPUs, at most 4), 1 = streaming thread only", 0, 64, 0, F));
     g_object_class_install_property(g, PROP_DCT8X8, g_param_spec_boolean("dct8x8", "8x8 transform",
         "Adaptive spatial transform size as in x264enc: High-profile stream, P macroblocks use the 8x8 transform", FALSE, F));
     g_object_class_install_property(g, PROP_STATS, g_param_spec_boolean("stats", "Print stats", "Print a JSON line with counters when the encoder closes", FALSE, F));
@@ -300,7 +300,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->bps = 2048000; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
-    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 1; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
+    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
 }
 
 GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */

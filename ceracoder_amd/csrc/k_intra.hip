@@ -341,9 +341,14 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         else if (lane < 33) T4[(lane - 16) * 24] = (uint8_t)LEFT(0, lane - 17);
         const int half = (lane >> 4) & 1, px = lane & 3, py = (lane >> 2) & 3;
         const qparams q4 = make_q(T, qp, true);
-        const int cl4 = (!(px & 1) && !(py & 1)) ? 0 : ((px & 1) && (py & 1)) ? 1 : 2;
+        // The 4x4 transforms run as two-stage butterflies over DPP lane exchanges (partner x^3 then x^1 forward, x^1 then x^3
+        // inverse; rows within the quad, columns across the 16-lane row), which leaves the coefficients in the lane order
+        // 0, 2, 1, 3 per dimension: lane (px, py) holds frequency (fx, fy) = (F[px], F[py]).  Quantiser class and zig-zag
+        // position follow the frequency; the inverse butterfly takes that order and returns samples in natural order.
+        const int fx = ((px & 1) << 1) | (px >> 1), fy = ((py & 1) << 1) | (py >> 1);
+        const int cl4 = (!(fx & 1) && !(fy & 1)) ? 0 : ((fx & 1) && (fy & 1)) ? 1 : 2;
         const int mf4 = cl4 == 0 ? q4.mf[0] : cl4 == 1 ? q4.mf[1] : q4.mf[2], v4 = cl4 == 0 ? q4.v[0] : cl4 == 1 ? q4.v[1] : q4.v[2];
-        const int kz4 = (int)((0xFEA9DB83C7426510ull >> (4 * (py * 4 + px))) & 15); // raster -> zig-zag position
+        const int kz4 = (int)((0xFEA9DB83C7426510ull >> (4 * (fy * 4 + fx))) & 15); // raster -> zig-zag position
         WAVE_SYNC();
 #pragma unroll 1
         for (int s4 = 0; s4 < 10; s4++) {
@@ -375,27 +380,27 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             const int ent = T->i4tab[bmode * 16 + py * 4 + px], j0 = ent & 15, kind = ent >> 4;
             const int za = zb[j0], zc = zb[j0 + 1], zd = zb[j0 + 2];
             const int bpred = kind == 0 ? za : kind == 1 ? (za + zc + 1) >> 1 : kind == 2 ? (za + 2 * zc + zd + 2) >> 2 : dc4;
-            // residual -> 4x4 core transform across the 16 lanes (rows, then columns)
+            // residual -> 4x4 core transform (8.5.12's forward counterpart): rows, then columns
             const int res = sv - bpred;
-            const int cbase = lane & ~12;
-            int a0 = quad_bcast<0>(res), a1 = quad_bcast<1>(res), a2 = quad_bcast<2>(res), a3 = quad_bcast<3>(res);
-            int tr = px == 0 ? a0 + a1 + a2 + a3 : px == 1 ? 2 * a0 + a1 - a2 - 2 * a3 : px == 2 ? a0 - a1 - a2 + a3 : a0 - 2 * a1 + 2 * a2 - a3;
-            a0 = __shfl(tr, cbase, 64); a1 = __shfl(tr, cbase + 4, 64); a2 = __shfl(tr, cbase + 8, 64); a3 = __shfl(tr, cbase + 12, 64);
-            const int coef = py == 0 ? a0 + a1 + a2 + a3 : py == 1 ? 2 * a0 + a1 - a2 - 2 * a3 : py == 2 ? a0 - a1 - a2 + a3 : a0 - 2 * a1 + 2 * a2 - a3;
+            int pr = quad_xor<3>(res);
+            int tr = px < 2 ? res + pr : pr - res;          // e0 e1 e2 e3
+            pr = quad_xor<1>(tr);
+            tr = px == 0 ? tr + pr : px == 1 ? pr - tr : px == 2 ? tr + 2 * pr : tr - 2 * pr; // f0 f2 f1 f3
+            pr = row_xor12(tr);
+            int tc = py < 2 ? tr + pr : pr - tr;
+            pr = row_xor4(tc);
+            const int coef = py == 0 ? tc + pr : py == 1 ? pr - tc : py == 2 ? tc + 2 * pr : tc - 2 * pr;
             const int lv4 = quant1(coef, mf4, q4.f, q4.qbits);
             // 8.5.12: scale, inverse transform (rows then columns), round
             const int dq = (lv4 * v4) << q4.shift;
-            a0 = quad_bcast<0>(dq); a1 = quad_bcast<1>(dq); a2 = quad_bcast<2>(dq); a3 = quad_bcast<3>(dq);
-            {
-                const int e0 = a0 + a2, e1 = a0 - a2, e2 = (a1 >> 1) - a3, e3 = a1 + (a3 >> 1);
-                tr = px == 0 ? e0 + e3 : px == 1 ? e1 + e2 : px == 2 ? e1 - e2 : e0 - e3;
-            }
-            a0 = __shfl(tr, cbase, 64); a1 = __shfl(tr, cbase + 4, 64); a2 = __shfl(tr, cbase + 8, 64); a3 = __shfl(tr, cbase + 12, 64);
-            int rr;
-            {
-                const int e0 = a0 + a2, e1 = a0 - a2, e2 = (a1 >> 1) - a3, e3 = a1 + (a3 >> 1);
-                rr = py == 0 ? e0 + e3 : py == 1 ? e1 + e2 : py == 2 ? e1 - e2 : e0 - e3;
-            }
+            pr = quad_xor<1>(dq);
+            tr = px == 0 ? dq + pr : px == 1 ? pr - dq : px == 2 ? (dq >> 1) - pr : pr + (dq >> 1);  // e0 e1 e2 e3
+            pr = quad_xor<3>(tr);
+            tr = px < 2 ? tr + pr : pr - tr;                // natural order again
+            pr = row_xor4(tr);
+            tc = py == 0 ? tr + pr : py == 1 ? pr - tr : py == 2 ? (tr >> 1) - pr : pr + (tr >> 1);
+            pr = row_xor12(tc);
+            const int rr = py < 2 ? tc + pr : pr - tc;
             const int recp = clip255(bpred + ((rr + 32) >> 6));
             const unsigned long long bal = __ballot(valid && lv4 != 0);
             const int b0 = ((by_lo >> 1) << 3) | (((s4 - 2 * by_lo) >> 1) << 2) | ((by_lo & 1) << 1) | ((s4 - 2 * by_lo) & 1);

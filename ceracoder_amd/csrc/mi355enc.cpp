@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include "h264_host.h"
 #include "mi355enc_dev.h"
@@ -114,7 +115,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0; c->cavlc_threads = 1; c->intra_mode = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0; c->cavlc_threads = 0; c->intra_mode = 0;
 }
 
 static unsigned *prog_set(const mi355enc_t *h, int set) { return h->d_progress + (size_t)set * h->n_progress; }
@@ -281,6 +282,11 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     }
     h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
     if (!h->writer) return MI355ENC_ERR_NOMEM;
+    if (h->cfg.cavlc_threads <= 0) { // auto, like x264enc's threads=0
+        const unsigned hw = std::thread::hardware_concurrency();
+        int n = (int)(hw / 4);
+        h->cfg.cavlc_threads = h->nmb < 1000 ? 1 : n < 1 ? 1 : n > 4 ? 4 : n;
+    }
     if (h->cfg.cavlc_threads > 1 && h264_writer_set_threads(h->writer, h->cfg.cavlc_threads)) return MI355ENC_ERR_NOMEM;
     rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -648,6 +654,7 @@ int mi355enc_get_stats(mi355enc_t *h, mi355enc_stats_t *st) {
     if (!h || !st) return MI355ENC_ERR_ARG;
     *st = h->st;
     st->target_bps = h->want_bps.load();
+    st->cavlc_threads = (uint32_t)h->cfg.cavlc_threads;
     return MI355ENC_OK;
 }
 void mi355enc_reset_stats(mi355enc_t *h) { if (h) memset(&h->st, 0, sizeof h->st); }

@@ -45,7 +45,7 @@ class Stats(C.Structure):
                 ("last_bytes", C.c_uint32), ("target_bps", C.c_uint32), ("ms_me", C.c_double), ("ms_inter", C.c_double),
                 ("ms_intra", C.c_double), ("ms_deblock", C.c_double), ("ms_total_gpu", C.c_double), ("ms_subpel", C.c_double), ("n_me", C.c_uint64),
                 ("n_inter", C.c_uint64), ("n_intra", C.c_uint64), ("n_deblock", C.c_uint64), ("ms_entropy", C.c_double),
-                ("ms_wait", C.c_double), ("n_total_gpu", C.c_uint64), ("ms_deblock_idr", C.c_double), ("n_deblock_idr", C.c_uint64)]
+                ("ms_wait", C.c_double), ("n_total_gpu", C.c_uint64), ("ms_deblock_idr", C.c_double), ("n_deblock_idr", C.c_uint64), ("cavlc_threads", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 _lib = None
@@ -169,7 +169,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, overlap=False, cavlc_threads=1, intra_mode=0):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, overlap=0, cavlc_threads=0, intra_mode=0):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)

@@ -69,7 +69,9 @@ typedef struct {
                                  equal-priority streams a stock HIP runtime backs with separate hardware queues); N >= 2: N
                                  pieces (useful with GPU_MAX_HW_QUEUES raised) */
     int cavlc_threads;        /* host threads that code the slice (ranges of macroblock rows, concatenated bit-exactly into the
-                                 same single slice); 1 (default): the calling thread only */
+                                 same single slice); 1: the calling thread only; 0 (default, like x264enc's threads=0): chosen
+                                 from the machine -- a quarter of the online CPUs, between 1 and 4 (1 for pictures under
+                                 1000 macroblocks, where waking workers costs more than it saves); mi355enc_stats_t reports it */
     int intra_mode;           /* 0 (default): persistent band kernel for the intra reconstruction wavefront; 1: one launch per
                                  anti-diagonal replayed as a hipGraph (plain form, kept as a cross-check) */
 } mi355enc_cfg_t;
@@ -86,6 +88,8 @@ typedef struct {
     uint64_t n_total_gpu;     /* pictures sampled into ms_total_gpu */
     double ms_deblock_idr;    /* the part of ms_deblock / n_deblock that came from IDR pictures */
     uint64_t n_deblock_idr;
+    uint32_t cavlc_threads;   /* host threads in use for entropy coding (cfg.cavlc_threads resolved) */
+    uint32_t reserved0;
 } mi355enc_stats_t;
 
 /* Fill cfg with the defaults of the element (gop 60, me_range 16, 2048 kbit/s like x264enc). */
