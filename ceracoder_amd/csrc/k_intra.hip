@@ -346,6 +346,13 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         // 0, 2, 1, 3 per dimension: lane (px, py) holds frequency (fx, fy) = (F[px], F[py]).  Quantiser class and zig-zag
         // position follow the frequency; the inverse butterfly takes that order and returns samples in natural order.
         const int fx = ((px & 1) << 1) | (px >> 1), fy = ((py & 1) << 1) | (py >> 1);
+        // butterfly coefficients per lane position p = 0..3 (x for rows, y for columns):
+        //   stage "x^3": own * s1 + partner, s1 = +1 +1 -1 -1            (a0+a3, a1+a2, a1-a2, a0-a3; and the inverse's second stage)
+        //   forward "x^1": own * fo + partner * fp, (fo, fp) = (1,1) (-1,1) (1,2) (1,-2)
+        //   inverse "x^1": (own >> is) * io + partner * ip, is = 0 0 1 1, (io, ip) = (1,1) (-1,1) (1,-1) (1,1)
+        const int sx1 = px < 2 ? 1 : -1, sy1 = py < 2 ? 1 : -1;
+        const int fxo = px == 1 ? -1 : 1, fxp = px < 2 ? 1 : px == 2 ? 2 : -2, fyo = py == 1 ? -1 : 1, fyp = py < 2 ? 1 : py == 2 ? 2 : -2;
+        const int ixs = px >> 1, ixo = px == 1 ? -1 : 1, ixp = px == 2 ? -1 : 1, iys = py >> 1, iyo = py == 1 ? -1 : 1, iyp = py == 2 ? -1 : 1;
         const int cl4 = (!(fx & 1) && !(fy & 1)) ? 0 : ((fx & 1) && (fy & 1)) ? 1 : 2;
         const int mf4 = cl4 == 0 ? q4.mf[0] : cl4 == 1 ? q4.mf[1] : q4.mf[2], v4 = cl4 == 0 ? q4.v[0] : cl4 == 1 ? q4.v[1] : q4.v[2];
         const int kz4 = (int)((0xFEA9DB83C7426510ull >> (4 * (fy * 4 + fx))) & 15); // raster -> zig-zag position
@@ -377,30 +384,35 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             const int sumL = wave16_sum(q16 >= 1 && q16 <= 4 ? zv : 0), sumT = wave16_sum(q16 >= 6 && q16 <= 9 ? zv : 0);
             const int dc4 = (up && lf) ? (sumT + sumL + 4) >> 3 : lf ? (sumL + 2) >> 2 : up ? (sumT + 2) >> 2 : 128;
             WAVE_SYNC();
+            // one weighted sum serves copy (4,0,0)/4, 2-tap (2,2,0 | +2)/4 and 3-tap (1,2,1 | +2)/4; selects written as
+            // arithmetic on per-lane constants: as ?: chains the compiler turns them into exec-mask branches (~25
+            // instructions each on this dependency chain)
             const int ent = T->i4tab[bmode * 16 + py * 4 + px], j0 = ent & 15, kind = ent >> 4;
             const int za = zb[j0], zc = zb[j0 + 1], zd = zb[j0 + 2];
-            const int bpred = kind == 0 ? za : kind == 1 ? (za + zc + 1) >> 1 : kind == 2 ? (za + 2 * zc + zd + 2) >> 2 : dc4;
+            const int w0 = 4 >> kind, w1 = kind ? 2 : 0, w2 = kind >> 1;
+            const int bdir = mad24(za, w0, mad24(zc, w1, mad24(zd, w2, w1))) >> 2;
+            const int bpred = kind == 3 ? dc4 : bdir;
             // residual -> 4x4 core transform (8.5.12's forward counterpart): rows, then columns
             const int res = sv - bpred;
             int pr = quad_xor<3>(res);
-            int tr = px < 2 ? res + pr : pr - res;          // e0 e1 e2 e3
+            int tr = mad24(res, sx1, pr);                                  // e0 e1 e2 e3
             pr = quad_xor<1>(tr);
-            tr = px == 0 ? tr + pr : px == 1 ? pr - tr : px == 2 ? tr + 2 * pr : tr - 2 * pr; // f0 f2 f1 f3
+            tr = mad24(tr, fxo, __mul24(pr, fxp));                        // f0 f2 f1 f3
             pr = row_xor12(tr);
-            int tc = py < 2 ? tr + pr : pr - tr;
+            int tc = mad24(tr, sy1, pr);
             pr = row_xor4(tc);
-            const int coef = py == 0 ? tc + pr : py == 1 ? pr - tc : py == 2 ? tc + 2 * pr : tc - 2 * pr;
+            const int coef = mad24(tc, fyo, __mul24(pr, fyp));
             const int lv4 = quant1(coef, mf4, q4.f, q4.qbits);
             // 8.5.12: scale, inverse transform (rows then columns), round
             const int dq = (lv4 * v4) << q4.shift;
             pr = quad_xor<1>(dq);
-            tr = px == 0 ? dq + pr : px == 1 ? pr - dq : px == 2 ? (dq >> 1) - pr : pr + (dq >> 1);  // e0 e1 e2 e3
+            tr = mad24(dq >> ixs, ixo, __mul24(pr, ixp));                 // e0 e1 e2 e3
             pr = quad_xor<3>(tr);
-            tr = px < 2 ? tr + pr : pr - tr;                // natural order again
+            tr = mad24(tr, sx1, pr);                                      // natural order again
             pr = row_xor4(tr);
-            tc = py == 0 ? tr + pr : py == 1 ? pr - tr : py == 2 ? (tr >> 1) - pr : pr + (tr >> 1);
+            tc = mad24(tr >> iys, iyo, __mul24(pr, iyp));
             pr = row_xor12(tc);
-            const int rr = py < 2 ? tc + pr : pr - tc;
+            const int rr = mad24(tc, sy1, pr);
             const int recp = clip255(bpred + ((rr + 32) >> 6));
             const unsigned long long bal = __ballot(valid && lv4 != 0);
             const int b0 = ((by_lo >> 1) << 3) | (((s4 - 2 * by_lo) >> 1) << 2) | ((by_lo & 1) << 1) | ((s4 - 2 * by_lo) & 1);
