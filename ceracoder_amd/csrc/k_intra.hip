@@ -283,7 +283,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
                        const uint4 dec0, const uint2 dec1, const uint2 *presrc = nullptr) { // presrc: this lane's source rows, loaded ahead (luma: .x of 4; chroma: 4 pairs)
     int (*top)[17] = L->top;
     int (*left)[17] = L->left;
-    int *sh_dc = L->dc, *sh_ldc = L->ldc, *sh_mode4 = L->mode4;
+    int *sh_mode4 = L->mode4;
     uint8_t *T4 = L->T4, *S4 = L->S4;
     const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
     const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
@@ -460,36 +460,34 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = src[k] - pred[k];
         fdct4(x);
-        sh_dc[(by >> 2) * 4 + (bx >> 2)] = x[0];
+        const int dc0 = x[0];
         bool nz = quant_dequant<1>(x, lev, q);
         store_levels(ctx->levels + (size_t)mbn * MB_LEVELS + L_LUMA + b * 16, lev);
         flags = nz ? 1 : 0;
-        WAVE_SYNC();
-        // lane p = raster position (i,j): hd = (M X M^T + 1) >> 1, M = [[1,1,1,1],[1,1,-1,-1],[1,-1,-1,1],[1,-1,1,-1]]
-        const int pi = lane >> 2, pj = lane & 3;
-        const int Mi[4] = {1, pi < 2 ? 1 : -1, (pi == 0 || pi == 3) ? 1 : -1, (pi & 1) ? -1 : 1};
-        const int Mj[4] = {1, pj < 2 ? 1 : -1, (pj == 0 || pj == 3) ? 1 : -1, (pj & 1) ? -1 : 1};
-        int acc = 0;
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int c2 = 0; c2 < 4; c2++) acc += Mi[a] * Mj[c2] * sh_dc[a * 4 + c2];
-        const int hd = (acc + 1) >> 1;
+        // 4x4 Hadamard of the 16 DC terms (8.5.10's forward counterpart) as four DPP butterfly stages over the blkIdx lanes:
+        // lane bits 0/2 carry the block column X, bits 1/3 the block row Y.  The butterflies produce the natural-ordered
+        // transform (H2 x H2 per dimension); with M = rows (++++, ++--, +--+, +-+-) of the standard, natural index k holds
+        // M-frequency G[k], G = 0 3 1 2 -- so this lane's coefficient belongs at raster position (G[Y], G[X]).  M is
+        // symmetric: the same four stages applied to the quantised levels in place return this lane's own block's term.
+        const int X = ((lane >> 1) & 2) | (lane & 1), Y = ((lane >> 2) & 2) | ((lane >> 1) & 1);
+        const int s0 = (lane & 1) ? -1 : 1, s1 = (lane & 2) ? -1 : 1, s2 = (lane & 4) ? -1 : 1, s3 = (lane & 8) ? -1 : 1;
+        int hv = dc0;
+        hv = mad24(hv, s0, quad_xor<1>(hv));
+        hv = mad24(hv, s1, quad_xor<2>(hv));
+        hv = mad24(hv, s2, row_xor4(hv));
+        hv = mad24(hv, s3, row_xor8(hv));
+        const int hd = (hv + 1) >> 1;
         const int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
-        sh_ldc[lane] = ldc;
-        const int kz = (int)((0xFEA9DB83C7426510ull >> (4 * lane)) & 15); // zig-zag position of raster index `lane` (inverse of zz)
+        const int gx = (0x2130 >> (4 * X)) & 3, gy = (0x2130 >> (4 * Y)) & 3;             // G[X], G[Y]
+        const int kz = (int)((0xFEA9DB83C7426510ull >> (4 * (gy * 4 + gx))) & 15);       // zig-zag position of that raster index
         stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + kz], ldc);
         if (ldc) flags |= 2;
-        WAVE_SYNC();
-        { // inverse for this lane's own block position (by/4, bx/4): f = M c M^T, then 8.5.10 scaling
-            const int bi = by >> 2, bj = bx >> 2;
-            const int Ni[4] = {1, bi < 2 ? 1 : -1, (bi == 0 || bi == 3) ? 1 : -1, (bi & 1) ? -1 : 1};
-            const int Nj[4] = {1, bj < 2 ? 1 : -1, (bj == 0 || bj == 3) ? 1 : -1, (bj & 1) ? -1 : 1};
-            int f = 0;
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int c2 = 0; c2 < 4; c2++) f += Ni[a] * Nj[c2] * sh_ldc[a * 4 + c2];
+        {
+            int f = ldc;
+            f = mad24(f, s0, quad_xor<1>(f));
+            f = mad24(f, s1, quad_xor<2>(f));
+            f = mad24(f, s2, row_xor4(f));
+            f = mad24(f, s3, row_xor8(f));
             const int ls = 16 * q.v[0];
             x[0] = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
         }
@@ -607,7 +605,7 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
 // the bottom row of a macroblock travels to the row below through a 4-deep LDS ring, its right column stays in the row's
 // own LDS for the next step.  Between bands the bottom rows of the last row are stored with `sc1` and announced through a
 // progress counter, exactly like the deblocking bands; the first row of a band prefetches them one step ahead.
-#define IB_ROWS 4
+#define IB_ROWS 2
 struct ib_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; };
 
 __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {

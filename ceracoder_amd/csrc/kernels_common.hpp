@@ -222,6 +222,7 @@ DEV int mad24(int a, int b, int c) { return __mul24(a, b) + c; } // v_mad_i32_i2
 // (lane ^ 7) or the row mirror (lane ^ 15)
 DEV int row_xor4(int v) { return __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xF, 0xF, false), 0x141, 0xF, 0xF, false); }
 DEV int row_xor12(int v) { return __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xF, 0xF, false), 0x140, 0xF, 0xF, false); }
+DEV int row_xor8(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); } // row_ror:8 == lane ^ 8 within the row
 template <int K> DEV int quad_xor(int v) { return __builtin_amdgcn_update_dpp(0, v, K == 1 ? 0xB1 : K == 2 ? 0x4E : 0x1B, 0xF, 0xF, false); }
 // pred[16]: prediction of this lane's 4x4 block.  Handles the 2x2 DC Hadamard across the four
 // lanes of a plane with shuffles (8.5.11), writes levels + reconstruction, returns the AC flag
