@@ -258,8 +258,11 @@ DEV void edge_luma2(const edge_par &P, int p3, int &p2, int &p1, int &p0, int &q
     if (MBEDGE && any4) { // bS 4 exists only on macroblock edges, and only if some lane of the wave is intra
         const bool s4 = bS == 4, small = d < ((alpha >> 2) + 2);
         const bool sp = ap & small, sq = aq & small;
-        const int sp0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
-        const int sq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+        // both arms of every select are named values computed up front: written inside the ?: they stay a branch diamond
+        // (exec-mask save/restore around a few instructions) on the dependency chain
+        const int sp0a = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, sp0b = (2 * p1 + p0 + q1 + 2) >> 2;
+        const int sq0a = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, sq0b = (2 * q1 + q0 + p1 + 2) >> 2;
+        const int sp0 = sp ? sp0a : sp0b, sq0 = sq ? sq0a : sq0b;
         const int sp1 = (p2 + p1 + p0 + q0 + 2) >> 2, sp2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
         const int sq1 = (p0 + q0 + q1 + q2 + 2) >> 2, sq2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
         np0 = s4 ? sp0 : np0; nq0 = s4 ? sq0 : nq0; np1 = s4 ? sp1 : np1; nq1 = s4 ? sq1 : nq1;
@@ -275,8 +278,8 @@ DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int b
     const int tc = (int)((P.tc0 >> (8 * ((bS - 1) & 3))) & 0xFF) + 1;
     const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
     const bool s4 = bS == 4;
-    const int np0 = s4 ? (2 * p1 + p0 + q1 + 2) >> 2 : clip255(p0 + dl);
-    const int nq0 = s4 ? (2 * q1 + q0 + p1 + 2) >> 2 : clip255(q0 - dl);
+    const int sp0 = (2 * p1 + p0 + q1 + 2) >> 2, sq0 = (2 * q1 + q0 + p1 + 2) >> 2, wp0 = clip255(p0 + dl), wq0 = clip255(q0 - dl);
+    const int np0 = s4 ? sp0 : wp0, nq0 = s4 ? sq0 : wq0; // named arms: see edge_luma2
     p0 = f ? np0 : p0; q0 = f ? nq0 : q0;
 }
 
