@@ -152,13 +152,28 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
 #define SP_GS 24 /* G row stride (23 used) */
 #define SP_PS 20 /* plane row stride (18/19 used) */
 struct sp_lds {
-    uint8_t G[23 * SP_GS];     // rows iy-3 .. iy+19, cols ix-3 .. ix+19
-    int16_t B1[23 * 18];       // unrounded horizontal half samples: rows iy-3 .. iy+19, cols ix-1 .. ix+16
+    uint8_t G[23 * SP_GS];     // rows iy-3 .. iy+19, cols ix-3 .. ix+19 (+1 spare: a row is 6 dwords)
+    int16_t H1[18 * SP_GS];    // unrounded vertical half samples at every G column: rows iy-1 .. iy+16 (taps G rows r .. r+5)
     uint8_t b[19 * SP_PS];     // rows iy-1 .. iy+17, cols ix-1 .. ix+16
-    uint8_t h[18 * SP_PS];     // rows iy-1 .. iy+16, cols ix-1 .. ix+17
+    uint8_t h[18 * SP_GS];     // rows iy-1 .. iy+16, indexed by G column (ix-1 is column 2): dword stores stay aligned
     uint8_t j[18 * SP_PS];     // rows iy-1 .. iy+16, cols ix-1 .. ix+16
     uint8_t pad[16];           // lds4() may read one word past the last sample of a plane
 };
+typedef short sp_s2 __attribute__((ext_vector_type(2)));
+DEV sp_s2 as_s2(unsigned v) { return __builtin_bit_cast(sp_s2, v); }
+DEV unsigned as_u(sp_s2 v) { return __builtin_bit_cast(unsigned, v); }
+// bytes 0,1 / 2,3 of a word as two 16-bit lanes (v_perm_b32; selector 0x0c = constant zero)
+DEV sp_s2 bytes_lo(unsigned w) { return as_s2(__builtin_amdgcn_perm(0u, w, 0x0c010c00u)); }
+DEV sp_s2 bytes_hi(unsigned w) { return as_s2(__builtin_amdgcn_perm(0u, w, 0x0c030c02u)); }
+DEV sp_s2 clip255_s2(sp_s2 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, (sp_s2)(0)), (sp_s2)(255)); }
+// the low bytes of the four 16-bit lanes of (lo, hi) as one word
+// four samples (already shifted, not yet clipped; each fits 16 bits) -> clipped bytes of one word, through the packed 16-bit
+// forms.  Not `clip255(a >> n) | clip255(b >> n) << 8 | ...` on 32-bit values: for that hipcc (ROCm 7.2) selects gfx950's
+// v_ashr_pk_u8_i32 for the first pair and ORs the other two into bits 31:16 of its result, which the instruction does not
+// clear on this hardware (tools/ubench_planes.hip shows samples 2 and 3 of every word wrong).
+DEV sp_s2 pair_s2(int a, int b) { return as_s2(__builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x05040100u)); }
+DEV unsigned pack_s2(sp_s2 lo, sp_s2 hi) { return __builtin_amdgcn_perm(as_u(hi), as_u(lo), 0x06040200u); }
+DEV unsigned clip_pack4(int a, int b, int c, int d) { return pack_s2(clip255_s2(pair_s2(a, b)), clip255_s2(pair_s2(c, d))); }
 DEV int mvq_bits(int q) { // bits of se(q)
     unsigned k = q > 0 ? (unsigned)(2 * q - 1) : (unsigned)(-2 * q);
     return 2 * (31 - __clz((int)(k + 1))) + 1;
@@ -173,7 +188,7 @@ DEV unsigned lds4(const uint8_t *plane, int o) {
 DEV unsigned sp_sample4(const sp_lds *L, int X, int Y, int fx, int fy) {
 #define SG(x, y) lds4(L->G, ((y) + 2) * SP_GS + (x) + 2)
 #define SB(x, y) lds4(L->b, (y) * SP_PS + (x))
-#define SH(x, y) lds4(L->h, (y) * SP_PS + (x))
+#define SH(x, y) lds4(L->h, (y) * SP_GS + (x) + 2)
 #define SJ(x, y) lds4(L->j, (y) * SP_PS + (x))
     if (fy == 0) {
         if (fx == 0) return SG(X, Y);
@@ -188,6 +203,68 @@ DEV unsigned sp_sample4(const sp_lds *L, int X, int Y, int fx, int fy) {
 #undef SB
 #undef SH
 #undef SJ
+}
+// G (filled, visible to the wave) -> H1, h, b, j
+DEV void sp_planes(sp_lds *L, const int lane) {
+    // ---- the three half-sample planes (8.4.2.2.1), four samples per lane and pass:
+    //  * vertical 6-tap as packed 16-bit arithmetic on whole words of G (a lane owns one word column and two output rows,
+    //    sliding over 7 input rows): unrounded H1 at every G column, rounded h;
+    //  * horizontal 6-tap as two v_dot4_i32_i8 per sample: samples are biased to signed bytes (x ^ 0x80), the taps
+    //    (1,-5,20,20 | -5,1,0,0) are byte constants and the bias returns as 128 * 32 in the accumulator: rounded b;
+    //  * centre samples j = horizontal 6-tap over H1 (the standard allows either order), three v_dot2_i32_i16 per sample.
+    if (lane < 54) {
+        const int d = lane % 6, seg = lane / 6;
+        sp_s2 lo[7], hi[7];
+#pragma unroll
+        for (int r = 0; r < 7; r++) {
+            const unsigned w = *(const unsigned *)&L->G[(2 * seg + r) * SP_GS + 4 * d];
+            lo[r] = bytes_lo(w); hi[r] = bytes_hi(w);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const sp_s2 vl = (lo[t + 2] + lo[t + 3]) * (sp_s2)(20) - (lo[t + 1] + lo[t + 4]) * (sp_s2)(5) + (lo[t] + lo[t + 5]);
+            const sp_s2 vh = (hi[t + 2] + hi[t + 3]) * (sp_s2)(20) - (hi[t + 1] + hi[t + 4]) * (sp_s2)(5) + (hi[t] + hi[t + 5]);
+            const int R = 2 * seg + t;
+            unsigned *o = (unsigned *)&L->H1[R * SP_GS + 4 * d];
+            o[0] = as_u(vl); o[1] = as_u(vh);
+            *(unsigned *)&L->h[R * SP_GS + 4 * d] = pack_s2(clip255_s2((vl + (sp_s2)(16)) >> (sp_s2)(5)), clip255_s2((vh + (sp_s2)(16)) >> (sp_s2)(5)));
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int i = lane + 64 * it;
+        if (i < 19 * 5) {
+            const int R = i / 5, g = i - R * 5;
+            const unsigned *gw = (const unsigned *)&L->G[(R + 2) * SP_GS + 4 * g];
+            const unsigned d0 = gw[0] ^ 0x80808080u, d1 = gw[1] ^ 0x80808080u, d2 = gw[2] ^ 0x80808080u; // g == 4 reads into the next row: unused samples only
+            int o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned w0 = k ? __builtin_amdgcn_alignbyte(d1, d0, (unsigned)k) : d0, w1 = k ? __builtin_amdgcn_alignbyte(d2, d1, (unsigned)k) : d1;
+                const int v = __builtin_amdgcn_sdot4((int)w0, 0x1414FB01, __builtin_amdgcn_sdot4((int)w1, 0x000001FB, 4096, false), false);
+                o[k] = (v + 16) >> 5;
+            }
+            *(unsigned *)&L->b[R * SP_PS + 4 * g] = clip_pack4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int i = lane + 64 * it;
+        if (i < 18 * 5) {
+            const int R = i / 5, g = i - R * 5;
+            const unsigned *hw = (const unsigned *)&L->H1[R * SP_GS + 4 * g]; // pairs (4g + 2m, 4g + 2m + 1)
+            const unsigned p0 = hw[0], p1 = hw[1], p2 = hw[2], p3 = hw[3], p4 = hw[4];
+            const unsigned q0 = __builtin_amdgcn_alignbyte(p1, p0, 2u), q1 = __builtin_amdgcn_alignbyte(p2, p1, 2u),
+                           q2 = __builtin_amdgcn_alignbyte(p3, p2, 2u), q3 = __builtin_amdgcn_alignbyte(p4, p3, 2u);
+            const sp_s2 ca = {1, -5}, cb = {20, 20}, cc = {-5, 1};
+#define J3(a, b, c) __builtin_amdgcn_sdot2(as_s2(a), ca, __builtin_amdgcn_sdot2(as_s2(b), cb, __builtin_amdgcn_sdot2(as_s2(c), cc, 512, false), false), false)
+            const int v0 = J3(p0, p1, p2), v1 = J3(q0, q1, q2), v2 = J3(p1, p2, p3), v3 = J3(q1, q2, q3);
+#undef J3
+            *(unsigned *)&L->j[R * SP_PS + 4 * g] = clip_pack4(v0 >> 10, v1 >> 10, v2 >> 10, v3 >> 10);
+        }
+    }
+    WAVE_SYNC();
 }
 __global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t cv, int mb0, int mb1) {
     const frame_ctx_t *__restrict__ ctx = &cv;
@@ -227,30 +304,7 @@ __global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t cv, int m
         curw = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + x0 + pc);
     }
     WAVE_SYNC();
-    // ---- horizontal half samples (unrounded B1, rounded b)
-    for (int i = lane; i < 23 * 18; i += 64) {
-        int r = i / 18, c = i - r * 18; // position x = ix-1+c -> G column c+2; taps at G columns c .. c+5
-        const uint8_t *g = &L->G[r * SP_GS + c];
-        int v = tap6(g[0], g[1], g[2], g[3], g[4], g[5]);
-        L->B1[r * 18 + c] = (int16_t)v;
-        if (r >= 2 && r < 21) L->b[(r - 2) * SP_PS + c] = (uint8_t)clip255((v + 16) >> 5);
-    }
-    // ---- vertical half samples h: rows iy-1 .. iy+16 (G rows 2..19), cols ix-1 .. ix+17 (G cols 2..20)
-    for (int i = lane; i < 18 * 19; i += 64) {
-        int r = i / 19, c = i - r * 19;
-        const uint8_t *g = &L->G[r * SP_GS + c + 2]; // taps at G rows r .. r+5
-        int v = tap6(g[0], g[SP_GS], g[2 * SP_GS], g[3 * SP_GS], g[4 * SP_GS], g[5 * SP_GS]);
-        L->h[r * SP_PS + c] = (uint8_t)clip255((v + 16) >> 5);
-    }
-    WAVE_SYNC();
-    // ---- centre samples j: vertical 6-tap over B1
-    for (int i = lane; i < 18 * 18; i += 64) {
-        int r = i / 18, c = i - r * 18;
-        const int16_t *q = &L->B1[r * 18 + c];
-        int v = tap6(q[0], q[18], q[36], q[54], q[72], q[90]);
-        L->j[r * SP_PS + c] = (uint8_t)clip255((v + 512) >> 10);
-    }
-    WAVE_SYNC();
+    sp_planes(L, lane);
     // ---- two refinement rounds (half, then quarter).  The 8 candidates of a round are scored together: per lane one
     // v_sad_u8 over its 4 pixels each, two 16-bit partial sums per register (64 lanes x 1020 < 65536), one wave reduction
     // for all of them; then the candidates are compared in scan order with a strict `<`, as the oracle does.

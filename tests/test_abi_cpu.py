@@ -213,3 +213,19 @@ def test_rate_control_emergency_drop_lands_within_a_few_pictures(delay):
     assert all(s < 1.5 * per_frame for s in sizes[drop_at + 3 + delay:drop_at + 20]), sizes[drop_at:drop_at + 8]
     # ... and the half second after the drop carries no more than 1.3x the new rate
     assert sum(sizes[drop_at + 2:drop_at + 32]) * 8 * fps / 30 < 1.3 * 500_000
+
+
+def test_device_code_avoids_miscompiled_pack_instruction(tmp_path):
+    """hipcc (ROCm 7.2) selects gfx950's v_ashr_pk_u8_i32 for `clip255(a >> n) | clip255(b >> n) << 8` and then ORs further
+    bytes into bits 31:16 of its result, which the instruction does not clear on MI355X (found with
+    tools/ubench_planes.hip: samples 2 and 3 of every packed word wrong).  The kernels route such packs through packed
+    16-bit forms (k_motion.hip, clip_pack4); this keeps the instruction from creeping back in."""
+    import subprocess
+    src = os.path.join(ROOT, "ceracoder_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if not f.endswith(".hip"):
+            continue
+        out = str(tmp_path / (f + ".s"))
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                        "-I" + os.path.join(ROOT, "include"), "-o", out, os.path.join(src, f)], check=True, capture_output=True)
+        assert "v_ashr_pk_u8_i32" not in open(out).read(), f
