@@ -342,7 +342,9 @@ DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *ld
         }
         D3_TICK(0);
         // ---- B. vertical edges.  All LDS reads of the phase are issued together (one round trip).
-        const unsigned bvl = act ? recw[0] : 0u, bvh = act ? recw[1] : 0u, bhl = act ? recw[2] : 0u, bhh = act ? recw[3] : 0u;
+        const uint2 bsv = *(const uint2 *)recw, bsh = *(const uint2 *)(recw + 2); // read unconditionally, masked afterwards: no exec toggling per word
+        const unsigned am = act ? ~0u : 0u;
+        const unsigned bvl = bsv.x & am, bvh = bsv.y & am, bhl = bsh.x & am, bhh = bsh.y & am;
         constexpr int o = CHROMA ? 10 : 4;
         const edge_par PL = par_of(recw[o], recw[o + 1]), PT = par_of(recw[o + 2], recw[o + 3]), PI = par_of(recw[o + 4], recw[o + 5]);
         if (!CHROMA) {
