@@ -276,16 +276,20 @@ def main():
         ALG = {"me_kernel": 2.03125, "subpel_kernel": 2.125, "inter_kernel": 7.5625, "intra (analyse + x+y wavefront)": 6.0625,
                "deblock (prep + band16 kernel)": 3.0625}
         db_p = (st.ms_deblock - st.ms_deblock_idr, st.n_deblock - st.n_deblock_idr) if st.n_deblock > st.n_deblock_idr else (st.ms_deblock, st.n_deblock)
-        per = {"me_kernel": (st.ms_me, st.n_me), "subpel_kernel": (st.ms_subpel, st.n_me), "inter_kernel": (st.ms_inter, st.n_inter),
+        FUSED = "pmb_kernel (refinement + prediction + residual, fused)"
+        fused = not args.dct8x8  # the 8x8-transform path keeps subpel_kernel + inter_kernel
+        ALG[FUSED] = 7.5625      # the inter stage's bytes; the refinement re-reads the same reference window from LDS
+        per = {"me_kernel": (st.ms_me, st.n_me), "subpel_kernel": (st.ms_subpel, 0 if fused else st.n_me), ("inter_kernel" if not fused else FUSED): (st.ms_inter, st.n_inter),
                "intra (analyse + x+y wavefront)": (st.ms_intra, st.n_intra), "deblock (prep + band16 kernel)": db_p}
         bound = {"me_kernel": "VALU SAD issue rate (~142 T abs-diff/s chip-wide, tools/ubench_sad.hip): 1089*P abs-diffs -> >=17.6 us @1080p",
                  "subpel_kernel": "LDS-staged 6-tap planes, latency/LDS", "inter_kernel": "launch + byte stores of interleaved chroma",
+                 FUSED: "VALU issue: one wave per macroblock, ~1000 instructions (6-tap planes, 16 candidates, transforms on all 64 lanes)",
                  "intra (analyse + x+y wavefront)": "dependency chain: mbw+mbh-1 dependent launches (hipGraph)",
                  "deblock (prep + band16 kernel)": "dependency chain of the normative filter order: ~mbw+mbh dependent steps of ~1.5 us inside one persistent launch"}
         pmc_name = {"me_kernel": "me_kernel", "deblock (prep + band16 kernel)": "deblock_band16_kernel"}
         kernels = []
         n_idr, n_p = int(st.idr_frames), int(st.frames - st.idr_frames)
-        weight = {"me_kernel": n_p, "subpel_kernel": n_p, "inter_kernel": n_p, "intra (analyse + x+y wavefront)": n_idr,
+        weight = {"me_kernel": n_p, "subpel_kernel": n_p, "inter_kernel": n_p, FUSED: n_p, "intra (analyse + x+y wavefront)": n_idr,
                   "deblock (prep + band16 kernel)": n_idr + n_p}  # pictures of the timed region each kernel ran in (timers are sampled)
         db_i_avg = st.ms_deblock_idr / st.n_deblock_idr if st.n_deblock_idr else 0.0
         if n_p and st.n_deblock_idr:  # deblocking of P pictures is the roofline entry; IDR pictures are added to the total separately
@@ -321,7 +325,7 @@ def main():
                        "pipeline_depth": args.depth, "dct8x8": bool(args.dct8x8), "cavlc_threads": int(st.cavlc_threads)},
             "roofline": roof,
             "roofline_kernels": kernels,
-            "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "inter": round(st.ms_inter / max(1, st.n_inter), 4),
+            "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), ("refine_inter_fused" if fused else "inter"): round(st.ms_inter / max(1, st.n_inter), 4),
                                      "subpel": round(st.ms_subpel / max(1, st.n_me), 4),
                                      "intra_wavefront": round(st.ms_intra / max(1, st.n_intra), 4),
                                      "deblock_wavefront": round(db_p[0] / max(1, db_p[1]), 4), "deblock_wavefront_idr": round(db_i_avg, 4),

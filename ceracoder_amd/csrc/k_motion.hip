@@ -347,6 +347,247 @@ __global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t cv, int m
     }
 }
 
+// =================================================================== P macroblocks, fused: refinement + prediction + residual
+// One wave = one macroblock (the shape of subpel_kernel, whose first half this repeats): after the refinement the
+// half-sample planes are still in LDS, so the luma prediction of the winning vector is one sp_sample4() per lane -- the
+// lane's four pixels of row lane>>2 -- instead of inter_kernel's 81 byte loads and per-pixel case analysis per 4x4 block.
+// From there a 4x4 block lives on the four lanes that hold its rows (lane bits 3:2 = row in block, 1:0 = block column,
+// 5:4 = block row): the row transforms are in-lane, the column transforms two-stage DPP butterflies inside the 16-lane row
+// (as in the Intra4x4 path: coefficients stay in the lane order 0 2 1 3 and are addressed by frequency), so all 64 lanes
+// carry luma; chroma runs on 32 lanes in the same layout (16-lane row = the four blocks Cb0 Cb1 Cr0 Cr1 of one block row),
+// reads the reference and the source as words, and the Cb lanes store interleaved 8-byte row segments after fetching
+// their Cr partners' samples with one DPP move.  Used for every P picture without the 8x8 transform; the separate
+// subpel_kernel / inter_kernel remain for the High-profile path and the single-stage entry points.
+DEV void fwd_rows4(int *r) { // 4-point forward core transform, in place
+    const int e0 = r[0] + r[3], e1 = r[1] + r[2], e2 = r[1] - r[2], e3 = r[0] - r[3];
+    r[0] = e0 + e1; r[1] = 2 * e3 + e2; r[2] = e0 - e1; r[3] = e3 - 2 * e2;
+}
+DEV void inv_rows4(int *d) { // 8.5.12.2, one row
+    const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
+    d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
+}
+struct col_bf { int s1, fo, fp, is, io, ip; }; // per-lane butterfly coefficients of the column direction (see k_intra.hip, Intra_4x4)
+DEV col_bf make_col_bf(int py) {
+    col_bf c;
+    c.s1 = py < 2 ? 1 : -1; c.fo = py == 1 ? -1 : 1; c.fp = py < 2 ? 1 : py == 2 ? 2 : -2;
+    c.is = py >> 1; c.io = py == 1 ? -1 : 1; c.ip = py == 2 ? -1 : 1;
+    return c;
+}
+DEV int fwd_col(int v, const col_bf &c) { // rows of the block are 4 lanes apart; result: frequency F[py], F = 0 2 1 3
+    int t = mad24(v, c.s1, row_xor12(v));
+    return mad24(t, c.fo, __mul24(row_xor4(t), c.fp));
+}
+DEV int inv_col(int v, const col_bf &c) { // takes frequency order F[py], returns row py
+    int t = mad24(v >> c.is, c.io, __mul24(row_xor4(v), c.ip));
+    return mad24(t, c.s1, row_xor12(t));
+}
+__global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    __shared__ __attribute__((aligned(16))) sp_lds LD[4];
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = ctx->qp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int mbn = mb0 + blockIdx.x * 4 + wave; // the launch covers macroblocks mb0 .. mb1-1
+    const bool ok = mbn < mb1;             // wave-uniform
+    if (!ok) mbn = mb1 - 1;
+    const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
+    sp_lds *L = &LD[wave];
+    const mb_info_t info = ld_mbinfo(&ctx->mbi[mbn]);
+    const int ix = x0 + (info.mvx >> 2), iy = y0 + (info.mvy >> 2); // integer winner (vector is a multiple of 4 here)
+    const uint8_t *__restrict__ ref = ctx->ref_y;
+    if (ix - 3 >= 0 && iy - 3 >= 0 && ((ix - 3) & ~3) + 28 <= W && iy + 19 < H) {
+        const int a = (ix - 3) & 3;
+        const uint8_t *base = ref + (size_t)(iy - 3) * stride + ((ix - 3) & ~3);
+        for (int i = lane; i < 23 * 6; i += 64) {
+            const int r = i / 6, d = i - r * 6;
+            const unsigned w0 = ldg32(base + (size_t)r * stride + 4 * d), w1 = ldg32(base + (size_t)r * stride + 4 * d + 4);
+            *(unsigned *)&L->G[r * SP_GS + 4 * d] = __builtin_amdgcn_alignbyte(w1, w0, (unsigned)a);
+        }
+    } else
+        for (int i = lane; i < 23 * 23; i += 64) {
+            int r = i / 23, c = i - r * 23;
+            int yy = clip3(0, H - 1, iy - 3 + r), xx = clip3(0, W - 1, ix - 3 + c);
+            L->G[r * SP_GS + c] = (uint8_t)ldg8(ref + (size_t)yy * stride + xx);
+        }
+    const int pr = lane >> 2, pc = (lane & 3) * 4; // luma: lane owns row pr, columns pc .. pc+3
+    unsigned curw;
+    {
+        int sy = y0 + pr;
+        sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
+        curw = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + x0 + pc);
+    }
+    WAVE_SYNC();
+    int bqx = info.mvx, bqy = info.mvy;
+    unsigned best = info.cost;
+    if (refine) { // ---- as subpel_kernel
+        sp_planes(L, lane);
+        const int lambda = ctx->lambda;
+#pragma unroll 1
+        for (int step = 2; step >= 1; step--) {
+            const int cqx = bqx, cqy = bqy;
+            unsigned acc[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int c8 = 0; c8 < 8; c8++) {
+                const int k = c8 < 4 ? c8 : c8 + 1;
+                const int qx = cqx + (k % 3 - 1) * step, qy = cqy + (k / 3 - 1) * step;
+                const int ox = qx - info.mvx, oy = qy - info.mvy;
+                const unsigned sad = __builtin_amdgcn_sad_u8(curw, sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3), 0u);
+                acc[c8 >> 1] |= sad << (16 * (c8 & 1));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int v = wave16_sum((int)acc[q]);
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                acc[q] = (unsigned)v;
+            }
+#pragma unroll
+            for (int c8 = 0; c8 < 8; c8++) {
+                const int k = c8 < 4 ? c8 : c8 + 1;
+                const int qx = cqx + (k % 3 - 1) * step, qy = cqy + (k / 3 - 1) * step;
+                const unsigned sad = (acc[c8 >> 1] >> (16 * (c8 & 1))) & 0xFFFFu;
+                const unsigned cost = sad + (unsigned)(lambda * (mvq_bits(qx) + mvq_bits(qy)));
+                if (cost < best) { best = cost; bqx = qx; bqy = qy; }
+            }
+        }
+    }
+    const dev_tables *T = &g_tab;
+    const int py = (lane >> 2) & 3, fy = ((py & 1) << 1) | (py >> 1);
+    const col_bf cb = make_col_bf(py);
+    const int kz0 = (int)((0xFEA9DB83C7426510ull >> (16 * fy)) & 0xFFFF); // zig-zag positions of raster 4 fy + 0 .. 3, a nibble each
+    int16_t *lv = ctx->levels + (size_t)mbn * MB_LEVELS;
+    unsigned nz_luma = 0;
+    { // ---- luma: prediction of the final vector, residual, transform, quantisation, reconstruction
+        const int ox = bqx - info.mvx, oy = bqy - info.mvy;
+        const unsigned pw = sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3);
+        const qparams q = make_q(T, qp, false);
+        const int mfe = py < 2 ? q.mf[0] : q.mf[2], mfo = py < 2 ? q.mf[2] : q.mf[1], ve = py < 2 ? q.v[0] : q.v[2], vo = py < 2 ? q.v[2] : q.v[1];
+        int x[4], lev[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = byte_of(curw, i) - byte_of(pw, i);
+        fwd_rows4(x);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int cf = fwd_col(x[i], cb);
+            lev[i] = quant1(cf, (i & 1) ? mfo : mfe, q.f, q.qbits);
+            x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
+        }
+        const int bx = lane & 3, by = lane >> 4, b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1);
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) stg16(&lv[L_LUMA + b * 16 + ((kz0 >> (4 * i)) & 15)], lev[i]);
+        }
+        inv_rows4(x);
+        int o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = clip255(byte_of(pw, i) + ((inv_col(x[i], cb) + 32) >> 6));
+        if (ok) stg32(ctx->rec_y + (size_t)(y0 + pr) * stride + x0 + pc, pack4(o[0], o[1], o[2], o[3]));
+        // non-zero blocks: OR over the block's four lanes, then into luma4x4BlkIdx order
+        const unsigned long long bal = __ballot((lev[0] | lev[1] | lev[2] | lev[3]) != 0);
+        const unsigned long long t = bal | (bal >> 4) | (bal >> 8) | (bal >> 12); // bit 16 by + bx
+        const int rb = lane & 15, rbx = blkx(rb) >> 2, rby = blky(rb) >> 2;
+        nz_luma = (unsigned)(__ballot(lane < 16 && ((t >> (16 * rby + rbx)) & 1)) & 0xFFFFull);
+    }
+    unsigned nz_c = 0, dc_c = 0;
+    { // ---- chroma on lanes 0..31: bit 4 = block row, bits 3:2 = row in block, bit 1 = plane, bit 0 = block column
+        const bool cl = lane < 32;
+        const int cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1;
+        const int cx0 = x0 >> 1, cy0 = y0 >> 1, cw = W >> 1, ch = H >> 1;
+        const int cy = cby * 4 + py, cxb = cbx * 4;
+        // 8.4.1.4 / 8.4.2.2.2: the chroma vector is the luma vector read in 1/8 chroma-sample units
+        const int xi = bqx >> 3, yi = bqy >> 3, xf = bqx & 7, yf = bqy & 7;
+        const uint8_t *__restrict__ rf = ctx->ref_uv;
+        int A[5], B[5];
+        if (cx0 + xi >= 0 && cx0 + xi + 9 <= cw && cy0 + yi >= 0 && cy0 + yi + 9 <= ch) { // whole 9 x 9 neighbourhood inside (wave-uniform)
+            const int o = 2 * (cx0 + cxb + xi) + c, a = o & 3;
+            const uint8_t *r0 = rf + (size_t)(cy0 + cy + yi) * stride + (o & ~3), *r1 = r0 + stride;
+            const unsigned a0 = ldg32(r0), a1 = ldg32(r0 + 4), a2 = ldg32(r0 + 8), b0 = ldg32(r1), b1 = ldg32(r1 + 4), b2 = ldg32(r1 + 8);
+            const unsigned sa0 = __builtin_amdgcn_alignbyte(a1, a0, (unsigned)a), sa1 = __builtin_amdgcn_alignbyte(a2, a1, (unsigned)a);
+            const unsigned sb0 = __builtin_amdgcn_alignbyte(b1, b0, (unsigned)a), sb1 = __builtin_amdgcn_alignbyte(b2, b1, (unsigned)a);
+            A[0] = byte_of(sa0, 0); A[1] = byte_of(sa0, 2); A[2] = byte_of(sa1, 0); A[3] = byte_of(sa1, 2); A[4] = (int)((a2 >> (8 * a)) & 255);
+            B[0] = byte_of(sb0, 0); B[1] = byte_of(sb0, 2); B[2] = byte_of(sb1, 0); B[3] = byte_of(sb1, 2); B[4] = (int)((b2 >> (8 * a)) & 255);
+        } else {
+            const int ya = clip3(0, ch - 1, cy0 + cy + yi), yb = clip3(0, ch - 1, cy0 + cy + yi + 1);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int xx = clip3(0, cw - 1, cx0 + cxb + i + xi);
+                A[i] = (int)ldg8(rf + (size_t)ya * stride + 2 * xx + c);
+                B[i] = (int)ldg8(rf + (size_t)yb * stride + 2 * xx + c);
+            }
+        }
+        int sy = cy0 + cy;
+        const int vh2 = ctx->vis_h >> 1;
+        sy = sy < vh2 ? sy : vh2 - 1;
+        const uint2 sw = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * (cx0 + cxb));
+        const unsigned slo = c ? (sw.x >> 8) : sw.x, shi = c ? (sw.y >> 8) : sw.y;
+        const int sv[4] = {(int)(slo & 255), (int)((slo >> 16) & 255), (int)(shi & 255), (int)((shi >> 16) & 255)};
+        const int w00 = (8 - xf) * (8 - yf), w10 = xf * (8 - yf), w01 = (8 - xf) * yf, w11 = xf * yf;
+        const qparams q = make_q(T, T->qpc[qp], false);
+        const int mfe = py < 2 ? q.mf[0] : q.mf[2], mfo = py < 2 ? q.mf[2] : q.mf[1], ve = py < 2 ? q.v[0] : q.v[2], vo = py < 2 ? q.v[2] : q.v[1];
+        int pd[4], x[4], lev[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            pd[i] = (w00 * A[i] + w10 * A[i + 1] + w01 * B[i] + w11 * B[i + 1] + 32) >> 6;
+            x[i] = sv[i] - pd[i];
+        }
+        fwd_rows4(x);
+        int cf[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) cf[i] = fwd_col(x[i], cb);
+        // 8.5.11: the plane's four DC terms (element 0 of the py == 0 lanes) through the 2x2 Hadamard -- block column is
+        // lane bit 0, block row lane bit 4 -- quantised with doubled rounding, transformed back and scaled
+        const int sbx = cbx ? -1 : 1, sby = cby ? -1 : 1;
+        int hd = mad24(cf[0], sbx, quad_xor<1>(cf[0]));
+        hd = mad24(hd, sby, __shfl_xor(hd, 16, 64));
+        const int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
+        int g = mad24(ldc, sbx, quad_xor<1>(ldc));
+        g = mad24(g, sby, __shfl_xor(g, 16, 64));
+        const int dcc = ((g * 16 * q.v[0]) << q.shift) >> 5;
+        const bool dcl = py == 0; // this lane holds a DC term
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            lev[i] = (i == 0 && dcl) ? 0 : quant1(cf[i], (i & 1) ? mfo : mfe, q.f, q.qbits);
+            x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
+        }
+        if (dcl) x[0] = dcc;
+        const int b = cby * 2 + cbx;
+        if (ok && cl) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) stg16(&lv[L_CAC + (4 * c + b) * 16 + ((kz0 >> (4 * i)) & 15)], lev[i]);
+            if (dcl) stg16(&lv[L_CDC + 4 * c + b], ldc);
+        }
+        inv_rows4(x);
+        int o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = clip255(pd[i] + ((inv_col(x[i], cb) + 32) >> 6));
+        // Cb lanes fetch their Cr partners (lane ^ 2) and store the interleaved 8-byte segment of the row
+        const unsigned mine = pack4(o[0], o[1], o[2], o[3]), other = (unsigned)quad_xor<2>((int)mine);
+        if (ok && cl && c == 0) {
+            uint2 out;
+            out.x = __builtin_amdgcn_perm(other, mine, 0x05010400u); // U0 V0 U1 V1
+            out.y = __builtin_amdgcn_perm(other, mine, 0x07030602u); // U2 V2 U3 V3
+            stg64(ctx->rec_uv + (size_t)(cy0 + cy) * stride + 2 * (cx0 + cxb), out);
+        }
+        const unsigned long long bal = __ballot(cl && (lev[0] | lev[1] | lev[2] | lev[3]) != 0);
+        const unsigned long long t = bal | (bal >> 4) | (bal >> 8) | (bal >> 12); // bit 16 cby + 2 c + cbx
+        // blocks in record order: 4 c + 2 cby + cbx
+        const int k8 = lane & 7, kc = k8 >> 2, kby = (k8 >> 1) & 1, kbx = k8 & 1;
+        nz_c = (unsigned)(__ballot(lane < 8 && ((t >> (16 * kby + 2 * kc + kbx)) & 1)) & 0xFFull);
+        const unsigned long long dcb = __ballot(cl && dcl && ldc != 0);
+        dc_c = ((dcb & 0x00030003ull) ? 1u : 0u) | ((dcb & 0x000C000Cull) ? 2u : 0u); // lanes with c == 0 / c == 1 among py == 0
+    }
+    if (ok && lane == 0) {
+        unsigned nzm = nz_luma | (nz_c << 16);
+        if (dc_c & 1) nzm |= NZ_CBDC;
+        if (dc_c & 2) nzm |= NZ_CRDC;
+        mb_info_t *mb = &ctx->mbi[mbn];
+        stg32(&mb->mvx, ((unsigned)(uint16_t)bqx) | ((unsigned)(uint16_t)bqy << 16));
+        stg32(&mb->cost, best);
+        stg32(&mb->mb_type, 1u | ((unsigned)qp << 24)); // mb_type 1, modes 0, qp
+        stg32(&mb->nzmask, nzm);
+    }
+    if (ok && lane < 2) stg128(lv + L_LDC + 8 * lane, make_uint4(0, 0, 0, 0)); // luma DC levels: unused by P macroblocks, kept zero
+}
+
 // =================================================================== launchers
 // The three P-picture kernels take a macroblock-row range [row0, row1): the host overlaps the upper part of picture n+1
 // with the tail of picture n's deblocking (mi355enc.cpp, enqueue_picture).
@@ -356,4 +597,8 @@ void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStrea
 }
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
     if (row1 > row0) hipLaunchKernelGGL(subpel_kernel, dim3((mbw * (row1 - row0) + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw);
+}
+void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, hipStream_t s) {
+    int n = mbw * (row1 - row0);
+    if (n > 0) hipLaunchKernelGGL(pmb_kernel, dim3((n + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine);
 }

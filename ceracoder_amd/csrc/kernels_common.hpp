@@ -75,6 +75,7 @@ DEV int ldg16(const void *p) { return *(const GAS int16_t *)p; }
 DEV void stg8(void *p, unsigned v) { *(GAS uint8_t *)p = (uint8_t)v; }
 DEV void stg16(void *p, int v) { *(GAS int16_t *)p = (int16_t)v; }
 DEV void stg32(void *p, unsigned v) { *(GAS unsigned *)p = v; }
+DEV void stg64(void *p, uint2 v) { v2u t; t.x = v.x; t.y = v.y; *(GAS v2u *)p = t; }
 DEV void stg128(void *p, uint4 v) { v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(GAS v4u *)p = t; }
 DEV mb_info_t unpack_mbinfo(const uint4 r) {
     mb_info_t m;

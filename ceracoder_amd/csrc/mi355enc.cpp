@@ -50,7 +50,7 @@ struct slot_t {
     hipEvent_t ev_up, ev_all;                  // uploads finished / every device step of a sequentially scheduled picture finished
     hipEvent_t ev_fe[MAX_PIECES], ev_db[MAX_PIECES]; // band-pipelined schedule: piece p's records + reconstruction final / piece p deblocked
     hipEvent_t pv[MAX_PIECES][6];              // stage timers of a sampled pipelined picture (created on first use)
-    int pipelined, prof;
+    int pipelined, prof, fused;
     int is_idr, qp, frame_num, idr_pic_id, rec_index, set;
     int64_t pts;
 };
@@ -426,6 +426,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     const int prof = h->cfg.profile_events > 0 && (idr || h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
     const int np = h->npieces;
     const bool pl = !idr && np >= 2;
+    const bool fused = !h->cfg.transform8x8; // refinement + prediction + residual in one kernel (pmb_kernel); the 8x8-transform path keeps the two-kernel form
     slot_t *prev = h->prev_slot;
     const bool up_ev = uploaded && upload_stream(h) != h->stream;
     if (up_ev) HIPCHK(hipEventRecord(s->ev_up, h->astream));
@@ -444,9 +445,10 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
             if (prof) HIPCHK(hipEventRecord(s->pv[p][0], st));
             k_launch_me(c, h->mbw, r0, r1, st);
             if (prof) HIPCHK(hipEventRecord(s->pv[p][1], st));
-            if (h->cfg.subpel) k_launch_subpel(c, h->mbw, r0, r1, st);
+            if (fused) k_launch_pmb(c, h->mbw, r0, r1, h->cfg.subpel, st);
+            else if (h->cfg.subpel) k_launch_subpel(c, h->mbw, r0, r1, st);
             if (prof) HIPCHK(hipEventRecord(s->pv[p][2], st));
-            k_launch_inter(c, h->mbw, r0, r1, st);
+            if (!fused) k_launch_inter(c, h->mbw, r0, r1, st);
             if (prof) HIPCHK(hipEventRecord(s->pv[p][3], st));
             HIPCHK(hipEventRecord(s->ev_fe[p], st));
             if (h->d_pre_y) {
@@ -476,9 +478,10 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         } else {
             k_launch_me(c, h->mbw, 0, h->mbh, h->stream);
             if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
-            if (h->cfg.subpel) k_launch_subpel(c, h->mbw, 0, h->mbh, h->stream);
+            if (fused) k_launch_pmb(c, h->mbw, 0, h->mbh, h->cfg.subpel, h->stream);
+            else if (h->cfg.subpel) k_launch_subpel(c, h->mbw, 0, h->mbh, h->stream);
             if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
-            k_launch_inter(c, h->mbw, 0, h->mbh, h->stream);
+            if (!fused) k_launch_inter(c, h->mbw, 0, h->mbh, h->stream);
             if (prof) HIPCHK(hipEventRecord(s->ev[11], h->stream));
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
@@ -501,7 +504,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     HIPCHK(hipEventRecord(s->done, h->cstream));
     h->n_submitted++;
     s->is_idr = idr; s->qp = qp; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
-    s->pts = pts; s->rec_index = nxt; s->set = set; s->pipelined = pl ? 1 : 0; s->prof = prof;
+    s->pts = pts; s->rec_index = nxt; s->set = set; s->pipelined = pl ? 1 : 0; s->prof = prof; s->fused = fused && !idr;
     if (idr) h->idr_count++;
     h->frames_since_idr++;
     h->cur = nxt; h->have_ref = 1; h->prev_slot = s;
@@ -616,15 +619,18 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
             for (int p = 0; p < np; p++) HIPCHK(hipEventSynchronize(s->pv[p][5]));
             for (int p = 0; p < np; p++) {
                 (void)hipEventElapsedTime(&t, s->pv[p][0], s->pv[p][1]); a += t;
-                (void)hipEventElapsedTime(&t, s->pv[p][1], s->pv[p][2]); sp += t;
-                (void)hipEventElapsedTime(&t, s->pv[p][2], s->pv[p][3]); b += t;
+                (void)hipEventElapsedTime(&t, s->pv[p][1], s->pv[p][2]); if (s->fused) b += t; else sp += t; // fused: refinement + inter are one kernel, booked as inter
+                if (!s->fused) { (void)hipEventElapsedTime(&t, s->pv[p][2], s->pv[p][3]); b += t; }
                 (void)hipEventElapsedTime(&t, s->pv[0][4], s->pv[p][5]); if (t > c) c = t;
                 (void)hipEventElapsedTime(&t, s->pv[0][0], s->pv[p][5]); if (t > tot) tot = t;
             }
         } else {
             HIPCHK(hipEventSynchronize(s->ev[4])); // the access unit is ready before deblocking ends; the stage timers are not
             (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
-            if (!s->is_idr) { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
+            if (!s->is_idr) {
+                if (s->fused) (void)hipEventElapsedTime(&b, s->ev[1], s->ev[5]); // refinement + inter are one kernel, booked as inter
+                else { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
+            }
             (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
             (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]);
         }

@@ -61,6 +61,7 @@ typedef struct {
  * (kernarg segment); d_ctx: device copy, for the kernels that are replayed from a hipGraph. */
 void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
+void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, hipStream_t s); // fused refinement + inter (4x4 transform)
 void k_launch_inter(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
