@@ -266,7 +266,7 @@ struct intra_lds {
     int dc[16], ldc[16];
     __attribute__((aligned(4))) uint8_t T4[17 * 24]; // Intra_4x4: reconstructed samples incl. the row above / column left
     __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
-    __attribute__((aligned(4))) uint8_t crec[8 * 16]; // reconstructed chroma, interleaved Cb Cr (OUT only)
+    __attribute__((aligned(8))) uint8_t crec[8 * 16]; // reconstructed chroma, interleaved Cb Cr (OUT only)
     int mode4[16];
     __attribute__((aligned(4))) uint8_t z4[2 * 16];   // Intra_4x4: the neighbour line of the (up to two) blocks of a sub-step
     unsigned cflags[2];                               // chroma wave -> luma wave: ballots of its blocks' AC / DC flags
@@ -280,7 +280,7 @@ struct intra_lds {
 // decisions).  Needs L->top / L->left in place and visible; dec0/dec1: the 24-byte decision of intra_analyse_kernel.
 template <bool OUT>
 DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, intra_lds *L, const int mx, const int my, const int wave, const int lane,
-                       const uint4 dec0, const uint2 dec1, const uint2 *presrc = nullptr) { // presrc: this lane's source rows, loaded ahead (luma: .x of 4; chroma: 4 pairs)
+                       const uint4 dec0, const uint2 dec1, const uint2 *presrc = nullptr) { // presrc: this lane's source samples, loaded ahead (luma: .x, one word; chroma: the 8 interleaved bytes)
     int (*top)[17] = L->top;
     int (*left)[17] = L->left;
     int *sh_mode4 = L->mode4;
@@ -289,35 +289,28 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
     const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
     const bool has_top = my > 0, has_left = mx > 0;
     uint8_t *__restrict__ ry = ctx->rec_y;
-    const bool is_luma = wave == 0 && lane < 16, is_chroma = wave == 1 && lane >= 16 && lane < 24;
+    // Four lanes per 4x4 block (kernels_common.hpp): luma on all 64 lanes of wave 0 -- lane bits 5:4 block row, 3:2 row in block,
+    // 1:0 block column -- and chroma on lanes 0..31 of wave 1 (bit 4 block row, 3:2 row in block, 1 plane, 0 block column).
+    // The Intra_4x4 loop keeps its own arrangement (one pixel per lane) and reads the source from S4.
+    const int py = (lane >> 2) & 3;
     const int slot = mx & 3;
-    int src[16];
-    if (is_luma || is_chroma) {
+    unsigned srcw = 0;   // luma wave: this lane's four source samples (row 4 by + py, columns 4 bx ..)
+    int csv[4] = {0, 0, 0, 0}; // chroma wave: this lane's four source samples of its plane
+    {
         const int ss = ctx->src_stride;
-        if (is_luma) {
-            const uint8_t *__restrict__ s = ctx->src_y;
-            const int bx = blkx(lane), by = blky(lane), vh = ctx->vis_h;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int sy = y0 + by + r;
-                sy = sy < vh ? sy : vh - 1;
-                unsigned sw = presrc ? presrc[r].x : ldg32(s + (size_t)sy * ss + x0 + bx);
-#pragma unroll
-                for (int i = 0; i < 4; i++) src[r * 4 + i] = byte_of(sw, i);
-                *(unsigned *)&S4[(by + r) * 16 + bx] = sw;
-            }
+        if (wave == 0) {
+            const int row = 4 * (lane >> 4) + py, col = 4 * (lane & 3), vh = ctx->vis_h;
+            int sy = y0 + row;
+            sy = sy < vh ? sy : vh - 1;
+            srcw = presrc ? presrc[0].x : ldg32(ctx->src_y + (size_t)sy * ss + x0 + col);
+            *(unsigned *)&S4[row * 16 + col] = srcw;
         } else {
-            const uint8_t *__restrict__ s = ctx->src_uv;
-            const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4, vh2 = ctx->vis_h >> 1;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int sy = cy0 + by + r;
-                sy = sy < vh2 ? sy : vh2 - 1;
-                uint2 w = presrc ? presrc[r] : ldg64(s + (size_t)sy * ss + 2 * (cx0 + bx));
-                unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
-                src[r * 4 + 0] = (int)(lo & 255); src[r * 4 + 1] = (int)((lo >> 16) & 255);
-                src[r * 4 + 2] = (int)(hi & 255); src[r * 4 + 3] = (int)((hi >> 16) & 255);
-            }
+            const int c = (lane >> 1) & 1, vh2 = ctx->vis_h >> 1;
+            int sy = cy0 + 4 * ((lane >> 4) & 1) + py;
+            sy = sy < vh2 ? sy : vh2 - 1;
+            const uint2 w = presrc ? presrc[0] : ldg64(ctx->src_uv + (size_t)sy * ss + 2 * (cx0 + 4 * (lane & 1)));
+            const unsigned lo = c ? (w.x >> 8) : w.x, hi = c ? (w.y >> 8) : w.y;
+            csv[0] = (int)(lo & 255); csv[1] = (int)((lo >> 16) & 255); csv[2] = (int)(hi & 255); csv[3] = (int)((hi >> 16) & 255);
         }
     }
 #define TOP(p, i) top[p][(i) + 1]
@@ -332,8 +325,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         sh_mode4[lane] = (int)((w >> (8 * (bb & 3))) & 255);
     }
     WAVE_SYNC();
-    int pred[16];
-    int flags = 0;
+    unsigned nz16 = 0, ldc_any = 0, cnz8 = 0, cdc2 = 0;
     if (use_i4 && wave == 0) {
         // ================================================================ Intra_4x4 reconstruction (8.3.1.2 + 8.5)
         // Same block order; up to two blocks per step, 16 lanes each, lane = one pixel; transforms across lanes.
@@ -430,83 +422,95 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             WAVE_SYNC();
         }
         if (OUT && lane < 16) { L->bot_y[slot][lane] = T4[16 * 24 + lane + 1]; L->right_y[lane] = T4[(lane + 1) * 24 + 16]; }
-    } else if (is_luma) {
+    } else if (wave == 0) {
         // ================================================================ Intra_16x16 reconstruction (8.3.3 + 8.5.10)
-        const int b = lane, bx = blkx(b), by = blky(b), mode = mode16;
-        // neighbour statistics once per macroblock, reduced over the 16 lanes (lane j holds top j / left j): sums for DC,
-        // the weighted sums of 8.3.3.4 for Plane (weights j - 7, and -8 for the corner)
-        const int tj = TOP(0, lane), lj = LEFT(0, lane), cor = TOP(0, -1);
-        const int st = wave16_sum(tj), sl = wave16_sum(lj);
+        const int bx = lane & 3, by = lane >> 4, mode = mode16, yy = 4 * by + py;
+        // neighbour statistics: every 16-lane row reduces the same 16 top / left samples (lane & 15 = j), so each lane ends up
+        // with the sums for DC and the weighted sums of 8.3.3.4 for Plane (weights j - 7, and -8 for the corner)
+        const int j16 = lane & 15, tj = TOP(0, j16), lj = LEFT(0, j16), cor = TOP(0, -1);
+        int pd[4];
         if (mode == 0) { // wave-uniform: only the chosen predictor is evaluated
 #pragma unroll
-            for (int i = 0; i < 4; i++) { const int t = TOP(0, bx + i); pred[i] = t; pred[4 + i] = t; pred[8 + i] = t; pred[12 + i] = t; }
+            for (int i = 0; i < 4; i++) pd[i] = TOP(0, 4 * bx + i);
         } else if (mode == 1) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) { const int l = LEFT(0, by + r); pred[r * 4] = l; pred[r * 4 + 1] = l; pred[r * 4 + 2] = l; pred[r * 4 + 3] = l; }
+            const int l = LEFT(0, yy);
+            pd[0] = l; pd[1] = l; pd[2] = l; pd[3] = l;
         } else if (mode == 2) {
+            const int st = wave16_sum(tj), sl = wave16_sum(lj);
             const int dcv = (has_top && has_left) ? (st + sl + 16) >> 5 : has_top ? (st + 8) >> 4 : has_left ? (sl + 8) >> 4 : 128;
-#pragma unroll
-            for (int k = 0; k < 16; k++) pred[k] = dcv;
+            pd[0] = dcv; pd[1] = dcv; pd[2] = dcv; pd[3] = dcv;
         } else {
-            const int Hh = wave16_sum((lane - 7) * tj) - 8 * cor, Vv = wave16_sum((lane - 7) * lj) - 8 * cor;
+            const int Hh = wave16_sum((j16 - 7) * tj) - 8 * cor, Vv = wave16_sum((j16 - 7) * lj) - 8 * cor;
             const int pa = 16 * (LEFT(0, 15) + TOP(0, 15)), pb = (5 * Hh + 32) >> 6, pc = (5 * Vv + 32) >> 6;
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) pred[r * 4 + i] = clip255((pa + pb * (bx + i - 7) + pc * (by + r - 7) + 16) >> 5);
+            for (int i = 0; i < 4; i++) pd[i] = clip255((pa + pb * (4 * bx + i - 7) + pc * (yy - 7) + 16) >> 5);
         }
         const qparams q = make_q(T, qp, true);
-        int x[16], lev[16];
+        const int fy = ((py & 1) << 1) | (py >> 1);
+        const col_bf cb = make_col_bf(py);
+        const int kz0 = (int)((0xFEA9DB83C7426510ull >> (16 * fy)) & 0xFFFF); // zig-zag positions of raster 4 fy + 0 .. 3
+        const int mfe = py < 2 ? q.mf[0] : q.mf[2], mfo = py < 2 ? q.mf[2] : q.mf[1], ve = py < 2 ? q.v[0] : q.v[2], vo = py < 2 ? q.v[2] : q.v[1];
+        int x[4], lev[4], cf[4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = src[k] - pred[k];
-        fdct4(x);
-        const int dc0 = x[0];
-        bool nz = quant_dequant<1>(x, lev, q);
-        store_levels(ctx->levels + (size_t)mbn * MB_LEVELS + L_LUMA + b * 16, lev);
-        flags = nz ? 1 : 0;
-        // 4x4 Hadamard of the 16 DC terms (8.5.10's forward counterpart) as four DPP butterfly stages over the blkIdx lanes:
-        // lane bits 0/2 carry the block column X, bits 1/3 the block row Y.  The butterflies produce the natural-ordered
-        // transform (H2 x H2 per dimension); with M = rows (++++, ++--, +--+, +-+-) of the standard, natural index k holds
-        // M-frequency G[k], G = 0 3 1 2 -- so this lane's coefficient belongs at raster position (G[Y], G[X]).  M is
-        // symmetric: the same four stages applied to the quantised levels in place return this lane's own block's term.
-        const int X = ((lane >> 1) & 2) | (lane & 1), Y = ((lane >> 2) & 2) | ((lane >> 1) & 1);
-        const int s0 = (lane & 1) ? -1 : 1, s1 = (lane & 2) ? -1 : 1, s2 = (lane & 4) ? -1 : 1, s3 = (lane & 8) ? -1 : 1;
-        int hv = dc0;
+        for (int i = 0; i < 4; i++) x[i] = byte_of(srcw, i) - pd[i];
+        fwd_rows4(x);
+#pragma unroll
+        for (int i = 0; i < 4; i++) cf[i] = fwd_col(x[i], cb);
+        // 4x4 Hadamard of the 16 DC terms (element 0 of the py == 0 lanes; 8.5.10's forward counterpart): block column = lane
+        // bits 1:0, block row = lane bits 5:4, four butterfly stages (two DPP, two cross-row shuffles).  The butterflies give
+        // the natural-ordered transform (H2 x H2 per dimension); with M = rows (++++, ++--, +--+, +-+-) of the standard,
+        // natural index k holds M-frequency G[k], G = 0 3 1 2, so this lane's coefficient belongs at raster position
+        // (G[by], G[bx]).  M is symmetric: the same stages on the quantised levels return this lane's own block's term.
+        const int s0 = (lane & 1) ? -1 : 1, s1 = (lane & 2) ? -1 : 1, s2 = (lane & 16) ? -1 : 1, s3 = (lane & 32) ? -1 : 1;
+        int hv = cf[0];
         hv = mad24(hv, s0, quad_xor<1>(hv));
         hv = mad24(hv, s1, quad_xor<2>(hv));
-        hv = mad24(hv, s2, row_xor4(hv));
-        hv = mad24(hv, s3, row_xor8(hv));
-        const int hd = (hv + 1) >> 1;
-        const int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
-        const int gx = (0x2130 >> (4 * X)) & 3, gy = (0x2130 >> (4 * Y)) & 3;             // G[X], G[Y]
-        const int kz = (int)((0xFEA9DB83C7426510ull >> (4 * (gy * 4 + gx))) & 15);       // zig-zag position of that raster index
-        stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + kz], ldc);
-        if (ldc) flags |= 2;
-        {
-            int f = ldc;
-            f = mad24(f, s0, quad_xor<1>(f));
-            f = mad24(f, s1, quad_xor<2>(f));
-            f = mad24(f, s2, row_xor4(f));
-            f = mad24(f, s3, row_xor8(f));
-            const int ls = 16 * q.v[0];
-            x[0] = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
-        }
-        idct4(x);
+        hv = mad24(hv, s2, __shfl_xor(hv, 16, 64));
+        hv = mad24(hv, s3, __shfl_xor(hv, 32, 64));
+        const int ldc = quant1((hv + 1) >> 1, q.mf[0], 2 * q.f, q.qbits + 1);
+        int f = ldc;
+        f = mad24(f, s0, quad_xor<1>(f));
+        f = mad24(f, s1, quad_xor<2>(f));
+        f = mad24(f, s2, __shfl_xor(f, 16, 64));
+        f = mad24(f, s3, __shfl_xor(f, 32, 64));
+        const int ls = 16 * q.v[0];
+        const int dcv2 = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+        const bool dcl = py == 0; // this lane holds a DC term
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const unsigned rw = pack4(clip255(pred[r * 4] + x[r * 4]), clip255(pred[r * 4 + 1] + x[r * 4 + 1]),
-                                      clip255(pred[r * 4 + 2] + x[r * 4 + 2]), clip255(pred[r * 4 + 3] + x[r * 4 + 3]));
-            stg32(ry + (size_t)(y0 + by + r) * stride + x0 + bx, rw);
-            if (OUT) {
-                if (by == 12 && r == 3) *(unsigned *)&L->bot_y[slot][bx] = rw;
-                if (bx == 12) L->right_y[by + r] = (uint8_t)(rw >> 24);
-            }
+        for (int i = 0; i < 4; i++) {
+            lev[i] = (i == 0 && dcl) ? 0 : quant1(cf[i], (i & 1) ? mfo : mfe, q.f, q.qbits);
+            x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
         }
+        if (dcl) x[0] = dcv2;
+        const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1);
+        int16_t *lv = ctx->levels + (size_t)mbn * MB_LEVELS;
+#pragma unroll
+        for (int i = 0; i < 4; i++) stg16(&lv[L_LUMA + b * 16 + ((kz0 >> (4 * i)) & 15)], lev[i]);
+        if (dcl) {
+            const int gx = (0x2130 >> (4 * bx)) & 3, gy = (0x2130 >> (4 * by)) & 3; // G[bx], G[by]
+            stg16(&lv[L_LDC + (int)((0xFEA9DB83C7426510ull >> (4 * (gy * 4 + gx))) & 15)], ldc);
+        }
+        inv_rows4(x);
+        int o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = clip255(pd[i] + ((inv_col(x[i], cb) + 32) >> 6));
+        const unsigned rw = pack4(o[0], o[1], o[2], o[3]);
+        stg32(ry + (size_t)(y0 + yy) * stride + x0 + 4 * bx, rw);
+        if (OUT) {
+            if (yy == 15) *(unsigned *)&L->bot_y[slot][4 * bx] = rw;
+            if (bx == 3) L->right_y[yy] = (uint8_t)(rw >> 24);
+        }
+        const unsigned long long bal = __ballot((lev[0] | lev[1] | lev[2] | lev[3]) != 0);
+        const unsigned long long t = bal | (bal >> 4) | (bal >> 8) | (bal >> 12); // bit 16 by + bx
+        const int rb = lane & 15, rbx = blkx(rb) >> 2, rby = blky(rb) >> 2;
+        nz16 = (unsigned)(__ballot(lane < 16 && ((t >> (16 * rby + rbx)) & 1)) & 0xFFFFull);
+        ldc_any = __ballot(dcl && ldc != 0) != 0 ? 1u : 0u;
     }
-    if (is_chroma) { // wave 1, lanes 16-23: the 8 chroma blocks (a plane's four blocks in one DPP quad)
-        const int cl = lane & 7, c = cl >> 2, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4;
-        const int p = 1 + c;
-        if (cmode == 0) { // wave-uniform: only the chosen predictor is evaluated.  DC of this 4x4 block (8.3.4.1-3)
+    if (wave == 1) { // ================================================================ chroma (8.3.4 + 8.5.11)
+        const int cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1, p = 1 + c;
+        const int bx = 4 * cbx, by = 4 * cby, yy = by + py, b = 2 * cby + cbx;
+        int pd[4];
+        if (cmode == 0) { // wave-uniform: only the chosen predictor is evaluated.  DC of this lane's 4x4 block (8.3.4.1-3)
             int st = 0, sl = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) { st += TOP(p, bx + i); sl += LEFT(p, by + i); }
@@ -514,14 +518,13 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             if (b == 1 && has_top) ul = false;
             if (b == 2 && has_left) ut = false;
             const int dcv = (ut && ul) ? (st + sl + 4) >> 3 : ut ? (st + 2) >> 2 : ul ? (sl + 2) >> 2 : 128;
-#pragma unroll
-            for (int k = 0; k < 16; k++) pred[k] = dcv;
+            pd[0] = dcv; pd[1] = dcv; pd[2] = dcv; pd[3] = dcv;
         } else if (cmode == 1) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) { const int l = LEFT(p, by + r); pred[r * 4] = l; pred[r * 4 + 1] = l; pred[r * 4 + 2] = l; pred[r * 4 + 3] = l; }
+            const int l = LEFT(p, yy);
+            pd[0] = l; pd[1] = l; pd[2] = l; pd[3] = l;
         } else if (cmode == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) { const int t = TOP(p, bx + i); pred[i] = t; pred[4 + i] = t; pred[8 + i] = t; pred[12 + i] = t; }
+            for (int i = 0; i < 4; i++) pd[i] = TOP(p, bx + i);
         } else {
             int Hh = 0, Vv = 0;
 #pragma unroll
@@ -531,15 +534,12 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             }
             const int pa = 16 * (LEFT(p, 7) + TOP(p, 7)), pb = (34 * Hh + 32) >> 6, pc = (34 * Vv + 32) >> 6;
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int i = 0; i < 4; i++) pred[r * 4 + i] = clip255((pa + pb * (bx + i - 3) + pc * (by + r - 3) + 16) >> 5);
+            for (int i = 0; i < 4; i++) pd[i] = clip255((pa + pb * (bx + i - 3) + pc * (yy - 3) + 16) >> 5);
         }
-        if (is_chroma) flags = chroma_block(ctx, T, mbn, cx0, cy0, cl, pred, qp, true, OUT ? L->crec : nullptr, presrc);
+        chroma_rows4(ctx, T, ctx->levels + (size_t)mbn * MB_LEVELS, cx0, cy0, lane, pd, csv, qp, true, true, OUT ? L->crec : nullptr, cnz8, cdc2);
     }
 #undef TOP
 #undef LEFT
-    const unsigned long long any = __ballot(flags & 1), dcm = __ballot(flags & 2);
     if (wave == 1) {
         if (OUT) {
             WAVE_SYNC();
@@ -550,16 +550,16 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             }
         }
         if (lane == 0) {
-            L->cflags[0] = (unsigned)((any >> 16) & 0xFF); L->cflags[1] = (unsigned)((dcm >> 16) & 0xFF);
+            L->cflags[0] = cnz8; L->cflags[1] = cdc2;
             __hip_atomic_store(&L->cseq, (unsigned)mbn + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     } else if (lane == 0) { // the luma wave writes the record once the chroma wave's flags are in (both waves are resident: plain spin)
         while (__hip_atomic_load(&L->cseq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)mbn + 1u) __builtin_amdgcn_s_sleep(1);
         const unsigned cany = L->cflags[0], cdc = L->cflags[1];
-        unsigned nzm = (use_i4 ? nz4 : (unsigned)(any & 0xFFFF)) | (cany << 16);
-        if (!use_i4 && (dcm & 0xFFFF)) nzm |= NZ_LDC;
-        if (cdc & 0x0F) nzm |= NZ_CBDC;
-        if (cdc & 0xF0) nzm |= NZ_CRDC;
+        unsigned nzm = (use_i4 ? nz4 : nz16) | (cany << 16);
+        if (!use_i4 && ldc_any) nzm |= NZ_LDC;
+        if (cdc & 1) nzm |= NZ_CBDC;
+        if (cdc & 2) nzm |= NZ_CRDC;
         mb_info_t mb;
         mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)mode16; mb.chroma_mode = (uint8_t)cmode;
         mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = dec1.y;
@@ -637,8 +637,8 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     int avail = 0;
     uint4 dec0n = make_uint4(0, 0, 0, 0);
     uint2 dec1n = make_uint2(0, 0);
-    uint2 srcn[4] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)}; // this lane's source rows of the next macroblock
-    const bool src_luma = role == 0 && lane < 16, src_chroma = role == 1 && lane >= 16 && lane < 24;
+    uint2 srcn = make_uint2(0, 0); // this lane's source samples of the next macroblock (layout: intra_compute)
+    const int spy = (lane >> 2) & 3;
     const int nsteps = mbw + IB_ROWS + 1;
 #ifdef IB_PROF /* debug builds: cycles inside intra_compute per wave, and of the whole loop, left in ctx->isad */
     unsigned long long ib_cyc = 0, ib_n = 0;
@@ -654,20 +654,21 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
         // ---- land what was prefetched for this step, prefetch for the next one
         const uint4 dec0 = dec0n;
         const uint2 dec1 = dec1n;
-        const uint2 srcc[4] = {srcn[0], srcn[1], srcn[2], srcn[3]};
+        const uint2 srcc = srcn;
         if (fed && act && lane >= 24 && lane < 29) stage[role][lane - 24] = gpre;
         if (pf) {
             const size_t mbn_n = (size_t)my * mbw + xn;
             dec0n = ldg128(ctx->idec + mbn_n * IDEC_BYTES);
             dec1n = ldg64(ctx->idec + mbn_n * IDEC_BYTES + 16);
-            if (src_luma) {
-                const int bx = blkx(lane), by = blky(lane), vh = ctx->vis_h;
-#pragma unroll
-                for (int q = 0; q < 4; q++) { int sy = my * 16 + by + q; sy = sy < vh ? sy : vh - 1; srcn[q].x = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + xn * 16 + bx); }
-            } else if (src_chroma) {
-                const int cl = lane & 7, b = cl & 3, bx = (b & 1) * 4, by = (b >> 1) * 4, vh2 = ctx->vis_h >> 1;
-#pragma unroll
-                for (int q = 0; q < 4; q++) { int sy = my * 8 + by + q; sy = sy < vh2 ? sy : vh2 - 1; srcn[q] = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * (xn * 8 + bx)); }
+            if (role == 0) {
+                int sy = my * 16 + 4 * (lane >> 4) + spy;
+                sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
+                srcn.x = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + xn * 16 + 4 * (lane & 3));
+            } else if (lane < 32) {
+                const int vh2 = ctx->vis_h >> 1;
+                int sy = my * 8 + 4 * (lane >> 4) + spy;
+                sy = sy < vh2 ? sy : vh2 - 1;
+                srcn = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * (xn * 8 + 4 * (lane & 1)));
             }
             if (fed) {
                 if (avail < xn + 1) avail = db_wait_get(prog_up, a.err, xn + 1);
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
 #ifdef IB_PROF
             const unsigned long long ib_t0 = __builtin_readcyclecounter();
 #endif
-            intra_compute<true>(ctx, T, L, x, my, role, lane, dec0, dec1, srcc);
+            intra_compute<true>(ctx, T, L, x, my, role, lane, dec0, dec1, &srcc);
 #ifdef IB_PROF
             ib_cyc += __builtin_readcyclecounter() - ib_t0; ib_n++;
 #endif

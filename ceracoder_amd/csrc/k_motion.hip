@@ -358,29 +358,6 @@ __global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t cv, int m
 // reads the reference and the source as words, and the Cb lanes store interleaved 8-byte row segments after fetching
 // their Cr partners' samples with one DPP move.  Used for every P picture without the 8x8 transform; the separate
 // subpel_kernel / inter_kernel remain for the High-profile path and the single-stage entry points.
-DEV void fwd_rows4(int *r) { // 4-point forward core transform, in place
-    const int e0 = r[0] + r[3], e1 = r[1] + r[2], e2 = r[1] - r[2], e3 = r[0] - r[3];
-    r[0] = e0 + e1; r[1] = 2 * e3 + e2; r[2] = e0 - e1; r[3] = e3 - 2 * e2;
-}
-DEV void inv_rows4(int *d) { // 8.5.12.2, one row
-    const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
-    d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
-}
-struct col_bf { int s1, fo, fp, is, io, ip; }; // per-lane butterfly coefficients of the column direction (see k_intra.hip, Intra_4x4)
-DEV col_bf make_col_bf(int py) {
-    col_bf c;
-    c.s1 = py < 2 ? 1 : -1; c.fo = py == 1 ? -1 : 1; c.fp = py < 2 ? 1 : py == 2 ? 2 : -2;
-    c.is = py >> 1; c.io = py == 1 ? -1 : 1; c.ip = py == 2 ? -1 : 1;
-    return c;
-}
-DEV int fwd_col(int v, const col_bf &c) { // rows of the block are 4 lanes apart; result: frequency F[py], F = 0 2 1 3
-    int t = mad24(v, c.s1, row_xor12(v));
-    return mad24(t, c.fo, __mul24(row_xor4(t), c.fp));
-}
-DEV int inv_col(int v, const col_bf &c) { // takes frequency order F[py], returns row py
-    int t = mad24(v >> c.is, c.io, __mul24(row_xor4(v), c.ip));
-    return mad24(t, c.s1, row_xor12(t));
-}
 __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
@@ -489,7 +466,6 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
     }
     unsigned nz_c = 0, dc_c = 0;
     { // ---- chroma on lanes 0..31: bit 4 = block row, bits 3:2 = row in block, bit 1 = plane, bit 0 = block column
-        const bool cl = lane < 32;
         const int cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1;
         const int cx0 = x0 >> 1, cy0 = y0 >> 1, cw = W >> 1, ch = H >> 1;
         const int cy = cby * 4 + py, cxb = cbx * 4;
@@ -521,59 +497,10 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
         const unsigned slo = c ? (sw.x >> 8) : sw.x, shi = c ? (sw.y >> 8) : sw.y;
         const int sv[4] = {(int)(slo & 255), (int)((slo >> 16) & 255), (int)(shi & 255), (int)((shi >> 16) & 255)};
         const int w00 = (8 - xf) * (8 - yf), w10 = xf * (8 - yf), w01 = (8 - xf) * yf, w11 = xf * yf;
-        const qparams q = make_q(T, T->qpc[qp], false);
-        const int mfe = py < 2 ? q.mf[0] : q.mf[2], mfo = py < 2 ? q.mf[2] : q.mf[1], ve = py < 2 ? q.v[0] : q.v[2], vo = py < 2 ? q.v[2] : q.v[1];
-        int pd[4], x[4], lev[4];
+        int pd[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            pd[i] = (w00 * A[i] + w10 * A[i + 1] + w01 * B[i] + w11 * B[i + 1] + 32) >> 6;
-            x[i] = sv[i] - pd[i];
-        }
-        fwd_rows4(x);
-        int cf[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) cf[i] = fwd_col(x[i], cb);
-        // 8.5.11: the plane's four DC terms (element 0 of the py == 0 lanes) through the 2x2 Hadamard -- block column is
-        // lane bit 0, block row lane bit 4 -- quantised with doubled rounding, transformed back and scaled
-        const int sbx = cbx ? -1 : 1, sby = cby ? -1 : 1;
-        int hd = mad24(cf[0], sbx, quad_xor<1>(cf[0]));
-        hd = mad24(hd, sby, __shfl_xor(hd, 16, 64));
-        const int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
-        int g = mad24(ldc, sbx, quad_xor<1>(ldc));
-        g = mad24(g, sby, __shfl_xor(g, 16, 64));
-        const int dcc = ((g * 16 * q.v[0]) << q.shift) >> 5;
-        const bool dcl = py == 0; // this lane holds a DC term
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            lev[i] = (i == 0 && dcl) ? 0 : quant1(cf[i], (i & 1) ? mfo : mfe, q.f, q.qbits);
-            x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
-        }
-        if (dcl) x[0] = dcc;
-        const int b = cby * 2 + cbx;
-        if (ok && cl) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) stg16(&lv[L_CAC + (4 * c + b) * 16 + ((kz0 >> (4 * i)) & 15)], lev[i]);
-            if (dcl) stg16(&lv[L_CDC + 4 * c + b], ldc);
-        }
-        inv_rows4(x);
-        int o[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = clip255(pd[i] + ((inv_col(x[i], cb) + 32) >> 6));
-        // Cb lanes fetch their Cr partners (lane ^ 2) and store the interleaved 8-byte segment of the row
-        const unsigned mine = pack4(o[0], o[1], o[2], o[3]), other = (unsigned)quad_xor<2>((int)mine);
-        if (ok && cl && c == 0) {
-            uint2 out;
-            out.x = __builtin_amdgcn_perm(other, mine, 0x05010400u); // U0 V0 U1 V1
-            out.y = __builtin_amdgcn_perm(other, mine, 0x07030602u); // U2 V2 U3 V3
-            stg64(ctx->rec_uv + (size_t)(cy0 + cy) * stride + 2 * (cx0 + cxb), out);
-        }
-        const unsigned long long bal = __ballot(cl && (lev[0] | lev[1] | lev[2] | lev[3]) != 0);
-        const unsigned long long t = bal | (bal >> 4) | (bal >> 8) | (bal >> 12); // bit 16 cby + 2 c + cbx
-        // blocks in record order: 4 c + 2 cby + cbx
-        const int k8 = lane & 7, kc = k8 >> 2, kby = (k8 >> 1) & 1, kbx = k8 & 1;
-        nz_c = (unsigned)(__ballot(lane < 8 && ((t >> (16 * kby + 2 * kc + kbx)) & 1)) & 0xFFull);
-        const unsigned long long dcb = __ballot(cl && dcl && ldc != 0);
-        dc_c = ((dcb & 0x00030003ull) ? 1u : 0u) | ((dcb & 0x000C000Cull) ? 2u : 0u); // lanes with c == 0 / c == 1 among py == 0
+        for (int i = 0; i < 4; i++) pd[i] = (w00 * A[i] + w10 * A[i + 1] + w01 * B[i] + w11 * B[i + 1] + 32) >> 6;
+        chroma_rows4(ctx, T, lv, cx0, cy0, lane, pd, sv, qp, false, ok, nullptr, nz_c, dc_c);
     }
     if (ok && lane == 0) {
         unsigned nzm = nz_luma | (nz_c << 16);
