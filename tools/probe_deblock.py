@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ceracoder_amd import enc as E
+E.LIB_PATH = os.environ.get("MI355ENC_LIB", E.LIB_PATH)  # e.g. an experiment build
 
 for (w, h) in ((1920, 64), (1920, 1088)):
     e = E.Encoder(w, h, fixed_qp=30)
