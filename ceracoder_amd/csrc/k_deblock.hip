@@ -287,12 +287,13 @@ DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int b
 // chroma -- the planes share nothing but the records, and on separate CUs neither steals issue
 // slots from the other's dependency chain).  4 waves, one per SIMD; a wave serves four rows, 16
 // lanes each.
-template <bool CHROMA>
+template <bool CHROMA, bool ALL_INTRA>
 DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *lds) {
     constexpr int rows_mb = CHROMA ? 8 : 16, strip = CHROMA ? 2 : 4, ring_n = CHROMA ? 8 : 16;
     constexpr int ROW_LDS = CHROMA ? (int)sizeof(d3_chroma) : (int)sizeof(d3_luma);
     const frame_ctx_t *__restrict__ ctx = &a.ctx;
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
+    constexpr bool all_intra = ALL_INTRA; // a separate instantiation: the extra code would cost the P-picture kernel ~2 % if it shared it
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, k = lane & 15, r = 4 * wave + g, my = band * D3_ROWS + r;
     const bool row_ok = my < mbh, last_row = my == mbh - 1;
@@ -356,15 +357,22 @@ DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *ld
                 int px[20];
 #pragma unroll
                 for (int i = 0; i < 20; i++) px[i] = byte_of(w5[i >> 2], i & 3);
-                {
-                    const int bS = (int)((bvl >> sh) & 15);
-                    const unsigned long long nz = __ballot(bS != 0);
-                    if (nz) edge_luma2<true>(PL, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], bS, __ballot(bS == 4) != 0);
-                }
+                if (all_intra) { // one basic block: no per-edge tests, and the scheduler may overlap an edge's independent half with the previous edge
+                    edge_luma2<true>(PL, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], (int)((bvl >> sh) & 15), true);
 #pragma unroll
-                for (int e = 1; e < 4; e++) {
-                    const int bS = (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15);
-                    if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
+                    for (int e = 1; e < 4; e++)
+                        edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15), false);
+                } else {
+                    {
+                        const int bS = (int)((bvl >> sh) & 15);
+                        const unsigned long long nz = __ballot(bS != 0);
+                        if (nz) edge_luma2<true>(PL, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], bS, __ballot(bS == 4) != 0);
+                    }
+#pragma unroll
+                    for (int e = 1; e < 4; e++) {
+                        const int bS = (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15);
+                        if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
+                    }
                 }
                 if (act) {
                     const unsigned l0 = pack4(px[0], px[1], px[2], px[3]);
@@ -412,14 +420,21 @@ DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *ld
 #pragma unroll
                 for (int i = 0; i < 20; i++) px[i] = tile[i * D3_TS + 16 + k];
                 if (__ballot((bhl | bhh) != 0)) {
-                    {
-                        const int bS = (int)((bhl >> sh) & 15);
-                        if (__ballot(bS != 0)) edge_luma2<true>(PT, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], bS, __ballot(bS == 4) != 0);
-                    }
+                    if (all_intra) {
+                        edge_luma2<true>(PT, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], (int)((bhl >> sh) & 15), true);
 #pragma unroll
-                    for (int e = 1; e < 4; e++) {
-                        const int bS = (int)(((e < 2 ? bhl : bhh) >> (16 * (e & 1) + sh)) & 15);
-                        if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
+                        for (int e = 1; e < 4; e++)
+                            edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], (int)(((e < 2 ? bhl : bhh) >> (16 * (e & 1) + sh)) & 15), false);
+                    } else {
+                        {
+                            const int bS = (int)((bhl >> sh) & 15);
+                            if (__ballot(bS != 0)) edge_luma2<true>(PT, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], bS, __ballot(bS == 4) != 0);
+                        }
+#pragma unroll
+                        for (int e = 1; e < 4; e++) {
+                            const int bS = (int)(((e < 2 ? bhl : bhh) >> (16 * (e & 1) + sh)) & 15);
+                            if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
+                        }
                     }
                     if (act) {
 #pragma unroll
@@ -487,11 +502,12 @@ DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *ld
 #endif
 }
 
+template <bool ALL_INTRA>
 __global__ __launch_bounds__(256) void deblock_band16_kernel(db_args a) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[D3_ROWS * sizeof(d3_luma)];
     const int nl = gridDim.x >> 1;
-    if ((int)blockIdx.x < nl) band16_body<false>(a, a.band0 + blockIdx.x, a.nb_total, lds);
-    else band16_body<true>(a, a.band0 + blockIdx.x - nl, a.nb_total, lds);
+    if ((int)blockIdx.x < nl) band16_body<false, ALL_INTRA>(a, a.band0 + blockIdx.x, a.nb_total, lds);
+    else band16_body<true, ALL_INTRA>(a, a.band0 + blockIdx.x - nl, a.nb_total, lds);
 }
 
 // =================================================================== launchers
@@ -514,5 +530,7 @@ void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int row0, int row1
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
     db_args a;
     a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh);
-    if (band1 > band0) hipLaunchKernelGGL(deblock_band16_kernel, dim3(2 * (band1 - band0)), dim3(256), 0, s, a);
+    if (band1 <= band0) return;
+    if (h_ctx->all_intra) hipLaunchKernelGGL(deblock_band16_kernel<true>, dim3(2 * (band1 - band0)), dim3(256), 0, s, a); // IDR pictures: every edge has work
+    else hipLaunchKernelGGL(deblock_band16_kernel<false>, dim3(2 * (band1 - band0)), dim3(256), 0, s, a);
 }

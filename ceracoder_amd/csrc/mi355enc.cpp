@@ -421,7 +421,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
     c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set]; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec;
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
-    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
     // stage timers: an event record costs ~5 us of queue time, so profile_events = k samples every k-th picture (IDR pictures always)
     const int prof = h->cfg.profile_events > 0 && (idr || h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
     const int np = h->npieces;
@@ -698,7 +698,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     HIPCHK(hipStreamSynchronize(h->cstream));
     { int r = sync_compute(h); if (r) return r; }
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
-    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8;
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = 0;
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     return 0;
 }

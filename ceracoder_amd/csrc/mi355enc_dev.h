@@ -49,6 +49,7 @@ typedef struct {
     int32_t qp, me_range, lambda;
     int32_t i4x4;                  /* try Intra_4x4 in I pictures */
     int32_t t8;                    /* P macroblocks use the 8x8 transform (High profile stream) */
+    int32_t all_intra;             /* every macroblock of the picture is intra (IDR): the deblocker runs all edges without per-edge tests */
 } frame_ctx_t;
 
 #ifdef __cplusplus
