@@ -326,10 +326,7 @@ __global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t cv, int m
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            int v = wave16_sum((int)acc[q]);
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            acc[q] = (unsigned)v;
+            acc[q] = (unsigned)wave64_sum((int)acc[q]);
         }
 #pragma unroll
         for (int c8 = 0; c8 < 8; c8++) {
@@ -412,10 +409,7 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                int v = wave16_sum((int)acc[q]);
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                acc[q] = (unsigned)v;
+                acc[q] = (unsigned)wave64_sum((int)acc[q]);
             }
 #pragma unroll
             for (int c8 = 0; c8 < 8; c8++) {

@@ -219,6 +219,14 @@ DEV int byte_of(unsigned w, int i) { return (int)((w >> (8 * i)) & 255); }
 // Chroma of one macroblock, run by 8 consecutive lanes (cl = 0..7: plane c = cl>>2, block b = cl&3).
 // value of lane (l ^ K) of this lane's quad, K = 1..3 (DPP quad_perm)
 DEV int mad24(int a, int b, int c) { return __mul24(a, b) + c; } // v_mad_i32_i24: operands must fit 24 bits
+// sum over the whole wave, returned uniformly (an SGPR): row sums by DPP, then row_bcast15 / row_bcast31 carry them down
+// the rows (GFX9 DPP controls) and lane 63 holds the total -- no LDS-crossbar shuffles
+DEV int wave64_sum(int v) {
+    v = wave16_sum(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
 // lane ^ 4 / lane ^ 12 inside a row of 16 lanes, two DPP moves each: quad reversal (lane ^ 3) followed by the half-row mirror
 // (lane ^ 7) or the row mirror (lane ^ 15)
 DEV int row_xor4(int v) { return __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xF, 0xF, false), 0x141, 0xF, 0xF, false); }
