@@ -17,7 +17,8 @@ def short(name):
     if m:
         n = int(m.group(1))
         return name[m.end():m.end() + n]
-    return re.sub(r"(\(.*|\.kd)$", "", name)
+    name = re.sub(r"^void\s+", "", name)          # demangled template instantiations: "void kernel<true>(args)"
+    return re.sub(r"(<.*|\(.*|\.kd)$", "", name)
 
 
 def load(d, counter):
@@ -41,10 +42,13 @@ for k in sorted(set(F) | set(W)):
         e["WRITE_SIZE"] = {"launches": len(w), "avg_kb": round(sum(w) / len(w), 3), "min_kb": min(w), "max_kb": max(w)}
     if f and w:
         e["hbm_bytes_per_launch_corrected"] = int((2 * sum(f) / len(f) + sum(w) / len(w)) * 1024)
-    for name, line in trace.items():
+    calls = tot = 0
+    for name, line in trace.items():  # template instantiations of one kernel are merged (weighted by calls)
         if short(line["Name"]) == k:
-            e["kernel_trace_avg_us"] = round(float(line["AverageNs"]) / 1e3, 3)
-            e["kernel_trace_calls"] = int(line["Calls"])
+            calls += int(line["Calls"]); tot += float(line["TotalDurationNs"])
+    if calls:
+        e["kernel_trace_avg_us"] = round(tot / calls / 1e3, 3)
+        e["kernel_trace_calls"] = calls
     kern[k] = e
 doc = {"round": int(rnd), "workload": workload,
        "commands": {"kernel_stats": "cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d … -- python3 bench.py --no-cpu-baseline  (rocpd database, summarised by tools/rocpd_summary.py)",
