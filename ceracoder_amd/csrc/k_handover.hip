@@ -14,15 +14,29 @@
 DEV int pack_count(unsigned nz, unsigned mb_type) {
     return __popc(nz & 0x01FFFFFFu) + ((nz & (NZ_CBDC | NZ_CRDC)) ? 1 : 0) + (mb_type == 2 ? 1 : 0);
 }
-// exclusive prefix sum of the block counts: one workgroup, thread t owns a run of consecutive macroblocks
+// exclusive prefix sum of the block counts: one workgroup, thread t owns a run of PER consecutive macroblocks whose counts
+// stay in registers (all PER loads are in flight together: the kernel sits on the latency path of every access unit).
+// PER = 0: any picture size, counts re-read in the second pass.
+template <int PER>
 __global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__restrict__ mbi, int nmb, int mbw, unsigned *__restrict__ off,
                                                            unsigned *__restrict__ hdr, const unsigned *__restrict__ err) {
     __shared__ unsigned wsum[16];
-    const int tid = threadIdx.x, per = (nmb + 1023) / 1024, base = tid * per;
+    const int tid = threadIdx.x, per = PER ? PER : (nmb + 1023) / 1024, base = tid * per;
+    unsigned cnt[PER ? PER : 1];
     unsigned mine = 0;
-    for (int i = 0; i < per; i++) {
-        const int mb = base + i;
-        if (mb < nmb) { const uint4 r = ldg128(&mbi[mb]); mine += (unsigned)pack_count(r.z, r.y & 255); }
+    if (PER) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int mb = base + i;
+            const uint4 r = ldg128(&mbi[mb < nmb ? mb : nmb - 1]);
+            cnt[i] = mb < nmb ? (unsigned)pack_count(r.z, r.y & 255) : 0u;
+            mine += cnt[i];
+        }
+    } else {
+        for (int i = 0; i < per; i++) {
+            const int mb = base + i;
+            if (mb < nmb) { const uint4 r = ldg128(&mbi[mb]); mine += (unsigned)pack_count(r.z, r.y & 255); }
+        }
     }
     unsigned incl = mine;
 #pragma unroll
@@ -32,12 +46,24 @@ __global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__re
     unsigned before = 0;
     for (int w = 0; w < (tid >> 6); w++) before += wsum[w];
     unsigned run = before + incl - mine;
-    for (int i = 0; i < per; i++) {
-        const int mb = base + i;
-        if (mb < nmb) {
-            off[mb] = run;
-            if (mb % mbw == 0) hdr[2 + mb / mbw] = run; // where each macroblock row starts: lets the host code rows in parallel
-            const uint4 r = ldg128(&mbi[mb]); run += (unsigned)pack_count(r.z, r.y & 255);
+    if (PER) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const int mb = base + i;
+            if (mb < nmb) {
+                off[mb] = run;
+                if (mb % mbw == 0) hdr[2 + mb / mbw] = run; // where each macroblock row starts: lets the host code rows in parallel
+                run += cnt[i];
+            }
+        }
+    } else {
+        for (int i = 0; i < per; i++) {
+            const int mb = base + i;
+            if (mb < nmb) {
+                off[mb] = run;
+                if (mb % mbw == 0) hdr[2 + mb / mbw] = run;
+                const uint4 r = ldg128(&mbi[mb]); run += (unsigned)pack_count(r.z, r.y & 255);
+            }
         }
     }
     if (tid == 1023) { hdr[0] = run; hdr[1] = ldg32(err); } // total blocks; sticky error word of the band deblocker
@@ -68,7 +94,10 @@ __global__ __launch_bounds__(256) void levels_pack_kernel(const mb_info_t *__res
 }
 void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, int mbw, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,
                    unsigned *h_hdr, const unsigned *d_err, hipStream_t s) {
-    hipLaunchKernelGGL(levels_scan_kernel, dim3(1), dim3(1024), 0, s, d_mbi, nmb, mbw, d_off, h_hdr, d_err);
+    if (nmb <= 4 * 1024) hipLaunchKernelGGL(levels_scan_kernel<4>, dim3(1), dim3(1024), 0, s, d_mbi, nmb, mbw, d_off, h_hdr, d_err);
+    else if (nmb <= 8 * 1024) hipLaunchKernelGGL(levels_scan_kernel<8>, dim3(1), dim3(1024), 0, s, d_mbi, nmb, mbw, d_off, h_hdr, d_err); // 1080p: 8160
+    else if (nmb <= 32 * 1024) hipLaunchKernelGGL(levels_scan_kernel<32>, dim3(1), dim3(1024), 0, s, d_mbi, nmb, mbw, d_off, h_hdr, d_err); // 2160p: 32400
+    else hipLaunchKernelGGL(levels_scan_kernel<0>, dim3(1), dim3(1024), 0, s, d_mbi, nmb, mbw, d_off, h_hdr, d_err);
     hipLaunchKernelGGL(levels_pack_kernel, dim3((nmb + 3) / 4), dim3(256), 0, s, d_mbi, d_levels, nmb, d_off, h_mbi, h_packed);
 }
 

@@ -256,14 +256,12 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *_
 }
 
 // =================================================================== intra (I) macroblocks
-// One wave per macroblock, launched once per anti-diagonal x + y = diag (left, top and
-// top-left neighbours are then complete).  Lanes 0-15: luma 4x4 blocks; lanes 16-23: chroma.
+// Two waves per macroblock (luma, chroma), run in x + y order (left, top and top-left neighbours are then complete).
 // Per-macroblock working set of the intra reconstruction, in LDS.  Filled by the caller: top / left (reconstructed
 // neighbours, [plane 0 = Y, 1 = Cb, 2 = Cr][index i + 1 holds sample i, index 0 the corner]).  Produced for the neighbours
 // to the right and below (persistent kernel): bottom rows into a 4-deep ring, the right column.
 struct intra_lds {
     int top[3][17], left[3][17];
-    int dc[16], ldc[16];
     __attribute__((aligned(4))) uint8_t T4[17 * 24]; // Intra_4x4: reconstructed samples incl. the row above / column left
     __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
     __attribute__((aligned(8))) uint8_t crec[8 * 16]; // reconstructed chroma, interleaved Cb Cr (OUT only)

@@ -5,10 +5,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ceracoder_amd import enc as E, synth
+E.LIB_PATH = os.environ.get("MI355ENC_LIB", E.LIB_PATH)  # A/B against another build
 w, h = 1920, 1080
 fr = [np.concatenate([y, uv]) for y, uv in synth.s2_frames(w, h, 24)]
 for gap_ms in (0.0, 16.7):
-    for thr in (1, 2, 4, 0):
+    for thr in ((0,) if os.environ.get("QUICK") else (1, 2, 4, 0)):
         e = E.Encoder(w, h, fps=60, gop=60, bitrate_bps=6_000_000, pipeline_depth=0, cavlc_threads=thr)
         lat = []
         n = 150 if gap_ms == 0 else 60
