@@ -743,6 +743,24 @@ int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }
+int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv,
+                       int qp, int refine, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels) {
+    if (!h || !src_y || !src_uv || !ref_y || !ref_uv || !mbinfo_inout || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rec_uv[0], ref_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
+    int r = stage_ctx(h, qp, true); if (r) return r;
+    k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, refine ? 1 : 0, h->stream);
+    HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
 int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out, uint8_t *rec_y,
                          uint8_t *rec_uv, int16_t *levels) {
     if (!h || !src_y || !src_uv || !mbinfo_out || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;

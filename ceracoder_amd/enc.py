@@ -27,7 +27,7 @@ EXPORTS = [
     "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_encode", "mi355enc_submit",
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
-    "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
+    "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_pmb", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
     "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
     "mi355enc_rc_pick_qp", "mi355enc_rc_update",
 ]
@@ -87,6 +87,7 @@ def load():
         L.mi355enc_stage_me.argtypes = [vp, vp, vp, C.c_int, vp]
         L.mi355enc_stage_subpel.argtypes = [vp, vp, vp, C.c_int, vp]
         L.mi355enc_stage_inter.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.mi355enc_stage_pmb.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_intra_analyse.argtypes = [vp, vp, vp, C.c_int, vp, vp]
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
@@ -294,6 +295,15 @@ class Encoder:
         self._chk(self.L.mi355enc_stage_inter(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)),
                                               _p(np.ascontiguousarray(ref_y)), _p(np.ascontiguousarray(ref_uv)), qp, _p(mbi),
                                               _p(rec_y), _p(rec_uv), _p(lev)), "stage_inter")
+        return rec_y, rec_uv, mbi, lev
+
+    def stage_pmb(self, src_y, src_uv, ref_y, ref_uv, mbi, qp, refine=True):
+        mbi = np.ascontiguousarray(mbi).copy()
+        rec_y, rec_uv = np.empty_like(src_y), np.empty_like(src_uv)
+        lev = np.empty((mbi.size, LEVELS_PER_MB), np.int16)
+        self._chk(self.L.mi355enc_stage_pmb(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)),
+                                            _p(np.ascontiguousarray(ref_y)), _p(np.ascontiguousarray(ref_uv)), qp, int(refine), _p(mbi),
+                                            _p(rec_y), _p(rec_uv), _p(lev)), "stage_pmb")
         return rec_y, rec_uv, mbi, lev
 
     def stage_intra(self, src_y, src_uv, qp):

@@ -154,6 +154,10 @@ int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *re
 int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y,
                          const uint8_t *ref_uv, int qp, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv,
                          int16_t *levels);
+/* The fused P-macroblock stage the encoder runs (refinement of the integer vectors in mbinfo_inout if `refine`, then
+ * prediction, residual, reconstruction): must equal mi355enc_stage_subpel followed by mi355enc_stage_inter. */
+int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv,
+                       int qp, int refine, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
 int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out,
                          uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
 /* open-loop intra analysis only: 152 uint16 per macroblock {i16[4], chroma[4], i4[16][9]}, 0xFFFF = mode unavailable; and

@@ -71,6 +71,28 @@ def test_inter_kernel_matches_oracle(E, oracle, w, h, qp, sub):
     e.close()
 
 
+@pytest.mark.parametrize("w,h", SIZES + [(16, 16), (50, 34), (1920, 1088)])
+@pytest.mark.parametrize("qp", [0, 18, 30, 51])
+@pytest.mark.parametrize("sub", [False, True])
+def test_fused_p_kernel_matches_oracle(E, oracle, w, h, qp, sub):
+    """pmb_kernel (what the encoder runs for P pictures: refinement + prediction + residual in one launch, four lanes per
+    4x4 block) against the oracle's refinement followed by its inter stage, from the oracle's integer vectors."""
+    f = frames(w, h, 2)
+    (cy, cuv), (ry, ruv) = f[1][:2], f[0][:2]
+    mbi0 = oracle.me_frame(cy, ry, 16, qp, threads=8)
+    mbi = oracle.subpel_frame(cy, ry, mbi0, qp, threads=8) if sub else mbi0
+    o_y, o_uv, o_mbi, o_lev = oracle.inter_frame(cy, cuv, ry, ruv, mbi, qp)
+    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp)
+    d_y, d_uv, d_mbi, d_lev = e.stage_pmb(cy, cuv, ry, ruv, mbi0, qp, refine=sub)
+    assert mbinfo_equal(d_mbi, o_mbi, ("mvx", "mvy", "mb_type", "qp", "nzmask")), first_diff(d_mbi["nzmask"], o_mbi["nzmask"])
+    if sub:
+        assert np.array_equal(d_mbi["cost"], mbi["cost"])
+    assert np.array_equal(d_lev, o_lev), first_diff(d_lev, o_lev)
+    assert np.array_equal(d_y, o_y), first_diff(d_y, o_y)
+    assert np.array_equal(d_uv, o_uv), first_diff(d_uv, o_uv)
+    e.close()
+
+
 @pytest.mark.parametrize("w,h", SIZES + [(16, 16), (1920, 1088)])
 def test_intra_analyse_kernel_matches_oracle(E, oracle, w, h):
     """Open-loop intra analysis (one flat launch): SAD of every I16 / chroma / I4x4 candidate, 152 u16 per macroblock,
