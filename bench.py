@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--deblock-mode", type=int, default=0)
     ap.add_argument("--sample", type=int, default=7, help="stage timers (HIP events) on every k-th picture; each event record costs ~5 us of queue time")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent streams encoded concurrently on each GPU (one host thread each); the headline configuration is 1")
-    ap.add_argument("--cavlc-threads", type=int, default=0, help="host threads coding one slice row-parallel (bit-identical output); 0 = the encoder's default (automatic, at most 4)")
+    ap.add_argument("--cavlc-threads", type=int, default=0, help="host threads coding one slice row-parallel (bit-identical output); 0 = the encoder's default (automatic, at most 8)")
     ap.add_argument("--overlap", type=int, default=0, help="band-pipelined schedule for P pictures: 0 off, 1 default piece count (4), N >= 2 pieces")
     ap.add_argument("--rate-script", default="auto", help="bitrate setpoints written to the encoder while it runs: 'none', or a balancer of the reference "
                     "(adaptive|aimd|fixed: tests/golden/balancer_<name>.txt, generated from the reference's own balancer code); auto = adaptive for 1080p_ippp "

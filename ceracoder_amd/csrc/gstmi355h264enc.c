@@ -287,7 +287,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
     g_object_class_install_property(g, PROP_SPEED_PRESET, g_param_spec_enum("speed-preset", "Speed preset",
         "Accepted for x264enc pipeline compatibility; ignored", speed_preset_type(), 6, F));
     g_object_class_install_property(g, PROP_THREADS, g_param_spec_int("threads", "Entropy-coding threads",
-        "Host threads that code one slice row-parallel (bit-identical output); like x264enc's property of the same name, 0 = automatic (a quarter of the CPUs, at most 4), 1 = streaming thread only", 0, 64, 0, F));
+        "Host threads that code one slice row-parallel (bit-identical output); like x264enc's property of the same name, 0 = automatic (a quarter of the CPUs, at most 8), 1 = streaming thread only", 0, 64, 0, F));
     g_object_class_install_property(g, PROP_DCT8X8, g_param_spec_boolean("dct8x8", "8x8 transform",
         "Adaptive spatial transform size as in x264enc: High-profile stream, P macroblocks use the 8x8 transform", FALSE, F));
     g_object_class_install_property(g, PROP_STATS, g_param_spec_boolean("stats", "Print stats", "Print a JSON line with counters when the encoder closes", FALSE, F));

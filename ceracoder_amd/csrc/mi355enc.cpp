@@ -285,7 +285,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     if (h->cfg.cavlc_threads <= 0) { // auto, like x264enc's threads=0
         const unsigned hw = std::thread::hardware_concurrency();
         int n = (int)(hw / 4);
-        h->cfg.cavlc_threads = h->nmb < 1000 ? 1 : n < 1 ? 1 : n > 4 ? 4 : n;
+        h->cfg.cavlc_threads = h->nmb < 1000 ? 1 : n < 1 ? 1 : n > 8 ? 8 : n;
     }
     if (h->cfg.cavlc_threads > 1 && h264_writer_set_threads(h->writer, h->cfg.cavlc_threads)) return MI355ENC_ERR_NOMEM;
     rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);

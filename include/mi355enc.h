@@ -70,7 +70,7 @@ typedef struct {
                                  pieces (useful with GPU_MAX_HW_QUEUES raised) */
     int cavlc_threads;        /* host threads that code the slice (ranges of macroblock rows, concatenated bit-exactly into the
                                  same single slice); 1: the calling thread only; 0 (default, like x264enc's threads=0): chosen
-                                 from the machine -- a quarter of the online CPUs, between 1 and 4 (1 for pictures under
+                                 from the machine -- a quarter of the online CPUs, between 1 and 8 (1 for pictures under
                                  1000 macroblocks, where waking workers costs more than it saves); mi355enc_stats_t reports it */
     int intra_mode;           /* 0 (default): persistent band kernel for the intra reconstruction wavefront; 1: one launch per
                                  anti-diagonal replayed as a hipGraph (plain form, kept as a cross-check) */
