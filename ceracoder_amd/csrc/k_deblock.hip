@@ -273,6 +273,23 @@ DEV void edge_luma2(const edge_par &P, int p3, int &p2, int &p1, int &p0, int &q
     p1 = (f & wp1) ? np1 : p1; q1 = (f & wq1) ? nq1 : q1;
     p2 = f ? np2 : p2; q2 = f ? nq2 : q2;
 }
+DEV int bsel(int m, int a, int b) { return (a & m) | (b & ~m); } // v_bfi_b32: m all-ones -> a
+// Inner edges (bS < 4) with the conditions kept as VALU masks (sign bit of `value - threshold`, spread by an arithmetic
+// shift) instead of compares into SGPR pairs + s_and + v_cndmask: no VALU -> SALU -> VALU round trips on the chain.
+DEV void edge_luma_inner(const edge_par &P, int &p2, int &p1, int &p0, int &q0, int &q1, int &q2, int bS) {
+    const int alpha = P.alpha, beta = P.beta;
+    const int mf = ((adiff(p0, q0) - alpha) & (adiff(p1, p0) - beta) & (adiff(q1, q0) - beta) & -bS) >> 31; // all true (bS is 0..3 here)
+    const int map = (adiff(p2, p0) - beta) >> 31, maq = (adiff(q2, q0) - beta) >> 31;
+    const int tc0 = (int)((P.tc0 >> (8 * ((bS - 1) & 3))) & 0xFF); // bS 0 reads a don't-care byte
+    const int tc = tc0 - map - maq;
+    const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    const int avg = (p0 + q0 + 1) >> 1;
+    const int np1 = p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1);
+    const int nq1 = q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
+    const int np0 = clip255(p0 + dl), nq0 = clip255(q0 - dl);
+    p0 = bsel(mf, np0, p0); q0 = bsel(mf, nq0, q0);
+    p1 = bsel(mf & map, np1, p1); q1 = bsel(mf & maq, nq1, q1);
+}
 DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int bS) {
     const bool f = (bS != 0) & (adiff(p0, q0) < P.alpha) & (adiff(p1, p0) < P.beta) & (adiff(q1, q0) < P.beta);
     const int tc = (int)((P.tc0 >> (8 * ((bS - 1) & 3))) & 0xFF) + 1;
@@ -371,7 +388,7 @@ DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *ld
 #pragma unroll
                     for (int e = 1; e < 4; e++) {
                         const int bS = (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15);
-                        if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
+                        if (__ballot(bS != 0)) edge_luma_inner(PI, px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], bS);
                     }
                 }
                 if (act) {
@@ -433,7 +450,7 @@ DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *ld
 #pragma unroll
                         for (int e = 1; e < 4; e++) {
                             const int bS = (int)(((e < 2 ? bhl : bhh) >> (16 * (e & 1) + sh)) & 15);
-                            if (__ballot(bS != 0)) edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], bS, false);
+                            if (__ballot(bS != 0)) edge_luma_inner(PI, px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], bS);
                         }
                     }
                     if (act) {
