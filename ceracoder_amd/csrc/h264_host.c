@@ -494,32 +494,52 @@ static size_t write_slice_impl(h264_writer_t *w, uint8_t *out, size_t cap, int i
  *   - mb_qp_delta is 0 everywhere (one QP per picture);
  *   - mb_skip_run crosses range boundaries -> the first run of a range is left to the stitcher.
  * Each worker owns a private h264_writer (context arrays + bit buffer): no shared mutable state. */
-typedef struct {
-    h264_writer_t *w;          /* private writer */
+typedef struct {              /* one chunk of consecutive macroblock rows */
     int row0, row1;
-    bits_t bits;
+    const uint8_t *base;       /* where its bits start (inside the buffer of the thread that coded it) */
+    bits_t bits;               /* state at its end */
     rows_result_t res;
 } cavlc_job_t;
+/* The chunks of a picture (more of them than threads) are claimed dynamically: a worker that wakes up late simply finds
+ * fewer chunks left, so the caller never waits for a sleeping thread -- only for chunks somebody has started.  With a
+ * static split the slowest wake-up of a 16.7 ms-idle worker set the latency of every live picture. */
 struct cavlc_pool {
-    int n;                     /* workers including the calling thread */
+    int n;                     /* threads including the calling one */
     pthread_t *th;
-    cavlc_job_t *job;
+    h264_writer_t **wr;        /* private writer (context arrays + bit buffer) per thread */
+    uint8_t **cursor;          /* per thread: where its next chunk's bits go */
+    cavlc_job_t *job; int job_cap;
     pthread_mutex_t mu;
     pthread_cond_t cv_go, cv_done;
     unsigned long long generation;
-    int remaining, stop;
+    int nchunk, next, done, stop;
     /* per call */
     int is_idr, slice_qp;
     const mb_info_t *mbi;
     const int16_t *packed;
     const uint32_t *row_off;
 };
-static void cavlc_run_job(struct cavlc_pool *p, int k) {
-    cavlc_job_t *j = &p->job[k];
-    bits_init(&j->bits, j->w->rbsp, j->w->rbsp_cap);
-    if (j->row1 <= j->row0) { j->res.has_coded = 0; j->res.lead_skip = 0; j->res.trail_skip = 0; return; }
-    if (j->row0 > 0) fill_ctx_row(j->w, j->row0 - 1, p->mbi, p->packed + (size_t)p->row_off[j->row0 - 1] * 16);
-    j->res = code_rows(j->w, &j->bits, j->row0, j->row1, p->is_idr, p->slice_qp, p->mbi, NULL, p->packed + (size_t)p->row_off[j->row0] * 16, 1);
+static void cavlc_run_chunk(struct cavlc_pool *p, int k, int c) {
+    cavlc_job_t *j = &p->job[c];
+    h264_writer_t *w = p->wr[k];
+    j->base = p->cursor[k];
+    bits_init(&j->bits, p->cursor[k], (size_t)(w->rbsp + w->rbsp_cap - p->cursor[k]));
+    if (j->row0 > 0) fill_ctx_row(w, j->row0 - 1, p->mbi, p->packed + (size_t)p->row_off[j->row0 - 1] * 16);
+    j->res = code_rows(w, &j->bits, j->row0, j->row1, p->is_idr, p->slice_qp, p->mbi, NULL, p->packed + (size_t)p->row_off[j->row0] * 16, 1);
+    p->cursor[k] = j->bits.p + 8; /* past the partial word the chunk's state still holds */
+    if (p->cursor[k] > w->rbsp + w->rbsp_cap) p->cursor[k] = w->rbsp + w->rbsp_cap;
+}
+static void cavlc_work(struct cavlc_pool *p, int k) { /* claim chunks until none is left */
+    for (;;) {
+        pthread_mutex_lock(&p->mu);
+        const int c = p->next < p->nchunk ? p->next++ : -1;
+        pthread_mutex_unlock(&p->mu);
+        if (c < 0) return;
+        cavlc_run_chunk(p, k, c);
+        pthread_mutex_lock(&p->mu);
+        if (++p->done == p->nchunk) pthread_cond_signal(&p->cv_done);
+        pthread_mutex_unlock(&p->mu);
+    }
 }
 typedef struct { struct cavlc_pool *p; int k; } cavlc_arg_t;
 static void *cavlc_thread(void *arg) {
@@ -532,19 +552,16 @@ static void *cavlc_thread(void *arg) {
         if (a.p->stop) { pthread_mutex_unlock(&a.p->mu); return NULL; }
         seen = a.p->generation;
         pthread_mutex_unlock(&a.p->mu);
-        cavlc_run_job(a.p, a.k);
-        pthread_mutex_lock(&a.p->mu);
-        if (--a.p->remaining == 0) pthread_cond_signal(&a.p->cv_done);
-        pthread_mutex_unlock(&a.p->mu);
+        cavlc_work(a.p, a.k);
     }
 }
 static void cavlc_pool_free(struct cavlc_pool *p) {
     if (!p) return;
     pthread_mutex_lock(&p->mu); p->stop = 1; pthread_cond_broadcast(&p->cv_go); pthread_mutex_unlock(&p->mu);
-    for (int k = 1; k < p->n; k++) if (p->th[k]) pthread_join(p->th[k], NULL);
-    for (int k = 0; k < p->n; k++) if (p->job[k].w) { p->job[k].w->pool = NULL; h264_writer_free(p->job[k].w); }
+    for (int k = 1; k < p->n; k++) if (p->th && p->th[k]) pthread_join(p->th[k], NULL);
+    for (int k = 0; k < p->n; k++) if (p->wr && p->wr[k]) { p->wr[k]->pool = NULL; h264_writer_free(p->wr[k]); }
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_go); pthread_cond_destroy(&p->cv_done);
-    free(p->th); free(p->job); free(p);
+    free(p->th); free(p->wr); free(p->cursor); free(p->job); free(p);
 }
 int h264_writer_set_threads(h264_writer_t *w, int threads) {
     if (!w) return -1;
@@ -554,11 +571,14 @@ int h264_writer_set_threads(h264_writer_t *w, int threads) {
     struct cavlc_pool *p = (struct cavlc_pool *)calloc(1, sizeof *p);
     if (!p) return -1;
     p->n = threads;
+    p->job_cap = 4 * threads < w->mbh ? 4 * threads : w->mbh;
     p->th = (pthread_t *)calloc((size_t)threads, sizeof *p->th);
-    p->job = (cavlc_job_t *)calloc((size_t)threads, sizeof *p->job);
+    p->wr = (h264_writer_t **)calloc((size_t)threads, sizeof *p->wr);
+    p->cursor = (uint8_t **)calloc((size_t)threads, sizeof *p->cursor);
+    p->job = (cavlc_job_t *)calloc((size_t)p->job_cap, sizeof *p->job);
     pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv_go, NULL); pthread_cond_init(&p->cv_done, NULL);
-    int ok = p->th && p->job;
-    for (int k = 0; ok && k < threads; k++) { p->job[k].w = h264_writer_new(w->mbw, w->mbh, w->t8); ok = p->job[k].w != NULL; }
+    int ok = p->th && p->wr && p->cursor && p->job;
+    for (int k = 0; ok && k < threads; k++) { p->wr[k] = h264_writer_new(w->mbw, w->mbh, w->t8); ok = p->wr[k] != NULL; }
     for (int k = 1; ok && k < threads; k++) {
         cavlc_arg_t *a = (cavlc_arg_t *)malloc(sizeof *a);
         if (!a) { ok = 0; break; }
@@ -581,24 +601,30 @@ size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, 
     struct cavlc_pool *p = w->pool;
     if (!p || !row_off) return write_slice_impl(w, out, cap, is_idr, frame_num, idr_pic_id, slice_qp, mbi, NULL, packed);
     p->is_idr = is_idr; p->slice_qp = slice_qp; p->mbi = mbi; p->packed = packed; p->row_off = row_off;
-    for (int k = 0; k < p->n; k++) { p->job[k].row0 = (int)((long long)w->mbh * k / p->n); p->job[k].row1 = (int)((long long)w->mbh * (k + 1) / p->n); }
+    /* chunks of about four rows, at least one per thread and at most four: small enough to balance rows of unequal cost and to
+     * leave late threads nothing to hold up, large enough that deriving the context of the row above stays a small share */
+    int nchunk = w->mbh / 4;
+    if (nchunk < p->n) nchunk = p->n;
+    if (nchunk > p->job_cap) nchunk = p->job_cap;
+    for (int c = 0; c < nchunk; c++) { p->job[c].row0 = (int)((long long)w->mbh * c / nchunk); p->job[c].row1 = (int)((long long)w->mbh * (c + 1) / nchunk); }
+    for (int k = 0; k < p->n; k++) p->cursor[k] = p->wr[k]->rbsp;
     pthread_mutex_lock(&p->mu);
-    p->remaining = p->n - 1; p->generation++;
+    p->nchunk = nchunk; p->next = 0; p->done = 0; p->generation++;
     pthread_cond_broadcast(&p->cv_go);
     pthread_mutex_unlock(&p->mu);
-    cavlc_run_job(p, 0);
+    cavlc_work(p, 0);
     pthread_mutex_lock(&p->mu);
-    while (p->remaining) pthread_cond_wait(&p->cv_done, &p->mu);
+    while (p->done < p->nchunk) pthread_cond_wait(&p->cv_done, &p->mu);
     pthread_mutex_unlock(&p->mu);
     bits_t b;
     bits_init(&b, w->rbsp, w->rbsp_cap);
     slice_header(&b, is_idr, frame_num, idr_pic_id, slice_qp);
     int pending = 0;
-    for (int k = 0; k < p->n; k++) {
-        const cavlc_job_t *j = &p->job[k];
+    for (int c = 0; c < nchunk; c++) {
+        const cavlc_job_t *j = &p->job[c];
         if (j->res.has_coded) {
             if (!is_idr) bits_ue(&b, (uint32_t)(pending + j->res.lead_skip));
-            bits_append(&b, &j->bits, j->w->rbsp);
+            bits_append(&b, &j->bits, j->base);
             pending = j->res.trail_skip;
         } else pending += j->res.lead_skip;
     }
