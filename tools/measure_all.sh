@@ -1,3 +1,6 @@
+# Refreshes everything under profiles/ on a GPU box: bench lines of the four workloads and the multi-stream runs, the rocprofv3
+# kernel trace and the two PMC passes; afterwards (here): python tools/pmc_summary.py 1 1080p_ippp gpurun_out/final/ks/ks_results.db gpurun_out/final/pmc_f gpurun_out/final/pmc_w
+#   gpurun --timeout 1200 -- bash tools/measure_all.sh
 set -e
 R=$PWD
 mkdir -p gpurun_out/final
