@@ -20,10 +20,10 @@ DEV int pack_count(unsigned nz, unsigned mb_type) {
 template <int PER>
 __global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__restrict__ mbi, int nmb, int mbw, unsigned *__restrict__ off,
                                                            unsigned *__restrict__ hdr, const unsigned *__restrict__ err) {
-    __shared__ unsigned wsum[16];
+    __shared__ unsigned wsum[16], csum[16];
     const int tid = threadIdx.x, per = PER ? PER : (nmb + 1023) / 1024, base = tid * per;
     unsigned cnt[PER ? PER : 1];
-    unsigned mine = 0;
+    unsigned mine = 0, cost = 0; // cost: sum of the macroblocks' costs (scene-cut recovery on the host); < 2^20 each
     if (PER) {
 #pragma unroll
         for (int i = 0; i < PER; i++) {
@@ -31,17 +31,19 @@ __global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__re
             const uint4 r = ldg128(&mbi[mb < nmb ? mb : nmb - 1]);
             cnt[i] = mb < nmb ? (unsigned)pack_count(r.z, r.y & 255) : 0u;
             mine += cnt[i];
+            cost += mb < nmb ? r.w : 0u;
         }
     } else {
         for (int i = 0; i < per; i++) {
             const int mb = base + i;
-            if (mb < nmb) { const uint4 r = ldg128(&mbi[mb]); mine += (unsigned)pack_count(r.z, r.y & 255); }
+            if (mb < nmb) { const uint4 r = ldg128(&mbi[mb]); mine += (unsigned)pack_count(r.z, r.y & 255); cost += r.w; }
         }
     }
+    cost = (unsigned)wave64_sum((int)cost); // < 2^20 * 8 * 64 per wave: fits
     unsigned incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const unsigned v = __shfl_up(incl, d); if ((tid & 63) >= d) incl += v; }
-    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    if ((tid & 63) == 63) { wsum[tid >> 6] = incl; csum[tid >> 6] = cost; }
     __syncthreads();
     unsigned before = 0;
     for (int w = 0; w < (tid >> 6); w++) before += wsum[w];
@@ -66,7 +68,13 @@ __global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__re
             }
         }
     }
-    if (tid == 1023) { hdr[0] = run; hdr[1] = ldg32(err); } // total blocks; sticky error word of the band deblocker
+    if (tid == 1023) {
+        hdr[0] = run; hdr[1] = ldg32(err); // total blocks; sticky error word of the band deblocker
+        unsigned long long c64 = 0;
+        for (int w = 0; w < 16; w++) c64 += csum[w];
+        const int rows = (nmb + mbw - 1) / mbw;
+        hdr[2 + rows] = (unsigned)c64; hdr[3 + rows] = (unsigned)(c64 >> 32); // after the row offsets
+    }
 }
 // one wave per macroblock: lane c < 27 is one candidate block of the stream order above
 __global__ __launch_bounds__(256) void levels_pack_kernel(const mb_info_t *__restrict__ mbi, const int16_t *__restrict__ levels, int nmb,

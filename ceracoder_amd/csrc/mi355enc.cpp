@@ -51,6 +51,7 @@ struct slot_t {
     hipEvent_t ev_fe[MAX_PIECES], ev_db[MAX_PIECES]; // band-pipelined schedule: piece p's records + reconstruction final / piece p deblocked
     hipEvent_t pv[MAX_PIECES][6];              // stage timers of a sampled pipelined picture (created on first use)
     int pipelined, prof, fused;
+    uint64_t index;            // position of the picture in the stream
     int is_idr, qp, frame_num, idr_pic_id, rec_index, set;
     int64_t pts;
 };
@@ -69,6 +70,7 @@ struct mi355enc {
     int16_t *d_levels, *d_levels_set[2];
     hipStream_t cstream;                 // copy stream for the D2H hand-over
     uint64_t n_submitted;
+    uint64_t sc_sum, sc_force_at; int sc_cnt; // scene-cut recovery: summed cost / number of the P pictures since the last IDR; picture to force
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
     uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock
     uint8_t *d_idec;      // intra decisions, IDEC_BYTES per macroblock
@@ -115,7 +117,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0; c->cavlc_threads = 0; c->intra_mode = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1;
 }
 
 static unsigned *prog_set(const mi355enc_t *h, int set) { return h->d_progress + (size_t)set * h->n_progress; }
@@ -219,6 +221,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMemsetAsync(h->d_mbi_set[i], 0, (size_t)h->nmb * sizeof(mb_info_t), h->stream));
     }
     h->d_mbi = h->d_mbi_set[0]; h->d_levels = h->d_levels_set[0]; h->n_submitted = 0;
+    h->sc_sum = 0; h->sc_cnt = 0; h->sc_force_at = ~0ull;
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&h->d_rec_y[i], h->ysz + SURF_PAD));
         HIPCHK(hipMalloc((void **)&h->d_rec_uv[i], h->csz + SURF_PAD));
@@ -243,7 +246,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipHostMalloc((void **)&s->h_ctx, sizeof(frame_ctx_t), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&s->h_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&s->h_levels, (size_t)h->nmb * PACK_BLOCKS_MAX * 32, hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&s->h_hdr, (size_t)(2 + h->mbh) * sizeof(unsigned), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&s->h_hdr, (size_t)(4 + h->mbh) * sizeof(unsigned), hipHostMallocDefault)); // + the summed macroblock cost (two words)
         s->h_hdr[0] = s->h_hdr[1] = 0;
         HIPCHK(hipMalloc((void **)&s->d_src_y, h->ysz + SURF_PAD));
         HIPCHK(hipMalloc((void **)&s->d_src_uv, h->csz + SURF_PAD));
@@ -407,7 +410,8 @@ static int ensure_piece_timers(slot_t *s, int np) {
 // Correctness never depends on streams running concurrently: every spin-wait targets work submitted earlier.
 static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride,
                            int64_t pts, int force_idr, bool uploaded) {
-    const int idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop;
+    const int idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop ||
+                    (h->n_submitted == h->sc_force_at && h->prev_slot && !h->prev_slot->is_idr); // scene-cut recovery, see collect()
     if (idr) h->frames_since_idr = 0;
     // rate control: latch the setpoint written by the control thread, pick this picture's QP
     rc_set_bitrate(&h->rc, h->want_bps.load(std::memory_order_relaxed));
@@ -504,7 +508,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     HIPCHK(hipEventRecord(s->done, h->cstream));
     h->n_submitted++;
     s->is_idr = idr; s->qp = qp; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
-    s->pts = pts; s->rec_index = nxt; s->set = set; s->pipelined = pl ? 1 : 0; s->prof = prof; s->fused = fused && !idr;
+    s->pts = pts; s->rec_index = nxt; s->set = set; s->pipelined = pl ? 1 : 0; s->prof = prof; s->fused = fused && !idr; s->index = h->n_submitted - 1;
     if (idr) h->idr_count++;
     h->frames_since_idr++;
     h->cur = nxt; h->have_ref = 1; h->prev_slot = s;
@@ -612,6 +616,17 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     if (pts) *pts = s->pts;
     if (qp) *qp = s->qp;
     rc_update(&h->rc, s->is_idr, s->qp, n + m);
+    // Scene-cut recovery (cfg.scenecut; the oracle's orc_enc_frame applies the same rule): the summed cost of the picture's
+    // macroblocks came with the hand-over.  The decision lands on picture index + 2, the first one not submitted yet whatever
+    // the pipeline depth, and is skipped there if picture index + 1 turned out to be an IDR: the stream does not depend on
+    // the order of submit() and collect() calls.
+    if (s->is_idr) { h->sc_sum = 0; h->sc_cnt = 0; }
+    else {
+        const uint64_t cost = (uint64_t)s->h_hdr[2 + h->mbh] | ((uint64_t)s->h_hdr[3 + h->mbh] << 32);
+        const bool pending = h->sc_force_at != ~0ull && h->sc_force_at > s->index; // a decision not yet carried out stands
+        if (h->cfg.scenecut && !pending && h->sc_cnt >= 2 && cost > 3 * (h->sc_sum / (uint64_t)h->sc_cnt)) h->sc_force_at = s->index + 2;
+        h->sc_sum += cost; h->sc_cnt++;
+    }
     if (s->prof) {
         float a = 0, b = 0, c = 0, tot = 0, sp = 0, t = 0;
         if (s->pipelined) { // kernel times add up over the pieces; deblocking and the total are spans (the pieces run side by side)

@@ -74,6 +74,11 @@ typedef struct {
                                  1000 macroblocks, where waking workers costs more than it saves); mi355enc_stats_t reports it */
     int intra_mode;           /* 0 (default): persistent band kernel for the intra reconstruction wavefront; 1: one launch per
                                  anti-diagonal replayed as a hipGraph (plain form, kept as a cross-check) */
+    int scenecut;             /* 1 (default, like x264's scenecut): when the summed motion cost of a P picture exceeds three times
+                                 the mean of the P pictures since the last IDR (at least two of them), the picture two
+                                 positions later is coded as IDR -- recovery within two pictures instead of a GOP, with no wait
+                                 on the device (the sum arrives with the picture's hand-over).  0: IDR only every `gop`
+                                 pictures or on request */
 } mi355enc_cfg_t;
 
 typedef struct {

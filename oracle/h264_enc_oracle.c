@@ -1339,6 +1339,8 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
 struct orc_enc {
     int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads, subpel;
     int frames_since_idr, idr_count, have_ref;
+    int scenecut, sc_cnt, prev_idr;                      /* scene-cut recovery: mirrors mi355enc.cpp (collect / enqueue_picture) */
+    unsigned long long sc_sum, sc_force_at, pic_index;
     uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv;
     int cur; /* index of the surface holding the last reconstructed picture */
     orc_mbinfo_t *mbi;
@@ -1353,6 +1355,7 @@ orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop
     e->width = width; e->height = height;
     e->mbw = (width + 15) / 16; e->mbh = (height + 15) / 16; e->stride = e->mbw * 16;
     e->fps_num = fps_num; e->fps_den = fps_den; e->gop = gop; e->me_range = me_range; e->threads = threads; e->subpel = 1;
+    e->scenecut = 1; e->sc_force_at = ~0ull;
     size_t ysz = (size_t)e->stride * e->mbh * 16, csz = ysz / 2;
     e->src_y = (uint8_t *)malloc(ysz); e->src_uv = (uint8_t *)malloc(csz);
     e->pre_y = (uint8_t *)malloc(ysz); e->pre_uv = (uint8_t *)malloc(csz);
@@ -1386,7 +1389,7 @@ static void load_padded(orc_enc_t *e, const uint8_t *y, int ys, const uint8_t *u
 int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
                   int qp, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len, int *is_idr) {
     if (!e || qp < 0 || qp > 51) return -1;
-    int idr = force_idr || !e->have_ref || e->frames_since_idr >= e->gop;
+    int idr = force_idr || !e->have_ref || e->frames_since_idr >= e->gop || (e->pic_index == e->sc_force_at && !e->prev_idr);
     if (idr) { e->frames_since_idr = 0; }
     load_padded(e, y, y_stride, uv, uv_stride);
     int nxt = e->cur ^ 1;
@@ -1412,12 +1415,21 @@ int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *u
     if (!s) return -2;
     *out_len = n + s;
     if (is_idr) *is_idr = idr;
-    if (idr) e->idr_count++;
+    if (idr) { e->idr_count++; e->sc_sum = 0; e->sc_cnt = 0; }
+    else { /* summed macroblock cost of this P picture against the mean of the P pictures since the last IDR */
+        unsigned long long cost = 0;
+        for (int i = 0; i < e->mbw * e->mbh; i++) cost += e->mbi[i].cost;
+        const int pending = e->sc_force_at != ~0ull && e->sc_force_at > e->pic_index;
+        if (e->scenecut && !pending && e->sc_cnt >= 2 && cost > 3 * (e->sc_sum / (unsigned long long)e->sc_cnt)) e->sc_force_at = e->pic_index + 2;
+        e->sc_sum += cost; e->sc_cnt++;
+    }
+    e->prev_idr = idr; e->pic_index++;
     e->frames_since_idr++;
     e->cur = nxt; e->have_ref = 1;
     return 0;
 }
 void orc_enc_set_subpel(orc_enc_t *e, int on) { e->subpel = on; }
+void orc_enc_set_scenecut(orc_enc_t *e, int on) { e->scenecut = on; }
 const uint8_t *orc_enc_recon_y(const orc_enc_t *e) { return e->rec_y[e->cur]; }
 const uint8_t *orc_enc_recon_uv(const orc_enc_t *e) { return e->rec_uv[e->cur]; }
 const uint8_t *orc_enc_prefilter_y(const orc_enc_t *e) { return e->pre_y; }

@@ -102,7 +102,8 @@ typedef struct orc_enc orc_enc_t;
 orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop,
                         int me_range, int threads);
 void orc_enc_close(orc_enc_t *e);
-void orc_enc_set_subpel(orc_enc_t *e, int on); /* default on */
+void orc_enc_set_subpel(orc_enc_t *e, int on);
+void orc_enc_set_scenecut(orc_enc_t *e, int on); /* default on */
 /* Encode one NV12 frame at a caller-chosen QP.  Returns 0, or <0 on error. */
 int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv,
                   int uv_stride, int qp, int force_idr, uint8_t *out, size_t out_cap,

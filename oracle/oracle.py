@@ -54,6 +54,8 @@ def lib():
         L.orc_subpel_frame.restype = None
         L.orc_enc_set_subpel.argtypes = [vp, C.c_int]
         L.orc_enc_set_subpel.restype = None
+        L.orc_enc_set_scenecut.argtypes = [vp, C.c_int]
+        L.orc_enc_set_scenecut.restype = None
         L.orc_set_transform8x8.argtypes = [C.c_int]
         L.orc_set_transform8x8.restype = None
         L.orc_fdct8.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -121,12 +123,13 @@ def _view(ptr, shape, dtype):
 class Encoder:
     """Whole-encoder oracle: one NV12 frame + QP in, Annex-B access unit + stage outputs out."""
 
-    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True):
+    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True, scenecut=True):
         self.L = lib()
         self.h = self.L.orc_enc_open(width, height, fps, 1, gop, me_range, threads)
         if not self.h:
             raise ValueError("orc_enc_open failed")
         self.L.orc_enc_set_subpel(self.h, int(subpel))
+        self.L.orc_enc_set_scenecut(self.h, int(scenecut))
         self.width, self.height = width, height
         self.mbw, self.mbh = self.L.orc_enc_mbw(self.h), self.L.orc_enc_mbh(self.h)
         self._out = np.empty(self.mbw * self.mbh * 1024 + 4096, np.uint8)

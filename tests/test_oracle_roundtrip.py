@@ -87,3 +87,23 @@ def test_decoder_rejects_garbage(oracle):
     dec = oracle.Decoder()
     with pytest.raises(RuntimeError):
         dec.decode(bytes([0, 0, 0, 1, 0x65, 0x88, 0x84, 0x00]))
+
+
+def test_scene_cut_recovery_rule(oracle):
+    """A hard cut at picture 5 of a GOP of 30: the cut picture and the next stay P, picture 7 becomes IDR (the rule of
+    orc_enc_frame / mi355enc collect()); without the option the GOP runs its length.  The stream still decodes to the
+    encoder's reconstruction."""
+    from tests.util import cut_clip
+    w, h = 176, 144
+    clip = cut_clip(w, h, 12, 5)
+    for sc, want in ((True, [0, 7]), (False, [0])):
+        oe = oracle.Encoder(w, h, gop=30, threads=4, scenecut=sc)
+        dec = oracle.Decoder()
+        idrs = []
+        for i, (y, uv) in enumerate(clip):
+            au, key = oe.encode(y, uv, 30)
+            if key:
+                idrs.append(i)
+            dy, duv = dec.decode(au)
+            assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv)
+        assert idrs == want, (sc, idrs)

@@ -306,6 +306,35 @@ def test_band_pipelined_schedule_equals_oracle(E, oracle, w, h, n, ov):
     e.close()
 
 
+@pytest.mark.parametrize("depth", [0, 1])
+def test_scene_cut_recovery_equals_oracle(E, oracle, depth):
+    """cfg.scenecut: after a hard cut (picture 5) the picture two positions later is coded as IDR, identically to the oracle
+    and independently of the pipeline depth (the decision uses the cost sum that arrives with the hand-over of picture 5, and
+    lands on the first picture that cannot have been submitted yet)."""
+    from tests.util import cut_clip
+    w, h, n = 320, 192, 12
+    clip = cut_clip(w, h, n, 5)
+    e = E.Encoder(w, h, gop=30, fixed_qp=30, pipeline_depth=depth)
+    oe = oracle.Encoder(w, h, gop=30, threads=8)
+    got = []
+    for i, (y, uv) in enumerate(clip):
+        e.submit(y, uv, pts=i)
+        if e.pending > depth:
+            got.append(e.collect())
+    while e.pending:
+        got.append(e.collect())
+    keys = []
+    for i, (y, uv) in enumerate(clip):
+        ref_au, ref_key = oe.encode(y, uv, 30)
+        assert got[i][0] == ref_au, ("bitstream", i, len(got[i][0]), len(ref_au))
+        assert got[i][1] == ref_key
+        if ref_key:
+            keys.append(i)
+    assert keys == [0, 7], keys
+    assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y)
+    e.close()
+
+
 def test_noise_worst_case_roundtrip(E, oracle):
     """S3 (i.i.d. noise) at low QP: maximum-size levels, escape codes, every block coded."""
     w, h = 176, 144

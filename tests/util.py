@@ -33,3 +33,11 @@ def mbinfo_equal(a, b, fields):
 def first_diff(a, b):
     d = np.argwhere(np.asarray(a) != np.asarray(b))
     return None if len(d) == 0 else (tuple(d[0]), len(d))
+
+
+def cut_clip(w, h, n, cut):
+    """S2 clip with a hard scene change at picture `cut`: from there on the pictures come from the S3 (noise) generator --
+    nothing in the new scene is predictable from the old one, as at a real cut."""
+    a = list(synth.s2_frames(w, h, n))
+    b = list(synth.s3_frames(w, h, n))
+    return [(np.ascontiguousarray(y), np.ascontiguousarray(uv)) for y, uv in (a[:cut] + b[cut:])]
