@@ -629,13 +629,16 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     const bool mover = role == 0 ? (lane >= 24 && lane < 41) : (lane >= 41 && lane < 59);
     const int mi = role == 0 ? lane - 25 : (lane - 41) % 9 - 1, mc = role == 0 ? 0 : (lane - 41) / 9;
     // ... and the lanes that fetch for a fed row: 5 dwords starting 4 bytes left of the macroblock (the corner is byte 3 of dword 0)
-    const bool fetcher = fed && lane >= 24 && lane < 29;
     const uint8_t *frow = role == 0 ? ry + (size_t)(my * 16 - 1) * stride : ruv + (size_t)(my * 8 - 1) * stride;
     unsigned gpre = 0;
     int avail = 0;
     uint4 dec0n = make_uint4(0, 0, 0, 0);
     uint2 dec1n = make_uint2(0, 0);
-    uint2 srcn = make_uint2(0, 0); // this lane's source samples of the next macroblock (layout: intra_compute)
+    // this lane's source samples of the next macroblock (layout: intra_compute).  Two variables, not one filled by an if / else: with
+    // one, the luma side's address arithmetic reuses the registers the (predicated-off) chroma load writes, and the compiler guards
+    // that with an s_waitcnt vmcnt(0) -- issued right after the decision loads, i.e. a full memory latency on the chain.
+    unsigned srcn_y = 0;
+    uint2 srcn_c = make_uint2(0, 0);
     const int spy = (lane >> 2) & 3;
     const int nsteps = mbw + IB_ROWS + 1;
 #ifdef IB_PROF /* debug builds: cycles inside intra_compute per wave, and of the whole loop, left in ctx->isad */
@@ -652,26 +655,29 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
         // ---- land what was prefetched for this step, prefetch for the next one
         const uint4 dec0 = dec0n;
         const uint2 dec1 = dec1n;
-        const uint2 srcc = srcn;
+        const uint2 srcc = role == 0 ? make_uint2(srcn_y, 0u) : srcn_c;
         if (fed && act && lane >= 24 && lane < 29) stage[role][lane - 24] = gpre;
-        if (pf) {
-            const size_t mbn_n = (size_t)my * mbw + xn;
+        // Every load below is issued unconditionally, from an address clamped into range (results of steps that have no next
+        // macroblock are never read).  As conditional assignments to loop-carried values they would need a merge with the old value
+        // after the load -- a move into the register the load is still filling, which the compiler guards with s_waitcnt
+        // vmcnt: a full memory latency right after issuing, every step, on the luma wave (~1800 cycles; per-phase cycle
+        // counters of an -DIB_PROF build).
+        {
+            if (pf && fed && avail < xn + 1) avail = db_wait_get(prog_up, a.err, xn + 1); // polls (and waits for its own loads) before the prefetch is in flight
+            const int xc = xn < 0 ? 0 : (xn < mbw ? xn : mbw - 1), myc = row_ok ? my : mbh - 1;
+            const size_t mbn_n = (size_t)myc * mbw + xc;
             dec0n = ldg128(ctx->idec + mbn_n * IDEC_BYTES);
             dec1n = ldg64(ctx->idec + mbn_n * IDEC_BYTES + 16);
-            if (role == 0) {
-                int sy = my * 16 + 4 * (lane >> 4) + spy;
-                sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
-                srcn.x = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + xn * 16 + 4 * (lane & 3));
-            } else if (lane < 32) {
-                const int vh2 = ctx->vis_h >> 1;
-                int sy = my * 8 + 4 * (lane >> 4) + spy;
-                sy = sy < vh2 ? sy : vh2 - 1;
-                srcn = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * (xn * 8 + 4 * (lane & 1)));
-            }
-            if (fed) {
-                if (avail < xn + 1) avail = db_wait_get(prog_up, a.err, xn + 1);
-                if (fetcher) gpre = xn > 0 || lane > 24 ? ld_sc1((const unsigned *)(frow + xn * 16 - 4 + 4 * (lane - 24))) : 0u;
-            }
+            int sy = myc * 16 + 4 * (lane >> 4) + spy;
+            sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
+            srcn_y = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + xc * 16 + 4 * (lane & 3));
+            const int vh2 = ctx->vis_h >> 1;
+            int cy = myc * 8 + 4 * ((lane >> 4) & 1) + spy;
+            cy = cy < vh2 ? cy : vh2 - 1;
+            srcn_c = ldg64(ctx->src_uv + (size_t)cy * ctx->src_stride + 2 * (xc * 8 + 4 * (lane & 1)));
+            const int fl = lane < 24 ? 0 : (lane < 29 ? lane - 24 : 4);
+            const unsigned gv = ld_sc1((const unsigned *)(fed ? frow + xc * 16 - 4 + 4 * fl : ry)); // rows that are not fed read a harmless word
+            gpre = (xn > 0 || lane > 24) ? gv : 0u;
         }
         WAVE_SYNC();
         if (act) {

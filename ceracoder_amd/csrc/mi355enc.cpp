@@ -692,7 +692,7 @@ int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
     case MI355ENC_FETCH_MBINFO: src = h->last_slot ? h->last_slot->h_mbi : nullptr; need = (size_t)h->nmb * sizeof(mb_info_t); host = true; break;
     case MI355ENC_FETCH_LEVELS: src = h->last_slot ? h->d_levels_set[h->last_slot->set] : nullptr; need = (size_t)h->nmb * MB_LEVELS * 2; break; // dense, from HBM
     case 100: src = h->d_dbrec; need = (size_t)h->nmb * 64; break; /* development: deblocking records (cycle counters in -DD3_PROF builds) */
-    case 101: src = h->d_isad; need = 256; break;                  /* development: cycle counters of -DIB_PROF builds */
+    case 101: src = h->d_isad; need = 1024; break;                 /* development: cycle counters of -DIB_PROF builds */
     default: return MI355ENC_ERR_ARG;
     }
     if (!src) return MI355ENC_ERR_STATE;
