@@ -603,7 +603,9 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
 // the bottom row of a macroblock travels to the row below through a 4-deep LDS ring, its right column stays in the row's
 // own LDS for the next step.  Between bands the bottom rows of the last row are stored with `sc1` and announced through a
 // progress counter, exactly like the deblocking bands; the first row of a band prefetches them one step ahead.
-#define IB_ROWS 2
+#ifndef IB_ROWS
+#define IB_ROWS 4
+#endif
 struct ib_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; };
 
 __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
