@@ -41,6 +41,7 @@ typedef struct {
     gint device_id, me_range, qp, pipeline_depth, speed_preset;
     gboolean stats, dct8x8;
     gint threads;
+    gboolean scenecut;
     /* streaming state */
     mi355enc_t *enc;
     GstVideoCodecState *input_state;
@@ -53,7 +54,7 @@ typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 G_DEFINE_TYPE(GstMi355H264Enc, gst_mi355h264enc, GST_TYPE_VIDEO_ENCODER)
 
 enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME_RANGE, PROP_QP, PROP_PIPELINE_DEPTH,
-       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS };
+       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT };
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-raw, format=(string){ NV12, I420, YUY2, UYVY }, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
@@ -87,6 +88,7 @@ static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *
     case PROP_STATS: s->stats = g_value_get_boolean(val); break;
     case PROP_DCT8X8: s->dct8x8 = g_value_get_boolean(val); break;
     case PROP_THREADS: s->threads = g_value_get_int(val); break;
+    case PROP_SCENECUT: s->scenecut = g_value_get_boolean(val); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -106,6 +108,7 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     case PROP_STATS: g_value_set_boolean(val, s->stats); break;
     case PROP_DCT8X8: g_value_set_boolean(val, s->dct8x8); break;
     case PROP_THREADS: g_value_set_int(val, s->threads); break;
+    case PROP_SCENECUT: g_value_set_boolean(val, s->scenecut); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -149,7 +152,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     GST_OBJECT_LOCK(s);
     cfg.gop = s->key_int_max ? (int)s->key_int_max : 250;
     cfg.me_range = s->me_range; cfg.bitrate_bps = s->bps; cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
-    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0;
+    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0; cfg.scenecut = s->scenecut ? 1 : 0;
     GST_OBJECT_UNLOCK(s);
     int r = mi355enc_open(&cfg, &e);
     if (r != MI355ENC_OK) {
@@ -288,6 +291,8 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
         "Accepted for x264enc pipeline compatibility; ignored", speed_preset_type(), 6, F));
     g_object_class_install_property(g, PROP_THREADS, g_param_spec_int("threads", "Entropy-coding threads",
         "Host threads that code one slice row-parallel (bit-identical output); like x264enc's property of the same name, 0 = automatic (a quarter of the CPUs, at most 8), 1 = streaming thread only", 0, 64, 0, F));
+    g_object_class_install_property(g, PROP_SCENECUT, g_param_spec_boolean("scenecut", "Scene-cut recovery",
+        "Code an IDR picture two pictures after a scene cut (detected from the summed motion cost; x264 decides inside its lookahead instead)", TRUE, F));
     g_object_class_install_property(g, PROP_DCT8X8, g_param_spec_boolean("dct8x8", "8x8 transform",
         "Adaptive spatial transform size as in x264enc: High-profile stream, P macroblocks use the 8x8 transform", FALSE, F));
     g_object_class_install_property(g, PROP_STATS, g_param_spec_boolean("stats", "Print stats", "Print a JSON line with counters when the encoder closes", FALSE, F));
@@ -300,7 +305,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->bps = 2048000; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
-    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
+    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
 }
 
 GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */
