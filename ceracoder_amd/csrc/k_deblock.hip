@@ -194,11 +194,15 @@ DEV edge_par par_of(unsigned ab, unsigned tc) { edge_par p; p.alpha = (int)(ab &
 // Covers macroblocks [mb0, mb1); also zeroes two ranges of band progress counters (which ones: see the launch sites -- a
 // counter must be zero before any kernel that polls it can start, so a launch never clears counters its own picture's bands
 // are about to use unless everything else has been joined).
-__global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv, unsigned *__restrict__ clr_a, int n_a, unsigned *__restrict__ clr_b, int n_b, int mb0, int mb1) {
+// `flags`: one word per band of this picture's set, raised if any macroblock of the band has an edge with bS != 0 -- a band
+// without one has nothing to filter, and its workgroups publish "done" and leave at once (static parts of live pictures).
+__global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv, unsigned *__restrict__ clr_a, int n_a, unsigned *__restrict__ clr_b, int n_b,
+                                                           unsigned *__restrict__ clr_c, int n_c, unsigned *__restrict__ flags, int mb0, int mb1) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     const int j = blockIdx.x * 256 + threadIdx.x, i = mb0 + j;
     if (j < n_a) clr_a[j] = 0;
     if (j < n_b) clr_b[j] = 0;
+    if (j < n_c) clr_c[j] = 0;
     const int mbw = ctx->mbw;
     if (i >= mb1) return;
     const dev_tables *T = &g_tab;
@@ -230,6 +234,15 @@ __global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv,
     uint8_t *o = ctx->dbrec + (size_t)i * DBREC_BYTES;
 #pragma unroll
     for (int q = 0; q < 4; q++) stg128(o + 16 * q, make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]));
+    { // a wave covers 64 consecutive macroblocks: at most two bands; one atomic per band that has work
+        const int band = my / D3_ROWS, band0 = __builtin_amdgcn_readfirstlane(band);
+        const bool work = (bv | bh) != 0;
+        const unsigned long long m0 = __ballot(work && band == band0), m1 = __ballot(work && band != band0);
+        if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) { // the first active lane
+            if (m0) atomicOr(&flags[band0], 1u);
+            if (m1) atomicOr(&flags[band0 + 1], 1u);
+        }
+    }
 }
 
 typedef v4u v4u_a4 __attribute__((aligned(4)));
@@ -317,6 +330,10 @@ DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *ld
     const bool fed = row_ok && r == 0 && band > 0;
     const bool feeds = row_ok && r == D3_ROWS - 1 && !last_row;
     unsigned *prog_up = a.progress + (CHROMA ? nb : 0) + (band > 0 ? band - 1 : 0), *prog_my = a.progress + (CHROMA ? nb : 0) + band;
+    if (!ALL_INTRA && a.progress[2 * nb + band] == 0) { // no edge of this band has work (deblock_prep_kernel): its samples are final as they are.  The band below
+        if (threadIdx.x == 0) st_sc1(prog_my, 0x40000000u); // reads this band's bottom strip straight from the picture, which is what it needs
+        return;
+    }
     uint8_t *__restrict__ plane = CHROMA ? ctx->rec_uv : ctx->rec_y;
     const uint8_t *__restrict__ dbrec = ctx->dbrec;
     const size_t row0 = (size_t)my * rows_mb;
@@ -540,9 +557,13 @@ int k_deblock_bands16(int mbh) { return (mbh + D3_ROWS - 1) / D3_ROWS; }
 // `d_progress` holds 2 * bands counters (luma, chroma) followed by the sticky error word at d_err.  The prep kernel clears
 // the counters; the band kernel may be launched in several pieces (bands [band0, band1)): a band only ever waits for the
 // band above it, so pieces may run concurrently on different streams as long as the upper piece is submitted first.
-void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, unsigned *clr_a, int n_a, unsigned *clr_b, int n_b, hipStream_t s) {
-    const int n = (row1 - row0) * mbw, m = n > n_a ? (n > n_b ? n : n_b) : (n_a > n_b ? n_a : n_b);
-    if (m > 0) hipLaunchKernelGGL(deblock_prep_kernel, dim3((m + 255) / 256), dim3(256), 0, s, *h_ctx, clr_a, n_a, clr_b, n_b, row0 * mbw, row1 * mbw);
+void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, unsigned *clr_a, int n_a, unsigned *clr_b, int n_b, unsigned *clr_c, int n_c,
+                           unsigned *flags, hipStream_t s) {
+    int m = (row1 - row0) * mbw;
+    if (n_a > m) m = n_a;
+    if (n_b > m) m = n_b;
+    if (n_c > m) m = n_c;
+    if (m > 0) hipLaunchKernelGGL(deblock_prep_kernel, dim3((m + 255) / 256), dim3(256), 0, s, *h_ctx, clr_a, n_a, clr_b, n_b, clr_c, n_c, flags, row0 * mbw, row1 * mbw);
 }
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
     db_args a;

@@ -157,7 +157,9 @@ static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
 static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
     if (h->cfg.deblock_mode == 0) { // prep kernel (also clears the progress counters) + persistent 16-row band kernel
         const int nb = k_deblock_bands16(h->mbh);
-        k_launch_deblock_prep(hc, h->mbw, 0, h->mbh, h->d_progress, 2 * h->n_progress, nullptr, 0, h->stream); // nothing else is in flight: clear both sets
+        // nothing else is in flight: clear the other set entirely and this set's counters (its flags were cleared by the previous picture's prep
+        // kernel or at open; this launch raises them)
+        k_launch_deblock_prep(hc, h->mbw, 0, h->mbh, prog_set(h, ci ^ 1), h->n_progress, prog_set(h, ci), 2 * nb, nullptr, 0, prog_set(h, ci) + 2 * nb, h->stream);
         k_launch_deblock_bands(hc, h->mbh, 0, nb, prog_set(h, ci), err_word(h), h->stream);
         HIPCHK(hipGetLastError());
         return 0;
@@ -231,7 +233,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t)));
     HIPCHK(hipMalloc((void **)&h->d_dbrec, (size_t)h->nmb * 64));
     HIPCHK(hipMalloc((void **)&h->d_idec, (size_t)h->nmb * IDEC_BYTES + 16));
-    h->n_progress = 2 * k_deblock_bands16(h->mbh);
+    h->n_progress = 3 * k_deblock_bands16(h->mbh); // per set: luma counters, chroma counters, per-band "has work" flags
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
@@ -461,7 +463,8 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
             }
             if (p > 0) HIPCHK(hipStreamWaitEvent(st, s->ev_fe[p - 1], 0));
             if (prof) HIPCHK(hipEventRecord(s->pv[p][4], st));
-            k_launch_deblock_prep(c, h->mbw, r0, r1, prog_set(h, set ^ 1) + b0, b1 - b0, prog_set(h, set ^ 1) + nb + b0, b1 - b0, st); // clears for picture n+1 (below)
+            k_launch_deblock_prep(c, h->mbw, r0, r1, prog_set(h, set ^ 1) + b0, b1 - b0, prog_set(h, set ^ 1) + nb + b0, b1 - b0, prog_set(h, set ^ 1) + 2 * nb + b0, b1 - b0,
+                                  prog_set(h, set) + 2 * nb, st); // clears for picture n+1 (below)
             k_launch_deblock_bands(c, h->mbh, b0, b1, prog_set(h, set), err_word(h), st);
             if (prof) HIPCHK(hipEventRecord(s->pv[p][5], st));
             HIPCHK(hipEventRecord(s->ev_db[p], st));

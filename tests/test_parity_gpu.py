@@ -335,6 +335,33 @@ def test_scene_cut_recovery_equals_oracle(E, oracle, depth):
     e.close()
 
 
+@pytest.mark.parametrize("w,h,static_lines,ov", [(640, 528, 288, 0), (640, 528, 288, 3), (1280, 720, 512, 0), (320, 1040, 800, 0)])
+def test_idle_deblocking_bands_equal_oracle(E, oracle, w, h, static_lines, ov):
+    """Still background over a moving scene: the upper 16-row deblocking bands of the P pictures have no edge with bS != 0,
+    so their workgroups publish "done" and leave (deblock_prep_kernel's per-band flags); the bands below read the strips
+    above them straight from the picture.  Streams and reconstructions must still equal the oracle's, picture by picture."""
+    from tests.util import half_static_clip
+    clip = half_static_clip(w, h, 7, static_lines)
+    e = E.Encoder(w, h, gop=30, fixed_qp=38, overlap=ov, pipeline_depth=1 if ov else 0)
+    oe = oracle.Encoder(w, h, gop=30, threads=8)
+    got = []
+    for i, (y, uv) in enumerate(clip):
+        e.submit(y, uv, pts=i)
+        if e.pending > (1 if ov else 0):
+            got.append(e.collect())
+    while e.pending:
+        got.append(e.collect())
+    for i, (y, uv) in enumerate(clip):
+        ref_au, _ = oe.encode(y, uv, 38)
+        assert got[i][0] == ref_au, ("bitstream", i)
+        if i == len(clip) - 1: # the top band really is idle by now: no coded block, no vector in its 16 macroblock rows
+            mbi = oe.mbinfo.reshape(oe.mbh, oe.mbw)[:16]
+            assert not mbi["nzmask"].any() and not mbi["mvx"].any() and not mbi["mvy"].any()
+    assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y), first_diff(e.fetch(E.FETCH_RECON_Y), oe.recon_y)
+    assert np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv)
+    e.close()
+
+
 def test_noise_worst_case_roundtrip(E, oracle):
     """S3 (i.i.d. noise) at low QP: maximum-size levels, escape codes, every block coded."""
     w, h = 176, 144

@@ -41,3 +41,17 @@ def cut_clip(w, h, n, cut):
     a = list(synth.s2_frames(w, h, n))
     b = list(synth.s3_frames(w, h, n))
     return [(np.ascontiguousarray(y), np.ascontiguousarray(uv)) for y, uv in (a[:cut] + b[cut:])]
+
+
+def half_static_clip(w, h, n, static_lines):
+    """S2 clip whose top `static_lines` lines never change (a still background above a moving scene): whole deblocking
+    bands of the P pictures have no edge to filter."""
+    fr = list(synth.s2_frames(w, h, n))
+    y0, uv0 = fr[0]
+    out = []
+    for y, uv in fr:
+        y, uv = y.copy(), uv.copy()
+        y[:static_lines] = y0[:static_lines]
+        uv[:static_lines // 2] = uv0[:static_lines // 2]
+        out.append((y, uv))
+    return out
