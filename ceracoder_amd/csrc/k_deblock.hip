@@ -395,7 +395,7 @@ DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *ld
                     edge_luma2<true>(PL, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], (int)((bvl >> sh) & 15), true);
 #pragma unroll
                     for (int e = 1; e < 4; e++)
-                        edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15), false);
+                        edge_luma_inner(PI, px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], (int)(((e < 2 ? bvl : bvh) >> (16 * (e & 1) + sh)) & 15));
                 } else {
                     {
                         const int bS = (int)((bvl >> sh) & 15);
@@ -458,7 +458,7 @@ DEV void band16_body(const db_args &a, const int band, const int nb, uint8_t *ld
                         edge_luma2<true>(PT, px[0], px[1], px[2], px[3], px[4], px[5], px[6], px[7], (int)((bhl >> sh) & 15), true);
 #pragma unroll
                         for (int e = 1; e < 4; e++)
-                            edge_luma2<false>(PI, px[4 * e], px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], px[4 * e + 7], (int)(((e < 2 ? bhl : bhh) >> (16 * (e & 1) + sh)) & 15), false);
+                            edge_luma_inner(PI, px[4 * e + 1], px[4 * e + 2], px[4 * e + 3], px[4 * e + 4], px[4 * e + 5], px[4 * e + 6], (int)(((e < 2 ? bhl : bhh) >> (16 * (e & 1) + sh)) & 15));
                     } else {
                         {
                             const int bS = (int)((bhl >> sh) & 15);
