@@ -106,3 +106,25 @@ def test_latency_probe_runs_the_graph_and_fails_loudly_without_a_device():
         assert r.returncode == 0 and json.loads(r.stdout.splitlines()[-1])["samples"] == 3, r.stderr
     else:
         assert r.returncode == 3 and "no usable HIP device" in r.stderr, r.stderr
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r01_bench_1080p_ippp.json is the line bench.py printed on the GPU box: the keys the driver reads, the roofline
+    object (algorithmic bytes / live launch time, agreeing with the rocprofv3 kernel trace and the PMC pass) and the CPU baseline."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_1080p_ippp.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "u8"
+    assert d["config"]["workload"] == "1080p_ippp" and "model" not in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 0.02  # value = pictures / time
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.05
+    assert r["algorithmic_bytes_per_launch"] == int(3.0625 * 1920 * 1088)             # SURVEY 8(d): deblocking, 3.0625 P
+    assert r["traffic"] and r["traffic"] >= r["algorithmic_bytes_per_launch"]          # PMC bytes, at least the algorithmic ones
+    assert abs(r["kernel_trace_avg_us"] - r["avg_launch_us"]) / r["avg_launch_us"] < 0.15  # HIP events (prep + band kernel) vs kernel trace (band kernel)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert any(k["kernel"] == "me_kernel" for k in d["roofline_kernels"])              # the kernel north_star names is listed
