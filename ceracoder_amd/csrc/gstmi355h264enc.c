@@ -10,6 +10,10 @@
  *  - the property the binary writes is "bps"        .../encoder_control.c:53
  *    (README/docs call it "bitrate": /root/reference/README.md:256) -> both exist here and
  *    alias one target; "bitrate" is kbit/s with x264enc's default 2048
+ *  - every x264 pipeline file of the reference says `name=venc_kbps`
+ *    (pipeline/generic/x264_*:5-6, generic-builder.ts:54), for which encoder_control.c:53
+ *    writes bitrate / 1000 into "bps": an element NAMED venc_kbps therefore reads and writes
+ *    "bps" in kbit/s, so that such a file works with only the factory token changed
  *  - first write happens in state NULL, before PLAYING /root/reference/src/ceracoder.c:515-518
  *  - later writes come from the GLib main thread every <= 20 ms while the streaming thread
  *    encodes                                         /root/reference/src/ceracoder.c:266-295
@@ -46,6 +50,8 @@ typedef struct {
     mi355enc_t *enc;
     GstVideoCodecState *input_state;
     gsize max_au;
+    guint8 *au_buf;     /* access units are coded here (worst-case size, allocated once per format) and copied into right-sized buffers */
+    GstClockTime last_pts;
 } GstMi355H264Enc;
 typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 
@@ -73,11 +79,19 @@ static GType speed_preset_type(void) {
     return t;
 }
 
+/* The unit of "bps" follows the reference's naming rule (encoder_control.c:29-32,53): an element named venc_kbps is sent
+ * bitrate / 1000.  Called with the object lock held (the name is guarded by it). */
+static guint bps_unit(GstMi355H264Enc *s) {
+    const gchar *n = GST_OBJECT_NAME(s);
+    return (n && strcmp(n, "venc_kbps") == 0) ? 1000u : 1u;
+}
+static guint clamp_bps(guint64 v) { return v < 1000 ? 1000u : v > 1000000000u ? 1000000000u : (guint)v; }
+
 static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *ps) {
     GstMi355H264Enc *s = GST_MI355H264ENC(obj);
     GST_OBJECT_LOCK(s);
     switch (id) {
-    case PROP_BPS: s->bps = g_value_get_uint(val); if (s->enc) mi355enc_set_bitrate(s->enc, s->bps); break;
+    case PROP_BPS: s->bps = clamp_bps((guint64)g_value_get_uint(val) * bps_unit(s)); if (s->enc) mi355enc_set_bitrate(s->enc, s->bps); break;
     case PROP_BITRATE: s->bps = g_value_get_uint(val) * 1000u; if (s->enc) mi355enc_set_bitrate(s->enc, s->bps); break;
     case PROP_KEY_INT_MAX: s->key_int_max = g_value_get_uint(val); break;
     case PROP_DEVICE_ID: s->device_id = g_value_get_int(val); break;
@@ -97,7 +111,7 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     GstMi355H264Enc *s = GST_MI355H264ENC(obj);
     GST_OBJECT_LOCK(s);
     switch (id) {
-    case PROP_BPS: g_value_set_uint(val, s->bps); break;
+    case PROP_BPS: g_value_set_uint(val, s->bps / bps_unit(s)); break;
     case PROP_BITRATE: g_value_set_uint(val, s->bps / 1000u); break;
     case PROP_KEY_INT_MAX: g_value_set_uint(val, s->key_int_max); break;
     case PROP_DEVICE_ID: g_value_set_int(val, s->device_id); break;
@@ -124,7 +138,8 @@ static void close_encoder(GstMi355H264Enc *s) {
             mi355enc_stats_t st;
             if (mi355enc_get_stats(e, &st) == 0)
                 g_printerr("{\"element\":\"mi355h264enc\",\"frames\":%" G_GUINT64_FORMAT ",\"idr\":%" G_GUINT64_FORMAT ",\"bytes\":%" G_GUINT64_FORMAT
-                           ",\"ms_entropy\":%.3f,\"ms_wait\":%.3f,\"last_qp\":%u}\n", st.frames, st.idr_frames, st.bytes, st.ms_entropy, st.ms_wait, st.last_qp);
+                           ",\"ms_entropy\":%.3f,\"ms_wait\":%.3f,\"last_qp\":%u,\"open_ms\":%.1f,\"target_bps\":%u}\n", st.frames, st.idr_frames, st.bytes,
+                           st.ms_entropy, st.ms_wait, st.last_qp, st.ms_open, st.target_bps);
         }
         mi355enc_close(e);
     }
@@ -133,8 +148,10 @@ static gboolean enc_stop(GstVideoEncoder *ve) {
     GstMi355H264Enc *s = GST_MI355H264ENC(ve);
     close_encoder(s);
     if (s->input_state) { gst_video_codec_state_unref(s->input_state); s->input_state = NULL; }
+    g_free(s->au_buf); s->au_buf = NULL;
     return TRUE;
 }
+static GstFlowReturn drain(GstMi355H264Enc *s, gboolean push);
 static gboolean enc_start(GstVideoEncoder *ve) {
     (void)ve;
     return TRUE; /* geometry is unknown until set_format; the device is opened there, still before data flows */
@@ -147,6 +164,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     mi355enc_t *e = NULL;
     int fn = GST_VIDEO_INFO_FPS_N(vi), fd = GST_VIDEO_INFO_FPS_D(vi);
     if (fn <= 0 || fd <= 0) { fn = 30; fd = 1; } /* variable framerate: rate control assumes 30 */
+    if (s->enc) drain(s, TRUE); /* renegotiation in mid-stream: the picture still on the device belongs to the old format (x264enc flushes here too) */
     close_encoder(s);
     mi355enc_default_cfg(&cfg, GST_VIDEO_INFO_WIDTH(vi), GST_VIDEO_INFO_HEIGHT(vi), fn, fd);
     GST_OBJECT_LOCK(s);
@@ -166,6 +184,14 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     mi355enc_set_bitrate(e, s->bps); /* a write that raced with open() must not be lost */
     GST_OBJECT_UNLOCK(s);
     s->max_au = mi355enc_max_au_bytes(e);
+    g_free(s->au_buf);
+    s->au_buf = g_malloc(s->max_au);
+    s->last_pts = GST_CLOCK_TIME_NONE;
+    {
+        mi355enc_stats_t st;
+        if (mi355enc_get_stats(e, &st) == 0)
+            GST_INFO_OBJECT(s, "opened %dx%d @%d/%d on device %d in %.1f ms, target %u bit/s, gop %d", cfg.width, cfg.height, fn, fd, cfg.device_id, st.ms_open, cfg.bitrate_bps, cfg.gop);
+    }
     if (s->input_state) gst_video_codec_state_unref(s->input_state);
     s->input_state = gst_video_codec_state_ref(state);
     GstCaps *caps = gst_caps_new_simple("video/x-h264", "stream-format", G_TYPE_STRING, "byte-stream", "alignment", G_TYPE_STRING, "au",
@@ -179,27 +205,31 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     return gst_video_encoder_negotiate(ve);
 }
 
-/* entropy-code the oldest submitted picture into `frame` and push it */
+/* entropy-code the oldest submitted picture and push it in a buffer of exactly its size (the worst case, max_au, is
+ * 12 MB at 1080p: buffers of that capacity would sit in the downstream queues of the reference's pipelines, which hold up
+ * to 1000 of them -- pipeline/generic/x264_superfast_camlink:7) */
 static GstFlowReturn collect_into(GstMi355H264Enc *s, GstVideoCodecFrame *frame) {
     GstVideoEncoder *ve = GST_VIDEO_ENCODER(s);
-    GstMapInfo map;
     size_t len = 0;
-    int key = 0;
-    GstFlowReturn fr = gst_video_encoder_allocate_output_frame(ve, frame, s->max_au);
-    if (fr != GST_FLOW_OK) { gst_video_encoder_finish_frame(ve, frame); return fr; }
-    if (!gst_buffer_map(frame->output_buffer, &map, GST_MAP_WRITE)) { gst_video_encoder_finish_frame(ve, frame); return GST_FLOW_ERROR; }
-    int r = mi355enc_collect(s->enc, map.data, map.size, &len, &key, NULL, NULL);
-    gst_buffer_unmap(frame->output_buffer, &map);
+    int key = 0, qp = 0;
+    int r = mi355enc_collect(s->enc, s->au_buf, s->max_au, &len, &key, NULL, &qp);
     if (r != MI355ENC_OK) {
         GST_ELEMENT_ERROR(s, STREAM, ENCODE, ("mi355h264enc: encode failed: %s", mi355enc_strerror(r)), ("mi355enc_collect returned %d", r));
-        gst_buffer_replace(&frame->output_buffer, NULL);
         gst_video_encoder_finish_frame(ve, frame);
         return GST_FLOW_ERROR;
     }
-    gst_buffer_set_size(frame->output_buffer, (gssize)len);
+    GstFlowReturn fr = gst_video_encoder_allocate_output_frame(ve, frame, len);
+    if (fr != GST_FLOW_OK) { gst_video_encoder_finish_frame(ve, frame); return fr; }
+    gst_buffer_fill(frame->output_buffer, 0, s->au_buf, len);
     if (key) GST_VIDEO_CODEC_FRAME_SET_SYNC_POINT(frame);
     else GST_VIDEO_CODEC_FRAME_UNSET_SYNC_POINT(frame);
-    frame->dts = frame->pts; /* no reordering; upstream forces DTS to 0 (ceracoder.c:377) */
+    /* No reordering: DTS = PTS.  Upstream (`identity name=ptsfixup`, ceracoder.c:371-423) rewrites PTS onto a fixed grid and
+     * zeroes DTS; whatever arrives, the PTS sequence leaving here never runs backwards (mpegtsmux and SRT receivers reject
+     * that), so a picture stamped at or before its predecessor takes the predecessor's stamp. */
+    if (GST_CLOCK_TIME_IS_VALID(frame->pts) && GST_CLOCK_TIME_IS_VALID(s->last_pts) && frame->pts < s->last_pts) frame->pts = s->last_pts;
+    if (GST_CLOCK_TIME_IS_VALID(frame->pts)) s->last_pts = frame->pts;
+    frame->dts = frame->pts;
+    GST_LOG_OBJECT(s, "access unit %" G_GSIZE_FORMAT " bytes, %s, qp %d, pts %" GST_TIME_FORMAT, len, key ? "IDR" : "P", qp, GST_TIME_ARGS(frame->pts));
     return gst_video_encoder_finish_frame(ve, frame);
 }
 
@@ -207,6 +237,12 @@ static GstFlowReturn enc_handle_frame(GstVideoEncoder *ve, GstVideoCodecFrame *f
     GstMi355H264Enc *s = GST_MI355H264ENC(ve);
     GstVideoFrame vf;
     if (!s->enc || !s->input_state) { gst_video_encoder_finish_frame(ve, frame); return GST_FLOW_NOT_NEGOTIATED; }
+    if (GST_BUFFER_FLAG_IS_SET(frame->input_buffer, GST_BUFFER_FLAG_DROPPABLE)) {
+        /* what `identity name=ptsfixup` does to a picture that arrived too early to get a slot on its PTS grid (ceracoder.c:414-419:
+         * "dropping an input buffer"): it keeps its raw, non-monotone PTS.  Not coded, no output buffer. */
+        GST_DEBUG_OBJECT(s, "input picture flagged DROPPABLE (pts %" GST_TIME_FORMAT "): not coded", GST_TIME_ARGS(frame->pts));
+        return gst_video_encoder_finish_frame(ve, frame);
+    }
     if (!gst_video_frame_map(&vf, &s->input_state->info, frame->input_buffer, GST_MAP_READ)) {
         gst_video_encoder_finish_frame(ve, frame);
         return GST_FLOW_ERROR;
@@ -250,9 +286,7 @@ static GstFlowReturn drain(GstMi355H264Enc *s, gboolean push) {
         if (push) fr = collect_into(s, old);
         else {
             size_t n = 0;
-            guint8 *tmp = g_malloc(s->max_au);
-            mi355enc_collect(s->enc, tmp, s->max_au, &n, NULL, NULL, NULL);
-            g_free(tmp);
+            mi355enc_collect(s->enc, s->au_buf, s->max_au, &n, NULL, NULL, NULL);
             gst_video_encoder_finish_frame(ve, old); /* no output buffer: dropped */
         }
         if (fr != GST_FLOW_OK) break;
@@ -277,7 +311,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
     const GParamFlags F = (GParamFlags)(G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS | GST_PARAM_MUTABLE_PLAYING);
     g->set_property = set_property; g->get_property = get_property; g->finalize = finalize;
     g_object_class_install_property(g, PROP_BPS, g_param_spec_uint("bps", "Bitrate (bit/s)",
-        "Target bitrate in bit/s; the property ceracoder's encoder_control writes (use with name=venc_bps)", 1000, 1000000000, 2048000, F));
+        "Target bitrate; the property ceracoder's encoder_control writes.  In bit/s -- except on an element named venc_kbps, which the reference sends kbit/s (encoder_control.c:29-32,53)", 1, 1000000000, 2048000, F));
     g_object_class_install_property(g, PROP_BITRATE, g_param_spec_uint("bitrate", "Bitrate (kbit/s)",
         "Target bitrate in kbit/s (x264enc-compatible alias of bps)", 1, 1000000, 2048, F));
     g_object_class_install_property(g, PROP_KEY_INT_MAX, g_param_spec_uint("key-int-max", "Key-frame interval",
@@ -305,7 +339,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->bps = 2048000; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
-    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->enc = NULL; s->input_state = NULL; s->max_au = 0;
+    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
 }
 
 GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */

@@ -634,6 +634,22 @@ size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, 
     return emit_nal(out, cap, is_idr ? 3 : 2, is_idr ? 5 : 1, w->rbsp, n);
 }
 
+size_t h264_pack_levels(int mbw, int mbh, const mb_info_t *mbi, const int16_t *levels, int16_t *packed, uint32_t *row_off) {
+    const size_t nmb = (size_t)mbw * mbh;
+    size_t nblk = 0;
+    for (size_t mb = 0; mb < nmb; mb++) {
+        const uint32_t nz = mbi[mb].nzmask;
+        const int16_t *lv = levels + mb * MB_LEVELS;
+        if (mb % (size_t)mbw == 0) row_off[mb / (size_t)mbw] = (uint32_t)nblk;
+        if (mbi[mb].mb_type == 2) memcpy(packed + 16 * nblk++, lv + L_LDC, 32);
+        if (nz & NZ_LDC) memcpy(packed + 16 * nblk++, lv + L_LDC, 32);
+        for (int i = 0; i < 16; i++) if ((nz >> i) & 1) memcpy(packed + 16 * nblk++, lv + L_LUMA + 16 * i, 32);
+        if (nz & (NZ_CBDC | NZ_CRDC)) memcpy(packed + 16 * nblk++, lv + L_CDC, 32);
+        for (int i = 0; i < 8; i++) if ((nz >> (16 + i)) & 1) memcpy(packed + 16 * nblk++, lv + L_CAC + 16 * i, 32);
+    }
+    return nblk;
+}
+
 size_t h264_write_slice(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                         int slice_qp, const mb_info_t *mbi, const int16_t *levels) {
     return write_slice_impl(w, out, cap, is_idr, frame_num, idr_pic_id, slice_qp, mbi, levels, NULL);

@@ -89,6 +89,7 @@ struct mi355enc {
     std::atomic<uint32_t> want_bps;
     std::atomic<int> fixed_qp;
     mi355enc_stats_t st;
+    double ms_open;
 };
 
 static double now_ms() {
@@ -174,6 +175,7 @@ static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
 int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     if (!cfg || !out) return MI355ENC_ERR_ARG;
     *out = nullptr;
+    const double t_open = now_ms();
     if (cfg->width < 16 || cfg->height < 16 || cfg->width > 8192 || cfg->height > 8192 || (cfg->width & 1) || (cfg->height & 1) ||
         cfg->fps_num <= 0 || cfg->fps_den <= 0 || cfg->gop < 1 || cfg->me_range < 1 || cfg->me_range > 16 ||
         cfg->pipeline_depth < 0 || cfg->pipeline_depth > NSLOT - 1 || cfg->fixed_qp > 51) {
@@ -296,6 +298,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipStreamSynchronize(h->astream));
+    h->ms_open = now_ms() - t_open;
     return MI355ENC_OK;
 }
 
@@ -679,6 +682,7 @@ int mi355enc_get_stats(mi355enc_t *h, mi355enc_stats_t *st) {
     *st = h->st;
     st->target_bps = h->want_bps.load();
     st->cavlc_threads = (uint32_t)h->cfg.cavlc_threads;
+    st->ms_open = h->ms_open;
     return MI355ENC_OK;
 }
 void mi355enc_reset_stats(mi355enc_t *h) { if (h) memset(&h->st, 0, sizeof h->st); }
@@ -888,17 +892,7 @@ int mi355enc_host_write_slice_packed(int mbw, int mbh, int is_idr, int frame_num
     h264_writer_t *w = h264_writer_new(mbw, mbh, t8);
     int rc = MI355ENC_ERR_NOMEM;
     if (packed && row_off && w && h264_writer_set_threads(w, threads) == 0) {
-        size_t nblk = 0;
-        for (size_t mb = 0; mb < nmb; mb++) {
-            const uint32_t nz = mbi[mb].nzmask;
-            const int16_t *lv = levels + mb * MB_LEVELS;
-            if (mb % mbw == 0) row_off[mb / mbw] = (uint32_t)nblk;
-            if (mbi[mb].mb_type == 2) memcpy(packed + 16 * nblk++, lv + L_LDC, 32);
-            if (nz & NZ_LDC) memcpy(packed + 16 * nblk++, lv + L_LDC, 32);
-            for (int i = 0; i < 16; i++) if ((nz >> i) & 1) memcpy(packed + 16 * nblk++, lv + L_LUMA + 16 * i, 32);
-            if (nz & (NZ_CBDC | NZ_CRDC)) memcpy(packed + 16 * nblk++, lv + L_CDC, 32);
-            for (int i = 0; i < 8; i++) if ((nz >> (16 + i)) & 1) memcpy(packed + 16 * nblk++, lv + L_CAC + 16 * i, 32);
-        }
+        h264_pack_levels(mbw, mbh, mbi, levels, packed, row_off);
         size_t n = h264_write_slice_packed_rows(w, out, cap, is_idr, frame_num, idr_pic_id, qp, mbi, packed, row_off);
         rc = n ? MI355ENC_OK : MI355ENC_ERR_OVERFLOW;
         *out_len = n;

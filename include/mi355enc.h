@@ -95,6 +95,8 @@ typedef struct {
     uint64_t n_deblock_idr;
     uint32_t cavlc_threads;   /* host threads in use for entropy coding (cfg.cavlc_threads resolved) */
     uint32_t reserved0;
+    double ms_open;           /* wall time mi355enc_open() took (device selection, allocations, stream creation): must stay far below
+                                 the 1 s tick of the reference's stall watchdog, /root/reference/src/ceracoder.c:152-200; survives reset_stats */
 } mi355enc_stats_t;
 
 /* Fill cfg with the defaults of the element (gop 60, me_range 16, 2048 kbit/s like x264enc). */

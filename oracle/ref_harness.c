@@ -16,6 +16,13 @@
  * does for srt_send, but over UDP to a loopback socket (libsrt is absent: the t2 - t1 segment is
  * "UDP loopback, same packetisation", not SRT).
  *
+ * Timestamp contract: an `identity name=ptsfixup signal-handoffs=TRUE` in the pipeline gets a handoff
+ * that restates cb_ptsfixup (/root/reference/src/ceracoder.c:371-423: DTS forced to 0, PTS moved onto a grid of one
+ * rolling-average frame period, pictures that arrive too early flagged DROPPABLE with their raw PTS); an
+ * `identity name=jitter signal-handoffs=TRUE` in front of it gets a handoff that damages the timestamps the way a capture
+ * device does (jitter of a few ms, repeated PTS, a picture stamped two periods early, garbage DTS).  The summary counts
+ * what left the pipeline: samples whose DTS differs from their PTS and samples whose PTS ran backwards.
+ *
  * usage: ref_harness PIPELINE_FILE OUT_FILE [SCRIPT_FILE]     (script lines: "<ms> <bps>")
  */
 #include <arpa/inet.h>
@@ -56,6 +63,46 @@ static struct sockaddr_in udp_dst;
 static unsigned char pkt[PKT_SIZE];
 static int pkt_len;
 static guint64 n_datagrams;
+
+/* ---- timestamp damage + the reference's repair (both optional, by element name) */
+static guint64 n_dts_ne_pts, n_pts_backwards, n_pts_repeated, n_droppable_in, last_out_pts = GST_CLOCK_TIME_NONE;
+static void jitter_cb(GstElement *identity, GstBuffer *buffer, gpointer user) {
+    (void)identity; (void)user;
+    static guint64 i, prev;
+    guint64 pts = GST_BUFFER_PTS(buffer);
+    gint64 d = ((gint64)((i * 7919u) % 5u) - 2) * 3 * GST_MSECOND; /* -6 .. +6 ms */
+    if (i && i % 17 == 0) pts = prev;                              /* the same stamp twice */
+    else if (i && i % 29 == 0) pts = pts > 40 * GST_MSECOND ? pts - 40 * GST_MSECOND : 0; /* far too early */
+    else if ((gint64)pts + d > 0) pts = (guint64)((gint64)pts + d);
+    GST_BUFFER_PTS(buffer) = pts;
+    GST_BUFFER_DTS(buffer) = (i * 1000003u) % 7919u; /* garbage: the encoder must not look at it */
+    prev = pts; i++;
+}
+static int sink_framerate(GstElement *e, int *num, int *den) {
+    GstPad *pad = gst_element_get_static_pad(e, "sink");
+    GstCaps *caps = pad ? gst_pad_get_current_caps(pad) : NULL;
+    int ok = 0;
+    if (caps && gst_caps_get_size(caps) > 0) ok = gst_structure_get_fraction(gst_caps_get_structure(caps, 0), "framerate", num, den);
+    if (caps) gst_caps_unref(caps);
+    if (pad) gst_object_unref(pad);
+    return ok && *num > 0 && *den > 0;
+}
+static void ptsfixup_cb(GstElement *identity, GstBuffer *buffer, gpointer user) { /* restates ceracoder.c:371-423 */
+    (void)user;
+    static gint64 out_pts, period, prev_in;
+    const gint64 in = (gint64)GST_BUFFER_PTS(buffer);
+    GST_BUFFER_DTS(buffer) = 0;                                    /* :377 */
+    if (out_pts == 0) {                                            /* first picture: nominal period from the caps */
+        int n = 0, d = 0;
+        if (sink_framerate(identity, &n, &d)) { out_pts = in; period = (gint64)GST_SECOND * d / n; }
+    } else {
+        period = (period * 997 + 500) / 1000 + ((in - prev_in) * 3 + 500) / 1000;  /* rolling average, weight 3/1000 */
+        const gint64 diff = in - out_pts, incr = (diff / 2 + period) / period * period;
+        if (incr > 0) { out_pts += incr; GST_BUFFER_PTS(buffer) = (guint64)out_pts; }
+        else { GST_BUFFER_FLAG_SET(buffer, GST_BUFFER_FLAG_DROPPABLE); n_droppable_in++; } /* :414-419 */
+    }
+    prev_in = in;
+}
 
 static GstPadProbeReturn enc_sink_probe(GstPad *pad, GstPadProbeInfo *info, gpointer user) {
     (void)pad; (void)user;
@@ -109,6 +156,10 @@ static GstFlowReturn new_buf_cb(GstAppSink *sink, gpointer user) {
     if (gst_buffer_map(buf, &map, GST_MAP_READ)) {
         guint32 len = (guint32)map.size;
         guint64 pts = GST_BUFFER_PTS(buf);
+        if (GST_BUFFER_DTS(buf) != pts) n_dts_ne_pts++;
+        if (last_out_pts != GST_CLOCK_TIME_NONE && pts < last_out_pts) n_pts_backwards++;
+        if (last_out_pts != GST_CLOCK_TIME_NONE && pts == last_out_pts) n_pts_repeated++;
+        last_out_pts = pts;
         send_regrouped(map.data, map.size);
         const gint64 t2 = g_get_monotonic_time();
         gint64 t0 = -1;
@@ -167,12 +218,18 @@ int main(int argc, char **argv) {
     int have_enc = encoder_control_init(&enc, pipeline) == 0;
     int first = script_n ? script[0].bps : 6000000;
     if (have_enc) encoder_control_set_bitrate(&enc, first); /* state NULL, as ceracoder.c:515-518 */
-    guint bps_prop = 0;
+    guint bps_prop = 0, kbps_prop = 0;
     if (have_enc) g_object_get(G_OBJECT(enc.element), "bps", &bps_prop, NULL);
-    fprintf(stderr, "{\"encoder_found\":%d,\"bitrate_div\":%d,\"bps_after_null_state_write\":%u}\n", have_enc, enc.bitrate_div, bps_prop);
+    if (have_enc && g_object_class_find_property(G_OBJECT_GET_CLASS(enc.element), "bitrate")) g_object_get(G_OBJECT(enc.element), "bitrate", &kbps_prop, NULL);
+    fprintf(stderr, "{\"encoder_found\":%d,\"bitrate_div\":%d,\"bps_after_null_state_write\":%u,\"bitrate_kbps\":%u}\n", have_enc, enc.bitrate_div, bps_prop, kbps_prop);
     if (have_enc) {
         GstPad *sp = gst_element_get_static_pad(enc.element, "sink");
         if (sp) { gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_BUFFER, enc_sink_probe, NULL, NULL); gst_object_unref(sp); }
+    }
+    {
+        GstElement *j = gst_bin_get_by_name(GST_BIN(pipeline), "jitter"), *f = gst_bin_get_by_name(GST_BIN(pipeline), "ptsfixup");
+        if (j) { g_signal_connect(j, "handoff", G_CALLBACK(jitter_cb), NULL); gst_object_unref(j); }
+        if (f) { g_signal_connect(f, "handoff", G_CALLBACK(ptsfixup_cb), NULL); gst_object_unref(f); } /* ceracoder.c:536-543 */
     }
     udp_open();
     GstElement *sink = gst_bin_get_by_name(GST_BIN(pipeline), "appsink");
@@ -188,6 +245,8 @@ int main(int argc, char **argv) {
     fclose(out);
     printf("{\"samples\":%" G_GUINT64_FORMAT ",\"bytes\":%" G_GUINT64_FORMAT ",\"seconds\":%.3f,\"setpoints_applied\":%d,\"datagrams_1316\":%" G_GUINT64_FORMAT,
            n_samples, n_bytes, secs, script_i, n_datagrams);
+    printf(",\"dts_ne_pts\":%" G_GUINT64_FORMAT ",\"pts_backwards\":%" G_GUINT64_FORMAT ",\"pts_repeated\":%" G_GUINT64_FORMAT ",\"droppable_in\":%" G_GUINT64_FORMAT,
+           n_dts_ne_pts, n_pts_backwards, n_pts_repeated, n_droppable_in);
     unsigned skip = lat_n > 90 ? 60 : 0; /* discard the first GOP (warm-up) when the run is long enough */
     print_pct("ms_encoder_sink_to_appsink", lat_enc + skip, lat_n - skip);
     print_pct("ms_appsink_to_last_udp_send", lat_send + skip, lat_n - skip);

@@ -64,7 +64,8 @@ def test_plugin_registers_with_expected_properties():
 @pytest.mark.parametrize("name,div", [("venc_bps", 1), ("venc_kbps", 1000)])
 def test_reference_encoder_control_drives_bps_in_null_state(tmp_path, name, div):
     """encoder_control.c finds the element by name and writes "bps" before PLAYING; the element must
-    hold the value.  (Named venc_kbps the reference divides by 1000 -- documented, not recommended.)"""
+    hold the value.  Named venc_kbps (as in every x264 pipeline file of the reference) the reference writes
+    bitrate / 1000 into "bps": the element then takes "bps" in kbit/s, so both names end at 4.3 Mbit/s."""
     pf = tmp_path / "pipe"
     pf.write_text("videotestsrc num-buffers=3 ! video/x-raw,width=320,height=192,framerate=30/1,format=NV12 ! "
                   "mi355h264enc key-int-max=30 speed-preset=superfast name=%s ! appsink name=appsink sync=false\n" % name)
@@ -72,7 +73,7 @@ def test_reference_encoder_control_drives_bps_in_null_state(tmp_path, name, div)
     script.write_text("0 4300000\n")
     r = subprocess.run([HARNESS, str(pf), str(tmp_path / "out.bin"), str(script)], env=gst_env(), capture_output=True, text=True, timeout=120)
     info = json.loads([l for l in r.stderr.splitlines() if l.startswith("{\"encoder_found\"")][0])
-    assert info == {"encoder_found": 1, "bitrate_div": div, "bps_after_null_state_write": 4300000 // div}
+    assert info == {"encoder_found": 1, "bitrate_div": div, "bps_after_null_state_write": 4300000 // div, "bitrate_kbps": 4300}
     if _has_gpu():
         assert r.returncode == 0, r.stderr
         assert json.loads(r.stdout.splitlines()[-1])["samples"] == 3
@@ -87,8 +88,27 @@ def test_pipeline_files_name_the_element_like_the_reference():
     assert "h264_test_pattern_1080p60" in files and "h264_test_pattern_2160p60" in files and "h264_test_pattern_720p30" in files
     for f in files:
         text = open(os.path.join(d, f)).read()
-        assert "mi355h264enc" in text and "name=venc_bps" in text and "appsink name=appsink" in text, f
+        assert "mi355h264enc" in text and ("name=venc_bps" in text or "name=venc_kbps" in text) and "appsink name=appsink" in text, f
         assert "x264enc" not in text
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/pipeline/generic"), reason="reference tree only exists in the build container")
+def test_reference_pipeline_file_converts_by_changing_one_token():
+    """pipeline/mi355x/x264_superfast_camlink is /root/reference/pipeline/generic/x264_superfast_camlink with the factory token
+    changed and nothing else: same properties (speed-preset=2 key-int-max=60), same element name (venc_kbps)."""
+    ref = open("/root/reference/pipeline/generic/x264_superfast_camlink").read().split()
+    ours = open(os.path.join(ROOT, "pipeline", "mi355x", "x264_superfast_camlink")).read().split()
+    assert len(ref) == len(ours)
+    diff = [(a, b) for a, b in zip(ref, ours) if a != b]
+    assert diff == [("x264enc", "mi355h264enc")]
+
+
+def encoder_line_of_reference_file():
+    """The encoder hop of the converted reference file, verbatim: `mi355h264enc speed-preset=2 key-int-max=60 name=venc_kbps`."""
+    text = open(os.path.join(ROOT, "pipeline", "mi355x", "x264_superfast_camlink")).read()
+    line = [l for l in text.splitlines() if l.startswith("mi355h264enc")][0]
+    assert line.rstrip(" !") == "mi355h264enc speed-preset=2 key-int-max=60 name=venc_kbps"
+    return line.rstrip(" !")
 
 
 @needs_gst

@@ -115,3 +115,79 @@ def test_element_takes_raw_formats_without_videoconvert(tmp_path, oracle, fmt):
     # SMPTE bars: the left-most bar is white or light grey, the 7th blue (Y ~ 35); chroma of the blue bar: Cb high, Cr low
     assert float(y[20:100, 5:35].mean()) > 150 and float(y[20:100, 280:310].mean()) < 70
     assert float(uv[10:50, 280:310:2].mean()) > 170 and float(uv[10:50, 281:311:2].mean()) < 128
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
+def test_reference_x264_line_with_only_the_factory_token_changed_runs_at_the_written_rate(tmp_path):
+    """The encoder hop of pipeline/mi355x/x264_superfast_camlink (the reference's file, `x264enc` -> `mi355h264enc`, still
+    `name=venc_kbps`) between a test source and the appsink: the reference's encoder_control divides by 1000 for that name
+    (encoder_control.c:29-32,53) and the element takes "bps" in kbit/s there, so 4.3 Mbit/s is what comes out."""
+    from tests.test_boundary_cpu import encoder_line_of_reference_file
+    pf = tmp_path / "pipe"
+    pf.write_text("videotestsrc num-buffers=240 pattern=snow ! video/x-raw,width=640,height=368,framerate=30/1 ! videoconvert ! \n"
+                  + encoder_line_of_reference_file() + " ! \nappsink name=appsink sync=false\n")
+    script = tmp_path / "script"
+    script.write_text("0 4300000\n")
+    out = tmp_path / "out.bin"
+    r = subprocess.run([HARNESS, str(pf), str(out), str(script)], env=gst_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    info = json.loads([l for l in r.stderr.splitlines() if l.startswith("{\"encoder_found\"")][0])
+    assert info["bitrate_div"] == 1000 and info["bps_after_null_state_write"] == 4300 and info["bitrate_kbps"] == 4300
+    sizes = np.array([len(a) for _, a in read_records(str(out))], float)
+    rate = sizes[60:240].sum() * 8 * 30 / 180  # three GOPs of 60 after the first
+    assert abs(rate - 4.3e6) / 4.3e6 < 0.10, rate
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
+@pytest.mark.parametrize("fixup", [False, True])
+@pytest.mark.parametrize("depth", [0, 1])
+def test_damaged_timestamps_leave_monotone_with_dts_equal_pts(tmp_path, oracle, fixup, depth):
+    """upstream of the encoder the reference rewrites PTS, zeroes DTS and flags early pictures DROPPABLE
+    (ceracoder.c:371-423).  With timestamps damaged the way a capture device damages them (jitter, repeats, a picture two
+    periods early, garbage DTS) -- repaired by the reference's ptsfixup logic or not -- every sample leaves with DTS == PTS,
+    PTS never runs backwards, DROPPABLE pictures are not coded, and the stream still decodes."""
+    pf = tmp_path / "pipe"
+    pf.write_text("videotestsrc num-buffers=120 pattern=ball ! video/x-raw,width=320,height=192,framerate=30/1,format=NV12 ! "
+                  "identity name=jitter signal-handoffs=TRUE ! " + ("identity name=ptsfixup signal-handoffs=TRUE ! " if fixup else "") +
+                  "queue ! mi355h264enc key-int-max=30 pipeline-depth=%d name=venc_bps ! appsink name=appsink sync=false\n" % depth)
+    out = tmp_path / "out.bin"
+    r = subprocess.run([HARNESS, str(pf), str(out)], env=gst_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    s = json.loads(r.stdout.splitlines()[-1])
+    assert s["dts_ne_pts"] == 0 and s["pts_backwards"] == 0, s
+    assert s["samples"] == 120 - s["droppable_in"]
+    if fixup:
+        assert s["droppable_in"] >= 1 and s["pts_repeated"] == 0, s   # the early pictures were flagged upstream and not coded
+    recs = read_records(str(out))
+    pts = [p for p, _ in recs]
+    assert pts == sorted(pts)
+    dec = oracle.Decoder()
+    for _, au in recs:
+        dec.decode(au)
+    assert dec.size == (320, 192)
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
+def test_device_id_without_a_device_fails_through_the_bus(tmp_path):
+    """`device-id` beyond the box's GPUs is MI355ENC_ERR_NO_DEVICE -> bus ERROR -> the harness's
+    cb_pipeline equivalent stops with code 3 (ceracoder.c:425-438); nothing is encoded."""
+    import torch
+    pf = tmp_path / "pipe"
+    pf.write_text("videotestsrc num-buffers=5 ! video/x-raw,width=320,height=192,framerate=30/1,format=NV12 ! "
+                  "mi355h264enc device-id=%d name=venc_bps ! appsink name=appsink sync=false\n" % torch.cuda.device_count())
+    r = subprocess.run([HARNESS, str(pf), str(tmp_path / "out.bin")], env=gst_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "no usable HIP device" in r.stderr, r.stderr[-2000:]
+    assert json.loads(r.stdout.splitlines()[-1])["samples"] == 0
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
+def test_open_is_far_below_the_stall_watchdog_tick(tmp_path):
+    """stall_check (ceracoder.c:152-200) stops the app when the position stands still for a 1 s tick; the element
+    opens the device in set_format.  mi355enc_open() must take well under 500 ms, first use of the GPU in the process included."""
+    pf = tmp_path / "pipe"
+    pf.write_text("videotestsrc num-buffers=10 ! video/x-raw,width=1920,height=1080,framerate=60/1,format=NV12 ! "
+                  "mi355h264enc stats=true name=venc_bps ! appsink name=appsink sync=false\n")
+    r = subprocess.run([HARNESS, str(pf), str(tmp_path / "out.bin")], env=gst_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    st = json.loads([l for l in r.stderr.splitlines() if l.startswith("{\"element\"")][0])
+    assert st["frames"] == 10 and 0 < st["open_ms"] < 500, st
