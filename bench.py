@@ -97,12 +97,16 @@ def gst_latency(width, height, fps, gop, bps, dev, seconds=4):
 
 def third_party_probe():
     """x264enc / an H.264 decoder / ffmpeg on the box would allow an x264 baseline and a third-party decode of
-    our stream.  They are not part of this image; record what is (not) there instead of failing."""
+    our stream.  None of them is part of this image; record everything that was looked for instead of failing: programs,
+    GStreamer elements, shared libraries (software and hardware decoders: libavcodec, openh264, rocDecode, VA-API, AMF) and
+    the render nodes a VA-API / rocDecode decoder would need."""
+    import ctypes.util
+    import glob
     import shutil
     import subprocess
-    found = {"ffmpeg": bool(shutil.which("ffmpeg")), "x264": bool(shutil.which("x264"))}
+    found = {p: bool(shutil.which(p)) for p in ("ffmpeg", "ffprobe", "x264", "vainfo", "gst-launch-1.0")}
     insp = "/opt/conda/bin/gst-inspect-1.0" if os.path.exists("/opt/conda/bin/gst-inspect-1.0") else shutil.which("gst-inspect-1.0")
-    for el in ("x264enc", "avdec_h264", "h264parse", "mpegtsmux"):
+    for el in ("x264enc", "avdec_h264", "openh264dec", "vaapih264dec", "vah264dec", "h264parse", "mpegtsmux"):
         ok = False
         if insp:
             try:
@@ -112,8 +116,33 @@ def third_party_probe():
             except Exception:
                 ok = False
         found[el] = ok
+    libs = {}
+    for lib in ("avcodec", "x264", "openh264", "rocdecode", "va", "va-drm", "amfrt64"):
+        hit = ctypes.util.find_library(lib) or next(iter(glob.glob("/opt/rocm/lib/lib%s.so*" % lib) + glob.glob("/opt/conda/lib/lib%s.so*" % lib)), None)
+        libs[lib] = hit or False
+    found["libraries"] = libs
+    found["render_nodes"] = sorted(glob.glob("/dev/dri/renderD*"))
+    found["decoder_available"] = bool(found["ffmpeg"] or found["avdec_h264"] or found["openh264dec"] or found["vaapih264dec"] or found["vah264dec"] or
+                                      libs["avcodec"] or libs["openh264"] or libs["rocdecode"])
     found["note"] = ("x264enc absent: cpu_baseline is this repo's own CPU restatement, not x264" if not found["x264enc"] else "x264enc present")
     return found
+
+
+def third_party_decode(aus, width, height):
+    """Decode the access units with ffmpeg when the box has one: returns the decoded NV12 frames (list of (y, uv)) or None.
+    The only third-party decoder path this repository can drive without linking anything; never available on this image."""
+    import shutil
+    import subprocess
+    if not shutil.which("ffmpeg"):
+        return None
+    r = subprocess.run(["ffmpeg", "-v", "error", "-f", "h264", "-i", "pipe:0", "-f", "rawvideo", "-pix_fmt", "nv12", "pipe:1"], input=b"".join(aus),
+                       capture_output=True, timeout=600)
+    if r.returncode:
+        raise RuntimeError("ffmpeg failed to decode the stream: " + r.stderr.decode(errors="replace")[-500:])
+    fsz = width * height * 3 // 2
+    raw = np.frombuffer(r.stdout, np.uint8)
+    return [(raw[i * fsz:i * fsz + width * height].reshape(height, width), raw[i * fsz + width * height:(i + 1) * fsz].reshape(height // 2, width))
+            for i in range(len(raw) // fsz)]
 
 
 def main():

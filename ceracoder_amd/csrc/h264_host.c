@@ -240,6 +240,22 @@ static inline void put_chroma_dc(bits_t *b, const int16_t *coef) { /* 4 coeffici
     }
 }
 
+/* Test hook (include/mi355enc.h, mi355enc_host_cavlc_block): one residual block through the coder above. */
+int h264_cavlc_block_bits(const int16_t *coef, int maxnum, int nC, uint8_t *out, size_t cap) {
+    int16_t tmp[16] __attribute__((aligned(16))) = {0};
+    bits_t b;
+    if (cap < 64 || (maxnum != 16 && maxnum != 15 && maxnum != 4)) return -1;
+    memset(out, 0, cap);
+    bits_init(&b, out, cap);
+    if (maxnum == 4) { memcpy(tmp, coef, 8); put_chroma_dc(&b, tmp); }
+    else if (maxnum == 15) { memcpy(tmp + 1, coef, 30); put_block16(&b, tmp, 1, nC); }
+    else { memcpy(tmp, coef, 32); put_block16(&b, tmp, 0, nC); }
+    int n = (int)(8 * (b.p - out)) + b.n;
+    if (b.n & 7) bits_put(&b, 8 - (b.n & 7), 0);
+    while (b.n > 0) { b.n -= 8; *b.p++ = (uint8_t)(b.acc >> b.n); }
+    return b.overflow ? -1 : n;
+}
+
 /* ------------------------------------------------------------------ motion vector prediction */
 static inline int med3(int a, int b, int c) {
     int lo = a < b ? a : b, hi = a < b ? b : a;

@@ -30,6 +30,9 @@ int h264_writer_set_threads(h264_writer_t *w, int threads);
 size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                                     int slice_qp, const mb_info_t *mbi, const int16_t *packed, const uint32_t *row_off);
 
+/* one CAVLC residual block (maxnum 16, 15 or 4; nC as 9.2.1 derives it, ignored for 4): bits MSB-first into out (cap >= 64), returns their number */
+int h264_cavlc_block_bits(const int16_t *coef, int maxnum, int nC, uint8_t *out, size_t cap);
+
 /* Host statement of the device's hand-over (levels_scan_kernel + levels_pack_kernel): dense levels -> packed stream of 32-byte
  * blocks + first block of every macroblock row.  `packed` must hold mbw*mbh*PACK_BLOCKS_MAX*16 int16.  Returns the block count. */
 size_t h264_pack_levels(int mbw, int mbh, const mb_info_t *mbi, const int16_t *levels, int16_t *packed, uint32_t *row_off);

@@ -900,6 +900,10 @@ int mi355enc_host_write_slice_packed(int mbw, int mbh, int is_idr, int frame_num
     h264_writer_free(w); free(packed); free(row_off);
     return rc;
 }
+int mi355enc_host_cavlc_block(const int16_t *coef, int maxnum, int nC, uint8_t *out, size_t cap) {
+    if (!coef || !out) return MI355ENC_ERR_ARG;
+    return h264_cavlc_block_bits(coef, maxnum, nC, out, cap);
+}
 static_assert(sizeof(rc_state_t) <= MI355ENC_RC_BYTES, "MI355ENC_RC_BYTES too small");
 void mi355enc_rc_init(void *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max) { rc_init((rc_state_t *)rc, fps, gop, bps, qp_min, qp_max); }
 void mi355enc_rc_set_bitrate(void *rc, uint32_t bps) { rc_set_bitrate((rc_state_t *)rc, bps); }

@@ -29,7 +29,7 @@ EXPORTS = [
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
     "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_pmb", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
     "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
-    "mi355enc_rc_pick_qp", "mi355enc_rc_update",
+    "mi355enc_rc_pick_qp", "mi355enc_rc_update", "mi355enc_host_cavlc_block",
 ]
 
 
@@ -97,6 +97,7 @@ def load():
         L.mi355enc_host_write_headers.argtypes = [C.c_int] * 5 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_write_slice.argtypes = [C.c_int] * 7 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_write_slice_packed.argtypes = [C.c_int] * 8 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi355enc_host_cavlc_block.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
         L.mi355enc_rc_init.restype = None
         L.mi355enc_rc_init.argtypes = [vp, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_int]
         L.mi355enc_rc_set_bitrate.restype = None
@@ -106,6 +107,18 @@ def load():
         L.mi355enc_rc_update.argtypes = [vp, C.c_int, C.c_int, C.c_size_t]
         _lib = L
     return _lib
+
+
+def host_cavlc_block(coef, maxnum, nC):
+    """One residual block through the product's CAVLC block coder; returns the bits as a '0'/'1' string."""
+    L = load()
+    c = np.ascontiguousarray(coef, np.int16)
+    assert c.size == maxnum
+    out = np.zeros(64, np.uint8)
+    n = L.mi355enc_host_cavlc_block(c.ctypes.data_as(C.c_void_p), maxnum, nC, out.ctypes.data_as(C.c_void_p), out.size)
+    if n < 0:
+        raise RuntimeError("mi355enc_host_cavlc_block: %d" % n)
+    return "".join("{:08b}".format(b) for b in out)[:n]
 
 
 def host_write_headers(width, height, fps_num, fps_den=1, transform8x8=False):

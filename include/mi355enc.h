@@ -188,6 +188,10 @@ int mi355enc_host_write_slice(int mb_width, int mb_height, int is_idr, int frame
 /* the same slice through the packed hand-over format and `threads` row-parallel host threads (bit-identical result) */
 int mi355enc_host_write_slice_packed(int mbw, int mbh, int is_idr, int frame_num, int idr_pic_id, int qp, int t8, int threads, const void *mbinfo,
                                      const int16_t *levels, uint8_t *out, size_t cap, size_t *out_len);
+/* One CAVLC residual block (9.2) through the slice writer's block coder, for known-answer tests: coef in scan order, maxnum 16
+ * (whole 4x4 block), 15 (AC of Intra16x16 / chroma) or 4 (chroma DC); nC as 9.2.1 derives it.  Bits MSB-first into out
+ * (cap >= 64 bytes); returns the number of bits, negative on error. */
+int mi355enc_host_cavlc_block(const int16_t *coef, int maxnum, int nC, uint8_t *out, size_t cap);
 /* Rate-control model on its own: feed (is_idr, produced bytes) per picture, get the next QP.
  * rc is an opaque block of MI355ENC_RC_BYTES bytes owned by the caller. */
 #define MI355ENC_RC_BYTES 128

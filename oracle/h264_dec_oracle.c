@@ -165,6 +165,8 @@ struct orc_dec {
     /* bit reader over the current RBSP */
     const uint8_t *rb; size_t rb_bits, pos; int rb_fail;
     uint8_t *rbsp; size_t rbsp_cap;
+    /* optional capture of the parsed syntax in the encoder's record layout (tests: syntax round trip) */
+    orc_mbinfo_t *cap_mbi; int16_t *cap_lev;
 };
 
 static int fail(orc_dec_t *d, const char *fmt, ...) {
@@ -617,6 +619,11 @@ static void add_res4(orc_dec_t *d, int X, int Y, int c[4][4]) {
 static const uint8_t D_blkx[16] = {0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3}; /* blkIdx -> 4x4 column */
 static const uint8_t D_blky[16] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3};
 
+/* capture (tests only): where the parsed syntax of macroblock (mx, my) goes, in the layout of orc_mbinfo_t / ORC_L_* */
+static orc_mbinfo_t *cap_rec(orc_dec_t *d, int mx, int my) { return d->cap_mbi ? &d->cap_mbi[my * d->mbw + mx] : NULL; }
+static int16_t *cap_levels(orc_dec_t *d, int mx, int my) { return d->cap_lev ? d->cap_lev + (size_t)(my * d->mbw + mx) * ORC_LEVELS_PER_MB : NULL; }
+static int any_nz(const int16_t *l, int n) { for (int i = 0; i < n; i++) if (l[i]) return 1; return 0; }
+
 static int decode_chroma_residual(orc_dec_t *d, int mx, int my, int slice, int cbp_chroma, int qpc) {
     dmb_t *m = &d->mb[my * d->mbw + mx];
     int16_t dc[2][4] = {{0}}, ac[2][4][15];
@@ -629,6 +636,17 @@ static int decode_chroma_residual(orc_dec_t *d, int mx, int my, int slice, int c
                 if (n < 0) return fail(d, "chroma AC residual");
                 m->tc_c[c][b] = (uint8_t)n;
             }
+    if (d->cap_mbi && d->cap_lev) {
+        orc_mbinfo_t *r = cap_rec(d, mx, my); int16_t *cl = cap_levels(d, mx, my);
+        for (int c = 0; c < 2; c++) {
+            memcpy(cl + ORC_L_CDC + 4 * c, dc[c], 8);
+            if (any_nz(dc[c], 4)) r->nzmask |= c ? ORC_NZ_CRDC : ORC_NZ_CBDC;
+            for (int b = 0; b < 4; b++) {
+                memcpy(cl + ORC_L_CAC + (4 * c + b) * 16 + 1, ac[c][b], 30);
+                if (any_nz(ac[c][b], 15)) r->nzmask |= 1u << (16 + 4 * c + b);
+            }
+        }
+    }
     for (int c = 0; c < 2; c++) {
         /* 8.5.11: c = [[dc0 dc1][dc2 dc3]], f = A c A */
         int f[4] = {dc[c][0] + dc[c][1] + dc[c][2] + dc[c][3], dc[c][0] - dc[c][1] + dc[c][2] - dc[c][3],
@@ -649,15 +667,19 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
     dmb_t *m = &d->mb[my * d->mbw + mx];
     memset(m->tc_l, 0, 16); memset(m->tc_c, 0, 8); memset(m->i4mode, 2, 16);
     m->slice = (int16_t)slice; m->coded = 0; m->is_i4 = 0; m->mvx = m->mvy = 0; m->t8 = 0;
+    orc_mbinfo_t *cr = cap_rec(d, mx, my); int16_t *cl = cap_levels(d, mx, my);
+    if (cr) memset(cr, 0, sizeof *cr);
+    if (cl) memset(cl, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
     if (skipped) {
         int px, py; predict_mv(d, mx, my, slice, 1, &px, &py);
         m->mvx = (int16_t)px; m->mvy = (int16_t)py;
         inter_pred_mb(d, mx, my, px, py);
         m->kind = 1; m->qp = (int8_t)*qp; m->qpc = (int8_t)chroma_qp(d, *qp);
+        if (cr) { cr->mb_type = 1; cr->mvx = m->mvx; cr->mvy = m->mvy; cr->qp = (uint8_t)*qp; }
         return 0;
     }
     int t = (int)rd_ue(d);
-    int intra = 1, i16 = 0, i16mode = 0, cbp = 0;
+    int intra = 1, i16 = 0, i16mode = 0, cbp = 0, cap_cmode = 0;
     if (is_p) { if (t < 5) intra = 0; else t -= 5; }
     if (!intra) {
         if (t != 0) return fail(d, "P macroblock type %d unsupported", t);
@@ -691,6 +713,7 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
         }
         int cmode = (int)rd_ue(d);
         if (cmode > 3) return fail(d, "intra_chroma_pred_mode %d", cmode);
+        cap_cmode = cmode;
         if (m->is_i4) { unsigned k = rd_ue(d); if (k > 47) return fail(d, "cbp codeNum %u", k); cbp = D_cbp_intra[k]; }
         int err = 0;
         pred_chroma8(d, mx, my, slice, cmode, &err);
@@ -703,11 +726,18 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
     }
     m->qp = (int8_t)*qp; m->qpc = (int8_t)chroma_qp(d, *qp);
     int q = *qp;
+    if (cr) {
+        cr->mb_type = (uint8_t)(!intra ? 1 : m->is_i4 ? 2 : 0); cr->mvx = m->mvx; cr->mvy = m->mvy; cr->qp = (uint8_t)q;
+        cr->i16_mode = (uint8_t)i16mode; cr->chroma_mode = (uint8_t)cap_cmode;
+        if (m->t8) cr->nzmask |= ORC_NZ_T8;
+        if (cl && m->is_i4) for (int b = 0; b < 16; b++) cl[ORC_L_LDC + b] = m->i4mode[D_blky[b] * 4 + D_blkx[b]];
+    }
     /* --- luma residual */
     int dcy[16]; memset(dcy, 0, sizeof dcy);
     if (i16) {
         int16_t l[16];
         if (residual_block(d, l, 16, ctx_nC(d, mx, my, slice, 0, 0, 0)) < 0) return fail(d, "I16 DC residual");
+        if (cl) { memcpy(cl + ORC_L_LDC, l, 32); if (any_nz(l, 16)) cr->nzmask |= ORC_NZ_LDC; }
         int c[4][4], t2[4][4], f[4][4];
         for (int k = 0; k < 16; k++) c[D_zz_y[k]][D_zz_x[k]] = l[k];
         for (int y = 0; y < 4; y++) { /* 8.5.10: f = A c A with the +1 +1 +1 +1 / +1 +1 -1 -1 / +1 -1 -1 +1 / +1 -1 +1 -1 matrix */
@@ -735,6 +765,7 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
                 if (n < 0) return fail(d, "luma 8x8 residual at MB %d,%d", mx, my);
                 m->tc_l[by * 4 + bx] = (uint8_t)n;
                 any |= n;
+                if (cl) { memcpy(cl + ORC_L_LUMA + b * 16, l, 32); if (n) cr->nzmask |= 1u << b; }
                 for (int k = 0; k < 16; k++) lev8[4 * k + j] = l[k];
             }
             if (!any) continue;
@@ -776,6 +807,7 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
             if (n < 0) return fail(d, "luma residual at MB %d,%d blk %d", mx, my, b);
             m->tc_l[by * 4 + bx] = (uint8_t)n;
             if (n) m->coded |= (uint16_t)(1u << (by * 4 + bx));
+            if (cl) { memcpy(cl + ORC_L_LUMA + b * 16 + (i16 ? 1 : 0), l, i16 ? 30 : 32); if (n) cr->nzmask |= 1u << b; }
         }
         if (n || i16) {
             int co[4][4];
@@ -926,6 +958,7 @@ static int decode_slice(orc_dec_t *d, int nal_type, int ref_idc) {
 }
 
 orc_dec_t *orc_dec_open(void) { return (orc_dec_t *)calloc(1, sizeof(orc_dec_t)); }
+void orc_dec_set_capture(orc_dec_t *d, orc_mbinfo_t *mbinfo, int16_t *levels) { d->cap_mbi = mbinfo; d->cap_lev = levels; }
 void orc_dec_close(orc_dec_t *d) {
     if (!d) return;
     free(d->cur_y); free(d->cur_uv); free(d->ref_y); free(d->ref_uv); free(d->mb); free(d->rbsp); free(d);

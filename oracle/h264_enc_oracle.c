@@ -1088,6 +1088,17 @@ static int cavlc_block(bw_t *bw, const int16_t *coef, int maxnum, int nC) {
     return total;
 }
 
+int orc_cavlc_block_bits(const int16_t *coef, int maxnum, int nC, uint8_t *out, size_t cap) {
+    init_tables();
+    bw_t b;
+    memset(out, 0, cap);
+    bw_init(&b, out, cap);
+    cavlc_block(&b, coef, maxnum, nC);
+    int n = (int)(8 * b.pos) + b.nbits;
+    if (b.nbits) bw_put(&b, 8 - b.nbits, 0);
+    return b.overflow ? -1 : n;
+}
+
 static int median3(int a, int b, int c) {
     int mn = a < b ? a : b, mx = a < b ? b : a;
     return c < mn ? mn : (c > mx ? mx : c);

@@ -139,6 +139,12 @@ int orc_dec_coded_height(const orc_dec_t *d);
 const uint8_t *orc_dec_y(const orc_dec_t *d);  /* coded-size planes, stride = coded width */
 const uint8_t *orc_dec_uv(const orc_dec_t *d); /* interleaved CbCr                         */
 const char *orc_dec_error(const orc_dec_t *d);
+/* Tests: have the decoder write the syntax it parses from the next access units into caller-owned arrays in the encoder's
+ * layout (coded-size mbw*mbh records / mbw*mbh*ORC_LEVELS_PER_MB levels; cost = 0, nzmask from the parsed levels). */
+void orc_dec_set_capture(orc_dec_t *d, orc_mbinfo_t *mbinfo, int16_t *levels);
+/* One CAVLC residual block through the encoder oracle's cavlc_block (9.2.1-9.2.3): coef in scan order, maxnum 16 / 15 / 4,
+ * nC as 9.2.1 derives it (-1: chroma DC).  Writes the bits MSB-first into out, returns their number. */
+int orc_cavlc_block_bits(const int16_t *coef, int maxnum, int nC, uint8_t *out, size_t cap);
 
 /* ---- small known-answer helpers exported for tests ------------------------------ */
 void orc_fdct4(const int16_t in[16], int16_t out[16]);

@@ -106,6 +106,9 @@ def lib():
         L.orc_enc_cbp_codenum.argtypes = [C.c_int, C.c_int]
         L.orc_dec_cbp.argtypes = [C.c_int, C.c_int]
         L.orc_dec_const.argtypes = [C.c_int, C.c_int]
+        L.orc_cavlc_block_bits.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+        L.orc_dec_set_capture.argtypes = [vp, vp, vp]
+        L.orc_dec_set_capture.restype = None
         _lib = L
     return _lib
 
@@ -197,6 +200,13 @@ class Decoder:
         uv = _view(self.L.orc_dec_uv(self.h), (ch // 2, cw), np.uint8).copy()
         return y, uv
 
+    def capture(self, n_mb):
+        """Have the decoder record the syntax it parses (records + levels in the encoder's layout) from now on."""
+        self.cap_mbi = np.zeros(n_mb, MBINFO_DTYPE)
+        self.cap_lev = np.zeros((n_mb, LEVELS_PER_MB), np.int16)
+        self.L.orc_dec_set_capture(self.h, _ptr(self.cap_mbi), _ptr(self.cap_lev))
+        return self.cap_mbi, self.cap_lev
+
     @property
     def size(self):
         return self.L.orc_dec_width(self.h), self.L.orc_dec_height(self.h)
@@ -207,6 +217,18 @@ class Decoder:
             self.h = None
 
     __del__ = close
+
+
+def cavlc_block(coef, maxnum, nC):
+    """One residual block through the encoder oracle's cavlc_block; returns the bits as a '0'/'1' string."""
+    L = lib()
+    c = np.ascontiguousarray(coef, np.int16)
+    assert c.size == maxnum
+    out = np.zeros(64, np.uint8)
+    n = L.orc_cavlc_block_bits(_ptr(c), maxnum, nC, _ptr(out), out.size)
+    if n < 0:
+        raise RuntimeError("orc_cavlc_block_bits failed")
+    return "".join("{:08b}".format(b) for b in out)[:n]
 
 
 def me_frame(cur_y, ref_y, rng, qp, threads=1):
