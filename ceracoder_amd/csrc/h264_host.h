@@ -51,6 +51,8 @@ typedef struct {
 void rc_init(rc_state_t *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max);
 void rc_set_bitrate(rc_state_t *rc, uint32_t bps);
 int rc_pick_qp(rc_state_t *rc, int is_idr);
+/* QP and, once QP 51 is not enough, the drop level of the ladder below it (P pictures: 0 .. DROP_MAX, DROP_SKIP = all-skip picture) */
+void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop);
 void rc_update(rc_state_t *rc, int is_idr, int qp, size_t bytes);
 
 #ifdef __cplusplus

@@ -46,7 +46,10 @@ DEV bool mode4_ok(int b, int md, bool up, bool lf, bool ul) {
     return !((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul)) || (b == 5 && (md == 3 || md == 7)));
 }
 #define IA_S 24 /* luma tile stride: row 0 = y -1, col 0 = x -1 */
-__global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *__restrict__ ctx) {
+// P pictures (gate_p): only macroblocks whose whole-sample search cost reaches INTRA_GATE are analysed -- the fused P stage
+// never considers the others for intra (oracle: orc_pmb_frame, step 4).
+__global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv, int gate_p) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ uint16_t sh_sad[4][ISAD_PER_MB]; // this wave's macroblock: the same 152 values that go to ctx->isad
     __shared__ int sh_m4[4][16];                // Intra_4x4 modes chosen so far, raster order
     __shared__ __attribute__((aligned(4))) uint8_t SL[4][17 * IA_S];
@@ -56,6 +59,10 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *_
     int mbn = blockIdx.x * 4 + wave;
     const bool ok = mbn < nmb;
     if (!ok) mbn = nmb - 1;
+    if (gate_p) { // wave-uniform exit: the kernel has no workgroup barrier
+        const uint2 iv = ldg64(k_final_imv_dev(ctx) + mbn);
+        if ((iv.y & 0xFFFFu) + (unsigned)ctx->lambda * (iv.y >> 16) < INTRA_GATE(ctx->lambda)) return;
+    }
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
     const bool has_top = my > 0, has_left = mx > 0;
     const uint8_t *__restrict__ sy = ctx->src_y;
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *_
             use_i4 = cost4 + (unsigned)(32 * lam) < cost16;
             if (use_i4) cost_luma = cost4 + (unsigned)(32 * lam);
         }
-        if (lane < 6 && ok) { // 24-byte record {u8 modes4[16] by blkIdx; u8 mode16, cmode, use_i4, 0; u32 cost}
+        if (lane < 8 && ok) { // 32-byte record {u8 modes4[16] by blkIdx; u8 mode16, cmode, use_i4, 0; u32 cost, cost_luma, 0}
             unsigned w = 0;
             if (lane < 4) {
 #pragma unroll
@@ -249,7 +256,8 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t *_
                     w |= (ctx->i4x4 ? (unsigned)sh_m4[wave][r] & 0xFF : 0u) << (8 * i);
                 }
             } else if (lane == 4) w = (unsigned)mode16 | ((unsigned)cmode << 8) | ((use_i4 ? 1u : 0u) << 16);
-            else w = cost_luma + costc;
+            else if (lane == 5) w = cost_luma + costc;
+            else if (lane == 6) w = cost_luma;
             stg32(ctx->idec + (size_t)mbn * IDEC_BYTES + 4 * lane, w);
         }
     }
@@ -735,8 +743,81 @@ void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, unsigned *d_progress
 
 // =================================================================== launchers
 int k_intra_diags(int mbw, int mbh) { return mbw + mbh - 1; }
-void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s) {
-    hipLaunchKernelGGL(intra_analyse_kernel, dim3((mbw * mbh + 3) / 4), dim3(256), 0, s, d_ctx);
+void k_launch_intra_analyse(const frame_ctx_t *h_ctx, int mbw, int mbh, int gate_p, hipStream_t s) {
+    hipLaunchKernelGGL(intra_analyse_kernel, dim3((mbw * mbh + 3) / 4), dim3(256), 0, s, *h_ctx, gate_p);
+}
+
+// =================================================================== intra macroblocks of P pictures
+// pmb_kernel has reconstructed every inter macroblock and left type + modes in the records of the ones it decided to code
+// intra; those predict from their neighbours' reconstructed samples (8.3; constrained_intra_pred_flag = 0), so an intra
+// macroblock waits for the intra ones among its left, top and top-left neighbours (the analysis never picks a mode that
+// reads the macroblock above-right).  A fixed number of resident workgroups each walk their share of the macroblocks in
+// raster order -- workgroup w takes w, w + G, w + 2G, ... -- and skip the inter ones at once.  No dispatch order is assumed:
+// the smallest unfinished macroblock always belongs to a workgroup that has finished everything before it, and its
+// dependencies are smaller still, so somebody can always proceed (every spin is bounded anyway and reports through `err`).
+// Hand-off between workgroups: producer -- all stores, every wave's vmcnt(0), workgroup barrier, agent-scope release, stamp
+// store (sc1); consumer -- one sc1 poll per needed neighbour, agent-scope acquire, workgroup barrier, plain loads
+// (MI355X_MICROARCH.md, "Valid forms").  Oracle: orc_intra_p_frame.
+#define IP_WGS 512
+__global__ __launch_bounds__(128) void intra_p_kernel(const frame_ctx_t cv, unsigned *__restrict__ err) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    __shared__ intra_lds LD;
+    __shared__ unsigned tabw[TAB_DWORDS];
+    const dev_tables *T = (const dev_tables *)tabw;
+    const int mbw = ctx->mbw, nmb = mbw * ctx->mbh, stride = ctx->stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint8_t *__restrict__ ry = ctx->rec_y;
+    const uint8_t *__restrict__ ruv = ctx->rec_uv;
+    for (int i = threadIdx.x; i < TAB_DWORDS; i += 128) tabw[i] = ((const unsigned *)&g_tab)[i];
+    for (int mbn = blockIdx.x; mbn < nmb; mbn += gridDim.x) {
+        const uint4 rec = ldg128(&ctx->mbi[mbn]);
+        if (((rec.y) & 255u) == 1u) continue; // inter: reconstructed by pmb_kernel (workgroup-uniform)
+        const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
+        const bool has_top = my > 0, has_left = mx > 0;
+        __syncthreads(); // the previous macroblock of this workgroup is done with LD
+        if (threadIdx.x == 0) {
+            LD.cseq = 0;
+            int waited = 0;
+            const int nb[3] = {has_left ? mbn - 1 : -1, has_top ? mbn - mbw : -1, (has_left && has_top) ? mbn - mbw - 1 : -1};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (nb[k] < 0) continue;
+                if ((ldg32(&ctx->mbi[nb[k]].mb_type) & 255u) == 1u) continue; // inter neighbour: final since the previous launch
+                int spins = 0;
+                while (ld_sc1(&ctx->idone[nb[k]]) != ctx->epoch) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(err))) { st_sc1(err, 2u); break; }
+                }
+                waited = 1;
+            }
+            if (waited) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        }
+        __syncthreads();
+        const uint4 dec0 = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES);
+        const uint2 dec1 = ldg64(ctx->idec + (size_t)mbn * IDEC_BYTES + 16);
+        if (wave == 0 && lane >= 24 && lane < 24 + 17) { // luma neighbours; index i+1 holds sample i, index 0 the corner
+            int i = lane - 24 - 1;
+            LD.top[0][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ry + (size_t)(y0 - 1) * stride + x0 + i) : 0;
+            LD.left[0][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ry + (size_t)(y0 + i) * stride + x0 - 1) : 0;
+        } else if (wave == 1 && lane >= 41 && lane < 41 + 18) { // chroma neighbours
+            int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
+            LD.top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c) : 0;
+            LD.left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c) : 0;
+        }
+        __syncthreads();
+        intra_compute<false>(ctx, T, &LD, mx, my, wave, lane, dec0, dec1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_sc1(&ctx->idone[mbn], ctx->epoch);
+        }
+    }
+}
+void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_err, hipStream_t s) {
+    const int n = mbw * mbh;
+    hipLaunchKernelGGL(intra_p_kernel, dim3(n < IP_WGS ? n : IP_WGS), dim3(128), 0, s, *h_ctx, d_err);
 }
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s) {
     int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;

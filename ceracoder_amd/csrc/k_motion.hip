@@ -5,17 +5,20 @@
 // =================================================================== motion search
 // One workgroup = ME_MBS horizontally adjacent macroblocks of one macroblock row, one wave per
 // macroblock.  The 48 x (16*ME_MBS+32) luma search window (+-16 around the strip) is staged once in
-// LDS.  Lane l < 63 of a wave owns the candidates
+// LDS, the reference extended beyond the picture by coordinate clamping (8.4.2.2: vectors may leave
+// the picture).  Lane l < 63 of a wave owns the candidates
 //   dy in [-16 + 5*(l/9), +5)   x   dx in [-16 + 4*(l%9), +4)
 // (7 x 9 tiles cover 35 x 36 >= 33 x 33; 85 % of the computed SADs are real candidates) and
 // accumulates them with v_qsad_pk_u16_u8 -- four 4-pixel SADs per instruction -- re-using each
-// window row for the 5 dy it serves.  The (cost, dy, dx) minimum is reduced over the wave with
-// cross-lane shuffles.
+// window row for the 5 dy it serves.  Every SAD goes to the macroblock's surface in HBM (SURF_U16
+// uint16: the accumulators are four packed uint16 already, so a lane stores its tile as five 8-byte
+// words), and a first vector selection is made with the bits charged against zero; me_select_kernel
+// re-selects from the surfaces against the neighbours' choices (oracle: orc_me_frame / orc_me_select).
 #ifndef ME_MBS
 #define ME_MBS 4
 #endif
 #define ME_WQ (ME_MBS + 2)      /* uint4 per window row: 16*ME_MBS + 32 bytes */
-#define ME_ROWS 50   /* 48 real rows + 2 that only masked candidates (dy = 17, 18) ever touch */
+#define ME_ROWS 50   /* 48 real rows + 2 that only out-of-range candidates (dy = 17, 18) ever touch */
 #define ME_STRIDE 53 /* words; 5*53 mod 32 = 9 -> consecutive dy-groups start 9 banks apart */
 #define ME_K 5       /* dy per lane */
 
@@ -26,6 +29,72 @@ DEV unsigned long long qsad(unsigned lo, unsigned hi, unsigned cur, unsigned lon
 DEV int mv_bits(int v) { // bits of se(4v): 1 for 0, else 7 + 2*floor(log2|v|)
     int a = iabs(v);
     return a == 0 ? 1 : 7 + 2 * (31 - __clz(a));
+}
+DEV int med3(int a, int b, int c) {
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return c < lo ? lo : (c > hi ? hi : c);
+}
+// 8.4.1.3 on a whole-sample vector field (every neighbour taken as inter, refIdx 0) and the 8.4.1.1 P_Skip inference on the
+// same field; quarter-sample units.  Wave-uniform inputs -> wave-uniform result.  Oracle: field_pred.
+struct fpred_t { int px, py, sx, sy; };
+DEV fpred_t field_pred(const imv_t *__restrict__ f, int mbw, int mx, int my) {
+    const bool avA = mx > 0, avB = my > 0, avC = my > 0 && mx + 1 < mbw, avD = mx > 0 && my > 0, hasC = avC || avD;
+    const int self = my * mbw + mx;
+    const unsigned wa = avA ? ldg32(f + self - 1) : 0u, wb = avB ? ldg32(f + self - mbw) : 0u;
+    const unsigned wc = avC ? ldg32(f + self - mbw + 1) : (avD ? ldg32(f + self - mbw - 1) : 0u);
+    const int ax = (int)(int16_t)(wa & 0xFFFF), ay = (int)(int16_t)(wa >> 16), bx = (int)(int16_t)(wb & 0xFFFF), by = (int)(int16_t)(wb >> 16);
+    const int cx = (int)(int16_t)(wc & 0xFFFF), cy = (int)(int16_t)(wc >> 16);
+    const int n = (avA ? 1 : 0) + (avB ? 1 : 0) + (hasC ? 1 : 0);
+    fpred_t r;
+    if (n == 1) { r.px = avA ? ax : avB ? bx : cx; r.py = avA ? ay : avB ? by : cy; }
+    else { r.px = med3(ax, bx, cx); r.py = med3(ay, by, cy); }
+    const bool zero = !avA || !avB || wa == 0u || wb == 0u;
+    r.sx = zero ? 0 : r.px; r.sy = zero ? 0 : r.py;
+    return r;
+}
+// The selection over one lane's 5 x 4 tile of SADs (acc[d]: four packed uint16, dx ascending) and the wave-wide minimum:
+// key = cost << 12 | (dy+16) << 6 | (dx+16), cost = SAD + lambda * (bits(dx - px) + bits(dy - py) + SEL_BONUS) -- the candidate
+// equal to the skip inference (sx, sy) is charged nothing; ties resolve to the first candidate in (dy, dx) raster order.
+// px .. sy in whole samples.
+DEV unsigned select_min(const unsigned long long *acc, int g, int dxg, bool active, int R, int lambda, int px, int py, int sx, int sy) {
+    const unsigned INVALID = 0x40000000u;
+    unsigned bo[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int dx = -16 + 4 * dxg + o;
+        bo[o] = (dx >= -R && dx <= R && active) ? (((unsigned)(lambda * mv_bits(dx - px)) << 12) | (unsigned)(dx + 16)) : INVALID;
+    }
+    const int so = sx + 16 - 4 * dxg; // which of this lane's four columns is the skip candidate's (0..3), if any
+    unsigned best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int d = 0; d < ME_K; d++) {
+        const int dy = -16 + ME_K * g + d;
+        const unsigned pos = (unsigned)(dy + 16) << 6;
+        const unsigned bd = (dy >= -R && dy <= R) ? (((unsigned)(lambda * (mv_bits(dy - py) + SEL_BONUS)) << 12) | pos) : INVALID;
+        const unsigned lo = (unsigned)acc[d], hi = (unsigned)(acc[d] >> 32);
+        unsigned s[4] = {(lo << 16) >> 4, (lo & 0xFFFF0000u) >> 4, (hi << 16) >> 4, (hi & 0xFFFF0000u) >> 4}; // SAD << 12
+        unsigned k[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const bool is_skip = dy == sy && so == o && active; // in range by construction: a median of in-range vectors
+            k[o] = is_skip ? (s[o] | pos | (unsigned)(sx + 16)) : s[o] + bd + bo[o];
+        }
+        unsigned ka = k[0] < k[1] ? k[0] : k[1], kb = k[2] < k[3] ? k[2] : k[3];
+        ka = ka < kb ? ka : kb;
+        best = best < ka ? best : ka;
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        unsigned o = (unsigned)__shfl_xor((int)best, sft, 64);
+        best = best < o ? best : o;
+    }
+    return best;
+}
+DEV void store_imv(imv_t *dst, unsigned best, int lambda, int px, int py, int sx, int sy) {
+    const int bx = (int)(best & 63) - 16, by = (int)((best >> 6) & 63) - 16;
+    const unsigned bits = (bx == sx && by == sy) ? 0u : (unsigned)(mv_bits(bx - px) + mv_bits(by - py) + SEL_BONUS);
+    const unsigned sad = (best >> 12) - (unsigned)lambda * bits;
+    stg64(dst, make_uint2(((unsigned)(uint16_t)(4 * bx)) | ((unsigned)(uint16_t)(4 * by) << 16), sad | (bits << 16))); // quarter-sample units
 }
 
 __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, int row0) { // context by value: lives in the kernarg segment, no per-picture upload
@@ -39,12 +108,13 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
     const int t = threadIdx.x;
     const uint8_t *__restrict__ ref = ctx->ref_y;
 
-    // ---- stage the window: 48 rows x 10 uint4 (coalesced 16 B per lane)
+    // ---- stage the window: 48 rows x 10 uint4 (coalesced 16 B per lane); rows / 16-byte groups beyond the picture repeat its edge
     for (int i = t; i < 48 * ME_WQ; i += 64 * ME_MBS) {
         int row = i / ME_WQ, q = i - row * ME_WQ;
-        int gy = my * 16 - 16 + row, gx = sx * (ME_MBS * 16) - 16 + 16 * q;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ldg128(ref + (size_t)gy * stride + gx);
+        const int gy = clip3(0, H - 1, my * 16 - 16 + row), gx = sx * (ME_MBS * 16) - 16 + 16 * q;
+        uint4 v;
+        if (gx >= 0 && gx < W) v = ldg128(ref + (size_t)gy * stride + gx);
+        else { const unsigned e = ldg8(ref + (size_t)gy * stride + (gx < 0 ? 0 : W - 1)) * 0x01010101u; v = make_uint4(e, e, e, e); }
         unsigned *d = &win[row * ME_STRIDE + 4 * q];
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -101,45 +171,36 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
         __builtin_amdgcn_sched_barrier(0);
         w0 = n0; w1 = n1; w2 = n2; w3 = n3; w4 = n4;
     }
+    // ---- the surface: this lane's tile, five 8-byte words
+    if (active) {
+        uint16_t *sf = ctx->surf + (size_t)(my * mbw + mx) * SURF_U16 + 4 * dxg;
+#pragma unroll
+        for (int d = 0; d < ME_K; d++) stg64(sf + (ME_K * g + d) * SURF_COLS, make_uint2((unsigned)acc[d], (unsigned)(acc[d] >> 32)));
+    }
+    // ---- first selection: bits against the zero vector
+    const unsigned best = select_min(acc, g, dxg, active, ctx->me_range, ctx->lambda, 0, 0, 0, 0);
+    if (lane == 0 && mx < mbw) store_imv(&ctx->imv_a[my * mbw + mx], best, ctx->lambda, 0, 0, 0, 0);
+}
 
-    // ---- cost = SAD + lambda*(bits(dx)+bits(dy)); key = cost<<12 | (dy+16)<<6 | (dx+16)
-    const int R = ctx->me_range, lambda = ctx->lambda;
-    const int x0 = mxc * 16, y0 = my * 16;
-    const int dx_lo = -R < -x0 ? -x0 : -R, dx_hi = R > W - 16 - x0 ? W - 16 - x0 : R;
-    const int dy_lo = -R < -y0 ? -y0 : -R, dy_hi = R > H - 16 - y0 ? H - 16 - y0 : R;
-    const unsigned INVALID = 0x40000000u;
-    unsigned bo[4];
+// One Jacobi iteration of the selection: one wave per macroblock re-reads its surface (each lane the tile it wrote) and
+// selects against the 8.4.1.3 median / 8.4.1.1 skip inference of the field `in`.  HBM-shaped: 2520 bytes per macroblock.
+__global__ __launch_bounds__(256) void me_select_kernel(const frame_ctx_t cv, int mb0, int mb1, const imv_t *__restrict__ in, imv_t *__restrict__ out) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    const int mbw = ctx->mbw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mbn = mb0 + xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
+    if (mbn >= mb1) return; // wave-uniform; no workgroup barrier below
+    const int my = mbn / mbw, mx = mbn - my * mbw;
+    const bool active = lane < 63;
+    const int g = active ? lane / 9 : 0, dxg = active ? lane % 9 : 0;
+    unsigned long long acc[ME_K];
+    const uint16_t *sf = ctx->surf + (size_t)mbn * SURF_U16 + 4 * dxg;
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-        int dx = -16 + 4 * dxg + o;
-        bo[o] = (dx >= dx_lo && dx <= dx_hi && active) ? (((unsigned)(lambda * mv_bits(dx)) << 12) | (unsigned)(dx + 16)) : INVALID;
-    }
-    unsigned best = 0xFFFFFFFFu;
-#pragma unroll
-    for (int d = 0; d < ME_K; d++) {
-        int dy = -16 + ME_K * g + d;
-        unsigned bd = (dy >= dy_lo && dy <= dy_hi) ? (((unsigned)(lambda * mv_bits(dy)) << 12) | ((unsigned)(dy + 16) << 6)) : INVALID;
-        unsigned lo = (unsigned)acc[d], hi = (unsigned)(acc[d] >> 32);
-        unsigned k0 = ((lo << 16) >> 4) + bd + bo[0];
-        unsigned k1 = ((lo & 0xFFFF0000u) >> 4) + bd + bo[1];
-        unsigned k2 = ((hi << 16) >> 4) + bd + bo[2];
-        unsigned k3 = ((hi & 0xFFFF0000u) >> 4) + bd + bo[3];
-        unsigned ka = k0 < k1 ? k0 : k1, kb = k2 < k3 ? k2 : k3;
-        ka = ka < kb ? ka : kb;
-        best = best < ka ? best : ka;
-    }
-    // ---- wave-wide minimum
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-        unsigned o = (unsigned)__shfl_xor((int)best, sft, 64);
-        best = best < o ? best : o;
-    }
-    if (lane == 0 && mx < mbw) {
-        mb_info_t *mb = &ctx->mbi[my * mbw + mx];
-        const int bx_ = (int)(best & 63) - 16, by_ = (int)((best >> 6) & 63) - 16;
-        stg32(&mb->mvx, ((unsigned)(uint16_t)(4 * bx_)) | ((unsigned)(uint16_t)(4 * by_) << 16)); // quarter-sample units
-        stg32(&mb->cost, best >> 12);
-    }
+    for (int d = 0; d < ME_K; d++) { const uint2 v = ldg64(sf + (ME_K * g + d) * SURF_COLS); acc[d] = ((unsigned long long)v.y << 32) | v.x; }
+    const fpred_t fp = field_pred(in, mbw, mx, my);
+    const int px = fp.px >> 2, py = fp.py >> 2, sx = fp.sx >> 2, sy = fp.sy >> 2;
+    const unsigned best = select_min(acc, g, dxg, active, ctx->me_range, ctx->lambda, px, py, sx, sy);
+    if (lane == 0) store_imv(&out[mbn], best, ctx->lambda, px, py, sx, sy);
 }
 
 // =================================================================== sub-sample refinement
@@ -344,29 +405,202 @@ __global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t cv, int m
     }
 }
 
-// =================================================================== P macroblocks, fused: refinement + prediction + residual
-// One wave = one macroblock (the shape of subpel_kernel, whose first half this repeats): after the refinement the
-// half-sample planes are still in LDS, so the luma prediction of the winning vector is one sp_sample4() per lane -- the
-// lane's four pixels of row lane>>2 -- instead of inter_kernel's 81 byte loads and per-pixel case analysis per 4x4 block.
-// From there a 4x4 block lives on the four lanes that hold its rows (lane bits 3:2 = row in block, 1:0 = block column,
-// 5:4 = block row): the row transforms are in-lane, the column transforms two-stage DPP butterflies inside the 16-lane row
-// (as in the Intra4x4 path: coefficients stay in the lane order 0 2 1 3 and are addressed by frequency), so all 64 lanes
-// carry luma; chroma runs on 32 lanes in the same layout (16-lane row = the four blocks Cb0 Cb1 Cr0 Cr1 of one block row),
-// reads the reference and the source as words, and the Cb lanes store interleaved 8-byte row segments after fetching
-// their Cr partners' samples with one DPP move.  Used for every P picture without the 8x8 transform; the separate
-// subpel_kernel / inter_kernel remain for the High-profile path and the single-stage entry points.
+// =================================================================== P macroblocks, fused stage
+// One wave = one macroblock; everything a P macroblock needs after the vector field is settled (oracle: orc_pmb_frame):
+//   1. predictor estimates p_est / ps_est from the whole-sample field (field_pred);
+//   2. skip probe at ps_est -- worth running only when its SAD (already on the surface) is within lambda * SKIP_MARGIN_BITS
+//      of the best whole-sample SAD: prediction straight from the reference picture, residual through the transform and
+//      the quantiser with coefficient decimation; if nothing is left (luma, chroma AC and DC) the macroblock takes ps_est
+//      without residual and the wave is done.  Rate control's ladder below QP 51 (ctx->drop_sad) passes the probe on the
+//      SAD alone;
+//   3. sub-sample refinement around the whole-sample winner (planes in LDS as in subpel_kernel), bits against p_est:
+//      half-sample round by SAD, quarter-sample round by SATD (4x4 Hadamard on the four-lanes-per-block layout);
+//   4. intra instead, when the macroblock was analysed (search cost >= INTRA_GATE) and the open-loop intra cost wins:
+//      only type and modes go to the record, intra_p_kernel reconstructs;
+//   5. residual of the final vector: a 4x4 block lives on the four lanes that hold its rows (lane bits 3:2 = row in
+//      block, 1:0 = block column, 5:4 = block row), row transforms in-lane, column transforms as DPP butterflies;
+//      decimation scores from the blocks' 16-bit significance masks (no run loops); chroma on 32 lanes (chroma_rows4).
+DEV int dec_score(unsigned M) { return dec_score_mask(M); }
+DEV int row_or4(int v) { // OR over the four lanes l, l+4, l+8, l+12 of a 16-lane row (the four rows of a 4x4 block)
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false); // row_ror:8
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false); // row_ror:4
+    return v;
+}
+// four luma samples at whole-sample position (x .. x+3, y) of the reference, one per byte; `inside`: the macroblock's whole
+// 16 x 16 block lies in the picture (wave-uniform), otherwise coordinates clamp (8.4.2.2)
+DEV unsigned ref_word4(const uint8_t *__restrict__ ref, int stride, int W, int H, int x, int y, bool inside) {
+    if (inside) {
+        const uint8_t *b = ref + (size_t)y * stride + (x & ~3);
+        return __builtin_amdgcn_alignbyte(ldg32(b + 4), ldg32(b), (unsigned)(x & 3)); // may touch 4 bytes past the row: SURF_PAD
+    }
+    const uint8_t *r = ref + (size_t)clip3(0, H - 1, y) * stride;
+    return pack4((int)ldg8(r + clip3(0, W - 1, x)), (int)ldg8(r + clip3(0, W - 1, x + 1)), (int)ldg8(r + clip3(0, W - 1, x + 2)), (int)ldg8(r + clip3(0, W - 1, x + 3)));
+}
+// chroma prediction (8.4.2.2.2) of this lane's four samples for the quarter-sample luma vector (mvx, mvy); lanes 0..31:
+// bit 4 = block row, bits 3:2 = row in block, bit 1 = plane, bit 0 = block column
+DEV void chroma_pred4(const frame_ctx_t *__restrict__ ctx, int lane, int x0, int y0, int W, int H, int mvx, int mvy, int *pd) {
+    const int stride = ctx->stride;
+    const int py = (lane >> 2) & 3, cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1;
+    const int cx0 = x0 >> 1, cy0 = y0 >> 1, cw = W >> 1, ch = H >> 1;
+    const int cy = cby * 4 + py, cxb = cbx * 4;
+    const int xi = mvx >> 3, yi = mvy >> 3, xf = mvx & 7, yf = mvy & 7;
+    const uint8_t *__restrict__ rf = ctx->ref_uv;
+    int A[5], B[5];
+    if (cx0 + xi >= 0 && cx0 + xi + 9 <= cw && cy0 + yi >= 0 && cy0 + yi + 9 <= ch) { // whole 9 x 9 neighbourhood inside (wave-uniform)
+        const int o = 2 * (cx0 + cxb + xi) + c, a = o & 3;
+        const uint8_t *r0 = rf + (size_t)(cy0 + cy + yi) * stride + (o & ~3), *r1 = r0 + stride;
+        const unsigned a0 = ldg32(r0), a1 = ldg32(r0 + 4), a2 = ldg32(r0 + 8), b0 = ldg32(r1), b1 = ldg32(r1 + 4), b2 = ldg32(r1 + 8);
+        const unsigned sa0 = __builtin_amdgcn_alignbyte(a1, a0, (unsigned)a), sa1 = __builtin_amdgcn_alignbyte(a2, a1, (unsigned)a);
+        const unsigned sb0 = __builtin_amdgcn_alignbyte(b1, b0, (unsigned)a), sb1 = __builtin_amdgcn_alignbyte(b2, b1, (unsigned)a);
+        A[0] = byte_of(sa0, 0); A[1] = byte_of(sa0, 2); A[2] = byte_of(sa1, 0); A[3] = byte_of(sa1, 2); A[4] = (int)((a2 >> (8 * a)) & 255);
+        B[0] = byte_of(sb0, 0); B[1] = byte_of(sb0, 2); B[2] = byte_of(sb1, 0); B[3] = byte_of(sb1, 2); B[4] = (int)((b2 >> (8 * a)) & 255);
+    } else {
+        const int ya = clip3(0, ch - 1, cy0 + cy + yi), yb = clip3(0, ch - 1, cy0 + cy + yi + 1);
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int xx = clip3(0, cw - 1, cx0 + cxb + i + xi);
+            A[i] = (int)ldg8(rf + (size_t)ya * stride + 2 * xx + c);
+            B[i] = (int)ldg8(rf + (size_t)yb * stride + 2 * xx + c);
+        }
+    }
+    const int w00 = (8 - xf) * (8 - yf), w10 = xf * (8 - yf), w01 = (8 - xf) * yf, w11 = xf * yf;
+#pragma unroll
+    for (int i = 0; i < 4; i++) pd[i] = (w00 * A[i] + w10 * A[i + 1] + w01 * B[i] + w11 * B[i + 1] + 32) >> 6;
+}
+// Luma of an inter macroblock on all 64 lanes: residual of the lane's source word against its prediction word, transform,
+// quantiser, decimation.  lev[4]: this lane's levels (frequency row fy of its block) after decimation; x[4]: the dequantised
+// coefficients, ready for inv_rows4 / inv_col.  Returns the blkIdx-order mask of blocks that keep levels (wave-uniform).
+DEV unsigned pmb_luma_tq(const dev_tables *T, int lane, unsigned curw, unsigned pw, int qp, bool decimate, int *lev, int *x) {
+    const int py = (lane >> 2) & 3, fy = ((py & 1) << 1) | (py >> 1);
+    const col_bf cb = make_col_bf(py);
+    const int kz0 = (int)((0xFEA9DB83C7426510ull >> (16 * fy)) & 0xFFFF); // zig-zag positions of raster 4 fy + 0 .. 3, a nibble each
+    const qparams q = make_q(T, qp, false);
+    const int mfe = py < 2 ? q.mf[0] : q.mf[2], mfo = py < 2 ? q.mf[2] : q.mf[1], ve = py < 2 ? q.v[0] : q.v[2], vo = py < 2 ? q.v[2] : q.v[1];
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = byte_of(curw, i) - byte_of(pw, i);
+    fwd_rows4(x);
+    unsigned m = 0, big = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int cf = fwd_col(x[i], cb);
+        lev[i] = quant1(cf, (i & 1) ? mfo : mfe, q.f, q.qbits);
+        m |= (lev[i] != 0 ? 1u : 0u) << ((kz0 >> (4 * i)) & 15);
+        big |= (lev[i] > 1 || lev[i] < -1) ? 1u : 0u;
+    }
+    if (decimate) {
+        const unsigned mm = (unsigned)row_or4((int)(m | (big << 16))); // the block's 16 significance bits + "has a level beyond +-1"
+        int s = (mm >> 16) ? 9 : dec_score(((mm & 0xFFFFu) << 1) | 1u);
+        int s8 = s + quad_xor<1>(s);            // the 8x8 block: block columns 2k, 2k+1 ...
+        s8 += __shfl_xor(s8, 16, 64);           // ... and block rows 2k, 2k+1
+        int tot = s8 + quad_xor<2>(s8);
+        tot += __shfl_xor(tot, 32, 64);
+        if (s8 < 4 || tot < 6) { lev[0] = lev[1] = lev[2] = lev[3] = 0; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
+    // non-zero blocks: OR over the block's four lanes, then into luma4x4BlkIdx order
+    const unsigned long long bal = __ballot((lev[0] | lev[1] | lev[2] | lev[3]) != 0);
+    const unsigned long long t = bal | (bal >> 4) | (bal >> 8) | (bal >> 12); // bit 16 by + bx
+    const int rb = lane & 15, rbx = blkx(rb) >> 2, rby = blky(rb) >> 2;
+    return (unsigned)(__ballot(lane < 16 && ((t >> (16 * rby + rbx)) & 1)) & 0xFFFFull);
+}
+// sum of |H d H^T| over the macroblock's sixteen 4x4 blocks for prediction word pw (unhalved; wave-uniform result)
+DEV unsigned pmb_satd(int lane, unsigned curw, unsigned pw) {
+    const int py = (lane >> 2) & 3, s1 = py < 2 ? 1 : -1, s2 = (py & 1) ? -1 : 1;
+    const int d0 = byte_of(curw, 0) - byte_of(pw, 0), d1 = byte_of(curw, 1) - byte_of(pw, 1), d2 = byte_of(curw, 2) - byte_of(pw, 2), d3 = byte_of(curw, 3) - byte_of(pw, 3);
+    const int a = d0 + d3, b = d1 + d2, c = d1 - d2, e = d0 - d3;
+    int t[4] = {a + b, e + c, a - b, e - c};
+    int acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int u = mad24(t[i], s1, row_xor8(t[i])); // rows py and py ^ 2
+        const int w = mad24(u, s2, row_xor4(u));       // ... and py ^ 1
+        acc += iabs(w);
+    }
+    return (unsigned)wave64_sum(acc);
+}
+// write a macroblock that carries no residual: the prediction is the reconstruction, every level is zero
+DEV void pmb_store_pred_only(const frame_ctx_t *__restrict__ ctx, int16_t *lv, int lane, int x0, int y0, unsigned pw, const int *pd) {
+    const int stride = ctx->stride, pr = lane >> 2, pc = (lane & 3) * 4;
+    stg32(ctx->rec_y + (size_t)(y0 + pr) * stride + x0 + pc, pw);
+    const int py = (lane >> 2) & 3, cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1;
+    const unsigned mine = pack4(pd[0], pd[1], pd[2], pd[3]), other = (unsigned)quad_xor<2>((int)mine);
+    if (lane < 32 && c == 0) {
+        uint2 out;
+        out.x = __builtin_amdgcn_perm(other, mine, 0x05010400u); // U0 V0 U1 V1
+        out.y = __builtin_amdgcn_perm(other, mine, 0x07030602u); // U2 V2 U3 V3
+        stg64(ctx->rec_uv + (size_t)((y0 >> 1) + cby * 4 + py) * stride + 2 * ((x0 >> 1) + cbx * 4), out);
+    }
+    if (lane < MB_LEVELS * 2 / 16) stg128(lv + 8 * lane, make_uint4(0, 0, 0, 0)); // 816 bytes = 51 x 16
+}
+
 __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
-    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = ctx->qp;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = ctx->qp, lambda = ctx->lambda;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int mbn = mb0 + blockIdx.x * 4 + wave; // the launch covers macroblocks mb0 .. mb1-1
-    const bool ok = mbn < mb1;             // wave-uniform
-    if (!ok) mbn = mb1 - 1;
+    const int mbn = mb0 + blockIdx.x * 4 + wave; // the launch covers macroblocks mb0 .. mb1-1
+    if (mbn >= mb1) return;                      // wave-uniform; the kernel has no workgroup barrier
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
     sp_lds *L = &LD[wave];
-    const mb_info_t info = ld_mbinfo(&ctx->mbi[mbn]);
-    const int ix = x0 + (info.mvx >> 2), iy = y0 + (info.mvy >> 2); // integer winner (vector is a multiple of 4 here)
+    const dev_tables *T = &g_tab;
+    const imv_t *__restrict__ field = k_final_imv_dev(ctx);
+    const uint2 selfw = ldg64(field + mbn);
+    const int imx = (int)(int16_t)(selfw.x & 0xFFFF), imy = (int)(int16_t)(selfw.x >> 16); // whole-sample winner, quarter-sample units
+    const unsigned di = selfw.y & 0xFFFFu, ibits = selfw.y >> 16;
+    const fpred_t fp = field_pred(field, mbw, mx, my);
+    const int pr = lane >> 2, pc = (lane & 3) * 4; // luma: lane owns row pr, columns pc .. pc+3
+    const int py = (lane >> 2) & 3;
+    unsigned curw;
+    {
+        int sy = y0 + pr;
+        sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
+        curw = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + x0 + pc);
+    }
+    int sv[4]; // chroma source samples of this lane (lanes 0..31)
+    {
+        const int cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1;
+        int sy = (y0 >> 1) + cby * 4 + py;
+        const int vh2 = ctx->vis_h >> 1;
+        sy = sy < vh2 ? sy : vh2 - 1;
+        const uint2 sw = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * ((x0 >> 1) + cbx * 4));
+        const unsigned slo = c ? (sw.x >> 8) : sw.x, shi = c ? (sw.y >> 8) : sw.y;
+        sv[0] = (int)(slo & 255); sv[1] = (int)((slo >> 16) & 255); sv[2] = (int)(shi & 255); sv[3] = (int)((shi >> 16) & 255);
+    }
+    int16_t *lv = ctx->levels + (size_t)mbn * MB_LEVELS;
+    mb_info_t *mb = &ctx->mbi[mbn];
+    // ---- 2. skip probe
+    {
+        const unsigned ds = (unsigned)*(const GAS uint16_t *)(ctx->surf + (size_t)mbn * SURF_U16 + ((fp.sy >> 2) + 16) * SURF_COLS + (fp.sx >> 2) + 16);
+        bool pass = ctx->drop_sad && ds < ctx->drop_sad;
+        const bool worth = ds <= di + (unsigned)(lambda * SKIP_MARGIN_BITS);
+        if (pass || worth) {
+            const int X = x0 + (fp.sx >> 2), Y = y0 + (fp.sy >> 2);
+            const bool inside = X >= 0 && Y >= 0 && X + 16 <= W && Y + 16 <= H;
+            const unsigned pw = ref_word4(ctx->ref_y, stride, W, H, X + pc, Y + pr, inside);
+            int pd[4];
+            chroma_pred4(ctx, lane, x0, y0, W, H, fp.sx, fp.sy, pd);
+            if (!pass) {
+                int lev[4], x[4];
+                if (pmb_luma_tq(T, lane, curw, pw, qp, true, lev, x) == 0) {
+                    unsigned nz_c = 0, dc_c = 0;
+                    chroma_rows4(ctx, T, lv, x0 >> 1, y0 >> 1, lane, pd, sv, qp, false, false, nullptr, nz_c, dc_c, true);
+                    pass = (nz_c | dc_c) == 0;
+                }
+            }
+            if (pass) {
+                pmb_store_pred_only(ctx, lv, lane, x0, y0, pw, pd);
+                if (lane == 0) {
+                    mb_info_t m;
+                    m.mvx = (int16_t)fp.sx; m.mvy = (int16_t)fp.sy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = ds;
+                    st_mbinfo(mb, m);
+                }
+                return;
+            }
+        }
+    }
+    // ---- 3. refinement around the whole-sample winner
+    const int ix = x0 + (imx >> 2), iy = y0 + (imy >> 2);
     const uint8_t *__restrict__ ref = ctx->ref_y;
     if (ix - 3 >= 0 && iy - 3 >= 0 && ((ix - 3) & ~3) + 28 <= W && iy + 19 < H) {
         const int a = (ix - 3) & 3;
@@ -382,139 +616,137 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
             int yy = clip3(0, H - 1, iy - 3 + r), xx = clip3(0, W - 1, ix - 3 + c);
             L->G[r * SP_GS + c] = (uint8_t)ldg8(ref + (size_t)yy * stride + xx);
         }
-    const int pr = lane >> 2, pc = (lane & 3) * 4; // luma: lane owns row pr, columns pc .. pc+3
-    unsigned curw;
-    {
-        int sy = y0 + pr;
-        sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
-        curw = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + x0 + pc);
-    }
     WAVE_SYNC();
-    int bqx = info.mvx, bqy = info.mvy;
-    unsigned best = info.cost;
-    if (refine) { // ---- as subpel_kernel
+    int bqx = imx, bqy = imy;
+    unsigned best = di + (unsigned)(lambda * (mvq_bits(imx - fp.px) + mvq_bits(imy - fp.py)));
+    if (refine) {
         sp_planes(L, lane);
-        const int lambda = ctx->lambda;
-#pragma unroll 1
-        for (int step = 2; step >= 1; step--) {
+        { // half-sample round: SAD, the 8 candidates scored together (two 16-bit partial sums per register)
             const int cqx = bqx, cqy = bqy;
             unsigned acc[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int c8 = 0; c8 < 8; c8++) {
                 const int k = c8 < 4 ? c8 : c8 + 1;
-                const int qx = cqx + (k % 3 - 1) * step, qy = cqy + (k / 3 - 1) * step;
-                const int ox = qx - info.mvx, oy = qy - info.mvy;
+                const int qx = cqx + (k % 3 - 1) * 2, qy = cqy + (k / 3 - 1) * 2;
+                const int ox = qx - imx, oy = qy - imy;
                 const unsigned sad = __builtin_amdgcn_sad_u8(curw, sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3), 0u);
                 acc[c8 >> 1] |= sad << (16 * (c8 & 1));
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                acc[q] = (unsigned)wave64_sum((int)acc[q]);
-            }
+            for (int q = 0; q < 4; q++) acc[q] = (unsigned)wave64_sum((int)acc[q]);
 #pragma unroll
             for (int c8 = 0; c8 < 8; c8++) {
                 const int k = c8 < 4 ? c8 : c8 + 1;
-                const int qx = cqx + (k % 3 - 1) * step, qy = cqy + (k / 3 - 1) * step;
+                const int qx = cqx + (k % 3 - 1) * 2, qy = cqy + (k / 3 - 1) * 2;
                 const unsigned sad = (acc[c8 >> 1] >> (16 * (c8 & 1))) & 0xFFFFu;
-                const unsigned cost = sad + (unsigned)(lambda * (mvq_bits(qx) + mvq_bits(qy)));
+                const unsigned cost = sad + (unsigned)(lambda * (mvq_bits(qx - fp.px) + mvq_bits(qy - fp.py)));
+                if (cost < best) { best = cost; bqx = qx; bqy = qy; }
+            }
+        }
+        { // quarter-sample round: SATD; the standing best is restated in the same measure first
+            const int cqx = bqx, cqy = bqy;
+            {
+                const int ox = cqx - imx, oy = cqy - imy;
+                best = (pmb_satd(lane, curw, sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3)) >> 1) +
+                       (unsigned)(lambda * (mvq_bits(cqx - fp.px) + mvq_bits(cqy - fp.py)));
+            }
+#pragma unroll 1
+            for (int k = 0; k < 9; k++) {
+                if (k == 4) continue;
+                const int qx = cqx + (k % 3 - 1), qy = cqy + (k / 3 - 1);
+                const int ox = qx - imx, oy = qy - imy;
+                const unsigned d = pmb_satd(lane, curw, sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3)) >> 1;
+                const unsigned cost = d + (unsigned)(lambda * (mvq_bits(qx - fp.px) + mvq_bits(qy - fp.py)));
                 if (cost < best) { best = cost; bqx = qx; bqy = qy; }
             }
         }
     }
-    const dev_tables *T = &g_tab;
-    const int py = (lane >> 2) & 3, fy = ((py & 1) << 1) | (py >> 1);
-    const col_bf cb = make_col_bf(py);
-    const int kz0 = (int)((0xFEA9DB83C7426510ull >> (16 * fy)) & 0xFFFF); // zig-zag positions of raster 4 fy + 0 .. 3, a nibble each
-    int16_t *lv = ctx->levels + (size_t)mbn * MB_LEVELS;
-    unsigned nz_luma = 0;
-    { // ---- luma: prediction of the final vector, residual, transform, quantisation, reconstruction
-        const int ox = bqx - info.mvx, oy = bqy - info.mvy;
-        const unsigned pw = sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3);
-        const qparams q = make_q(T, qp, false);
-        const int mfe = py < 2 ? q.mf[0] : q.mf[2], mfo = py < 2 ? q.mf[2] : q.mf[1], ve = py < 2 ? q.v[0] : q.v[2], vo = py < 2 ? q.v[2] : q.v[1];
-        int x[4], lev[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) x[i] = byte_of(curw, i) - byte_of(pw, i);
-        fwd_rows4(x);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int cf = fwd_col(x[i], cb);
-            lev[i] = quant1(cf, (i & 1) ? mfo : mfe, q.f, q.qbits);
-            x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
+    // ---- the final vector's prediction and its cost in the SAD domain
+    const int ox = bqx - imx, oy = bqy - imy;
+    const unsigned pw = sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3);
+    const unsigned dsad = (unsigned)wave64_sum((int)__builtin_amdgcn_sad_u8(curw, pw, 0u));
+    const unsigned jinter = dsad + (unsigned)(lambda * (mvq_bits(bqx - fp.px) + mvq_bits(bqy - fp.py)));
+    // ---- 4. intra instead?
+    if (ctx->intra_p && di + (unsigned)lambda * ibits >= INTRA_GATE(lambda)) {
+        const uint4 dw = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES + 16); // mode16 | cmode << 8 | use_i4 << 16; cost; cost_luma; 0
+        const unsigned jintra = dw.z + (dw.z >> 3) + (unsigned)(lambda * 12);
+        if (jintra < jinter) {
+            if (lane == 0) {
+                const bool i4 = ((dw.x >> 16) & 255u) != 0;
+                mb_info_t m;
+                m.mvx = 0; m.mvy = 0; m.mb_type = i4 ? 2 : 0; m.i16_mode = i4 ? 0 : (uint8_t)(dw.x & 255u); m.chroma_mode = (uint8_t)((dw.x >> 8) & 255u);
+                m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = dw.y;
+                st_mbinfo(mb, m);
+            }
+            return;
         }
+    }
+    // ---- 5. residual
+    int pd[4];
+    chroma_pred4(ctx, lane, x0, y0, W, H, bqx, bqy, pd);
+    if (ctx->drop_sad && dsad < ctx->drop_sad) { // rate control's ladder below QP 51: prediction only
+        pmb_store_pred_only(ctx, lv, lane, x0, y0, pw, pd);
+        if (lane == 0) {
+            mb_info_t m;
+            m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = jinter;
+            st_mbinfo(mb, m);
+        }
+        return;
+    }
+    unsigned nz_luma;
+    {
+        const int fy = ((py & 1) << 1) | (py >> 1);
+        const col_bf cb = make_col_bf(py);
+        const int kz0 = (int)((0xFEA9DB83C7426510ull >> (16 * fy)) & 0xFFFF);
+        int lev[4], x[4];
+        nz_luma = pmb_luma_tq(T, lane, curw, pw, qp, true, lev, x);
         const int bx = lane & 3, by = lane >> 4, b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1);
-        if (ok) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) stg16(&lv[L_LUMA + b * 16 + ((kz0 >> (4 * i)) & 15)], lev[i]);
-        }
+        for (int i = 0; i < 4; i++) stg16(&lv[L_LUMA + b * 16 + ((kz0 >> (4 * i)) & 15)], lev[i]);
         inv_rows4(x);
         int o[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) o[i] = clip255(byte_of(pw, i) + ((inv_col(x[i], cb) + 32) >> 6));
-        if (ok) stg32(ctx->rec_y + (size_t)(y0 + pr) * stride + x0 + pc, pack4(o[0], o[1], o[2], o[3]));
-        // non-zero blocks: OR over the block's four lanes, then into luma4x4BlkIdx order
-        const unsigned long long bal = __ballot((lev[0] | lev[1] | lev[2] | lev[3]) != 0);
-        const unsigned long long t = bal | (bal >> 4) | (bal >> 8) | (bal >> 12); // bit 16 by + bx
-        const int rb = lane & 15, rbx = blkx(rb) >> 2, rby = blky(rb) >> 2;
-        nz_luma = (unsigned)(__ballot(lane < 16 && ((t >> (16 * rby + rbx)) & 1)) & 0xFFFFull);
+        stg32(ctx->rec_y + (size_t)(y0 + pr) * stride + x0 + pc, pack4(o[0], o[1], o[2], o[3]));
     }
     unsigned nz_c = 0, dc_c = 0;
-    { // ---- chroma on lanes 0..31: bit 4 = block row, bits 3:2 = row in block, bit 1 = plane, bit 0 = block column
-        const int cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1;
-        const int cx0 = x0 >> 1, cy0 = y0 >> 1, cw = W >> 1, ch = H >> 1;
-        const int cy = cby * 4 + py, cxb = cbx * 4;
-        // 8.4.1.4 / 8.4.2.2.2: the chroma vector is the luma vector read in 1/8 chroma-sample units
-        const int xi = bqx >> 3, yi = bqy >> 3, xf = bqx & 7, yf = bqy & 7;
-        const uint8_t *__restrict__ rf = ctx->ref_uv;
-        int A[5], B[5];
-        if (cx0 + xi >= 0 && cx0 + xi + 9 <= cw && cy0 + yi >= 0 && cy0 + yi + 9 <= ch) { // whole 9 x 9 neighbourhood inside (wave-uniform)
-            const int o = 2 * (cx0 + cxb + xi) + c, a = o & 3;
-            const uint8_t *r0 = rf + (size_t)(cy0 + cy + yi) * stride + (o & ~3), *r1 = r0 + stride;
-            const unsigned a0 = ldg32(r0), a1 = ldg32(r0 + 4), a2 = ldg32(r0 + 8), b0 = ldg32(r1), b1 = ldg32(r1 + 4), b2 = ldg32(r1 + 8);
-            const unsigned sa0 = __builtin_amdgcn_alignbyte(a1, a0, (unsigned)a), sa1 = __builtin_amdgcn_alignbyte(a2, a1, (unsigned)a);
-            const unsigned sb0 = __builtin_amdgcn_alignbyte(b1, b0, (unsigned)a), sb1 = __builtin_amdgcn_alignbyte(b2, b1, (unsigned)a);
-            A[0] = byte_of(sa0, 0); A[1] = byte_of(sa0, 2); A[2] = byte_of(sa1, 0); A[3] = byte_of(sa1, 2); A[4] = (int)((a2 >> (8 * a)) & 255);
-            B[0] = byte_of(sb0, 0); B[1] = byte_of(sb0, 2); B[2] = byte_of(sb1, 0); B[3] = byte_of(sb1, 2); B[4] = (int)((b2 >> (8 * a)) & 255);
-        } else {
-            const int ya = clip3(0, ch - 1, cy0 + cy + yi), yb = clip3(0, ch - 1, cy0 + cy + yi + 1);
-#pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const int xx = clip3(0, cw - 1, cx0 + cxb + i + xi);
-                A[i] = (int)ldg8(rf + (size_t)ya * stride + 2 * xx + c);
-                B[i] = (int)ldg8(rf + (size_t)yb * stride + 2 * xx + c);
-            }
-        }
-        int sy = cy0 + cy;
-        const int vh2 = ctx->vis_h >> 1;
-        sy = sy < vh2 ? sy : vh2 - 1;
-        const uint2 sw = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * (cx0 + cxb));
-        const unsigned slo = c ? (sw.x >> 8) : sw.x, shi = c ? (sw.y >> 8) : sw.y;
-        const int sv[4] = {(int)(slo & 255), (int)((slo >> 16) & 255), (int)(shi & 255), (int)((shi >> 16) & 255)};
-        const int w00 = (8 - xf) * (8 - yf), w10 = xf * (8 - yf), w01 = (8 - xf) * yf, w11 = xf * yf;
-        int pd[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) pd[i] = (w00 * A[i] + w10 * A[i + 1] + w01 * B[i] + w11 * B[i + 1] + 32) >> 6;
-        chroma_rows4(ctx, T, lv, cx0, cy0, lane, pd, sv, qp, false, ok, nullptr, nz_c, dc_c);
-    }
-    if (ok && lane == 0) {
+    chroma_rows4(ctx, T, lv, x0 >> 1, y0 >> 1, lane, pd, sv, qp, false, true, nullptr, nz_c, dc_c, true);
+    if (lane == 0) {
         unsigned nzm = nz_luma | (nz_c << 16);
         if (dc_c & 1) nzm |= NZ_CBDC;
         if (dc_c & 2) nzm |= NZ_CRDC;
-        mb_info_t *mb = &ctx->mbi[mbn];
-        stg32(&mb->mvx, ((unsigned)(uint16_t)bqx) | ((unsigned)(uint16_t)bqy << 16));
-        stg32(&mb->cost, best);
-        stg32(&mb->mb_type, 1u | ((unsigned)qp << 24)); // mb_type 1, modes 0, qp
-        stg32(&mb->nzmask, nzm);
+        mb_info_t m;
+        m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = nzm; m.cost = jinter;
+        st_mbinfo(mb, m);
     }
-    if (ok && lane < 2) stg128(lv + L_LDC + 8 * lane, make_uint4(0, 0, 0, 0)); // luma DC levels: unused by P macroblocks, kept zero
+    if (lane < 2) stg128(lv + L_LDC + 8 * lane, make_uint4(0, 0, 0, 0)); // luma DC levels: unused by P macroblocks, kept zero
+}
+
+// whole-sample field -> records for the two-kernel (8x8-transform) path: subpel_kernel compares absolute-vector costs
+__global__ __launch_bounds__(256) void imv_to_mbi_kernel(const frame_ctx_t cv, int mb0, int mb1) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    const int i = mb0 + blockIdx.x * 256 + threadIdx.x;
+    if (i >= mb1) return;
+    const uint2 w = ldg64(k_final_imv_dev(ctx) + i);
+    const int vx = (int)(int16_t)(w.x & 0xFFFF), vy = (int)(int16_t)(w.x >> 16);
+    stg32(&ctx->mbi[i].mvx, w.x);
+    stg32(&ctx->mbi[i].cost, (w.y & 0xFFFFu) + (unsigned)(ctx->lambda * (mvq_bits(vx) + mvq_bits(vy))));
 }
 
 // =================================================================== launchers
-// The three P-picture kernels take a macroblock-row range [row0, row1): the host overlaps the upper part of picture n+1
-// with the tail of picture n's deblocking (mi355enc.cpp, enqueue_picture).
+// The P-picture kernels take a macroblock-row range [row0, row1).
 void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
     int strips = (mbw + ME_MBS - 1) / ME_MBS;
     if (row1 > row0) hipLaunchKernelGGL(me_kernel, dim3(strips * (row1 - row0)), dim3(64 * ME_MBS), 0, s, *h_ctx, row0);
+}
+void k_launch_me_select(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, const imv_t *in, imv_t *out, hipStream_t s) {
+    int n = mbw * (row1 - row0);
+    if (n > 0) hipLaunchKernelGGL(me_select_kernel, dim3((n + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, in, out);
+}
+const imv_t *k_final_imv(const frame_ctx_t *h_ctx) { return (ME_ITERS & 1) ? h_ctx->imv_b : h_ctx->imv_a; }
+void k_launch_imv_to_mbi(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
+    int n = mbw * (row1 - row0);
+    if (n > 0) hipLaunchKernelGGL(imv_to_mbi_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw);
 }
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
     if (row1 > row0) hipLaunchKernelGGL(subpel_kernel, dim3((mbw * (row1 - row0) + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw);

@@ -93,6 +93,9 @@ DEV void st_mbinfo(mb_info_t *p, const mb_info_t &m) {
     stg128(p, r);
 }
 
+// where the last of the ME_ITERS selection iterations leaves the whole-sample vector field (they alternate imv_a -> imv_b -> ...)
+DEV const imv_t *k_final_imv_dev(const frame_ctx_t *ctx) { return (ME_ITERS & 1) ? ctx->imv_b : ctx->imv_a; }
+
 // ------------------------------------------------------------------ cross-workgroup hand-off inside a persistent launch
 // Agent-scope (sc1, L1-bypassing) accesses for data one workgroup produces and another consumes while both run, and a bounded
 // wait on a monotonic progress counter (MI355X_MICROARCH.md, "Valid forms": producer stores the data sc1, s_waitcnt vmcnt(0),
@@ -331,8 +334,15 @@ DEV int inv_col(int v, const col_bf &c) { // takes frequency order F[py], return
 // the reconstruction (Cb lanes fetch their Cr partners with one DPP move and store interleaved 8-byte segments; also into
 // the 8 x 16 LDS tile `lrec` if given).  Every lane of the wave must call (DPP, ballots).  nz8: blocks with AC levels in
 // record order 4 c + 2 by + bx; dc2: bit 0 Cb / bit 1 Cr have DC levels.
+// decimate (inter macroblocks, x264 dct-decimate): a plane whose four blocks' AC run/level score stays below 7 loses its AC levels.
+// ok == false: nothing is stored (the skip probe only wants nz8 / dc2).
+DEV int dec_score_mask(unsigned M) { // decimate score of a +-1-only block from its significance mask with a sentinel bit below the first position
+    const unsigned c0 = (unsigned)__popc(M & (M << 1));
+    const unsigned a1 = M & ~(M << 1) & ~1u, a3 = a1 & ~(M << 2) & ~(M << 3), a6 = a3 & ~(M << 4) & ~(M << 5) & ~(M << 6);
+    return (int)(3 * c0 + 2 * (unsigned)__popc(a1) - (unsigned)__popc(a3) - (unsigned)__popc(a6));
+}
 DEV void chroma_rows4(const frame_ctx_t *ctx, const dev_tables *T, int16_t *lv, int cx0, int cy0, int lane, const int *pd, const int *sv, int qp,
-                      bool intra, bool ok, uint8_t *lrec, unsigned &nz8, unsigned &dc2) {
+                      bool intra, bool ok, uint8_t *lrec, unsigned &nz8, unsigned &dc2, bool decimate = false) {
     const bool cl = lane < 32;
     const int py = (lane >> 2) & 3, fy = ((py & 1) << 1) | (py >> 1);
     const int cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1, cy = cby * 4 + py, cxb = cbx * 4;
@@ -356,11 +366,24 @@ DEV void chroma_rows4(const frame_ctx_t *ctx, const dev_tables *T, int16_t *lv, 
     g = mad24(g, sby, __shfl_xor(g, 16, 64));
     const int dcc = ((g * 16 * q.v[0]) << q.shift) >> 5;
     const bool dcl = py == 0; // this lane holds a DC term
+    unsigned sig = 0, big = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         lev[i] = (i == 0 && dcl) ? 0 : quant1(cf[i], (i & 1) ? mfo : mfe, q.f, q.qbits);
-        x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
+        sig |= (lev[i] != 0 ? 1u : 0u) << ((kz0 >> (4 * i)) & 15);
+        big |= (lev[i] > 1 || lev[i] < -1) ? 1u : 0u;
     }
+    if (decimate) {
+        int mm = (int)(sig | (big << 16)); // OR over the block's four lanes (l, l+4, l+8, l+12 of the 16-lane row)
+        mm |= __builtin_amdgcn_update_dpp(0, mm, 0x128, 0xF, 0xF, false);
+        mm |= __builtin_amdgcn_update_dpp(0, mm, 0x124, 0xF, 0xF, false);
+        int s = ((unsigned)mm >> 16) ? 9 : dec_score_mask(((unsigned)mm & 0xFFFFu) | 1u); // AC only: position 0 is the sentinel
+        s += quad_xor<1>(s);            // the plane's two block columns ...
+        s += __shfl_xor(s, 16, 64);     // ... and two block rows
+        if (s < 7) { lev[0] = lev[1] = lev[2] = lev[3] = 0; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
     if (dcl) x[0] = dcc;
     const int b = cby * 2 + cbx;
     if (ok && cl) {

@@ -2,9 +2,11 @@
 // surfaces, the stream, the captured launch graphs, the picture pipeline and rate control.
 //
 // Per picture, on one HIP stream:
-//   [H2D source] -> ctx upload -> IDR: intra wavefront (x+y diagonals)
-//                                 P  : me_kernel -> inter_kernel
-//                -> deblock (prep + persistent band kernel) -> D2H {mb records, levels} -> event
+//   [H2D source] -> IDR: intra analysis (flat) -> intra wavefront (persistent bands)
+//                   P  : me_kernel (SAD surfaces + first selection) -> me_select_kernel x ME_ITERS
+//                        -> intra analysis of the badly predicted macroblocks -> pmb_kernel -> intra_p_kernel
+//                -> deblock (prep + persistent band kernel)
+//   and on a second stream, from the moment records and levels are final: scan + pack into pinned host memory -> event
 // and on the host, when the event has fired: CAVLC slice coding (h264_host.c).
 // With pipeline_depth = 1 the host codes picture n while the device works on n+1.
 #include "../../include/mi355enc.h"
@@ -36,7 +38,6 @@ static const uint8_t k_lambda[52] = {1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1, 
                                      16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91};
 
 #define NSLOT 2
-#define MAX_PIECES 8
 #define SURF_PAD 256 /* bytes past each surface: unaligned-pair loads may touch 4 bytes beyond */
 
 struct slot_t {
@@ -47,12 +48,10 @@ struct slot_t {
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
     uint8_t *d_raw;              // staging of non-NV12 input before the conversion kernel (allocated on first use)
     hipEvent_t done, gpu_done, ev[12];
-    hipEvent_t ev_up, ev_all;                  // uploads finished / every device step of a sequentially scheduled picture finished
-    hipEvent_t ev_fe[MAX_PIECES], ev_db[MAX_PIECES]; // band-pipelined schedule: piece p's records + reconstruction final / piece p deblocked
-    hipEvent_t pv[MAX_PIECES][6];              // stage timers of a sampled pipelined picture (created on first use)
-    int pipelined, prof, fused;
+    int prof, fused;
+    int all_skip;              // the picture is one run of P_Skip macroblocks: written by the host alone, no device work
     uint64_t index;            // position of the picture in the stream
-    int is_idr, qp, frame_num, idr_pic_id, rec_index, set;
+    int is_idr, qp, drop, frame_num, idr_pic_id, rec_index, set;
     int64_t pts;
 };
 
@@ -61,9 +60,6 @@ struct mi355enc {
     int mbw, mbh, W, H, nmb;
     size_t ysz, csz;
     hipStream_t stream;                  // main compute stream
-    hipStream_t astream;                 // low-priority stream: source uploads + colour conversion of the band-pipelined schedule
-    hipStream_t pstream[MAX_PIECES];     // band-pipelined schedule: one stream per piece of the picture; pstream[0] == stream
-    int npieces, piece_band[MAX_PIECES + 1]; // piece p owns deblocking bands [piece_band[p], piece_band[p+1]); npieces < 2: schedule off
     frame_ctx_t *d_ctx, *d_ctx2[2];      // one context per picture parity (two pictures are in flight on the device); d_ctx = d_ctx2[0]
     slot_t *prev_slot;                   // slot of the picture enqueued last
     mb_info_t *d_mbi, *d_mbi_set[2];     // two record/level sets: the D2H of picture n overlaps the kernels of n+1
@@ -78,6 +74,10 @@ struct mi355enc {
     unsigned *d_progress; // two sets (picture parity) of [2*bands] strip counters of the band deblocker, then one error word
     unsigned *d_iprogress; // progress counters of the persistent intra kernel, one per band
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
+    uint16_t *d_surf;     // SAD surfaces of the motion search, SURF_U16 per macroblock
+    imv_t *d_imv[2];      // whole-sample vector fields (search result / selection iterations alternate)
+    uint32_t *d_idone;    // intra macroblocks of P pictures: "reconstructed" stamps
+    uint32_t epoch;
     int n_progress;
     slot_t slot[NSLOT];
     int head, tail, pending;
@@ -87,7 +87,7 @@ struct mi355enc {
     h264_writer_t *writer;
     rc_state_t rc;
     std::atomic<uint32_t> want_bps;
-    std::atomic<int> fixed_qp;
+    std::atomic<int> fixed_qp, fixed_drop;
     mi355enc_stats_t st;
     double ms_open;
 };
@@ -118,7 +118,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->overlap = 0; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1;
 }
 
 static unsigned *prog_set(const mi355enc_t *h, int set) { return h->d_progress + (size_t)set * h->n_progress; }
@@ -142,7 +142,7 @@ static int build_graph(mi355enc_t *h, int which, int ci, hipGraphExec_t *out) {
     return 0;
 }
 static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
-    k_launch_intra_analyse(h->d_ctx2[ci], h->mbw, h->mbh, h->stream); // open-loop mode analysis + decisions: one flat launch
+    k_launch_intra_analyse(hc, h->mbw, h->mbh, 0, h->stream); // open-loop mode analysis + decisions: one flat launch
     if (h->cfg.intra_mode == 0) { // persistent band kernel
         k_launch_intra_band(hc, h->mbh, h->d_iprogress, err_word(h), h->stream);
         HIPCHK(hipGetLastError());
@@ -202,12 +202,13 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
-    h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->astream = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->npieces = 0; memset(h->pstream, 0, sizeof h->pstream); h->d_pre_y = h->d_pre_uv = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf = nullptr; h->d_imv[0] = h->d_imv[1] = nullptr; h->d_idone = nullptr; h->epoch = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
     h->fixed_qp.store(cfg->fixed_qp);
+    h->fixed_drop.store(0);
     *out = h; // from here on close() cleans up partial state
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
@@ -217,7 +218,6 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
-        HIPCHK(hipStreamCreateWithPriority(&h->astream, hipStreamNonBlocking, lo)); // a third level; correctness never depends on it (see enqueue_picture)
     }
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&h->d_mbi_set[i], (size_t)h->nmb * sizeof(mb_info_t)));
@@ -239,6 +239,10 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
+    HIPCHK(hipMalloc((void **)&h->d_surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t)));
+    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_imv[i], (size_t)h->nmb * sizeof(imv_t)));
+    HIPCHK(hipMalloc((void **)&h->d_idone, (size_t)h->nmb * sizeof(uint32_t)));
+    HIPCHK(hipMemsetAsync(h->d_idone, 0, (size_t)h->nmb * sizeof(uint32_t), h->stream)); // stamps: the epoch starts at 1
     HIPCHK(hipMalloc((void **)&h->d_iprogress, (size_t)k_intra_bands(h->mbh) * sizeof(unsigned)));
     if (cfg->keep_prefilter) {
         HIPCHK(hipMalloc((void **)&h->d_pre_y, h->ysz));
@@ -257,35 +261,6 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->gpu_done, hipEventDisableTiming));
         for (int k = 0; k < 12; k++) HIPCHK(hipEventCreate(&s->ev[k]));
-        HIPCHK(hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&s->ev_all, hipEventDisableTiming));
-        for (int k = 0; k < MAX_PIECES; k++) {
-            HIPCHK(hipEventCreateWithFlags(&s->ev_fe[k], hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&s->ev_db[k], hipEventDisableTiming));
-        }
-    }
-    { // Band-pipelined schedule (deblock_mode 0): cut the picture into up to `overlap` pieces of whole deblocking bands, one stream
-      // each.  overlap = 1 asks for the default, 4: this many equal-priority streams still get a hardware queue each on a stock
-      // HIP runtime (tools/ubench_streams.hip), and pieces that shared a queue would serialise what the schedule overlaps.
-        const int nb = k_deblock_bands16(h->mbh);
-        int want = h->cfg.overlap <= 0 ? 0 : h->cfg.overlap == 1 ? 4 : h->cfg.overlap;
-        if (want > MAX_PIECES) want = MAX_PIECES;
-        if (want > nb) want = nb;
-        h->pstream[0] = h->stream;
-        if (want >= 2 && h->cfg.deblock_mode == 0) {
-            // the last `nb % want` pieces take one band more: the last band of a picture is usually short, and what bounds the
-            // picture rate is the largest sum of two neighbouring pieces' rows (see enqueue_picture)
-            const int base = nb / want, extra = nb % want;
-            h->piece_band[0] = 0;
-            for (int p = 0; p < want; p++) h->piece_band[p + 1] = h->piece_band[p] + base + (p >= want - extra ? 1 : 0);
-            // HIP keeps a pool of (by default 4) hardware queues per priority level and the application's own streams draw from
-            // the normal pool too, so the piece streams alternate between the normal and the high level: two pieces that
-            // shared a queue would run one after the other and undo the schedule.
-            int lo = 0, hi = 0;
-            HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            for (int p = 1; p < want; p++) HIPCHK(hipStreamCreateWithPriority(&h->pstream[p], hipStreamNonBlocking, (p & 1) ? hi : (lo + hi) / 2));
-            h->npieces = want;
-        }
     }
     h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
     if (!h->writer) return MI355ENC_ERR_NOMEM;
@@ -297,7 +272,6 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     if (h->cfg.cavlc_threads > 1 && h264_writer_set_threads(h->writer, h->cfg.cavlc_threads)) return MI355ENC_ERR_NOMEM;
     rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipStreamSynchronize(h->astream));
     h->ms_open = now_ms() - t_open;
     return MI355ENC_OK;
 }
@@ -305,8 +279,6 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
 void mi355enc_close(mi355enc_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device_id);
-    if (h->astream) (void)hipStreamSynchronize(h->astream);
-    for (int p = 1; p < h->npieces; p++) if (h->pstream[p]) { (void)hipStreamSynchronize(h->pstream[p]); (void)hipStreamDestroy(h->pstream[p]); }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 2; i++) { if (h->g_intra[i]) (void)hipGraphExecDestroy(h->g_intra[i]); if (h->g_deblock[i]) (void)hipGraphExecDestroy(h->g_deblock[i]); }
     for (int i = 0; i < NSLOT; i++) {
@@ -321,13 +293,6 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->gpu_done) (void)hipEventDestroy(s->gpu_done);
         for (int k = 0; k < 12; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
-        if (s->ev_up) (void)hipEventDestroy(s->ev_up);
-        if (s->ev_all) (void)hipEventDestroy(s->ev_all);
-        for (int k = 0; k < MAX_PIECES; k++) {
-            if (s->ev_fe[k]) (void)hipEventDestroy(s->ev_fe[k]);
-            if (s->ev_db[k]) (void)hipEventDestroy(s->ev_db[k]);
-            for (int q = 0; q < 6; q++) if (s->pv[k][q]) (void)hipEventDestroy(s->pv[k][q]);
-        }
     }
     for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
     if (h->d_pre_y) (void)hipFree(h->d_pre_y);
@@ -337,11 +302,13 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_idec) (void)hipFree(h->d_idec);
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->d_off) (void)hipFree(h->d_off);
+    if (h->d_surf) (void)hipFree(h->d_surf);
+    for (int i = 0; i < 2; i++) if (h->d_imv[i]) (void)hipFree(h->d_imv[i]);
+    if (h->d_idone) (void)hipFree(h->d_idone);
     if (h->d_iprogress) (void)hipFree(h->d_iprogress);
     for (int i = 0; i < 2; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
     for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
-    if (h->astream) (void)hipStreamDestroy(h->astream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h264_writer_free(h->writer);
     delete h;
@@ -358,141 +325,105 @@ int mi355enc_set_fixed_qp(mi355enc_t *h, int qp) {
     h->fixed_qp.store(qp < 0 ? -1 : qp, std::memory_order_relaxed);
     return MI355ENC_OK;
 }
+int mi355enc_set_fixed_drop(mi355enc_t *h, int drop) {
+    if (!h || drop < 0 || (drop > DROP_MAX && drop != DROP_SKIP)) return MI355ENC_ERR_ARG;
+    h->fixed_drop.store(drop, std::memory_order_relaxed);
+    return MI355ENC_OK;
+}
 int mi355enc_pending(const mi355enc_t *h) { return h ? h->pending : 0; }
 size_t mi355enc_max_au_bytes(const mi355enc_t *h) { return h ? h264_max_au_bytes(h->mbw, h->mbh) : 0; }
 int mi355enc_mb_width(const mi355enc_t *h) { return h ? h->mbw : 0; }
 int mi355enc_mb_height(const mi355enc_t *h) { return h ? h->mbh : 0; }
 
-// Uploads (and the colour conversion) of a picture go through the low-priority stream when the band-pipelined schedule is on,
-// so that they never queue behind a deblocking kernel; enqueue_picture() makes every consumer wait for them.
-static int sync_compute(mi355enc_t *h) { // every stream that carries kernels of a picture (the hand-over stream aside)
-    HIPCHK(hipStreamSynchronize(h->astream));
-    for (int p = 1; p < h->npieces; p++) HIPCHK(hipStreamSynchronize(h->pstream[p]));
+static int sync_compute(mi355enc_t *h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
-static hipStream_t upload_stream(const mi355enc_t *h) { return h->npieces >= 2 ? h->astream : h->stream; }
+static hipStream_t upload_stream(const mi355enc_t *h) { return h->stream; }
 
-static int ensure_piece_timers(slot_t *s, int np) {
-    for (int p = 0; p < np; p++)
-        for (int q = 0; q < 6; q++)
-            if (!s->pv[p][q]) HIPCHK(hipEventCreate(&s->pv[p][q]));
+// rate control's ladder below QP 51 (oracle: k_drop_sad): the SAD under which a P macroblock carries no residual / takes the skip vector
+static const uint32_t k_drop_sad[DROP_MAX + 1] = {0, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 0xFFFFFFFFu};
+
+static void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr) {
+    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec;
+    c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh;
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
+    c->surf = h->d_surf; c->imv_a = h->d_imv[0]; c->imv_b = h->d_imv[1]; c->idone = h->d_idone;
+    if (++h->epoch == 0) h->epoch = 1;
+    c->epoch = h->epoch;
+    c->drop_sad = (drop > 0 && drop <= DROP_MAX) ? k_drop_sad[drop] : 0;
+    c->intra_p = (h->cfg.intra_in_p && !h->cfg.transform8x8) ? 1 : 0;
+}
+// the device steps of a P picture up to (not including) deblocking; hc: host copy of the context (every kernel takes it by value)
+static int run_p_picture(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof) {
+    k_launch_me(hc, h->mbw, 0, h->mbh, h->stream);
+    for (int it = 0; it < ME_ITERS; it++) k_launch_me_select(hc, h->mbw, 0, h->mbh, (it & 1) ? hc->imv_b : hc->imv_a, (it & 1) ? hc->imv_a : hc->imv_b, h->stream);
+    if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
+    if (h->cfg.transform8x8) { // High profile: the two-kernel form (absolute-vector refinement, 8x8 transform), no skip / intra logic
+        k_launch_imv_to_mbi(hc, h->mbw, 0, h->mbh, h->stream);
+        if (h->cfg.subpel) k_launch_subpel(hc, h->mbw, 0, h->mbh, h->stream);
+        if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
+        k_launch_inter(hc, h->mbw, 0, h->mbh, h->stream);
+    } else {
+        if (hc->intra_p) k_launch_intra_analyse(hc, h->mbw, h->mbh, 1, h->stream);
+        k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, h->stream);
+        if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
+        if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, err_word(h), h->stream);
+    }
+    if (prof) HIPCHK(hipEventRecord(s->ev[11], h->stream));
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
 // Enqueue every device step of one picture whose source is described by (src_y, src_uv, src_stride).  Anything the caller
-// uploaded for this picture was enqueued on upload_stream().
-//
-// Sequential schedule (IDR pictures, deblock_mode 1, overlap off), all on `stream`:
-//     intra | me, subpel, inter -> prep -> all bands                       pack (cstream) starts after intra / inter
-//
-// Band-pipelined schedule (P pictures, cfg.overlap): what bounds the picture rate is the dependency chain of the deblocking
-// filter, ~(mbw + mbh) steps per picture, during which a dozen workgroups are busy and the rest of the device idles -- while
-// the next picture's search only needs reference rows two macroblock rows below its own.  The picture is cut into pieces of
-// whole deblocking bands, piece p on stream p, each stream running for picture n
-//     wait db(n-1, p-1), db(n-1, p+1)           db(n-1, p) precedes in stream order
-//     me, subpel, inter over the piece's rows   -> event fe(n, p)        (the pack kernels on cstream wait for every fe)
-//     wait fe(n, p-1)                           prep reads the records of the row above
-//     prep + band kernel of the piece's bands   its first band spin-waits on the last band of piece p-1 like any band on
-//                                               the one above (k_deblock.hip); piece p-1 is always submitted first
-//     -> event db(n, p)
-// so piece p of picture n+1 starts when piece p+1 of picture n is done instead of when its last band is: consecutive
-// pictures overlap by all bands below p+1, and the search/transform kernels disappear behind the deblocking of the picture
-// before.  Why the waits suffice:
-//   * reference rows: rows r of piece p search lines up to 16 r + 35 (range 16 + 0.75 + 3 filter taps) and down to
-//     16 r - 20, i.e. inside pieces p-1 .. p+1 of the reference, which are final (the last lines the band below touches are
-//     the bottom 3 of a piece; the search stays 12 lines clear of piece p+1's bottom unless that piece is the last one);
-//   * the reconstruction of n+1 overwrites the plane picture n used as its reference: the readers of piece p's rows are the
-//     search kernels of pieces p-1, p, p+1 of picture n, all ahead of db(n, .) in their streams;
-//   * records / levels (two sets, by picture parity) of picture n-1 were consumed by pack (collect() returned before this
-//     submit) and by prep(n-1, p), prep(n-1, p+1), both ahead of db(n-1, .) which precede db(n, .) in stream order;
-//   * deblocking records are written by prep(n+1, p) after the band kernel of (n, p) in the same stream;
-//   * progress counters exist in two sets (picture parity).  A band kernel must never see a stale "complete" counter of the
-//     band above, and piece p+1 runs independently of piece p's prep kernel, so a piece cannot clear its own counters:
-//     prep(n, p) clears piece p's counters of the OTHER set, for picture n+1 -- their last reader, the band kernel of
-//     (n-1, p+1), is ahead of fe(n, p) via db(n-1, p+1), and their next reader (n+1, p+1) starts after db(n, p).
-//     Sequentially scheduled pictures have joined everything and clear both sets.
-// Correctness never depends on streams running concurrently: every spin-wait targets work submitted earlier.
+// uploaded for this picture was enqueued on the same stream.
 static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride,
-                           int64_t pts, int force_idr, bool uploaded) {
+                           int64_t pts, int force_idr) {
     const int idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop ||
                     (h->n_submitted == h->sc_force_at && h->prev_slot && !h->prev_slot->is_idr); // scene-cut recovery, see collect()
     if (idr) h->frames_since_idr = 0;
-    // rate control: latch the setpoint written by the control thread, pick this picture's QP
+    // rate control: latch the setpoint written by the control thread, pick this picture's QP (and, below QP 51, its drop level)
     rc_set_bitrate(&h->rc, h->want_bps.load(std::memory_order_relaxed));
     int fq = h->fixed_qp.load(std::memory_order_relaxed);
-    const int qp = fq >= 0 ? fq : rc_pick_qp(&h->rc, idr);
-    const int nxt = h->cur ^ 1;
+    int qp, drop;
+    if (fq >= 0) { qp = fq; drop = h->fixed_drop.load(std::memory_order_relaxed); }
+    else rc_pick(&h->rc, idr, &qp, &drop);
+    if (idr) drop = 0;
+    const int all_skip = !idr && drop == DROP_SKIP;
+    const int nxt = all_skip ? h->cur : (h->cur ^ 1); // an all-skip picture IS its reference: nothing is written
     const int set = (int)(h->n_submitted & 1), ci = set;
     frame_ctx_t *c = s->h_ctx, *dctx = h->d_ctx2[ci];
-    c->src_y = src_y; c->src_uv = src_uv; c->src_stride = src_stride;
-    c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
-    c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
-    c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set]; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec;
-    c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->cfg.height;
-    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
     // stage timers: an event record costs ~5 us of queue time, so profile_events = k samples every k-th picture (IDR pictures always)
-    const int prof = h->cfg.profile_events > 0 && (idr || h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
-    const int np = h->npieces;
-    const bool pl = !idr && np >= 2;
-    const bool fused = !h->cfg.transform8x8; // refinement + prediction + residual in one kernel (pmb_kernel); the 8x8-transform path keeps the two-kernel form
-    slot_t *prev = h->prev_slot;
-    const bool up_ev = uploaded && upload_stream(h) != h->stream;
-    if (up_ev) HIPCHK(hipEventRecord(s->ev_up, h->astream));
-    if (pl) {
-        const int nb = k_deblock_bands16(h->mbh);
-        if (prof) { int r = ensure_piece_timers(s, np); if (r) return r; }
-        for (int p = 0; p < np; p++) {
-            hipStream_t st = h->pstream[p];
-            const int b0 = h->piece_band[p], b1 = h->piece_band[p + 1];
-            const int r0 = 16 * b0, r1 = 16 * b1 < h->mbh ? 16 * b1 : h->mbh;
-            if (prev && prev->pipelined) {
-                if (p > 0) HIPCHK(hipStreamWaitEvent(st, prev->ev_db[p - 1], 0));
-                if (p + 1 < np) HIPCHK(hipStreamWaitEvent(st, prev->ev_db[p + 1], 0));
-            } else if (prev && p > 0) HIPCHK(hipStreamWaitEvent(st, prev->ev_all, 0)); // stream 0 carried the sequential picture itself
-            if (up_ev) HIPCHK(hipStreamWaitEvent(st, s->ev_up, 0));
-            if (prof) HIPCHK(hipEventRecord(s->pv[p][0], st));
-            k_launch_me(c, h->mbw, r0, r1, st);
-            if (prof) HIPCHK(hipEventRecord(s->pv[p][1], st));
-            if (fused) k_launch_pmb(c, h->mbw, r0, r1, h->cfg.subpel, st);
-            else if (h->cfg.subpel) k_launch_subpel(c, h->mbw, r0, r1, st);
-            if (prof) HIPCHK(hipEventRecord(s->pv[p][2], st));
-            if (!fused) k_launch_inter(c, h->mbw, r0, r1, st);
-            if (prof) HIPCHK(hipEventRecord(s->pv[p][3], st));
-            HIPCHK(hipEventRecord(s->ev_fe[p], st));
-            if (h->d_pre_y) {
-                HIPCHK(hipMemcpyAsync(h->d_pre_y + (size_t)r0 * 16 * h->W, h->d_rec_y[nxt] + (size_t)r0 * 16 * h->W, (size_t)(r1 - r0) * 16 * h->W, hipMemcpyDeviceToDevice, st));
-                HIPCHK(hipMemcpyAsync(h->d_pre_uv + (size_t)r0 * 8 * h->W, h->d_rec_uv[nxt] + (size_t)r0 * 8 * h->W, (size_t)(r1 - r0) * 8 * h->W, hipMemcpyDeviceToDevice, st));
-            }
-            if (p > 0) HIPCHK(hipStreamWaitEvent(st, s->ev_fe[p - 1], 0));
-            if (prof) HIPCHK(hipEventRecord(s->pv[p][4], st));
-            k_launch_deblock_prep(c, h->mbw, r0, r1, prog_set(h, set ^ 1) + b0, b1 - b0, prog_set(h, set ^ 1) + nb + b0, b1 - b0, prog_set(h, set ^ 1) + 2 * nb + b0, b1 - b0,
-                                  prog_set(h, set) + 2 * nb, st); // clears for picture n+1 (below)
-            k_launch_deblock_bands(c, h->mbh, b0, b1, prog_set(h, set), err_word(h), st);
-            if (prof) HIPCHK(hipEventRecord(s->pv[p][5], st));
-            HIPCHK(hipEventRecord(s->ev_db[p], st));
-            HIPCHK(hipStreamWaitEvent(h->cstream, s->ev_fe[p], 0));
+    const int prof = !all_skip && h->cfg.profile_events > 0 && (idr || h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
+    const bool fused = !h->cfg.transform8x8;
+    if (all_skip) {
+        // one run of P_Skip macroblocks with the zero vector (8.4.1.1 infers it: every neighbour's vector is zero): the host
+        // writes the records itself; no source sample is read, no kernel runs, the reference stays where it is
+        memset(s->h_mbi, 0, (size_t)h->nmb * sizeof(mb_info_t));
+        for (int i = 0; i < h->nmb; i++) { s->h_mbi[i].mb_type = 1; s->h_mbi[i].qp = (uint8_t)qp; }
+        s->h_hdr[0] = 0; s->h_hdr[1] = 0;
+        for (int r = 0; r < h->mbh; r++) s->h_hdr[2 + r] = 0;
+        s->h_hdr[2 + h->mbh] = s->h_hdr[3 + h->mbh] = 0;
+        if (h->d_pre_y) {
+            HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
         }
-        HIPCHK(hipGetLastError());
     } else {
-        // The P-picture kernels and the band deblocker take the context by value; only the kernels replayed from a hipGraph
-        // (intra wavefront, deblock_mode 1) read the device copy, so only those pictures pay for an upload.
-        if (idr || h->cfg.deblock_mode != 0) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
-        if (prev && prev->pipelined)
-            for (int p = 1; p < np; p++) HIPCHK(hipStreamWaitEvent(h->stream, prev->ev_db[p], 0)); // join: piece 0 precedes in stream order
-        if (up_ev) HIPCHK(hipStreamWaitEvent(h->stream, s->ev_up, 0));
+        c->src_y = src_y; c->src_uv = src_uv; c->src_stride = src_stride;
+        c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
+        c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
+        c->vis_h = h->cfg.height;
+        fill_ctx(h, c, qp, drop, idr);
+        c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set];
+        // Every kernel of the default path takes the context by value; only the kernels replayed from a hipGraph
+        // (intra_mode 1, deblock_mode 1) read the device copy, so only those pictures pay for an upload.
+        if ((idr && h->cfg.intra_mode != 0) || h->cfg.deblock_mode != 0) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
         if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
         if (idr) {
             int r = run_intra(h, ci, c); if (r) return r;
             if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
         } else {
-            k_launch_me(c, h->mbw, 0, h->mbh, h->stream);
-            if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
-            if (fused) k_launch_pmb(c, h->mbw, 0, h->mbh, h->cfg.subpel, h->stream);
-            else if (h->cfg.subpel) k_launch_subpel(c, h->mbw, 0, h->mbh, h->stream);
-            if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
-            if (!fused) k_launch_inter(c, h->mbw, 0, h->mbh, h->stream);
-            if (prof) HIPCHK(hipEventRecord(s->ev[11], h->stream));
+            int r = run_p_picture(h, c, s, prof); if (r) return r;
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
@@ -504,17 +435,16 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         }
         int r = run_deblock(h, ci, c); if (r) return r;
         if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
-        if (np >= 2) HIPCHK(hipEventRecord(s->ev_all, h->stream)); // only a later pipelined picture waits on it
         HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
+        // Hand-over on the second stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:
+        // the device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
+        k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, err_word(h), h->cstream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->done, h->cstream));
     }
-    // Hand-over on the third stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:
-    // the device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
-    k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, err_word(h), h->cstream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s->done, h->cstream));
     h->n_submitted++;
-    s->is_idr = idr; s->qp = qp; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
-    s->pts = pts; s->rec_index = nxt; s->set = set; s->pipelined = pl ? 1 : 0; s->prof = prof; s->fused = fused && !idr; s->index = h->n_submitted - 1;
+    s->is_idr = idr; s->qp = qp; s->drop = drop; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
+    s->pts = pts; s->rec_index = nxt; s->set = set; s->prof = prof; s->fused = fused && !idr; s->index = h->n_submitted - 1; s->all_skip = all_skip;
     if (idr) h->idr_count++;
     h->frames_since_idr++;
     h->cur = nxt; h->have_ref = 1; h->prev_slot = s;
@@ -532,7 +462,7 @@ int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
     HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, y, y_stride, w, ht, hipMemcpyHostToDevice, up));
     HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, up));
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
-    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr, true);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }
 
 // Upload the planes of a non-NV12 picture tightly into the slot's raw staging buffer and convert into its NV12 staging surfaces.
@@ -566,7 +496,7 @@ int mi355enc_submit_fmt(mi355enc_t *h, int fmt, const uint8_t *const planes[3], 
     slot_t *s = &h->slot[h->head];
     int r = upload_and_convert(h, s, fmt, planes, strides, upload_stream(h));
     if (r) return r;
-    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr, true);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }
 
 int mi355enc_stage_csc(mi355enc_t *h, int fmt, const uint8_t *const planes[3], const int strides[3], uint8_t *out_y, uint8_t *out_uv) {
@@ -589,11 +519,11 @@ int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const v
     const int w = h->cfg.width, ht = h->cfg.height;
     hipStream_t up = upload_stream(h);
     const bool direct = w == h->W && y_stride == uv_stride && (y_stride & 15) == 0 && (((uintptr_t)d_y | (uintptr_t)d_uv) & 15) == 0;
-    if (direct) return enqueue_picture(h, s, (const uint8_t *)d_y, (const uint8_t *)d_uv, y_stride, pts, force_idr, false);
+    if (direct) return enqueue_picture(h, s, (const uint8_t *)d_y, (const uint8_t *)d_uv, y_stride, pts, force_idr);
     HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, d_y, y_stride, w, ht, hipMemcpyDeviceToDevice, up));
     HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, d_uv, uv_stride, w, ht / 2, hipMemcpyDeviceToDevice, up));
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
-    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr, true);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }
 
 int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_len, int *is_keyframe, int64_t *pts, int *qp) {
@@ -602,7 +532,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[h->tail];
     double t0 = now_ms();
-    HIPCHK(hipEventSynchronize(s->done));
+    if (!s->all_skip) HIPCHK(hipEventSynchronize(s->done));
     double t1 = now_ms();
     h->st.ms_wait += t1 - t0;
     if (s->h_hdr[1]) { // sticky: set by a band of an earlier picture's deblocking launch that gave up waiting
@@ -627,29 +557,19 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     // the pipeline depth, and is skipped there if picture index + 1 turned out to be an IDR: the stream does not depend on
     // the order of submit() and collect() calls.
     if (s->is_idr) { h->sc_sum = 0; h->sc_cnt = 0; }
-    else {
+    else if (!s->all_skip) {
         const uint64_t cost = (uint64_t)s->h_hdr[2 + h->mbh] | ((uint64_t)s->h_hdr[3 + h->mbh] << 32);
         const bool pending = h->sc_force_at != ~0ull && h->sc_force_at > s->index; // a decision not yet carried out stands
         if (h->cfg.scenecut && !pending && h->sc_cnt >= 2 && cost > 3 * (h->sc_sum / (uint64_t)h->sc_cnt)) h->sc_force_at = s->index + 2;
         h->sc_sum += cost; h->sc_cnt++;
     }
     if (s->prof) {
-        float a = 0, b = 0, c = 0, tot = 0, sp = 0, t = 0;
-        if (s->pipelined) { // kernel times add up over the pieces; deblocking and the total are spans (the pieces run side by side)
-            const int np = h->npieces;
-            for (int p = 0; p < np; p++) HIPCHK(hipEventSynchronize(s->pv[p][5]));
-            for (int p = 0; p < np; p++) {
-                (void)hipEventElapsedTime(&t, s->pv[p][0], s->pv[p][1]); a += t;
-                (void)hipEventElapsedTime(&t, s->pv[p][1], s->pv[p][2]); if (s->fused) b += t; else sp += t; // fused: refinement + inter are one kernel, booked as inter
-                if (!s->fused) { (void)hipEventElapsedTime(&t, s->pv[p][2], s->pv[p][3]); b += t; }
-                (void)hipEventElapsedTime(&t, s->pv[0][4], s->pv[p][5]); if (t > c) c = t;
-                (void)hipEventElapsedTime(&t, s->pv[0][0], s->pv[p][5]); if (t > tot) tot = t;
-            }
-        } else {
+        float a = 0, b = 0, c = 0, tot = 0, sp = 0;
+        {
             HIPCHK(hipEventSynchronize(s->ev[4])); // the access unit is ready before deblocking ends; the stage timers are not
             (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
             if (!s->is_idr) {
-                if (s->fused) (void)hipEventElapsedTime(&b, s->ev[1], s->ev[5]); // refinement + inter are one kernel, booked as inter
+                if (s->fused) (void)hipEventElapsedTime(&b, s->ev[1], s->ev[11]); // intra analysis of the gated macroblocks + fused stage + intra macroblocks, booked as inter
                 else { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
             }
             (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
@@ -711,7 +631,7 @@ int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
 }
 
 // ---------------------------------------------------------------- single-stage entry points
-static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
+static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging, int drop = 0) {
     if (h->pending) return MI355ENC_ERR_STATE;
     slot_t *s = &h->slot[0];
     frame_ctx_t *c = s->h_ctx;
@@ -719,69 +639,94 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging) {
     c->ref_y = h->d_rec_y[0]; c->ref_uv = h->d_rec_uv[0]; c->rec_y = h->d_rec_y[1]; c->rec_uv = h->d_rec_uv[1];
     HIPCHK(hipStreamSynchronize(h->cstream));
     { int r = sync_compute(h); if (r) return r; }
-    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec; c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh; c->vis_h = h->H;
-    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = 0;
+    c->vis_h = h->H;
+    fill_ctx(h, c, qp, drop, 0);
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     return 0;
 }
-int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_out) {
-    if (!h || !cur_y || !ref_y || !mbinfo_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
-    HIPCHK(hipSetDevice(h->cfg.device_id));
+static int upload_luma_pair(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y) {
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, cur_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
-    int r = stage_ctx(h, qp, true); if (r) return r;
+    return 0;
+}
+int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, uint16_t *surf_out, void *imv_out) {
+    if (!h || !cur_y || !ref_y || !imv_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    int r = upload_luma_pair(h, cur_y, ref_y); if (r) return r;
+    r = stage_ctx(h, qp, true); if (r) return r;
     k_launch_me(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
-    HIPCHK(hipMemcpyAsync(mbinfo_out, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(imv_out, h->d_imv[0], (size_t)h->nmb * sizeof(imv_t), hipMemcpyDeviceToHost, h->stream));
+    if (surf_out) HIPCHK(hipMemcpyAsync(surf_out, h->d_surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
+int mi355enc_stage_me_select(mi355enc_t *h, const uint16_t *surf, const void *imv_in, int qp, void *imv_out) {
+    if (!h || !surf || !imv_in || !imv_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    int r = stage_ctx(h, qp, true); if (r) return r;
+    HIPCHK(hipMemcpyAsync(h->d_surf, surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_imv[0], imv_in, (size_t)h->nmb * sizeof(imv_t), hipMemcpyHostToDevice, h->stream));
+    k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0], h->d_imv[1], h->stream);
+    HIPCHK(hipMemcpyAsync(imv_out, h->d_imv[1], (size_t)h->nmb * sizeof(imv_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }
 int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_inout) {
     if (!h || !cur_y || !ref_y || !mbinfo_inout || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, cur_y, h->ysz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    int r = upload_luma_pair(h, cur_y, ref_y); if (r) return r;
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
-    int r = stage_ctx(h, qp, true); if (r) return r;
+    r = stage_ctx(h, qp, true); if (r) return r;
     k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
     HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }
+static int upload_planes4(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv) {
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_rec_uv[0], ref_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+static int download_picture(mi355enc_t *h, void *mbinfo, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels) {
+    HIPCHK(hipMemcpyAsync(mbinfo, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
 int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv,
                          int qp, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels) {
     if (!h || !src_y || !src_uv || !ref_y || !ref_uv || !mbinfo_inout || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_rec_uv[0], ref_uv, h->csz, hipMemcpyHostToDevice, h->stream));
+    int r = upload_planes4(h, src_y, src_uv, ref_y, ref_uv); if (r) return r;
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
-    int r = stage_ctx(h, qp, true); if (r) return r;
+    r = stage_ctx(h, qp, true); if (r) return r;
     k_launch_inter(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
-    HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * 2, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return MI355ENC_OK;
+    return download_picture(h, mbinfo_inout, rec_y, rec_uv, levels) ? MI355ENC_ERR_HIP : MI355ENC_OK;
 }
 int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv,
-                       int qp, int refine, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels) {
-    if (!h || !src_y || !src_uv || !ref_y || !ref_uv || !mbinfo_inout || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+                       int qp, int drop, int refine, const void *imv, const uint16_t *surf, const void *idec, int run_intra_p,
+                       void *mbinfo_out, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels) {
+    if (!h || !src_y || !src_uv || !ref_y || !ref_uv || !imv || !surf || !mbinfo_out || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51 || drop < 0 || drop > DROP_MAX)
+        return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_rec_y[0], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_rec_uv[0], ref_uv, h->csz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
-    int r = stage_ctx(h, qp, true); if (r) return r;
-    k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, refine ? 1 : 0, h->stream);
-    HIPCHK(hipMemcpyAsync(mbinfo_inout, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * 2, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return MI355ENC_OK;
+    int r = upload_planes4(h, src_y, src_uv, ref_y, ref_uv); if (r) return r;
+    r = stage_ctx(h, qp, true, drop); if (r) return r;
+    frame_ctx_t *c = h->slot[0].h_ctx;
+    c->intra_p = idec ? 1 : 0;
+    HIPCHK(hipMemcpyAsync((void *)k_final_imv(c), imv, (size_t)h->nmb * sizeof(imv_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_surf, surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+    if (idec) HIPCHK(hipMemcpyAsync(h->d_idec, idec, (size_t)h->nmb * IDEC_BYTES, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_rec_y[1], 0, h->ysz, h->stream)); // macroblocks decided intra stay untouched unless run_intra_p
+    HIPCHK(hipMemsetAsync(h->d_rec_uv[1], 0, h->csz, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_levels, 0, (size_t)h->nmb * MB_LEVELS * 2, h->stream));
+    k_launch_pmb(c, h->mbw, 0, h->mbh, refine ? 1 : 0, h->stream);
+    if (idec && run_intra_p) k_launch_intra_p(c, h->mbw, h->mbh, err_word(h), h->stream);
+    HIPCHK(hipGetLastError());
+    return download_picture(h, mbinfo_out, rec_y, rec_uv, levels) ? MI355ENC_ERR_HIP : MI355ENC_OK;
 }
 int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out, uint8_t *rec_y,
                          uint8_t *rec_uv, int16_t *levels) {
@@ -791,12 +736,7 @@ int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
     r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r;
-    HIPCHK(hipMemcpyAsync(mbinfo_out, h->d_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(levels, h->d_levels, (size_t)h->nmb * MB_LEVELS * 2, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return MI355ENC_OK;
+    return download_picture(h, mbinfo_out, rec_y, rec_uv, levels) ? MI355ENC_ERR_HIP : MI355ENC_OK;
 }
 int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, uint16_t *isad_out, void *idec_out) {
     if (!h || !src_y || !src_uv || !isad_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
@@ -804,7 +744,7 @@ int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    k_launch_intra_analyse(h->d_ctx, h->mbw, h->mbh, h->stream);
+    k_launch_intra_analyse(h->slot[0].h_ctx, h->mbw, h->mbh, 0, h->stream);
     HIPCHK(hipMemcpyAsync(isad_out, h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
     if (idec_out) HIPCHK(hipMemcpyAsync(idec_out, h->d_idec, (size_t)h->nmb * IDEC_BYTES, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -824,16 +764,13 @@ int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const
     return MI355ENC_OK;
 }
 int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
-    if (!h || !avg_ms || iters < 1 || stage < 0 || stage > 7) return MI355ENC_ERR_ARG;
+    if (!h || !avg_ms || iters < 1 || stage < 0 || stage > 10) return MI355ENC_ERR_ARG;
     if (h->pending) return MI355ENC_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[0];
     // a valid context in both places: the last picture's host copy (slot 0) re-uploaded, or a fresh stage context
     if (!h->have_ref) { int r = stage_ctx(h, 26, true); if (r) return r; }
-    else {
-        HIPCHK(hipStreamSynchronize(h->astream));
-        HIPCHK(hipMemcpyAsync(h->d_ctx, s->h_ctx, sizeof(frame_ctx_t), hipMemcpyHostToDevice, h->stream));
-    }
+    else HIPCHK(hipMemcpyAsync(h->d_ctx, s->h_ctx, sizeof(frame_ctx_t), hipMemcpyHostToDevice, h->stream));
     if (stage >= 5 && !s->d_raw) { // input conversion (5 I420, 6 YUY2, 7 UYVY): any bytes will do as a source
         HIPCHK(hipMalloc((void **)&s->d_raw, (size_t)(2 * h->W + 32) * h->H + 64));
         HIPCHK(hipMemsetAsync(s->d_raw, 0x55, (size_t)(2 * h->W + 32) * h->H + 64, h->stream));
@@ -845,6 +782,9 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
             else if (stage == 1) k_launch_inter(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 2) { int r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r; }
             else if (stage == 4) k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
+            else if (stage == 8) k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0], h->d_imv[1], h->stream);
+            else if (stage == 9) k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, 1, h->stream);
+            else if (stage == 10) k_launch_intra_p(h->slot[0].h_ctx, h->mbw, h->mbh, err_word(h), h->stream);
             else if (stage >= 5) {
                 const int w = h->cfg.width, ht = h->cfg.height, r0 = stage == 5 ? (w + 15) & ~15 : (2 * w + 15) & ~15, r1 = (w / 2 + 15) & ~15;
                 const uint8_t *p0 = s->d_raw, *p1 = p0 + (size_t)r0 * ht, *p2 = p1 + (size_t)r1 * (ht / 2);

@@ -19,9 +19,27 @@ typedef struct {
     uint32_t cost;
 } mb_info_t;
 
+/* 8-byte result of the whole-sample motion search per macroblock (me_kernel / me_select_kernel) */
+typedef struct {
+    int16_t mvx, mvy;     /* whole-sample vector in quarter-sample units (multiples of 4)      */
+    uint16_t sad;         /* its SAD                                                            */
+    uint16_t bits;        /* the vector + header bits it was charged (cost = sad + lambda*bits) */
+} imv_t;
+
 #define MB_LEVELS 408
 #define ISAD_PER_MB 152
-#define IDEC_BYTES 24 /* intra decisions per macroblock: u8 modes4[16] (by blkIdx); u8 mode16, cmode, use_i4, 0; u32 cost */
+#define IDEC_BYTES 32 /* intra decisions per macroblock: u8 modes4[16] (by blkIdx); u8 mode16, cmode, use_i4, 0; u32 cost (luma + chroma), cost_luma, 0 */
+/* SAD surface of the motion search: per macroblock 35 rows (dy = -16 .. 18) x 36 columns (dx = -16 .. 19) of uint16; the search
+ * range is the 33 x 33 upper-left part, the rest is what the lanes' 5 x 4 candidate tiles compute beyond it */
+#define SURF_COLS 36
+#define SURF_ROWS 35
+#define SURF_U16 (SURF_ROWS * SURF_COLS)
+#define ME_ITERS 3          /* Jacobi iterations of the vector selection after the search's own (oracle: ORC_ME_ITERS) */
+#define SEL_BONUS 2         /* oracle: ORC_SEL_BONUS */
+#define SKIP_MARGIN_BITS 4  /* oracle: ORC_SKIP_MARGIN_BITS */
+#define INTRA_GATE(lambda) (768u + 8u * (unsigned)(lambda)) /* oracle: ORC_INTRA_GATE */
+#define DROP_MAX 12
+#define DROP_SKIP 255
 #define L_LUMA 0
 #define L_LDC 256
 #define L_CDC 272
@@ -50,6 +68,13 @@ typedef struct {
     int32_t i4x4;                  /* try Intra_4x4 in I pictures */
     int32_t t8;                    /* P macroblocks use the 8x8 transform (High profile stream) */
     int32_t all_intra;             /* every macroblock of the picture is intra (IDR): the deblocker runs all edges without per-edge tests */
+    /* P pictures */
+    uint16_t *surf;                /* SAD surfaces, SURF_U16 per macroblock */
+    imv_t *imv_a, *imv_b;          /* whole-sample vector fields: the search writes imv_a, the selection iterations alternate; ME_ITERS odd -> final in imv_b */
+    uint32_t *idone;               /* intra macroblocks of P pictures: per-macroblock "reconstructed" stamps (value = epoch) */
+    uint32_t epoch;                /* picture stamp for idone (never 0) */
+    uint32_t drop_sad;             /* rate control's ladder below QP 51: 0 off, else the SAD below which a P macroblock carries no residual / takes the skip vector */
+    int32_t intra_p;               /* P macroblocks may be intra (the analysis of this picture's source is in isad / idec) */
 } frame_ctx_t;
 
 #ifdef __cplusplus
@@ -61,10 +86,14 @@ typedef struct {
 /* launchers (k_*.hip); all asynchronous on `s`.  h_ctx: HOST copy of the context, passed to the kernel by value
  * (kernarg segment); d_ctx: device copy, for the kernels that are replayed from a hipGraph. */
 void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
+void k_launch_me_select(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, const imv_t *in, imv_t *out, hipStream_t s);
+void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_err, hipStream_t s);
+const imv_t *k_final_imv(const frame_ctx_t *h_ctx); /* where the last selection iteration leaves the field */
+void k_launch_imv_to_mbi(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s); // whole-sample field -> records, for the two-kernel (8x8 transform) path
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, hipStream_t s); // fused refinement + inter (4x4 transform)
 void k_launch_inter(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
-void k_launch_intra_analyse(const frame_ctx_t *d_ctx, int mbw, int mbh, hipStream_t s);
+void k_launch_intra_analyse(const frame_ctx_t *h_ctx, int mbw, int mbh, int gate_p, hipStream_t s); /* gate_p: P picture -- only macroblocks whose search cost reaches INTRA_GATE */
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
 void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
 int k_deblock_bands16(int mbh);

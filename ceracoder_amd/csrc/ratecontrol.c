@@ -64,6 +64,10 @@ int rc_pick_qp(rc_state_t *rc, int is_idr) {
     if (qp > rc->qp_max) qp = rc->qp_max;
     return qp;
 }
+void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
+    *qp = rc_pick_qp(rc, is_idr);
+    *drop = 0;
+}
 void rc_update(rc_state_t *rc, int is_idr, int qp, size_t bytes) {
     const double bits = 8.0 * (double)bytes, c = bits * qstep(qp);
     if (is_idr) {

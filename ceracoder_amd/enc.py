@@ -19,12 +19,15 @@ MBINFO_DTYPE = np.dtype(
 
 FETCH_RECON_Y, FETCH_RECON_UV, FETCH_PREFILTER_Y, FETCH_PREFILTER_UV, FETCH_MBINFO, FETCH_LEVELS = range(6)
 FMT_NV12, FMT_I420, FMT_YUY2, FMT_UYVY = range(4)
-IDEC = np.dtype([("modes4", "u1", (16,)), ("mode16", "u1"), ("cmode", "u1"), ("use_i4", "u1"), ("pad", "u1"), ("cost", "<u4")])
-STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK, STAGE_SUBPEL, STAGE_CSC_I420, STAGE_CSC_YUY2, STAGE_CSC_UYVY = range(8)
+IDEC = np.dtype([("modes4", "u1", (16,)), ("mode16", "u1"), ("cmode", "u1"), ("use_i4", "u1"), ("pad", "u1"), ("cost", "<u4"), ("cost_luma", "<u4"), ("rsv", "<u4")])
+IMV_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("sad", "<u2"), ("bits", "<u2")])
+SURF_ROWS, SURF_COLS = 35, 36
+DROP_MAX, DROP_SKIP = 12, 255
+STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK, STAGE_SUBPEL, STAGE_CSC_I420, STAGE_CSC_YUY2, STAGE_CSC_UYVY, STAGE_ME_SELECT, STAGE_PMB, STAGE_INTRA_P = range(11)
 
 EXPORTS = [
     "mi355enc_abi_version", "mi355enc_strerror", "mi355enc_default_cfg", "mi355enc_open", "mi355enc_close",
-    "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_encode", "mi355enc_submit",
+    "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_set_fixed_drop", "mi355enc_stage_me_select", "mi355enc_encode", "mi355enc_submit",
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
     "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_pmb", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
@@ -37,7 +40,7 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
                 ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
-                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("overlap", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("scenecut", C.c_int)]
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("intra_in_p", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("scenecut", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -69,6 +72,7 @@ def load():
         L.mi355enc_get_bitrate.restype = C.c_uint32
         L.mi355enc_get_bitrate.argtypes = [vp]
         L.mi355enc_set_fixed_qp.argtypes = [vp, C.c_int]
+        L.mi355enc_set_fixed_drop.argtypes = [vp, C.c_int]
         L.mi355enc_encode.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int, vp, C.c_size_t,
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
         L.mi355enc_submit.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int]
@@ -84,10 +88,11 @@ def load():
         L.mi355enc_fetch.argtypes = [vp, C.c_int, vp, C.c_size_t]
         L.mi355enc_mb_width.argtypes = [vp]
         L.mi355enc_mb_height.argtypes = [vp]
-        L.mi355enc_stage_me.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.mi355enc_stage_me.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+        L.mi355enc_stage_me_select.argtypes = [vp, vp, vp, C.c_int, vp]
         L.mi355enc_stage_subpel.argtypes = [vp, vp, vp, C.c_int, vp]
         L.mi355enc_stage_inter.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
-        L.mi355enc_stage_pmb.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+        L.mi355enc_stage_pmb.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_intra_analyse.argtypes = [vp, vp, vp, C.c_int, vp, vp]
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
@@ -183,7 +188,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, overlap=0, cavlc_threads=0, intra_mode=0, scenecut=True):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
@@ -191,7 +196,7 @@ class Encoder:
         cfg.pipeline_depth, cfg.profile_events, cfg.use_graphs, cfg.keep_prefilter = (
             pipeline_depth, int(profile_events), int(use_graphs), int(keep_prefilter))
         cfg.deblock_mode = deblock_mode
-        cfg.overlap = int(overlap)
+        cfg.intra_in_p = int(intra_in_p)
         cfg.cavlc_threads = int(cavlc_threads)
         cfg.scenecut = int(scenecut)
         cfg.intra_mode = int(intra_mode)
@@ -224,6 +229,9 @@ class Encoder:
 
     def set_fixed_qp(self, qp):
         self._chk(self.L.mi355enc_set_fixed_qp(self.h, int(qp)), "set_fixed_qp")
+
+    def set_fixed_drop(self, drop):
+        self._chk(self.L.mi355enc_set_fixed_drop(self.h, int(drop)), "set_fixed_drop")
 
     def encode(self, y, uv, pts=0, force_idr=False):
         y = np.ascontiguousarray(y, np.uint8)
@@ -293,9 +301,17 @@ class Encoder:
 
     # ---- single-stage entry points (coded-size host planes)
     def stage_me(self, cur_y, ref_y, qp):
-        mbi = np.zeros(self.mbw * self.mbh, MBINFO_DTYPE)
-        self._chk(self.L.mi355enc_stage_me(self.h, _p(np.ascontiguousarray(cur_y)), _p(np.ascontiguousarray(ref_y)), qp, _p(mbi)), "stage_me")
-        return mbi
+        """-> (surfaces (n_mb, 35, 36) uint16: [dy+16][dx+16], first selection IMV_DTYPE (n_mb,))"""
+        n = self.mbw * self.mbh
+        imv = np.zeros(n, IMV_DTYPE)
+        surf = np.zeros((n, SURF_ROWS, SURF_COLS), np.uint16)
+        self._chk(self.L.mi355enc_stage_me(self.h, _p(np.ascontiguousarray(cur_y)), _p(np.ascontiguousarray(ref_y)), qp, _p(surf), _p(imv)), "stage_me")
+        return surf, imv
+
+    def stage_me_select(self, surf, imv, qp):
+        out = np.zeros(imv.size, IMV_DTYPE)
+        self._chk(self.L.mi355enc_stage_me_select(self.h, _p(np.ascontiguousarray(surf, np.uint16)), _p(np.ascontiguousarray(imv)), qp, _p(out)), "stage_me_select")
+        return out
 
     def stage_subpel(self, cur_y, ref_y, mbi, qp):
         mbi = np.ascontiguousarray(mbi).copy()
@@ -311,13 +327,17 @@ class Encoder:
                                               _p(rec_y), _p(rec_uv), _p(lev)), "stage_inter")
         return rec_y, rec_uv, mbi, lev
 
-    def stage_pmb(self, src_y, src_uv, ref_y, ref_uv, mbi, qp, refine=True):
-        mbi = np.ascontiguousarray(mbi).copy()
+    def stage_pmb(self, src_y, src_uv, ref_y, ref_uv, imv, surf, qp, drop=0, refine=True, idec=None, run_intra_p=True):
+        """surf: device layout (n_mb, 35, 36).  -> rec_y, rec_uv, records, levels"""
+        n = self.mbw * self.mbh
+        mbi = np.zeros(n, MBINFO_DTYPE)
         rec_y, rec_uv = np.empty_like(src_y), np.empty_like(src_uv)
-        lev = np.empty((mbi.size, LEVELS_PER_MB), np.int16)
+        lev = np.empty((n, LEVELS_PER_MB), np.int16)
+        dec = np.ascontiguousarray(idec) if idec is not None else None
         self._chk(self.L.mi355enc_stage_pmb(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)),
-                                            _p(np.ascontiguousarray(ref_y)), _p(np.ascontiguousarray(ref_uv)), qp, int(refine), _p(mbi),
-                                            _p(rec_y), _p(rec_uv), _p(lev)), "stage_pmb")
+                                            _p(np.ascontiguousarray(ref_y)), _p(np.ascontiguousarray(ref_uv)), qp, int(drop), int(refine),
+                                            _p(np.ascontiguousarray(imv)), _p(np.ascontiguousarray(surf, np.uint16)), _p(dec) if dec is not None else None,
+                                            int(run_intra_p), _p(mbi), _p(rec_y), _p(rec_uv), _p(lev)), "stage_pmb")
         return rec_y, rec_uv, mbi, lev
 
     def stage_intra(self, src_y, src_uv, qp):

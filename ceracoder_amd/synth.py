@@ -81,6 +81,38 @@ def s2_frames(width, height, count, seed=S2_SEED, start=0):
         yield y, uv
 
 
+def s4_frames(width, height, count, seed=0x11FE, pan_after=None):
+    """S4 "live camera": a still textured scene with fresh sensor noise (+-2) on every picture, a few moving objects, and
+    (optionally, from picture `pan_after` on) a slow pan of 1 px/frame -- what a contribution encoder sees most of the time,
+    and where P_Skip and the rate-control floor matter.  Same planes as s2_frames."""
+    r = _XorShift32(seed)
+    objs = [dict(w=r.rng(32, max(33, width // 6)), h=r.rng(32, max(33, height // 5)), x=r.rng(0, width - 1), y=r.rng(0, height - 1),
+                 vx=r.rng(-5, 5), vy=r.rng(-3, 3), seed=r.next()) for _ in range(5)]
+    g = np.random.Generator(np.random.PCG64(seed))
+    for f in range(count):
+        pan = max(0, f - pan_after) if pan_after is not None else 0
+        xs = np.arange(width, dtype=np.int64) + (1 << 18) + pan
+        ys = np.arange(height, dtype=np.int64) + (1 << 18)
+        X, Y = np.meshgrid(xs, ys)
+        base = 120.0 + 40.0 * np.sin(X / 29.0) * np.cos(Y / 37.0) + 25.0 * np.sin((X + 2 * Y) / 11.0)
+        fine = (_hash2(X & 0xFFFFF, Y & 0xFFFFF, seed) % np.uint64(9)).astype(np.int32) - 4
+        y = np.rint(base).astype(np.int32) + fine
+        cb = np.full((height // 2, width // 2), 118, np.int32) + (np.rint(base[::2, ::2]).astype(np.int32) - 120) // 6
+        cr = np.full((height // 2, width // 2), 136, np.int32) - (np.rint(base[::2, ::2]).astype(np.int32) - 120) // 8
+        for q in objs:
+            x0, y0 = (q["x"] + q["vx"] * f) % width, (q["y"] + q["vy"] * f) % height
+            x1, y1 = min(width, x0 + q["w"]), min(height, y0 + q["h"])
+            rx, ry = np.arange(x1 - x0, dtype=np.int64), np.arange(y1 - y0, dtype=np.int64)
+            y[y0:y1, x0:x1] = _texture(rx, ry, q["seed"])
+            cb[y0 // 2:y1 // 2, x0 // 2:x1 // 2] = 100 + (q["seed"] & 63)
+            cr[y0 // 2:y1 // 2, x0 // 2:x1 // 2] = 100 + ((q["seed"] >> 8) & 63)
+        y = np.clip(y + g.integers(-2, 3, y.shape), 16, 235).astype(np.uint8)
+        uv = np.empty((height // 2, width), np.uint8)
+        uv[:, 0::2] = np.clip(cb + g.integers(-1, 2, cb.shape), 16, 240)
+        uv[:, 1::2] = np.clip(cr + g.integers(-1, 2, cr.shape), 16, 240)
+        yield y, uv
+
+
 def s3_frames(width, height, count, seed=S3_SEED):
     g = np.random.Generator(np.random.PCG64(seed))
     for _ in range(count):

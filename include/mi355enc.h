@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355ENC_ABI_VERSION 1
+#define MI355ENC_ABI_VERSION 2
 
 enum {
     MI355ENC_OK = 0,
@@ -61,13 +61,9 @@ typedef struct {
     int subpel;               /* 1 (default): half- then quarter-sample refinement after the integer search */
     int deblock_mode;         /* 0: boundary-strength prep kernel + persistent 16-row band kernel (x+y order);
                                  1: one launch per x+2y wavefront (plain form, kept as a cross-check) */
-    int overlap;              /* band-pipelined schedule for P pictures (deblock_mode 0): the picture is cut into pieces of whole
-                                 deblocking bands, one HIP stream each; piece p of picture n+1 (search, transform, deblocking)
-                                 starts as soon as pieces p-1..p+1 of picture n are deblocked, so consecutive pictures overlap on
-                                 the device instead of queueing behind the deblocking chain of the whole picture.  Bit-identical
-                                 output.  0 (default): one picture after the other; 1: default piece count (4, the number of
-                                 equal-priority streams a stock HIP runtime backs with separate hardware queues); N >= 2: N
-                                 pieces (useful with GPU_MAX_HW_QUEUES raised) */
+    int intra_in_p;           /* 1 (default): macroblocks of P pictures may be coded intra (uncovered regions, partial scene changes): decided in
+                                 the fused P stage from the open-loop intra analysis, reconstructed by a short dependent pass
+                                 after it.  0: P pictures hold inter macroblocks only */
     int cavlc_threads;        /* host threads that code the slice (ranges of macroblock rows, concatenated bit-exactly into the
                                  same single slice); 1: the calling thread only; 0 (default, like x264enc's threads=0): chosen
                                  from the machine -- a quarter of the online CPUs, between 1 and 8 (1 for pictures under
@@ -111,6 +107,9 @@ int mi355enc_set_bitrate(mi355enc_t *h, uint32_t bps);
 uint32_t mi355enc_get_bitrate(const mi355enc_t *h);
 /* Constant-QP override for the next pictures (tests/bench); -1 returns to rate control. */
 int mi355enc_set_fixed_qp(mi355enc_t *h, int qp);
+/* With a constant QP: the level of rate control's ladder below QP 51 for the next P pictures (tests): 0 off .. 12: P macroblocks
+ * whose prediction error is small enough carry no residual / take the P_Skip vector; 255: whole pictures as one P_Skip run. */
+int mi355enc_set_fixed_drop(mi355enc_t *h, int drop);
 
 /* Synchronous: one NV12 picture in host memory -> one Annex-B access unit
  * (SPS+PPS precede every IDR).  Borrowed input, caller-owned output. */
@@ -155,26 +154,35 @@ int mi355enc_mb_height(const mi355enc_t *h);
 /* ---- single-stage entry points (parity tests; same kernels the encoder launches) ----
  * All planes are host pointers to coded-size (multiple-of-16) surfaces with stride 16*mbw;
  * mbinfo is mbw*mbh 16-byte records, levels mbw*mbh*408 int16. */
-int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_out);
-/* refine the integer vectors in mbinfo (mvx, mvy in quarter-sample units, cost) in place */
+/* Whole-sample motion search: SAD surfaces (35 x 36 uint16 per macroblock: row dy+16, column dx+16; the 33 x 33 upper-left
+ * part is the +-16 search range; surf_out may be NULL) and the first selection, 8 bytes per macroblock {i16 mvx, mvy
+ * (quarter-sample units, multiples of 4); u16 sad, bits}. */
+int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, uint16_t *surf_out, void *imv_out);
+/* One more selection over the surfaces, bits charged against the median of the neighbours' vectors in imv_in. */
+int mi355enc_stage_me_select(mi355enc_t *h, const uint16_t *surf, const void *imv_in, int qp, void *imv_out);
+/* Two-kernel form of the P stage (High-profile path): refine the vectors in mbinfo (mvx, mvy in quarter-sample units, cost) in place ... */
 int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_inout);
+/* ... and prediction, residual (4x4 or 8x8 transform), reconstruction for the vectors in mbinfo */
 int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y,
                          const uint8_t *ref_uv, int qp, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv,
                          int16_t *levels);
-/* The fused P-macroblock stage the encoder runs (refinement of the integer vectors in mbinfo_inout if `refine`, then
- * prediction, residual, reconstruction): must equal mi355enc_stage_subpel followed by mi355enc_stage_inter. */
+/* The fused P-macroblock stage the encoder runs, from the final whole-sample field `imv` and the surfaces: predictor estimates,
+ * skip probe, sub-sample refinement (if `refine`), intra-or-inter against `idec` (32 bytes per macroblock as written by
+ * mi355enc_stage_intra_analyse; NULL: inter only), residual with coefficient decimation; `drop`: 0 .. 12.  With run_intra_p the
+ * macroblocks decided intra are reconstructed afterwards (intra_p_kernel); without, they only carry type and modes. */
 int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv,
-                       int qp, int refine, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
+                       int qp, int drop, int refine, const void *imv, const uint16_t *surf, const void *idec, int run_intra_p,
+                       void *mbinfo_out, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
 int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out,
                          uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
 /* open-loop intra analysis only: 152 uint16 per macroblock {i16[4], chroma[4], i4[16][9]}, 0xFFFF = mode unavailable; and
- * (idec_out may be NULL) the decisions taken from them at `qp`: 24 bytes per macroblock {u8 modes4[16] by luma4x4BlkIdx;
- * u8 mode16, chroma mode, use_i4, 0; u32 cost} */
+ * (idec_out may be NULL) the decisions taken from them at `qp`: 32 bytes per macroblock {u8 modes4[16] by luma4x4BlkIdx;
+ * u8 mode16, chroma mode, use_i4, 0; u32 cost (luma + chroma), cost_luma, 0} */
 int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, uint16_t *isad_out, void *idec_out);
 int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const void *mbinfo);
 /* Time `iters` back-to-back launches of one stage on the handle's stream with HIP events;
  * stage: 0 ME, 1 inter, 2 intra (whole wavefront), 3 deblock (whole wavefront), 4 sub-sample refinement,
- * 5 / 6 / 7 input conversion from I420 / YUY2 / UYVY.
+ * 5 / 6 / 7 input conversion from I420 / YUY2 / UYVY, 8 one vector-selection iteration, 9 fused P stage, 10 intra macroblocks of a P picture.
  * Uses whatever the handle's surfaces currently hold.  Returns average ms per launch. */
 int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms);
 

@@ -364,17 +364,42 @@ static void dq_block(const int16_t lev_zz[16], int qp, int first, int have_dc, i
 }
 
 /* ================================================================== motion search */
-static inline int mv_bits(int v_int) { /* se(v) length of the quarter-pel value 4*v_int */
-    int q = 4 * v_int;
-    uint32_t k = q > 0 ? (uint32_t)(2 * q - 1) : (uint32_t)(-2 * q);
-    return orc_ue_bits(k, NULL);
+static inline int se_bits(int v) { return orc_ue_bits(v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v), NULL); } /* bits of se(v), 9.1 */
+static inline int ref_at(const uint8_t *p, int stride, int W, int H, int x, int y) { /* 8.4.2.2: the reference picture extended by coordinate clamping */
+    return p[(size_t)CLIP3(0, H - 1, y) * stride + CLIP3(0, W - 1, x)];
 }
-/* Encoder choice (the standard does not constrain motion search).  For each macroblock:
- * candidates (dx,dy) in [-range,range]^2 whose 16x16 block lies inside the coded picture;
- * cost = SAD + lambda(qp) * (bits(se(4dx)) + bits(se(4dy)));
- * winner = lowest cost, then lowest dy, then lowest dx (i.e. first in raster scan). */
+/* Encoder choice (the standard does not constrain motion search).
+ *
+ * orc_me_frame: the SAD of EVERY candidate (dx,dy) in [-range,range]^2 of every macroblock -- vectors may leave the picture
+ * (the SPS says motion_vectors_over_pic_boundaries_flag = 1), the reference being extended by coordinate clamping as 8.4.2.2
+ * prescribes -- kept as a surface of 33 x 33 uint16 per macroblock (index (dy+16)*33 + dx+16; 0xFFFF outside the range), and a
+ * first selection with the bits charged against the zero vector.
+ *
+ * orc_me_select: one more selection over the same surfaces, the bits charged against the 8.4.1.3 median of the vectors the
+ * NEIGHBOURS chose in the previous selection (Jacobi iteration: every macroblock at once).  cost = SAD + lambda(qp) *
+ * (bits(se(4(dx - px))) + bits(se(4(dy - py))) + ORC_SEL_BONUS), px,py whole samples -- except for the one candidate that equals the
+ * 8.4.1.1 P_Skip inference on the same field, which is charged nothing (as P_Skip it would cost no macroblock header at all);
+ * winner = lowest cost, then lowest dy, then lowest dx.
+ * Where the scene really moves, textured macroblocks find the motion in the first selection and their flat neighbours follow
+ * in the next ones (the surface is flat there, the bits decide); where nothing moves everything stays at zero.  After a few
+ * iterations the field is what a sequential encoder's predictor-relative search would settle on, without its raster-order
+ * dependency -- and the predictor estimates of the fused macroblock stage are taken from that field.
+ * Output per macroblock: whole-sample vector in quarter-sample units, its SAD and the vector bits it was charged. */
+int g_sel_bonus = ORC_SEL_BONUS; /* dev hook: orc_set_tuning(4, v) */
+static void select_mb(const uint16_t *sf, int range, int lambda, int px, int py, int sx, int sy, orc_imv_t *o) {
+    uint32_t best_cost = 0xFFFFFFFFu;
+    int bdx = 0, bdy = 0, bsad = 0, bbits = 0;
+    for (int dy = -range; dy <= range; dy++)
+        for (int dx = -range; dx <= range; dx++) {
+            const uint32_t sad = sf[(dy + 16) * 33 + dx + 16];
+            const int bits = (dx == sx && dy == sy) ? 0 : se_bits(4 * (dx - px)) + se_bits(4 * (dy - py)) + g_sel_bonus;
+            const uint32_t cost = sad + (uint32_t)(lambda * bits);
+            if (cost < best_cost) { best_cost = cost; bdx = dx; bdy = dy; bsad = (int)sad; bbits = bits; } /* scan order dy then dx resolves ties */
+        }
+    o->mvx = (int16_t)(4 * bdx); o->mvy = (int16_t)(4 * bdy); o->sad = (uint16_t)bsad; o->bits = (uint16_t)bbits;
+}
 void orc_me_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mbw, int mbh,
-                  int range, int qp, orc_mbinfo_t *mbi, int threads) {
+                  int range, int qp, uint16_t *surf, orc_imv_t *imv, int threads) {
     const int W = mbw * 16, H = mbh * 16;
     const int lambda = orc_me_lambda(qp);
     (void)threads;
@@ -382,26 +407,53 @@ void orc_me_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mb
     for (int my = 0; my < mbh; my++) {
         for (int mx = 0; mx < mbw; mx++) {
             int x0 = mx * 16, y0 = my * 16;
-            int dx_lo = -range < -x0 ? -x0 : -range, dx_hi = range > W - 16 - x0 ? W - 16 - x0 : range;
-            int dy_lo = -range < -y0 ? -y0 : -range, dy_hi = range > H - 16 - y0 ? H - 16 - y0 : range;
-            uint32_t best_cost = 0xFFFFFFFFu;
-            int best_dx = 0, best_dy = 0;
+            uint16_t *sf = surf + (size_t)(my * mbw + mx) * ORC_SURF;
             const uint8_t *c = cur_y + (size_t)y0 * stride + x0;
-            for (int dy = dy_lo; dy <= dy_hi; dy++) {
-                for (int dx = dx_lo; dx <= dx_hi; dx++) {
-                    const uint8_t *r = ref_y + (size_t)(y0 + dy) * stride + x0 + dx;
+            for (int i = 0; i < ORC_SURF; i++) sf[i] = 0xFFFF;
+            for (int dy = -range; dy <= range; dy++) {
+                for (int dx = -range; dx <= range; dx++) {
                     uint32_t sad = 0;
-                    for (int y = 0; y < 16; y++)
-                        for (int x = 0; x < 16; x++) sad += (uint32_t)iabs(c[y * stride + x] - r[y * stride + x]);
-                    uint32_t cost = sad + (uint32_t)(lambda * (mv_bits(dx) + mv_bits(dy)));
-                    int better = cost < best_cost; /* scan order dy then dx resolves ties */
-                    if (better) { best_cost = cost; best_dx = dx; best_dy = dy; }
+                    if (x0 + dx >= 0 && y0 + dy >= 0 && x0 + dx + 16 <= W && y0 + dy + 16 <= H) {
+                        const uint8_t *r = ref_y + (size_t)(y0 + dy) * stride + x0 + dx;
+                        for (int y = 0; y < 16; y++)
+                            for (int x = 0; x < 16; x++) sad += (uint32_t)iabs(c[y * stride + x] - r[y * stride + x]);
+                    } else
+                        for (int y = 0; y < 16; y++)
+                            for (int x = 0; x < 16; x++) sad += (uint32_t)iabs(c[y * stride + x] - ref_at(ref_y, stride, W, H, x0 + dx + x, y0 + dy + y));
+                    sf[(dy + 16) * 33 + dx + 16] = (uint16_t)sad; /* <= 65280 */
                 }
             }
-            orc_mbinfo_t *m = &mbi[my * mbw + mx];
-            m->mvx = (int16_t)(4 * best_dx); m->mvy = (int16_t)(4 * best_dy); m->cost = best_cost; /* quarter-sample units */
+            select_mb(sf, range, lambda, 0, 0, 0, 0, &imv[my * mbw + mx]);
         }
     }
+}
+static int median3(int a, int b, int c) {
+    int mn = a < b ? a : b, mx = a < b ? b : a;
+    return c < mn ? mn : (c > mx ? mx : c);
+}
+/* 8.4.1.3 on a whole-sample field (every neighbour taken as inter, refIdx 0) and the 8.4.1.1 skip inference on the same field */
+static void field_pred(const orc_imv_t *f, int mbw, int mx, int my, int *px, int *py, int *sx, int *sy) {
+    const int avA = mx > 0, avB = my > 0, avC = my > 0 && mx + 1 < mbw, avD = mx > 0 && my > 0;
+    const orc_imv_t *A = avA ? &f[my * mbw + mx - 1] : NULL, *B = avB ? &f[(my - 1) * mbw + mx] : NULL;
+    const orc_imv_t *C = avC ? &f[(my - 1) * mbw + mx + 1] : (avD ? &f[(my - 1) * mbw + mx - 1] : NULL);
+    const int n = (A != NULL) + (B != NULL) + (C != NULL);
+    if (n == 1) { const orc_imv_t *o = A ? A : B ? B : C; *px = o->mvx; *py = o->mvy; }
+    else { *px = median3(A ? A->mvx : 0, B ? B->mvx : 0, C ? C->mvx : 0); *py = median3(A ? A->mvy : 0, B ? B->mvy : 0, C ? C->mvy : 0); }
+    if (sx) {
+        *sx = *px; *sy = *py;
+        if (!avA || !avB || (A->mvx == 0 && A->mvy == 0) || (B->mvx == 0 && B->mvy == 0)) { *sx = 0; *sy = 0; }
+    }
+}
+void orc_me_select(const uint16_t *surf, int mbw, int mbh, int range, int qp, const orc_imv_t *in, orc_imv_t *out, int threads) {
+    const int lambda = orc_me_lambda(qp);
+    (void)threads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            int px, py, sx, sy;
+            field_pred(in, mbw, mx, my, &px, &py, &sx, &sy);
+            select_mb(surf + (size_t)(my * mbw + mx) * ORC_SURF, range, lambda, px >> 2, py >> 2, sx >> 2, sy >> 2, &out[my * mbw + mx]);
+        }
 }
 
 /* ================================================================== chroma helpers */
@@ -462,9 +514,6 @@ static void chroma_tq_recon(const uint8_t *src_uv, uint8_t *rec_uv, int stride, 
 /* ================================================================== inter (P) picture */
 /* 8.4.2.2.1 luma sample interpolation (6-tap half samples, averaged quarter samples) with the
  * reference picture extended by coordinate clamping, written from Figure 8-4 / Table 8-12. */
-static inline int ref_at(const uint8_t *p, int stride, int W, int H, int x, int y) {
-    return p[(size_t)CLIP3(0, H - 1, y) * stride + CLIP3(0, W - 1, x)];
-}
 static inline int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
 static int half_h(const uint8_t *p, int stride, int W, int H, int x, int y) { /* b1 at the right of (x,y) */
     return tap6(ref_at(p, stride, W, H, x - 2, y), ref_at(p, stride, W, H, x - 1, y), ref_at(p, stride, W, H, x, y),
@@ -821,6 +870,7 @@ void orc_intra_decide(const orc_isad_t *isad, int mbw, int mbh, int qp, int i4x4
                 for (int b = 0; b < 16; b++) d->modes4[b] = (uint8_t)lev[ORC_L_LDC + b];
             }
             d->cost = luma_sad + chroma_sad;
+            d->cost_luma = luma_sad;
         }
 }
 /* reconstruction of an Intra_4x4 macroblock with the modes in lev[ORC_L_LDC..] (8.3.1.2 + 8.5) */
@@ -843,19 +893,11 @@ static void intra4x4_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int
     }
 }
 
-/* I picture.  Analysis and decisions (above) need only the source picture; then per macroblock in raster order the
- * reconstruction with the chosen modes. */
-void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
-                     uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
-                     orc_mbinfo_t *mbi, int16_t *levels) {
-    orc_isad_t *isad = (orc_isad_t *)malloc((size_t)mbw * mbh * sizeof(orc_isad_t));
-    orc_idec_t *idec = (orc_idec_t *)malloc((size_t)mbw * mbh * sizeof(orc_idec_t));
-    orc_intra_analyse(src_y, src_uv, stride, mbw, mbh, isad);
-    orc_intra_decide(isad, mbw, mbh, qp, g_orc_i4x4, idec);
-    for (int my = 0; my < mbh; my++)
-        for (int mx = 0; mx < mbw; mx++) {
+/* Reconstruction of one intra macroblock with the decision `dec` (8.3 + 8.5): prediction from the reconstructed neighbours in
+ * rec_y / rec_uv (whatever their type: constrained_intra_pred_flag is 0), residual, levels, record. */
+static void intra_mb(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mx, int my, int qp,
+                     const orc_idec_t *dec, orc_mbinfo_t *mbi, int16_t *levels) {
             orc_mbinfo_t *m = &mbi[my * mbw + mx];
-            const orc_idec_t *dec = &idec[my * mbw + mx];
             int16_t *lev = levels + (size_t)(my * mbw + mx) * ORC_LEVELS_PER_MB;
             memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
             int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0;
@@ -930,9 +972,276 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
                     for (int x = 0; x < 8; x++) UV(rec_uv, stride, x0 / 2 + x, y0 / 2 + y, c) = cp[y * 8 + x];
             }
             chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 1, lev, &m->nzmask);
-        }
+}
+
+/* I picture.  Analysis and decisions (above) need only the source picture; then per macroblock in raster order the
+ * reconstruction with the chosen modes. */
+void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
+                     uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
+                     orc_mbinfo_t *mbi, int16_t *levels) {
+    orc_isad_t *isad = (orc_isad_t *)malloc((size_t)mbw * mbh * sizeof(orc_isad_t));
+    orc_idec_t *idec = (orc_idec_t *)malloc((size_t)mbw * mbh * sizeof(orc_idec_t));
+    orc_intra_analyse(src_y, src_uv, stride, mbw, mbh, isad);
+    orc_intra_decide(isad, mbw, mbh, qp, g_orc_i4x4, idec);
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) intra_mb(src_y, src_uv, rec_y, rec_uv, stride, mbw, mx, my, qp, &idec[my * mbw + mx], mbi, levels);
     free(isad);
     free(idec);
+}
+/* The intra macroblocks of a P picture (mb_type 0 / 2 left by orc_pmb_frame), in raster order, after every inter macroblock
+ * of the picture has been reconstructed: their neighbours' samples (before deblocking) are what 8.3 predicts from. */
+void orc_intra_p_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
+                       const orc_idec_t *idec, orc_mbinfo_t *mbi, int16_t *levels) {
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++)
+            if (mbi[my * mbw + mx].mb_type != 1) intra_mb(src_y, src_uv, rec_y, rec_uv, stride, mbw, mx, my, qp, &idec[my * mbw + mx], mbi, levels);
+}
+
+/* ================================================================== P pictures: the fused macroblock stage */
+/* Everything below is encoder choice unless a clause is cited.  Per P picture and macroblock, independently of every other
+ * macroblock's RESULT (neighbours are consulted only through the whole-sample vector field of orc_me_frame, which is complete
+ * before this stage starts -- so the device runs the stage as one flat launch):
+ *   1. predictor estimates from that field: p_est = 8.4.1.3 median over A, B, C of the field (every neighbour taken as inter,
+ *      refIdx 0); ps_est = the 8.4.1.1 P_Skip inference on the field (0 on the left / top border or next to a zero vector).
+ *      They equal the true predictors wherever the neighbours keep their whole-sample vectors.
+ *   2. skip probe at ps_est (as x264's probe_pskip): if the residual of the prediction at ps_est quantises to nothing (luma
+ *      after decimation, chroma DC and AC after decimation) the macroblock takes ps_est and no residual, and nothing else is
+ *      evaluated.  Rate control's ladder below QP 51 (drop > 0) widens this: SAD(ps_est) < T[drop] passes as well.
+ *   3. sub-sample refinement around the whole-sample winner, bits against p_est: 8 half-sample neighbours by SAD, then the
+ *      8 quarter-sample neighbours by SATD (4x4 Hadamard, x264 subme 2) -- strictly cheaper wins, (dy, dx) raster order.
+ *   4. intra or inter (when the open-loop intra analysis of the macroblock is available): SAD-domain comparison.
+ *   5. inter residual: 4x4 transform, dead-zone quantiser, coefficient decimation (x264 dct-decimate: an 8x8 whose
+ *      run/level score is below 4 and a macroblock whose score is below 6 are emptied; chroma AC of a plane below 7),
+ *      normative reconstruction.  drop > 0 and SAD(final) < T[drop]: no residual at all. */
+static int g_orc_feat = ORC_F_ALL;
+static int g_tune[8] = {ORC_SKIP_MARGIN_BITS, 0, 12, 3, 0, 0, 0, 0}; /* dev: skip margin bits, skip shift (0 = none), intra bias bits, intra shift */
+extern int g_sel_bonus;
+void orc_set_tuning(int which, int value) { if (which >= 0 && which < 8) g_tune[which] = value; if (which == 4) g_sel_bonus = value; }
+void orc_set_features(int mask) { g_orc_feat = mask; }
+int orc_get_features(void) { return g_orc_feat; }
+
+const uint32_t k_drop_sad[ORC_DROP_MAX + 1] = {0, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 0xFFFFFFFFu};
+uint32_t orc_drop_threshold(int drop) { return k_drop_sad[CLIP3(0, ORC_DROP_MAX, drop)]; }
+
+/* x264's decimate score of one 4x4 block (levels in scan order from `first`): 9 as soon as a level exceeds 1 in magnitude,
+ * otherwise the sum over its +-1 levels of a weight that falls with the run of zeros below the level */
+int orc_decimate_score(const int16_t *lev, int first) {
+    static const uint8_t w[16] = {3, 2, 2, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int idx = 15, score = 0;
+    while (idx >= first && lev[idx] == 0) idx--;
+    while (idx >= first) {
+        if (lev[idx] > 1 || lev[idx] < -1) return 9;
+        idx--;
+        int run = 0;
+        while (idx >= first && lev[idx] == 0) { idx--; run++; }
+        score += w[run];
+    }
+    return score;
+}
+/* luma prediction of the macroblock at quarter-sample vector (qx, qy) into pred[256] */
+static void luma_pred16(const uint8_t *ref_y, int stride, int W, int H, int x0, int y0, int qx, int qy, uint8_t *pred) {
+    for (int y = 0; y < 16; y++)
+        for (int x = 0; x < 16; x++) pred[y * 16 + x] = (uint8_t)luma_qpel(ref_y, stride, W, H, x0 + x + (qx >> 2), y0 + y + (qy >> 2), qx & 3, qy & 3);
+}
+static uint32_t sad16(const uint8_t *src, int stride, const uint8_t *pred) {
+    uint32_t s = 0;
+    for (int y = 0; y < 16; y++) for (int x = 0; x < 16; x++) s += (uint32_t)iabs(src[(size_t)y * stride + x] - pred[y * 16 + x]);
+    return s;
+}
+/* sum over the sixteen 4x4 blocks of sum |H d H^T| (4x4 Hadamard of the difference), halved once at the end */
+uint32_t orc_satd16(const uint8_t *src, int stride, const uint8_t *pred) {
+    uint32_t total = 0;
+    for (int by = 0; by < 16; by += 4)
+        for (int bx = 0; bx < 16; bx += 4) {
+            int d[16], t[16];
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) d[y * 4 + x] = src[(size_t)(by + y) * stride + bx + x] - pred[(by + y) * 16 + bx + x];
+            for (int i = 0; i < 4; i++) {
+                int a = d[i * 4] + d[i * 4 + 3], b = d[i * 4 + 1] + d[i * 4 + 2], c = d[i * 4 + 1] - d[i * 4 + 2], e = d[i * 4] - d[i * 4 + 3];
+                t[i * 4] = a + b; t[i * 4 + 1] = e + c; t[i * 4 + 2] = a - b; t[i * 4 + 3] = e - c;
+            }
+            for (int j = 0; j < 4; j++) {
+                int a = t[j] + t[12 + j], b = t[4 + j] + t[8 + j], c = t[4 + j] - t[8 + j], e = t[j] - t[12 + j];
+                total += (uint32_t)(iabs(a + b) + iabs(e + c) + iabs(a - b) + iabs(e - c));
+            }
+        }
+    return total >> 1;
+}
+/* luma of an inter macroblock: residual of src against pred -> levels (scan order), decimation; returns the blkIdx mask of
+ * blocks that keep levels.  Nothing is reconstructed here. */
+static uint32_t inter_luma_tq(const uint8_t *src, int stride, const uint8_t *pred, int qp, int decimate, int16_t *lev /* 16 x 16 */) {
+    uint32_t nz = 0;
+    int score[16];
+    for (int b = 0; b < 16; b++) {
+        int16_t res[16];
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) res[y * 4 + x] = (int16_t)(src[(size_t)(k_blk_y[b] + y) * stride + k_blk_x[b] + x] - pred[(k_blk_y[b] + y) * 16 + k_blk_x[b] + x]);
+        if (tq_block(res, qp, 0, 0, lev + b * 16, NULL)) nz |= 1u << b;
+        score[b] = orc_decimate_score(lev + b * 16, 0);
+    }
+    if (decimate) {
+        int total = 0;
+        for (int g = 0; g < 4; g++) { /* luma4x4BlkIdx 4g .. 4g+3 form one 8x8 block (6.4.3) */
+            const int s8 = score[4 * g] + score[4 * g + 1] + score[4 * g + 2] + score[4 * g + 3];
+            total += s8;
+            if (s8 < 4) { memset(lev + 64 * g, 0, 64 * sizeof(int16_t)); nz &= ~(0xFu << (4 * g)); }
+        }
+        if (total < 6) { memset(lev, 0, 256 * sizeof(int16_t)); nz = 0; }
+    }
+    return nz;
+}
+/* chroma of an inter macroblock whose prediction is already in rec_uv: levels, decimation of each plane's AC, reconstruction */
+static void inter_chroma_tq_recon(const uint8_t *src_uv, uint8_t *rec_uv, int stride, int cx0, int cy0, int qp, int decimate,
+                                  int16_t *lev, uint32_t *nzmask, int probe_only) {
+    const int qpc = k_chroma_qp[CLIP3(0, 51, qp)];
+    for (int c = 0; c < 2; c++) {
+        int16_t dc[4];
+        int16_t *ldc = lev + ORC_L_CDC + 4 * c;
+        int sc = 0;
+        for (int b = 0; b < 4; b++) {
+            int bx = (b & 1) * 4, by = (b >> 1) * 4;
+            int16_t res[16];
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++)
+                    res[y * 4 + x] = (int16_t)(UV(src_uv, stride, cx0 + bx + x, cy0 + by + y, c) - UV(rec_uv, stride, cx0 + bx + x, cy0 + by + y, c));
+            int16_t *l = lev + ORC_L_CAC + (4 * c + b) * 16;
+            if (tq_block(res, qpc, 0, 1, l, &dc[b])) *nzmask |= 1u << (16 + 4 * c + b);
+            sc += orc_decimate_score(l, 1);
+        }
+        if (decimate && sc < 7) { /* the plane's AC levels are not worth their bits */
+            memset(lev + ORC_L_CAC + 4 * c * 16, 0, 64 * sizeof(int16_t));
+            *nzmask &= ~(0xFu << (16 + 4 * c));
+        }
+        int f0 = dc[0] + dc[1] + dc[2] + dc[3], f1 = dc[0] - dc[1] + dc[2] - dc[3];
+        int f2 = dc[0] + dc[1] - dc[2] - dc[3], f3 = dc[0] - dc[1] - dc[2] + dc[3];
+        ldc[0] = (int16_t)quant_dc(f0, qpc, 0); ldc[1] = (int16_t)quant_dc(f1, qpc, 0);
+        ldc[2] = (int16_t)quant_dc(f2, qpc, 0); ldc[3] = (int16_t)quant_dc(f3, qpc, 0);
+        if (ldc[0] | ldc[1] | ldc[2] | ldc[3]) *nzmask |= (c ? ORC_NZ_CRDC : ORC_NZ_CBDC);
+    }
+    if (probe_only) return;
+    for (int c = 0; c < 2; c++) { /* 8.5.11.1/2 + 8.5.12 */
+        const int16_t *ldc = lev + ORC_L_CDC + 4 * c;
+        int g0 = ldc[0] + ldc[1] + ldc[2] + ldc[3], g1 = ldc[0] - ldc[1] + ldc[2] - ldc[3];
+        int g2 = ldc[0] + ldc[1] - ldc[2] - ldc[3], g3 = ldc[0] - ldc[1] - ldc[2] + ldc[3];
+        int ls = 16 * k_dequant_v[qpc % 6][0];
+        int dcv[4] = {((g0 * ls) << (qpc / 6)) >> 5, ((g1 * ls) << (qpc / 6)) >> 5, ((g2 * ls) << (qpc / 6)) >> 5, ((g3 * ls) << (qpc / 6)) >> 5};
+        for (int b = 0; b < 4; b++) {
+            int bx = (b & 1) * 4, by = (b >> 1) * 4;
+            int32_t d[16];
+            dq_block(lev + ORC_L_CAC + (4 * c + b) * 16, qpc, 1, 1, dcv[b], d);
+            idct4_add_step(d, &UV(rec_uv, stride, cx0 + bx, cy0 + by, c), stride, 2);
+        }
+    }
+}
+/* chroma prediction only (8.4.2.2.2) */
+static void chroma_pred8(const uint8_t *ref_uv, uint8_t *rec_uv, int stride, int W, int H, int x0, int y0, int mvx, int mvy) {
+    int cw = W / 2, ch = H / 2, cx0 = x0 / 2, cy0 = y0 / 2;
+    int xi = mvx >> 3, yi = mvy >> 3, xf = mvx & 7, yf = mvy & 7;
+    for (int c = 0; c < 2; c++)
+        for (int y = 0; y < 8; y++)
+            for (int x = 0; x < 8; x++) {
+                int ax = CLIP3(0, cw - 1, cx0 + x + xi), bx = CLIP3(0, cw - 1, cx0 + x + xi + 1);
+                int ay = CLIP3(0, ch - 1, cy0 + y + yi), cy = CLIP3(0, ch - 1, cy0 + y + yi + 1);
+                int A = UV(ref_uv, stride, ax, ay, c), B = UV(ref_uv, stride, bx, ay, c);
+                int C = UV(ref_uv, stride, ax, cy, c), D = UV(ref_uv, stride, bx, cy, c);
+                UV(rec_uv, stride, cx0 + x, cy0 + y, c) = (uint8_t)(((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6);
+            }
+}
+
+void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv, uint8_t *rec_y, uint8_t *rec_uv,
+                   int stride, int mbw, int mbh, int qp, int drop, int refine, const orc_imv_t *imv, const uint16_t *surf, const orc_idec_t *idec,
+                   orc_mbinfo_t *mbi, int16_t *levels, int threads) {
+    const int W = mbw * 16, H = mbh * 16, lambda = orc_me_lambda(qp), feat = g_orc_feat;
+    const uint32_t tdrop = drop > 0 ? orc_drop_threshold(drop) : 0;
+    (void)threads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16;
+            orc_mbinfo_t *m = &mbi[mbn];
+            int16_t *lev = levels + (size_t)mbn * ORC_LEVELS_PER_MB;
+            const uint8_t *sy = src_y + (size_t)y0 * stride + x0;
+            uint8_t pred[256];
+            int px, py, sx, sy_;
+            memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
+            m->mb_type = 1; m->i16_mode = 0; m->chroma_mode = 0; m->qp = (uint8_t)qp; m->nzmask = 0;
+            field_pred(imv, mbw, mx, my, &px, &py, &sx, &sy_);
+            if (!(feat & ORC_F_MVDCOST)) { px = 0; py = 0; }
+            /* ---- 2. skip probe */
+            if (feat & ORC_F_SKIPPROBE) {
+                /* ps_est is a median of in-range whole-sample vectors: its SAD is on the surface already.  The probe is only worth
+                 * running when that prediction is not much worse than the best whole-sample one (at high QP everything quantises to
+                 * nothing, and the distortion is all there is to tell two vectors apart). */
+                const uint32_t ds = surf[(size_t)mbn * ORC_SURF + ((sy_ >> 2) + 16) * 33 + (sx >> 2) + 16];
+                const uint32_t di = imv[mbn].sad;
+                int pass = tdrop && ds < tdrop;
+                const int worth = ds <= di + (g_tune[1] ? (di >> g_tune[1]) : 0) + (uint32_t)(lambda * g_tune[0]);
+                if (pass || worth) luma_pred16(ref_y, stride, W, H, x0, y0, sx, sy_, pred);
+                if (!pass && worth) {
+                    int16_t pl[ORC_LEVELS_PER_MB];
+                    uint32_t pnz = 0;
+                    memset(pl, 0, sizeof pl);
+                    if (inter_luma_tq(sy, stride, pred, qp, 1, pl) == 0) {
+                        chroma_pred8(ref_uv, rec_uv, stride, W, H, x0, y0, sx, sy_);
+                        inter_chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 1, pl, &pnz, 1);
+                        pass = pnz == 0;
+                    }
+                }
+                if (pass) {
+                    m->mvx = (int16_t)sx; m->mvy = (int16_t)sy_; m->cost = ds;
+                    for (int y = 0; y < 16; y++) memcpy(rec_y + (size_t)(y0 + y) * stride + x0, pred + y * 16, 16);
+                    chroma_pred8(ref_uv, rec_uv, stride, W, H, x0, y0, sx, sy_);
+                    continue;
+                }
+            }
+            /* ---- 3. refinement */
+            int bx = imv[mbn].mvx, by = imv[mbn].mvy;
+            luma_pred16(ref_y, stride, W, H, x0, y0, bx, by, pred);
+            uint32_t best = sad16(sy, stride, pred) + (uint32_t)(lambda * (se_bits(bx - px) + se_bits(by - py)));
+            if (refine)
+                for (int step = 2; step >= 1; step--) {
+                    const int satd = step == 1 && (feat & ORC_F_SATD);
+                    if (satd) { /* the quarter-sample round compares in the transform domain: restate the standing best there */
+                        luma_pred16(ref_y, stride, W, H, x0, y0, bx, by, pred);
+                        best = orc_satd16(sy, stride, pred) + (uint32_t)(lambda * (se_bits(bx - px) + se_bits(by - py)));
+                    }
+                    const int cx = bx, cy = by;
+                    for (int dy = -1; dy <= 1; dy++)
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (!dx && !dy) continue;
+                            const int qx = cx + dx * step, qy = cy + dy * step;
+                            luma_pred16(ref_y, stride, W, H, x0, y0, qx, qy, pred);
+                            const uint32_t d = satd ? orc_satd16(sy, stride, pred) : sad16(sy, stride, pred);
+                            const uint32_t cost = d + (uint32_t)(lambda * (se_bits(qx - px) + se_bits(qy - py)));
+                            if (cost < best) { best = cost; bx = qx; by = qy; }
+                        }
+                }
+            luma_pred16(ref_y, stride, W, H, x0, y0, bx, by, pred);
+            const uint32_t dsad = sad16(sy, stride, pred);
+            const uint32_t jinter = dsad + (uint32_t)(lambda * (se_bits(bx - px) + se_bits(by - py)));
+            m->mvx = (int16_t)bx; m->mvy = (int16_t)by; m->cost = jinter;
+            /* ---- 4. intra instead?  (reconstructed later, by orc_intra_p_frame, once every inter macroblock is in place) */
+            if ((feat & ORC_F_INTRAP) && idec && imv[mbn].sad + (uint32_t)(lambda * imv[mbn].bits) >= ORC_INTRA_GATE(lambda)) {
+                const orc_idec_t *d = &idec[mbn];
+                const uint32_t jintra = d->cost_luma + (g_tune[3] ? (d->cost_luma >> g_tune[3]) : 0) + (uint32_t)(lambda * g_tune[2]);
+                if (jintra < jinter) {
+                    m->mb_type = (uint8_t)(d->use_i4 ? 2 : 0); m->mvx = 0; m->mvy = 0;
+                    m->i16_mode = (uint8_t)(d->use_i4 ? 0 : d->mode16); m->chroma_mode = d->cmode; m->cost = d->cost;
+                    continue;
+                }
+            }
+            /* ---- 5. residual */
+            for (int y = 0; y < 16; y++) memcpy(rec_y + (size_t)(y0 + y) * stride + x0, pred + y * 16, 16);
+            chroma_pred8(ref_uv, rec_uv, stride, W, H, x0, y0, bx, by);
+            if (tdrop && dsad < tdrop) continue; /* rate control's ladder below QP 51: prediction only */
+            m->nzmask = inter_luma_tq(sy, stride, pred, qp, (feat & ORC_F_DECIMATE) != 0, lev + ORC_L_LUMA);
+            for (int b = 0; b < 16; b++) {
+                if (!(m->nzmask & (1u << b))) continue;
+                int32_t d[16];
+                dq_block(lev + ORC_L_LUMA + b * 16, qp, 0, 0, 0, d);
+                orc_idct4_add(d, rec_y + (size_t)(y0 + k_blk_y[b]) * stride + x0 + k_blk_x[b], stride);
+            }
+            inter_chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, (feat & ORC_F_DECIMATE) != 0, lev, &m->nzmask, 0);
+        }
 }
 
 /* ================================================================== deblocking (8.7) */
@@ -1099,10 +1408,6 @@ int orc_cavlc_block_bits(const int16_t *coef, int maxnum, int nC, uint8_t *out, 
     return b.overflow ? -1 : n;
 }
 
-static int median3(int a, int b, int c) {
-    int mn = a < b ? a : b, mx = a < b ? b : a;
-    return c < mn ? mn : (c > mx ? mx : c);
-}
 /* 8.4.1.3 motion vector prediction for a 16x16 partition with refIdx 0 (quarter-pel units
  * are not needed: vectors are compared/added as integer-pel*4 by the caller).
  * type[] : -1 unavailable, 0 intra (refIdx -1), 1 inter (refIdx 0). */
@@ -1354,8 +1659,15 @@ struct orc_enc {
     unsigned long long sc_sum, sc_force_at, pic_index;
     uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv;
     int cur; /* index of the surface holding the last reconstructed picture */
-    orc_mbinfo_t *mbi;
+    orc_mbinfo_t *mbi, *prev_mbi;   /* records of this picture / of the previous one (temporal vector predictor) */
+    int prev_is_p;                  /* prev_mbi holds a P picture's records */
+    orc_imv_t *imv, *imv2;
+    uint16_t *surf;
+    int me_iters;
+    orc_isad_t *isad;
+    orc_idec_t *idec;
     int16_t *levels;
+    int last_qp;
 };
 
 orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop, int me_range, int threads) {
@@ -1366,20 +1678,27 @@ orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop
     e->width = width; e->height = height;
     e->mbw = (width + 15) / 16; e->mbh = (height + 15) / 16; e->stride = e->mbw * 16;
     e->fps_num = fps_num; e->fps_den = fps_den; e->gop = gop; e->me_range = me_range; e->threads = threads; e->subpel = 1;
-    e->scenecut = 1; e->sc_force_at = ~0ull;
-    size_t ysz = (size_t)e->stride * e->mbh * 16, csz = ysz / 2;
+    e->scenecut = 1; e->sc_force_at = ~0ull; e->last_qp = 26;
+    size_t ysz = (size_t)e->stride * e->mbh * 16, csz = ysz / 2, nmb = (size_t)e->mbw * e->mbh;
     e->src_y = (uint8_t *)malloc(ysz); e->src_uv = (uint8_t *)malloc(csz);
     e->pre_y = (uint8_t *)malloc(ysz); e->pre_uv = (uint8_t *)malloc(csz);
     for (int i = 0; i < 2; i++) { e->rec_y[i] = (uint8_t *)malloc(ysz); e->rec_uv[i] = (uint8_t *)malloc(csz); }
-    e->mbi = (orc_mbinfo_t *)calloc((size_t)e->mbw * e->mbh, sizeof(orc_mbinfo_t));
-    e->levels = (int16_t *)calloc((size_t)e->mbw * e->mbh * ORC_LEVELS_PER_MB, sizeof(int16_t));
+    e->mbi = (orc_mbinfo_t *)calloc(nmb, sizeof(orc_mbinfo_t));
+    e->prev_mbi = (orc_mbinfo_t *)calloc(nmb, sizeof(orc_mbinfo_t));
+    e->imv = (orc_imv_t *)calloc(nmb, sizeof(orc_imv_t));
+    e->imv2 = (orc_imv_t *)calloc(nmb, sizeof(orc_imv_t));
+    e->surf = (uint16_t *)malloc(nmb * ORC_SURF * sizeof(uint16_t));
+    e->me_iters = ORC_ME_ITERS;
+    e->isad = (orc_isad_t *)calloc(nmb, sizeof(orc_isad_t));
+    e->idec = (orc_idec_t *)calloc(nmb, sizeof(orc_idec_t));
+    e->levels = (int16_t *)calloc(nmb * ORC_LEVELS_PER_MB, sizeof(int16_t));
     return e;
 }
 void orc_enc_close(orc_enc_t *e) {
     if (!e) return;
     free(e->src_y); free(e->src_uv); free(e->pre_y); free(e->pre_uv);
     for (int i = 0; i < 2; i++) { free(e->rec_y[i]); free(e->rec_uv[i]); }
-    free(e->mbi); free(e->levels); free(e);
+    free(e->mbi); free(e->prev_mbi); free(e->imv); free(e->imv2); free(e->surf); free(e->isad); free(e->idec); free(e->levels); free(e);
 }
 /* copy the visible picture into the coded-size surface, replicating the last column/row */
 static void load_padded(orc_enc_t *e, const uint8_t *y, int ys, const uint8_t *uv, int uvs) {
@@ -1397,25 +1716,59 @@ static void load_padded(orc_enc_t *e, const uint8_t *y, int ys, const uint8_t *u
         for (int x = e->width; x < W; x += 2) { d[x] = s[e->width - 2]; d[x + 1] = s[e->width - 1]; }
     }
 }
-int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
-                  int qp, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len, int *is_idr) {
-    if (!e || qp < 0 || qp > 51) return -1;
+/* One picture.  qp 0..51; drop 0..ORC_DROP_MAX (P pictures: rate control's ladder below QP 51); drop == ORC_DROP_SKIP: the
+ * picture is coded as one run of P_Skip macroblocks (no source sample is looked at; the reconstruction is the reference) --
+ * what rate control emits when even the ladder's last step would overshoot.  An IDR is never dropped. */
+int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
+                   int qp, int drop, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len, int *is_idr) {
+    if (!e || qp < 0 || qp > 51 || drop < 0 || (drop > ORC_DROP_MAX && drop != ORC_DROP_SKIP)) return -1;
     int idr = force_idr || !e->have_ref || e->frames_since_idr >= e->gop || (e->pic_index == e->sc_force_at && !e->prev_idr);
     if (idr) { e->frames_since_idr = 0; }
-    load_padded(e, y, y_stride, uv, uv_stride);
+    const int nmb = e->mbw * e->mbh;
+    const int all_skip = !idr && drop == ORC_DROP_SKIP;
     int nxt = e->cur ^ 1;
     size_t ysz = (size_t)e->stride * e->mbh * 16;
-    if (idr)
-        orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
-    else {
-        orc_me_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, e->me_range, qp, e->mbi, e->threads);
-        if (e->subpel) orc_subpel_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, qp, e->mbi, e->threads);
-        orc_inter_frame(e->src_y, e->src_uv, e->rec_y[e->cur], e->rec_uv[e->cur], e->rec_y[nxt], e->rec_uv[nxt],
-                        e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
+    if (all_skip) {
+        nxt = e->cur; /* the reconstruction IS the reference: every macroblock P_Skip with the zero vector, nothing to filter */
+        for (int i = 0; i < nmb; i++) { memset(&e->mbi[i], 0, sizeof e->mbi[i]); e->mbi[i].mb_type = 1; e->mbi[i].qp = (uint8_t)qp; }
+        memset(e->levels, 0, (size_t)nmb * ORC_LEVELS_PER_MB * sizeof(int16_t));
+        memcpy(e->pre_y, e->rec_y[nxt], ysz);
+        memcpy(e->pre_uv, e->rec_uv[nxt], ysz / 2);
+    } else {
+        load_padded(e, y, y_stride, uv, uv_stride);
+        if (idr)
+            orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
+        else {
+            orc_me_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, e->me_range, qp, e->surf, e->imv, e->threads);
+            if (g_orc_feat & ORC_F_MVDCOST)
+                for (int it = 0; it < e->me_iters; it++) {
+                    orc_me_select(e->surf, e->mbw, e->mbh, e->me_range, qp, e->imv, e->imv2, e->threads);
+                    orc_imv_t *t = e->imv; e->imv = e->imv2; e->imv2 = t;
+                }
+            if (g_orc_t8) { /* High-profile path: the two-stage form (refinement with absolute-vector cost, 8x8 transform), no intra / skip logic */
+                const int lam = orc_me_lambda(qp);
+                for (int i = 0; i < nmb; i++) {
+                    e->mbi[i].mvx = e->imv[i].mvx; e->mbi[i].mvy = e->imv[i].mvy;
+                    e->mbi[i].cost = e->imv[i].sad + (uint32_t)(lam * (se_bits(e->imv[i].mvx) + se_bits(e->imv[i].mvy))); /* refinement compares absolute-vector costs */
+                }
+                if (e->subpel) orc_subpel_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, qp, e->mbi, e->threads);
+                orc_inter_frame(e->src_y, e->src_uv, e->rec_y[e->cur], e->rec_uv[e->cur], e->rec_y[nxt], e->rec_uv[nxt],
+                                e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
+            } else {
+                const int intra_p = (g_orc_feat & ORC_F_INTRAP) != 0;
+                if (intra_p) {
+                    orc_intra_analyse(e->src_y, e->src_uv, e->stride, e->mbw, e->mbh, e->isad);
+                    orc_intra_decide(e->isad, e->mbw, e->mbh, qp, g_orc_i4x4, e->idec);
+                }
+                orc_pmb_frame(e->src_y, e->src_uv, e->rec_y[e->cur], e->rec_uv[e->cur], e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh,
+                              qp, drop, e->subpel, e->imv, e->surf, intra_p ? e->idec : NULL, e->mbi, e->levels, e->threads);
+                if (intra_p) orc_intra_p_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, e->idec, e->mbi, e->levels);
+            }
+        }
+        memcpy(e->pre_y, e->rec_y[nxt], ysz);
+        memcpy(e->pre_uv, e->rec_uv[nxt], ysz / 2);
+        orc_deblock_frame(e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, e->mbi);
     }
-    memcpy(e->pre_y, e->rec_y[nxt], ysz);
-    memcpy(e->pre_uv, e->rec_uv[nxt], ysz / 2);
-    orc_deblock_frame(e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, e->mbi);
     size_t n = 0;
     if (idr) {
         n = orc_write_headers(out, out_cap, e->width, e->height, e->fps_num, e->fps_den);
@@ -1427,25 +1780,34 @@ int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *u
     *out_len = n + s;
     if (is_idr) *is_idr = idr;
     if (idr) { e->idr_count++; e->sc_sum = 0; e->sc_cnt = 0; }
-    else { /* summed macroblock cost of this P picture against the mean of the P pictures since the last IDR */
+    else if (!all_skip) { /* summed macroblock cost of this P picture against the mean of the P pictures since the last IDR */
         unsigned long long cost = 0;
-        for (int i = 0; i < e->mbw * e->mbh; i++) cost += e->mbi[i].cost;
+        for (int i = 0; i < nmb; i++) cost += e->mbi[i].cost;
         const int pending = e->sc_force_at != ~0ull && e->sc_force_at > e->pic_index;
         if (e->scenecut && !pending && e->sc_cnt >= 2 && cost > 3 * (e->sc_sum / (unsigned long long)e->sc_cnt)) e->sc_force_at = e->pic_index + 2;
         e->sc_sum += cost; e->sc_cnt++;
     }
+    memcpy(e->prev_mbi, e->mbi, (size_t)nmb * sizeof(orc_mbinfo_t));
+    e->prev_is_p = !idr;
     e->prev_idr = idr; e->pic_index++;
     e->frames_since_idr++;
-    e->cur = nxt; e->have_ref = 1;
+    e->cur = nxt; e->have_ref = 1; e->last_qp = qp;
     return 0;
+}
+int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
+                  int qp, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len, int *is_idr) {
+    return orc_enc_frame2(e, y, y_stride, uv, uv_stride, qp, 0, force_idr, out, out_cap, out_len, is_idr);
 }
 void orc_enc_set_subpel(orc_enc_t *e, int on) { e->subpel = on; }
 void orc_enc_set_scenecut(orc_enc_t *e, int on) { e->scenecut = on; }
+void orc_enc_set_me_iters(orc_enc_t *e, int n) { e->me_iters = n < 0 ? 0 : n; }
 const uint8_t *orc_enc_recon_y(const orc_enc_t *e) { return e->rec_y[e->cur]; }
 const uint8_t *orc_enc_recon_uv(const orc_enc_t *e) { return e->rec_uv[e->cur]; }
 const uint8_t *orc_enc_prefilter_y(const orc_enc_t *e) { return e->pre_y; }
 const uint8_t *orc_enc_prefilter_uv(const orc_enc_t *e) { return e->pre_uv; }
 const orc_mbinfo_t *orc_enc_mbinfo(const orc_enc_t *e) { return e->mbi; }
+const orc_imv_t *orc_enc_imv(const orc_enc_t *e) { return e->imv; }
+const orc_idec_t *orc_enc_idec(const orc_enc_t *e) { return e->idec; }
 const int16_t *orc_enc_levels(const orc_enc_t *e) { return e->levels; }
 int orc_enc_mbw(const orc_enc_t *e) { return e->mbw; }
 int orc_enc_mbh(const orc_enc_t *e) { return e->mbh; }

@@ -55,10 +55,17 @@ typedef struct {
 
 /* ---- stage functions (each is the checker for one HIP kernel) ------------------- */
 
-/* Full-search integer-pel SAD motion search, +-range, on coded-size luma planes.
- * Writes mvx,mvy (quarter-sample units, multiples of 4) and cost of every macroblock. */
+/* Full-search integer-pel SAD motion search, +-range, on coded-size luma planes; vectors may leave the picture.  Keeps the
+ * SAD of every candidate (ORC_SURF uint16 per macroblock, index (dy+16)*33 + dx+16, 0xFFFF outside the range) and makes a first
+ * selection with the vector bits charged against zero.  orc_me_select: one Jacobi iteration of the selection, the bits charged
+ * against the median of the neighbours' vectors in `in`.  Per macroblock 8 bytes: whole-sample vector (quarter-sample
+ * units, multiples of 4), its SAD, the vector bits it was charged (cost = sad + lambda * bits). */
+#define ORC_SURF (33 * 33)
+#define ORC_SEL_BONUS 2 /* header bits every candidate but the P_Skip one is charged on top of its vector bits */
+typedef struct { int16_t mvx, mvy; uint16_t sad, bits; } orc_imv_t;
 void orc_me_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mbw, int mbh,
-                  int range, int qp, orc_mbinfo_t *mbi, int threads);
+                  int range, int qp, uint16_t *surf, orc_imv_t *imv, int threads);
+void orc_me_select(const uint16_t *surf, int mbw, int mbh, int range, int qp, const orc_imv_t *in, orc_imv_t *out, int threads);
 
 /* Half- then quarter-sample refinement of the vectors left by orc_me_frame (mvx,mvy,cost updated). */
 void orc_subpel_frame(const uint8_t *cur_y, const uint8_t *ref_y, int stride, int mbw, int mbh, int qp,
@@ -74,7 +81,7 @@ void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t 
 typedef struct { uint16_t i16[4], chroma[4], i4[16][9]; } orc_isad_t; /* 304 bytes per macroblock */
 void orc_intra_analyse(const uint8_t *src_y, const uint8_t *src_uv, int stride, int mbw, int mbh, orc_isad_t *out);
 /* Mode decisions of an I picture from those SADs alone: 16 bytes per macroblock (layout shared with the device) */
-typedef struct { uint8_t modes4[16]; uint8_t mode16, cmode, use_i4, pad; uint32_t cost; } orc_idec_t; /* 24 bytes */
+typedef struct { uint8_t modes4[16]; uint8_t mode16, cmode, use_i4, pad; uint32_t cost, cost_luma, rsv0; } orc_idec_t; /* 32 bytes; cost = luma + chroma */
 void orc_intra_decide(const orc_isad_t *isad, int mbw, int mbh, int qp, int i4x4, orc_idec_t *out);
 
 /* I picture: Intra16x16 + chroma prediction, mode decision by SAD, transform/quant,
@@ -82,6 +89,25 @@ void orc_intra_decide(const orc_isad_t *isad, int mbw, int mbh, int qp, int i4x4
 void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
                      uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
                      orc_mbinfo_t *mbi, int16_t *levels);
+
+/* P macroblocks, fused stage (what the device's pmb_kernel computes): predictor estimates from the whole-sample field `imv`,
+ * skip probe, sub-sample refinement (`refine`), intra-or-inter against `idec` (may be NULL: no intra macroblocks), inter
+ * residual with coefficient decimation.  `drop`: rate control's ladder below QP 51, 0 .. ORC_DROP_MAX.  Macroblocks decided
+ * intra get their record's type and modes only; orc_intra_p_frame reconstructs them afterwards. */
+#define ORC_DROP_MAX 12
+#define ORC_SKIP_MARGIN_BITS 4 /* the skip probe runs when SAD(ps_est) <= SAD(best whole-sample vector) + lambda * this */
+#define ORC_INTRA_GATE(lambda) (768u + 8u * (uint32_t)(lambda)) /* whole-sample search cost below which a P macroblock is never analysed for intra */
+enum { ORC_F_MVDCOST = 1, ORC_F_SKIPPROBE = 2, ORC_F_DECIMATE = 4, ORC_F_SATD = 8, ORC_F_INTRAP = 16, ORC_F_ALL = 31 };
+void orc_set_features(int mask); /* process-wide ablation switches for the rate-distortion tables (default ORC_F_ALL = what the device does) */
+int orc_get_features(void);
+uint32_t orc_drop_threshold(int drop);
+int orc_decimate_score(const int16_t *lev, int first);
+uint32_t orc_satd16(const uint8_t *src, int stride, const uint8_t *pred /* 16 x 16, stride 16 */);
+void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv, uint8_t *rec_y, uint8_t *rec_uv,
+                   int stride, int mbw, int mbh, int qp, int drop, int refine, const orc_imv_t *imv, const uint16_t *surf, const orc_idec_t *idec,
+                   orc_mbinfo_t *mbi, int16_t *levels, int threads);
+void orc_intra_p_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
+                       const orc_idec_t *idec, orc_mbinfo_t *mbi, int16_t *levels);
 
 void orc_set_transform8x8(int on); /* process-wide: High-profile stream, 8x8 transform for P macroblocks (default off) */
 int orc_get_transform8x8(void);
@@ -104,10 +130,19 @@ orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop
 void orc_enc_close(orc_enc_t *e);
 void orc_enc_set_subpel(orc_enc_t *e, int on);
 void orc_enc_set_scenecut(orc_enc_t *e, int on); /* default on */
+void orc_enc_set_me_iters(orc_enc_t *e, int n);  /* orc_me_select iterations after the first selection (default ORC_ME_ITERS) */
+#define ORC_ME_ITERS 3
 /* Encode one NV12 frame at a caller-chosen QP.  Returns 0, or <0 on error. */
 int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv,
                   int uv_stride, int qp, int force_idr, uint8_t *out, size_t out_cap,
                   size_t *out_len, int *is_idr);
+/* The same with rate control's ladder below QP 51: drop 0 .. ORC_DROP_MAX for P pictures, ORC_DROP_SKIP = the whole picture
+ * as one run of P_Skip macroblocks (the input planes are not read and may be NULL). */
+#define ORC_DROP_SKIP 255
+int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
+                   int qp, int drop, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len, int *is_idr);
+const orc_imv_t *orc_enc_imv(const orc_enc_t *e);
+const orc_idec_t *orc_enc_idec(const orc_enc_t *e);
 /* Views into the last encoded frame (coded size, stride = 16*mbw). */
 const uint8_t *orc_enc_recon_y(const orc_enc_t *e);
 const uint8_t *orc_enc_recon_uv(const orc_enc_t *e);

@@ -17,6 +17,12 @@ MBINFO_DTYPE = np.dtype(
      ("qp", "u1"), ("nzmask", "<u4"), ("cost", "<u4")]
 )
 assert MBINFO_DTYPE.itemsize == 16
+IDEC = np.dtype([("modes4", "u1", (16,)), ("mode16", "u1"), ("cmode", "u1"), ("use_i4", "u1"), ("pad", "u1"), ("cost", "<u4"), ("cost_luma", "<u4"), ("rsv", "<u4")])
+assert IDEC.itemsize == 32
+IMV_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("sad", "<u2"), ("bits", "<u2")])
+SURF = 33 * 33
+DROP_MAX, DROP_SKIP = 12, 255
+F_MVDCOST, F_SKIPPROBE, F_DECIMATE, F_SATD, F_INTRAP, F_ALL = 1, 2, 4, 8, 16, 31
 
 
 def build(force=False):
@@ -48,8 +54,29 @@ def lib():
             f.argtypes = [vp]
         L.orc_enc_mbw.argtypes = [vp]
         L.orc_enc_mbh.argtypes = [vp]
-        L.orc_me_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.orc_me_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
         L.orc_me_frame.restype = None
+        L.orc_me_select.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
+        L.orc_me_select.restype = None
+        L.orc_enc_set_me_iters.argtypes = [vp, C.c_int]
+        L.orc_enc_set_me_iters.restype = None
+        L.orc_enc_frame2.restype = C.c_int
+        L.orc_enc_frame2.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        for n in ("imv", "idec"):
+            f = getattr(L, "orc_enc_" + n)
+            f.restype = vp
+            f.argtypes = [vp]
+        L.orc_pmb_frame.argtypes = [vp] * 6 + [C.c_int] * 6 + [vp, vp, vp, vp, vp, C.c_int]
+        L.orc_pmb_frame.restype = None
+        L.orc_intra_p_frame.argtypes = [vp] * 4 + [C.c_int] * 4 + [vp, vp, vp]
+        L.orc_intra_p_frame.restype = None
+        L.orc_set_features.argtypes = [C.c_int]
+        L.orc_set_features.restype = None
+        L.orc_drop_threshold.restype = C.c_uint32
+        L.orc_drop_threshold.argtypes = [C.c_int]
+        L.orc_decimate_score.argtypes = [vp, C.c_int]
+        L.orc_satd16.restype = C.c_uint32
+        L.orc_satd16.argtypes = [vp, C.c_int, vp]
         L.orc_subpel_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
         L.orc_subpel_frame.restype = None
         L.orc_enc_set_subpel.argtypes = [vp, C.c_int]
@@ -126,27 +153,38 @@ def _view(ptr, shape, dtype):
 class Encoder:
     """Whole-encoder oracle: one NV12 frame + QP in, Annex-B access unit + stage outputs out."""
 
-    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True, scenecut=True):
+    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True, scenecut=True, me_iters=None):
         self.L = lib()
         self.h = self.L.orc_enc_open(width, height, fps, 1, gop, me_range, threads)
         if not self.h:
             raise ValueError("orc_enc_open failed")
         self.L.orc_enc_set_subpel(self.h, int(subpel))
         self.L.orc_enc_set_scenecut(self.h, int(scenecut))
+        if me_iters is not None:
+            self.L.orc_enc_set_me_iters(self.h, int(me_iters))
         self.width, self.height = width, height
         self.mbw, self.mbh = self.L.orc_enc_mbw(self.h), self.L.orc_enc_mbh(self.h)
         self._out = np.empty(self.mbw * self.mbh * 1024 + 4096, np.uint8)
 
-    def encode(self, y, uv, qp, force_idr=False):
+    def encode(self, y, uv, qp, force_idr=False, drop=0):
+        """drop: rate control's ladder below QP 51 for P pictures (0 .. DROP_MAX), DROP_SKIP = an all-skip picture."""
         y = np.ascontiguousarray(y, np.uint8)
         uv = np.ascontiguousarray(uv, np.uint8)
         assert y.shape == (self.height, self.width) and uv.shape == (self.height // 2, self.width)
         n, idr = C.c_size_t(0), C.c_int(0)
-        r = self.L.orc_enc_frame(self.h, _ptr(y), self.width, _ptr(uv), self.width, qp, int(force_idr),
-                                 _ptr(self._out), self._out.size, C.byref(n), C.byref(idr))
+        r = self.L.orc_enc_frame2(self.h, _ptr(y), self.width, _ptr(uv), self.width, qp, int(drop), int(force_idr),
+                                  _ptr(self._out), self._out.size, C.byref(n), C.byref(idr))
         if r:
-            raise RuntimeError("orc_enc_frame -> %d" % r)
+            raise RuntimeError("orc_enc_frame2 -> %d" % r)
         return bytes(self._out[: n.value]), bool(idr.value)
+
+    @property
+    def imv(self):
+        return _view(self.L.orc_enc_imv(self.h), (self.mbh * self.mbw,), IMV_DTYPE).copy()
+
+    @property
+    def idec(self):
+        return _view(self.L.orc_enc_idec(self.h), (self.mbh * self.mbw,), IDEC).copy()
 
     def _plane(self, fn, rows):
         return _view(fn(self.h), (rows, self.mbw * 16), np.uint8).copy()
@@ -232,12 +270,78 @@ def cavlc_block(coef, maxnum, nC):
 
 
 def me_frame(cur_y, ref_y, rng, qp, threads=1):
+    """Whole-sample search: (SAD surfaces (n_mb, SURF) uint16, first selection IMV_DTYPE (n_mb,))."""
     L = lib()
     H, W = cur_y.shape
-    mbi = np.zeros((H // 16) * (W // 16), MBINFO_DTYPE)
-    L.orc_me_frame(_ptr(np.ascontiguousarray(cur_y)), _ptr(np.ascontiguousarray(ref_y)), W, W // 16, H // 16, rng, qp,
-                   _ptr(mbi), threads)
-    return mbi
+    n = (H // 16) * (W // 16)
+    imv, surf = np.zeros(n, IMV_DTYPE), np.zeros((n, SURF), np.uint16)
+    L.orc_me_frame(_ptr(np.ascontiguousarray(cur_y)), _ptr(np.ascontiguousarray(ref_y)), W, W // 16, H // 16, rng, qp, _ptr(surf), _ptr(imv), threads)
+    return surf, imv
+
+
+def me_select(surf, imv, mbw, mbh, rng, qp, threads=1):
+    """One Jacobi iteration of the selection (bits against the median of the neighbours' vectors in imv)."""
+    out = np.zeros(imv.size, IMV_DTYPE)
+    lib().orc_me_select(_ptr(np.ascontiguousarray(surf)), mbw, mbh, rng, qp, _ptr(np.ascontiguousarray(imv)), _ptr(out), threads)
+    return out
+
+
+def se_bits(v):
+    v = np.asarray(v, np.int64)
+    k = np.where(v > 0, 2 * v - 1, -2 * v) + 1
+    return 2 * np.floor(np.log2(k)).astype(np.int64) + 1
+
+
+def imv_to_mbinfo(imv, qp):
+    """Records for the two-stage (8x8-transform) path: vector + the absolute-vector cost its refinement compares."""
+    m = np.zeros(imv.size, MBINFO_DTYPE)
+    m["mvx"], m["mvy"] = imv["mvx"], imv["mvy"]
+    m["cost"] = imv["sad"].astype(np.int64) + lib().orc_me_lambda(qp) * (se_bits(imv["mvx"]) + se_bits(imv["mvy"]))
+    return m
+
+
+def surf_to_device(surf):
+    """(n_mb, 1089) oracle surfaces -> the device layout (n_mb, 35, 36); cells outside the 33 x 33 range are zero."""
+    out = np.zeros((surf.shape[0], 35, 36), np.uint16)
+    out[:, :33, :33] = surf.reshape(-1, 33, 33)
+    return out
+
+
+def pmb_frame(src_y, src_uv, ref_y, ref_uv, imv, surf, qp, drop=0, refine=True, idec=None, threads=1):
+    """The fused P-macroblock stage (then the intra macroblocks it decided, if idec is given): rec_y, rec_uv, records, levels."""
+    L = lib()
+    H, W = src_y.shape
+    src_y, src_uv, ref_y, ref_uv = (np.ascontiguousarray(a) for a in (src_y, src_uv, ref_y, ref_uv))
+    rec_y, rec_uv = np.zeros_like(src_y), np.zeros_like(src_uv)
+    mbi = np.zeros(imv.size, MBINFO_DTYPE)
+    lev = np.zeros((imv.size, LEVELS_PER_MB), np.int16)
+    imv = np.ascontiguousarray(imv)
+    dec = np.ascontiguousarray(idec) if idec is not None else None
+    L.orc_pmb_frame(_ptr(src_y), _ptr(src_uv), _ptr(ref_y), _ptr(ref_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16, H // 16, qp, drop, int(refine),
+                    _ptr(imv), _ptr(np.ascontiguousarray(surf)), _ptr(dec) if dec is not None else None, _ptr(mbi), _ptr(lev), threads)
+    pre = (mbi.copy(), rec_y.copy(), rec_uv.copy())
+    if dec is not None:
+        L.orc_intra_p_frame(_ptr(src_y), _ptr(src_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16, H // 16, qp, _ptr(dec), _ptr(mbi), _ptr(lev))
+    return rec_y, rec_uv, mbi, lev, pre
+
+
+def set_features(mask):
+    """Process-wide ablation switches of the P-macroblock stage (default F_ALL)."""
+    lib().orc_set_features(int(mask))
+
+
+def drop_threshold(drop):
+    return lib().orc_drop_threshold(int(drop))
+
+
+def decimate_score(lev16, first=0):
+    a = np.ascontiguousarray(lev16, np.int16)
+    return lib().orc_decimate_score(_ptr(a), first)
+
+
+def satd16(src16, pred16):
+    a, b = np.ascontiguousarray(src16, np.uint8), np.ascontiguousarray(pred16, np.uint8)
+    return lib().orc_satd16(_ptr(a), 16, _ptr(b))
 
 
 def subpel_frame(cur_y, ref_y, mbi, qp, threads=1):
@@ -268,7 +372,7 @@ def intra_analyse(src_y, src_uv):
     return out
 
 
-IDEC = np.dtype([("modes4", "u1", (16,)), ("mode16", "u1"), ("cmode", "u1"), ("use_i4", "u1"), ("pad", "u1"), ("cost", "<u4")])
+
 
 
 def intra_decide(isad, mbw, mbh, qp, i4x4=True):
