@@ -161,7 +161,6 @@ def main():
     ap.add_argument("--sample", type=int, default=7, help="stage timers (HIP events) on every k-th picture; each event record costs ~5 us of queue time")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent streams encoded concurrently on each GPU (one host thread each); the headline configuration is 1")
     ap.add_argument("--cavlc-threads", type=int, default=0, help="host threads coding one slice row-parallel (bit-identical output); 0 = the encoder's default (automatic, at most 8)")
-    ap.add_argument("--overlap", type=int, default=0, help="band-pipelined schedule for P pictures: 0 off, 1 default piece count (4), N >= 2 pieces")
     ap.add_argument("--rate-script", default="auto", help="bitrate setpoints written to the encoder while it runs: 'none', or a balancer of the reference "
                     "(adaptive|aimd|fixed: tests/golden/balancer_<name>.txt, generated from the reference's own balancer code); auto = adaptive for 1080p_ippp "
                     "(BASELINE.json configs[2]: 'balancer driving the bitrate property'), none elsewhere")
@@ -213,7 +212,7 @@ def main():
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                          pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                         transform8x8=bool(args.dct8x8), overlap=args.overlap, cavlc_threads=args.cavlc_threads)
+                         transform8x8=bool(args.dct8x8), cavlc_threads=args.cavlc_threads)
 
     encs = [make_encoder() for _ in range(S)]
     e = encs[0]

@@ -37,23 +37,30 @@ int h264_cavlc_block_bits(const int16_t *coef, int maxnum, int nC, uint8_t *out,
  * blocks + first block of every macroblock row.  `packed` must hold mbw*mbh*PACK_BLOCKS_MAX*16 int16.  Returns the block count. */
 size_t h264_pack_levels(int mbw, int mbh, const mb_info_t *mbi, const int16_t *levels, int16_t *packed, uint32_t *row_off);
 
-/* ---- rate control (ratecontrol.c): one QP per picture from a bits/s setpoint ---- */
+/* ---- rate control (ratecontrol.c): one QP (+ below QP 51 a drop level) per picture from a bits/s setpoint ---- */
 typedef struct {
     double fps;
-    int gop, qp_min, qp_max;
+    int gop, qp_min, qp_max, vbv_ms;
     double target_bps;
-    double cplx_i, cplx_p;     /* bits * qstep of recent I / P pictures          */
-    double fullness;           /* virtual buffer: produced - budgeted bits        */
-    int last_qp_i, last_qp_p;
-    int frames_in_gop;
+    double cplx_i, cplx_p;     /* bits * qstep(virtual QP) of recent I / P pictures */
+    double gop_bits;           /* what the current GOP may still spend (planned sizes of pictures in flight already taken off) */
+    int gop_left, started;     /* pictures of the current GOP still to be picked    */
+    double vbv;                /* leaky bucket at the setpoint's rate, bits         */
+    double last_bits_p, last_target_p; /* the last P picture whose size is known: what it took, what it was given */
+    double cliff_bits; int cliff_vqp, cliff_age; /* the quantiser at which a P picture last cost several times its target, what it cost, pictures left to remember it */
+    int last_vqp_i, last_vqp_p;
     int have_i, have_p;
+    double plan[4];            /* planned bits of the pictures picked but not yet updated (pipeline depth <= 1) */
+    unsigned n_pick, n_upd;
 } rc_state_t;
 void rc_init(rc_state_t *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max);
+void rc_set_vbv(rc_state_t *rc, int vbv_ms);
 void rc_set_bitrate(rc_state_t *rc, uint32_t bps);
 int rc_pick_qp(rc_state_t *rc, int is_idr);
-/* QP and, once QP 51 is not enough, the drop level of the ladder below it (P pictures: 0 .. DROP_MAX, DROP_SKIP = all-skip picture) */
+/* QP and, once qp_max is not enough, the drop level of the ladder below it (P pictures: 0 .. DROP_MAX, DROP_SKIP = all-skip picture).
+ * Every rc_pick() is followed (possibly one picture later) by one rc_update() for the same picture, in the same order. */
 void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop);
-void rc_update(rc_state_t *rc, int is_idr, int qp, size_t bytes);
+void rc_update(rc_state_t *rc, int is_idr, int qp, int drop, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
             sh_sad[wave][4] = (uint16_t)t0; sh_sad[wave][5] = (uint16_t)v1; sh_sad[wave][6] = (uint16_t)v2; sh_sad[wave][7] = (uint16_t)v3;
         }
     }
-    // ---- Intra_4x4: four blocks at a time, 16 lanes (pixels) each
-    {
+    // ---- Intra_4x4: four blocks at a time, 16 lanes (pixels) each (I pictures only: intra macroblocks of P pictures are Intra_16x16)
+    if (!gate_p) {
         const int px = lane & 3, py = (lane >> 2) & 3;
 #pragma unroll 1
         for (int rnd = 0; rnd < 4; rnd++) {
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
         }
         bool use_i4 = false;
         unsigned cost_luma = cost16;
-        if (ctx->i4x4) { // Intra_4x4 modes block by block: SAD + lambda * (mode == expected ? 1 : 4); blocks visited along bx + 2*by
+        if (ctx->i4x4 && !gate_p) { // Intra_4x4 modes block by block: SAD + lambda * (mode == expected ? 1 : 4); blocks visited along bx + 2*by
             unsigned cost4 = 0;
             const int half = (lane >> 4) & 1, cand = lane & 15;
             int (*m4)[16] = &sh_m4[wave];
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int bb = lane * 4 + i, r = (blky(bb) >> 2) * 4 + (blkx(bb) >> 2);
-                    w |= (ctx->i4x4 ? (unsigned)sh_m4[wave][r] & 0xFF : 0u) << (8 * i);
+                    w |= ((ctx->i4x4 && !gate_p) ? (unsigned)sh_m4[wave][r] & 0xFF : 0u) << (8 * i);
                 }
             } else if (lane == 4) w = (unsigned)mode16 | ((unsigned)cmode << 8) | ((use_i4 ? 1u : 0u) << 16);
             else if (lane == 5) w = cost_luma + costc;
@@ -473,7 +473,14 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         hv = mad24(hv, s1, quad_xor<2>(hv));
         hv = mad24(hv, s2, __shfl_xor(hv, 16, 64));
         hv = mad24(hv, s3, __shfl_xor(hv, 32, 64));
-        const int ldc = quant1((hv + 1) >> 1, q.mf[0], 2 * q.f, q.qbits + 1);
+        int ldc = quant1((hv + 1) >> 1, q.mf[0], 2 * q.f, q.qbits + 1);
+        const bool dcl = py == 0; // this lane holds a DC term
+#pragma unroll
+        for (int i = 0; i < 4; i++) lev[i] = (i == 0 && dcl) ? 0 : quant1(cf[i], (i & 1) ? mfo : mfe, q.f, q.qbits);
+        if (ctx->iac_drop) { // rate control's ladder for I pictures: luma levels (DC and AC) summing to no more than the threshold are not sent
+            const int sm = wave64_sum((dcl ? iabs(ldc) : 0) + iabs(lev[0]) + iabs(lev[1]) + iabs(lev[2]) + iabs(lev[3]));
+            if (sm <= ctx->iac_drop) { ldc = 0; lev[0] = lev[1] = lev[2] = lev[3] = 0; }
+        }
         int f = ldc;
         f = mad24(f, s0, quad_xor<1>(f));
         f = mad24(f, s1, quad_xor<2>(f));
@@ -481,12 +488,8 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         f = mad24(f, s3, __shfl_xor(f, 32, 64));
         const int ls = 16 * q.v[0];
         const int dcv2 = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
-        const bool dcl = py == 0; // this lane holds a DC term
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            lev[i] = (i == 0 && dcl) ? 0 : quant1(cf[i], (i & 1) ? mfo : mfe, q.f, q.qbits);
-            x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
-        }
+        for (int i = 0; i < 4; i++) x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
         if (dcl) x[0] = dcv2;
         const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1);
         int16_t *lv = ctx->levels + (size_t)mbn * MB_LEVELS;
@@ -542,7 +545,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
 #pragma unroll
             for (int i = 0; i < 4; i++) pd[i] = clip255((pa + pb * (bx + i - 3) + pc * (yy - 3) + 16) >> 5);
         }
-        chroma_rows4(ctx, T, ctx->levels + (size_t)mbn * MB_LEVELS, cx0, cy0, lane, pd, csv, qp, true, true, OUT ? L->crec : nullptr, cnz8, cdc2);
+        chroma_rows4(ctx, T, ctx->levels + (size_t)mbn * MB_LEVELS, cx0, cy0, lane, pd, csv, qp, true, true, OUT ? L->crec : nullptr, cnz8, cdc2, false, ctx->iac_drop);
     }
 #undef TOP
 #undef LEFT
@@ -749,75 +752,125 @@ void k_launch_intra_analyse(const frame_ctx_t *h_ctx, int mbw, int mbh, int gate
 
 // =================================================================== intra macroblocks of P pictures
 // pmb_kernel has reconstructed every inter macroblock and left type + modes in the records of the ones it decided to code
-// intra; those predict from their neighbours' reconstructed samples (8.3; constrained_intra_pred_flag = 0), so an intra
-// macroblock waits for the intra ones among its left, top and top-left neighbours (the analysis never picks a mode that
-// reads the macroblock above-right).  A fixed number of resident workgroups each walk their share of the macroblocks in
-// raster order -- workgroup w takes w, w + G, w + 2G, ... -- and skip the inter ones at once.  No dispatch order is assumed:
-// the smallest unfinished macroblock always belongs to a workgroup that has finished everything before it, and its
-// dependencies are smaller still, so somebody can always proceed (every spin is bounded anyway and reports through `err`).
-// Hand-off between workgroups: producer -- all stores, every wave's vmcnt(0), workgroup barrier, agent-scope release, stamp
-// store (sc1); consumer -- one sc1 poll per needed neighbour, agent-scope acquire, workgroup barrier, plain loads
-// (MI355X_MICROARCH.md, "Valid forms").  Oracle: orc_intra_p_frame.
-#define IP_WGS 512
-__global__ __launch_bounds__(128) void intra_p_kernel(const frame_ctx_t cv, unsigned *__restrict__ err) {
-    const frame_ctx_t *__restrict__ ctx = &cv;
+// intra (Intra_16x16 only); those predict from their neighbours' reconstructed samples (8.3; constrained_intra_pred_flag = 0).
+// One workgroup (luma wave + chroma wave, as everywhere in this file) per macroblock ROW walks the row's intra
+// macroblocks from left to right:
+//  * the left neighbour, when it is intra itself, was this workgroup's previous macroblock: its right column is still in LDS;
+//  * the row above publishes, per macroblock it finishes, a 32-byte strip (bottom luma line, bottom chroma line) with `sc1`
+//    stores and then a progress word = "every macroblock left of this column is final" (epoch in the upper bits, so nothing is
+//    ever cleared); a macroblock whose top or top-left neighbour is intra polls that word and reads the strips with `sc1`
+//    loads (MI355X_MICROARCH.md, "Valid forms": sc1 stores, vmcnt(0), barrier, sc1 flag / sc1 poll, sc1 loads);
+//  * every other neighbour sample comes from the picture: inter macroblocks were final before this launch.
+// Rows only ever wait for the row above, so the wait graph is acyclic whatever the dispatch order (every spin is bounded and
+// reports through `err`).  A row without intra macroblocks publishes "done" and leaves.  Oracle: orc_intra_p_frame.
+struct ip_args { frame_ctx_t ctx; unsigned *progress; uint8_t *strips; unsigned *err; };
+#define IP_EPOCH(e) (((e) & 0xFFFFFu) << 12)
+__global__ __launch_bounds__(128) void intra_p_kernel(ip_args a) {
+    const frame_ctx_t *__restrict__ ctx = &a.ctx;
     __shared__ intra_lds LD;
     __shared__ unsigned tabw[TAB_DWORDS];
+    __shared__ unsigned ibits[16]; // which macroblocks of this row are intra (mbw <= 512)
+    __shared__ int sh_bad;
     const dev_tables *T = (const dev_tables *)tabw;
-    const int mbw = ctx->mbw, nmb = mbw * ctx->mbh, stride = ctx->stride;
+    const int mbw = ctx->mbw, stride = ctx->stride, my = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint8_t *__restrict__ ry = ctx->rec_y;
     const uint8_t *__restrict__ ruv = ctx->rec_uv;
+    const unsigned ep = IP_EPOCH(ctx->epoch);
+    if (threadIdx.x < 16) ibits[threadIdx.x] = 0;
+    if (threadIdx.x == 0) sh_bad = 0;
+    __syncthreads();
+    for (int x = threadIdx.x; x < ((mbw + 63) & ~63); x += 128) {
+        const bool in = x < mbw && (ldg32(&ctx->mbi[my * mbw + x].mb_type) & 255u) != 1u;
+        const unsigned long long b = __ballot(in);
+        if (lane == 0) { ibits[(x >> 5)] = (unsigned)b; ibits[(x >> 5) + 1] = (unsigned)(b >> 32); }
+    }
     for (int i = threadIdx.x; i < TAB_DWORDS; i += 128) tabw[i] = ((const unsigned *)&g_tab)[i];
-    for (int mbn = blockIdx.x; mbn < nmb; mbn += gridDim.x) {
-        const uint4 rec = ldg128(&ctx->mbi[mbn]);
-        if (((rec.y) & 255u) == 1u) continue; // inter: reconstructed by pmb_kernel (workgroup-uniform)
-        const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
-        const bool has_top = my > 0, has_left = mx > 0;
-        __syncthreads(); // the previous macroblock of this workgroup is done with LD
-        if (threadIdx.x == 0) {
-            LD.cseq = 0;
-            int waited = 0;
-            const int nb[3] = {has_left ? mbn - 1 : -1, has_top ? mbn - mbw : -1, (has_left && has_top) ? mbn - mbw - 1 : -1};
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (nb[k] < 0) continue;
-                if ((ldg32(&ctx->mbi[nb[k]].mb_type) & 255u) == 1u) continue; // inter neighbour: final since the previous launch
-                int spins = 0;
-                while (ld_sc1(&ctx->idone[nb[k]]) != ctx->epoch) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(err))) { st_sc1(err, 2u); break; }
+    __syncthreads();
+    int prev_x = -2; // the macroblock this workgroup reconstructed last (its right column is in LD)
+    for (int w = 0; w < (mbw + 31) / 32; w++) {
+        unsigned bits = ibits[w];
+        while (bits) {
+            const int mx = 32 * w + __builtin_ctz(bits);
+            bits &= bits - 1;
+            const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
+            const bool has_top = my > 0, has_left = mx > 0;
+            const bool b_intra = has_top && (ldg32(&ctx->mbi[mbn - mbw].mb_type) & 255u) != 1u;
+            const bool d_intra = has_top && has_left && (ldg32(&ctx->mbi[mbn - mbw - 1].mb_type) & 255u) != 1u;
+            const bool a_intra = has_left && prev_x == mx - 1;
+            __syncthreads(); // the previous macroblock is done with LD.top / LD.left (its right column and bottom lines stay)
+            if (threadIdx.x == 0) {
+                LD.cseq = 0;
+                if (b_intra || d_intra) { // the row above must have passed column mx
+                    int spins = 0;
+                    for (;;) {
+                        const unsigned v = ld_sc1(&a.progress[my - 1]);
+                        if ((v & ~0xFFFu) == ep && (int)(v & 0xFFFu) > mx) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 2u); sh_bad = 1; break; }
+                    }
                 }
-                waited = 1;
             }
-            if (waited) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        }
-        __syncthreads();
-        const uint4 dec0 = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES);
-        const uint2 dec1 = ldg64(ctx->idec + (size_t)mbn * IDEC_BYTES + 16);
-        if (wave == 0 && lane >= 24 && lane < 24 + 17) { // luma neighbours; index i+1 holds sample i, index 0 the corner
-            int i = lane - 24 - 1;
-            LD.top[0][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ry + (size_t)(y0 - 1) * stride + x0 + i) : 0;
-            LD.left[0][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ry + (size_t)(y0 + i) * stride + x0 - 1) : 0;
-        } else if (wave == 1 && lane >= 41 && lane < 41 + 18) { // chroma neighbours
-            int c = (lane - 41) / 9, i = (lane - 41) % 9 - 1;
-            LD.top[1 + c][i + 1] = has_top && (i >= 0 || has_left) ? (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c) : 0;
-            LD.left[1 + c][i + 1] = has_left && (i >= 0 || has_top) ? (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c) : 0;
-        }
-        __syncthreads();
-        intra_compute<false>(ctx, T, &LD, mx, my, wave, lane, dec0, dec1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (sh_bad) return; // uniform: the error word is set, the host reports it
+            const uint4 dec0 = make_uint4(0, 0, 0, 0);
+            const uint2 dec1 = ldg64(ctx->idec + (size_t)mbn * IDEC_BYTES + 16);
+            // neighbour samples into LD.top / LD.left ([plane][i + 1] = sample i, [0] = corner)
+            if (wave == 0 && lane < 17) { // luma top line + corner
+                const int i = lane - 1;
+                int v = 0;
+                if (has_top && (i >= 0 || has_left)) {
+                    const bool from_strip = i >= 0 ? b_intra : d_intra;
+                    if (from_strip) v = (int)(ld_sc1((const unsigned *)(a.strips + (size_t)(mbn - mbw + (i >= 0 ? 0 : -1)) * 32) + ((i >= 0 ? i : 15) >> 2)) >> (8 * ((i >= 0 ? i : 15) & 3))) & 255;
+                    else v = (int)ldg8(ry + (size_t)(y0 - 1) * stride + x0 + i);
+                }
+                LD.top[0][i + 1] = v;
+            } else if (wave == 0 && lane >= 32 && lane < 48) { // luma left column
+                const int i = lane - 32;
+                LD.left[0][i + 1] = !has_left ? 0 : a_intra ? (int)LD.right_y[i] : (int)ldg8(ry + (size_t)(y0 + i) * stride + x0 - 1);
+            } else if (wave == 1 && lane < 18) { // chroma top lines + corners
+                const int c = lane / 9, i = lane % 9 - 1;
+                int v = 0;
+                if (has_top && (i >= 0 || has_left)) {
+                    const bool from_strip = i >= 0 ? b_intra : d_intra;
+                    const int k = 2 * (i >= 0 ? i : 7) + c; // byte of the interleaved 16-byte bottom chroma line
+                    if (from_strip) v = (int)(ld_sc1((const unsigned *)(a.strips + (size_t)(mbn - mbw + (i >= 0 ? 0 : -1)) * 32 + 16) + (k >> 2)) >> (8 * (k & 3))) & 255;
+                    else v = (int)ldg8(ruv + (size_t)(cy0 - 1) * stride + 2 * (cx0 + i) + c);
+                }
+                LD.top[1 + c][i + 1] = v;
+            } else if (wave == 1 && lane >= 32 && lane < 48) { // chroma left columns
+                const int c = (lane - 32) >> 3, i = (lane - 32) & 7;
+                LD.left[1 + c][i + 1] = !has_left ? 0 : a_intra ? (int)LD.right_c[c][i] : (int)ldg8(ruv + (size_t)(cy0 + i) * stride + 2 * (cx0 - 1) + c);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) { LD.left[0][0] = LD.top[0][0]; LD.left[1][0] = LD.top[1][0]; LD.left[2][0] = LD.top[2][0]; }
+            __syncthreads();
+            intra_compute<true>(ctx, T, &LD, mx, my, wave, lane, dec0, dec1);
+            __syncthreads(); // bot_y / bot_c / right_* of this macroblock are in LD
+            // publish the bottom lines for the row below: 32 bytes, sc1
+            if (threadIdx.x < 8) {
+                const int slot = mx & 3;
+                const unsigned v = threadIdx.x < 4 ? *(const unsigned *)&LD.bot_y[slot][4 * threadIdx.x] : *(const unsigned *)&LD.bot_c[slot][4 * (threadIdx.x - 4)];
+                st_sc1((unsigned *)(a.strips + (size_t)mbn * 32) + threadIdx.x, v);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            st_sc1(&ctx->idone[mbn], ctx->epoch);
+            __syncthreads();
+            if (threadIdx.x == 0) { // everything left of the next intra macroblock of this row (or the whole row) is final now
+                unsigned rest = bits;
+                int nx = rest ? 32 * w + __builtin_ctz(rest) : -1;
+                for (int w2 = w + 1; nx < 0 && w2 < (mbw + 31) / 32; w2++) if (ibits[w2]) nx = 32 * w2 + __builtin_ctz(ibits[w2]);
+                st_sc1(&a.progress[my], ep | (unsigned)(nx < 0 ? mbw : nx));
+            }
+            prev_x = mx;
         }
     }
+    if (prev_x == -2 && threadIdx.x == 0) st_sc1(&a.progress[my], ep | (unsigned)mbw); // no intra macroblock in this row
 }
-void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_err, hipStream_t s) {
-    const int n = mbw * mbh;
-    hipLaunchKernelGGL(intra_p_kernel, dim3(n < IP_WGS ? n : IP_WGS), dim3(128), 0, s, *h_ctx, d_err);
+void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_progress, uint8_t *d_strips, unsigned *d_err, hipStream_t s) {
+    (void)mbw;
+    ip_args a;
+    a.ctx = *h_ctx; a.progress = d_progress; a.strips = d_strips; a.err = d_err;
+    hipLaunchKernelGGL(intra_p_kernel, dim3(mbh), dim3(128), 0, s, a);
 }
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s) {
     int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;

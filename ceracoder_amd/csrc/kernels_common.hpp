@@ -342,7 +342,7 @@ DEV int dec_score_mask(unsigned M) { // decimate score of a +-1-only block from 
     return (int)(3 * c0 + 2 * (unsigned)__popc(a1) - (unsigned)__popc(a3) - (unsigned)__popc(a6));
 }
 DEV void chroma_rows4(const frame_ctx_t *ctx, const dev_tables *T, int16_t *lv, int cx0, int cy0, int lane, const int *pd, const int *sv, int qp,
-                      bool intra, bool ok, uint8_t *lrec, unsigned &nz8, unsigned &dc2, bool decimate = false) {
+                      bool intra, bool ok, uint8_t *lrec, unsigned &nz8, unsigned &dc2, bool decimate = false, int all_drop = 0) {
     const bool cl = lane < 32;
     const int py = (lane >> 2) & 3, fy = ((py & 1) << 1) | (py >> 1);
     const int cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1, cy = cby * 4 + py, cxb = cbx * 4;
@@ -361,10 +361,7 @@ DEV void chroma_rows4(const frame_ctx_t *ctx, const dev_tables *T, int16_t *lv, 
     const int sbx = cbx ? -1 : 1, sby = cby ? -1 : 1;
     int hd = mad24(cf[0], sbx, quad_xor<1>(cf[0]));
     hd = mad24(hd, sby, __shfl_xor(hd, 16, 64));
-    const int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
-    int g = mad24(ldc, sbx, quad_xor<1>(ldc));
-    g = mad24(g, sby, __shfl_xor(g, 16, 64));
-    const int dcc = ((g * 16 * q.v[0]) << q.shift) >> 5;
+    int ldc = quant1(hd, q.mf[0], 2 * q.f, q.qbits + 1);
     const bool dcl = py == 0; // this lane holds a DC term
     unsigned sig = 0, big = 0;
 #pragma unroll
@@ -382,6 +379,13 @@ DEV void chroma_rows4(const frame_ctx_t *ctx, const dev_tables *T, int16_t *lv, 
         s += __shfl_xor(s, 16, 64);     // ... and two block rows
         if (s < 7) { lev[0] = lev[1] = lev[2] = lev[3] = 0; }
     }
+    if (all_drop) { // rate control's ladder for I pictures: chroma levels (both planes, DC and AC) summing to no more than the threshold are not sent
+        const int sm = wave64_sum(cl ? (dcl ? iabs(ldc) : 0) + iabs(lev[0]) + iabs(lev[1]) + iabs(lev[2]) + iabs(lev[3]) : 0);
+        if (sm <= all_drop) { ldc = 0; lev[0] = lev[1] = lev[2] = lev[3] = 0; }
+    }
+    int g = mad24(ldc, sbx, quad_xor<1>(ldc));
+    g = mad24(g, sby, __shfl_xor(g, 16, 64));
+    const int dcc = ((g * 16 * q.v[0]) << q.shift) >> 5;
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = (lev[i] * ((i & 1) ? vo : ve)) << q.shift;
     if (dcl) x[0] = dcc;

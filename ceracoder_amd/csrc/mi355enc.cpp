@@ -76,7 +76,8 @@ struct mi355enc {
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
     uint16_t *d_surf;     // SAD surfaces of the motion search, SURF_U16 per macroblock
     imv_t *d_imv[2];      // whole-sample vector fields (search result / selection iterations alternate)
-    uint32_t *d_idone;    // intra macroblocks of P pictures: "reconstructed" stamps
+    unsigned *d_ip_progress; // intra macroblocks of P pictures: one progress word per macroblock row (epoch-tagged, never cleared)
+    uint8_t *d_ip_strips;    // ... and the bottom lines they publish for the row below, 32 bytes per macroblock
     uint32_t epoch;
     int n_progress;
     slot_t slot[NSLOT];
@@ -90,6 +91,7 @@ struct mi355enc {
     std::atomic<int> fixed_qp, fixed_drop;
     mi355enc_stats_t st;
     double ms_open;
+    uint64_t n_skip_pictures;
 };
 
 static double now_ms() {
@@ -118,7 +120,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1;
 }
 
 static unsigned *prog_set(const mi355enc_t *h, int set) { return h->d_progress + (size_t)set * h->n_progress; }
@@ -203,7 +205,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf = nullptr; h->d_imv[0] = h->d_imv[1] = nullptr; h->d_idone = nullptr; h->epoch = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf = nullptr; h->d_imv[0] = h->d_imv[1] = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -241,8 +243,9 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
     HIPCHK(hipMalloc((void **)&h->d_surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t)));
     for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_imv[i], (size_t)h->nmb * sizeof(imv_t)));
-    HIPCHK(hipMalloc((void **)&h->d_idone, (size_t)h->nmb * sizeof(uint32_t)));
-    HIPCHK(hipMemsetAsync(h->d_idone, 0, (size_t)h->nmb * sizeof(uint32_t), h->stream)); // stamps: the epoch starts at 1
+    HIPCHK(hipMalloc((void **)&h->d_ip_progress, (size_t)h->mbh * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(h->d_ip_progress, 0, (size_t)h->mbh * sizeof(unsigned), h->stream)); // epoch-tagged: the epoch starts at 1
+    HIPCHK(hipMalloc((void **)&h->d_ip_strips, (size_t)h->nmb * 32));
     HIPCHK(hipMalloc((void **)&h->d_iprogress, (size_t)k_intra_bands(h->mbh) * sizeof(unsigned)));
     if (cfg->keep_prefilter) {
         HIPCHK(hipMalloc((void **)&h->d_pre_y, h->ysz));
@@ -271,8 +274,9 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     }
     if (h->cfg.cavlc_threads > 1 && h264_writer_set_threads(h->writer, h->cfg.cavlc_threads)) return MI355ENC_ERR_NOMEM;
     rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);
+    if (h->cfg.vbv_ms > 0) rc_set_vbv(&h->rc, h->cfg.vbv_ms);
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->ms_open = now_ms() - t_open;
+    h->ms_open = now_ms() - t_open; h->n_skip_pictures = 0;
     return MI355ENC_OK;
 }
 
@@ -304,7 +308,8 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_off) (void)hipFree(h->d_off);
     if (h->d_surf) (void)hipFree(h->d_surf);
     for (int i = 0; i < 2; i++) if (h->d_imv[i]) (void)hipFree(h->d_imv[i]);
-    if (h->d_idone) (void)hipFree(h->d_idone);
+    if (h->d_ip_progress) (void)hipFree(h->d_ip_progress);
+    if (h->d_ip_strips) (void)hipFree(h->d_ip_strips);
     if (h->d_iprogress) (void)hipFree(h->d_iprogress);
     for (int i = 0; i < 2; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
     for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
@@ -343,15 +348,19 @@ static hipStream_t upload_stream(const mi355enc_t *h) { return h->stream; }
 
 // rate control's ladder below QP 51 (oracle: k_drop_sad): the SAD under which a P macroblock carries no residual / takes the skip vector
 static const uint32_t k_drop_sad[DROP_MAX + 1] = {0, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 0xFFFFFFFFu};
+// ... and its counterpart for I pictures (oracle: k_idrop_ac): the sum of level magnitudes up to which a macroblock's luma / chroma residual is not sent
+static const int32_t k_idrop_ac[DROP_MAX + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64, 0x7FFFFFFF};
 
 static void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr) {
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec;
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
-    c->surf = h->d_surf; c->imv_a = h->d_imv[0]; c->imv_b = h->d_imv[1]; c->idone = h->d_idone;
+    c->surf = h->d_surf; c->imv_a = h->d_imv[0]; c->imv_b = h->d_imv[1];
     if (++h->epoch == 0) h->epoch = 1;
     c->epoch = h->epoch;
-    c->drop_sad = (drop > 0 && drop <= DROP_MAX) ? k_drop_sad[drop] : 0;
+    c->drop_sad = (!idr && drop > 0 && drop <= DROP_MAX) ? k_drop_sad[drop] : 0;
+    c->iac_drop = (idr && drop > 0 && drop <= DROP_MAX) ? k_idrop_ac[drop] : 0;
+    if (c->iac_drop) c->i4x4 = 0; // on the ladder: Intra_16x16 only
     c->intra_p = (h->cfg.intra_in_p && !h->cfg.transform8x8) ? 1 : 0;
 }
 // the device steps of a P picture up to (not including) deblocking; hc: host copy of the context (every kernel takes it by value)
@@ -368,7 +377,7 @@ static int run_p_picture(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int pr
         if (hc->intra_p) k_launch_intra_analyse(hc, h->mbw, h->mbh, 1, h->stream);
         k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
-        if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, err_word(h), h->stream);
+        if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
     }
     if (prof) HIPCHK(hipEventRecord(s->ev[11], h->stream));
     HIPCHK(hipGetLastError());
@@ -388,7 +397,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     int qp, drop;
     if (fq >= 0) { qp = fq; drop = h->fixed_drop.load(std::memory_order_relaxed); }
     else rc_pick(&h->rc, idr, &qp, &drop);
-    if (idr) drop = 0;
+    if (idr && drop == DROP_SKIP) drop = 0; // an IDR picture is never skipped; it has a ladder of its own
     const int all_skip = !idr && drop == DROP_SKIP;
     const int nxt = all_skip ? h->cur : (h->cur ^ 1); // an all-skip picture IS its reference: nothing is written
     const int set = (int)(h->n_submitted & 1), ci = set;
@@ -551,7 +560,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     if (is_keyframe) *is_keyframe = s->is_idr;
     if (pts) *pts = s->pts;
     if (qp) *qp = s->qp;
-    rc_update(&h->rc, s->is_idr, s->qp, n + m);
+    rc_update(&h->rc, s->is_idr, s->qp, s->drop, n + m);
     // Scene-cut recovery (cfg.scenecut; the oracle's orc_enc_frame applies the same rule): the summed cost of the picture's
     // macroblocks came with the hand-over.  The decision lands on picture index + 2, the first one not submitted yet whatever
     // the pipeline depth, and is skipped there if picture index + 1 turned out to be an IDR: the stream does not depend on
@@ -582,7 +591,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
         h->st.ms_total_gpu += tot; h->st.n_total_gpu++;
     }
     h->st.frames++; h->st.idr_frames += s->is_idr; h->st.bytes += n + m;
-    h->st.last_qp = (uint32_t)s->qp; h->st.last_bytes = (uint32_t)(n + m); h->st.target_bps = h->want_bps.load();
+    h->st.last_qp = (uint32_t)s->qp; h->st.last_drop = (uint32_t)s->drop; h->n_skip_pictures += s->all_skip; h->st.last_bytes = (uint32_t)(n + m); h->st.target_bps = h->want_bps.load();
     h->last_slot = s; h->last_collected_rec = s->rec_index;
     h->tail = (h->tail + 1) % NSLOT; h->pending--;
     return MI355ENC_OK;
@@ -631,7 +640,7 @@ int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
 }
 
 // ---------------------------------------------------------------- single-stage entry points
-static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging, int drop = 0) {
+static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging, int drop = 0, int idr = 0) {
     if (h->pending) return MI355ENC_ERR_STATE;
     slot_t *s = &h->slot[0];
     frame_ctx_t *c = s->h_ctx;
@@ -640,7 +649,8 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging, int drop = 0) {
     HIPCHK(hipStreamSynchronize(h->cstream));
     { int r = sync_compute(h); if (r) return r; }
     c->vis_h = h->H;
-    fill_ctx(h, c, qp, drop, 0);
+    fill_ctx(h, c, qp, drop, idr);
+    c->all_intra = 0; // the single-stage deblocking entry point takes records of either picture type
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     return 0;
 }
@@ -724,17 +734,17 @@ int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_u
     HIPCHK(hipMemsetAsync(h->d_rec_uv[1], 0, h->csz, h->stream));
     HIPCHK(hipMemsetAsync(h->d_levels, 0, (size_t)h->nmb * MB_LEVELS * 2, h->stream));
     k_launch_pmb(c, h->mbw, 0, h->mbh, refine ? 1 : 0, h->stream);
-    if (idec && run_intra_p) k_launch_intra_p(c, h->mbw, h->mbh, err_word(h), h->stream);
+    if (idec && run_intra_p) k_launch_intra_p(c, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
     HIPCHK(hipGetLastError());
     return download_picture(h, mbinfo_out, rec_y, rec_uv, levels) ? MI355ENC_ERR_HIP : MI355ENC_OK;
 }
-int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out, uint8_t *rec_y,
+int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, int drop, void *mbinfo_out, uint8_t *rec_y,
                          uint8_t *rec_uv, int16_t *levels) {
-    if (!h || !src_y || !src_uv || !mbinfo_out || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    if (!h || !src_y || !src_uv || !mbinfo_out || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51 || drop < 0 || drop > DROP_MAX) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
-    int r = stage_ctx(h, qp, true); if (r) return r;
+    int r = stage_ctx(h, qp, true, drop, 1); if (r) return r;
     r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r;
     return download_picture(h, mbinfo_out, rec_y, rec_uv, levels) ? MI355ENC_ERR_HIP : MI355ENC_OK;
 }
@@ -784,7 +794,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
             else if (stage == 4) k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 8) k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0], h->d_imv[1], h->stream);
             else if (stage == 9) k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, 1, h->stream);
-            else if (stage == 10) k_launch_intra_p(h->slot[0].h_ctx, h->mbw, h->mbh, err_word(h), h->stream);
+            else if (stage == 10) k_launch_intra_p(h->slot[0].h_ctx, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
             else if (stage >= 5) {
                 const int w = h->cfg.width, ht = h->cfg.height, r0 = stage == 5 ? (w + 15) & ~15 : (2 * w + 15) & ~15, r1 = (w / 2 + 15) & ~15;
                 const uint8_t *p0 = s->d_raw, *p1 = p0 + (size_t)r0 * ht, *p2 = p1 + (size_t)r1 * (ht / 2);
@@ -847,7 +857,7 @@ int mi355enc_host_cavlc_block(const int16_t *coef, int maxnum, int nC, uint8_t *
 static_assert(sizeof(rc_state_t) <= MI355ENC_RC_BYTES, "MI355ENC_RC_BYTES too small");
 void mi355enc_rc_init(void *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max) { rc_init((rc_state_t *)rc, fps, gop, bps, qp_min, qp_max); }
 void mi355enc_rc_set_bitrate(void *rc, uint32_t bps) { rc_set_bitrate((rc_state_t *)rc, bps); }
-int mi355enc_rc_pick_qp(void *rc, int is_idr) { return rc_pick_qp((rc_state_t *)rc, is_idr); }
-void mi355enc_rc_update(void *rc, int is_idr, int qp, size_t bytes) { rc_update((rc_state_t *)rc, is_idr, qp, bytes); }
+void mi355enc_rc_pick(void *rc, int is_idr, int *qp, int *drop) { int q = 0, d = 0; rc_pick((rc_state_t *)rc, is_idr, &q, &d); if (qp) *qp = q; if (drop) *drop = d; }
+void mi355enc_rc_update(void *rc, int is_idr, int qp, int drop, size_t bytes) { rc_update((rc_state_t *)rc, is_idr, qp, drop, bytes); }
 
 } // extern "C"

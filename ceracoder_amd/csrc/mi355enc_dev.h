@@ -71,9 +71,10 @@ typedef struct {
     /* P pictures */
     uint16_t *surf;                /* SAD surfaces, SURF_U16 per macroblock */
     imv_t *imv_a, *imv_b;          /* whole-sample vector fields: the search writes imv_a, the selection iterations alternate; ME_ITERS odd -> final in imv_b */
-    uint32_t *idone;               /* intra macroblocks of P pictures: per-macroblock "reconstructed" stamps (value = epoch) */
-    uint32_t epoch;                /* picture stamp for idone (never 0) */
+    uint32_t epoch;                /* picture stamp (never 0): tags the progress words of intra_p_kernel so that nothing needs clearing */
     uint32_t drop_sad;             /* rate control's ladder below QP 51: 0 off, else the SAD below which a P macroblock carries no residual / takes the skip vector */
+    int32_t iac_drop;              /* I pictures on rate control's ladder: 0 off, else the sum of level magnitudes up to which a macroblock's luma / chroma
+                                      residual is not sent */
     int32_t intra_p;               /* P macroblocks may be intra (the analysis of this picture's source is in isad / idec) */
 } frame_ctx_t;
 
@@ -87,7 +88,8 @@ typedef struct {
  * (kernarg segment); d_ctx: device copy, for the kernels that are replayed from a hipGraph. */
 void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 void k_launch_me_select(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, const imv_t *in, imv_t *out, hipStream_t s);
-void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_err, hipStream_t s);
+void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_progress /* one word per macroblock row */, uint8_t *d_strips /* 32 bytes per macroblock */,
+                      unsigned *d_err, hipStream_t s);
 const imv_t *k_final_imv(const frame_ctx_t *h_ctx); /* where the last selection iteration leaves the field */
 void k_launch_imv_to_mbi(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s); // whole-sample field -> records, for the two-kernel (8x8 transform) path
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);

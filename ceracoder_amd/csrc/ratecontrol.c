@@ -1,85 +1,167 @@
 /*
- * ratecontrol.c -- one QP per picture from the bits/s setpoint that ceracoder's balancer
- * writes every 20 ms (/root/reference/src/ceracoder.c:237-264 ->
- * /root/reference/src/gst/encoder_control.c:45-57).  Setpoints are multiples of 100 kbit/s
- * inside [300 kbit/s, 30 Mbit/s] (/root/reference/src/core/bitrate_control.h:30-32,
- * bitrate_control.c:206).  Non-normative host logic (floating point allowed).
+ * ratecontrol.c -- one QP per picture, and below QP 51 one level of the drop ladder, from the bits/s setpoint that
+ * ceracoder's balancer writes every 20 ms (/root/reference/src/ceracoder.c:237-264 ->
+ * /root/reference/src/gst/encoder_control.c:45-57).  Setpoints are multiples of 100 kbit/s inside [300 kbit/s, 30 Mbit/s]
+ * (/root/reference/src/core/bitrate_control.h:30-32, bitrate_control.c:206), and the balancer cuts hardest exactly when the
+ * link is congested (bitrate_control.c:176-199): the whole range has to be honoured, not only the part a QP can reach.
+ * Non-normative host logic (floating point allowed).
  *
- * Model: bits(qp) ~= C / qstep(qp), qstep = 2^((qp-4)/6), with C tracked separately for
- * IDR and P pictures; a virtual buffer pulls the per-picture budget back to the setpoint
- * within about half a second, so a step on `bps` is honoured well inside one GOP.
+ * Quantiser model: bits(vqp) ~= C / qstep(vqp), qstep = 2^((vqp-4)/6), C tracked separately for IDR and P pictures.  vqp is a
+ * VIRTUAL quantiser: up to qp_max (51) it is the QP; above, every RC_DROP_DQ steps are one level of the ladder the macroblock
+ * stages implement (mi355enc_dev.h DROP_MAX: P macroblocks whose prediction error is below a threshold carry no residual /
+ * take the P_Skip vector; I pictures stop sending the residual of macroblocks that have little), and beyond the ladder's last
+ * level a P picture is coded as one run of P_Skip macroblocks (a few bytes).  The tracker does not need to know what a level
+ * is worth: it sees the bits that came out.  The quantiser may rise by 8 per picture but fall only by 2: on content whose
+ * size is a cliff in QP (a still scene with sensor noise: nothing, then everything) a model-sized dive overshoots by orders
+ * of magnitude.
+ *
+ * Allocation: GOP level, as in MPEG-2 TM5.  At every IDR picture the GOP is granted `gop` pictures' worth of the setpoint
+ * (plus a bounded carry of what the previous GOP left or overspent); the IDR picture takes the share its complexity asks for --
+ * capped by the VBV (x264enc's default vbv-buf-capacity, 600 ms of stream: an IDR may take half of it), floored by what an IDR
+ * costs on the last ladder level -- and every P picture gets what is left divided by the pictures left.  A step on the
+ * setpoint re-prices the pictures still to come.  So the bits of a GOP add up to the setpoint by construction, as long as
+ * the last pictures of the GOP can still absorb the error -- which the all-skip picture guarantees in the downward direction.
+ * `vbv` is the leaky bucket at the setpoint's rate; while it is nearly full the P pictures are all-skip.
  */
 #include <math.h>
+#include <string.h>
 
 #include "h264_host.h"
 
-static double qstep(int qp) { return pow(2.0, (qp - 4) / 6.0); }
+#define RC_DROP_DQ 2  /* virtual-QP steps per ladder level, P pictures */
+#define RC_DROP_DQ_I 0.5 /* ... and I pictures: their ladder (residual of macroblocks that have little is not sent) is worth about a factor of two in all */
+#define RC_VQP_MAX(rc) ((rc)->qp_max + RC_DROP_DQ * DROP_MAX)
+#define RC_SKIP_BITS 160.0 /* an all-skip picture: slice header + one skip run */
+
+static double qstep(double vqp) { return pow(2.0, (vqp - 4) / 6.0); }
 
 void rc_init(rc_state_t *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max) {
+    memset(rc, 0, sizeof *rc);
     rc->fps = fps > 0 ? fps : 30.0;
     rc->gop = gop > 0 ? gop : 1;
     rc->qp_min = qp_min; rc->qp_max = qp_max;
     rc->target_bps = bps;
-    rc->cplx_i = rc->cplx_p = 0;
-    rc->fullness = 0;
-    rc->last_qp_i = rc->last_qp_p = 30;
-    rc->frames_in_gop = 0;
-    rc->have_i = rc->have_p = 0;
+    rc->vbv_ms = 600;
+    rc->last_vqp_i = rc->last_vqp_p = 30;
 }
+void rc_set_vbv(rc_state_t *rc, int vbv_ms) { rc->vbv_ms = vbv_ms < 100 ? 100 : vbv_ms; }
 void rc_set_bitrate(rc_state_t *rc, uint32_t bps) {
     if (bps < 1000) bps = 1000;
     if ((double)bps != rc->target_bps) {
-        /* keep the debt proportional to the new rate so an emergency drop is not delayed */
-        rc->fullness *= (double)bps / rc->target_bps;
+        /* the pictures of this GOP still to come are re-priced; what is owed or saved so far scales with the rate, so that an
+         * emergency drop is not delayed by debts run up at the old rate */
+        const double k = (double)bps / rc->target_bps;
+        rc->gop_bits = rc->gop_bits * k;
         rc->target_bps = bps;
+        /* the bucket holds bits that are already on their way: a rate change does not change them.  After a cut they would
+         * keep the stream frozen for seconds (the buffer shrinks with the rate); half the new buffer is what is kept */
+        if (rc->vbv > 0.5 * bps * rc->vbv_ms / 1000.0) rc->vbv = 0.5 * bps * rc->vbv_ms / 1000.0;
+        /* the quantiser follows the model at once when the rate falls (the per-picture limit on its rise would otherwise let a
+         * few pictures through at the old size -- and they are the ones sent into the congestion the cut reacts to); when the
+         * rate rises it is moved at most two octaves, the rest it walks (see the note on cliffs above) */
+        int d = (int)lround(-6.0 * log2(k));
+        if (d < -12) d = -12;
+        rc->last_vqp_p += d; rc->last_vqp_i += d;
+        if (rc->last_vqp_p > RC_VQP_MAX(rc)) rc->last_vqp_p = RC_VQP_MAX(rc);
+        if (rc->last_vqp_i > RC_VQP_MAX(rc)) rc->last_vqp_i = RC_VQP_MAX(rc);
+        if (rc->last_vqp_p < rc->qp_min) rc->last_vqp_p = rc->qp_min;
+        if (rc->last_vqp_i < rc->qp_min) rc->last_vqp_i = rc->qp_min;
     }
-}
-int rc_pick_qp(rc_state_t *rc, int is_idr) {
-    const double per_frame = rc->target_bps / rc->fps;
-    /* share of an IDR relative to a P picture, from the tracked complexities */
-    double ratio = (rc->have_i && rc->have_p && rc->cplx_p > 0) ? rc->cplx_i / rc->cplx_p : 4.0;
-    if (ratio < 1.5) ratio = 1.5;
-    if (ratio > 12.0) ratio = 12.0;
-    const double gop_bits = per_frame * rc->gop;
-    const double p_bits = gop_bits / (rc->gop - 1 + ratio);
-    double budget = is_idr ? p_bits * ratio : p_bits;
-    /* buffer feedback: work the surplus/deficit off over ~fps/2 pictures */
-    budget -= rc->fullness / (0.5 * rc->fps);
-    if (budget < per_frame * 0.1) budget = per_frame * 0.1;
-    double cplx = is_idr ? rc->cplx_i : rc->cplx_p;
-    int have = is_idr ? rc->have_i : rc->have_p;
-    int qp;
-    if (!have) {
-        if (is_idr) { /* first picture: bits-per-pixel heuristic is not available here, start mid-range */
-            qp = rc->have_p ? rc->last_qp_p - 2 : 32;
-        } else qp = rc->last_qp_i + 2;
-    } else {
-        double q = cplx / budget; /* wanted qstep */
-        qp = (int)lround(4.0 + 6.0 * log2(q > 1e-6 ? q : 1e-6));
-        int last = is_idr ? rc->last_qp_i : rc->last_qp_p;
-        if (qp > last + 6) qp = last + 6;
-        if (qp < last - 4) qp = last - 4;
-    }
-    if (qp < rc->qp_min) qp = rc->qp_min;
-    if (qp > rc->qp_max) qp = rc->qp_max;
-    return qp;
 }
 void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
-    *qp = rc_pick_qp(rc, is_idr);
+    const double per = rc->target_bps / rc->fps, G = per * rc->gop, vbv_bits = rc->target_bps * rc->vbv_ms / 1000.0;
     *drop = 0;
-}
-void rc_update(rc_state_t *rc, int is_idr, int qp, size_t bytes) {
-    const double bits = 8.0 * (double)bytes, c = bits * qstep(qp);
-    if (is_idr) {
-        rc->cplx_i = rc->have_i ? 0.5 * rc->cplx_i + 0.5 * c : c;
-        rc->have_i = 1; rc->last_qp_i = qp; rc->frames_in_gop = 0;
-    } else {
-        rc->cplx_p = rc->have_p ? 0.7 * rc->cplx_p + 0.3 * c : c;
-        rc->have_p = 1; rc->last_qp_p = qp;
+    if (is_idr || rc->gop_left <= 0) { /* a new GOP: its grant, plus a bounded carry of the previous one's remainder */
+        double carry = rc->started ? rc->gop_bits : 0;
+        if (carry > 0.05 * G) carry = 0.05 * G;
+        if (carry < -0.10 * G) carry = -0.10 * G; /* an overspent GOP is repaid over the following ones, a tenth of a GOP at a time */
+        rc->gop_bits = G + carry;
+        rc->gop_left = rc->gop;
+        rc->started = 1;
     }
-    rc->frames_in_gop++;
-    rc->fullness += bits - rc->target_bps / rc->fps;
-    /* bound the memory of the buffer to one second of stream either way */
-    if (rc->fullness > rc->target_bps) rc->fullness = rc->target_bps;
-    if (rc->fullness < -rc->target_bps) rc->fullness = -rc->target_bps;
+    double target;
+    if (is_idr && rc->gop > 1) {
+        double ratio = (rc->have_i && rc->have_p && rc->cplx_p > 0) ? rc->cplx_i / rc->cplx_p : 4.0;
+        if (ratio < 1.5) ratio = 1.5;
+        if (ratio > 100.0) ratio = 100.0;
+        target = rc->gop_bits * ratio / (rc->gop - 1 + ratio);
+        if (target > 0.5 * vbv_bits) target = 0.5 * vbv_bits;                              /* VBV: an IDR may take half the buffer */
+        const double floor_i = rc->have_i ? rc->cplx_i / qstep(rc->qp_max + RC_DROP_DQ_I * DROP_MAX) : 0; /* what an IDR costs on the last ladder level */
+        if (target < floor_i) target = floor_i;
+        if (target > 0.9 * rc->gop_bits) target = 0.9 * rc->gop_bits;
+        if (target < per) target = per;
+    } else target = rc->gop_bits / (rc->gop_left > 0 ? rc->gop_left : 1);
+    const int vmax = RC_VQP_MAX(rc);
+    const double cplx = is_idr ? rc->cplx_i : rc->cplx_p;
+    const int have = is_idr ? rc->have_i : rc->have_p;
+    int skip = 0, vqp, idrop = 0;
+    if (!is_idr && (rc->vbv > 0.9 * vbv_bits || target < 2 * RC_SKIP_BITS)) skip = 1; /* the bucket is full, or the GOP has nothing left */
+    if (!have) {
+        if (is_idr) vqp = rc->have_p ? rc->last_vqp_p - 2 : 32; /* first picture: nothing is known yet, start mid-range */
+        else vqp = rc->last_vqp_i + 2;
+    } else {
+        const double q = cplx / (target > 1 ? target : 1); /* wanted qstep */
+        vqp = (int)lround(4.0 + 6.0 * log2(q > 1e-6 ? q : 1e-6));
+        if (is_idr) { /* IDR pictures are a second apart: the model decides, floored relative to where the P pictures are */
+            const int lp = rc->last_vqp_p > rc->qp_max ? rc->qp_max : rc->last_vqp_p;
+            if (rc->have_p && vqp < lp - 6) vqp = lp - 6;
+            if (vqp > rc->qp_max) { /* onto the I ladder: half a quantiser step per level */
+                const double v = 4.0 + 6.0 * log2(q > 1e-6 ? q : 1e-6);
+                int d = (int)ceil((v - rc->qp_max) / RC_DROP_DQ_I);
+                idrop = d < 1 ? 1 : d > DROP_MAX ? DROP_MAX : d;
+                vqp = rc->qp_max;
+            }
+        } else {
+            const int last = rc->last_vqp_p;
+            if (vqp > vmax + 3) skip = 1; /* even the ladder's last level is predicted to cost 1.4 x the target */
+            if (vqp > last + 8) vqp = last + 8;
+            /* a quantiser at which a picture cost several times its target is a cliff edge (a still scene with sensor noise codes
+             * nothing, then everything): it is not visited again before the target could pay most of what it cost */
+            if (rc->cliff_age > 0 && vqp <= rc->cliff_vqp && vqp <= rc->qp_max && target < 0.7 * rc->cliff_bits) vqp = rc->cliff_vqp + 1;
+            /* downwards two steps a picture while the pictures are far below their target, one step once they are within a
+             * factor of two of it: near a cliff a step of two is the difference between a tenth and ten times the target */
+            const int down = (rc->last_bits_p > 0.5 * rc->last_target_p) ? 1 : 2;
+            if (vqp < last - down) vqp = last - down;
+        }
+    }
+    if (skip) {
+        *qp = rc->qp_max; *drop = DROP_SKIP;
+        target = RC_SKIP_BITS;
+    } else {
+        if (vqp < rc->qp_min) vqp = rc->qp_min;
+        if (vqp > vmax) vqp = vmax;
+        if (is_idr) { if (vqp > rc->qp_max) vqp = rc->qp_max; *qp = vqp; *drop = idrop; }
+        else if (vqp <= rc->qp_max) *qp = vqp;
+        else { *qp = rc->qp_max; *drop = (vqp - rc->qp_max + RC_DROP_DQ - 1) / RC_DROP_DQ; vqp = rc->qp_max + RC_DROP_DQ * *drop; }
+        if (is_idr) rc->last_vqp_i = vqp; else rc->last_vqp_p = vqp; /* remembered when chosen: the picture's size arrives a picture later, after the next choice */
+    }
+    rc->plan[rc->n_pick++ & 3] = target; /* booked now, corrected when the picture's size is known */
+    rc->gop_bits -= target;
+    rc->gop_left--;
+}
+int rc_pick_qp(rc_state_t *rc, int is_idr) {
+    int qp, drop;
+    rc_pick(rc, is_idr, &qp, &drop);
+    return qp;
+}
+void rc_update(rc_state_t *rc, int is_idr, int qp, int drop, size_t bytes) {
+    const double bits = 8.0 * (double)bytes;
+    const double planned = rc->plan[rc->n_upd++ & 3];
+    if (drop != DROP_SKIP) {
+        const double vqp = is_idr ? qp + RC_DROP_DQ_I * drop : qp + RC_DROP_DQ * drop;
+        const double c = bits * qstep(vqp);
+        if (is_idr) {
+            rc->cplx_i = rc->have_i ? 0.5 * rc->cplx_i + 0.5 * c : c;
+            rc->have_i = 1;
+        } else {
+            const double a = (rc->have_p && c > rc->cplx_p) ? 0.6 : 0.35; /* believe bad news faster than good news */
+            rc->cplx_p = rc->have_p ? (1 - a) * rc->cplx_p + a * c : c;
+            rc->have_p = 1; rc->last_bits_p = bits; rc->last_target_p = planned;
+            if (bits > 3.0 * planned && planned > 4 * RC_SKIP_BITS && vqp <= rc->qp_max && vqp < rc->last_vqp_p + 2) { rc->cliff_vqp = (int)vqp; rc->cliff_bits = bits; rc->cliff_age = (int)rc->fps; }
+            else if (rc->cliff_age > 0) rc->cliff_age--;
+        }
+    }
+    rc->gop_bits += planned - bits;
+    rc->vbv += bits - rc->target_bps / rc->fps;
+    if (rc->vbv < 0) rc->vbv = 0; /* a CBR channel cannot send what has not been produced: the bucket does not go negative */
 }

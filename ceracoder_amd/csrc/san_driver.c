@@ -62,9 +62,11 @@ static int run_code(const char *in, const char *outp, int threads) {
     rc_init(&rc, c.h.fps, 60, 6000000, 10, 51);
     for (int i = 0; i < 400; i++) {
         if (i % 97 == 0) rc_set_bitrate(&rc, (uint32_t)(300000 + (i * 7919) % 29700000));
-        const int idr = i % 60 == 0, qp = rc_pick_qp(&rc, idr);
-        if (qp < 0 || qp > 51) return 5;
-        rc_update(&rc, idr, qp, (n + m) * (idr ? 6 : 1) * (size_t)(52 - qp) / 26);
+        const int idr = i % 60 == 0;
+        int qp, drop;
+        rc_pick(&rc, idr, &qp, &drop);
+        if (qp < 0 || qp > 51 || drop < 0 || (drop > DROP_MAX && drop != DROP_SKIP)) return 5;
+        rc_update(&rc, idr, qp, drop, drop == DROP_SKIP ? 12 : (n + m) * (idr ? 6 : 1) * (size_t)(52 - qp) / 26 / (size_t)(1 + drop));
     }
     /* transport stream */
     mi355ts_t *ts = mi355ts_open();
@@ -112,11 +114,12 @@ static int run_race(const char *in, int iters) {
     int bad = 0;
     for (int i = 0; i < iters; i++) {
         rc_set_bitrate(&rc, atomic_load_explicit(&want_bps, memory_order_relaxed)); /* latched once per picture, as enqueue_picture() does */
-        const int qp = rc_pick_qp(&rc, c.h.is_idr);
+        int qp, drop;
+        rc_pick(&rc, c.h.is_idr, &qp, &drop);
         const size_t m = h264_write_slice_packed_rows(wp, a, cap, c.h.is_idr, c.h.frame_num, c.h.idr_pic_id, c.h.qp, c.mbi, packed, row_off);
         if (!i) first = m;
         if (!m || m != first) bad = 1;
-        rc_update(&rc, c.h.is_idr, qp, m);
+        rc_update(&rc, c.h.is_idr, qp, drop, m);
     }
     atomic_store(&stop_flag, 1);
     pthread_join(th, NULL);

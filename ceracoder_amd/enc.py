@@ -32,7 +32,7 @@ EXPORTS = [
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
     "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_pmb", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
     "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
-    "mi355enc_rc_pick_qp", "mi355enc_rc_update", "mi355enc_host_cavlc_block",
+    "mi355enc_rc_pick", "mi355enc_rc_update", "mi355enc_host_cavlc_block",
 ]
 
 
@@ -40,7 +40,7 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
                 ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
-                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("intra_in_p", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("scenecut", C.c_int)]
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("intra_in_p", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("vbv_ms", C.c_int), ("scenecut", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -48,7 +48,7 @@ class Stats(C.Structure):
                 ("last_bytes", C.c_uint32), ("target_bps", C.c_uint32), ("ms_me", C.c_double), ("ms_inter", C.c_double),
                 ("ms_intra", C.c_double), ("ms_deblock", C.c_double), ("ms_total_gpu", C.c_double), ("ms_subpel", C.c_double), ("n_me", C.c_uint64),
                 ("n_inter", C.c_uint64), ("n_intra", C.c_uint64), ("n_deblock", C.c_uint64), ("ms_entropy", C.c_double),
-                ("ms_wait", C.c_double), ("n_total_gpu", C.c_uint64), ("ms_deblock_idr", C.c_double), ("n_deblock_idr", C.c_uint64), ("cavlc_threads", C.c_uint32), ("reserved0", C.c_uint32), ("ms_open", C.c_double)]
+                ("ms_wait", C.c_double), ("n_total_gpu", C.c_uint64), ("ms_deblock_idr", C.c_double), ("n_deblock_idr", C.c_uint64), ("cavlc_threads", C.c_uint32), ("last_drop", C.c_uint32), ("ms_open", C.c_double)]
 
 
 _lib = None
@@ -93,7 +93,7 @@ def load():
         L.mi355enc_stage_subpel.argtypes = [vp, vp, vp, C.c_int, vp]
         L.mi355enc_stage_inter.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_pmb.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp]
-        L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
+        L.mi355enc_stage_intra.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
         L.mi355enc_stage_intra_analyse.argtypes = [vp, vp, vp, C.c_int, vp, vp]
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
         L.mi355enc_submit_fmt.argtypes = [vp, C.c_int, vp, vp, C.c_int64, C.c_int]
@@ -107,9 +107,10 @@ def load():
         L.mi355enc_rc_init.argtypes = [vp, C.c_double, C.c_int, C.c_uint32, C.c_int, C.c_int]
         L.mi355enc_rc_set_bitrate.restype = None
         L.mi355enc_rc_set_bitrate.argtypes = [vp, C.c_uint32]
-        L.mi355enc_rc_pick_qp.argtypes = [vp, C.c_int]
+        L.mi355enc_rc_pick.restype = None
+        L.mi355enc_rc_pick.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mi355enc_rc_update.restype = None
-        L.mi355enc_rc_update.argtypes = [vp, C.c_int, C.c_int, C.c_size_t]
+        L.mi355enc_rc_update.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_size_t]
         _lib = L
     return _lib
 
@@ -162,17 +163,20 @@ class RateControl:
 
     def __init__(self, fps, gop, bps, qp_min=10, qp_max=51):
         self.L = load()
-        self.buf = (C.c_uint8 * 128)()
+        self.buf = (C.c_uint8 * 256)()
         self.L.mi355enc_rc_init(self.buf, float(fps), gop, bps, qp_min, qp_max)
 
     def set_bitrate(self, bps):
         self.L.mi355enc_rc_set_bitrate(self.buf, int(bps))
 
-    def pick_qp(self, is_idr):
-        return self.L.mi355enc_rc_pick_qp(self.buf, int(is_idr))
+    def pick(self, is_idr):
+        """-> (qp, drop): drop 0 .. DROP_MAX is the ladder below QP 51, DROP_SKIP an all-skip picture"""
+        qp, drop = C.c_int(0), C.c_int(0)
+        self.L.mi355enc_rc_pick(self.buf, int(is_idr), C.byref(qp), C.byref(drop))
+        return qp.value, drop.value
 
-    def update(self, is_idr, qp, nbytes):
-        self.L.mi355enc_rc_update(self.buf, int(is_idr), qp, nbytes)
+    def update(self, is_idr, qp, drop, nbytes):
+        self.L.mi355enc_rc_update(self.buf, int(is_idr), qp, drop, nbytes)
 
 
 class EncoderError(RuntimeError):
@@ -275,6 +279,11 @@ class Encoder:
         return au, bool(key.value), pts.value, qp.value
 
     @property
+    def last_drop(self):
+        """drop level of the last collected picture (0, 1 .. DROP_MAX, DROP_SKIP)"""
+        return int(self.stats().last_drop)
+
+    @property
     def pending(self):
         return self.L.mi355enc_pending(self.h)
 
@@ -340,11 +349,11 @@ class Encoder:
                                             int(run_intra_p), _p(mbi), _p(rec_y), _p(rec_uv), _p(lev)), "stage_pmb")
         return rec_y, rec_uv, mbi, lev
 
-    def stage_intra(self, src_y, src_uv, qp):
+    def stage_intra(self, src_y, src_uv, qp, drop=0):
         mbi = np.zeros(self.mbw * self.mbh, MBINFO_DTYPE)
         rec_y, rec_uv = np.empty_like(src_y), np.empty_like(src_uv)
         lev = np.empty((mbi.size, LEVELS_PER_MB), np.int16)
-        self._chk(self.L.mi355enc_stage_intra(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)), qp,
+        self._chk(self.L.mi355enc_stage_intra(self.h, _p(np.ascontiguousarray(src_y)), _p(np.ascontiguousarray(src_uv)), qp, int(drop),
                                               _p(mbi), _p(rec_y), _p(rec_uv), _p(lev)), "stage_intra")
         return rec_y, rec_uv, mbi, lev
 

@@ -70,6 +70,8 @@ typedef struct {
                                  1000 macroblocks, where waking workers costs more than it saves); mi355enc_stats_t reports it */
     int intra_mode;           /* 0 (default): persistent band kernel for the intra reconstruction wavefront; 1: one launch per
                                  anti-diagonal replayed as a hipGraph (plain form, kept as a cross-check) */
+    int vbv_ms;               /* rate control's buffer model in ms of stream at the setpoint (default 600: x264enc's vbv-buf-capacity): an IDR
+                                 picture is planned at most half of it, and P pictures are all-skip while the bucket is nearly full */
     int scenecut;             /* 1 (default, like x264's scenecut): when the summed motion cost of a P picture exceeds three times
                                  the mean of the P pictures since the last IDR (at least two of them), the picture two
                                  positions later is coded as IDR -- recovery within two pictures instead of a GOP, with no wait
@@ -78,7 +80,7 @@ typedef struct {
 } mi355enc_cfg_t;
 
 typedef struct {
-    uint64_t frames, idr_frames, bytes;
+    uint64_t frames, idr_frames, bytes;   /* pictures collected, IDR pictures among them, bytes produced */
     uint32_t last_qp, last_bytes, target_bps;
     /* accumulated device time per stage in ms and sample counts (profile_events > 0) */
     double ms_me, ms_inter, ms_intra, ms_deblock, ms_total_gpu;
@@ -90,7 +92,7 @@ typedef struct {
     double ms_deblock_idr;    /* the part of ms_deblock / n_deblock that came from IDR pictures */
     uint64_t n_deblock_idr;
     uint32_t cavlc_threads;   /* host threads in use for entropy coding (cfg.cavlc_threads resolved) */
-    uint32_t reserved0;
+    uint32_t last_drop;       /* drop level of the last collected picture (0: none; 1 .. 12: the ladder below QP 51; 255: all-skip picture) */
     double ms_open;           /* wall time mi355enc_open() took (device selection, allocations, stream creation): must stay far below
                                  the 1 s tick of the reference's stall watchdog, /root/reference/src/ceracoder.c:152-200; survives reset_stats */
 } mi355enc_stats_t;
@@ -173,7 +175,9 @@ int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
 int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv,
                        int qp, int drop, int refine, const void *imv, const uint16_t *surf, const void *idec, int run_intra_p,
                        void *mbinfo_out, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
-int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, void *mbinfo_out,
+/* I picture: analysis + reconstruction wavefront; `drop`: rate control's ladder for I pictures, 0 off .. 12 (Intra_16x16 only, and a
+ * macroblock's luma / chroma levels are not sent when their magnitudes sum to no more than the level's threshold) */
+int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, int drop, void *mbinfo_out,
                          uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels);
 /* open-loop intra analysis only: 152 uint16 per macroblock {i16[4], chroma[4], i4[16][9]}, 0xFFFF = mode unavailable; and
  * (idec_out may be NULL) the decisions taken from them at `qp`: 32 bytes per macroblock {u8 modes4[16] by luma4x4BlkIdx;
@@ -200,13 +204,14 @@ int mi355enc_host_write_slice_packed(int mbw, int mbh, int is_idr, int frame_num
  * (whole 4x4 block), 15 (AC of Intra16x16 / chroma) or 4 (chroma DC); nC as 9.2.1 derives it.  Bits MSB-first into out
  * (cap >= 64 bytes); returns the number of bits, negative on error. */
 int mi355enc_host_cavlc_block(const int16_t *coef, int maxnum, int nC, uint8_t *out, size_t cap);
-/* Rate-control model on its own: feed (is_idr, produced bytes) per picture, get the next QP.
+/* Rate-control model on its own: per picture one pick (QP and, below QP 51, the drop level: 0 .. 12, 255 = all-skip picture)
+ * and -- possibly one picture later, as with pipeline_depth 1 -- one update with the bytes it produced, in the same order.
  * rc is an opaque block of MI355ENC_RC_BYTES bytes owned by the caller. */
-#define MI355ENC_RC_BYTES 128
+#define MI355ENC_RC_BYTES 256
 void mi355enc_rc_init(void *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max);
 void mi355enc_rc_set_bitrate(void *rc, uint32_t bps);
-int mi355enc_rc_pick_qp(void *rc, int is_idr);
-void mi355enc_rc_update(void *rc, int is_idr, int qp, size_t bytes);
+void mi355enc_rc_pick(void *rc, int is_idr, int *qp, int *drop);
+void mi355enc_rc_update(void *rc, int is_idr, int qp, int drop, size_t bytes);
 
 #ifdef __cplusplus
 }

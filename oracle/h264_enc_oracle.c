@@ -464,7 +464,7 @@ void orc_me_select(const uint16_t *surf, int mbw, int mbh, int range, int qp, co
  * macroblock, given the prediction already written into rec_uv.  8.5.11 (chroma DC 2x2),
  * 8.5.12; Table 8-15 for QPc. */
 static void chroma_tq_recon(const uint8_t *src_uv, uint8_t *rec_uv, int stride, int cx0, int cy0,
-                            int qp, int intra, int16_t *lev, uint32_t *nzmask) {
+                            int qp, int intra, int16_t *lev, uint32_t *nzmask, int ac_drop) {
     int qpc = k_chroma_qp[CLIP3(0, 51, qp)];
     for (int c = 0; c < 2; c++) {
         int16_t dc[4];
@@ -489,6 +489,15 @@ static void chroma_tq_recon(const uint8_t *src_uv, uint8_t *rec_uv, int stride, 
         ldc[2] = (int16_t)quant_dc(f2, qpc, intra);
         ldc[3] = (int16_t)quant_dc(f3, qpc, intra);
         if (ldc[0] | ldc[1] | ldc[2] | ldc[3]) *nzmask |= (c ? ORC_NZ_CRDC : ORC_NZ_CBDC);
+    }
+    if (ac_drop) { /* rate control's ladder for I pictures: chroma levels (both planes, DC and AC) whose magnitudes sum to no more than the threshold are not sent */
+        int sum = 0;
+        for (int i = 0; i < 128; i++) sum += iabs(lev[ORC_L_CAC + i]);
+        for (int i = 0; i < 8; i++) sum += iabs(lev[ORC_L_CDC + i]);
+        if (sum <= ac_drop) {
+            memset(lev + ORC_L_CAC, 0, 128 * sizeof(int16_t)); memset(lev + ORC_L_CDC, 0, 8 * sizeof(int16_t));
+            *nzmask &= ~(0x00FF0000u | ORC_NZ_CBDC | ORC_NZ_CRDC);
+        }
     }
     /* 7.3.5: chroma AC levels are only transmitted when coded_block_pattern chroma == 2,
      * which this encoder sets when any AC level of either plane is non-zero. */
@@ -629,7 +638,7 @@ void orc_inter_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t 
                 orc_idct4_add(d, rec_y + (size_t)(y0 + k_blk_y[b]) * stride + x0 + k_blk_x[b], stride);
             }
             }
-            chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 0, lev, &m->nzmask);
+            chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 0, lev, &m->nzmask, 0);
         }
 }
 
@@ -896,7 +905,7 @@ static void intra4x4_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int
 /* Reconstruction of one intra macroblock with the decision `dec` (8.3 + 8.5): prediction from the reconstructed neighbours in
  * rec_y / rec_uv (whatever their type: constrained_intra_pred_flag is 0), residual, levels, record. */
 static void intra_mb(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mx, int my, int qp,
-                     const orc_idec_t *dec, orc_mbinfo_t *mbi, int16_t *levels) {
+                     const orc_idec_t *dec, orc_mbinfo_t *mbi, int16_t *levels, int iac) {
             orc_mbinfo_t *m = &mbi[my * mbw + mx];
             int16_t *lev = levels + (size_t)(my * mbw + mx) * ORC_LEVELS_PER_MB;
             memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
@@ -922,6 +931,7 @@ static void intra_mb(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
                 if (tq_block(res, qp, 1, 1, lev + ORC_L_LUMA + b * 16, &dc)) m->nzmask |= 1u << b;
                 dcs[(by / 4) * 4 + bx / 4] = dc;
             }
+
             /* forward Hadamard, halved with rounding (encoder choice), then DC quantiser */
             int t[16], hd[16];
             for (int i = 0; i < 4; i++) {
@@ -938,6 +948,12 @@ static void intra_mb(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
             for (int k = 0; k < 16; k++) {
                 ldc[k] = (int16_t)quant_dc(hd[k_zigzag4[k]], qp, 1);
                 if (ldc[k]) m->nzmask |= ORC_NZ_LDC;
+            }
+            if (iac) { /* rate control's ladder for I pictures: a macroblock whose luma levels (DC and AC) sum to no more than the threshold sends none */
+                int sum = 0;
+                for (int i = 0; i < 256; i++) sum += iabs(lev[ORC_L_LUMA + i]);
+                for (int k = 0; k < 16; k++) sum += iabs(ldc[k]);
+                if (sum <= iac) { memset(lev + ORC_L_LUMA, 0, 256 * sizeof(int16_t)); memset(ldc, 0, 16 * sizeof(int16_t)); m->nzmask &= ~(0xFFFFu | ORC_NZ_LDC); }
             }
             /* 7.3.5.3: Intra16x16 AC levels are sent for all 16 blocks or none (cbp luma 15/0) */
             /* --- luma reconstruction: 8.5.10 (DC) then 8.5.12 per block */
@@ -971,20 +987,22 @@ static void intra_mb(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
                 for (int y = 0; y < 8; y++)
                     for (int x = 0; x < 8; x++) UV(rec_uv, stride, x0 / 2 + x, y0 / 2 + y, c) = cp[y * 8 + x];
             }
-            chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 1, lev, &m->nzmask);
+            chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 1, lev, &m->nzmask, iac);
 }
 
 /* I picture.  Analysis and decisions (above) need only the source picture; then per macroblock in raster order the
  * reconstruction with the chosen modes. */
+const int32_t k_idrop_ac[ORC_DROP_MAX + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64, 0x7FFFFFFF};
 void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
-                     uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
+                     uint8_t *rec_uv, int stride, int mbw, int mbh, int qp, int drop,
                      orc_mbinfo_t *mbi, int16_t *levels) {
+    const int iac = k_idrop_ac[CLIP3(0, ORC_DROP_MAX, drop)];
     orc_isad_t *isad = (orc_isad_t *)malloc((size_t)mbw * mbh * sizeof(orc_isad_t));
     orc_idec_t *idec = (orc_idec_t *)malloc((size_t)mbw * mbh * sizeof(orc_idec_t));
     orc_intra_analyse(src_y, src_uv, stride, mbw, mbh, isad);
-    orc_intra_decide(isad, mbw, mbh, qp, g_orc_i4x4, idec);
+    orc_intra_decide(isad, mbw, mbh, qp, drop > 0 ? 0 : g_orc_i4x4, idec); /* on the ladder: Intra_16x16 only (Intra_4x4 costs its mode bits whatever the residual) */
     for (int my = 0; my < mbh; my++)
-        for (int mx = 0; mx < mbw; mx++) intra_mb(src_y, src_uv, rec_y, rec_uv, stride, mbw, mx, my, qp, &idec[my * mbw + mx], mbi, levels);
+        for (int mx = 0; mx < mbw; mx++) intra_mb(src_y, src_uv, rec_y, rec_uv, stride, mbw, mx, my, qp, &idec[my * mbw + mx], mbi, levels, iac);
     free(isad);
     free(idec);
 }
@@ -994,7 +1012,7 @@ void orc_intra_p_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec
                        const orc_idec_t *idec, orc_mbinfo_t *mbi, int16_t *levels) {
     for (int my = 0; my < mbh; my++)
         for (int mx = 0; mx < mbw; mx++)
-            if (mbi[my * mbw + mx].mb_type != 1) intra_mb(src_y, src_uv, rec_y, rec_uv, stride, mbw, mx, my, qp, &idec[my * mbw + mx], mbi, levels);
+            if (mbi[my * mbw + mx].mb_type != 1) intra_mb(src_y, src_uv, rec_y, rec_uv, stride, mbw, mx, my, qp, &idec[my * mbw + mx], mbi, levels, 0);
 }
 
 /* ================================================================== P pictures: the fused macroblock stage */
@@ -1009,7 +1027,8 @@ void orc_intra_p_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec
  *      evaluated.  Rate control's ladder below QP 51 (drop > 0) widens this: SAD(ps_est) < T[drop] passes as well.
  *   3. sub-sample refinement around the whole-sample winner, bits against p_est: 8 half-sample neighbours by SAD, then the
  *      8 quarter-sample neighbours by SATD (4x4 Hadamard, x264 subme 2) -- strictly cheaper wins, (dy, dx) raster order.
- *   4. intra or inter (when the open-loop intra analysis of the macroblock is available): SAD-domain comparison.
+ *   4. intra or inter (when the open-loop intra analysis of the macroblock is available; Intra_16x16 only in P pictures):
+ *      SAD-domain comparison.
  *   5. inter residual: 4x4 transform, dead-zone quantiser, coefficient decimation (x264 dct-decimate: an 8x8 whose
  *      run/level score is below 4 and a macroblock whose score is below 6 are emptied; chroma AC of a plane below 7),
  *      normative reconstruction.  drop > 0 and SAD(final) < T[drop]: no residual at all. */
@@ -1718,7 +1737,10 @@ static void load_padded(orc_enc_t *e, const uint8_t *y, int ys, const uint8_t *u
 }
 /* One picture.  qp 0..51; drop 0..ORC_DROP_MAX (P pictures: rate control's ladder below QP 51); drop == ORC_DROP_SKIP: the
  * picture is coded as one run of P_Skip macroblocks (no source sample is looked at; the reconstruction is the reference) --
- * what rate control emits when even the ladder's last step would overshoot.  An IDR is never dropped. */
+ * what rate control emits when even the ladder's last step would overshoot.  I pictures have a ladder of their own (drop
+ * 1 .. ORC_DROP_MAX: Intra_16x16 only, and a macroblock's luma / chroma levels are not sent when their magnitudes sum to
+ * no more than the level's threshold -- at the last level an I picture is prediction only); ORC_DROP_SKIP means nothing to
+ * an I picture. */
 int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
                    int qp, int drop, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len, int *is_idr) {
     if (!e || qp < 0 || qp > 51 || drop < 0 || (drop > ORC_DROP_MAX && drop != ORC_DROP_SKIP)) return -1;
@@ -1737,7 +1759,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
     } else {
         load_padded(e, y, y_stride, uv, uv_stride);
         if (idr)
-            orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
+            orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, drop == ORC_DROP_SKIP ? 0 : drop, e->mbi, e->levels);
         else {
             orc_me_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, e->me_range, qp, e->surf, e->imv, e->threads);
             if (g_orc_feat & ORC_F_MVDCOST)
@@ -1758,7 +1780,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
                 const int intra_p = (g_orc_feat & ORC_F_INTRAP) != 0;
                 if (intra_p) {
                     orc_intra_analyse(e->src_y, e->src_uv, e->stride, e->mbw, e->mbh, e->isad);
-                    orc_intra_decide(e->isad, e->mbw, e->mbh, qp, g_orc_i4x4, e->idec);
+                    orc_intra_decide(e->isad, e->mbw, e->mbh, qp, 0, e->idec); /* intra macroblocks of P pictures are Intra_16x16 only: nearly all of the gain, a fraction of the dependent work */
                 }
                 orc_pmb_frame(e->src_y, e->src_uv, e->rec_y[e->cur], e->rec_uv[e->cur], e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh,
                               qp, drop, e->subpel, e->imv, e->surf, intra_p ? e->idec : NULL, e->mbi, e->levels, e->threads);

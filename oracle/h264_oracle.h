@@ -87,7 +87,7 @@ void orc_intra_decide(const orc_isad_t *isad, int mbw, int mbh, int qp, int i4x4
 /* I picture: Intra16x16 + chroma prediction, mode decision by SAD, transform/quant,
  * reconstruction (pre-deblock), macroblocks in raster order. */
 void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y,
-                     uint8_t *rec_uv, int stride, int mbw, int mbh, int qp,
+                     uint8_t *rec_uv, int stride, int mbw, int mbh, int qp, int drop,
                      orc_mbinfo_t *mbi, int16_t *levels);
 
 /* P macroblocks, fused stage (what the device's pmb_kernel computes): predictor estimates from the whole-sample field `imv`,

@@ -99,7 +99,7 @@ def lib():
         L.orc_intra_analyse.restype = None
         L.orc_intra_decide.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
         L.orc_intra_decide.restype = None
-        L.orc_intra_frame.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.orc_intra_frame.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
         L.orc_intra_frame.restype = None
         L.orc_deblock_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
         L.orc_deblock_frame.restype = None
@@ -393,13 +393,13 @@ def set_i4x4(on):
     lib().orc_set_i4x4(int(on))
 
 
-def intra_frame(src_y, src_uv, qp):
+def intra_frame(src_y, src_uv, qp, drop=0):
     L = lib()
     H, W = src_y.shape
     rec_y, rec_uv = np.zeros_like(src_y), np.zeros_like(src_uv)
     mbi = np.zeros((H // 16) * (W // 16), MBINFO_DTYPE)
     lev = np.zeros((mbi.size, LEVELS_PER_MB), np.int16)
-    L.orc_intra_frame(_ptr(src_y), _ptr(src_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16, H // 16, qp, _ptr(mbi), _ptr(lev))
+    L.orc_intra_frame(_ptr(src_y), _ptr(src_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16, H // 16, qp, drop, _ptr(mbi), _ptr(lev))
     return rec_y, rec_uv, mbi, lev
 
 

@@ -162,29 +162,59 @@ def test_row_parallel_cavlc_is_bit_identical(oracle, w, h, qp, kind):
         assert len(au) < 200  # all skipped: proves the carried-run path ran
 
 
+def _synthetic_bytes(rng, idr, qp, drop, skip=255):
+    """A stand-in for the encoder: bits = C / qstep(virtual QP), every ladder level worth about 1.5 QP, all-skip pictures 12 bytes."""
+    if drop == skip:
+        return 12
+    cplx = (9e6 if idr else 1.2e6) * (1 + 0.1 * rng.standard_normal())
+    return max(12, int(cplx / 2 ** ((qp + 1.5 * drop - 4) / 6) / 8))
+
+
 def test_rate_control_model_converges_and_follows_steps():
     """Host logic only: synthetic pictures whose size is C/qstep; after a step on the setpoint the
-    mean rate over the following GOP must be within 10 %."""
+    mean rate over the following GOP must be within 10 % -- over the reference's whole setpoint
+    range, 300 kbit/s .. 30 Mbit/s (/root/reference/src/core/bitrate_control.h:30-32), i.e. also far below what QP 51 yields."""
     fps, gop = 60, 60
     rc = E.RateControl(fps, gop, 6_000_000)
     rng = np.random.default_rng(3)
-    sizes = []
-    for i in range(6 * gop):
-        if i == 2 * gop:
-            rc.set_bitrate(3_000_000)
-        if i == 4 * gop:
-            rc.set_bitrate(1_000_000)  # a deep emergency drop (floor is 300 kbit/s, bitrate_control.h:30)
+    sizes, levels = [], []
+    steps = [6_000_000, 3_000_000, 1_000_000, 300_000, 30_000_000, 1_500_000]
+    for i in range(2 * gop * len(steps)):
+        if i % (2 * gop) == 0:
+            rc.set_bitrate(steps[i // (2 * gop)])
         idr = i % gop == 0
-        qp = rc.pick_qp(idr)
-        assert 10 <= qp <= 51
-        cplx = (9e6 if idr else 1.2e6) * (1 + 0.1 * rng.standard_normal())
-        nbytes = max(40, int(cplx / 2 ** ((qp - 4) / 6) / 8))
-        rc.update(idr, qp, nbytes)
+        qp, drop = rc.pick(idr)
+        assert 10 <= qp <= 51 and (0 <= drop <= E.DROP_MAX or drop == E.DROP_SKIP) and not (idr and drop == E.DROP_SKIP)
+        nbytes = _synthetic_bytes(rng, idr, qp, drop)
+        rc.update(idr, qp, drop, nbytes)
         sizes.append(nbytes)
+        levels.append(drop)
     rate = lambda g: sum(sizes[g * gop:(g + 1) * gop]) * 8 * fps / gop
-    assert abs(rate(1) - 6e6) / 6e6 < 0.10, rate(1)
-    assert abs(rate(3) - 3e6) / 3e6 < 0.10, rate(3)
-    assert abs(rate(5) - 1e6) / 1e6 < 0.10, rate(5)
+    for k, bps in enumerate(steps):
+        assert abs(rate(2 * k + 1) - bps) / bps < 0.10, (bps, rate(2 * k + 1))
+    assert max(levels[6 * gop:8 * gop]) > 0          # 300 kbit/s really needed the ladder below QP 51
+    assert max(levels[8 * gop + 10:10 * gop]) == 0   # ... and 30 Mbit/s does not
+
+
+def test_rate_control_plans_idr_pictures_inside_the_vbv():
+    """An IDR picture is planned at most half of the 600 ms buffer (x264enc's vbv-buf-capacity); the leaky bucket at the
+    setpoint's rate never runs more than the buffer ahead in steady state."""
+    fps, gop, bps = 60, 60, 4_000_000
+    rc = E.RateControl(fps, gop, bps)
+    rng = np.random.default_rng(11)
+    bucket, worst, idr_sizes = 0.0, 0.0, []
+    for i in range(8 * gop):
+        idr = i % gop == 0
+        qp, drop = rc.pick(idr)
+        nbytes = _synthetic_bytes(rng, idr, qp, drop)
+        rc.update(idr, qp, drop, nbytes)
+        bucket = max(0.0, bucket + 8 * nbytes - bps / fps)
+        if i >= 2 * gop:
+            worst = max(worst, bucket)
+            if idr:
+                idr_sizes.append(8 * nbytes)
+    assert max(idr_sizes) < 0.5 * 0.6 * bps * 1.25, idr_sizes   # within a quarter of the plan's cap
+    assert worst < 0.6 * bps, worst
 
 
 @pytest.mark.parametrize("delay", [0, 1])
@@ -201,10 +231,9 @@ def test_rate_control_emergency_drop_lands_within_a_few_pictures(delay):
         if i == drop_at:
             rc.set_bitrate(500_000)
         idr = i % gop == 0
-        qp = rc.pick_qp(idr)
-        cplx = (9e6 if idr else 1.2e6) * (1 + 0.1 * rng.standard_normal())
-        nbytes = max(40, int(cplx / 2 ** ((qp - 4) / 6) / 8))
-        pend.append((idr, qp, nbytes))
+        qp, drop = rc.pick(idr)
+        nbytes = _synthetic_bytes(rng, idr, qp, drop)
+        pend.append((idr, qp, drop, nbytes))
         if len(pend) > delay:
             rc.update(*pend.pop(0))
         sizes.append(nbytes)

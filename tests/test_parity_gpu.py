@@ -117,7 +117,7 @@ def test_fused_p_kernel_matches_oracle(E, oracle, w, h, qp, drop, sub, intra):
     surf, imv = _settled_field(oracle, cy, ry, qp)
     idec = None
     if intra:
-        idec = oracle.intra_decide(oracle.intra_analyse(cy, cuv), cy.shape[1] // 16, cy.shape[0] // 16, qp, True)
+        idec = oracle.intra_decide(oracle.intra_analyse(cy, cuv), cy.shape[1] // 16, cy.shape[0] // 16, qp, False)  # P pictures: Intra_16x16 only
     o_y, o_uv, o_mbi, o_lev, _ = oracle.pmb_frame(cy, cuv, ry, ruv, imv, surf, qp, drop=drop, refine=sub, idec=idec, threads=8)
     e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp)
     d_y, d_uv, d_mbi, d_lev = e.stage_pmb(cy, cuv, ry, ruv, imv, oracle.surf_to_device(surf), qp, drop=drop, refine=sub, idec=idec)
@@ -135,7 +135,7 @@ def test_fused_p_kernel_exercises_every_branch(oracle):
     f = frames(1280, 720, 2)
     (cy, cuv), (ry, ruv) = f[1][:2], f[0][:2]
     surf, imv = _settled_field(oracle, cy, ry, 30)
-    idec = oracle.intra_decide(oracle.intra_analyse(cy, cuv), 80, 45, 30, True)
+    idec = oracle.intra_decide(oracle.intra_analyse(cy, cuv), 80, 45, 30, False)
     _, _, mbi, lev, (pre, _, _) = oracle.pmb_frame(cy, cuv, ry, ruv, imv, surf, 30, idec=idec, threads=8)
     inter = mbi["mb_type"] == 1
     assert (mbi["mb_type"] != 1).sum() > 5                                  # intra macroblocks in a P picture
@@ -159,6 +159,26 @@ def test_intra_analyse_kernel_matches_oracle(E, oracle, w, h):
         for f in ("mode16", "cmode", "use_i4", "cost", "cost_luma", "modes4"):
             assert np.array_equal(ddec[f], odec[f]), (f, qp, i4, first_diff(ddec[f], odec[f]))
         e.close()
+
+
+@pytest.mark.parametrize("w,h", [(176, 144), (320, 180), (1280, 720), (48, 272)])
+@pytest.mark.parametrize("qp,drop", [(51, 1), (51, 2), (51, 4), (51, 12), (38, 7), (44, 3)])
+@pytest.mark.parametrize("imode", [0, 1])
+def test_intra_kernel_drop_ladder_matches_oracle(E, oracle, w, h, qp, drop, imode):
+    """Rate control's ladder for I pictures (below what QP 51 reaches): Intra_16x16 only, and a macroblock's luma / chroma
+    levels are not sent when their magnitudes sum to no more than the level's threshold."""
+    cy, cuv = frames(w, h, 1)[0][:2]
+    o_y, o_uv, o_mbi, o_lev = oracle.intra_frame(cy, cuv, qp, drop)
+    assert not (o_mbi["mb_type"] == 2).any()
+    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp, intra_mode=imode)
+    d_y, d_uv, d_mbi, d_lev = e.stage_intra(cy, cuv, qp, drop)
+    assert mbinfo_equal(d_mbi, o_mbi, ("mb_type", "i16_mode", "chroma_mode", "cost", "qp", "nzmask")), first_diff(d_mbi["nzmask"], o_mbi["nzmask"])
+    assert np.array_equal(d_lev, o_lev), first_diff(d_lev, o_lev)
+    assert np.array_equal(d_y, o_y), first_diff(d_y, o_y)
+    assert np.array_equal(d_uv, o_uv), first_diff(d_uv, o_uv)
+    if drop == 12:
+        assert not o_lev[:, :280].any() and not o_mbi["nzmask"].any()   # the last level: prediction only
+    e.close()
 
 
 @pytest.mark.parametrize("w,h", SIZES + [(48, 272), (80, 528)])
@@ -252,6 +272,40 @@ def test_high_profile_8x8_transform_equals_oracle(E, oracle, w, h, n, mode):
         e.close()
     finally:
         oracle.set_transform8x8(False)
+
+
+@pytest.mark.parametrize("w,h,depth", [(176, 144, 0), (640, 368, 0), (640, 368, 1), (1920, 1080, 1)])
+def test_drop_ladder_and_all_skip_pictures_equal_oracle(E, oracle, w, h, depth):
+    """What rate control does below QP 51, under test control (fixed QP + fixed drop level): P pictures on every part of the
+    ladder, an IDR picture on its own ladder, runs of all-skip pictures (no device work: the reconstruction is the reference)
+    and the return to normal coding -- access units, reconstruction and the independent decoder all agree with the oracle."""
+    plan = [(40, 0), (51, 0), (51, 2), (51, 7), (51, 12), (51, 255), (51, 255), (51, 5), (51, 3), (46, 0), (51, 255), (51, 9), (30, 0), (51, 12)]
+    n = len(plan) if w < 1000 else 9
+    e = E.Encoder(w, h, gop=8, fixed_qp=40, pipeline_depth=depth, keep_prefilter=True)
+    oe = oracle.Encoder(w, h, gop=8, threads=8)
+    dec = oracle.Decoder()
+    clip = [(y, uv) for _, _, y, uv in frames(w, h, n)]
+    got = []
+    for i, (y, uv) in enumerate(clip):
+        qp, drop = plan[i]
+        e.set_fixed_qp(qp); e.set_fixed_drop(drop)
+        e.submit(y, uv, pts=i)
+        if e.pending > depth:
+            got.append(e.collect() + (e.last_drop,))
+    while e.pending:
+        got.append(e.collect() + (e.last_drop,))
+    for i, (y, uv) in enumerate(clip):
+        qp, drop = plan[i]
+        ref_au, ref_key = oe.encode(y, uv, qp, drop=drop)
+        au, key, pts, gqp, gdrop = got[i]
+        assert (key, pts, gqp) == (ref_key, i, qp) and gdrop == (drop if not (key and drop == 255) else 0)
+        assert au == ref_au, ("bitstream", i, len(au), len(ref_au))
+        if drop == 255 and not key:
+            assert len(au) < 40                                        # a slice header and one skip run
+        dy, duv = dec.decode(au)
+        assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv)
+    assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y) and np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv)
+    e.close()
 
 
 @pytest.mark.parametrize("w,h", [(16, 16), (32, 16), (16, 48), (18, 18), (4096, 32)])
@@ -401,23 +455,6 @@ def test_noise_worst_case_roundtrip(E, oracle):
         assert au == oe.encode(y, uv, qp)[0]
         dy, duv = dec.decode(au)
         assert np.array_equal(dy, e.fetch(E.FETCH_RECON_Y)) and np.array_equal(duv, e.fetch(E.FETCH_RECON_UV))
-    e.close()
-
-
-def test_rate_control_tracks_setpoint_within_one_gop(E):
-    """M4: after a step on the bitrate property the mean rate over the next GOP is within 10 %."""
-    w, h, fps, gop = 640, 368, 30, 30
-    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=2_000_000)
-    sizes = []
-    fr = frames(w, h, 4 * gop)
-    for i, (_, _, y, uv) in enumerate(fr):
-        if i == 2 * gop:
-            e.set_bitrate(1_000_000)
-        sizes.append(len(e.encode(y, uv)[0]))
-    rate = lambda a, b: sum(sizes[a:b]) * 8 * fps / (b - a)
-    assert abs(rate(gop, 2 * gop) - 2_000_000) / 2_000_000 < 0.10, rate(gop, 2 * gop)
-    assert abs(rate(2 * gop, 3 * gop) - 1_000_000) / 1_000_000 < 0.10, rate(2 * gop, 3 * gop)
-    assert abs(rate(3 * gop, 4 * gop) - 1_000_000) / 1_000_000 < 0.10, rate(3 * gop, 4 * gop)
     e.close()
 
 
