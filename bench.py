@@ -257,11 +257,27 @@ def main():
 
     extra = {}
     if rank == 0:
-        # Untimed extras.  (1) quality of the last picture: encoder reconstruction vs its source (luma PSNR).
+        # Untimed extras.  (1) quality: a separate pass over two GOPs of the same clip with the same rate control (and the same
+        # setpoint script), reconstruction fetched after every picture -- mean PSNR of Y, Cb, Cr over ALL its pictures.
         from ceracoder_amd import synth
-        last = frames_np[bounce(args.warmup + args.steps - 1, args.unique)]
-        rec = e.fetch(E.FETCH_RECON_Y)[:height, :width]
-        extra["psnr_y_last_picture_db"] = round(synth.psnr(last[:height], rec), 2)
+        q_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads,
+                          transform8x8=bool(args.dct8x8))
+        nq, ps, qbytes, last_b = (2 * gop if gop > 1 else 30), [], 0, None
+        for i in range(nq):
+            if script:
+                b_ = setpoint(i)
+                if b_ != last_b:
+                    q_enc.set_bitrate(b_)
+                    last_b = b_
+            f = frames_np[bounce(i, args.unique)]
+            qbytes += len(q_enc.encode(f[:height], f[height:], pts=i)[0])
+            ry, ruv = q_enc.fetch(E.FETCH_RECON_Y)[:height, :width], q_enc.fetch(E.FETCH_RECON_UV)[:height // 2, :width]
+            ps.append((synth.psnr(f[:height], ry), synth.psnr(f[height:, 0::2], ruv[:, 0::2]), synth.psnr(f[height:, 1::2], ruv[:, 1::2])))
+        q_enc.close()
+        pm = np.mean(np.array(ps), axis=0)
+        extra["psnr_db"] = {"y": round(float(pm[0]), 2), "u": round(float(pm[1]), 2), "v": round(float(pm[2]), 2), "pictures": nq,
+                            "bitrate_bps": round(qbytes * 8 * fps / nq), "min_y": round(float(np.min(np.array(ps)[:, 0])), 2),
+                            "note": "mean over all pictures of an untimed pass (two GOPs, same clip, same rate control); encoder reconstruction vs source"}
         # (2) per-picture latency of the synchronous path an element in a live graph uses (pipeline_depth 0):
         # host NV12 in -> H2D -> kernels -> D2H -> CAVLC -> access unit out, PCIe included.
         lat_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads)
@@ -299,30 +315,39 @@ def main():
         except Exception:
             prof = None
         P = coded(width) * coded(height)
-        # SURVEY.md 8(d) algorithmic bytes per launch (P = coded luma pixels); sub-pel refinement is not in the survey's
-        # table: cur luma P + reference window P + 16 B/MB record read and written = 2.125 P.
-        ALG = {"me_kernel": 2.03125, "subpel_kernel": 2.125, "inter_kernel": 7.5625, "intra (analyse + x+y wavefront)": 6.0625,
-               "deblock (prep + band16 kernel)": 3.0625}
+        # SURVEY.md 8(d) algorithmic bytes per launch (P = coded luma pixels).  Kernels the survey has no line for: sub-pel
+        # refinement = cur luma P + reference window P + 16 B/MB record read and written = 2.125 P; one vector-selection
+        # iteration = the macroblock's SAD surface read once (35 x 36 uint16) + the three neighbours' vectors + its own 8-byte
+        # result = 2552 B/MB = 9.97 P (the stage this design adds to make the motion search's HBM output do the regularising).
+        ALG = {"me_kernel": 2.03125, "me_select_kernel (one of %d iterations)" % 3: 2552.0 / 256, "subpel_kernel": 2.125, "inter_kernel": 7.5625,
+               "intra (analyse + x+y wavefront)": 6.0625, "deblock (prep + band16 kernel)": 3.0625}
+        SEL = "me_select_kernel (one of %d iterations)" % 3
         db_p = (st.ms_deblock - st.ms_deblock_idr, st.n_deblock - st.n_deblock_idr) if st.n_deblock > st.n_deblock_idr else (st.ms_deblock, st.n_deblock)
-        FUSED = "pmb_kernel (refinement + prediction + residual, fused)"
+        FUSED = "pmb_kernel (skip probe + refinement + intra-or-inter + residual, fused)"
         fused = not args.dct8x8  # the 8x8-transform path keeps subpel_kernel + inter_kernel
-        ALG[FUSED] = 7.5625      # the inter stage's bytes; the refinement re-reads the same reference window from LDS
-        per = {"me_kernel": (st.ms_me, st.n_me), "subpel_kernel": (st.ms_subpel, 0 if fused else st.n_me), ("inter_kernel" if not fused else FUSED): (st.ms_inter, st.n_inter),
+        ALG[FUSED] = 7.5625      # the inter stage's bytes; probe and refinement re-read the same reference window
+        pmb_ms = st.ms_inter - st.ms_analyse_p - st.ms_intra_p if fused else st.ms_inter
+        per = {"me_kernel": (st.ms_me, st.n_me), SEL: (st.ms_select / 3.0, st.n_me), "subpel_kernel": (st.ms_subpel, 0 if fused else st.n_me),
+               ("inter_kernel" if not fused else FUSED): (pmb_ms, st.n_inter),
                "intra (analyse + x+y wavefront)": (st.ms_intra, st.n_intra), "deblock (prep + band16 kernel)": db_p}
-        bound = {"me_kernel": "VALU SAD issue rate (~142 T abs-diff/s chip-wide, tools/ubench_sad.hip): 1089*P abs-diffs -> >=17.6 us @1080p",
+        bound = {"me_kernel": "VALU SAD issue rate (~142 T abs-diff/s chip-wide, tools/ubench_sad.hip): 1089*P abs-diffs -> >=17.6 us @1080p; besides the survey's "
+                              "2.03 P it writes the 9.84 P of SAD surfaces (2520 B per macroblock) that the selection iterations and the fused stage read",
+                 SEL: "HBM / Infinity Cache: streams every macroblock's SAD surface once per iteration",
                  "subpel_kernel": "LDS-staged 6-tap planes, latency/LDS", "inter_kernel": "launch + byte stores of interleaved chroma",
-                 FUSED: "VALU issue: one wave per macroblock, ~1000 instructions (6-tap planes, 16 candidates, transforms on all 64 lanes)",
-                 "intra (analyse + x+y wavefront)": "dependency chain: mbw+mbh-1 dependent launches (hipGraph)",
+                 FUSED: "VALU issue: one wave per macroblock (skip probe; 6-tap planes, 8 SAD + 9 SATD candidates; transforms on all 64 lanes; decimation)",
+                 "intra (analyse + x+y wavefront)": "dependency chain: mbw+mbh-1 dependent steps of the persistent band kernel",
                  "deblock (prep + band16 kernel)": "dependency chain of the normative filter order: ~mbw+mbh dependent steps of ~1.5 us inside one persistent launch"}
-        pmc_name = {"me_kernel": "me_kernel", "deblock (prep + band16 kernel)": "deblock_band16_kernel"}
+        pmc_name = {"me_kernel": "me_kernel", SEL: "me_select_kernel", FUSED: "pmb_kernel", "intra (analyse + x+y wavefront)": "intra_band_kernel",
+                    "deblock (prep + band16 kernel)": "deblock_band16_kernel"}
         kernels = []
-        n_idr, n_p = int(st.idr_frames), int(st.frames - st.idr_frames)
-        weight = {"me_kernel": n_p, "subpel_kernel": n_p, "inter_kernel": n_p, FUSED: n_p, "intra (analyse + x+y wavefront)": n_idr,
-                  "deblock (prep + band16 kernel)": n_idr + n_p}  # pictures of the timed region each kernel ran in (timers are sampled)
+        n_idr, n_p = int(st.idr_frames), int(st.frames - st.idr_frames - st.skip_pictures)
+        weight = {"me_kernel": n_p, SEL: 3 * n_p, "subpel_kernel": n_p, "inter_kernel": n_p, FUSED: n_p, "intra (analyse + x+y wavefront)": n_idr,
+                  "deblock (prep + band16 kernel)": n_idr + n_p}  # launches in the timed region (timers are sampled)
         db_i_avg = st.ms_deblock_idr / st.n_deblock_idr if st.n_deblock_idr else 0.0
         if n_p and st.n_deblock_idr:  # deblocking of P pictures is the roofline entry; IDR pictures are added to the total separately
             weight["deblock (prep + band16 kernel)"] = n_p
-        est_total = (sum(weight[k] * (ms / n) for k, (ms, n) in per.items() if n) + (n_idr * db_i_avg if n_p else 0.0)) or 1e-9
+        other_p = (st.ms_analyse_p + st.ms_intra_p) / max(1, st.n_inter)  # gated intra analysis + intra macroblocks of P pictures
+        est_total = (sum(weight[k] * (ms / n) for k, (ms, n) in per.items() if n) + (n_idr * db_i_avg if n_p else 0.0) + n_p * other_p) or 1e-9
         for name, (ms, n) in per.items():
             if not n:
                 continue
@@ -339,21 +364,31 @@ def main():
                 "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                 "launches": dom["launches_timed"], "kernel_trace_avg_us": dom["kernel_trace_avg_us"], "time_share": dom["time_share"],
                 "note": "dominant kernel by GPU time; " + dom["bounded_by"] + ". Every kernel of the path is listed in roofline_kernels "
-                        "(the motion search north_star names is 'me_kernel')."}
+                        "(the motion search north_star names is 'me_kernel'; the HBM-shaped one is the vector selection)."}
+        # picture times from the stage timers (kernel time only, no launch gaps): what a GOP costs, whatever part of it the timed region saw
+        t_p = (st.ms_me + st.ms_select) / max(1, st.n_me) + st.ms_inter / max(1, st.n_inter) + st.ms_subpel / max(1, st.n_me) + db_p[0] / max(1, db_p[1])
+        t_i = st.ms_intra / max(1, st.n_intra) + db_i_avg
+        gop_fps = (1e3 * gop / ((gop - 1) * t_p + t_i)) if (gop > 1 and st.n_me and st.n_intra) else None
         out = {
             "metric": "1080p H.264 encoded frames/sec per GPU" if args.workload.startswith("1080p") else "H.264 encoded frames/sec per GPU",
             "value": round(world * S * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / (S * args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic (S2: panning texture + 12 moving rectangles, seed 0x5EED), resident in HBM",
-            "config": {"workload": args.workload, "width": width, "height": height, "fps_nominal": fps, "gop": gop,
+            "idr_in_timed_region": n_idr, "skip_pictures_in_timed_region": int(st.skip_pictures),
+            "gop_weighted_frames_per_s": round(gop_fps, 1) if gop_fps else None,
+            "gop_weighted_note": "gop / ((gop-1) * P-picture kernel time + IDR-picture kernel time) from the stage timers: what the device sustains over whole GOPs, "
+                                 "independent of how many IDR pictures the timed region happened to contain (an upper bound: launch gaps excluded)",
+            "config": {"workload": args.workload, "width": width, "height": height, "fps_nominal": fps, "gop": gop, "h2d_in_timed_region": False,
                        "rate_control": ("fixed qp %d" % args.fixed_qp) if args.fixed_qp >= 0 else ("cbr %d bit/s" % bps) if not script else
                        "cbr, setpoint driven by the reference's '%s' balancer script (%d..%d kbit/s, tests/golden/balancer_%s.txt)" % (
                            script_name, min(b for _, b in script) // 1000, max(b for _, b in script) // 1000, script_name),
-                       "me": "full search +-16 integer-pel SAD + half/quarter-sample refinement", "streams_per_gpu": S, "parallelism": "%d independent streams" % (world * S),
+                       "me": "full search +-16 integer-pel SAD (surfaces kept) + %d median-regularised selection iterations + half-sample SAD / quarter-sample SATD refinement" % 3, "streams_per_gpu": S, "parallelism": "%d independent streams" % (world * S),
                        "pipeline_depth": args.depth, "dct8x8": bool(args.dct8x8), "cavlc_threads": int(st.cavlc_threads)},
             "roofline": roof,
             "roofline_kernels": kernels,
-            "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), ("refine_inter_fused" if fused else "inter"): round(st.ms_inter / max(1, st.n_inter), 4),
+            "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "me_select_x3": round(st.ms_select / max(1, st.n_me), 4),
+                                     ("p_stage_total" if fused else "inter"): round(st.ms_inter / max(1, st.n_inter), 4),
+                                     "p_intra_analyse_gated": round(st.ms_analyse_p / max(1, st.n_inter), 4), "p_intra_macroblocks": round(st.ms_intra_p / max(1, st.n_inter), 4),
                                      "subpel": round(st.ms_subpel / max(1, st.n_me), 4),
                                      "intra_wavefront": round(st.ms_intra / max(1, st.n_intra), 4),
                                      "deblock_wavefront": round(db_p[0] / max(1, db_p[1]), 4), "deblock_wavefront_idr": round(db_i_avg, 4),

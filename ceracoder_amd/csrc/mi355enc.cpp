@@ -366,6 +366,7 @@ static void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr) {
 // the device steps of a P picture up to (not including) deblocking; hc: host copy of the context (every kernel takes it by value)
 static int run_p_picture(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof) {
     k_launch_me(hc, h->mbw, 0, h->mbh, h->stream);
+    if (prof) HIPCHK(hipEventRecord(s->ev[6], h->stream));
     for (int it = 0; it < ME_ITERS; it++) k_launch_me_select(hc, h->mbw, 0, h->mbh, (it & 1) ? hc->imv_b : hc->imv_a, (it & 1) ? hc->imv_a : hc->imv_b, h->stream);
     if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
     if (h->cfg.transform8x8) { // High profile: the two-kernel form (absolute-vector refinement, 8x8 transform), no skip / intra logic
@@ -375,6 +376,7 @@ static int run_p_picture(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int pr
         k_launch_inter(hc, h->mbw, 0, h->mbh, h->stream);
     } else {
         if (hc->intra_p) k_launch_intra_analyse(hc, h->mbw, h->mbh, 1, h->stream);
+        if (prof) HIPCHK(hipEventRecord(s->ev[7], h->stream));
         k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, h->stream);
         if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
         if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
@@ -576,7 +578,14 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
         float a = 0, b = 0, c = 0, tot = 0, sp = 0;
         {
             HIPCHK(hipEventSynchronize(s->ev[4])); // the access unit is ready before deblocking ends; the stage timers are not
-            (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
+            float sel = 0, an = 0, ip = 0;
+            if (s->is_idr) (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
+            else {
+                (void)hipEventElapsedTime(&a, s->ev[0], s->ev[6]);
+                (void)hipEventElapsedTime(&sel, s->ev[6], s->ev[1]);
+                if (s->fused) { (void)hipEventElapsedTime(&an, s->ev[1], s->ev[7]); (void)hipEventElapsedTime(&ip, s->ev[5], s->ev[11]); }
+                h->st.ms_select += sel; h->st.ms_analyse_p += an; h->st.ms_intra_p += ip;
+            }
             if (!s->is_idr) {
                 if (s->fused) (void)hipEventElapsedTime(&b, s->ev[1], s->ev[11]); // intra analysis of the gated macroblocks + fused stage + intra macroblocks, booked as inter
                 else { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
@@ -611,10 +620,10 @@ int mi355enc_get_stats(mi355enc_t *h, mi355enc_stats_t *st) {
     *st = h->st;
     st->target_bps = h->want_bps.load();
     st->cavlc_threads = (uint32_t)h->cfg.cavlc_threads;
-    st->ms_open = h->ms_open;
+    st->ms_open = h->ms_open; st->skip_pictures = h->n_skip_pictures;
     return MI355ENC_OK;
 }
-void mi355enc_reset_stats(mi355enc_t *h) { if (h) memset(&h->st, 0, sizeof h->st); }
+void mi355enc_reset_stats(mi355enc_t *h) { if (h) { memset(&h->st, 0, sizeof h->st); h->n_skip_pictures = 0; } }
 
 int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
     if (!h || !dst) return MI355ENC_ERR_ARG;

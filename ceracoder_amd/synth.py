@@ -81,6 +81,34 @@ def s2_frames(width, height, count, seed=S2_SEED, start=0):
         yield y, uv
 
 
+def s1_frames(width, height, count):
+    """S1 "reference-faithful": what `videotestsrc` (default pattern, SMPTE bars) feeds the reference's test pipelines
+    (/root/reference/bindings/typescript/src/pipeline/generic-builder.ts:94) -- a still picture of colour bars, restated here
+    (75 % bars over two thirds of the height, a reverse strip, a luminance ramp strip with a noise patch at the right as in
+    the GStreamer pattern; the noise patch is the only thing that changes between pictures).  Trivial for motion search:
+    reported, never the headline."""
+    bars = [(180, 128, 128), (162, 44, 142), (131, 156, 44), (112, 72, 58), (84, 184, 198), (65, 100, 212), (35, 212, 114)]  # Y Cb Cr, 75 % white yellow cyan green magenta red blue
+    y = np.empty((height, width), np.uint8)
+    cb = np.empty((height // 2, width // 2), np.uint8)
+    cr = np.empty((height // 2, width // 2), np.uint8)
+    h1, h2 = (2 * height // 3) & ~1, (3 * height // 4) & ~1
+    for i, (yy, u, v) in enumerate(bars):
+        x0, x1 = (i * width // 7) & ~1, ((i + 1) * width // 7) & ~1 if i < 6 else width
+        y[:h1, x0:x1] = yy; cb[:h1 // 2, x0 // 2:x1 // 2] = u; cr[:h1 // 2, x0 // 2:x1 // 2] = v
+        ry, ru, rv = bars[6 - i] if i % 2 == 0 else (16, 128, 128)
+        y[h1:h2, x0:x1] = ry; cb[h1 // 2:h2 // 2, x0 // 2:x1 // 2] = ru; cr[h1 // 2:h2 // 2, x0 // 2:x1 // 2] = rv
+    ramp = np.linspace(16, 235, width).astype(np.uint8)
+    y[h2:] = ramp[None, :]; cb[h2 // 2:] = 128; cr[h2 // 2:] = 128
+    g = np.random.Generator(np.random.PCG64(0x51))
+    nx = (5 * width // 6) & ~1
+    for _ in range(count):
+        yf = y.copy()
+        yf[h2:, nx:] = g.integers(16, 236, (height - h2, width - nx), dtype=np.uint8)
+        uv = np.empty((height // 2, width), np.uint8)
+        uv[:, 0::2] = cb; uv[:, 1::2] = cr
+        yield yf, uv
+
+
 def s4_frames(width, height, count, seed=0x11FE, pan_after=None):
     """S4 "live camera": a still textured scene with fresh sensor noise (+-2) on every picture, a few moving objects, and
     (optionally, from picture `pan_after` on) a slow pan of 1 px/frame -- what a contribution encoder sees most of the time,

@@ -93,6 +93,10 @@ typedef struct {
     uint64_t n_deblock_idr;
     uint32_t cavlc_threads;   /* host threads in use for entropy coding (cfg.cavlc_threads resolved) */
     uint32_t last_drop;       /* drop level of the last collected picture (0: none; 1 .. 12: the ladder below QP 51; 255: all-skip picture) */
+    double ms_select;         /* P pictures: the ME_ITERS vector-selection iterations (not part of ms_me), n_me samples */
+    double ms_analyse_p;      /* P pictures: intra analysis of the gated macroblocks, n_inter samples (also contained in ms_inter) */
+    double ms_intra_p;        /* P pictures: reconstruction of the intra macroblocks, n_inter samples (also contained in ms_inter) */
+    uint64_t skip_pictures;   /* pictures coded as one P_Skip run (rate control's last resort) */
     double ms_open;           /* wall time mi355enc_open() took (device selection, allocations, stream creation): must stay far below
                                  the 1 s tick of the reference's stall watchdog, /root/reference/src/ceracoder.c:152-200; survives reset_stats */
 } mi355enc_stats_t;
