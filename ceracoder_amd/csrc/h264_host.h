@@ -47,6 +47,7 @@ typedef struct {
     int gop_left, started;     /* pictures of the current GOP still to be picked    */
     double vbv;                /* leaky bucket at the setpoint's rate, bits         */
     double last_bits_p, last_target_p; /* the last P picture whose size is known: what it took, what it was given */
+    int since_real;            /* P pictures coded as skip runs since the last really coded one */
     double cliff_bits; int cliff_vqp, cliff_age; /* the quantiser at which a P picture last cost several times its target, what it cost, pictures left to remember it */
     int last_vqp_i, last_vqp_p;
     int have_i, have_p;

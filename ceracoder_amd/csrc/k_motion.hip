@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int my = row0 + tile / strips, sx = tile % strips; // the launch covers macroblock rows row0 .. row0 + gridDim.x / strips - 1
     const int t = threadIdx.x;
-    const uint8_t *__restrict__ ref = ctx->ref_y;
+    const uint8_t *__restrict__ ref = ctx->me_ref_y; // source against source: the padded source luma of the last coded picture (oracle: orc_enc_frame2)
 
     // ---- stage the window: 48 rows x 10 uint4 (coalesced 16 B per lane); rows / 16-byte groups beyond the picture repeat its edge
     for (int i = t; i < 48 * ME_WQ; i += 64 * ME_MBS) {
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
             sy = sy < vh ? sy : vh - 1;
             uint4 v = ldg128(src + (size_t)sy * ss + mxc * 16);
             c[r][0] = v.x; c[r][1] = v.y; c[r][2] = v.z; c[r][3] = v.w;
+            if (lane == r && mx < mbw) stg128(ctx->psrc_out + (size_t)(my * 16 + r) * stride + mxc * 16, v); // the next picture searches against this
         }
     }
     __syncthreads();
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
                 pmb_store_pred_only(ctx, lv, lane, x0, y0, pw, pd);
                 if (lane == 0) {
                     mb_info_t m;
-                    m.mvx = (int16_t)fp.sx; m.mvy = (int16_t)fp.sy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = ds;
+                    m.mvx = (int16_t)fp.sx; m.mvy = (int16_t)fp.sy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = di;
                     st_mbinfo(mb, m);
                 }
                 return;
@@ -618,7 +619,10 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
         }
     WAVE_SYNC();
     int bqx = imx, bqy = imy;
-    unsigned best = di + (unsigned)(lambda * (mvq_bits(imx - fp.px) + mvq_bits(imy - fp.py)));
+    // the whole-sample winner's SAD against the REFERENCE (the surface holds its SAD against the previous source: the search runs
+    // source against source)
+    unsigned best = (unsigned)wave64_sum((int)__builtin_amdgcn_sad_u8(curw, sp_sample4(L, 1 + pc, 1 + pr, 0, 0), 0u)) +
+                    (unsigned)(lambda * (mvq_bits(imx - fp.px) + mvq_bits(imy - fp.py)));
     if (refine) {
         sp_planes(L, lane);
         { // half-sample round: SAD, the 8 candidates scored together (two 16-bit partial sums per register)
@@ -688,7 +692,7 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
         pmb_store_pred_only(ctx, lv, lane, x0, y0, pw, pd);
         if (lane == 0) {
             mb_info_t m;
-            m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = jinter;
+            m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = di;
             st_mbinfo(mb, m);
         }
         return;
@@ -716,10 +720,25 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
         if (dc_c & 1) nzm |= NZ_CBDC;
         if (dc_c & 2) nzm |= NZ_CRDC;
         mb_info_t m;
-        m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = nzm; m.cost = jinter;
+        m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = nzm; m.cost = di;
         st_mbinfo(mb, m);
     }
     if (lane < 2) stg128(lv + L_LDC + 8 * lane, make_uint4(0, 0, 0, 0)); // luma DC levels: unused by P macroblocks, kept zero
+}
+
+// I pictures: the padded source luma for the next picture's search (P pictures: me_kernel writes it on its way)
+__global__ __launch_bounds__(256) void copy_luma_kernel(const frame_ctx_t cv) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    const int W = ctx->mbw * 16, H = ctx->mbh * 16, per_row = W / 16;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_row * H) return;
+    const int y = i / per_row, x = (i - y * per_row) * 16;
+    const int sy = y < ctx->vis_h ? y : ctx->vis_h - 1;
+    stg128(ctx->psrc_out + (size_t)y * ctx->stride + x, ldg128(ctx->src_y + (size_t)sy * ctx->src_stride + x));
+}
+void k_launch_copy_luma(const frame_ctx_t *h_ctx, hipStream_t s) {
+    const int n = h_ctx->mbw * h_ctx->mbh * 16;
+    hipLaunchKernelGGL(copy_luma_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *h_ctx);
 }
 
 // whole-sample field -> records for the two-kernel (8x8-transform) path: subpel_kernel compares absolute-vector costs

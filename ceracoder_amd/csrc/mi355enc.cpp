@@ -48,6 +48,7 @@ struct slot_t {
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
     uint8_t *d_raw;              // staging of non-NV12 input before the conversion kernel (allocated on first use)
     hipEvent_t done, gpu_done, ev[12];
+    hipEvent_t ev_front;       // the front stream's part of the picture is done (source in place, search + selection + analysis)
     int prof, fused;
     int all_skip;              // the picture is one run of P_Skip macroblocks: written by the host alone, no device work
     uint64_t index;            // position of the picture in the stream
@@ -59,7 +60,10 @@ struct mi355enc {
     mi355enc_cfg_t cfg;
     int mbw, mbh, W, H, nmb;
     size_t ysz, csz;
-    hipStream_t stream;                  // main compute stream
+    hipStream_t stream;                  // "back" stream: everything of a picture that needs the picture before it -- fused P stage / intra wavefront, deblocking
+    hipStream_t fstream;                 // "front" stream: source upload / conversion, and for P pictures the whole-sample search, the vector selection
+                                         // and the gated intra analysis (source against source: nothing of the previous picture's coding is needed, so
+                                         // they run beside its deblocking)
     frame_ctx_t *d_ctx, *d_ctx2[2];      // one context per picture parity (two pictures are in flight on the device); d_ctx = d_ctx2[0]
     slot_t *prev_slot;                   // slot of the picture enqueued last
     mb_info_t *d_mbi, *d_mbi_set[2];     // two record/level sets: the D2H of picture n overlaps the kernels of n+1
@@ -74,8 +78,11 @@ struct mi355enc {
     unsigned *d_progress; // two sets (picture parity) of [2*bands] strip counters of the band deblocker, then one error word
     unsigned *d_iprogress; // progress counters of the persistent intra kernel, one per band
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
-    uint16_t *d_surf;     // SAD surfaces of the motion search, SURF_U16 per macroblock
-    imv_t *d_imv[2];      // whole-sample vector fields (search result / selection iterations alternate)
+    uint16_t *d_surf[2];  // SAD surfaces of the motion search, SURF_U16 per macroblock; two sets (picture parity): the front stages of picture n+1 run beside the back stages of n
+    imv_t *d_imv[2][2];   // whole-sample vector fields (search result / selection iterations alternate), per set
+    uint8_t *d_idec2[2];  // intra decisions per set (d_idec = set 0)
+    uint8_t *d_psrc[2];   // padded source luma of the last two coded pictures: the search runs source against source
+    int psrc_cur;         // which of them holds the last coded picture
     unsigned *d_ip_progress; // intra macroblocks of P pictures: one progress word per macroblock row (epoch-tagged, never cleared)
     uint8_t *d_ip_strips;    // ... and the bottom lines they publish for the row below, 32 bytes per macroblock
     uint32_t epoch;
@@ -205,7 +212,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf = nullptr; h->d_imv[0] = h->d_imv[1] = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -220,6 +227,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, lo));
     }
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&h->d_mbi_set[i], (size_t)h->nmb * sizeof(mb_info_t)));
@@ -237,12 +245,18 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t)));
     HIPCHK(hipMalloc((void **)&h->d_dbrec, (size_t)h->nmb * 64));
     HIPCHK(hipMalloc((void **)&h->d_idec, (size_t)h->nmb * IDEC_BYTES + 16));
+    h->d_idec2[0] = h->d_idec;
     h->n_progress = 3 * k_deblock_bands16(h->mbh); // per set: luma counters, chroma counters, per-band "has work" flags
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
-    HIPCHK(hipMalloc((void **)&h->d_surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t)));
-    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_imv[i], (size_t)h->nmb * sizeof(imv_t)));
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(hipMalloc((void **)&h->d_surf[k], (size_t)h->nmb * SURF_U16 * sizeof(uint16_t)));
+        for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_imv[k][i], (size_t)h->nmb * sizeof(imv_t)));
+        HIPCHK(hipMalloc((void **)&h->d_psrc[k], h->ysz + SURF_PAD));
+        HIPCHK(hipMemsetAsync(h->d_psrc[k], 0, h->ysz + SURF_PAD, h->stream));
+    }
+    HIPCHK(hipMalloc((void **)&h->d_idec2[1], (size_t)h->nmb * IDEC_BYTES + 16));
     HIPCHK(hipMalloc((void **)&h->d_ip_progress, (size_t)h->mbh * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_ip_progress, 0, (size_t)h->mbh * sizeof(unsigned), h->stream)); // epoch-tagged: the epoch starts at 1
     HIPCHK(hipMalloc((void **)&h->d_ip_strips, (size_t)h->nmb * 32));
@@ -263,6 +277,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMalloc((void **)&s->d_src_uv, h->csz + SURF_PAD));
         HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->gpu_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_front, hipEventDisableTiming));
         for (int k = 0; k < 12; k++) HIPCHK(hipEventCreate(&s->ev[k]));
     }
     h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
@@ -283,6 +298,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
 void mi355enc_close(mi355enc_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device_id);
+    if (h->fstream) (void)hipStreamSynchronize(h->fstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 2; i++) { if (h->g_intra[i]) (void)hipGraphExecDestroy(h->g_intra[i]); if (h->g_deblock[i]) (void)hipGraphExecDestroy(h->g_deblock[i]); }
     for (int i = 0; i < NSLOT; i++) {
@@ -296,6 +312,7 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->d_raw) (void)hipFree(s->d_raw);
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->gpu_done) (void)hipEventDestroy(s->gpu_done);
+        if (s->ev_front) (void)hipEventDestroy(s->ev_front);
         for (int k = 0; k < 12; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
     }
     for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
@@ -306,14 +323,19 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_idec) (void)hipFree(h->d_idec);
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->d_off) (void)hipFree(h->d_off);
-    if (h->d_surf) (void)hipFree(h->d_surf);
-    for (int i = 0; i < 2; i++) if (h->d_imv[i]) (void)hipFree(h->d_imv[i]);
+    for (int k = 0; k < 2; k++) {
+        if (h->d_surf[k]) (void)hipFree(h->d_surf[k]);
+        for (int i = 0; i < 2; i++) if (h->d_imv[k][i]) (void)hipFree(h->d_imv[k][i]);
+        if (h->d_psrc[k]) (void)hipFree(h->d_psrc[k]);
+    }
+    if (h->d_idec2[1]) (void)hipFree(h->d_idec2[1]);
     if (h->d_ip_progress) (void)hipFree(h->d_ip_progress);
     if (h->d_ip_strips) (void)hipFree(h->d_ip_strips);
     if (h->d_iprogress) (void)hipFree(h->d_iprogress);
     for (int i = 0; i < 2; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
     for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
+    if (h->fstream) (void)hipStreamDestroy(h->fstream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h264_writer_free(h->writer);
     delete h;
@@ -341,21 +363,23 @@ int mi355enc_mb_width(const mi355enc_t *h) { return h ? h->mbw : 0; }
 int mi355enc_mb_height(const mi355enc_t *h) { return h ? h->mbh : 0; }
 
 static int sync_compute(mi355enc_t *h) {
+    HIPCHK(hipStreamSynchronize(h->fstream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
-static hipStream_t upload_stream(const mi355enc_t *h) { return h->stream; }
+static hipStream_t upload_stream(const mi355enc_t *h) { return h->fstream; }
 
 // rate control's ladder below QP 51 (oracle: k_drop_sad): the SAD under which a P macroblock carries no residual / takes the skip vector
 static const uint32_t k_drop_sad[DROP_MAX + 1] = {0, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 0xFFFFFFFFu};
 // ... and its counterpart for I pictures (oracle: k_idrop_ac): the sum of level magnitudes up to which a macroblock's luma / chroma residual is not sent
 static const int32_t k_idrop_ac[DROP_MAX + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64, 0x7FFFFFFF};
 
-static void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr) {
-    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec;
+static void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set = 0) {
+    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec2[set];
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
-    c->surf = h->d_surf; c->imv_a = h->d_imv[0]; c->imv_b = h->d_imv[1];
+    c->surf = h->d_surf[set]; c->imv_a = h->d_imv[set][0]; c->imv_b = h->d_imv[set][1];
+    c->me_ref_y = h->d_psrc[h->psrc_cur]; c->psrc_out = h->d_psrc[h->psrc_cur ^ 1];
     if (++h->epoch == 0) h->epoch = 1;
     c->epoch = h->epoch;
     c->drop_sad = (!idr && drop > 0 && drop <= DROP_MAX) ? k_drop_sad[drop] : 0;
@@ -363,25 +387,34 @@ static void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr) {
     if (c->iac_drop) c->i4x4 = 0; // on the ladder: Intra_16x16 only
     c->intra_p = (h->cfg.intra_in_p && !h->cfg.transform8x8) ? 1 : 0;
 }
-// the device steps of a P picture up to (not including) deblocking; hc: host copy of the context (every kernel takes it by value)
-static int run_p_picture(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof) {
-    k_launch_me(hc, h->mbw, 0, h->mbh, h->stream);
-    if (prof) HIPCHK(hipEventRecord(s->ev[6], h->stream));
-    for (int it = 0; it < ME_ITERS; it++) k_launch_me_select(hc, h->mbw, 0, h->mbh, (it & 1) ? hc->imv_b : hc->imv_a, (it & 1) ? hc->imv_a : hc->imv_b, h->stream);
-    if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
+// P picture, front part (front stream): nothing here depends on the coding of the picture before
+static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof) {
+    hipStream_t st = h->fstream;
+    if (prof) HIPCHK(hipEventRecord(s->ev[0], st));
+    k_launch_me(hc, h->mbw, 0, h->mbh, st);
+    if (prof) HIPCHK(hipEventRecord(s->ev[6], st));
+    for (int it = 0; it < ME_ITERS; it++) k_launch_me_select(hc, h->mbw, 0, h->mbh, (it & 1) ? hc->imv_b : hc->imv_a, (it & 1) ? hc->imv_a : hc->imv_b, st);
+    if (prof) HIPCHK(hipEventRecord(s->ev[1], st));
+    if (!h->cfg.transform8x8 && hc->intra_p) k_launch_intra_analyse(hc, h->mbw, h->mbh, 1, st);
+    if (prof) HIPCHK(hipEventRecord(s->ev[7], st));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// ... and back part (back stream): needs the deblocked picture before it
+static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof) {
+    hipStream_t st = h->stream;
+    if (prof) HIPCHK(hipEventRecord(s->ev[8], st));
     if (h->cfg.transform8x8) { // High profile: the two-kernel form (absolute-vector refinement, 8x8 transform), no skip / intra logic
-        k_launch_imv_to_mbi(hc, h->mbw, 0, h->mbh, h->stream);
-        if (h->cfg.subpel) k_launch_subpel(hc, h->mbw, 0, h->mbh, h->stream);
-        if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
-        k_launch_inter(hc, h->mbw, 0, h->mbh, h->stream);
+        k_launch_imv_to_mbi(hc, h->mbw, 0, h->mbh, st);
+        if (h->cfg.subpel) k_launch_subpel(hc, h->mbw, 0, h->mbh, st);
+        if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
+        k_launch_inter(hc, h->mbw, 0, h->mbh, st);
     } else {
-        if (hc->intra_p) k_launch_intra_analyse(hc, h->mbw, h->mbh, 1, h->stream);
-        if (prof) HIPCHK(hipEventRecord(s->ev[7], h->stream));
-        k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, h->stream);
-        if (prof) HIPCHK(hipEventRecord(s->ev[5], h->stream));
-        if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
+        k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, st);
+        if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
+        if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
     }
-    if (prof) HIPCHK(hipEventRecord(s->ev[11], h->stream));
+    if (prof) HIPCHK(hipEventRecord(s->ev[11], st));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -424,17 +457,24 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
         c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
         c->vis_h = h->cfg.height;
-        fill_ctx(h, c, qp, drop, idr);
+        fill_ctx(h, c, qp, drop, idr, set);
         c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set];
         // Every kernel of the default path takes the context by value; only the kernels replayed from a hipGraph
         // (intra_mode 1, deblock_mode 1) read the device copy, so only those pictures pay for an upload.
         if ((idr && h->cfg.intra_mode != 0) || h->cfg.deblock_mode != 0) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
-        if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
+        // front stream: the source is in place (upload / conversion were enqueued there); P pictures: search, selection, gated intra
+        // analysis; I pictures: only the padded source copy the next picture's search will run against
+        if (idr) k_launch_copy_luma(c, h->fstream);
+        else { int r = run_p_front(h, c, s, prof); if (r) return r; }
+        HIPCHK(hipEventRecord(s->ev_front, h->fstream));
+        HIPCHK(hipStreamWaitEvent(h->stream, s->ev_front, 0));
+        h->psrc_cur ^= 1;
         if (idr) {
+            if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
             int r = run_intra(h, ci, c); if (r) return r;
             if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
         } else {
-            int r = run_p_picture(h, c, s, prof); if (r) return r;
+            int r = run_p_back(h, c, s, prof); if (r) return r;
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
@@ -579,19 +619,20 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
         {
             HIPCHK(hipEventSynchronize(s->ev[4])); // the access unit is ready before deblocking ends; the stage timers are not
             float sel = 0, an = 0, ip = 0;
-            if (s->is_idr) (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]);
-            else {
+            if (s->is_idr) { (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]); (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]); }
+            else { // front-stream stages and back-stream stages are timed on their own streams; the picture's total is their sum
+                float fe = 0, be = 0;
                 (void)hipEventElapsedTime(&a, s->ev[0], s->ev[6]);
                 (void)hipEventElapsedTime(&sel, s->ev[6], s->ev[1]);
-                if (s->fused) { (void)hipEventElapsedTime(&an, s->ev[1], s->ev[7]); (void)hipEventElapsedTime(&ip, s->ev[5], s->ev[11]); }
+                (void)hipEventElapsedTime(&an, s->ev[1], s->ev[7]);
+                (void)hipEventElapsedTime(&fe, s->ev[0], s->ev[7]);
+                (void)hipEventElapsedTime(&be, s->ev[8], s->ev[4]);
+                tot = fe + be;
+                if (s->fused) { (void)hipEventElapsedTime(&b, s->ev[8], s->ev[11]); b += an; (void)hipEventElapsedTime(&ip, s->ev[5], s->ev[11]); } // analysis + fused stage + intra macroblocks, booked as inter
+                else { (void)hipEventElapsedTime(&sp, s->ev[8], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
                 h->st.ms_select += sel; h->st.ms_analyse_p += an; h->st.ms_intra_p += ip;
             }
-            if (!s->is_idr) {
-                if (s->fused) (void)hipEventElapsedTime(&b, s->ev[1], s->ev[11]); // intra analysis of the gated macroblocks + fused stage + intra macroblocks, booked as inter
-                else { (void)hipEventElapsedTime(&sp, s->ev[1], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
-            }
             (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
-            (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]);
         }
         if (s->is_idr) { h->st.ms_intra += a; h->st.n_intra++; }
         else { h->st.ms_me += a; h->st.n_me++; h->st.ms_inter += b; h->st.n_inter++; h->st.ms_subpel += sp; }
@@ -671,11 +712,12 @@ static int upload_luma_pair(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *
 int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, uint16_t *surf_out, void *imv_out) {
     if (!h || !cur_y || !ref_y || !imv_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
-    int r = upload_luma_pair(h, cur_y, ref_y); if (r) return r;
-    r = stage_ctx(h, qp, true); if (r) return r;
+    HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, cur_y, h->ysz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_psrc[h->psrc_cur], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream)); // what the search runs against (in the encoder: the previous source)
+    int r = stage_ctx(h, qp, true); if (r) return r;
     k_launch_me(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
-    HIPCHK(hipMemcpyAsync(imv_out, h->d_imv[0], (size_t)h->nmb * sizeof(imv_t), hipMemcpyDeviceToHost, h->stream));
-    if (surf_out) HIPCHK(hipMemcpyAsync(surf_out, h->d_surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(imv_out, h->d_imv[0][0], (size_t)h->nmb * sizeof(imv_t), hipMemcpyDeviceToHost, h->stream));
+    if (surf_out) HIPCHK(hipMemcpyAsync(surf_out, h->d_surf[0], (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }
@@ -683,10 +725,10 @@ int mi355enc_stage_me_select(mi355enc_t *h, const uint16_t *surf, const void *im
     if (!h || !surf || !imv_in || !imv_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     int r = stage_ctx(h, qp, true); if (r) return r;
-    HIPCHK(hipMemcpyAsync(h->d_surf, surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_imv[0], imv_in, (size_t)h->nmb * sizeof(imv_t), hipMemcpyHostToDevice, h->stream));
-    k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0], h->d_imv[1], h->stream);
-    HIPCHK(hipMemcpyAsync(imv_out, h->d_imv[1], (size_t)h->nmb * sizeof(imv_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_surf[0], surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_imv[0][0], imv_in, (size_t)h->nmb * sizeof(imv_t), hipMemcpyHostToDevice, h->stream));
+    k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], h->stream);
+    HIPCHK(hipMemcpyAsync(imv_out, h->d_imv[0][1], (size_t)h->nmb * sizeof(imv_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }
@@ -737,7 +779,7 @@ int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_u
     frame_ctx_t *c = h->slot[0].h_ctx;
     c->intra_p = idec ? 1 : 0;
     HIPCHK(hipMemcpyAsync((void *)k_final_imv(c), imv, (size_t)h->nmb * sizeof(imv_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_surf, surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_surf[0], surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
     if (idec) HIPCHK(hipMemcpyAsync(h->d_idec, idec, (size_t)h->nmb * IDEC_BYTES, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->d_rec_y[1], 0, h->ysz, h->stream)); // macroblocks decided intra stay untouched unless run_intra_p
     HIPCHK(hipMemsetAsync(h->d_rec_uv[1], 0, h->csz, h->stream));
@@ -801,7 +843,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
             else if (stage == 1) k_launch_inter(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 2) { int r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r; }
             else if (stage == 4) k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
-            else if (stage == 8) k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0], h->d_imv[1], h->stream);
+            else if (stage == 8) k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], h->stream);
             else if (stage == 9) k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, 1, h->stream);
             else if (stage == 10) k_launch_intra_p(h->slot[0].h_ctx, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
             else if (stage >= 5) {

@@ -69,6 +69,8 @@ typedef struct {
     int32_t t8;                    /* P macroblocks use the 8x8 transform (High profile stream) */
     int32_t all_intra;             /* every macroblock of the picture is intra (IDR): the deblocker runs all edges without per-edge tests */
     /* P pictures */
+    const uint8_t *me_ref_y;       /* what the whole-sample search runs against: the padded SOURCE luma of the last coded picture (coded size, stride `stride`) */
+    uint8_t *psrc_out;             /* where this picture's padded source luma goes for the next picture's search (written by me_kernel / copy_luma_kernel) */
     uint16_t *surf;                /* SAD surfaces, SURF_U16 per macroblock */
     imv_t *imv_a, *imv_b;          /* whole-sample vector fields: the search writes imv_a, the selection iterations alternate; ME_ITERS odd -> final in imv_b */
     uint32_t epoch;                /* picture stamp (never 0): tags the progress words of intra_p_kernel so that nothing needs clearing */
@@ -87,6 +89,7 @@ typedef struct {
 /* launchers (k_*.hip); all asynchronous on `s`.  h_ctx: HOST copy of the context, passed to the kernel by value
  * (kernarg segment); d_ctx: device copy, for the kernels that are replayed from a hipGraph. */
 void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
+void k_launch_copy_luma(const frame_ctx_t *h_ctx, hipStream_t s); /* I pictures: source luma -> psrc_out (rows beyond the visible picture repeat its last row) */
 void k_launch_me_select(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, const imv_t *in, imv_t *out, hipStream_t s);
 void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_progress /* one word per macroblock row */, uint8_t *d_strips /* 32 bytes per macroblock */,
                       unsigned *d_err, hipStream_t s);

@@ -113,7 +113,15 @@ void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
             }
         } else {
             const int last = rc->last_vqp_p;
-            if (vqp > vmax + 3) skip = 1; /* even the ladder's last level is predicted to cost 1.4 x the target */
+            /* Below the ladder: when even its last level is predicted to cost well over a picture's share, pictures are coded at
+             * a regular cadence -- one in every (cost / share), the others as P_Skip runs -- rather than in bursts between long
+             * freezes; what a coded picture really costs (more, the more pictures were skipped before it) comes back through the
+             * complexity tracker. */
+            const double at_vmax = cplx / qstep(vmax);
+            if (at_vmax > 1.4 * target) {
+                if (rc->since_real + 1 < 0.9 * at_vmax / (target > 1 ? target : 1)) skip = 1;
+                else vqp = vmax;
+            }
             if (vqp > last + 8) vqp = last + 8;
             /* a quantiser at which a picture cost several times its target is a cliff edge (a still scene with sensor noise codes
              * nothing, then everything): it is not visited again before the target could pay most of what it cost */
@@ -124,6 +132,7 @@ void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
             if (vqp < last - down) vqp = last - down;
         }
     }
+    if (!is_idr) rc->since_real = skip ? rc->since_real + 1 : 0;
     if (skip) {
         *qp = rc->qp_max; *drop = DROP_SKIP;
         target = RC_SKIP_BITS;

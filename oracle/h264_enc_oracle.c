@@ -1206,7 +1206,7 @@ void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *r
                     }
                 }
                 if (pass) {
-                    m->mvx = (int16_t)sx; m->mvy = (int16_t)sy_; m->cost = ds;
+                    m->mvx = (int16_t)sx; m->mvy = (int16_t)sy_; m->cost = di;
                     for (int y = 0; y < 16; y++) memcpy(rec_y + (size_t)(y0 + y) * stride + x0, pred + y * 16, 16);
                     chroma_pred8(ref_uv, rec_uv, stride, W, H, x0, y0, sx, sy_);
                     continue;
@@ -1237,7 +1237,7 @@ void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *r
             luma_pred16(ref_y, stride, W, H, x0, y0, bx, by, pred);
             const uint32_t dsad = sad16(sy, stride, pred);
             const uint32_t jinter = dsad + (uint32_t)(lambda * (se_bits(bx - px) + se_bits(by - py)));
-            m->mvx = (int16_t)bx; m->mvy = (int16_t)by; m->cost = jinter;
+            m->mvx = (int16_t)bx; m->mvy = (int16_t)by; m->cost = imv[mbn].sad; /* the record's cost is the whole-sample SAD source against source: what scene-cut detection sums, independent of QP and of what the macroblock became */
             /* ---- 4. intra instead?  (reconstructed later, by orc_intra_p_frame, once every inter macroblock is in place) */
             if ((feat & ORC_F_INTRAP) && idec && imv[mbn].sad + (uint32_t)(lambda * imv[mbn].bits) >= ORC_INTRA_GATE(lambda)) {
                 const orc_idec_t *d = &idec[mbn];
@@ -1676,7 +1676,8 @@ struct orc_enc {
     int frames_since_idr, idr_count, have_ref;
     int scenecut, sc_cnt, prev_idr;                      /* scene-cut recovery: mirrors mi355enc.cpp (collect / enqueue_picture) */
     unsigned long long sc_sum, sc_force_at, pic_index;
-    uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv;
+    uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv, *prev_src_y;
+    int prev_src_valid;
     int cur; /* index of the surface holding the last reconstructed picture */
     orc_mbinfo_t *mbi, *prev_mbi;   /* records of this picture / of the previous one (temporal vector predictor) */
     int prev_is_p;                  /* prev_mbi holds a P picture's records */
@@ -1700,7 +1701,7 @@ orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop
     e->scenecut = 1; e->sc_force_at = ~0ull; e->last_qp = 26;
     size_t ysz = (size_t)e->stride * e->mbh * 16, csz = ysz / 2, nmb = (size_t)e->mbw * e->mbh;
     e->src_y = (uint8_t *)malloc(ysz); e->src_uv = (uint8_t *)malloc(csz);
-    e->pre_y = (uint8_t *)malloc(ysz); e->pre_uv = (uint8_t *)malloc(csz);
+    e->pre_y = (uint8_t *)malloc(ysz); e->pre_uv = (uint8_t *)malloc(csz); e->prev_src_y = (uint8_t *)malloc(ysz);
     for (int i = 0; i < 2; i++) { e->rec_y[i] = (uint8_t *)malloc(ysz); e->rec_uv[i] = (uint8_t *)malloc(csz); }
     e->mbi = (orc_mbinfo_t *)calloc(nmb, sizeof(orc_mbinfo_t));
     e->prev_mbi = (orc_mbinfo_t *)calloc(nmb, sizeof(orc_mbinfo_t));
@@ -1761,7 +1762,11 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
         if (idr)
             orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, drop == ORC_DROP_SKIP ? 0 : drop, e->mbi, e->levels);
         else {
-            orc_me_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, e->me_range, qp, e->surf, e->imv, e->threads);
+            /* The whole-sample search runs SOURCE against SOURCE: the padded source of the last coded picture stands in for the
+             * reference.  True motion is what it finds -- the fields are smoother than against a quantised reference (fewer vector
+             * bits at the same distortion from QP 32 up) -- and the search of a picture no longer waits for anything of the picture
+             * before it (on the device it runs beside that picture's deblocking).  Refinement and prediction use the reference. */
+            orc_me_frame(e->src_y, e->prev_src_y, e->stride, e->mbw, e->mbh, e->me_range, qp, e->surf, e->imv, e->threads);
             if (g_orc_feat & ORC_F_MVDCOST)
                 for (int it = 0; it < e->me_iters; it++) {
                     orc_me_select(e->surf, e->mbw, e->mbh, e->me_range, qp, e->imv, e->imv2, e->threads);
@@ -1809,6 +1814,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
         if (e->scenecut && !pending && e->sc_cnt >= 2 && cost > 3 * (e->sc_sum / (unsigned long long)e->sc_cnt)) e->sc_force_at = e->pic_index + 2;
         e->sc_sum += cost; e->sc_cnt++;
     }
+    if (!all_skip) { memcpy(e->prev_src_y, e->src_y, ysz); e->prev_src_valid = 1; }
     memcpy(e->prev_mbi, e->mbi, (size_t)nmb * sizeof(orc_mbinfo_t));
     e->prev_is_p = !idr;
     e->prev_idr = idr; e->pic_index++;

@@ -148,7 +148,7 @@ def test_row_parallel_cavlc_is_bit_identical(oracle, w, h, qp, kind):
     """one slice coded by several host threads (ranges of macroblock rows, first mb_skip_run of each
     range written by the stitcher) must equal the single-thread coder and the oracle.  "static": a still picture
     sequence, where whole ranges consist of skipped macroblocks and the runs have to be carried across ranges."""
-    oe = oracle.Encoder(w, h, gop=6, threads=8)
+    oe = oracle.Encoder(w, h, gop=6, threads=8, scenecut=False)  # every IDR of this run has idr_pic_id 0
     fr = list(synth.s2_frames(w, h, 6))
     if kind == "static":
         fr = [fr[0]] * 3 + [fr[1]] * 3

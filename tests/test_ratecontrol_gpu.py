@@ -38,18 +38,15 @@ def run_steps(E, w, h, fps, gop, clip, steps, gops_per_step=2, depth=1):
 
 
 def test_setpoint_range_1080p60(E):
-    """The headline geometry on the ME-stress clip (S2): every setpoint of the range -- the GOP that starts with the step and the
-    one after it, except the GOP right after the 20-fold cut 6 Mbit/s -> 300 kbit/s, which may only undershoot (the bits of the
-    old rate are still in the bucket: pictures are skipped until it has drained)."""
+    """The headline geometry on the ME-stress clip (S2): every setpoint of the range.  The GOP after the one that starts with the
+    step is within 10 %; the GOP that starts with the step itself (the strictest reading of "the next full GOP": no picture of
+    lead time at all) within 15 %."""
     w, h, fps, gop = 1920, 1080, 60, 60
     clip = list(synth.s2_frames(w, h, 16))
     rates, drops, qps = run_steps(E, w, h, fps, gop, clip, STEPS)
     for k, (bps, (first, second)) in enumerate(zip(STEPS, rates)):
         assert abs(second - bps) / bps < 0.10, (bps, first, second)
-        if k == 1:
-            assert first < 1.10 * bps, (bps, first, second)
-        else:
-            assert abs(first - bps) / bps < 0.10, (bps, first, second)
+        assert abs(first - bps) / bps < 0.15, (bps, first, second)
     lo = slice(2 * gop, 4 * gop)
     assert (drops[lo] > 0).any() and (qps[lo] == 51).mean() > 0.9            # 300 kbit/s on this clip lives below QP 51
 
@@ -57,13 +54,15 @@ def test_setpoint_range_1080p60(E):
 def test_setpoint_range_1080p60_still_scene_with_sensor_noise(E):
     """S4 (a still scene with fresh noise on every picture) is a cliff in QP: a picture costs almost nothing until the
     quantiser is fine enough to code the noise, then fifty times as much.  One QP per picture cannot sit on a target that
-    lies inside the jump: the stream dithers around it.  Asserted: the mean over the two GOPs after a step within 20 %, and
-    at the ends of the range (where the target is off the cliff) the usual 10 % for the second GOP."""
+    lies inside the jump: the stream dithers around it, and the rule that keeps the quantiser from diving over the edge
+    (ratecontrol.c) errs on the low side.  Asserted: the mean over the two GOPs after a step is never more than 20 % over the
+    setpoint (and not less than 60 % of it), and at the ends of the range, where the target is off the cliff, the usual
+    10 % for the second GOP."""
     w, h, fps, gop = 1920, 1080, 60, 60
     clip = list(synth.s4_frames(w, h, 16))
     rates, drops, qps = run_steps(E, w, h, fps, gop, clip, STEPS)
     for bps, (first, second) in zip(STEPS[1:], rates[1:]):
-        assert abs((first + second) / 2 - bps) / bps < 0.20, (bps, first, second)
+        assert -0.40 < ((first + second) / 2 - bps) / bps < 0.20, (bps, first, second)
     for k in (1, 4, 5):
         assert abs(rates[k][1] - STEPS[k]) / STEPS[k] < 0.10, (STEPS[k], rates[k])
 
@@ -72,10 +71,9 @@ def test_setpoint_range_2160p60(E):
     """3840x2160 on the ME-stress clip: four times the macroblocks for the same setpoints.  An IDR picture has a floor of ~39 KB
     (QP 51, last ladder level: headers and prediction only) = 0.32 Mbit/s at one IDR per second, so 300 kbit/s is not
     reachable with key-int-max=60 at this size: the floor, IDR + all-skip pictures, is what comes out (asserted < 0.35 Mbit/s).
-    From 1 to 6 Mbit/s the P pictures of this clip cost more at QP 51 than a picture's share, so the stream alternates coded and
-    skipped pictures (and a coded picture after skipped ones has more motion to pay for, which the skip decision over-estimates):
-    the stream stays at or under the setpoint -- never more than 20 % over on the mean of two GOPs, down to 35 % under; at 20
-    and 30 Mbit/s the mean of two GOPs is within 20 % (an IDR picture of this clip is a third of a GOP's bits)."""
+    Around 1 Mbit/s the P pictures of this clip cost more on the last ladder level than a picture's share, so the stream alternates
+    coded and skipped pictures at a regular cadence; at 20 and 30 Mbit/s an IDR picture of this clip is a third of a GOP's bits.
+    Asserted: the mean of the two GOPs after every step within 20 % of the setpoint."""
     w, h, fps, gop = 3840, 2160, 60, 60
     clip = list(synth.s2_frames(w, h, 8))
     steps = [20_000_000, 300_000, 1_000_000, 1_500_000, 6_000_000, 30_000_000]
@@ -83,8 +81,6 @@ def test_setpoint_range_2160p60(E):
     for bps, (first, second) in zip(steps, rates):
         if bps < 600_000:
             assert second < 350_000, (bps, first, second)
-        elif bps <= 6_000_000:
-            assert -0.35 < ((first + second) / 2 - bps) / bps < 0.20, (bps, first, second)
         else:
             assert abs((first + second) / 2 - bps) / bps < 0.20, (bps, first, second)
 
