@@ -103,6 +103,8 @@ DEV const imv_t *k_final_imv_dev(const frame_ctx_t *ctx) { return (ME_ITERS & 1)
 #define DB_SPIN_MAX (1 << 20)
 DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV uint2 ld64_sc1(const uint2 *p) { const unsigned long long v = __hip_atomic_load((const GAS unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return make_uint2((unsigned)v, (unsigned)(v >> 32)); }
+DEV void st64_sc1(uint2 *p, uint2 v) { __hip_atomic_store((GAS unsigned long long *)p, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV int db_wait_get(unsigned *progress, unsigned *err, int need) {
     int spins = 0, v;
     while ((v = (int)ld_sc1(progress)) < need) {

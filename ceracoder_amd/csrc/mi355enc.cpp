@@ -75,6 +75,7 @@ struct mi355enc {
     uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock
     uint8_t *d_idec;      // intra decisions, IDEC_BYTES per macroblock
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
+    uint2 *d_db_gran;     // strips between deblocking bands, as epoch-tagged granules (never cleared)
     unsigned *d_progress; // two sets (picture parity) of [2*bands] strip counters of the band deblocker, then one error word
     unsigned *d_iprogress; // progress counters of the persistent intra kernel, one per band
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
@@ -170,7 +171,7 @@ static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
         // nothing else is in flight: clear the other set entirely and this set's counters (its flags were cleared by the previous picture's prep
         // kernel or at open; this launch raises them)
         k_launch_deblock_prep(hc, h->mbw, 0, h->mbh, prog_set(h, ci ^ 1), h->n_progress, prog_set(h, ci), 2 * nb, nullptr, 0, prog_set(h, ci) + 2 * nb, h->stream);
-        k_launch_deblock_bands(hc, h->mbh, 0, nb, prog_set(h, ci), err_word(h), h->stream);
+        k_launch_deblock_bands(hc, h->mbh, 0, nb, prog_set(h, ci), err_word(h), h->d_db_gran, h->stream);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -212,7 +213,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->d_db_gran = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -249,6 +250,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->n_progress = 3 * k_deblock_bands16(h->mbh); // per set: luma counters, chroma counters, per-band "has work" flags
     HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
+    HIPCHK(hipMalloc((void **)&h->d_db_gran, k_deblock_gran_bytes(h->mbw, h->mbh)));
+    HIPCHK(hipMemsetAsync(h->d_db_gran, 0, k_deblock_gran_bytes(h->mbw, h->mbh), h->stream)); // epoch 0 is never used
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
     for (int k = 0; k < 2; k++) {
         HIPCHK(hipMalloc((void **)&h->d_surf[k], (size_t)h->nmb * SURF_U16 * sizeof(uint16_t)));
@@ -322,6 +325,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_dbrec) (void)hipFree(h->d_dbrec);
     if (h->d_idec) (void)hipFree(h->d_idec);
     if (h->d_progress) (void)hipFree(h->d_progress);
+    if (h->d_db_gran) (void)hipFree(h->d_db_gran);
     if (h->d_off) (void)hipFree(h->d_off);
     for (int k = 0; k < 2; k++) {
         if (h->d_surf[k]) (void)hipFree(h->d_surf[k]);
@@ -851,7 +855,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
                 const uint8_t *p0 = s->d_raw, *p1 = p0 + (size_t)r0 * ht, *p2 = p1 + (size_t)r1 * (ht / 2);
                 k_launch_csc(stage - 4, p0, p1, p2, r0, r1, r1, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, h->stream);
             }
-            else { int r = run_deblock(h, 0, h->slot[0].h_ctx); if (r) return r; }
+            else { if (++h->epoch == 0) h->epoch = 1; h->slot[0].h_ctx->epoch = h->epoch; int r = run_deblock(h, 0, h->slot[0].h_ctx); if (r) return r; } // a fresh stamp per launch: the strips between bands are epoch-tagged
         }
         if (warm) HIPCHK(hipEventRecord(s->ev[1], h->stream));
     }
