@@ -21,14 +21,3 @@ for n, (_, _, y, uv) in enumerate(frames(w, h, 2)):
         print("qp", set(oe.mbinfo["qp"].tolist()), "types", set(oe.mbinfo["mb_type"].tolist()))
         for name, a in (("pre", oe.prefilter_uv), ("exp", oe.recon_uv), ("got", d_uv)):
             print(name); print(a[r0:r1, c0:c1])
-    if os.environ.get("PROF") and n == int(os.environ.get("PROF_FRAME", "1")) and mode == 0:
-        # library built with -DD3_PROF=1|2: the band kernel leaves cycle counters in the first deblocking records
-        import ctypes as C
-        buf = np.zeros((e.mbw * e.mbh, 16), np.uint32)
-        assert e.L.mi355enc_fetch(e.h, 100, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
-        flat = buf.reshape(-1)
-        names = ["A prefetch", "B vertical", "C barrier", "D horizontal", "tail", "E wait", "E+F", "loop total"]
-        for blk, label in enumerate(["luma band0 wave0", "luma band0 wave3", "luma band1 wave0", "luma band1 wave3",
-                                     "chroma band0 wave0", "chroma band0 wave3", "chroma band1 wave0", "chroma band1 wave3"]):
-            v = flat[blk * 8: blk * 8 + 8]
-            print(label, {names[i]: int(v[i]) for i in range(8)})
