@@ -299,43 +299,54 @@ DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int b
     p0 = f ? np0 : p0; q0 = f ? nq0 : q0;
 }
 
-// ------------------------------------------------------------------ the band kernel: one wave per macroblock row
-// The four vertical (then
-// the four horizontal) edges of a macroblock are almost independent: a normal-strength filter changes p1, p0, q0, q1 and
-// reads p2 and q2; q2 of edge e is p1 of edge e + 1 (which edge e + 1 changes, but only after edge e has read it: everybody
-// reads originals) and q1 of edge e is p2 of edge e + 1 -- the single true dependency.  q1' needs only the q side, p0 and the
-// filter flag, none of which involve p2, so all four edges compute q1' at once, hand it to the next edge's lanes with one DPP
-// move, and finish.  The strong filter (bS 4) exists only on the macroblock edge and also changes q2 = p1 of edge 1, which
-// edge 1's flag reads: a wave that sees a bS 4 runs the macroblock edge as a pass of its own first.  So the chain of a step is
-// one or two edge filters per direction instead of four, on 64 lanes = 16 lines x 4 edges of ONE macroblock, and a
-// workgroup is a band of DB_ROWS rows with one wave each (luma and chroma in separate workgroups: they share nothing but
-// the records).  The form this replaced -- 16 lanes per macroblock, a wave serving four rows, 16-row bands, strips + drain +
-// progress counter between bands -- took 0.34 ms per 1080p P picture against 0.20 ms.
-#define RFL2(v) ((unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
-#define DBR_TS 20 /* tile row: bytes 0..3 = the four samples left of the macroblock (chroma: two per plane), 4..19 = its 16 bytes */
-struct dbr_luma { uint8_t t[20 * DBR_TS]; unsigned ring[4][16]; };   // rows -4..15
-struct dbr_chroma { uint8_t t[10 * DBR_TS]; unsigned ring[4][8]; };  // rows -2..7
+// ------------------------------------------------------------------ the band kernel: the four edges of a direction in parallel
+// The four vertical (then the four horizontal) luma edges of a macroblock are almost independent: a normal-strength filter
+// changes p1, p0, q0, q1 and reads p2 and q2; q2 of edge e is p1 of edge e + 1 (which edge e + 1 changes, but only after edge e
+// has read it: everybody reads originals) and q1 of edge e is p2 of edge e + 1 -- the single true dependency.  q1' needs only
+// the q side, p0 and the filter flag, none of which involve p2, so all four edges compute q1' at once, hand it to the next
+// edge's lanes with one DPP move, and finish.  The strong filter (bS 4) exists only on the macroblock edge and also changes
+// q2 = p1 of edge 1, which edge 1's flag reads: a wave that sees a bS 4 runs the macroblock edge as a pass of its own first.
+// So the chain of a step is one or two edge filters per direction instead of four, on 64 lanes = 16 lines x 4 edges of ONE
+// macroblock (lane = 4 * line + edge), and a workgroup is a band of DB_ROWS rows (luma and chroma in separate workgroups:
+// they share nothing but the records).
+//
+// Three waves per macroblock row.  A first form of this kernel gave a row ONE wave that did everything; per-phase cycle
+// counters showed its step to be ~25 % filters and ~75 % data movement (prefetch, landing, ring copies, final-sample reads,
+// stores) on the very wave whose instruction stream IS the dependency chain.  Here F filters and touches nothing but LDS; M
+// loads macroblocks two steps ahead, lands them in a ring of 8 tiles and turns the 64-byte record into one parameter word
+// per lane and direction {bS, alpha, beta, tc0[bS]}; S reads finished lines out of the ring and stores them, and publishes the
+// band's bottom strip.  With 4-row bands that is 12 waves, M and S sharing a SIMD with their row's F: they issue VMEM / LDS /
+// SALU beside its VALU.  Nothing is copied between steps: the left strip of macroblock x is columns 12..15 of tile x-1, the
+// strip above is rows 12..15 of the tile of the row above (for the first row of a band: a small ring its M wave fills from the
+// band above's granules), so vertical edge 0 and horizontal edge 0 simply address the neighbouring tile.
+// Strips between bands travel as 8-byte {samples, picture epoch} granules, one `sc1` store each, which the consumer polls
+// directly (MI355X_MICROARCH.md, hand-off R2 / handoff-1to1): no drain, no separate counter, nothing to clear.
+// 1080p P picture: 16 lanes per macroblock + 16-row bands + strips/drain/counter 0.34 ms -> one wave per row, edges in
+// parallel 0.25 -> granules 0.20 -> three waves per row 0.13 (I pictures 0.45 -> 0.22).
 DEV int quad_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x90, 0xF, 0xF, false); } // quad_perm:[0,0,1,2]: value of lane - 1 of the quad
 DEV int quad_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xF9, 0xF, 0xF, false); } // quad_perm:[1,2,3,3]: value of lane + 1 of the quad
+#define DBT_NB 8
+struct dbt_luma { uint8_t t[DBT_NB][256]; uint8_t up[DBT_NB][64]; unsigned par[4][2][64]; unsigned rec[2][16]; };   // 4.7 KB per row
+struct dbt_chroma { uint8_t t[DBT_NB][128]; uint8_t up[DBT_NB][32]; unsigned par[4][2][64]; unsigned rec[2][16]; }; // 3.4 KB per row
+DEV uint4 lds128(const void *p) { return *(const uint4 *)p; }
 
-// The four luma edges of one direction; lane = 4 * line + edge.  s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 of this lane's edge
-// (originals); on return s[2..5] (p1 p0 q0 q1) are final, for edge 0 also s[1] (p2), and s[6] is NOT (it is the next edge's p1).
-// bS: this lane's boundary strength; PE / PI: parameters of the macroblock edge / the inner edges.
+// The four luma edges of one direction; lane = 4 * line + edge, `par` = this lane's {bS, alpha, beta, tc0}.  s[0..7] = p3 p2 p1 p0 q0 q1
+// q2 q3 of this lane's edge (originals); on return s[2..5] (p1 p0 q0 q1) are final, for edge 0 also s[1] (p2), and s[6] is NOT (it
+// is the next edge's p1).
 template <bool ALL_INTRA>
-DEV void edges4_luma(const edge_par &PE, const edge_par &PI, int e, int bS, bool any4, int *s) {
+DEV void edges4p_luma(const int e, const unsigned par, const bool any4, int *s) {
+    int bS = (int)(par & 15u);
+    const int alpha = (int)((par >> 8) & 255u), beta = (int)((par >> 16) & 255u), tc0 = (int)(par >> 24);
     if (ALL_INTRA || any4) { // the macroblock edge first (lanes of the other edges compute and discard)
-        const int b0 = e == 0 ? bS : 0;
-        edge_luma2<true>(PE, s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], b0, true);
+        edge_par PE; PE.alpha = alpha; PE.beta = beta; PE.tc0 = (unsigned)tc0 * 0x010101u;
+        edge_luma2<true>(PE, s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], e == 0 ? bS : 0, true);
         const int f1 = quad_prev(s[5]), f2 = quad_prev(s[6]); // edge 0's q1', q2' are edge 1's p2, p1
         s[1] = e == 1 ? f1 : s[1]; s[2] = e == 1 ? f2 : s[2];
         bS = e == 0 ? 0 : bS;
     }
-    const int alpha = (!(ALL_INTRA || any4) && e == 0) ? PE.alpha : PI.alpha, beta = (!(ALL_INTRA || any4) && e == 0) ? PE.beta : PI.beta;
-    const unsigned tcw = (!(ALL_INTRA || any4) && e == 0) ? PE.tc0 : PI.tc0;
     const int p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6];
     const int mf = ((adiff(p0, q0) - alpha) & (adiff(p1, p0) - beta) & (adiff(q1, q0) - beta) & -bS) >> 31; // bS is 0..3 here
     const int maq = (adiff(q2, q0) - beta) >> 31;
-    const int tc0 = (int)((tcw >> (8 * ((bS - 1) & 3))) & 0xFF); // bS 0 reads a don't-care byte
     const int avg = (p0 + q0 + 1) >> 1;
     const int nq1 = q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
     const int q1f = bsel(mf & maq, nq1, q1);
@@ -348,227 +359,263 @@ DEV void edges4_luma(const edge_par &PE, const edge_par &PI, int e, int bS, bool
     s[3] = bsel(mf, clip255(p0 + dl), p0); s[4] = bsel(mf, clip255(q0 - dl), q0);
     s[2] = bsel(mf & map, np1, p1); s[5] = q1f;
 }
+DEV void edge_chroma_p(const unsigned par, int p1, int &p0, int &q0, int q1) {
+    const int bS = (int)(par & 15u), alpha = (int)((par >> 8) & 255u), beta = (int)((par >> 16) & 255u), tc = (int)(par >> 24) + 1;
+    const bool f = (bS != 0) & (adiff(p0, q0) < alpha) & (adiff(p1, p0) < beta) & (adiff(q1, q0) < beta);
+    const int dl = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    const bool s4 = bS == 4;
+    const int sp0 = (2 * p1 + p0 + q1 + 2) >> 2, sq0 = (2 * q1 + q0 + p1 + 2) >> 2, wp0 = clip255(p0 + dl), wq0 = clip255(q0 - dl);
+    const int np0 = s4 ? sp0 : wp0, nq0 = s4 ? sq0 : wq0;
+    p0 = f ? np0 : p0; q0 = f ? nq0 : q0;
+}
+// {bS, alpha, beta, tc0[bS]} of one lane's edge: nib = the lane's bS nibble, ab / tcw = the edge class's packed parameters
+DEV unsigned par_word(unsigned nib, unsigned ab, unsigned tcw) { return nib | (ab << 8) | (((tcw >> (8 * ((nib - 1) & 3))) & 255u) << 24); }
 
 template <bool CHROMA, bool ALL_INTRA, int ROWS>
-DEV void rows_body(const db_args &a, const unsigned *__restrict__ recs, const int band, const int nb, uint8_t *lds) {
-    constexpr int rows_mb = CHROMA ? 8 : 16, strip = CHROMA ? 2 : 4, ring_n = CHROMA ? 8 : 16, TS = DBR_TS;
-    constexpr int ROW_LDS = CHROMA ? (int)sizeof(dbr_chroma) : (int)sizeof(dbr_luma);
-    constexpr int T_BYTES = (CHROMA ? 10 : 20) * TS;
+DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const int band, const int nb, uint8_t *lds) {
+    constexpr int rows_mb = CHROMA ? 8 : 16, strip = CHROMA ? 2 : 4, ring_n = CHROMA ? 8 : 16;
+    constexpr int ROW_LDS = CHROMA ? (int)sizeof(dbt_chroma) : (int)sizeof(dbt_luma);
+    constexpr int TILE = rows_mb * 16, UPB = strip * 16;
     const frame_ctx_t *__restrict__ ctx = &a.ctx;
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63; // the wave index as an SGPR: everything derived from it
-    const int my = band * ROWS + wave;                                                              // (row, step, activity) is scalar control flow
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int role = wid / ROWS, r = wid - role * ROWS; // 0: filter, 1: mover (loads), 2: storer
+    const int my = band * ROWS + r;
     const bool row_ok = my < mbh, last_row = my == mbh - 1;
-    const bool fed = row_ok && wave == 0 && band > 0;
-    const bool feeds = row_ok && wave == ROWS - 1 && !last_row;
-    // no edge of this band has work (deblock_prep_kernel's flags): its samples are final as they are, and the band below, which
-    // reads the same flags, takes this band's bottom strip straight from the picture
+    const bool fed = row_ok && r == 0 && band > 0;
+    const bool feeds = row_ok && r == ROWS - 1 && !last_row;
+    // no edge of this band has work (deblock_prep_kernel's flags): its samples are final as they are, and its neighbours, which
+    // read the same flags, take its strips straight from the picture
     if (!ALL_INTRA && a.progress[2 * nb + band] == 0) return;
-    const bool up_work = ALL_INTRA || (band > 0 && a.progress[2 * nb + band - 1] != 0);     // the band above publishes its strips
-    const bool dn_work = ALL_INTRA || (band + 1 < nb && a.progress[2 * nb + band + 1] != 0); // ... and the band below reads ours
-    // The band kernel may be launched in several pieces (bands [band0, band1)).  Strips between bands travel as 8-byte {samples, picture epoch} granules, one `sc1` store each, which the consumer polls
-    // directly (MI355X_MICROARCH.md, hand-off R2 / handoff-1to1): no drain, no separate counter, one round trip.
+    const bool up_work = ALL_INTRA || (band > 0 && a.progress[2 * nb + band - 1] != 0);
+    const bool dn_work = ALL_INTRA || (band + 1 < nb && a.progress[2 * nb + band + 1] != 0);
     const unsigned epoch = ctx->epoch;
     uint2 *gran_up = a.gran + (CHROMA ? (size_t)nb * mbw * 16 : 0) + (size_t)(band > 0 ? band - 1 : 0) * mbw * ring_n;
     uint2 *gran_my = a.gran + (CHROMA ? (size_t)nb * mbw * 16 : 0) + (size_t)band * mbw * ring_n;
     uint8_t *__restrict__ plane = CHROMA ? ctx->rec_uv : ctx->rec_y;
     const size_t row0 = (size_t)my * rows_mb;
-    uint8_t *tile = lds + wave * ROW_LDS;
-    unsigned *ring = (unsigned *)(tile + T_BYTES);
-    const unsigned *ring_up = (const unsigned *)(lds + (wave > 0 ? wave - 1 : 0) * ROW_LDS + T_BYTES);
-    const int keep = last_row ? rows_mb : rows_mb - strip; // rows stored by this row itself; the strip below goes through the ring
-    // lane roles.  Filters: line k = lane >> 2 (luma) with edge e = lane & 3.  Data movement: word (lane & 3) of line (lane >> 2).
-    const int k = lane >> 2, e = lane & 3;
-    const int mrow = lane >> 2, mword = lane & 3;       // one word per lane covers 16 lines x 16 bytes
-    const bool mlane = CHROMA ? lane < 32 : true;       // chroma: 8 lines
-    const bool slane = lane < strip * 4;                // one word per lane covers a strip
-    unsigned own = 0, stripv = 0, recv = 0;
-    // the 64-byte record of a macroblock is wave-uniform (one macroblock per wave): loaded one word per lane a step ahead, moved to SGPRs by v_readlane when it has landed
-    const int rec_row = __builtin_amdgcn_readfirstlane(row_ok ? my : 0) * mbw;
-    uint4 rc0 = make_uint4(0, 0, 0, 0), rc1 = rc0, rc2 = rc0;
-    // per-lane addresses of this row's lines, less the macroblock's x offset
-    const uint8_t *ld_base = plane + (row0 + mrow) * stride + 4 * mword;
-    uint8_t *sc_base = plane + (row0 - (my > 0 ? strip : 0) + mrow) * stride + 4 * mword;
-    uint2 gnext = make_uint2(0, 0);
-    const int nsteps = mbw + ROWS + 2;
-#ifdef DBR_PROF /* debug builds only: per-phase cycle sums of wave 1 of band 1 (every tick drains lgkmcnt: perturbs) */
-    unsigned long long pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tm0 = 0, tm1;
-#define DBR_TICK(i) do { tm1 = __builtin_readcyclecounter(); pc[i] += tm1 - tm0; tm0 = tm1; } while (0)
+    uint8_t *rowl = lds + r * ROW_LDS;
+    uint8_t *tiles = rowl;                                        // [DBT_NB][TILE]
+    uint8_t *ups = rowl + DBT_NB * TILE;                          // [DBT_NB][UPB]: the strip above, first row of a band only
+    unsigned *pars = (unsigned *)(rowl + DBT_NB * (TILE + UPB));  // [4][2][64]
+    unsigned *recl = pars + 4 * 2 * 64;                           // [2][16]: the mover's scratch for the record it is landing
+    uint8_t *tiles_up = lds + (r > 0 ? r - 1 : 0) * ROW_LDS;      // the row above's tiles
+    const int keep = last_row ? rows_mb : rows_mb - strip;
+    const int t_end = mbw + ROWS + 1;
+    // ---- per-role state
+    const int k = lane >> 2, e = lane & 3;                        // filter lanes (luma): line / column k, edge e
+    uint4 preA, preB; // mover: two macroblock loads in flight.  Deliberately not initialised: a phi with a constant at the loop header
+    uint2 gA, gB;     // costs a register copy on the back edge, and a copy of a register with a load in flight waits for the load
+    const bool rlane = lane < rows_mb, uplane = lane >= 16 && lane < 16 + strip, glane = lane >= 32 && lane < 32 + ring_n;
+    // every lane of the mover loads, every step, from a clamped address (lanes without a role repeat a record quarter): a load
+    // under a branch or a predicate is a conditional assignment to a loop-carried value, which costs a merge move -- and the wait
+    // for the load right behind its issue
+    const int my_c = row_ok ? my : mbh - 1;
+    const uint8_t *ld_ptr = rlane ? plane + ((size_t)my_c * rows_mb + lane) * stride : (const uint8_t *)(recs + (size_t)my_c * mbw * (DBREC_BYTES / 4) + 4 * (lane & 3));
+    const int ld_step = rlane ? 16 : DBREC_BYTES;
+    uint8_t *st_ptr = lane < 16 ? plane + ((size_t)my_c * rows_mb + lane) * stride : plane + ((size_t)my_c * rows_mb - (my_c > 0 ? strip : 0) + (lane & 3)) * stride; // storer: this lane's line
+    const int gj = glane ? lane - 32 : 0;
+    const uint8_t *g_ptr = up_work ? (const uint8_t *)(gran_up + gj) : plane + ((size_t)my_c * rows_mb - (my_c > 0 ? strip : 0) + (gj >> 2)) * stride + 4 * (gj & 3);
+    const int g_step = up_work ? ring_n * 8 : 16;
+#ifdef DBT_PROF /* debug builds: cycles before the barrier, in it, after it, per role; row 1 of band 1 */
+    unsigned long long pc[3] = {0, 0, 0}, tm0 = 0, tm1;
+    unsigned nmiss = 0;
+#define DBT_TICK(i) do { tm1 = __builtin_readcyclecounter(); pc[i] += tm1 - tm0; tm0 = tm1; } while (0)
+#define DBT_T0() tm0 = __builtin_readcyclecounter()
 #else
-#define DBR_TICK(i) do { } while (0)
+#define DBT_TICK(i) do { } while (0)
+#define DBT_T0() do { } while (0)
 #endif
-    for (int t = 0; t < nsteps; t++) {
-        const int x = t - 1 - wave, xn = x + 1;
-        const bool act = row_ok && x >= 0 && x < mbw;
-        const bool pf = row_ok && xn >= 0 && xn < mbw;
-        const bool pub = feeds && x >= 1 && x <= mbw;         // strip of macroblock x-1 becomes final in this step's vertical phase
-        const int x0b = x * 16;
-#ifdef DBR_PROF
-        tm0 = __builtin_readcyclecounter();
-#endif
-        // ---- A. prefetch macroblock x+1 (its samples, its record, the strip of the band above)
-        if (pf) {
-            if (fed && slane) {
-                if (up_work) gnext = ld64_sc1(gran_up + (size_t)xn * ring_n + lane);
-                else { gnext.x = ldg32(plane + (row0 - strip + mrow) * stride + xn * 16 + 4 * mword); gnext.y = epoch; }
-            }
-#ifndef DBX_NOLOAD
-            if (mlane) own = ldg32(ld_base + xn * 16);
-#endif
-            if (lane < 16) recv = ldg32(recs + (size_t)(rec_row + xn) * (DBREC_BYTES / 4) + lane);
-        }
-        DBR_TICK(0);
-        // the record is wave-uniform now (one macroblock per wave): boundary strengths in SGPRs
-        unsigned bvl = 0, bvh = 0, bhl = 0, bhh = 0;
-        if (act) { bvl = rc0.x; bvh = rc0.y; bhl = rc0.z; bhh = rc0.w; }
-        const edge_par PL = par_of(rc1.x, rc1.y), PT = par_of(rc1.z, rc1.w), PI = par_of(rc2.x, rc2.y);
-        DBR_TICK(1);
-        // ---- B. vertical edges
+    const int t_last = t_end | 1; // every role runs the same, even number of steps (the mover's loop is unrolled by two)
+    // Each role runs its own loop (one barrier per step in each): compiled as one loop with a role switch inside, the three
+    // roles share a register assignment at the back edge, and the merge moves there wait for the mover's loads in flight and for
+    // the storer's stores.
+    if (role == 0) {
+        for (int t = -2; t <= t_last; t++) {
+            DBT_T0();
+            const int x = t - 1 - r;
+            const bool act = row_ok && x >= 0 && x < mbw;
+            // =========================================================== F: vertical edges | barrier | horizontal edges
+                uint8_t *tile = tiles + (x & (DBT_NB - 1)) * TILE;
+                if (act) {
+                    const unsigned par = pars[((x & 3) * 2 + 0) * 64 + lane];
+                    if (!CHROMA) {
+                        uint8_t *tl = tiles + ((x - 1) & (DBT_NB - 1)) * TILE;
+                        unsigned *pw = (unsigned *)(e == 0 ? tl + k * 16 + 12 : tile + k * 16 + 4 * e - 4), *qw = (unsigned *)(tile + k * 16 + 4 * e);
+                        const unsigned w0 = *pw, w1 = *qw;
+                        const unsigned long long work = __ballot((par & 15u) != 0);
 #ifdef DBX_NOFILT
-        if (0) {
+                        if (0) {
 #else
-        if (ALL_INTRA ? act : (bvl | bvh) != 0) {
+                        if (ALL_INTRA || work) {
 #endif
-            if (!CHROMA) {
-                unsigned *tw = (unsigned *)&tile[(k + 4) * TS + 4 * e];
-                const unsigned w0 = tw[0], w1 = tw[1];
-                int s[8];
+                            int s[8];
 #pragma unroll
-                for (int i = 0; i < 4; i++) { s[i] = byte_of(w0, i); s[4 + i] = byte_of(w1, i); }
-                const unsigned bw = e < 2 ? bvl : bvh;
-                const int bS = (int)((bw >> (16 * (e & 1) + 4 * (k >> 2))) & 15);
-                edges4_luma<ALL_INTRA>(PL, PI, e, bS, (bvl & 0x4444u) != 0, s);
-                // word of columns 4e .. 4e+3: own q0 q1, then the next edge's p1 p0 (edge 3: own q2 q3, which no edge of this macroblock changes)
-                const int nx = quad_next(s[2] | (s[3] << 8));
-                const unsigned hi = e == 3 ? (unsigned)(s[6] | (s[7] << 8)) : (unsigned)nx;
-                tw[1] = (unsigned)s[4] | ((unsigned)s[5] << 8) | (hi << 16);
-                if (e == 0) {
-                    const unsigned l0 = pack4(s[0], s[1], s[2], s[3]);
-                    tw[0] = l0;
-                    if (k >= 12 && x > 0 && !last_row) ring[((x - 1) & 3) * 16 + (k - 12) * 4 + 3] = l0; // columns 12..15 of the previous macroblock's strip
+                            for (int i = 0; i < 4; i++) { s[i] = byte_of(w0, i); s[4 + i] = byte_of(w1, i); }
+                            edges4p_luma<ALL_INTRA>(e, par, __ballot((par & 15u) == 4u) != 0, s);
+                            const int nx = quad_next(s[2] | (s[3] << 8));
+                            const unsigned hi = e == 3 ? (unsigned)(s[6] | (s[7] << 8)) : (unsigned)nx;
+                            *qw = (unsigned)s[4] | ((unsigned)s[5] << 8) | (hi << 16);
+                            if (e == 0 && x > 0) *pw = pack4(s[0], s[1], s[2], s[3]);
+                        }
+                    } else if (lane < 32) {
+                        const int kk = lane >> 2, c = (lane >> 1) & 1, ee = lane & 1; // line, plane, edge (luma edges 0 and 2)
+                        uint8_t *tl = tiles + ((x - 1) & (DBT_NB - 1)) * TILE;
+                        uint8_t *pb = ee == 0 ? tl + kk * 16 + 12 + c : tile + kk * 16 + 4 + c, *qb = tile + kk * 16 + 8 * ee + c;
+                        int p1 = pb[0], p0 = pb[2], q0 = qb[0], q1 = qb[2];
+                        edge_chroma_p(par, p1, p0, q0, q1);
+                        if (ee != 0 || x > 0) pb[2] = (uint8_t)p0;
+                        qb[0] = (uint8_t)q0;
+                    }
                 }
-            } else if (lane < 32) {
-                const int kk = lane >> 2, c = (lane >> 1) & 1, ee = lane & 1; // line, plane, edge (luma edges 0 and 2)
-                uint8_t *b = &tile[(kk + 2) * TS + c + 8 * ee];               // samples of a plane sit 2 bytes apart; p1 p0 q0 q1
-                int p1 = b[0], p0 = b[2], q0 = b[4], q1 = b[6];
-                const int bS = (int)(((ee ? bvh : bvl) >> (4 * (kk >> 1))) & 15);
-                const edge_par P = ee ? PI : PL;
-                edge_chroma2(P, p1, p0, q0, q1, bS);
-                b[2] = (uint8_t)p0; b[4] = (uint8_t)q0;
-            }
-            if (CHROMA) {
-                WAVE_SYNC();
-                if (lane >= 6 && lane < 8 && x > 0 && !last_row) ring[((x - 1) & 3) * 8 + (lane - 6) * 4 + 3] = *(const unsigned *)&tile[(lane + 2) * TS];
-            }
-        }
-        // ---- the strip of macroblock x-1 is final now: hand it to the band below
-        if (pub) {
-            WAVE_SYNC();
-            if (slane) {
-                const unsigned w = ring[((x - 1) & 3) * ring_n + lane];
-                if (dn_work) st64_sc1(gran_my + (size_t)(x - 1) * ring_n + lane, make_uint2(w, epoch));
-                else stg32(plane + (row0 + rows_mb - strip + mrow) * stride + (x - 1) * 16 + 4 * mword, w); // nobody below will store it
-            }
-        }
-        DBR_TICK(2);
-        // ---- C. the one barrier of the step: every vertical edge of this step precedes every horizontal edge
-        BAND_BARRIER();
-        DBR_TICK(3);
-        unsigned fin = 0, fsb = 0, fsc = 0;
-        if (act) {
-            // ---- D. horizontal edges
-            if (my > 0 && slane) *(unsigned *)&tile[mrow * TS + 4 + 4 * mword] = fed ? stripv : ring_up[(x & 3) * ring_n + lane];
-            WAVE_SYNC();
+                DBT_TICK(0);
+                BAND_BARRIER();
+                DBT_TICK(1);
+                if (act) {
+                    const unsigned par = pars[((x & 3) * 2 + 1) * 64 + lane];
+                    uint8_t *upb = fed ? ups + (x & (DBT_NB - 1)) * UPB : tiles_up + (x & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
+                    if (!CHROMA) {
+                        uint8_t *pb = (e == 0 ? upb : tile + (4 * e - 4) * 16) + k, *qb = tile + 4 * e * 16 + k;
+                        int s[8];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { s[i] = pb[i * 16]; s[4 + i] = qb[i * 16]; }
+                        const unsigned long long work = __ballot((par & 15u) != 0);
 #ifdef DBX_NOFILT
-            if (0) {
+                        if (0) {
 #else
-            if (ALL_INTRA || (bhl | bhh) != 0) {
+                        if (ALL_INTRA || work) {
 #endif
-                if (!CHROMA) {
-                    uint8_t *col = &tile[(4 * e) * TS + 4 + k]; // column k, rows 4e-4 .. 4e+3
-                    int s[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) s[i] = col[i * TS];
-                    const unsigned bw = e < 2 ? bhl : bhh;
-                    const int bS = (int)((bw >> (16 * (e & 1) + 4 * (k >> 2))) & 15);
-                    const bool any4 = (bhl & 0x4444u) != 0;
-                    edges4_luma<ALL_INTRA>(PT, PI, e, bS, any4, s);
-                    col[2 * TS] = (uint8_t)s[2]; col[3 * TS] = (uint8_t)s[3]; col[4 * TS] = (uint8_t)s[4]; col[5 * TS] = (uint8_t)s[5];
-                    if ((ALL_INTRA || any4) && e == 0) col[1 * TS] = (uint8_t)s[1];
-                } else if (lane < 32) {
-                    const int kb = lane >> 1, ee = lane & 1; // byte column, edge
-                    uint8_t *col = &tile[(4 * ee) * TS + 4 + kb];
-                    int p1 = col[0], p0 = col[TS], q0 = col[2 * TS], q1 = col[3 * TS];
-                    const int bS = (int)(((ee ? bhh : bhl) >> (4 * (kb >> 2))) & 15);
-                    const edge_par P = ee ? PI : PT;
-                    edge_chroma2(P, p1, p0, q0, q1, bS);
-                    col[TS] = (uint8_t)p0; col[2 * TS] = (uint8_t)q0;
+                            const bool any4 = __ballot((par & 15u) == 4u) != 0;
+                            edges4p_luma<ALL_INTRA>(e, par, any4, s);
+                            if (e != 0 || my > 0) { pb[2 * 16] = (uint8_t)s[2]; pb[3 * 16] = (uint8_t)s[3]; }
+                            qb[0] = (uint8_t)s[4]; qb[16] = (uint8_t)s[5];
+                            if ((ALL_INTRA || any4) && e == 0 && my > 0) pb[16] = (uint8_t)s[1];
+                        }
+                    } else if (lane < 32) {
+                        const int kb = lane >> 1, ee = lane & 1; // byte column, edge
+                        uint8_t *pb = (ee == 0 ? upb : tile + 2 * 16) + kb, *qb = tile + 4 * ee * 16 + kb;
+                        int p1 = pb[0], p0 = pb[16], q0 = qb[0], q1 = qb[16];
+                        edge_chroma_p(par, p1, p0, q0, q1);
+                        if (ee != 0 || my > 0) pb[16] = (uint8_t)p0;
+                        qb[0] = (uint8_t)q0;
+                    }
                 }
-            }
-            WAVE_SYNC();
-            DBR_TICK(4);
-            // ---- E. bottom strip -> ring (read by the row below after the next barrier); final samples into registers
-            if (!last_row && slane) ring[(x & 3) * ring_n + lane] = *(const unsigned *)&tile[(rows_mb + mrow) * TS + 4 + 4 * mword];
-            if (mlane) {
-                const unsigned *rp = (const unsigned *)&tile[(mrow + strip) * TS];
-                fin = rp[mword]; // line mrow, byte columns 4*mword-4 .. 4*mword-1 (the left strip is final now)
-                fsb = rp[4];     // ... and columns 12..15, which only the last macroblock of a row stores itself
-            }
-            if (my > 0 && slane) fsc = *(const unsigned *)&tile[mrow * TS + 4 + 4 * mword]; // the strip of the row above is final after this top edge
-            WAVE_SYNC();
-            if (mlane && mword == 0) *(unsigned *)&tile[(mrow + strip) * TS] = fsb; // right strip becomes the next macroblock's left strip
+            DBT_TICK(2);
         }
-        DBR_TICK(5);
-        // ---- land the prefetch (issued a whole step ago) before this step's stores queue up behind it
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" ::"v"(own), "v"(recv), "v"(gnext.x), "v"(gnext.y));
-        DBR_TICK(6);
-        if (pf) {
-            if (fed) { // every granule of the strip must carry this picture's epoch; in steady state the first load already does
-                int spins = 0;
-                while (__ballot(slane && gnext.y != epoch)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (slane) gnext = ld64_sc1(gran_up + (size_t)xn * ring_n + lane);
-                    if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; } // bounded; once tripped, nobody waits again
+    } else if (role == 1) {
+        // `cur` is the load set of this step's parity (two macroblock loads are in flight: the loop is unrolled by two so that
+        // both sets are plain registers -- a set chosen by `t & 1` lives in scratch, and its load gets waited for at once)
+        auto mstep = [&](const int t, uint4 &cur, uint2 &gpre) __attribute__((always_inline)) {
+            DBT_T0();
+            const int x = t - 1 - r;
+            const bool act = row_ok && x >= 0 && x < mbw;
+            // =========================================================== M: land macroblock x+1 | barrier | load macroblock x+3 (and the strip above x+1)
+                const int xm = x + 1, xl = x + 3;
+                const bool lands = row_ok && xm >= 0 && xm < mbw;
+                if (lands) {
+                    if (rlane) *(uint4 *)(tiles + (xm & (DBT_NB - 1)) * TILE + lane * 16) = cur;
+                    // the record goes through LDS: its four quarters are on lanes 16..19, and every lane picks the words of ITS edge
+                    // (16 v_readlane + selects cost the mover ~200 cycles more per step, and the mover sets the band's pace)
+                    unsigned *rq = recl + (xm & 1) * 16;
+                    if (lane >= 16 && lane < 20) *(uint4 *)(rq + 4 * (lane & 3)) = cur;
+                    unsigned pv, ph;
+                    if (!CHROMA) { // words 0..3: bS of the vertical / horizontal edges, two edges per word; 4..9: {alpha|beta<<8, tc0 bytes} left, top, inner
+                        const int sh = 16 * (e & 1) + 4 * (k >> 2);
+                        const unsigned vb = rq[e >> 1], hb = rq[2 + (e >> 1)];
+                        const uint2 vp = *(const uint2 *)(rq + (e == 0 ? 4 : 8)), hp = *(const uint2 *)(rq + (e == 0 ? 6 : 8));
+                        pv = par_word((vb >> sh) & 15u, vp.x, vp.y);
+                        ph = par_word((hb >> sh) & 15u, hp.x, hp.y);
+                    } else {       // chroma edges are luma edges 0 and 2: the low halves of words 0/1 and 2/3; parameters at words 10..15
+                        const int kk = lane >> 2, ee = lane & 1, kb = lane >> 1; // vertical: line kk, edge ee; horizontal: byte column kb, edge ee
+                        const unsigned vb = rq[ee], hb = rq[2 + ee];
+                        const uint2 vp = *(const uint2 *)(rq + (ee ? 14 : 10)), hp = *(const uint2 *)(rq + (ee ? 14 : 12));
+                        pv = par_word((vb >> (4 * (kk >> 1))) & 15u, vp.x, vp.y);
+                        ph = par_word((hb >> (4 * (kb >> 2))) & 15u, hp.x, hp.y);
+                    }
+                    pars[((xm & 3) * 2 + 0) * 64 + lane] = pv;
+                    pars[((xm & 3) * 2 + 1) * 64 + lane] = ph;
                 }
-                stripv = gnext.x;
-            }
-            WAVE_SYNC();
-            if (mlane) *(unsigned *)&tile[(mrow + strip) * TS + 4 + 4 * mword] = own;
-        }
-        DBR_TICK(7);
-        // ---- F. stores (nobody inside this launch reads them back)
-#ifndef DBX_NOSTORE
-        if (act) {
-            if (mlane && mrow < keep && (x > 0 || mword > 0)) stg32((uint8_t *)ld_base + x0b - 4, fin);
-            if (x == mbw - 1 && mlane && mrow < keep && mword == 3) stg32((uint8_t *)ld_base + x0b, fsb); // no right neighbour will patch columns 12..15
-            if (my > 0 && slane) stg32(sc_base + x0b, fsc);
-        }
+                if (fed && act) { // the strip above macroblock x, asked for two steps ago: every granule must carry this picture's epoch
+                    // the first test stands outside the retry loop: a loop that reloads `gpre` makes the compiler wait for every load in
+                    // flight at its header (vmcnt(0): also the loads issued half a step ago), the common case needs only the one from two steps ago
+                    unsigned gw = gpre.x;
+#ifndef DBX_NOWAITG
+                    if (up_work && __ballot(glane && gpre.y != epoch)) {
+                        uint2 g2 = gpre;
+                        int spins = 0;
+#ifdef DBT_PROF
+                        nmiss++;
 #endif
-        DBR_TICK(8);
-        {
-#define RL(i) ((unsigned)__builtin_amdgcn_readlane((int)recv, (i)))
-            constexpr int o = CHROMA ? 10 : 4; // luma: left, top, inner at words 4..9; chroma: at words 10..15
-            rc0 = make_uint4(RL(0), RL(1), RL(2), RL(3));
-            rc1 = make_uint4(RL(o), RL(o + 1), RL(o + 2), RL(o + 3));
-            rc2 = make_uint4(RL(o + 4), RL(o + 5), 0, 0);
+                        do {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (glane) g2 = ld64_sc1(gran_up + (size_t)x * ring_n + (lane - 32));
+                            if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; } // bounded; once tripped, nobody waits again
+                        } while (__ballot(glane && g2.y != epoch));
+                        gw = g2.x;
+                    }
+#endif
+                    if (glane) *(unsigned *)(ups + (x & (DBT_NB - 1)) * UPB + 4 * (lane - 32)) = gw;
+                }
+                DBT_TICK(0);
+                BAND_BARRIER();
+                DBT_TICK(1);
+                {
+                    const int xg = x + 2, xgc = xg < 0 ? 0 : (xg < mbw ? xg : mbw - 1), xlc = xl < 0 ? 0 : (xl < mbw ? xl : mbw - 1);
+                    cur = ldg128(ld_ptr + (size_t)xlc * ld_step); // first: memory operations return in order, and the granule load below (sc1, another XCD's data) takes about two steps
+                    gpre = ld64_sc1((const uint2 *)(g_ptr + (size_t)xgc * g_step)); // the strip above macroblock x+2, two steps ahead like the macroblocks: a cross-XCD round trip is longer than a step (first row of a band; elsewhere unused)
+                }
+            DBT_TICK(2);
+        };
+        for (int t = -2; t <= t_last; t += 2) { mstep(t, preA, gA); mstep(t + 1, preB, gB); }
+    } else {
+        for (int t = -2; t <= t_last; t++) {
+            DBT_T0();
+            const int x = t - 1 - r;
+            // =========================================================== S: store macroblock x-2 | barrier | publish the strip of macroblock x-1
+            // Lines 0 .. keep-1 of macroblock x-2 and the strip above it became final with the barrier of the step before (this row's
+            // vertical phase of x-1 patched its columns 12..15; the horizontal phase of x-2 finished the strip above): one LDS read
+            // and one 16-byte store per lane, per-lane addresses.
+            const int xs2 = x - 2;
+            if (row_ok && xs2 >= 0 && xs2 < mbw) {
+                const bool is_row = lane < keep, is_up = uplane && my > 0;
+                const uint8_t *upb = fed ? ups + (xs2 & (DBT_NB - 1)) * UPB : tiles_up + (xs2 & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
+                const uint8_t *src = is_row ? tiles + (xs2 & (DBT_NB - 1)) * TILE + lane * 16 : upb + (lane & 3) * 16;
+                if (is_row || is_up) stg128(st_ptr + xs2 * 16, lds128(src));
+            }
+            DBT_TICK(0);
+            BAND_BARRIER();
+            DBT_TICK(1);
+            const int xs = x - 1; // its bottom strip is final within this band now: the band below waits for it
+            if (feeds && xs >= 0 && xs < mbw && glane) {
+                const int j = lane - 32;
+                const unsigned w = *(const unsigned *)(tiles + (xs & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16 + 4 * j);
+                if (dn_work) st64_sc1(gran_my + (size_t)xs * ring_n + j, make_uint2(w, epoch));
+                else stg32(plane + (row0 + rows_mb - strip + (j >> 2)) * stride + xs * 16 + 4 * (j & 3), w); // nobody below will store it
+            }
+            DBT_TICK(2);
         }
     }
-#ifdef DBR_PROF
-    if (lane == 0 && wave == 1 && band == 1) {
-        unsigned *o = (unsigned *)(ctx->dbrec) + (CHROMA ? 16 : 0); // debug build only: overwrites the first records after use
-        for (int i = 0; i < 9; i++) o[i] = (unsigned)pc[i];
-        o[9] = (unsigned)nsteps;
+#ifdef DBT_PROF
+    if (lane == 0 && band < 2) { // rows 0..3 of bands 0 and 1
+        unsigned *o = (unsigned *)(ctx->dbrec) + (CHROMA ? 128 : 0) + 64 * band + 16 * r + 4 * role; // debug build only: overwrites the first records after use
+        for (int i = 0; i < 3; i++) o[i] = (unsigned)pc[i];
+        o[3] = (unsigned)(t_last + 3) | (nmiss << 16);
     }
 #endif
 }
 
 template <int ROWS, bool ALL_INTRA>
-__global__ __launch_bounds__(64 * ROWS) void deblock_rows_kernel(db_args a, const unsigned *__restrict__ recs) { // recs = a.ctx.dbrec, as a noalias argument: scalar loads
-    __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS * sizeof(dbr_luma)];
+__global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a, const unsigned *__restrict__ recs) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS * sizeof(dbt_luma)];
     const int nl = gridDim.x >> 1;
-    if ((int)blockIdx.x < nl) rows_body<false, ALL_INTRA, ROWS>(a, recs, a.band0 + blockIdx.x, a.nb_total, lds);
-    else rows_body<true, ALL_INTRA, ROWS>(a, recs, a.band0 + blockIdx.x - nl, a.nb_total, lds);
+#ifndef DBX_NOLUMA
+    if ((int)blockIdx.x < nl) rows3_body<false, ALL_INTRA, ROWS>(a, recs, a.band0 + blockIdx.x, a.nb_total, lds);
+#else
+    if ((int)blockIdx.x < nl) return;
+#endif
+#ifndef DBX_NOCHROMA
+    else rows3_body<true, ALL_INTRA, ROWS>(a, recs, a.band0 + blockIdx.x - nl, a.nb_total, lds);
+#endif
 }
 
 // =================================================================== launchers
@@ -580,7 +627,9 @@ void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag,
     if (y_hi < y_lo) return;
     hipLaunchKernelGGL(deblock_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
 }
-#define DB_ROWS 4 /* rows per band = waves per workgroup, one per SIMD; 8 is as fast on P pictures and 13 % slower on I pictures */
+#ifndef DB_ROWS
+#define DB_ROWS 4 /* rows per band: three waves per row, one row per SIMD (5 rows = 15 waves is equal on P pictures, a third slower on I pictures) */
+#endif
 int k_deblock_bands16(int mbh) { return (mbh + DB_ROWS - 1) / DB_ROWS; }
 size_t k_deblock_gran_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * mbw * 24 * sizeof(uint2); } // per band boundary and macroblock: 16 luma + 8 chroma granules
 // `d_progress` holds 2 * bands counters (luma, chroma) followed by the sticky error word at d_err.  The prep kernel clears
@@ -599,6 +648,6 @@ void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int ba
     a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran;
     if (band1 <= band0) return;
     const dim3 g(2 * (band1 - band0));
-    if (h_ctx->all_intra) hipLaunchKernelGGL((deblock_rows_kernel<DB_ROWS, true>), g, dim3(64 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec); // IDR pictures: every edge has work
-    else hipLaunchKernelGGL((deblock_rows_kernel<DB_ROWS, false>), g, dim3(64 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec);
+    if (h_ctx->all_intra) hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, true>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec); // IDR pictures: every edge has work
+    else hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, false>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec);
 }
