@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; int band0, nb_total; uint2 *gran; }; // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; }; // ip_progress: see GATED // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -371,7 +371,14 @@ DEV void edge_chroma_p(const unsigned par, int p1, int &p0, int &q0, int q1) {
 // {bS, alpha, beta, tc0[bS]} of one lane's edge: nib = the lane's bS nibble, ab / tcw = the edge class's packed parameters
 DEV unsigned par_word(unsigned nib, unsigned ab, unsigned tcw) { return nib | (ab << 8) | (((tcw >> (8 * ((nib - 1) & 3))) & 255u) << 24); }
 
-template <bool CHROMA, bool ALL_INTRA, int ROWS>
+// GATED: intra_p_kernel of the same picture may still be running (on another stream).  Its progress word of a macroblock row
+// says how many leading macroblocks of the row are final (it stores their samples sc1 and drains before it publishes); the
+// mover loads macroblock x only below that mark, and takes an acquire fence whenever it has read a new mark (a 128-byte line
+// holds eight macroblocks of a line: an earlier load may have cached bytes that were not final yet).  That is all the
+// ordering there is to keep: intra prediction reads the line above and the column to the left of a macroblock from the
+// picture, and this kernel writes a macroblock's lines 0..11 once its row is three macroblocks further, its bottom lines
+// once the ROW BELOW is -- by which time the marks say that the intra macroblocks that read them are done.
+template <bool CHROMA, bool ALL_INTRA, int ROWS, bool GATED>
 DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const int band, const int nb, uint8_t *lds) {
     constexpr int rows_mb = CHROMA ? 8 : 16, strip = CHROMA ? 2 : 4, ring_n = CHROMA ? 8 : 16;
     constexpr int ROW_LDS = CHROMA ? (int)sizeof(dbt_chroma) : (int)sizeof(dbt_luma);
@@ -505,6 +512,7 @@ DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const i
     } else if (role == 1) {
         // `cur` is the load set of this step's parity (two macroblock loads are in flight: the loop is unrolled by two so that
         // both sets are plain registers -- a set chosen by `t & 1` lives in scratch, and its load gets waited for at once)
+        int fin = GATED ? 0 : 0x7FFF; // macroblocks of this row known to be final
         auto mstep = [&](const int t, uint4 &cur, uint2 &gpre) __attribute__((always_inline)) {
             DBT_T0();
             const int x = t - 1 - r;
@@ -561,6 +569,17 @@ DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const i
                 DBT_TICK(1);
                 {
                     const int xg = x + 2, xgc = xg < 0 ? 0 : (xg < mbw ? xg : mbw - 1), xlc = xl < 0 ? 0 : (xl < mbw ? xl : mbw - 1);
+                    if (GATED && row_ok && xl >= 0 && xl < mbw && xl >= fin) {
+                        const unsigned tag = (epoch & 0xFFFFFu) << 12; // IP_EPOCH of k_intra.hip
+                        int spins = 0;
+                        for (;;) {
+                            const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_sc1(a.ip_progress + my));
+                            if ((v & ~0xFFFu) == tag && (int)(v & 0xFFFu) > xl) { fin = (int)(v & 0xFFFu); break; }
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); fin = 0x7FFF; break; } // bounded; once tripped, nobody waits again
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
                     cur = ldg128(ld_ptr + (size_t)xlc * ld_step); // first: memory operations return in order, and the granule load below (sc1, another XCD's data) takes about two steps
                     gpre = ld64_sc1((const uint2 *)(g_ptr + (size_t)xgc * g_step)); // the strip above macroblock x+2, two steps ahead like the macroblocks: a cross-XCD round trip is longer than a step (first row of a band; elsewhere unused)
                 }
@@ -604,17 +623,17 @@ DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const i
 #endif
 }
 
-template <int ROWS, bool ALL_INTRA>
+template <int ROWS, bool ALL_INTRA, bool GATED>
 __global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a, const unsigned *__restrict__ recs) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS * sizeof(dbt_luma)];
     const int nl = gridDim.x >> 1;
 #ifndef DBX_NOLUMA
-    if ((int)blockIdx.x < nl) rows3_body<false, ALL_INTRA, ROWS>(a, recs, a.band0 + blockIdx.x, a.nb_total, lds);
+    if ((int)blockIdx.x < nl) rows3_body<false, ALL_INTRA, ROWS, GATED>(a, recs, a.band0 + blockIdx.x, a.nb_total, lds);
 #else
     if ((int)blockIdx.x < nl) return;
 #endif
 #ifndef DBX_NOCHROMA
-    else rows3_body<true, ALL_INTRA, ROWS>(a, recs, a.band0 + blockIdx.x - nl, a.nb_total, lds);
+    else rows3_body<true, ALL_INTRA, ROWS, GATED>(a, recs, a.band0 + blockIdx.x - nl, a.nb_total, lds);
 #endif
 }
 
@@ -643,11 +662,12 @@ void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int row0, int row1
     if (n_c > m) m = n_c;
     if (m > 0) hipLaunchKernelGGL(deblock_prep_kernel, dim3((m + 255) / 256), dim3(256), 0, s, *h_ctx, clr_a, n_a, clr_b, n_b, clr_c, n_c, flags, row0 * mbw, row1 * mbw, DB_ROWS);
 }
-void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, uint2 *d_gran, hipStream_t s) {
+void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, uint2 *d_gran, const unsigned *d_ip_progress, hipStream_t s) {
     db_args a;
-    a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran;
+    a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress;
     if (band1 <= band0) return;
     const dim3 g(2 * (band1 - band0));
-    if (h_ctx->all_intra) hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, true>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec); // IDR pictures: every edge has work
-    else hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, false>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec);
+    if (h_ctx->all_intra) hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, true, false>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec); // IDR pictures: every edge has work
+    else if (d_ip_progress) hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, false, true>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec); // beside intra_p_kernel
+    else hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, false, false>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec);
 }

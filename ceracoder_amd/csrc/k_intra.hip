@@ -284,7 +284,7 @@ struct intra_lds {
 
 // Reconstruction of one intra macroblock by two waves (wave 0 luma, wave 1 chroma; the planes share nothing after the
 // decisions).  Needs L->top / L->left in place and visible; dec0/dec1: the 24-byte decision of intra_analyse_kernel.
-template <bool OUT>
+template <bool OUT, bool SC1 = false> // SC1: reconstruction stored write-through (sc1): intra_p_kernel, whose samples the deblocker reads while the kernel runs
 DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, intra_lds *L, const int mx, const int my, const int wave, const int lane,
                        const uint4 dec0, const uint2 dec1, const uint2 *presrc = nullptr) { // presrc: this lane's source samples, loaded ahead (luma: .x, one word; chroma: the 8 interleaved bytes)
     int (*top)[17] = L->top;
@@ -504,7 +504,8 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
 #pragma unroll
         for (int i = 0; i < 4; i++) o[i] = clip255(pd[i] + ((inv_col(x[i], cb) + 32) >> 6));
         const unsigned rw = pack4(o[0], o[1], o[2], o[3]);
-        stg32(ry + (size_t)(y0 + yy) * stride + x0 + 4 * bx, rw);
+        if (SC1) st_sc1((unsigned *)(ry + (size_t)(y0 + yy) * stride + x0 + 4 * bx), rw);
+        else stg32(ry + (size_t)(y0 + yy) * stride + x0 + 4 * bx, rw);
         if (OUT) {
             if (yy == 15) *(unsigned *)&L->bot_y[slot][4 * bx] = rw;
             if (bx == 3) L->right_y[yy] = (uint8_t)(rw >> 24);
@@ -545,7 +546,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
 #pragma unroll
             for (int i = 0; i < 4; i++) pd[i] = clip255((pa + pb * (bx + i - 3) + pc * (yy - 3) + 16) >> 5);
         }
-        chroma_rows4(ctx, T, ctx->levels + (size_t)mbn * MB_LEVELS, cx0, cy0, lane, pd, csv, qp, true, true, OUT ? L->crec : nullptr, cnz8, cdc2, false, ctx->iac_drop);
+        chroma_rows4(ctx, T, ctx->levels + (size_t)mbn * MB_LEVELS, cx0, cy0, lane, pd, csv, qp, true, true, OUT ? L->crec : nullptr, cnz8, cdc2, false, ctx->iac_drop, SC1);
     }
 #undef TOP
 #undef LEFT
@@ -787,6 +788,11 @@ __global__ __launch_bounds__(128) void intra_p_kernel(ip_args a) {
     }
     for (int i = threadIdx.x; i < TAB_DWORDS; i += 128) tabw[i] = ((const unsigned *)&g_tab)[i];
     __syncthreads();
+    if (threadIdx.x == 0) { // everything left of the row's first intra macroblock is final already (pmb_kernel): the deblocker may start on it
+        int nx = mbw;
+        for (int w2 = (mbw + 31) / 32 - 1; w2 >= 0; w2--) if (ibits[w2]) nx = 32 * w2 + __builtin_ctz(ibits[w2]);
+        if (nx < mbw) st_sc1(&a.progress[my], ep | (unsigned)nx);
+    }
     int prev_x = -2; // the macroblock this workgroup reconstructed last (its right column is in LD)
     for (int w = 0; w < (mbw + 31) / 32; w++) {
         unsigned bits = ibits[w];
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(128) void intra_p_kernel(ip_args a) {
             __syncthreads();
             if (threadIdx.x == 0) { LD.left[0][0] = LD.top[0][0]; LD.left[1][0] = LD.top[1][0]; LD.left[2][0] = LD.top[2][0]; }
             __syncthreads();
-            intra_compute<true>(ctx, T, &LD, mx, my, wave, lane, dec0, dec1);
+            intra_compute<true, true>(ctx, T, &LD, mx, my, wave, lane, dec0, dec1);
             __syncthreads(); // bot_y / bot_c / right_* of this macroblock are in LD
             // publish the bottom lines for the row below: 32 bytes, sc1
             if (threadIdx.x < 8) {

@@ -344,7 +344,7 @@ DEV int dec_score_mask(unsigned M) { // decimate score of a +-1-only block from 
     return (int)(3 * c0 + 2 * (unsigned)__popc(a1) - (unsigned)__popc(a3) - (unsigned)__popc(a6));
 }
 DEV void chroma_rows4(const frame_ctx_t *ctx, const dev_tables *T, int16_t *lv, int cx0, int cy0, int lane, const int *pd, const int *sv, int qp,
-                      bool intra, bool ok, uint8_t *lrec, unsigned &nz8, unsigned &dc2, bool decimate = false, int all_drop = 0) {
+                      bool intra, bool ok, uint8_t *lrec, unsigned &nz8, unsigned &dc2, bool decimate = false, int all_drop = 0, bool sc1 = false) {
     const bool cl = lane < 32;
     const int py = (lane >> 2) & 3, fy = ((py & 1) << 1) | (py >> 1);
     const int cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1, cy = cby * 4 + py, cxb = cbx * 4;
@@ -406,7 +406,9 @@ DEV void chroma_rows4(const frame_ctx_t *ctx, const dev_tables *T, int16_t *lv, 
         uint2 out;
         out.x = __builtin_amdgcn_perm(other, mine, 0x05010400u); // U0 V0 U1 V1
         out.y = __builtin_amdgcn_perm(other, mine, 0x07030602u); // U2 V2 U3 V3
-        stg64(ctx->rec_uv + (size_t)(cy0 + cy) * ctx->stride + 2 * (cx0 + cxb), out);
+        uint8_t *dst = ctx->rec_uv + (size_t)(cy0 + cy) * ctx->stride + 2 * (cx0 + cxb);
+        if (sc1) st64_sc1((uint2 *)dst, out); // intra macroblocks of P pictures: the deblocker of the same picture follows the reconstruction while it is written
+        else stg64(dst, out);
         if (lrec) *(uint2 *)&lrec[cy * 16 + 2 * cxb] = out;
     }
     const unsigned long long bal = __ballot(cl && (lev[0] | lev[1] | lev[2] | lev[3]) != 0);

@@ -87,6 +87,9 @@ struct mi355enc {
     unsigned *d_ip_progress; // intra macroblocks of P pictures: one progress word per macroblock row (epoch-tagged, never cleared)
     uint8_t *d_ip_strips;    // ... and the bottom lines they publish for the row below, 32 bytes per macroblock
     uint32_t epoch;
+    hipStream_t dstream;       // prep + band deblocker of a P picture with intra macroblocks: beside intra_p_kernel, which it follows row by row
+    hipEvent_t ev_db[2], ev_pmb; // [reconstruction buffer]: its last deblocking on dstream has finished; ev_pmb: the fused P stage of the picture is done
+    int db_split[2];           // ... whether that deblocking ran on dstream
     int n_progress;
     slot_t slot[NSLOT];
     int head, tail, pending;
@@ -165,13 +168,13 @@ static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
     return 0;
 }
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
-static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
+static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress) {
     if (h->cfg.deblock_mode == 0) { // prep kernel (also clears the progress counters) + persistent 16-row band kernel
         const int nb = k_deblock_bands16(h->mbh);
         // nothing else is in flight: clear the other set entirely and this set's counters (its flags were cleared by the previous picture's prep
         // kernel or at open; this launch raises them)
-        k_launch_deblock_prep(hc, h->mbw, 0, h->mbh, prog_set(h, ci ^ 1), h->n_progress, prog_set(h, ci), 2 * nb, nullptr, 0, prog_set(h, ci) + 2 * nb, h->stream);
-        k_launch_deblock_bands(hc, h->mbh, 0, nb, prog_set(h, ci), err_word(h), h->d_db_gran, h->stream);
+        k_launch_deblock_prep(hc, h->mbw, 0, h->mbh, prog_set(h, ci ^ 1), h->n_progress, prog_set(h, ci), 2 * nb, nullptr, 0, prog_set(h, ci) + 2 * nb, st);
+        k_launch_deblock_bands(hc, h->mbh, 0, nb, prog_set(h, ci), err_word(h), h->d_db_gran, ip_progress, st);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -213,7 +216,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->d_db_gran = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->dstream = nullptr; h->ev_db[0] = h->ev_db[1] = h->ev_pmb = nullptr; h->db_split[0] = h->db_split[1] = 0; h->d_db_gran = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -229,6 +232,9 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
         HIPCHK(hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, lo));
+        HIPCHK(hipStreamCreateWithPriority(&h->dstream, hipStreamNonBlocking, 0));
+        for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_db[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_pmb, hipEventDisableTiming));
     }
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&h->d_mbi_set[i], (size_t)h->nmb * sizeof(mb_info_t)));
@@ -303,6 +309,9 @@ void mi355enc_close(mi355enc_t *h) {
     (void)hipSetDevice(h->cfg.device_id);
     if (h->fstream) (void)hipStreamSynchronize(h->fstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->dstream) (void)hipStreamSynchronize(h->dstream);
+    for (int i = 0; i < 2; i++) if (h->ev_db[i]) (void)hipEventDestroy(h->ev_db[i]);
+    if (h->ev_pmb) (void)hipEventDestroy(h->ev_pmb);
     for (int i = 0; i < 2; i++) { if (h->g_intra[i]) (void)hipGraphExecDestroy(h->g_intra[i]); if (h->g_deblock[i]) (void)hipGraphExecDestroy(h->g_deblock[i]); }
     for (int i = 0; i < NSLOT; i++) {
         slot_t *s = &h->slot[i];
@@ -340,6 +349,7 @@ void mi355enc_close(mi355enc_t *h) {
     for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
     if (h->fstream) (void)hipStreamDestroy(h->fstream);
+    if (h->dstream) (void)hipStreamDestroy(h->dstream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h264_writer_free(h->writer);
     delete h;
@@ -369,6 +379,7 @@ int mi355enc_mb_height(const mi355enc_t *h) { return h ? h->mbh : 0; }
 static int sync_compute(mi355enc_t *h) {
     HIPCHK(hipStreamSynchronize(h->fstream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->dstream));
     return 0;
 }
 static hipStream_t upload_stream(const mi355enc_t *h) { return h->fstream; }
@@ -405,7 +416,7 @@ static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof
     return 0;
 }
 // ... and back part (back stream): needs the deblocked picture before it
-static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof) {
+static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split) {
     hipStream_t st = h->stream;
     if (prof) HIPCHK(hipEventRecord(s->ev[8], st));
     if (h->cfg.transform8x8) { // High profile: the two-kernel form (absolute-vector refinement, 8x8 transform), no skip / intra logic
@@ -416,6 +427,7 @@ static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof)
     } else {
         k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, st);
         if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
+        if (split) HIPCHK(hipEventRecord(h->ev_pmb, st)); // prep + the band deblocker start from here on their own stream, beside intra_p_kernel
         if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
     }
     if (prof) HIPCHK(hipEventRecord(s->ev[11], st));
@@ -473,12 +485,19 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         HIPCHK(hipEventRecord(s->ev_front, h->fstream));
         HIPCHK(hipStreamWaitEvent(h->stream, s->ev_front, 0));
         h->psrc_cur ^= 1;
+        // A deblocking still running on its own stream (see below) is joined here: a P picture reads all of it, an IDR picture writes
+        // the other reconstruction buffer, whose deblocking came earlier on the same stream.
+        for (int b = 0; b < 2; b++) if (h->db_split[b]) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_db[b], 0)); h->db_split[b] = 0; }
+        // P picture with intra macroblocks: intra_p_kernel (a chain along rows, 10..50 us) and the band deblocker (a chain along
+        // x + y) overlap -- the deblocker's movers follow intra_p_kernel's per-row progress words (GATED, k_deblock.hip).  Not on
+        // pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
+        const int split = !idr && fused && c->intra_p && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof;
         if (idr) {
             if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
             int r = run_intra(h, ci, c); if (r) return r;
             if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
         } else {
-            int r = run_p_back(h, c, s, prof); if (r) return r;
+            int r = run_p_back(h, c, s, prof, split); if (r) return r;
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
@@ -488,7 +507,14 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
             HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
             if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         }
-        int r = run_deblock(h, ci, c); if (r) return r;
+        if (split) {
+            HIPCHK(hipStreamWaitEvent(h->dstream, h->ev_pmb, 0));
+            int r = run_deblock(h, ci, c, h->dstream, h->d_ip_progress); if (r) return r;
+            HIPCHK(hipEventRecord(h->ev_db[nxt], h->dstream));
+            h->db_split[nxt] = 1;
+        } else {
+            int r = run_deblock(h, ci, c, h->stream, nullptr); if (r) return r;
+        }
         if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
         HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
         // Hand-over on the second stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:
@@ -822,7 +848,7 @@ int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const
     HIPCHK(hipMemcpyAsync(h->d_rec_uv[1], rec_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, 26, false); if (r) return r;
-    r = run_deblock(h, 0, h->slot[0].h_ctx); if (r) return r;
+    r = run_deblock(h, 0, h->slot[0].h_ctx, h->stream, nullptr); if (r) return r;
     HIPCHK(hipMemcpyAsync(rec_y, h->d_rec_y[1], h->ysz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(rec_uv, h->d_rec_uv[1], h->csz, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -855,7 +881,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
                 const uint8_t *p0 = s->d_raw, *p1 = p0 + (size_t)r0 * ht, *p2 = p1 + (size_t)r1 * (ht / 2);
                 k_launch_csc(stage - 4, p0, p1, p2, r0, r1, r1, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, h->stream);
             }
-            else { if (++h->epoch == 0) h->epoch = 1; h->slot[0].h_ctx->epoch = h->epoch; int r = run_deblock(h, 0, h->slot[0].h_ctx); if (r) return r; } // a fresh stamp per launch: the strips between bands are epoch-tagged
+            else { if (++h->epoch == 0) h->epoch = 1; h->slot[0].h_ctx->epoch = h->epoch; int r = run_deblock(h, 0, h->slot[0].h_ctx, h->stream, nullptr); if (r) return r; } // a fresh stamp per launch: the strips between bands are epoch-tagged
         }
         if (warm) HIPCHK(hipEventRecord(s->ev[1], h->stream));
     }
