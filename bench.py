@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--fixed-qp", type=int, default=-1)
     ap.add_argument("--depth", type=int, default=1)
     ap.add_argument("--deblock-mode", type=int, default=0)
-    ap.add_argument("--sample", type=int, default=7, help="stage timers (HIP events) on every k-th picture; each event record costs ~5 us of queue time")
+    ap.add_argument("--sample", type=int, default=13, help="stage timers (HIP events) on every k-th picture (and every IDR): a sampled picture costs ~12 event records of ~5 us queue time each and runs its stages strictly in order (no deblocking beside the intra macroblocks of a P picture)")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent streams encoded concurrently on each GPU (one host thread each); the headline configuration is 1")
     ap.add_argument("--cavlc-threads", type=int, default=0, help="host threads coding one slice row-parallel (bit-identical output); 0 = the encoder's default (automatic, at most 8)")
     ap.add_argument("--rate-script", default="auto", help="bitrate setpoints written to the encoder while it runs: 'none', or a balancer of the reference "
@@ -320,8 +320,11 @@ def main():
         # iteration = the macroblock's SAD surface read once (35 x 36 uint16) + the three neighbours' vectors + its own 8-byte
         # result = 2552 B/MB = 9.97 P (the stage this design adds to make the motion search's HBM output do the regularising).
         ALG = {"me_kernel": 2.03125, "me_select_kernel (one of %d iterations)" % 3: 2552.0 / 256, "subpel_kernel": 2.125, "inter_kernel": 7.5625,
-               "intra (analyse + x+y wavefront)": 6.0625, "deblock (prep + band16 kernel)": 3.0625}
+               "intra (analyse + x+y wavefront)": 6.0625, "deblock (prep + band kernel)": 3.0625}
         SEL = "me_select_kernel (one of %d iterations)" % 3
+        # what THIS design moves per launch where that differs from the survey's figure: me_kernel also writes the SAD surfaces (2520 B/MB) and the
+        # source copy the next picture searches against -- traffic is to be compared with this one
+        DESIGN = {"me_kernel": 3.0 + 2528.0 / 256}
         db_p = (st.ms_deblock - st.ms_deblock_idr, st.n_deblock - st.n_deblock_idr) if st.n_deblock > st.n_deblock_idr else (st.ms_deblock, st.n_deblock)
         FUSED = "pmb_kernel (skip probe + refinement + intra-or-inter + residual, fused)"
         fused = not args.dct8x8  # the 8x8-transform path keeps subpel_kernel + inter_kernel
@@ -329,23 +332,23 @@ def main():
         pmb_ms = st.ms_inter - st.ms_analyse_p - st.ms_intra_p if fused else st.ms_inter
         per = {"me_kernel": (st.ms_me, st.n_me), SEL: (st.ms_select / 3.0, st.n_me), "subpel_kernel": (st.ms_subpel, 0 if fused else st.n_me),
                ("inter_kernel" if not fused else FUSED): (pmb_ms, st.n_inter),
-               "intra (analyse + x+y wavefront)": (st.ms_intra, st.n_intra), "deblock (prep + band16 kernel)": db_p}
+               "intra (analyse + x+y wavefront)": (st.ms_intra, st.n_intra), "deblock (prep + band kernel)": db_p}
         bound = {"me_kernel": "VALU SAD issue rate (~142 T abs-diff/s chip-wide, tools/ubench_sad.hip): 1089*P abs-diffs -> >=17.6 us @1080p; besides the survey's "
                               "2.03 P it writes the 9.84 P of SAD surfaces (2520 B per macroblock) that the selection iterations and the fused stage read",
                  SEL: "HBM / Infinity Cache: streams every macroblock's SAD surface once per iteration",
                  "subpel_kernel": "LDS-staged 6-tap planes, latency/LDS", "inter_kernel": "launch + byte stores of interleaved chroma",
                  FUSED: "VALU issue: one wave per macroblock (skip probe; 6-tap planes, 8 SAD + 9 SATD candidates; transforms on all 64 lanes; decimation)",
                  "intra (analyse + x+y wavefront)": "dependency chain: mbw+mbh-1 dependent steps of the persistent band kernel",
-                 "deblock (prep + band16 kernel)": "dependency chain of the normative filter order: ~mbw+mbh dependent steps of ~1.5 us inside one persistent launch"}
+                 "deblock (prep + band kernel)": "dependency chain of the normative filter order: mbw+mbh dependent steps of ~0.35 us + ~2 us per band boundary inside one persistent launch (three waves per macroblock row: filter / mover / storer)"}
         pmc_name = {"me_kernel": "me_kernel", SEL: "me_select_kernel", FUSED: "pmb_kernel", "intra (analyse + x+y wavefront)": "intra_band_kernel",
-                    "deblock (prep + band16 kernel)": "deblock_band16_kernel"}
+                    "deblock (prep + band kernel)": "deblock_rows3_kernel"}
         kernels = []
         n_idr, n_p = int(st.idr_frames), int(st.frames - st.idr_frames - st.skip_pictures)
         weight = {"me_kernel": n_p, SEL: 3 * n_p, "subpel_kernel": n_p, "inter_kernel": n_p, FUSED: n_p, "intra (analyse + x+y wavefront)": n_idr,
-                  "deblock (prep + band16 kernel)": n_idr + n_p}  # launches in the timed region (timers are sampled)
+                  "deblock (prep + band kernel)": n_idr + n_p}  # launches in the timed region (timers are sampled)
         db_i_avg = st.ms_deblock_idr / st.n_deblock_idr if st.n_deblock_idr else 0.0
         if n_p and st.n_deblock_idr:  # deblocking of P pictures is the roofline entry; IDR pictures are added to the total separately
-            weight["deblock (prep + band16 kernel)"] = n_p
+            weight["deblock (prep + band kernel)"] = n_p
         other_p = (st.ms_analyse_p + st.ms_intra_p) / max(1, st.n_inter)  # gated intra analysis + intra macroblocks of P pictures
         est_total = (sum(weight[k] * (ms / n) for k, (ms, n) in per.items() if n) + (n_idr * db_i_avg if n_p else 0.0) + n_p * other_p) or 1e-9
         for name, (ms, n) in per.items():
@@ -356,9 +359,12 @@ def main():
             pk = (prof or {}).get(pmc_name.get(name, ""), {})
             kernels.append({"kernel": name, "launches_timed": int(n), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": int(ALG[name] * P),
                             "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                            "design_bytes_per_launch": int(DESIGN.get(name, ALG[name]) * P),
                             "traffic": pk.get("hbm_bytes_per_launch_corrected"), "kernel_trace_avg_us": pk.get("kernel_trace_avg_us"),
                             "time_share": round(weight[name] * (ms / n) / est_total, 4), "bounded_by": bound[name]})
         kernels.sort(key=lambda k: -k["time_share"])
+        if not kernels:
+            raise SystemExit("bench.py: no stage timers were sampled (--sample 0?): the roofline block needs them")
         dom = kernels[0]
         roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
                 "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],

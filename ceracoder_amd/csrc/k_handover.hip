@@ -79,7 +79,7 @@ __global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__re
 // one wave per macroblock: lane c < 27 is one candidate block of the stream order above
 __global__ __launch_bounds__(256) void levels_pack_kernel(const mb_info_t *__restrict__ mbi, const int16_t *__restrict__ levels, int nmb,
                                                           const unsigned *__restrict__ off, mb_info_t *__restrict__ h_mbi, int16_t *__restrict__ h_packed) {
-    const int mb = blockIdx.x * 4 + (threadIdx.x >> 6), c = threadIdx.x & 63;
+    const int mb = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = threadIdx.x & 63;
     if (mb >= nmb) return;
     const uint4 r = ldg128(&mbi[mb]);
     const unsigned nz = r.z, type = r.y & 255;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void inter_kernel(const frame_ctx_t cv, int mb
     const frame_ctx_t *__restrict__ ctx = &cv;
     const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
     const int W = mbw * 16, H = ctx->mbh * 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     const int pair = blockIdx.x * 4 + wave;
     const bool is_luma = lane < 32, is_chroma = lane >= 32 && lane < 48;
     const int sel = is_luma ? lane >> 4 : (is_chroma ? (lane - 32) >> 3 : 0);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
     __shared__ __attribute__((aligned(4))) uint8_t SL[4][17 * IA_S];
     __shared__ __attribute__((aligned(4))) uint8_t SC[4][2][9 * 12]; // [plane][row 0 = y -1][col 0 = x -1]
     const int mbw = ctx->mbw, nmb = mbw * ctx->mbh;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     int mbn = blockIdx.x * 4 + wave;
     const bool ok = mbn < nmb;
     if (!ok) mbn = nmb - 1;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
     const int my = y_lo + blockIdx.x, mx = diag - my;
     const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
     const bool has_top = my > 0, has_left = mx > 0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     const uint8_t *__restrict__ ry = ctx->rec_y;
     const uint8_t *__restrict__ ruv = ctx->rec_uv;
     for (int i = threadIdx.x; i < TAB_DWORDS; i += 128) tabw[i] = ((const unsigned *)&g_tab)[i];
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     const dev_tables *T = (const dev_tables *)tabw;
     const frame_ctx_t *__restrict__ ctx = &a.ctx;
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
-    const int band = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = w >> 1, role = w & 1;
+    const int band = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = w >> 1, role = w & 1; // (w through readfirstlane, i.e. scalar control flow, made this kernel 14 % SLOWER: measured, left as it is)
     const int my = band * IB_ROWS + r;
     const bool row_ok = my < mbh, has_top = my > 0;
     const bool fed = row_ok && r == 0 && band > 0;                        // top samples come from the band above
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(128) void intra_p_kernel(ip_args a) {
     __shared__ int sh_bad;
     const dev_tables *T = (const dev_tables *)tabw;
     const int mbw = ctx->mbw, stride = ctx->stride, my = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     const uint8_t *__restrict__ ry = ctx->rec_y;
     const uint8_t *__restrict__ ruv = ctx->rec_uv;
     const unsigned ep = IP_EPOCH(ctx->epoch);

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
 __global__ __launch_bounds__(256) void me_select_kernel(const frame_ctx_t cv, int mb0, int mb1, const imv_t *__restrict__ in, imv_t *__restrict__ out) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     const int mbw = ctx->mbw;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     const int mbn = mb0 + xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     if (mbn >= mb1) return; // wave-uniform; no workgroup barrier below
     const int my = mbn / mbw, mx = mbn - my * mbw;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void subpel_kernel(const frame_ctx_t cv, int m
     const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     int mbn = mb0 + blockIdx.x * 4 + wave; // the launch covers macroblocks mb0 .. mb1-1
     const bool ok = mbn < mb1;
     if (!ok) mbn = mb1 - 1;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
     const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = ctx->qp, lambda = ctx->lambda;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     const int mbn = mb0 + blockIdx.x * 4 + wave; // the launch covers macroblocks mb0 .. mb1-1
     if (mbn >= mb1) return;                      // wave-uniform; the kernel has no workgroup barrier
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;

@@ -87,9 +87,8 @@ struct mi355enc {
     unsigned *d_ip_progress; // intra macroblocks of P pictures: one progress word per macroblock row (epoch-tagged, never cleared)
     uint8_t *d_ip_strips;    // ... and the bottom lines they publish for the row below, 32 bytes per macroblock
     uint32_t epoch;
-    hipStream_t dstream;       // prep + band deblocker of a P picture with intra macroblocks: beside intra_p_kernel, which it follows row by row
-    hipEvent_t ev_db[2], ev_pmb; // [reconstruction buffer]: its last deblocking on dstream has finished; ev_pmb: the fused P stage of the picture is done
-    int db_split[2];           // ... whether that deblocking ran on dstream
+    hipStream_t istream;       // intra_p_kernel of a P picture: beside prep + the band deblocker, which follows it row by row
+    hipEvent_t ev_pmb;         // the fused P stage of the picture is done
     int n_progress;
     slot_t slot[NSLOT];
     int head, tail, pending;
@@ -216,7 +215,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->dstream = nullptr; h->ev_db[0] = h->ev_db[1] = h->ev_pmb = nullptr; h->db_split[0] = h->db_split[1] = 0; h->d_db_gran = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -232,8 +231,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
         HIPCHK(hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, lo));
-        HIPCHK(hipStreamCreateWithPriority(&h->dstream, hipStreamNonBlocking, 0));
-        for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_db[i], hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, 0));
         HIPCHK(hipEventCreateWithFlags(&h->ev_pmb, hipEventDisableTiming));
     }
     for (int i = 0; i < 2; i++) {
@@ -309,8 +307,7 @@ void mi355enc_close(mi355enc_t *h) {
     (void)hipSetDevice(h->cfg.device_id);
     if (h->fstream) (void)hipStreamSynchronize(h->fstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->dstream) (void)hipStreamSynchronize(h->dstream);
-    for (int i = 0; i < 2; i++) if (h->ev_db[i]) (void)hipEventDestroy(h->ev_db[i]);
+    if (h->istream) (void)hipStreamSynchronize(h->istream);
     if (h->ev_pmb) (void)hipEventDestroy(h->ev_pmb);
     for (int i = 0; i < 2; i++) { if (h->g_intra[i]) (void)hipGraphExecDestroy(h->g_intra[i]); if (h->g_deblock[i]) (void)hipGraphExecDestroy(h->g_deblock[i]); }
     for (int i = 0; i < NSLOT; i++) {
@@ -349,7 +346,7 @@ void mi355enc_close(mi355enc_t *h) {
     for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
     if (h->fstream) (void)hipStreamDestroy(h->fstream);
-    if (h->dstream) (void)hipStreamDestroy(h->dstream);
+    if (h->istream) (void)hipStreamDestroy(h->istream);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h264_writer_free(h->writer);
     delete h;
@@ -379,7 +376,7 @@ int mi355enc_mb_height(const mi355enc_t *h) { return h ? h->mbh : 0; }
 static int sync_compute(mi355enc_t *h) {
     HIPCHK(hipStreamSynchronize(h->fstream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipStreamSynchronize(h->dstream));
+    HIPCHK(hipStreamSynchronize(h->istream));
     return 0;
 }
 static hipStream_t upload_stream(const mi355enc_t *h) { return h->fstream; }
@@ -427,8 +424,11 @@ static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof,
     } else {
         k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, st);
         if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
-        if (split) HIPCHK(hipEventRecord(h->ev_pmb, st)); // prep + the band deblocker start from here on their own stream, beside intra_p_kernel
-        if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
+        if (split) { // intra_p_kernel leaves the chain: prep + the band deblocker follow the fused stage directly and overtake it row by row
+            HIPCHK(hipEventRecord(h->ev_pmb, st));
+            HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0));
+            k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->istream);
+        } else if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
     }
     if (prof) HIPCHK(hipEventRecord(s->ev[11], st));
     HIPCHK(hipGetLastError());
@@ -485,12 +485,10 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         HIPCHK(hipEventRecord(s->ev_front, h->fstream));
         HIPCHK(hipStreamWaitEvent(h->stream, s->ev_front, 0));
         h->psrc_cur ^= 1;
-        // A deblocking still running on its own stream (see below) is joined here: a P picture reads all of it, an IDR picture writes
-        // the other reconstruction buffer, whose deblocking came earlier on the same stream.
-        for (int b = 0; b < 2; b++) if (h->db_split[b]) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_db[b], 0)); h->db_split[b] = 0; }
-        // P picture with intra macroblocks: intra_p_kernel (a chain along rows, 10..50 us) and the band deblocker (a chain along
-        // x + y) overlap -- the deblocker's movers follow intra_p_kernel's per-row progress words (GATED, k_deblock.hip).  Not on
-        // pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
+        // P picture with intra macroblocks: intra_p_kernel (a chain along rows, 10..80 us) and the band deblocker (a chain along
+        // x + y) overlap -- intra_p_kernel runs on a stream of its own and the deblocker's movers follow its per-row progress words
+        // (GATED, k_deblock.hip); the chain pmb -> prep -> deblocker -> next pmb stays on one stream (a cross-stream event on the
+        // chain costs 10-17 us).  Not on pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
         const int split = !idr && fused && c->intra_p && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof;
         if (idr) {
             if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
@@ -501,20 +499,13 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(s->gpu_done, h->stream)); // records and levels are final here; they do not depend on deblocking
+        HIPCHK(hipEventRecord(s->gpu_done, split ? h->istream : h->stream)); // records and levels are final here; they do not depend on deblocking
         if (h->d_pre_y) {
             HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
             HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
             if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         }
-        if (split) {
-            HIPCHK(hipStreamWaitEvent(h->dstream, h->ev_pmb, 0));
-            int r = run_deblock(h, ci, c, h->dstream, h->d_ip_progress); if (r) return r;
-            HIPCHK(hipEventRecord(h->ev_db[nxt], h->dstream));
-            h->db_split[nxt] = 1;
-        } else {
-            int r = run_deblock(h, ci, c, h->stream, nullptr); if (r) return r;
-        }
+        { int r = run_deblock(h, ci, c, h->stream, split ? h->d_ip_progress : nullptr); if (r) return r; }
         if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
         HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
         // Hand-over on the second stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:

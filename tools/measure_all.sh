@@ -1,18 +1,10 @@
-# Refreshes everything under profiles/ on a GPU box: bench lines of the four workloads and the multi-stream runs, the rocprofv3
-# kernel trace and the two PMC passes; afterwards (here): python tools/pmc_summary.py 1 1080p_ippp gpurun_out/final/ks/ks_results.db gpurun_out/final/pmc_f gpurun_out/final/pmc_w
-#   gpurun --timeout 1200 -- bash tools/measure_all.sh
+# Refreshes everything under profiles/ on a GPU box: the rocprofv3 kernel trace and the two PMC passes first (so that the bench lines can
+# attach the HBM traffic of THIS build), then the bench lines of the four workloads and the multi-stream runs.
+#   gpurun --timeout 1200 -- bash tools/measure_all.sh [ROUND]      afterwards: cp gpurun_out/final/profiles/* profiles/
 set -e
 R=$PWD
-mkdir -p gpurun_out/final
-for wl in 1080p_ippp 1080p_intra 2160p_ippp 720p_ippp; do
-  extra=""; [ $wl != 1080p_ippp ] && extra="--no-gst-latency"
-  timeout -k 10 400 python bench.py --workload $wl $extra > gpurun_out/final/bench_$wl.log 2>&1
-  echo "bench $wl done"
-done
-for s in 4 8; do
-  timeout -k 10 300 python bench.py --streams-per-gpu $s --no-gst-latency --no-cpu-baseline > gpurun_out/final/bench_1080p_ippp_streams$s.log 2>&1
-  echo "streams $s done"
-done
+RND=${1:-2}
+mkdir -p gpurun_out/final/profiles
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/final/ks -o ks -- python3 $R/bench.py --no-cpu-baseline --no-gst-latency > $R/gpurun_out/final/ks.log 2>&1
 echo "kernel stats done"
@@ -21,5 +13,18 @@ echo "pmc fetch done"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_w -o w -- python3 $R/bench.py --steps 120 --warmup 20 --no-cpu-baseline --no-gst-latency > $R/gpurun_out/final/pmc_w.log 2>&1
 echo "pmc write done"
 cd $R
+python tools/pmc_summary.py $RND 1080p_ippp gpurun_out/final/ks/ks_results.db gpurun_out/final/pmc_f gpurun_out/final/pmc_w > gpurun_out/final/pmc_summary.log 2>&1
+for wl in 1080p_ippp 1080p_intra 2160p_ippp 720p_ippp; do
+  extra=""; [ $wl != 1080p_ippp ] && extra="--no-gst-latency"
+  timeout -k 10 400 python bench.py --workload $wl $extra > gpurun_out/final/bench_$wl.log 2>&1
+  grep '^{' gpurun_out/final/bench_$wl.log | tail -1 > profiles/r0${RND}_bench_$wl.json
+  echo "bench $wl done"
+done
+for s in 2 4; do
+  timeout -k 10 300 python bench.py --streams-per-gpu $s --no-gst-latency --no-cpu-baseline > gpurun_out/final/bench_1080p_ippp_streams$s.log 2>&1
+  grep '^{' gpurun_out/final/bench_1080p_ippp_streams$s.log | tail -1 > profiles/r0${RND}_bench_1080p_ippp_streams$s.json
+  echo "streams $s done"
+done
+cp profiles/r0${RND}_* gpurun_out/final/profiles/
 find gpurun_out/final -name "*.db" -size +30M -delete || true
-ls -la gpurun_out/final gpurun_out/final/ks gpurun_out/final/pmc_f | head -40
+ls -la gpurun_out/final/profiles
