@@ -129,10 +129,10 @@ def test_latency_probe_runs_the_graph_and_fails_loudly_without_a_device():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r01_bench_1080p_ippp.json is the line bench.py printed on the GPU box: the keys the driver reads, the roofline
+    """profiles/r02_bench_1080p_ippp.json is the line bench.py printed on the GPU box: the keys the driver reads, the roofline
     object (algorithmic bytes / live launch time, agreeing with the rocprofv3 kernel trace and the PMC pass) and the CPU baseline."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_1080p_ippp.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_1080p_ippp.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "u8"
@@ -148,3 +148,6 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert any(k["kernel"] == "me_kernel" for k in d["roofline_kernels"])              # the kernel north_star names is listed
+    assert all(k["traffic"] for k in d["roofline_kernels"])                            # every listed kernel has its PMC traffic attached
+    assert d["idr_in_timed_region"] >= 1 and d["gop_weighted_frames_per_s"] < d["value"] and d["config"]["h2d_in_timed_region"] is False
+    assert d["psnr_db"]["pictures"] >= 60 and d["psnr_db"]["y"] > 30.0                 # mean over all pictures of two GOPs at the 6 Mbit/s setpoint
