@@ -618,7 +618,7 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
 #ifndef IB_ROWS
 #define IB_ROWS 4
 #endif
-struct ib_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; };
+struct ib_args { frame_ctx_t ctx; uint2 *gran; unsigned *err; }; // gran: the bottom lines between bands, 8 granules {4 samples, tag} per macroblock and boundary
 
 __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     __shared__ intra_lds LD[IB_ROWS];
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     __shared__ unsigned stage[2][8]; // first row of a band: the prefetched samples of the band above (luma, chroma), 5 dwords each
     const dev_tables *T = (const dev_tables *)tabw;
     const frame_ctx_t *__restrict__ ctx = &a.ctx;
-    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride;
+    const int mbw = ctx->mbw, mbh = ctx->mbh;
     const int band = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = w >> 1, role = w & 1; // (w through readfirstlane, i.e. scalar control flow, made this kernel 14 % SLOWER: measured, left as it is)
     const int my = band * IB_ROWS + r;
     const bool row_ok = my < mbh, has_top = my > 0;
@@ -636,16 +636,16 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     const intra_lds *Lup = &LD[r > 0 ? r - 1 : 0];
     for (int i = threadIdx.x; i < TAB_DWORDS; i += IB_ROWS * 128) tabw[i] = ((const unsigned *)&g_tab)[i];
     if (lane == 0 && role == 0) L->cseq = 0;
-    const uint8_t *__restrict__ ry = ctx->rec_y;
-    const uint8_t *__restrict__ ruv = ctx->rec_uv;
-    unsigned *prog_up = a.progress + (band > 0 ? band - 1 : 0), *prog_my = a.progress + band;
+    // Between bands the bottom lines travel as 8-byte granules {4 samples, tag}, one sc1 store each, polled directly by the band below
+    // (MI355X_MICROARCH.md hand-off R2): no drain on the producer, no counter.  The tag is the picture's epoch inverted -- the band
+    // deblocker of the same picture uses the same buffer with the plain epoch.
+    const unsigned tag = ~ctx->epoch;
+    uint2 *gran_up = a.gran + (size_t)(band > 0 ? band - 1 : 0) * mbw * 8 + 4 * role, *gran_my = a.gran + (size_t)band * mbw * 8 + 4 * role;
     // the lanes that move neighbour samples: luma wave 24..40 (i = -1..15), chroma wave 41..58 (plane c, i = -1..7)
     const bool mover = role == 0 ? (lane >= 24 && lane < 41) : (lane >= 41 && lane < 59);
     const int mi = role == 0 ? lane - 25 : (lane - 41) % 9 - 1, mc = role == 0 ? 0 : (lane - 41) / 9;
     // ... and the lanes that fetch for a fed row: 5 dwords starting 4 bytes left of the macroblock (the corner is byte 3 of dword 0)
-    const uint8_t *frow = role == 0 ? ry + (size_t)(my * 16 - 1) * stride : ruv + (size_t)(my * 8 - 1) * stride;
-    unsigned gpre = 0;
-    int avail = 0;
+    uint2 gpre = make_uint2(0, 0);
     uint4 dec0n = make_uint4(0, 0, 0, 0);
     uint2 dec1n = make_uint2(0, 0);
     // this lane's source samples of the next macroblock (layout: intra_compute).  Two variables, not one filled by an if / else: with
@@ -662,22 +662,29 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     for (int t = -1; t < nsteps; t++) { // step -1 only prefetches for the first row
         const int x = t - r, xn = x + 1;
         const bool act = row_ok && x >= 0 && x < mbw;
-        const bool pf = row_ok && xn >= 0 && xn < mbw;
-        if (feeds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // both waves: the bottom rows stored in the previous step have landed
         __syncthreads(); // the rings and right columns written in the previous step are visible
-        if (feeds && role == 0 && lane == 0 && x >= 1 && x <= mbw) st_sc1(prog_my, (unsigned)x); // ... announce them
         // ---- land what was prefetched for this step, prefetch for the next one
         const uint4 dec0 = dec0n;
         const uint2 dec1 = dec1n;
         const uint2 srcc = role == 0 ? make_uint2(srcn_y, 0u) : srcn_c;
-        if (fed && act && lane >= 24 && lane < 29) stage[role][lane - 24] = gpre;
+        if (fed && act) { // lanes 24..28: the corner (last word of macroblock x-1's line) and the four words of macroblock x's line, asked for a step ago
+            const bool mine = lane >= 24 && lane < 29 && (x > 0 || lane > 24);
+            if (__ballot(mine && gpre.y != tag)) { // not there yet: poll (bounded)
+                int spins = 0;
+                do {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (mine) gpre = ld64_sc1(gran_up + (size_t)(x - (lane == 24 ? 1 : 0)) * 8 + (lane == 24 ? 3 : lane - 25));
+                    if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; }
+                } while (__ballot(mine && gpre.y != tag));
+            }
+            if (lane >= 24 && lane < 29) stage[role][lane - 24] = mine ? gpre.x : 0u;
+        }
         // Every load below is issued unconditionally, from an address clamped into range (results of steps that have no next
         // macroblock are never read).  As conditional assignments to loop-carried values they would need a merge with the old value
         // after the load -- a move into the register the load is still filling, which the compiler guards with s_waitcnt
         // vmcnt: a full memory latency right after issuing, every step, on the luma wave (~1800 cycles; per-phase cycle
         // counters of an -DIB_PROF build).
         {
-            if (pf && fed && avail < xn + 1) avail = db_wait_get(prog_up, a.err, xn + 1); // polls (and waits for its own loads) before the prefetch is in flight
             const int xc = xn < 0 ? 0 : (xn < mbw ? xn : mbw - 1), myc = row_ok ? my : mbh - 1;
             const size_t mbn_n = (size_t)myc * mbw + xc;
             dec0n = ldg128(ctx->idec + mbn_n * IDEC_BYTES);
@@ -689,9 +696,9 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
             int cy = myc * 8 + 4 * ((lane >> 4) & 1) + spy;
             cy = cy < vh2 ? cy : vh2 - 1;
             srcn_c = ldg64(ctx->src_uv + (size_t)cy * ctx->src_stride + 2 * (xc * 8 + 4 * (lane & 1)));
-            const int fl = lane < 24 ? 0 : (lane < 29 ? lane - 24 : 4);
-            const unsigned gv = ld_sc1((const unsigned *)(fed ? frow + xc * 16 - 4 + 4 * fl : ry)); // rows that are not fed read a harmless word
-            gpre = (xn > 0 || lane > 24) ? gv : 0u;
+            const int fl = lane < 24 ? 0 : (lane < 29 ? lane - 24 : 4);                        // 0: the corner, 1..4: the line's words
+            const int gx = fl == 0 ? (xc > 0 ? xc - 1 : 0) : xc;
+            gpre = ld64_sc1(gran_up + (size_t)gx * 8 + (fl == 0 ? 3 : fl - 1)); // every row loads (rows that are not fed never look at it)
         }
         WAVE_SYNC();
         if (act) {
@@ -722,10 +729,7 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
             // ---- last row of the band: its bottom rows go to the band below
             if (feeds) {
                 WAVE_SYNC();
-                if (lane < 4) {
-                    if (role == 0) st_sc1((unsigned *)(ctx->rec_y + (size_t)(my * 16 + 15) * stride + x * 16) + lane, ((const unsigned *)L->bot_y[x & 3])[lane]);
-                    else st_sc1((unsigned *)(ctx->rec_uv + (size_t)(my * 8 + 7) * stride + x * 16) + lane, ((const unsigned *)L->bot_c[x & 3])[lane]);
-                }
+                if (lane < 4) st64_sc1(gran_my + (size_t)x * 8 + lane, make_uint2(role == 0 ? ((const unsigned *)L->bot_y[x & 3])[lane] : ((const unsigned *)L->bot_c[x & 3])[lane], tag));
             }
         }
     }
@@ -737,11 +741,10 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
 #endif
 }
 int k_intra_bands(int mbh) { return (mbh + IB_ROWS - 1) / IB_ROWS; }
-// d_progress: one counter per band (cleared here), then the sticky error word
-void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, unsigned *d_progress, unsigned *d_err, hipStream_t s) {
+// d_gran: the granule buffer shared with the band deblocker (k_deblock_gran_bytes covers 8 granules per macroblock and band here)
+void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, hipStream_t s) {
     ib_args a;
-    a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err;
-    (void)hipMemsetAsync(d_progress, 0, (size_t)k_intra_bands(mbh) * sizeof(unsigned), s);
+    a.ctx = *h_ctx; a.gran = d_gran; a.err = d_err;
     hipLaunchKernelGGL(intra_band_kernel, dim3(k_intra_bands(mbh)), dim3(IB_ROWS * 128), 0, s, a);
 }
 

@@ -77,7 +77,6 @@ struct mi355enc {
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
     uint2 *d_db_gran;     // strips between deblocking bands, as epoch-tagged granules (never cleared)
     unsigned *d_progress; // two sets (picture parity) of [2*bands] strip counters of the band deblocker, then one error word
-    unsigned *d_iprogress; // progress counters of the persistent intra kernel, one per band
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
     uint16_t *d_surf[2];  // SAD surfaces of the motion search, SURF_U16 per macroblock; two sets (picture parity): the front stages of picture n+1 run beside the back stages of n
     imv_t *d_imv[2][2];   // whole-sample vector fields (search result / selection iterations alternate), per set
@@ -156,7 +155,7 @@ static int build_graph(mi355enc_t *h, int which, int ci, hipGraphExec_t *out) {
 static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
     k_launch_intra_analyse(hc, h->mbw, h->mbh, 0, h->stream); // open-loop mode analysis + decisions: one flat launch
     if (h->cfg.intra_mode == 0) { // persistent band kernel
-        k_launch_intra_band(hc, h->mbh, h->d_iprogress, err_word(h), h->stream);
+        k_launch_intra_band(hc, h->mbh, h->d_db_gran, err_word(h), h->stream);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -215,7 +214,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_iprogress = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -267,7 +266,6 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_ip_progress, (size_t)h->mbh * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_ip_progress, 0, (size_t)h->mbh * sizeof(unsigned), h->stream)); // epoch-tagged: the epoch starts at 1
     HIPCHK(hipMalloc((void **)&h->d_ip_strips, (size_t)h->nmb * 32));
-    HIPCHK(hipMalloc((void **)&h->d_iprogress, (size_t)k_intra_bands(h->mbh) * sizeof(unsigned)));
     if (cfg->keep_prefilter) {
         HIPCHK(hipMalloc((void **)&h->d_pre_y, h->ysz));
         HIPCHK(hipMalloc((void **)&h->d_pre_uv, h->csz));
@@ -341,7 +339,6 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_idec2[1]) (void)hipFree(h->d_idec2[1]);
     if (h->d_ip_progress) (void)hipFree(h->d_ip_progress);
     if (h->d_ip_strips) (void)hipFree(h->d_ip_strips);
-    if (h->d_iprogress) (void)hipFree(h->d_iprogress);
     for (int i = 0; i < 2; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
     for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
@@ -862,7 +859,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
         for (int i = 0; i < (warm ? iters : 1); i++) {
             if (stage == 0) k_launch_me(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 1) k_launch_inter(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
-            else if (stage == 2) { int r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r; }
+            else if (stage == 2) { if (++h->epoch == 0) h->epoch = 1; h->slot[0].h_ctx->epoch = h->epoch; int r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r; } // a fresh stamp per launch: the lines between bands are epoch-tagged
             else if (stage == 4) k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 8) k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], h->stream);
             else if (stage == 9) k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, 1, h->stream);
