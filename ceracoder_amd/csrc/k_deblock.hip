@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { frame_ctx_t ctx; unsigned *progress; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; }; // ip_progress: see GATED // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; }; // ip_progress: see GATED // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -174,30 +174,17 @@ DEV unsigned pack_par_ab(const dev_tables *T, int idx) { return (unsigned)T->alp
 DEV unsigned pack_par_tc(const dev_tables *T, int idx) { return (unsigned)T->tc0[idx][0] | ((unsigned)T->tc0[idx][1] << 8) | ((unsigned)T->tc0[idx][2] << 16); }
 DEV edge_par par_of(unsigned ab, unsigned tc) { edge_par p; p.alpha = (int)(ab & 255); p.beta = (int)(ab >> 8); p.tc0 = tc; return p; }
 
-// One thread per macroblock: words 0-1 bS of the vertical edges (nibble 4*edge + segment), 2-3 of
-// the horizontal edges, then {alpha|beta<<8, tc0 bytes} for luma left / top / inner and chroma
-// left / top / inner.  Edges that are not filtered (picture border, 8x8-transform inner edges) get bS 0.
-// Covers macroblocks [mb0, mb1); also zeroes two ranges of band progress counters (which ones: see the launch sites -- a
-// counter must be zero before any kernel that polls it can start, so a launch never clears counters its own picture's bands
-// are about to use unless everything else has been joined).
-// `flags`: one word per band of this picture's set, raised if any macroblock of the band has an edge with bS != 0 -- a band
-// without one has nothing to filter, and its workgroups publish "done" and leave at once (static parts of live pictures).
-__global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv, unsigned *__restrict__ clr_a, int n_a, unsigned *__restrict__ clr_b, int n_b,
-                                                           unsigned *__restrict__ clr_c, int n_c, unsigned *__restrict__ flags, int mb0, int mb1, int band_rows) {
-    const frame_ctx_t *__restrict__ ctx = &cv;
-    const int j = blockIdx.x * 256 + threadIdx.x, i = mb0 + j;
-    if (j < n_a) clr_a[j] = 0;
-    if (j < n_b) clr_b[j] = 0;
-    if (j < n_c) clr_c[j] = 0;
-    const int mbw = ctx->mbw;
-    if (i >= mb1) return;
-    const dev_tables *T = &g_tab;
-    const int my = i / mbw, mx = i - my * mbw;
+// The record of one macroblock: words 0-1 bS of the vertical edges (nibble 4*edge + segment), 2-3 of the horizontal edges, then
+// {alpha|beta<<8, tc0 bytes} for luma left / top / inner and chroma left / top / inner.  Edges that are not filtered (picture
+// border, 8x8-transform inner edges) get bS 0.  Returns whether any edge of the macroblock has bS != 0.  (A flat kernel of its own
+// in r01 and most of r02; now the band kernel's prologue: one launch and one launch gap less on the chain that sets the picture
+// period.)
+DEV bool db_record(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, const int mx, const int my, unsigned *w) {
+    const int mbw = ctx->mbw, i = my * mbw + mx;
     const mb_info_t cur = ld_mbinfo(&ctx->mbi[i]);
     const mb_info_t lft = ld_mbinfo(&ctx->mbi[mx > 0 ? i - 1 : i]);
     const mb_info_t upp = ld_mbinfo(&ctx->mbi[my > 0 ? i - mbw : i]);
     const bool t8 = (cur.nzmask & NZ_T8) != 0;
-    unsigned w[16];
     unsigned long long bv = 0, bh = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++)
@@ -217,22 +204,8 @@ __global__ __launch_bounds__(256) void deblock_prep_kernel(const frame_ctx_t cv,
     w[4] = pack_par_ab(T, il); w[5] = pack_par_tc(T, il); w[6] = pack_par_ab(T, it); w[7] = pack_par_tc(T, it);
     w[8] = pack_par_ab(T, ii); w[9] = pack_par_tc(T, ii); w[10] = pack_par_ab(T, cl); w[11] = pack_par_tc(T, cl);
     w[12] = pack_par_ab(T, ct); w[13] = pack_par_tc(T, ct); w[14] = pack_par_ab(T, qc); w[15] = pack_par_tc(T, qc);
-    uint8_t *o = ctx->dbrec + (size_t)i * DBREC_BYTES;
-#pragma unroll
-    for (int q = 0; q < 4; q++) stg128(o + 16 * q, make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]));
-    { // one atomic per band that has work among the 64 consecutive macroblocks of this wave
-        const int band = my / band_rows;
-        const bool work = (bv | bh) != 0;
-        unsigned long long rem = __ballot(work);
-        while (rem) {
-            const int l = __builtin_ctzll(rem);
-            const int b = __builtin_amdgcn_readlane(band, l);
-            if ((int)(threadIdx.x & 63) == l) atomicOr(&flags[b], 1u);
-            rem &= ~__ballot(work && band == b);
-        }
-    }
+    return (bv | bh) != 0;
 }
-
 
 // Branch-free forms of the edge filters (8.7.2.3 / 8.7.2.4): every lane computes both candidates and
 // selects, so a step costs the same few dozen VALU instructions whatever the lanes decide -- the
@@ -326,8 +299,8 @@ DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int b
 DEV int quad_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x90, 0xF, 0xF, false); } // quad_perm:[0,0,1,2]: value of lane - 1 of the quad
 DEV int quad_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xF9, 0xF, 0xF, false); } // quad_perm:[1,2,3,3]: value of lane + 1 of the quad
 #define DBT_NB 8
-struct dbt_luma { uint8_t t[DBT_NB][256]; uint8_t up[DBT_NB][64]; unsigned par[4][2][64]; unsigned rec[2][16]; };   // 4.7 KB per row
-struct dbt_chroma { uint8_t t[DBT_NB][128]; uint8_t up[DBT_NB][32]; unsigned par[4][2][64]; unsigned rec[2][16]; }; // 3.4 KB per row
+struct dbt_luma { uint8_t t[DBT_NB][256]; uint8_t up[DBT_NB][64]; unsigned par[4][2][64]; };   // 4.6 KB per row
+struct dbt_chroma { uint8_t t[DBT_NB][128]; uint8_t up[DBT_NB][32]; unsigned par[4][2][64]; }; // 3.3 KB per row
 DEV uint4 lds128(const void *p) { return *(const uint4 *)p; }
 
 // The four luma edges of one direction; lane = 4 * line + edge, `par` = this lane's {bS, alpha, beta, tc0}.  s[0..7] = p3 p2 p1 p0 q0 q1
@@ -379,7 +352,7 @@ DEV unsigned par_word(unsigned nib, unsigned ab, unsigned tcw) { return nib | (a
 // picture, and this kernel writes a macroblock's lines 0..11 once its row is three macroblocks further, its bottom lines
 // once the ROW BELOW is -- by which time the marks say that the intra macroblocks that read them are done.
 template <bool CHROMA, bool ALL_INTRA, int ROWS, bool GATED>
-DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const int band, const int nb, uint8_t *lds) {
+DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds) {
     constexpr int rows_mb = CHROMA ? 8 : 16, strip = CHROMA ? 2 : 4, ring_n = CHROMA ? 8 : 16;
     constexpr int ROW_LDS = CHROMA ? (int)sizeof(dbt_chroma) : (int)sizeof(dbt_luma);
     constexpr int TILE = rows_mb * 16, UPB = strip * 16;
@@ -391,11 +364,52 @@ DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const i
     const bool row_ok = my < mbh, last_row = my == mbh - 1;
     const bool fed = row_ok && r == 0 && band > 0;
     const bool feeds = row_ok && r == ROWS - 1 && !last_row;
-    // no edge of this band has work (deblock_prep_kernel's flags): its samples are final as they are, and its neighbours, which
-    // read the same flags, take its strips straight from the picture
-    if (!ALL_INTRA && a.progress[2 * nb + band] == 0) return;
-    const bool up_work = ALL_INTRA || (band > 0 && a.progress[2 * nb + band - 1] != 0);
-    const bool dn_work = ALL_INTRA || (band + 1 < nb && a.progress[2 * nb + band + 1] != 0);
+    // ---- prologue: the records of this band's macroblocks into LDS, and whether this band and its two neighbours have any edge to
+    // filter (the neighbours evaluate the same records for themselves: no workgroup waits for another).  A band without work -- the
+    // still part of a live picture -- leaves at once: its samples are final as they are, and its neighbours take its strips straight
+    // from the picture.
+    unsigned *bandrec = (unsigned *)(lds + ROWS * ROW_LDS); // [ROWS * mbw][16]
+    unsigned *flagw = bandrec + (size_t)ROWS * mbw * 16;    // [3]: band - 1, band, band + 1
+    if (threadIdx.x < 3) flagw[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        const dev_tables *T = &g_tab;
+        const int per = ROWS * mbw;
+        for (int j = threadIdx.x; j < per; j += 192 * ROWS) { // this band: the full records
+            const int row = band * ROWS + j / mbw;
+            if (row < mbh) {
+                unsigned w[16];
+                const bool work = db_record(ctx, T, j % mbw, row, w);
+#pragma unroll
+                for (int q = 0; q < 4; q++) *(uint4 *)(bandrec + (size_t)j * 16 + 4 * q) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+                if (work) flagw[1] = 1u;
+            }
+        }
+        if (!ALL_INTRA) {
+            // the neighbours: "is there an intra macroblock or a coded luma block" (=> an inner edge with bS >= 2) settles it nearly always, with one load per macroblock;
+            // only a band of nothing but bare vectors needs the records' own test (vector differences across edges)
+            for (int i = threadIdx.x; i < 2 * per; i += 192 * ROWS) {
+                const int which = i < per ? 0 : 2, j = i < per ? i : i - per;
+                const int row = (band - 1 + which) * ROWS + j / mbw;
+                if (row >= 0 && row < mbh) {
+                    const mb_info_t m = ld_mbinfo(&ctx->mbi[(size_t)row * mbw + j % mbw]);
+                    if (m.mb_type != 1 || (m.nzmask & 0xFFFFu) != 0) flagw[which] = 1u; // (luma blocks only: chroma coefficients raise no boundary strength)
+                }
+            }
+            __syncthreads();
+            for (int which = 0; which < 3; which += 2)
+                if (flagw[which] == 0) // (workgroup-uniform)
+                    for (int j = threadIdx.x; j < per; j += 192 * ROWS) {
+                        const int row = (band - 1 + which) * ROWS + j / mbw;
+                        unsigned w[16];
+                        if (row >= 0 && row < mbh && db_record(ctx, T, j % mbw, row, w)) flagw[which] = 1u;
+                    }
+        }
+    }
+    __syncthreads();
+    if (!ALL_INTRA && flagw[1] == 0) return;
+    const bool up_work = ALL_INTRA || flagw[0] != 0; // the band above publishes its strips
+    const bool dn_work = ALL_INTRA || flagw[2] != 0; // ... and the band below reads ours
     const unsigned epoch = ctx->epoch;
     uint2 *gran_up = a.gran + (CHROMA ? (size_t)nb * mbw * 16 : 0) + (size_t)(band > 0 ? band - 1 : 0) * mbw * ring_n;
     uint2 *gran_my = a.gran + (CHROMA ? (size_t)nb * mbw * 16 : 0) + (size_t)band * mbw * ring_n;
@@ -405,7 +419,6 @@ DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const i
     uint8_t *tiles = rowl;                                        // [DBT_NB][TILE]
     uint8_t *ups = rowl + DBT_NB * TILE;                          // [DBT_NB][UPB]: the strip above, first row of a band only
     unsigned *pars = (unsigned *)(rowl + DBT_NB * (TILE + UPB));  // [4][2][64]
-    unsigned *recl = pars + 4 * 2 * 64;                           // [2][16]: the mover's scratch for the record it is landing
     uint8_t *tiles_up = lds + (r > 0 ? r - 1 : 0) * ROW_LDS;      // the row above's tiles
     const int keep = last_row ? rows_mb : rows_mb - strip;
     const int t_end = mbw + ROWS + 1;
@@ -418,8 +431,8 @@ DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const i
     // under a branch or a predicate is a conditional assignment to a loop-carried value, which costs a merge move -- and the wait
     // for the load right behind its issue
     const int my_c = row_ok ? my : mbh - 1;
-    const uint8_t *ld_ptr = rlane ? plane + ((size_t)my_c * rows_mb + lane) * stride : (const uint8_t *)(recs + (size_t)my_c * mbw * (DBREC_BYTES / 4) + 4 * (lane & 3));
-    const int ld_step = rlane ? 16 : DBREC_BYTES;
+    const uint8_t *ld_ptr = plane + ((size_t)my_c * rows_mb + (lane & (rows_mb - 1))) * stride; // (lanes without a line repeat one)
+    const int ld_step = 16;
     uint8_t *st_ptr = lane < 16 ? plane + ((size_t)my_c * rows_mb + lane) * stride : plane + ((size_t)my_c * rows_mb - (my_c > 0 ? strip : 0) + (lane & 3)) * stride; // storer: this lane's line
     const int gj = glane ? lane - 32 : 0;
     const uint8_t *g_ptr = up_work ? (const uint8_t *)(gran_up + gj) : plane + ((size_t)my_c * rows_mb - (my_c > 0 ? strip : 0) + (gj >> 2)) * stride + 4 * (gj & 3);
@@ -524,8 +537,7 @@ DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const i
                     if (rlane) *(uint4 *)(tiles + (xm & (DBT_NB - 1)) * TILE + lane * 16) = cur;
                     // the record goes through LDS: its four quarters are on lanes 16..19, and every lane picks the words of ITS edge
                     // (16 v_readlane + selects cost the mover ~200 cycles more per step, and the mover sets the band's pace)
-                    unsigned *rq = recl + (xm & 1) * 16;
-                    if (lane >= 16 && lane < 20) *(uint4 *)(rq + 4 * (lane & 3)) = cur;
+                    const unsigned *rq = bandrec + ((size_t)r * mbw + xm) * 16;
                     unsigned pv, ph;
                     if (!CHROMA) { // words 0..3: bS of the vertical / horizontal edges, two edges per word; 4..9: {alpha|beta<<8, tc0 bytes} left, top, inner
                         const int sh = 16 * (e & 1) + 4 * (k >> 2);
@@ -624,17 +636,11 @@ DEV void rows3_body(const db_args &a, const unsigned *__restrict__ recs, const i
 }
 
 template <int ROWS, bool ALL_INTRA, bool GATED>
-__global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a, const unsigned *__restrict__ recs) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[ROWS * sizeof(dbt_luma)];
+__global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[]; // ROWS rows of tiles, then the band's records (ROWS * mbw * 64 bytes) and three flags
     const int nl = gridDim.x >> 1;
-#ifndef DBX_NOLUMA
-    if ((int)blockIdx.x < nl) rows3_body<false, ALL_INTRA, ROWS, GATED>(a, recs, a.band0 + blockIdx.x, a.nb_total, lds);
-#else
-    if ((int)blockIdx.x < nl) return;
-#endif
-#ifndef DBX_NOCHROMA
-    else rows3_body<true, ALL_INTRA, ROWS, GATED>(a, recs, a.band0 + blockIdx.x - nl, a.nb_total, lds);
-#endif
+    if ((int)blockIdx.x < nl) rows3_body<false, ALL_INTRA, ROWS, GATED>(a, a.band0 + blockIdx.x, a.nb_total, lds);
+    else rows3_body<true, ALL_INTRA, ROWS, GATED>(a, a.band0 + blockIdx.x - nl, a.nb_total, lds);
 }
 
 // =================================================================== launchers
@@ -651,23 +657,20 @@ void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag,
 #endif
 int k_deblock_bands16(int mbh) { return (mbh + DB_ROWS - 1) / DB_ROWS; }
 size_t k_deblock_gran_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * mbw * 24 * sizeof(uint2); } // per band boundary and macroblock: 16 luma + 8 chroma granules
-// `d_progress` holds 2 * bands counters (luma, chroma) followed by the sticky error word at d_err.  The prep kernel clears
-// the counters; the band kernel may be launched in several pieces (bands [band0, band1)): a band only ever waits for the
-// band above it, so pieces may run concurrently on different streams as long as the upper piece is submitted first.
-void k_launch_deblock_prep(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, unsigned *clr_a, int n_a, unsigned *clr_b, int n_b, unsigned *clr_c, int n_c,
-                           unsigned *flags, hipStream_t s) {
-    int m = (row1 - row0) * mbw;
-    if (n_a > m) m = n_a;
-    if (n_b > m) m = n_b;
-    if (n_c > m) m = n_c;
-    if (m > 0) hipLaunchKernelGGL(deblock_prep_kernel, dim3((m + 255) / 256), dim3(256), 0, s, *h_ctx, clr_a, n_a, clr_b, n_b, clr_c, n_c, flags, row0 * mbw, row1 * mbw, DB_ROWS);
+// The band kernel may be launched in several pieces (bands [band0, band1)): a band only ever waits for the band above it.
+// d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the movers follow its per-row progress words.
+template <typename K>
+static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStream_t s) {
+    const size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + (size_t)DB_ROWS * mbw * DBREC_BYTES + 16;
+    static size_t granted = 48 * 1024; // above 64 KB of dynamic LDS the kernel has to be told (4K pictures: 80 KB; the device has 160 KB per CU)
+    if (lds > granted) { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
+    hipLaunchKernelGGL(kernel, dim3(2 * nbands), dim3(192 * DB_ROWS), lds, s, a);
 }
-void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_progress, unsigned *d_err, uint2 *d_gran, const unsigned *d_ip_progress, hipStream_t s) {
+void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, const unsigned *d_ip_progress, hipStream_t s) {
     db_args a;
-    a.ctx = *h_ctx; a.progress = d_progress; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress;
+    a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress;
     if (band1 <= band0) return;
-    const dim3 g(2 * (band1 - band0));
-    if (h_ctx->all_intra) hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, true, false>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec); // IDR pictures: every edge has work
-    else if (d_ip_progress) hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, false, true>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec); // beside intra_p_kernel
-    else hipLaunchKernelGGL((deblock_rows3_kernel<DB_ROWS, false, false>), g, dim3(192 * DB_ROWS), 0, s, a, (const unsigned *)h_ctx->dbrec);
+    if (h_ctx->all_intra) launch_bands(deblock_rows3_kernel<DB_ROWS, true, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
+    else if (d_ip_progress) launch_bands(deblock_rows3_kernel<DB_ROWS, false, true>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel
+    else launch_bands(deblock_rows3_kernel<DB_ROWS, false, false>, a, band1 - band0, h_ctx->mbw, s);
 }

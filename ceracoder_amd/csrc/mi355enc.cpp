@@ -76,7 +76,7 @@ struct mi355enc {
     uint8_t *d_idec;      // intra decisions, IDEC_BYTES per macroblock
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
     uint2 *d_db_gran;     // strips between deblocking bands, as epoch-tagged granules (never cleared)
-    unsigned *d_progress; // two sets (picture parity) of [2*bands] strip counters of the band deblocker, then one error word
+    unsigned *d_progress; // the sticky error word of the persistent kernels (bounded spins report here)
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
     uint16_t *d_surf[2];  // SAD surfaces of the motion search, SURF_U16 per macroblock; two sets (picture parity): the front stages of picture n+1 run beside the back stages of n
     imv_t *d_imv[2][2];   // whole-sample vector fields (search result / selection iterations alternate), per set
@@ -88,7 +88,6 @@ struct mi355enc {
     uint32_t epoch;
     hipStream_t istream;       // intra_p_kernel of a P picture: beside prep + the band deblocker, which follows it row by row
     hipEvent_t ev_pmb;         // the fused P stage of the picture is done
-    int n_progress;
     slot_t slot[NSLOT];
     int head, tail, pending;
     int cur, have_ref, frames_since_idr, idr_count, last_collected_rec;
@@ -132,8 +131,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1;
 }
 
-static unsigned *prog_set(const mi355enc_t *h, int set) { return h->d_progress + (size_t)set * h->n_progress; }
-static unsigned *err_word(const mi355enc_t *h) { return h->d_progress + 2 * (size_t)h->n_progress; }
+static unsigned *err_word(const mi355enc_t *h) { return h->d_progress; }
 
 static void launch_intra_all(mi355enc_t *h, int ci) {
     int n = k_intra_diags(h->mbw, h->mbh);
@@ -167,12 +165,8 @@ static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
 }
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
 static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress) {
-    if (h->cfg.deblock_mode == 0) { // prep kernel (also clears the progress counters) + persistent 16-row band kernel
-        const int nb = k_deblock_bands16(h->mbh);
-        // nothing else is in flight: clear the other set entirely and this set's counters (its flags were cleared by the previous picture's prep
-        // kernel or at open; this launch raises them)
-        k_launch_deblock_prep(hc, h->mbw, 0, h->mbh, prog_set(h, ci ^ 1), h->n_progress, prog_set(h, ci), 2 * nb, nullptr, 0, prog_set(h, ci) + 2 * nb, st);
-        k_launch_deblock_bands(hc, h->mbh, 0, nb, prog_set(h, ci), err_word(h), h->d_db_gran, ip_progress, st);
+    if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
+        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, ip_progress, st);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -250,9 +244,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_dbrec, (size_t)h->nmb * 64));
     HIPCHK(hipMalloc((void **)&h->d_idec, (size_t)h->nmb * IDEC_BYTES + 16));
     h->d_idec2[0] = h->d_idec;
-    h->n_progress = 3 * k_deblock_bands16(h->mbh); // per set: luma counters, chroma counters, per-band "has work" flags
-    HIPCHK(hipMalloc((void **)&h->d_progress, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned)));
-    HIPCHK(hipMemsetAsync(h->d_progress, 0, (size_t)(2 * h->n_progress + 1) * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
+    HIPCHK(hipMalloc((void **)&h->d_progress, 4 * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
     HIPCHK(hipMalloc((void **)&h->d_db_gran, k_deblock_gran_bytes(h->mbw, h->mbh)));
     HIPCHK(hipMemsetAsync(h->d_db_gran, 0, k_deblock_gran_bytes(h->mbw, h->mbh), h->stream)); // epoch 0 is never used
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
