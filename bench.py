@@ -371,10 +371,13 @@ def main():
                 "launches": dom["launches_timed"], "kernel_trace_avg_us": dom["kernel_trace_avg_us"], "time_share": dom["time_share"],
                 "note": "dominant kernel by GPU time; " + dom["bounded_by"] + ". Every kernel of the path is listed in roofline_kernels "
                         "(the motion search north_star names is 'me_kernel'; the HBM-shaped one is the vector selection)."}
-        # picture times from the stage timers (kernel time only, no launch gaps): what a GOP costs, whatever part of it the timed region saw
-        t_p = (st.ms_me + st.ms_select) / max(1, st.n_me) + st.ms_inter / max(1, st.n_inter) + st.ms_subpel / max(1, st.n_me) + db_p[0] / max(1, db_p[1])
+        # What the device sustains over whole GOPs, whatever share of IDR pictures the timed region happened to hold: an IDR picture's stages run
+        # strictly in order, so its time is its stage timers' sum; a P picture's stages overlap (front stream beside the previous picture's
+        # deblocking, intra macroblocks beside the deblocker), so its effective period is what is left of the measured wall time.
         t_i = st.ms_intra / max(1, st.n_intra) + db_i_avg
-        gop_fps = (1e3 * gop / ((gop - 1) * t_p + t_i)) if (gop > 1 and st.n_me and st.n_intra) else None
+        n_p_all = int(st.frames - st.idr_frames)
+        t_p = (dt * 1e3 - n_idr * t_i) / max(1, n_p_all)  # (per encoder: with several streams per GPU each one coded its own `steps` pictures in dt)
+        gop_fps = (1e3 * gop / ((gop - 1) * t_p + t_i)) if (gop > 1 and st.n_me and st.n_intra and t_p > 0) else None
         out = {
             "metric": "1080p H.264 encoded frames/sec per GPU" if args.workload.startswith("1080p") else "H.264 encoded frames/sec per GPU",
             "value": round(world * S * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -382,8 +385,8 @@ def main():
             "dtype": "u8", "data": "synthetic (S2: panning texture + 12 moving rectangles, seed 0x5EED), resident in HBM",
             "idr_in_timed_region": n_idr, "skip_pictures_in_timed_region": int(st.skip_pictures),
             "gop_weighted_frames_per_s": round(gop_fps, 1) if gop_fps else None,
-            "gop_weighted_note": "gop / ((gop-1) * P-picture kernel time + IDR-picture kernel time) from the stage timers: what the device sustains over whole GOPs, "
-                                 "independent of how many IDR pictures the timed region happened to contain (an upper bound: launch gaps excluded)",
+            "gop_weighted_note": "gop / ((gop-1) * t_P + t_IDR): t_IDR = an IDR picture's stage timers (its stages run in order), t_P = (wall time - IDR pictures * t_IDR) / "
+                                 "P pictures of the timed region -- what the device sustains over whole GOPs, however many IDR pictures the timed region happened to contain",
             "config": {"workload": args.workload, "width": width, "height": height, "fps_nominal": fps, "gop": gop, "h2d_in_timed_region": False,
                        "rate_control": ("fixed qp %d" % args.fixed_qp) if args.fixed_qp >= 0 else ("cbr %d bit/s" % bps) if not script else
                        "cbr, setpoint driven by the reference's '%s' balancer script (%d..%d kbit/s, tests/golden/balancer_%s.txt)" % (
