@@ -299,8 +299,8 @@ DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int b
 DEV int quad_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x90, 0xF, 0xF, false); } // quad_perm:[0,0,1,2]: value of lane - 1 of the quad
 DEV int quad_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xF9, 0xF, 0xF, false); } // quad_perm:[1,2,3,3]: value of lane + 1 of the quad
 #define DBT_NB 8
-struct dbt_luma { uint8_t t[DBT_NB][256]; uint8_t up[DBT_NB][64]; unsigned par[DBT_NB][2][64]; };   // 6.6 KB per row
-struct dbt_chroma { uint8_t t[DBT_NB][128]; uint8_t up[DBT_NB][32]; unsigned par[DBT_NB][2][64]; }; // 5.3 KB per row
+struct dbt_luma { uint8_t t[DBT_NB][256]; uint8_t up[DBT_NB][64]; unsigned par[4][2][64]; };   // 4.6 KB per row
+struct dbt_chroma { uint8_t t[DBT_NB][128]; uint8_t up[DBT_NB][32]; unsigned par[4][2][64]; }; // 3.3 KB per row
 DEV uint4 lds128(const void *p) { return *(const uint4 *)p; }
 
 // The four luma edges of one direction; lane = 4 * line + edge, `par` = this lane's {bS, alpha, beta, tc0}.  s[0..7] = p3 p2 p1 p0 q0 q1
@@ -370,8 +370,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     // from the picture.
     unsigned *bandrec = (unsigned *)(lds + ROWS * ROW_LDS); // [ROWS * mbw][16]
     unsigned *flagw = bandrec + (size_t)ROWS * mbw * 16;    // [3]: band - 1, band, band + 1
-    unsigned *rowflags = flagw + 4;                          // [ROWS][8]: the rows' dataflow counters, see below
-    if (threadIdx.x < 4 + ROWS * 8) flagw[threadIdx.x] = 0;
+    if (threadIdx.x < 3) flagw[threadIdx.x] = 0;
     __syncthreads();
     {
         const dev_tables *T = &g_tab;
@@ -419,9 +418,10 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     uint8_t *rowl = lds + r * ROW_LDS;
     uint8_t *tiles = rowl;                                        // [DBT_NB][TILE]
     uint8_t *ups = rowl + DBT_NB * TILE;                          // [DBT_NB][UPB]: the strip above, first row of a band only
-    unsigned *pars = (unsigned *)(rowl + DBT_NB * (TILE + UPB));  // [DBT_NB][2][64]
+    unsigned *pars = (unsigned *)(rowl + DBT_NB * (TILE + UPB));  // [4][2][64]
     uint8_t *tiles_up = lds + (r > 0 ? r - 1 : 0) * ROW_LDS;      // the row above's tiles
     const int keep = last_row ? rows_mb : rows_mb - strip;
+    const int t_end = mbw + ROWS + 1;
     // ---- per-role state
     const int k = lane >> 2, e = lane & 3;                        // filter lanes (luma): line / column k, edge e
     uint4 preA, preB; // mover: two macroblock loads in flight.  Deliberately not initialised: a phi with a constant at the loop header
@@ -437,190 +437,202 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     const int gj = glane ? lane - 32 : 0;
     const uint8_t *g_ptr = up_work ? (const uint8_t *)(gran_up + gj) : plane + ((size_t)my_c * rows_mb - (my_c > 0 ? strip : 0) + (gj >> 2)) * stride + 4 * (gj & 3);
     const int g_step = up_work ? ring_n * 8 : 16;
-    // ---- three roles per row, synchronised by DATAFLOW: no barrier.  A step of the lock-step form of this kernel cost what the
-    // slowest of the band's twelve waves needed plus the barrier's release (~785 cycles, of which the filter wave worked ~350).
-    // Here every wave runs its own loop over the row's macroblocks and waits only for what it reads: five monotonic counters
-    // per row in LDS (LDS operations of a wave execute in order, so "data, then counter" needs no more than a compiler fence):
-    //   land  macroblocks whose tile + parameter words the mover has put in the ring      (mover  -> filter)
-    //   upl   ... and whose strip above it has landed (first row of a band only)          (mover  -> filter, storer)
-    //   fv    macroblocks whose vertical edges are filtered                               (filter -> filter of the row below, storer)
-    //   fh    macroblocks whose horizontal edges are filtered                             (filter -> storer)
-    //   st    macroblocks stored (lines 0..11, the strip above, the band's bottom strip)  (storer -> movers: ring slots are free)
-    // The wait graph follows x and the rows upwards plus the ring's back-pressure eight macroblocks behind: acyclic.  Spins are bounded.
-    enum { F_LAND = 0, F_UPL = 1, F_FV = 2, F_FH = 3, F_ST = 4 };
-    volatile unsigned *myf = rowflags + r * 8, *upf = rowflags + (r > 0 ? r - 1 : 0) * 8, *dnf = rowflags + (r + 1 < ROWS ? r + 1 : r) * 8;
-    const bool has_dn = r + 1 < ROWS && my + 1 < mbh; // a row below in this workgroup reads this row's tiles
-    auto wait_for = [&](volatile unsigned *f, const int need, int &seen) __attribute__((always_inline)) {
-        if (seen >= need) return;
-        int spins = 0;
-        for (;;) {
-            seen = (int)*f;
-            if (seen >= need) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); seen = 0x7FFFFFFF; break; } // bounded; once tripped, nobody waits again
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (compiler ordering only: the LDS queue of a wave is in order, and LDS has no cache)
-    };
-    auto publish = [&](volatile unsigned *f, const int v) __attribute__((always_inline)) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (a workgroup-scope release would also drain the storer's global stores: the counters guard LDS only)
-        *f = (unsigned)v;
-    };
-    if (!row_ok) return;
+#ifdef DBT_PROF /* debug builds: cycles before the barrier, in it, after it, per role; row 1 of band 1 */
+    unsigned long long pc[3] = {0, 0, 0}, tm0 = 0, tm1;
+    unsigned nmiss = 0;
+#define DBT_TICK(i) do { tm1 = __builtin_readcyclecounter(); pc[i] += tm1 - tm0; tm0 = tm1; } while (0)
+#define DBT_T0() tm0 = __builtin_readcyclecounter()
+#else
+#define DBT_TICK(i) do { } while (0)
+#define DBT_T0() do { } while (0)
+#endif
+    const int t_last = t_end | 1; // every role runs the same, even number of steps (the mover's loop is unrolled by two)
+    // Each role runs its own loop (one barrier per step in each): compiled as one loop with a role switch inside, the three
+    // roles share a register assignment at the back edge, and the merge moves there wait for the mover's loads in flight and for
+    // the storer's stores.
     if (role == 0) {
-        // =========================================================== F: vertical edges, horizontal edges; touches nothing but LDS
-        int s_land = 0, s_up = 0, s_uph = 0;
-        for (int x = 0; x < mbw; x++) {
-            wait_for(myf + F_LAND, x + 1, s_land);
-            uint8_t *tile = tiles + (x & (DBT_NB - 1)) * TILE;
-            {
-                const unsigned par = pars[((x & (DBT_NB - 1)) * 2 + 0) * 64 + lane];
-                if (!CHROMA) {
-                    uint8_t *tl = tiles + ((x - 1) & (DBT_NB - 1)) * TILE;
-                    unsigned *pw = (unsigned *)(e == 0 ? tl + k * 16 + 12 : tile + k * 16 + 4 * e - 4), *qw = (unsigned *)(tile + k * 16 + 4 * e);
-                    const unsigned w0 = *pw, w1 = *qw;
-                    const unsigned long long work = __ballot((par & 15u) != 0);
-                    if (ALL_INTRA || work) {
+        for (int t = -2; t <= t_last; t++) {
+            DBT_T0();
+            const int x = t - 1 - r;
+            const bool act = row_ok && x >= 0 && x < mbw;
+            // =========================================================== F: vertical edges | barrier | horizontal edges
+                uint8_t *tile = tiles + (x & (DBT_NB - 1)) * TILE;
+                if (act) {
+                    const unsigned par = pars[((x & 3) * 2 + 0) * 64 + lane];
+                    if (!CHROMA) {
+                        uint8_t *tl = tiles + ((x - 1) & (DBT_NB - 1)) * TILE;
+                        unsigned *pw = (unsigned *)(e == 0 ? tl + k * 16 + 12 : tile + k * 16 + 4 * e - 4), *qw = (unsigned *)(tile + k * 16 + 4 * e);
+                        const unsigned w0 = *pw, w1 = *qw;
+                        const unsigned long long work = __ballot((par & 15u) != 0);
+#ifdef DBX_NOFILT
+                        if (0) {
+#else
+                        if (ALL_INTRA || work) {
+#endif
+                            int s[8];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) { s[i] = byte_of(w0, i); s[4 + i] = byte_of(w1, i); }
+                            edges4p_luma<ALL_INTRA>(e, par, __ballot((par & 15u) == 4u) != 0, s);
+                            const int nx = quad_next(s[2] | (s[3] << 8));
+                            const unsigned hi = e == 3 ? (unsigned)(s[6] | (s[7] << 8)) : (unsigned)nx;
+                            *qw = (unsigned)s[4] | ((unsigned)s[5] << 8) | (hi << 16);
+                            if (e == 0 && x > 0) *pw = pack4(s[0], s[1], s[2], s[3]);
+                        }
+                    } else if (lane < 32) {
+                        const int kk = lane >> 2, c = (lane >> 1) & 1, ee = lane & 1; // line, plane, edge (luma edges 0 and 2)
+                        uint8_t *tl = tiles + ((x - 1) & (DBT_NB - 1)) * TILE;
+                        uint8_t *pb = ee == 0 ? tl + kk * 16 + 12 + c : tile + kk * 16 + 4 + c, *qb = tile + kk * 16 + 8 * ee + c;
+                        int p1 = pb[0], p0 = pb[2], q0 = qb[0], q1 = qb[2];
+                        edge_chroma_p(par, p1, p0, q0, q1);
+                        if (ee != 0 || x > 0) pb[2] = (uint8_t)p0;
+                        qb[0] = (uint8_t)q0;
+                    }
+                }
+                DBT_TICK(0);
+                BAND_BARRIER();
+                DBT_TICK(1);
+                if (act) {
+                    const unsigned par = pars[((x & 3) * 2 + 1) * 64 + lane];
+                    uint8_t *upb = fed ? ups + (x & (DBT_NB - 1)) * UPB : tiles_up + (x & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
+                    if (!CHROMA) {
+                        uint8_t *pb = (e == 0 ? upb : tile + (4 * e - 4) * 16) + k, *qb = tile + 4 * e * 16 + k;
                         int s[8];
 #pragma unroll
-                        for (int i = 0; i < 4; i++) { s[i] = byte_of(w0, i); s[4 + i] = byte_of(w1, i); }
-                        edges4p_luma<ALL_INTRA>(e, par, __ballot((par & 15u) == 4u) != 0, s);
-                        const int nx = quad_next(s[2] | (s[3] << 8));
-                        const unsigned hi = e == 3 ? (unsigned)(s[6] | (s[7] << 8)) : (unsigned)nx;
-                        *qw = (unsigned)s[4] | ((unsigned)s[5] << 8) | (hi << 16);
-                        if (e == 0 && x > 0) *pw = pack4(s[0], s[1], s[2], s[3]);
+                        for (int i = 0; i < 4; i++) { s[i] = pb[i * 16]; s[4 + i] = qb[i * 16]; }
+                        const unsigned long long work = __ballot((par & 15u) != 0);
+#ifdef DBX_NOFILT
+                        if (0) {
+#else
+                        if (ALL_INTRA || work) {
+#endif
+                            const bool any4 = __ballot((par & 15u) == 4u) != 0;
+                            edges4p_luma<ALL_INTRA>(e, par, any4, s);
+                            if (e != 0 || my > 0) { pb[2 * 16] = (uint8_t)s[2]; pb[3 * 16] = (uint8_t)s[3]; }
+                            qb[0] = (uint8_t)s[4]; qb[16] = (uint8_t)s[5];
+                            if ((ALL_INTRA || any4) && e == 0 && my > 0) pb[16] = (uint8_t)s[1];
+                        }
+                    } else if (lane < 32) {
+                        const int kb = lane >> 1, ee = lane & 1; // byte column, edge
+                        uint8_t *pb = (ee == 0 ? upb : tile + 2 * 16) + kb, *qb = tile + 4 * ee * 16 + kb;
+                        int p1 = pb[0], p0 = pb[16], q0 = qb[0], q1 = qb[16];
+                        edge_chroma_p(par, p1, p0, q0, q1);
+                        if (ee != 0 || my > 0) pb[16] = (uint8_t)p0;
+                        qb[0] = (uint8_t)q0;
                     }
-                } else if (lane < 32) {
-                    const int kk = lane >> 2, c = (lane >> 1) & 1, ee = lane & 1; // line, plane, edge (luma edges 0 and 2)
-                    uint8_t *tl = tiles + ((x - 1) & (DBT_NB - 1)) * TILE;
-                    uint8_t *pb = ee == 0 ? tl + kk * 16 + 12 + c : tile + kk * 16 + 4 + c, *qb = tile + kk * 16 + 8 * ee + c;
-                    int p1 = pb[0], p0 = pb[2], q0 = qb[0], q1 = qb[2];
-                    edge_chroma_p(par, p1, p0, q0, q1);
-                    if (ee != 0 || x > 0) pb[2] = (uint8_t)p0;
-                    qb[0] = (uint8_t)q0;
                 }
-            }
-            publish(myf + F_FV, x + 1);
-            // the strip above is final once the row above has filtered the vertical edges of macroblock x+1 (its left edge patches the
-            // strip's last columns) -- which it does after the horizontal edges of x
-            // (the last macroblock of a row has no x+1: wait for the row above's own horizontal edges of it)
-            if (r > 0) { if (x + 1 < mbw) wait_for(upf + F_FV, x + 2, s_up); else wait_for(upf + F_FH, mbw, s_uph); }
-            else if (fed) wait_for(myf + F_UPL, x + 1, s_up);
-            {
-                const unsigned par = pars[((x & (DBT_NB - 1)) * 2 + 1) * 64 + lane];
-                uint8_t *upb = fed ? ups + (x & (DBT_NB - 1)) * UPB : tiles_up + (x & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
-                if (!CHROMA) {
-                    uint8_t *pb = (e == 0 ? upb : tile + (4 * e - 4) * 16) + k, *qb = tile + 4 * e * 16 + k;
-                    int s[8];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { s[i] = pb[i * 16]; s[4 + i] = qb[i * 16]; }
-                    const unsigned long long work = __ballot((par & 15u) != 0);
-                    if (ALL_INTRA || work) {
-                        const bool any4 = __ballot((par & 15u) == 4u) != 0;
-                        edges4p_luma<ALL_INTRA>(e, par, any4, s);
-                        if (e != 0 || my > 0) { pb[2 * 16] = (uint8_t)s[2]; pb[3 * 16] = (uint8_t)s[3]; }
-                        qb[0] = (uint8_t)s[4]; qb[16] = (uint8_t)s[5];
-                        if ((ALL_INTRA || any4) && e == 0 && my > 0) pb[16] = (uint8_t)s[1];
-                    }
-                } else if (lane < 32) {
-                    const int kb = lane >> 1, ee = lane & 1; // byte column, edge
-                    uint8_t *pb = (ee == 0 ? upb : tile + 2 * 16) + kb, *qb = tile + 4 * ee * 16 + kb;
-                    int p1 = pb[0], p0 = pb[16], q0 = qb[0], q1 = qb[16];
-                    edge_chroma_p(par, p1, p0, q0, q1);
-                    if (ee != 0 || my > 0) pb[16] = (uint8_t)p0;
-                    qb[0] = (uint8_t)q0;
-                }
-            }
-            publish(myf + F_FH, x + 1);
+            DBT_TICK(2);
         }
     } else if (role == 1) {
-        // =========================================================== M: land macroblock i, ask for macroblock i+2 (and the strips above them)
-        // `cur` is the load set of this iteration's parity (two macroblock loads are in flight: the loop is unrolled by two so that
-        // both sets are plain registers -- a set chosen by `i & 1` lives in scratch, and its load gets waited for at once)
+        // `cur` is the load set of this step's parity (two macroblock loads are in flight: the loop is unrolled by two so that
+        // both sets are plain registers -- a set chosen by `t & 1` lives in scratch, and its load gets waited for at once)
         int fin = GATED ? 0 : 0x7FFF; // macroblocks of this row known to be final
-        int s_st = 0, s_dn = 0;
-        auto mstep = [&](const int i, uint4 &cur, uint2 &gpre) __attribute__((always_inline)) {
-            if (i >= 0 && i < mbw) {
-                // the ring slot's previous tenant (macroblock i-8) must have been stored by this row's storer and, where a row below
-                // reads this row's tiles as its strip above, by that row's storer too
-                wait_for(myf + F_ST, i - (DBT_NB - 1), s_st);
-                if (has_dn) wait_for(dnf + F_ST, i - (DBT_NB - 1), s_dn);
-                if (rlane) *(uint4 *)(tiles + (i & (DBT_NB - 1)) * TILE + lane * 16) = cur;
-                // one parameter word per lane and direction from the record: every lane picks the words of ITS edge
-                const unsigned *rq = bandrec + ((size_t)r * mbw + i) * 16;
-                unsigned pv, ph;
-                if (!CHROMA) { // words 0..3: bS of the vertical / horizontal edges, two edges per word; 4..9: {alpha|beta<<8, tc0 bytes} left, top, inner
-                    const int sh = 16 * (e & 1) + 4 * (k >> 2);
-                    const unsigned vb = rq[e >> 1], hb = rq[2 + (e >> 1)];
-                    const uint2 vp = *(const uint2 *)(rq + (e == 0 ? 4 : 8)), hp = *(const uint2 *)(rq + (e == 0 ? 6 : 8));
-                    pv = par_word((vb >> sh) & 15u, vp.x, vp.y);
-                    ph = par_word((hb >> sh) & 15u, hp.x, hp.y);
-                } else {       // chroma edges are luma edges 0 and 2: the low halves of words 0/1 and 2/3; parameters at words 10..15
-                    const int kk = lane >> 2, ee = lane & 1, kb = lane >> 1; // vertical: line kk, edge ee; horizontal: byte column kb, edge ee
-                    const unsigned vb = rq[ee], hb = rq[2 + ee];
-                    const uint2 vp = *(const uint2 *)(rq + (ee ? 14 : 10)), hp = *(const uint2 *)(rq + (ee ? 14 : 12));
-                    pv = par_word((vb >> (4 * (kk >> 1))) & 15u, vp.x, vp.y);
-                    ph = par_word((hb >> (4 * (kb >> 2))) & 15u, hp.x, hp.y);
+        auto mstep = [&](const int t, uint4 &cur, uint2 &gpre) __attribute__((always_inline)) {
+            DBT_T0();
+            const int x = t - 1 - r;
+            const bool act = row_ok && x >= 0 && x < mbw;
+            // =========================================================== M: land macroblock x+1 | barrier | load macroblock x+3 (and the strip above x+1)
+                const int xm = x + 1, xl = x + 3;
+                const bool lands = row_ok && xm >= 0 && xm < mbw;
+                if (lands) {
+                    if (rlane) *(uint4 *)(tiles + (xm & (DBT_NB - 1)) * TILE + lane * 16) = cur;
+                    // the record goes through LDS: its four quarters are on lanes 16..19, and every lane picks the words of ITS edge
+                    // (16 v_readlane + selects cost the mover ~200 cycles more per step, and the mover sets the band's pace)
+                    const unsigned *rq = bandrec + ((size_t)r * mbw + xm) * 16;
+                    unsigned pv, ph;
+                    if (!CHROMA) { // words 0..3: bS of the vertical / horizontal edges, two edges per word; 4..9: {alpha|beta<<8, tc0 bytes} left, top, inner
+                        const int sh = 16 * (e & 1) + 4 * (k >> 2);
+                        const unsigned vb = rq[e >> 1], hb = rq[2 + (e >> 1)];
+                        const uint2 vp = *(const uint2 *)(rq + (e == 0 ? 4 : 8)), hp = *(const uint2 *)(rq + (e == 0 ? 6 : 8));
+                        pv = par_word((vb >> sh) & 15u, vp.x, vp.y);
+                        ph = par_word((hb >> sh) & 15u, hp.x, hp.y);
+                    } else {       // chroma edges are luma edges 0 and 2: the low halves of words 0/1 and 2/3; parameters at words 10..15
+                        const int kk = lane >> 2, ee = lane & 1, kb = lane >> 1; // vertical: line kk, edge ee; horizontal: byte column kb, edge ee
+                        const unsigned vb = rq[ee], hb = rq[2 + ee];
+                        const uint2 vp = *(const uint2 *)(rq + (ee ? 14 : 10)), hp = *(const uint2 *)(rq + (ee ? 14 : 12));
+                        pv = par_word((vb >> (4 * (kk >> 1))) & 15u, vp.x, vp.y);
+                        ph = par_word((hb >> (4 * (kb >> 2))) & 15u, hp.x, hp.y);
+                    }
+                    pars[((xm & 3) * 2 + 0) * 64 + lane] = pv;
+                    pars[((xm & 3) * 2 + 1) * 64 + lane] = ph;
                 }
-                pars[((i & (DBT_NB - 1)) * 2 + 0) * 64 + lane] = pv;
-                pars[((i & (DBT_NB - 1)) * 2 + 1) * 64 + lane] = ph;
-                publish(myf + F_LAND, i + 1);
-                if (fed) { // the strip above macroblock i, asked for two iterations ago: every granule must carry this picture's epoch
+                if (fed && act) { // the strip above macroblock x, asked for two steps ago: every granule must carry this picture's epoch
                     // the first test stands outside the retry loop: a loop that reloads `gpre` makes the compiler wait for every load in
-                    // flight at its header (vmcnt(0): also the loads just issued), the common case needs only the one from two iterations ago
+                    // flight at its header (vmcnt(0): also the loads issued half a step ago), the common case needs only the one from two steps ago
                     unsigned gw = gpre.x;
+#ifndef DBX_NOWAITG
                     if (up_work && __ballot(glane && gpre.y != epoch)) {
                         uint2 g2 = gpre;
                         int spins = 0;
+#ifdef DBT_PROF
+                        nmiss++;
+#endif
                         do {
                             __builtin_amdgcn_s_sleep(1);
-                            if (glane) g2 = ld64_sc1(gran_up + (size_t)i * ring_n + (lane - 32));
+                            if (glane) g2 = ld64_sc1(gran_up + (size_t)x * ring_n + (lane - 32));
                             if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; } // bounded; once tripped, nobody waits again
                         } while (__ballot(glane && g2.y != epoch));
                         gw = g2.x;
                     }
-                    if (glane) *(unsigned *)(ups + (i & (DBT_NB - 1)) * UPB + 4 * (lane - 32)) = gw;
-                    publish(myf + F_UPL, i + 1);
+#endif
+                    if (glane) *(unsigned *)(ups + (x & (DBT_NB - 1)) * UPB + 4 * (lane - 32)) = gw;
                 }
-            }
-            {
-                const int xl = i + 2, xlc = xl < 0 ? 0 : (xl < mbw ? xl : mbw - 1);
-                if (GATED && xl >= 0 && xl < mbw && xl >= fin) {
-                    const unsigned tag = (epoch & 0xFFFFFu) << 12; // IP_EPOCH of k_intra.hip
-                    int spins = 0;
-                    for (;;) {
-                        const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_sc1(a.ip_progress + my));
-                        if ((v & ~0xFFFu) == tag && (int)(v & 0xFFFu) > xl) { fin = (int)(v & 0xFFFu); break; }
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); fin = 0x7FFF; break; } // bounded; once tripped, nobody waits again
+                DBT_TICK(0);
+                BAND_BARRIER();
+                DBT_TICK(1);
+                {
+                    const int xg = x + 2, xgc = xg < 0 ? 0 : (xg < mbw ? xg : mbw - 1), xlc = xl < 0 ? 0 : (xl < mbw ? xl : mbw - 1);
+                    if (GATED && row_ok && xl >= 0 && xl < mbw && xl >= fin) {
+                        const unsigned tag = (epoch & 0xFFFFFu) << 12; // IP_EPOCH of k_intra.hip
+                        int spins = 0;
+                        for (;;) {
+                            const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_sc1(a.ip_progress + my));
+                            if ((v & ~0xFFFu) == tag && (int)(v & 0xFFFu) > xl) { fin = (int)(v & 0xFFFu); break; }
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); fin = 0x7FFF; break; } // bounded; once tripped, nobody waits again
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    cur = ldg128(ld_ptr + (size_t)xlc * ld_step); // first: memory operations return in order, and the granule load below (sc1, another XCD's data) takes about two steps
+                    gpre = ld64_sc1((const uint2 *)(g_ptr + (size_t)xgc * g_step)); // the strip above macroblock x+2, two steps ahead like the macroblocks: a cross-XCD round trip is longer than a step (first row of a band; elsewhere unused)
                 }
-                cur = ldg128(ld_ptr + (size_t)xlc * ld_step); // first: memory operations return in order, and the granule load below (sc1, another XCD's data) is slow
-                gpre = ld64_sc1((const uint2 *)(g_ptr + (size_t)xlc * g_step)); // the strip above macroblock i+2 (first row of a band; elsewhere unused)
-            }
+            DBT_TICK(2);
         };
-        for (int i = -2; i < mbw; i += 2) { mstep(i, preA, gA); mstep(i + 1, preB, gB); }
+        for (int t = -2; t <= t_last; t += 2) { mstep(t, preA, gA); mstep(t + 1, preB, gB); }
     } else {
-        // =========================================================== S: store macroblock x, publish its bottom strip
-        // Lines 0 .. keep-1 of macroblock x are final once the vertical edges of x+1 are filtered (its left edge patches columns 12..15),
-        // the strip above it once this row's horizontal edges of x are: one LDS read and one 16-byte store per lane, per-lane addresses.
-        int s_fv = 0, s_fh = 0;
-        for (int x = 0; x < mbw; x++) {
-            wait_for(myf + F_FV, x + 2 < mbw ? x + 2 : mbw, s_fv);
-            wait_for(myf + F_FH, x + 1, s_fh);
-            const bool is_row = lane < keep, is_up = uplane && my > 0;
-            const uint8_t *upb = fed ? ups + (x & (DBT_NB - 1)) * UPB : tiles_up + (x & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
-            const uint8_t *src = is_row ? tiles + (x & (DBT_NB - 1)) * TILE + lane * 16 : upb + (lane & 3) * 16;
-            if (is_row || is_up) stg128(st_ptr + x * 16, lds128(src));
-            if (feeds && glane) { // the band's bottom strip: the band below waits for it
-                const int j = lane - 32;
-                const unsigned w = *(const unsigned *)(tiles + (x & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16 + 4 * j);
-                if (dn_work) st64_sc1(gran_my + (size_t)x * ring_n + j, make_uint2(w, epoch));
-                else stg32(plane + (row0 + rows_mb - strip + (j >> 2)) * stride + x * 16 + 4 * (j & 3), w); // nobody below will store it
+        for (int t = -2; t <= t_last; t++) {
+            DBT_T0();
+            const int x = t - 1 - r;
+            // =========================================================== S: store macroblock x-2 | barrier | publish the strip of macroblock x-1
+            // Lines 0 .. keep-1 of macroblock x-2 and the strip above it became final with the barrier of the step before (this row's
+            // vertical phase of x-1 patched its columns 12..15; the horizontal phase of x-2 finished the strip above): one LDS read
+            // and one 16-byte store per lane, per-lane addresses.
+            const int xs2 = x - 2;
+            if (row_ok && xs2 >= 0 && xs2 < mbw) {
+                const bool is_row = lane < keep, is_up = uplane && my > 0;
+                const uint8_t *upb = fed ? ups + (xs2 & (DBT_NB - 1)) * UPB : tiles_up + (xs2 & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
+                const uint8_t *src = is_row ? tiles + (xs2 & (DBT_NB - 1)) * TILE + lane * 16 : upb + (lane & 3) * 16;
+                if (is_row || is_up) stg128(st_ptr + xs2 * 16, lds128(src));
             }
-            publish(myf + F_ST, x + 1);
+            DBT_TICK(0);
+            BAND_BARRIER();
+            DBT_TICK(1);
+            const int xs = x - 1; // its bottom strip is final within this band now: the band below waits for it
+            if (feeds && xs >= 0 && xs < mbw && glane) {
+                const int j = lane - 32;
+                const unsigned w = *(const unsigned *)(tiles + (xs & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16 + 4 * j);
+                if (dn_work) st64_sc1(gran_my + (size_t)xs * ring_n + j, make_uint2(w, epoch));
+                else stg32(plane + (row0 + rows_mb - strip + (j >> 2)) * stride + xs * 16 + 4 * (j & 3), w); // nobody below will store it
+            }
+            DBT_TICK(2);
         }
     }
+#ifdef DBT_PROF
+    if (lane == 0 && band < 2) { // rows 0..3 of bands 0 and 1
+        unsigned *o = (unsigned *)(ctx->dbrec) + (CHROMA ? 128 : 0) + 64 * band + 16 * r + 4 * role; // debug build only: overwrites the first records after use
+        for (int i = 0; i < 3; i++) o[i] = (unsigned)pc[i];
+        o[3] = (unsigned)(t_last + 3) | (nmiss << 16);
+    }
+#endif
 }
 
 template <int ROWS, bool ALL_INTRA, bool GATED>
@@ -649,7 +661,7 @@ size_t k_deblock_gran_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the movers follow its per-row progress words.
 template <typename K>
 static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStream_t s) {
-    const size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + (size_t)DB_ROWS * mbw * DBREC_BYTES + 16 + DB_ROWS * 32;
+    const size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + (size_t)DB_ROWS * mbw * DBREC_BYTES + 16;
     static size_t granted = 48 * 1024; // above 64 KB of dynamic LDS the kernel has to be told (4K pictures: 80 KB; the device has 160 KB per CU)
     if (lds > granted) { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
     hipLaunchKernelGGL(kernel, dim3(2 * nbands), dim3(192 * DB_ROWS), lds, s, a);
