@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; }; // ip_progress: see GATED // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; }; // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -299,8 +299,8 @@ DEV void edge_chroma2(const edge_par &P, int p1, int &p0, int &q0, int q1, int b
 DEV int quad_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x90, 0xF, 0xF, false); } // quad_perm:[0,0,1,2]: value of lane - 1 of the quad
 DEV int quad_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xF9, 0xF, 0xF, false); } // quad_perm:[1,2,3,3]: value of lane + 1 of the quad
 #define DBT_NB 8
-struct dbt_luma { uint8_t t[DBT_NB][256]; uint8_t up[DBT_NB][64]; unsigned par[4][2][64]; };   // 4.6 KB per row
-struct dbt_chroma { uint8_t t[DBT_NB][128]; uint8_t up[DBT_NB][32]; unsigned par[4][2][64]; }; // 3.3 KB per row
+struct dbt_luma { uint8_t t[DBT_NB][256]; uint8_t up[DBT_NB][64]; unsigned par[4][32]; };   // 3.1 KB per row
+struct dbt_chroma { uint8_t t[DBT_NB][128]; uint8_t up[DBT_NB][32]; unsigned par[4][32]; }; // 1.8 KB per row
 DEV uint4 lds128(const void *p) { return *(const uint4 *)p; }
 
 // The four luma edges of one direction; lane = 4 * line + edge, `par` = this lane's {bS, alpha, beta, tc0}.  s[0..7] = p3 p2 p1 p0 q0 q1
@@ -364,24 +364,44 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     const bool row_ok = my < mbh, last_row = my == mbh - 1;
     const bool fed = row_ok && r == 0 && band > 0;
     const bool feeds = row_ok && r == ROWS - 1 && !last_row;
-    // ---- prologue: the records of this band's macroblocks into LDS, and whether this band and its two neighbours have any edge to
-    // filter (the neighbours evaluate the same records for themselves: no workgroup waits for another).  A band without work -- the
-    // still part of a live picture -- leaves at once: its samples are final as they are, and its neighbours take its strips straight
-    // from the picture.
-    unsigned *bandrec = (unsigned *)(lds + ROWS * ROW_LDS); // [ROWS * mbw][16]
-    unsigned *flagw = bandrec + (size_t)ROWS * mbw * 16;    // [3]: band - 1, band, band + 1
+    // ---- prologue: per macroblock of this band, the parameter word {bS, alpha, beta, tc0[bS]} of every (edge, segment) of either
+    // direction -- 32 words for luma, 16 for chroma -- into a table in global memory (it stays in L2; the movers bring a
+    // macroblock's words in with the same load instruction as its samples), and whether this band and its two neighbours have
+    // any edge to filter (the neighbours evaluate that for themselves: no workgroup waits for another).  A band without work -- the
+    // still part of a live picture -- leaves at once: its samples are final as they are, and its neighbours take its strips
+    // straight from the picture.  (The movers used to derive the words from the 64-byte record, ~50 instructions per macroblock on
+    // the SIMD whose issue rate sets the band's pace.)
+    constexpr int PARW = CHROMA ? 16 : 32;                                  // parameter words per macroblock
+    unsigned *partab = a.partab + (CHROMA ? (size_t)nb * ROWS * mbw * 32 : 0) + (size_t)band * ROWS * mbw * PARW;
+    unsigned *flagw = (unsigned *)(lds + ROWS * ROW_LDS);   // [3]: band - 1, band, band + 1
     if (threadIdx.x < 3) flagw[threadIdx.x] = 0;
     __syncthreads();
     {
         const dev_tables *T = &g_tab;
         const int per = ROWS * mbw;
-        for (int j = threadIdx.x; j < per; j += 192 * ROWS) { // this band: the full records
+        for (int j = threadIdx.x; j < per; j += 192 * ROWS) { // this band
             const int row = band * ROWS + j / mbw;
             if (row < mbh) {
-                unsigned w[16];
+                unsigned w[16], pw[PARW];
                 const bool work = db_record(ctx, T, j % mbw, row, w);
 #pragma unroll
-                for (int q = 0; q < 4; q++) *(uint4 *)(bandrec + (size_t)j * 16 + 4 * q) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+                for (int d = 0; d < 2; d++)
+#pragma unroll
+                    for (int ed = 0; ed < (CHROMA ? 2 : 4); ed++)
+#pragma unroll
+                        for (int sg = 0; sg < 4; sg++) {
+                            unsigned nib, ab, tc;
+                            if (!CHROMA) { // record words 0..3: bS, two edges per word; 4..9: {alpha|beta<<8, tc0 bytes} left, top, inner
+                                nib = (w[2 * d + (ed >> 1)] >> (16 * (ed & 1) + 4 * sg)) & 15u;
+                                ab = ed == 0 ? w[4 + 2 * d] : w[8]; tc = ed == 0 ? w[5 + 2 * d] : w[9];
+                            } else {       // chroma edges are luma edges 0 and 2 (the low halves of the bS words); parameters at words 10..15: left, top, inner
+                                nib = (w[2 * d + ed] >> (4 * sg)) & 15u;
+                                ab = ed == 0 ? w[10 + 2 * d] : w[14]; tc = ed == 0 ? w[11 + 2 * d] : w[15];
+                            }
+                            pw[d * (PARW / 2) + ed * 4 + sg] = par_word(nib, ab, tc);
+                        }
+#pragma unroll
+                for (int q = 0; q < PARW / 4; q++) stg128(partab + (size_t)j * PARW + 4 * q, make_uint4(pw[4 * q], pw[4 * q + 1], pw[4 * q + 2], pw[4 * q + 3]));
                 if (work) flagw[1] = 1u;
             }
         }
@@ -406,6 +426,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                     }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the table's stores have left this CU before its movers load them
     __syncthreads();
     if (!ALL_INTRA && flagw[1] == 0) return;
     const bool up_work = ALL_INTRA || flagw[0] != 0; // the band above publishes its strips
@@ -418,7 +439,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     uint8_t *rowl = lds + r * ROW_LDS;
     uint8_t *tiles = rowl;                                        // [DBT_NB][TILE]
     uint8_t *ups = rowl + DBT_NB * TILE;                          // [DBT_NB][UPB]: the strip above, first row of a band only
-    unsigned *pars = (unsigned *)(rowl + DBT_NB * (TILE + UPB));  // [4][2][64]
+    unsigned *pars = (unsigned *)(rowl + DBT_NB * (TILE + UPB));  // [4][PARW]: the parameter words of the macroblocks in flight
     uint8_t *tiles_up = lds + (r > 0 ? r - 1 : 0) * ROW_LDS;      // the row above's tiles
     const int keep = last_row ? rows_mb : rows_mb - strip;
     const int t_end = mbw + ROWS + 1;
@@ -431,8 +452,11 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     // under a branch or a predicate is a conditional assignment to a loop-carried value, which costs a merge move -- and the wait
     // for the load right behind its issue
     const int my_c = row_ok ? my : mbh - 1;
-    const uint8_t *ld_ptr = plane + ((size_t)my_c * rows_mb + (lane & (rows_mb - 1))) * stride; // (lanes without a line repeat one)
-    const int ld_step = 16;
+    constexpr int PL = PARW / 4;                                  // lanes 16 .. 16+PL-1 bring the macroblock's parameter words (16 bytes each)
+    const bool plane_l = lane >= 16 && lane < 16 + PL;
+    const uint8_t *ld_ptr = plane_l ? (const uint8_t *)(partab + (size_t)r * mbw * PARW + 4 * (lane - 16))
+                                    : plane + ((size_t)my_c * rows_mb + (lane & (rows_mb - 1))) * stride; // (lanes without a role repeat a line)
+    const int ld_step = plane_l ? PARW * 4 : 16;
     uint8_t *st_ptr = lane < 16 ? plane + ((size_t)my_c * rows_mb + lane) * stride : plane + ((size_t)my_c * rows_mb - (my_c > 0 ? strip : 0) + (lane & 3)) * stride; // storer: this lane's line
     const int gj = glane ? lane - 32 : 0;
     const uint8_t *g_ptr = up_work ? (const uint8_t *)(gran_up + gj) : plane + ((size_t)my_c * rows_mb - (my_c > 0 ? strip : 0) + (gj >> 2)) * stride + 4 * (gj & 3);
@@ -458,7 +482,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
             // =========================================================== F: vertical edges | barrier | horizontal edges
                 uint8_t *tile = tiles + (x & (DBT_NB - 1)) * TILE;
                 if (act) {
-                    const unsigned par = pars[((x & 3) * 2 + 0) * 64 + lane];
+                    const unsigned par = pars[(x & 3) * PARW + (CHROMA ? (lane & 1) * 4 + (lane >> 3) : e * 4 + (k >> 2))]; // vertical: (edge, segment of this lane's line)
                     if (!CHROMA) {
                         uint8_t *tl = tiles + ((x - 1) & (DBT_NB - 1)) * TILE;
                         unsigned *pw = (unsigned *)(e == 0 ? tl + k * 16 + 12 : tile + k * 16 + 4 * e - 4), *qw = (unsigned *)(tile + k * 16 + 4 * e);
@@ -492,7 +516,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                 BAND_BARRIER();
                 DBT_TICK(1);
                 if (act) {
-                    const unsigned par = pars[((x & 3) * 2 + 1) * 64 + lane];
+                    const unsigned par = pars[(x & 3) * PARW + PARW / 2 + (CHROMA ? (lane & 1) * 4 + (lane >> 3) : e * 4 + (k >> 2))]; // horizontal: (edge, segment of this lane's column)
                     uint8_t *upb = fed ? ups + (x & (DBT_NB - 1)) * UPB : tiles_up + (x & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
                     if (!CHROMA) {
                         uint8_t *pb = (e == 0 ? upb : tile + (4 * e - 4) * 16) + k, *qb = tile + 4 * e * 16 + k;
@@ -535,25 +559,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                 const bool lands = row_ok && xm >= 0 && xm < mbw;
                 if (lands) {
                     if (rlane) *(uint4 *)(tiles + (xm & (DBT_NB - 1)) * TILE + lane * 16) = cur;
-                    // the record goes through LDS: its four quarters are on lanes 16..19, and every lane picks the words of ITS edge
-                    // (16 v_readlane + selects cost the mover ~200 cycles more per step, and the mover sets the band's pace)
-                    const unsigned *rq = bandrec + ((size_t)r * mbw + xm) * 16;
-                    unsigned pv, ph;
-                    if (!CHROMA) { // words 0..3: bS of the vertical / horizontal edges, two edges per word; 4..9: {alpha|beta<<8, tc0 bytes} left, top, inner
-                        const int sh = 16 * (e & 1) + 4 * (k >> 2);
-                        const unsigned vb = rq[e >> 1], hb = rq[2 + (e >> 1)];
-                        const uint2 vp = *(const uint2 *)(rq + (e == 0 ? 4 : 8)), hp = *(const uint2 *)(rq + (e == 0 ? 6 : 8));
-                        pv = par_word((vb >> sh) & 15u, vp.x, vp.y);
-                        ph = par_word((hb >> sh) & 15u, hp.x, hp.y);
-                    } else {       // chroma edges are luma edges 0 and 2: the low halves of words 0/1 and 2/3; parameters at words 10..15
-                        const int kk = lane >> 2, ee = lane & 1, kb = lane >> 1; // vertical: line kk, edge ee; horizontal: byte column kb, edge ee
-                        const unsigned vb = rq[ee], hb = rq[2 + ee];
-                        const uint2 vp = *(const uint2 *)(rq + (ee ? 14 : 10)), hp = *(const uint2 *)(rq + (ee ? 14 : 12));
-                        pv = par_word((vb >> (4 * (kk >> 1))) & 15u, vp.x, vp.y);
-                        ph = par_word((hb >> (4 * (kb >> 2))) & 15u, hp.x, hp.y);
-                    }
-                    pars[((xm & 3) * 2 + 0) * 64 + lane] = pv;
-                    pars[((xm & 3) * 2 + 1) * 64 + lane] = ph;
+                    if (plane_l) *(uint4 *)(pars + (xm & 3) * PARW + 4 * (lane - 16)) = cur; // ... and its parameter words
                 }
                 if (fed && act) { // the strip above macroblock x, asked for two steps ago: every granule must carry this picture's epoch
                     // the first test stands outside the retry loop: a loop that reloads `gpre` makes the compiler wait for every load in
@@ -661,14 +667,15 @@ size_t k_deblock_gran_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the movers follow its per-row progress words.
 template <typename K>
 static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStream_t s) {
-    const size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + (size_t)DB_ROWS * mbw * DBREC_BYTES + 16;
+    const size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + 16;
     static size_t granted = 48 * 1024; // above 64 KB of dynamic LDS the kernel has to be told (4K pictures: 80 KB; the device has 160 KB per CU)
     if (lds > granted) { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
     hipLaunchKernelGGL(kernel, dim3(2 * nbands), dim3(192 * DB_ROWS), lds, s, a);
 }
-void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, const unsigned *d_ip_progress, hipStream_t s) {
+size_t k_deblock_partab_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * DB_ROWS * mbw * 48 * sizeof(unsigned); } // 32 luma + 16 chroma words per macroblock
+void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress, hipStream_t s) {
     db_args a;
-    a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress;
+    a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab;
     if (band1 <= band0) return;
     if (h_ctx->all_intra) launch_bands(deblock_rows3_kernel<DB_ROWS, true, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
     else if (d_ip_progress) launch_bands(deblock_rows3_kernel<DB_ROWS, false, true>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel

@@ -75,6 +75,7 @@ struct mi355enc {
     uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock
     uint8_t *d_idec;      // intra decisions, IDEC_BYTES per macroblock
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
+    unsigned *d_db_par;   // the band deblocker's table of per-edge parameter words (written by its prologue, read by its movers)
     uint2 *d_db_gran;     // strips between deblocking bands, as epoch-tagged granules (never cleared)
     unsigned *d_progress; // the sticky error word of the persistent kernels (bounded spins report here)
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
@@ -166,7 +167,7 @@ static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
 static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress) {
     if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
-        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, ip_progress, st);
+        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, st);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -208,7 +209,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_par = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -246,6 +247,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->d_idec2[0] = h->d_idec;
     HIPCHK(hipMalloc((void **)&h->d_progress, 4 * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
+    HIPCHK(hipMalloc((void **)&h->d_db_par, k_deblock_partab_bytes(h->mbw, h->mbh)));
     HIPCHK(hipMalloc((void **)&h->d_db_gran, k_deblock_gran_bytes(h->mbw, h->mbh)));
     HIPCHK(hipMemsetAsync(h->d_db_gran, 0, k_deblock_gran_bytes(h->mbw, h->mbh), h->stream)); // epoch 0 is never used
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
@@ -323,6 +325,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_idec) (void)hipFree(h->d_idec);
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->d_db_gran) (void)hipFree(h->d_db_gran);
+    if (h->d_db_par) (void)hipFree(h->d_db_par);
     if (h->d_off) (void)hipFree(h->d_off);
     for (int k = 0; k < 2; k++) {
         if (h->d_surf[k]) (void)hipFree(h->d_surf[k]);

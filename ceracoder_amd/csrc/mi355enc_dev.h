@@ -104,7 +104,8 @@ void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag,
 int k_deblock_bands16(int mbh);
  // flags: per-band "has work" words of this picture's set
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the band kernel follows its per-row progress words
-void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, const unsigned *d_ip_progress, hipStream_t s);
+void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress, hipStream_t s);
+size_t k_deblock_partab_bytes(int mbw, int mbh); // scratch of the band kernel: one parameter word per (edge, segment) of every macroblock
 size_t k_deblock_gran_bytes(int mbw, int mbh); // the strips between bands: 8-byte {samples, epoch} granules
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s);
 int k_intra_diags(int mbw, int mbh);
