@@ -564,23 +564,26 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                 if (fed && act) { // the strip above macroblock x, asked for two steps ago: every granule must carry this picture's epoch
                     // the first test stands outside the retry loop: a loop that reloads `gpre` makes the compiler wait for every load in
                     // flight at its header (vmcnt(0): also the loads issued half a step ago), the common case needs only the one from two steps ago
-                    unsigned gw = gpre.x;
-#ifndef DBX_NOWAITG
-                    if (up_work && __ballot(glane && gpre.y != epoch)) {
-                        uint2 g2 = gpre;
+                    unsigned *dst = (unsigned *)(ups + (x & (DBT_NB - 1)) * UPB) + gj;
+                    // The prefetched word is stored unconditionally; a strip that had not been published yet when it was asked for is
+                    // fetched again into variables of its own and stored over it.  (Any form in which the two values meet in one store --
+                    // a select, or two stores the compiler can merge -- costs a copy of gpre.x on the loop's back edge, which waits for the
+                    // sc1 load issued right there: a full cross-XCD round trip per two steps, on every mover.)
+                    const bool late = up_work && __ballot(glane && gpre.y != epoch) != 0;
+                    if (glane) *dst = gpre.x;
+                    if (late) {
+                        uint2 g2;
                         int spins = 0;
 #ifdef DBT_PROF
                         nmiss++;
 #endif
                         do {
                             __builtin_amdgcn_s_sleep(1);
-                            if (glane) g2 = ld64_sc1(gran_up + (size_t)x * ring_n + (lane - 32));
+                            g2 = ld64_sc1(gran_up + (size_t)x * ring_n + gj);
                             if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; } // bounded; once tripped, nobody waits again
                         } while (__ballot(glane && g2.y != epoch));
-                        gw = g2.x;
+                        if (glane) *dst = g2.x;
                     }
-#endif
-                    if (glane) *(unsigned *)(ups + (x & (DBT_NB - 1)) * UPB + 4 * (lane - 32)) = gw;
                 }
                 DBT_TICK(0);
                 BAND_BARRIER();
