@@ -488,11 +488,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                         unsigned *pw = (unsigned *)(e == 0 ? tl + k * 16 + 12 : tile + k * 16 + 4 * e - 4), *qw = (unsigned *)(tile + k * 16 + 4 * e);
                         const unsigned w0 = *pw, w1 = *qw;
                         const unsigned long long work = __ballot((par & 15u) != 0);
-#ifdef DBX_NOFILT
-                        if (0) {
-#else
                         if (ALL_INTRA || work) {
-#endif
                             int s[8];
 #pragma unroll
                             for (int i = 0; i < 4; i++) { s[i] = byte_of(w0, i); s[4 + i] = byte_of(w1, i); }
@@ -524,11 +520,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
 #pragma unroll
                         for (int i = 0; i < 4; i++) { s[i] = pb[i * 16]; s[4 + i] = qb[i * 16]; }
                         const unsigned long long work = __ballot((par & 15u) != 0);
-#ifdef DBX_NOFILT
-                        if (0) {
-#else
                         if (ALL_INTRA || work) {
-#endif
                             const bool any4 = __ballot((par & 15u) == 4u) != 0;
                             edges4p_luma<ALL_INTRA>(e, par, any4, s);
                             if (e != 0 || my > 0) { pb[2 * 16] = (uint8_t)s[2]; pb[3 * 16] = (uint8_t)s[3]; }
