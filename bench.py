@@ -254,6 +254,8 @@ def main():
         enc.reset_stats()
     dt, (qps, nbytes) = ranks.timed(lambda: run(args.steps, args.warmup), sync=torch.cuda.synchronize)
     st = e.stats()
+    for enc in encs:  # (closed before the untimed extras open encoders of their own: several encoders in one process run their stages in order)
+        enc.close()
 
     extra = {}
     if rank == 0:
@@ -411,8 +413,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np, width, height, fps, gop, qps)
         print(json.dumps(out), flush=True)
-    for enc in encs:
-        enc.close()
     ranks.close()
 
 

@@ -133,6 +133,13 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
 }
 
 static unsigned *err_word(const mi355enc_t *h) { return h->d_progress; }
+// A kernel that follows another kernel's progress (the band deblocker beside intra_p_kernel) needs the two to be able to run at the
+// same time.  One encoder's own streams guarantee that (intra_p_kernel is enqueued first).  Several encoders in one process share the
+// process's hardware queues, where a waiting kernel of one can sit in front of the kernel another one waits for; and tools that
+// serialise dispatches (rocprofv3 --pmc) run one kernel at a time.  So: only with a single open encoder in the process, and not when
+// MI355ENC_SERIAL is set (tools/measure_all.sh sets it for the counter passes).  Every wait is bounded and reported anyway.
+static std::atomic<int> g_open_encoders{0};
+static bool overlap_allowed() { static const bool serial = getenv("MI355ENC_SERIAL") != nullptr; return !serial && g_open_encoders.load(std::memory_order_relaxed) == 1; }
 
 static void launch_intra_all(mi355enc_t *h, int ci) {
     int n = k_intra_diags(h->mbw, h->mbh);
@@ -216,6 +223,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->fixed_qp.store(cfg->fixed_qp);
     h->fixed_drop.store(0);
     *out = h; // from here on close() cleans up partial state
+    g_open_encoders.fetch_add(1, std::memory_order_relaxed);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
     h->d_ctx = h->d_ctx2[0];
@@ -297,6 +305,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
 
 void mi355enc_close(mi355enc_t *h) {
     if (!h) return;
+    g_open_encoders.fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(h->cfg.device_id);
     if (h->fstream) (void)hipStreamSynchronize(h->fstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -482,7 +491,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         // x + y) overlap -- intra_p_kernel runs on a stream of its own and the deblocker's movers follow its per-row progress words
         // (GATED, k_deblock.hip); the chain pmb -> prep -> deblocker -> next pmb stays on one stream (a cross-stream event on the
         // chain costs 10-17 us).  Not on pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
-        const int split = !idr && fused && c->intra_p && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof;
+        const int split = !idr && fused && c->intra_p && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
         if (idr) {
             if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
             int r = run_intra(h, ci, c); if (r) return r;

@@ -55,3 +55,28 @@ def test_two_processes_one_stream_each_equal_the_single_process_stream(tmp_path,
     assert all(x["digest"] == m.hexdigest() for x in res), res
     assert all(x["frames"] == 2 * n and x["dt"] > 0 for x in res)
     assert all(0 < x["open_ms"] < 500 for x in res), res
+
+
+@pytest.mark.gpu
+def test_two_encoders_in_one_process_equal_the_single_stream(E):
+    """Several encoders in ONE process share its hardware queues, so the band deblocker must not wait there for an intra_p_kernel of
+    its own picture that may be queued behind another encoder's waiting kernel: with more than one encoder open every stage runs in
+    stream order.  Same bits either way."""
+    from ceracoder_amd import synth
+    w, h, n = 640, 368, 14
+    frames = list(synth.s2_frames(w, h, n))
+    single = E.Encoder(w, h, gop=7, fixed_qp=28)
+    ref = [single.encode(y, uv, pts=i)[0] for i, (y, uv) in enumerate(frames)]
+    single.close()
+    a, b = E.Encoder(w, h, gop=7, fixed_qp=28, pipeline_depth=1), E.Encoder(w, h, gop=7, fixed_qp=28, pipeline_depth=1)
+    out = {id(a): [], id(b): []}
+    for i, (y, uv) in enumerate(frames):
+        for e in (a, b):
+            e.submit(y, uv, pts=i)
+            if e.pending > 1:
+                out[id(e)].append(bytes(e.collect()[0]))
+    for e in (a, b):
+        while e.pending:
+            out[id(e)].append(bytes(e.collect()[0]))
+        e.close()
+    assert out[id(a)] == ref and out[id(b)] == ref

@@ -1,5 +1,6 @@
 # Refreshes everything under profiles/ on a GPU box: the rocprofv3 kernel trace and the two PMC passes first (so that the bench lines can
-# attach the HBM traffic of THIS build), then the bench lines of the four workloads and the multi-stream runs.
+# attach the HBM traffic of THIS build; MI355ENC_SERIAL=1 there: counter collection serialises kernel dispatches, and the band deblocker
+# cannot follow an intra_p_kernel that is not allowed to run beside it), then the bench lines of the four workloads and the multi-stream runs.
 #   gpurun --timeout 1200 -- bash tools/measure_all.sh [ROUND]      afterwards: cp gpurun_out/final/profiles/* profiles/
 set -e
 R=$PWD
@@ -8,9 +9,9 @@ mkdir -p gpurun_out/final/profiles
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/final/ks -o ks -- python3 $R/bench.py --no-cpu-baseline --no-gst-latency > $R/gpurun_out/final/ks.log 2>&1
 echo "kernel stats done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_f -o f -- python3 $R/bench.py --steps 120 --warmup 20 --no-cpu-baseline --no-gst-latency > $R/gpurun_out/final/pmc_f.log 2>&1
+MI355ENC_SERIAL=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_f -o f -- python3 $R/bench.py --steps 120 --warmup 20 --no-cpu-baseline --no-gst-latency > $R/gpurun_out/final/pmc_f.log 2>&1
 echo "pmc fetch done"
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_w -o w -- python3 $R/bench.py --steps 120 --warmup 20 --no-cpu-baseline --no-gst-latency > $R/gpurun_out/final/pmc_w.log 2>&1
+MI355ENC_SERIAL=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_w -o w -- python3 $R/bench.py --steps 120 --warmup 20 --no-cpu-baseline --no-gst-latency > $R/gpurun_out/final/pmc_w.log 2>&1
 echo "pmc write done"
 cd $R
 python tools/pmc_summary.py $RND 1080p_ippp gpurun_out/final/ks/ks_results.db gpurun_out/final/pmc_f gpurun_out/final/pmc_w > gpurun_out/final/pmc_summary.log 2>&1
