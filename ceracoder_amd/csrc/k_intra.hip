@@ -616,9 +616,10 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
 // own LDS for the next step.  Between bands the bottom rows of the last row are stored with `sc1` and announced through a
 // progress counter, exactly like the deblocking bands; the first row of a band prefetches them one step ahead.
 #ifndef IB_ROWS
-#define IB_ROWS 4
+#define IB_ROWS MI355_BAND_ROWS
 #endif
-struct ib_args { frame_ctx_t ctx; uint2 *gran; unsigned *err; }; // gran: the bottom lines between bands, 8 granules {4 samples, tag} per macroblock and boundary
+static_assert(IB_ROWS == MI355_BAND_ROWS, "the band deblocker gates its bands on the intra bands of the same rows");
+struct ib_args { frame_ctx_t ctx; uint2 *gran; unsigned *err; unsigned *band_done; }; // gran: the bottom lines between bands, 8 granules {4 samples, tag} per macroblock and boundary
 
 __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     __shared__ intra_lds LD[IB_ROWS];
@@ -733,6 +734,18 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
             }
         }
     }
+    // ---- this band's reconstruction and records are complete: tell the band deblocker, which may be waiting on another stream
+    // (release pattern of MI355X_MICROARCH.md: every storing wave drains, the workgroup meets, one lane writes this XCD's L2 back and
+    // only then publishes the tagged flag)
+    if (a.band_done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_sc1(a.band_done + band, tag);
+        }
+    }
 #ifdef IB_PROF
     if (lane == 0 && band < 2) {
         unsigned *o = (unsigned *)ctx->isad + (band * 8 + w) * 4;
@@ -741,10 +754,11 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
 #endif
 }
 int k_intra_bands(int mbh) { return (mbh + IB_ROWS - 1) / IB_ROWS; }
-// d_gran: the granule buffer shared with the band deblocker (k_deblock_gran_bytes covers 8 granules per macroblock and band here)
-void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, hipStream_t s) {
+// d_gran: 8 granules per macroblock and band boundary (a buffer of its own: the band deblocker of the PREVIOUS picture may still be running)
+// d_band_done (may be null): one word per band, set to the inverted epoch once the band is complete in memory (the band deblocker's gate)
+void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, unsigned *d_band_done, hipStream_t s) {
     ib_args a;
-    a.ctx = *h_ctx; a.gran = d_gran; a.err = d_err;
+    a.ctx = *h_ctx; a.gran = d_gran; a.err = d_err; a.band_done = d_band_done;
     hipLaunchKernelGGL(intra_band_kernel, dim3(k_intra_bands(mbh)), dim3(IB_ROWS * 128), 0, s, a);
 }
 

@@ -75,6 +75,10 @@ struct mi355enc {
     uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock
     uint8_t *d_idec;      // intra decisions, IDEC_BYTES per macroblock
     uint16_t *d_isad;     // intra analysis SADs, ISAD_PER_MB u16 per macroblock
+    uint2 *d_ib_gran;     // the intra band kernel's bottom lines between bands (tagged granules)
+    unsigned *d_iband_done; // ... and its per-band completion flags (the band deblocker's gate on IDR pictures)
+    hipEvent_t ev_dbI[2];  // [reconstruction buffer]: the deblocking of an IDR picture that ran beside its intra wavefront on the intra stream has finished
+    int dbI_busy[2];
     unsigned *d_db_par;   // the band deblocker's table of per-edge parameter words (written by its prologue, read by its movers)
     uint2 *d_db_gran;     // strips between deblocking bands, as epoch-tagged granules (never cleared)
     unsigned *d_progress; // the sticky error word of the persistent kernels (bounded spins report here)
@@ -158,10 +162,10 @@ static int build_graph(mi355enc_t *h, int which, int ci, hipGraphExec_t *out) {
     HIPCHK(hipGraphDestroy(g));
     return 0;
 }
-static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
+static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done = nullptr) {
     k_launch_intra_analyse(hc, h->mbw, h->mbh, 0, h->stream); // open-loop mode analysis + decisions: one flat launch
     if (h->cfg.intra_mode == 0) { // persistent band kernel
-        k_launch_intra_band(hc, h->mbh, h->d_db_gran, err_word(h), h->stream);
+        k_launch_intra_band(hc, h->mbh, h->d_ib_gran, err_word(h), band_done, h->stream);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -172,9 +176,9 @@ static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc) {
     return 0;
 }
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
-static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress) {
+static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done = nullptr) {
     if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
-        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, st);
+        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, st);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -216,7 +220,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_par = nullptr; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -256,6 +260,11 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_progress, 4 * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
     HIPCHK(hipMalloc((void **)&h->d_db_par, k_deblock_partab_bytes(h->mbw, h->mbh)));
+    HIPCHK(hipMalloc((void **)&h->d_ib_gran, (size_t)k_intra_bands(h->mbh) * h->mbw * 8 * sizeof(uint2)));
+    HIPCHK(hipMemsetAsync(h->d_ib_gran, 0, (size_t)k_intra_bands(h->mbh) * h->mbw * 8 * sizeof(uint2), h->stream));
+    HIPCHK(hipMalloc((void **)&h->d_iband_done, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned))); // one set per reconstruction buffer: the next picture's wavefront runs beside this one's deblocking
+    HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned), h->stream));
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_dbI[i], hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&h->d_db_gran, k_deblock_gran_bytes(h->mbw, h->mbh)));
     HIPCHK(hipMemsetAsync(h->d_db_gran, 0, k_deblock_gran_bytes(h->mbw, h->mbh), h->stream)); // epoch 0 is never used
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
@@ -335,6 +344,9 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->d_db_gran) (void)hipFree(h->d_db_gran);
     if (h->d_db_par) (void)hipFree(h->d_db_par);
+    if (h->d_ib_gran) (void)hipFree(h->d_ib_gran);
+    if (h->d_iband_done) (void)hipFree(h->d_iband_done);
+    for (int i = 0; i < 2; i++) if (h->ev_dbI[i]) (void)hipEventDestroy(h->ev_dbI[i]);
     if (h->d_off) (void)hipFree(h->d_off);
     for (int k = 0; k < 2; k++) {
         if (h->d_surf[k]) (void)hipFree(h->d_surf[k]);
@@ -456,7 +468,9 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     const int set = (int)(h->n_submitted & 1), ci = set;
     frame_ctx_t *c = s->h_ctx, *dctx = h->d_ctx2[ci];
     // stage timers: an event record costs ~5 us of queue time, so profile_events = k samples every k-th picture (IDR pictures always)
-    const int prof = !all_skip && h->cfg.profile_events > 0 && (idr || h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
+    // (a sampled picture runs its stages strictly in order; IDR pictures: every other one, or at the P pictures' cadence in an all-intra stream)
+    const int prof = !all_skip && h->cfg.profile_events > 0 &&
+                     ((idr && h->cfg.gop > 1) ? (h->idr_count & 1) == 0 : h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
     const bool fused = !h->cfg.transform8x8;
     if (all_skip) {
         // one run of P_Skip macroblocks with the zero vector (8.4.1.1 infers it: every neighbour's vector is zero): the host
@@ -492,9 +506,17 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         // (GATED, k_deblock.hip); the chain pmb -> prep -> deblocker -> next pmb stays on one stream (a cross-stream event on the
         // chain costs 10-17 us).  Not on pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
         const int split = !idr && fused && c->intra_p && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
+        // IDR picture: the band deblocker runs on the intra stream BESIDE the intra wavefront, each of its bands waiting for the intra bands
+        // of the same rows (flags + acquire); in an all-intra stream the next picture's wavefront then starts while this one is still
+        // being deblocked.  What has to wait for such a deblocking: a P picture (it reads the whole reference), and whoever writes
+        // the reconstruction buffer it works on (the picture after next).
+        const int isplit = idr && h->cfg.intra_mode == 0 && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
+        for (int b = 0; b < 2; b++)
+            if (h->dbI_busy[b] && (!idr || b == nxt)) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_dbI[b], 0)); h->dbI_busy[b] = 0; }
         if (idr) {
+            if (isplit) { HIPCHK(hipEventRecord(h->ev_pmb, h->stream)); HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0)); } // behind everything enqueued so far (a P picture's deblocker, its tables)
             if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
-            int r = run_intra(h, ci, c); if (r) return r;
+            int r = run_intra(h, ci, c, isplit ? h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh) : nullptr); if (r) return r;
             if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
         } else {
             int r = run_p_back(h, c, s, prof, split); if (r) return r;
@@ -507,7 +529,11 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
             HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
             if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         }
-        { int r = run_deblock(h, ci, c, h->stream, split ? h->d_ip_progress : nullptr); if (r) return r; }
+        if (isplit) {
+            int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh)); if (r) return r;
+            HIPCHK(hipEventRecord(h->ev_dbI[nxt], h->istream));
+            h->dbI_busy[nxt] = 1;
+        } else { int r = run_deblock(h, ci, c, h->stream, split ? h->d_ip_progress : nullptr); if (r) return r; }
         if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
         HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
         // Hand-over on the second stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:

@@ -34,6 +34,7 @@ typedef struct {
 #define SURF_COLS 36
 #define SURF_ROWS 35
 #define SURF_U16 (SURF_ROWS * SURF_COLS)
+#define MI355_BAND_ROWS 4 /* macroblock rows per band of BOTH persistent wavefront kernels: the deblocker's bands wait for the intra bands of the same rows */
 #define ME_ITERS 3          /* Jacobi iterations of the vector selection after the search's own (oracle: ORC_ME_ITERS) */
 #define SEL_BONUS 2         /* oracle: ORC_SEL_BONUS */
 #define SKIP_MARGIN_BITS 4  /* oracle: ORC_SKIP_MARGIN_BITS */
@@ -104,13 +105,15 @@ void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag,
 int k_deblock_bands16(int mbh);
  // flags: per-band "has work" words of this picture's set
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the band kernel follows its per-row progress words
-void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress, hipStream_t s);
+// d_iband_done (may be null; all-intra pictures): the intra band kernel of the same picture is still running; a band waits for its flags
+void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
+                            const unsigned *d_iband_done, hipStream_t s);
 size_t k_deblock_partab_bytes(int mbw, int mbh); // scratch of the band kernel: one parameter word per (edge, segment) of every macroblock
 size_t k_deblock_gran_bytes(int mbw, int mbh); // the strips between bands: 8-byte {samples, epoch} granules
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s);
 int k_intra_diags(int mbw, int mbh);
 int k_intra_bands(int mbh);
-void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, hipStream_t s);
+void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, unsigned *d_band_done, hipStream_t s);
 int k_launch_csc(int fmt, const uint8_t *p0, const uint8_t *p1, const uint8_t *p2, int s0, int s1, int s2, uint8_t *dy, uint8_t *duv,
                  int vw, int vh, int W, int H, hipStream_t s);
 void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, int mbw, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,
