@@ -621,6 +621,7 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
 static_assert(IB_ROWS == MI355_BAND_ROWS, "the band deblocker gates its bands on the intra bands of the same rows");
 struct ib_args { frame_ctx_t ctx; uint2 *gran; unsigned *err; unsigned *band_done; }; // gran: the bottom lines between bands, 8 granules {4 samples, tag} per macroblock and boundary
 
+template <bool PAIR> // which waves share a SIMD, see below
 __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     __shared__ intra_lds LD[IB_ROWS];
     __shared__ unsigned tabw[TAB_DWORDS];
@@ -628,7 +629,10 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     const dev_tables *T = (const dev_tables *)tabw;
     const frame_ctx_t *__restrict__ ctx = &a.ctx;
     const int mbw = ctx->mbw, mbh = ctx->mbh;
-    const int band = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = w >> 1, role = w & 1; // (w through readfirstlane, i.e. scalar control flow, made this kernel 14 % SLOWER: measured, left as it is)
+    const int band = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = PAIR ? w % IB_ROWS : w >> 1, role = PAIR ? w / IB_ROWS : w & 1; // (w through readfirstlane, i.e. scalar control flow, made this kernel 14 % SLOWER: measured, left as it is)
+    // (waves go to SIMD w % 4.  With Intra_4x4 in play a luma wave is 3-4x a chroma wave: every SIMD gets one row's luma and another row's
+    // chroma wave, 1.29 -> 1.20 ms per picture.  Intra_16x16 only (the rate-control ladder's pictures): the two are equal, and the pairing
+    // luma+luma / chroma+chroma was measured 5 % faster)
     const int my = band * IB_ROWS + r;
     const bool row_ok = my < mbh, has_top = my > 0;
     const bool fed = row_ok && r == 0 && band > 0;                        // top samples come from the band above
@@ -759,7 +763,8 @@ int k_intra_bands(int mbh) { return (mbh + IB_ROWS - 1) / IB_ROWS; }
 void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, unsigned *d_band_done, hipStream_t s) {
     ib_args a;
     a.ctx = *h_ctx; a.gran = d_gran; a.err = d_err; a.band_done = d_band_done;
-    hipLaunchKernelGGL(intra_band_kernel, dim3(k_intra_bands(mbh)), dim3(IB_ROWS * 128), 0, s, a);
+    if (h_ctx->i4x4) hipLaunchKernelGGL(intra_band_kernel<true>, dim3(k_intra_bands(mbh)), dim3(IB_ROWS * 128), 0, s, a);
+    else hipLaunchKernelGGL(intra_band_kernel<false>, dim3(k_intra_bands(mbh)), dim3(IB_ROWS * 128), 0, s, a);
 }
 
 // =================================================================== launchers

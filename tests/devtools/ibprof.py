@@ -8,7 +8,7 @@ for i4, qp in ((False, 40), (True, 24)):
     fr = list(synth.s2_frames(1920, 1080, 1))
     e.stage_intra(np.pad(fr[0][0], ((0, 8), (0, 0)), mode="edge"), np.pad(fr[0][1], ((0, 4), (0, 0)), mode="edge"), qp)
     import ctypes as C
-    raw = np.zeros(64, np.uint32)
+    raw = np.zeros(256, np.uint32)  # fetch 101 hands out 1024 bytes
     assert e.L.mi355enc_fetch(e.h, 101, raw.ctypes.data_as(C.c_void_p), raw.nbytes) == 0
     for band in range(2):
         for w in range(8):
