@@ -166,7 +166,7 @@ def main():
                     "(BASELINE.json configs[2]: 'balancer driving the bitrate property'), none elsewhere")
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     args = ap.parse_args()
-    if args.streams_per_gpu > 1:  # every encoder owns three HIP streams; the runtime's default of 4 hardware queues would serialise them
+    if args.streams_per_gpu > 1:  # every encoder owns five HIP streams; the runtime's default of 4 hardware queues would serialise them
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch

@@ -1,4 +1,4 @@
-// k_deblock.hip -- in-loop deblocking filter (H.264 8.7): prep + persistent 16-row bands, and the per-diagonal form
+// k_deblock.hip -- in-loop deblocking filter (H.264 8.7): the persistent band kernel, and the per-diagonal form
 // Hand-written HIP for gfx950 (CDNA4, wave64); part of libmi355enc (see kernels_common.hpp).
 #include "kernels_common.hpp"
 
@@ -159,7 +159,7 @@ struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gra
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
 //  (1) Boundary strengths and the alpha/beta/tc0 triples depend only on the macroblock records,
-//      so a flat kernel (deblock_prep_kernel) computes them for the whole picture up front:
+//      so they are computed up front (the band kernel's prologue, db_record):
 //      64 bytes per macroblock {bS nibbles V/H, six packed parameter pairs}.
 //  (2) x + 2y is sufficient but not necessary.  Macroblock (x, y) only conflicts with its
 //      top-right neighbour (x+1, y-1) on the 3x3 corner of (x, y-1) that the neighbour's left

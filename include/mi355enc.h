@@ -59,7 +59,7 @@ typedef struct {
     int transform8x8;         /* 1: High-profile stream, P macroblocks use the 8x8 transform; 0 (default): Constrained Baseline */
     int i4x4;                 /* 1 (default): try Intra_4x4 besides Intra_16x16 in I pictures */
     int subpel;               /* 1 (default): half- then quarter-sample refinement after the integer search */
-    int deblock_mode;         /* 0: boundary-strength prep kernel + persistent 16-row band kernel (x+y order);
+    int deblock_mode;         /* 0: persistent band kernel (x+y order, three waves per macroblock row; boundary strengths in its prologue);
                                  1: one launch per x+2y wavefront (plain form, kept as a cross-check) */
     int intra_in_p;           /* 1 (default): macroblocks of P pictures may be coded intra (uncovered regions, partial scene changes): decided in
                                  the fused P stage from the open-loop intra analysis, reconstructed by a short dependent pass
