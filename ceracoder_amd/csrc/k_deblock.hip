@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; }; // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; }; // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -374,15 +374,18 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     if (ALL_INTRA && a.iband_done) {
         // The intra band kernel of the same picture may still be running (on another stream): this band's macroblocks -- and the row
         // above them, whose records the boundary strengths read and whose bottom lines this band's top edge changes -- are complete
-        // once the intra bands `band` and `band - 1` (same rows: IB_ROWS == DB_ROWS) have published the picture's tag.  One lane
-        // polls, takes the acquire, the workgroup meets (MI355X_MICROARCH.md, consumer form).
+        // once the intra bands that hold macroblock rows band * ROWS - 1 .. band * ROWS + ROWS - 1 (the intra kernel's bands have
+        // a.ib_rows rows) have published the picture's tag.  One lane polls, takes the acquire, the workgroup meets
+        // (MI355X_MICROARCH.md, consumer form).
         if (threadIdx.x == 0) {
             const unsigned tag = ~ctx->epoch;
+            const int r_lo = band * ROWS > 0 ? band * ROWS - 1 : 0, r_hi = band * ROWS + ROWS - 1 < mbh ? band * ROWS + ROWS - 1 : mbh - 1;
             int spins = 0;
-            while (ld_sc1(a.iband_done + band) != tag || (band > 0 && ld_sc1(a.iband_done + band - 1) != tag)) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; } // bounded; the host reports the picture as failed
-            }
+            for (int ib = r_lo / a.ib_rows; ib <= r_hi / a.ib_rows; ib++)
+                while (ld_sc1(a.iband_done + ib) != tag) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; } // bounded; the host reports the picture as failed
+                }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -671,9 +674,8 @@ void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag,
     hipLaunchKernelGGL(deblock_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
 }
 #ifndef DB_ROWS
-#define DB_ROWS 4 /* rows per band: three waves per row, one row per SIMD (5 rows = 15 waves is equal on P pictures, a third slower on I pictures) */
+#define DB_ROWS MI355_BAND_ROWS /* rows per band: three waves per row, one row per SIMD (5 rows = 15 waves is equal on P pictures, a third slower on I pictures) */
 #endif
-static_assert(DB_ROWS == MI355_BAND_ROWS, "the band deblocker gates its bands on the intra bands of the same rows");
 int k_deblock_bands16(int mbh) { return (mbh + DB_ROWS - 1) / DB_ROWS; }
 size_t k_deblock_gran_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * mbw * 24 * sizeof(uint2); } // per band boundary and macroblock: 16 luma + 8 chroma granules
 // The band kernel may be launched in several pieces (bands [band0, band1)): a band only ever waits for the band above it.
@@ -687,9 +689,9 @@ static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStr
 }
 size_t k_deblock_partab_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * DB_ROWS * mbw * 48 * sizeof(unsigned); } // 32 luma + 16 chroma words per macroblock
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
-                            const unsigned *d_iband_done, hipStream_t s) {
+                            const unsigned *d_iband_done, int ib_rows, hipStream_t s) {
     db_args a;
-    a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab; a.iband_done = d_iband_done;
+    a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab; a.iband_done = d_iband_done; a.ib_rows = ib_rows > 0 ? ib_rows : DB_ROWS;
     if (band1 <= band0) return;
     if (h_ctx->all_intra) launch_bands(deblock_rows3_kernel<DB_ROWS, true, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
     else if (d_ip_progress) launch_bands(deblock_rows3_kernel<DB_ROWS, false, true>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel

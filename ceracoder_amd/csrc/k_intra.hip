@@ -616,9 +616,10 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
 // own LDS for the next step.  Between bands the bottom rows of the last row are stored with `sc1` and announced through a
 // progress counter, exactly like the deblocking bands; the first row of a band prefetches them one step ahead.
 #ifndef IB_ROWS
-#define IB_ROWS MI355_BAND_ROWS
+#define IB_ROWS 2 /* rows per band: four waves, one per SIMD.  With four rows two compute-heavy waves shared every SIMD and a step cost their sum
+                     (an Intra_16x16-only 1080p picture 0.51 ms, 0.44 with two rows; one row 0.49, three 0.51): since the bottom lines
+                     between bands travel as granules a band boundary costs little more than a row boundary inside a band */
 #endif
-static_assert(IB_ROWS == MI355_BAND_ROWS, "the band deblocker gates its bands on the intra bands of the same rows");
 struct ib_args { frame_ctx_t ctx; uint2 *gran; unsigned *err; unsigned *band_done; }; // gran: the bottom lines between bands, 8 granules {4 samples, tag} per macroblock and boundary
 
 template <bool PAIR> // which waves share a SIMD, see below
@@ -758,6 +759,7 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
 #endif
 }
 int k_intra_bands(int mbh) { return (mbh + IB_ROWS - 1) / IB_ROWS; }
+int k_intra_band_rows(void) { return IB_ROWS; }
 // d_gran: 8 granules per macroblock and band boundary (a buffer of its own: the band deblocker of the PREVIOUS picture may still be running)
 // d_band_done (may be null): one word per band, set to the inverted epoch once the band is complete in memory (the band deblocker's gate)
 void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, unsigned *d_band_done, hipStream_t s) {

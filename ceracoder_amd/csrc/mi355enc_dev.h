@@ -34,7 +34,9 @@ typedef struct {
 #define SURF_COLS 36
 #define SURF_ROWS 35
 #define SURF_U16 (SURF_ROWS * SURF_COLS)
-#define MI355_BAND_ROWS 4 /* macroblock rows per band of BOTH persistent wavefront kernels: the deblocker's bands wait for the intra bands of the same rows */
+#ifndef MI355_BAND_ROWS
+#define MI355_BAND_ROWS 4 /* macroblock rows per band of the band deblocker (the intra band kernel has bands of its own height, k_intra_band_rows()) */
+#endif
 #define ME_ITERS 3          /* Jacobi iterations of the vector selection after the search's own (oracle: ORC_ME_ITERS) */
 #define SEL_BONUS 2         /* oracle: ORC_SEL_BONUS */
 #define SKIP_MARGIN_BITS 4  /* oracle: ORC_SKIP_MARGIN_BITS */
@@ -107,7 +109,8 @@ int k_deblock_bands16(int mbh);
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the band kernel follows its per-row progress words
 // d_iband_done (may be null; all-intra pictures): the intra band kernel of the same picture is still running; a band waits for its flags
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
-                            const unsigned *d_iband_done, hipStream_t s);
+                            const unsigned *d_iband_done, int ib_rows /* rows per intra band */, hipStream_t s);
+int k_intra_band_rows(void);
 size_t k_deblock_partab_bytes(int mbw, int mbh); // scratch of the band kernel: one parameter word per (edge, segment) of every macroblock
 size_t k_deblock_gran_bytes(int mbw, int mbh); // the strips between bands: 8-byte {samples, epoch} granules
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s);
