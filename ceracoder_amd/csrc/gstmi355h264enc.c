@@ -326,7 +326,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
     g_object_class_install_property(g, PROP_ME_RANGE, g_param_spec_int("me-range", "Motion search range", "Full-search radius, integer pels", 1, 16, 16, F));
     g_object_class_install_property(g, PROP_QP, g_param_spec_int("qp", "Constant QP", "-1: rate control on; 0..51: constant quantiser", -1, 51, -1, F));
     g_object_class_install_property(g, PROP_PIPELINE_DEPTH, g_param_spec_int("pipeline-depth", "Pipeline depth",
-        "0: output each picture before taking the next; 1: overlap host entropy coding with the next picture (+1 frame latency)", 0, 1, 0, F));
+        "0: output each picture before taking the next; 1: overlap host entropy coding with the next picture (+1 frame latency); 2: three pictures in flight (+2 frames)", 0, 2, 0, F));
     g_object_class_install_property(g, PROP_SPEED_PRESET, g_param_spec_enum("speed-preset", "Speed preset",
         "Accepted for x264enc pipeline compatibility; ignored", speed_preset_type(), 6, F));
     g_object_class_install_property(g, PROP_THREADS, g_param_spec_int("threads", "Entropy-coding threads",

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; }; // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; unsigned *band_done; unsigned *started; }; // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -448,7 +448,10 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the table's stores have left this CU before its movers load them
     __syncthreads();
-    if (!ALL_INTRA && flagw[1] == 0) return;
+    if (!ALL_INTRA && flagw[1] == 0) { // nothing written here: the samples were final at the previous kernel boundary
+        if (a.band_done && threadIdx.x < DB_DONE_COPIES) st_sc1(a.band_done + DB_DONE_STRIDE * threadIdx.x + 2 * band + (CHROMA ? 1 : 0), ctx->epoch);
+        return;
+    }
     const bool up_work = ALL_INTRA || flagw[0] != 0; // the band above publishes its strips
     const bool dn_work = ALL_INTRA || flagw[2] != 0; // ... and the band below reads ours
     const unsigned epoch = ctx->epoch;
@@ -647,6 +650,18 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
             DBT_TICK(2);
         }
     }
+    // ---- this band's lines are final in memory: tell the next picture's P stage, which may be running already (pmb_kernel's gate).
+    // Release pattern: every storing wave drains, the workgroup meets, one lane writes this XCD's L2 back and publishes the epoch.
+    if (a.band_done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x < DB_DONE_COPIES) { // (one copy per poller group: a few thousand waves reading one word would make its memory channel a hot spot)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_sc1(a.band_done + DB_DONE_STRIDE * threadIdx.x + 2 * band + (CHROMA ? 1 : 0), epoch);
+        }
+    }
+    tl_last(ctx, 8);
 #ifdef DBT_PROF
     if (lane == 0 && band < 2) { // rows 0..3 of bands 0 and 1
         unsigned *o = (unsigned *)(ctx->dbrec) + (CHROMA ? 128 : 0) + 64 * band + 16 * r + 4 * role; // debug build only: overwrites the first records after use
@@ -660,6 +675,8 @@ template <int ROWS, bool ALL_INTRA, bool GATED>
 __global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[]; // ROWS rows of tiles, then the band's records (ROWS * mbw * 64 bytes) and three flags
     const int nl = gridDim.x >> 1;
+    if (blockIdx.x == 0) tl_first(&a.ctx, 7);
+    if (a.started && threadIdx.x == 0) __hip_atomic_fetch_add(a.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this workgroup holds its place on a CU (wait_started_kernel)
     if ((int)blockIdx.x < nl) rows3_body<false, ALL_INTRA, ROWS, GATED>(a, a.band0 + blockIdx.x, a.nb_total, lds);
     else rows3_body<true, ALL_INTRA, ROWS, GATED>(a, a.band0 + blockIdx.x - nl, a.nb_total, lds);
 }
@@ -687,11 +704,25 @@ static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStr
     if (lds > granted) { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
     hipLaunchKernelGGL(kernel, dim3(2 * nbands), dim3(192 * DB_ROWS), lds, s, a);
 }
+// One wave that ends once `count` workgroups of band-deblocking launches have been placed since the encoder was opened (the count only
+// grows; the comparison is wrap-safe).  On a stream in front of a kernel whose workgroups wait for the deblocker's flags, it keeps
+// them from filling the chip before the deblocker is on it.
+__global__ __launch_bounds__(64) void wait_started_kernel(const unsigned *started, unsigned count, unsigned *err) {
+    if (threadIdx.x) return;
+    int spins = 0;
+    while ((int)(ld_sc1(started) - count) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (++spins > DB_SPIN_MAX) { st_sc1(err, 4u); break; } // bounded; the host reports the picture as failed
+        if ((spins & 255) == 0 && ld_sc1(err)) break;
+    }
+}
+void k_launch_wait_started(const unsigned *d_started, unsigned count, unsigned *d_err, hipStream_t s) { hipLaunchKernelGGL(wait_started_kernel, dim3(1), dim3(64), 0, s, d_started, count, d_err); }
+size_t k_deblock_done_bytes(void) { return (size_t)DB_DONE_COPIES * DB_DONE_STRIDE * sizeof(unsigned); } // 2 words per band: up to 512 bands
 size_t k_deblock_partab_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * DB_ROWS * mbw * 48 * sizeof(unsigned); } // 32 luma + 16 chroma words per macroblock
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
-                            const unsigned *d_iband_done, int ib_rows, hipStream_t s) {
+                            const unsigned *d_iband_done, int ib_rows, unsigned *d_band_done, unsigned *d_started, hipStream_t s) {
     db_args a;
-    a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab; a.iband_done = d_iband_done; a.ib_rows = ib_rows > 0 ? ib_rows : DB_ROWS;
+    a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab; a.iband_done = d_iband_done; a.ib_rows = ib_rows > 0 ? ib_rows : DB_ROWS; a.band_done = d_band_done; a.started = d_started;
     if (band1 <= band0) return;
     if (h_ctx->all_intra) launch_bands(deblock_rows3_kernel<DB_ROWS, true, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
     else if (d_ip_progress) launch_bands(deblock_rows3_kernel<DB_ROWS, false, true>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel

@@ -792,6 +792,7 @@ struct ip_args { frame_ctx_t ctx; unsigned *progress; uint8_t *strips; unsigned 
 #define IP_EPOCH(e) (((e) & 0xFFFFFu) << 12)
 __global__ __launch_bounds__(128) void intra_p_kernel(ip_args a) {
     const frame_ctx_t *__restrict__ ctx = &a.ctx;
+    if (blockIdx.x == 0) tl_first(ctx, 5);
     __shared__ intra_lds LD;
     __shared__ unsigned tabw[TAB_DWORDS];
     __shared__ unsigned ibits[16]; // which macroblocks of this row are intra (mbw <= 512)
@@ -895,6 +896,7 @@ __global__ __launch_bounds__(128) void intra_p_kernel(ip_args a) {
         }
     }
     if (prev_x == -2 && threadIdx.x == 0) st_sc1(&a.progress[my], ep | (unsigned)mbw); // no intra macroblock in this row
+    tl_last(ctx, 6);
 }
 void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_progress, uint8_t *d_strips, unsigned *d_err, hipStream_t s) {
     (void)mbw;

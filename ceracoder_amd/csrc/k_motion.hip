@@ -99,6 +99,7 @@ DEV void store_imv(imv_t *dst, unsigned best, int lambda, int px, int py, int sx
 
 __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, int row0) { // context by value: lives in the kernarg segment, no per-picture upload
     const frame_ctx_t *__restrict__ ctx = &cv;
+    if (blockIdx.x == 0) tl_first(ctx, 0);
     __shared__ unsigned win[ME_ROWS * ME_STRIDE];
     const int stride = ctx->stride, mbw = ctx->mbw, mbh = ctx->mbh;
     const int W = mbw * 16, H = mbh * 16;
@@ -181,6 +182,7 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
     // ---- first selection: bits against the zero vector
     const unsigned best = select_min(acc, g, dxg, active, ctx->me_range, ctx->lambda, 0, 0, 0, 0);
     if (lane == 0 && mx < mbw) store_imv(&ctx->imv_a[my * mbw + mx], best, ctx->lambda, 0, 0, 0, 0);
+    tl_last(ctx, 1);
 }
 
 // One Jacobi iteration of the selection: one wave per macroblock re-reads its surface (each lane the tile it wrote) and
@@ -535,15 +537,10 @@ DEV void pmb_store_pred_only(const frame_ctx_t *__restrict__ ctx, int16_t *lv, i
     if (lane < MB_LEVELS * 2 / 16) stg128(lv + 8 * lane, make_uint4(0, 0, 0, 0)); // 816 bytes = 51 x 16
 }
 
-__global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine) {
-    const frame_ctx_t *__restrict__ ctx = &cv;
-    __shared__ __attribute__((aligned(16))) sp_lds LD[4];
+// One P macroblock on one wave (no workgroup barrier anywhere: the four waves of a workgroup are independent).
+DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, const int lane, const int refine) {
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = ctx->qp, lambda = ctx->lambda;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
-    const int mbn = mb0 + blockIdx.x * 4 + wave; // the launch covers macroblocks mb0 .. mb1-1
-    if (mbn >= mb1) return;                      // wave-uniform; the kernel has no workgroup barrier
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
-    sp_lds *L = &LD[wave];
     const dev_tables *T = &g_tab;
     const imv_t *__restrict__ field = k_final_imv_dev(ctx);
     const uint2 selfw = ldg64(field + mbn);
@@ -726,6 +723,52 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
     if (lane < 2) stg128(lv + L_LDC + 8 * lane, make_uint4(0, 0, 0, 0)); // luma DC levels: unused by P macroblocks, kept zero
 }
 
+// The launch covers macroblocks mb0 .. mb1-1, four per workgroup and turn.
+// GATED: the reference picture's band deblocker may still be running (this launch then sits on the intra stream, beside the
+// reference's deblocking).  Macroblock row r reads reference lines up to 16 (r + 2) + 3 (whole-sample vectors of +-16, three more for
+// the six-tap filter and the quarter sample; chroma likewise inside row r + 2), all of which the deblocker's row r + 2 stores, or
+// the row below it in the same band or the next -- so a workgroup waits until the band that holds row r + 2 carries the reference's
+// epoch for both planes and then takes an acquire fence: the deblocker's workgroups sit on other XCDs.  Nothing below a band a wave has acquired is ever read, so no stale line can enter this XCD's L2 ahead of the
+// fence.
+// Waiting workgroups must never keep the kernel they wait for from being placed (it may not have started yet: after a picture whose
+// stages ran in order this launch is early by a whole picture).  A band of the deblocker needs three waves of 112 VGPRs on each SIMD
+// of one CU; four workgroups of this kernel on a CU (4 x 56 VGPRs per SIMD) leave no room for it, and a chip full of waiting
+// workgroups leaves none anywhere (seen: every band timed out).  So a gated launch follows wait_started_kernel (k_deblock.hip) on its
+// stream: by the time the first workgroup of this kernel is placed, every workgroup of the reference's deblocking launch is.  The
+// deblocker's bands finish within the last third of its run (they advance along x together), and that is when this launch, whole
+// and resident, takes its macroblocks row by row behind them.
+template <bool GATED>
+__global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine, const unsigned *__restrict__ gate_done, unsigned ref_epoch, unsigned *err) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    __shared__ __attribute__((aligned(16))) sp_lds LD[4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
+    const int mbn = mb0 + 4 * (int)blockIdx.x + wave;
+    if (mb0 == 0 && blockIdx.x == 0) tl_first(ctx, 2);
+    if (GATED) { // wave 0 waits for the band the workgroup's last macroblock needs, the others for wave 0
+        if (wave == 0) {
+            const int mbw = ctx->mbw, mbh = ctx->mbh;
+            const int last = mb0 + 4 * (int)blockIdx.x + 3 < mb1 ? mb0 + 4 * (int)blockIdx.x + 3 : mb1 - 1;
+            int rr = last / mbw + 2;
+            rr = rr < mbh ? rr : mbh - 1;
+            const uint2 *flag = (const uint2 *)(gate_done + DB_DONE_STRIDE * (blockIdx.x & (DB_DONE_COPIES - 1))) + rr / MI355_BAND_ROWS;
+            int spins = 0;
+            for (;;) {
+                const uint2 f = ld64_sc1(flag);
+                if (f.x == ref_epoch && f.y == ref_epoch) break;
+                __builtin_amdgcn_s_sleep(64);
+                if (++spins > DB_SPIN_MAX) { st_sc1(err, 3u); break; }
+                if ((spins & 255) == 0 && ld_sc1(err)) break; // somebody else gave up: nobody waits again // bounded; the host reports the picture as failed
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        tl_last(ctx, 3);
+    }
+    if (mbn >= mb1) return; // wave-uniform
+    pmb_mb(ctx, &LD[wave], mbn, lane, refine);
+    tl_last(ctx, 4);
+}
+
 // I pictures: the padded source luma for the next picture's search (P pictures: me_kernel writes it on its way)
 __global__ __launch_bounds__(256) void copy_luma_kernel(const frame_ctx_t cv) {
     const frame_ctx_t *__restrict__ ctx = &cv;
@@ -770,7 +813,9 @@ void k_launch_imv_to_mbi(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, 
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
     if (row1 > row0) hipLaunchKernelGGL(subpel_kernel, dim3((mbw * (row1 - row0) + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw);
 }
-void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, hipStream_t s) {
-    int n = mbw * (row1 - row0);
-    if (n > 0) hipLaunchKernelGGL(pmb_kernel, dim3((n + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine);
+void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, const unsigned *gate_done, unsigned ref_epoch, unsigned *d_err, hipStream_t s) {
+    const int n = mbw * (row1 - row0), g = (n + 3) / 4;
+    if (n <= 0) return;
+    if (gate_done) hipLaunchKernelGGL(pmb_kernel<true>, dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err);
+    else hipLaunchKernelGGL(pmb_kernel<false>, dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err);
 }

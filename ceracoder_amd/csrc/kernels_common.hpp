@@ -101,6 +101,18 @@ DEV const imv_t *k_final_imv_dev(const frame_ctx_t *ctx) { return (ME_ITERS & 1)
 // wait on a monotonic progress counter (MI355X_MICROARCH.md, "Valid forms": producer stores the data sc1, s_waitcnt vmcnt(0),
 // then stores the counter sc1; consumer polls the counter and reads the data with sc1 loads).
 #define DB_SPIN_MAX (1 << 20)
+// band-done words of the band deblocker (read by the next picture's pmb_kernel): DB_DONE_COPIES copies, DB_DONE_STRIDE words apart
+// (4 KB: different memory channels), each {luma epoch, chroma epoch} per band
+#define DB_DONE_COPIES 16
+#define DB_DONE_STRIDE 1024
+// development builds (-DTL_PROF, tests/devtools/timeline.py): wall-clock marks (100 MHz) per picture epoch, left in ctx->dbrec
+#ifdef TL_PROF
+DEV void tl_first(const frame_ctx_t *ctx, int slot) { if (threadIdx.x == 0) *((volatile unsigned long long *)ctx->dbrec + (ctx->epoch & 63) * 16 + slot) = wall_clock64(); }
+DEV void tl_last(const frame_ctx_t *ctx, int slot) { if (threadIdx.x == 0) atomicMax((unsigned long long *)ctx->dbrec + (ctx->epoch & 63) * 16 + slot, (unsigned long long)wall_clock64()); }
+#else
+#define tl_first(c, s) ((void)0)
+#define tl_last(c, s) ((void)0)
+#endif
 DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV uint2 ld64_sc1(const uint2 *p) { const unsigned long long v = __hip_atomic_load((const GAS unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return make_uint2((unsigned)v, (unsigned)(v >> 32)); }

@@ -37,7 +37,8 @@ static const uint8_t k_lambda[52] = {1,  1,  1,  1,  1,  1,  1,  1,  1,  1,  1, 
                                      2,  2,  3,  3,  3,  4,  4,  4,  5,  6,  6,  7,  8,  9,  10, 11, 13, 14,
                                      16, 18, 20, 23, 25, 29, 32, 36, 40, 45, 51, 57, 64, 72, 81, 91};
 
-#define NSLOT 2
+#define NSLOT 3 /* pictures in flight: pipeline_depth + 1 */
+#define NSET 3  /* device-side sets of what one picture's stages hand to each other (and to the host): one per picture in flight */
 #define SURF_PAD 256 /* bytes past each surface: unaligned-pair loads may touch 4 bytes beyond */
 
 struct slot_t {
@@ -64,10 +65,10 @@ struct mi355enc {
     hipStream_t fstream;                 // "front" stream: source upload / conversion, and for P pictures the whole-sample search, the vector selection
                                          // and the gated intra analysis (source against source: nothing of the previous picture's coding is needed, so
                                          // they run beside its deblocking)
-    frame_ctx_t *d_ctx, *d_ctx2[2];      // one context per picture parity (two pictures are in flight on the device); d_ctx = d_ctx2[0]
+    frame_ctx_t *d_ctx, *d_ctx2[NSET];   // one context per picture in flight; d_ctx = d_ctx2[0]
     slot_t *prev_slot;                   // slot of the picture enqueued last
-    mb_info_t *d_mbi, *d_mbi_set[2];     // two record/level sets: the D2H of picture n overlaps the kernels of n+1
-    int16_t *d_levels, *d_levels_set[2];
+    mb_info_t *d_mbi, *d_mbi_set[NSET];  // record/level sets: the hand-over of picture n overlaps the kernels of n+1 (and n+2)
+    int16_t *d_levels, *d_levels_set[NSET];
     hipStream_t cstream;                 // copy stream for the D2H hand-over
     uint64_t n_submitted;
     uint64_t sc_sum, sc_force_at; int sc_cnt; // scene-cut recovery: summed cost / number of the P pictures since the last IDR; picture to force
@@ -80,12 +81,15 @@ struct mi355enc {
     hipEvent_t ev_dbI[2];  // [reconstruction buffer]: the deblocking of an IDR picture that ran beside its intra wavefront on the intra stream has finished
     int dbI_busy[2];
     unsigned *d_db_par;   // the band deblocker's table of per-edge parameter words (written by its prologue, read by its movers)
+    unsigned *d_db_done;  // per reconstruction buffer: one word per band and plane, = the epoch of the picture whose deblocking of that band is complete
+    uint32_t db_started_total; // workgroups of all band-deblocking launches so far (the device counts them as they are placed: d_progress[1])
+    uint32_t rec_epoch[2]; // ... and the epoch those words carry once the buffer's picture is done (0: no flags for it)
     uint2 *d_db_gran;     // strips between deblocking bands, as epoch-tagged granules (never cleared)
-    unsigned *d_progress; // the sticky error word of the persistent kernels (bounded spins report here)
+    unsigned *d_progress; // [0] the sticky error word of the persistent kernels (bounded spins report here), [1] workgroups of band-deblocking launches placed
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
-    uint16_t *d_surf[2];  // SAD surfaces of the motion search, SURF_U16 per macroblock; two sets (picture parity): the front stages of picture n+1 run beside the back stages of n
-    imv_t *d_imv[2][2];   // whole-sample vector fields (search result / selection iterations alternate), per set
-    uint8_t *d_idec2[2];  // intra decisions per set (d_idec = set 0)
+    uint16_t *d_surf[NSET]; // SAD surfaces of the motion search, SURF_U16 per macroblock; one set per picture in flight: the front stages of picture n+1 (n+2) run beside the back stages of n
+    imv_t *d_imv[NSET][2];   // whole-sample vector fields (search result / selection iterations alternate), per set
+    uint8_t *d_idec2[NSET];  // intra decisions per set (d_idec = set 0)
     uint8_t *d_psrc[2];   // padded source luma of the last two coded pictures: the search runs source against source
     int psrc_cur;         // which of them holds the last coded picture
     unsigned *d_ip_progress; // intra macroblocks of P pictures: one progress word per macroblock row (epoch-tagged, never cleared)
@@ -97,7 +101,7 @@ struct mi355enc {
     int head, tail, pending;
     int cur, have_ref, frames_since_idr, idr_count, last_collected_rec;
     slot_t *last_slot;
-    hipGraphExec_t g_intra[2], g_deblock[2]; // per context
+    hipGraphExec_t g_intra[NSET], g_deblock[NSET]; // per context
     h264_writer_t *writer;
     rc_state_t rc;
     std::atomic<uint32_t> want_bps;
@@ -176,9 +180,10 @@ static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *ban
     return 0;
 }
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
-static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done = nullptr) {
+static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done = nullptr, unsigned *band_done = nullptr) {
     if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
-        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, k_intra_band_rows(), st);
+        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, k_intra_band_rows(), band_done, h->d_progress + 1, st);
+        h->db_started_total += 2u * (unsigned)k_deblock_bands16(h->mbh);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -219,9 +224,10 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
     h->head = h->tail = h->pending = 0;
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
-    h->g_intra[0] = h->g_intra[1] = nullptr; h->g_deblock[0] = h->g_deblock[1] = nullptr; h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_ctx2[0] = h->d_ctx2[1] = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; h->d_surf[0] = h->d_surf[1] = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_idec2[0] = h->d_idec2[1] = nullptr; h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
-    h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->d_mbi_set[0] = h->d_mbi_set[1] = nullptr; h->d_levels_set[0] = h->d_levels_set[1] = nullptr;
+    for (int i = 0; i < NSET; i++) { h->g_intra[i] = h->g_deblock[i] = nullptr; h->d_ctx2[i] = nullptr; h->d_surf[i] = nullptr; h->d_idec2[i] = nullptr; h->d_mbi_set[i] = nullptr; h->d_levels_set[i] = nullptr; }
+    h->prev_slot = nullptr;
+    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; 
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
     h->fixed_qp.store(cfg->fixed_qp);
@@ -229,7 +235,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     *out = h; // from here on close() cleans up partial state
     g_open_encoders.fetch_add(1, std::memory_order_relaxed);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
+    for (int i = 0; i < NSET; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
     h->d_ctx = h->d_ctx2[0];
     { // The hand-over stream gets its own priority level: HIP then backs it with a different hardware queue, so its
       // kernels run beside the persistent deblocking kernel instead of queueing behind it.
@@ -240,7 +246,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, 0));
         HIPCHK(hipEventCreateWithFlags(&h->ev_pmb, hipEventDisableTiming));
     }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NSET; i++) {
         HIPCHK(hipMalloc((void **)&h->d_mbi_set[i], (size_t)h->nmb * sizeof(mb_info_t)));
         HIPCHK(hipMalloc((void **)&h->d_levels_set[i], (size_t)h->nmb * MB_LEVELS * sizeof(int16_t)));
         HIPCHK(hipMemsetAsync(h->d_mbi_set[i], 0, (size_t)h->nmb * sizeof(mb_info_t), h->stream));
@@ -265,16 +271,20 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_iband_done, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned))); // one set per reconstruction buffer: the next picture's wavefront runs beside this one's deblocking
     HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned), h->stream));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_dbI[i], hipEventDisableTiming));
+    HIPCHK(hipMalloc((void **)&h->d_db_done, 2 * k_deblock_done_bytes()));
+    HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream)); // epoch 0 is never used
     HIPCHK(hipMalloc((void **)&h->d_db_gran, k_deblock_gran_bytes(h->mbw, h->mbh)));
     HIPCHK(hipMemsetAsync(h->d_db_gran, 0, k_deblock_gran_bytes(h->mbw, h->mbh), h->stream)); // epoch 0 is never used
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < NSET; k++) {
         HIPCHK(hipMalloc((void **)&h->d_surf[k], (size_t)h->nmb * SURF_U16 * sizeof(uint16_t)));
         for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_imv[k][i], (size_t)h->nmb * sizeof(imv_t)));
+        if (k > 0) HIPCHK(hipMalloc((void **)&h->d_idec2[k], (size_t)h->nmb * IDEC_BYTES + 16));
+    }
+    for (int k = 0; k < 2; k++) {
         HIPCHK(hipMalloc((void **)&h->d_psrc[k], h->ysz + SURF_PAD));
         HIPCHK(hipMemsetAsync(h->d_psrc[k], 0, h->ysz + SURF_PAD, h->stream));
     }
-    HIPCHK(hipMalloc((void **)&h->d_idec2[1], (size_t)h->nmb * IDEC_BYTES + 16));
     HIPCHK(hipMalloc((void **)&h->d_ip_progress, (size_t)h->mbh * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_ip_progress, 0, (size_t)h->mbh * sizeof(unsigned), h->stream)); // epoch-tagged: the epoch starts at 1
     HIPCHK(hipMalloc((void **)&h->d_ip_strips, (size_t)h->nmb * 32));
@@ -320,7 +330,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->istream) (void)hipStreamSynchronize(h->istream);
     if (h->ev_pmb) (void)hipEventDestroy(h->ev_pmb);
-    for (int i = 0; i < 2; i++) { if (h->g_intra[i]) (void)hipGraphExecDestroy(h->g_intra[i]); if (h->g_deblock[i]) (void)hipGraphExecDestroy(h->g_deblock[i]); }
+    for (int i = 0; i < NSET; i++) { if (h->g_intra[i]) (void)hipGraphExecDestroy(h->g_intra[i]); if (h->g_deblock[i]) (void)hipGraphExecDestroy(h->g_deblock[i]); }
     for (int i = 0; i < NSLOT; i++) {
         slot_t *s = &h->slot[i];
         if (s->h_ctx) (void)hipHostFree(s->h_ctx);
@@ -343,21 +353,22 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_idec) (void)hipFree(h->d_idec);
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->d_db_gran) (void)hipFree(h->d_db_gran);
+    if (h->d_db_done) (void)hipFree(h->d_db_done);
     if (h->d_db_par) (void)hipFree(h->d_db_par);
     if (h->d_ib_gran) (void)hipFree(h->d_ib_gran);
     if (h->d_iband_done) (void)hipFree(h->d_iband_done);
     for (int i = 0; i < 2; i++) if (h->ev_dbI[i]) (void)hipEventDestroy(h->ev_dbI[i]);
     if (h->d_off) (void)hipFree(h->d_off);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < NSET; k++) {
         if (h->d_surf[k]) (void)hipFree(h->d_surf[k]);
         for (int i = 0; i < 2; i++) if (h->d_imv[k][i]) (void)hipFree(h->d_imv[k][i]);
-        if (h->d_psrc[k]) (void)hipFree(h->d_psrc[k]);
+        if (k > 0 && h->d_idec2[k]) (void)hipFree(h->d_idec2[k]);
     }
-    if (h->d_idec2[1]) (void)hipFree(h->d_idec2[1]);
+    for (int k = 0; k < 2; k++) if (h->d_psrc[k]) (void)hipFree(h->d_psrc[k]);
     if (h->d_ip_progress) (void)hipFree(h->d_ip_progress);
     if (h->d_ip_strips) (void)hipFree(h->d_ip_strips);
-    for (int i = 0; i < 2; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
-    for (int i = 0; i < 2; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
+    for (int i = 0; i < NSET; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
+    for (int i = 0; i < NSET; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
     if (h->fstream) (void)hipStreamDestroy(h->fstream);
     if (h->istream) (void)hipStreamDestroy(h->istream);
@@ -393,6 +404,9 @@ static int sync_compute(mi355enc_t *h) {
     HIPCHK(hipStreamSynchronize(h->istream));
     return 0;
 }
+// scene-cut recovery: the decision taken with picture k's hand-over lands on picture k + lag, the first one that cannot have been
+// submitted yet (depth 0 behaves as depth 1, so that the stream is the same for both)
+static int sc_lag(const mi355enc_t *h) { return h->cfg.pipeline_depth >= 2 ? h->cfg.pipeline_depth + 1 : 2; }
 static hipStream_t upload_stream(const mi355enc_t *h) { return h->fstream; }
 
 // rate control's ladder below QP 51 (oracle: k_drop_sad): the SAD under which a P macroblock carries no residual / takes the skip vector
@@ -427,8 +441,9 @@ static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof
     return 0;
 }
 // ... and back part (back stream): needs the deblocked picture before it
-static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split) {
-    hipStream_t st = h->stream;
+// gate: the reference picture's band-done words (the fused stage then runs on the intra stream, beside that picture's deblocking)
+static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split, const unsigned *gate, unsigned ref_epoch) {
+    hipStream_t st = gate ? h->istream : h->stream;
     if (prof) HIPCHK(hipEventRecord(s->ev[8], st));
     if (h->cfg.transform8x8) { // High profile: the two-kernel form (absolute-vector refinement, 8x8 transform), no skip / intra logic
         k_launch_imv_to_mbi(hc, h->mbw, 0, h->mbh, st);
@@ -436,9 +451,14 @@ static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof,
         if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
         k_launch_inter(hc, h->mbw, 0, h->mbh, st);
     } else {
-        k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, st);
+        if (gate) k_launch_wait_started(h->d_progress + 1, h->db_started_total, err_word(h), st); // not before the reference's deblocking launch is on the chip
+        k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, gate, ref_epoch, err_word(h), st);
         if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
-        if (split) { // intra_p_kernel leaves the chain: prep + the band deblocker follow the fused stage directly and overtake it row by row
+        if (gate) { // the main stream carries nothing but deblocking launches: this picture's follows its fused stage, and its movers intra_p_kernel
+            HIPCHK(hipEventRecord(h->ev_pmb, st));
+            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pmb, 0));
+            if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
+        } else if (split) { // intra_p_kernel leaves the chain: prep + the band deblocker follow the fused stage directly and overtake it row by row
             HIPCHK(hipEventRecord(h->ev_pmb, st));
             HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0));
             k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->istream);
@@ -454,7 +474,7 @@ static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof,
 static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride,
                            int64_t pts, int force_idr) {
     const int idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop ||
-                    (h->n_submitted == h->sc_force_at && h->prev_slot && !h->prev_slot->is_idr); // scene-cut recovery, see collect()
+                    (h->n_submitted == h->sc_force_at && h->frames_since_idr >= sc_lag(h)); // scene-cut recovery, see collect(): not when an IDR picture came in between
     if (idr) h->frames_since_idr = 0;
     // rate control: latch the setpoint written by the control thread, pick this picture's QP (and, below QP 51, its drop level)
     rc_set_bitrate(&h->rc, h->want_bps.load(std::memory_order_relaxed));
@@ -465,7 +485,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     if (idr && drop == DROP_SKIP) drop = 0; // an IDR picture is never skipped; it has a ladder of its own
     const int all_skip = !idr && drop == DROP_SKIP;
     const int nxt = all_skip ? h->cur : (h->cur ^ 1); // an all-skip picture IS its reference: nothing is written
-    const int set = (int)(h->n_submitted & 1), ci = set;
+    const int set = (int)(h->n_submitted % NSET), ci = set;
     frame_ctx_t *c = s->h_ctx, *dctx = h->d_ctx2[ci];
     // stage timers: an event record costs ~5 us of queue time, so profile_events = k samples every k-th picture (IDR pictures always)
     // (a sampled picture runs its stages strictly in order; IDR pictures: every other one, or at the P pictures' cadence in an all-intra stream)
@@ -499,7 +519,6 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         if (idr) k_launch_copy_luma(c, h->fstream);
         else { int r = run_p_front(h, c, s, prof); if (r) return r; }
         HIPCHK(hipEventRecord(s->ev_front, h->fstream));
-        HIPCHK(hipStreamWaitEvent(h->stream, s->ev_front, 0));
         h->psrc_cur ^= 1;
         // P picture with intra macroblocks: intra_p_kernel (a chain along rows, 10..80 us) and the band deblocker (a chain along
         // x + y) overlap -- intra_p_kernel runs on a stream of its own and the deblocker's movers follow its per-row progress words
@@ -510,6 +529,11 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         // of the same rows (flags + acquire); in an all-intra stream the next picture's wavefront then starts while this one is still
         // being deblocked.  What has to wait for such a deblocking: a P picture (it reads the whole reference), and whoever writes
         // the reconstruction buffer it works on (the picture after next).
+        // P picture whose reference is still being deblocked: the fused stage leaves the chain too.  It runs on the intra stream, each of
+        // its waves waiting for the reference's bands it reads (pmb_kernel<GATED>), so it is all but done when that deblocking ends.
+        const size_t nbd = k_deblock_done_bytes() / sizeof(unsigned); // words per reconstruction buffer
+        const int pgate = !idr && fused && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed() && h->rec_epoch[h->cur] != 0 && !getenv("MI355ENC_NO_PGATE");
+        HIPCHK(hipStreamWaitEvent(pgate ? h->istream : h->stream, s->ev_front, 0));
         const int isplit = idr && h->cfg.intra_mode == 0 && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
         for (int b = 0; b < 2; b++)
             if (h->dbI_busy[b] && (!idr || b == nxt)) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_dbI[b], 0)); h->dbI_busy[b] = 0; }
@@ -519,21 +543,22 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
             int r = run_intra(h, ci, c, isplit ? h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh) : nullptr); if (r) return r;
             if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
         } else {
-            int r = run_p_back(h, c, s, prof, split); if (r) return r;
+            int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur]); if (r) return r;
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(s->gpu_done, split ? h->istream : h->stream)); // records and levels are final here; they do not depend on deblocking
+        HIPCHK(hipEventRecord(s->gpu_done, (split || pgate) ? h->istream : h->stream)); // records and levels are final here; they do not depend on deblocking
         if (h->d_pre_y) {
             HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
             HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
             if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         }
         if (isplit) {
-            int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh)); if (r) return r;
+            int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh), h->d_db_done + (size_t)nxt * nbd); if (r) return r;
             HIPCHK(hipEventRecord(h->ev_dbI[nxt], h->istream));
             h->dbI_busy[nxt] = 1;
-        } else { int r = run_deblock(h, ci, c, h->stream, split ? h->d_ip_progress : nullptr); if (r) return r; }
+        } else { int r = run_deblock(h, ci, c, h->stream, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd); if (r) return r; }
+        h->rec_epoch[nxt] = h->cfg.deblock_mode == 0 ? c->epoch : 0;
         if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
         HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
         // Hand-over on the second stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:
@@ -660,7 +685,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     else if (!s->all_skip) {
         const uint64_t cost = (uint64_t)s->h_hdr[2 + h->mbh] | ((uint64_t)s->h_hdr[3 + h->mbh] << 32);
         const bool pending = h->sc_force_at != ~0ull && h->sc_force_at > s->index; // a decision not yet carried out stands
-        if (h->cfg.scenecut && !pending && h->sc_cnt >= 2 && cost > 3 * (h->sc_sum / (uint64_t)h->sc_cnt)) h->sc_force_at = s->index + 2;
+        if (h->cfg.scenecut && !pending && h->sc_cnt >= 2 && cost > 3 * (h->sc_sum / (uint64_t)h->sc_cnt)) h->sc_force_at = s->index + (uint64_t)sc_lag(h);
         h->sc_sum += cost; h->sc_cnt++;
     }
     if (s->prof) {
@@ -833,7 +858,7 @@ int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_u
     HIPCHK(hipMemsetAsync(h->d_rec_y[1], 0, h->ysz, h->stream)); // macroblocks decided intra stay untouched unless run_intra_p
     HIPCHK(hipMemsetAsync(h->d_rec_uv[1], 0, h->csz, h->stream));
     HIPCHK(hipMemsetAsync(h->d_levels, 0, (size_t)h->nmb * MB_LEVELS * 2, h->stream));
-    k_launch_pmb(c, h->mbw, 0, h->mbh, refine ? 1 : 0, h->stream);
+    k_launch_pmb(c, h->mbw, 0, h->mbh, refine ? 1 : 0, nullptr, 0, err_word(h), h->stream);
     if (idec && run_intra_p) k_launch_intra_p(c, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
     HIPCHK(hipGetLastError());
     return download_picture(h, mbinfo_out, rec_y, rec_uv, levels) ? MI355ENC_ERR_HIP : MI355ENC_OK;
@@ -893,7 +918,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
             else if (stage == 2) { if (++h->epoch == 0) h->epoch = 1; h->slot[0].h_ctx->epoch = h->epoch; int r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r; } // a fresh stamp per launch: the lines between bands are epoch-tagged
             else if (stage == 4) k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 8) k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], h->stream);
-            else if (stage == 9) k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, 1, h->stream);
+            else if (stage == 9) k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, 1, nullptr, 0, err_word(h), h->stream);
             else if (stage == 10) k_launch_intra_p(h->slot[0].h_ctx, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
             else if (stage >= 5) {
                 const int w = h->cfg.width, ht = h->cfg.height, r0 = stage == 5 ? (w + 15) & ~15 : (2 * w + 15) & ~15, r1 = (w / 2 + 15) & ~15;

@@ -99,7 +99,8 @@ void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_pr
 const imv_t *k_final_imv(const frame_ctx_t *h_ctx); /* where the last selection iteration leaves the field */
 void k_launch_imv_to_mbi(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s); // whole-sample field -> records, for the two-kernel (8x8 transform) path
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
-void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, hipStream_t s); // fused refinement + inter (4x4 transform)
+// gate_done (may be null): the reference picture's band deblocker may still be running; a wave waits until the band that holds macroblock row r + 2 carries ref_epoch
+void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, const unsigned *gate_done, unsigned ref_epoch, unsigned *d_err, hipStream_t s); // fused refinement + inter (4x4 transform)
 void k_launch_inter(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 void k_launch_intra_analyse(const frame_ctx_t *h_ctx, int mbw, int mbh, int gate_p, hipStream_t s); /* gate_p: P picture -- only macroblocks whose search cost reaches INTRA_GATE */
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
@@ -109,10 +110,14 @@ int k_deblock_bands16(int mbh);
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the band kernel follows its per-row progress words
 // d_iband_done (may be null; all-intra pictures): the intra band kernel of the same picture is still running; a band waits for its flags
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
-                            const unsigned *d_iband_done, int ib_rows /* rows per intra band */, hipStream_t s);
+                            const unsigned *d_iband_done, int ib_rows /* rows per intra band */,
+                            unsigned *d_band_done /* may be null: DB_DONE_COPIES x {luma, chroma} per band = the picture's epoch once the band is final in memory */,
+                            unsigned *d_started /* may be null: counts the workgroups placed */, hipStream_t s);
 int k_intra_band_rows(void);
 size_t k_deblock_partab_bytes(int mbw, int mbh); // scratch of the band kernel: one parameter word per (edge, segment) of every macroblock
-size_t k_deblock_gran_bytes(int mbw, int mbh); // the strips between bands: 8-byte {samples, epoch} granules
+size_t k_deblock_gran_bytes(int mbw, int mbh);
+void k_launch_wait_started(const unsigned *d_started, unsigned count, unsigned *d_err, hipStream_t s);
+size_t k_deblock_done_bytes(void); /* band-done words of one picture (all copies) */ // the strips between bands: 8-byte {samples, epoch} granules
 void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int W, int H, hipStream_t s);
 int k_intra_diags(int mbw, int mbh);
 int k_intra_bands(int mbh);

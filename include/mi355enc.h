@@ -50,7 +50,10 @@ typedef struct {
     int fixed_qp;             /* >= 0: constant QP, rate control off (tests, bench); -1: CBR */
     int qp_min, qp_max;       /* rate-control clamp; 0,0 -> defaults 10..51                */
     int pipeline_depth;       /* 0: encode() returns this frame's AU; 1: host entropy coding
-                                 of frame n overlaps device work of frame n+1             */
+                                 of frame n overlaps device work of frame n+1; 2: ... and the
+                                 device never waits for the host (three pictures in flight; rate
+                                 control sees a picture's size two pictures later, scene-cut
+                                 recovery lands one picture later than at depth 0/1)       */
     int profile_events;       /* k > 0: bracket the kernel stages of every k-th picture (and every IDR) with HIP events
                                  for the stage statistics; an event record costs ~5 us of queue time, so k = 1 slows
                                  the stream by several per cent */

@@ -1674,7 +1674,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
 struct orc_enc {
     int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads, subpel;
     int frames_since_idr, idr_count, have_ref;
-    int scenecut, sc_cnt, prev_idr;                      /* scene-cut recovery: mirrors mi355enc.cpp (collect / enqueue_picture) */
+    int scenecut, sc_cnt, prev_idr, sc_lag;                      /* scene-cut recovery: mirrors mi355enc.cpp (collect / enqueue_picture) */
     unsigned long long sc_sum, sc_force_at, pic_index;
     uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv, *prev_src_y;
     int prev_src_valid;
@@ -1698,7 +1698,7 @@ orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop
     e->width = width; e->height = height;
     e->mbw = (width + 15) / 16; e->mbh = (height + 15) / 16; e->stride = e->mbw * 16;
     e->fps_num = fps_num; e->fps_den = fps_den; e->gop = gop; e->me_range = me_range; e->threads = threads; e->subpel = 1;
-    e->scenecut = 1; e->sc_force_at = ~0ull; e->last_qp = 26;
+    e->scenecut = 1; e->sc_lag = 2; e->sc_force_at = ~0ull; e->last_qp = 26;
     size_t ysz = (size_t)e->stride * e->mbh * 16, csz = ysz / 2, nmb = (size_t)e->mbw * e->mbh;
     e->src_y = (uint8_t *)malloc(ysz); e->src_uv = (uint8_t *)malloc(csz);
     e->pre_y = (uint8_t *)malloc(ysz); e->pre_uv = (uint8_t *)malloc(csz); e->prev_src_y = (uint8_t *)malloc(ysz);
@@ -1745,7 +1745,7 @@ static void load_padded(orc_enc_t *e, const uint8_t *y, int ys, const uint8_t *u
 int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
                    int qp, int drop, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len, int *is_idr) {
     if (!e || qp < 0 || qp > 51 || drop < 0 || (drop > ORC_DROP_MAX && drop != ORC_DROP_SKIP)) return -1;
-    int idr = force_idr || !e->have_ref || e->frames_since_idr >= e->gop || (e->pic_index == e->sc_force_at && !e->prev_idr);
+    int idr = force_idr || !e->have_ref || e->frames_since_idr >= e->gop || (e->pic_index == e->sc_force_at && e->frames_since_idr >= e->sc_lag);
     if (idr) { e->frames_since_idr = 0; }
     const int nmb = e->mbw * e->mbh;
     const int all_skip = !idr && drop == ORC_DROP_SKIP;
@@ -1811,7 +1811,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
         unsigned long long cost = 0;
         for (int i = 0; i < nmb; i++) cost += e->mbi[i].cost;
         const int pending = e->sc_force_at != ~0ull && e->sc_force_at > e->pic_index;
-        if (e->scenecut && !pending && e->sc_cnt >= 2 && cost > 3 * (e->sc_sum / (unsigned long long)e->sc_cnt)) e->sc_force_at = e->pic_index + 2;
+        if (e->scenecut && !pending && e->sc_cnt >= 2 && cost > 3 * (e->sc_sum / (unsigned long long)e->sc_cnt)) e->sc_force_at = e->pic_index + (unsigned long long)e->sc_lag;
         e->sc_sum += cost; e->sc_cnt++;
     }
     if (!all_skip) { memcpy(e->prev_src_y, e->src_y, ysz); e->prev_src_valid = 1; }
@@ -1828,6 +1828,7 @@ int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *u
 }
 void orc_enc_set_subpel(orc_enc_t *e, int on) { e->subpel = on; }
 void orc_enc_set_scenecut(orc_enc_t *e, int on) { e->scenecut = on; }
+void orc_enc_set_sc_lag(orc_enc_t *e, int lag) { e->sc_lag = lag < 2 ? 2 : lag; } /* mi355enc.cpp sc_lag(): pipeline_depth + 1 from depth 2 on */
 void orc_enc_set_me_iters(orc_enc_t *e, int n) { e->me_iters = n < 0 ? 0 : n; }
 const uint8_t *orc_enc_recon_y(const orc_enc_t *e) { return e->rec_y[e->cur]; }
 const uint8_t *orc_enc_recon_uv(const orc_enc_t *e) { return e->rec_uv[e->cur]; }

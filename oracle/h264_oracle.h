@@ -130,6 +130,7 @@ orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop
 void orc_enc_close(orc_enc_t *e);
 void orc_enc_set_subpel(orc_enc_t *e, int on);
 void orc_enc_set_scenecut(orc_enc_t *e, int on); /* default on */
+void orc_enc_set_sc_lag(orc_enc_t *e, int lag);  /* scene-cut recovery lands on picture k + lag (default 2; the device: pipeline_depth + 1 from depth 2 on) */
 void orc_enc_set_me_iters(orc_enc_t *e, int n);  /* orc_me_select iterations after the first selection (default ORC_ME_ITERS) */
 #define ORC_ME_ITERS 3
 /* Encode one NV12 frame at a caller-chosen QP.  Returns 0, or <0 on error. */

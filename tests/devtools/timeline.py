@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""dev tool: device-side timeline of the P-picture stages in a free-running stream (no profiler in the way of the host).  Library built
+with tools/build_tlprof.sh (wall-clock marks per picture epoch in ctx->dbrec):
+    MI355ENC_LIB=ceracoder_amd/variants/libmi355enc_TL.so python tests/devtools/timeline.py [depth] [pictures]"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from ceracoder_amd import enc as E, synth
+E.LIB_PATH = os.environ.get("MI355ENC_LIB", E.LIB_PATH)
+depth = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+w, h = 1920, 1080
+clip = list(synth.s2_frames(w, h, 16))
+bufs = [torch.from_numpy(np.concatenate([y.reshape(-1), uv.reshape(-1)])).cuda() for y, uv in clip]
+torch.cuda.synchronize()
+e = E.Encoder(w, h, fps=60, gop=600, bitrate_bps=6_000_000, pipeline_depth=depth)
+for i in range(n):
+    k = i % 30
+    p = bufs[k if k < 16 else 30 - k].data_ptr()
+    e.submit_device(p, w, p + w * h, w, pts=i)
+    if e.pending > depth:
+        e.collect(copy=False)
+while e.pending:
+    e.collect(copy=False)
+buf = np.zeros((e.mbw * e.mbh, 8), np.uint64)
+assert e.L.mi355enc_fetch(e.h, 100, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+t = buf.reshape(-1)[:64 * 16].reshape(64, 16).astype(np.int64)
+rows = sorted((r for r in t if r[7] > 0 and r[0] > 0), key=lambda r: r[7])[-40:]
+names = ["me0", "me1", "pmb0", "gate", "pmb1", "ip0", "ip1", "db0", "db1"]
+print("per picture, us relative to the start of its deblocking (100 MHz clock): " + " ".join("%7s" % x for x in names) + "   db0 - previous db1 | period")
+prev = None
+for r in rows:
+    us = [(int(r[k]) - int(r[7])) / 100.0 for k in range(9)]
+    gap = (int(r[7]) - int(prev[8])) / 100.0 if prev is not None else float("nan")
+    per = (int(r[7]) - int(prev[7])) / 100.0 if prev is not None else float("nan")
+    print(" " * 73 + " ".join("%7.1f" % x for x in us) + "   %7.1f | %7.1f" % (gap, per))
+    prev = r
+e.close()
