@@ -156,7 +156,7 @@ def main():
     ap.add_argument("--no-gst-latency", action="store_true", help="skip the live GStreamer latency probe (M2)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--fixed-qp", type=int, default=-1)
-    ap.add_argument("--depth", type=int, default=1)
+    ap.add_argument("--depth", type=int, default=2, help="pipeline_depth: pictures in flight - 1 (2: the device never waits for the host)")
     ap.add_argument("--deblock-mode", type=int, default=0)
     ap.add_argument("--sample", type=int, default=29, help="stage timers (HIP events) on every k-th picture (and every IDR): a sampled picture costs ~12 event records of ~5 us queue time each and runs its stages strictly in order (no deblocking beside the intra macroblocks of a P picture)")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent streams encoded concurrently on each GPU (one host thread each); the headline configuration is 1")

@@ -384,7 +384,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
             for (int ib = r_lo / a.ib_rows; ib <= r_hi / a.ib_rows; ib++)
                 while (ld_sc1(a.iband_done + ib) != tag) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; } // bounded; the host reports the picture as failed
+                    if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 11u); break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { break; } // bounded; the host reports the picture as failed
                 }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -595,7 +595,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                         do {
                             __builtin_amdgcn_s_sleep(1);
                             g2 = ld64_sc1(gran_up + (size_t)x * ring_n + gj);
-                            if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; } // bounded; once tripped, nobody waits again
+                            if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 12u); break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { break; } // bounded; once tripped, nobody waits again
                         } while (__ballot(glane && g2.y != epoch));
                         if (glane) *dst = g2.x;
                     }
@@ -612,7 +612,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                             const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_sc1(a.ip_progress + my));
                             if ((v & ~0xFFFu) == tag && (int)(v & 0xFFFu) > xl) { fin = (int)(v & 0xFFFu); break; }
                             __builtin_amdgcn_s_sleep(2);
-                            if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); fin = 0x7FFF; break; } // bounded; once tripped, nobody waits again
+                            if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 13u); fin = 0x7FFF; break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { fin = 0x7FFF; break; } // bounded; once tripped, nobody waits again
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     }

@@ -680,7 +680,7 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
                 do {
                     __builtin_amdgcn_s_sleep(1);
                     if (mine) gpre = ld64_sc1(gran_up + (size_t)(x - (lane == 24 ? 1 : 0)) * 8 + (lane == 24 ? 3 : lane - 25));
-                    if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 1u); break; }
+                    if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 14u); break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { break; }
                 } while (__ballot(mine && gpre.y != tag));
             }
             if (lane >= 24 && lane < 29) stage[role][lane - 24] = mine ? gpre.x : 0u;
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(128) void intra_p_kernel(ip_args a) {
                         const unsigned v = ld_sc1(&a.progress[my - 1]);
                         if ((v & ~0xFFFu) == ep && (int)(v & 0xFFFu) > mx) break;
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(a.err))) { st_sc1(a.err, 2u); sh_bad = 1; break; }
+                        if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 15u); sh_bad = 1; break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { sh_bad = 1; break; }
                     }
                 }
             }

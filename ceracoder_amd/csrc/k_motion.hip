@@ -734,7 +734,8 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
 // stages ran in order this launch is early by a whole picture).  A band of the deblocker needs three waves of 112 VGPRs on each SIMD
 // of one CU; four workgroups of this kernel on a CU (4 x 56 VGPRs per SIMD) leave no room for it, and a chip full of waiting
 // workgroups leaves none anywhere (seen: every band timed out).  So a gated launch follows wait_started_kernel (k_deblock.hip) on its
-// stream: by the time the first workgroup of this kernel is placed, every workgroup of the reference's deblocking launch is.  The
+// stream: by the time the first workgroup of this kernel is placed, every workgroup of the reference's deblocking launch is (nothing
+// else that launch waits for can be outstanding: the reference's fused stage and intra_p_kernel are earlier on this stream).  The
 // deblocker's bands finish within the last third of its run (they advance along x together), and that is when this launch, whole
 // and resident, takes its macroblocks row by row behind them.
 template <bool GATED>

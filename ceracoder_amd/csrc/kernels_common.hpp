@@ -121,7 +121,7 @@ DEV int db_wait_get(unsigned *progress, unsigned *err, int need) {
     int spins = 0, v;
     while ((v = (int)ld_sc1(progress)) < need) {
         __builtin_amdgcn_s_sleep(2);
-        if (++spins > DB_SPIN_MAX || ((spins & 1023) == 0 && ld_sc1(err))) { st_sc1(err, 1u); return 0x7FFFFFFF; } // bounded; once tripped, nobody waits again
+        if (++spins > DB_SPIN_MAX) { st_sc1(err, 16u); return 0x7FFFFFFF; } if ((spins & 1023) == 0 && ld_sc1(err)) { return 0x7FFFFFFF; } // bounded; once tripped, nobody waits again
     }
     return v;
 }

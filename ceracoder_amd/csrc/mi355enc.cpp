@@ -661,7 +661,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     double t1 = now_ms();
     h->st.ms_wait += t1 - t0;
     if (s->h_hdr[1]) { // sticky: set by a band of an earlier picture's deblocking launch that gave up waiting
-        fprintf(stderr, "mi355enc: deblocking wavefront timed out waiting for a neighbouring band (device error word %u)\n", s->h_hdr[1]);
+        fprintf(stderr, "mi355enc: a device-side wait timed out (error word %u: 3 pmb_kernel gate, 4 wait_started_kernel, 11 deblocker / intra bands, 12 deblocker / strips, 13 deblocker / intra_p_kernel, 14 intra band / strips, 15 intra_p_kernel / row above, 16 progress counter)\n", s->h_hdr[1]);
         return MI355ENC_ERR_HIP;
     }
     size_t n = 0;
