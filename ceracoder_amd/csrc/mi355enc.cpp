@@ -71,7 +71,7 @@ struct mi355enc {
     int16_t *d_levels, *d_levels_set[NSET];
     hipStream_t cstream;                 // copy stream for the D2H hand-over
     uint64_t n_submitted;
-    uint64_t sc_sum, sc_force_at; int sc_cnt; // scene-cut recovery: summed cost / number of the P pictures since the last IDR; picture to force
+    uint64_t sc_sum, sc_force_at; int sc_cnt, sc_prev_skip; // scene-cut recovery: summed cost / number of the P pictures since the last IDR; picture to force
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
     uint8_t *d_dbrec;     // deblocking records, 64 B per macroblock
     uint8_t *d_idec;      // intra decisions, IDEC_BYTES per macroblock
@@ -252,7 +252,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMemsetAsync(h->d_mbi_set[i], 0, (size_t)h->nmb * sizeof(mb_info_t), h->stream));
     }
     h->d_mbi = h->d_mbi_set[0]; h->d_levels = h->d_levels_set[0]; h->n_submitted = 0;
-    h->sc_sum = 0; h->sc_cnt = 0; h->sc_force_at = ~0ull;
+    h->sc_sum = 0; h->sc_cnt = 0; h->sc_prev_skip = 0; h->sc_force_at = ~0ull;
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&h->d_rec_y[i], h->ysz + SURF_PAD));
         HIPCHK(hipMalloc((void **)&h->d_rec_uv[i], h->csz + SURF_PAD));
@@ -682,12 +682,13 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     // the pipeline depth, and is skipped there if picture index + 1 turned out to be an IDR: the stream does not depend on
     // the order of submit() and collect() calls.
     if (s->is_idr) { h->sc_sum = 0; h->sc_cnt = 0; }
-    else if (!s->all_skip) {
+    else if (!s->all_skip && !h->sc_prev_skip) { // (a picture that follows P_Skip-run pictures is searched against an older source: its cost says nothing about a cut)
         const uint64_t cost = (uint64_t)s->h_hdr[2 + h->mbh] | ((uint64_t)s->h_hdr[3 + h->mbh] << 32);
         const bool pending = h->sc_force_at != ~0ull && h->sc_force_at > s->index; // a decision not yet carried out stands
         if (h->cfg.scenecut && !pending && h->sc_cnt >= 2 && cost > 3 * (h->sc_sum / (uint64_t)h->sc_cnt)) h->sc_force_at = s->index + (uint64_t)sc_lag(h);
         h->sc_sum += cost; h->sc_cnt++;
     }
+    h->sc_prev_skip = s->all_skip;
     if (s->prof) {
         float a = 0, b = 0, c = 0, tot = 0, sp = 0;
         {

@@ -1674,7 +1674,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
 struct orc_enc {
     int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads, subpel;
     int frames_since_idr, idr_count, have_ref;
-    int scenecut, sc_cnt, prev_idr, sc_lag;                      /* scene-cut recovery: mirrors mi355enc.cpp (collect / enqueue_picture) */
+    int scenecut, sc_cnt, prev_idr, sc_lag, prev_all_skip;                      /* scene-cut recovery: mirrors mi355enc.cpp (collect / enqueue_picture) */
     unsigned long long sc_sum, sc_force_at, pic_index;
     uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv, *prev_src_y;
     int prev_src_valid;
@@ -1807,7 +1807,8 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
     *out_len = n + s;
     if (is_idr) *is_idr = idr;
     if (idr) { e->idr_count++; e->sc_sum = 0; e->sc_cnt = 0; }
-    else if (!all_skip) { /* summed macroblock cost of this P picture against the mean of the P pictures since the last IDR */
+    else if (!all_skip && !e->prev_all_skip) { /* summed macroblock cost of this P picture against the mean of the P pictures since the last IDR
+                                                  (not of a picture that follows P_Skip-run pictures: it was searched against an older source) */
         unsigned long long cost = 0;
         for (int i = 0; i < nmb; i++) cost += e->mbi[i].cost;
         const int pending = e->sc_force_at != ~0ull && e->sc_force_at > e->pic_index;
@@ -1817,7 +1818,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
     if (!all_skip) { memcpy(e->prev_src_y, e->src_y, ysz); e->prev_src_valid = 1; }
     memcpy(e->prev_mbi, e->mbi, (size_t)nmb * sizeof(orc_mbinfo_t));
     e->prev_is_p = !idr;
-    e->prev_idr = idr; e->pic_index++;
+    e->prev_idr = idr; e->prev_all_skip = all_skip; e->pic_index++;
     e->frames_since_idr++;
     e->cur = nxt; e->have_ref = 1; e->last_qp = qp;
     return 0;
