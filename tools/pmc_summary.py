@@ -45,6 +45,10 @@ for k in sorted(set(F) | set(W)):
     calls = tot = 0
     for name, line in trace.items():  # template instantiations of one kernel are merged (weighted by calls)
         if short(line["Name"]) == k:
+            if "pmb_kernelILb1E" in line["Name"]:  # ... except the one whose workgroups wait for another kernel's flags: its duration is not work
+                e["gated_instantiation"] = {"calls": int(line["Calls"]), "avg_us": round(float(line["TotalDurationNs"]) / int(line["Calls"]) / 1e3, 3),
+                                            "note": "pmb_kernel<GATED>: runs beside the reference picture's deblocking launch and waits per workgroup for the band it reads; the launch duration includes that wait"}
+                continue
             calls += int(line["Calls"]); tot += float(line["TotalDurationNs"])
     if calls:
         e["kernel_trace_avg_us"] = round(tot / calls / 1e3, 3)
