@@ -107,3 +107,26 @@ def test_scene_cut_recovery_rule(oracle):
             dy, duv = dec.decode(au)
             assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv)
         assert idrs == want, (sc, idrs)
+
+
+def test_scene_cut_recovery_lag_and_skip_runs(oracle):
+    """orc_enc_set_sc_lag(3) (what the device does with three pictures in flight): the IDR picture lands one picture later.  And a
+    picture that follows P_Skip-run pictures is searched against an older source: its cost neither triggers a cut nor enters
+    the mean -- a cadence of coded and skipped pictures (rate control below the ladder) must not force IDR pictures."""
+    from tests.util import cut_clip
+    from ceracoder_amd import synth
+    w, h = 176, 144
+    clip = cut_clip(w, h, 12, 5)
+    oe = oracle.Encoder(w, h, gop=30, threads=4, sc_lag=3)
+    idrs = [i for i, (y, uv) in enumerate(clip) if oe.encode(y, uv, 30)[1]]
+    assert idrs == [0, 8], idrs
+    fr = list(synth.s2_frames(w, h, 24))
+    for skip_runs, want in ((True, [0]), (False, None)):
+        oe = oracle.Encoder(w, h, gop=60, threads=4)
+        idrs = []
+        for i, (y, uv) in enumerate(fr):
+            drop = oracle.DROP_SKIP if (skip_runs and i > 3 and i % 4 != 0) else 0   # every fourth picture coded, the others P_Skip runs
+            if oe.encode(y, uv, 30, drop=drop)[1]:
+                idrs.append(i)
+        if want is not None:
+            assert idrs == want, idrs

@@ -387,6 +387,36 @@ def test_pipelined_submit_collect_equals_sync(E, oracle, depth):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 40), (3840, 2160, 14)])
+def test_three_pictures_in_flight_equal_one_at_a_time(E, w, h, n):
+    """Full-size pictures, fixed QP, scene-cut recovery off (its landing picture depends on the depth): with pipeline_depth 2 every P
+    picture's fused stage runs beside the deblocking of the picture before it, workgroup by workgroup behind that launch's bands, and
+    three pictures share the device; with depth 0 every picture is alone on it.  Same access units, same reconstruction -- including
+    across forced IDR pictures and straight after them."""
+    from ceracoder_amd import synth
+    clip = list(synth.s2_frames(w, h, 8))
+    force = {9, 10, 23}
+    streams = []
+    for depth in (0, 2):
+        e = E.Encoder(w, h, gop=16, fixed_qp=30, pipeline_depth=depth, scenecut=False)
+        got = []
+        for i in range(n):
+            k = i % 14
+            y, uv = clip[k if k < 8 else 14 - k]
+            e.submit(y, uv, pts=i, force_idr=i in force)
+            if e.pending > depth:
+                got.append(e.collect())
+        while e.pending:
+            got.append(e.collect())
+        streams.append(([g[0] for g in got], [g[1] for g in got], e.fetch(E.FETCH_RECON_Y), e.fetch(E.FETCH_RECON_UV)))
+        e.close()
+    a, b = streams
+    assert a[1] == b[1] and sum(a[1]) >= 3
+    for i, (x, y) in enumerate(zip(a[0], b[0])):
+        assert x == y, ("access unit", i, len(x), len(y))
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
 @pytest.mark.parametrize("depth", [0, 1, 2])
 def test_scene_cut_recovery_equals_oracle(E, oracle, depth):
     """cfg.scenecut: after a hard cut (picture 5) the picture two positions later is coded as IDR, identically to the oracle
