@@ -147,6 +147,7 @@ static unsigned *err_word(const mi355enc_t *h) { return h->d_progress; }
 // serialise dispatches (rocprofv3 --pmc) run one kernel at a time.  So: only with a single open encoder in the process, and not when
 // MI355ENC_SERIAL is set (tools/measure_all.sh sets it for the counter passes).  Every wait is bounded and reported anyway.
 static std::atomic<int> g_open_encoders{0};
+static bool no_pgate() { static const bool off = getenv("MI355ENC_NO_PGATE") != nullptr; return off; } // A/B switch: the fused P stage in stream order behind the deblocking launch
 static bool overlap_allowed() { static const bool serial = getenv("MI355ENC_SERIAL") != nullptr; return !serial && g_open_encoders.load(std::memory_order_relaxed) == 1; }
 
 static void launch_intra_all(mi355enc_t *h, int ci) {
@@ -532,7 +533,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         // P picture whose reference is still being deblocked: the fused stage leaves the chain too.  It runs on the intra stream, each of
         // its waves waiting for the reference's bands it reads (pmb_kernel<GATED>), so it is all but done when that deblocking ends.
         const size_t nbd = k_deblock_done_bytes() / sizeof(unsigned); // words per reconstruction buffer
-        const int pgate = !idr && fused && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed() && h->rec_epoch[h->cur] != 0 && !getenv("MI355ENC_NO_PGATE");
+        const int pgate = !idr && fused && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed() && h->rec_epoch[h->cur] != 0 && !no_pgate();
         HIPCHK(hipStreamWaitEvent(pgate ? h->istream : h->stream, s->ev_front, 0));
         const int isplit = idr && h->cfg.intra_mode == 0 && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
         for (int b = 0; b < 2; b++)
