@@ -52,6 +52,20 @@ def test_open_rejects_bad_geometry():
         assert not hnd.value
 
 
+def test_open_takes_up_to_three_pictures_in_flight():
+    """pipeline_depth 0..2 pass the argument check (what comes back then depends on whether a device is there); 3 does not."""
+    L = E.load()
+    for depth, ok in ((0, True), (2, True), (3, False), (-1, False)):
+        cfg = E.Cfg()
+        L.mi355enc_default_cfg(C.byref(cfg), 320, 192, 30, 1)
+        cfg.pipeline_depth = depth
+        hnd = C.c_void_p()
+        r = L.mi355enc_open(C.byref(cfg), C.byref(hnd))
+        assert (r != -1) == ok, (depth, r)
+        if hnd.value:
+            L.mi355enc_close(hnd)
+
+
 @pytest.mark.skipif(_has_gpu(), reason="only meaningful where no HIP device exists")
 def test_no_device_fails_loudly_no_cpu_fallback():
     with pytest.raises(E.EncoderError, match="no usable HIP device"):
@@ -217,11 +231,11 @@ def test_rate_control_plans_idr_pictures_inside_the_vbv():
     assert worst < 0.6 * bps, worst
 
 
-@pytest.mark.parametrize("delay", [0, 1])
+@pytest.mark.parametrize("delay", [0, 1, 2])
 def test_rate_control_emergency_drop_lands_within_a_few_pictures(delay):
     """the balancer's emergency drops (/root/reference/src/core/bitrate_control.c:176-199 cut the
     setpoint towards min_bitrate in one 20 ms tick) must show in the stream within a few pictures, not a GOP.
-    delay=1 models pipeline_depth=1, where picture n is coded before the size of picture n-1 is known."""
+    delay=1 models pipeline_depth=1, where picture n is coded before the size of picture n-1 is known; delay=2 three pictures in flight."""
     fps, gop = 60, 60
     rc = E.RateControl(fps, gop, 6_000_000)
     rng = np.random.default_rng(5)
