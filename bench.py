@@ -209,6 +209,8 @@ def main():
                 cur = b
         return cur
 
+    if args.sample > 0:  # a short run (the driver's --steps 20) still gets at least four sampled pictures inside the timed region
+        args.sample = max(1, min(args.sample, args.steps // 4 if args.steps >= 4 else 1))
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                          pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
