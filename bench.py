@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--fixed-qp", type=int, default=-1)
     ap.add_argument("--depth", type=int, default=2, help="pipeline_depth: pictures in flight - 1 (2: the device never waits for the host)")
     ap.add_argument("--deblock-mode", type=int, default=0)
+    ap.add_argument("--shared-gpu", action="store_true", help="other processes encode on the same GPU: do not set exclusive_device (include/mi355enc.h); the default is the metric's one stream per GPU")
     ap.add_argument("--sample", type=int, default=29, help="stage timers (HIP events) on every k-th picture (and every IDR): a sampled picture costs ~12 event records of ~5 us queue time each and runs its stages strictly in order (no deblocking beside the intra macroblocks of a P picture)")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent streams encoded concurrently on each GPU (one host thread each); the headline configuration is 1")
     ap.add_argument("--cavlc-threads", type=int, default=0, help="host threads coding one slice row-parallel (bit-identical output); 0 = the encoder's default (automatic, at most 8)")
@@ -214,7 +215,7 @@ def main():
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                          pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                         transform8x8=bool(args.dct8x8), cavlc_threads=args.cavlc_threads)
+                         transform8x8=bool(args.dct8x8), cavlc_threads=args.cavlc_threads, exclusive=(S == 1 and not args.shared_gpu))
 
     encs = [make_encoder() for _ in range(S)]
     e = encs[0]
@@ -396,7 +397,7 @@ def main():
                        "cbr, setpoint driven by the reference's '%s' balancer script (%d..%d kbit/s, tests/golden/balancer_%s.txt)" % (
                            script_name, min(b for _, b in script) // 1000, max(b for _, b in script) // 1000, script_name),
                        "me": "full search +-16 integer-pel SAD (surfaces kept) + %d median-regularised selection iterations + half-sample SAD / quarter-sample SATD refinement" % 3, "streams_per_gpu": S, "parallelism": "%d independent streams" % (world * S),
-                       "pipeline_depth": args.depth, "dct8x8": bool(args.dct8x8), "cavlc_threads": int(st.cavlc_threads)},
+                       "pipeline_depth": args.depth, "exclusive_device": bool(S == 1 and not args.shared_gpu), "dct8x8": bool(args.dct8x8), "cavlc_threads": int(st.cavlc_threads)},
             "roofline": roof,
             "roofline_kernels": kernels,
             "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "me_select_x3": round(st.ms_select / max(1, st.n_me), 4),

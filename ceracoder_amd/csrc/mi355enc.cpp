@@ -137,7 +137,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0;
 }
 
 static unsigned *err_word(const mi355enc_t *h) { return h->d_progress; }
@@ -147,6 +147,7 @@ static unsigned *err_word(const mi355enc_t *h) { return h->d_progress; }
 // serialise dispatches (rocprofv3 --pmc) run one kernel at a time.  So: only with a single open encoder in the process, and not when
 // MI355ENC_SERIAL is set (tools/measure_all.sh sets it for the counter passes).  Every wait is bounded and reported anyway.
 static std::atomic<int> g_open_encoders{0};
+static bool exclusive_device(const mi355enc_t *h) { static const bool env = getenv("MI355ENC_EXCLUSIVE") != nullptr; return h->cfg.exclusive_device != 0 || env; } // cfg.exclusive_device, or the environment for tools
 static bool no_pgate() { static const bool off = getenv("MI355ENC_NO_PGATE") != nullptr; return off; } // A/B switch: the fused P stage in stream order behind the deblocking launch
 static bool overlap_allowed() { static const bool serial = getenv("MI355ENC_SERIAL") != nullptr; return !serial && g_open_encoders.load(std::memory_order_relaxed) == 1; }
 
@@ -533,7 +534,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         // P picture whose reference is still being deblocked: the fused stage leaves the chain too.  It runs on the intra stream, each of
         // its waves waiting for the reference's bands it reads (pmb_kernel<GATED>), so it is all but done when that deblocking ends.
         const size_t nbd = k_deblock_done_bytes() / sizeof(unsigned); // words per reconstruction buffer
-        const int pgate = !idr && fused && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed() && h->rec_epoch[h->cur] != 0 && !no_pgate();
+        const int pgate = !idr && fused && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed() && h->rec_epoch[h->cur] != 0 && exclusive_device(h) && !no_pgate();
         HIPCHK(hipStreamWaitEvent(pgate ? h->istream : h->stream, s->ev_front, 0));
         const int isplit = idr && h->cfg.intra_mode == 0 && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
         for (int b = 0; b < 2; b++)

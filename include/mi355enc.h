@@ -80,6 +80,12 @@ typedef struct {
                                  positions later is coded as IDR -- recovery within two pictures instead of a GOP, with no wait
                                  on the device (the sum arrives with the picture's hand-over).  0: IDR only every `gop`
                                  pictures or on request */
+    int exclusive_device;     /* 0 (default): other processes may use the same GPU.  1: this encoder has the GPU to itself (one
+                                 stream per GPU, BASELINE configs[4]; what bench.py sets): a P picture's fused stage is launched
+                                 beside the deblocking of the picture before it and its workgroups wait ON the device for the
+                                 bands they read -- a chip full of waiting workgroups.  With another process on the same GPU
+                                 such launches can keep each other's kernels off the chip (seen: one of two processes ran into
+                                 the bound of its wait), so it is opt-in.  Same stream either way */
 } mi355enc_cfg_t;
 
 typedef struct {

@@ -14,7 +14,7 @@ half = [(np.concatenate([s2[0][0][:544], f[0][544:]]), np.concatenate([s2[0][1][
 scenes = [("moving", [s2[i % 24] for i in range(70)]), ("still", [s2[5]] * 45), ("half still", [half[i % 24] for i in range(58)]),
           ("noise", [s3[i % 6] for i in range(22)]), ("moving again", [s2[(3 * i) % 24] for i in range(70)])]
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-e = E.Encoder(w, h, fps=60, gop=60, bitrate_bps=8_000_000, pipeline_depth=depth)
+e = E.Encoder(w, h, fps=60, gop=60, bitrate_bps=8_000_000, pipeline_depth=depth, exclusive=depth == 2)
 dec = O.Decoder()
 t0, n, keys, pend = time.time(), 0, [], []
 def take():

@@ -13,7 +13,7 @@ w, h = 1920, 1080
 clip = list(synth.s2_frames(w, h, 16))
 bufs = [torch.from_numpy(np.concatenate([y.reshape(-1), uv.reshape(-1)])).cuda() for y, uv in clip]
 torch.cuda.synchronize()
-e = E.Encoder(w, h, fps=60, gop=600, bitrate_bps=6_000_000, pipeline_depth=depth)
+e = E.Encoder(w, h, fps=60, gop=600, bitrate_bps=6_000_000, pipeline_depth=depth, exclusive=True)
 for i in range(n):
     k = i % 30
     p = bufs[k if k < 16 else 30 - k].data_ptr()

@@ -373,7 +373,7 @@ def test_pipelined_submit_collect_equals_sync(E, oracle, depth):
     w, h, n = 320, 192, 11
     fr = frames(w, h, n)
     a = E.Encoder(w, h, gop=5, fixed_qp=29)
-    b = E.Encoder(w, h, gop=5, fixed_qp=29, pipeline_depth=depth)
+    b = E.Encoder(w, h, gop=5, fixed_qp=29, pipeline_depth=depth, exclusive=True)
     sync = [a.encode(y, uv)[0] for _, _, y, uv in fr]
     piped = []
     for i, (_, _, y, uv) in enumerate(fr):
@@ -391,14 +391,14 @@ def test_pipelined_submit_collect_equals_sync(E, oracle, depth):
 def test_three_pictures_in_flight_equal_one_at_a_time(E, w, h, n):
     """Full-size pictures, fixed QP, scene-cut recovery off (its landing picture depends on the depth): with pipeline_depth 2 every P
     picture's fused stage runs beside the deblocking of the picture before it, workgroup by workgroup behind that launch's bands, and
-    three pictures share the device; with depth 0 every picture is alone on it.  Same access units, same reconstruction -- including
+    three pictures share the device (`exclusive`: the encoder has the GPU to itself, which is what allows kernels to wait for each other on it); with depth 0 every picture is alone on it.  Same access units, same reconstruction -- including
     across forced IDR pictures and straight after them."""
     from ceracoder_amd import synth
     clip = list(synth.s2_frames(w, h, 8))
     force = {9, 10, 23}
     streams = []
     for depth in (0, 2):
-        e = E.Encoder(w, h, gop=16, fixed_qp=30, pipeline_depth=depth, scenecut=False)
+        e = E.Encoder(w, h, gop=16, fixed_qp=30, pipeline_depth=depth, scenecut=False, exclusive=depth == 2)
         got = []
         for i in range(n):
             k = i % 14
@@ -425,7 +425,7 @@ def test_scene_cut_recovery_equals_oracle(E, oracle, depth):
     from tests.util import cut_clip
     w, h, n = 320, 192, 12
     clip = cut_clip(w, h, n, 5)
-    e = E.Encoder(w, h, gop=30, fixed_qp=30, pipeline_depth=depth)
+    e = E.Encoder(w, h, gop=30, fixed_qp=30, pipeline_depth=depth, exclusive=depth == 2)
     oe = oracle.Encoder(w, h, gop=30, threads=8, sc_lag=max(2, depth + 1))
     got = []
     for i, (y, uv) in enumerate(clip):
@@ -453,7 +453,7 @@ def test_idle_deblocking_bands_equal_oracle(E, oracle, w, h, static_lines, depth
     above them straight from the picture.  Streams and reconstructions must still equal the oracle's, picture by picture."""
     from tests.util import half_static_clip
     clip = half_static_clip(w, h, 7, static_lines)
-    e = E.Encoder(w, h, gop=30, fixed_qp=38, pipeline_depth=depth)
+    e = E.Encoder(w, h, gop=30, fixed_qp=38, pipeline_depth=depth, exclusive=depth == 2)
     oe = oracle.Encoder(w, h, gop=30, threads=8)
     got = []
     for i, (y, uv) in enumerate(clip):
@@ -494,7 +494,7 @@ def test_rate_control_emergency_drop_on_the_device(E, depth):
     """N3: a 4x cut of the setpoint between two key frames shows in the access-unit sizes within a few pictures
     (pipeline_depth 1 adds one picture of feedback delay)."""
     w, h, fps, gop = 640, 368, 30, 60
-    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=2_400_000, pipeline_depth=depth)
+    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=2_400_000, pipeline_depth=depth, exclusive=depth == 2)
     sizes, drop_at = [], 75
     fr = frames(w, h, 120)
     for i, (_, _, y, uv) in enumerate(fr):

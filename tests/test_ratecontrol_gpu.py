@@ -16,7 +16,7 @@ STEPS = [6_000_000, 300_000, 1_000_000, 1_500_000, 20_000_000, 30_000_000, 6_000
 
 
 def run_steps(E, w, h, fps, gop, clip, steps, gops_per_step=2, depth=1):
-    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=steps[0], pipeline_depth=depth)
+    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=steps[0], pipeline_depth=depth, exclusive=depth == 2)
     sizes, drops, qps = [], [], []
     n = len(steps) * gops_per_step * gop
     for i in range(n):

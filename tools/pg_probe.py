@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from ceracoder_amd import enc as E, synth
 def trial(w, h, depth, sample, n=200, gop=60, dev=True):
     clip = list(synth.s2_frames(w, h, 8))
-    e = E.Encoder(w, h, fps=60, gop=gop, bitrate_bps=6_000_000, pipeline_depth=depth, profile_events=sample)
+    e = E.Encoder(w, h, fps=60, gop=gop, bitrate_bps=6_000_000, pipeline_depth=depth, profile_events=sample, exclusive=True)
     bufs = [torch.from_numpy(np.concatenate([y.reshape(-1), uv.reshape(-1)])).cuda() for y, uv in clip]
     torch.cuda.synchronize()
     try:

@@ -4,7 +4,7 @@ from ceracoder_amd import enc as E, synth
 w, h, fps, gop = 3840, 2160, 60, 60
 clip = list(synth.s2_frames(w, h, 8))
 depth = int(sys.argv[1])
-e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=20_000_000, pipeline_depth=depth)
+e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=20_000_000, pipeline_depth=depth, exclusive=depth == 2)
 out = []
 for i in range(4 * gop):
     k = i % (2 * len(clip) - 2)

@@ -8,7 +8,7 @@ from tests.test_ratecontrol_gpu import STEPS
 w, h, fps, gop = 1920, 1080, 60, 60
 clip = list(synth.s2_frames(w, h, 16))
 def run(depth, steps, gops_per_step=2):
-    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=steps[0], pipeline_depth=depth)
+    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=steps[0], pipeline_depth=depth, exclusive=depth == 2)
     out = []
     n = len(steps) * gops_per_step * gop
     for i in range(n):
