@@ -55,7 +55,7 @@ def test_golden_balancer_scripts_regenerate_identically():
 def test_plugin_registers_with_expected_properties():
     out = subprocess.run(["/opt/conda/bin/gst-inspect-1.0", "mi355h264enc"], env=gst_env(), capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    for needle in ("bps ", "bitrate ", "key-int-max", "device-id", "speed-preset", "video/x-h264", "byte-stream", "NV12"):
+    for needle in ("bps ", "bitrate ", "key-int-max", "device-id", "speed-preset", "pipeline-depth", "exclusive-gpu", "video/x-h264", "byte-stream", "NV12"):
         assert needle in out.stdout, needle
 
 
