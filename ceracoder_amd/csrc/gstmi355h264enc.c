@@ -43,6 +43,7 @@ typedef struct {
     guint bps;          /* bit/s */
     guint key_int_max;
     gint device_id, me_range, qp, pipeline_depth, speed_preset;
+    gint open_depth;  /* pipeline-depth the encoder was opened with: a write to the property in mid-stream takes effect at the next (re)negotiation */
     gboolean stats, dct8x8;
     gint threads;
     gboolean scenecut, exclusive_gpu;
@@ -189,6 +190,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     }
     GST_OBJECT_LOCK(s);
     s->enc = e;
+    s->open_depth = cfg.pipeline_depth;
     mi355enc_set_bitrate(e, s->bps); /* a write that raced with open() must not be lost */
     GST_OBJECT_UNLOCK(s);
     s->max_au = mi355enc_max_au_bytes(e);
@@ -278,7 +280,7 @@ static GstFlowReturn enc_handle_frame(GstVideoEncoder *ve, GstVideoCodecFrame *f
         return GST_FLOW_ERROR;
     }
     GstFlowReturn fr = GST_FLOW_OK;
-    if (mi355enc_pending(s->enc) > s->pipeline_depth) {
+    if (mi355enc_pending(s->enc) > s->open_depth) {
         GstVideoCodecFrame *old = gst_video_encoder_get_oldest_frame(ve);
         if (old) fr = collect_into(s, old); /* finish_frame() consumes the reference */
     }

@@ -140,7 +140,7 @@ def test_reference_x264_line_with_only_the_factory_token_changed_runs_at_the_wri
 
 @pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
 @pytest.mark.parametrize("fixup", [False, True])
-@pytest.mark.parametrize("depth", [0, 1])
+@pytest.mark.parametrize("depth", [0, 1, 2])
 def test_damaged_timestamps_leave_monotone_with_dts_equal_pts(tmp_path, oracle, fixup, depth):
     """upstream of the encoder the reference rewrites PTS, zeroes DTS and flags early pictures DROPPABLE
     (ceracoder.c:371-423).  With timestamps damaged the way a capture device damages them (jitter, repeats, a picture two
@@ -149,7 +149,7 @@ def test_damaged_timestamps_leave_monotone_with_dts_equal_pts(tmp_path, oracle, 
     pf = tmp_path / "pipe"
     pf.write_text("videotestsrc num-buffers=120 pattern=ball ! video/x-raw,width=320,height=192,framerate=30/1,format=NV12 ! "
                   "identity name=jitter signal-handoffs=TRUE ! " + ("identity name=ptsfixup signal-handoffs=TRUE ! " if fixup else "") +
-                  "queue ! mi355h264enc key-int-max=30 pipeline-depth=%d name=venc_bps ! appsink name=appsink sync=false\n" % depth)
+                  "queue ! mi355h264enc key-int-max=30 pipeline-depth=%d exclusive-gpu=%s name=venc_bps ! appsink name=appsink sync=false\n" % (depth, "true" if depth == 2 else "false"))
     out = tmp_path / "out.bin"
     r = subprocess.run([HARNESS, str(pf), str(out)], env=gst_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
