@@ -346,7 +346,7 @@ DEV unsigned par_word(unsigned nib, unsigned ab, unsigned tcw) { return nib | (a
 
 // GATED: intra_p_kernel of the same picture may still be running (on another stream).  Its progress word of a macroblock row
 // says how many leading macroblocks of the row are final (it stores their samples sc1 and drains before it publishes); the
-// mover loads macroblock x only below that mark, and takes an acquire fence whenever it has read a new mark (a 128-byte line
+// mover loads macroblock x only when x + 1 is below that mark as well (or the row is complete), and takes an acquire fence whenever it has read a new mark (a 128-byte line
 // holds eight macroblocks of a line: an earlier load may have cached bytes that were not final yet).  That is all the
 // ordering there is to keep: intra prediction reads the line above and the column to the left of a macroblock from the
 // picture, and this kernel writes a macroblock's lines 0..11 once its row is three macroblocks further, its bottom lines
@@ -605,12 +605,16 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                 DBT_TICK(1);
                 {
                     const int xg = x + 2, xgc = xg < 0 ? 0 : (xg < mbw ? xg : mbw - 1), xlc = xl < 0 ? 0 : (xl < mbw ? xl : mbw - 1);
-                    if (GATED && row_ok && xl >= 0 && xl < mbw && xl >= fin) {
+                    // macroblock xl may be loaded (and, a step later, filtered) once it AND its right neighbour are final: filtering xl's horizontal
+                    // edges changes its right column, and its top edge the sample above that column's top -- the left column and the corner an intra
+                    // macroblock at xl + 1 predicts from.  (The first form of the test was `> xl`: safe only as long as intra_p_kernel has a head start.)
+                    const int need = xl + 2 < mbw ? xl + 2 : mbw;
+                    if (GATED && row_ok && xl >= 0 && xl < mbw && fin < need) {
                         const unsigned tag = (epoch & 0xFFFFFu) << 12; // IP_EPOCH of k_intra.hip
                         int spins = 0;
                         for (;;) {
                             const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_sc1(a.ip_progress + my));
-                            if ((v & ~0xFFFu) == tag && (int)(v & 0xFFFu) > xl) { fin = (int)(v & 0xFFFu); break; }
+                            if ((v & ~0xFFFu) == tag && (int)(v & 0xFFFu) >= need) { fin = (int)(v & 0xFFFu); break; }
                             __builtin_amdgcn_s_sleep(2);
                             if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 13u); fin = 0x7FFF; break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { fin = 0x7FFF; break; } // bounded; once tripped, nobody waits again
                         }

@@ -387,7 +387,7 @@ def test_pipelined_submit_collect_equals_sync(E, oracle, depth):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("w,h,n", [(1920, 1080, 40), (3840, 2160, 14)])
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 90), (3840, 2160, 14)])
 def test_three_pictures_in_flight_equal_one_at_a_time(E, w, h, n):
     """Full-size pictures, fixed QP, scene-cut recovery off (its landing picture depends on the depth): with pipeline_depth 2 every P
     picture's fused stage runs beside the deblocking of the picture before it, workgroup by workgroup behind that launch's bands, and
@@ -395,7 +395,7 @@ def test_three_pictures_in_flight_equal_one_at_a_time(E, w, h, n):
     across forced IDR pictures and straight after them."""
     from ceracoder_amd import synth
     clip = list(synth.s2_frames(w, h, 8))
-    force = {9, 10, 23}
+    force = {9, 10, 23, 61}
     streams = []
     for depth in (0, 2):
         e = E.Encoder(w, h, gop=16, fixed_qp=30, pipeline_depth=depth, scenecut=False, exclusive=depth == 2)
