@@ -727,8 +727,9 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
 // GATED: the reference picture's band deblocker may still be running (this launch then sits on the intra stream, beside the
 // reference's deblocking).  Macroblock row r reads reference lines up to 16 (r + 2) + 3 (whole-sample vectors of +-16, three more for
 // the six-tap filter and the quarter sample; chroma likewise inside row r + 2), all of which the deblocker's row r + 2 stores, or
-// the row below it in the same band or the next -- so a workgroup waits until the band that holds row r + 2 carries the reference's
-// epoch for both planes and then takes an acquire fence: the deblocker's workgroups sit on other XCDs.  Nothing below a band a wave has acquired is ever read, so no stale line can enter this XCD's L2 ahead of the
+// the row below it in the same band or the next; upwards it reads from line 16 (r - 2) + 13 on.  So a workgroup waits until every band
+// from the one that holds row r - 2 to the one that holds row r + 2 carries the reference's epoch for both planes, and then takes an
+// acquire fence: the deblocker's workgroups sit on other XCDs.  Nothing below a band a wave has acquired is ever read, so no stale line can enter this XCD's L2 ahead of the
 // fence.
 // Waiting workgroups must never keep the kernel they wait for from being placed (it may not have started yet: after a picture whose
 // stages ran in order this launch is early by a whole picture).  A band of the deblocker needs three waves of 112 VGPRs on each SIMD
@@ -745,17 +746,23 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     const int mbn = mb0 + 4 * (int)blockIdx.x + wave;
     if (mb0 == 0 && blockIdx.x == 0) tl_first(ctx, 2);
-    if (GATED) { // wave 0 waits for the band the workgroup's last macroblock needs, the others for wave 0
+    if (GATED) { // wave 0 waits for the bands the workgroup's macroblocks read, the others for wave 0
         if (wave == 0) {
+            // EVERY band the window touches, not only the lowest: a band's word says that ITS lines are in memory -- the band above it has
+            // filtered further (its strips were needed), but may not have written its own lines back yet, and a band that had no strips
+            // to wait for can be done long before the one above it.  (Waiting for the lowest band alone gave streams that differed from
+            // the in-order path in one macroblock every few hundred pictures.)
             const int mbw = ctx->mbw, mbh = ctx->mbh;
-            const int last = mb0 + 4 * (int)blockIdx.x + 3 < mb1 ? mb0 + 4 * (int)blockIdx.x + 3 : mb1 - 1;
-            int rr = last / mbw + 2;
-            rr = rr < mbh ? rr : mbh - 1;
-            const uint2 *flag = (const uint2 *)(gate_done + DB_DONE_STRIDE * (blockIdx.x & (DB_DONE_COPIES - 1))) + rr / MI355_BAND_ROWS;
-            int spins = 0;
+            const int first = mb0 + 4 * (int)blockIdx.x, last = first + 3 < mb1 ? first + 3 : mb1 - 1;
+            int r_lo = first / mbw - 2, r_hi = last / mbw + 2;
+            r_lo = r_lo > 0 ? r_lo : 0;
+            r_hi = r_hi < mbh ? r_hi : mbh - 1;
+            const uint2 *flags = (const uint2 *)(gate_done + DB_DONE_STRIDE * (blockIdx.x & (DB_DONE_COPIES - 1)));
+            int spins = 0, b = r_lo / MI355_BAND_ROWS;
+            const int b_hi = r_hi / MI355_BAND_ROWS;
             for (;;) {
-                const uint2 f = ld64_sc1(flag);
-                if (f.x == ref_epoch && f.y == ref_epoch) break;
+                const uint2 f = ld64_sc1(flags + b);
+                if (f.x == ref_epoch && f.y == ref_epoch) { if (++b > b_hi) break; continue; }
                 __builtin_amdgcn_s_sleep(64);
                 if (++spins > DB_SPIN_MAX) { st_sc1(err, 3u); break; }
                 if ((spins & 255) == 0 && ld_sc1(err)) break; // somebody else gave up: nobody waits again // bounded; the host reports the picture as failed
