@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; unsigned *band_done; unsigned *started; }; // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; unsigned *band_done; unsigned *started; const unsigned *row_done; unsigned row_need; }; // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -371,6 +371,26 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     // still part of a live picture -- leaves at once: its samples are final as they are, and its neighbours take its strips
     // straight from the picture.  (The movers used to derive the words from the 64-byte record, ~50 instructions per macroblock on
     // the SIMD whose issue rate sets the band's pace.)
+    if (!ALL_INTRA && a.row_done) {
+        // The fused P stage of the same picture may still be running (pmb_kernel<GATED>, on another stream; this launch sits directly behind
+        // the previous picture's): it stores samples and records through to memory and then counts each macroblock for its row.  This
+        // band reads the records of its own rows and of the two neighbouring bands' (their work flags), and the samples of its own: it
+        // starts when those rows are complete -- the counts only grow, a.row_need is what they reach with this picture.
+        if (threadIdx.x < 64) {
+            const int r = (band - 1) * ROWS + (int)threadIdx.x;
+            const bool mine = (int)threadIdx.x < 3 * ROWS && r >= 0 && r < mbh;
+            const unsigned *w = a.row_done + (mine ? r : 0);
+            int spins = 0;
+            while (__ballot(mine && (int)(ld_sc1(w) - a.row_need) < 0)) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 17u); break; } // bounded; the host reports the picture as failed
+                if ((spins & 1023) == 0 && ld_sc1(a.err)) break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
     if (ALL_INTRA && a.iband_done) {
         // The intra band kernel of the same picture may still be running (on another stream): this band's macroblocks -- and the row
         // above them, whose records the boundary strengths read and whose bottom lines this band's top edge changes -- are complete
@@ -394,7 +414,9 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     constexpr int PARW = CHROMA ? 16 : 32;                                  // parameter words per macroblock
     unsigned *partab = a.partab + (CHROMA ? (size_t)nb * ROWS * mbw * 32 : 0) + (size_t)band * ROWS * mbw * PARW;
     unsigned *flagw = (unsigned *)(lds + ROWS * ROW_LDS);   // [3]: band - 1, band, band + 1
+    unsigned *firsti = flagw + 4;                           // [ROWS] (GATED): the first intra macroblock of each row of this band
     if (threadIdx.x < 3) flagw[threadIdx.x] = 0;
+    if (GATED && threadIdx.x < ROWS) firsti[threadIdx.x] = (unsigned)mbw;
     __syncthreads();
     {
         const dev_tables *T = &g_tab;
@@ -404,6 +426,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
             if (row < mbh) {
                 unsigned w[16], pw[PARW];
                 const bool work = db_record(ctx, T, j % mbw, row, w);
+                if (GATED && (ldg32(&ctx->mbi[(size_t)row * mbw + j % mbw].mb_type) & 255u) != 1u) atomicMin(&firsti[j / mbw], (unsigned)(j % mbw));
 #pragma unroll
                 for (int d = 0; d < 2; d++)
 #pragma unroll
@@ -564,7 +587,9 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     } else if (role == 1) {
         // `cur` is the load set of this step's parity (two macroblock loads are in flight: the loop is unrolled by two so that
         // both sets are plain registers -- a set chosen by `t & 1` lives in scratch, and its load gets waited for at once)
-        int fin = GATED ? 0 : 0x7FFF; // macroblocks of this row known to be final
+        // macroblocks of this row known to be final: everything left of the row's first intra macroblock is (the fused stage wrote it; what
+        // intra_p_kernel publishes first says the same, but that kernel may not have started yet)
+        int fin = GATED ? (int)firsti[r] : 0x7FFF;
         auto mstep = [&](const int t, uint4 &cur, uint2 &gpre) __attribute__((always_inline)) {
             DBT_T0();
             const int x = t - 1 - r;
@@ -703,7 +728,7 @@ size_t k_deblock_gran_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the movers follow its per-row progress words.
 template <typename K>
 static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStream_t s) {
-    const size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + 16;
+    const size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + 16 + 4 * DB_ROWS;
     static size_t granted = 48 * 1024; // above 64 KB of dynamic LDS the kernel has to be told (4K pictures: 80 KB; the device has 160 KB per CU)
     if (lds > granted) { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
     hipLaunchKernelGGL(kernel, dim3(2 * nbands), dim3(192 * DB_ROWS), lds, s, a);
@@ -724,9 +749,9 @@ void k_launch_wait_started(const unsigned *d_started, unsigned count, unsigned *
 size_t k_deblock_done_bytes(void) { return (size_t)DB_DONE_COPIES * DB_DONE_STRIDE * sizeof(unsigned); } // 2 words per band: up to 512 bands
 size_t k_deblock_partab_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * DB_ROWS * mbw * 48 * sizeof(unsigned); } // 32 luma + 16 chroma words per macroblock
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
-                            const unsigned *d_iband_done, int ib_rows, unsigned *d_band_done, unsigned *d_started, hipStream_t s) {
+                            const unsigned *d_iband_done, int ib_rows, unsigned *d_band_done, unsigned *d_started, const unsigned *d_row_done, unsigned row_need, hipStream_t s) {
     db_args a;
-    a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab; a.iband_done = d_iband_done; a.ib_rows = ib_rows > 0 ? ib_rows : DB_ROWS; a.band_done = d_band_done; a.started = d_started;
+    a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab; a.iband_done = d_iband_done; a.ib_rows = ib_rows > 0 ? ib_rows : DB_ROWS; a.band_done = d_band_done; a.started = d_started; a.row_done = d_row_done; a.row_need = row_need;
     if (band1 <= band0) return;
     if (h_ctx->all_intra) launch_bands(deblock_rows3_kernel<DB_ROWS, true, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
     else if (d_ip_progress) launch_bands(deblock_rows3_kernel<DB_ROWS, false, true>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel

@@ -523,21 +523,24 @@ DEV unsigned pmb_satd(int lane, unsigned curw, unsigned pw) {
     return (unsigned)wave64_sum(acc);
 }
 // write a macroblock that carries no residual: the prediction is the reconstruction, every level is zero
+template <bool SC1>
 DEV void pmb_store_pred_only(const frame_ctx_t *__restrict__ ctx, int16_t *lv, int lane, int x0, int y0, unsigned pw, const int *pd) {
     const int stride = ctx->stride, pr = lane >> 2, pc = (lane & 3) * 4;
-    stg32(ctx->rec_y + (size_t)(y0 + pr) * stride + x0 + pc, pw);
+    stx32<SC1>(ctx->rec_y + (size_t)(y0 + pr) * stride + x0 + pc, pw);
     const int py = (lane >> 2) & 3, cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1;
     const unsigned mine = pack4(pd[0], pd[1], pd[2], pd[3]), other = (unsigned)quad_xor<2>((int)mine);
     if (lane < 32 && c == 0) {
         uint2 out;
         out.x = __builtin_amdgcn_perm(other, mine, 0x05010400u); // U0 V0 U1 V1
         out.y = __builtin_amdgcn_perm(other, mine, 0x07030602u); // U2 V2 U3 V3
-        stg64(ctx->rec_uv + (size_t)((y0 >> 1) + cby * 4 + py) * stride + 2 * ((x0 >> 1) + cbx * 4), out);
+        stx64<SC1>(ctx->rec_uv + (size_t)((y0 >> 1) + cby * 4 + py) * stride + 2 * ((x0 >> 1) + cbx * 4), out);
     }
     if (lane < MB_LEVELS * 2 / 16) stg128(lv + 8 * lane, make_uint4(0, 0, 0, 0)); // 816 bytes = 51 x 16
 }
 
 // One P macroblock on one wave (no workgroup barrier anywhere: the four waves of a workgroup are independent).
+// SC1: the reconstruction and the record are stored through to memory -- the picture's own deblocking launch reads them without a kernel boundary in between.
+template <bool SC1>
 DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, const int lane, const int refine) {
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = ctx->qp, lambda = ctx->lambda;
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
@@ -582,16 +585,16 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
                 int lev[4], x[4];
                 if (pmb_luma_tq(T, lane, curw, pw, qp, true, lev, x) == 0) {
                     unsigned nz_c = 0, dc_c = 0;
-                    chroma_rows4(ctx, T, lv, x0 >> 1, y0 >> 1, lane, pd, sv, qp, false, false, nullptr, nz_c, dc_c, true);
+                    chroma_rows4(ctx, T, lv, x0 >> 1, y0 >> 1, lane, pd, sv, qp, false, false, nullptr, nz_c, dc_c, true, 0, SC1);
                     pass = (nz_c | dc_c) == 0;
                 }
             }
             if (pass) {
-                pmb_store_pred_only(ctx, lv, lane, x0, y0, pw, pd);
+                pmb_store_pred_only<SC1>(ctx, lv, lane, x0, y0, pw, pd);
                 if (lane == 0) {
                     mb_info_t m;
                     m.mvx = (int16_t)fp.sx; m.mvy = (int16_t)fp.sy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = di;
-                    st_mbinfo(mb, m);
+                    st_mbinfo_x<SC1>(mb, m);
                 }
                 return;
             }
@@ -677,7 +680,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
                 mb_info_t m;
                 m.mvx = 0; m.mvy = 0; m.mb_type = i4 ? 2 : 0; m.i16_mode = i4 ? 0 : (uint8_t)(dw.x & 255u); m.chroma_mode = (uint8_t)((dw.x >> 8) & 255u);
                 m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = dw.y;
-                st_mbinfo(mb, m);
+                st_mbinfo_x<SC1>(mb, m);
             }
             return;
         }
@@ -686,11 +689,11 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
     int pd[4];
     chroma_pred4(ctx, lane, x0, y0, W, H, bqx, bqy, pd);
     if (ctx->drop_sad && dsad < ctx->drop_sad) { // rate control's ladder below QP 51: prediction only
-        pmb_store_pred_only(ctx, lv, lane, x0, y0, pw, pd);
+        pmb_store_pred_only<SC1>(ctx, lv, lane, x0, y0, pw, pd);
         if (lane == 0) {
             mb_info_t m;
             m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = di;
-            st_mbinfo(mb, m);
+            st_mbinfo_x<SC1>(mb, m);
         }
         return;
     }
@@ -708,17 +711,17 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
         int o[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) o[i] = clip255(byte_of(pw, i) + ((inv_col(x[i], cb) + 32) >> 6));
-        stg32(ctx->rec_y + (size_t)(y0 + pr) * stride + x0 + pc, pack4(o[0], o[1], o[2], o[3]));
+        stx32<SC1>(ctx->rec_y + (size_t)(y0 + pr) * stride + x0 + pc, pack4(o[0], o[1], o[2], o[3]));
     }
     unsigned nz_c = 0, dc_c = 0;
-    chroma_rows4(ctx, T, lv, x0 >> 1, y0 >> 1, lane, pd, sv, qp, false, true, nullptr, nz_c, dc_c, true);
+    chroma_rows4(ctx, T, lv, x0 >> 1, y0 >> 1, lane, pd, sv, qp, false, true, nullptr, nz_c, dc_c, true, 0, SC1);
     if (lane == 0) {
         unsigned nzm = nz_luma | (nz_c << 16);
         if (dc_c & 1) nzm |= NZ_CBDC;
         if (dc_c & 2) nzm |= NZ_CRDC;
         mb_info_t m;
         m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = nzm; m.cost = di;
-        st_mbinfo(mb, m);
+        st_mbinfo_x<SC1>(mb, m);
     }
     if (lane < 2) stg128(lv + L_LDC + 8 * lane, make_uint4(0, 0, 0, 0)); // luma DC levels: unused by P macroblocks, kept zero
 }
@@ -740,7 +743,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
 // deblocker's bands finish within the last third of its run (they advance along x together), and that is when this launch, whole
 // and resident, takes its macroblocks row by row behind them.
 template <bool GATED>
-__global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine, const unsigned *__restrict__ gate_done, unsigned ref_epoch, unsigned *err) {
+__global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine, const unsigned *__restrict__ gate_done, unsigned ref_epoch, unsigned *err, unsigned *row_done) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
@@ -773,7 +776,11 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
         tl_last(ctx, 3);
     }
     if (mbn >= mb1) return; // wave-uniform
-    pmb_mb(ctx, &LD[wave], mbn, lane, refine);
+    pmb_mb<GATED>(ctx, &LD[wave], mbn, lane, refine);
+    if (GATED) { // this macroblock's samples and record are in memory: count it for its row (the picture's deblocking launch, already on the chip, waits for whole rows)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(row_done + mbn / ctx->mbw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     tl_last(ctx, 4);
 }
 
@@ -821,9 +828,9 @@ void k_launch_imv_to_mbi(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, 
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
     if (row1 > row0) hipLaunchKernelGGL(subpel_kernel, dim3((mbw * (row1 - row0) + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw);
 }
-void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, const unsigned *gate_done, unsigned ref_epoch, unsigned *d_err, hipStream_t s) {
+void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, const unsigned *gate_done, unsigned ref_epoch, unsigned *d_err, unsigned *d_row_done, hipStream_t s) {
     const int n = mbw * (row1 - row0), g = (n + 3) / 4;
     if (n <= 0) return;
-    if (gate_done) hipLaunchKernelGGL(pmb_kernel<true>, dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err);
-    else hipLaunchKernelGGL(pmb_kernel<false>, dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err);
+    if (gate_done) hipLaunchKernelGGL(pmb_kernel<true>, dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
+    else hipLaunchKernelGGL(pmb_kernel<false>, dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
 }

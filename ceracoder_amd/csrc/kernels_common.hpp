@@ -117,6 +117,14 @@ DEV unsigned ld_sc1(const unsigned *p) { return __hip_atomic_load((const GAS uns
 DEV void st_sc1(unsigned *p, unsigned v) { __hip_atomic_store((GAS unsigned *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEV uint2 ld64_sc1(const uint2 *p) { const unsigned long long v = __hip_atomic_load((const GAS unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return make_uint2((unsigned)v, (unsigned)(v >> 32)); }
 DEV void st64_sc1(uint2 *p, uint2 v) { __hip_atomic_store((GAS unsigned long long *)p, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a store the consumer may read while this kernel still runs (SC1), or an ordinary one
+template <bool SC1> DEV void stx32(void *p, unsigned v) { if (SC1) st_sc1((unsigned *)p, v); else stg32(p, v); }
+template <bool SC1> DEV void stx64(void *p, uint2 v) { if (SC1) st64_sc1((uint2 *)p, v); else stg64(p, v); }
+template <bool SC1> DEV void st_mbinfo_x(mb_info_t *p, const mb_info_t &m) {
+    if (!SC1) { st_mbinfo(p, m); return; }
+    st64_sc1((uint2 *)p, make_uint2(((unsigned)(uint16_t)m.mvx) | ((unsigned)(uint16_t)m.mvy << 16), (unsigned)m.mb_type | ((unsigned)m.i16_mode << 8) | ((unsigned)m.chroma_mode << 16) | ((unsigned)m.qp << 24)));
+    st64_sc1((uint2 *)p + 1, make_uint2(m.nzmask, m.cost));
+}
 DEV int db_wait_get(unsigned *progress, unsigned *err, int need) {
     int spins = 0, v;
     while ((v = (int)ld_sc1(progress)) < need) {

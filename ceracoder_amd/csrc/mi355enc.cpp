@@ -82,6 +82,8 @@ struct mi355enc {
     int dbI_busy[2];
     unsigned *d_db_par;   // the band deblocker's table of per-edge parameter words (written by its prologue, read by its movers)
     unsigned *d_db_done;  // per reconstruction buffer: one word per band and plane, = the epoch of the picture whose deblocking of that band is complete
+    unsigned *d_row_done;      // per macroblock row: macroblocks the gated P-stage launches have completed so far (the picture's deblocking launch waits for its rows)
+    uint32_t pmb_rows_total;   // ... and what each of those counts reaches with the last gated launch enqueued
     uint32_t db_started_total; // workgroups of all band-deblocking launches so far (the device counts them as they are placed: d_progress[1])
     uint32_t rec_epoch[2]; // ... and the epoch those words carry once the buffer's picture is done (0: no flags for it)
     uint2 *d_db_gran;     // strips between deblocking bands, as epoch-tagged granules (never cleared)
@@ -182,9 +184,9 @@ static int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *ban
     return 0;
 }
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
-static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done = nullptr, unsigned *band_done = nullptr) {
+static int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done = nullptr, unsigned *band_done = nullptr, bool after_gated_pmb = false) {
     if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
-        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, k_intra_band_rows(), band_done, h->d_progress + 1, st);
+        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, k_intra_band_rows(), band_done, h->d_progress + 1, after_gated_pmb ? h->d_row_done : nullptr, h->pmb_rows_total, st);
         h->db_started_total += 2u * (unsigned)k_deblock_bands16(h->mbh);
         HIPCHK(hipGetLastError());
         return 0;
@@ -228,7 +230,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     for (int i = 0; i < NSET; i++) { h->g_intra[i] = h->g_deblock[i] = nullptr; h->d_ctx2[i] = nullptr; h->d_surf[i] = nullptr; h->d_idec2[i] = nullptr; h->d_mbi_set[i] = nullptr; h->d_levels_set[i] = nullptr; }
     h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->d_row_done = nullptr; h->pmb_rows_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; 
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -273,6 +275,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_iband_done, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned))); // one set per reconstruction buffer: the next picture's wavefront runs beside this one's deblocking
     HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned), h->stream));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_dbI[i], hipEventDisableTiming));
+    HIPCHK(hipMalloc((void **)&h->d_row_done, (size_t)h->mbh * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * sizeof(unsigned), h->stream));
     HIPCHK(hipMalloc((void **)&h->d_db_done, 2 * k_deblock_done_bytes()));
     HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream)); // epoch 0 is never used
     HIPCHK(hipMalloc((void **)&h->d_db_gran, k_deblock_gran_bytes(h->mbw, h->mbh)));
@@ -356,6 +360,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_progress) (void)hipFree(h->d_progress);
     if (h->d_db_gran) (void)hipFree(h->d_db_gran);
     if (h->d_db_done) (void)hipFree(h->d_db_done);
+    if (h->d_row_done) (void)hipFree(h->d_row_done);
     if (h->d_db_par) (void)hipFree(h->d_db_par);
     if (h->d_ib_gran) (void)hipFree(h->d_ib_gran);
     if (h->d_iband_done) (void)hipFree(h->d_iband_done);
@@ -454,11 +459,10 @@ static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof,
         k_launch_inter(hc, h->mbw, 0, h->mbh, st);
     } else {
         if (gate) k_launch_wait_started(h->d_progress + 1, h->db_started_total, err_word(h), st); // not before the reference's deblocking launch is on the chip
-        k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, gate, ref_epoch, err_word(h), st);
+        k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, gate, ref_epoch, err_word(h), h->d_row_done, st);
         if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
-        if (gate) { // the main stream carries nothing but deblocking launches: this picture's follows its fused stage, and its movers intra_p_kernel
-            HIPCHK(hipEventRecord(h->ev_pmb, st));
-            HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pmb, 0));
+        if (gate) { // the main stream carries nothing but deblocking launches, back to back: this picture's bands wait on the device for the fused
+            h->pmb_rows_total += (uint32_t)h->mbw; // stage's rows (row counts, no event between the streams), and its movers follow intra_p_kernel
             if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
         } else if (split) { // intra_p_kernel leaves the chain: prep + the band deblocker follow the fused stage directly and overtake it row by row
             HIPCHK(hipEventRecord(h->ev_pmb, st));
@@ -559,7 +563,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
             int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh), h->d_db_done + (size_t)nxt * nbd); if (r) return r;
             HIPCHK(hipEventRecord(h->ev_dbI[nxt], h->istream));
             h->dbI_busy[nxt] = 1;
-        } else { int r = run_deblock(h, ci, c, h->stream, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd); if (r) return r; }
+        } else { int r = run_deblock(h, ci, c, h->stream, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, pgate != 0); if (r) return r; }
         h->rec_epoch[nxt] = h->cfg.deblock_mode == 0 ? c->epoch : 0;
         if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
         HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
@@ -861,7 +865,7 @@ int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_u
     HIPCHK(hipMemsetAsync(h->d_rec_y[1], 0, h->ysz, h->stream)); // macroblocks decided intra stay untouched unless run_intra_p
     HIPCHK(hipMemsetAsync(h->d_rec_uv[1], 0, h->csz, h->stream));
     HIPCHK(hipMemsetAsync(h->d_levels, 0, (size_t)h->nmb * MB_LEVELS * 2, h->stream));
-    k_launch_pmb(c, h->mbw, 0, h->mbh, refine ? 1 : 0, nullptr, 0, err_word(h), h->stream);
+    k_launch_pmb(c, h->mbw, 0, h->mbh, refine ? 1 : 0, nullptr, 0, err_word(h), nullptr, h->stream);
     if (idec && run_intra_p) k_launch_intra_p(c, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
     HIPCHK(hipGetLastError());
     return download_picture(h, mbinfo_out, rec_y, rec_uv, levels) ? MI355ENC_ERR_HIP : MI355ENC_OK;
@@ -921,7 +925,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
             else if (stage == 2) { if (++h->epoch == 0) h->epoch = 1; h->slot[0].h_ctx->epoch = h->epoch; int r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r; } // a fresh stamp per launch: the lines between bands are epoch-tagged
             else if (stage == 4) k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 8) k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], h->stream);
-            else if (stage == 9) k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, 1, nullptr, 0, err_word(h), h->stream);
+            else if (stage == 9) k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, 1, nullptr, 0, err_word(h), nullptr, h->stream);
             else if (stage == 10) k_launch_intra_p(h->slot[0].h_ctx, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
             else if (stage >= 5) {
                 const int w = h->cfg.width, ht = h->cfg.height, r0 = stage == 5 ? (w + 15) & ~15 : (2 * w + 15) & ~15, r1 = (w / 2 + 15) & ~15;

@@ -100,7 +100,8 @@ const imv_t *k_final_imv(const frame_ctx_t *h_ctx); /* where the last selection 
 void k_launch_imv_to_mbi(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s); // whole-sample field -> records, for the two-kernel (8x8 transform) path
 void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 // gate_done (may be null): the reference picture's band deblocker may still be running; a wave waits until the band that holds macroblock row r + 2 carries ref_epoch
-void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, const unsigned *gate_done, unsigned ref_epoch, unsigned *d_err, hipStream_t s); // fused refinement + inter (4x4 transform)
+void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, const unsigned *gate_done, unsigned ref_epoch, unsigned *d_err,
+                  unsigned *d_row_done /* gated launches: one count per macroblock row, + mbw per launch */, hipStream_t s); // fused refinement + inter (4x4 transform)
 void k_launch_inter(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 void k_launch_intra_analyse(const frame_ctx_t *h_ctx, int mbw, int mbh, int gate_p, hipStream_t s); /* gate_p: P picture -- only macroblocks whose search cost reaches INTRA_GATE */
 void k_launch_intra_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag, hipStream_t s);
@@ -112,7 +113,8 @@ int k_deblock_bands16(int mbh);
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
                             const unsigned *d_iband_done, int ib_rows /* rows per intra band */,
                             unsigned *d_band_done /* may be null: DB_DONE_COPIES x {luma, chroma} per band = the picture's epoch once the band is final in memory */,
-                            unsigned *d_started /* may be null: counts the workgroups placed */, hipStream_t s);
+                            unsigned *d_started /* may be null: counts the workgroups placed */,
+                            const unsigned *d_row_done /* may be null: pmb_kernel<GATED> of this picture is still running; per macroblock row, it counts up to row_need */, unsigned row_need, hipStream_t s);
 int k_intra_band_rows(void);
 size_t k_deblock_partab_bytes(int mbw, int mbh); // scratch of the band kernel: one parameter word per (edge, segment) of every macroblock
 size_t k_deblock_gran_bytes(int mbw, int mbh);
