@@ -742,7 +742,9 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
 // else that launch waits for can be outstanding: the reference's fused stage and intra_p_kernel are earlier on this stream).  The
 // deblocker's bands finish within the last third of its run (they advance along x together), and that is when this launch, whole
 // and resident, takes its macroblocks row by row behind them.
-template <bool GATED>
+// ROWS (only with GATED): the picture's deblocking launch is already on the chip and waits for this kernel's rows -- samples and records
+// are stored through to memory (sc1) and every macroblock is counted for its row.
+template <bool GATED, bool ROWS>
 __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine, const unsigned *__restrict__ gate_done, unsigned ref_epoch, unsigned *err, unsigned *row_done) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
@@ -776,8 +778,8 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
         tl_last(ctx, 3);
     }
     if (mbn >= mb1) return; // wave-uniform
-    pmb_mb<GATED>(ctx, &LD[wave], mbn, lane, refine);
-    if (GATED) { // this macroblock's samples and record are in memory: count it for its row (the picture's deblocking launch, already on the chip, waits for whole rows)
+    pmb_mb<ROWS>(ctx, &LD[wave], mbn, lane, refine);
+    if (ROWS) { // this macroblock's samples and record are in memory: count it for its row (the picture's deblocking launch, already on the chip, waits for whole rows)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(row_done + mbn / ctx->mbw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -831,6 +833,7 @@ void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipS
 void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, const unsigned *gate_done, unsigned ref_epoch, unsigned *d_err, unsigned *d_row_done, hipStream_t s) {
     const int n = mbw * (row1 - row0), g = (n + 3) / 4;
     if (n <= 0) return;
-    if (gate_done) hipLaunchKernelGGL(pmb_kernel<true>, dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
-    else hipLaunchKernelGGL(pmb_kernel<false>, dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
+    if (gate_done && d_row_done) hipLaunchKernelGGL((pmb_kernel<true, true>), dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
+    else if (gate_done) hipLaunchKernelGGL((pmb_kernel<true, false>), dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
+    else hipLaunchKernelGGL((pmb_kernel<false, false>), dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
 }
