@@ -4,16 +4,18 @@ same bytes every time (rate control sees the same sizes in the same order).  Pri
 import sys, hashlib; sys.path.insert(0, '.')
 import numpy as np, torch
 from ceracoder_amd import enc as E, synth
-w, h, n = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 600
-clip = list(synth.s2_frames(w, h, 16))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+clip = list(synth.s2_frames(w, h, 16 if w < 2000 else 8))
+NC = len(clip)
 bufs = [torch.from_numpy(np.concatenate([y.reshape(-1), uv.reshape(-1)])).cuda() for y, uv in clip]
 torch.cuda.synchronize()
 def run(exclusive, sample):
-    e = E.Encoder(w, h, fps=60, gop=60, bitrate_bps=6_000_000, pipeline_depth=2, exclusive=exclusive, profile_events=sample)
+    e = E.Encoder(w, h, fps=60, gop=60, bitrate_bps=6_000_000 * (4 if w > 2000 else 1), pipeline_depth=2, exclusive=exclusive, profile_events=sample)
     out = []
     for i in range(n):
-        k = i % 30
-        p = bufs[k if k < 16 else 30 - k].data_ptr()
+        k = i % (2 * NC - 2)
+        p = bufs[k if k < NC else 2 * NC - 2 - k].data_ptr()
         e.submit_device(p, w, p + w * h, w, pts=i)
         if e.pending > 2:
             out.append(bytes(e.collect()[0]))
