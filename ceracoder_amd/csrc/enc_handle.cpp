@@ -1,0 +1,286 @@
+// enc_handle.cpp -- the handle of the C-ABI shim (include/mi355enc.h): open / close, the setters the control thread calls,
+// statistics and the inspection of the last collected picture.  The picture pipeline is in enc_schedule.cpp.
+#include "enc_internal.hpp"
+
+// A kernel that follows another kernel's progress (the band deblocker beside intra_p_kernel) needs the two to be able to run at the
+// same time.  One encoder's own streams guarantee that (intra_p_kernel is enqueued first).  Several encoders in one process share the
+// process's hardware queues, where a waiting kernel of one can sit in front of the kernel another one waits for; and tools that
+// serialise dispatches (rocprofv3 --pmc) run one kernel at a time.  So: only with a single open encoder in the process, and not when
+// MI355ENC_SERIAL is set (tools/measure_all.sh sets it for the counter passes).  Every wait is bounded and reported anyway.
+std::atomic<int> g_open_encoders{0};
+bool exclusive_device(const mi355enc_t *h) { static const bool env = getenv("MI355ENC_EXCLUSIVE") != nullptr; return h->cfg.exclusive_device != 0 || env; } // cfg.exclusive_device, or the environment for tools
+bool no_pgate() { static const bool off = getenv("MI355ENC_NO_PGATE") != nullptr; return off; } // A/B switch: the fused P stage in stream order behind the deblocking launch
+bool overlap_allowed() { static const bool serial = getenv("MI355ENC_SERIAL") != nullptr; return !serial && g_open_encoders.load(std::memory_order_relaxed) == 1; }
+
+int sync_compute(mi355enc_t *h) {
+    HIPCHK(hipStreamSynchronize(h->fstream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->istream));
+    return 0;
+}
+
+extern "C" {
+
+int mi355enc_abi_version(void) { return MI355ENC_ABI_VERSION; }
+
+const char *mi355enc_strerror(int code) {
+    switch (code) {
+    case MI355ENC_OK: return "ok";
+    case MI355ENC_ERR_ARG: return "invalid argument";
+    case MI355ENC_ERR_NO_DEVICE: return "no usable HIP device (this encoder has no CPU fallback)";
+    case MI355ENC_ERR_HIP: return "HIP runtime error";
+    case MI355ENC_ERR_NOMEM: return "out of memory";
+    case MI355ENC_ERR_OVERFLOW: return "output buffer too small";
+    case MI355ENC_ERR_STATE: return "call order violated";
+    default: return "unknown error";
+    }
+}
+
+void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num, int fps_den) {
+    memset(c, 0, sizeof *c);
+    c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
+    c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0;
+}
+
+int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
+    if (!cfg || !out) return MI355ENC_ERR_ARG;
+    *out = nullptr;
+    const double t_open = now_ms();
+    if (cfg->width < 16 || cfg->height < 16 || cfg->width > 8192 || cfg->height > 8192 || (cfg->width & 1) || (cfg->height & 1) ||
+        cfg->fps_num <= 0 || cfg->fps_den <= 0 || cfg->gop < 1 || cfg->me_range < 1 || cfg->me_range > 16 ||
+        cfg->pipeline_depth < 0 || cfg->pipeline_depth > NSLOT - 1 || cfg->fixed_qp > 51) {
+        fprintf(stderr, "mi355enc: invalid configuration\n");
+        return MI355ENC_ERR_ARG;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || cfg->device_id < 0 || cfg->device_id >= ndev) {
+        fprintf(stderr, "mi355enc: no usable HIP device (count=%d, device-id=%d, %s); this encoder has no CPU path\n", ndev,
+                cfg->device_id, e == hipSuccess ? "ok" : hipGetErrorString(e));
+        return MI355ENC_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(cfg->device_id));
+    mi355enc_t *h = new (std::nothrow) mi355enc();
+    if (!h) return MI355ENC_ERR_NOMEM;
+    memset((void *)&h->cfg, 0, sizeof h->cfg);
+    h->cfg = *cfg;
+    if (h->cfg.qp_min <= 0 && h->cfg.qp_max <= 0) { h->cfg.qp_min = 10; h->cfg.qp_max = 51; }
+    if (h->cfg.qp_max > 51) h->cfg.qp_max = 51;
+    if (h->cfg.qp_min < 0) h->cfg.qp_min = 0;
+    h->mbw = (cfg->width + 15) / 16; h->mbh = (cfg->height + 15) / 16;
+    h->W = h->mbw * 16; h->H = h->mbh * 16; h->nmb = h->mbw * h->mbh;
+    h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
+    h->head = h->tail = h->pending = 0;
+    h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
+    for (int i = 0; i < NSET; i++) { h->g_intra[i] = h->g_deblock[i] = nullptr; h->d_ctx2[i] = nullptr; h->d_surf[i] = nullptr; h->d_idec2[i] = nullptr; h->d_mbi_set[i] = nullptr; h->d_levels_set[i] = nullptr; }
+    h->prev_slot = nullptr;
+    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->d_row_done = nullptr; h->pmb_rows_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; 
+    memset(&h->st, 0, sizeof h->st);
+    h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
+    h->fixed_qp.store(cfg->fixed_qp);
+    h->fixed_drop.store(0);
+    *out = h; // from here on close() cleans up partial state
+    g_open_encoders.fetch_add(1, std::memory_order_relaxed);
+    HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (int i = 0; i < NSET; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
+    h->d_ctx = h->d_ctx2[0];
+    { // The hand-over stream gets its own priority level: HIP then backs it with a different hardware queue, so its
+      // kernels run beside the persistent deblocking kernel instead of queueing behind it.
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, lo));
+        HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, 0));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_pmb, hipEventDisableTiming));
+    }
+    for (int i = 0; i < NSET; i++) {
+        HIPCHK(hipMalloc((void **)&h->d_mbi_set[i], (size_t)h->nmb * sizeof(mb_info_t)));
+        HIPCHK(hipMalloc((void **)&h->d_levels_set[i], (size_t)h->nmb * MB_LEVELS * sizeof(int16_t)));
+        HIPCHK(hipMemsetAsync(h->d_mbi_set[i], 0, (size_t)h->nmb * sizeof(mb_info_t), h->stream));
+    }
+    h->d_mbi = h->d_mbi_set[0]; h->d_levels = h->d_levels_set[0]; h->n_submitted = 0;
+    h->sc_sum = 0; h->sc_cnt = 0; h->sc_prev_skip = 0; h->sc_force_at = ~0ull;
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc((void **)&h->d_rec_y[i], h->ysz + SURF_PAD));
+        HIPCHK(hipMalloc((void **)&h->d_rec_uv[i], h->csz + SURF_PAD));
+        HIPCHK(hipMemsetAsync(h->d_rec_y[i], 0, h->ysz + SURF_PAD, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_rec_uv[i], 0, h->csz + SURF_PAD, h->stream));
+    }
+    HIPCHK(hipMalloc((void **)&h->d_isad, (size_t)h->nmb * ISAD_PER_MB * sizeof(uint16_t)));
+    HIPCHK(hipMalloc((void **)&h->d_dbrec, (size_t)h->nmb * 64));
+    HIPCHK(hipMalloc((void **)&h->d_idec, (size_t)h->nmb * IDEC_BYTES + 16));
+    h->d_idec2[0] = h->d_idec;
+    HIPCHK(hipMalloc((void **)&h->d_progress, 4 * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
+    HIPCHK(hipMalloc((void **)&h->d_db_par, k_deblock_partab_bytes(h->mbw, h->mbh)));
+    HIPCHK(hipMalloc((void **)&h->d_ib_gran, (size_t)k_intra_bands(h->mbh) * h->mbw * 8 * sizeof(uint2)));
+    HIPCHK(hipMemsetAsync(h->d_ib_gran, 0, (size_t)k_intra_bands(h->mbh) * h->mbw * 8 * sizeof(uint2), h->stream));
+    HIPCHK(hipMalloc((void **)&h->d_iband_done, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned))); // one set per reconstruction buffer: the next picture's wavefront runs beside this one's deblocking
+    HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned), h->stream));
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_dbI[i], hipEventDisableTiming));
+    HIPCHK(hipMalloc((void **)&h->d_row_done, (size_t)h->mbh * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * sizeof(unsigned), h->stream));
+    HIPCHK(hipMalloc((void **)&h->d_db_done, 2 * k_deblock_done_bytes()));
+    HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream)); // epoch 0 is never used
+    HIPCHK(hipMalloc((void **)&h->d_db_gran, k_deblock_gran_bytes(h->mbw, h->mbh)));
+    HIPCHK(hipMemsetAsync(h->d_db_gran, 0, k_deblock_gran_bytes(h->mbw, h->mbh), h->stream)); // epoch 0 is never used
+    HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
+    for (int k = 0; k < NSET; k++) {
+        HIPCHK(hipMalloc((void **)&h->d_surf[k], (size_t)h->nmb * SURF_U16 * sizeof(uint16_t)));
+        for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_imv[k][i], (size_t)h->nmb * sizeof(imv_t)));
+        if (k > 0) HIPCHK(hipMalloc((void **)&h->d_idec2[k], (size_t)h->nmb * IDEC_BYTES + 16));
+    }
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(hipMalloc((void **)&h->d_psrc[k], h->ysz + SURF_PAD));
+        HIPCHK(hipMemsetAsync(h->d_psrc[k], 0, h->ysz + SURF_PAD, h->stream));
+    }
+    HIPCHK(hipMalloc((void **)&h->d_ip_progress, (size_t)h->mbh * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(h->d_ip_progress, 0, (size_t)h->mbh * sizeof(unsigned), h->stream)); // epoch-tagged: the epoch starts at 1
+    HIPCHK(hipMalloc((void **)&h->d_ip_strips, (size_t)h->nmb * 32));
+    if (cfg->keep_prefilter) {
+        HIPCHK(hipMalloc((void **)&h->d_pre_y, h->ysz));
+        HIPCHK(hipMalloc((void **)&h->d_pre_uv, h->csz));
+    }
+    for (int i = 0; i < NSLOT; i++) {
+        slot_t *s = &h->slot[i];
+        memset(s, 0, sizeof *s);
+        HIPCHK(hipHostMalloc((void **)&s->h_ctx, sizeof(frame_ctx_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&s->h_mbi, (size_t)h->nmb * sizeof(mb_info_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&s->h_levels, (size_t)h->nmb * PACK_BLOCKS_MAX * 32, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&s->h_hdr, (size_t)(4 + h->mbh) * sizeof(unsigned), hipHostMallocDefault)); // + the summed macroblock cost (two words)
+        s->h_hdr[0] = s->h_hdr[1] = 0;
+        HIPCHK(hipMalloc((void **)&s->d_src_y, h->ysz + SURF_PAD));
+        HIPCHK(hipMalloc((void **)&s->d_src_uv, h->csz + SURF_PAD));
+        HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->gpu_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_front, hipEventDisableTiming));
+        for (int k = 0; k < 12; k++) HIPCHK(hipEventCreate(&s->ev[k]));
+    }
+    h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
+    if (!h->writer) return MI355ENC_ERR_NOMEM;
+    if (h->cfg.cavlc_threads <= 0) { // auto, like x264enc's threads=0
+        const unsigned hw = std::thread::hardware_concurrency();
+        int n = (int)(hw / 4);
+        h->cfg.cavlc_threads = h->nmb < 1000 ? 1 : n < 1 ? 1 : n > 8 ? 8 : n;
+    }
+    if (h->cfg.cavlc_threads > 1 && h264_writer_set_threads(h->writer, h->cfg.cavlc_threads)) return MI355ENC_ERR_NOMEM;
+    rc_init(&h->rc, (double)cfg->fps_num / cfg->fps_den, cfg->gop, h->want_bps.load(), h->cfg.qp_min, h->cfg.qp_max);
+    if (h->cfg.vbv_ms > 0) rc_set_vbv(&h->rc, h->cfg.vbv_ms);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->ms_open = now_ms() - t_open; h->n_skip_pictures = 0;
+    return MI355ENC_OK;
+}
+
+void mi355enc_close(mi355enc_t *h) {
+    if (!h) return;
+    g_open_encoders.fetch_sub(1, std::memory_order_relaxed);
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->fstream) (void)hipStreamSynchronize(h->fstream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->istream) (void)hipStreamSynchronize(h->istream);
+    if (h->ev_pmb) (void)hipEventDestroy(h->ev_pmb);
+    for (int i = 0; i < NSET; i++) { if (h->g_intra[i]) (void)hipGraphExecDestroy(h->g_intra[i]); if (h->g_deblock[i]) (void)hipGraphExecDestroy(h->g_deblock[i]); }
+    for (int i = 0; i < NSLOT; i++) {
+        slot_t *s = &h->slot[i];
+        if (s->h_ctx) (void)hipHostFree(s->h_ctx);
+        if (s->h_mbi) (void)hipHostFree(s->h_mbi);
+        if (s->h_levels) (void)hipHostFree(s->h_levels);
+        if (s->h_hdr) (void)hipHostFree(s->h_hdr);
+        if (s->d_src_y) (void)hipFree(s->d_src_y);
+        if (s->d_src_uv) (void)hipFree(s->d_src_uv);
+        if (s->d_raw) (void)hipFree(s->d_raw);
+        if (s->done) (void)hipEventDestroy(s->done);
+        if (s->gpu_done) (void)hipEventDestroy(s->gpu_done);
+        if (s->ev_front) (void)hipEventDestroy(s->ev_front);
+        for (int k = 0; k < 12; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
+    }
+    for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
+    if (h->d_pre_y) (void)hipFree(h->d_pre_y);
+    if (h->d_pre_uv) (void)hipFree(h->d_pre_uv);
+    if (h->d_isad) (void)hipFree(h->d_isad);
+    if (h->d_dbrec) (void)hipFree(h->d_dbrec);
+    if (h->d_idec) (void)hipFree(h->d_idec);
+    if (h->d_progress) (void)hipFree(h->d_progress);
+    if (h->d_db_gran) (void)hipFree(h->d_db_gran);
+    if (h->d_db_done) (void)hipFree(h->d_db_done);
+    if (h->d_row_done) (void)hipFree(h->d_row_done);
+    if (h->d_db_par) (void)hipFree(h->d_db_par);
+    if (h->d_ib_gran) (void)hipFree(h->d_ib_gran);
+    if (h->d_iband_done) (void)hipFree(h->d_iband_done);
+    for (int i = 0; i < 2; i++) if (h->ev_dbI[i]) (void)hipEventDestroy(h->ev_dbI[i]);
+    if (h->d_off) (void)hipFree(h->d_off);
+    for (int k = 0; k < NSET; k++) {
+        if (h->d_surf[k]) (void)hipFree(h->d_surf[k]);
+        for (int i = 0; i < 2; i++) if (h->d_imv[k][i]) (void)hipFree(h->d_imv[k][i]);
+        if (k > 0 && h->d_idec2[k]) (void)hipFree(h->d_idec2[k]);
+    }
+    for (int k = 0; k < 2; k++) if (h->d_psrc[k]) (void)hipFree(h->d_psrc[k]);
+    if (h->d_ip_progress) (void)hipFree(h->d_ip_progress);
+    if (h->d_ip_strips) (void)hipFree(h->d_ip_strips);
+    for (int i = 0; i < NSET; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
+    for (int i = 0; i < NSET; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
+    if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
+    if (h->fstream) (void)hipStreamDestroy(h->fstream);
+    if (h->istream) (void)hipStreamDestroy(h->istream);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    h264_writer_free(h->writer);
+    delete h;
+}
+
+int mi355enc_set_bitrate(mi355enc_t *h, uint32_t bps) {
+    if (!h) return MI355ENC_ERR_ARG;
+    h->want_bps.store(bps < 1000 ? 1000 : bps, std::memory_order_relaxed);
+    return MI355ENC_OK;
+}
+uint32_t mi355enc_get_bitrate(const mi355enc_t *h) { return h ? h->want_bps.load(std::memory_order_relaxed) : 0; }
+int mi355enc_set_fixed_qp(mi355enc_t *h, int qp) {
+    if (!h || qp > 51) return MI355ENC_ERR_ARG;
+    h->fixed_qp.store(qp < 0 ? -1 : qp, std::memory_order_relaxed);
+    return MI355ENC_OK;
+}
+int mi355enc_set_fixed_drop(mi355enc_t *h, int drop) {
+    if (!h || drop < 0 || (drop > DROP_MAX && drop != DROP_SKIP)) return MI355ENC_ERR_ARG;
+    h->fixed_drop.store(drop, std::memory_order_relaxed);
+    return MI355ENC_OK;
+}
+int mi355enc_pending(const mi355enc_t *h) { return h ? h->pending : 0; }
+size_t mi355enc_max_au_bytes(const mi355enc_t *h) { return h ? h264_max_au_bytes(h->mbw, h->mbh) : 0; }
+int mi355enc_mb_width(const mi355enc_t *h) { return h ? h->mbw : 0; }
+int mi355enc_mb_height(const mi355enc_t *h) { return h ? h->mbh : 0; }
+
+int mi355enc_get_stats(mi355enc_t *h, mi355enc_stats_t *st) {
+    if (!h || !st) return MI355ENC_ERR_ARG;
+    *st = h->st;
+    st->target_bps = h->want_bps.load();
+    st->cavlc_threads = (uint32_t)h->cfg.cavlc_threads;
+    st->ms_open = h->ms_open; st->skip_pictures = h->n_skip_pictures;
+    return MI355ENC_OK;
+}
+void mi355enc_reset_stats(mi355enc_t *h) { if (h) { memset(&h->st, 0, sizeof h->st); h->n_skip_pictures = 0; } }
+
+int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
+    if (!h || !dst) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    const void *src = nullptr; size_t need = 0; bool host = false;
+    switch (what) {
+    case MI355ENC_FETCH_RECON_Y: src = h->d_rec_y[h->last_collected_rec]; need = h->ysz; break;
+    case MI355ENC_FETCH_RECON_UV: src = h->d_rec_uv[h->last_collected_rec]; need = h->csz; break;
+    case MI355ENC_FETCH_PREFILTER_Y: src = h->d_pre_y; need = h->ysz; break;
+    case MI355ENC_FETCH_PREFILTER_UV: src = h->d_pre_uv; need = h->csz; break;
+    case MI355ENC_FETCH_MBINFO: src = h->last_slot ? h->last_slot->h_mbi : nullptr; need = (size_t)h->nmb * sizeof(mb_info_t); host = true; break;
+    case MI355ENC_FETCH_LEVELS: src = h->last_slot ? h->d_levels_set[h->last_slot->set] : nullptr; need = (size_t)h->nmb * MB_LEVELS * 2; break; // dense, from HBM
+    case 100: src = h->d_dbrec; need = (size_t)h->nmb * 64; break; /* development: deblocking records (cycle counters in -DD3_PROF builds) */
+    case 101: src = h->d_isad; need = 1024; break;                 /* development: cycle counters of -DIB_PROF builds */
+    default: return MI355ENC_ERR_ARG;
+    }
+    if (!src) return MI355ENC_ERR_STATE;
+    if (n < need) return MI355ENC_ERR_OVERFLOW;
+    if (host) { memcpy(dst, src, need); return MI355ENC_OK; }
+    { int r = sync_compute(h); if (r) return r; }
+    HIPCHK(hipMemcpy(dst, src, need, hipMemcpyDeviceToHost));
+    return MI355ENC_OK;
+}
+
+} // extern "C"

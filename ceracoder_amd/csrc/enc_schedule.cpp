@@ -1,0 +1,379 @@
+// enc_schedule.cpp -- the picture pipeline of the C-ABI shim.
+//
+// Per picture:
+//   front stream: [H2D source | conversion] -> P: me_kernel (SAD surfaces + first selection) -> me_select_kernel x ME_ITERS
+//                 -> intra analysis of the badly predicted macroblocks;  IDR: the source copy the next search runs against
+//   back stream:  IDR: intra analysis (flat) -> intra wavefront (persistent bands) | P: pmb_kernel -> intra_p_kernel
+//                 -> deblocking (persistent band kernel)
+//   hand-over stream, from the moment records and levels are final: scan + pack into pinned host memory -> event
+//   host, when the event has fired: CAVLC slice coding (h264_host.c).
+// With pipeline_depth = 1 the host codes picture n while the device works on n+1; with 2 a third picture is in flight.
+#include "enc_internal.hpp"
+
+static void launch_intra_all(mi355enc_t *h, int ci) {
+    int n = k_intra_diags(h->mbw, h->mbh);
+    for (int d = 0; d < n; d++) k_launch_intra_diag(h->d_ctx2[ci], h->mbw, h->mbh, d, h->stream);
+}
+static void launch_deblock_all(mi355enc_t *h, int ci) {
+    int n = k_deblock_diags(h->mbw, h->mbh);
+    for (int d = 0; d < n; d++) k_launch_deblock_diag(h->d_ctx2[ci], h->mbw, h->mbh, d, h->stream);
+}
+static int build_graph(mi355enc_t *h, int which, int ci, hipGraphExec_t *out) {
+    hipGraph_t g;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    if (which == 0) launch_intra_all(h, ci); else launch_deblock_all(h, ci);
+    HIPCHK(hipStreamEndCapture(h->stream, &g));
+    HIPCHK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(g));
+    return 0;
+}
+int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done) {
+    k_launch_intra_analyse(hc, h->mbw, h->mbh, 0, h->stream); // open-loop mode analysis + decisions: one flat launch
+    if (h->cfg.intra_mode == 0) { // persistent band kernel
+        k_launch_intra_band(hc, h->mbh, h->d_ib_gran, err_word(h), band_done, h->stream);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (h->cfg.use_graphs) {
+        if (!h->g_intra[ci]) { int r = build_graph(h, 0, ci, &h->g_intra[ci]); if (r) return r; }
+        HIPCHK(hipGraphLaunch(h->g_intra[ci], h->stream));
+    } else launch_intra_all(h, ci);
+    return 0;
+}
+// whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
+int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done, unsigned *band_done, bool after_gated_pmb) {
+    if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
+        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, k_intra_band_rows(), band_done, h->d_progress + 1, after_gated_pmb ? h->d_row_done : nullptr, h->pmb_rows_total, st);
+        h->db_started_total += 2u * (unsigned)k_deblock_bands16(h->mbh);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (h->cfg.use_graphs) {
+        if (!h->g_deblock[ci]) { int r = build_graph(h, 1, ci, &h->g_deblock[ci]); if (r) return r; }
+        HIPCHK(hipGraphLaunch(h->g_deblock[ci], h->stream));
+    } else launch_deblock_all(h, ci);
+    return 0;
+}
+// scene-cut recovery: the decision taken with picture k's hand-over lands on picture k + lag, the first one that cannot have been
+// submitted yet (depth 0 behaves as depth 1, so that the stream is the same for both)
+static int sc_lag(const mi355enc_t *h) { return h->cfg.pipeline_depth >= 2 ? h->cfg.pipeline_depth + 1 : 2; }
+static hipStream_t upload_stream(const mi355enc_t *h) { return h->fstream; }
+
+// rate control's ladder below QP 51 (oracle: k_drop_sad): the SAD under which a P macroblock carries no residual / takes the skip vector
+static const uint32_t k_drop_sad[DROP_MAX + 1] = {0, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 0xFFFFFFFFu};
+// ... and its counterpart for I pictures (oracle: k_idrop_ac): the sum of level magnitudes up to which a macroblock's luma / chroma residual is not sent
+static const int32_t k_idrop_ac[DROP_MAX + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64, 0x7FFFFFFF};
+
+void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set) {
+    c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec2[set];
+    c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh;
+    c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
+    c->surf = h->d_surf[set]; c->imv_a = h->d_imv[set][0]; c->imv_b = h->d_imv[set][1];
+    c->me_ref_y = h->d_psrc[h->psrc_cur]; c->psrc_out = h->d_psrc[h->psrc_cur ^ 1];
+    if (++h->epoch == 0) h->epoch = 1;
+    c->epoch = h->epoch;
+    c->drop_sad = (!idr && drop > 0 && drop <= DROP_MAX) ? k_drop_sad[drop] : 0;
+    c->iac_drop = (idr && drop > 0 && drop <= DROP_MAX) ? k_idrop_ac[drop] : 0;
+    if (c->iac_drop) c->i4x4 = 0; // on the ladder: Intra_16x16 only
+    c->intra_p = (h->cfg.intra_in_p && !h->cfg.transform8x8) ? 1 : 0;
+}
+// P picture, front part (front stream): nothing here depends on the coding of the picture before
+static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof) {
+    hipStream_t st = h->fstream;
+    if (prof) HIPCHK(hipEventRecord(s->ev[0], st));
+    k_launch_me(hc, h->mbw, 0, h->mbh, st);
+    if (prof) HIPCHK(hipEventRecord(s->ev[6], st));
+    for (int it = 0; it < ME_ITERS; it++) k_launch_me_select(hc, h->mbw, 0, h->mbh, (it & 1) ? hc->imv_b : hc->imv_a, (it & 1) ? hc->imv_a : hc->imv_b, st);
+    if (prof) HIPCHK(hipEventRecord(s->ev[1], st));
+    if (!h->cfg.transform8x8 && hc->intra_p) k_launch_intra_analyse(hc, h->mbw, h->mbh, 1, st);
+    if (prof) HIPCHK(hipEventRecord(s->ev[7], st));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// ... and back part (back stream): needs the deblocked picture before it
+// gate: the reference picture's band-done words (the fused stage then runs on the intra stream, beside that picture's deblocking)
+// rows: the picture's deblocking launch will sit directly behind the previous one and wait on the device for this stage's rows (no event)
+static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split, const unsigned *gate, unsigned ref_epoch, int rows) {
+    hipStream_t st = gate ? h->istream : h->stream;
+    if (prof) HIPCHK(hipEventRecord(s->ev[8], st));
+    if (h->cfg.transform8x8) { // High profile: the two-kernel form (absolute-vector refinement, 8x8 transform), no skip / intra logic
+        k_launch_imv_to_mbi(hc, h->mbw, 0, h->mbh, st);
+        if (h->cfg.subpel) k_launch_subpel(hc, h->mbw, 0, h->mbh, st);
+        if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
+        k_launch_inter(hc, h->mbw, 0, h->mbh, st);
+    } else {
+        if (gate) k_launch_wait_started(h->d_progress + 1, h->db_started_total, err_word(h), st); // not before the reference's deblocking launch is on the chip
+        k_launch_pmb(hc, h->mbw, 0, h->mbh, h->cfg.subpel, gate, ref_epoch, err_word(h), rows ? h->d_row_done : nullptr, st);
+        if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
+        if (gate) { // the main stream carries nothing but deblocking launches, back to back: this picture's bands wait on the device for the fused
+            if (rows) h->pmb_rows_total += (uint32_t)h->mbw; // stage's rows (row counts, no event between the streams), and its movers follow intra_p_kernel
+            else { HIPCHK(hipEventRecord(h->ev_pmb, st)); HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pmb, 0)); } // (fewer than three pictures in flight: by event)
+            if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
+        } else if (split) { // intra_p_kernel leaves the chain: prep + the band deblocker follow the fused stage directly and overtake it row by row
+            HIPCHK(hipEventRecord(h->ev_pmb, st));
+            HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0));
+            k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->istream);
+        } else if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
+    }
+    if (prof) HIPCHK(hipEventRecord(s->ev[11], st));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Enqueue every device step of one picture whose source is described by (src_y, src_uv, src_stride).  Anything the caller
+// uploaded for this picture was enqueued on the same stream.
+static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride,
+                           int64_t pts, int force_idr) {
+    const int idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop ||
+                    (h->n_submitted == h->sc_force_at && h->frames_since_idr >= sc_lag(h)); // scene-cut recovery, see collect(): not when an IDR picture came in between
+    if (idr) h->frames_since_idr = 0;
+    // rate control: latch the setpoint written by the control thread, pick this picture's QP (and, below QP 51, its drop level)
+    rc_set_bitrate(&h->rc, h->want_bps.load(std::memory_order_relaxed));
+    int fq = h->fixed_qp.load(std::memory_order_relaxed);
+    int qp, drop;
+    if (fq >= 0) { qp = fq; drop = h->fixed_drop.load(std::memory_order_relaxed); }
+    else rc_pick(&h->rc, idr, &qp, &drop);
+    if (idr && drop == DROP_SKIP) drop = 0; // an IDR picture is never skipped; it has a ladder of its own
+    const int all_skip = !idr && drop == DROP_SKIP;
+    const int nxt = all_skip ? h->cur : (h->cur ^ 1); // an all-skip picture IS its reference: nothing is written
+    const int set = (int)(h->n_submitted % NSET), ci = set;
+    frame_ctx_t *c = s->h_ctx, *dctx = h->d_ctx2[ci];
+    // stage timers: an event record costs ~5 us of queue time, so profile_events = k samples every k-th picture (IDR pictures always)
+    // (a sampled picture runs its stages strictly in order; IDR pictures: every other one, or at the P pictures' cadence in an all-intra stream)
+    const int prof = !all_skip && h->cfg.profile_events > 0 &&
+                     ((idr && h->cfg.gop > 1) ? (h->idr_count & 1) == 0 : h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
+    const bool fused = !h->cfg.transform8x8;
+    if (all_skip) {
+        // one run of P_Skip macroblocks with the zero vector (8.4.1.1 infers it: every neighbour's vector is zero): the host
+        // writes the records itself; no source sample is read, no kernel runs, the reference stays where it is
+        memset(s->h_mbi, 0, (size_t)h->nmb * sizeof(mb_info_t));
+        for (int i = 0; i < h->nmb; i++) { s->h_mbi[i].mb_type = 1; s->h_mbi[i].qp = (uint8_t)qp; }
+        s->h_hdr[0] = 0; s->h_hdr[1] = 0;
+        for (int r = 0; r < h->mbh; r++) s->h_hdr[2 + r] = 0;
+        s->h_hdr[2 + h->mbh] = s->h_hdr[3 + h->mbh] = 0;
+        if (h->d_pre_y) {
+            HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
+        }
+    } else {
+        c->src_y = src_y; c->src_uv = src_uv; c->src_stride = src_stride;
+        c->ref_y = h->d_rec_y[h->cur]; c->ref_uv = h->d_rec_uv[h->cur];
+        c->rec_y = h->d_rec_y[nxt]; c->rec_uv = h->d_rec_uv[nxt];
+        c->vis_h = h->cfg.height;
+        fill_ctx(h, c, qp, drop, idr, set);
+        c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set];
+        // Every kernel of the default path takes the context by value; only the kernels replayed from a hipGraph
+        // (intra_mode 1, deblock_mode 1) read the device copy, so only those pictures pay for an upload.
+        if ((idr && h->cfg.intra_mode != 0) || h->cfg.deblock_mode != 0) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
+        // front stream: the source is in place (upload / conversion were enqueued there); P pictures: search, selection, gated intra
+        // analysis; I pictures: only the padded source copy the next picture's search will run against
+        if (idr) k_launch_copy_luma(c, h->fstream);
+        else { int r = run_p_front(h, c, s, prof); if (r) return r; }
+        HIPCHK(hipEventRecord(s->ev_front, h->fstream));
+        h->psrc_cur ^= 1;
+        // P picture with intra macroblocks: intra_p_kernel (a chain along rows, 10..80 us) and the band deblocker (a chain along
+        // x + y) overlap -- intra_p_kernel runs on a stream of its own and the deblocker's movers follow its per-row progress words
+        // (GATED, k_deblock.hip); the chain pmb -> prep -> deblocker -> next pmb stays on one stream (a cross-stream event on the
+        // chain costs 10-17 us).  Not on pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
+        const int split = !idr && fused && c->intra_p && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
+        // IDR picture: the band deblocker runs on the intra stream BESIDE the intra wavefront, each of its bands waiting for the intra bands
+        // of the same rows (flags + acquire); in an all-intra stream the next picture's wavefront then starts while this one is still
+        // being deblocked.  What has to wait for such a deblocking: a P picture (it reads the whole reference), and whoever writes
+        // the reconstruction buffer it works on (the picture after next).
+        // P picture whose reference is still being deblocked: the fused stage leaves the chain too.  It runs on the intra stream, each of
+        // its waves waiting for the reference's bands it reads (pmb_kernel<GATED>), so it is all but done when that deblocking ends.
+        const size_t nbd = k_deblock_done_bytes() / sizeof(unsigned); // words per reconstruction buffer
+        const int pgate = !idr && fused && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed() && h->rec_epoch[h->cur] != 0 && exclusive_device(h) && !no_pgate();
+        HIPCHK(hipStreamWaitEvent(pgate ? h->istream : h->stream, s->ev_front, 0));
+        // ... and with three pictures in flight (the next picture's front stages are done long before this launch ends) the deblocking launches go back
+        // to back, each waiting on the device for its picture's rows; with fewer the host sits on the chain and a launch waiting on the chip only
+        // gets in the way (1080p depth 1: 4465 -> 3980 frames/s, 2160p: 2050 -> 1615)
+        const int prows = pgate && h->cfg.pipeline_depth >= 2;
+        const int isplit = idr && h->cfg.intra_mode == 0 && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
+        for (int b = 0; b < 2; b++)
+            if (h->dbI_busy[b] && (!idr || b == nxt)) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_dbI[b], 0)); h->dbI_busy[b] = 0; }
+        if (idr) {
+            if (isplit) { HIPCHK(hipEventRecord(h->ev_pmb, h->stream)); HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0)); } // behind everything enqueued so far (a P picture's deblocker, its tables)
+            if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
+            int r = run_intra(h, ci, c, isplit ? h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh) : nullptr); if (r) return r;
+            if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
+        } else {
+            int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur], prows); if (r) return r;
+        }
+        if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->gpu_done, (split || pgate) ? h->istream : h->stream)); // records and levels are final here; they do not depend on deblocking
+        if (h->d_pre_y) {
+            HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_pre_uv, h->d_rec_uv[nxt], h->csz, hipMemcpyDeviceToDevice, h->stream));
+            if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
+        }
+        if (isplit) {
+            int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh), h->d_db_done + (size_t)nxt * nbd); if (r) return r;
+            HIPCHK(hipEventRecord(h->ev_dbI[nxt], h->istream));
+            h->dbI_busy[nxt] = 1;
+        } else { int r = run_deblock(h, ci, c, h->stream, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, prows != 0); if (r) return r; }
+        h->rec_epoch[nxt] = h->cfg.deblock_mode == 0 ? c->epoch : 0;
+        if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
+        HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
+        // Hand-over on the second stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:
+        // the device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
+        k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, err_word(h), h->cstream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->done, h->cstream));
+    }
+    h->n_submitted++;
+    s->is_idr = idr; s->qp = qp; s->drop = drop; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
+    s->pts = pts; s->rec_index = nxt; s->set = set; s->prof = prof; s->fused = fused && !idr; s->index = h->n_submitted - 1; s->all_skip = all_skip;
+    if (idr) h->idr_count++;
+    h->frames_since_idr++;
+    h->cur = nxt; h->have_ref = 1; h->prev_slot = s;
+    h->head = (h->head + 1) % NSLOT; h->pending++;
+    return MI355ENC_OK;
+}
+
+// Upload the planes of a non-NV12 picture tightly into the slot's raw staging buffer and convert into its NV12 staging surfaces.
+int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const planes[3], const int strides[3], hipStream_t up) {
+    const int w = h->cfg.width, ht = h->cfg.height;
+    if (fmt < MI355ENC_FMT_I420 || fmt > MI355ENC_FMT_UYVY || !planes || !strides || !planes[0]) return MI355ENC_ERR_ARG;
+    if (!s->d_raw) HIPCHK(hipMalloc((void **)&s->d_raw, (size_t)(2 * h->W + 32) * h->H + 64));
+    if (fmt == MI355ENC_FMT_I420) {
+        if (!planes[1] || !planes[2] || strides[0] < w || strides[1] < w / 2 || strides[2] < w / 2) return MI355ENC_ERR_ARG;
+        const int r0 = (w + 15) & ~15, r1 = (w / 2 + 15) & ~15;
+        uint8_t *dy = s->d_raw, *du = dy + (size_t)r0 * ht, *dv = du + (size_t)r1 * (ht / 2);
+        HIPCHK(hipMemcpy2DAsync(dy, r0, planes[0], strides[0], w, ht, hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpy2DAsync(du, r1, planes[1], strides[1], w / 2, ht / 2, hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpy2DAsync(dv, r1, planes[2], strides[2], w / 2, ht / 2, hipMemcpyHostToDevice, up));
+        if (k_launch_csc(fmt, dy, du, dv, r0, r1, r1, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, up)) return MI355ENC_ERR_ARG;
+    } else {
+        if (strides[0] < 2 * w) return MI355ENC_ERR_ARG;
+        const int r0 = (2 * w + 15) & ~15;
+        HIPCHK(hipMemcpy2DAsync(s->d_raw, r0, planes[0], strides[0], 2 * w, ht, hipMemcpyHostToDevice, up));
+        if (k_launch_csc(fmt, s->d_raw, nullptr, nullptr, r0, 0, 0, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, up)) return MI355ENC_ERR_ARG;
+    }
+    HIPCHK(hipGetLastError());
+    return MI355ENC_OK;
+}
+
+extern "C" {
+
+int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride, int64_t pts, int force_idr) {
+    if (!h || !y || !uv || y_stride < h->cfg.width || uv_stride < h->cfg.width) return MI355ENC_ERR_ARG;
+    if (h->pending > h->cfg.pipeline_depth) return MI355ENC_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[h->head];
+    const int w = h->cfg.width, ht = h->cfg.height;
+    hipStream_t up = upload_stream(h);
+    HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, y, y_stride, w, ht, hipMemcpyHostToDevice, up));
+    HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, up));
+    if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+}
+
+int mi355enc_submit_fmt(mi355enc_t *h, int fmt, const uint8_t *const planes[3], const int strides[3], int64_t pts, int force_idr) {
+    if (!h || !planes || !strides) return MI355ENC_ERR_ARG;
+    if (fmt == MI355ENC_FMT_NV12) return mi355enc_submit(h, planes[0], strides[0], planes[1], strides[1], pts, force_idr);
+    if (h->pending > h->cfg.pipeline_depth) return MI355ENC_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[h->head];
+    int r = upload_and_convert(h, s, fmt, planes, strides, upload_stream(h));
+    if (r) return r;
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+}
+
+int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const void *d_uv, int uv_stride, int64_t pts, int force_idr) {
+    if (!h || !d_y || !d_uv || y_stride < h->cfg.width || uv_stride < h->cfg.width) return MI355ENC_ERR_ARG;
+    if (h->pending > h->cfg.pipeline_depth) return MI355ENC_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[h->head];
+    const int w = h->cfg.width, ht = h->cfg.height;
+    hipStream_t up = upload_stream(h);
+    const bool direct = w == h->W && y_stride == uv_stride && (y_stride & 15) == 0 && (((uintptr_t)d_y | (uintptr_t)d_uv) & 15) == 0;
+    if (direct) return enqueue_picture(h, s, (const uint8_t *)d_y, (const uint8_t *)d_uv, y_stride, pts, force_idr);
+    HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, d_y, y_stride, w, ht, hipMemcpyDeviceToDevice, up));
+    HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, d_uv, uv_stride, w, ht / 2, hipMemcpyDeviceToDevice, up));
+    if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
+    return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
+}
+
+int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_len, int *is_keyframe, int64_t *pts, int *qp) {
+    if (!h || !out || !out_len) return MI355ENC_ERR_ARG;
+    if (h->pending <= 0) return MI355ENC_ERR_STATE;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    slot_t *s = &h->slot[h->tail];
+    double t0 = now_ms();
+    if (!s->all_skip) HIPCHK(hipEventSynchronize(s->done));
+    double t1 = now_ms();
+    h->st.ms_wait += t1 - t0;
+    if (s->h_hdr[1]) { // sticky: set by a band of an earlier picture's deblocking launch that gave up waiting
+        fprintf(stderr, "mi355enc: a device-side wait timed out (error word %u: 3 pmb_kernel gate, 4 wait_started_kernel, 11 deblocker / intra bands, 12 deblocker / strips, 13 deblocker / intra_p_kernel, 14 intra band / strips, 15 intra_p_kernel / row above, 16 progress counter)\n", s->h_hdr[1]);
+        return MI355ENC_ERR_HIP;
+    }
+    size_t n = 0;
+    if (s->is_idr) {
+        n = h264_write_headers(out, out_cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den, h->cfg.transform8x8);
+        if (!n) return MI355ENC_ERR_OVERFLOW;
+    }
+    size_t m = h264_write_slice_packed_rows(h->writer, out + n, out_cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels, s->h_hdr + 2);
+    if (!m) return MI355ENC_ERR_OVERFLOW;
+    h->st.ms_entropy += now_ms() - t1;
+    *out_len = n + m;
+    if (is_keyframe) *is_keyframe = s->is_idr;
+    if (pts) *pts = s->pts;
+    if (qp) *qp = s->qp;
+    rc_update(&h->rc, s->is_idr, s->qp, s->drop, n + m);
+    // Scene-cut recovery (cfg.scenecut; the oracle's orc_enc_frame applies the same rule): the summed cost of the picture's
+    // macroblocks came with the hand-over.  The decision lands on picture index + 2, the first one not submitted yet whatever
+    // the pipeline depth, and is skipped there if picture index + 1 turned out to be an IDR: the stream does not depend on
+    // the order of submit() and collect() calls.
+    if (s->is_idr) { h->sc_sum = 0; h->sc_cnt = 0; }
+    else if (!s->all_skip && !h->sc_prev_skip) { // (a picture that follows P_Skip-run pictures is searched against an older source: its cost says nothing about a cut)
+        const uint64_t cost = (uint64_t)s->h_hdr[2 + h->mbh] | ((uint64_t)s->h_hdr[3 + h->mbh] << 32);
+        const bool pending = h->sc_force_at != ~0ull && h->sc_force_at > s->index; // a decision not yet carried out stands
+        if (h->cfg.scenecut && !pending && h->sc_cnt >= 2 && cost > 3 * (h->sc_sum / (uint64_t)h->sc_cnt)) h->sc_force_at = s->index + (uint64_t)sc_lag(h);
+        h->sc_sum += cost; h->sc_cnt++;
+    }
+    h->sc_prev_skip = s->all_skip;
+    if (s->prof) {
+        float a = 0, b = 0, c = 0, tot = 0, sp = 0;
+        {
+            HIPCHK(hipEventSynchronize(s->ev[4])); // the access unit is ready before deblocking ends; the stage timers are not
+            float sel = 0, an = 0, ip = 0;
+            if (s->is_idr) { (void)hipEventElapsedTime(&a, s->ev[0], s->ev[1]); (void)hipEventElapsedTime(&tot, s->ev[0], s->ev[4]); }
+            else { // front-stream stages and back-stream stages are timed on their own streams; the picture's total is their sum
+                float fe = 0, be = 0;
+                (void)hipEventElapsedTime(&a, s->ev[0], s->ev[6]);
+                (void)hipEventElapsedTime(&sel, s->ev[6], s->ev[1]);
+                (void)hipEventElapsedTime(&an, s->ev[1], s->ev[7]);
+                (void)hipEventElapsedTime(&fe, s->ev[0], s->ev[7]);
+                (void)hipEventElapsedTime(&be, s->ev[8], s->ev[4]);
+                tot = fe + be;
+                if (s->fused) { (void)hipEventElapsedTime(&b, s->ev[8], s->ev[11]); b += an; (void)hipEventElapsedTime(&ip, s->ev[5], s->ev[11]); } // analysis + fused stage + intra macroblocks, booked as inter
+                else { (void)hipEventElapsedTime(&sp, s->ev[8], s->ev[5]); (void)hipEventElapsedTime(&b, s->ev[5], s->ev[11]); }
+                h->st.ms_select += sel; h->st.ms_analyse_p += an; h->st.ms_intra_p += ip;
+            }
+            (void)hipEventElapsedTime(&c, s->ev[2], s->ev[3]);
+        }
+        if (s->is_idr) { h->st.ms_intra += a; h->st.n_intra++; }
+        else { h->st.ms_me += a; h->st.n_me++; h->st.ms_inter += b; h->st.n_inter++; h->st.ms_subpel += sp; }
+        h->st.ms_deblock += c; h->st.n_deblock++;
+        if (s->is_idr) { h->st.ms_deblock_idr += c; h->st.n_deblock_idr++; }
+        h->st.ms_total_gpu += tot; h->st.n_total_gpu++;
+    }
+    h->st.frames++; h->st.idr_frames += s->is_idr; h->st.bytes += n + m;
+    h->st.last_qp = (uint32_t)s->qp; h->st.last_drop = (uint32_t)s->drop; h->n_skip_pictures += s->all_skip; h->st.last_bytes = (uint32_t)(n + m); h->st.target_bps = h->want_bps.load();
+    h->last_slot = s; h->last_collected_rec = s->rec_index;
+    h->tail = (h->tail + 1) % NSLOT; h->pending--;
+    return MI355ENC_OK;
+}
+
+int mi355enc_encode(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride, int64_t pts, int force_idr,
+                    uint8_t *out, size_t out_cap, size_t *out_len, int *is_keyframe) {
+    if (!h) return MI355ENC_ERR_ARG;
+    if (h->pending) return MI355ENC_ERR_STATE;
+    int r = mi355enc_submit(h, y, y_stride, uv, uv_stride, pts, force_idr);
+    if (r) return r;
+    return mi355enc_collect(h, out, out_cap, out_len, is_keyframe, nullptr, nullptr);
+}
+
+} // extern "C"

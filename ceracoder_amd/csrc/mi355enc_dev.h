@@ -1,4 +1,4 @@
-/* Internal: types shared by the host orchestration (mi355enc.cpp), the host entropy coder
+/* Internal: types shared by the host orchestration (enc_*.cpp), the host entropy coder
  * (h264_host.c) and the HIP kernels (k_*.hip, kernels_common.hpp).  Not part of the C ABI. */
 #ifndef MI355ENC_DEV_H
 #define MI355ENC_DEV_H

@@ -1674,7 +1674,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
 struct orc_enc {
     int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads, subpel;
     int frames_since_idr, idr_count, have_ref;
-    int scenecut, sc_cnt, prev_idr, sc_lag, prev_all_skip;                      /* scene-cut recovery: mirrors mi355enc.cpp (collect / enqueue_picture) */
+    int scenecut, sc_cnt, prev_idr, sc_lag, prev_all_skip;                      /* scene-cut recovery: mirrors enc_schedule.cpp (collect / enqueue_picture) */
     unsigned long long sc_sum, sc_force_at, pic_index;
     uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv, *prev_src_y;
     int prev_src_valid;
@@ -1829,7 +1829,7 @@ int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *u
 }
 void orc_enc_set_subpel(orc_enc_t *e, int on) { e->subpel = on; }
 void orc_enc_set_scenecut(orc_enc_t *e, int on) { e->scenecut = on; }
-void orc_enc_set_sc_lag(orc_enc_t *e, int lag) { e->sc_lag = lag < 2 ? 2 : lag; } /* mi355enc.cpp sc_lag(): pipeline_depth + 1 from depth 2 on */
+void orc_enc_set_sc_lag(orc_enc_t *e, int lag) { e->sc_lag = lag < 2 ? 2 : lag; } /* enc_schedule.cpp sc_lag(): pipeline_depth + 1 from depth 2 on */
 void orc_enc_set_me_iters(orc_enc_t *e, int n) { e->me_iters = n < 0 ? 0 : n; }
 const uint8_t *orc_enc_recon_y(const orc_enc_t *e) { return e->rec_y[e->cur]; }
 const uint8_t *orc_enc_recon_uv(const orc_enc_t *e) { return e->rec_uv[e->cur]; }
