@@ -167,6 +167,23 @@ def main():
                     "(BASELINE.json configs[2]: 'balancer driving the bitrate property'), none elsewhere")
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # One process per stream, as the reference runs them (bindings/typescript/src/process.ts:129-170): start the ranks ourselves, each a fresh
+        # child with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, its device and its CPU set (ceracoder_amd/multistream.py).  Nothing has touched
+        # the GPU in this process (no torch, no HIP so far), and the children are started, never exec'ed into.
+        from ceracoder_amd import multistream
+        code, out0, errs, plans = multistream.launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:], timeout=3000)
+        line = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+        if code or not line:
+            for r, e in sorted(errs.items()):
+                if e.strip():
+                    sys.stderr.write("--- rank %d stderr (tail) ---\n%s\n" % (r, e))
+            raise SystemExit(code or 1)
+        print(line[-1], flush=True)
+        return
+    from ceracoder_amd import multistream as _ms
+    _ms.self_plan()                   # ranks started by torch.distributed.run: same device / CPU plan as our own launcher's
+    rank_cpus = _ms.apply_affinity()  # before the first GPU call: threads created from here on (HIP's, the entropy coders) inherit it
     if args.streams_per_gpu > 1:  # every encoder owns five HIP streams; the runtime's default of 4 hardware queues would serialise them
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -176,7 +193,9 @@ def main():
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the encoder has no CPU path")
-    dev = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    dev = int(os.environ.get("MI355_BENCH_DEVICE", local_rank)) % n_dev
+    shared_gpu = args.shared_gpu or world > n_dev  # ranks beyond the box's GPUs share devices: no kernel may then wait on the device for another
     torch.cuda.set_device(dev)
 
     from ceracoder_amd import enc as E
@@ -215,7 +234,7 @@ def main():
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                          pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                         transform8x8=bool(args.dct8x8), cavlc_threads=args.cavlc_threads, exclusive=(S == 1 and not args.shared_gpu))
+                         transform8x8=bool(args.dct8x8), cavlc_threads=args.cavlc_threads, exclusive=(S == 1 and not shared_gpu))
 
     encs = [make_encoder() for _ in range(S)]
     e = encs[0]
@@ -397,7 +416,8 @@ def main():
                        "cbr, setpoint driven by the reference's '%s' balancer script (%d..%d kbit/s, tests/golden/balancer_%s.txt)" % (
                            script_name, min(b for _, b in script) // 1000, max(b for _, b in script) // 1000, script_name),
                        "me": "full search +-16 integer-pel SAD (surfaces kept) + %d median-regularised selection iterations + half-sample SAD / quarter-sample SATD refinement" % 3, "streams_per_gpu": S, "parallelism": "%d independent streams" % (world * S),
-                       "pipeline_depth": args.depth, "exclusive_device": bool(S == 1 and not args.shared_gpu), "dct8x8": bool(args.dct8x8), "cavlc_threads": int(st.cavlc_threads)},
+                       "pipeline_depth": args.depth, "exclusive_device": bool(S == 1 and not shared_gpu), "devices_on_box": n_dev, "ranks_share_devices": bool(world > n_dev),
+                       "rank0_cpus": rank_cpus if world > 1 else None, "rank0_numa_node": int(os.environ.get("MI355_BENCH_NUMA_NODE", "-1")), "dct8x8": bool(args.dct8x8), "cavlc_threads": int(st.cavlc_threads)},
             "roofline": roof,
             "roofline_kernels": kernels,
             "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "me_select_x3": round(st.ms_select / max(1, st.n_me), 4),
