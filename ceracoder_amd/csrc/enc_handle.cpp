@@ -10,7 +10,10 @@
 std::atomic<int> g_open_encoders{0};
 bool exclusive_device(const mi355enc_t *h) { static const bool env = getenv("MI355ENC_EXCLUSIVE") != nullptr; return h->cfg.exclusive_device != 0 || env; } // cfg.exclusive_device, or the environment for tools
 bool no_pgate() { static const bool off = getenv("MI355ENC_NO_PGATE") != nullptr; return off; } // A/B switch: the fused P stage in stream order behind the deblocking launch
-bool overlap_allowed() { static const bool serial = getenv("MI355ENC_SERIAL") != nullptr; return !serial && g_open_encoders.load(std::memory_order_relaxed) == 1; }
+bool overlap_allowed(const mi355enc_t *h) {
+    static const bool serial = getenv("MI355ENC_SERIAL") != nullptr;
+    return !serial && h->safe_level == 0 && g_open_encoders.load(std::memory_order_relaxed) == 1;
+}
 
 int sync_compute(mi355enc_t *h) {
     HIPCHK(hipStreamSynchronize(h->fstream));
@@ -170,6 +173,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     if (h->cfg.vbv_ms > 0) rc_set_vbv(&h->rc, h->cfg.vbv_ms);
     HIPCHK(hipStreamSynchronize(h->stream));
     h->ms_open = now_ms() - t_open; h->n_skip_pictures = 0;
+    h->safe_level = 0; h->n_recoveries = 0; h->last_error_word = 0;
     return MI355ENC_OK;
 }
 
@@ -256,6 +260,7 @@ int mi355enc_get_stats(mi355enc_t *h, mi355enc_stats_t *st) {
     st->target_bps = h->want_bps.load();
     st->cavlc_threads = (uint32_t)h->cfg.cavlc_threads;
     st->ms_open = h->ms_open; st->skip_pictures = h->n_skip_pictures;
+    st->recoveries = h->n_recoveries; st->last_error_word = h->last_error_word; st->safe_level = (uint32_t)h->safe_level;
     return MI355ENC_OK;
 }
 void mi355enc_reset_stats(mi355enc_t *h) { if (h) { memset(&h->st, 0, sizeof h->st); h->n_skip_pictures = 0; } }

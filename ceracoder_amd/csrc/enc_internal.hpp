@@ -52,6 +52,7 @@ struct slot_t {
     uint64_t index;            // position of the picture in the stream
     int is_idr, qp, drop, frame_num, idr_pic_id, rec_index, set;
     int64_t pts;
+    const uint8_t *src_y, *src_uv; int src_stride, force_idr; // what enqueue_picture() was given: a recovery re-enqueues the pictures in flight from here
 };
 
 struct mi355enc {
@@ -108,6 +109,11 @@ struct mi355enc {
     mi355enc_stats_t st;
     double ms_open;
     uint64_t n_skip_pictures;
+    // Degradation ladder of the device-side waits (collect(): recover()).  0: kernels may wait on the device for other kernels' progress
+    // (what exclusive_device and a single encoder per process allow); 1: kernels run in stream order, the only waits left are those between the
+    // workgroups of ONE persistent launch (bands of the intra wavefront / the deblocker); 2: one launch per wavefront step, no wait on the device at all.
+    int safe_level;
+    uint32_t n_recoveries, last_error_word;
 };
 
 static inline double now_ms() {
@@ -120,12 +126,13 @@ static inline unsigned *err_word(const mi355enc_t *h) { return h->d_progress; }
 extern std::atomic<int> g_open_encoders;
 bool exclusive_device(const mi355enc_t *h);
 bool no_pgate();
-bool overlap_allowed();
+bool overlap_allowed(const mi355enc_t *h);
 int sync_compute(mi355enc_t *h);
 // enc_schedule.cpp
 int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done = nullptr);
 int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done = nullptr,
                 unsigned *band_done = nullptr, bool after_gated_pmb = false);
 void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set = 0);
+int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride, int64_t pts, int force_idr);
 int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const planes[3], const int strides[3], hipStream_t up);
 #endif

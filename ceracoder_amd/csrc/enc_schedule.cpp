@@ -122,8 +122,7 @@ static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof,
 
 // Enqueue every device step of one picture whose source is described by (src_y, src_uv, src_stride).  Anything the caller
 // uploaded for this picture was enqueued on the same stream.
-static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride,
-                           int64_t pts, int force_idr) {
+int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride, int64_t pts, int force_idr) {
     const int idr = force_idr || !h->have_ref || h->frames_since_idr >= h->cfg.gop ||
                     (h->n_submitted == h->sc_force_at && h->frames_since_idr >= sc_lag(h)); // scene-cut recovery, see collect(): not when an IDR picture came in between
     if (idr) h->frames_since_idr = 0;
@@ -175,7 +174,10 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         // x + y) overlap -- intra_p_kernel runs on a stream of its own and the deblocker's movers follow its per-row progress words
         // (GATED, k_deblock.hip); the chain pmb -> prep -> deblocker -> next pmb stays on one stream (a cross-stream event on the
         // chain costs 10-17 us).  Not on pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
-        const int split = !idr && fused && c->intra_p && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
+        // Every kernel-waits-for-kernel overlap below is opt-in (cfg.exclusive_device): next to another process's kernels on the same GPU a
+        // kernel that waits on the device for a kernel that has not been placed yet can run into the bound of its wait.
+        const bool may_wait = overlap_allowed(h) && exclusive_device(h) && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof;
+        const int split = !idr && fused && c->intra_p && may_wait;
         // IDR picture: the band deblocker runs on the intra stream BESIDE the intra wavefront, each of its bands waiting for the intra bands
         // of the same rows (flags + acquire); in an all-intra stream the next picture's wavefront then starts while this one is still
         // being deblocked.  What has to wait for such a deblocking: a P picture (it reads the whole reference), and whoever writes
@@ -183,13 +185,13 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
         // P picture whose reference is still being deblocked: the fused stage leaves the chain too.  It runs on the intra stream, each of
         // its waves waiting for the reference's bands it reads (pmb_kernel<GATED>), so it is all but done when that deblocking ends.
         const size_t nbd = k_deblock_done_bytes() / sizeof(unsigned); // words per reconstruction buffer
-        const int pgate = !idr && fused && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed() && h->rec_epoch[h->cur] != 0 && exclusive_device(h) && !no_pgate();
+        const int pgate = !idr && fused && may_wait && h->rec_epoch[h->cur] != 0 && !no_pgate();
         HIPCHK(hipStreamWaitEvent(pgate ? h->istream : h->stream, s->ev_front, 0));
         // ... and with three pictures in flight (the next picture's front stages are done long before this launch ends) the deblocking launches go back
         // to back, each waiting on the device for its picture's rows; with fewer the host sits on the chain and a launch waiting on the chip only
         // gets in the way (1080p depth 1: 4465 -> 3980 frames/s, 2160p: 2050 -> 1615)
         const int prows = pgate && h->cfg.pipeline_depth >= 2;
-        const int isplit = idr && h->cfg.intra_mode == 0 && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && overlap_allowed();
+        const int isplit = idr && h->cfg.intra_mode == 0 && may_wait;
         for (int b = 0; b < 2; b++)
             if (h->dbI_busy[b] && (!idr || b == nxt)) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_dbI[b], 0)); h->dbI_busy[b] = 0; }
         if (idr) {
@@ -224,6 +226,7 @@ static int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const
     }
     h->n_submitted++;
     s->is_idr = idr; s->qp = qp; s->drop = drop; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
+    s->src_y = src_y; s->src_uv = src_uv; s->src_stride = src_stride; s->force_idr = force_idr;
     s->pts = pts; s->rec_index = nxt; s->set = set; s->prof = prof; s->fused = fused && !idr; s->index = h->n_submitted - 1; s->all_skip = all_skip;
     if (idr) h->idr_count++;
     h->frames_since_idr++;
@@ -252,6 +255,59 @@ int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const p
         if (k_launch_csc(fmt, s->d_raw, nullptr, nullptr, r0, 0, 0, s->d_src_y, s->d_src_uv, w, ht, h->W, h->H, up)) return MI355ENC_ERR_ARG;
     }
     HIPCHK(hipGetLastError());
+    return MI355ENC_OK;
+}
+
+static const char *wait_name(unsigned code) {
+    switch (code) {
+    case 3: return "pmb_kernel waiting for the reference's deblocking bands";
+    case 4: return "wait_started_kernel";
+    case 11: return "deblocker waiting for the intra bands";
+    case 12: return "deblocker waiting for the strips of the band above";
+    case 13: return "deblocker waiting for intra_p_kernel";
+    case 14: return "intra band waiting for the lines of the band above";
+    case 15: return "intra_p_kernel waiting for the row above";
+    case 16: return "progress counter";
+    case 17: return "deblocker waiting for pmb_kernel's rows";
+    default: return "injected / unknown";
+    }
+}
+// A bounded wait on the device ran out (the kernels report it in the sticky word d_progress[0], which the hand-over copies into h_hdr[1]; once
+// it is set nobody waits any more, so everything in flight completes, possibly from data that was not final).  Nothing that was produced since
+// can be trusted, but nothing needs to be lost either: the sources of the pictures in flight are still where submit() put them (the slots'
+// staging surfaces, or the caller's device memory, which stays valid until the matching collect()).  So: drain, clear the device-side words,
+// step one level down the ladder of mi355enc::safe_level, and enqueue the pictures in flight again, the first one as an IDR picture.  The
+// stream continues without a gap; the decoder re-synchronises at that IDR picture.
+static int recover(mi355enc_t *h, unsigned code) {
+    h->safe_level++;
+    h->n_recoveries++; h->last_error_word = code;
+    fprintf(stderr, "mi355enc: a device-side wait timed out (error word %u: %s); %s\n", code, wait_name(code),
+            h->safe_level == 1 ? "re-encoding the pictures in flight from an IDR picture; kernels run in stream order from now on" :
+            h->safe_level == 2 ? "again: one launch per wavefront step from now on (no waits on the device at all)" : "giving up");
+    if (h->safe_level > 2) return MI355ENC_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(h->cstream));
+    { int r = sync_compute(h); if (r) return r; }
+    HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * sizeof(unsigned), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->pmb_rows_total = 0; h->db_started_total = 0; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->dbI_busy[0] = h->dbI_busy[1] = 0;
+    if (h->safe_level == 2) { h->cfg.deblock_mode = 1; h->cfg.intra_mode = 1; }
+    const int n = h->pending;
+    struct { const uint8_t *y, *uv; int stride, force_idr; int64_t pts; } again[NSLOT];
+    for (int i = 0; i < n; i++) {
+        slot_t *p = &h->slot[(h->tail + i) % NSLOT];
+        again[i] = {p->src_y, p->src_uv, p->src_stride, p->force_idr, p->pts};
+        if (p->is_idr) h->idr_count--;
+        p->h_hdr[1] = 0;
+    }
+    for (int i = 0; i < n; i++) rc_cancel(&h->rc); // their rate-control bookings, newest first
+    h->n_submitted -= (uint64_t)n; h->head = h->tail; h->pending = 0; h->have_ref = 0;
+    for (int i = 0; i < n; i++) {
+        int r = enqueue_picture(h, &h->slot[h->head], again[i].y, again[i].uv, again[i].stride, again[i].pts, i == 0 ? 1 : again[i].force_idr);
+        if (r) return r;
+    }
     return MI355ENC_OK;
 }
 
@@ -305,9 +361,12 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     if (!s->all_skip) HIPCHK(hipEventSynchronize(s->done));
     double t1 = now_ms();
     h->st.ms_wait += t1 - t0;
-    if (s->h_hdr[1]) { // sticky: set by a band of an earlier picture's deblocking launch that gave up waiting
-        fprintf(stderr, "mi355enc: a device-side wait timed out (error word %u: 3 pmb_kernel gate, 4 wait_started_kernel, 11 deblocker / intra bands, 12 deblocker / strips, 13 deblocker / intra_p_kernel, 14 intra band / strips, 15 intra_p_kernel / row above, 16 progress counter)\n", s->h_hdr[1]);
-        return MI355ENC_ERR_HIP;
+    for (int attempt = 0; s->h_hdr[1]; attempt++) { // set by a kernel of this or an earlier picture that gave up waiting on the device
+        if (attempt >= 2) return MI355ENC_ERR_HIP;
+        int r = recover(h, s->h_hdr[1]);
+        if (r) return r;
+        s = &h->slot[h->tail];
+        if (!s->all_skip) HIPCHK(hipEventSynchronize(s->done));
     }
     size_t n = 0;
     if (s->is_idr) {

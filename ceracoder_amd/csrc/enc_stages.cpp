@@ -17,6 +17,10 @@ int mi355enc_stage_csc(mi355enc_t *h, int fmt, const uint8_t *const planes[3], c
 }
 
 // ---------------------------------------------------------------- single-stage entry points
+// A single-stage call overwrites the reconstruction buffers, the previous-source planes and the record sets behind the encoder's back: the
+// next picture submitted through the pipeline must not predict from any of it, so it is coded as an IDR picture and nothing of the
+// previous picture's on-device progress words is trusted.
+static void stage_touched(mi355enc_t *h) { h->have_ref = 0; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->dbI_busy[0] = h->dbI_busy[1] = 0; }
 static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging, int drop = 0, int idr = 0) {
     if (h->pending) return MI355ENC_ERR_STATE;
     slot_t *s = &h->slot[0];
@@ -29,6 +33,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging, int drop = 0, i
     fill_ctx(h, c, qp, drop, idr);
     c->all_intra = 0; // the single-stage deblocking entry point takes records of either picture type
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
+    stage_touched(h);
     return 0;
 }
 static int upload_luma_pair(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y) {
@@ -151,14 +156,30 @@ int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }
+int mi355enc_debug_trip_wait(mi355enc_t *h, unsigned code) {
+    if (!h || !code) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    HIPCHK(hipStreamSynchronize(h->cstream));
+    { int r = sync_compute(h); if (r) return r; }
+    HIPCHK(hipMemcpy(h->d_progress, &code, sizeof code, hipMemcpyHostToDevice));
+    return MI355ENC_OK;
+}
 int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
     if (!h || !avg_ms || iters < 1 || stage < 0 || stage > 10) return MI355ENC_ERR_ARG;
     if (h->pending) return MI355ENC_ERR_STATE;
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[0];
-    // a valid context in both places: the last picture's host copy (slot 0) re-uploaded, or a fresh stage context
-    if (!h->have_ref) { int r = stage_ctx(h, 26, true); if (r) return r; }
-    else HIPCHK(hipMemcpyAsync(h->d_ctx, s->h_ctx, sizeof(frame_ctx_t), hipMemcpyHostToDevice, h->stream));
+    // a valid context in both places: the LAST COLLECTED picture's host copy (the slots rotate: it is slot 0's only one time in three), brought
+    // to slot 0 and re-uploaded -- or a fresh stage context.  The stages run on that picture's surfaces in place (stage 3 filters its
+    // reconstruction again), so the next picture through the pipeline starts a new GOP.
+    if (!h->have_ref || !h->last_slot) { int r = stage_ctx(h, 26, true); if (r) return r; }
+    else {
+        { int r = sync_compute(h); if (r) return r; }
+        HIPCHK(hipStreamSynchronize(h->cstream));
+        if (h->last_slot != s) *s->h_ctx = *h->last_slot->h_ctx;
+        HIPCHK(hipMemcpyAsync(h->d_ctx, s->h_ctx, sizeof(frame_ctx_t), hipMemcpyHostToDevice, h->stream));
+        stage_touched(h);
+    }
     if (stage >= 5 && !s->d_raw) { // input conversion (5 I420, 6 YUY2, 7 UYVY): any bytes will do as a source
         HIPCHK(hipMalloc((void **)&s->d_raw, (size_t)(2 * h->W + 32) * h->H + 64));
         HIPCHK(hipMemsetAsync(s->d_raw, 0x55, (size_t)(2 * h->W + 32) * h->H + 64, h->stream));

@@ -40,7 +40,8 @@ GST_DEBUG_CATEGORY_STATIC(mi355_debug);
 typedef struct {
     GstVideoEncoder parent;
     /* properties (guarded by the object lock; bitrate is additionally forwarded atomically) */
-    guint bps;          /* bit/s */
+    guint rate_raw;     /* the target as it was written: through "bps" in the unit the element's NAME implies, through "bitrate" in kbit/s */
+    gboolean rate_is_bps; /* the last write came through "bps" */
     guint key_int_max;
     gint device_id, me_range, qp, pipeline_depth, speed_preset;
     gint open_depth;  /* pipeline-depth the encoder was opened with: a write to the property in mid-stream takes effect at the next (re)negotiation */
@@ -89,13 +90,16 @@ static guint bps_unit(GstMi355H264Enc *s) {
     return (n && strcmp(n, "venc_kbps") == 0) ? 1000u : 1u;
 }
 static guint clamp_bps(guint64 v) { return v < 1000 ? 1000u : v > 1000000000u ? 1000000000u : (guint)v; }
+/* The target in bit/s, resolved where it is consumed (object lock held): `mi355h264enc bps=6000 name=venc_kbps` sets the property before
+ * the element has its name, and g_object_set followed by gst_object_set_name does the same -- a unit applied at write time would be wrong. */
+static guint target_bps(GstMi355H264Enc *s) { return clamp_bps((guint64)s->rate_raw * (s->rate_is_bps ? bps_unit(s) : 1000u)); }
 
 static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *ps) {
     GstMi355H264Enc *s = GST_MI355H264ENC(obj);
     GST_OBJECT_LOCK(s);
     switch (id) {
-    case PROP_BPS: s->bps = clamp_bps((guint64)g_value_get_uint(val) * bps_unit(s)); if (s->enc) mi355enc_set_bitrate(s->enc, s->bps); break;
-    case PROP_BITRATE: s->bps = g_value_get_uint(val) * 1000u; if (s->enc) mi355enc_set_bitrate(s->enc, s->bps); break;
+    case PROP_BPS: s->rate_raw = g_value_get_uint(val); s->rate_is_bps = TRUE; if (s->enc) mi355enc_set_bitrate(s->enc, target_bps(s)); break;
+    case PROP_BITRATE: s->rate_raw = g_value_get_uint(val); s->rate_is_bps = FALSE; if (s->enc) mi355enc_set_bitrate(s->enc, target_bps(s)); break;
     case PROP_KEY_INT_MAX: s->key_int_max = g_value_get_uint(val); break;
     case PROP_DEVICE_ID: s->device_id = g_value_get_int(val); break;
     case PROP_ME_RANGE: s->me_range = g_value_get_int(val); break;
@@ -117,8 +121,8 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     GstMi355H264Enc *s = GST_MI355H264ENC(obj);
     GST_OBJECT_LOCK(s);
     switch (id) {
-    case PROP_BPS: g_value_set_uint(val, s->bps / bps_unit(s)); break;
-    case PROP_BITRATE: g_value_set_uint(val, s->bps / 1000u); break;
+    case PROP_BPS: g_value_set_uint(val, s->rate_is_bps ? s->rate_raw : target_bps(s) / bps_unit(s)); break;
+    case PROP_BITRATE: g_value_set_uint(val, target_bps(s) / 1000u); break;
     case PROP_KEY_INT_MAX: g_value_set_uint(val, s->key_int_max); break;
     case PROP_DEVICE_ID: g_value_set_int(val, s->device_id); break;
     case PROP_ME_RANGE: g_value_set_int(val, s->me_range); break;
@@ -178,7 +182,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     mi355enc_default_cfg(&cfg, GST_VIDEO_INFO_WIDTH(vi), GST_VIDEO_INFO_HEIGHT(vi), fn, fd);
     GST_OBJECT_LOCK(s);
     cfg.gop = s->key_int_max ? (int)s->key_int_max : 250;
-    cfg.me_range = s->me_range; cfg.bitrate_bps = s->bps; cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
+    cfg.me_range = s->me_range; cfg.bitrate_bps = target_bps(s); cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
     cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0; cfg.scenecut = s->scenecut ? 1 : 0; cfg.exclusive_device = s->exclusive_gpu ? 1 : 0; cfg.vbv_ms = (int)s->vbv_ms; cfg.intra_in_p = s->intra_in_p ? 1 : 0;
     GST_OBJECT_UNLOCK(s);
     int r = mi355enc_open(&cfg, &e);
@@ -191,7 +195,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     GST_OBJECT_LOCK(s);
     s->enc = e;
     s->open_depth = cfg.pipeline_depth;
-    mi355enc_set_bitrate(e, s->bps); /* a write that raced with open() must not be lost */
+    mi355enc_set_bitrate(e, target_bps(s)); /* a write that raced with open() must not be lost */
     GST_OBJECT_UNLOCK(s);
     s->max_au = mi355enc_max_au_bytes(e);
     g_free(s->au_buf);
@@ -354,7 +358,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
     v->finish = enc_finish; v->flush = enc_flush; v->propose_allocation = enc_propose_allocation;
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
-    s->bps = 2048000; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
+    s->rate_raw = 2048; s->rate_is_bps = FALSE; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
     s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = TRUE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
 }
 

@@ -62,6 +62,7 @@ int rc_pick_qp(rc_state_t *rc, int is_idr);
  * Every rc_pick() is followed (possibly one picture later) by one rc_update() for the same picture, in the same order. */
 void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop);
 void rc_update(rc_state_t *rc, int is_idr, int qp, int drop, size_t bytes);
+void rc_cancel(rc_state_t *rc);
 
 #ifdef __cplusplus
 }

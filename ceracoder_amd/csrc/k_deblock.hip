@@ -375,10 +375,14 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
         // The fused P stage of the same picture may still be running (pmb_kernel<GATED>, on another stream; this launch sits directly behind
         // the previous picture's): it stores samples and records through to memory and then counts each macroblock for its row.  This
         // band reads the records of its own rows and of the two neighbouring bands' (their work flags), and the samples of its own: it
-        // starts when those rows are complete -- the counts only grow, a.row_need is what they reach with this picture.
+        // starts when those rows are complete -- the counts only grow, a.row_need is what they reach with this picture.  One row more at
+        // the top: the work flag of the band above comes from db_record() over ITS macroblocks, and the record of a macroblock in its first
+        // row reads the macroblock above it -- the last row of the band above THAT.  (Without it this band could take a stale record there
+        // for an intra macroblock, expect strips from a band that -- seeing the final record -- had nothing to filter and left at once,
+        // and wait for them until the bound: error word 12, once in several thousand pictures at low rates, where bands are often idle.)
         if (threadIdx.x < 64) {
-            const int r = (band - 1) * ROWS + (int)threadIdx.x;
-            const bool mine = (int)threadIdx.x < 3 * ROWS && r >= 0 && r < mbh;
+            const int r = (band - 1) * ROWS - 1 + (int)threadIdx.x;
+            const bool mine = (int)threadIdx.x < 3 * ROWS + 1 && r >= 0 && r < mbh;
             const unsigned *w = a.row_done + (mine ? r : 0);
             int spins = 0;
             while (__ballot(mine && (int)(ld_sc1(w) - a.row_need) < 0)) {
@@ -702,7 +706,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
 
 template <int ROWS, bool ALL_INTRA, bool GATED>
 __global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[]; // ROWS rows of tiles, then the band's records (ROWS * mbw * 64 bytes) and three flags
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[]; // ROWS rows of tile rings, then three work flags and the rows' first intra macroblocks
     const int nl = gridDim.x >> 1;
     if (blockIdx.x == 0) tl_first(&a.ctx, 7);
     if (a.started && threadIdx.x == 0) __hip_atomic_fetch_add(a.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this workgroup holds its place on a CU (wait_started_kernel)
@@ -728,9 +732,8 @@ size_t k_deblock_gran_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the movers follow its per-row progress words.
 template <typename K>
 static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStream_t s) {
-    const size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + 16 + 4 * DB_ROWS;
-    static size_t granted = 48 * 1024; // above 64 KB of dynamic LDS the kernel has to be told (4K pictures: 80 KB; the device has 160 KB per CU)
-    if (lds > granted) { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted = lds; }
+    constexpr size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + 16 + 4 * DB_ROWS; // the rows' tile rings + three work flags + the rows' first intra macroblocks: ~12.5 KB
+    static_assert(lds <= 48 * 1024, "above 48 KB of dynamic LDS every instantiation launched here would need hipFuncAttributeMaxDynamicSharedMemorySize");
     hipLaunchKernelGGL(kernel, dim3(2 * nbands), dim3(192 * DB_ROWS), lds, s, a);
 }
 // One wave that ends once `count` workgroups of band-deblocking launches have been placed since the encoder was opened (the count only

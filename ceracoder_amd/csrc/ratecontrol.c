@@ -148,6 +148,12 @@ void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
     rc->gop_bits -= target;
     rc->gop_left--;
 }
+/* takes the newest pick back (the picture will be picked again: a recovery re-enqueues the pictures in flight) */
+void rc_cancel(rc_state_t *rc) {
+    if (rc->n_pick == rc->n_upd) return;
+    rc->gop_bits += rc->plan[--rc->n_pick & 3];
+    rc->gop_left++;
+}
 int rc_pick_qp(rc_state_t *rc, int is_idr) {
     int qp, drop;
     rc_pick(rc, is_idr, &qp, &drop);

@@ -32,7 +32,7 @@ EXPORTS = [
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
     "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_pmb", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
     "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
-    "mi355enc_rc_pick", "mi355enc_rc_update", "mi355enc_host_cavlc_block",
+    "mi355enc_rc_pick", "mi355enc_rc_update", "mi355enc_host_cavlc_block", "mi355enc_debug_trip_wait",
 ]
 
 
@@ -48,7 +48,8 @@ class Stats(C.Structure):
                 ("last_bytes", C.c_uint32), ("target_bps", C.c_uint32), ("ms_me", C.c_double), ("ms_inter", C.c_double),
                 ("ms_intra", C.c_double), ("ms_deblock", C.c_double), ("ms_total_gpu", C.c_double), ("ms_subpel", C.c_double), ("n_me", C.c_uint64),
                 ("n_inter", C.c_uint64), ("n_intra", C.c_uint64), ("n_deblock", C.c_uint64), ("ms_entropy", C.c_double),
-                ("ms_wait", C.c_double), ("n_total_gpu", C.c_uint64), ("ms_deblock_idr", C.c_double), ("n_deblock_idr", C.c_uint64), ("cavlc_threads", C.c_uint32), ("last_drop", C.c_uint32), ("ms_select", C.c_double), ("ms_analyse_p", C.c_double), ("ms_intra_p", C.c_double), ("skip_pictures", C.c_uint64), ("ms_open", C.c_double)]
+                ("ms_wait", C.c_double), ("n_total_gpu", C.c_uint64), ("ms_deblock_idr", C.c_double), ("n_deblock_idr", C.c_uint64), ("cavlc_threads", C.c_uint32), ("last_drop", C.c_uint32), ("ms_select", C.c_double), ("ms_analyse_p", C.c_double), ("ms_intra_p", C.c_double), ("skip_pictures", C.c_uint64), ("ms_open", C.c_double),
+                ("recoveries", C.c_uint32), ("last_error_word", C.c_uint32), ("safe_level", C.c_uint32)]
 
 
 _lib = None
@@ -98,6 +99,7 @@ def load():
         L.mi355enc_stage_deblock.argtypes = [vp, vp, vp, vp]
         L.mi355enc_submit_fmt.argtypes = [vp, C.c_int, vp, vp, C.c_int64, C.c_int]
         L.mi355enc_stage_csc.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+        L.mi355enc_debug_trip_wait.argtypes = [vp, C.c_uint]
         L.mi355enc_time_stage.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mi355enc_host_write_headers.argtypes = [C.c_int] * 5 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_write_slice.argtypes = [C.c_int] * 7 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -368,6 +370,10 @@ class Encoder:
         y, uv = np.ascontiguousarray(rec_y).copy(), np.ascontiguousarray(rec_uv).copy()
         self._chk(self.L.mi355enc_stage_deblock(self.h, _p(y), _p(uv), _p(np.ascontiguousarray(mbi))), "stage_deblock")
         return y, uv
+
+    def debug_trip_wait(self, code):
+        """fault injection: as if a bounded device-side wait had just run out (include/mi355enc.h)"""
+        self._chk(self.L.mi355enc_debug_trip_wait(self.h, int(code)), "debug_trip_wait")
 
     def time_stage(self, stage, iters=20):
         ms = C.c_double(0)

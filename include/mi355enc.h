@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355ENC_ABI_VERSION 2
+#define MI355ENC_ABI_VERSION 3
 
 enum {
     MI355ENC_OK = 0,
@@ -108,6 +108,10 @@ typedef struct {
     uint64_t skip_pictures;   /* pictures coded as one P_Skip run (rate control's last resort) */
     double ms_open;           /* wall time mi355enc_open() took (device selection, allocations, stream creation): must stay far below
                                  the 1 s tick of the reference's stall watchdog, /root/reference/src/ceracoder.c:152-200; survives reset_stats */
+    uint32_t recoveries;      /* times a bounded device-side wait ran out and the pictures in flight were re-encoded from an IDR picture
+                                 (survives reset_stats); last_error_word: which wait it was (text on stderr); safe_level: 0 kernels may wait
+                                 on the device for each other, 1 stream order only, 2 one launch per wavefront step (no device-side wait left) */
+    uint32_t last_error_word, safe_level;
 } mi355enc_stats_t;
 
 /* Fill cfg with the defaults of the element (gop 60, me_range 16, 2048 kbit/s like x264enc). */
@@ -150,6 +154,11 @@ int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const v
 int mi355enc_pending(const mi355enc_t *h);
 int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_len, int *is_keyframe,
                      int64_t *pts, int *qp);
+
+/* Fault injection (tests): behaves as if a kernel's bounded wait on the device had just run out with error word `code` (> 0): waits
+ * for the device to drain, then sets the sticky word every waiting kernel reports through.  The pictures submitted next come back from
+ * collect() through the recovery path: re-encoded in stream order, starting with an IDR picture; stats.recoveries counts it. */
+int mi355enc_debug_trip_wait(mi355enc_t *h, unsigned code);
 
 int mi355enc_get_stats(mi355enc_t *h, mi355enc_stats_t *st);
 void mi355enc_reset_stats(mi355enc_t *h);

@@ -217,6 +217,11 @@ int main(int argc, char **argv) {
     gst_bus_add_watch(bus, bus_cb, NULL);
     int have_enc = encoder_control_init(&enc, pipeline) == 0;
     int first = script_n ? script[0].bps : 6000000;
+    if (have_enc && g_object_class_find_property(G_OBJECT_GET_CLASS(enc.element), "bitrate")) { /* what the pipeline text itself set, before the first control write */
+        guint b0 = 0, k0 = 0;
+        g_object_get(G_OBJECT(enc.element), "bps", &b0, "bitrate", &k0, NULL);
+        fprintf(stderr, "{\"bps_from_pipeline_text\":%u,\"bitrate_kbps_from_pipeline_text\":%u}\n", b0, k0);
+    }
     if (have_enc) encoder_control_set_bitrate(&enc, first); /* state NULL, as ceracoder.c:515-518 */
     guint bps_prop = 0, kbps_prop = 0;
     if (have_enc) g_object_get(G_OBJECT(enc.element), "bps", &bps_prop, NULL);

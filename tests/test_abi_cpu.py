@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(E.EXPORTS) == declared, set(declared) ^ set(E.EXPORTS)
-    assert L.mi355enc_abi_version() == 2
+    assert L.mi355enc_abi_version() == 3
 
 
 def test_error_strings_and_defaults():

@@ -81,6 +81,23 @@ def test_reference_encoder_control_drives_bps_in_null_state(tmp_path, name, div)
         assert r.returncode == 3 and "no usable HIP device" in r.stderr, r.stderr
 
 
+@needs_gst
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref not built")
+@pytest.mark.parametrize("line,bps,kbps", [("mi355h264enc bps=6000 name=venc_kbps", 6000, 6000), ("mi355h264enc name=venc_kbps bps=6000", 6000, 6000),
+                                           ("mi355h264enc bps=5000000 name=venc_bps", 5000000, 5000), ("mi355h264enc bitrate=3500 name=venc_kbps", 3500, 3500),
+                                           ("mi355h264enc bitrate=3500 name=venc_bps", 3500000, 3500)])
+def test_bps_unit_is_resolved_when_used_not_when_written(tmp_path, line, bps, kbps):
+    """gst_parse_launch sets properties in text order: with `bps=6000 name=venc_kbps` the value arrives before the element has the name that
+    gives it its unit (encoder_control.c:29-36).  The element keeps what was written and applies the unit where the target is consumed."""
+    pf = tmp_path / "pipe"
+    pf.write_text("videotestsrc num-buffers=1 ! video/x-raw,width=320,height=192,framerate=30/1,format=NV12 ! %s ! appsink name=appsink sync=false\n" % line)
+    script = tmp_path / "script"
+    script.write_text("0 4300000\n")
+    r = subprocess.run([HARNESS, str(pf), str(tmp_path / "out.bin"), str(script)], env=gst_env(), capture_output=True, text=True, timeout=120)
+    info = json.loads([l for l in r.stderr.splitlines() if l.startswith("{\"bps_from_pipeline_text\"")][0])
+    assert info == {"bps_from_pipeline_text": bps, "bitrate_kbps_from_pipeline_text": kbps}
+
+
 def test_pipeline_files_name_the_element_like_the_reference():
     """The swap point is one token: same line shape as pipeline/generic/x264_superfast_*:5-6."""
     d = os.path.join(ROOT, "pipeline", "mi355x")
