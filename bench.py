@@ -95,6 +95,35 @@ def gst_latency(width, height, fps, gop, bps, dev, seconds=4):
     return out
 
 
+def gst_throughput(width, height, fps, gop, bps, dev, depth, buffers=660):
+    """M1 through the element (SURVEY 8d "Timing method"): a NON-live source, the element instantiated by gst_parse_launch the way
+    /root/reference/src/io/pipeline_loader.c:59 does, wall-clock between buffers arriving at the sink behind it, first GOP discarded.
+    The source is videotestsrc (what the reference's own test pipelines use); its own ceiling -- the same source into the same sink
+    without the encoder -- is measured beside it, because at 1080p it paints slower than the encoder codes."""
+    import subprocess
+    probe = os.path.join(ROOT, "ceracoder_amd", "mi355_gst_probe")
+    if not (os.path.exists(probe) and os.path.exists("/opt/conda/lib/gstreamer-1.0")):
+        return {"unavailable": "GStreamer 1.14 of this image or the probe binary not found"}
+    env = dict(os.environ)
+    env.update(GST_PLUGIN_SYSTEM_PATH="/opt/conda/lib/gstreamer-1.0", GST_PLUGIN_SCANNER="/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner",
+               GST_REGISTRY="/tmp/ceracoder_amd_gst_registry_bench.bin", GST_PLUGIN_PATH=os.path.join(ROOT, "ceracoder_amd", "gst-plugins"),
+               LD_PRELOAD="/usr/lib/x86_64-linux-gnu/libstdc++.so.6")
+    src = "videotestsrc is-live=false num-buffers=%d pattern=smpte horizontal-speed=5 ! video/x-raw,width=%d,height=%d,framerate=%d/1,format=NV12" % (buffers, width, height, fps)
+    encoder = "mi355h264enc key-int-max=%d bps=%d device-id=%d pipeline-depth=%d exclusive-gpu=true name=venc_bps" % (gop, bps, dev, depth)
+    out = {}
+    for key, desc, extra in (("element", "%s ! queue ! %s ! appsink name=appsink sync=false" % (src, encoder), []),
+                             ("element_pageable_input", "%s ! queue ! %s pinned-input=false ! appsink name=appsink sync=false" % (src, encoder), []),
+                             ("source_alone", "%s ! queue ! appsink name=appsink sync=false" % src, ["--no-encoder"])):
+        try:
+            r = subprocess.run([probe, desc] + extra, env=env, capture_output=True, text=True, timeout=180)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            out[key] = {"frames_per_s": j.get("fps_after_first_gop"), "buffers_timed": j.get("buffers_timed"), "samples": j.get("samples")}
+        except Exception as e:
+            out[key] = {"unavailable": "probe failed: %s" % e}
+    out["pipeline"] = "%s ! queue ! %s ! appsink sync=false (non-live; wall-clock between buffers at the sink, first 60 discarded)" % (src, encoder)
+    return out
+
+
 def third_party_probe():
     """x264enc / an H.264 decoder / ffmpeg on the box would allow an x264 baseline and a third-party decode of
     our stream.  None of them is part of this image; record everything that was looked for instead of failing: programs,
@@ -324,8 +353,69 @@ def main():
                                        "%d fps (p50/p95) or back to back; appsink->SRT segment not measurable here (no libsrt / mpegtsmux in the image)" % fps,
                                "host_input_frames_per_s": round(1e3 / float(lat.mean()), 1)}
 
+        # (3) host input with three pictures in flight (pipeline_depth 2), through mi355enc_submit: from ordinary (pageable) memory -- one
+        # staging pass of the calling thread per picture, then an asynchronous transfer beside the kernels -- and from memory obtained with
+        # mi355enc_host_alloc (what the element offers its upstream through the ALLOCATION query): transferred in place.  PCIe included.
+        def host_run(src_frames, n):
+            he = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=2, cavlc_threads=args.cavlc_threads,
+                           exclusive=not shared_gpu)
+            def go(k, first):
+                for i in range(k):
+                    f = src_frames[bounce(first + i, len(src_frames))]
+                    he.submit(f[:height], f[height:], pts=first + i)
+                    if he.pending > 2:
+                        he.collect(copy=False)
+                while he.pending:
+                    he.collect(copy=False)
+            go(gop + 10, 0)  # warm-up: first GOP
+            t0 = time.perf_counter()
+            go(n, gop + 10)
+            dt_h = time.perf_counter() - t0
+            pinned = int(he.stats().pinned_inputs)
+            he.close()
+            return n / dt_h, pinned
+        n_host = min(args.steps, 300) if args.steps >= 60 else 120
+        r_page, _ = host_run(frames_np, n_host)
+        extra["host_input_depth2_frames_per_s"] = round(r_page, 1)
+        try:
+            nu = min(args.unique, 16)
+            pin = E.PinnedBuffer(nu * frames_np[0].nbytes)
+            pframes = pin.array.reshape((nu,) + frames_np[0].shape)
+            pframes[:] = frames_np[:nu]
+            r_pin, n_pinned = host_run(pframes, n_host)
+            extra["host_pinned_input_depth2_frames_per_s"] = round(r_pin, 1)
+            extra["host_input_note"] = ("mi355enc_submit from host memory, pipeline_depth 2, PCIe in the loop, %d pictures after a warm-up GOP: pageable numpy planes "
+                                        "(staged once by the calling thread) / planes in mi355enc_host_alloc memory (%d of them transferred in place)" % (n_host, n_pinned))
+            del pframes
+            pin.free()
+        except E.EncoderError as ex:
+            extra["host_pinned_input_depth2_frames_per_s"] = None
+            extra["host_input_note"] = "pinned leg failed: %s" % ex
+        # (4) an IDR picture's device time at this run's operating point, for the GOP-weighted rate of a timed region that holds no IDR picture
+        # (the driver's --steps 20): fixed QP = the timed region's mean, stage timers on, a forced IDR picture every third picture.
+        idr_probe = None
+        if gop > 1:
+            ie = E.Encoder(width, height, fps=fps, gop=10 ** 6, bitrate_bps=bps, device_id=dev, fixed_qp=int(round(float(np.mean(qps)))), pipeline_depth=0,
+                           profile_events=1, cavlc_threads=args.cavlc_threads)
+            for i in range(3):   # cold start: code objects, first launches
+                f = frames_np[bounce(i, args.unique)]
+                ie.encode(f[:height], f[height:], pts=i)
+            ie.reset_stats()
+            for i in range(3, 3 + 18):
+                f = frames_np[bounce(i, args.unique)]
+                ie.encode(f[:height], f[height:], pts=i, force_idr=(i % 3 == 0))
+            ist = ie.stats()
+            ie.close()
+            if ist.n_intra and ist.n_deblock_idr:
+                idr_probe = {"ms_intra": ist.ms_intra / ist.n_intra, "ms_deblock": ist.ms_deblock_idr / ist.n_deblock_idr, "samples": int(ist.n_intra),
+                             "qp": int(round(float(np.mean(qps))))}
+        extra["idr_probe"] = idr_probe
+
     if rank == 0 and world == 1 and not args.no_gst_latency:
         extra["latency_gst_ms"] = gst_latency(width, height, fps, gop, bps, dev)
+        g = gst_throughput(width, height, fps, gop, bps, dev, args.depth)
+        extra["gst_throughput"] = g
+        extra["gst_frames_per_s"] = (g.get("element") or {}).get("frames_per_s")
         extra["third_party"] = third_party_probe()
 
     if rank == 0:
@@ -398,19 +488,28 @@ def main():
         # What the device sustains over whole GOPs, whatever share of IDR pictures the timed region happened to hold: an IDR picture's stages run
         # strictly in order, so its time is its stage timers' sum; a P picture's stages overlap (front stream beside the previous picture's
         # deblocking, intra macroblocks beside the deblocker), so its effective period is what is left of the measured wall time.
-        t_i = st.ms_intra / max(1, st.n_intra) + db_i_avg
-        n_p_all = int(st.frames - st.idr_frames)
+        ip = extra.get("idr_probe")
+        if st.n_intra:
+            t_i, t_i_src = st.ms_intra / max(1, st.n_intra) + db_i_avg, "IDR pictures of the timed region"
+        elif ip:
+            t_i, t_i_src = ip["ms_intra"] + ip["ms_deblock"], "untimed IDR probe at the timed region's mean QP (%d), %d IDR pictures" % (ip["qp"], ip["samples"])
+        else:
+            t_i, t_i_src = 0.0, None
+        n_p_all = int(st.frames - st.idr_frames - st.skip_pictures)
         t_p = (dt * 1e3 - n_idr * t_i) / max(1, n_p_all)  # (per encoder: with several streams per GPU each one coded its own `steps` pictures in dt)
-        gop_fps = (1e3 * gop / ((gop - 1) * t_p + t_i)) if (gop > 1 and st.n_me and st.n_intra and t_p > 0) else None
+        gop_fps = (1e3 * gop / ((gop - 1) * t_p + t_i)) if (gop > 1 and st.n_me and t_i > 0 and t_p > 0) else None
         out = {
             "metric": "1080p H.264 encoded frames/sec per GPU" if args.workload.startswith("1080p") else "H.264 encoded frames/sec per GPU",
-            "value": round(world * S * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(world * S * (args.steps - int(st.skip_pictures)) / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / (S * args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic (S2: panning texture + 12 moving rectangles, seed 0x5EED), resident in HBM",
             "idr_in_timed_region": n_idr, "skip_pictures_in_timed_region": int(st.skip_pictures),
+            "value_note": "pictures that went through the device per second: rate control's all-skip pictures (one P_Skip run written by the host, no kernel) are not counted",
+            "frames_per_s_including_skip_pictures": round(world * S * args.steps / dt, 2),
             "gop_weighted_frames_per_s": round(gop_fps, 1) if gop_fps else None,
             "gop_weighted_note": "gop / ((gop-1) * t_P + t_IDR): t_IDR = an IDR picture's stage timers (its stages run in order), t_P = (wall time - IDR pictures * t_IDR) / "
                                  "P pictures of the timed region -- what the device sustains over whole GOPs, however many IDR pictures the timed region happened to contain",
+            "gop_weighted_t_idr_ms": round(t_i, 4) if t_i else None, "gop_weighted_t_idr_source": t_i_src,
             "config": {"workload": args.workload, "width": width, "height": height, "fps_nominal": fps, "gop": gop, "h2d_in_timed_region": False,
                        "rate_control": ("fixed qp %d" % args.fixed_qp) if args.fixed_qp >= 0 else ("cbr %d bit/s" % bps) if not script else
                        "cbr, setpoint driven by the reference's '%s' balancer script (%d..%d kbit/s, tests/golden/balancer_%s.txt)" % (

@@ -22,7 +22,37 @@ int sync_compute(mi355enc_t *h) {
     return 0;
 }
 
+// ---- pinned input memory (mi355enc_host_alloc): a process-wide list of ranges, so that submit() can tell a picture it may DMA from directly
+#include <mutex>
+#include <vector>
+static std::mutex g_pin_mu;
+static std::vector<std::pair<uintptr_t, size_t>> g_pins;
+bool host_range_pinned(const void *p, size_t bytes) {
+    const uintptr_t a = (uintptr_t)p;
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    for (const auto &r : g_pins)
+        if (a >= r.first && a + bytes <= r.first + r.second) return true;
+    return false;
+}
+
 extern "C" {
+
+void *mi355enc_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> g(g_pin_mu);
+    g_pins.emplace_back((uintptr_t)p, bytes);
+    return p;
+}
+void mi355enc_host_free(void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pin_mu);
+        for (size_t i = 0; i < g_pins.size(); i++)
+            if (g_pins[i].first == (uintptr_t)p) { g_pins.erase(g_pins.begin() + (long)i); break; }
+    }
+    (void)hipHostFree(p);
+}
 
 int mi355enc_abi_version(void) { return MI355ENC_ABI_VERSION; }
 
@@ -192,6 +222,7 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->h_mbi) (void)hipHostFree(s->h_mbi);
         if (s->h_levels) (void)hipHostFree(s->h_levels);
         if (s->h_hdr) (void)hipHostFree(s->h_hdr);
+        if (s->h_src) (void)hipHostFree(s->h_src);
         if (s->d_src_y) (void)hipFree(s->d_src_y);
         if (s->d_src_uv) (void)hipFree(s->d_src_uv);
         if (s->d_raw) (void)hipFree(s->d_raw);

@@ -43,6 +43,7 @@ struct slot_t {
     mb_info_t *h_mbi;     // pinned
     int16_t *h_levels;    // pinned: packed level stream, written by levels_pack_kernel over PCIe (no D2H copy)
     unsigned *h_hdr;      // pinned: [0] blocks in the stream, [1] error word of the band deblocker, [2 + r] first block of macroblock row r
+    uint8_t *h_src;              // pinned staging for pictures submitted from pageable host memory (allocated on first use): rows at stride W
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
     uint8_t *d_raw;              // staging of non-NV12 input before the conversion kernel (allocated on first use)
     hipEvent_t done, gpu_done, ev[12];
@@ -128,6 +129,7 @@ bool exclusive_device(const mi355enc_t *h);
 bool no_pgate();
 bool overlap_allowed(const mi355enc_t *h);
 int sync_compute(mi355enc_t *h);
+bool host_range_pinned(const void *p, size_t bytes); // inside memory handed out by mi355enc_host_alloc()
 // enc_schedule.cpp
 int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done = nullptr);
 int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done = nullptr,

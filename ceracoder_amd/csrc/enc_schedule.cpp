@@ -313,6 +313,11 @@ static int recover(mi355enc_t *h, unsigned code) {
 
 extern "C" {
 
+// Host input.  A picture in memory from mi355enc_host_alloc() is DMA'd from where it lies (the call returns at once; the memory is the
+// caller's again after the matching collect()).  Anything else is pageable as far as HIP knows: a stream-ordered copy from pageable memory
+// blocks the calling thread while the runtime stages it chunk by chunk through its own pinned buffers -- so the picture is copied once, by
+// this thread, into the slot's pinned staging buffer and leaves from there in one asynchronous transfer per plane, on the front stream,
+// beside the kernels of the pictures before it.
 int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride, int64_t pts, int force_idr) {
     if (!h || !y || !uv || y_stride < h->cfg.width || uv_stride < h->cfg.width) return MI355ENC_ERR_ARG;
     if (h->pending > h->cfg.pipeline_depth) return MI355ENC_ERR_STATE;
@@ -320,8 +325,20 @@ int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
     slot_t *s = &h->slot[h->head];
     const int w = h->cfg.width, ht = h->cfg.height;
     hipStream_t up = upload_stream(h);
-    HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, y, y_stride, w, ht, hipMemcpyHostToDevice, up));
-    HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, up));
+    if (host_range_pinned(y, (size_t)y_stride * (ht - 1) + w) && host_range_pinned(uv, (size_t)uv_stride * (ht / 2 - 1) + w)) {
+        HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, y, y_stride, w, ht, hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, up));
+        h->st.pinned_inputs++;
+    } else {
+        if (!s->h_src) HIPCHK(hipHostMalloc((void **)&s->h_src, h->ysz + h->csz, hipHostMallocDefault));
+        uint8_t *hy = s->h_src, *huv = s->h_src + (size_t)h->W * ht; // rows at the coded stride: each plane is one contiguous transfer
+        if (y_stride == h->W) memcpy(hy, y, (size_t)h->W * (ht - 1) + w);
+        else for (int r = 0; r < ht; r++) memcpy(hy + (size_t)r * h->W, y + (size_t)r * y_stride, (size_t)w);
+        if (uv_stride == h->W) memcpy(huv, uv, (size_t)h->W * (ht / 2 - 1) + w);
+        else for (int r = 0; r < ht / 2; r++) memcpy(huv + (size_t)r * h->W, uv + (size_t)r * uv_stride, (size_t)w);
+        HIPCHK(hipMemcpyAsync(s->d_src_y, hy, (size_t)h->W * (ht - 1) + w, hipMemcpyHostToDevice, up));
+        HIPCHK(hipMemcpyAsync(s->d_src_uv, huv, (size_t)h->W * (ht / 2 - 1) + w, hipMemcpyHostToDevice, up));
+    }
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
     return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }

@@ -49,7 +49,7 @@ typedef struct {
     gint threads;
     gboolean scenecut, exclusive_gpu;
     guint vbv_ms;
-    gboolean intra_in_p;
+    gboolean intra_in_p, pinned_input;
     /* streaming state */
     mi355enc_t *enc;
     GstVideoCodecState *input_state;
@@ -64,7 +64,7 @@ typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 G_DEFINE_TYPE(GstMi355H264Enc, gst_mi355h264enc, GST_TYPE_VIDEO_ENCODER)
 
 enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME_RANGE, PROP_QP, PROP_PIPELINE_DEPTH,
-       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE };
+       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE, PROP_PINNED_INPUT };
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-raw, format=(string){ NV12, I420, YUY2, UYVY }, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
@@ -113,6 +113,7 @@ static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *
     case PROP_EXCLUSIVE: s->exclusive_gpu = g_value_get_boolean(val); break;
     case PROP_VBV: s->vbv_ms = g_value_get_uint(val); break;
     case PROP_INTRA_IN_P: s->intra_in_p = g_value_get_boolean(val); break;
+    case PROP_PINNED_INPUT: s->pinned_input = g_value_get_boolean(val); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -136,6 +137,7 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     case PROP_EXCLUSIVE: g_value_set_boolean(val, s->exclusive_gpu); break;
     case PROP_VBV: g_value_set_uint(val, s->vbv_ms); break;
     case PROP_INTRA_IN_P: g_value_set_boolean(val, s->intra_in_p); break;
+    case PROP_PINNED_INPUT: g_value_set_boolean(val, s->pinned_input); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -277,7 +279,8 @@ static GstFlowReturn enc_handle_frame(GstVideoEncoder *ve, GstVideoCodecFrame *f
         strides[i] = GST_VIDEO_FRAME_PLANE_STRIDE(&vf, i);
     }
     int r = mi355enc_submit_fmt(s->enc, fmt, planes, strides, (int64_t)frame->pts, GST_VIDEO_CODEC_FRAME_IS_FORCE_KEYFRAME(frame) ? 1 : 0);
-    gst_video_frame_unmap(&vf); /* submit() has copied the planes to the device (stream-ordered from pageable memory) */
+    gst_video_frame_unmap(&vf); /* pageable memory: submit() has copied the picture out; pinned memory of our pool: the transfer is in flight and the
+                                   codec frame keeps the buffer until the picture is collected */
     if (r != MI355ENC_OK) {
         GST_ELEMENT_ERROR(s, STREAM, ENCODE, ("mi355h264enc: submit failed: %s", mi355enc_strerror(r)), ("mi355enc_submit returned %d", r));
         gst_video_encoder_finish_frame(ve, frame);
@@ -309,7 +312,47 @@ static GstFlowReturn drain(GstMi355H264Enc *s, gboolean push) {
 }
 static GstFlowReturn enc_finish(GstVideoEncoder *ve) { return drain(GST_MI355H264ENC(ve), TRUE); }
 static gboolean enc_flush(GstVideoEncoder *ve) { drain(GST_MI355H264ENC(ve), FALSE); return TRUE; }
+/* ---- pinned input memory for the upstream element.  The ALLOCATION query is answered with a buffer pool whose memory comes from
+ * mi355enc_host_alloc(): a source that takes the offer (videotestsrc, v4l2src in its copying modes, decoders, videoconvert) writes its
+ * pictures straight into pinned memory and mi355enc_submit() transfers them from there asynchronously -- no staging pass over the picture
+ * on the streaming thread.  A source that declines (its own pool, mmap'ed capture buffers) is staged by submit() as before. */
+typedef struct { GstAllocator parent; } GstMi355PinAllocator;
+typedef struct { GstAllocatorClass parent_class; } GstMi355PinAllocatorClass;
+G_DEFINE_TYPE(GstMi355PinAllocator, gst_mi355_pin_allocator, GST_TYPE_ALLOCATOR)
+static GstMemory *pin_alloc(GstAllocator *a, gsize size, GstAllocationParams *params) {
+    (void)a;
+    const gsize align = params->align | 63u, maxsize = size + params->prefix + params->padding + align;
+    guint8 *data = (guint8 *)mi355enc_host_alloc(maxsize);
+    if (!data) return NULL; /* GStreamer falls back to the default allocator */
+    const gsize off = ((gsize)(-(gintptr)(data + params->prefix)) & align) + params->prefix; /* data + off is aligned */
+    return gst_memory_new_wrapped((GstMemoryFlags)0, data, maxsize, off, size, data, (GDestroyNotify)mi355enc_host_free); /* sysmem semantics; freed through the notify */
+}
+static void pin_free(GstAllocator *a, GstMemory *m) { (void)a; (void)m; } /* never reached: wrapped memory belongs to the system allocator */
+static void gst_mi355_pin_allocator_class_init(GstMi355PinAllocatorClass *k) { GST_ALLOCATOR_CLASS(k)->alloc = pin_alloc; GST_ALLOCATOR_CLASS(k)->free = pin_free; }
+static void gst_mi355_pin_allocator_init(GstMi355PinAllocator *a) { GST_OBJECT_FLAG_SET(a, GST_ALLOCATOR_FLAG_CUSTOM_ALLOC); }
+
 static gboolean enc_propose_allocation(GstVideoEncoder *ve, GstQuery *q) {
+    GstMi355H264Enc *s = GST_MI355H264ENC(ve);
+    GstCaps *caps = NULL;
+    gboolean need_pool = FALSE;
+    GstVideoInfo vi;
+    gst_query_parse_allocation(q, &caps, &need_pool);
+    if (s->pinned_input && caps && gst_video_info_from_caps(&vi, caps)) {
+        GstAllocator *alloc = (GstAllocator *)g_object_new(gst_mi355_pin_allocator_get_type(), NULL);
+        GstAllocationParams params;
+        gst_allocation_params_init(&params);
+        params.align = 63;
+        gst_query_add_allocation_param(q, alloc, &params);
+        const guint min = (guint)s->pipeline_depth + 2; /* pictures in flight hold their buffers until collect() */
+        GstBufferPool *pool = gst_video_buffer_pool_new();
+        GstStructure *cfg = gst_buffer_pool_get_config(pool);
+        gst_buffer_pool_config_set_params(cfg, caps, (guint)GST_VIDEO_INFO_SIZE(&vi), min, 0);
+        gst_buffer_pool_config_set_allocator(cfg, alloc, &params);
+        gst_buffer_pool_config_add_option(cfg, GST_BUFFER_POOL_OPTION_VIDEO_META);
+        if (gst_buffer_pool_set_config(pool, cfg)) gst_query_add_allocation_pool(q, pool, (guint)GST_VIDEO_INFO_SIZE(&vi), min, 0);
+        gst_object_unref(pool);
+        gst_object_unref(alloc);
+    }
     gst_query_add_allocation_meta(q, GST_VIDEO_META_API_TYPE, NULL);
     return GST_VIDEO_ENCODER_CLASS(gst_mi355h264enc_parent_class)->propose_allocation(ve, q);
 }
@@ -344,7 +387,9 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
     g_object_class_install_property(g, PROP_INTRA_IN_P, g_param_spec_boolean("intra-in-p", "Intra macroblocks in P pictures",
         "Macroblocks of P pictures may be coded intra (uncovered regions, partial scene changes)", TRUE, F));
     g_object_class_install_property(g, PROP_EXCLUSIVE, g_param_spec_boolean("exclusive-gpu", "This stream has the GPU to itself",
-        "One stream per GPU: a P picture's motion-compensation stage is launched beside the previous picture's deblocking and waits on the device for it (about 7 % more frames/s); leave false when other processes encode on the same GPU", FALSE, F));
+        "One stream per GPU: kernels may wait on the device for other kernels' progress (a P picture's motion-compensation stage beside the previous picture's deblocking, the deblocker beside the intra macroblocks: about 10 % more frames/s); leave false when other processes encode on the same GPU", FALSE, F));
+    g_object_class_install_property(g, PROP_PINNED_INPUT, g_param_spec_boolean("pinned-input", "Offer pinned input buffers",
+        "Answer the upstream ALLOCATION query with a buffer pool in pinned host memory: a source that takes it writes pictures the GPU can fetch without a staging copy", TRUE, F));
     g_object_class_install_property(g, PROP_SCENECUT, g_param_spec_boolean("scenecut", "Scene-cut recovery",
         "Code an IDR picture two pictures after a scene cut (detected from the summed motion cost; x264 decides inside its lookahead instead)", TRUE, F));
     g_object_class_install_property(g, PROP_DCT8X8, g_param_spec_boolean("dct8x8", "8x8 transform",
@@ -359,7 +404,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->rate_raw = 2048; s->rate_is_bps = FALSE; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
-    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = TRUE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
+    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = TRUE; s->pinned_input = TRUE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
 }
 
 GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */

@@ -9,7 +9,11 @@
  * (/root/reference/src/ceracoder.c:48-51,313-332) but over UDP to a loopback socket: libsrt is not in this image, so
  * t2 - t1 is "UDP loopback, same packetisation", not SRT.  Prints one JSON line.
  *
- * usage: mi355_gst_probe "PIPELINE DESCRIPTION"
+ * Throughput (SURVEY.md 8d "Timing method"): with a non-live source the same run gives frames/s as wall-clock between buffers arriving at the
+ * sink behind the encoder, the first GOP (60 buffers) discarded: "fps_after_first_gop".  With --no-encoder the description needs no
+ * `venc_bps` (the source's own ceiling: `videotestsrc ! appsink`).
+ *
+ * usage: mi355_gst_probe "PIPELINE DESCRIPTION" [--no-encoder]
  */
 #include <arpa/inet.h>
 #include <gst/app/gstappsink.h>
@@ -30,6 +34,7 @@ static struct { guint64 pts; gint64 t0; } ring[RING];
 static unsigned head;
 static GMutex lock;
 static float l_enc[MAXN], l_send[MAXN];
+static gint64 t_arr[MAXN]; /* arrival of every sample at the sink */
 static unsigned n_lat;
 static guint64 n_samples, n_bytes, n_dgrams;
 static int tx = -1, rx = -1, exit_code;
@@ -75,6 +80,7 @@ static GstFlowReturn on_sample(GstAppSink *sink, gpointer u) {
             if (ring[(head - 1 - i) % RING].pts == pts) { t0 = ring[(head - 1 - i) % RING].t0; break; }
         g_mutex_unlock(&lock);
         if (t0 >= 0 && n_lat < MAXN) { l_enc[n_lat] = (float)((t1 - t0) / 1e3); l_send[n_lat] = (float)((t2 - t1) / 1e3); n_lat++; }
+        if (n_samples < MAXN) t_arr[n_samples] = t1;
         n_samples++; n_bytes += m.size;
         gst_buffer_unmap(b, &m);
     }
@@ -105,10 +111,13 @@ int main(int argc, char **argv) {
     GstElement *pipe = gst_parse_launch(argv[1], &err);
     if (!pipe) { fprintf(stderr, "parse error: %s\n", err ? err->message : "?"); return 2; }
     GstElement *enc = gst_bin_get_by_name(GST_BIN(pipe), "venc_bps"), *sink = gst_bin_get_by_name(GST_BIN(pipe), "appsink");
-    if (!enc || !sink) { fprintf(stderr, "the description needs elements named venc_bps and appsink\n"); return 2; }
-    GstPad *sp = gst_element_get_static_pad(enc, "sink");
-    gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_BUFFER, on_enc_sink, NULL, NULL);
-    gst_object_unref(sp);
+    const int no_enc = argc > 2 && strcmp(argv[2], "--no-encoder") == 0;
+    if ((!enc && !no_enc) || !sink) { fprintf(stderr, "the description needs elements named venc_bps and appsink\n"); return 2; }
+    if (enc) {
+        GstPad *sp = gst_element_get_static_pad(enc, "sink");
+        gst_pad_add_probe(sp, GST_PAD_PROBE_TYPE_BUFFER, on_enc_sink, NULL, NULL);
+        gst_object_unref(sp);
+    }
     rx = socket(AF_INET, SOCK_DGRAM, 0); tx = socket(AF_INET, SOCK_DGRAM, 0);
     struct sockaddr_in a; memset(&a, 0, sizeof a);
     a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
@@ -126,6 +135,11 @@ int main(int argc, char **argv) {
     const double secs = (g_get_monotonic_time() - t_start) / 1e6;
     gst_element_set_state(pipe, GST_STATE_NULL);
     printf("{\"samples\":%" G_GUINT64_FORMAT ",\"bytes\":%" G_GUINT64_FORMAT ",\"seconds\":%.3f,\"datagrams_1316\":%" G_GUINT64_FORMAT, n_samples, n_bytes, secs, n_dgrams);
+    {
+        const guint64 n = n_samples < MAXN ? n_samples : MAXN;
+        if (n > 120 && t_arr[n - 1] > t_arr[60]) printf(",\"fps_after_first_gop\":%.1f,\"buffers_timed\":%" G_GUINT64_FORMAT, (double)(n - 1 - 60) * 1e6 / (double)(t_arr[n - 1] - t_arr[60]), n - 1 - 60);
+        else printf(",\"fps_after_first_gop\":null");
+    }
     const unsigned skip = n_lat > 90 ? 60 : 0; /* discard the first GOP (warm-up) */
     pct("ms_encoder_sink_to_appsink", l_enc + skip, n_lat - skip);
     pct("ms_appsink_to_last_udp_send", l_send + skip, n_lat - skip);

@@ -32,7 +32,7 @@ EXPORTS = [
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
     "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_pmb", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
     "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
-    "mi355enc_rc_pick", "mi355enc_rc_update", "mi355enc_host_cavlc_block", "mi355enc_debug_trip_wait",
+    "mi355enc_rc_pick", "mi355enc_rc_update", "mi355enc_host_cavlc_block", "mi355enc_debug_trip_wait", "mi355enc_host_alloc", "mi355enc_host_free",
 ]
 
 
@@ -49,7 +49,7 @@ class Stats(C.Structure):
                 ("ms_intra", C.c_double), ("ms_deblock", C.c_double), ("ms_total_gpu", C.c_double), ("ms_subpel", C.c_double), ("n_me", C.c_uint64),
                 ("n_inter", C.c_uint64), ("n_intra", C.c_uint64), ("n_deblock", C.c_uint64), ("ms_entropy", C.c_double),
                 ("ms_wait", C.c_double), ("n_total_gpu", C.c_uint64), ("ms_deblock_idr", C.c_double), ("n_deblock_idr", C.c_uint64), ("cavlc_threads", C.c_uint32), ("last_drop", C.c_uint32), ("ms_select", C.c_double), ("ms_analyse_p", C.c_double), ("ms_intra_p", C.c_double), ("skip_pictures", C.c_uint64), ("ms_open", C.c_double),
-                ("recoveries", C.c_uint32), ("last_error_word", C.c_uint32), ("safe_level", C.c_uint32)]
+                ("recoveries", C.c_uint32), ("last_error_word", C.c_uint32), ("safe_level", C.c_uint32), ("pinned_inputs", C.c_uint64)]
 
 
 _lib = None
@@ -100,6 +100,10 @@ def load():
         L.mi355enc_submit_fmt.argtypes = [vp, C.c_int, vp, vp, C.c_int64, C.c_int]
         L.mi355enc_stage_csc.argtypes = [vp, C.c_int, vp, vp, vp, vp]
         L.mi355enc_debug_trip_wait.argtypes = [vp, C.c_uint]
+        L.mi355enc_host_alloc.restype = vp
+        L.mi355enc_host_alloc.argtypes = [C.c_size_t]
+        L.mi355enc_host_free.restype = None
+        L.mi355enc_host_free.argtypes = [vp]
         L.mi355enc_time_stage.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mi355enc_host_write_headers.argtypes = [C.c_int] * 5 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_write_slice.argtypes = [C.c_int] * 7 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -179,6 +183,26 @@ class RateControl:
 
     def update(self, is_idr, qp, drop, nbytes):
         self.L.mi355enc_rc_update(self.buf, int(is_idr), qp, drop, nbytes)
+
+
+class PinnedBuffer:
+    """nbytes of pinned host memory from mi355enc_host_alloc(), viewed as a numpy uint8 array (`.array`); pictures submitted from it
+    are DMA'd in place."""
+
+    def __init__(self, nbytes):
+        self.L = load()
+        self.ptr = self.L.mi355enc_host_alloc(nbytes)
+        if not self.ptr:
+            raise EncoderError("mi355enc_host_alloc(%d) failed" % nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self.ptr))
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.L.mi355enc_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
 
 
 class EncoderError(RuntimeError):

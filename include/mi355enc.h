@@ -112,6 +112,7 @@ typedef struct {
                                  (survives reset_stats); last_error_word: which wait it was (text on stderr); safe_level: 0 kernels may wait
                                  on the device for each other, 1 stream order only, 2 one launch per wavefront step (no device-side wait left) */
     uint32_t last_error_word, safe_level;
+    uint64_t pinned_inputs;   /* pictures submitted from mi355enc_host_alloc() memory (DMA'd in place, no staging copy) */
 } mi355enc_stats_t;
 
 /* Fill cfg with the defaults of the element (gop 60, me_range 16, 2048 kbit/s like x264enc). */
@@ -135,6 +136,14 @@ int mi355enc_set_fixed_drop(mi355enc_t *h, int drop);
 int mi355enc_encode(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t *uv, int uv_stride,
                     int64_t pts, int force_idr, uint8_t *out, size_t out_cap, size_t *out_len,
                     int *is_keyframe);
+
+/* Pinned host memory for input pictures.  mi355enc_submit() copies a picture from ordinary (pageable) memory into a pinned staging buffer
+ * first -- one pass of the calling thread over the picture, 3.1 MB at 1080p.  A picture that lies in memory obtained here is transferred
+ * from where it is, asynchronously: submit() returns at once, and the memory must then stay untouched until the matching collect()
+ * (the element offers such memory to its upstream through the ALLOCATION query, so a source writes its pictures straight into it).
+ * Process-wide; usable on every device.  NULL when there is no HIP device or no memory. */
+void *mi355enc_host_alloc(size_t bytes);
+void mi355enc_host_free(void *p);
 
 /* Split form.  submit() enqueues all device work of a picture and returns; collect()
  * entropy-codes the oldest submitted picture.  At most pipeline_depth+1 pictures may be

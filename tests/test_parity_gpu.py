@@ -311,7 +311,7 @@ def test_drop_ladder_and_all_skip_pictures_equal_oracle(E, oracle, w, h, depth):
 @pytest.mark.parametrize("w,h", [(16, 16), (32, 16), (16, 48), (18, 18), (4096, 32)])
 def test_degenerate_geometries(E, oracle, w, h):
     """Single macroblock, single row/column, non-multiple-of-16, and the widest row the caps allow."""
-    e = E.Encoder(w, h, gop=3, fixed_qp=27)
+    e = E.Encoder(w, h, gop=3, fixed_qp=27, exclusive=True)
     oe = oracle.Encoder(w, h, gop=3, threads=4)
     dec = oracle.Decoder()
     for i, (_, _, y, uv) in enumerate(frames(w, h, 5)):
@@ -340,7 +340,7 @@ def test_me_range_property(E, oracle, rng):
 def test_2160p_one_gop_head_equals_oracle(E, oracle):
     """BASELINE config 4 geometry at full size: IDR + P, bit-exact (32 400 macroblocks, 34 deblock bands)."""
     w, h = 3840, 2160
-    e = E.Encoder(w, h, gop=60, fixed_qp=32)
+    e = E.Encoder(w, h, gop=60, fixed_qp=32, exclusive=True)
     oe = oracle.Encoder(w, h, gop=60, threads=16)
     for i, (_, _, y, uv) in enumerate(frames(w, h, 2)):
         au, _ = e.encode(y, uv, pts=i)
@@ -398,7 +398,7 @@ def test_three_pictures_in_flight_equal_one_at_a_time(E, w, h, n):
     force = {9, 10, 23, 61}
     streams = []
     for depth in (0, 2):
-        e = E.Encoder(w, h, gop=16, fixed_qp=30, pipeline_depth=depth, scenecut=False, exclusive=depth == 2)
+        e = E.Encoder(w, h, gop=16, fixed_qp=30, pipeline_depth=depth, scenecut=False, exclusive=True)
         got = []
         for i in range(n):
             k = i % 14
@@ -425,7 +425,7 @@ def test_scene_cut_recovery_equals_oracle(E, oracle, depth):
     from tests.util import cut_clip
     w, h, n = 320, 192, 12
     clip = cut_clip(w, h, n, 5)
-    e = E.Encoder(w, h, gop=30, fixed_qp=30, pipeline_depth=depth, exclusive=depth == 2)
+    e = E.Encoder(w, h, gop=30, fixed_qp=30, pipeline_depth=depth, exclusive=True)
     oe = oracle.Encoder(w, h, gop=30, threads=8, sc_lag=max(2, depth + 1))
     got = []
     for i, (y, uv) in enumerate(clip):
@@ -453,7 +453,7 @@ def test_idle_deblocking_bands_equal_oracle(E, oracle, w, h, static_lines, depth
     above them straight from the picture.  Streams and reconstructions must still equal the oracle's, picture by picture."""
     from tests.util import half_static_clip
     clip = half_static_clip(w, h, 7, static_lines)
-    e = E.Encoder(w, h, gop=30, fixed_qp=38, pipeline_depth=depth, exclusive=depth == 2)
+    e = E.Encoder(w, h, gop=30, fixed_qp=38, pipeline_depth=depth, exclusive=True)
     oe = oracle.Encoder(w, h, gop=30, threads=8)
     got = []
     for i, (y, uv) in enumerate(clip):
@@ -494,7 +494,7 @@ def test_rate_control_emergency_drop_on_the_device(E, depth):
     """N3: a 4x cut of the setpoint between two key frames shows in the access-unit sizes within a few pictures
     (pipeline_depth 1 adds one picture of feedback delay)."""
     w, h, fps, gop = 640, 368, 30, 60
-    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=2_400_000, pipeline_depth=depth, exclusive=depth == 2)
+    e = E.Encoder(w, h, fps=fps, gop=gop, bitrate_bps=2_400_000, pipeline_depth=depth, exclusive=True)
     sizes, drop_at = [], 75
     fr = frames(w, h, 120)
     for i, (_, _, y, uv) in enumerate(fr):
