@@ -83,7 +83,7 @@ def gst_latency(width, height, fps, gop, bps, dev, seconds=4):
                GST_REGISTRY="/tmp/ceracoder_amd_gst_registry_bench.bin", GST_PLUGIN_PATH=os.path.join(ROOT, "ceracoder_amd", "gst-plugins"),
                LD_PRELOAD="/usr/lib/x86_64-linux-gnu/libstdc++.so.6")
     desc = ("videotestsrc is-live=true num-buffers=%d pattern=smpte horizontal-speed=5 ! video/x-raw,width=%d,height=%d,framerate=%d/1,format=NV12 ! queue ! "
-            "mi355h264enc key-int-max=%d bps=%d device-id=%d name=venc_bps ! mi355tsmux ! appsink name=appsink sync=false"
+            "mi355h264enc key-int-max=%d bps=%d device-id=%d exclusive-gpu=true name=venc_bps ! mi355tsmux ! appsink name=appsink sync=false"
             % (seconds * fps, width, height, fps, gop, bps, dev))
     try:
         r = subprocess.run([probe, desc], env=env, capture_output=True, text=True, timeout=60 + 3 * seconds)
@@ -116,6 +116,16 @@ def gst_throughput(width, height, fps, gop, bps, dev, depth, buffers=660):
                              ("source_alone", "%s ! queue ! appsink name=appsink sync=false" % src, ["--no-encoder"])):
         try:
             r = subprocess.run([probe, desc] + extra, env=env, capture_output=True, text=True, timeout=180)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            out[key] = {"frames_per_s": j.get("fps_after_first_gop"), "buffers_timed": j.get("buffers_timed"), "samples": j.get("samples")}
+        except Exception as e:
+            out[key] = {"unavailable": "probe failed: %s" % e}
+    # ... and with the probe feeding pre-rendered pictures through appsrc (no copy, no painting): what the element itself sustains
+    asrc = "appsrc name=src ! video/x-raw,width=%d,height=%d,framerate=%d/1,format=NV12" % (width & ~3, height, fps)
+    for key, extra in (("element_appsrc_pageable", []), ("element_appsrc_pinned", ["pinned"])):
+        try:
+            r = subprocess.run([probe, "%s ! queue ! %s ! appsink name=appsink sync=false" % (asrc, encoder), "--appsrc", str(2 * buffers), str(width), str(height)] + extra,
+                               env=env, capture_output=True, text=True, timeout=180)
             j = json.loads(r.stdout.strip().splitlines()[-1])
             out[key] = {"frames_per_s": j.get("fps_after_first_gop"), "buffers_timed": j.get("buffers_timed"), "samples": j.get("samples")}
         except Exception as e:
@@ -333,7 +343,8 @@ def main():
                             "note": "mean over all pictures of an untimed pass (two GOPs, same clip, same rate control); encoder reconstruction vs source"}
         # (2) per-picture latency of the synchronous path an element in a live graph uses (pipeline_depth 0):
         # host NV12 in -> H2D -> kernels -> D2H -> CAVLC -> access unit out, PCIe included.
-        lat_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads)
+        lat_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads,
+                            exclusive=not shared_gpu)
         def lat_run(n, gap_s):
             v = []
             for i in range(n):
@@ -415,7 +426,8 @@ def main():
         extra["latency_gst_ms"] = gst_latency(width, height, fps, gop, bps, dev)
         g = gst_throughput(width, height, fps, gop, bps, dev, args.depth)
         extra["gst_throughput"] = g
-        extra["gst_frames_per_s"] = (g.get("element") or {}).get("frames_per_s")
+        extra["gst_frames_per_s"] = (g.get("element") or {}).get("frames_per_s")                     # videotestsrc in front: the source's own painting rate bounds it
+        extra["gst_appsrc_frames_per_s"] = (g.get("element_appsrc_pinned") or {}).get("frames_per_s")  # pre-rendered pictures in pinned memory through appsrc
         extra["third_party"] = third_party_probe()
 
     if rank == 0:

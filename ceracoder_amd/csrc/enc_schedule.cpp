@@ -331,12 +331,18 @@ int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
         h->st.pinned_inputs++;
     } else {
         if (!s->h_src) HIPCHK(hipHostMalloc((void **)&s->h_src, h->ysz + h->csz, hipHostMallocDefault));
-        uint8_t *hy = s->h_src, *huv = s->h_src + (size_t)h->W * ht; // rows at the coded stride: each plane is one contiguous transfer
-        if (y_stride == h->W) memcpy(hy, y, (size_t)h->W * (ht - 1) + w);
-        else for (int r = 0; r < ht; r++) memcpy(hy + (size_t)r * h->W, y + (size_t)r * y_stride, (size_t)w);
+        // rows at the coded stride, so that a range of rows is one contiguous transfer; in four pieces (three of luma, the chroma plane), each
+        // sent as soon as it is staged: the transfer of one piece runs beside the staging of the next
+        uint8_t *hy = s->h_src, *huv = s->h_src + (size_t)h->W * ht;
+        for (int k = 0; k < 3; k++) {
+            const int r0 = (ht * k / 3) & ~1, r1 = k == 2 ? ht : (ht * (k + 1) / 3) & ~1;
+            if (r1 <= r0) continue;
+            if (y_stride == h->W) memcpy(hy + (size_t)r0 * h->W, y + (size_t)r0 * y_stride, (size_t)h->W * (r1 - r0 - 1) + w);
+            else for (int r = r0; r < r1; r++) memcpy(hy + (size_t)r * h->W, y + (size_t)r * y_stride, (size_t)w);
+            HIPCHK(hipMemcpyAsync(s->d_src_y + (size_t)r0 * h->W, hy + (size_t)r0 * h->W, (size_t)h->W * (r1 - r0 - 1) + w, hipMemcpyHostToDevice, up));
+        }
         if (uv_stride == h->W) memcpy(huv, uv, (size_t)h->W * (ht / 2 - 1) + w);
         else for (int r = 0; r < ht / 2; r++) memcpy(huv + (size_t)r * h->W, uv + (size_t)r * uv_stride, (size_t)w);
-        HIPCHK(hipMemcpyAsync(s->d_src_y, hy, (size_t)h->W * (ht - 1) + w, hipMemcpyHostToDevice, up));
         HIPCHK(hipMemcpyAsync(s->d_src_uv, huv, (size_t)h->W * (ht / 2 - 1) + w, hipMemcpyHostToDevice, up));
     }
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);

@@ -13,10 +13,18 @@
  * sink behind the encoder, the first GOP (60 buffers) discarded: "fps_after_first_gop".  With --no-encoder the description needs no
  * `venc_bps` (the source's own ceiling: `videotestsrc ! appsink`).
  *
- * usage: mi355_gst_probe "PIPELINE DESCRIPTION" [--no-encoder]
+ * With --appsrc N W H [pinned] the description starts with `appsrc name=src`: the probe feeds N NV12 pictures itself (eight
+ * pre-rendered pictures of a panning texture, wrapped without a copy, as fast as the pipeline takes them), so that the figure is the
+ * element's and not the test source's (videotestsrc paints 1080p at 300-400 pictures/s).  `pinned`: the pictures lie in
+ * mi355enc_host_alloc memory, as a capture source that adopted the element's buffer pool would deliver them.
+ *
+ * usage: mi355_gst_probe "PIPELINE DESCRIPTION" [--no-encoder | --appsrc N W H [pinned]]
  */
 #include <arpa/inet.h>
 #include <gst/app/gstappsink.h>
+#include <gst/app/gstappsrc.h>
+#include <dlfcn.h>
+#include <libgen.h>
 #include <gst/gst.h>
 #include <netinet/in.h>
 #include <stdio.h>
@@ -37,6 +45,7 @@ static float l_enc[MAXN], l_send[MAXN];
 static gint64 t_arr[MAXN]; /* arrival of every sample at the sink */
 static unsigned n_lat;
 static guint64 n_samples, n_bytes, n_dgrams;
+static volatile gint n_out; /* samples that reached the sink (read by the feeder) */
 static int tx = -1, rx = -1, exit_code;
 static struct sockaddr_in dst;
 static unsigned char pkt[PKT];
@@ -82,6 +91,7 @@ static GstFlowReturn on_sample(GstAppSink *sink, gpointer u) {
         if (t0 >= 0 && n_lat < MAXN) { l_enc[n_lat] = (float)((t1 - t0) / 1e3); l_send[n_lat] = (float)((t2 - t1) / 1e3); n_lat++; }
         if (n_samples < MAXN) t_arr[n_samples] = t1;
         n_samples++; n_bytes += m.size;
+        g_atomic_int_inc(&n_out);
         gst_buffer_unmap(b, &m);
     }
     gst_sample_unref(s);
@@ -98,6 +108,37 @@ static gboolean on_bus(GstBus *bus, GstMessage *msg, gpointer u) {
     } else if (GST_MESSAGE_TYPE(msg) == GST_MESSAGE_EOS) g_main_loop_quit(loop);
     return TRUE;
 }
+/* ---- --appsrc: eight pictures of a texture panning by (+3, -2) per picture, pushed round-robin */
+static struct { GstElement *src; int n, w, h, fps; guint8 *mem; gsize fsz; } feed;
+static gpointer feeder(gpointer u) {
+    (void)u;
+    for (int i = 0; i < feed.n; i++) {
+        guint8 *d = feed.mem + (gsize)(i & 7) * feed.fsz;
+        GstBuffer *b = gst_buffer_new_wrapped_full(GST_MEMORY_FLAG_READONLY, d, feed.fsz, 0, feed.fsz, NULL, NULL);
+        GST_BUFFER_PTS(b) = gst_util_uint64_scale(GST_SECOND, (guint64)i, (guint64)feed.fps);
+        GST_BUFFER_DURATION(b) = gst_util_uint64_scale(GST_SECOND, 1, (guint64)feed.fps);
+        if (gst_app_src_push_buffer(GST_APP_SRC(feed.src), b) != GST_FLOW_OK) break;
+        /* own flow control (appsrc's block=true stalls with this GStreamer 1.14 when fed from a thread of ours): at most 8 pictures between
+         * the source and the sink, which keeps the encoder's pipeline (three in flight) and the queue in front of it full */
+        while (i + 1 - (int)g_atomic_int_get(&n_out) > 8 && !exit_code) g_usleep(20);
+    }
+    gst_app_src_end_of_stream(GST_APP_SRC(feed.src));
+    return NULL;
+}
+static void render_pictures(void) {
+    const int w = feed.w, h = feed.h;
+    for (int f = 0; f < 8; f++) {
+        guint8 *y = feed.mem + (gsize)f * feed.fsz, *uv = y + (gsize)w * h;
+        for (int r = 0; r < h; r++)
+            for (int c = 0; c < w; c++) {
+                const unsigned tx = (unsigned)(c + 3 * f), ty = (unsigned)(r + 2 * (8 - f));
+                unsigned v = 128u + (((tx * 7u) ^ (ty * 13u)) & 31u) + (((tx >> 5) + (ty >> 5)) & 1u) * 40u + ((tx * tx + ty * 31u) >> 7 & 15u);
+                y[(gsize)r * w + c] = (guint8)(v > 235u ? 235u : v);
+            }
+        for (int r = 0; r < h / 2; r++)
+            for (int c = 0; c < w; c++) uv[(gsize)r * w + c] = (guint8)(128 + ((((c >> 1) + 3 * f / 2) >> 4) + (r >> 4)) % 9 - 4);
+    }
+}
 static int cmpf(const void *a, const void *b) { float x = *(const float *)a, y = *(const float *)b; return (x > y) - (x < y); }
 static void pct(const char *name, float *v, unsigned n) {
     if (!n) { printf(",\"%s\":null", name); return; }
@@ -111,7 +152,35 @@ int main(int argc, char **argv) {
     GstElement *pipe = gst_parse_launch(argv[1], &err);
     if (!pipe) { fprintf(stderr, "parse error: %s\n", err ? err->message : "?"); return 2; }
     GstElement *enc = gst_bin_get_by_name(GST_BIN(pipe), "venc_bps"), *sink = gst_bin_get_by_name(GST_BIN(pipe), "appsink");
-    const int no_enc = argc > 2 && strcmp(argv[2], "--no-encoder") == 0;
+    int no_enc = 0, use_appsrc = 0, pinned = 0, ai = 0;
+    for (int i = 2; i < argc; i++) {
+        if (!strcmp(argv[i], "--no-encoder")) no_enc = 1;
+        else if (!strcmp(argv[i], "--appsrc") && i + 3 < argc) { use_appsrc = 1; ai = i; i += 3; }
+        else if (!strcmp(argv[i], "pinned")) pinned = 1;
+    }
+    if (use_appsrc) {
+        feed.src = gst_bin_get_by_name(GST_BIN(pipe), "src");
+        feed.n = atoi(argv[ai + 1]); feed.w = atoi(argv[ai + 2]) & ~3; feed.h = atoi(argv[ai + 3]) & ~1; feed.fps = 60;
+        if (!feed.src || feed.n < 1 || feed.w < 16 || feed.h < 16) { fprintf(stderr, "--appsrc needs `appsrc name=src` in the description and N W H\n"); return 2; }
+        feed.fsz = (gsize)feed.w * feed.h * 3 / 2;
+        if (pinned) { /* libmi355enc.so sits beside this program; loaded here rather than linked (this image's GStreamer brings an older libstdc++ than HIP's) */
+            char exe[4096];
+            ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 32);
+            if (n > 0) {
+                exe[n] = 0;
+                char lib[4200];
+                snprintf(lib, sizeof lib, "%s/libmi355enc.so", dirname(exe));
+                void *dl = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+                void *(*alloc)(size_t) = dl ? (void *(*)(size_t))dlsym(dl, "mi355enc_host_alloc") : NULL;
+                if (alloc) feed.mem = (guint8 *)alloc(8 * feed.fsz);
+                else fprintf(stderr, "cannot load %s: %s\n", lib, dlerror());
+            }
+        }
+        if (pinned && !feed.mem) fprintf(stderr, "mi355enc_host_alloc unavailable: pageable pictures instead\n");
+        if (!feed.mem) feed.mem = (guint8 *)g_malloc(8 * feed.fsz);
+        render_pictures();
+        g_object_set(feed.src, "format", GST_FORMAT_TIME, NULL);
+    }
     if ((!enc && !no_enc) || !sink) { fprintf(stderr, "the description needs elements named venc_bps and appsink\n"); return 2; }
     if (enc) {
         GstPad *sp = gst_element_get_static_pad(enc, "sink");
@@ -131,7 +200,9 @@ int main(int argc, char **argv) {
     gst_bus_add_watch(bus, on_bus, NULL);
     const gint64 t_start = g_get_monotonic_time();
     gst_element_set_state(pipe, GST_STATE_PLAYING);
+    GThread *ft = use_appsrc ? g_thread_new("feeder", feeder, NULL) : NULL;
     g_main_loop_run(loop);
+    if (ft && exit_code == 0) g_thread_join(ft);
     const double secs = (g_get_monotonic_time() - t_start) / 1e6;
     gst_element_set_state(pipe, GST_STATE_NULL);
     printf("{\"samples\":%" G_GUINT64_FORMAT ",\"bytes\":%" G_GUINT64_FORMAT ",\"seconds\":%.3f,\"datagrams_1316\":%" G_GUINT64_FORMAT, n_samples, n_bytes, secs, n_dgrams);

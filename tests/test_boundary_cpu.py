@@ -145,6 +145,17 @@ def test_latency_probe_runs_the_graph_and_fails_loudly_without_a_device():
         assert r.returncode == 3 and "no usable HIP device" in r.stderr, r.stderr
 
 
+@needs_gst
+def test_probe_feeds_pictures_through_appsrc():
+    """bench.py's through-the-element throughput leg with the probe as the source (--appsrc): every picture pushed arrives at the sink, and
+    the rate over the pictures after the first GOP is reported."""
+    probe = os.path.join(ROOT, "ceracoder_amd", "mi355_gst_probe")
+    desc = "appsrc name=src ! video/x-raw,width=320,height=192,framerate=60/1,format=NV12 ! queue ! appsink name=appsink sync=false"
+    r = subprocess.run([probe, desc, "--appsrc", "200", "320", "192", "--no-encoder"], env=gst_env(), capture_output=True, text=True, timeout=60)
+    out = json.loads(r.stdout.splitlines()[-1])
+    assert r.returncode == 0 and out["samples"] == 200 and out["buffers_timed"] == 139 and out["fps_after_first_gop"] > 0
+
+
 def test_committed_bench_line_keeps_the_contract():
     """profiles/r02_bench_1080p_ippp.json is the line bench.py printed on the GPU box: the keys the driver reads, the roofline
     object (algorithmic bytes / live launch time, agreeing with the rocprofv3 kernel trace and the PMC pass) and the CPU baseline."""
