@@ -148,10 +148,10 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_progress, 4 * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
     HIPCHK(hipMalloc((void **)&h->d_db_par, k_deblock_partab_bytes(h->mbw, h->mbh)));
-    HIPCHK(hipMalloc((void **)&h->d_ib_gran, (size_t)k_intra_bands(h->mbh) * h->mbw * 8 * sizeof(uint2)));
-    HIPCHK(hipMemsetAsync(h->d_ib_gran, 0, (size_t)k_intra_bands(h->mbh) * h->mbw * 8 * sizeof(uint2), h->stream));
-    HIPCHK(hipMalloc((void **)&h->d_iband_done, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned))); // one set per reconstruction buffer: the next picture's wavefront runs beside this one's deblocking
-    HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned), h->stream));
+    HIPCHK(hipMalloc((void **)&h->d_ib_gran, (size_t)h->mbh * h->mbw * 8 * sizeof(uint2)));
+    HIPCHK(hipMemsetAsync(h->d_ib_gran, 0, (size_t)h->mbh * h->mbw * 8 * sizeof(uint2), h->stream));
+    HIPCHK(hipMalloc((void **)&h->d_iband_done, 2 * (size_t)h->mbh * sizeof(unsigned))); // one word per macroblock row (intra_mode 2: per band), one set per reconstruction buffer: the next picture's wavefront runs beside this one's deblocking
+    HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)h->mbh * sizeof(unsigned), h->stream));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_dbI[i], hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&h->d_row_done, (size_t)h->mbh * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * sizeof(unsigned), h->stream));

@@ -29,8 +29,9 @@ static int build_graph(mi355enc_t *h, int which, int ci, hipGraphExec_t *out) {
 }
 int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done) {
     k_launch_intra_analyse(hc, h->mbw, h->mbh, 0, h->stream); // open-loop mode analysis + decisions: one flat launch
-    if (h->cfg.intra_mode == 0) { // persistent band kernel
-        k_launch_intra_band(hc, h->mbh, h->d_ib_gran, err_word(h), band_done, h->stream);
+    if (h->cfg.intra_mode == 0 || h->cfg.intra_mode == 2) { // one persistent launch: dataflow per macroblock row (0) / the lock-step band kernel (2, kept for A/B)
+        if (h->cfg.intra_mode == 0) k_launch_intra_rows(hc, h->mbh, h->d_ib_gran, err_word(h), band_done, h->stream);
+        else k_launch_intra_band(hc, h->mbh, h->d_ib_gran, err_word(h), band_done, h->stream);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -43,7 +44,7 @@ int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done)
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
 int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done, unsigned *band_done, bool after_gated_pmb) {
     if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
-        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, k_intra_band_rows(), band_done, h->d_progress + 1, after_gated_pmb ? h->d_row_done : nullptr, h->pmb_rows_total, st);
+        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, h->cfg.intra_mode == 2 ? k_intra_band_rows() : 1, band_done, h->d_progress + 1, after_gated_pmb ? h->d_row_done : nullptr, h->pmb_rows_total, st);
         h->db_started_total += 2u * (unsigned)k_deblock_bands16(h->mbh);
         HIPCHK(hipGetLastError());
         return 0;
@@ -163,7 +164,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         c->mbi = h->d_mbi_set[set]; c->levels = h->d_levels_set[set];
         // Every kernel of the default path takes the context by value; only the kernels replayed from a hipGraph
         // (intra_mode 1, deblock_mode 1) read the device copy, so only those pictures pay for an upload.
-        if ((idr && h->cfg.intra_mode != 0) || h->cfg.deblock_mode != 0) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
+        if ((idr && h->cfg.intra_mode == 1) || h->cfg.deblock_mode != 0) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
         // front stream: the source is in place (upload / conversion were enqueued there); P pictures: search, selection, gated intra
         // analysis; I pictures: only the padded source copy the next picture's search will run against
         if (idr) k_launch_copy_luma(c, h->fstream);
@@ -191,13 +192,13 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // to back, each waiting on the device for its picture's rows; with fewer the host sits on the chain and a launch waiting on the chip only
         // gets in the way (1080p depth 1: 4465 -> 3980 frames/s, 2160p: 2050 -> 1615)
         const int prows = pgate && h->cfg.pipeline_depth >= 2;
-        const int isplit = idr && h->cfg.intra_mode == 0 && may_wait;
+        const int isplit = idr && h->cfg.intra_mode != 1 && may_wait;
         for (int b = 0; b < 2; b++)
             if (h->dbI_busy[b] && (!idr || b == nxt)) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_dbI[b], 0)); h->dbI_busy[b] = 0; }
         if (idr) {
             if (isplit) { HIPCHK(hipEventRecord(h->ev_pmb, h->stream)); HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0)); } // behind everything enqueued so far (a P picture's deblocker, its tables)
             if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
-            int r = run_intra(h, ci, c, isplit ? h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh) : nullptr); if (r) return r;
+            int r = run_intra(h, ci, c, isplit ? h->d_iband_done + (size_t)nxt * h->mbh : nullptr); if (r) return r;
             if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
         } else {
             int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur], prows); if (r) return r;
@@ -211,7 +212,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
             if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         }
         if (isplit) {
-            int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * k_intra_bands(h->mbh), h->d_db_done + (size_t)nxt * nbd); if (r) return r;
+            int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * h->mbh, h->d_db_done + (size_t)nxt * nbd); if (r) return r;
             HIPCHK(hipEventRecord(h->ev_dbI[nxt], h->istream));
             h->dbI_busy[nxt] = 1;
         } else { int r = run_deblock(h, ci, c, h->stream, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, prows != 0); if (r) return r; }
@@ -290,7 +291,7 @@ static int recover(mi355enc_t *h, unsigned code) {
     HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream));
     HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * sizeof(unsigned), h->stream));
     HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)k_intra_bands(h->mbh) * sizeof(unsigned), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)h->mbh * sizeof(unsigned), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->pmb_rows_total = 0; h->db_started_total = 0; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->dbI_busy[0] = h->dbI_busy[1] = 0;
     if (h->safe_level == 2) { h->cfg.deblock_mode = 1; h->cfg.intra_mode = 1; }

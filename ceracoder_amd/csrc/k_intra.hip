@@ -1,6 +1,7 @@
 // k_intra.hip -- I pictures: open-loop analysis + decisions, reconstruction wavefront (persistent bands / per diagonal)
 // Hand-written HIP for gfx950 (CDNA4, wave64); part of libmi355enc (see kernels_common.hpp).
 #include "kernels_common.hpp"
+#include <cstddef>
 
 // =================================================================== intra analysis (open loop)
 // SAD of every intra candidate of every macroblock, with predictions built from the SOURCE picture's
@@ -270,7 +271,11 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
 // to the right and below (persistent kernel): bottom rows into a 4-deep ring, the right column.
 struct intra_lds {
     int top[3][17], left[3][17];
-    __attribute__((aligned(4))) uint8_t T4[17 * 24]; // Intra_4x4: reconstructed samples incl. the row above / column left
+    // Intra_4x4: reconstructed samples incl. the row above / the column to the left, twice: sample (r, c), r, c = -1 .. 15 (top line up to
+    // c = 19), lives at T4[(r + 1) * 24 + c + 4] and, transposed, at T4t[(c + 1) * 24 + r + 4].  The four samples above a block and the four
+    // to its left are then one aligned dword each, and E(i) of 8.3.1.2 is T4[(4 by) * 24 + 4 bx + 3 + i] for i >= 0 (corner, top, top-right:
+    // contiguous) and T4t[(4 bx) * 24 + 4 by + 3 - i] for i < 0 (the left column bottom-up: contiguous).
+    __attribute__((aligned(4))) uint8_t T4[17 * 24], T4t[17 * 24];
     __attribute__((aligned(4))) uint8_t S4[256];     // source macroblock, raster
     __attribute__((aligned(8))) uint8_t crec[8 * 16]; // reconstructed chroma, interleaved Cb Cr (OUT only)
     int mode4[16];
@@ -282,14 +287,24 @@ struct intra_lds {
     int corner[3];                                    // bottom-right sample of the macroblock before the one in right_*: the next corner
 };
 
+// Hooks of intra_compute for a caller that overlaps macroblocks at 4x4-block granularity (intra_rows_kernel): before(s) runs at the top of
+// Intra_4x4 sub-step s (the blocks with bx + 2 by = s) and has to leave the neighbour samples those blocks read in L->T4; after(s) runs once
+// their reconstruction is in L->T4.  own_record: the caller assembles the macroblock record itself from what luma_done / chroma_done report.
+struct ic_nohook {
+    static constexpr bool own_record = false;
+    DEV void before(int) {}
+    DEV void after(int, int, int, int, int, bool, int) {}
+    DEV void luma_done(unsigned, bool) {}
+    DEV void chroma_done(unsigned, unsigned) {}
+};
+static_assert(offsetof(intra_lds, T4t) == offsetof(intra_lds, T4) + 17 * 24, "the transposed tile follows the tile (addressed as one array)");
 // Reconstruction of one intra macroblock by two waves (wave 0 luma, wave 1 chroma; the planes share nothing after the
 // decisions).  Needs L->top / L->left in place and visible; dec0/dec1: the 24-byte decision of intra_analyse_kernel.
-template <bool OUT, bool SC1 = false> // SC1: reconstruction stored write-through (sc1): intra_p_kernel, whose samples the deblocker reads while the kernel runs
+template <bool OUT, bool SC1, class HK> // SC1: reconstruction stored write-through (sc1): intra_p_kernel, whose samples the deblocker reads while the kernel runs
 DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, intra_lds *L, const int mx, const int my, const int wave, const int lane,
-                       const uint4 dec0, const uint2 dec1, const uint2 *presrc = nullptr) { // presrc: this lane's source samples, loaded ahead (luma: .x, one word; chroma: the 8 interleaved bytes)
+                       const uint4 dec0, const uint2 dec1, const uint2 *presrc, HK &hk) { // presrc: this lane's source samples, loaded ahead (luma: .x, one word; chroma: the 8 interleaved bytes)
     int (*top)[17] = L->top;
     int (*left)[17] = L->left;
-    int *sh_mode4 = L->mode4;
     uint8_t *T4 = L->T4, *S4 = L->S4;
     const int mbw = ctx->mbw, stride = ctx->stride, qp = ctx->qp;
     const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
@@ -325,18 +340,18 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
     const int mode16 = (int)(dec1.x & 255), cmode = (int)((dec1.x >> 8) & 255);
     const bool use_i4 = ((dec1.x >> 16) & 255) != 0;
     unsigned nz4 = 0;
-    if (use_i4 && wave == 0 && lane < 16) { // raster order for the reconstruction loop
-        const int bb = ((lane >> 3) << 3) | (((lane & 3) >> 1) << 2) | (((lane >> 2) & 1) << 1) | (lane & 1); // raster (by = lane>>2, bx = lane&3) -> blkIdx
-        const unsigned w = bb < 4 ? dec0.x : bb < 8 ? dec0.y : bb < 12 ? dec0.z : dec0.w;
-        sh_mode4[lane] = (int)((w >> (8 * (bb & 3))) & 255);
-    }
-    WAVE_SYNC();
+    WAVE_SYNC(); // S4 is in place
     unsigned nz16 = 0, ldc_any = 0, cnz8 = 0, cdc2 = 0;
     if (use_i4 && wave == 0) {
         // ================================================================ Intra_4x4 reconstruction (8.3.1.2 + 8.5)
-        // Same block order; up to two blocks per step, 16 lanes each, lane = one pixel; transforms across lanes.
-        if (lane < 17) T4[lane] = (uint8_t)TOP(0, lane - 1);
-        else if (lane < 33) T4[(lane - 16) * 24] = (uint8_t)LEFT(0, lane - 17);
+        // Blocks in the order bx + 2 by = s, up to two per sub-step, 16 lanes each, lane = one pixel; transforms across lanes.
+        // A sub-step is a dependency chain (the next one predicts from this one's reconstruction), so everything that does not depend on
+        // reconstructed samples is taken off it: mode, predictor-table entry and source sample of all ten sub-steps are gathered into
+        // packed registers up front; what is left per sub-step is ONE round of LDS reads (three predictor taps at per-lane addresses, the
+        // dwords above and to the left for DC), arithmetic, and the two byte writes of the reconstruction (tile and transposed tile).
+        uint8_t *T4t = L->T4t;
+        if (lane < 21) T4[lane + 3] = (uint8_t)(lane < 17 ? TOP(0, lane - 1) : TOP(0, 15));            // corner, top line (the four beyond it are never read: block 5 skips the modes that would)
+        else if (lane >= 32 && lane < 48) { const uint8_t v = (uint8_t)LEFT(0, lane - 32); T4t[lane - 32 + 4] = v; T4[(lane - 32 + 1) * 24 + 3] = v; }
         const int half = (lane >> 4) & 1, px = lane & 3, py = (lane >> 2) & 3;
         const qparams q4 = make_q(T, qp, true);
         // The 4x4 transforms run as two-stage butterflies over DPP lane exchanges (partner x^3 then x^1 forward, x^1 then x^3
@@ -354,6 +369,22 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         const int cl4 = (!(fx & 1) && !(fy & 1)) ? 0 : ((fx & 1) && (fy & 1)) ? 1 : 2;
         const int mf4 = cl4 == 0 ? q4.mf[0] : cl4 == 1 ? q4.mf[1] : q4.mf[2], v4 = cl4 == 0 ? q4.v[0] : cl4 == 1 ? q4.v[1] : q4.v[2];
         const int kz4 = (int)((0xFEA9DB83C7426510ull >> (4 * (fy * 4 + fx))) & 15); // raster -> zig-zag position
+        // ---- per sub-step, per lane: {predictor-table entry, source sample}, 16 bits each, five registers of two sub-steps
+        unsigned pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0;
+#pragma unroll
+        for (int s4 = 0; s4 < 10; s4++) {
+            const int by_lo = s4 > 3 ? (s4 - 2) >> 1 : 0, by_hi = (s4 >> 1) < 3 ? (s4 >> 1) : 3;
+            const bool two = by_lo + 1 <= by_hi;
+            const int by = (half && two) ? by_lo + 1 : by_lo, bx = s4 - 2 * by;
+            const int b = ((by >> 1) << 3) | ((bx >> 1) << 2) | ((by & 1) << 1) | (bx & 1); // blkIdx
+            const unsigned mw = b < 4 ? dec0.x : b < 8 ? dec0.y : b < 12 ? dec0.z : dec0.w;
+            const unsigned bmode = (mw >> (8 * (b & 3))) & 255u;
+            const unsigned ent = T->i4tab[bmode * 16 + py * 4 + px];
+            const unsigned sv = S4[(by * 4 + py) * 16 + bx * 4 + px];
+            const unsigned e = (ent | (sv << 8)) << (16 * (s4 & 1));
+            if (s4 < 2) pk0 |= e; else if (s4 < 4) pk1 |= e; else if (s4 < 6) pk2 |= e; else if (s4 < 8) pk3 |= e; else pk4 |= e;
+            if ((lane & 15) == 0 && lane < 32 && (half == 0 || two)) stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + b], (int)bmode); // the mode, for the entropy coder
+        }
         WAVE_SYNC();
 #pragma unroll 1
         for (int s4 = 0; s4 < 10; s4++) {
@@ -366,27 +397,22 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             const int trb = by > 0 && bx < 3 ? ((((by - 1) >> 1) << 3) | (((bx + 1) >> 1) << 2) | (((by - 1) & 1) << 1) | ((bx + 1) & 1)) : 99;
             const bool ur = by == 0 ? (bx < 3 && has_top) : (bx < 3 && trb < b);
             const int emax = ur ? 8 : 4;
-            const uint8_t *tb = &T4[(by * 4) * 24 + bx * 4];
-            // The 13 neighbours E(-4..8) (left column bottom-up, corner, top row with the top-right substitution) laid out as
-            // one line, both ends replicated: zb[j] = E(clamp(j - 5, -4, emax)).  Lane q of the block's 16 lanes builds
-            // entry q; every directional mode is then "copy / 2-tap / 3-tap at a table-given position of that line"
-            // (8.3.1.2.1-9 rewritten: T->i4tab[mode][pixel] = position + 5 | kind << 4).
-            const int q16 = lane & 15;
-            int ei = q16 - 5;
-            ei = ei < -4 ? -4 : (ei > emax ? emax : ei);
-            const int zv = ei < 0 ? (int)tb[(-ei) * 24] : (int)tb[ei];
-            uint8_t *zb = &L->z4[half * 16];
-            if (lane < 32) zb[q16] = (uint8_t)zv;
-            const int bmode = sh_mode4[by * 4 + bx];
-            const int sv = S4[(by * 4 + py) * 16 + bx * 4 + px];
-            const int sumL = wave16_sum(q16 >= 1 && q16 <= 4 ? zv : 0), sumT = wave16_sum(q16 >= 6 && q16 <= 9 ? zv : 0);
-            const int dc4 = (up && lf) ? (sumT + sumL + 4) >> 3 : lf ? (sumL + 2) >> 2 : up ? (sumT + 2) >> 2 : 128;
-            WAVE_SYNC();
+            const unsigned pw = s4 < 2 ? pk0 : s4 < 4 ? pk1 : s4 < 6 ? pk2 : s4 < 8 ? pk3 : pk4;
+            const unsigned pe = (pw >> (16 * (s4 & 1))) & 0xFFFFu;
+            const int j0 = (int)(pe & 15u), kind = (int)((pe >> 4) & 3u), sv = (int)(pe >> 8);
+            // E(i) of 8.3.1.2, i = -4 .. emax (beyond: replicated), see intra_lds: one byte address per tap
+            const int A0 = (4 * by) * 24 + 4 * bx + 3, B0 = 17 * 24 + (4 * bx) * 24 + 4 * by + 3;
+            const int ia = clip3(-4, emax, j0 - 5), ic = clip3(-4, emax, j0 - 4), id = clip3(-4, emax, j0 - 3);
+            const int oa = ia >= 0 ? A0 + ia : B0 - ia, oc = ic >= 0 ? A0 + ic : B0 - ic, od = id >= 0 ? A0 + id : B0 - id;
+            hk.before(s4);
+            const int za = T4[oa], zc = T4[oc], zd = T4[od];
+            const unsigned topw = *(const unsigned *)&T4[A0 + 1], leftw = *(const unsigned *)&T4[B0 + 1];
+            const int sumT = (int)__builtin_amdgcn_sad_u8(topw, 0u, 0u), sumL = (int)__builtin_amdgcn_sad_u8(leftw, 0u, 0u);
+            const int dcb = (sumT + sumL + 4) >> 3, dct = (sumT + 2) >> 2, dcl = (sumL + 2) >> 2;
+            const int dc4 = (up && lf) ? dcb : lf ? dcl : up ? dct : 128;
             // one weighted sum serves copy (4,0,0)/4, 2-tap (2,2,0 | +2)/4 and 3-tap (1,2,1 | +2)/4; selects written as
             // arithmetic on per-lane constants: as ?: chains the compiler turns them into exec-mask branches (~25
             // instructions each on this dependency chain)
-            const int ent = T->i4tab[bmode * 16 + py * 4 + px], j0 = ent & 15, kind = ent >> 4;
-            const int za = zb[j0], zc = zb[j0 + 1], zd = zb[j0 + 2];
             const int w0 = 4 >> kind, w1 = kind ? 2 : 0, w2 = kind >> 1;
             const int bdir = mad24(za, w0, mad24(zc, w1, mad24(zd, w2, w1))) >> 2;
             const int bpred = kind == 3 ? dc4 : bdir;
@@ -412,6 +438,12 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             pr = row_xor12(tc);
             const int rr = mad24(tc, sy1, pr);
             const int recp = clip255(bpred + ((rr + 32) >> 6));
+            if (valid) {
+                T4[(by * 4 + py + 1) * 24 + bx * 4 + px + 4] = (uint8_t)recp;
+                T4[17 * 24 + (bx * 4 + px + 1) * 24 + by * 4 + py + 4] = (uint8_t)recp;
+            }
+            WAVE_SYNC();
+            hk.after(s4, bx, by, px, py, valid, recp);
             const unsigned long long bal = __ballot(valid && lv4 != 0);
             const int b0 = ((by_lo >> 1) << 3) | (((s4 - 2 * by_lo) >> 1) << 2) | ((by_lo & 1) << 1) | ((s4 - 2 * by_lo) & 1);
             if (bal & 0xFFFFull) nz4 |= 1u << b0;
@@ -419,15 +451,12 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
                 const int by1 = by_lo + 1, bx1 = s4 - 2 * by1, b1 = ((by1 >> 1) << 3) | ((bx1 >> 1) << 2) | ((by1 & 1) << 1) | (bx1 & 1);
                 if (bal & 0xFFFF0000ull) nz4 |= 1u << b1;
             }
-            if (valid) {
-                T4[(by * 4 + py + 1) * 24 + bx * 4 + px + 1] = (uint8_t)recp;
+            if (valid) { // off the chain: nothing waits for these
                 stg8(ry + (size_t)(y0 + by * 4 + py) * stride + x0 + bx * 4 + px, (unsigned)recp);
                 stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + b * 16 + kz4], lv4);
-                if ((lane & 15) == 0) stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + b], bmode);
             }
-            WAVE_SYNC();
         }
-        if (OUT && lane < 16) { L->bot_y[slot][lane] = T4[16 * 24 + lane + 1]; L->right_y[lane] = T4[(lane + 1) * 24 + 16]; }
+        if (OUT && lane < 16) { L->bot_y[slot][lane] = T4[16 * 24 + lane + 4]; L->right_y[lane] = T4[17 * 24 + 16 * 24 + lane + 4]; }
     } else if (wave == 0) {
         // ================================================================ Intra_16x16 reconstruction (8.3.3 + 8.5.10)
         const int bx = lane & 3, by = lane >> 4, mode = mode16, yy = 4 * by + py;
@@ -550,6 +579,20 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
     }
 #undef TOP
 #undef LEFT
+    if (HK::own_record) {
+        if (wave == 1) {
+            if (OUT) {
+                WAVE_SYNC();
+                if (lane >= 16 && lane < 32) {
+                    const int i = lane - 16;
+                    L->bot_c[slot][i] = L->crec[7 * 16 + i];
+                    L->right_c[i >> 3][i & 7] = L->crec[(i & 7) * 16 + 14 + (i >> 3)];
+                }
+            }
+            hk.chroma_done(cnz8, cdc2);
+        } else hk.luma_done(use_i4 ? nz4 : nz16, !use_i4 && ldc_any != 0);
+        return;
+    }
     if (wave == 1) {
         if (OUT) {
             WAVE_SYNC();
@@ -575,6 +618,13 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = dec1.y;
         st_mbinfo(&ctx->mbi[mbn], mb);
     }
+}
+
+template <bool OUT, bool SC1 = false>
+DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, intra_lds *L, const int mx, const int my, const int wave, const int lane,
+                       const uint4 dec0, const uint2 dec1, const uint2 *presrc = nullptr) {
+    ic_nohook hk;
+    intra_compute<OUT, SC1, ic_nohook>(ctx, T, L, mx, my, wave, lane, dec0, dec1, presrc, hk);
 }
 
 // One launch per anti-diagonal x + y (replayed as a hipGraph): neighbours come from the reconstructed picture in global
@@ -767,6 +817,360 @@ void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsig
     a.ctx = *h_ctx; a.gran = d_gran; a.err = d_err; a.band_done = d_band_done;
     if (h_ctx->i4x4) hipLaunchKernelGGL(intra_band_kernel<true>, dim3(k_intra_bands(mbh)), dim3(IB_ROWS * 128), 0, s, a);
     else hipLaunchKernelGGL(intra_band_kernel<false>, dim3(k_intra_bands(mbh)), dim3(IB_ROWS * 128), 0, s, a);
+}
+
+// =================================================================== intra pictures, dataflow at 4x4-block granularity (intra_mode 0)
+// The band kernel above walks the picture in x + y order with one barrier per step: a macroblock is a unit, an Intra_4x4 macroblock is ten
+// dependent sub-steps (blocks with bx + 2 by = s), so the critical path is 10 (mbw + mbh) sub-steps.  But macroblock x + 1 reads only the
+// right column of macroblock x, whose block (3, by) is final after sub-step 3 + 2 by: its sub-step s may run once x has finished sub-step
+// s + 3 -- a lag of four sub-steps, not ten.  And the row below reads only the bottom lines of the blocks (bx, 3), final after sub-steps
+// 6 .. 9 (the top-right neighbour of a macroblock's block 5 is never used: the analysis leaves the two modes that read it out): a lag of
+// eight.  Critical path 4 mbw + 8 mbh sub-steps (1080p: ~1030 against ~1880) -- if macroblocks overlap.  So:
+//   * one workgroup per macroblock ROW, IR_LW luma waves taking the row's macroblocks in turn (x mod IR_LW: 2.5 macroblocks of a row are in
+//     flight at a lag of four) and one chroma wave walking the row by itself (8x8 chroma is a third of an Intra_4x4 macroblock's work and
+//     depends on nothing of luma): four waves, one per SIMD;
+//   * inside the row everything is dataflow through LDS: a progress word per macroblock (x << 4 | sub-steps done) and its right column in a
+//     ring of IR_RING slots; a wave waits for exactly the word it needs before the sub-step that needs it (hooks of intra_compute);
+//   * between rows the bottom line of every 4x4 block column travels as an 8-byte granule {4 samples, tag}, one sc1 store the moment the
+//     block is done, polled by the row below (MI355X_MICROARCH.md hand-off R2; the tag is the picture's epoch inverted, nothing is cleared);
+//   * the record of a macroblock needs the luma and the chroma wave's flags: whoever finishes second writes it (one LDS word per macroblock in
+//     a ring of eight; a wave that is eight macroblocks ahead of the other plane waits there).
+// An Intra_16x16 macroblock needs its whole left column and top line, so it simply waits for "ten sub-steps done" of its left neighbour: the
+// dataflow form degrades to the x + y order exactly where the standard demands it.  Every wait is bounded and reports through `err`.
+#ifndef IR_LW
+#define IR_LW 3
+#endif
+#ifndef IR_SLEEP
+#define IR_SLEEP 1
+#endif
+#define IR_RING 4
+#define IR_TR 8 /* macroblocks of top lines / source samples / decisions the movers keep in LDS */
+#define IR_WAVES (IR_LW + 3)
+#define IR_LDONE (1u << 30)
+#define IR_CDONE (1u << 31)
+struct ir_args { frame_ctx_t ctx; uint2 *gran; unsigned *err; unsigned *row_done; };
+struct ir_shared {
+    unsigned prog[IR_RING];                                   // (x << 4) | sub-steps done (10: the macroblock is complete), slot x % IR_RING
+    unsigned rec[8];                                          // nzmask bits of one plane + IR_LDONE / IR_CDONE, slot x % 8
+    __attribute__((aligned(4))) uint8_t right[IR_RING][16];   // right luma column of macroblock x
+    // what the two mover waves bring in, rings of IR_TR macroblocks, and how far they and their readers are (all counts only grow)
+    unsigned nly;                                             // 4 x + j: the luma top-line granules (x', 0..3) of every x' < x and (x, 0 .. j-1) are in topy
+    unsigned ncu;                                             // macroblocks whose chroma top line is in topc
+    unsigned nsrc;                                            // macroblocks whose source samples and decision are in srcy / srcc / dec
+    unsigned ldone, cdone;                                    // macroblocks the luma waves / the chroma wave have completed
+    __attribute__((aligned(16))) uint8_t topy[IR_TR][16], topc[IR_TR][16];
+    __attribute__((aligned(16))) unsigned srcy[IR_TR][64];
+    __attribute__((aligned(16))) uint2 srcc[IR_TR][32];
+    __attribute__((aligned(16))) unsigned dec[IR_TR][8];
+};
+// LDS-only ordering: a wave's LDS operations are carried out in the order it issued them, so "data, then flag" needs nothing but the
+// compiler to keep the order, and "flag, then data" nothing but the wait for the flag's value.  (A workgroup-scope acquire / release on a
+// generic pointer also waits for every global store the wave has in flight -- the levels and reconstruction stores of the sub-step before:
+// a memory round trip per sub-step on the dependency chain.)
+DEV unsigned lds_ld_acq(const unsigned *p) {
+    const unsigned v = *(const volatile __attribute__((address_space(3))) unsigned *)p;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return v;
+}
+DEV void lds_st_rel(unsigned *p, unsigned v) {
+    asm volatile("" ::: "memory");
+    *(volatile __attribute__((address_space(3))) unsigned *)p = v;
+}
+// wave-uniform bounded wait for an LDS word to reach `need` (words only grow)
+DEV void ir_wait_lds(const unsigned *p, unsigned need, unsigned *err, unsigned code) {
+    int spins = 0;
+    while ((int)(lds_ld_acq(p) - need) < 0) {
+        __builtin_amdgcn_s_sleep(IR_SLEEP);
+        if (++spins > 8 * DB_SPIN_MAX) { st_sc1(err, code); break; }
+        if ((spins & 8191) == 0 && ld_sc1(err)) break;
+    }
+}
+DEV void ir_put_record(const frame_ctx_t *ctx, int mbn, uint2 dec1, unsigned bits) {
+    const bool use_i4 = ((dec1.x >> 16) & 255) != 0;
+    mb_info_t mb;
+    mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)(dec1.x & 255); mb.chroma_mode = (uint8_t)((dec1.x >> 8) & 255);
+    mb.qp = (uint8_t)ctx->qp; mb.nzmask = bits & ~(IR_LDONE | IR_CDONE); mb.cost = dec1.y;
+    st_mbinfo(&ctx->mbi[mbn], mb);
+}
+// deposit one plane's bits for macroblock x; the second plane to arrive writes the record and frees the slot (lane 0 of the wave)
+DEV void ir_deposit(ir_shared *sh, const frame_ctx_t *ctx, int mbn, int x, uint2 dec1, unsigned bits, unsigned mine, unsigned other) {
+    const unsigned old = atomicOr(&sh->rec[x & 7], bits | mine);
+    if (old & other) { ir_put_record(ctx, mbn, dec1, old | bits); lds_st_rel(&sh->rec[x & 7], 0u); }
+}
+#ifdef IR_PROF /* debug builds: cycle counters per wave, left in ctx->isad (tests/devtools/irprof.py) */
+#define IR_T0() const unsigned long long ir_t0 = __builtin_readcyclecounter()
+#define IR_ACC(v) v += __builtin_readcyclecounter() - ir_t0
+#else
+#define IR_T0() do { } while (0)
+#define IR_ACC(v) do { } while (0)
+#endif
+struct ir_luma_hook {
+    static constexpr bool own_record = true;
+    ir_shared *sh; uint8_t *T4; uint2 *gran_my; unsigned *err; unsigned tag; int x, lane; bool has_top, has_left, feeds;
+    unsigned nz; bool ldc;
+    unsigned long long c_wait_top = 0, c_wait_left = 0, c_after = 0;
+    DEV void before(int s) {
+        if (has_top && s <= 2) { // the top line arrives with the blocks that read it: (x, 0), (x, 1) and the corner for sub-step 0, then (x, 2), then (x, 3)
+            { IR_T0(); ir_wait_lds(&sh->nly, 4u * (unsigned)x + (unsigned)(s + 2), err, 14u); IR_ACC(c_wait_top); }
+            const uint8_t *line = sh->topy[x & (IR_TR - 1)];
+            if (s == 0) {
+                if (lane == 0) T4[3] = has_left ? sh->topy[(x - 1) & (IR_TR - 1)][15] : (uint8_t)0;
+                else if (lane < 9) T4[3 + lane] = line[lane - 1];
+            } else if (lane < 4) T4[8 + 4 * s + lane] = line[4 + 4 * s + lane];
+        }
+        if (has_left && !(s & 1) && s <= 6) { // block (0, s / 2) reads rows 2 s .. 2 s + 3 of the left neighbour's right column: final after its sub-step s + 3
+            { IR_T0(); ir_wait_lds(&sh->prog[(x - 1) & (IR_RING - 1)], ((unsigned)(x - 1) << 4) | (unsigned)(s + 4), err, 18u); IR_ACC(c_wait_left); }
+            if (lane < 4) {
+                const uint8_t v = sh->right[(x - 1) & (IR_RING - 1)][2 * s + lane];
+                T4[17 * 24 + 4 + 2 * s + lane] = v;        // transposed tile: the column left of the macroblock
+                T4[(2 * s + lane + 1) * 24 + 3] = v;       // tile: the corner of the blocks (0, by > 0)
+            }
+        }
+        WAVE_SYNC();
+    }
+    // straight from the lanes' registers: the right column of block (3, by) for macroblock x + 1, the bottom line of block (bx, 3) for the row below
+    DEV void after(int s, int bx, int by, int px, int py, bool valid, int recp) {
+        IR_T0();
+        if (valid && bx == 3 && px == 3) sh->right[x & (IR_RING - 1)][4 * by + py] = (uint8_t)recp;
+        if (feeds && s >= 6) {
+            int v = recp << (8 * px);
+            v |= quad_xor<1>(v);
+            v |= quad_xor<2>(v);
+            if (valid && by == 3 && py == 3 && px == 0) st64_sc1(gran_my + (size_t)x * 8 + bx, make_uint2((unsigned)v, tag));
+        }
+        if (lane == 0) lds_st_rel(&sh->prog[x & (IR_RING - 1)], ((unsigned)x << 4) | (unsigned)(s + 1));
+        IR_ACC(c_after);
+    }
+    DEV void luma_done(unsigned nzb, bool dc) { nz = nzb; ldc = dc; }
+    DEV void chroma_done(unsigned, unsigned) {}
+};
+struct ir_chroma_hook {
+    static constexpr bool own_record = true;
+    unsigned nz8, dc2;
+    DEV void before(int) {}
+    DEV void after(int, int, int, int, int, bool, int) {}
+    DEV void luma_done(unsigned, bool) {}
+    DEV void chroma_done(unsigned a, unsigned b) { nz8 = a; dc2 = b; }
+};
+
+__global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
+    __shared__ intra_lds LD[IR_LW + 1]; // private to each compute wave
+    __shared__ ir_shared SH;
+    __shared__ unsigned tabw[TAB_DWORDS];
+    const dev_tables *T = (const dev_tables *)tabw;
+    const frame_ctx_t *__restrict__ ctx = &a.ctx;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, my = blockIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool has_top = my > 0, feeds = my < mbh - 1;
+    for (int i = threadIdx.x; i < TAB_DWORDS; i += 64 * IR_WAVES) tabw[i] = ((const unsigned *)&g_tab)[i];
+    if (threadIdx.x < IR_RING) SH.prog[threadIdx.x] = 0;
+    if (threadIdx.x < 8) SH.rec[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { SH.nly = 0; SH.ncu = 0; SH.nsrc = 0; SH.ldone = 0; SH.cdone = 0; }
+    const unsigned tag = ~ctx->epoch;
+    const uint2 *gran_up = a.gran + (size_t)(my > 0 ? my - 1 : 0) * mbw * 8;
+    uint2 *gran_my = a.gran + (size_t)my * mbw * 8;
+    const int spy = (lane >> 2) & 3;
+    __syncthreads();
+    if (w < IR_LW) {
+        // ================================================================ luma: macroblocks w, w + IR_LW, ...  Nothing here waits for memory:
+        // source samples, decisions and the row above's bottom lines come through LDS (the movers), stores are fire-and-forget.
+        intra_lds *L = &LD[w];
+        ir_luma_hook hk;
+        hk.sh = &SH; hk.T4 = L->T4; hk.gran_my = gran_my; hk.err = a.err; hk.tag = tag; hk.lane = lane; hk.has_top = has_top; hk.feeds = feeds;
+#ifdef IR_PROF
+        unsigned long long c_mb4 = 0, c_mb16 = 0, c_src = 0, c_rec = 0, n4 = 0, n16 = 0;
+        const unsigned long long c_start = __builtin_readcyclecounter();
+#endif
+        for (int x = w; x < mbw; x += IR_LW) {
+            { IR_T0(); ir_wait_lds(&SH.nsrc, (unsigned)x + 1u, a.err, 20u); IR_ACC(c_src); }
+            const unsigned *dw = SH.dec[x & (IR_TR - 1)];
+            const uint4 dec0 = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+            const uint2 dec1 = make_uint2(dw[4], dw[5]);
+            const uint2 srcc = make_uint2(SH.srcy[x & (IR_TR - 1)][lane], 0u);
+            const bool use_i4 = ((dec1.x >> 16) & 255) != 0, has_left = x > 0;
+            hk.x = x; hk.has_left = has_left; hk.nz = 0; hk.ldc = false;
+            if (!use_i4) { // Intra_16x16: the whole top line, the corner, the whole left column
+                int tv = 0, lv = 0;
+                if (has_left) ir_wait_lds(&SH.prog[(x - 1) & (IR_RING - 1)], ((unsigned)(x - 1) << 4) | 10u, a.err, 18u);
+                if (has_top) {
+                    ir_wait_lds(&SH.nly, 4u * (unsigned)x + 4u, a.err, 14u);
+                    if (lane >= 1 && lane < 17) tv = (int)SH.topy[x & (IR_TR - 1)][lane - 1];
+                    if (lane == 0 && has_left) tv = (int)SH.topy[(x - 1) & (IR_TR - 1)][15];
+                }
+                if (has_left && lane >= 1 && lane < 17) lv = (int)SH.right[(x - 1) & (IR_RING - 1)][lane - 1];
+                if (lane == 0) lv = tv; // the corner belongs to both arrays (0 unless both neighbours exist)
+                if (lane < 17) { L->top[0][lane] = tv; L->left[0][lane] = lv; }
+                WAVE_SYNC();
+            }
+            {
+                IR_T0();
+                if (lane == 0) { // a luma wave eight macroblocks ahead of the chroma wave waits for its record slot
+                    int spins = 0;
+                    while (lds_ld_acq(&SH.rec[x & 7]) & IR_LDONE) { __builtin_amdgcn_s_sleep(2); if (++spins > 8 * DB_SPIN_MAX) { st_sc1(a.err, 19u); break; } }
+                }
+                IR_ACC(c_rec);
+            }
+            {
+                IR_T0();
+                intra_compute<true, false, ir_luma_hook>(ctx, T, L, x, my, 0, lane, dec0, dec1, &srcc, hk);
+#ifdef IR_PROF
+                if (use_i4) { IR_ACC(c_mb4); n4++; } else { IR_ACC(c_mb16); n16++; }
+#endif
+            }
+            if (!use_i4) { // published at once: right column, bottom line, "complete"
+                WAVE_SYNC();
+                if (lane < 16) SH.right[x & (IR_RING - 1)][lane] = L->right_y[lane];
+                if (feeds && lane < 4) st64_sc1(gran_my + (size_t)x * 8 + lane, make_uint2(((const unsigned *)L->bot_y[x & 3])[lane], tag));
+                if (lane == 0) lds_st_rel(&SH.prog[x & (IR_RING - 1)], ((unsigned)x << 4) | 10u);
+            }
+            if (lane == 0) {
+                ir_deposit(&SH, ctx, my * mbw + x, x, dec1, hk.nz | (hk.ldc ? NZ_LDC : 0u), IR_LDONE, IR_CDONE);
+                atomicMax(&SH.ldone, (unsigned)x + 1u); // (macroblocks complete in order -- x cannot pass sub-step 6 before x - 1 is done -- but the waves reach this line in any order)
+            }
+        }
+#ifdef IR_PROF
+        if (lane == 0 && my < 4) {
+            unsigned *o = (unsigned *)ctx->isad + (my * 4 + w) * 16;
+            o[0] = (unsigned)(__builtin_readcyclecounter() - c_start); o[1] = (unsigned)c_mb4; o[2] = (unsigned)n4; o[3] = (unsigned)c_mb16; o[4] = (unsigned)n16;
+            o[5] = (unsigned)hk.c_wait_top; o[6] = (unsigned)hk.c_wait_left; o[7] = (unsigned)hk.c_after; o[8] = (unsigned)c_src; o[9] = (unsigned)c_rec;
+        }
+#endif
+    } else if (w == IR_LW) {
+        // ================================================================ chroma: every macroblock of the row, left to right
+        intra_lds *L = &LD[IR_LW];
+        ir_chroma_hook hk;
+        const bool tlane = lane < 18; // plane c = lane / 9, sample i = lane % 9 - 1 (-1: the corner)
+        const int mc = lane / 9, mi = lane % 9 - 1;
+#ifdef IR_PROF
+        unsigned long long c_cmp = 0, c_src = 0, c_top = 0, c_rec = 0;
+        const unsigned long long c_start = __builtin_readcyclecounter();
+#endif
+        for (int x = 0; x < mbw; x++) {
+            { IR_T0(); ir_wait_lds(&SH.nsrc, (unsigned)x + 1u, a.err, 20u); IR_ACC(c_src); }
+            const unsigned *dw = SH.dec[x & (IR_TR - 1)];
+            const uint2 dec1 = make_uint2(dw[4], dw[5]);
+            const uint2 srcc = SH.srcc[x & (IR_TR - 1)][lane & 31];
+            const bool has_left = x > 0;
+            int tv = 0, lv = 0;
+            if (has_top) {
+                { IR_T0(); ir_wait_lds(&SH.ncu, (unsigned)x + 1u, a.err, 14u); IR_ACC(c_top); }
+                if (tlane && (mi >= 0 || has_left)) tv = mi >= 0 ? (int)SH.topc[x & (IR_TR - 1)][2 * mi + mc] : (int)SH.topc[(x - 1) & (IR_TR - 1)][14 + mc];
+            }
+            if (tlane && has_left && (mi >= 0 || has_top)) lv = mi >= 0 ? (int)L->right_c[mc][mi] : tv;
+            WAVE_SYNC(); // (right_c of the previous macroblock has been read)
+            if (tlane) { L->top[1 + mc][mi + 1] = tv; L->left[1 + mc][mi + 1] = lv; }
+            {
+                IR_T0();
+                if (lane == 0) {
+                    int spins = 0;
+                    while (lds_ld_acq(&SH.rec[x & 7]) & IR_CDONE) { __builtin_amdgcn_s_sleep(2); if (++spins > 8 * DB_SPIN_MAX) { st_sc1(a.err, 19u); break; } }
+                }
+                WAVE_SYNC();
+                IR_ACC(c_rec);
+            }
+            { IR_T0(); intra_compute<true, false, ir_chroma_hook>(ctx, T, L, x, my, 1, lane, make_uint4(0, 0, 0, 0), dec1, &srcc, hk); IR_ACC(c_cmp); }
+            WAVE_SYNC();
+            if (feeds && lane < 4) st64_sc1(gran_my + (size_t)x * 8 + 4 + lane, make_uint2(((const unsigned *)L->bot_c[x & 3])[lane], tag));
+            unsigned bits = hk.nz8 << 16;
+            if (hk.dc2 & 1) bits |= NZ_CBDC;
+            if (hk.dc2 & 2) bits |= NZ_CRDC;
+            if (lane == 0) {
+                ir_deposit(&SH, ctx, my * mbw + x, x, dec1, bits, IR_CDONE, IR_LDONE);
+                lds_st_rel(&SH.cdone, (unsigned)x + 1u);
+            }
+        }
+#ifdef IR_PROF
+        if (lane == 0 && my < 4) {
+            unsigned *o = (unsigned *)ctx->isad + (my * 4 + 3) * 16;
+            o[0] = (unsigned)(__builtin_readcyclecounter() - c_start); o[1] = (unsigned)c_cmp; o[2] = (unsigned)mbw; o[5] = (unsigned)c_top; o[8] = (unsigned)c_src; o[9] = (unsigned)c_rec;
+        }
+#endif
+    } else if (w == IR_LW + 1) {
+        // ================================================================ mover G: the bottom lines of the row above, granule by granule, into LDS.
+        // Lanes 0..3 follow the luma granules of macroblock xl (they arrive in the order 0 1 2 3), lanes 4..7 the chroma line of
+        // macroblock xc.  This wave stores nothing, so its waits for the polled loads are nothing but their latency.
+        if (has_top) {
+            int xl = 0, nj = 0, xc = 0, idle = 0;
+            while (xl < mbw || xc < mbw) {
+                const unsigned ld = lds_ld_acq(&SH.ldone), cd = lds_ld_acq(&SH.cdone);
+                const bool go_l = xl < mbw && xl < (int)ld + IR_TR - 2, go_c = xc < mbw && xc < (int)cd + IR_TR - 2; // the ring slot's previous line (macroblock x - 8) is the corner of x - 7
+                const bool mine = lane < 4 ? go_l : (lane < 8 && go_c);
+                const int gx = lane < 4 ? (xl < mbw ? xl : mbw - 1) : (xc < mbw ? xc : mbw - 1);
+                uint2 g = make_uint2(0u, ~tag);
+                if (mine) g = ld64_sc1(gran_up + (size_t)gx * 8 + (lane & 7));
+                const unsigned ok = (unsigned)__ballot(mine && g.y == tag);
+                bool moved = false;
+                int np = __builtin_ctz(~(ok & 15u)); // granules 0 .. np-1 of xl are there
+                if (go_l && np > nj) {
+                    if (lane >= nj && lane < np) *(unsigned *)&SH.topy[xl & (IR_TR - 1)][4 * lane] = g.x;
+                    nj = np; moved = true;
+                    if (nj == 4) { xl++; nj = 0; }
+                    if (lane == 0) lds_st_rel(&SH.nly, 4u * (unsigned)xl + (unsigned)nj);
+                }
+                if (go_c && (ok & 0xF0u) == 0xF0u) {
+                    if (lane >= 4 && lane < 8) *(unsigned *)&SH.topc[xc & (IR_TR - 1)][4 * (lane - 4)] = g.x;
+                    xc++; moved = true;
+                    if (lane == 0) lds_st_rel(&SH.ncu, (unsigned)xc);
+                }
+                if (moved) idle = 0;
+                else {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++idle > DB_SPIN_MAX) { st_sc1(a.err, 14u); break; }
+                    if ((idle & 1023) == 0 && ld_sc1(a.err)) break;
+                }
+            }
+        }
+    } else {
+        // ================================================================ mover S: source samples and decisions, two macroblocks ahead of their landing
+        int sy = my * 16 + 4 * (lane >> 4) + spy;
+        sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
+        const uint8_t *srow = ctx->src_y + (size_t)sy * ctx->src_stride + 4 * (lane & 3);
+        const int vh2 = ctx->vis_h >> 1;
+        int cy = my * 8 + 4 * ((lane >> 4) & 1) + spy;
+        cy = cy < vh2 ? cy : vh2 - 1;
+        const uint8_t *crow = ctx->src_uv + (size_t)cy * ctx->src_stride + 8 * (lane & 1);
+        const uint8_t *drow = ctx->idec + (size_t)my * mbw * IDEC_BYTES + 4 * (lane & 7);
+        unsigned yA, yB, dA, dB;
+        uint2 cA, cB;
+        auto issue = [&](int x, unsigned &yv, uint2 &cv, unsigned &dv) __attribute__((always_inline)) {
+            const int xc = x < mbw ? x : mbw - 1;
+            yv = ldg32(srow + xc * 16); cv = ldg64(crow + xc * 16); dv = ldg32(drow + (size_t)xc * IDEC_BYTES);
+        };
+        auto land = [&](int x, unsigned yv, uint2 cv, unsigned dv) __attribute__((always_inline)) {
+            // slot x % IR_TR held macroblock x - IR_TR: both planes must be through with it
+            ir_wait_lds(&SH.ldone, (unsigned)(x - IR_TR + 1), a.err, 20u);
+            ir_wait_lds(&SH.cdone, (unsigned)(x - IR_TR + 1), a.err, 20u);
+            SH.srcy[x & (IR_TR - 1)][lane] = yv;
+            if (lane < 32) SH.srcc[x & (IR_TR - 1)][lane] = cv;
+            if (lane < 8) SH.dec[x & (IR_TR - 1)][lane] = dv;
+            if (lane == 0) lds_st_rel(&SH.nsrc, (unsigned)x + 1u);
+        };
+        issue(0, yA, cA, dA);
+        issue(1, yB, cB, dB);
+        for (int x = 0; x < mbw; x += 2) {
+            land(x, yA, cA, dA);
+            issue(x + 2, yA, cA, dA);
+            if (x + 1 < mbw) land(x + 1, yB, cB, dB);
+            issue(x + 3, yB, cB, dB);
+        }
+    }
+    // ---- this row's reconstruction and records are complete: tell the band deblocker, which may be waiting on another stream (release
+    // pattern of MI355X_MICROARCH.md: every storing wave drains, the workgroup meets, one lane writes this XCD's L2 back, then the tagged flag)
+    if (a.row_done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_sc1(a.row_done + my, tag);
+        }
+    }
+}
+// d_gran: 8 granules per macroblock (four luma block columns, four words of the interleaved chroma line), one set per row
+void k_launch_intra_rows(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, unsigned *d_row_done, hipStream_t s) {
+    ir_args a;
+    a.ctx = *h_ctx; a.gran = d_gran; a.err = d_err; a.row_done = d_row_done;
+    hipLaunchKernelGGL(intra_rows_kernel, dim3(mbh), dim3(64 * IR_WAVES), 0, s, a);
 }
 
 // =================================================================== launchers

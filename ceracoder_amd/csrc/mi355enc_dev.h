@@ -124,6 +124,8 @@ void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int
 int k_intra_diags(int mbw, int mbh);
 int k_intra_bands(int mbh);
 void k_launch_intra_band(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, unsigned *d_band_done, hipStream_t s);
+/* I pictures, dataflow at 4x4-block granularity: one workgroup per macroblock row; d_gran: 8 granules per macroblock; d_row_done (may be null): one tagged word per row */
+void k_launch_intra_rows(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, unsigned *d_row_done, hipStream_t s);
 int k_launch_csc(int fmt, const uint8_t *p0, const uint8_t *p1, const uint8_t *p2, int s0, int s1, int s2, uint8_t *dy, uint8_t *duv,
                  int vw, int vh, int W, int H, hipStream_t s);
 void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, int mbw, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,

@@ -71,8 +71,9 @@ typedef struct {
                                  same single slice); 1: the calling thread only; 0 (default, like x264enc's threads=0): chosen
                                  from the machine -- a quarter of the online CPUs, between 1 and 8 (1 for pictures under
                                  1000 macroblocks, where waking workers costs more than it saves); mi355enc_stats_t reports it */
-    int intra_mode;           /* 0 (default): persistent band kernel for the intra reconstruction wavefront; 1: one launch per
-                                 anti-diagonal replayed as a hipGraph (plain form, kept as a cross-check) */
+    int intra_mode;           /* 0 (default): one persistent launch, a workgroup per macroblock row, macroblocks overlapping at 4x4-block
+                                 granularity (dataflow); 1: one launch per anti-diagonal replayed as a hipGraph (plain form, kept as a
+                                 cross-check); 2: the lock-step band kernel of rounds 1-2 (x + y order, one barrier per step; kept for A/B) */
     int vbv_ms;               /* rate control's buffer model in ms of stream at the setpoint (default 600: x264enc's vbv-buf-capacity): an IDR
                                  picture is planned at most half of it, and P pictures are all-skip while the bucket is nearly full */
     int scenecut;             /* 1 (default, like x264's scenecut): when the summed motion cost of a P picture exceeds three times

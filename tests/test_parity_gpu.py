@@ -163,7 +163,7 @@ def test_intra_analyse_kernel_matches_oracle(E, oracle, w, h):
 
 @pytest.mark.parametrize("w,h", [(176, 144), (320, 180), (1280, 720), (48, 272)])
 @pytest.mark.parametrize("qp,drop", [(51, 1), (51, 2), (51, 4), (51, 12), (38, 7), (44, 3)])
-@pytest.mark.parametrize("imode", [0, 1])
+@pytest.mark.parametrize("imode", [0, 1, 2])
 def test_intra_kernel_drop_ladder_matches_oracle(E, oracle, w, h, qp, drop, imode):
     """Rate control's ladder for I pictures (below what QP 51 reaches): Intra_16x16 only, and a macroblock's luma / chroma
     levels are not sent when their magnitudes sum to no more than the level's threshold."""
@@ -184,10 +184,10 @@ def test_intra_kernel_drop_ladder_matches_oracle(E, oracle, w, h, qp, drop, imod
 @pytest.mark.parametrize("w,h", SIZES + [(48, 272), (80, 528)])
 @pytest.mark.parametrize("qp", [0, 12, 28, 40, 51])
 @pytest.mark.parametrize("i4", [True, False])
-@pytest.mark.parametrize("imode", [0, 1])
+@pytest.mark.parametrize("imode", [0, 1, 2])
 def test_intra_kernel_matches_oracle(E, oracle, w, h, qp, i4, imode):
-    """imode 0: persistent band kernel (LDS hand-off inside a band, sc1 + progress counters between bands);
-    imode 1: one launch per anti-diagonal from a hipGraph."""
+    """imode 0: one workgroup per macroblock row, macroblocks overlapping at 4x4-block granularity (dataflow through LDS inside the row,
+    tagged granules between rows); imode 1: one launch per anti-diagonal from a hipGraph; imode 2: the lock-step band kernel."""
     cy, cuv = frames(w, h, 1)[0][:2]
     oracle.set_i4x4(i4)
     try:
@@ -225,7 +225,7 @@ def test_deblock_kernel_matches_oracle(E, oracle, w, h, qp, mode):
 
 
 @pytest.mark.parametrize("w,h,n", [(64, 48, 9), (176, 144, 7), (322, 182, 5), (1280, 720, 4), (1920, 1080, 3)])
-@pytest.mark.parametrize("graphs,mode,sub,thr,imode", [(True, 0, True, 1, 0), (False, 0, False, 3, 1), (True, 1, True, 1, 1), (True, 0, True, 4, 0)])
+@pytest.mark.parametrize("graphs,mode,sub,thr,imode", [(True, 0, True, 1, 0), (False, 0, False, 3, 1), (True, 1, True, 1, 1), (True, 0, True, 4, 0), (True, 0, True, 2, 2)])
 def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub, thr, imode):
     """Whole path: identical access units, identical reconstruction, and the independent
     decoder reproduces both."""

@@ -3,8 +3,10 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ceracoder_amd import enc as E, synth
+E.LIB_PATH = os.environ.get('MI355ENC_LIB', E.LIB_PATH)
+MODES = tuple(int(m) for m in os.environ.get('IMODES', '0,2,1').split(','))
 for (w, h) in ((1920, 64), (1920, 1080)):
-    for imode in (0, 1):
+    for imode in MODES:
         for i4, qp in ((True, 24), (True, 40), (False, 40)):
             e = E.Encoder(w, h, gop=60, fixed_qp=qp, i4x4=i4, intra_mode=imode)
             fr = list(synth.s2_frames(w, h, 1))
