@@ -516,6 +516,7 @@ def main():
             "ms_per_step": round(dt / (S * args.steps) * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic (S2: panning texture + 12 moving rectangles, seed 0x5EED), resident in HBM",
             "idr_in_timed_region": n_idr, "skip_pictures_in_timed_region": int(st.skip_pictures),
+            "device_wait_recoveries": int(st.recoveries), "safe_level": int(st.safe_level),  # must be 0 / 0: a recovery means a bounded device-side wait ran out
             "value_note": "pictures that went through the device per second: rate control's all-skip pictures (one P_Skip run written by the host, no kernel) are not counted",
             "frames_per_s_including_skip_pictures": round(world * S * args.steps / dt, 2),
             "gop_weighted_frames_per_s": round(gop_fps, 1) if gop_fps else None,

@@ -10,6 +10,10 @@
 std::atomic<int> g_open_encoders{0};
 bool exclusive_device(const mi355enc_t *h) { static const bool env = getenv("MI355ENC_EXCLUSIVE") != nullptr; return h->cfg.exclusive_device != 0 || env; } // cfg.exclusive_device, or the environment for tools
 bool no_pgate() { static const bool off = getenv("MI355ENC_NO_PGATE") != nullptr; return off; } // A/B switch: the fused P stage in stream order behind the deblocking launch
+// Two deblocking launches in flight (consecutive pictures' launches on two streams, the intra macroblock rows of a P picture riding in its
+// deblocking launch): built, bit-exact, and in round 3 SLOWER than one launch behind the other (1080p: 3100-3800 against 4990 frames/s; device
+// timeline in DESIGN.md section 5), so it is off unless MI355ENC_DB2 is set.
+bool no_db2() { static const bool on = getenv("MI355ENC_DB2") != nullptr; return !on; }
 bool overlap_allowed(const mi355enc_t *h) {
     static const bool serial = getenv("MI355ENC_SERIAL") != nullptr;
     return !serial && h->safe_level == 0 && g_open_encoders.load(std::memory_order_relaxed) == 1;
@@ -18,6 +22,7 @@ bool overlap_allowed(const mi355enc_t *h) {
 int sync_compute(mi355enc_t *h) {
     HIPCHK(hipStreamSynchronize(h->fstream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->cstream)); // (also the second home of the deblocking launches)
     HIPCHK(hipStreamSynchronize(h->istream));
     return 0;
 }
@@ -108,8 +113,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     for (int i = 0; i < NSET; i++) { h->g_intra[i] = h->g_deblock[i] = nullptr; h->d_ctx2[i] = nullptr; h->d_surf[i] = nullptr; h->d_idec2[i] = nullptr; h->d_mbi_set[i] = nullptr; h->d_levels_set[i] = nullptr; }
     h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->d_row_done = nullptr; h->pmb_rows_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
-    h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; 
+    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->ip_done_total = 0; h->d_row_done = nullptr; h->pmb_rows_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->ev_join = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
     h->fixed_qp.store(cfg->fixed_qp);
@@ -117,6 +122,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     *out = h; // from here on close() cleans up partial state
     g_open_encoders.fetch_add(1, std::memory_order_relaxed);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    h->db_flip = 0; h->s2_dirty = 0; h->inorder_since_s2 = 0;
     for (int i = 0; i < NSET; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
     h->d_ctx = h->d_ctx2[0];
     { // The hand-over stream gets its own priority level: HIP then backs it with a different hardware queue, so its
@@ -259,6 +266,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
     if (h->fstream) (void)hipStreamDestroy(h->fstream);
     if (h->istream) (void)hipStreamDestroy(h->istream);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h264_writer_free(h->writer);
     delete h;

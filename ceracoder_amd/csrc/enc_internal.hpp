@@ -68,7 +68,13 @@ struct mi355enc {
     slot_t *prev_slot;                   // slot of the picture enqueued last
     mb_info_t *d_mbi, *d_mbi_set[NSET];  // record/level sets: the hand-over of picture n overlaps the kernels of n+1 (and n+2)
     int16_t *d_levels, *d_levels_set[NSET];
-    hipStream_t cstream;                 // copy stream for the D2H hand-over
+    // With three pictures in flight consecutive pictures' deblocking launches alternate between `stream` and `cstream`, so that the next
+    // picture's upper bands run beside this picture's lower ones (the hand-over kernels of such pictures go to the intra stream, behind
+    // intra_p_kernel).  No stream of its own for that: a fifth stream in the process cost a third of the frame rate (the runtime then maps
+    // two of them onto one hardware queue, and kernels meant to run beside each other take turns), whatever GPU_MAX_HW_QUEUES said.
+    hipEvent_t ev_join;                  // orders the two against each other where a picture runs its stages in order
+    int db_flip, s2_dirty, inorder_since_s2;
+    hipStream_t cstream;                 // hand-over stream (scan + pack into pinned host memory); second home of the deblocking launches
     uint64_t n_submitted;
     uint64_t sc_sum, sc_force_at; int sc_cnt, sc_prev_skip; // scene-cut recovery: summed cost / number of the P pictures since the last IDR; picture to force
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
@@ -84,6 +90,7 @@ struct mi355enc {
     unsigned *d_row_done;      // per macroblock row: macroblocks the gated P-stage launches have completed so far (the picture's deblocking launch waits for its rows)
     uint32_t pmb_rows_total;   // ... and what each of those counts reaches with the last gated launch enqueued
     uint32_t db_started_total; // workgroups of all band-deblocking launches so far (the device counts them as they are placed: d_progress[1])
+    uint32_t ip_done_total;    // intra macroblock rows of all fused launches so far (the device counts them as they complete: d_progress[2])
     uint32_t rec_epoch[2]; // ... and the epoch those words carry once the buffer's picture is done (0: no flags for it)
     uint2 *d_db_gran;     // strips between deblocking bands, as epoch-tagged granules (never cleared)
     unsigned *d_progress; // [0] the sticky error word of the persistent kernels (bounded spins report here), [1] workgroups of band-deblocking launches placed
@@ -127,13 +134,14 @@ static inline unsigned *err_word(const mi355enc_t *h) { return h->d_progress; }
 extern std::atomic<int> g_open_encoders;
 bool exclusive_device(const mi355enc_t *h);
 bool no_pgate();
+bool no_db2();
 bool overlap_allowed(const mi355enc_t *h);
 int sync_compute(mi355enc_t *h);
 bool host_range_pinned(const void *p, size_t bytes); // inside memory handed out by mi355enc_host_alloc()
 // enc_schedule.cpp
 int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done = nullptr);
 int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done = nullptr,
-                unsigned *band_done = nullptr, bool after_gated_pmb = false);
+                unsigned *band_done = nullptr, bool after_gated_pmb = false, unsigned row_need = 0, bool fused_ip = false);
 void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set = 0);
 int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride, int64_t pts, int force_idr);
 int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const planes[3], const int strides[3], hipStream_t up);

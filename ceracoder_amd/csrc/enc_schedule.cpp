@@ -42,9 +42,11 @@ int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done)
     return 0;
 }
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
-int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done, unsigned *band_done, bool after_gated_pmb) {
+int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done, unsigned *band_done, bool after_gated_pmb, unsigned row_need, bool fused_ip) {
     if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
-        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, h->cfg.intra_mode == 2 ? k_intra_band_rows() : 1, band_done, h->d_progress + 1, after_gated_pmb ? h->d_row_done : nullptr, h->pmb_rows_total, st);
+        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, h->cfg.intra_mode == 2 ? k_intra_band_rows() : 1, band_done, h->d_progress + 1, after_gated_pmb ? h->d_row_done : nullptr, row_need ? row_need : h->pmb_rows_total,
+                               fused_ip ? h->d_ip_strips : nullptr, fused_ip ? h->d_progress + 2 : nullptr, st);
+        if (fused_ip) h->ip_done_total += (uint32_t)h->mbh;
         h->db_started_total += 2u * (unsigned)k_deblock_bands16(h->mbh);
         HIPCHK(hipGetLastError());
         return 0;
@@ -94,7 +96,7 @@ static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof
 // ... and back part (back stream): needs the deblocked picture before it
 // gate: the reference picture's band-done words (the fused stage then runs on the intra stream, beside that picture's deblocking)
 // rows: the picture's deblocking launch will sit directly behind the previous one and wait on the device for this stage's rows (no event)
-static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split, const unsigned *gate, unsigned ref_epoch, int rows) {
+static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split, const unsigned *gate, unsigned ref_epoch, int rows, bool fused_ip = false) {
     hipStream_t st = gate ? h->istream : h->stream;
     if (prof) HIPCHK(hipEventRecord(s->ev[8], st));
     if (h->cfg.transform8x8) { // High profile: the two-kernel form (absolute-vector refinement, 8x8 transform), no skip / intra logic
@@ -109,7 +111,8 @@ static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof,
         if (gate) { // the main stream carries nothing but deblocking launches, back to back: this picture's bands wait on the device for the fused
             if (rows) h->pmb_rows_total += (uint32_t)h->mbw; // stage's rows (row counts, no event between the streams), and its movers follow intra_p_kernel
             else { HIPCHK(hipEventRecord(h->ev_pmb, st)); HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pmb, 0)); } // (fewer than three pictures in flight: by event)
-            if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
+            if (fused_ip) k_launch_wait_started(h->d_progress + 2, h->ip_done_total, err_word(h), st); // the intra macroblock rows ride in the deblocking launch (enqueued already): records and levels are final once they have all counted themselves
+            else if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
         } else if (split) { // intra_p_kernel leaves the chain: prep + the band deblocker follow the fused stage directly and overtake it row by row
             HIPCHK(hipEventRecord(h->ev_pmb, st));
             HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0));
@@ -193,15 +196,39 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // gets in the way (1080p depth 1: 4465 -> 3980 frames/s, 2160p: 2050 -> 1615)
         const int prows = pgate && h->cfg.pipeline_depth >= 2;
         const int isplit = idr && h->cfg.intra_mode != 1 && may_wait;
+        // Where this picture's deblocking launch goes.  A launch that waits on the device for its rows need not wait for the previous
+        // picture's launch to END: its upper bands can run beside that launch's lower ones (the bands of a launch finish staggered by the
+        // x + y order's skew, a third of the launch).  What orders the two is already on the device: pmb_kernel<GATED> of this picture reads a
+        // reference band only when the previous launch has published it, and this launch's band b starts when pmb_kernel has completed the
+        // rows of bands b-1 .. b+1 -- by then the previous launch is through band b+2, so band b's strips and parameter table are free.
+        // So consecutive such launches alternate between two streams; a picture whose stages run in order joins both.
+        hipStream_t mst = h->stream;
+        bool early_db = false;
+        if (prows && !no_db2()) {
+            h->db_flip ^= 1;
+            if (h->db_flip) {
+                mst = h->cstream;
+                if (h->inorder_since_s2) { HIPCHK(hipEventRecord(h->ev_join, h->stream)); HIPCHK(hipStreamWaitEvent(h->cstream, h->ev_join, 0)); h->inorder_since_s2 = 0; }
+                h->s2_dirty = 1;
+            }
+        } else {
+            if (h->s2_dirty) { HIPCHK(hipEventRecord(h->ev_join, h->cstream)); HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0)); h->s2_dirty = 0; }
+            if (!prows) h->inorder_since_s2 = 1;
+        }
         for (int b = 0; b < 2; b++)
-            if (h->dbI_busy[b] && (!idr || b == nxt)) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_dbI[b], 0)); h->dbI_busy[b] = 0; }
+            if (h->dbI_busy[b] && (!idr || b == nxt)) { HIPCHK(hipStreamWaitEvent(mst, h->ev_dbI[b], 0)); h->dbI_busy[b] = 0; }
         if (idr) {
             if (isplit) { HIPCHK(hipEventRecord(h->ev_pmb, h->stream)); HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0)); } // behind everything enqueued so far (a P picture's deblocker, its tables)
             if (prof) HIPCHK(hipEventRecord(s->ev[0], h->stream));
             int r = run_intra(h, ci, c, isplit ? h->d_iband_done + (size_t)nxt * h->mbh : nullptr); if (r) return r;
             if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
         } else {
-            int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur], prows); if (r) return r;
+            // Two launches in flight: this picture's deblocking launch is enqueued FIRST, and the gated P stage behind wait_started_kernel counts
+            // it in -- once pmb_kernel's waiting workgroups fill the chip, a launch of 34 workgroups of twelve 112-register waves finds no CU to
+            // land on until they drain (device timeline: the launch sat there for 250 us and did its work after pmb_kernel had ended).
+            early_db = prows && !no_db2();
+            if (early_db) { int r = run_deblock(h, ci, c, mst, c->intra_p ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, true, h->pmb_rows_total + (uint32_t)h->mbw, c->intra_p != 0); if (r) return r; }
+            int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur], prows, early_db && c->intra_p); if (r) return r;
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
@@ -215,15 +242,17 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
             int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * h->mbh, h->d_db_done + (size_t)nxt * nbd); if (r) return r;
             HIPCHK(hipEventRecord(h->ev_dbI[nxt], h->istream));
             h->dbI_busy[nxt] = 1;
-        } else { int r = run_deblock(h, ci, c, h->stream, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, prows != 0); if (r) return r; }
+        } else if (!early_db) { int r = run_deblock(h, ci, c, mst, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, prows != 0); if (r) return r; }
         h->rec_epoch[nxt] = h->cfg.deblock_mode == 0 ? c->epoch : 0;
         if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
-        HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
-        // Hand-over on the second stream, enqueued after the deblocking launches so that it cannot be dispatched ahead of them:
-        // the device packs the non-zero blocks straight into the pinned host buffer while the band deblocker runs.
-        k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, err_word(h), h->cstream);
+        // Hand-over, enqueued after the deblocking launches so that it cannot be dispatched ahead of them: the device packs the non-zero
+        // blocks straight into the pinned host buffer while the band deblocker runs.  On the hand-over stream -- or, where that stream takes
+        // every other deblocking launch, on the intra stream right behind intra_p_kernel (records and levels are final there).
+        hipStream_t pst = (prows && !no_db2()) ? h->istream : h->cstream;
+        if (pst == h->cstream) HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
+        k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, err_word(h), pst);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(s->done, h->cstream));
+        HIPCHK(hipEventRecord(s->done, pst));
     }
     h->n_submitted++;
     s->is_idr = idr; s->qp = qp; s->drop = drop; s->frame_num = h->frames_since_idr; s->idr_pic_id = h->idr_count & 0xFFFF;
@@ -260,7 +289,7 @@ int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const p
 }
 
 static const char *wait_name(unsigned code) {
-    switch (code) {
+    switch (code & 255u) { // (the upper bits say where: band << 8, chroma << 15, macroblock column << 16)
     case 3: return "pmb_kernel waiting for the reference's deblocking bands";
     case 4: return "wait_started_kernel";
     case 11: return "deblocker waiting for the intra bands";
@@ -293,7 +322,7 @@ static int recover(mi355enc_t *h, unsigned code) {
     HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream));
     HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)h->mbh * sizeof(unsigned), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->pmb_rows_total = 0; h->db_started_total = 0; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->dbI_busy[0] = h->dbI_busy[1] = 0;
+    h->pmb_rows_total = 0; h->db_started_total = 0; h->ip_done_total = 0; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->dbI_busy[0] = h->dbI_busy[1] = 0;
     if (h->safe_level == 2) { h->cfg.deblock_mode = 1; h->cfg.intra_mode = 1; }
     const int n = h->pending;
     struct { const uint8_t *y, *uv; int stride, force_idr; int64_t pts; } again[NSLOT];

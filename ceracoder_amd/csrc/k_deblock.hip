@@ -1,6 +1,6 @@
 // k_deblock.hip -- in-loop deblocking filter (H.264 8.7): the persistent band kernel, and the per-diagonal form
 // Hand-written HIP for gfx950 (CDNA4, wave64); part of libmi355enc (see kernels_common.hpp).
-#include "kernels_common.hpp"
+#include "intra_mb.hpp"
 
 // =================================================================== deblocking (8.7)
 DEV void filter_line(const dev_tables *T, uint8_t *pix, int step, int bS, int qp_p, int qp_q, bool chroma) {
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; unsigned *band_done; unsigned *started; const unsigned *row_done; unsigned row_need; }; // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; unsigned *band_done; unsigned *started; const unsigned *row_done; unsigned row_need; int nip; unsigned *ip_progress_w; uint8_t *ip_strips; unsigned *ip_done; }; // nip > 0: the launch's first nip workgroups are the picture's intra macroblock rows (intra_p_row) // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -387,7 +387,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
             int spins = 0;
             while (__ballot(mine && (int)(ld_sc1(w) - a.row_need) < 0)) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 17u); break; } // bounded; the host reports the picture as failed
+                if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 17u | ((unsigned)band << 8) | (CHROMA ? 0x8000u : 0u)); break; } // bounded; the host reports the picture as failed
                 if ((spins & 1023) == 0 && ld_sc1(a.err)) break;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -415,6 +415,9 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
         }
         __syncthreads();
     }
+#ifdef TL_PROF
+    if (!CHROMA && threadIdx.x == 0) { const int sl = band == 0 ? 9 : band == nb / 2 ? 11 : band == nb - 1 ? 13 : -1; if (sl >= 0) *((volatile unsigned long long *)ctx->dbrec + (ctx->epoch & 63) * 16 + sl) = wall_clock64(); }
+#endif
     constexpr int PARW = CHROMA ? 16 : 32;                                  // parameter words per macroblock
     unsigned *partab = a.partab + (CHROMA ? (size_t)nb * ROWS * mbw * 32 : 0) + (size_t)band * ROWS * mbw * PARW;
     unsigned *flagw = (unsigned *)(lds + ROWS * ROW_LDS);   // [3]: band - 1, band, band + 1
@@ -624,7 +627,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                         do {
                             __builtin_amdgcn_s_sleep(1);
                             g2 = ld64_sc1(gran_up + (size_t)x * ring_n + gj);
-                            if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 12u); break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { break; } // bounded; once tripped, nobody waits again
+                            if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 12u | ((unsigned)band << 8) | (CHROMA ? 0x8000u : 0u) | ((unsigned)x << 16) | ((unsigned)((__ballot(glane && g2.y == epoch) >> 32) & 0xFu) << 28)); break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { break; } // bounded; once tripped, nobody waits again
                         } while (__ballot(glane && g2.y != epoch));
                         if (glane) *dst = g2.x;
                     }
@@ -695,6 +698,9 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
         }
     }
     tl_last(ctx, 8);
+#ifdef TL_PROF
+    if (!CHROMA && threadIdx.x == 0) { const int sl = band == 0 ? 10 : band == nb / 2 ? 12 : -1; if (sl >= 0) *((volatile unsigned long long *)ctx->dbrec + (ctx->epoch & 63) * 16 + sl) = wall_clock64(); }
+#endif
 #ifdef DBT_PROF
     if (lane == 0 && band < 2) { // rows 0..3 of bands 0 and 1
         unsigned *o = (unsigned *)(ctx->dbrec) + (CHROMA ? 128 : 0) + 64 * band + 16 * r + 4 * role; // debug build only: overwrites the first records after use
@@ -704,14 +710,40 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
 #endif
 }
 
-template <int ROWS, bool ALL_INTRA, bool GATED>
+// FUSED_IP: the intra macroblocks of the same P picture ride in this launch -- its first a.nip workgroups run intra_p_row (two waves each, the
+// other waves end at once), one macroblock row each, behind the same row counts of pmb_kernel<GATED, ROWS> the bands wait for.  As a kernel of
+// its own intra_p_kernel could only follow pmb_kernel in stream order, i.e. after its LAST row -- and with two deblocking launches in flight the
+// bands of a launch that starts early would sit at every row's first intra macroblock until then (device timeline: band 0 done 280 us after
+// the launch started, 120 us of them waiting).  In one launch, leading the grid, the rows are on the chip before any band is (workgroups are
+// placed in index order), whatever else fills it; they wait for nothing but pmb_kernel's rows and the row above.
+template <int ROWS, bool ALL_INTRA, bool GATED, bool FUSED_IP>
 __global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[]; // ROWS rows of tile rings, then three work flags and the rows' first intra macroblocks
-    const int nl = gridDim.x >> 1;
-    if (blockIdx.x == 0) tl_first(&a.ctx, 7);
+    int bi = (int)blockIdx.x, nwg = (int)gridDim.x;
+    if (FUSED_IP) {
+        if (bi < a.nip) {
+            if (threadIdx.x >= 128) return;
+            ip_args ia;
+            ia.ctx = a.ctx; ia.progress = a.ip_progress_w; ia.strips = a.ip_strips; ia.err = a.err;
+            intra_p_row(ia, bi, a.row_done, a.row_need);
+            // records and levels of this row's intra macroblocks are read by the hand-over kernels of another stream while this launch still
+            // runs: drain, meet, write this XCD's L2 back, then count the row as done (the host's wait kernel follows the count)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(a.ip_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        bi -= a.nip; nwg -= a.nip;
+    }
+    const int nl = nwg >> 1;
+    if (bi == 0) tl_first(&a.ctx, 7);
     if (a.started && threadIdx.x == 0) __hip_atomic_fetch_add(a.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this workgroup holds its place on a CU (wait_started_kernel)
-    if ((int)blockIdx.x < nl) rows3_body<false, ALL_INTRA, ROWS, GATED>(a, a.band0 + blockIdx.x, a.nb_total, lds);
-    else rows3_body<true, ALL_INTRA, ROWS, GATED>(a, a.band0 + blockIdx.x - nl, a.nb_total, lds);
+    if (bi < nl) rows3_body<false, ALL_INTRA, ROWS, GATED>(a, a.band0 + bi, a.nb_total, lds);
+    else rows3_body<true, ALL_INTRA, ROWS, GATED>(a, a.band0 + bi - nl, a.nb_total, lds);
 }
 
 // =================================================================== launchers
@@ -734,7 +766,7 @@ template <typename K>
 static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStream_t s) {
     constexpr size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + 16 + 4 * DB_ROWS; // the rows' tile rings + three work flags + the rows' first intra macroblocks: ~12.5 KB
     static_assert(lds <= 48 * 1024, "above 48 KB of dynamic LDS every instantiation launched here would need hipFuncAttributeMaxDynamicSharedMemorySize");
-    hipLaunchKernelGGL(kernel, dim3(2 * nbands), dim3(192 * DB_ROWS), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3(2 * nbands + (a.nip > 0 ? a.nip : 0)), dim3(192 * DB_ROWS), lds, s, a);
 }
 // One wave that ends once `count` workgroups of band-deblocking launches have been placed since the encoder was opened (the count only
 // grows; the comparison is wrap-safe).  On a stream in front of a kernel whose workgroups wait for the deblocker's flags, it keeps
@@ -752,11 +784,16 @@ void k_launch_wait_started(const unsigned *d_started, unsigned count, unsigned *
 size_t k_deblock_done_bytes(void) { return (size_t)DB_DONE_COPIES * DB_DONE_STRIDE * sizeof(unsigned); } // 2 words per band: up to 512 bands
 size_t k_deblock_partab_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * DB_ROWS * mbw * 48 * sizeof(unsigned); } // 32 luma + 16 chroma words per macroblock
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
-                            const unsigned *d_iband_done, int ib_rows, unsigned *d_band_done, unsigned *d_started, const unsigned *d_row_done, unsigned row_need, hipStream_t s) {
+                            const unsigned *d_iband_done, int ib_rows, unsigned *d_band_done, unsigned *d_started, const unsigned *d_row_done, unsigned row_need,
+                            uint8_t *d_ip_strips, unsigned *d_ip_done, hipStream_t s) {
     db_args a;
     a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab; a.iband_done = d_iband_done; a.ib_rows = ib_rows > 0 ? ib_rows : DB_ROWS; a.band_done = d_band_done; a.started = d_started; a.row_done = d_row_done; a.row_need = row_need;
+    a.nip = 0; a.ip_progress_w = nullptr; a.ip_strips = nullptr; a.ip_done = nullptr;
     if (band1 <= band0) return;
-    if (h_ctx->all_intra) launch_bands(deblock_rows3_kernel<DB_ROWS, true, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
-    else if (d_ip_progress) launch_bands(deblock_rows3_kernel<DB_ROWS, false, true>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel
-    else launch_bands(deblock_rows3_kernel<DB_ROWS, false, false>, a, band1 - band0, h_ctx->mbw, s);
+    if (h_ctx->all_intra) launch_bands(deblock_rows3_kernel<DB_ROWS, true, false, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
+    else if (d_ip_progress && d_ip_done && d_row_done && band0 == 0) { // the picture's intra macroblock rows lead the launch (pmb_kernel<GATED, ROWS> of the same picture still runs)
+        a.nip = mbh; a.ip_progress_w = const_cast<unsigned *>(d_ip_progress); a.ip_strips = d_ip_strips; a.ip_done = d_ip_done;
+        launch_bands(deblock_rows3_kernel<DB_ROWS, false, true, true>, a, band1 - band0, h_ctx->mbw, s);
+    } else if (d_ip_progress) launch_bands(deblock_rows3_kernel<DB_ROWS, false, true, false>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel
+    else launch_bands(deblock_rows3_kernel<DB_ROWS, false, false, false>, a, band1 - band0, h_ctx->mbw, s);
 }

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355enc.so")
+LIB_PATH = os.environ.get("MI355ENC_LIB") or os.path.join(_HERE, "libmi355enc.so")  # (MI355ENC_LIB: development builds, tools/build_variant.sh)
 
 LEVELS_PER_MB = 408
 MBINFO_DTYPE = np.dtype(

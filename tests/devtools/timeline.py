@@ -26,11 +26,11 @@ buf = np.zeros((e.mbw * e.mbh, 8), np.uint64)
 assert e.L.mi355enc_fetch(e.h, 100, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
 t = buf.reshape(-1)[:64 * 16].reshape(64, 16).astype(np.int64)
 rows = sorted((r for r in t if r[7] > 0 and r[0] > 0), key=lambda r: r[7])[-40:]
-names = ["me0", "me1", "pmb0", "gate", "pmb1", "ip0", "ip1", "db0", "db1"]
+names = ["me0", "me1", "pmb0", "gate", "pmb1", "ip0", "ip1", "db0", "db1", "b0go", "b0end", "bMgo", "bMend", "bLgo"]  # b0 / bM / bL: first, middle, last luma band: past its row wait / done
 print("per picture, us relative to the start of its deblocking (100 MHz clock): " + " ".join("%7s" % x for x in names) + "   db0 - previous db1 | period")
 prev = None
 for r in rows:
-    us = [(int(r[k]) - int(r[7])) / 100.0 for k in range(9)]
+    us = [(int(r[k]) - int(r[7])) / 100.0 if r[k] > 0 else float('nan') for k in range(14)]
     gap = (int(r[7]) - int(prev[8])) / 100.0 if prev is not None else float("nan")
     per = (int(r[7]) - int(prev[7])) / 100.0 if prev is not None else float("nan")
     print(" " * 73 + " ".join("%7.1f" % x for x in us) + "   %7.1f | %7.1f" % (gap, per))
