@@ -78,7 +78,7 @@ void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set)
     c->drop_sad = (!idr && drop > 0 && drop <= DROP_MAX) ? k_drop_sad[drop] : 0;
     c->iac_drop = (idr && drop > 0 && drop <= DROP_MAX) ? k_idrop_ac[drop] : 0;
     if (c->iac_drop) c->i4x4 = 0; // on the ladder: Intra_16x16 only
-    c->intra_p = (h->cfg.intra_in_p && !h->cfg.transform8x8) ? 1 : 0;
+    c->intra_p = (h->cfg.intra_in_p && !h->cfg.transform8x8) ? (h->cfg.i4x4 && h->cfg.intra_in_p > 1 ? 2 : 1) : 0; // 2: Intra_4x4 as well
 }
 // P picture, front part (front stream): nothing here depends on the coding of the picture before
 static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof) {
@@ -355,10 +355,14 @@ int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
     slot_t *s = &h->slot[h->head];
     const int w = h->cfg.width, ht = h->cfg.height;
     hipStream_t up = upload_stream(h);
-    if (host_range_pinned(y, (size_t)y_stride * (ht - 1) + w) && host_range_pinned(uv, (size_t)uv_stride * (ht / 2 - 1) + w)) {
+    const bool pinned = host_range_pinned(y, (size_t)y_stride * (ht - 1) + w) && host_range_pinned(uv, (size_t)uv_stride * (ht / 2 - 1) + w);
+    if (pinned || h->cfg.pipeline_depth == 0) {
+        // pinned: transferred in place.  pipeline_depth 0 (the latency mode: collect() follows at once, there is nothing to run beside): the
+        // runtime's own pageable path, which stages and transfers in chunks on its side of the call (measured 0.06 ms less per 1080p picture
+        // than staging here and transferring afterwards)
         HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, y, y_stride, w, ht, hipMemcpyHostToDevice, up));
         HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, uv, uv_stride, w, ht / 2, hipMemcpyHostToDevice, up));
-        h->st.pinned_inputs++;
+        h->st.pinned_inputs += pinned ? 1 : 0;
     } else {
         if (!s->h_src) HIPCHK(hipHostMalloc((void **)&s->h_src, h->ysz + h->csz, hipHostMallocDefault));
         // rows at the coded stride, so that a range of rows is one contiguous transfer; in four pieces (three of luma, the chroma plane), each

@@ -194,10 +194,12 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
                 if (bal & 0xFFFF0000ull) nz4 |= 1u << b1;
             }
             if (valid) { // off the chain: nothing waits for these
-                stg8(ry + (size_t)(y0 + by * 4 + py) * stride + x0 + bx * 4 + px, (unsigned)recp);
+                if (!SC1) stg8(ry + (size_t)(y0 + by * 4 + py) * stride + x0 + bx * 4 + px, (unsigned)recp);
                 stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + b * 16 + kz4], lv4);
             }
         }
+        if (SC1) // the deblocker of the same picture follows the reconstruction while it is written: the whole tile, write-through, a word per lane
+            st_sc1((unsigned *)(ry + (size_t)(y0 + (lane >> 2)) * stride + x0 + 4 * (lane & 3)), *(const unsigned *)&T4[((lane >> 2) + 1) * 24 + 4 + 4 * (lane & 3)]);
         if (OUT && lane < 16) { L->bot_y[slot][lane] = T4[16 * 24 + lane + 4]; L->right_y[lane] = T4[17 * 24 + 16 * 24 + lane + 4]; }
     } else if (wave == 0) {
         // ================================================================ Intra_16x16 reconstruction (8.3.3 + 8.5.10)
@@ -457,7 +459,7 @@ DEV void intra_p_row(const ip_args &a, const int my, const unsigned *row_done, c
             }
             __syncthreads();
             if (sh_bad) return; // uniform: the error word is set, the host reports it
-            const uint4 dec0 = make_uint4(0, 0, 0, 0);
+            const uint4 dec0 = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES); // the sixteen Intra_4x4 modes (ctx->intra_p == 2; zeros otherwise)
             const uint2 dec1 = ldg64(ctx->idec + (size_t)mbn * IDEC_BYTES + 16);
             // neighbour samples into LD.top / LD.left ([plane][i + 1] = sample i, [0] = corner)
             if (wave == 0 && lane < 17) { // luma top line + corner

@@ -176,8 +176,9 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
             sh_sad[wave][4] = (uint16_t)t0; sh_sad[wave][5] = (uint16_t)v1; sh_sad[wave][6] = (uint16_t)v2; sh_sad[wave][7] = (uint16_t)v3;
         }
     }
-    // ---- Intra_4x4: four blocks at a time, 16 lanes (pixels) each (I pictures only: intra macroblocks of P pictures are Intra_16x16)
-    if (!gate_p) {
+    // ---- Intra_4x4: four blocks at a time, 16 lanes (pixels) each (P pictures: for the gated macroblocks, when ctx->intra_p == 2)
+    const bool do4 = !gate_p || ctx->intra_p == 2;
+    if (do4) {
         const int px = lane & 3, py = (lane >> 2) & 3;
 #pragma unroll 1
         for (int rnd = 0; rnd < 4; rnd++) {
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
         }
         bool use_i4 = false;
         unsigned cost_luma = cost16;
-        if (ctx->i4x4 && !gate_p) { // Intra_4x4 modes block by block: SAD + lambda * (mode == expected ? 1 : 4); blocks visited along bx + 2*by
+        if (ctx->i4x4 && do4) { // Intra_4x4 modes block by block: SAD + lambda * (mode == expected ? 1 : 4); blocks visited along bx + 2*by
             unsigned cost4 = 0;
             const int half = (lane >> 4) & 1, cand = lane & 15;
             int (*m4)[16] = &sh_m4[wave];
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int bb = lane * 4 + i, r = (blky(bb) >> 2) * 4 + (blkx(bb) >> 2);
-                    w |= ((ctx->i4x4 && !gate_p) ? (unsigned)sh_m4[wave][r] & 0xFF : 0u) << (8 * i);
+                    w |= ((ctx->i4x4 && do4) ? (unsigned)sh_m4[wave][r] & 0xFF : 0u) << (8 * i);
                 }
             } else if (lane == 4) w = (unsigned)mode16 | ((unsigned)cmode << 8) | ((use_i4 ? 1u : 0u) << 16);
             else if (lane == 5) w = cost_luma + costc;

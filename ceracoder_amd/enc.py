@@ -226,7 +226,7 @@ class Encoder:
         cfg.pipeline_depth, cfg.profile_events, cfg.use_graphs, cfg.keep_prefilter = (
             pipeline_depth, int(profile_events), int(use_graphs), int(keep_prefilter))
         cfg.deblock_mode = deblock_mode
-        cfg.intra_in_p = int(intra_in_p)
+        cfg.intra_in_p = int(intra_in_p)  # True / 1: Intra_16x16 (the default); 2: Intra_4x4 as well
         cfg.cavlc_threads = int(cavlc_threads)
         cfg.scenecut = int(scenecut)
         cfg.exclusive_device = int(exclusive)  # this encoder has the GPU to itself: kernels may wait on the device for each other (include/mi355enc.h)

@@ -1032,7 +1032,7 @@ void orc_intra_p_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec
  *   5. inter residual: 4x4 transform, dead-zone quantiser, coefficient decimation (x264 dct-decimate: an 8x8 whose
  *      run/level score is below 4 and a macroblock whose score is below 6 are emptied; chroma AC of a plane below 7),
  *      normative reconstruction.  drop > 0 and SAD(final) < T[drop]: no residual at all. */
-static int g_orc_feat = ORC_F_ALL;
+static int g_orc_feat = ORC_F_ALL & ~ORC_F_I4P; /* Intra_4x4 in P pictures is an option (the device's intra_in_p = 2): rate-distortion neutral on the S2 / S4 clips, ten dependent sub-steps per macroblock */
 static int g_tune[8] = {ORC_SKIP_MARGIN_BITS, 0, 12, 3, 0, 0, 0, 0}; /* dev: skip margin bits, skip shift (0 = none), intra bias bits, intra shift */
 extern int g_sel_bonus;
 void orc_set_tuning(int which, int value) { if (which >= 0 && which < 8) g_tune[which] = value; if (which == 4) g_sel_bonus = value; }
@@ -1785,7 +1785,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
                 const int intra_p = (g_orc_feat & ORC_F_INTRAP) != 0;
                 if (intra_p) {
                     orc_intra_analyse(e->src_y, e->src_uv, e->stride, e->mbw, e->mbh, e->isad);
-                    orc_intra_decide(e->isad, e->mbw, e->mbh, qp, 0, e->idec); /* intra macroblocks of P pictures are Intra_16x16 only: nearly all of the gain, a fraction of the dependent work */
+                    orc_intra_decide(e->isad, e->mbw, e->mbh, qp, (g_orc_feat & ORC_F_I4P) && g_orc_i4x4, e->idec); /* (r03) Intra_4x4 as well: what x264's superfast keeps of its partition search (i8x8, i4x4) */
                 }
                 orc_pmb_frame(e->src_y, e->src_uv, e->rec_y[e->cur], e->rec_uv[e->cur], e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh,
                               qp, drop, e->subpel, e->imv, e->surf, intra_p ? e->idec : NULL, e->mbi, e->levels, e->threads);

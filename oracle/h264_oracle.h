@@ -97,7 +97,7 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
 #define ORC_DROP_MAX 12
 #define ORC_SKIP_MARGIN_BITS 4 /* the skip probe runs when SAD(ps_est) <= SAD(best whole-sample vector) + lambda * this */
 #define ORC_INTRA_GATE(lambda) (768u + 8u * (uint32_t)(lambda)) /* whole-sample search cost below which a P macroblock is never analysed for intra */
-enum { ORC_F_MVDCOST = 1, ORC_F_SKIPPROBE = 2, ORC_F_DECIMATE = 4, ORC_F_SATD = 8, ORC_F_INTRAP = 16, ORC_F_ALL = 31 };
+enum { ORC_F_MVDCOST = 1, ORC_F_SKIPPROBE = 2, ORC_F_DECIMATE = 4, ORC_F_SATD = 8, ORC_F_INTRAP = 16, ORC_F_I4P = 32 /* intra macroblocks of P pictures may be Intra_4x4 (x264 superfast: partitions i8x8,i4x4) */, ORC_F_ALL = 63 };
 void orc_set_features(int mask); /* process-wide ablation switches for the rate-distortion tables (default ORC_F_ALL = what the device does) */
 int orc_get_features(void);
 uint32_t orc_drop_threshold(int drop);

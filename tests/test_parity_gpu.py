@@ -308,6 +308,39 @@ def test_drop_ladder_and_all_skip_pictures_equal_oracle(E, oracle, w, h, depth):
     e.close()
 
 
+@pytest.mark.parametrize("w,h,n,depth", [(176, 144, 6, 0), (640, 368, 6, 0), (1280, 720, 5, 1), (1920, 1080, 5, 2)])
+def test_intra4x4_macroblocks_in_p_pictures_equal_oracle(E, oracle, w, h, n, depth):
+    """intra_in_p = 2: the intra macroblocks of P pictures may be Intra_4x4 (gated analysis with the nine-mode search, intra_p_row walking ten
+    sub-steps, the tile stored write-through for the deblocker that follows it).  The clip uncovers texture behind moving rectangles every
+    picture and cuts to another scene half way, so both kinds occur; access units, reconstruction and the independent decoder agree."""
+    from tests.util import cut_clip
+    clip = cut_clip(w, h, n, n // 2 + 1)
+    oracle.set_features(63)
+    try:
+        e = E.Encoder(w, h, gop=30, fixed_qp=26, intra_in_p=2, pipeline_depth=depth, exclusive=True, scenecut=False)
+        oe = oracle.Encoder(w, h, gop=30, threads=8, scenecut=False)
+        dec = oracle.Decoder()
+        got, n_i4 = [], 0
+        for i, (y, uv) in enumerate(clip):
+            e.submit(y, uv, pts=i)
+            if e.pending > depth:
+                got.append(e.collect()[0])
+        while e.pending:
+            got.append(e.collect()[0])
+        for i, (y, uv) in enumerate(clip):
+            ref_au, _ = oe.encode(y, uv, 26)
+            assert got[i] == ref_au, ("bitstream", i, len(got[i]), len(ref_au))
+            dy, duv = dec.decode(ref_au)
+            assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv)
+            if i:
+                n_i4 += int((oe.mbinfo["mb_type"] == 2).sum())
+        assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y) and np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv)
+        assert n_i4 > 0, "the clip produced no Intra_4x4 macroblock in a P picture"
+        e.close()
+    finally:
+        oracle.set_features(31)
+
+
 @pytest.mark.parametrize("w,h", [(16, 16), (32, 16), (16, 48), (18, 18), (4096, 32)])
 def test_degenerate_geometries(E, oracle, w, h):
     """Single macroblock, single row/column, non-multiple-of-16, and the widest row the caps allow."""

@@ -58,7 +58,7 @@ def bd_rate(a, b):
     return (np.exp(np.mean(np.interp(xs, pb, lb) - np.interp(xs, pa, la))) - 1) * 100
 
 
-names = {0: "none", 1: "mvdcost", 2: "skip probe", 4: "decimate", 8: "satd", 16: "intra in P"}
+names = {0: "none", 1: "mvdcost", 2: "skip probe", 4: "decimate", 8: "satd", 16: "intra in P", 32: "Intra_4x4 in P"}
 base = None
 for f, it in [(int(v), int(i)) for i in args.iters.split(",") for v in args.feat.split(",")]:
     t0 = time.time()
