@@ -98,6 +98,7 @@ struct mi355enc {
     uint16_t *d_surf[NSET]; // SAD surfaces of the motion search, SURF_U16 per macroblock; one set per picture in flight: the front stages of picture n+1 (n+2) run beside the back stages of n
     imv_t *d_imv[NSET][2];   // whole-sample vector fields (search result / selection iterations alternate), per set
     uint8_t *d_idec2[NSET];  // intra decisions per set (d_idec = set 0)
+    int8_t *d_qp_off[NSET];  // adaptive quantisation: QP offset per macroblock, per set (null unless cfg.aq_mode)
     uint8_t *d_psrc[2];   // padded source luma of the last two coded pictures: the search runs source against source
     int psrc_cur;         // which of them holds the last coded picture
     unsigned *d_ip_progress; // intra macroblocks of P pictures: one progress word per macroblock row (epoch-tagged, never cleared)

@@ -78,6 +78,7 @@ void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set)
     c->drop_sad = (!idr && drop > 0 && drop <= DROP_MAX) ? k_drop_sad[drop] : 0;
     c->iac_drop = (idr && drop > 0 && drop <= DROP_MAX) ? k_idrop_ac[drop] : 0;
     if (c->iac_drop) c->i4x4 = 0; // on the ladder: Intra_16x16 only
+    c->qp_off = h->cfg.aq_mode ? h->d_qp_off[set] : nullptr;
     c->intra_p = (h->cfg.intra_in_p && !h->cfg.transform8x8) ? (h->cfg.i4x4 && h->cfg.intra_in_p > 1 ? 2 : 1) : 0; // 2: Intra_4x4 as well
 }
 // P picture, front part (front stream): nothing here depends on the coding of the picture before
@@ -170,6 +171,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         if ((idr && h->cfg.intra_mode == 1) || h->cfg.deblock_mode != 0) HIPCHK(hipMemcpyAsync(dctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
         // front stream: the source is in place (upload / conversion were enqueued there); P pictures: search, selection, gated intra
         // analysis; I pictures: only the padded source copy the next picture's search will run against
+        if (c->qp_off) k_launch_aq(c, h->d_qp_off[set], h->fstream); // adaptive quantisation: the offsets of this picture's macroblocks
         if (idr) k_launch_copy_luma(c, h->fstream);
         else { int r = run_p_front(h, c, s, prof); if (r) return r; }
         HIPCHK(hipEventRecord(s->ev_front, h->fstream));
@@ -180,7 +182,8 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // chain costs 10-17 us).  Not on pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
         // Every kernel-waits-for-kernel overlap below is opt-in (cfg.exclusive_device): next to another process's kernels on the same GPU a
         // kernel that waits on the device for a kernel that has not been placed yet can run into the bound of its wait.
-        const bool may_wait = overlap_allowed(h) && exclusive_device(h) && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof;
+        const bool may_wait = overlap_allowed(h) && exclusive_device(h) && h->cfg.deblock_mode == 0 && !h->d_pre_y && !prof && !h->cfg.aq_mode; // (adaptive quantisation: the QP_Y chain
+                                                                                                                                                    // over the whole picture sits between a picture's records and its deblocking)
         const int split = !idr && fused && c->intra_p && may_wait;
         // IDR picture: the band deblocker runs on the intra stream BESIDE the intra wavefront, each of its bands waiting for the intra bands
         // of the same rows (flags + acquire); in an all-intra stream the next picture's wavefront then starts while this one is still
@@ -232,6 +235,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
+        if (c->qp_off) k_launch_qp_chain(h->d_mbi_set[set], h->nmb, qp, h->stream); // 7.4.5: QP_Y of the macroblocks without mb_qp_delta, for the deblocker (everything runs on the main stream here)
         HIPCHK(hipEventRecord(s->gpu_done, (split || pgate) ? h->istream : h->stream)); // records and levels are final here; they do not depend on deblocking
         if (h->d_pre_y) {
             HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));

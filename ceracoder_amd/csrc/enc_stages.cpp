@@ -32,6 +32,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging, int drop = 0, i
     c->vis_h = h->H;
     fill_ctx(h, c, qp, drop, idr);
     c->all_intra = 0; // the single-stage deblocking entry point takes records of either picture type
+    c->qp_off = nullptr; // (single stages: one QP per picture)
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
     stage_touched(h);
     return 0;

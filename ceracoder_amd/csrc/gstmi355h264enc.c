@@ -50,6 +50,7 @@ typedef struct {
     gboolean scenecut, exclusive_gpu;
     guint vbv_ms;
     gboolean intra_in_p, pinned_input;
+    gint aq_mode;
     /* streaming state */
     mi355enc_t *enc;
     GstVideoCodecState *input_state;
@@ -64,7 +65,7 @@ typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 G_DEFINE_TYPE(GstMi355H264Enc, gst_mi355h264enc, GST_TYPE_VIDEO_ENCODER)
 
 enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME_RANGE, PROP_QP, PROP_PIPELINE_DEPTH,
-       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE, PROP_PINNED_INPUT };
+       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE, PROP_PINNED_INPUT, PROP_AQ_MODE };
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-raw, format=(string){ NV12, I420, YUY2, UYVY }, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
@@ -114,6 +115,7 @@ static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *
     case PROP_VBV: s->vbv_ms = g_value_get_uint(val); break;
     case PROP_INTRA_IN_P: s->intra_in_p = g_value_get_boolean(val); break;
     case PROP_PINNED_INPUT: s->pinned_input = g_value_get_boolean(val); break;
+    case PROP_AQ_MODE: s->aq_mode = g_value_get_int(val); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -138,6 +140,7 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     case PROP_VBV: g_value_set_uint(val, s->vbv_ms); break;
     case PROP_INTRA_IN_P: g_value_set_boolean(val, s->intra_in_p); break;
     case PROP_PINNED_INPUT: g_value_set_boolean(val, s->pinned_input); break;
+    case PROP_AQ_MODE: g_value_set_int(val, s->aq_mode); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
     GST_OBJECT_UNLOCK(s);
@@ -185,7 +188,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     GST_OBJECT_LOCK(s);
     cfg.gop = s->key_int_max ? (int)s->key_int_max : 250;
     cfg.me_range = s->me_range; cfg.bitrate_bps = target_bps(s); cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
-    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0; cfg.scenecut = s->scenecut ? 1 : 0; cfg.exclusive_device = s->exclusive_gpu ? 1 : 0; cfg.vbv_ms = (int)s->vbv_ms; cfg.intra_in_p = s->intra_in_p ? 1 : 0;
+    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0; cfg.scenecut = s->scenecut ? 1 : 0; cfg.exclusive_device = s->exclusive_gpu ? 1 : 0; cfg.vbv_ms = (int)s->vbv_ms; cfg.intra_in_p = s->intra_in_p ? 1 : 0; cfg.aq_mode = s->aq_mode;
     GST_OBJECT_UNLOCK(s);
     int r = mi355enc_open(&cfg, &e);
     if (r != MI355ENC_OK) {
@@ -388,6 +391,8 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
         "Macroblocks of P pictures may be coded intra (uncovered regions, partial scene changes)", TRUE, F));
     g_object_class_install_property(g, PROP_EXCLUSIVE, g_param_spec_boolean("exclusive-gpu", "This stream has the GPU to itself",
         "One stream per GPU: kernels may wait on the device for other kernels' progress (a P picture's motion-compensation stage beside the previous picture's deblocking, the deblocker beside the intra macroblocks: about 10 % more frames/s); leave false when other processes encode on the same GPU", FALSE, F));
+    g_object_class_install_property(g, PROP_AQ_MODE, g_param_spec_int("aq-mode", "Adaptive quantisation",
+        "0: one quantiser per picture; 1: a QP offset per macroblock from the variance of its source samples (x264enc's aq-mode 1 in spirit), coded with mb_qp_delta", 0, 1, 0, F));
     g_object_class_install_property(g, PROP_PINNED_INPUT, g_param_spec_boolean("pinned-input", "Offer pinned input buffers",
         "Answer the upstream ALLOCATION query with a buffer pool in pinned host memory: a source that takes it writes pictures the GPU can fetch without a staging copy", TRUE, F));
     g_object_class_install_property(g, PROP_SCENECUT, g_param_spec_boolean("scenecut", "Scene-cut recovery",
@@ -404,7 +409,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->rate_raw = 2048; s->rate_is_bps = FALSE; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
-    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = TRUE; s->pinned_input = TRUE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
+    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = TRUE; s->pinned_input = TRUE; s->aq_mode = 0; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
 }
 
 GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */

@@ -360,7 +360,11 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
     rows_result_t res = {0, 0, 0};
     memset(w->tc_l + (size_t)row0 * mbw * 16, 0, (size_t)(row1 - row0) * mbw * 16);
     memset(w->tc_c + (size_t)row0 * mbw * 8, 0, (size_t)(row1 - row0) * mbw * 8);
-    int skip = 0, prev_qp = slice_qp; /* one QP per picture: mb_qp_delta is 0 wherever it is sent, whatever the range */
+    /* QP_Y,PRED of the range's first macroblock (7.4.5): the QP_Y of the last macroblock before it that sent an mb_qp_delta (Intra_16x16, or any
+     * coded block), the slice's if there is none.  (One QP per picture: the slice's everywhere; adaptive quantisation: whatever that macroblock had.) */
+    int skip = 0, prev_qp = slice_qp;
+    for (int i = row0 * mbw - 1; i >= 0; i--)
+        if (mbi[i].mb_type == 0 || (mbi[i].nzmask & 0x07FFFFFFu) != 0) { prev_qp = mbi[i].qp; break; }
     for (int my = row0, mbn = row0 * mbw; my < row1; my++)
         for (int mx = 0; mx < mbw; mx++, mbn++) {
             const mb_info_t *m = mbi + mbn;

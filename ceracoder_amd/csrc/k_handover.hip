@@ -218,3 +218,58 @@ void k_launch_pad(uint8_t *y, uint8_t *uv, int stride, int vis_w, int vis_h, int
     int n = W * H + W * H / 2;
     hipLaunchKernelGGL(pad_kernel, dim3((n + 255) / 256), dim3(256), 0, s, y, uv, stride, vis_w, vis_h, W, H);
 }
+
+// =================================================================== adaptive quantisation
+// One wave per macroblock (four per workgroup): sum and sum of squares of the 256 source luma samples by two packed dot products per
+// lane and a wave reduction, then the offset rule of the oracle (orc_aq_offset_of) in the same integer arithmetic.
+__global__ __launch_bounds__(256) void aq_kernel(const frame_ctx_t cv, int8_t *__restrict__ off) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    const int lane = threadIdx.x & 63, mbn = blockIdx.x * 4 + (int)(threadIdx.x >> 6), nmb = ctx->mbw * ctx->mbh;
+    if (mbn >= nmb) return; // wave-uniform
+    const int my = mbn / ctx->mbw, mx = mbn - my * ctx->mbw;
+    int sy = my * 16 + (lane >> 2);
+    sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
+    const unsigned w = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + mx * 16 + 4 * (lane & 3));
+    unsigned s = __builtin_amdgcn_sad_u8(w, 0u, 0u), s2 = __builtin_amdgcn_udot4(w, w, 0u, false);
+    for (int o = 32; o; o >>= 1) { s += (unsigned)__shfl_xor((int)s, o, 64); s2 += (unsigned)__shfl_xor((int)s2, o, 64); }
+    if (lane == 0) {
+        const unsigned v = s2 - ((s * s) >> 8);
+        int L2 = 0;
+        if (v > 1) { const int msb = 31 - __builtin_clz(v); L2 = 2 * msb + (int)((v >> (msb - 1)) & 1u); }
+        int o = (3 * (L2 - 28) + 4) >> 3;
+        o = o < -4 ? -4 : (o > 4 ? 4 : o);
+        off[mbn] = (int8_t)o;
+    }
+}
+void k_launch_aq(const frame_ctx_t *h_ctx, int8_t *d_off, hipStream_t s) {
+    hipLaunchKernelGGL(aq_kernel, dim3((h_ctx->mbw * h_ctx->mbh + 3) / 4), dim3(256), 0, s, *h_ctx, d_off);
+}
+// 7.4.5: a macroblock without mb_qp_delta (not Intra_16x16 and no coded block) has the QP_Y of the macroblock before it in decoding
+// order.  One workgroup: every thread walks a run of consecutive macroblocks, the runs' "last coded QP" are carried forward by a scan over
+// the 1024 threads (a thread whose run has no coded macroblock passes its predecessor's on), then every thread rewrites the qp byte of its
+// uncoded macroblocks.  The records are otherwise final; the deblocker that follows in stream order reads QP_Y from them.
+__global__ __launch_bounds__(1024) void qp_chain_kernel(mb_info_t *__restrict__ mbi, int nmb, int slice_qp) {
+    __shared__ int carry[1024];
+    const int t = threadIdx.x, per = (nmb + 1023) / 1024, i0 = t * per, i1 = i0 + per < nmb ? i0 + per : nmb;
+    int last = -1; // this run's last coded QP
+    for (int i = i0; i < i1; i++) {
+        const uint4 r = ldg128(&mbi[i]);
+        if ((r.y & 255u) == 0u || (r.z & 0x07FFFFFFu) != 0u) last = (int)(r.y >> 24);
+    }
+    carry[t] = last;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { // inclusive "last defined" scan
+        const int a = carry[t], b = t >= d ? carry[t - d] : -1;
+        __syncthreads();
+        carry[t] = a >= 0 ? a : b;
+        __syncthreads();
+    }
+    int prev = t > 0 ? carry[t - 1] : -1;
+    if (prev < 0) prev = slice_qp;
+    for (int i = i0; i < i1; i++) {
+        const uint4 r = ldg128(&mbi[i]);
+        if ((r.y & 255u) == 0u || (r.z & 0x07FFFFFFu) != 0u) prev = (int)(r.y >> 24);
+        else stg32((unsigned *)&mbi[i] + 1, (r.y & 0x00FFFFFFu) | ((unsigned)prev << 24));
+    }
+}
+void k_launch_qp_chain(mb_info_t *d_mbi, int nmb, int slice_qp, hipStream_t s) { hipLaunchKernelGGL(qp_chain_kernel, dim3(1), dim3(1024), 0, s, d_mbi, nmb, slice_qp); }

@@ -526,7 +526,7 @@ DEV void ir_put_record(const frame_ctx_t *ctx, int mbn, uint2 dec1, unsigned bit
     const bool use_i4 = ((dec1.x >> 16) & 255) != 0;
     mb_info_t mb;
     mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)(dec1.x & 255); mb.chroma_mode = (uint8_t)((dec1.x >> 8) & 255);
-    mb.qp = (uint8_t)ctx->qp; mb.nzmask = bits & ~(IR_LDONE | IR_CDONE); mb.cost = dec1.y;
+    mb.qp = (uint8_t)mb_qp_dev(ctx, mbn); mb.nzmask = bits & ~(IR_LDONE | IR_CDONE); mb.cost = dec1.y;
     st_mbinfo(&ctx->mbi[mbn], mb);
 }
 // deposit one plane's bits for macroblock x; the second plane to arrive writes the record and frees the slot (lane 0 of the wave)

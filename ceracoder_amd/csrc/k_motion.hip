@@ -542,7 +542,7 @@ DEV void pmb_store_pred_only(const frame_ctx_t *__restrict__ ctx, int16_t *lv, i
 // SC1: the reconstruction and the record are stored through to memory -- the picture's own deblocking launch reads them without a kernel boundary in between.
 template <bool SC1>
 DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, const int lane, const int refine) {
-    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = ctx->qp, lambda = ctx->lambda;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = mb_qp_dev(ctx, mbn), lambda = ctx->lambda; // (quantisation only: search, refinement and decisions keep the picture's lambda)
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
     const dev_tables *T = &g_tab;
     const imv_t *__restrict__ field = k_final_imv_dev(ctx);

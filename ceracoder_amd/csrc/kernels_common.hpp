@@ -93,6 +93,13 @@ DEV void st_mbinfo(mb_info_t *p, const mb_info_t &m) {
     stg128(p, r);
 }
 
+// QP_Y of a macroblock: the picture's, or with adaptive quantisation the picture's plus the macroblock's offset (oracle: mb_qp)
+DEV int mb_qp_dev(const frame_ctx_t *ctx, int mbn) {
+    if (!ctx->qp_off) return ctx->qp; // (uniform)
+    const int q = ctx->qp + (int)(int8_t)ldg8(ctx->qp_off + mbn);
+    return q < 0 ? 0 : (q > 51 ? 51 : q);
+}
+
 // where the last of the ME_ITERS selection iterations leaves the whole-sample vector field (they alternate imv_a -> imv_b -> ...)
 DEV const imv_t *k_final_imv_dev(const frame_ctx_t *ctx) { return (ME_ITERS & 1) ? ctx->imv_b : ctx->imv_a; }
 

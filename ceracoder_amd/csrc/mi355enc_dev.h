@@ -81,6 +81,7 @@ typedef struct {
     int32_t iac_drop;              /* I pictures on rate control's ladder: 0 off, else the sum of level magnitudes up to which a macroblock's luma / chroma
                                       residual is not sent */
     int32_t intra_p;               /* P macroblocks may be intra (the analysis of this picture's source is in isad / idec) */
+    const int8_t *qp_off;          /* adaptive quantisation: one QP offset per macroblock (aq_kernel), or null: one QP per picture */
 } frame_ctx_t;
 
 #ifdef __cplusplus
@@ -133,5 +134,9 @@ int k_launch_csc(int fmt, const uint8_t *p0, const uint8_t *p1, const uint8_t *p
 void k_launch_pack(const mb_info_t *d_mbi, const int16_t *d_levels, int nmb, int mbw, unsigned *d_off, mb_info_t *h_mbi, int16_t *h_packed,
                    unsigned *h_hdr, const unsigned *d_err, hipStream_t s);
 int k_deblock_diags(int mbw, int mbh);
+/* adaptive quantisation: per-macroblock QP offsets from the source's luma variance (oracle: orc_aq_offsets), and -- once a picture's records are
+ * final -- the QP_Y of macroblocks that send no mb_qp_delta (7.4.5: that of the macroblock before them), which the deblocker reads (orc_qp_chain) */
+void k_launch_aq(const frame_ctx_t *h_ctx, int8_t *d_off, hipStream_t s);
+void k_launch_qp_chain(mb_info_t *d_mbi, int nmb, int slice_qp, hipStream_t s);
 #endif
 #endif

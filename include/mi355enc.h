@@ -89,6 +89,11 @@ typedef struct {
                                  bands they read -- a chip full of waiting workgroups.  With another process on the same GPU
                                  such launches can keep each other's kernels off the chip (seen: one of two processes ran into
                                  the bound of its wait), so it is opt-in.  Same stream either way */
+    int aq_mode;              /* 0 (default): one QP per picture.  1: adaptive quantisation -- a QP offset of -4 .. +4 per macroblock from the luma
+                                 variance of its source samples (flat areas finer, busy texture coarser), coded with mb_qp_delta.  The QP_Y of
+                                 macroblocks that send no mb_qp_delta is that of the macroblock before them (7.4.5), which the deblocker reads: a
+                                 whole-picture dependency, so with aq_mode 1 a picture's kernels run in stream order (no kernel follows another
+                                 kernel's progress on the device; about a tenth fewer frames/s).  Not with transform8x8 */
 } mi355enc_cfg_t;
 
 typedef struct {

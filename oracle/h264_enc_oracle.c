@@ -385,6 +385,47 @@ static inline int ref_at(const uint8_t *p, int stride, int W, int H, int x, int 
  * iterations the field is what a sequential encoder's predictor-relative search would settle on, without its raster-order
  * dependency -- and the predictor estimates of the fused macroblock stage are taken from that field.
  * Output per macroblock: whole-sample vector in quarter-sample units, its SAD and the vector bits it was charged. */
+
+/* ================================================================== adaptive quantisation (non-normative; device: aq_kernel, qp_chain_kernel)
+ * One QP offset per macroblock from the luma variance of the SOURCE macroblock: flat areas, where quantisation noise and blocking show
+ * first, get a finer quantiser, busy texture a coarser one (the idea of x264's aq-mode 1, in integers).  With s = sum and s2 = sum of squares
+ * of the 256 samples, v = s2 - (s * s >> 8) is 256 x the variance; L2 = floor(2 log2 v) in half-octave steps (2 msb + next bit); the offset
+ * is (3 (L2 - 28) + 4) >> 3 clamped to -4 .. +4: 0 at a standard deviation of 8, -3 on flat ground, +3 on noise.  Rate control is not told:
+ * it sees the bytes.  Motion search and mode decisions keep the picture's lambda; only quantisation and the macroblock's QP_Y change.
+ * A macroblock that sends no mb_qp_delta (P_Skip, no coded block and not Intra_16x16: 7.3.5) has the QP_Y of the macroblock before it in
+ * decoding order (7.4.5: QP_Y,PRED) -- which is what the deblocking filter then reads for it: orc_qp_chain rewrites the records' qp
+ * accordingly once a picture's records are final. */
+static const int8_t *g_aq; /* offsets of the picture being coded; NULL: one QP per picture */
+void orc_set_aq_map(const int8_t *off) { g_aq = off; }
+static int mb_qp(int qp, int mbn) {
+    if (!g_aq) return qp;
+    const int q = qp + g_aq[mbn];
+    return CLIP3(0, 51, q);
+}
+int orc_aq_offset_of(uint32_t s, uint32_t s2) {
+    const uint32_t v = s2 - ((s * s) >> 8); /* s <= 65280: s * s fits 32 bits */
+    int L2 = 0;
+    if (v > 1) { int msb = 31; while (!(v >> msb)) msb--; L2 = 2 * msb + (int)((v >> (msb - 1)) & 1u); }
+    const int o = (3 * (L2 - 28) + 4) >> 3;
+    return CLIP3(-4, 4, o);
+}
+void orc_aq_offsets(const uint8_t *src_y, int stride, int mbw, int mbh, int8_t *off) {
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            uint32_t s = 0, s2 = 0;
+            for (int y = 0; y < 16; y++)
+                for (int x = 0; x < 16; x++) { const uint32_t p = src_y[(size_t)(my * 16 + y) * stride + mx * 16 + x]; s += p; s2 += p * p; }
+            off[my * mbw + mx] = (int8_t)orc_aq_offset_of(s, s2);
+        }
+}
+void orc_qp_chain(orc_mbinfo_t *mbi, int nmb, int slice_qp) {
+    int prev = slice_qp;
+    for (int i = 0; i < nmb; i++) {
+        const int coded = mbi[i].mb_type == 0 || (mbi[i].nzmask & 0x07FFFFFFu) != 0;
+        if (coded) prev = mbi[i].qp; else mbi[i].qp = (uint8_t)prev;
+    }
+}
+
 int g_sel_bonus = ORC_SEL_BONUS; /* dev hook: orc_set_tuning(4, v) */
 static void select_mb(const uint16_t *sf, int range, int lambda, int px, int py, int sx, int sy, orc_imv_t *o) {
     uint32_t best_cost = 0xFFFFFFFFu;
@@ -909,6 +950,7 @@ static void intra_mb(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
             orc_mbinfo_t *m = &mbi[my * mbw + mx];
             int16_t *lev = levels + (size_t)(my * mbw + mx) * ORC_LEVELS_PER_MB;
             memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
+            qp = mb_qp(qp, my * mbw + mx);
             int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0;
             m->mb_type = 0; m->mvx = 0; m->mvy = 0; m->qp = (uint8_t)qp; m->nzmask = 0;
             const int best_mode = dec->mode16, best_cmode = dec->cmode, use_i4 = dec->use_i4;
@@ -1182,7 +1224,8 @@ void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *r
             uint8_t pred[256];
             int px, py, sx, sy_;
             memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
-            m->mb_type = 1; m->i16_mode = 0; m->chroma_mode = 0; m->qp = (uint8_t)qp; m->nzmask = 0;
+            const int mqp = mb_qp(qp, mbn); /* quantisation only: search, refinement and decisions keep the picture's lambda */
+            m->mb_type = 1; m->i16_mode = 0; m->chroma_mode = 0; m->qp = (uint8_t)mqp; m->nzmask = 0;
             field_pred(imv, mbw, mx, my, &px, &py, &sx, &sy_);
             if (!(feat & ORC_F_MVDCOST)) { px = 0; py = 0; }
             /* ---- 2. skip probe */
@@ -1199,9 +1242,9 @@ void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *r
                     int16_t pl[ORC_LEVELS_PER_MB];
                     uint32_t pnz = 0;
                     memset(pl, 0, sizeof pl);
-                    if (inter_luma_tq(sy, stride, pred, qp, 1, pl) == 0) {
+                    if (inter_luma_tq(sy, stride, pred, mqp, 1, pl) == 0) {
                         chroma_pred8(ref_uv, rec_uv, stride, W, H, x0, y0, sx, sy_);
-                        inter_chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, 1, pl, &pnz, 1);
+                        inter_chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, mqp, 1, pl, &pnz, 1);
                         pass = pnz == 0;
                     }
                 }
@@ -1252,14 +1295,14 @@ void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *r
             for (int y = 0; y < 16; y++) memcpy(rec_y + (size_t)(y0 + y) * stride + x0, pred + y * 16, 16);
             chroma_pred8(ref_uv, rec_uv, stride, W, H, x0, y0, bx, by);
             if (tdrop && dsad < tdrop) continue; /* rate control's ladder below QP 51: prediction only */
-            m->nzmask = inter_luma_tq(sy, stride, pred, qp, (feat & ORC_F_DECIMATE) != 0, lev + ORC_L_LUMA);
+            m->nzmask = inter_luma_tq(sy, stride, pred, mqp, (feat & ORC_F_DECIMATE) != 0, lev + ORC_L_LUMA);
             for (int b = 0; b < 16; b++) {
                 if (!(m->nzmask & (1u << b))) continue;
                 int32_t d[16];
-                dq_block(lev + ORC_L_LUMA + b * 16, qp, 0, 0, 0, d);
+                dq_block(lev + ORC_L_LUMA + b * 16, mqp, 0, 0, 0, d);
                 orc_idct4_add(d, rec_y + (size_t)(y0 + k_blk_y[b]) * stride + x0 + k_blk_x[b], stride);
             }
-            inter_chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, qp, (feat & ORC_F_DECIMATE) != 0, lev, &m->nzmask, 0);
+            inter_chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, mqp, (feat & ORC_F_DECIMATE) != 0, lev, &m->nzmask, 0);
         }
 }
 
@@ -1674,6 +1717,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
 struct orc_enc {
     int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads, subpel;
     int frames_since_idr, idr_count, have_ref;
+    int aq; int8_t *aq_off;                                                    /* adaptive quantisation: per-macroblock QP offsets of the picture being coded */
     int scenecut, sc_cnt, prev_idr, sc_lag, prev_all_skip;                      /* scene-cut recovery: mirrors enc_schedule.cpp (collect / enqueue_picture) */
     unsigned long long sc_sum, sc_force_at, pic_index;
     uint8_t *src_y, *src_uv, *rec_y[2], *rec_uv[2], *pre_y, *pre_uv, *prev_src_y;
@@ -1712,13 +1756,14 @@ orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop
     e->isad = (orc_isad_t *)calloc(nmb, sizeof(orc_isad_t));
     e->idec = (orc_idec_t *)calloc(nmb, sizeof(orc_idec_t));
     e->levels = (int16_t *)calloc(nmb * ORC_LEVELS_PER_MB, sizeof(int16_t));
+    e->aq_off = (int8_t *)calloc(nmb, 1);
     return e;
 }
 void orc_enc_close(orc_enc_t *e) {
     if (!e) return;
     free(e->src_y); free(e->src_uv); free(e->pre_y); free(e->pre_uv);
     for (int i = 0; i < 2; i++) { free(e->rec_y[i]); free(e->rec_uv[i]); }
-    free(e->mbi); free(e->prev_mbi); free(e->imv); free(e->imv2); free(e->surf); free(e->isad); free(e->idec); free(e->levels); free(e);
+    free(e->mbi); free(e->prev_mbi); free(e->imv); free(e->imv2); free(e->surf); free(e->isad); free(e->idec); free(e->levels); free(e->aq_off); free(e);
 }
 /* copy the visible picture into the coded-size surface, replicating the last column/row */
 static void load_padded(orc_enc_t *e, const uint8_t *y, int ys, const uint8_t *uv, int uvs) {
@@ -1759,6 +1804,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
         memcpy(e->pre_uv, e->rec_uv[nxt], ysz / 2);
     } else {
         load_padded(e, y, y_stride, uv, uv_stride);
+        if (e->aq && !g_orc_t8) { orc_aq_offsets(e->src_y, e->stride, e->mbw, e->mbh, e->aq_off); g_aq = e->aq_off; }
         if (idr)
             orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, drop == ORC_DROP_SKIP ? 0 : drop, e->mbi, e->levels);
         else {
@@ -1794,6 +1840,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
         }
         memcpy(e->pre_y, e->rec_y[nxt], ysz);
         memcpy(e->pre_uv, e->rec_uv[nxt], ysz / 2);
+        if (g_aq) { orc_qp_chain(e->mbi, nmb, qp); g_aq = NULL; }
         orc_deblock_frame(e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, e->mbi);
     }
     size_t n = 0;
@@ -1828,6 +1875,7 @@ int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *u
     return orc_enc_frame2(e, y, y_stride, uv, uv_stride, qp, 0, force_idr, out, out_cap, out_len, is_idr);
 }
 void orc_enc_set_subpel(orc_enc_t *e, int on) { e->subpel = on; }
+void orc_enc_set_aq(orc_enc_t *e, int on) { e->aq = on; }
 void orc_enc_set_scenecut(orc_enc_t *e, int on) { e->scenecut = on; }
 void orc_enc_set_sc_lag(orc_enc_t *e, int lag) { e->sc_lag = lag < 2 ? 2 : lag; } /* enc_schedule.cpp sc_lag(): pipeline_depth + 1 from depth 2 on */
 void orc_enc_set_me_iters(orc_enc_t *e, int n) { e->me_iters = n < 0 ? 0 : n; }

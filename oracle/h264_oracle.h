@@ -129,6 +129,11 @@ orc_enc_t *orc_enc_open(int width, int height, int fps_num, int fps_den, int gop
                         int me_range, int threads);
 void orc_enc_close(orc_enc_t *e);
 void orc_enc_set_subpel(orc_enc_t *e, int on);
+void orc_enc_set_aq(orc_enc_t *e, int on);      /* adaptive quantisation: a QP offset per macroblock from the source's luma variance (default off) */
+void orc_set_aq_map(const int8_t *off);          /* stage functions: the offsets of the picture being coded (NULL: none) */
+void orc_aq_offsets(const uint8_t *src_y, int stride, int mbw, int mbh, int8_t *off);
+int orc_aq_offset_of(uint32_t sum, uint32_t sum_sq);
+void orc_qp_chain(orc_mbinfo_t *mbi, int nmb, int slice_qp); /* 7.4.5: macroblocks without mb_qp_delta take the QP_Y of the one before them */
 void orc_enc_set_scenecut(orc_enc_t *e, int on); /* default on */
 void orc_enc_set_sc_lag(orc_enc_t *e, int lag);  /* scene-cut recovery lands on picture k + lag (default 2; the device: pipeline_depth + 1 from depth 2 on) */
 void orc_enc_set_me_iters(orc_enc_t *e, int n);  /* orc_me_select iterations after the first selection (default ORC_ME_ITERS) */

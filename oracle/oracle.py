@@ -82,6 +82,12 @@ def lib():
         L.orc_enc_set_subpel.argtypes = [vp, C.c_int]
         L.orc_enc_set_subpel.restype = None
         L.orc_enc_set_scenecut.argtypes = [vp, C.c_int]
+        L.orc_enc_set_aq.argtypes = [vp, C.c_int]
+        L.orc_enc_set_aq.restype = None
+        L.orc_aq_offsets.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
+        L.orc_aq_offsets.restype = None
+        L.orc_qp_chain.argtypes = [vp, C.c_int, C.c_int]
+        L.orc_qp_chain.restype = None
         L.orc_enc_set_scenecut.restype = None
         L.orc_enc_set_sc_lag.argtypes = [vp, C.c_int]
         L.orc_enc_set_sc_lag.restype = None
@@ -155,13 +161,14 @@ def _view(ptr, shape, dtype):
 class Encoder:
     """Whole-encoder oracle: one NV12 frame + QP in, Annex-B access unit + stage outputs out."""
 
-    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True, scenecut=True, me_iters=None, sc_lag=2):
+    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True, scenecut=True, me_iters=None, sc_lag=2, aq=False):
         self.L = lib()
         self.h = self.L.orc_enc_open(width, height, fps, 1, gop, me_range, threads)
         if not self.h:
             raise ValueError("orc_enc_open failed")
         self.L.orc_enc_set_subpel(self.h, int(subpel))
         self.L.orc_enc_set_scenecut(self.h, int(scenecut))
+        self.L.orc_enc_set_aq(self.h, int(aq))
         self.L.orc_enc_set_sc_lag(self.h, int(sc_lag))
         if me_iters is not None:
             self.L.orc_enc_set_me_iters(self.h, int(me_iters))

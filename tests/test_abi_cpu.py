@@ -88,6 +88,21 @@ def test_host_cavlc_equals_oracle_on_real_pictures(oracle, w, h, qp):
         assert hdr + mine == au, (i, len(mine), len(au))
 
 
+@pytest.mark.parametrize("w,h,qp,threads", [(176, 144, 30, 1), (320, 180, 24, 3), (640, 368, 36, 8)])
+def test_host_cavlc_with_adaptive_quantisation_equals_oracle(oracle, w, h, qp, threads):
+    """mb_qp_delta: the oracle's records of pictures coded with a QP per macroblock through the product's slice writer, also split over
+    row ranges -- every range starts from the QP_Y of the last macroblock before it that sent an mb_qp_delta (7.4.5)."""
+    oe = oracle.Encoder(w, h, gop=4, threads=4, aq=True)
+    seen = set()
+    for i, (y, uv) in enumerate(synth.s2_frames(w, h, 5)):
+        au, idr = oe.encode(y, uv, qp)
+        mine = E.host_write_slice_packed(oe.mbw, oe.mbh, idr, i % 4, 0, qp, oe.mbinfo, oe.levels, threads=threads)
+        hdr = oracle.write_headers(w, h, 60) if idr else b""
+        assert hdr + mine == au, (i, len(mine), len(au))
+        seen |= set(int(q) for q in np.unique(oe.mbinfo["qp"]))
+    assert len(seen) > 1
+
+
 @pytest.mark.parametrize("w,h,qp", [(176, 144, 22), (320, 180, 34)])
 def test_host_cavlc_high_profile_equals_oracle(oracle, w, h, qp):
     """transform8x8: High-profile parameter sets and transform_size_8x8_flag from the product's writer."""

@@ -341,6 +341,37 @@ def test_intra4x4_macroblocks_in_p_pictures_equal_oracle(E, oracle, w, h, n, dep
         oracle.set_features(31)
 
 
+@pytest.mark.parametrize("w,h,n,depth", [(64, 48, 7, 0), (322, 182, 6, 0), (640, 368, 7, 1), (1920, 1080, 5, 2), (1920, 1080, 4, 0)])
+def test_adaptive_quantisation_equals_oracle(E, oracle, w, h, n, depth):
+    """aq_mode 1: a QP offset per macroblock from the variance of its source samples (aq_kernel == orc_aq_offsets), quantisation with the
+    macroblock's own QP in the I and P stages, mb_qp_delta in the slice, and the QP_Y of macroblocks without mb_qp_delta taken from the
+    macroblock before them for the deblocker (qp_chain_kernel == orc_qp_chain, 7.4.5).  Access units, reconstruction and the independent
+    decoder -- which derives QP_Y from the bitstream alone -- all agree."""
+    from tests.util import half_static_clip
+    clip = half_static_clip(w, h, n, (h // 3) & ~15) if w >= 322 else [(y, uv) for _, _, y, uv in frames(w, h, n)]
+    qps = [30, 26, 34, 22, 40, 30, 51]
+    e = E.Encoder(w, h, gop=4, fixed_qp=30, aq=True, pipeline_depth=depth, exclusive=True)
+    oe = oracle.Encoder(w, h, gop=4, threads=8, aq=True)
+    dec = oracle.Decoder()
+    got, seen = [], set()
+    for i, (y, uv) in enumerate(clip):
+        e.set_fixed_qp(qps[i % len(qps)])
+        e.submit(y, uv, pts=i)
+        if e.pending > depth:
+            got.append(e.collect()[0])
+    while e.pending:
+        got.append(e.collect()[0])
+    for i, (y, uv) in enumerate(clip):
+        ref_au, _ = oe.encode(y, uv, qps[i % len(qps)])
+        assert got[i] == ref_au, ("bitstream", i, len(got[i]), len(ref_au))
+        dy, duv = dec.decode(ref_au)
+        assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv), i
+        seen |= set(int(q) - qps[i % len(qps)] for q in np.unique(oe.mbinfo["qp"]))
+    assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y) and np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv)
+    assert len(seen) >= 2, seen  # more than one offset occurred
+    e.close()
+
+
 @pytest.mark.parametrize("w,h", [(16, 16), (32, 16), (16, 48), (18, 18), (4096, 32)])
 def test_degenerate_geometries(E, oracle, w, h):
     """Single macroblock, single row/column, non-multiple-of-16, and the widest row the caps allow."""
