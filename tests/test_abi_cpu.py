@@ -94,7 +94,7 @@ def test_host_cavlc_with_adaptive_quantisation_equals_oracle(oracle, w, h, qp, t
     row ranges -- every range starts from the QP_Y of the last macroblock before it that sent an mb_qp_delta (7.4.5)."""
     oe = oracle.Encoder(w, h, gop=4, threads=4, aq=True)
     seen = set()
-    for i, (y, uv) in enumerate(synth.s2_frames(w, h, 5)):
+    for i, (y, uv) in enumerate(synth.s2_frames(w, h, 4)):
         au, idr = oe.encode(y, uv, qp)
         mine = E.host_write_slice_packed(oe.mbw, oe.mbh, idr, i % 4, 0, qp, oe.mbinfo, oe.levels, threads=threads)
         hdr = oracle.write_headers(w, h, 60) if idr else b""
