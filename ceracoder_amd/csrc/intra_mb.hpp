@@ -501,6 +501,9 @@ DEV void intra_p_row(const ip_args &a, const int my, const unsigned *row_done, c
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#ifdef DBG_DELAY_IP /* adversarial-schedule build: every progress word comes ~20 us late, so the deblocker that follows this kernel catches up with it at every intra macroblock */
+            for (int i = 0; i < 6; i++) __builtin_amdgcn_s_sleep(127);
+#endif
             if (threadIdx.x == 0) { // everything left of the next intra macroblock of this row (or the whole row) is final now
                 unsigned rest = bits;
                 int nx = rest ? 32 * w + __builtin_ctz(rest) : -1;

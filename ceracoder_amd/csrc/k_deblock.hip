@@ -667,7 +667,11 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
             // vertical phase of x-1 patched its columns 12..15; the horizontal phase of x-2 finished the strip above): one LDS read
             // and one 16-byte store per lane, per-lane addresses.
             const int xs2 = x - 2;
+#ifdef DBG_DELAY_BAND /* adversarial-schedule build: the band's last four macroblocks of every row are written back long after its loop has ended (below) */
+            if (row_ok && xs2 >= 0 && xs2 < mbw && !(band == DBG_DELAY_BAND && xs2 >= mbw - 4 && lane < keep)) {
+#else
             if (row_ok && xs2 >= 0 && xs2 < mbw) {
+#endif
                 const bool is_row = lane < keep, is_up = uplane && my > 0;
                 const uint8_t *upb = fed ? ups + (xs2 & (DBT_NB - 1)) * UPB : tiles_up + (xs2 & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
                 const uint8_t *src = is_row ? tiles + (xs2 & (DBT_NB - 1)) * TILE + lane * 16 : upb + (lane & 3) * 16;
@@ -689,6 +693,15 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     // ---- this band's lines are final in memory: tell the next picture's P stage, which may be running already (pmb_kernel's gate).
     // Release pattern: every storing wave drains, the workgroup meets, one lane writes this XCD's L2 back and publishes the epoch.
     if (a.band_done) {
+#ifdef DBG_DELAY_BAND /* adversarial-schedule build (tests/test_adversarial_gpu.py): this band's last macroblocks reach memory ~0.3 ms after its loop has
+                         ended -- long after the bands below it, which only needed its strips, have published: a reader of the next picture that
+                         checked the lowest band of its window alone (round 2's first form of pmb_kernel's gate) reads lines that are not there yet */
+        if (band == DBG_DELAY_BAND) {
+            for (int i = 0; i < 100; i++) __builtin_amdgcn_s_sleep(127); // 100 x 127 x 64 cycles
+            if (role == 2 && row_ok && lane < keep)
+                for (int xs2 = mbw - 4 > 0 ? mbw - 4 : 0; xs2 < mbw; xs2++) stg128(st_ptr + xs2 * 16, lds128(tiles + (xs2 & (DBT_NB - 1)) * TILE + lane * 16));
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x < DB_DONE_COPIES) { // (one copy per poller group: a few thousand waves reading one word would make its memory channel a hot spot)

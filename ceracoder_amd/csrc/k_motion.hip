@@ -763,8 +763,12 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
             r_lo = r_lo > 0 ? r_lo : 0;
             r_hi = r_hi < mbh ? r_hi : mbh - 1;
             const uint2 *flags = (const uint2 *)(gate_done + DB_DONE_STRIDE * (blockIdx.x & (DB_DONE_COPIES - 1)));
-            int spins = 0, b = r_lo / MI355_BAND_ROWS;
             const int b_hi = r_hi / MI355_BAND_ROWS;
+#ifdef DBG_OLD_GATE /* what round 2 first shipped: the lowest band alone (tests/test_adversarial_gpu.py was checked to FAIL with this and the ADVBAND delay) */
+            int spins = 0, b = b_hi;
+#else
+            int spins = 0, b = r_lo / MI355_BAND_ROWS;
+#endif
             for (;;) {
                 const uint2 f = ld64_sc1(flags + b);
                 if (f.x == ref_epoch && f.y == ref_epoch) { if (++b > b_hi) break; continue; }
