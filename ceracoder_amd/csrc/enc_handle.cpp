@@ -16,7 +16,7 @@ bool no_pgate() { static const bool off = getenv("MI355ENC_NO_PGATE") != nullptr
 bool no_db2() { static const bool on = getenv("MI355ENC_DB2") != nullptr; return !on; }
 bool overlap_allowed(const mi355enc_t *h) {
     static const bool serial = getenv("MI355ENC_SERIAL") != nullptr;
-    return !serial && h->safe_level == 0 && g_open_encoders.load(std::memory_order_relaxed) == 1;
+    return !serial && h->safe_level == 0 && !h->cfg.single_stream && g_open_encoders.load(std::memory_order_relaxed) == 1;
 }
 
 int sync_compute(mi355enc_t *h) {
@@ -78,7 +78,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0; c->aq_mode = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0; c->aq_mode = 0; c->single_stream = 0;
 }
 
 int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
@@ -127,7 +127,10 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->db_flip = 0; h->s2_dirty = 0; h->inorder_since_s2 = 0;
     for (int i = 0; i < NSET; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
     h->d_ctx = h->d_ctx2[0];
-    { // The hand-over stream gets its own priority level: HIP then backs it with a different hardware queue, so its
+    if (h->cfg.single_stream) { // one hardware queue per encoder: every stage in order on the main stream
+        h->cstream = h->fstream = h->istream = h->stream;
+        HIPCHK(hipEventCreateWithFlags(&h->ev_pmb, hipEventDisableTiming));
+    } else { // The hand-over stream gets its own priority level: HIP then backs it with a different hardware queue, so its
       // kernels run beside the persistent deblocking kernel instead of queueing behind it.
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -161,8 +164,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_iband_done, 2 * (size_t)h->mbh * sizeof(unsigned))); // one word per macroblock row (intra_mode 2: per band), one set per reconstruction buffer: the next picture's wavefront runs beside this one's deblocking
     HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)h->mbh * sizeof(unsigned), h->stream));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&h->ev_dbI[i], hipEventDisableTiming));
-    HIPCHK(hipMalloc((void **)&h->d_row_done, (size_t)h->mbh * sizeof(unsigned)));
-    HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * sizeof(unsigned), h->stream));
+    HIPCHK(hipMalloc((void **)&h->d_row_done, (size_t)h->mbh * MI355_PROG_STRIDE * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * MI355_PROG_STRIDE * sizeof(unsigned), h->stream));
     HIPCHK(hipMalloc((void **)&h->d_db_done, 2 * k_deblock_done_bytes()));
     HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream)); // epoch 0 is never used
     HIPCHK(hipMalloc((void **)&h->d_db_gran, k_deblock_gran_bytes(h->mbw, h->mbh)));
@@ -178,8 +181,8 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipMalloc((void **)&h->d_psrc[k], h->ysz + SURF_PAD));
         HIPCHK(hipMemsetAsync(h->d_psrc[k], 0, h->ysz + SURF_PAD, h->stream));
     }
-    HIPCHK(hipMalloc((void **)&h->d_ip_progress, (size_t)h->mbh * sizeof(unsigned)));
-    HIPCHK(hipMemsetAsync(h->d_ip_progress, 0, (size_t)h->mbh * sizeof(unsigned), h->stream)); // epoch-tagged: the epoch starts at 1
+    HIPCHK(hipMalloc((void **)&h->d_ip_progress, (size_t)h->mbh * MI355_PROG_STRIDE * sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(h->d_ip_progress, 0, (size_t)h->mbh * MI355_PROG_STRIDE * sizeof(unsigned), h->stream)); // epoch-tagged: the epoch starts at 1
     HIPCHK(hipMalloc((void **)&h->d_ip_strips, (size_t)h->nmb * 32));
     if (cfg->keep_prefilter) {
         HIPCHK(hipMalloc((void **)&h->d_pre_y, h->ysz));
@@ -266,9 +269,9 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_ip_strips) (void)hipFree(h->d_ip_strips);
     for (int i = 0; i < NSET; i++) if (h->d_ctx2[i]) (void)hipFree(h->d_ctx2[i]);
     for (int i = 0; i < NSET; i++) { if (h->d_mbi_set[i]) (void)hipFree(h->d_mbi_set[i]); if (h->d_levels_set[i]) (void)hipFree(h->d_levels_set[i]); }
-    if (h->cstream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
-    if (h->fstream) (void)hipStreamDestroy(h->fstream);
-    if (h->istream) (void)hipStreamDestroy(h->istream);
+    if (h->cstream && h->cstream != h->stream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
+    if (h->fstream && h->fstream != h->stream) (void)hipStreamDestroy(h->fstream);
+    if (h->istream && h->istream != h->stream) (void)hipStreamDestroy(h->istream);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h264_writer_free(h->writer);

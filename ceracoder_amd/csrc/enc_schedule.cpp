@@ -322,7 +322,7 @@ static int recover(mi355enc_t *h, unsigned code) {
     HIPCHK(hipStreamSynchronize(h->cstream));
     { int r = sync_compute(h); if (r) return r; }
     HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * sizeof(unsigned), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * MI355_PROG_STRIDE * sizeof(unsigned), h->stream));
     HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream));
     HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)h->mbh * sizeof(unsigned), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -409,7 +409,7 @@ DEV void intra_p_row(const ip_args &a, const int my, const unsigned *row_done, c
         if (threadIdx.x < 64) {
             const int r = my - 1 + (int)threadIdx.x;
             const bool mine = threadIdx.x < 2 && r >= 0;
-            const unsigned *w = row_done + (mine ? r : 0);
+            const unsigned *w = row_done + (mine ? r * MI355_PROG_STRIDE : 0);
             int spins = 0;
             while (__ballot(mine && (int)(ld_sc1(w) - row_need) < 0)) {
                 __builtin_amdgcn_s_sleep(8);
@@ -431,7 +431,7 @@ DEV void intra_p_row(const ip_args &a, const int my, const unsigned *row_done, c
     if (threadIdx.x == 0) { // everything left of the row's first intra macroblock is final already (pmb_kernel): the deblocker may start on it
         int nx = mbw;
         for (int w2 = (mbw + 31) / 32 - 1; w2 >= 0; w2--) if (ibits[w2]) nx = 32 * w2 + __builtin_ctz(ibits[w2]);
-        if (nx < mbw) st_sc1(&a.progress[my], ep | (unsigned)nx);
+        if (nx < mbw) st_sc1(&a.progress[my * MI355_PROG_STRIDE], ep | (unsigned)nx);
     }
     int prev_x = -2; // the macroblock this workgroup reconstructed last (its right column is in LD)
     for (int w = 0; w < (mbw + 31) / 32; w++) {
@@ -450,7 +450,7 @@ DEV void intra_p_row(const ip_args &a, const int my, const unsigned *row_done, c
                 if (b_intra || d_intra) { // the row above must have passed column mx
                     int spins = 0;
                     for (;;) {
-                        const unsigned v = ld_sc1(&a.progress[my - 1]);
+                        const unsigned v = ld_sc1(&a.progress[(my - 1) * MI355_PROG_STRIDE]);
                         if ((v & ~0xFFFu) == ep && (int)(v & 0xFFFu) > mx) break;
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 15u); sh_bad = 1; break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { sh_bad = 1; break; }
@@ -508,12 +508,12 @@ DEV void intra_p_row(const ip_args &a, const int my, const unsigned *row_done, c
                 unsigned rest = bits;
                 int nx = rest ? 32 * w + __builtin_ctz(rest) : -1;
                 for (int w2 = w + 1; nx < 0 && w2 < (mbw + 31) / 32; w2++) if (ibits[w2]) nx = 32 * w2 + __builtin_ctz(ibits[w2]);
-                st_sc1(&a.progress[my], ep | (unsigned)(nx < 0 ? mbw : nx));
+                st_sc1(&a.progress[my * MI355_PROG_STRIDE], ep | (unsigned)(nx < 0 ? mbw : nx));
             }
             prev_x = mx;
         }
     }
-    if (prev_x == -2 && threadIdx.x == 0) st_sc1(&a.progress[my], ep | (unsigned)mbw); // no intra macroblock in this row
+    if (prev_x == -2 && threadIdx.x == 0) st_sc1(&a.progress[my * MI355_PROG_STRIDE], ep | (unsigned)mbw); // no intra macroblock in this row
     tl_last(ctx, 6);
 }
 #endif

@@ -383,7 +383,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
         if (threadIdx.x < 64) {
             const int r = (band - 1) * ROWS - 1 + (int)threadIdx.x;
             const bool mine = (int)threadIdx.x < 3 * ROWS + 1 && r >= 0 && r < mbh;
-            const unsigned *w = a.row_done + (mine ? r : 0);
+            const unsigned *w = a.row_done + (mine ? r * MI355_PROG_STRIDE : 0);
             int spins = 0;
             while (__ballot(mine && (int)(ld_sc1(w) - a.row_need) < 0)) {
                 __builtin_amdgcn_s_sleep(8);
@@ -645,7 +645,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                         const unsigned tag = (epoch & 0xFFFFFu) << 12; // IP_EPOCH of k_intra.hip
                         int spins = 0;
                         for (;;) {
-                            const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_sc1(a.ip_progress + my));
+                            const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_sc1(a.ip_progress + my * MI355_PROG_STRIDE));
                             if ((v & ~0xFFFu) == tag && (int)(v & 0xFFFu) >= need) { fin = (int)(v & 0xFFFu); break; }
                             __builtin_amdgcn_s_sleep(2);
                             if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 13u); fin = 0x7FFF; break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { fin = 0x7FFF; break; } // bounded; once tripped, nobody waits again

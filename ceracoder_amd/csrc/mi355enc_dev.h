@@ -37,6 +37,11 @@ typedef struct {
 #ifndef MI355_BAND_ROWS
 #define MI355_BAND_ROWS 4 /* macroblock rows per band of the band deblocker (the intra band kernel has bands of its own height, k_intra_band_rows()) */
 #endif
+/* Words that one workgroup publishes and others poll (pmb_kernel's row counts, intra_p_kernel's progress words) lie this many words apart: one
+ * per 4 KB, i.e. on different memory channels -- dozens of waves polling neighbouring words of one cache line make its channel a hot spot. */
+#ifndef MI355_PROG_STRIDE
+#define MI355_PROG_STRIDE 1024
+#endif
 #define ME_ITERS 3          /* Jacobi iterations of the vector selection after the search's own (oracle: ORC_ME_ITERS) */
 #define SEL_BONUS 2         /* oracle: ORC_SEL_BONUS */
 #define SKIP_MARGIN_BITS 4  /* oracle: ORC_SKIP_MARGIN_BITS */

@@ -94,6 +94,10 @@ typedef struct {
                                  macroblocks that send no mb_qp_delta is that of the macroblock before them (7.4.5), which the deblocker reads: a
                                  whole-picture dependency, so with aq_mode 1 a picture's kernels run in stream order (no kernel follows another
                                  kernel's progress on the device; about a tenth fewer frames/s).  Not with transform8x8 */
+    int single_stream;        /* 0 (default): four HIP streams per encoder (front / main / intra / hand-over), so that a picture's independent stages and
+                                 consecutive pictures overlap.  1: everything on ONE stream, in order -- for many encoders on one GPU (several in a
+                                 process, or many processes): the GPU has a handful of hardware queues, and 8 encoders x 4 streams made the driver
+                                 time-slice them (8 streams in one process: 409 frames/s in ALL; with single_stream each encoder keeps one queue busy) */
 } mi355enc_cfg_t;
 
 typedef struct {

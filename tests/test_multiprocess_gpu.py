@@ -80,3 +80,27 @@ def test_two_encoders_in_one_process_equal_the_single_stream(E):
             out[id(e)].append(bytes(e.collect()[0]))
         e.close()
     assert out[id(a)] == ref and out[id(b)] == ref
+
+
+@pytest.mark.gpu
+def test_single_stream_encoders_share_a_gpu_and_equal_the_single_stream(E):
+    """cfg.single_stream: every stage of an encoder in order on ONE HIP stream (one hardware queue each) -- how many encoders share a GPU
+    without the driver time-slicing a few dozen streams.  Four of them, interleaved, three pictures in flight each: same bits as one alone."""
+    from ceracoder_amd import synth
+    w, h, n = 640, 368, 12
+    frames = list(synth.s2_frames(w, h, n))
+    single = E.Encoder(w, h, gop=6, fixed_qp=28)
+    ref = [single.encode(y, uv, pts=i)[0] for i, (y, uv) in enumerate(frames)]
+    single.close()
+    encs = [E.Encoder(w, h, gop=6, fixed_qp=28, pipeline_depth=2, single_stream=True) for _ in range(4)]
+    out = {id(e): [] for e in encs}
+    for i, (y, uv) in enumerate(frames):
+        for e in encs:
+            e.submit(y, uv, pts=i)
+            if e.pending > 2:
+                out[id(e)].append(bytes(e.collect()[0]))
+    for e in encs:
+        while e.pending:
+            out[id(e)].append(bytes(e.collect()[0]))
+        e.close()
+    assert all(out[id(e)] == ref for e in encs)
