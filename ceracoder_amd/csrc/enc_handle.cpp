@@ -135,7 +135,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
-        HIPCHK(hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, lo));
+        HIPCHK(hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, getenv("MI355ENC_FPRIO") ? atoi(getenv("MI355ENC_FPRIO")) : lo));
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, 0));
         HIPCHK(hipEventCreateWithFlags(&h->ev_pmb, hipEventDisableTiming));
     }
@@ -216,11 +216,27 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipStreamSynchronize(h->stream));
     h->ms_open = now_ms() - t_open; h->n_skip_pictures = 0;
     h->safe_level = 0; h->n_recoveries = 0; h->last_error_word = 0;
+    // Entropy coding off the caller's thread: with pictures in flight the caller's loop was submit (~60 us of launches) + slice coding (~100 us
+    // on the pool) per picture -- as long as the device's period.  A worker takes the slice coding: it waits for a picture's hand-over, codes the
+    // access unit into the slot's buffer and collect() only copies it out.  Not at pipeline_depth 0 (the latency mode: nothing to overlap).
+    h->wk_qh = h->wk_qt = 0; h->wk_stop = false; h->wk_on = false; h->au_cap = 0;
+    if (h->cfg.pipeline_depth >= 1 && !getenv("MI355ENC_SYNC_ENTROPY")) {
+        h->au_cap = h264_max_au_bytes(h->mbw, h->mbh);
+        for (int i = 0; i < NSLOT; i++) { h->slot[i].au = (uint8_t *)malloc(h->au_cap); if (!h->slot[i].au) return MI355ENC_ERR_NOMEM; }
+        h->wk_on = true;
+        h->wk = std::thread(entropy_worker, h);
+    }
     return MI355ENC_OK;
 }
 
 void mi355enc_close(mi355enc_t *h) {
     if (!h) return;
+    if (h->wk_on) {
+        { std::lock_guard<std::mutex> g(h->wk_mu); h->wk_stop = true; }
+        h->wk_cv.notify_all();
+        h->wk.join();
+        h->wk_on = false;
+    }
     g_open_encoders.fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(h->cfg.device_id);
     if (h->fstream) (void)hipStreamSynchronize(h->fstream);
@@ -235,6 +251,7 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->h_levels) (void)hipHostFree(s->h_levels);
         if (s->h_hdr) (void)hipHostFree(s->h_hdr);
         if (s->h_src) (void)hipHostFree(s->h_src);
+        free(s->au);
         if (s->d_src_y) (void)hipFree(s->d_src_y);
         if (s->d_src_uv) (void)hipFree(s->d_src_uv);
         if (s->d_raw) (void)hipFree(s->d_raw);

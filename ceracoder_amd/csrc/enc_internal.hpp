@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,6 +55,9 @@ struct slot_t {
     uint64_t index;            // position of the picture in the stream
     int is_idr, qp, drop, frame_num, idr_pic_id, rec_index, set;
     int64_t pts;
+    // entropy coding on the handle's worker thread (pipeline_depth >= 1): the access unit is coded here while the caller submits the next picture
+    uint8_t *au; size_t au_len; int au_state; // 0 not submitted to the worker, 1 queued / being coded, 2 coded (au_len 0: did not fit), 3 the hand-over carried an error word
+    double au_ms;
     const uint8_t *src_y, *src_uv; int src_stride, force_idr; // what enqueue_picture() was given: a recovery re-enqueues the pictures in flight from here
 };
 
@@ -123,6 +128,13 @@ struct mi355enc {
     // workgroups of ONE persistent launch (bands of the intra wavefront / the deblocker); 2: one launch per wavefront step, no wait on the device at all.
     int safe_level;
     uint32_t n_recoveries, last_error_word;
+    // the entropy-coding worker (started by open() when pipeline_depth >= 1)
+    std::thread wk;
+    std::mutex wk_mu;
+    std::condition_variable wk_cv, wk_done_cv;
+    int wk_q[NSLOT + 1], wk_qh, wk_qt;
+    bool wk_stop, wk_on;
+    size_t au_cap;
 };
 
 static inline double now_ms() {
@@ -145,5 +157,6 @@ int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, co
                 unsigned *band_done = nullptr, bool after_gated_pmb = false, unsigned row_need = 0, bool fused_ip = false);
 void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set = 0);
 int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_t *src_uv, int src_stride, int64_t pts, int force_idr);
+void entropy_worker(mi355enc_t *h);
 int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const planes[3], const int strides[3], hipStream_t up);
 #endif

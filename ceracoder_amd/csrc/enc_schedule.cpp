@@ -10,6 +10,8 @@
 // With pipeline_depth = 1 the host codes picture n while the device works on n+1; with 2 a third picture is in flight.
 #include "enc_internal.hpp"
 
+static void worker_push(mi355enc_t *h, int slot_index);
+
 static void launch_intra_all(mi355enc_t *h, int ci) {
     int n = k_intra_diags(h->mbw, h->mbh);
     for (int d = 0; d < n; d++) k_launch_intra_diag(h->d_ctx2[ci], h->mbw, h->mbh, d, h->stream);
@@ -265,7 +267,9 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
     if (idr) h->idr_count++;
     h->frames_since_idr++;
     h->cur = nxt; h->have_ref = 1; h->prev_slot = s;
+    const int slot_index = (int)(s - h->slot);
     h->head = (h->head + 1) % NSLOT; h->pending++;
+    if (h->wk_on) worker_push(h, slot_index);
     return MI355ENC_OK;
 }
 
@@ -290,6 +294,51 @@ int upload_and_convert(mi355enc_t *h, slot_t *s, int fmt, const uint8_t *const p
     }
     HIPCHK(hipGetLastError());
     return MI355ENC_OK;
+}
+
+// ---- the entropy-coding worker: one picture at a time, in submission order
+static size_t code_access_unit(mi355enc_t *h, slot_t *s, uint8_t *out, size_t cap) {
+    size_t n = 0;
+    if (s->is_idr) {
+        n = h264_write_headers(out, cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den, h->cfg.transform8x8);
+        if (!n) return 0;
+    }
+    const size_t m = h264_write_slice_packed_rows(h->writer, out + n, cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels, s->h_hdr + 2);
+    return m ? n + m : 0;
+}
+void entropy_worker(mi355enc_t *h) {
+    (void)hipSetDevice(h->cfg.device_id);
+    for (;;) {
+        int k;
+        {
+            std::unique_lock<std::mutex> g(h->wk_mu);
+            h->wk_cv.wait(g, [&] { return h->wk_stop || h->wk_qh != h->wk_qt; });
+            if (h->wk_stop) return;
+            k = h->wk_q[h->wk_qh];
+        }
+        slot_t *s = &h->slot[k];
+        int state = 2;
+        if (!s->all_skip && hipEventSynchronize(s->done) != hipSuccess) state = 3;
+        const double t0 = now_ms();
+        if (state == 2 && s->h_hdr[1]) state = 3; // a device-side wait ran out: collect() recovers (and queues the pictures again)
+        if (state == 2) s->au_len = code_access_unit(h, s, s->au, h->au_cap);
+        s->au_ms = now_ms() - t0;
+        {
+            std::lock_guard<std::mutex> g(h->wk_mu);
+            h->wk_qh = (h->wk_qh + 1) % (NSLOT + 1);
+            s->au_state = state;
+        }
+        h->wk_done_cv.notify_all();
+    }
+}
+static void worker_push(mi355enc_t *h, int slot_index) {
+    { std::lock_guard<std::mutex> g(h->wk_mu); h->slot[slot_index].au_state = 1; h->wk_q[h->wk_qt] = slot_index; h->wk_qt = (h->wk_qt + 1) % (NSLOT + 1); }
+    h->wk_cv.notify_one();
+}
+// waits until the worker has nothing queued or in hand (recover() re-enqueues pictures behind its back)
+static void worker_drain(mi355enc_t *h) {
+    std::unique_lock<std::mutex> g(h->wk_mu);
+    h->wk_done_cv.wait(g, [&] { return h->wk_qh == h->wk_qt; });
 }
 
 static const char *wait_name(unsigned code) {
@@ -319,6 +368,7 @@ static int recover(mi355enc_t *h, unsigned code) {
             h->safe_level == 1 ? "re-encoding the pictures in flight from an IDR picture; kernels run in stream order from now on" :
             h->safe_level == 2 ? "again: one launch per wavefront step from now on (no waits on the device at all)" : "giving up");
     if (h->safe_level > 2) return MI355ENC_ERR_HIP;
+    if (h->wk_on) worker_drain(h); // (the pictures behind the failing one are coded and thrown away: they are enqueued again below)
     HIPCHK(hipStreamSynchronize(h->cstream));
     { int r = sync_compute(h); if (r) return r; }
     HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream));
@@ -419,24 +469,37 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     HIPCHK(hipSetDevice(h->cfg.device_id));
     slot_t *s = &h->slot[h->tail];
     double t0 = now_ms();
-    if (!s->all_skip) HIPCHK(hipEventSynchronize(s->done));
-    double t1 = now_ms();
-    h->st.ms_wait += t1 - t0;
-    for (int attempt = 0; s->h_hdr[1]; attempt++) { // set by a kernel of this or an earlier picture that gave up waiting on the device
-        if (attempt >= 2) return MI355ENC_ERR_HIP;
-        int r = recover(h, s->h_hdr[1]);
-        if (r) return r;
-        s = &h->slot[h->tail];
+    size_t n = 0, m = 0;
+    if (h->wk_on) { // the worker codes the access unit; here it is only copied out
+        for (int attempt = 0;; attempt++) {
+            { std::unique_lock<std::mutex> g(h->wk_mu); h->wk_done_cv.wait(g, [&] { return s->au_state >= 2; }); }
+            if (s->au_state == 2) break;
+            if (attempt >= 2 || !s->h_hdr[1]) return MI355ENC_ERR_HIP;
+            int r = recover(h, s->h_hdr[1]);
+            if (r) return r;
+            s = &h->slot[h->tail];
+        }
+        h->st.ms_wait += now_ms() - t0 - s->au_ms > 0 ? now_ms() - t0 - s->au_ms : 0;
+        h->st.ms_entropy += s->au_ms;
+        if (!s->au_len || s->au_len > out_cap) return MI355ENC_ERR_OVERFLOW;
+        memcpy(out, s->au, s->au_len);
+        m = s->au_len;
+        s->au_state = 0;
+    } else {
         if (!s->all_skip) HIPCHK(hipEventSynchronize(s->done));
+        double t1 = now_ms();
+        h->st.ms_wait += t1 - t0;
+        for (int attempt = 0; s->h_hdr[1]; attempt++) { // set by a kernel of this or an earlier picture that gave up waiting on the device
+            if (attempt >= 2) return MI355ENC_ERR_HIP;
+            int r = recover(h, s->h_hdr[1]);
+            if (r) return r;
+            s = &h->slot[h->tail];
+            if (!s->all_skip) HIPCHK(hipEventSynchronize(s->done));
+        }
+        m = code_access_unit(h, s, out, out_cap);
+        if (!m) return MI355ENC_ERR_OVERFLOW;
+        h->st.ms_entropy += now_ms() - t1;
     }
-    size_t n = 0;
-    if (s->is_idr) {
-        n = h264_write_headers(out, out_cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den, h->cfg.transform8x8);
-        if (!n) return MI355ENC_ERR_OVERFLOW;
-    }
-    size_t m = h264_write_slice_packed_rows(h->writer, out + n, out_cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels, s->h_hdr + 2);
-    if (!m) return MI355ENC_ERR_OVERFLOW;
-    h->st.ms_entropy += now_ms() - t1;
     *out_len = n + m;
     if (is_keyframe) *is_keyframe = s->is_idr;
     if (pts) *pts = s->pts;

@@ -51,7 +51,17 @@ typedef struct {
     double cliff_bits; int cliff_vqp, cliff_age; /* the quantiser at which a P picture last cost several times its target, what it cost, pictures left to remember it */
     int last_vqp_i, last_vqp_p;
     int have_i, have_p;
-    double plan[4];            /* planned bits of the pictures picked but not yet updated (pipeline depth <= 1) */
+    double plan[4];            /* planned bits of the pictures picked but not yet updated (three pictures in flight at most) */
+    double plan_k[4];          /* ... the factor the setpoint has moved by since they were picked (1: no change) */
+    short plan_gap[4];         /* ... how many all-skip pictures preceded them */
+    double cplx_gap;           /* the same, averaged over the samples the P tracker holds: a picture after a skip run costs more than one after a coded picture */
+    short plan_vqp[4];         /* ... and the virtual quantiser they were given (P pictures; 0x7FFF: an IDR or all-skip picture) */
+    unsigned plan_gop[4];      /* ... and the GOP they belong to */
+    unsigned gop_serial;       /* the current GOP */
+    double prev_rest, carry_used; /* what the previous GOP left (uncapped) when this one was granted, and the carry granted from it: pictures of the previous
+                                * GOP whose sizes arrive after the grant settle through the same cap */
+    int upd_drop_p, catchup;   /* ladder level of the last P picture whose size is known; pictures still to come whose size is a catch-up transient */
+    int known_vqp_p;           /* the virtual quantiser of the last P picture whose size is known */
     unsigned n_pick, n_upd;
 } rc_state_t;
 void rc_init(rc_state_t *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max);

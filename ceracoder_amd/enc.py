@@ -164,12 +164,15 @@ def host_write_slice_packed(mbw, mbh, is_idr, frame_num, idr_pic_id, qp, mbinfo,
     return bytes(out[: n.value])
 
 
+RC_BYTES = 512  # include/mi355enc.h MI355ENC_RC_BYTES
+
+
 class RateControl:
     """The encoder's rate-control model by itself (host logic; no device)."""
 
     def __init__(self, fps, gop, bps, qp_min=10, qp_max=51):
         self.L = load()
-        self.buf = (C.c_uint8 * 256)()
+        self.buf = (C.c_uint8 * RC_BYTES)()
         self.L.mi355enc_rc_init(self.buf, float(fps), gop, bps, qp_min, qp_max)
 
     def set_bitrate(self, bps):

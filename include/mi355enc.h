@@ -250,7 +250,7 @@ int mi355enc_host_cavlc_block(const int16_t *coef, int maxnum, int nC, uint8_t *
 /* Rate-control model on its own: per picture one pick (QP and, below QP 51, the drop level: 0 .. 12, 255 = all-skip picture)
  * and -- possibly one picture later, as with pipeline_depth 1 -- one update with the bytes it produced, in the same order.
  * rc is an opaque block of MI355ENC_RC_BYTES bytes owned by the caller. */
-#define MI355ENC_RC_BYTES 256
+#define MI355ENC_RC_BYTES 512
 void mi355enc_rc_init(void *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max);
 void mi355enc_rc_set_bitrate(void *rc, uint32_t bps);
 void mi355enc_rc_pick(void *rc, int is_idr, int *qp, int *drop);
