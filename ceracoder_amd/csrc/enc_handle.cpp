@@ -20,6 +20,7 @@ bool overlap_allowed(const mi355enc_t *h) {
 }
 
 int sync_compute(mi355enc_t *h) {
+    if (h->ustream) HIPCHK(hipStreamSynchronize(h->ustream));
     HIPCHK(hipStreamSynchronize(h->fstream));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipStreamSynchronize(h->cstream)); // (also the second home of the deblocking launches)
@@ -114,7 +115,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     for (int i = 0; i < NSET; i++) { h->g_intra[i] = h->g_deblock[i] = nullptr; h->d_ctx2[i] = nullptr; h->d_surf[i] = nullptr; h->d_idec2[i] = nullptr; h->d_mbi_set[i] = nullptr; h->d_levels_set[i] = nullptr; h->d_qp_off[i] = nullptr; }
     h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->ip_done_total = 0; h->d_row_done = nullptr; h->pmb_rows_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->ustream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->ip_done_total = 0; h->d_row_done = nullptr; h->pmb_rows_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->ev_join = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -137,6 +138,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
         HIPCHK(hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, getenv("MI355ENC_FPRIO") ? atoi(getenv("MI355ENC_FPRIO")) : lo));
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, 0));
+        if (h->cfg.pipeline_depth >= 1 && !getenv("MI355ENC_NO_UPSTREAM")) HIPCHK(hipStreamCreateWithFlags(&h->ustream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->ev_pmb, hipEventDisableTiming));
     }
     for (int i = 0; i < NSET; i++) {
@@ -173,7 +175,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_off, (size_t)h->nmb * sizeof(unsigned)));
     for (int k = 0; k < NSET; k++) {
         HIPCHK(hipMalloc((void **)&h->d_surf[k], (size_t)h->nmb * SURF_U16 * sizeof(uint16_t)));
-        for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void **)&h->d_imv[k][i], (size_t)h->nmb * sizeof(imv_t)));
+        for (int i = 0; i < 3; i++) HIPCHK(hipMalloc((void **)&h->d_imv[k][i], (size_t)h->nmb * sizeof(imv_t)));
         if (k > 0) HIPCHK(hipMalloc((void **)&h->d_idec2[k], (size_t)h->nmb * IDEC_BYTES + 16));
         if (h->cfg.aq_mode) HIPCHK(hipMalloc((void **)&h->d_qp_off[k], (size_t)h->nmb + 16));
     }
@@ -201,6 +203,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->gpu_done, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_front, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming));
         for (int k = 0; k < 12; k++) HIPCHK(hipEventCreate(&s->ev[k]));
     }
     h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
@@ -239,6 +242,7 @@ void mi355enc_close(mi355enc_t *h) {
     }
     g_open_encoders.fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(h->cfg.device_id);
+    if (h->ustream) { (void)hipStreamSynchronize(h->ustream); (void)hipStreamDestroy(h->ustream); }
     if (h->fstream) (void)hipStreamSynchronize(h->fstream);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->istream) (void)hipStreamSynchronize(h->istream);
@@ -258,6 +262,7 @@ void mi355enc_close(mi355enc_t *h) {
         if (s->done) (void)hipEventDestroy(s->done);
         if (s->gpu_done) (void)hipEventDestroy(s->gpu_done);
         if (s->ev_front) (void)hipEventDestroy(s->ev_front);
+        if (s->ev_up) (void)hipEventDestroy(s->ev_up);
         for (int k = 0; k < 12; k++) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
     }
     for (int i = 0; i < 2; i++) { if (h->d_rec_y[i]) (void)hipFree(h->d_rec_y[i]); if (h->d_rec_uv[i]) (void)hipFree(h->d_rec_uv[i]); }
@@ -277,7 +282,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_off) (void)hipFree(h->d_off);
     for (int k = 0; k < NSET; k++) {
         if (h->d_surf[k]) (void)hipFree(h->d_surf[k]);
-        for (int i = 0; i < 2; i++) if (h->d_imv[k][i]) (void)hipFree(h->d_imv[k][i]);
+        for (int i = 0; i < 3; i++) if (h->d_imv[k][i]) (void)hipFree(h->d_imv[k][i]);
         if (k > 0 && h->d_idec2[k]) (void)hipFree(h->d_idec2[k]);
         if (h->d_qp_off[k]) (void)hipFree(h->d_qp_off[k]);
     }

@@ -49,6 +49,7 @@ struct slot_t {
     uint8_t *d_src_y, *d_src_uv; // staging for host / unaligned input
     uint8_t *d_raw;              // staging of non-NV12 input before the conversion kernel (allocated on first use)
     hipEvent_t done, gpu_done, ev[12];
+    hipEvent_t ev_up;          // the source has arrived (upload stream; only when that is a stream of its own)
     hipEvent_t ev_front;       // the front stream's part of the picture is done (source in place, search + selection + analysis)
     int prof, fused;
     int all_skip;              // the picture is one run of P_Skip macroblocks: written by the host alone, no device work
@@ -101,7 +102,7 @@ struct mi355enc {
     unsigned *d_progress; // [0] the sticky error word of the persistent kernels (bounded spins report here), [1] workgroups of band-deblocking launches placed
     unsigned *d_off;      // per-macroblock block offsets of the packed stream (scan kernel -> pack kernel)
     uint16_t *d_surf[NSET]; // SAD surfaces of the motion search, SURF_U16 per macroblock; one set per picture in flight: the front stages of picture n+1 (n+2) run beside the back stages of n
-    imv_t *d_imv[NSET][2];   // whole-sample vector fields (search result / selection iterations alternate), per set
+    imv_t *d_imv[NSET][3];   // whole-sample vector fields (search result / selection iterations alternate), per set
     uint8_t *d_idec2[NSET];  // intra decisions per set (d_idec = set 0)
     int8_t *d_qp_off[NSET];  // adaptive quantisation: QP offset per macroblock, per set (null unless cfg.aq_mode)
     uint8_t *d_psrc[2];   // padded source luma of the last two coded pictures: the search runs source against source
@@ -109,6 +110,8 @@ struct mi355enc {
     unsigned *d_ip_progress; // intra macroblocks of P pictures: one progress word per macroblock row (epoch-tagged, never cleared)
     uint8_t *d_ip_strips;    // ... and the bottom lines they publish for the row below, 32 bytes per macroblock
     uint32_t epoch;
+    hipStream_t ustream;       // host-to-device copies of the source pictures (pipeline_depth >= 1): a copy engine's queue, so that a picture's transfer runs beside the
+                               // previous picture's search instead of in front of this one's; nullptr: the front stream carries them
     hipStream_t istream;       // intra_p_kernel of a P picture: beside prep + the band deblocker, which follows it row by row
     hipEvent_t ev_pmb;         // the fused P stage of the picture is done
     slot_t slot[NSLOT];

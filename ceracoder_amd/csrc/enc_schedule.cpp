@@ -62,7 +62,12 @@ int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, co
 // scene-cut recovery: the decision taken with picture k's hand-over lands on picture k + lag, the first one that cannot have been
 // submitted yet (depth 0 behaves as depth 1, so that the stream is the same for both)
 static int sc_lag(const mi355enc_t *h) { return h->cfg.pipeline_depth >= 2 ? h->cfg.pipeline_depth + 1 : 2; }
-static hipStream_t upload_stream(const mi355enc_t *h) { return h->fstream; }
+static hipStream_t upload_stream(const mi355enc_t *h) { return h->ustream ? h->ustream : h->fstream; }
+// the front stream's kernels read the source: behind the upload, if that went to a stream of its own
+static int upload_done(mi355enc_t *h, slot_t *s) {
+    if (h->ustream) { HIPCHK(hipEventRecord(s->ev_up, h->ustream)); HIPCHK(hipStreamWaitEvent(h->fstream, s->ev_up, 0)); }
+    return 0;
+}
 
 // rate control's ladder below QP 51 (oracle: k_drop_sad): the SAD under which a P macroblock carries no residual / takes the skip vector
 static const uint32_t k_drop_sad[DROP_MAX + 1] = {0, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 0xFFFFFFFFu};
@@ -73,7 +78,7 @@ void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set)
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec2[set];
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
-    c->surf = h->d_surf[set]; c->imv_a = h->d_imv[set][0]; c->imv_b = h->d_imv[set][1];
+    c->surf = h->d_surf[set]; c->imv_a = h->d_imv[set][0]; c->imv_b = h->d_imv[set][1]; c->imv_c = h->d_imv[set][2];
     c->me_ref_y = h->d_psrc[h->psrc_cur]; c->psrc_out = h->d_psrc[h->psrc_cur ^ 1];
     if (++h->epoch == 0) h->epoch = 1;
     c->epoch = h->epoch;
@@ -89,7 +94,7 @@ static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof
     if (prof) HIPCHK(hipEventRecord(s->ev[0], st));
     k_launch_me(hc, h->mbw, 0, h->mbh, st);
     if (prof) HIPCHK(hipEventRecord(s->ev[6], st));
-    for (int it = 0; it < ME_ITERS; it++) k_launch_me_select(hc, h->mbw, 0, h->mbh, (it & 1) ? hc->imv_b : hc->imv_a, (it & 1) ? hc->imv_a : hc->imv_b, st);
+    k_launch_me_select_all(hc, h->mbw, 0, h->mbh, st);
     if (prof) HIPCHK(hipEventRecord(s->ev[1], st));
     if (!h->cfg.transform8x8 && hc->intra_p) k_launch_intra_analyse(hc, h->mbw, h->mbh, 1, st);
     if (prof) HIPCHK(hipEventRecord(s->ev[7], st));
@@ -434,6 +439,7 @@ int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
         HIPCHK(hipMemcpyAsync(s->d_src_uv, huv, (size_t)h->W * (ht / 2 - 1) + w, hipMemcpyHostToDevice, up));
     }
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
+    { int r = upload_done(h, s); if (r) return r; }
     return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }
 
@@ -445,6 +451,7 @@ int mi355enc_submit_fmt(mi355enc_t *h, int fmt, const uint8_t *const planes[3], 
     slot_t *s = &h->slot[h->head];
     int r = upload_and_convert(h, s, fmt, planes, strides, upload_stream(h));
     if (r) return r;
+    r = upload_done(h, s); if (r) return r;
     return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }
 
@@ -460,6 +467,7 @@ int mi355enc_submit_device(mi355enc_t *h, const void *d_y, int y_stride, const v
     HIPCHK(hipMemcpy2DAsync(s->d_src_y, h->W, d_y, y_stride, w, ht, hipMemcpyDeviceToDevice, up));
     HIPCHK(hipMemcpy2DAsync(s->d_src_uv, h->W, d_uv, uv_stride, w, ht / 2, hipMemcpyDeviceToDevice, up));
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
+    { int r = upload_done(h, s); if (r) return r; }
     return enqueue_picture(h, s, s->d_src_y, s->d_src_uv, h->W, pts, force_idr);
 }
 

@@ -60,7 +60,7 @@ int mi355enc_stage_me_select(mi355enc_t *h, const uint16_t *surf, const void *im
     int r = stage_ctx(h, qp, true); if (r) return r;
     HIPCHK(hipMemcpyAsync(h->d_surf[0], surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_imv[0][0], imv_in, (size_t)h->nmb * sizeof(imv_t), hipMemcpyHostToDevice, h->stream));
-    k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], h->stream);
+    k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], nullptr, 0, h->stream);
     HIPCHK(hipMemcpyAsync(imv_out, h->d_imv[0][1], (size_t)h->nmb * sizeof(imv_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
@@ -192,7 +192,7 @@ int mi355enc_time_stage(mi355enc_t *h, int stage, int iters, double *avg_ms) {
             else if (stage == 1) k_launch_inter(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
             else if (stage == 2) { if (++h->epoch == 0) h->epoch = 1; h->slot[0].h_ctx->epoch = h->epoch; int r = run_intra(h, 0, h->slot[0].h_ctx); if (r) return r; } // a fresh stamp per launch: the lines between bands are epoch-tagged
             else if (stage == 4) k_launch_subpel(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->stream);
-            else if (stage == 8) k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], h->stream);
+            else if (stage == 8) k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], nullptr, 0, h->stream);
             else if (stage == 9) k_launch_pmb(h->slot[0].h_ctx, h->mbw, 0, h->mbh, 1, nullptr, 0, err_word(h), nullptr, h->stream);
             else if (stage == 10) k_launch_intra_p(h->slot[0].h_ctx, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), h->stream);
             else if (stage >= 5) {

@@ -133,13 +133,17 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
     {
         const uint8_t *__restrict__ src = ctx->src_y;
         const int ss = ctx->src_stride, vh = ctx->vis_h;
+        // wave-uniform, so they live in SGPRs (v_qsad takes one scalar source): 64 VGPRs less, 8 waves per SIMD instead of 5 -- every workgroup of a
+        // 1080p picture is resident at once (36.1 -> 35.2 us alone, 2160p 130 -> 123)
+        const int mu = __builtin_amdgcn_readfirstlane(mxc);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             int sy = my * 16 + r;
             sy = sy < vh ? sy : vh - 1;
-            uint4 v = ldg128(src + (size_t)sy * ss + mxc * 16);
-            c[r][0] = v.x; c[r][1] = v.y; c[r][2] = v.z; c[r][3] = v.w;
-            if (lane == r && mx < mbw) stg128(ctx->psrc_out + (size_t)(my * 16 + r) * stride + mxc * 16, v); // the next picture searches against this
+            const uint4 v = ldg128(src + (size_t)sy * ss + mu * 16);
+            if (lane == r && mx < mbw) stg128(ctx->psrc_out + (size_t)(my * 16 + r) * stride + mu * 16, v); // the next picture searches against this
+            c[r][0] = __builtin_amdgcn_readfirstlane(v.x); c[r][1] = __builtin_amdgcn_readfirstlane(v.y);
+            c[r][2] = __builtin_amdgcn_readfirstlane(v.z); c[r][3] = __builtin_amdgcn_readfirstlane(v.w);
         }
     }
     __syncthreads();
@@ -150,6 +154,9 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
     const unsigned *wp = &win[(ME_K * g) * ME_STRIDE + 4 * m + dxg];
     // one window row ahead in registers; sched_barrier keeps the compiler from hoisting all 100 LDS
     // reads to the top (which costs > 200 VGPRs and halves the occupancy)
+#ifdef ME_DBG_REPEAT
+    for (int rep = 0; rep < ME_DBG_REPEAT; rep++) {
+#endif
     unsigned w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4];
 #pragma unroll
     for (int j = 0; j < 16 + ME_K - 1; j++) {
@@ -173,8 +180,15 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
         __builtin_amdgcn_sched_barrier(0);
         w0 = n0; w1 = n1; w2 = n2; w3 = n3; w4 = n4;
     }
+#ifdef ME_DBG_REPEAT
+    }
+#endif
     // ---- the surface: this lane's tile, five 8-byte words
+#ifdef ME_DBG_NOSURF
+    if (active && acc[0] == 0x123456789ull) {
+#else
     if (active) {
+#endif
         uint16_t *sf = ctx->surf + (size_t)(my * mbw + mx) * SURF_U16 + 4 * dxg;
 #pragma unroll
         for (int d = 0; d < ME_K; d++) stg64(sf + (ME_K * g + d) * SURF_COLS, make_uint2((unsigned)acc[d], (unsigned)(acc[d] >> 32)));
@@ -187,21 +201,34 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
 
 // One Jacobi iteration of the selection: one wave per macroblock re-reads its surface (each lane the tile it wrote) and
 // selects against the 8.4.1.3 median / 8.4.1.1 skip inference of the field `in`.  HBM-shaped: 2520 bytes per macroblock.
-__global__ __launch_bounds__(256) void me_select_kernel(const frame_ctx_t cv, int mb0, int mb1, const imv_t *__restrict__ in, imv_t *__restrict__ out) {
+// An iteration changes a macroblock's result only if its predictors changed: the result is a function of the surface and of
+// (px, py, sx, sy) alone, so where the field `prev` the previous iteration read gives the same four numbers (mode 2; mode 1: the
+// search's own selection, which used zeros) the previous result is copied and the surface is not read (on the S2 clip 9 of 10
+// macroblocks from the second iteration on).  mode 0: always recompute.
+__global__ __launch_bounds__(256) void me_select_kernel(const frame_ctx_t cv, int mb0, int mb1, const imv_t *__restrict__ in, imv_t *__restrict__ out,
+                                                        const imv_t *__restrict__ prev, int mode) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     const int mbw = ctx->mbw;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     const int mbn = mb0 + xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     if (mbn >= mb1) return; // wave-uniform; no workgroup barrier below
     const int my = mbn / mbw, mx = mbn - my * mbw;
+    const fpred_t fp = field_pred(in, mbw, mx, my);
+    const int px = fp.px >> 2, py = fp.py >> 2, sx = fp.sx >> 2, sy = fp.sy >> 2;
+    if (mode) {
+        fpred_t fq = {0, 0, 0, 0};
+        if (mode == 2) fq = field_pred(prev, mbw, mx, my);
+        if (px == (fq.px >> 2) && py == (fq.py >> 2) && sx == (fq.sx >> 2) && sy == (fq.sy >> 2)) { // wave-uniform
+            if (lane == 0) stg64(&out[mbn], ldg64(&in[mbn]));
+            return;
+        }
+    }
     const bool active = lane < 63;
     const int g = active ? lane / 9 : 0, dxg = active ? lane % 9 : 0;
     unsigned long long acc[ME_K];
     const uint16_t *sf = ctx->surf + (size_t)mbn * SURF_U16 + 4 * dxg;
 #pragma unroll
     for (int d = 0; d < ME_K; d++) { const uint2 v = ldg64(sf + (ME_K * g + d) * SURF_COLS); acc[d] = ((unsigned long long)v.y << 32) | v.x; }
-    const fpred_t fp = field_pred(in, mbw, mx, my);
-    const int px = fp.px >> 2, py = fp.py >> 2, sx = fp.sx >> 2, sy = fp.sy >> 2;
     const unsigned best = select_min(acc, g, dxg, active, ctx->me_range, ctx->lambda, px, py, sx, sy);
     if (lane == 0) store_imv(&out[mbn], best, ctx->lambda, px, py, sx, sy);
 }
@@ -822,11 +849,16 @@ void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStrea
     int strips = (mbw + ME_MBS - 1) / ME_MBS;
     if (row1 > row0) hipLaunchKernelGGL(me_kernel, dim3(strips * (row1 - row0)), dim3(64 * ME_MBS), 0, s, *h_ctx, row0);
 }
-void k_launch_me_select(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, const imv_t *in, imv_t *out, hipStream_t s) {
+void k_launch_me_select(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, const imv_t *in, imv_t *out, const imv_t *prev, int mode, hipStream_t s) {
     int n = mbw * (row1 - row0);
-    if (n > 0) hipLaunchKernelGGL(me_select_kernel, dim3((n + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, in, out);
+    if (n > 0) hipLaunchKernelGGL(me_select_kernel, dim3((n + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, in, out, prev, mode);
 }
-const imv_t *k_final_imv(const frame_ctx_t *h_ctx) { return (ME_ITERS & 1) ? h_ctx->imv_b : h_ctx->imv_a; }
+// The ME_ITERS iterations walk a -> b -> c -> a ...: iteration k reads field k % 3, writes (k + 1) % 3 and compares with what iteration k - 1 read.
+void k_launch_me_select_all(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
+    imv_t *const f[3] = {h_ctx->imv_a, h_ctx->imv_b, h_ctx->imv_c};
+    for (int it = 0; it < ME_ITERS; it++) k_launch_me_select(h_ctx, mbw, row0, row1, f[it % 3], f[(it + 1) % 3], it ? f[(it - 1) % 3] : nullptr, it ? 2 : 1, s);
+}
+const imv_t *k_final_imv(const frame_ctx_t *h_ctx) { return ME_ITERS % 3 == 0 ? h_ctx->imv_a : ME_ITERS % 3 == 1 ? h_ctx->imv_b : h_ctx->imv_c; }
 void k_launch_imv_to_mbi(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {
     int n = mbw * (row1 - row0);
     if (n > 0) hipLaunchKernelGGL(imv_to_mbi_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw);

@@ -100,8 +100,8 @@ DEV int mb_qp_dev(const frame_ctx_t *ctx, int mbn) {
     return q < 0 ? 0 : (q > 51 ? 51 : q);
 }
 
-// where the last of the ME_ITERS selection iterations leaves the whole-sample vector field (they alternate imv_a -> imv_b -> ...)
-DEV const imv_t *k_final_imv_dev(const frame_ctx_t *ctx) { return (ME_ITERS & 1) ? ctx->imv_b : ctx->imv_a; }
+// where the last of the ME_ITERS selection iterations leaves the whole-sample vector field (they walk imv_a -> imv_b -> imv_c -> imv_a ...)
+DEV const imv_t *k_final_imv_dev(const frame_ctx_t *ctx) { return ME_ITERS % 3 == 0 ? ctx->imv_a : ME_ITERS % 3 == 1 ? ctx->imv_b : ctx->imv_c; }
 
 // ------------------------------------------------------------------ cross-workgroup hand-off inside a persistent launch
 // Agent-scope (sc1, L1-bypassing) accesses for data one workgroup produces and another consumes while both run, and a bounded

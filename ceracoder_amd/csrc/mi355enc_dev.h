@@ -80,7 +80,7 @@ typedef struct {
     const uint8_t *me_ref_y;       /* what the whole-sample search runs against: the padded SOURCE luma of the last coded picture (coded size, stride `stride`) */
     uint8_t *psrc_out;             /* where this picture's padded source luma goes for the next picture's search (written by me_kernel / copy_luma_kernel) */
     uint16_t *surf;                /* SAD surfaces, SURF_U16 per macroblock */
-    imv_t *imv_a, *imv_b;          /* whole-sample vector fields: the search writes imv_a, the selection iterations alternate; ME_ITERS odd -> final in imv_b */
+    imv_t *imv_a, *imv_b, *imv_c;  /* whole-sample vector fields: the search writes imv_a, selection iteration k reads field k % 3 and writes (k + 1) % 3 */
     uint32_t epoch;                /* picture stamp (never 0): tags the progress words of intra_p_kernel so that nothing needs clearing */
     uint32_t drop_sad;             /* rate control's ladder below QP 51: 0 off, else the SAD below which a P macroblock carries no residual / takes the skip vector */
     int32_t iac_drop;              /* I pictures on rate control's ladder: 0 off, else the sum of level magnitudes up to which a macroblock's luma / chroma
@@ -99,7 +99,8 @@ typedef struct {
  * (kernarg segment); d_ctx: device copy, for the kernels that are replayed from a hipGraph. */
 void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s);
 void k_launch_copy_luma(const frame_ctx_t *h_ctx, hipStream_t s); /* I pictures: source luma -> psrc_out (rows beyond the visible picture repeat its last row) */
-void k_launch_me_select(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, const imv_t *in, imv_t *out, hipStream_t s);
+void k_launch_me_select(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, const imv_t *in, imv_t *out, const imv_t *prev, int mode, hipStream_t s); /* mode 0: recompute all; 1 / 2: copy where the predictors equal zeros / those of `prev` */
+void k_launch_me_select_all(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s); /* the ME_ITERS iterations */
 void k_launch_intra_p(const frame_ctx_t *h_ctx, int mbw, int mbh, unsigned *d_progress /* one word per macroblock row */, uint8_t *d_strips /* 32 bytes per macroblock */,
                       unsigned *d_err, hipStream_t s);
 const imv_t *k_final_imv(const frame_ctx_t *h_ctx); /* where the last selection iteration leaves the field */
