@@ -79,7 +79,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0; c->aq_mode = 0; c->single_stream = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0; c->aq_mode = 0; c->single_stream = 0; c->intra_slices = 0;
 }
 
 int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
@@ -109,6 +109,12 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     if (h->cfg.transform8x8) h->cfg.aq_mode = 0; // (the 8x8-transform path keeps one QP per picture)
     if (h->cfg.qp_min < 0) h->cfg.qp_min = 0;
     h->mbw = (cfg->width + 15) / 16; h->mbh = (cfg->height + 15) / 16;
+    {   // slices per I picture (oracle: orc_auto_intra_slices): about 17 rows each, at most 8
+        int ns = h->cfg.intra_slices > 0 ? h->cfg.intra_slices : h->mbh / 17 < 1 ? 1 : h->mbh / 17 > 8 ? 8 : h->mbh / 17;
+        if (ns > h->mbh) ns = h->mbh;
+        h->islice_rows = ns > 1 ? (h->mbh + ns - 1) / ns : 0;
+        h->stage_slice_rows = 0;
+    }
     h->W = h->mbw * 16; h->H = h->mbh * 16; h->nmb = h->mbw * h->mbh;
     h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
     h->head = h->tail = h->pending = 0;
@@ -207,6 +213,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         for (int k = 0; k < 12; k++) HIPCHK(hipEventCreate(&s->ev[k]));
     }
     h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
+    h264_writer_set_slice_rows(h->writer, h->islice_rows);
     if (!h->writer) return MI355ENC_ERR_NOMEM;
     if (h->cfg.cavlc_threads <= 0) { // auto, like x264enc's threads=0
         const unsigned hw = std::thread::hardware_concurrency();

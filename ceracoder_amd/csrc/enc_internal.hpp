@@ -110,6 +110,7 @@ struct mi355enc {
     unsigned *d_ip_progress; // intra macroblocks of P pictures: one progress word per macroblock row (epoch-tagged, never cleared)
     uint8_t *d_ip_strips;    // ... and the bottom lines they publish for the row below, 32 bytes per macroblock
     uint32_t epoch;
+    int islice_rows, stage_slice_rows;   // rows per slice of an I picture (cfg.intra_slices; 0: one slice) / what the single-stage entry points use
     hipStream_t ustream;       // host-to-device copies of the source pictures (pipeline_depth >= 1): a copy engine's queue, so that a picture's transfer runs beside the
                                // previous picture's search instead of in front of this one's; nullptr: the front stream carries them
     hipStream_t istream;       // intra_p_kernel of a P picture: beside prep + the band deblocker, which follows it row by row

@@ -77,6 +77,7 @@ static const int32_t k_idrop_ac[DROP_MAX + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24
 void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set) {
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec2[set];
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh;
+    c->slice_rows = idr ? h->islice_rows : 0;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
     c->surf = h->d_surf[set]; c->imv_a = h->d_imv[set][0]; c->imv_b = h->d_imv[set][1]; c->imv_c = h->d_imv[set][2];
     c->me_ref_y = h->d_psrc[h->psrc_cur]; c->psrc_out = h->d_psrc[h->psrc_cur ^ 1];
@@ -242,7 +243,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
-        if (c->qp_off) k_launch_qp_chain(h->d_mbi_set[set], h->nmb, qp, h->stream); // 7.4.5: QP_Y of the macroblocks without mb_qp_delta, for the deblocker (everything runs on the main stream here)
+        if (c->qp_off) k_launch_qp_chain(h->d_mbi_set[set], h->nmb, qp, c->slice_rows * h->mbw, h->stream); // 7.4.5: QP_Y of the macroblocks without mb_qp_delta, for the deblocker (everything runs on the main stream here)
         HIPCHK(hipEventRecord(s->gpu_done, (split || pgate) ? h->istream : h->stream)); // records and levels are final here; they do not depend on deblocking
         if (h->d_pre_y) {
             HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));

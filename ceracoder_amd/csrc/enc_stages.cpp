@@ -31,6 +31,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging, int drop = 0, i
     { int r = sync_compute(h); if (r) return r; }
     c->vis_h = h->H;
     fill_ctx(h, c, qp, drop, idr);
+    c->slice_rows = h->stage_slice_rows;
     c->all_intra = 0; // the single-stage deblocking entry point takes records of either picture type
     c->qp_off = nullptr; // (single stages: one QP per picture)
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
@@ -219,11 +220,16 @@ int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den,
     *out_len = n;
     return MI355ENC_OK;
 }
+static int g_host_slice_rows = 0;
+void mi355enc_host_set_slice_rows(int rows) { g_host_slice_rows = rows > 0 ? rows : 0; }
+int mi355enc_stage_set_slice_rows(mi355enc_t *h, int rows) { if (!h || rows < 0) return MI355ENC_ERR_ARG; h->stage_slice_rows = rows; return MI355ENC_OK; }
+int mi355enc_slice_rows(const mi355enc_t *h) { return h ? h->islice_rows : 0; }
 int mi355enc_host_write_slice(int mbw, int mbh, int is_idr, int frame_num, int idr_pic_id, int qp, int t8, const void *mbinfo,
                               const int16_t *levels, uint8_t *out, size_t cap, size_t *out_len) {
     if (!out || !out_len || !mbinfo || !levels || mbw < 1 || mbh < 1 || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     h264_writer_t *w = h264_writer_new(mbw, mbh, t8);
     if (!w) return MI355ENC_ERR_NOMEM;
+    h264_writer_set_slice_rows(w, g_host_slice_rows);
     size_t n = h264_write_slice(w, out, cap, is_idr, frame_num, idr_pic_id, qp, (const mb_info_t *)mbinfo, levels);
     h264_writer_free(w);
     if (!n) return MI355ENC_ERR_OVERFLOW;
@@ -242,6 +248,7 @@ int mi355enc_host_write_slice_packed(int mbw, int mbh, int is_idr, int frame_num
     h264_writer_t *w = h264_writer_new(mbw, mbh, t8);
     int rc = MI355ENC_ERR_NOMEM;
     if (packed && row_off && w && h264_writer_set_threads(w, threads) == 0) {
+        h264_writer_set_slice_rows(w, g_host_slice_rows);
         h264_pack_levels(mbw, mbh, mbi, levels, packed, row_off);
         size_t n = h264_write_slice_packed_rows(w, out, cap, is_idr, frame_num, idr_pic_id, qp, mbi, packed, row_off);
         rc = n ? MI355ENC_OK : MI355ENC_ERR_OVERFLOW;

@@ -282,6 +282,7 @@ static inline void predict_mv(const mb_info_t *mbi, int mbw, int mx, int my, int
 /* ------------------------------------------------------------------ slice */
 struct h264_writer {
     int mbw, mbh, t8;
+    int slice_rows; /* I pictures: a new slice (own NAL unit; the row above its first row not available, 6.4.8) every so many macroblock rows; 0: one slice */
     uint8_t *rbsp; size_t rbsp_cap;
     uint8_t *tc_l; /* TotalCoeff per luma 4x4 in raster order, 16 per macroblock */
     uint8_t *tc_c; /* per chroma AC block: Cb 0-3, Cr 4-7 */
@@ -301,6 +302,7 @@ h264_writer_t *h264_writer_new(int mbw, int mbh, int t8) {
     if (!w->rbsp || !w->tc_l || !w->tc_c || !w->i4m) { h264_writer_free(w); return NULL; }
     return w;
 }
+void h264_writer_set_slice_rows(h264_writer_t *w, int rows) { if (w) w->slice_rows = rows > 0 ? rows : 0; }
 static void cavlc_pool_free(struct cavlc_pool *p);
 void h264_writer_free(h264_writer_t *w) {
     if (!w) return;
@@ -309,22 +311,22 @@ void h264_writer_free(h264_writer_t *w) {
 }
 size_t h264_max_au_bytes(int mbw, int mbh) { return (size_t)mbw * mbh * 1536 + 4096; }
 
-static inline int ctx_luma(const h264_writer_t *w, int mbn, int mx, int my, int bx, int by) {
+static inline int ctx_luma(const h264_writer_t *w, int mbn, int mx, int top, int bx, int by) { /* top: the row above is available (same slice) */
     const uint8_t *t = w->tc_l + (size_t)mbn * 16;
     int na = -1, nb = -1;
     if (bx) na = t[by * 4 + bx - 1];
     else if (mx) na = t[-16 + by * 4 + 3];
     if (by) nb = t[(by - 1) * 4 + bx];
-    else if (my) nb = t[-16 * w->mbw + 12 + bx];
+    else if (top) nb = t[-16 * w->mbw + 12 + bx];
     return (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));
 }
-static inline int ctx_chroma(const h264_writer_t *w, int mbn, int mx, int my, int c, int bx, int by) {
+static inline int ctx_chroma(const h264_writer_t *w, int mbn, int mx, int top, int c, int bx, int by) {
     const uint8_t *t = w->tc_c + (size_t)mbn * 8 + 4 * c;
     int na = -1, nb = -1;
     if (bx) na = t[by * 2];
     else if (mx) na = t[-8 + by * 2 + 1];
     if (by) nb = t[bx];
-    else if (my) nb = t[-8 * w->mbw + 2 + bx];
+    else if (top) nb = t[-8 * w->mbw + 2 + bx];
     return (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));
 }
 
@@ -333,8 +335,8 @@ static inline int ctx_chroma(const h264_writer_t *w, int mbn, int mx, int my, in
  * [luma block b for each set bit b][chroma DC if NZ_CBDC|NZ_CRDC][chroma AC block i for each set bit 16+i]; blocks that
  * are absent are all-zero by construction and read from k_zero_block. */
 static const int16_t k_zero_block[16] __attribute__((aligned(32))) = {0};
-static void slice_header(bits_t *bp, int is_idr, int frame_num, int idr_pic_id, int slice_qp) { /* 7.3.3 */
-    bits_ue(bp, 0);
+static void slice_header(bits_t *bp, int first_mb, int is_idr, int frame_num, int idr_pic_id, int slice_qp) { /* 7.3.3 */
+    bits_ue(bp, (uint32_t)first_mb);
     bits_ue(bp, is_idr ? 7 : 5);
     bits_ue(bp, 0);
     bits_put(bp, 8, (uint32_t)frame_num & 0xFF);
@@ -362,10 +364,12 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
     memset(w->tc_c + (size_t)row0 * mbw * 8, 0, (size_t)(row1 - row0) * mbw * 8);
     /* QP_Y,PRED of the range's first macroblock (7.4.5): the QP_Y of the last macroblock before it that sent an mb_qp_delta (Intra_16x16, or any
      * coded block), the slice's if there is none.  (One QP per picture: the slice's everywhere; adaptive quantisation: whatever that macroblock had.) */
+    const int srows = is_idr ? w->slice_rows : 0; /* (a range never straddles two slices) */
     int skip = 0, prev_qp = slice_qp;
-    for (int i = row0 * mbw - 1; i >= 0; i--)
+    for (int i = row0 * mbw - 1; i >= (srows ? row0 / srows * srows * mbw : 0); i--)
         if (mbi[i].mb_type == 0 || (mbi[i].nzmask & 0x07FFFFFFu) != 0) { prev_qp = mbi[i].qp; break; }
-    for (int my = row0, mbn = row0 * mbw; my < row1; my++)
+    for (int my = row0, mbn = row0 * mbw; my < row1; my++) {
+        const int top = srows ? my % srows != 0 : my > 0; /* the row above belongs to this slice */
         for (int mx = 0; mx < mbw; mx++, mbn++) {
             const mb_info_t *m = mbi + mbn;
             const uint32_t nz = m->nzmask;
@@ -424,7 +428,7 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
                         if (bx) ma = im[blk_to_raster[by * 4 + bx - 1]];
                         else if (mx) ma = m[-1].mb_type == 2 ? im[-16 + blk_to_raster[by * 4 + 3]] : 2;
                         if (by) mb_ = im[blk_to_raster[(by - 1) * 4 + bx]];
-                        else if (my) mb_ = m[-mbw].mb_type == 2 ? im[-(ptrdiff_t)mbw * 16 + blk_to_raster[12 + bx]] : 2;
+                        else if (top) mb_ = m[-mbw].mb_type == 2 ? im[-(ptrdiff_t)mbw * 16 + blk_to_raster[12 + bx]] : 2;
                         const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode = im[blk];
                         if (mode == pm) bits_put(&b, 1, 1);
                         else bits_put(&b, 4, (uint32_t)(mode < pm ? mode : mode - 1)); /* flag 0 + 3-bit rem */
@@ -435,12 +439,12 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
             }
             if (i16 || cbp_l || cbp_c) { bits_se(&b, (int)m->qp - prev_qp); prev_qp = m->qp; }
             uint8_t *tl = w->tc_l + (size_t)mbn * 16;
-            if (i16) put_block16(&b, p_ldc, 0, ctx_luma(w, mbn, mx, my, 0, 0));
+            if (i16) put_block16(&b, p_ldc, 0, ctx_luma(w, mbn, mx, top, 0, 0));
             if (cbp_l)
                 for (int blk = 0; blk < 16; blk++) {
                     if (!(cbp_l & (1 << (blk >> 2)))) continue;
                     const int r = blk_to_raster[blk], bx = r & 3, by = r >> 2;
-                    const int nC = ctx_luma(w, mbn, mx, my, bx, by);
+                    const int nC = ctx_luma(w, mbn, mx, top, bx, by);
                     if ((nz >> blk) & 1) tl[r] = (uint8_t)put_block16(&b, p_luma[blk], i16, nC);
                     else { const int cls = nC < 2 ? 0 : nC < 4 ? 1 : nC < 8 ? 2 : 3; bits_put(&b, vlc_coeff_token[cls][0][0].len, vlc_coeff_token[cls][0][0].bits); }
                 }
@@ -450,11 +454,12 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
                 if (cbp_c == 2)
                     for (int c = 0; c < 2; c++)
                         for (int blk = 0; blk < 4; blk++) {
-                            const int nC = ctx_chroma(w, mbn, mx, my, c, blk & 1, blk >> 1);
+                            const int nC = ctx_chroma(w, mbn, mx, top, c, blk & 1, blk >> 1);
                             w->tc_c[(size_t)mbn * 8 + 4 * c + blk] = (uint8_t)put_block16(&b, p_cac[4 * c + blk], 1, nC);
                         }
             }
         }
+    }
     if (!res.has_coded) res.lead_skip = skip; else res.trail_skip = skip;
     *bp = b;
     return res;
@@ -492,17 +497,35 @@ static void fill_ctx_row(h264_writer_t *w, int row, const mb_info_t *mbi, const 
     }
 }
 
+/* the packed stream behind `n` macroblocks starting at `m` (their blocks are counted from the records) */
+static const int16_t *skip_packed_rows(const mb_info_t *m, int n, const int16_t *packed) {
+    for (int i = 0; i < n; i++) {
+        const uint32_t nz = m[i].nzmask;
+        int blocks = (m[i].mb_type == 2) + ((nz & NZ_LDC) != 0) + __builtin_popcount(nz & 0xFFFFu) + ((nz & (NZ_CBDC | NZ_CRDC)) != 0) + __builtin_popcount((nz >> 16) & 0xFFu);
+        packed += 16 * blocks;
+    }
+    return packed;
+}
 static size_t write_slice_impl(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                                int slice_qp, const mb_info_t *mbi, const int16_t *levels, const int16_t *packed) {
-    bits_t b;
-    bits_init(&b, w->rbsp, w->rbsp_cap);
-    slice_header(&b, is_idr, frame_num, idr_pic_id, slice_qp);
-    rows_result_t r = code_rows(w, &b, 0, w->mbh, is_idr, slice_qp, mbi, levels, packed, 0);
-    const int tail = r.has_coded ? r.trail_skip : r.lead_skip;
-    if (!is_idr && tail) bits_ue(&b, (uint32_t)tail);
-    size_t n = bits_finish(&b, w->rbsp);
-    if (b.overflow) return 0;
-    return emit_nal(out, cap, is_idr ? 3 : 2, is_idr ? 5 : 1, w->rbsp, n);
+    const int srows = (is_idr && w->slice_rows > 0) ? w->slice_rows : w->mbh;
+    size_t total = 0;
+    for (int row0 = 0; row0 < w->mbh; row0 += srows) { /* one NAL unit per slice */
+        const int row1 = row0 + srows < w->mbh ? row0 + srows : w->mbh;
+        bits_t b;
+        bits_init(&b, w->rbsp, w->rbsp_cap);
+        slice_header(&b, row0 * w->mbw, is_idr, frame_num, idr_pic_id, slice_qp);
+        if (packed && row0 > 0) packed = skip_packed_rows(mbi + (size_t)(row0 - srows) * w->mbw, srows * w->mbw, packed);
+        rows_result_t r = code_rows(w, &b, row0, row1, is_idr, slice_qp, mbi, levels, packed, 0);
+        const int tail = r.has_coded ? r.trail_skip : r.lead_skip;
+        if (!is_idr && tail) bits_ue(&b, (uint32_t)tail);
+        size_t n = bits_finish(&b, w->rbsp);
+        if (b.overflow) return 0;
+        n = emit_nal(out + total, cap - total, is_idr ? 3 : 2, is_idr ? 5 : 1, w->rbsp, n);
+        if (!n) return 0;
+        total += n;
+    }
+    return total;
 }
 
 /* ------------------------------------------------------------------ row-parallel CAVLC
@@ -622,12 +645,23 @@ size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, 
     if (!p || !row_off) return write_slice_impl(w, out, cap, is_idr, frame_num, idr_pic_id, slice_qp, mbi, NULL, packed);
     p->is_idr = is_idr; p->slice_qp = slice_qp; p->mbi = mbi; p->packed = packed; p->row_off = row_off;
     /* chunks of about four rows, at least one per thread and at most four: small enough to balance rows of unequal cost and to
-     * leave late threads nothing to hold up, large enough that deriving the context of the row above stays a small share */
-    int nchunk = w->mbh / 4;
-    if (nchunk < p->n) nchunk = p->n;
-    if (nchunk > p->job_cap) nchunk = p->job_cap;
-    for (int c = 0; c < nchunk; c++) { p->job[c].row0 = (int)((long long)w->mbh * c / nchunk); p->job[c].row1 = (int)((long long)w->mbh * (c + 1) / nchunk); }
-    for (int k = 0; k < p->n; k++) p->cursor[k] = p->wr[k]->rbsp;
+     * leave late threads nothing to hold up, large enough that deriving the context of the row above stays a small share.  A chunk
+     * never straddles two slices (I pictures, slice_rows): every slice is cut into its own chunks. */
+    const int srows = (is_idr && w->slice_rows > 0) ? w->slice_rows : w->mbh;
+    const int nslice = (w->mbh + srows - 1) / srows;
+    int want = w->mbh / 4;
+    if (want < p->n) want = p->n;
+    if (want > p->job_cap) want = p->job_cap;
+    int per = (want + nslice - 1) / nslice; /* chunks per slice */
+    if (per < 1) per = 1;
+    while (per > 1 && per * nslice > p->job_cap) per--;
+    if (per * nslice > p->job_cap) return write_slice_impl(w, out, cap, is_idr, frame_num, idr_pic_id, slice_qp, mbi, NULL, packed);
+    int nchunk = 0;
+    for (int sl = 0; sl < nslice; sl++) {
+        const int r0 = sl * srows, r1 = r0 + srows < w->mbh ? r0 + srows : w->mbh, rows = r1 - r0, k = per < rows ? per : rows;
+        for (int c = 0; c < k; c++) { p->job[nchunk].row0 = r0 + (int)((long long)rows * c / k); p->job[nchunk].row1 = r0 + (int)((long long)rows * (c + 1) / k); nchunk++; }
+    }
+    for (int k = 0; k < p->n; k++) { p->cursor[k] = p->wr[k]->rbsp; p->wr[k]->slice_rows = w->slice_rows; }
     pthread_mutex_lock(&p->mu);
     p->nchunk = nchunk; p->next = 0; p->done = 0; p->generation++;
     pthread_cond_broadcast(&p->cv_go);
@@ -636,22 +670,29 @@ size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, 
     pthread_mutex_lock(&p->mu);
     while (p->done < p->nchunk) pthread_cond_wait(&p->cv_done, &p->mu);
     pthread_mutex_unlock(&p->mu);
-    bits_t b;
-    bits_init(&b, w->rbsp, w->rbsp_cap);
-    slice_header(&b, is_idr, frame_num, idr_pic_id, slice_qp);
-    int pending = 0;
-    for (int c = 0; c < nchunk; c++) {
-        const cavlc_job_t *j = &p->job[c];
-        if (j->res.has_coded) {
-            if (!is_idr) bits_ue(&b, (uint32_t)(pending + j->res.lead_skip));
-            bits_append(&b, &j->bits, j->base);
-            pending = j->res.trail_skip;
-        } else pending += j->res.lead_skip;
+    size_t total = 0;
+    for (int c = 0; c < nchunk;) { /* one NAL unit per slice: its header, then its chunks bit-exactly one after the other */
+        const int first_row = p->job[c].row0, end_row = first_row + srows < w->mbh ? first_row + srows : w->mbh;
+        bits_t b;
+        bits_init(&b, w->rbsp, w->rbsp_cap);
+        slice_header(&b, first_row * w->mbw, is_idr, frame_num, idr_pic_id, slice_qp);
+        int pending = 0;
+        for (; c < nchunk && p->job[c].row0 < end_row; c++) {
+            const cavlc_job_t *j = &p->job[c];
+            if (j->res.has_coded) {
+                if (!is_idr) bits_ue(&b, (uint32_t)(pending + j->res.lead_skip));
+                bits_append(&b, &j->bits, j->base);
+                pending = j->res.trail_skip;
+            } else pending += j->res.lead_skip;
+        }
+        if (!is_idr && pending) bits_ue(&b, (uint32_t)pending);
+        size_t n = bits_finish(&b, w->rbsp);
+        if (b.overflow) return 0;
+        n = emit_nal(out + total, cap - total, is_idr ? 3 : 2, is_idr ? 5 : 1, w->rbsp, n);
+        if (!n) return 0;
+        total += n;
     }
-    if (!is_idr && pending) bits_ue(&b, (uint32_t)pending);
-    size_t n = bits_finish(&b, w->rbsp);
-    if (b.overflow) return 0;
-    return emit_nal(out, cap, is_idr ? 3 : 2, is_idr ? 5 : 1, w->rbsp, n);
+    return total;
 }
 
 size_t h264_pack_levels(int mbw, int mbh, const mb_info_t *mbi, const int16_t *levels, int16_t *packed, uint32_t *row_off) {

@@ -27,6 +27,8 @@ size_t h264_write_slice_packed(h264_writer_t *w, uint8_t *out, size_t cap, int i
  * rows concurrently and the result is concatenated bit-exactly.  row_off[r] = index of the first 32-byte block of
  * macroblock row r in the packed stream (written by the device's scan kernel).  threads <= 1: everything on the caller. */
 int h264_writer_set_threads(h264_writer_t *w, int threads);
+/* I pictures written from now on are cut into slices of `rows` macroblock rows, one NAL unit each (0: one slice); P pictures stay one slice */
+void h264_writer_set_slice_rows(h264_writer_t *w, int rows);
 size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                                     int slice_qp, const mb_info_t *mbi, const int16_t *packed, const uint32_t *row_off);
 

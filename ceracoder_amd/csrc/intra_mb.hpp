@@ -50,7 +50,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
     uint8_t *T4 = L->T4, *S4 = L->S4;
     const int mbw = ctx->mbw, stride = ctx->stride;
     const int mbn = my * mbw + mx, qp = mb_qp_dev(ctx, mbn), x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
-    const bool has_top = my > 0, has_left = mx > 0;
+    const bool has_top = row_has_top(ctx, my), has_left = mx > 0;
     uint8_t *__restrict__ ry = ctx->rec_y;
     // Four lanes per 4x4 block (kernels_common.hpp): luma on all 64 lanes of wave 0 -- lane bits 5:4 block row, 3:2 row in block,
     // 1:0 block column -- and chroma on lanes 0..31 of wave 1 (bit 4 block row, 3:2 row in block, 1 plane, 0 block column).

@@ -272,4 +272,7 @@ __global__ __launch_bounds__(1024) void qp_chain_kernel(mb_info_t *__restrict__ 
         else stg32((unsigned *)&mbi[i] + 1, (r.y & 0x00FFFFFFu) | ((unsigned)prev << 24));
     }
 }
-void k_launch_qp_chain(mb_info_t *d_mbi, int nmb, int slice_qp, hipStream_t s) { hipLaunchKernelGGL(qp_chain_kernel, dim3(1), dim3(1024), 0, s, d_mbi, nmb, slice_qp); }
+void k_launch_qp_chain(mb_info_t *d_mbi, int nmb, int slice_qp, int slice_mbs, hipStream_t s) { // slice_mbs > 0: the chain starts again with every slice
+    if (slice_mbs <= 0) slice_mbs = nmb;
+    for (int i = 0; i < nmb; i += slice_mbs) hipLaunchKernelGGL(qp_chain_kernel, dim3(1), dim3(1024), 0, s, d_mbi + i, nmb - i < slice_mbs ? nmb - i : slice_mbs, slice_qp);
+}

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
         if ((iv.y & 0xFFFFu) + (unsigned)ctx->lambda * (iv.y >> 16) < INTRA_GATE(ctx->lambda)) return;
     }
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
-    const bool has_top = my > 0, has_left = mx > 0;
+    const bool has_top = row_has_top(ctx, my), has_left = mx > 0;
     const uint8_t *__restrict__ sy = ctx->src_y;
     const uint8_t *__restrict__ suv = ctx->src_uv;
     const int ss = ctx->src_stride, vh = ctx->vis_h, vh2 = vh >> 1;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(128) void intra_kernel(const frame_ctx_t *__restric
     const int y_lo = diag - (mbw - 1) > 0 ? diag - (mbw - 1) : 0;
     const int my = y_lo + blockIdx.x, mx = diag - my;
     const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
-    const bool has_top = my > 0, has_left = mx > 0;
+    const bool has_top = row_has_top(ctx, my), has_left = mx > 0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     const uint8_t *__restrict__ ry = ctx->rec_y;
     const uint8_t *__restrict__ ruv = ctx->rec_uv;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(IB_ROWS * 128) void intra_band_kernel(ib_args a) {
     // chroma wave, 1.29 -> 1.20 ms per picture.  Intra_16x16 only (the rate-control ladder's pictures): the two are equal, and the pairing
     // luma+luma / chroma+chroma was measured 5 % faster)
     const int my = band * IB_ROWS + r;
-    const bool row_ok = my < mbh, has_top = my > 0;
+    const bool row_ok = my < mbh, has_top = row_has_top(ctx, my);
     const bool fed = row_ok && r == 0 && band > 0;                        // top samples come from the band above
     const bool feeds = row_ok && r == IB_ROWS - 1 && my != mbh - 1;       // bottom rows go to the band below
     intra_lds *L = &LD[r];
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
     const frame_ctx_t *__restrict__ ctx = &a.ctx;
     const int mbw = ctx->mbw, mbh = ctx->mbh, my = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const bool has_top = my > 0, feeds = my < mbh - 1;
+    const bool has_top = row_has_top(ctx, my), feeds = my < mbh - 1; // (a slice's first row reads nothing of the row above and does not wait for it: the slices are independent chains)
     for (int i = threadIdx.x; i < TAB_DWORDS; i += 64 * IR_WAVES) tabw[i] = ((const unsigned *)&g_tab)[i];
     if (threadIdx.x < IR_RING) SH.prog[threadIdx.x] = 0;
     if (threadIdx.x < 8) SH.rec[threadIdx.x] = 0;

@@ -100,6 +100,8 @@ DEV int mb_qp_dev(const frame_ctx_t *ctx, int mbn) {
     return q < 0 ? 0 : (q > 51 ? 51 : q);
 }
 
+// 6.4.8 for the row above: another slice's macroblocks are not available (I pictures cut into slices of ctx->slice_rows rows; oracle: top_ok)
+DEV bool row_has_top(const frame_ctx_t *ctx, int my) { return my > 0 && (ctx->slice_rows <= 0 || my % ctx->slice_rows != 0); }
 // where the last of the ME_ITERS selection iterations leaves the whole-sample vector field (they walk imv_a -> imv_b -> imv_c -> imv_a ...)
 DEV const imv_t *k_final_imv_dev(const frame_ctx_t *ctx) { return ME_ITERS % 3 == 0 ? ctx->imv_a : ME_ITERS % 3 == 1 ? ctx->imv_b : ctx->imv_c; }
 

@@ -87,6 +87,7 @@ typedef struct {
                                       residual is not sent */
     int32_t intra_p;               /* P macroblocks may be intra (the analysis of this picture's source is in isad / idec) */
     const int8_t *qp_off;          /* adaptive quantisation: one QP offset per macroblock (aq_kernel), or null: one QP per picture */
+    int32_t slice_rows;            /* I pictures: a new slice every so many macroblock rows (0: one slice); the row above a slice's first row is not available (6.4.8) */
 } frame_ctx_t;
 
 #ifdef __cplusplus
@@ -143,6 +144,6 @@ int k_deblock_diags(int mbw, int mbh);
 /* adaptive quantisation: per-macroblock QP offsets from the source's luma variance (oracle: orc_aq_offsets), and -- once a picture's records are
  * final -- the QP_Y of macroblocks that send no mb_qp_delta (7.4.5: that of the macroblock before them), which the deblocker reads (orc_qp_chain) */
 void k_launch_aq(const frame_ctx_t *h_ctx, int8_t *d_off, hipStream_t s);
-void k_launch_qp_chain(mb_info_t *d_mbi, int nmb, int slice_qp, hipStream_t s);
+void k_launch_qp_chain(mb_info_t *d_mbi, int nmb, int slice_qp, int slice_mbs, hipStream_t s);
 #endif
 #endif

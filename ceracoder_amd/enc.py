@@ -31,7 +31,7 @@ EXPORTS = [
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
     "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_pmb", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
-    "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
+    "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_host_set_slice_rows", "mi355enc_stage_set_slice_rows", "mi355enc_slice_rows", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
     "mi355enc_rc_pick", "mi355enc_rc_update", "mi355enc_host_cavlc_block", "mi355enc_debug_trip_wait", "mi355enc_host_alloc", "mi355enc_host_free",
 ]
 
@@ -40,7 +40,7 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
                 ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
-                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("intra_in_p", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("vbv_ms", C.c_int), ("scenecut", C.c_int), ("exclusive_device", C.c_int), ("aq_mode", C.c_int), ("single_stream", C.c_int)]
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("intra_in_p", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("vbv_ms", C.c_int), ("scenecut", C.c_int), ("exclusive_device", C.c_int), ("aq_mode", C.c_int), ("single_stream", C.c_int), ("intra_slices", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -106,6 +106,10 @@ def load():
         L.mi355enc_host_free.argtypes = [vp]
         L.mi355enc_time_stage.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.mi355enc_host_write_headers.argtypes = [C.c_int] * 5 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.mi355enc_host_set_slice_rows.argtypes = [C.c_int]
+        L.mi355enc_host_set_slice_rows.restype = None
+        L.mi355enc_stage_set_slice_rows.argtypes = [vp, C.c_int]
+        L.mi355enc_slice_rows.argtypes = [vp]
         L.mi355enc_host_write_slice.argtypes = [C.c_int] * 7 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_write_slice_packed.argtypes = [C.c_int] * 8 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_cavlc_block.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
@@ -140,6 +144,11 @@ def host_write_headers(width, height, fps_num, fps_den=1, transform8x8=False):
     if r:
         raise RuntimeError("mi355enc_host_write_headers: %d" % r)
     return bytes(out[: n.value])
+
+
+def host_set_slice_rows(rows):
+    """The host stage functions write I pictures as slices of `rows` macroblock rows from now on (0: one slice)."""
+    load().mi355enc_host_set_slice_rows(int(rows))
 
 
 def host_write_slice(mbw, mbh, is_idr, frame_num, idr_pic_id, qp, mbinfo, levels, transform8x8=False):
@@ -221,7 +230,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False, intra_slices=0):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
@@ -236,6 +245,7 @@ class Encoder:
         cfg.intra_mode = int(intra_mode)
         cfg.aq_mode = int(aq)
         cfg.single_stream = int(single_stream)
+        cfg.intra_slices = int(intra_slices)  # 0: about 17 macroblock rows per slice (1080p: 4 slices per I picture)
         cfg.subpel = int(subpel)
         cfg.i4x4 = int(i4x4)
         cfg.transform8x8 = int(transform8x8)
@@ -399,6 +409,15 @@ class Encoder:
         y, uv = np.ascontiguousarray(rec_y).copy(), np.ascontiguousarray(rec_uv).copy()
         self._chk(self.L.mi355enc_stage_deblock(self.h, _p(y), _p(uv), _p(np.ascontiguousarray(mbi))), "stage_deblock")
         return y, uv
+
+    @property
+    def slice_rows(self):
+        """macroblock rows per slice of this encoder's I pictures (0: one slice)"""
+        return int(self.L.mi355enc_slice_rows(self.h))
+
+    def stage_set_slice_rows(self, rows):
+        """the single-stage entry points treat the picture as slices of `rows` macroblock rows (0, the default: one slice)"""
+        self._chk(self.L.mi355enc_stage_set_slice_rows(self.h, int(rows)), "stage_set_slice_rows")
 
     def debug_trip_wait(self, code):
         """fault injection: as if a bounded device-side wait had just run out (include/mi355enc.h)"""

@@ -259,6 +259,15 @@ int orc_dequant4(int level, int qp, int pos) {
 static int g_orc_t8 = 0; /* process-wide: transform_8x8_mode (High profile stream, 8x8 transform for P macroblocks) */
 void orc_set_transform8x8(int on) { g_orc_t8 = on; }
 int orc_get_transform8x8(void) { return g_orc_t8; }
+/* Slices of an I picture: g_slice_rows > 0 cuts the picture into slices of that many macroblock rows (7.3.2.8: each its own NAL unit).  Inside the
+ * encoder only the availability of the row above changes (6.4.8: a macroblock of another slice is not available for intra prediction, for the
+ * Intra_4x4 mode predictor, for nC, for QP_Y,PRED); the deblocking filter runs across slice boundaries (disable_deblocking_filter_idc 0).  The
+ * slices of a picture are independent chains for the intra wavefront -- that is what they are for here.  P pictures stay one slice. */
+static int g_slice_rows = 0;
+void orc_set_slice_rows(int rows) { g_slice_rows = rows > 0 ? rows : 0; }
+int orc_get_slice_rows(void) { return g_slice_rows; }
+int orc_auto_intra_slices(int mbh) { int n = mbh / 17; return n < 1 ? 1 : n > 8 ? 8 : n; } /* about 17 rows each (1080p: 4), at most 8 */
+static int top_ok(int my) { return my > 0 && !(g_slice_rows > 0 && my % g_slice_rows == 0); }
 /* 8.5.6 8x8 zig-zag (frame) scan: scan position -> raster index y*8+x */
 static const uint8_t k_zigzag8[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                       41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
@@ -418,9 +427,11 @@ void orc_aq_offsets(const uint8_t *src_y, int stride, int mbw, int mbh, int8_t *
             off[my * mbw + mx] = (int8_t)orc_aq_offset_of(s, s2);
         }
 }
-void orc_qp_chain(orc_mbinfo_t *mbi, int nmb, int slice_qp) {
+void orc_qp_chain(orc_mbinfo_t *mbi, int nmb, int slice_qp) { orc_qp_chain_slices(mbi, nmb, slice_qp, 0); }
+void orc_qp_chain_slices(orc_mbinfo_t *mbi, int nmb, int slice_qp, int slice_mbs) { /* slice_mbs > 0: a new slice (QP_Y,PRED = the slice's QP) every so many macroblocks */
     int prev = slice_qp;
     for (int i = 0; i < nmb; i++) {
+        if (slice_mbs > 0 && i % slice_mbs == 0) prev = slice_qp;
         const int coded = mbi[i].mb_type == 0 || (mbi[i].nzmask & 0x07FFFFFFu) != 0;
         if (coded) prev = mbi[i].qp; else mbi[i].qp = (uint8_t)prev;
     }
@@ -833,7 +844,7 @@ void orc_intra_analyse(const uint8_t *src_y, const uint8_t *src_uv, int stride, 
     for (int my = 0; my < mbh; my++)
         for (int mx = 0; mx < mbw; mx++) {
             orc_isad_t *o = &out[my * mbw + mx];
-            const int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0, has_tr = my > 0 && mx + 1 < mbw;
+            const int x0 = mx * 16, y0 = my * 16, has_top = top_ok(my), has_left = mx > 0, has_tr = top_ok(my) && mx + 1 < mbw;
             uint8_t pred[256], cp[64];
             for (int mode = 0; mode < 4; mode++) {
                 o->i16[mode] = 0xFFFF;
@@ -887,7 +898,7 @@ static uint32_t intra4x4_choose(const orc_isad_t *sad, int mx, int my, int lambd
     for (int b = 0; b < 16; b++) {
         const int bx = k_blk_x[b] >> 2, by = k_blk_y[b] >> 2;
         const int ma = bx > 0 ? lev[ORC_L_LDC + raster_blk[by * 4 + bx - 1]] : (mx > 0 ? 2 : -1);
-        const int mb_ = by > 0 ? lev[ORC_L_LDC + raster_blk[(by - 1) * 4 + bx]] : (my > 0 ? 2 : -1);
+        const int mb_ = by > 0 ? lev[ORC_L_LDC + raster_blk[(by - 1) * 4 + bx]] : (top_ok(my) ? 2 : -1);
         const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
         uint32_t best = 0xFFFFFFFFu; int best_mode = 2;
         for (int mode = 0; mode < 9; mode++) {
@@ -925,7 +936,7 @@ void orc_intra_decide(const orc_isad_t *isad, int mbw, int mbh, int qp, int i4x4
 }
 /* reconstruction of an Intra_4x4 macroblock with the modes in lev[ORC_L_LDC..] (8.3.1.2 + 8.5) */
 static void intra4x4_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int mbw, int mx, int my, int qp, int16_t *lev, uint32_t *nzmask) {
-    const int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0, has_tr = my > 0 && mx + 1 < mbw;
+    const int x0 = mx * 16, y0 = my * 16, has_top = top_ok(my), has_left = mx > 0, has_tr = top_ok(my) && mx + 1 < mbw;
     for (int b = 0; b < 16; b++) {
         const int X = x0 + k_blk_x[b], Y = y0 + k_blk_y[b];
         int up, lf, ul, ur, e[13];
@@ -951,7 +962,7 @@ static void intra_mb(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
             int16_t *lev = levels + (size_t)(my * mbw + mx) * ORC_LEVELS_PER_MB;
             memset(lev, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
             qp = mb_qp(qp, my * mbw + mx);
-            int x0 = mx * 16, y0 = my * 16, has_top = my > 0, has_left = mx > 0;
+            int x0 = mx * 16, y0 = my * 16, has_top = top_ok(my), has_left = mx > 0;
             m->mb_type = 0; m->mvx = 0; m->mvy = 0; m->qp = (uint8_t)qp; m->nzmask = 0;
             const int best_mode = dec->mode16, best_cmode = dec->cmode, use_i4 = dec->use_i4;
             m->i16_mode = (uint8_t)(use_i4 ? 0 : best_mode);
@@ -1596,26 +1607,41 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
     uint8_t *tc_l = (uint8_t *)calloc((size_t)nmb, 16); /* TotalCoeff per luma blkIdx   */
     uint8_t *tc_c = (uint8_t *)calloc((size_t)nmb, 8);  /* per chroma AC block (Cb 0-3, Cr 4-7) */
     if (!rb || !tc_l || !tc_c) { free(rb); free(tc_l); free(tc_c); return 0; }
+    const int srows = (is_idr && g_slice_rows > 0) ? g_slice_rows : 0; /* I pictures: a new slice every so many macroblock rows */
+    size_t total = 0;
     bw_t b;
-    bw_init(&b, rb, rcap);
-    bw_ue(&b, 0);                                 /* first_mb_in_slice */
-    bw_ue(&b, is_idr ? 7 : 5);                    /* slice_type: all slices of the picture I / P */
-    bw_ue(&b, 0);                                 /* pic_parameter_set_id */
-    bw_put(&b, 8, (uint32_t)(frame_num & 0xFF));  /* frame_num, log2_max_frame_num = 8 */
-    if (is_idr) bw_ue(&b, (uint32_t)idr_pic_id);
-    if (!is_idr) bw_put(&b, 1, 0);                /* num_ref_idx_active_override_flag */
-    if (!is_idr) bw_put(&b, 1, 0);                /* ref_pic_list_modification_flag_l0 */
-    if (is_idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); } /* no_output_of_prior_pics, long_term_reference */
-    else bw_put(&b, 1, 0);                        /* adaptive_ref_pic_marking_mode_flag */
-    bw_se(&b, qp - 26);                           /* slice_qp_delta */
-    bw_ue(&b, 0);                                 /* disable_deblocking_filter_idc */
-    bw_se(&b, 0);                                 /* slice_alpha_c0_offset_div2 */
-    bw_se(&b, 0);                                 /* slice_beta_offset_div2 */
+#define SLICE_HEADER(first_mb)                                                                        \
+    do {                                                                                              \
+        bw_init(&b, rb, rcap);                                                                        \
+        bw_ue(&b, (uint32_t)(first_mb));              /* first_mb_in_slice */                         \
+        bw_ue(&b, is_idr ? 7 : 5);                    /* slice_type: all slices of the picture I / P */ \
+        bw_ue(&b, 0);                                 /* pic_parameter_set_id */                      \
+        bw_put(&b, 8, (uint32_t)(frame_num & 0xFF));  /* frame_num, log2_max_frame_num = 8 */         \
+        if (is_idr) bw_ue(&b, (uint32_t)idr_pic_id);                                                  \
+        if (!is_idr) bw_put(&b, 1, 0);                /* num_ref_idx_active_override_flag */          \
+        if (!is_idr) bw_put(&b, 1, 0);                /* ref_pic_list_modification_flag_l0 */         \
+        if (is_idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); } /* no_output_of_prior_pics, long_term_reference */ \
+        else bw_put(&b, 1, 0);                        /* adaptive_ref_pic_marking_mode_flag */        \
+        bw_se(&b, qp - 26);                           /* slice_qp_delta */                            \
+        bw_ue(&b, 0);                                 /* disable_deblocking_filter_idc */             \
+        bw_se(&b, 0);                                 /* slice_alpha_c0_offset_div2 */                \
+        bw_se(&b, 0);                                 /* slice_beta_offset_div2 */                    \
+    } while (0)
+    SLICE_HEADER(0);
 
     static const uint8_t blk_raster[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* blkIdx -> by*4+bx */
     static const uint8_t raster_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* by*4+bx -> blkIdx */
     int skip_run = 0, prev_qp = qp;
-    for (int my = 0; my < mbh; my++)
+    for (int my = 0; my < mbh; my++) {
+        if (srows && my > 0 && my % srows == 0) { /* the slice ends (I slices: no skip run pending), the next one starts */
+            bw_trailing(&b);
+            const size_t n = b.overflow ? 0 : write_nal(out + total, cap - total, 3, 5, rb, b.pos);
+            if (!n) { free(rb); free(tc_l); free(tc_c); return 0; }
+            total += n;
+            SLICE_HEADER(my * mbw);
+            prev_qp = qp;
+        }
+        const int top = srows ? my % srows != 0 : my > 0; /* the row above belongs to this slice */
         for (int mx = 0; mx < mbw; mx++) {
             int mbn = my * mbw + mx;
             const orc_mbinfo_t *m = &mbi[mbn];
@@ -1646,7 +1672,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
                     if (bx > 0) ma = lev[ORC_L_LDC + rb[by * 4 + bx - 1]];
                     else if (mx > 0) ma = m[-1].mb_type == 2 ? lev[-ORC_LEVELS_PER_MB + ORC_L_LDC + rb[by * 4 + 3]] : 2;
                     if (by > 0) mb_ = lev[ORC_L_LDC + rb[(by - 1) * 4 + bx]];
-                    else if (my > 0) mb_ = m[-mbw].mb_type == 2 ? lev[-(ptrdiff_t)mbw * ORC_LEVELS_PER_MB + ORC_L_LDC + rb[12 + bx]] : 2;
+                    else if (top) mb_ = m[-mbw].mb_type == 2 ? lev[-(ptrdiff_t)mbw * ORC_LEVELS_PER_MB + ORC_L_LDC + rb[12 + bx]] : 2;
                     int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode = lev[ORC_L_LDC + blk];
                     if (mode == pm) bw_put(&b, 1, 1);
                     else { bw_put(&b, 1, 0); bw_put(&b, 3, (uint32_t)(mode < pm ? mode : mode - 1)); }
@@ -1673,7 +1699,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
         if ((bx) > 0) na = tc_l[mbn * 16 + raster_blk[(by) * 4 + (bx) - 1]];                         \
         else if (mx > 0) na = tc_l[(mbn - 1) * 16 + raster_blk[(by) * 4 + 3]];                      \
         if ((by) > 0) nb = tc_l[mbn * 16 + raster_blk[((by) - 1) * 4 + (bx)]];                       \
-        else if (my > 0) nb = tc_l[(mbn - mbw) * 16 + raster_blk[12 + (bx)]];                       \
+        else if (top) nb = tc_l[(mbn - mbw) * 16 + raster_blk[12 + (bx)]];                          \
         (out) = (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));    \
     } while (0)
             if (i16) {
@@ -1700,23 +1726,26 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
                         if (bx > 0) na = tc_c[mbn * 8 + 4 * c + blk - 1];
                         else if (mx > 0) na = tc_c[(mbn - 1) * 8 + 4 * c + by * 2 + 1];
                         if (by > 0) nb = tc_c[mbn * 8 + 4 * c + blk - 2];
-                        else if (my > 0) nb = tc_c[(mbn - mbw) * 8 + 4 * c + 2 + bx];
+                        else if (top) nb = tc_c[(mbn - mbw) * 8 + 4 * c + 2 + bx];
                         nC = (na >= 0 && nb >= 0) ? (na + nb + 1) >> 1 : (na >= 0 ? na : (nb >= 0 ? nb : 0));
                         tc_c[mbn * 8 + 4 * c + blk] = (uint8_t)cavlc_block(&b, lev + ORC_L_CAC + (4 * c + blk) * 16 + 1, 15, nC);
                     }
 #undef NC_LUMA
         }
+    }
+#undef SLICE_HEADER
     if (!is_idr && skip_run) bw_ue(&b, (uint32_t)skip_run);
     bw_trailing(&b);
-    size_t n = b.overflow ? 0 : write_nal(out, cap, is_idr ? 3 : 2, is_idr ? 5 : 1, rb, b.pos);
+    size_t n = b.overflow ? 0 : write_nal(out + total, cap - total, is_idr ? 3 : 2, is_idr ? 5 : 1, rb, b.pos);
     free(rb); free(tc_l); free(tc_c);
-    return n;
+    return n ? total + n : 0;
 }
 
 /* ================================================================== encoder wrapper */
 struct orc_enc {
     int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads, subpel;
     int frames_since_idr, idr_count, have_ref;
+    int intra_slices;               /* slices per I picture (0: orc_auto_intra_slices) */
     int aq; int8_t *aq_off;                                                    /* adaptive quantisation: per-macroblock QP offsets of the picture being coded */
     int scenecut, sc_cnt, prev_idr, sc_lag, prev_all_skip;                      /* scene-cut recovery: mirrors enc_schedule.cpp (collect / enqueue_picture) */
     unsigned long long sc_sum, sc_force_at, pic_index;
@@ -1805,6 +1834,10 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
     } else {
         load_padded(e, y, y_stride, uv, uv_stride);
         if (e->aq && !g_orc_t8) { orc_aq_offsets(e->src_y, e->stride, e->mbw, e->mbh, e->aq_off); g_aq = e->aq_off; }
+        {
+            const int ns = e->intra_slices > 0 ? e->intra_slices : orc_auto_intra_slices(e->mbh);
+            g_slice_rows = (idr && ns > 1) ? (e->mbh + ns - 1) / ns : 0;
+        }
         if (idr)
             orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, drop == ORC_DROP_SKIP ? 0 : drop, e->mbi, e->levels);
         else {
@@ -1840,7 +1873,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
         }
         memcpy(e->pre_y, e->rec_y[nxt], ysz);
         memcpy(e->pre_uv, e->rec_uv[nxt], ysz / 2);
-        if (g_aq) { orc_qp_chain(e->mbi, nmb, qp); g_aq = NULL; }
+        if (g_aq) { orc_qp_chain_slices(e->mbi, nmb, qp, g_slice_rows * e->mbw); g_aq = NULL; }
         orc_deblock_frame(e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, e->mbi);
     }
     size_t n = 0;
@@ -1850,6 +1883,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
     }
     size_t s = orc_write_slice(out + n, out_cap - n, e->mbw, e->mbh, idr, e->frames_since_idr, e->idr_count & 0xFFFF,
                                qp, e->mbi, e->levels);
+    g_slice_rows = 0;
     if (!s) return -2;
     *out_len = n + s;
     if (is_idr) *is_idr = idr;
@@ -1876,6 +1910,7 @@ int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *u
 }
 void orc_enc_set_subpel(orc_enc_t *e, int on) { e->subpel = on; }
 void orc_enc_set_aq(orc_enc_t *e, int on) { e->aq = on; }
+void orc_enc_set_intra_slices(orc_enc_t *e, int n) { e->intra_slices = n < 0 ? 0 : n; }
 void orc_enc_set_scenecut(orc_enc_t *e, int on) { e->scenecut = on; }
 void orc_enc_set_sc_lag(orc_enc_t *e, int lag) { e->sc_lag = lag < 2 ? 2 : lag; } /* enc_schedule.cpp sc_lag(): pipeline_depth + 1 from depth 2 on */
 void orc_enc_set_me_iters(orc_enc_t *e, int n) { e->me_iters = n < 0 ? 0 : n; }

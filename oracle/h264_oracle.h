@@ -133,6 +133,11 @@ void orc_enc_set_aq(orc_enc_t *e, int on);      /* adaptive quantisation: a QP o
 void orc_set_aq_map(const int8_t *off);          /* stage functions: the offsets of the picture being coded (NULL: none) */
 void orc_aq_offsets(const uint8_t *src_y, int stride, int mbw, int mbh, int8_t *off);
 int orc_aq_offset_of(uint32_t sum, uint32_t sum_sq);
+void orc_qp_chain_slices(orc_mbinfo_t *mbi, int nmb, int slice_qp, int slice_mbs); /* ... with a new slice every slice_mbs macroblocks (0: one slice) */
+void orc_set_slice_rows(int rows);              /* stage functions: the I picture being coded is cut into slices of `rows` macroblock rows (0: one slice) */
+int orc_get_slice_rows(void);
+int orc_auto_intra_slices(int mbh);             /* the default number of slices of an I picture: about 17 rows each, at most 8 */
+void orc_enc_set_intra_slices(orc_enc_t *e, int n); /* slices per I picture (0: the default above) */
 void orc_qp_chain(orc_mbinfo_t *mbi, int nmb, int slice_qp); /* 7.4.5: macroblocks without mb_qp_delta take the QP_Y of the one before them */
 void orc_enc_set_scenecut(orc_enc_t *e, int on); /* default on */
 void orc_enc_set_sc_lag(orc_enc_t *e, int lag);  /* scene-cut recovery lands on picture k + lag (default 2; the device: pipeline_depth + 1 from depth 2 on) */

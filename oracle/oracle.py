@@ -88,6 +88,13 @@ def lib():
         L.orc_aq_offsets.restype = None
         L.orc_qp_chain.argtypes = [vp, C.c_int, C.c_int]
         L.orc_qp_chain.restype = None
+        L.orc_qp_chain_slices.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.orc_qp_chain_slices.restype = None
+        L.orc_set_slice_rows.argtypes = [C.c_int]
+        L.orc_set_slice_rows.restype = None
+        L.orc_auto_intra_slices.argtypes = [C.c_int]
+        L.orc_enc_set_intra_slices.argtypes = [vp, C.c_int]
+        L.orc_enc_set_intra_slices.restype = None
         L.orc_enc_set_scenecut.restype = None
         L.orc_enc_set_sc_lag.argtypes = [vp, C.c_int]
         L.orc_enc_set_sc_lag.restype = None
@@ -161,7 +168,7 @@ def _view(ptr, shape, dtype):
 class Encoder:
     """Whole-encoder oracle: one NV12 frame + QP in, Annex-B access unit + stage outputs out."""
 
-    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True, scenecut=True, me_iters=None, sc_lag=2, aq=False):
+    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True, scenecut=True, me_iters=None, sc_lag=2, aq=False, intra_slices=0):
         self.L = lib()
         self.h = self.L.orc_enc_open(width, height, fps, 1, gop, me_range, threads)
         if not self.h:
@@ -169,6 +176,7 @@ class Encoder:
         self.L.orc_enc_set_subpel(self.h, int(subpel))
         self.L.orc_enc_set_scenecut(self.h, int(scenecut))
         self.L.orc_enc_set_aq(self.h, int(aq))
+        self.L.orc_enc_set_intra_slices(self.h, int(intra_slices))  # 0: the default (about 17 macroblock rows per slice)
         self.L.orc_enc_set_sc_lag(self.h, int(sc_lag))
         if me_iters is not None:
             self.L.orc_enc_set_me_iters(self.h, int(me_iters))
@@ -333,6 +341,17 @@ def pmb_frame(src_y, src_uv, ref_y, ref_uv, imv, surf, qp, drop=0, refine=True, 
     if dec is not None:
         L.orc_intra_p_frame(_ptr(src_y), _ptr(src_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16, H // 16, qp, _ptr(dec), _ptr(mbi), _ptr(lev))
     return rec_y, rec_uv, mbi, lev, pre
+
+
+def set_slice_rows(rows):
+    """Stage functions: the I picture being coded is cut into slices of `rows` macroblock rows (0: one slice)."""
+    lib().orc_set_slice_rows(int(rows))
+
+
+def slice_rows_for(mbh, slices=0):
+    """Rows per slice the encoders use for `slices` slices per I picture (0: the default number); 0 = one slice."""
+    n = slices if slices > 0 else lib().orc_auto_intra_slices(int(mbh))
+    return (mbh + n - 1) // n if n > 1 else 0
 
 
 def set_features(mask):

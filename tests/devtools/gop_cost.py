@@ -13,7 +13,7 @@ clip = list(synth.s2_frames(w, h, 16))
 bufs = [torch.from_numpy(np.concatenate([y.reshape(-1), uv.reshape(-1)])).cuda() for y, uv in clip]
 torch.cuda.synchronize()
 res = {}
-for gop in (600, 60, 600, 60):
+for gop in (600, 60, 600, 60, 600, 60):
     e = E.Encoder(w, h, fps=60, gop=gop, fixed_qp=qp, pipeline_depth=2, exclusive=True)
     ent = {True: [], False: []}
     def col():
@@ -32,7 +32,8 @@ for gop in (600, 60, 600, 60):
     run(60, 0)
     t0 = time.perf_counter(); run(n, 60); t = time.perf_counter() - t0
     res.setdefault(gop, []).append(t)
-    print("key-int %d: %.1f us per picture (%.0f pictures/s); entropy coding: IDR %.0f us / %.0f KB, P %.0f us / %.1f KB" % (gop, t / n * 1e6, n / t,
+    st = e.stats()
+    print("key-int %d: %.1f us per picture (%.0f pictures/s); recoveries %d, safe level %d; entropy coding: IDR %.0f us / %.0f KB, P %.0f us / %.1f KB" % (gop, t / n * 1e6, n / t, st.recoveries, st.safe_level,
           1e3 * np.mean([x[0] for x in ent[True]]), np.mean([x[1] for x in ent[True]]) / 1e3, 1e3 * np.mean([x[0] for x in ent[False]]), np.mean([x[1] for x in ent[False]]) / 1e3), flush=True)
     e.close()
 d = (min(res[60]) - min(res[600])) / (n // 60 - 1)

@@ -177,7 +177,7 @@ def test_row_parallel_cavlc_is_bit_identical(oracle, w, h, qp, kind):
     """one slice coded by several host threads (ranges of macroblock rows, first mb_skip_run of each
     range written by the stitcher) must equal the single-thread coder and the oracle.  "static": a still picture
     sequence, where whole ranges consist of skipped macroblocks and the runs have to be carried across ranges."""
-    oe = oracle.Encoder(w, h, gop=6, threads=8, scenecut=False)  # every IDR of this run has idr_pic_id 0
+    oe = oracle.Encoder(w, h, gop=6, threads=8, scenecut=False, intra_slices=1)  # every IDR of this run has idr_pic_id 0
     fr = list(synth.s2_frames(w, h, 6))
     if kind == "static":
         fr = [fr[0]] * 3 + [fr[1]] * 3
@@ -189,6 +189,32 @@ def test_row_parallel_cavlc_is_bit_identical(oracle, w, h, qp, kind):
             assert hdr + mine == au, (i, thr, len(mine), len(au))
     if kind == "static":
         assert len(au) < 200  # all skipped: proves the carried-run path ran
+
+
+@pytest.mark.parametrize("w,h,slices,aq", [(320, 192, 2, False), (320, 192, 3, True), (640, 368, 4, False), (1280, 720, 0, True), (1920, 1080, 0, False), (1920, 1080, 7, False)])
+def test_sliced_i_pictures_from_the_host_writer_equal_oracle(oracle, w, h, slices, aq):
+    """I pictures as several slices (cfg.intra_slices; 0 = the default, about 17 macroblock rows each): the oracle encoder's records through the
+    product's writer -- one NAL unit of type 5 per slice, first_mb_in_slice at the row boundary, the row above a slice's first row not
+    available to nC and to the Intra_4x4 mode predictor, QP_Y,PRED back at the slice's QP -- on one thread and on several (chunks of rows
+    never straddle a slice); the independent decoder reproduces the oracle's reconstruction from it."""
+    oe = oracle.Encoder(w, h, gop=3, threads=8, intra_slices=slices, aq=aq)
+    rows = oracle.slice_rows_for(oe.mbh, slices)
+    want = (oe.mbh + rows - 1) // rows if rows else 1
+    dec = oracle.Decoder()
+    try:
+        E.host_set_slice_rows(rows)
+        for i, (y, uv) in enumerate(synth.s2_frames(w, h, 4)):
+            au, idr = oe.encode(y, uv, 28)
+            hdr = oracle.write_headers(w, h, 60) if idr else b""
+            assert hdr + E.host_write_slice(oe.mbw, oe.mbh, idr, i % 3, i // 3, 28, oe.mbinfo, oe.levels) == au, i
+            for thr in (2, 3, 8, oe.mbh + 1):
+                assert hdr + E.host_write_slice_packed(oe.mbw, oe.mbh, idr, i % 3, i // 3, 28, oe.mbinfo, oe.levels, threads=thr) == au, (i, thr)
+            if idr:
+                assert au.count(b"\x00\x00\x01\x65") == want
+            dy, duv = dec.decode(au)
+            assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv), i
+    finally:
+        E.host_set_slice_rows(0)
 
 
 def _synthetic_bytes(rng, idr, qp, drop, skip=255):

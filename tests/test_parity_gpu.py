@@ -207,6 +207,68 @@ def test_intra_kernel_matches_oracle(E, oracle, w, h, qp, i4, imode):
     e.close()
 
 
+@pytest.mark.parametrize("w,h,rows", [(176, 144, 3), (320, 180, 4), (640, 368, 6), (48, 272, 5), (1280, 720, 12), (1920, 1080, 17)])
+@pytest.mark.parametrize("qp", [12, 30, 44])
+@pytest.mark.parametrize("imode", [0, 1, 2])
+def test_intra_kernel_with_slices_matches_oracle(E, oracle, w, h, rows, qp, imode):
+    """An I picture cut into slices of `rows` macroblock rows: the row above a slice's first row is not available to the analysis, to the
+    Intra_4x4 mode decision or to the reconstruction (6.4.8) -- records, levels and reconstruction equal the oracle's (orc_set_slice_rows)."""
+    cy, cuv = frames(w, h, 1)[0][:2]
+    oracle.set_slice_rows(rows)
+    try:
+        o_y, o_uv, o_mbi, o_lev = oracle.intra_frame(cy, cuv, qp)
+        oracle.set_slice_rows(0)
+        p_y = oracle.intra_frame(cy, cuv, qp)[0]
+    finally:
+        oracle.set_slice_rows(0)
+    assert not np.array_equal(p_y, o_y)  # the slices do change the picture
+    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp, intra_mode=imode)
+    e.stage_set_slice_rows(rows)
+    d_y, d_uv, d_mbi, d_lev = e.stage_intra(cy, cuv, qp)
+    assert mbinfo_equal(d_mbi, o_mbi, ("mb_type", "i16_mode", "chroma_mode", "cost")), \
+        [(f, first_diff(d_mbi[f], o_mbi[f])) for f in ("mb_type", "i16_mode", "chroma_mode", "cost")]
+    assert np.array_equal(d_lev, o_lev), first_diff(d_lev, o_lev)
+    assert np.array_equal(d_y, o_y), first_diff(d_y, o_y)
+    assert np.array_equal(d_uv, o_uv), first_diff(d_uv, o_uv)
+    assert mbinfo_equal(d_mbi, o_mbi, ("mb_type", "qp", "nzmask", "mvx", "mvy"))
+    e.close()
+
+
+@pytest.mark.parametrize("w,h,n,slices,depth,aq", [(64, 48, 6, 3, 0, False), (176, 144, 7, 2, 0, True), (322, 182, 6, 4, 1, False), (640, 368, 7, 0, 1, True), (1280, 720, 5, 0, 2, False),
+                                                 (1280, 720, 5, 5, 0, True), (1920, 1080, 6, 0, 2, False), (1920, 1080, 5, 8, 2, True), (1920, 1080, 4, 1, 0, False)])
+@pytest.mark.parametrize("imode", [0, 1])
+def test_sliced_intra_pictures_equal_oracle(E, oracle, w, h, n, slices, depth, aq, imode):
+    """cfg.intra_slices (0: the default, about 17 macroblock rows per slice): every IDR picture is `slices` NAL units of type 5, the access units
+    equal the oracle's, and the independent decoder -- which takes the slice structure from first_mb_in_slice alone -- reproduces the
+    reconstruction; with adaptive quantisation the QP_Y chain starts again with every slice."""
+    qps = [30, 27, 34, 24, 40, 30, 51]
+    e = E.Encoder(w, h, gop=3, fixed_qp=30, pipeline_depth=depth, exclusive=True, aq=aq, intra_slices=slices, intra_mode=imode, cavlc_threads=3)
+    oe = oracle.Encoder(w, h, gop=3, threads=8, aq=aq, intra_slices=slices)
+    dec = oracle.Decoder()
+    clip = [(y, uv) for _, _, y, uv in frames(w, h, n)]
+    got = []
+    for i, (y, uv) in enumerate(clip):
+        e.set_fixed_qp(qps[i % len(qps)])
+        e.submit(y, uv, pts=i)
+        if e.pending > depth:
+            got.append(e.collect()[:2])
+    while e.pending:
+        got.append(e.collect()[:2])
+    mbh = (h + 15) // 16
+    rows = oracle.slice_rows_for(mbh, slices)
+    assert e.slice_rows == rows
+    want = (mbh + rows - 1) // rows if rows else 1
+    for i, (y, uv) in enumerate(clip):
+        ref_au, ref_key = oe.encode(y, uv, qps[i % len(qps)])
+        assert got[i][0] == ref_au, ("bitstream", i, len(got[i][0]), len(ref_au))
+        if ref_key:
+            assert ref_au.count(b"\x00\x00\x01\x65") == want, (i, want)
+        dy, duv = dec.decode(ref_au)
+        assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv), i
+    assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y) and np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv)
+    e.close()
+
+
 @pytest.mark.parametrize("w,h", SIZES + [(48, 272), (64, 256), (80, 528), (1920, 1080)])
 @pytest.mark.parametrize("qp", [16, 30, 44, 51])
 @pytest.mark.parametrize("mode", [0, 1])
