@@ -464,9 +464,10 @@ def main():
                  SEL: "HBM / Infinity Cache: streams every macroblock's SAD surface once per iteration",
                  "subpel_kernel": "LDS-staged 6-tap planes, latency/LDS", "inter_kernel": "launch + byte stores of interleaved chroma",
                  FUSED: "VALU issue: one wave per macroblock (skip probe; 6-tap planes, 8 SAD + 9 SATD candidates; transforms on all 64 lanes; decimation)",
-                 "intra (analyse + x+y wavefront)": "dependency chain: mbw+mbh-1 dependent steps of the persistent band kernel",
+                 "intra (analyse + x+y wavefront)": "dependency chain: Intra_4x4's left-neighbour dependency lets a macroblock start 4 block sub-steps (~0.8 us each) after the one before it, "
+                                                    "so a row of mbw macroblocks is ~4*mbw sub-steps however many rows run side by side; + the lag between the rows of a slice (4 slices at 1080p)",
                  "deblock (prep + band kernel)": "dependency chain of the normative filter order: mbw+mbh dependent steps of ~0.35 us + ~2 us per band boundary inside one persistent launch (three waves per macroblock row: filter / mover / storer)"}
-        pmc_name = {"me_kernel": "me_kernel", SEL: "me_select_kernel", FUSED: "pmb_kernel", "intra (analyse + x+y wavefront)": "intra_band_kernel",
+        pmc_name = {"me_kernel": "me_kernel", SEL: "me_select_kernel", FUSED: "pmb_kernel", "intra (analyse + x+y wavefront)": "intra_rows_kernel",
                     "deblock (prep + band kernel)": "deblock_rows3_kernel"}
         kernels = []
         n_idr, n_p = int(st.idr_frames), int(st.frames - st.idr_frames - st.skip_pictures)

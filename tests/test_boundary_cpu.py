@@ -157,10 +157,11 @@ def test_probe_feeds_pictures_through_appsrc():
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r02_bench_1080p_ippp.json is the line bench.py printed on the GPU box: the keys the driver reads, the roofline
-    object (algorithmic bytes / live launch time, agreeing with the rocprofv3 kernel trace and the PMC pass) and the CPU baseline."""
+    """profiles/r03_bench_1080p_ippp.json is the line bench.py printed on the GPU box: the keys the driver reads, the roofline
+    object (algorithmic bytes / live launch time, agreeing with the rocprofv3 kernel trace and the PMC pass), the CPU baseline, and
+    (r03) the host-input and through-the-element rates beside the HBM-resident one."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_1080p_ippp.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_1080p_ippp.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in d, k
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "u8"
@@ -180,3 +181,9 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["idr_in_timed_region"] == d["steps"] // d["config"]["gop"] and d["config"]["h2d_in_timed_region"] is False  # whole GOPs in the timed region ...
     assert abs(d["gop_weighted_frames_per_s"] - d["value"]) < 0.01 * d["value"]          # ... so the GOP-weighted rate is the headline itself
     assert d["psnr_db"]["pictures"] >= 60 and d["psnr_db"]["y"] > 30.0                 # mean over all pictures of two GOPs at the 6 Mbit/s setpoint
+    for k in ("host_input_depth2_frames_per_s", "host_pinned_input_depth2_frames_per_s", "gst_frames_per_s", "gst_appsrc_frames_per_s"):
+        assert d[k] and 0 < d[k] < 1.05 * d["value"], k                                # PCIe / the element in the loop: never more than the HBM-resident rate
+    assert d["device_wait_recoveries"] == 0 and d["safe_level"] == 0
+    for wl in ("2160p_ippp", "1080p_intra"):                                           # configs[3] and [1]: PMC traffic attached as well
+        o = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_%s.json" % wl)))
+        assert o["roofline"]["traffic"] and o["config"]["workload"] == wl
