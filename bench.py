@@ -198,6 +198,8 @@ def main():
     ap.add_argument("--depth", type=int, default=2, help="pipeline_depth: pictures in flight - 1 (2: the device never waits for the host)")
     ap.add_argument("--deblock-mode", type=int, default=0)
     ap.add_argument("--shared-gpu", action="store_true", help="other processes encode on the same GPU: do not set exclusive_device (include/mi355enc.h); the default is the metric's one stream per GPU")
+    ap.add_argument("--sample-in-order", action="store_true", help="sampled P pictures run their stages strictly in order (every timer is one kernel alone; such a picture costs "
+                    "the stream about two periods) instead of keeping the free-running schedule (timers then include what a launch waits for on the device, as a kernel trace shows it)")
     ap.add_argument("--sample", type=int, default=29, help="stage timers (HIP events) on every k-th picture (and every IDR): a sampled picture costs ~12 event records of ~5 us queue time each and runs its stages strictly in order (no deblocking beside the intra macroblocks of a P picture)")
     ap.add_argument("--streams-per-gpu", type=int, default=1, help="independent streams encoded concurrently on each GPU (one host thread each); the headline configuration is 1")
     ap.add_argument("--cavlc-threads", type=int, default=0, help="host threads coding one slice row-parallel (bit-identical output); 0 = the encoder's default (automatic, at most 8)")
@@ -273,7 +275,7 @@ def main():
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                          pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                         transform8x8=bool(args.dct8x8), cavlc_threads=args.cavlc_threads, exclusive=(S == 1 and not shared_gpu), single_stream=(S > 2))
+                         transform8x8=bool(args.dct8x8), cavlc_threads=args.cavlc_threads, exclusive=(S == 1 and not shared_gpu), single_stream=(S > 2), profile_overlap=not args.sample_in_order)
 
     encs = [make_encoder() for _ in range(S)]
     e = encs[0]
@@ -533,6 +535,10 @@ def main():
                        "rank0_cpus": rank_cpus if world > 1 else None, "rank0_numa_node": int(os.environ.get("MI355_BENCH_NUMA_NODE", "-1")), "dct8x8": bool(args.dct8x8), "cavlc_threads": int(st.cavlc_threads)},
             "roofline": roof,
             "roofline_kernels": kernels,
+            "stage_timers": ("HIP events on every %d-th P picture, on the streams the kernels are launched on" % args.sample) + (
+                "; the sampled picture runs its stages strictly in order (every timer is one kernel alone)" if args.sample_in_order else
+                "; the sampled picture keeps the free-running schedule: a launch that waits on the device for another kernel's rows (the gated P stage, the deblocking launch) "
+                "is timed with that wait, as the rocprofv3 kernel trace shows it") + "; IDR pictures: every other one, in order",
             "stage_ms_per_picture": {"me": round(st.ms_me / max(1, st.n_me), 4), "me_select_x3": round(st.ms_select / max(1, st.n_me), 4),
                                      ("p_stage_total" if fused else "inter"): round(st.ms_inter / max(1, st.n_inter), 4),
                                      "p_intra_analyse_gated": round(st.ms_analyse_p / max(1, st.n_inter), 4), "p_intra_macroblocks": round(st.ms_intra_p / max(1, st.n_inter), 4),

@@ -665,3 +665,33 @@ def test_gated_p_stage_gives_the_in_order_stream_under_rate_control(E):
     for k in (1, 2):
         diff = next((i for i, (a, b) in enumerate(zip(digests[0], digests[k])) if a != b), None)
         assert diff is None, ("first differing access unit", diff, "run", k)
+
+
+def test_stage_timers_on_the_free_running_schedule_change_nothing(E):
+    """profile_overlap: sampled P pictures keep the overlapped schedule (event pairs on the streams the kernels are launched on; the gated P stage and the
+    deblocking launch are timed with their device-side waits).  The stream is the same bytes as without any timer and as with in-order sampling, and
+    every sampled picture delivered its timers."""
+    import hashlib
+    from ceracoder_amd import synth
+    w, h, n = 1920, 1080, 150
+    clip = list(synth.s2_frames(w, h, 16))
+    digests, stats = [], []
+    for events, overlap in ((0, False), (5, True), (5, False)):
+        e = E.Encoder(w, h, fps=60, gop=60, bitrate_bps=6_000_000, pipeline_depth=2, exclusive=True, profile_events=events, profile_overlap=overlap)
+        out = []
+        for i in range(n):
+            k = i % 30
+            y, uv = clip[k if k < 16 else 30 - k]
+            e.submit(y, uv, pts=i)
+            if e.pending > 2:
+                out.append(bytes(e.collect()[0]))
+        while e.pending:
+            out.append(bytes(e.collect()[0]))
+        st = e.stats()
+        stats.append((int(st.n_me), int(st.n_deblock), st.ms_me, st.ms_deblock, int(st.recoveries)))
+        e.close()
+        digests.append([hashlib.sha256(x).hexdigest()[:12] for x in out])
+    assert digests[1] == digests[0] and digests[2] == digests[0]
+    assert stats[0][:2] == (0, 0) and all(s[4] == 0 for s in stats)
+    for n_me, n_db, ms_me, ms_db, _ in stats[1:]:
+        assert n_me >= 25 and n_db >= n_me and 0.02 < ms_me / n_me < 0.5 and 0.05 < ms_db / n_db < 1.5, stats
