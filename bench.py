@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pictures kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gst-latency", action="store_true", help="skip the live GStreamer latency probe (M2)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed host-input / latency / IDR-probe legs as well (for kernel traces: the trace then holds the timed "
+                    "region's schedule, its warm-up and the quality pass only)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--fixed-qp", type=int, default=-1)
     ap.add_argument("--depth", type=int, default=2, help="pipeline_depth: pictures in flight - 1 (2: the device never waits for the host)")
@@ -343,67 +345,68 @@ def main():
         extra["psnr_db"] = {"y": round(float(pm[0]), 2), "u": round(float(pm[1]), 2), "v": round(float(pm[2]), 2), "pictures": nq,
                             "bitrate_bps": round(qbytes * 8 * fps / nq), "min_y": round(float(np.min(np.array(ps)[:, 0])), 2),
                             "note": "mean over all pictures of an untimed pass (two GOPs, same clip, same rate control); encoder reconstruction vs source"}
-        # (2) per-picture latency of the synchronous path an element in a live graph uses (pipeline_depth 0):
-        # host NV12 in -> H2D -> kernels -> D2H -> CAVLC -> access unit out, PCIe included.
-        lat_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads,
-                            exclusive=not shared_gpu)
-        def lat_run(n, gap_s):
-            v = []
-            for i in range(n):
-                f = frames_np[bounce(i, args.unique)]
-                if gap_s:
-                    time.sleep(gap_s)
-                t0 = time.perf_counter()
-                lat_enc.encode(f[:height], f[height:], pts=i)
-                v.append((time.perf_counter() - t0) * 1e3)
-            return np.sort(np.array(v[30:]))
-        lat = lat_run(150, 0.0)         # back to back: a picture queues behind the deblocking of the one before (throughput-bound)
-        live = lat_run(120, 1.0 / fps)  # paced like a live source at the workload's frame rate: the device is idle when a picture arrives
-        lat_enc.close()
-        extra["latency_ms"] = {"p50": round(float(live[len(live) // 2]), 3), "p95": round(float(live[int(len(live) * 0.95)]), 3),
-                               "p50_back_to_back": round(float(lat[len(lat) // 2]), 3), "p95_back_to_back": round(float(lat[int(len(lat) * 0.95)]), 3),
-                               "path": "pipeline_depth=0: host NV12 -> H2D -> GPU -> D2H -> host CAVLC -> AU (the element's handle_frame), pictures arriving at "
-                                       "%d fps (p50/p95) or back to back; appsink->SRT segment not measurable here (no libsrt / mpegtsmux in the image)" % fps,
-                               "host_input_frames_per_s": round(1e3 / float(lat.mean()), 1)}
+        if not args.no_extras:
+            # (2) per-picture latency of the synchronous path an element in a live graph uses (pipeline_depth 0):
+            # host NV12 in -> H2D -> kernels -> D2H -> CAVLC -> access unit out, PCIe included.
+            lat_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads,
+                                exclusive=not shared_gpu)
+            def lat_run(n, gap_s):
+                v = []
+                for i in range(n):
+                    f = frames_np[bounce(i, args.unique)]
+                    if gap_s:
+                        time.sleep(gap_s)
+                    t0 = time.perf_counter()
+                    lat_enc.encode(f[:height], f[height:], pts=i)
+                    v.append((time.perf_counter() - t0) * 1e3)
+                return np.sort(np.array(v[30:]))
+            lat = lat_run(150, 0.0)         # back to back: a picture queues behind the deblocking of the one before (throughput-bound)
+            live = lat_run(120, 1.0 / fps)  # paced like a live source at the workload's frame rate: the device is idle when a picture arrives
+            lat_enc.close()
+            extra["latency_ms"] = {"p50": round(float(live[len(live) // 2]), 3), "p95": round(float(live[int(len(live) * 0.95)]), 3),
+                                   "p50_back_to_back": round(float(lat[len(lat) // 2]), 3), "p95_back_to_back": round(float(lat[int(len(lat) * 0.95)]), 3),
+                                   "path": "pipeline_depth=0: host NV12 -> H2D -> GPU -> D2H -> host CAVLC -> AU (the element's handle_frame), pictures arriving at "
+                                           "%d fps (p50/p95) or back to back; appsink->SRT segment not measurable here (no libsrt / mpegtsmux in the image)" % fps,
+                                   "host_input_frames_per_s": round(1e3 / float(lat.mean()), 1)}
 
-        # (3) host input with three pictures in flight (pipeline_depth 2), through mi355enc_submit: from ordinary (pageable) memory -- one
-        # staging pass of the calling thread per picture, then an asynchronous transfer beside the kernels -- and from memory obtained with
-        # mi355enc_host_alloc (what the element offers its upstream through the ALLOCATION query): transferred in place.  PCIe included.
-        def host_run(src_frames, n):
-            he = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=2, cavlc_threads=args.cavlc_threads,
-                           exclusive=not shared_gpu)
-            def go(k, first):
-                for i in range(k):
-                    f = src_frames[bounce(first + i, len(src_frames))]
-                    he.submit(f[:height], f[height:], pts=first + i)
-                    if he.pending > 2:
+            # (3) host input with three pictures in flight (pipeline_depth 2), through mi355enc_submit: from ordinary (pageable) memory -- one
+            # staging pass of the calling thread per picture, then an asynchronous transfer beside the kernels -- and from memory obtained with
+            # mi355enc_host_alloc (what the element offers its upstream through the ALLOCATION query): transferred in place.  PCIe included.
+            def host_run(src_frames, n):
+                he = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=2, cavlc_threads=args.cavlc_threads,
+                               exclusive=not shared_gpu)
+                def go(k, first):
+                    for i in range(k):
+                        f = src_frames[bounce(first + i, len(src_frames))]
+                        he.submit(f[:height], f[height:], pts=first + i)
+                        if he.pending > 2:
+                            he.collect(copy=False)
+                    while he.pending:
                         he.collect(copy=False)
-                while he.pending:
-                    he.collect(copy=False)
-            go(gop + 10, 0)  # warm-up: first GOP
-            t0 = time.perf_counter()
-            go(n, gop + 10)
-            dt_h = time.perf_counter() - t0
-            pinned = int(he.stats().pinned_inputs)
-            he.close()
-            return n / dt_h, pinned
-        n_host = min(args.steps, 300) if args.steps >= 60 else 120
-        r_page, _ = host_run(frames_np, n_host)
-        extra["host_input_depth2_frames_per_s"] = round(r_page, 1)
-        try:
-            nu = min(args.unique, 16)
-            pin = E.PinnedBuffer(nu * frames_np[0].nbytes)
-            pframes = pin.array.reshape((nu,) + frames_np[0].shape)
-            pframes[:] = frames_np[:nu]
-            r_pin, n_pinned = host_run(pframes, n_host)
-            extra["host_pinned_input_depth2_frames_per_s"] = round(r_pin, 1)
-            extra["host_input_note"] = ("mi355enc_submit from host memory, pipeline_depth 2, PCIe in the loop, %d pictures after a warm-up GOP: pageable numpy planes "
-                                        "(staged once by the calling thread) / planes in mi355enc_host_alloc memory (%d of them transferred in place)" % (n_host, n_pinned))
-            del pframes
-            pin.free()
-        except E.EncoderError as ex:
-            extra["host_pinned_input_depth2_frames_per_s"] = None
-            extra["host_input_note"] = "pinned leg failed: %s" % ex
+                go(gop + 10, 0)  # warm-up: first GOP
+                t0 = time.perf_counter()
+                go(n, gop + 10)
+                dt_h = time.perf_counter() - t0
+                pinned = int(he.stats().pinned_inputs)
+                he.close()
+                return n / dt_h, pinned
+            n_host = min(args.steps, 300) if args.steps >= 60 else 120
+            r_page, _ = host_run(frames_np, n_host)
+            extra["host_input_depth2_frames_per_s"] = round(r_page, 1)
+            try:
+                nu = min(args.unique, 16)
+                pin = E.PinnedBuffer(nu * frames_np[0].nbytes)
+                pframes = pin.array.reshape((nu,) + frames_np[0].shape)
+                pframes[:] = frames_np[:nu]
+                r_pin, n_pinned = host_run(pframes, n_host)
+                extra["host_pinned_input_depth2_frames_per_s"] = round(r_pin, 1)
+                extra["host_input_note"] = ("mi355enc_submit from host memory, pipeline_depth 2, PCIe in the loop, %d pictures after a warm-up GOP: pageable numpy planes "
+                                            "(staged once by the calling thread) / planes in mi355enc_host_alloc memory (%d of them transferred in place)" % (n_host, n_pinned))
+                del pframes
+                pin.free()
+            except E.EncoderError as ex:
+                extra["host_pinned_input_depth2_frames_per_s"] = None
+                extra["host_input_note"] = "pinned leg failed: %s" % ex
         # (4) an IDR picture's device time at this run's operating point, for the GOP-weighted rate of a timed region that holds no IDR picture
         # (the driver's --steps 20): fixed QP = the timed region's mean, stage timers on, a forced IDR picture every third picture.
         idr_probe = None

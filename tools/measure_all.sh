@@ -11,11 +11,11 @@ mkdir -p gpurun_out/final/profiles
 prof() { # workload, extra bench args
   wl=$1; shift
   cd /tmp && export TMPDIR=/tmp
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/final/ks_$wl -o ks -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-gst-latency "$@" > $R/gpurun_out/final/ks_$wl.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/final/ks_$wl -o ks -- python3 $R/bench.py --workload $wl --no-cpu-baseline --no-gst-latency --no-extras "$@" > $R/gpurun_out/final/ks_$wl.log 2>&1
   echo "kernel stats $wl done"
-  MI355ENC_SERIAL=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_f_$wl -o f -- python3 $R/bench.py --workload $wl --steps 120 --warmup 20 --no-cpu-baseline --no-gst-latency "$@" > $R/gpurun_out/final/pmc_f_$wl.log 2>&1
+  MI355ENC_SERIAL=1 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_f_$wl -o f -- python3 $R/bench.py --workload $wl --steps 120 --warmup 20 --no-cpu-baseline --no-extras --no-gst-latency "$@" > $R/gpurun_out/final/pmc_f_$wl.log 2>&1
   echo "pmc fetch $wl done"
-  MI355ENC_SERIAL=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_w_$wl -o w -- python3 $R/bench.py --workload $wl --steps 120 --warmup 20 --no-cpu-baseline --no-gst-latency "$@" > $R/gpurun_out/final/pmc_w_$wl.log 2>&1
+  MI355ENC_SERIAL=1 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/final/pmc_w_$wl -o w -- python3 $R/bench.py --workload $wl --steps 120 --warmup 20 --no-cpu-baseline --no-extras --no-gst-latency "$@" > $R/gpurun_out/final/pmc_w_$wl.log 2>&1
   echo "pmc write $wl done"
   cd $R
   python tools/pmc_summary.py $RND $wl gpurun_out/final/ks_$wl/ks_results.db gpurun_out/final/pmc_f_$wl gpurun_out/final/pmc_w_$wl > gpurun_out/final/pmc_summary_$wl.log 2>&1

@@ -55,8 +55,8 @@ for k in sorted(set(F) | set(W)):
         e["kernel_trace_calls"] = calls
     kern[k] = e
 doc = {"round": int(rnd), "workload": workload,
-       "commands": {"kernel_stats": "cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d … -- python3 bench.py --no-cpu-baseline  (rocpd database, summarised by tools/rocpd_summary.py)",
-                    "pmc": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --steps 120 --warmup 20 --no-cpu-baseline ; the same with --pmc WRITE_SIZE (two separate passes, no other trace domains)"},
+       "commands": {"kernel_stats": "cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d … -- python3 bench.py --workload W --no-cpu-baseline --no-gst-latency --no-extras  (rocpd database, summarised by tools/rocpd_summary.py)",
+                    "pmc": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --workload W --steps 120 --warmup 20 --no-cpu-baseline --no-gst-latency --no-extras ; the same with --pmc WRITE_SIZE (two separate passes, no other trace domains)"},
        "units": "counter values are KB; bytes = value*1024. On gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM), so hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; Infinity-Cache hits are counted, so this is memory-side traffic, not strictly HBM",
        "kernels": kern}
 out = os.path.join(root, "profiles", "r%02d_pmc_hbm_traffic_%s.json" % (int(rnd), workload))
