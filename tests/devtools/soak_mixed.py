@@ -27,7 +27,7 @@ for name, clip in scenes:
         e.submit(y, uv, pts=n)
         n += 1
         if e.pending > depth:
-            take()
+            y_d, uv_d = take()
     while e.pending:
         y_d, uv_d = take()
     assert np.array_equal(y_d, e.fetch(E.FETCH_RECON_Y)) and np.array_equal(uv_d, e.fetch(E.FETCH_RECON_UV)), "drift at the end of scene '%s'" % name
