@@ -236,6 +236,11 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         h->wk_on = true;
         h->wk = std::thread(entropy_worker, h);
     }
+    h->stg_n = h->stg_next = h->stg_done = h->stg_err = 0; h->stg_gen = 0; h->stg_stop = false; h->stg_on = false;
+    if (h->cfg.pipeline_depth >= 1 && !getenv("MI355ENC_NO_STAGE_THREADS")) {
+        h->stg_on = true;
+        for (auto &t : h->stg_th) t = std::thread(stage_helper, h);
+    }
     return MI355ENC_OK;
 }
 
@@ -246,6 +251,12 @@ void mi355enc_close(mi355enc_t *h) {
         h->wk_cv.notify_all();
         h->wk.join();
         h->wk_on = false;
+    }
+    if (h->stg_on) {
+        { std::lock_guard<std::mutex> g(h->stg_mu); h->stg_stop = true; }
+        h->stg_cv.notify_all();
+        for (auto &t : h->stg_th) t.join();
+        h->stg_on = false;
     }
     g_open_encoders.fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(h->cfg.device_id);

@@ -139,7 +139,18 @@ struct mi355enc {
     int wk_q[NSLOT + 1], wk_qh, wk_qt;
     bool wk_stop, wk_on;
     size_t au_cap;
+    // staging helpers (pageable host input at pipeline_depth >= 1): the pieces of a picture are copied into the slot's pinned buffer by the caller and
+    // two helper threads side by side, each piece transferred as soon as it is staged; submit() returns when all of them are on their way
+    struct stage_job { const uint8_t *src; uint8_t *dst, *dev; int src_stride, rows, width; size_t dst_stride; };
+    std::thread stg_th[2];
+    std::mutex stg_mu;
+    std::condition_variable stg_cv, stg_done_cv;
+    stage_job stg_job[8];
+    int stg_n, stg_next, stg_done, stg_err;
+    unsigned long long stg_gen;
+    bool stg_stop, stg_on;
 };
+void stage_helper(mi355enc_t *h);
 
 static inline double now_ms() {
     using namespace std::chrono;

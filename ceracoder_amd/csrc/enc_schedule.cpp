@@ -401,6 +401,33 @@ static int recover(mi355enc_t *h, unsigned code) {
     return MI355ENC_OK;
 }
 
+// one piece of a pageable source picture: into the pinned staging buffer, then on its way to the device
+static int stage_piece(mi355enc_t *h, const mi355enc::stage_job &j, hipStream_t up) {
+    if (j.src_stride == (int)j.dst_stride) memcpy(j.dst, j.src, j.dst_stride * (size_t)(j.rows - 1) + (size_t)j.width);
+    else for (int r = 0; r < j.rows; r++) memcpy(j.dst + (size_t)r * j.dst_stride, j.src + (size_t)r * j.src_stride, (size_t)j.width);
+    return hipMemcpyAsync(j.dev, j.dst, j.dst_stride * (size_t)(j.rows - 1) + (size_t)j.width, hipMemcpyHostToDevice, up) == hipSuccess ? 0 : 1;
+}
+void stage_helper(mi355enc_t *h) {
+    (void)hipSetDevice(h->cfg.device_id);
+    unsigned long long seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> g(h->stg_mu);
+            h->stg_cv.wait(g, [&] { return h->stg_stop || (h->stg_gen != seen && h->stg_next < h->stg_n); });
+            if (h->stg_stop) return;
+        }
+        const hipStream_t up = upload_stream(h);
+        for (;;) {
+            int i;
+            { std::lock_guard<std::mutex> g(h->stg_mu); seen = h->stg_gen; i = h->stg_next < h->stg_n ? h->stg_next++ : -1; }
+            if (i < 0) break;
+            const int e = stage_piece(h, h->stg_job[i], up);
+            bool last;
+            { std::lock_guard<std::mutex> g(h->stg_mu); if (e) h->stg_err = e; last = ++h->stg_done >= h->stg_n; }
+            if (last) h->stg_done_cv.notify_all();
+        }
+    }
+}
 extern "C" {
 
 // Host input.  A picture in memory from mi355enc_host_alloc() is DMA'd from where it lies (the call returns at once; the memory is the
@@ -425,19 +452,34 @@ int mi355enc_submit(mi355enc_t *h, const uint8_t *y, int y_stride, const uint8_t
         h->st.pinned_inputs += pinned ? 1 : 0;
     } else {
         if (!s->h_src) HIPCHK(hipHostMalloc((void **)&s->h_src, h->ysz + h->csz, hipHostMallocDefault));
-        // rows at the coded stride, so that a range of rows is one contiguous transfer; in four pieces (three of luma, the chroma plane), each
-        // sent as soon as it is staged: the transfer of one piece runs beside the staging of the next
+        // rows at the coded stride, so that a range of rows is one contiguous transfer; in pieces (luma thirds or sixths, the chroma plane in one or two), each
+        // sent as soon as it is staged: the transfer of one piece runs beside the staging of the next, and with the helper threads three pieces are
+        // staged side by side (a single thread copies 3.1 MB in 0.15-0.2 ms, as long as the device needs for the whole picture)
         uint8_t *hy = s->h_src, *huv = s->h_src + (size_t)h->W * ht;
-        for (int k = 0; k < 3; k++) {
-            const int r0 = (ht * k / 3) & ~1, r1 = k == 2 ? ht : (ht * (k + 1) / 3) & ~1;
-            if (r1 <= r0) continue;
-            if (y_stride == h->W) memcpy(hy + (size_t)r0 * h->W, y + (size_t)r0 * y_stride, (size_t)h->W * (r1 - r0 - 1) + w);
-            else for (int r = r0; r < r1; r++) memcpy(hy + (size_t)r * h->W, y + (size_t)r * y_stride, (size_t)w);
-            HIPCHK(hipMemcpyAsync(s->d_src_y + (size_t)r0 * h->W, hy + (size_t)r0 * h->W, (size_t)h->W * (r1 - r0 - 1) + w, hipMemcpyHostToDevice, up));
+        mi355enc::stage_job jobs[8];
+        int nj = 0;
+        const int ny = h->stg_on ? 6 : 3, nc = h->stg_on ? 2 : 1;
+        for (int k = 0; k < ny; k++) {
+            const int r0 = (ht * k / ny) & ~1, r1 = k == ny - 1 ? ht : (ht * (k + 1) / ny) & ~1;
+            if (r1 > r0) jobs[nj++] = {y + (size_t)r0 * y_stride, hy + (size_t)r0 * h->W, s->d_src_y + (size_t)r0 * h->W, y_stride, r1 - r0, w, (size_t)h->W};
         }
-        if (uv_stride == h->W) memcpy(huv, uv, (size_t)h->W * (ht / 2 - 1) + w);
-        else for (int r = 0; r < ht / 2; r++) memcpy(huv + (size_t)r * h->W, uv + (size_t)r * uv_stride, (size_t)w);
-        HIPCHK(hipMemcpyAsync(s->d_src_uv, huv, (size_t)h->W * (ht / 2 - 1) + w, hipMemcpyHostToDevice, up));
+        for (int k = 0; k < nc; k++) {
+            const int r0 = (ht / 2) * k / nc, r1 = (ht / 2) * (k + 1) / nc;
+            if (r1 > r0) jobs[nj++] = {uv + (size_t)r0 * uv_stride, huv + (size_t)r0 * h->W, s->d_src_uv + (size_t)r0 * h->W, uv_stride, r1 - r0, w, (size_t)h->W};
+        }
+        if (h->stg_on) {
+            { std::lock_guard<std::mutex> g(h->stg_mu); for (int i = 0; i < nj; i++) h->stg_job[i] = jobs[i]; h->stg_n = nj; h->stg_next = 0; h->stg_done = 0; h->stg_err = 0; h->stg_gen++; }
+            h->stg_cv.notify_all();
+            for (;;) { // the caller takes pieces too
+                int i;
+                { std::lock_guard<std::mutex> g(h->stg_mu); i = h->stg_next < h->stg_n ? h->stg_next++ : -1; }
+                if (i < 0) break;
+                const int e = stage_piece(h, h->stg_job[i], up);
+                { std::lock_guard<std::mutex> g(h->stg_mu); if (e) h->stg_err = e; h->stg_done++; }
+            }
+            { std::unique_lock<std::mutex> g(h->stg_mu); h->stg_done_cv.wait(g, [&] { return h->stg_done >= h->stg_n; }); if (h->stg_err) return MI355ENC_ERR_HIP; }
+        } else
+            for (int i = 0; i < nj; i++) if (stage_piece(h, jobs[i], up)) return MI355ENC_ERR_HIP;
     }
     if (w != h->W) k_launch_pad(s->d_src_y, s->d_src_uv, h->W, w, ht, h->W, h->H, up);
     { int r = upload_done(h, s); if (r) return r; }
