@@ -96,6 +96,7 @@ struct mi355enc {
     unsigned *d_row_done;      // per macroblock row: macroblocks the gated P-stage launches have completed so far (the picture's deblocking launch waits for its rows)
     uint32_t pmb_rows_total;   // ... and what each of those counts reaches with the last gated launch enqueued
     uint32_t db_started_total; // workgroups of all band-deblocking launches so far (the device counts them as they are placed: d_progress[1])
+    uint32_t qpc_total;        // macroblock rows whose QP_Y chain the deblocking launches have resolved so far (adaptive quantisation; the device counts them: d_progress[3])
     uint32_t ip_done_total;    // intra macroblock rows of all fused launches so far (the device counts them as they complete: d_progress[2])
     uint32_t rec_epoch[2]; // ... and the epoch those words carry once the buffer's picture is done (0: no flags for it)
     uint2 *d_db_gran;     // strips between deblocking bands, as epoch-tagged granules (never cleared)

@@ -47,7 +47,8 @@ int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done)
 int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done, unsigned *band_done, bool after_gated_pmb, unsigned row_need, bool fused_ip) {
     if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
         k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, h->cfg.intra_mode == 2 ? k_intra_band_rows() : 1, band_done, h->d_progress + 1, after_gated_pmb ? h->d_row_done : nullptr, row_need ? row_need : h->pmb_rows_total,
-                               fused_ip ? h->d_ip_strips : nullptr, fused_ip ? h->d_progress + 2 : nullptr, st);
+                               fused_ip ? h->d_ip_strips : nullptr, fused_ip ? h->d_progress + 2 : nullptr, h->d_progress + 3, h->qpc_total, st);
+        if (hc->qp_off) h->qpc_total += (uint32_t)h->mbh; // the QP_Y chain rides in the launch and counts the rows it has resolved
         if (fused_ip) h->ip_done_total += (uint32_t)h->mbh;
         h->db_started_total += 2u * (unsigned)k_deblock_bands16(h->mbh);
         HIPCHK(hipGetLastError());
@@ -190,7 +191,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // chain costs 10-17 us).  Not on pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
         // Every kernel-waits-for-kernel overlap below is opt-in (cfg.exclusive_device): next to another process's kernels on the same GPU a
         // kernel that waits on the device for a kernel that has not been placed yet can run into the bound of its wait.
-        const bool may_wait = overlap_allowed(h) && exclusive_device(h) && h->cfg.deblock_mode == 0 && !h->d_pre_y && !(prof && (idr || !h->cfg.profile_overlap)) && !h->cfg.aq_mode; // (adaptive quantisation: the QP_Y chain
+        const bool may_wait = overlap_allowed(h) && exclusive_device(h) && h->cfg.deblock_mode == 0 && !h->d_pre_y && !(prof && (idr || !h->cfg.profile_overlap)) && !(h->cfg.aq_mode && h->cfg.intra_in_p == 2); // (adaptive quantisation: the QP_Y chain
                                                                                                                                                     // over the whole picture sits between a picture's records and its deblocking)
         const int split = !idr && fused && c->intra_p && may_wait;
         // IDR picture: the band deblocker runs on the intra stream BESIDE the intra wavefront, each of its bands waiting for the intra bands
@@ -215,7 +216,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // So consecutive such launches alternate between two streams; a picture whose stages run in order joins both.
         hipStream_t mst = h->stream;
         bool early_db = false;
-        if (prows && !no_db2()) {
+        if (prows && !no_db2() && !c->qp_off) {
             h->db_flip ^= 1;
             if (h->db_flip) {
                 mst = h->cstream;
@@ -237,13 +238,13 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
             // Two launches in flight: this picture's deblocking launch is enqueued FIRST, and the gated P stage behind wait_started_kernel counts
             // it in -- once pmb_kernel's waiting workgroups fill the chip, a launch of 34 workgroups of twelve 112-register waves finds no CU to
             // land on until they drain (device timeline: the launch sat there for 250 us and did its work after pmb_kernel had ended).
-            early_db = prows && !no_db2();
+            early_db = prows && !no_db2() && !c->qp_off;
             if (early_db) { int r = run_deblock(h, ci, c, mst, c->intra_p ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, true, h->pmb_rows_total + (uint32_t)h->mbw, c->intra_p != 0); if (r) return r; }
             int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur], prows, early_db && c->intra_p); if (r) return r;
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
-        if (c->qp_off) k_launch_qp_chain(h->d_mbi_set[set], h->nmb, qp, c->slice_rows * h->mbw, h->stream); // 7.4.5: QP_Y of the macroblocks without mb_qp_delta, for the deblocker (everything runs on the main stream here)
+        if (c->qp_off && h->cfg.deblock_mode != 0) k_launch_qp_chain(h->d_mbi_set[set], h->nmb, qp, c->slice_rows * h->mbw, h->stream); // 7.4.5: QP_Y of the macroblocks without mb_qp_delta, for the deblocker (everything runs on the main stream here)
         HIPCHK(hipEventRecord(s->gpu_done, (split || pgate) ? h->istream : h->stream)); // records and levels are final here; they do not depend on deblocking
         if (h->d_pre_y) {
             HIPCHK(hipMemcpyAsync(h->d_pre_y, h->d_rec_y[nxt], h->ysz, hipMemcpyDeviceToDevice, h->stream));
@@ -260,7 +261,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // Hand-over, enqueued after the deblocking launches so that it cannot be dispatched ahead of them: the device packs the non-zero
         // blocks straight into the pinned host buffer while the band deblocker runs.  On the hand-over stream -- or, where that stream takes
         // every other deblocking launch, on the intra stream right behind intra_p_kernel (records and levels are final there).
-        hipStream_t pst = (prows && !no_db2()) ? h->istream : h->cstream;
+        hipStream_t pst = (prows && !no_db2() && !c->qp_off) ? h->istream : h->cstream;
         if (pst == h->cstream) HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
         k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, err_word(h), pst);
         HIPCHK(hipGetLastError());
@@ -358,6 +359,8 @@ static const char *wait_name(unsigned code) {
     case 15: return "intra_p_kernel waiting for the row above";
     case 16: return "progress counter";
     case 17: return "deblocker waiting for pmb_kernel's rows";
+    case 22: return "QP_Y chain waiting for a macroblock row";
+    case 23: return "deblocker waiting for the QP_Y chain";
     default: return "injected / unknown";
     }
 }
@@ -382,7 +385,7 @@ static int recover(mi355enc_t *h, unsigned code) {
     HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream));
     HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)h->mbh * sizeof(unsigned), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->pmb_rows_total = 0; h->db_started_total = 0; h->ip_done_total = 0; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->dbI_busy[0] = h->dbI_busy[1] = 0;
+    h->pmb_rows_total = 0; h->db_started_total = 0; h->ip_done_total = 0; h->qpc_total = 0; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->dbI_busy[0] = h->dbI_busy[1] = 0;
     if (h->safe_level == 2) { h->cfg.deblock_mode = 1; h->cfg.intra_mode = 1; }
     const int n = h->pending;
     struct { const uint8_t *y, *uv; int stride, force_idr; int64_t pts; } again[NSLOT];

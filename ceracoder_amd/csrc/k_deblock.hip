@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; unsigned *band_done; unsigned *started; const unsigned *row_done; unsigned row_need; int nip; unsigned *ip_progress_w; uint8_t *ip_strips; unsigned *ip_done; }; // nip > 0: the launch's first nip workgroups are the picture's intra macroblock rows (intra_p_row) // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; unsigned *band_done; unsigned *started; const unsigned *row_done; unsigned row_need; int nip; unsigned *ip_progress_w; uint8_t *ip_strips; unsigned *ip_done; unsigned *qpc; unsigned qpc_base; }; // qpc (adaptive quantisation): the launch's first workgroup resolves the QP_Y chain row by row and counts the rows there (qp_chain_rows) // nip > 0: the launch's first nip workgroups are the picture's intra macroblock rows (intra_p_row) // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -410,6 +410,20 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 11u); break; } if ((spins & 1023) == 0 && ld_sc1(a.err)) { break; } // bounded; the host reports the picture as failed
                 }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
+    if (a.qpc) { // adaptive quantisation: the QP_Y chain has passed this band's rows (the row above them was in an earlier batch or is in this one)
+        if (threadIdx.x == 0) {
+            const unsigned need = a.qpc_base + (unsigned)((band + 1) * ROWS < mbh ? (band + 1) * ROWS : mbh);
+            int spins = 0;
+            while ((int)(ld_sc1(a.qpc) - need) < 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 23u | ((unsigned)band << 8)); break; }
+                if ((spins & 1023) == 0 && ld_sc1(a.err)) break;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -723,6 +737,93 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
 #endif
 }
 
+// Adaptive quantisation: the QP_Y of a macroblock that sends no mb_qp_delta is that of the macroblock before it in decoding order (7.4.5), and the
+// filter reads it -- a chain over the whole picture (oracle: orc_qp_chain_slices).  As a kernel of its own between a picture's records and its
+// deblocking launch it put the picture's stages in stream order; here it rides in the deblocking launch as its FIRST workgroup (placed before any
+// band), walks the rows in batches of one row per wave behind the same progress the bands wait for -- pmb_kernel's row counts, the intra rows'
+// flags, or nothing (stream order) -- rewrites the qp byte of the macroblocks without a delta and counts the rows it has resolved; a band starts
+// when the count covers its rows and the row above them.  Intra_16x16 macroblocks always send a delta; an Intra_4x4 macroblock of a P picture does
+// not when it has no coefficients, which is known only after intra_p_kernel: with cfg.intra_in_p = 2 the host keeps the stages in order.
+template <int NW>
+DEV void qp_chain_rows(const db_args &a) {
+    __shared__ int row_last[NW], row_in[NW];
+    const frame_ctx_t *__restrict__ ctx = &a.ctx;
+    const int mbw = ctx->mbw, mbh = ctx->mbh, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned tag = ~ctx->epoch;
+    int carry = ctx->qp; // QP_Y,PRED at the start of a slice: the slice's QP
+    for (int r0 = 0; r0 < mbh; r0 += NW) {
+        const int r = r0 + w;
+        const bool mine = r < mbh;
+        if (mine && lane == 0) { // this wave's row is final: every macroblock counted (P pictures) / its intra band flagged (I pictures)
+            int spins = 0;
+            if (!ctx->all_intra && a.row_done)
+                while ((int)(ld_sc1(a.row_done + r * MI355_PROG_STRIDE) - a.row_need) < 0) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 22u | ((unsigned)r << 8)); break; }
+                    if ((spins & 1023) == 0 && ld_sc1(a.err)) break;
+                }
+            if (ctx->all_intra && a.iband_done)
+                while (ld_sc1(a.iband_done + r / a.ib_rows) != tag) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 22u | ((unsigned)r << 8)); break; }
+                    if ((spins & 1023) == 0 && ld_sc1(a.err)) break;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // pass 1: the last QP that was sent in this row (-1: none)
+        int last = -1;
+        if (mine)
+            for (int x0 = 0; x0 < mbw; x0 += 64) {
+                const int x = x0 + lane;
+                int q = -1;
+                if (x < mbw) { const uint4 rec = ldg128(&ctx->mbi[(size_t)r * mbw + x]); if ((rec.y & 255u) == 0u || (rec.z & 0x07FFFFFFu) != 0u) q = (int)(rec.y >> 24); }
+                const unsigned long long m = __ballot(q >= 0);
+                if (m) last = __shfl(q, 63 - __builtin_clzll(m), 64);
+            }
+        if (lane == 0) row_last[w] = mine ? last : -1;
+        __syncthreads();
+        // the carry into every row of the batch (a slice starts again from the slice's QP)
+        if (threadIdx.x == 0) {
+            int c = carry;
+            for (int k = 0; k < NW; k++) {
+                const int rr = r0 + k;
+                if (ctx->slice_rows > 0 && rr % ctx->slice_rows == 0) c = ctx->qp;
+                row_in[k] = c;
+                if (row_last[k] >= 0) c = row_last[k];
+            }
+            row_last[0] = c; // the carry out of the batch
+        }
+        __syncthreads();
+        // pass 2: every macroblock without a delta takes the QP of the last one before it that sent one
+        if (mine) {
+            int prev = row_in[w];
+            for (int x0 = 0; x0 < mbw; x0 += 64) {
+                const int x = x0 + lane;
+                int q = -1;
+                uint4 rec = make_uint4(0, 0, 0, 0);
+                if (x < mbw) { rec = ldg128(&ctx->mbi[(size_t)r * mbw + x]); if ((rec.y & 255u) == 0u || (rec.z & 0x07FFFFFFu) != 0u) q = (int)(rec.y >> 24); }
+                const unsigned long long m = __ballot(q >= 0);
+                const unsigned long long below = m & ((2ull << lane) - 1ull); // senders at or before this lane
+                const int src = below ? 63 - __builtin_clzll(below) : 0;
+                const int got = __shfl(q, src, 64);
+                const int res = below ? got : prev;
+                if (x < mbw && q < 0) stg32((unsigned *)&ctx->mbi[(size_t)r * mbw + x] + 1, (rec.y & 0x00FFFFFFu) | ((unsigned)res << 24));
+                if (m) prev = __shfl(q, 63 - __builtin_clzll(m), 64);
+            }
+        }
+        carry = row_last[0];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_sc1(a.qpc, a.qpc_base + (unsigned)(r0 + NW < mbh ? r0 + NW : mbh));
+        }
+        __syncthreads();
+    }
+}
+
 // FUSED_IP: the intra macroblocks of the same P picture ride in this launch -- its first a.nip workgroups run intra_p_row (two waves each, the
 // other waves end at once), one macroblock row each, behind the same row counts of pmb_kernel<GATED, ROWS> the bands wait for.  As a kernel of
 // its own intra_p_kernel could only follow pmb_kernel in stream order, i.e. after its LAST row -- and with two deblocking launches in flight the
@@ -733,6 +834,10 @@ template <int ROWS, bool ALL_INTRA, bool GATED, bool FUSED_IP>
 __global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[]; // ROWS rows of tile rings, then three work flags and the rows' first intra macroblocks
     int bi = (int)blockIdx.x, nwg = (int)gridDim.x;
+    if (!FUSED_IP && a.qpc) { // (adaptive quantisation: the QP_Y chain leads the launch)
+        if (bi == 0) { qp_chain_rows<3 * ROWS>(a); return; }
+        bi -= 1; nwg -= 1;
+    }
     if (FUSED_IP) {
         if (bi < a.nip) {
             if (threadIdx.x >= 128) return;
@@ -779,7 +884,7 @@ template <typename K>
 static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStream_t s) {
     constexpr size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + 16 + 4 * DB_ROWS; // the rows' tile rings + three work flags + the rows' first intra macroblocks: ~12.5 KB
     static_assert(lds <= 48 * 1024, "above 48 KB of dynamic LDS every instantiation launched here would need hipFuncAttributeMaxDynamicSharedMemorySize");
-    hipLaunchKernelGGL(kernel, dim3(2 * nbands + (a.nip > 0 ? a.nip : 0)), dim3(192 * DB_ROWS), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3(2 * nbands + (a.nip > 0 ? a.nip : 0) + (a.qpc && a.nip <= 0 ? 1 : 0)), dim3(192 * DB_ROWS), lds, s, a);
 }
 // One wave that ends once `count` workgroups of band-deblocking launches have been placed since the encoder was opened (the count only
 // grows; the comparison is wrap-safe).  On a stream in front of a kernel whose workgroups wait for the deblocker's flags, it keeps
@@ -798,10 +903,11 @@ size_t k_deblock_done_bytes(void) { return (size_t)DB_DONE_COPIES * DB_DONE_STRI
 size_t k_deblock_partab_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * DB_ROWS * mbw * 48 * sizeof(unsigned); } // 32 luma + 16 chroma words per macroblock
 void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
                             const unsigned *d_iband_done, int ib_rows, unsigned *d_band_done, unsigned *d_started, const unsigned *d_row_done, unsigned row_need,
-                            uint8_t *d_ip_strips, unsigned *d_ip_done, hipStream_t s) {
+                            uint8_t *d_ip_strips, unsigned *d_ip_done, unsigned *d_qpc, unsigned qpc_base, hipStream_t s) {
     db_args a;
     a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab; a.iband_done = d_iband_done; a.ib_rows = ib_rows > 0 ? ib_rows : DB_ROWS; a.band_done = d_band_done; a.started = d_started; a.row_done = d_row_done; a.row_need = row_need;
     a.nip = 0; a.ip_progress_w = nullptr; a.ip_strips = nullptr; a.ip_done = nullptr;
+    a.qpc = (h_ctx->qp_off && band0 == 0) ? d_qpc : nullptr; a.qpc_base = qpc_base; // (a launch of all the picture's bands)
     if (band1 <= band0) return;
     if (h_ctx->all_intra) launch_bands(deblock_rows3_kernel<DB_ROWS, true, false, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
     else if (d_ip_progress && d_ip_done && d_row_done && band0 == 0) { // the picture's intra macroblock rows lead the launch (pmb_kernel<GATED, ROWS> of the same picture still runs)

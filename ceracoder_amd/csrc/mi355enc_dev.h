@@ -124,7 +124,8 @@ void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int ba
                             unsigned *d_started /* may be null: counts the workgroups placed */,
                             const unsigned *d_row_done /* may be null: pmb_kernel<GATED> of this picture is still running; per macroblock row, it counts up to row_need */, unsigned row_need,
                             uint8_t *d_ip_strips, unsigned *d_ip_done /* both non-null (with d_ip_progress and d_row_done): the picture's intra macroblock rows run as the launch's
-                                                                            leading workgroups; each counts itself in d_ip_done when its records and levels are in memory */, hipStream_t s);
+                                                                            leading workgroups; each counts itself in d_ip_done when its records and levels are in memory */,
+                            unsigned *d_qpc, unsigned qpc_base /* adaptive quantisation (h_ctx->qp_off): the launch's first workgroup resolves the QP_Y chain and counts the rows in *d_qpc from qpc_base */, hipStream_t s);
 int k_intra_band_rows(void);
 size_t k_deblock_partab_bytes(int mbw, int mbh); // scratch of the band kernel: one parameter word per (edge, segment) of every macroblock
 size_t k_deblock_gran_bytes(int mbw, int mbh);
