@@ -10,7 +10,8 @@
  * byte stream that /root/reference/src/ceracoder.c:297-339 forwards over SRT).
  *
  * Supported: Baseline-style streams -- CAVLC, frame macroblocks, I/P slices (several per
- * picture allowed), I4x4, I16x16, P_L0_16x16, P_Skip, quarter-sample luma motion, one
+ * picture allowed), I4x4, I16x16, P_L0_16x16, P_L0_L0_16x8, P_L0_L0_8x16, P_8x8 with sub_mb_type P_L0_8x8,
+ * P_Skip, quarter-sample luma motion, one
  * reference picture, in-loop filter with all three disable_deblocking_filter_idc values.
  * Anything else sets an error string and returns < 0.
  */
@@ -142,7 +143,9 @@ typedef struct {
     int8_t kind;      /* -1 not decoded, 0 intra, 1 inter */
     int8_t is_i4;     /* intra 4x4 */
     int8_t qp, qpc;
-    int16_t mvx, mvy; /* quarter-sample units */
+    int16_t mvx, mvy; /* quarter-sample units (partition 0) */
+    int16_t qmv[4][2]; /* the vector of each 8x8 quadrant (raster), whatever the partitioning */
+    int8_t part;      /* 0 16x16, 1 16x8, 2 8x16, 3 8x8 */
     int16_t slice;
     uint8_t tc_l[16]; /* TotalCoeff per luma 4x4, raster by*4+bx */
     uint8_t tc_c[2][4];
@@ -570,15 +573,15 @@ static int luma_sample(const orc_dec_t *d, int x, int y, int fx, int fy) {
     if (fx == 2) return fy == 1 ? (b + j + 1) >> 1 : (j + s + 1) >> 1;
     return fx == 1 ? (h + j + 1) >> 1 : (j + m + 1) >> 1; /* fy == 2 */
 }
-static void inter_pred_mb(orc_dec_t *d, int mx, int my, int mvx, int mvy) {
+static void inter_pred_part(orc_dec_t *d, int mx, int my, int x0, int y0, int w, int h, int mvx, int mvy) { /* one partition: luma w x h at (x0, y0) of the macroblock */
     int X = mx * 16, Y = my * 16;
-    for (int y = 0; y < 16; y++)
-        for (int x = 0; x < 16; x++)
+    for (int y = y0; y < y0 + h; y++)
+        for (int x = x0; x < x0 + w; x++)
             DY(d, X + x, Y + y) = (uint8_t)luma_sample(d, X + x + (mvx >> 2), Y + y + (mvy >> 2), mvx & 3, mvy & 3);
     int cw = d->mbw * 8, ch = d->mbh * 8, xf = mvx & 7, yf = mvy & 7;
     for (int c = 0; c < 2; c++)
-        for (int y = 0; y < 8; y++)
-            for (int x = 0; x < 8; x++) {
+        for (int y = y0 / 2; y < (y0 + h) / 2; y++)
+            for (int x = x0 / 2; x < (x0 + w) / 2; x++) {
                 int xa = mx * 8 + x + (mvx >> 3), ya = my * 8 + y + (mvy >> 3), xb = xa + 1, yb = ya + 1;
                 xa = xa < 0 ? 0 : xa >= cw ? cw - 1 : xa; xb = xb < 0 ? 0 : xb >= cw ? cw - 1 : xb;
                 ya = ya < 0 ? 0 : ya >= ch ? ch - 1 : ya; yb = yb < 0 ? 0 : yb >= ch ? ch - 1 : yb;
@@ -587,24 +590,42 @@ static void inter_pred_mb(orc_dec_t *d, int mx, int my, int mvx, int mvy) {
                 DC_(d, mx * 8 + x, my * 8 + y, c) = (uint8_t)(((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6);
             }
 }
-/* 8.4.1.3: neighbour motion data for the 16x16 partition */
-static void nb_mv(const orc_dec_t *d, int mx, int my, int slice, int *avail, int *ref, int *vx, int *vy) {
-    *avail = mb_avail(d, mx, my, slice); *ref = -1; *vx = *vy = 0;
-    if (*avail && d->mb[my * d->mbw + mx].kind == 1) { *ref = 0; *vx = d->mb[my * d->mbw + mx].mvx; *vy = d->mb[my * d->mbw + mx].mvy; }
+static void inter_pred_mb(orc_dec_t *d, int mx, int my, int mvx, int mvy) { inter_pred_part(d, mx, my, 0, 0, 16, 16, mvx, mvy); }
+/* 6.4.11.7 / 8.4.1.3.2: motion data of the 8x8 block that covers luma sample (X, Y) of the picture, as a neighbour of a partition of macroblock
+ * (mx, my) whose quadrants in `done` (bit q) are decoded already.  Macroblocks after the current one in decoding order are not available. */
+static void nb_blk(const orc_dec_t *d, int mx, int my, int slice, unsigned done, int X, int Y, int *avail, int *ref, int *vx, int *vy) {
+    *avail = 0; *ref = -1; *vx = *vy = 0;
+    if (X < 0 || Y < 0 || X >= d->mbw * 16 || Y >= d->mbh * 16) return;
+    const int nx = X >> 4, ny = Y >> 4, q = ((Y & 15) >> 3) * 2 + ((X & 15) >> 3);
+    const dmb_t *n = &d->mb[ny * d->mbw + nx];
+    if (nx == mx && ny == my) { if (!((done >> q) & 1)) return; *avail = 1; *ref = 0; *vx = n->qmv[q][0]; *vy = n->qmv[q][1]; return; }
+    if (!mb_avail(d, nx, ny, slice)) return;
+    *avail = 1;
+    if (n->kind == 1) { *ref = 0; *vx = n->qmv[q][0]; *vy = n->qmv[q][1]; }
 }
 static int med(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
-static void predict_mv(const orc_dec_t *d, int mx, int my, int slice, int skip, int *px, int *py) {
+/* 8.4.1.3 for the partition (x0, y0, w, h) of shape `part` (0 16x16, 1 16x8, 2 8x16, 3 8x8), index idx; skip: 8.4.1.1's inference for P_Skip */
+static void predict_part(const orc_dec_t *d, int mx, int my, int slice, unsigned done, int part, int idx, int x0, int y0, int w, int skip, int *px, int *py) {
+    const int X = mx * 16 + x0, Y = my * 16 + y0;
     int aA, rA, ax, ay, aB, rB, bx, by, aC, rC, cx, cy;
-    nb_mv(d, mx - 1, my, slice, &aA, &rA, &ax, &ay);
-    nb_mv(d, mx, my - 1, slice, &aB, &rB, &bx, &by);
-    nb_mv(d, mx + 1, my - 1, slice, &aC, &rC, &cx, &cy);
-    if (!aC) nb_mv(d, mx - 1, my - 1, slice, &aC, &rC, &cx, &cy);
+    nb_blk(d, mx, my, slice, done, X - 1, Y, &aA, &rA, &ax, &ay);
+    nb_blk(d, mx, my, slice, done, X, Y - 1, &aB, &rB, &bx, &by);
+    nb_blk(d, mx, my, slice, done, X + w, Y - 1, &aC, &rC, &cx, &cy);
+    if (!aC) nb_blk(d, mx, my, slice, done, X - 1, Y - 1, &aC, &rC, &cx, &cy);
     if (skip && (!aA || !aB || (rA == 0 && !ax && !ay) || (rB == 0 && !bx && !by))) { *px = *py = 0; return; }
+    if (part == 1 && idx == 0 && rB == 0) { *px = bx; *py = by; return; } /* directional predictors (refIdx is 0 everywhere) */
+    if (part == 1 && idx == 1 && rA == 0) { *px = ax; *py = ay; return; }
+    if (part == 2 && idx == 0 && rA == 0) { *px = ax; *py = ay; return; }
+    if (part == 2 && idx == 1 && rC == 0) { *px = cx; *py = cy; return; }
     if (!aB && !aC && aA) { rB = rC = rA; bx = cx = ax; by = cy = ay; }
     int hits = (rA == 0) + (rB == 0) + (rC == 0);
     if (hits == 1) {
         if (rA == 0) { *px = ax; *py = ay; } else if (rB == 0) { *px = bx; *py = by; } else { *px = cx; *py = cy; }
     } else { *px = med(ax, bx, cx); *py = med(ay, by, cy); }
+}
+static void predict_mv(const orc_dec_t *d, int mx, int my, int slice, int skip, int *px, int *py) { predict_part(d, mx, my, slice, 0, 0, 0, 0, 0, 16, skip, px, py); }
+static void set_qmv(dmb_t *m, int x0, int y0, int w, int h, int vx, int vy) {
+    for (int q = 0; q < 4; q++) { const int qx = (q & 1) * 8, qy = (q >> 1) * 8; if (qx >= x0 && qx < x0 + w && qy >= y0 && qy < y0 + h) { m->qmv[q][0] = (int16_t)vx; m->qmv[q][1] = (int16_t)vy; } }
 }
 
 /* ---------------------------------------------------------------- macroblock decode */
@@ -672,7 +693,7 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
     if (cl) memset(cl, 0, ORC_LEVELS_PER_MB * sizeof(int16_t));
     if (skipped) {
         int px, py; predict_mv(d, mx, my, slice, 1, &px, &py);
-        m->mvx = (int16_t)px; m->mvy = (int16_t)py;
+        m->mvx = (int16_t)px; m->mvy = (int16_t)py; m->part = 0; set_qmv(m, 0, 0, 16, 16, px, py);
         inter_pred_mb(d, mx, my, px, py);
         m->kind = 1; m->qp = (int8_t)*qp; m->qpc = (int8_t)chroma_qp(d, *qp);
         if (cr) { cr->mb_type = 1; cr->mvx = m->mvx; cr->mvy = m->mvy; cr->qp = (uint8_t)*qp; }
@@ -682,13 +703,25 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
     int intra = 1, i16 = 0, i16mode = 0, cbp = 0, cap_cmode = 0;
     if (is_p) { if (t < 5) intra = 0; else t -= 5; }
     if (!intra) {
-        if (t != 0) return fail(d, "P macroblock type %d unsupported", t);
+        if (t > 3) return fail(d, "P macroblock type %d unsupported", t);
         if (d->num_ref_default > 1) return fail(d, "multiple references unsupported");
-        int px, py; predict_mv(d, mx, my, slice, 0, &px, &py);
-        int dx = rd_se(d), dy = rd_se(d);
-        m->mvx = (int16_t)(px + dx); m->mvy = (int16_t)(py + dy);
-        m->kind = 1;
-        inter_pred_mb(d, mx, my, m->mvx, m->mvy);
+        static const int8_t geo[4][4][4] = { /* shape -> partitions (x0, y0, w, h) */
+            {{0, 0, 16, 16}}, {{0, 0, 16, 8}, {0, 8, 16, 8}}, {{0, 0, 8, 16}, {8, 0, 8, 16}}, {{0, 0, 8, 8}, {8, 0, 8, 8}, {0, 8, 8, 8}, {8, 8, 8, 8}}};
+        const int np = t == 0 ? 1 : t == 3 ? 4 : 2;
+        if (t == 3) for (int i = 0; i < 4; i++) if (rd_ue(d) != 0) return fail(d, "sub_mb_type other than P_L0_8x8 unsupported");
+        m->part = (int8_t)t; m->kind = 1; /* (neighbour derivation inside the macroblock goes by `done`) */
+        unsigned done = 0;
+        int pv[4][2];
+        for (int i = 0; i < np; i++) { /* 7.3.5.1 / 7.3.5.2: the vector differences of the partitions in order (ref_idx is not sent: one reference) */
+            const int8_t *g = geo[t][i];
+            int px, py; predict_part(d, mx, my, slice, done, t, i, g[0], g[1], g[2], 0, &px, &py);
+            int dx = rd_se(d), dy = rd_se(d);
+            pv[i][0] = px + dx; pv[i][1] = py + dy;
+            set_qmv(m, g[0], g[1], g[2], g[3], pv[i][0], pv[i][1]);
+            for (int q = 0; q < 4; q++) { const int qx = (q & 1) * 8, qy = (q >> 1) * 8; if (qx >= g[0] && qx < g[0] + g[2] && qy >= g[1] && qy < g[1] + g[3]) done |= 1u << q; }
+        }
+        m->mvx = (int16_t)pv[0][0]; m->mvy = (int16_t)pv[0][1];
+        for (int i = 0; i < np; i++) { const int8_t *g = geo[t][i]; inter_pred_part(d, mx, my, g[0], g[1], g[2], g[3], pv[i][0], pv[i][1]); }
         unsigned k = rd_ue(d); if (k > 47) return fail(d, "cbp codeNum %u", k);
         cbp = D_cbp_inter[k];
         if (d->t8_mode && (cbp & 15)) m->t8 = (int8_t)rd_bit(d);
@@ -861,7 +894,8 @@ static void edge_filter(uint8_t *s, ptrdiff_t across, int bS, int qpav, int off_
 static int strength(const dmb_t *P, int pi, const dmb_t *Q, int qi, int mbedge) { /* pi, qi: raster 4x4 index */
     if (P->kind == 0 || Q->kind == 0) return mbedge ? 4 : 3;
     if (((P->coded >> pi) & 1) || ((Q->coded >> qi) & 1)) return 2;
-    if (abs(P->mvx - Q->mvx) >= 4 || abs(P->mvy - Q->mvy) >= 4) return 1;
+    const int pq = ((pi >> 2) >> 1) * 2 + ((pi & 3) >> 1), qq = ((qi >> 2) >> 1) * 2 + ((qi & 3) >> 1); /* the 8x8 quadrants of the two blocks */
+    if (abs(P->qmv[pq][0] - Q->qmv[qq][0]) >= 4 || abs(P->qmv[pq][1] - Q->qmv[qq][1]) >= 4) return 1;
     return 0;
 }
 static void deblock_picture(orc_dec_t *d) {

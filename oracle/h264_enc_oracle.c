@@ -1219,6 +1219,97 @@ static void chroma_pred8(const uint8_t *ref_uv, uint8_t *rec_uv, int stride, int
             }
 }
 
+/* ---- inter partitions (ORC_F_PART; encoder choice, oracle-side groundwork: the device does not produce them yet).
+ * Record: an inter macroblock's i16_mode holds its shape (0 16x16, 1 16x8, 2 8x16, 3 8x8); mvx / mvy are partition 0's vector, the vectors of partitions
+ * 1 .. 3 lie in the (otherwise unused) luma-DC slot of its levels, lev[ORC_L_LDC + 2 (idx - 1) + {0, 1}].
+ * Search: around the macroblock's refined 16x16 vector every partition tries the whole-sample offsets -2 .. +2 (SAD against the reference + lambda * bits
+ * against the same predictor estimate as the 16x16 search) and then the same two sub-sample rounds as the macroblock (half-sample SAD, quarter-sample SATD);
+ * a shape is taken when its partitions' final SAD costs plus lambda * (its mb_type / sub_mb_type bits) is strictly below the 16x16 cost + lambda. */
+static const int8_t k_part_geo[4][4][4] = {{{0, 0, 16, 16}}, {{0, 0, 16, 8}, {0, 8, 16, 8}}, {{0, 0, 8, 16}, {8, 0, 8, 16}}, {{0, 0, 8, 8}, {8, 0, 8, 8}, {0, 8, 8, 8}, {8, 8, 8, 8}}};
+static const int8_t k_part_n[4] = {1, 2, 2, 4}, k_part_hdr_bits[4] = {1, 3, 3, 9}; /* ue(mb_type) (+ four ue(0) sub_mb_type) */
+static const int16_t *g_part_lev; /* levels of the picture being filtered / written: where the partitions' vectors lie (NULL: 16x16 only) */
+void orc_set_part_levels(const int16_t *levels) { g_part_lev = levels; }
+static inline int mb_part(const orc_mbinfo_t *m) { return (g_part_lev && m->mb_type == 1) ? (m->i16_mode & 3) : 0; }
+static void mb_qmv(const orc_mbinfo_t *mbi, int mbn, int q, int *vx, int *vy) { /* the vector of 8x8 quadrant q (raster) of an inter macroblock */
+    const orc_mbinfo_t *m = &mbi[mbn];
+    const int part = mb_part(m), idx = part == 0 ? 0 : part == 1 ? (q >> 1) : part == 2 ? (q & 1) : q;
+    if (idx == 0) { *vx = m->mvx; *vy = m->mvy; }
+    else { const int16_t *l = g_part_lev + (size_t)mbn * ORC_LEVELS_PER_MB + ORC_L_LDC + 2 * (idx - 1); *vx = l[0]; *vy = l[1]; }
+}
+static void luma_pred_part(const uint8_t *ref_y, int stride, int W, int H, int X, int Y, int w, int h, int qx, int qy, uint8_t *pred /* stride 16, at (0,0) */) {
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) pred[y * 16 + x] = (uint8_t)luma_qpel(ref_y, stride, W, H, X + x + (qx >> 2), Y + y + (qy >> 2), qx & 3, qy & 3);
+}
+static uint32_t sad_part(const uint8_t *src, int stride, const uint8_t *pred, int w, int h) {
+    uint32_t s = 0;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) s += (uint32_t)iabs(src[(size_t)y * stride + x] - pred[y * 16 + x]);
+    return s;
+}
+static uint32_t satd_part(const uint8_t *src, int stride, const uint8_t *pred, int w, int h) { /* as orc_satd16, over the partition's 4x4 blocks */
+    uint32_t total = 0;
+    for (int by = 0; by < h; by += 4)
+        for (int bx = 0; bx < w; bx += 4) {
+            int d[16], t[16];
+            for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) d[y * 4 + x] = src[(size_t)(by + y) * stride + bx + x] - pred[(by + y) * 16 + bx + x];
+            for (int i = 0; i < 4; i++) {
+                int a = d[i * 4] + d[i * 4 + 3], b = d[i * 4 + 1] + d[i * 4 + 2], c = d[i * 4 + 1] - d[i * 4 + 2], e = d[i * 4] - d[i * 4 + 3];
+                t[i * 4] = a + b; t[i * 4 + 1] = e + c; t[i * 4 + 2] = a - b; t[i * 4 + 3] = e - c;
+            }
+            for (int j = 0; j < 4; j++) {
+                int a = t[j] + t[12 + j], b = t[4 + j] + t[8 + j], c = t[4 + j] - t[8 + j], e = t[j] - t[12 + j];
+                total += (uint32_t)(iabs(a + b) + iabs(e + c) + iabs(a - b) + iabs(e - c));
+            }
+        }
+    return total >> 1;
+}
+static void chroma_pred_part(const uint8_t *ref_uv, uint8_t *rec_uv, int stride, int W, int H, int x0, int y0, int px0, int py0, int w, int h, int mvx, int mvy) {
+    int cw = W / 2, ch = H / 2, cx0 = x0 / 2, cy0 = y0 / 2;
+    int xi = mvx >> 3, yi = mvy >> 3, xf = mvx & 7, yf = mvy & 7;
+    for (int c = 0; c < 2; c++)
+        for (int y = py0 / 2; y < (py0 + h) / 2; y++)
+            for (int x = px0 / 2; x < (px0 + w) / 2; x++) {
+                int ax = CLIP3(0, cw - 1, cx0 + x + xi), bx = CLIP3(0, cw - 1, cx0 + x + xi + 1);
+                int ay = CLIP3(0, ch - 1, cy0 + y + yi), cy = CLIP3(0, ch - 1, cy0 + y + yi + 1);
+                int A = UV(ref_uv, stride, ax, ay, c), B = UV(ref_uv, stride, bx, ay, c);
+                int C = UV(ref_uv, stride, ax, cy, c), D = UV(ref_uv, stride, bx, cy, c);
+                UV(rec_uv, stride, cx0 + x, cy0 + y, c) = (uint8_t)(((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6);
+            }
+}
+/* one partition: whole-sample offsets around (cx, cy) (quarter-sample units, the macroblock's vector), then the two sub-sample rounds; returns the final
+ * SAD cost (distortion + lambda * bits against (px, py)), the vector in *vx, *vy, the prediction in pred (stride 16) */
+static uint32_t part_search(const uint8_t *sy, const uint8_t *ref_y, int stride, int W, int H, int X, int Y, int w, int h, int cx, int cy, int px, int py,
+                            int lambda, int range, int refine, int use_satd, int *vx, int *vy, uint8_t *pred) {
+    const int ix = cx & ~3, iy = cy & ~3; /* the whole-sample position the local search is centred on */
+    int bx = ix, by = iy;
+    uint32_t best = 0xFFFFFFFFu;
+    for (int dy = -2; dy <= 2; dy++)
+        for (int dx = -2; dx <= 2; dx++) {
+            const int qx = ix + 4 * dx, qy = iy + 4 * dy;
+            if (qx < -4 * range || qx > 4 * range || qy < -4 * range || qy > 4 * range) continue;
+            luma_pred_part(ref_y, stride, W, H, X, Y, w, h, qx, qy, pred);
+            const uint32_t c = sad_part(sy, stride, pred, w, h) + (uint32_t)(lambda * (se_bits(qx - px) + se_bits(qy - py)));
+            if (c < best) { best = c; bx = qx; by = qy; }
+        }
+    if (refine)
+        for (int step = 2; step >= 1; step--) {
+            const int satd = step == 1 && use_satd;
+            if (satd) { luma_pred_part(ref_y, stride, W, H, X, Y, w, h, bx, by, pred); best = satd_part(sy, stride, pred, w, h) + (uint32_t)(lambda * (se_bits(bx - px) + se_bits(by - py))); }
+            const int ox = bx, oy = by;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    if (!dx && !dy) continue;
+                    const int qx = ox + dx * step, qy = oy + dy * step;
+                    luma_pred_part(ref_y, stride, W, H, X, Y, w, h, qx, qy, pred);
+                    const uint32_t d = satd ? satd_part(sy, stride, pred, w, h) : sad_part(sy, stride, pred, w, h);
+                    const uint32_t c = d + (uint32_t)(lambda * (se_bits(qx - px) + se_bits(qy - py)));
+                    if (c < best) { best = c; bx = qx; by = qy; }
+                }
+        }
+    luma_pred_part(ref_y, stride, W, H, X, Y, w, h, bx, by, pred);
+    *vx = bx; *vy = by;
+    return sad_part(sy, stride, pred, w, h) + (uint32_t)(lambda * (se_bits(bx - px) + se_bits(by - py)));
+}
+
 void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *ref_y, const uint8_t *ref_uv, uint8_t *rec_y, uint8_t *rec_uv,
                    int stride, int mbw, int mbh, int qp, int drop, int refine, const orc_imv_t *imv, const uint16_t *surf, const orc_idec_t *idec,
                    orc_mbinfo_t *mbi, int16_t *levels, int threads) {
@@ -1292,11 +1383,34 @@ void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *r
             const uint32_t dsad = sad16(sy, stride, pred);
             const uint32_t jinter = dsad + (uint32_t)(lambda * (se_bits(bx - px) + se_bits(by - py)));
             m->mvx = (int16_t)bx; m->mvy = (int16_t)by; m->cost = imv[mbn].sad; /* the record's cost is the whole-sample SAD source against source: what scene-cut detection sums, independent of QP and of what the macroblock became */
+            /* ---- 3b. partitions (oracle-side groundwork, off by default) */
+            int shape = 0, pvx[4] = {bx, 0, 0, 0}, pvy[4] = {by, 0, 0, 0};
+            uint32_t jbest = jinter + (uint32_t)(lambda * k_part_hdr_bits[0]);
+            uint8_t ppred[256];
+            if ((feat & ORC_F_PART) && !g_orc_t8) {
+                for (int sh = 1; sh <= 3; sh++) {
+                    uint32_t j = (uint32_t)(lambda * k_part_hdr_bits[sh]);
+                    int vx[4], vy[4];
+                    uint8_t tp[256], one[256];
+                    for (int i = 0; i < k_part_n[sh] && j < jbest; i++) {
+                        const int8_t *g = k_part_geo[sh][i];
+                        j += part_search(sy + (size_t)g[1] * stride + g[0], ref_y, stride, W, H, x0 + g[0], y0 + g[1], g[2], g[3], bx, by, px, py, lambda, 16, refine,
+                                         (feat & ORC_F_SATD) != 0, &vx[i], &vy[i], one);
+                        for (int y = 0; y < g[3]; y++) memcpy(tp + (g[1] + y) * 16 + g[0], one + y * 16, (size_t)g[2]);
+                    }
+                    if (j < jbest) { jbest = j; shape = sh; memcpy(ppred, tp, 256); for (int i = 0; i < k_part_n[sh]; i++) { pvx[i] = vx[i]; pvy[i] = vy[i]; } }
+                }
+                if (shape) { /* the partitions' vectors may coincide: the shape is kept all the same (its cost said so) */
+                    memcpy(pred, ppred, 256);
+                    m->mvx = (int16_t)pvx[0]; m->mvy = (int16_t)pvy[0]; m->i16_mode = (uint8_t)shape;
+                }
+            }
+            const uint32_t jinter_p = jbest - (uint32_t)(lambda * k_part_hdr_bits[0]); /* (a partitioned macroblock pays for its longer header here too) */
             /* ---- 4. intra instead?  (reconstructed later, by orc_intra_p_frame, once every inter macroblock is in place) */
             if ((feat & ORC_F_INTRAP) && idec && imv[mbn].sad + (uint32_t)(lambda * imv[mbn].bits) >= ORC_INTRA_GATE(lambda)) {
                 const orc_idec_t *d = &idec[mbn];
                 const uint32_t jintra = d->cost_luma + (g_tune[3] ? (d->cost_luma >> g_tune[3]) : 0) + (uint32_t)(lambda * g_tune[2]);
-                if (jintra < jinter) {
+                if (jintra < jinter_p) {
                     m->mb_type = (uint8_t)(d->use_i4 ? 2 : 0); m->mvx = 0; m->mvy = 0;
                     m->i16_mode = (uint8_t)(d->use_i4 ? 0 : d->mode16); m->chroma_mode = d->cmode; m->cost = d->cost;
                     continue;
@@ -1304,8 +1418,14 @@ void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *r
             }
             /* ---- 5. residual */
             for (int y = 0; y < 16; y++) memcpy(rec_y + (size_t)(y0 + y) * stride + x0, pred + y * 16, 16);
-            chroma_pred8(ref_uv, rec_uv, stride, W, H, x0, y0, bx, by);
-            if (tdrop && dsad < tdrop) continue; /* rate control's ladder below QP 51: prediction only */
+            if (!shape) chroma_pred8(ref_uv, rec_uv, stride, W, H, x0, y0, bx, by);
+            else
+                for (int i = 0; i < k_part_n[shape]; i++) {
+                    const int8_t *g = k_part_geo[shape][i];
+                    chroma_pred_part(ref_uv, rec_uv, stride, W, H, x0, y0, g[0], g[1], g[2], g[3], pvx[i], pvy[i]);
+                    if (i) { lev[ORC_L_LDC + 2 * (i - 1)] = (int16_t)pvx[i]; lev[ORC_L_LDC + 2 * (i - 1) + 1] = (int16_t)pvy[i]; }
+                }
+            if (tdrop && (shape ? sad16(sy, stride, pred) : dsad) < tdrop) continue; /* rate control's ladder below QP 51: prediction only */
             m->nzmask = inter_luma_tq(sy, stride, pred, mqp, (feat & ORC_F_DECIMATE) != 0, lev + ORC_L_LUMA);
             for (int b = 0; b < 16; b++) {
                 if (!(m->nzmask & (1u << b))) continue;
@@ -1368,14 +1488,21 @@ static int blk_has_coef(const orc_mbinfo_t *m, int bx4, int by4) {
     if (m->nzmask & ORC_NZ_T8) return ((m->nzmask >> (b & ~3)) & 0xF) != 0; /* 8.7.2.1: the 8x8 block containing the sample */
     return (m->nzmask >> b) & 1;
 }
+static const orc_mbinfo_t *g_db_base; /* the picture's records (orc_deblock_frame): a record's index is what finds its partitions' vectors */
 static int bs_of(const orc_mbinfo_t *mp, int bxp, int byp, const orc_mbinfo_t *mq, int bxq, int byq, int mb_edge) {
     if (mp->mb_type != 1 || mq->mb_type != 1) return mb_edge ? 4 : 3; /* mb_type 0 (I16x16) and 2 (I4x4) are intra */
     if (blk_has_coef(mp, bxp, byp) || blk_has_coef(mq, bxq, byq)) return 2;
-    if (iabs(mp->mvx - mq->mvx) >= 4 || iabs(mp->mvy - mq->mvy) >= 4) return 1; /* quarter-sample units */
+    int pvx = mp->mvx, pvy = mp->mvy, qvx = mq->mvx, qvy = mq->mvy;
+    if (g_part_lev && g_db_base) { /* the vectors of the 8x8 quadrants the two 4x4 blocks lie in */
+        mb_qmv(g_db_base, (int)(mp - g_db_base), (byp >> 1) * 2 + (bxp >> 1), &pvx, &pvy);
+        mb_qmv(g_db_base, (int)(mq - g_db_base), (byq >> 1) * 2 + (bxq >> 1), &qvx, &qvy);
+    }
+    if (iabs(pvx - qvx) >= 4 || iabs(pvy - qvy) >= 4) return 1; /* quarter-sample units */
     return 0;
 }
 void orc_deblock_frame(uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mbh,
                        const orc_mbinfo_t *mbi) {
+    g_db_base = mbi;
     for (int my = 0; my < mbh; my++)
         for (int mx = 0; mx < mbw; mx++) {
             const orc_mbinfo_t *m = &mbi[my * mbw + mx];
@@ -1484,34 +1611,43 @@ int orc_cavlc_block_bits(const int16_t *coef, int maxnum, int nC, uint8_t *out, 
 /* 8.4.1.3 motion vector prediction for a 16x16 partition with refIdx 0 (quarter-pel units
  * are not needed: vectors are compared/added as integer-pel*4 by the caller).
  * type[] : -1 unavailable, 0 intra (refIdx -1), 1 inter (refIdx 0). */
-static void mv_pred16(const orc_mbinfo_t *mbi, int mbw, int mx, int my, int *px, int *py) {
-    int avA = mx > 0, avB = my > 0, avC = my > 0 && mx + 1 < mbw, avD = mx > 0 && my > 0;
-    const orc_mbinfo_t *A = avA ? &mbi[my * mbw + mx - 1] : NULL;
-    const orc_mbinfo_t *B = avB ? &mbi[(my - 1) * mbw + mx] : NULL;
-    const orc_mbinfo_t *C = avC ? &mbi[(my - 1) * mbw + mx + 1] : (avD ? &mbi[(my - 1) * mbw + mx - 1] : NULL);
-    int rA = A && A->mb_type == 1, rB = B && B->mb_type == 1, rC = C && C->mb_type == 1; /* refIdx == 0 */
-    int ax = rA ? A->mvx : 0, ay = rA ? A->mvy : 0;
-    int bx = rB ? B->mvx : 0, by = rB ? B->mvy : 0;
-    int cx = rC ? C->mvx : 0, cy = rC ? C->mvy : 0;
-    if (!B && !C && A) { *px = ax; *py = ay; return; } /* only A available */
-    if (rA + rB + rC == 1) {
-        if (rA) { *px = ax; *py = ay; }
-        else if (rB) { *px = bx; *py = by; }
-        else { *px = cx; *py = cy; }
+/* 6.4.11.7 / 8.4.1.3.2: motion data of the 8x8 block covering luma sample (X, Y) as a neighbour of a partition of macroblock (mx, my), whose own
+ * quadrants in `done` carry the vectors cur[q]; macroblocks later in raster order are not available (P pictures are one slice). */
+static void nb_blk(const orc_mbinfo_t *mbi, int mbw, int mbh, int mx, int my, unsigned done, int cur[4][2], int X, int Y, int *avail, int *ref, int *vx, int *vy) {
+    *avail = 0; *ref = -1; *vx = *vy = 0;
+    if (X < 0 || Y < 0 || X >= mbw * 16 || Y >= mbh * 16) return;
+    const int nx = X >> 4, ny = Y >> 4, q = ((Y & 15) >> 3) * 2 + ((X & 15) >> 3);
+    if (nx == mx && ny == my) { if ((done >> q) & 1) { *avail = 1; *ref = 0; *vx = cur[q][0]; *vy = cur[q][1]; } return; }
+    if (!(ny < my || (ny == my && nx < mx))) return;
+    *avail = 1;
+    if (mbi[ny * mbw + nx].mb_type == 1) { *ref = 0; mb_qmv(mbi, ny * mbw + nx, q, vx, vy); }
+}
+/* 8.4.1.3 for partition idx of shape part at (x0, y0), width w; skip: 8.4.1.1's inference */
+static void mv_pred_part(const orc_mbinfo_t *mbi, int mbw, int mbh, int mx, int my, unsigned done, int cur[4][2], int part, int idx, int x0, int y0, int w, int skip, int *px, int *py) {
+    const int X = mx * 16 + x0, Y = my * 16 + y0;
+    int aA, rA, ax, ay, aB, rB, bx, by, aC, rC, cx, cy;
+    nb_blk(mbi, mbw, mbh, mx, my, done, cur, X - 1, Y, &aA, &rA, &ax, &ay);
+    nb_blk(mbi, mbw, mbh, mx, my, done, cur, X, Y - 1, &aB, &rB, &bx, &by);
+    nb_blk(mbi, mbw, mbh, mx, my, done, cur, X + w, Y - 1, &aC, &rC, &cx, &cy);
+    if (!aC) nb_blk(mbi, mbw, mbh, mx, my, done, cur, X - 1, Y - 1, &aC, &rC, &cx, &cy);
+    *px = 0; *py = 0;
+    if (skip && (!aA || !aB || (rA == 0 && !ax && !ay) || (rB == 0 && !bx && !by))) return;
+    if (part == 1 && idx == 0 && rB == 0) { *px = bx; *py = by; return; }
+    if (part == 1 && idx == 1 && rA == 0) { *px = ax; *py = ay; return; }
+    if (part == 2 && idx == 0 && rA == 0) { *px = ax; *py = ay; return; }
+    if (part == 2 && idx == 1 && rC == 0) { *px = cx; *py = cy; return; }
+    if (!aB && !aC && aA) { rB = rC = rA; bx = cx = ax; by = cy = ay; }
+    const int hits = (rA == 0) + (rB == 0) + (rC == 0);
+    if (hits == 1) {
+        if (rA == 0) { *px = ax; *py = ay; } else if (rB == 0) { *px = bx; *py = by; } else { *px = cx; *py = cy; }
         return;
     }
     *px = median3(ax, bx, cx);
     *py = median3(ay, by, cy);
 }
+static int g_pred_mbh = 1 << 20; /* (the 16x16 forms below never look below the current row) */
 /* 8.4.1.1 P_Skip vector */
-static void mv_pred_skip(const orc_mbinfo_t *mbi, int mbw, int mx, int my, int *px, int *py) {
-    *px = 0; *py = 0;
-    if (mx == 0 || my == 0) return;
-    const orc_mbinfo_t *A = &mbi[my * mbw + mx - 1], *B = &mbi[(my - 1) * mbw + mx];
-    if (A->mb_type == 1 && A->mvx == 0 && A->mvy == 0) return;
-    if (B->mb_type == 1 && B->mvx == 0 && B->mvy == 0) return;
-    mv_pred16(mbi, mbw, mx, my, px, py);
-}
+static void mv_pred_skip(const orc_mbinfo_t *mbi, int mbw, int mx, int my, int *px, int *py) { int cur[4][2] = {{0}}; mv_pred_part(mbi, mbw, g_pred_mbh, mx, my, 0, cur, 0, 0, 0, 0, 16, 1, px, py); }
 
 static int level_idc_for(int mbw, int mbh, int fps_num, int fps_den) {
     /* Table A-1: {level_idc, MaxMBPS, MaxFS} */
@@ -1656,7 +1792,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
             if (!is_idr && m->mb_type == 1) {
                 int sx, sy;
                 mv_pred_skip(mbi, mbw, mx, my, &sx, &sy);
-                if (cbp_luma == 0 && cbp_chroma == 0 && m->mvx == sx && m->mvy == sy) { skip_run++; continue; }
+                if (cbp_luma == 0 && cbp_chroma == 0 && mb_part(m) == 0 && m->mvx == sx && m->mvy == sy) { skip_run++; continue; }
             }
             if (!is_idr) { bw_ue(&b, (uint32_t)skip_run); skip_run = 0; }
             if (i16) {
@@ -1680,11 +1816,20 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
                 bw_ue(&b, m->chroma_mode);
                 bw_ue(&b, k_cbp_to_codenum_intra[cbp_chroma * 16 + cbp_luma]);
             } else {
-                bw_ue(&b, 0); /* P_L0_16x16 */
-                int px, py;
-                mv_pred16(mbi, mbw, mx, my, &px, &py);
-                bw_se(&b, m->mvx - px); /* mvd_l0, quarter-sample units */
-                bw_se(&b, m->mvy - py);
+                const int part = mb_part(m); /* 0 P_L0_16x16, 1 P_L0_L0_16x8, 2 P_L0_L0_8x16, 3 P_8x8 (four P_L0_8x8) */
+                bw_ue(&b, (uint32_t)part);
+                if (part == 3) for (int i = 0; i < 4; i++) bw_ue(&b, 0); /* sub_mb_type */
+                int cur[4][2];
+                unsigned done = 0;
+                for (int i = 0; i < k_part_n[part]; i++) { /* mvd_l0 of the partitions in order, quarter-sample units (ref_idx is not sent: one reference) */
+                    const int8_t *g = k_part_geo[part][i];
+                    int px, py, vx, vy;
+                    mv_pred_part(mbi, mbw, mbh, mx, my, done, cur, part, i, g[0], g[1], g[2], 0, &px, &py);
+                    mb_qmv(mbi, mbn, (g[1] >> 3) * 2 + (g[0] >> 3), &vx, &vy);
+                    bw_se(&b, vx - px);
+                    bw_se(&b, vy - py);
+                    for (int q = 0; q < 4; q++) { const int qx = (q & 1) * 8, qy = (q >> 1) * 8; if (qx >= g[0] && qx < g[0] + g[2] && qy >= g[1] && qy < g[1] + g[3]) { cur[q][0] = vx; cur[q][1] = vy; done |= 1u << q; } }
+                }
                 bw_ue(&b, k_cbp_to_codenum_inter[cbp_chroma * 16 + cbp_luma]);
                 if (g_orc_t8 && cbp_luma) bw_put(&b, 1, (m->nzmask & ORC_NZ_T8) ? 1 : 0); /* transform_size_8x8_flag */
             }
@@ -1874,6 +2019,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
         memcpy(e->pre_y, e->rec_y[nxt], ysz);
         memcpy(e->pre_uv, e->rec_uv[nxt], ysz / 2);
         if (g_aq) { orc_qp_chain_slices(e->mbi, nmb, qp, g_slice_rows * e->mbw); g_aq = NULL; }
+        g_part_lev = (!idr && (g_orc_feat & ORC_F_PART)) ? e->levels : NULL;
         orc_deblock_frame(e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, e->mbi);
     }
     size_t n = 0;
@@ -1883,7 +2029,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
     }
     size_t s = orc_write_slice(out + n, out_cap - n, e->mbw, e->mbh, idr, e->frames_since_idr, e->idr_count & 0xFFFF,
                                qp, e->mbi, e->levels);
-    g_slice_rows = 0;
+    g_slice_rows = 0; g_part_lev = NULL;
     if (!s) return -2;
     *out_len = n + s;
     if (is_idr) *is_idr = idr;

@@ -97,7 +97,7 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
 #define ORC_DROP_MAX 12
 #define ORC_SKIP_MARGIN_BITS 4 /* the skip probe runs when SAD(ps_est) <= SAD(best whole-sample vector) + lambda * this */
 #define ORC_INTRA_GATE(lambda) (768u + 8u * (uint32_t)(lambda)) /* whole-sample search cost below which a P macroblock is never analysed for intra */
-enum { ORC_F_MVDCOST = 1, ORC_F_SKIPPROBE = 2, ORC_F_DECIMATE = 4, ORC_F_SATD = 8, ORC_F_INTRAP = 16, ORC_F_I4P = 32 /* intra macroblocks of P pictures may be Intra_4x4 (x264 superfast: partitions i8x8,i4x4) */, ORC_F_ALL = 63 };
+enum { ORC_F_MVDCOST = 1, ORC_F_SKIPPROBE = 2, ORC_F_DECIMATE = 4, ORC_F_SATD = 8, ORC_F_INTRAP = 16, ORC_F_I4P = 32 /* intra macroblocks of P pictures may be Intra_4x4 (x264 superfast: partitions i8x8,i4x4) */, ORC_F_PART = 64 /* inter partitions 16x8 / 8x16 / 8x8 (oracle-side groundwork: encoder decision, syntax, decoder; the device does not produce them yet, so it is not part of ORC_F_ALL) */, ORC_F_ALL = 63 };
 void orc_set_features(int mask); /* process-wide ablation switches for the rate-distortion tables (default ORC_F_ALL = what the device does) */
 int orc_get_features(void);
 uint32_t orc_drop_threshold(int drop);
@@ -134,6 +134,7 @@ void orc_set_aq_map(const int8_t *off);          /* stage functions: the offsets
 void orc_aq_offsets(const uint8_t *src_y, int stride, int mbw, int mbh, int8_t *off);
 int orc_aq_offset_of(uint32_t sum, uint32_t sum_sq);
 void orc_qp_chain_slices(orc_mbinfo_t *mbi, int nmb, int slice_qp, int slice_mbs); /* ... with a new slice every slice_mbs macroblocks (0: one slice) */
+void orc_set_part_levels(const int16_t *levels); /* stage functions (deblocking, slice writer): where the vectors of an inter macroblock's partitions 1 .. 3 lie (the levels of the picture; NULL: 16x16 only) */
 void orc_set_slice_rows(int rows);              /* stage functions: the I picture being coded is cut into slices of `rows` macroblock rows (0: one slice) */
 int orc_get_slice_rows(void);
 int orc_auto_intra_slices(int mbh);             /* the default number of slices of an I picture: about 17 rows each, at most 8 */

@@ -23,6 +23,7 @@ IMV_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("sad", "<u2"), ("bits", "
 SURF = 33 * 33
 DROP_MAX, DROP_SKIP = 12, 255
 F_MVDCOST, F_SKIPPROBE, F_DECIMATE, F_SATD, F_INTRAP, F_ALL = 1, 2, 4, 8, 16, 31
+F_I4P, F_PART = 32, 64  # Intra_4x4 in P pictures; inter partitions (oracle-side groundwork: not produced by the device yet)
 
 
 def build(force=False):

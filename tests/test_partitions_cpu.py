@@ -1,0 +1,74 @@
+"""Inter partitions (P_L0_L0_16x8, P_L0_L0_8x16, P_8x8 with four P_L0_8x8), oracle side and host writer -- the groundwork for the
+device stage: the oracle encoder's decision (ORC_F_PART, off by default), its syntax, and the independent decoder, which derives every partition's
+predictor from 6.4.11.7 / 8.4.1.3 on its own.  No GPU."""
+import numpy as np
+import pytest
+
+from ceracoder_amd import synth
+
+
+def _encode(oracle, w, h, n, qp, feat, gop=30, clip=None):
+    oracle.set_features(feat)
+    try:
+        e, d = oracle.Encoder(w, h, gop=gop), oracle.Decoder()
+        out, shapes = [], np.zeros(4, int)
+        for i, (y, uv) in enumerate(clip or synth.s2_frames(w, h, n)):
+            au, key = e.encode(y, uv, qp)
+            dy, duv = d.decode(au)
+            assert np.array_equal(dy, e.recon_y) and np.array_equal(duv, e.recon_uv), (w, h, qp, i)
+            out.append(au)
+            if not key:
+                m = e.mbinfo
+                inter = m["mb_type"] == 1
+                for s in range(4):
+                    shapes[s] += int(((m["i16_mode"] == s) & inter).sum())
+        return out, shapes, e
+    finally:
+        oracle.set_features(oracle.F_ALL)
+
+
+@pytest.mark.parametrize("w,h,n", [(64, 48, 8), (176, 144, 6), (322, 182, 5), (640, 368, 4)])
+@pytest.mark.parametrize("qp", [12, 26, 34, 44])
+def test_partitioned_streams_decode_to_the_encoder_reconstruction(oracle, w, h, n, qp):
+    """Every picture of a stream coded with partitions on goes through the independent decoder and must equal the encoder's reconstruction:
+    mb_type / sub_mb_type, the vector differences against the directional and median predictors of every partition (neighbours inside the
+    macroblock included), motion compensation per partition and the boundary strengths on the inner 8x8 edges all have to agree."""
+    out, shapes, _ = _encode(oracle, w, h, n, qp, oracle.F_ALL | oracle.F_PART)
+    if qp <= 34 and w >= 176:
+        assert shapes[1] > 0 and shapes[2] > 0, shapes          # both two-partition shapes occur
+    if qp <= 26 and w >= 176:
+        assert shapes[3] > 0, shapes                            # ... and P_8x8
+
+
+def test_partitions_are_off_by_default_and_cost_nothing_then(oracle):
+    """ORC_F_PART is not part of ORC_F_ALL: the default stream has 16x16 partitions only, and it is the same stream as before the
+    partition code existed (the golden digests of tests/test_published_kat.py pin it); with the flag, the stream gets smaller at
+    about the same PSNR on the moving clip."""
+    w, h, n, qp = 320, 192, 6, 28
+    base, shapes0, e0 = _encode(oracle, w, h, n, qp, oracle.F_ALL)
+    part, shapes1, e1 = _encode(oracle, w, h, n, qp, oracle.F_ALL | oracle.F_PART)
+    assert shapes0[1:].sum() == 0 and shapes1[1:].sum() > 0
+    b0, b1 = sum(len(a) for a in base), sum(len(a) for a in part)
+    assert b1 < b0, (b0, b1)
+    y = list(synth.s2_frames(w, h, n))[-1][0]
+    assert synth.psnr(y[:h], e1.recon_y[:h, :w]) > synth.psnr(y[:h], e0.recon_y[:h, :w]) - 0.15
+
+
+def test_partition_vectors_survive_the_drop_ladder_and_intra_macroblocks(oracle):
+    """Partitions next to intra macroblocks (their refIdx is -1 in the predictors) and on rate control's ladder (prediction only: the vectors are still
+    coded): a clip with a hard cut in the middle of a GOP and pictures coded at QP 51 with drop levels."""
+    w, h = 320, 192
+    a, b = list(synth.s2_frames(w, h, 4)), list(synth.s3_frames(w, h, 3))
+    oracle.set_features(oracle.F_ALL | oracle.F_PART)
+    try:
+        e, d = oracle.Encoder(w, h, gop=30, scenecut=False), oracle.Decoder()
+        intra_in_p = 0
+        for i, ((y, uv), (qp, drop)) in enumerate(zip(a + b, [(30, 0), (30, 0), (51, 2), (30, 0), (30, 0), (51, 6), (28, 0)])):
+            au, key = e.encode(y, uv, qp, drop=drop)
+            dy, duv = d.decode(au)
+            assert np.array_equal(dy, e.recon_y) and np.array_equal(duv, e.recon_uv), i
+            if not key:
+                intra_in_p += int((e.mbinfo["mb_type"] != 1).sum())
+        assert intra_in_p > 0
+    finally:
+        oracle.set_features(oracle.F_ALL)
