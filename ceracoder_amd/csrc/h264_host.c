@@ -261,20 +261,47 @@ static inline int med3(int a, int b, int c) {
     int lo = a < b ? a : b, hi = a < b ? b : a;
     return c < lo ? lo : (c > hi ? hi : c);
 }
-/* 8.4.1.3 for a 16x16 partition, refIdx 0, single slice: A left, B top, C top-right else top-left */
-static inline void predict_mv(const mb_info_t *mbi, int mbw, int mx, int my, int *px, int *py) {
-    const mb_info_t *m = mbi + (size_t)my * mbw + mx;
-    const mb_info_t *A = mx > 0 ? m - 1 : NULL, *B = my > 0 ? m - mbw : NULL;
-    const mb_info_t *C = my > 0 ? (mx + 1 < mbw ? m - mbw + 1 : (mx > 0 ? m - mbw - 1 : NULL)) : NULL;
-    const int ra = A && A->mb_type == 1, rb = B && B->mb_type == 1, rc = C && C->mb_type == 1;
-    const int ax = ra ? A->mvx : 0, ay = ra ? A->mvy : 0, bx = rb ? B->mvx : 0, by = rb ? B->mvy : 0;
-    const int cx = rc ? C->mvx : 0, cy = rc ? C->mvy : 0;
-    if (!B && !C && A) { *px = ax; *py = ay; return; }
-    if (ra + rb + rc == 1) {
-        *px = ra ? ax : rb ? bx : cx;
-        *py = ra ? ay : rb ? by : cy;
-        return;
+/* Partitions (mb_type 1; i16_mode = shape 0 16x16, 1 16x8, 2 8x16, 3 8x8): geometry (x0, y0, w, h) and count */
+static const int8_t part_geo[4][4][4] = {{{0, 0, 16, 16}}, {{0, 0, 16, 8}, {0, 8, 16, 8}}, {{0, 0, 8, 16}, {8, 0, 8, 16}}, {{0, 0, 8, 8}, {8, 0, 8, 8}, {0, 8, 8, 8}, {8, 8, 8, 8}}};
+static const int8_t part_n[4] = {1, 2, 2, 4};
+static inline int mb_shape(const mb_info_t *m) { return m->mb_type == 1 ? (m->i16_mode & 3) : 0; }
+/* the quadrant vectors of an inter macroblock from its record and the block in the luma-DC slot of its levels (vectors of partitions 1 .. 3) */
+static inline void set_qmv(int16_t *q, const mb_info_t *m, const int16_t *ldc) {
+    const int sh = mb_shape(m);
+    for (int k = 0; k < 4; k++) {
+        const int idx = sh == 0 ? 0 : sh == 1 ? (k >> 1) : sh == 2 ? (k & 1) : k;
+        q[2 * k] = idx ? ldc[2 * (idx - 1)] : m->mvx; q[2 * k + 1] = idx ? ldc[2 * (idx - 1) + 1] : m->mvy;
     }
+}
+/* 6.4.11.7 / 8.4.1.3.2: the 8x8 block covering luma sample (X, Y) as a neighbour of a partition of macroblock (mx, my), whose own quadrants in `done`
+ * carry cur[]; one slice per P picture: a macroblock is available when it comes earlier in raster order */
+static inline void nb_blk(const int16_t *qmv, const mb_info_t *mbi, int mbw, int mx, int my, unsigned done, const int16_t *cur, int X, int Y, int *avail, int *ref, int *vx, int *vy) {
+    *avail = 0; *ref = -1; *vx = *vy = 0;
+    if (X < 0 || Y < 0 || X >= mbw * 16) return;
+    const int nx = X >> 4, ny = Y >> 4, q = ((Y & 15) >> 3) * 2 + ((X & 15) >> 3);
+    if (nx == mx && ny == my) { if ((done >> q) & 1) { *avail = 1; *ref = 0; *vx = cur[2 * q]; *vy = cur[2 * q + 1]; } return; }
+    if (!(ny < my || (ny == my && nx < mx))) return;
+    *avail = 1;
+    if (mbi[(size_t)ny * mbw + nx].mb_type == 1) { const int16_t *v = qmv + ((size_t)ny * mbw + nx) * 8 + 2 * q; *ref = 0; *vx = v[0]; *vy = v[1]; }
+}
+/* 8.4.1.3 for partition idx of shape `shape` at (x0, y0) of width wd, refIdx 0 everywhere; skip: 8.4.1.1's inference for P_Skip */
+static inline void predict_part(const int16_t *qmv, const mb_info_t *mbi, int mbw, int mx, int my, unsigned done, const int16_t *cur, int shape, int idx, int x0, int y0, int wd, int skip,
+                                int *px, int *py) {
+    const int X = mx * 16 + x0, Y = my * 16 + y0;
+    int aA, rA, ax, ay, aB, rB, bx, by, aC, rC, cx, cy;
+    nb_blk(qmv, mbi, mbw, mx, my, done, cur, X - 1, Y, &aA, &rA, &ax, &ay);
+    nb_blk(qmv, mbi, mbw, mx, my, done, cur, X, Y - 1, &aB, &rB, &bx, &by);
+    nb_blk(qmv, mbi, mbw, mx, my, done, cur, X + wd, Y - 1, &aC, &rC, &cx, &cy);
+    if (!aC) nb_blk(qmv, mbi, mbw, mx, my, done, cur, X - 1, Y - 1, &aC, &rC, &cx, &cy);
+    *px = 0; *py = 0;
+    if (skip && (!aA || !aB || (rA == 0 && !ax && !ay) || (rB == 0 && !bx && !by))) return;
+    if (shape == 1 && idx == 0 && rB == 0) { *px = bx; *py = by; return; }
+    if (shape == 1 && idx == 1 && rA == 0) { *px = ax; *py = ay; return; }
+    if (shape == 2 && idx == 0 && rA == 0) { *px = ax; *py = ay; return; }
+    if (shape == 2 && idx == 1 && rC == 0) { *px = cx; *py = cy; return; }
+    if (!aB && !aC && aA) { rB = rC = rA; bx = cx = ax; by = cy = ay; }
+    const int hits = (rA == 0) + (rB == 0) + (rC == 0);
+    if (hits == 1) { *px = rA == 0 ? ax : rB == 0 ? bx : cx; *py = rA == 0 ? ay : rB == 0 ? by : cy; return; }
     *px = med3(ax, bx, cx);
     *py = med3(ay, by, cy);
 }
@@ -287,6 +314,8 @@ struct h264_writer {
     uint8_t *tc_l; /* TotalCoeff per luma 4x4 in raster order, 16 per macroblock */
     uint8_t *tc_c; /* per chroma AC block: Cb 0-3, Cr 4-7 */
     uint8_t *i4m;  /* Intra4x4PredMode per luma4x4BlkIdx, 16 per macroblock (valid where mb_type == 2) */
+    int16_t *qmv;  /* the vector of each 8x8 quadrant of the inter macroblocks coded (or read, fill_ctx_row) so far, 8 per macroblock: what the predictors of
+                      partitioned macroblocks (mb_type 1 with a shape in i16_mode: 1 16x8, 2 8x16, 3 8x8) and of their neighbours are derived from */
     struct cavlc_pool *pool; /* row-parallel coding (h264_writer_set_threads); NULL = everything on the calling thread */
 };
 
@@ -299,7 +328,8 @@ h264_writer_t *h264_writer_new(int mbw, int mbh, int t8) {
     w->tc_l = (uint8_t *)malloc((size_t)mbw * mbh * 16);
     w->tc_c = (uint8_t *)malloc((size_t)mbw * mbh * 8);
     w->i4m = (uint8_t *)malloc((size_t)mbw * mbh * 16);
-    if (!w->rbsp || !w->tc_l || !w->tc_c || !w->i4m) { h264_writer_free(w); return NULL; }
+    w->qmv = (int16_t *)calloc((size_t)mbw * mbh * 8, sizeof(int16_t));
+    if (!w->rbsp || !w->tc_l || !w->tc_c || !w->i4m || !w->qmv) { h264_writer_free(w); return NULL; }
     return w;
 }
 void h264_writer_set_slice_rows(h264_writer_t *w, int rows) { if (w) w->slice_rows = rows > 0 ? rows : 0; }
@@ -307,7 +337,7 @@ static void cavlc_pool_free(struct cavlc_pool *p);
 void h264_writer_free(h264_writer_t *w) {
     if (!w) return;
     if (w->pool) cavlc_pool_free(w->pool);
-    free(w->rbsp); free(w->tc_l); free(w->tc_c); free(w->i4m); free(w);
+    free(w->rbsp); free(w->tc_l); free(w->tc_c); free(w->i4m); free(w->qmv); free(w);
 }
 size_t h264_max_au_bytes(int mbw, int mbh) { return (size_t)mbw * mbh * 1536 + 4096; }
 
@@ -376,7 +406,8 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
             const int intra = m->mb_type != 1, i16 = m->mb_type == 0;
             const int16_t *p_modes, *p_ldc, *p_cdc, *p_luma[16], *p_cac[8];
             if (packed) {
-                p_modes = m->mb_type == 2 ? packed : k_zero_block; if (m->mb_type == 2) packed += 16;
+                const int has_slot = m->mb_type == 2 || mb_shape(m) != 0; /* the luma-DC slot travels for Intra_4x4 modes and for the vectors of partitions 1 .. 3 */
+                p_modes = has_slot ? packed : k_zero_block; if (has_slot) packed += 16;
                 p_ldc = (nz & NZ_LDC) ? packed : k_zero_block; if (nz & NZ_LDC) packed += 16;
                 for (int i = 0; i < 16; i++) { if ((nz >> i) & 1) { p_luma[i] = packed; packed += 16; } else p_luma[i] = k_zero_block; }
                 p_cdc = (nz & (NZ_CBDC | NZ_CRDC)) ? packed : k_zero_block; if (nz & (NZ_CBDC | NZ_CRDC)) packed += 16;
@@ -394,22 +425,28 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
             else cbp_l = ((nz & 0x000F) ? 1 : 0) | ((nz & 0x00F0) ? 2 : 0) | ((nz & 0x0F00) ? 4 : 0) | ((nz & 0xF000) ? 8 : 0);
             const int cbp_c = (nz & 0x00FF0000u) ? 2 : ((nz & (NZ_CBDC | NZ_CRDC)) ? 1 : 0);
             if (!intra) {
-                int px, py;
-                predict_mv(mbi, mbw, mx, my, &px, &py);
-                if (!cbp_l && !cbp_c) { /* 8.4.1.1: P_Skip when the vector equals the inferred one */
-                    int sx = px, sy = py;
-                    if (!mx || !my) sx = sy = 0;
-                    else {
-                        const mb_info_t *A = m - 1, *B = m - mbw;
-                        if ((A->mb_type == 1 && !A->mvx && !A->mvy) || (B->mb_type == 1 && !B->mvx && !B->mvy)) sx = sy = 0;
-                    }
+                const int shape = mb_shape(m);
+                int16_t *qv = w->qmv + (size_t)mbn * 8;
+                set_qmv(qv, m, p_modes);
+                if (!cbp_l && !cbp_c && !shape) { /* 8.4.1.1: P_Skip when the vector equals the inferred one */
+                    int sx, sy;
+                    predict_part(w->qmv, mbi, mbw, mx, my, 0, qv, 0, 0, 0, 0, 16, 1, &sx, &sy);
                     if (m->mvx == sx && m->mvy == sy) { skip++; continue; }
                 }
                 if (defer_first_run && !res.has_coded) res.lead_skip = skip; else bits_ue(&b, (uint32_t)skip);
                 skip = 0; res.has_coded = 1;
-                bits_ue(&b, 0); /* P_L0_16x16 */
-                bits_se(&b, m->mvx - px); /* mvd_l0: vectors are kept in quarter-sample units */
-                bits_se(&b, m->mvy - py);
+                bits_ue(&b, (uint32_t)shape); /* P_L0_16x16, P_L0_L0_16x8, P_L0_L0_8x16, P_8x8 */
+                if (shape == 3) for (int i = 0; i < 4; i++) bits_ue(&b, 0); /* sub_mb_type: P_L0_8x8 */
+                unsigned done = 0;
+                for (int i = 0; i < part_n[shape]; i++) { /* mvd_l0 of the partitions in order (quarter-sample units; ref_idx is not sent: one reference) */
+                    const int8_t *g = part_geo[shape][i];
+                    const int q0 = (g[1] >> 3) * 2 + (g[0] >> 3);
+                    int px, py;
+                    predict_part(w->qmv, mbi, mbw, mx, my, done, qv, shape, i, g[0], g[1], g[2], 0, &px, &py);
+                    bits_se(&b, qv[2 * q0] - px);
+                    bits_se(&b, qv[2 * q0 + 1] - py);
+                    for (int q = 0; q < 4; q++) { const int qx = (q & 1) * 8, qy = (q >> 1) * 8; if (qx >= g[0] && qx < g[0] + g[2] && qy >= g[1] && qy < g[1] + g[3]) done |= 1u << q; }
+                }
                 bits_ue(&b, cbp_inter_code[cbp_c * 16 + cbp_l]);
                 if (w->t8 && cbp_l) bits_put(&b, 1, (nz & NZ_T8) ? 1u : 0u); /* transform_size_8x8_flag */
             } else {
@@ -476,6 +513,7 @@ static void fill_ctx_row(h264_writer_t *w, int row, const mb_info_t *mbi, const 
         uint8_t *tl = w->tc_l + (size_t)mbn * 16, *tc = w->tc_c + (size_t)mbn * 8, *im = w->i4m + (size_t)mbn * 16;
         memset(tl, 0, 16); memset(tc, 0, 8);
         if (m->mb_type == 2) { for (int i = 0; i < 16; i++) im[i] = (uint8_t)packed[i]; packed += 16; }
+        else if (m->mb_type == 1) { const int slot = mb_shape(m) != 0; set_qmv(w->qmv + (size_t)mbn * 8, m, slot ? packed : k_zero_block); if (slot) packed += 16; }
         if (nz & NZ_LDC) packed += 16;
         const int ac_only = m->mb_type == 0; /* Intra16x16: coefficient 0 travels in the DC block */
         for (int i = 0; i < 16; i++)
@@ -501,7 +539,7 @@ static void fill_ctx_row(h264_writer_t *w, int row, const mb_info_t *mbi, const 
 static const int16_t *skip_packed_rows(const mb_info_t *m, int n, const int16_t *packed) {
     for (int i = 0; i < n; i++) {
         const uint32_t nz = m[i].nzmask;
-        int blocks = (m[i].mb_type == 2) + ((nz & NZ_LDC) != 0) + __builtin_popcount(nz & 0xFFFFu) + ((nz & (NZ_CBDC | NZ_CRDC)) != 0) + __builtin_popcount((nz >> 16) & 0xFFu);
+        int blocks = (m[i].mb_type == 2 || mb_shape(&m[i]) != 0) + ((nz & NZ_LDC) != 0) + __builtin_popcount(nz & 0xFFFFu) + ((nz & (NZ_CBDC | NZ_CRDC)) != 0) + __builtin_popcount((nz >> 16) & 0xFFu);
         packed += 16 * blocks;
     }
     return packed;
@@ -702,7 +740,7 @@ size_t h264_pack_levels(int mbw, int mbh, const mb_info_t *mbi, const int16_t *l
         const uint32_t nz = mbi[mb].nzmask;
         const int16_t *lv = levels + mb * MB_LEVELS;
         if (mb % (size_t)mbw == 0) row_off[mb / (size_t)mbw] = (uint32_t)nblk;
-        if (mbi[mb].mb_type == 2) memcpy(packed + 16 * nblk++, lv + L_LDC, 32);
+        if (mbi[mb].mb_type == 2 || mb_shape(&mbi[mb]) != 0) memcpy(packed + 16 * nblk++, lv + L_LDC, 32); /* Intra_4x4 modes / the vectors of partitions 1 .. 3 */
         if (nz & NZ_LDC) memcpy(packed + 16 * nblk++, lv + L_LDC, 32);
         for (int i = 0; i < 16; i++) if ((nz >> i) & 1) memcpy(packed + 16 * nblk++, lv + L_LUMA + 16 * i, 32);
         if (nz & (NZ_CBDC | NZ_CRDC)) memcpy(packed + 16 * nblk++, lv + L_CDC, 32);

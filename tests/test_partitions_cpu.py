@@ -72,3 +72,26 @@ def test_partition_vectors_survive_the_drop_ladder_and_intra_macroblocks(oracle)
         assert intra_in_p > 0
     finally:
         oracle.set_features(oracle.F_ALL)
+
+
+@pytest.mark.parametrize("w,h,qp", [(176, 144, 24), (322, 182, 30), (640, 368, 20), (1280, 720, 28)])
+def test_host_writer_codes_partitioned_macroblocks_like_the_oracle(oracle, w, h, qp):
+    """The product's slice writer on the oracle's records of partitioned pictures: mb_type / sub_mb_type, the partitions' vector differences against
+    predictors it derives itself (quadrant vectors of the rows above through fill_ctx_row when row ranges are coded on several threads), the luma-DC
+    slot of the packed stream carrying the vectors of partitions 1 .. 3 -- dense levels on one thread and the packed stream on several."""
+    from ceracoder_amd import enc as E
+    oracle.set_features(oracle.F_ALL | oracle.F_PART)
+    try:
+        oe = oracle.Encoder(w, h, gop=30, threads=8, intra_slices=1)
+        seen = 0
+        for i, (y, uv) in enumerate(synth.s2_frames(w, h, 5)):
+            au, idr = oe.encode(y, uv, qp)
+            hdr = oracle.write_headers(w, h, 60) if idr else b""
+            assert hdr + E.host_write_slice(oe.mbw, oe.mbh, idr, i, 0, qp, oe.mbinfo, oe.levels) == au, i
+            for thr in (1, 3, 8):
+                assert hdr + E.host_write_slice_packed(oe.mbw, oe.mbh, idr, i, 0, qp, oe.mbinfo, oe.levels, threads=thr) == au, (i, thr)
+            if not idr:
+                seen += int(((oe.mbinfo["mb_type"] == 1) & (oe.mbinfo["i16_mode"] != 0)).sum())
+        assert seen > 0
+    finally:
+        oracle.set_features(oracle.F_ALL)
