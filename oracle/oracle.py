@@ -91,6 +91,8 @@ def lib():
         L.orc_qp_chain.restype = None
         L.orc_qp_chain_slices.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.orc_qp_chain_slices.restype = None
+        L.orc_set_part_levels.argtypes = [vp]
+        L.orc_set_part_levels.restype = None
         L.orc_set_slice_rows.argtypes = [C.c_int]
         L.orc_set_slice_rows.restype = None
         L.orc_auto_intra_slices.argtypes = [C.c_int]
@@ -342,6 +344,17 @@ def pmb_frame(src_y, src_uv, ref_y, ref_uv, imv, surf, qp, drop=0, refine=True, 
     if dec is not None:
         L.orc_intra_p_frame(_ptr(src_y), _ptr(src_uv), _ptr(rec_y), _ptr(rec_uv), W, W // 16, H // 16, qp, _ptr(dec), _ptr(mbi), _ptr(lev))
     return rec_y, rec_uv, mbi, lev, pre
+
+
+_part_levels_keep = None
+
+
+def set_part_levels(levels):
+    """Stage functions (deblock_frame, write_slice): the levels of the picture, where the vectors of partitions 1 .. 3 of its inter macroblocks lie
+    (None: every inter macroblock is one 16x16 partition).  The array is kept alive until the next call."""
+    global _part_levels_keep
+    _part_levels_keep = None if levels is None else np.ascontiguousarray(levels, np.int16)
+    lib().orc_set_part_levels(None if levels is None else _ptr(_part_levels_keep))
 
 
 def set_slice_rows(rows):

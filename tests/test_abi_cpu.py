@@ -138,6 +138,11 @@ def test_host_cavlc_equals_oracle_on_random_levels(oracle):
             mbi[m]["qp"] = 30
             mbi[m]["i16_mode"], mbi[m]["chroma_mode"] = rng.integers(0, 4), rng.integers(0, 4)
             mbi[m]["mvx"], mbi[m]["mvy"] = (0, 0) if intra else (rng.integers(-16, 17), rng.integers(-16, 17))
+            if not intra:  # an inter macroblock's i16_mode is its partition shape (0 16x16, 1 16x8, 2 8x16, 3 8x8); the vectors of partitions 1 .. 3 in the luma-DC slot
+                shape = int(rng.integers(0, 4)) if trial % 2 else 0
+                mbi[m]["i16_mode"] = shape
+                if shape:
+                    lev[m, 256:262] = rng.integers(-40, 41, 6)
             nz = 0
             for b in range(16):
                 if rng.random() < 0.7:
@@ -166,7 +171,11 @@ def test_host_cavlc_equals_oracle_on_random_levels(oracle):
                         nz |= int(v.any()) << (16 + 4 * c + b)
             mbi[m]["nzmask"] = nz
         a = E.host_write_slice(mbw, mbh, is_idr, trial % 256, trial, 30, mbi, lev)
-        b = oracle.write_slice(mbw, mbh, is_idr, trial % 256, trial, 30, mbi, lev)
+        oracle.set_part_levels(lev)
+        try:
+            b = oracle.write_slice(mbw, mbh, is_idr, trial % 256, trial, 30, mbi, lev)
+        finally:
+            oracle.set_part_levels(None)
         assert a == b, trial
         for thr in (1, 2, 3, 4):  # packed hand-over format, rows coded on `thr` threads and stitched
             assert E.host_write_slice_packed(mbw, mbh, is_idr, trial % 256, trial, 30, mbi, lev, threads=thr) == b, (trial, thr)
