@@ -42,14 +42,15 @@ def test_partitioned_streams_decode_to_the_encoder_reconstruction(oracle, w, h, 
 
 def test_partitions_are_off_by_default_and_cost_nothing_then(oracle):
     """ORC_F_PART is not part of ORC_F_ALL: the default stream has 16x16 partitions only, and it is the same stream as before the
-    partition code existed (the golden digests of tests/test_published_kat.py pin it); with the flag, the stream gets smaller at
-    about the same PSNR on the moving clip."""
+    partition code existed (the golden digests of tests/test_published_kat.py pin it); with the flag -- and the search the device can
+    afford: partitions choose among the vectors the macroblock's refinement visits -- the stream is rate-distortion neutral on the moving
+    clip (within 1 % of the bytes at the same PSNR; the dearer search with whole-sample offsets of its own per partition measured 1-3 % fewer)."""
     w, h, n, qp = 320, 192, 6, 28
     base, shapes0, e0 = _encode(oracle, w, h, n, qp, oracle.F_ALL)
     part, shapes1, e1 = _encode(oracle, w, h, n, qp, oracle.F_ALL | oracle.F_PART)
     assert shapes0[1:].sum() == 0 and shapes1[1:].sum() > 0
     b0, b1 = sum(len(a) for a in base), sum(len(a) for a in part)
-    assert b1 < b0, (b0, b1)
+    assert abs(b1 - b0) < 0.01 * b0, (b0, b1)
     y = list(synth.s2_frames(w, h, n))[-1][0]
     assert synth.psnr(y[:h], e1.recon_y[:h, :w]) > synth.psnr(y[:h], e0.recon_y[:h, :w]) - 0.15
 
