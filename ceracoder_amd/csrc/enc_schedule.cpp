@@ -79,6 +79,7 @@ void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set)
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec2[set];
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh;
     c->slice_rows = idr ? h->islice_rows : 0;
+    c->partitions = (!idr && h->cfg.partitions && !h->cfg.transform8x8 && h->cfg.deblock_mode == 0) ? 1 : 0;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
     c->surf = h->d_surf[set]; c->imv_a = h->d_imv[set][0]; c->imv_b = h->d_imv[set][1]; c->imv_c = h->d_imv[set][2];
     c->me_ref_y = h->d_psrc[h->psrc_cur]; c->psrc_out = h->d_psrc[h->psrc_cur ^ 1];

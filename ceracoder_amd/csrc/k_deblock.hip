@@ -55,6 +55,27 @@ DEV int bs_of(const mb_info_t &mp, int bxp, int byp, const mb_info_t &mq, int bx
     if (iabs(mp.mvx - mq.mvx) >= 4 || iabs(mp.mvy - mq.mvy) >= 4) return 1; // quarter-sample units
     return 0;
 }
+// ... with partitions (ctx->partitions): the vectors of the 8x8 quadrants the two 4x4 blocks lie in (vp / vq: x | y << 16 per quadrant, raster)
+DEV int bs_of_q(const mb_info_t &mp, const unsigned *vp, int bxp, int byp, const mb_info_t &mq, const unsigned *vq, int bxq, int byq, bool mb_edge) {
+    if (mp.mb_type != 1 || mq.mb_type != 1) return mb_edge ? 4 : 3;
+    if (has_coef(mp, bxp, byp) || has_coef(mq, bxq, byq)) return 2;
+    const unsigned a = vp[(byp >> 1) * 2 + (bxp >> 1)], b = vq[(byq >> 1) * 2 + (bxq >> 1)];
+    if (iabs((int)(int16_t)(a & 0xFFFF) - (int)(int16_t)(b & 0xFFFF)) >= 4 || iabs((int)(int16_t)(a >> 16) - (int)(int16_t)(b >> 16)) >= 4) return 1;
+    return 0;
+}
+// the quadrant vectors of macroblock mbn (record m): partition 0's from the record, the others from the luma-DC slot of its levels
+DEV void ld_qmv(const frame_ctx_t *__restrict__ ctx, int mbn, const mb_info_t &m, unsigned *v) {
+    const unsigned v0 = ((unsigned)(uint16_t)m.mvx) | ((unsigned)(uint16_t)m.mvy << 16);
+    const int shape = m.mb_type == 1 ? (m.i16_mode & 3) : 0;
+    v[0] = v[1] = v[2] = v[3] = v0;
+    if (shape) {
+        const int16_t *l = ctx->levels + (size_t)mbn * MB_LEVELS + L_LDC;
+        const unsigned w0 = ldg32(l), w1 = ldg32(l + 2), w2 = ldg32(l + 4); // partitions 1, 2, 3
+        if (shape == 1) { v[2] = v[3] = w0; }
+        else if (shape == 2) { v[1] = v[3] = w0; }
+        else { v[1] = w0; v[2] = w1; v[3] = w2; }
+    }
+}
 // One wave per macroblock, launched once per wavefront x + 2y = diag: then the left, top and
 // top-right macroblocks (everything the raster-order process of 8.7 has touched before this
 // macroblock that overlaps its support) are complete, and same-diagonal tiles are disjoint.
@@ -185,6 +206,9 @@ DEV bool db_record(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, con
     const mb_info_t lft = ld_mbinfo(&ctx->mbi[mx > 0 ? i - 1 : i]);
     const mb_info_t upp = ld_mbinfo(&ctx->mbi[my > 0 ? i - mbw : i]);
     const bool t8 = (cur.nzmask & NZ_T8) != 0;
+    const bool parts = ctx->partitions != 0; // (wave-uniform)
+    unsigned vc[4], vl[4], vu[4];
+    if (parts) { ld_qmv(ctx, i, cur, vc); ld_qmv(ctx, mx > 0 ? i - 1 : i, lft, vl); ld_qmv(ctx, my > 0 ? i - mbw : i, upp, vu); }
     unsigned long long bv = 0, bh = 0;
 #pragma unroll
     for (int e = 0; e < 4; e++)
@@ -192,8 +216,13 @@ DEV bool db_record(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, con
         for (int sg = 0; sg < 4; sg++) {
             int v = 0, h = 0;
             if (!(t8 && (e & 1))) {
-                if (!(e == 0 && mx == 0)) v = bs_of(e == 0 ? lft : cur, e == 0 ? 3 : e - 1, sg, cur, e, sg, e == 0);
-                if (!(e == 0 && my == 0)) h = bs_of(e == 0 ? upp : cur, sg, e == 0 ? 3 : e - 1, cur, sg, e, e == 0);
+                if (!parts) {
+                    if (!(e == 0 && mx == 0)) v = bs_of(e == 0 ? lft : cur, e == 0 ? 3 : e - 1, sg, cur, e, sg, e == 0);
+                    if (!(e == 0 && my == 0)) h = bs_of(e == 0 ? upp : cur, sg, e == 0 ? 3 : e - 1, cur, sg, e, e == 0);
+                } else {
+                    if (!(e == 0 && mx == 0)) v = bs_of_q(e == 0 ? lft : cur, e == 0 ? vl : vc, e == 0 ? 3 : e - 1, sg, cur, vc, e, sg, e == 0);
+                    if (!(e == 0 && my == 0)) h = bs_of_q(e == 0 ? upp : cur, e == 0 ? vu : vc, sg, e == 0 ? 3 : e - 1, cur, vc, sg, e, e == 0);
+                }
             }
             bv |= (unsigned long long)v << (4 * (e * 4 + sg));
             bh |= (unsigned long long)h << (4 * (e * 4 + sg));

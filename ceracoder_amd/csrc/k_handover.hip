@@ -7,12 +7,13 @@
 // them are zero.  Instead of copying the dense array over PCIe (6.6 MB per 1080p picture) the
 // device packs what the CAVLC writer will actually read, in the order it reads it, straight into
 // the pinned host buffer: per macroblock, 32-byte blocks
-//     [Intra4x4 modes, if mb_type == 2] [Intra16x16 DC, if NZ_LDC] [luma blkIdx b for every set bit b of nzmask]
+//     [the luma-DC slot, if it holds the Intra4x4 modes (mb_type == 2) or the vectors of partitions 1 .. 3 (mb_type == 1 with a shape in i16_mode)] [Intra16x16 DC, if NZ_LDC] [luma blkIdx b for every set bit b of nzmask]
 //     [chroma DC (Cb 4 + Cr 4), if NZ_CBDC | NZ_CRDC] [chroma AC block i for every set bit 16 + i]
 // The host walks the stream with a running pointer and needs no per-macroblock offsets.
 #define PACK_CAND 27
-DEV int pack_count(unsigned nz, unsigned mb_type) {
-    return __popc(nz & 0x01FFFFFFu) + ((nz & (NZ_CBDC | NZ_CRDC)) ? 1 : 0) + (mb_type == 2 ? 1 : 0);
+DEV bool pack_slot(unsigned ty) { return (ty & 255u) == 2u || ((ty & 255u) == 1u && ((ty >> 8) & 3u) != 0u); } // ty: mb_type | i16_mode << 8 (word 1 of the record)
+DEV int pack_count(unsigned nz, unsigned ty) {
+    return __popc(nz & 0x01FFFFFFu) + ((nz & (NZ_CBDC | NZ_CRDC)) ? 1 : 0) + (pack_slot(ty) ? 1 : 0);
 }
 // exclusive prefix sum of the block counts: one workgroup, thread t owns a run of PER consecutive macroblocks whose counts
 // stay in registers (all PER loads are in flight together: the kernel sits on the latency path of every access unit).
@@ -29,14 +30,14 @@ __global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__re
         for (int i = 0; i < PER; i++) {
             const int mb = base + i;
             const uint4 r = ldg128(&mbi[mb < nmb ? mb : nmb - 1]);
-            cnt[i] = mb < nmb ? (unsigned)pack_count(r.z, r.y & 255) : 0u;
+            cnt[i] = mb < nmb ? (unsigned)pack_count(r.z, r.y & 0xFFFFu) : 0u;
             mine += cnt[i];
             cost += mb < nmb ? r.w : 0u;
         }
     } else {
         for (int i = 0; i < per; i++) {
             const int mb = base + i;
-            if (mb < nmb) { const uint4 r = ldg128(&mbi[mb]); mine += (unsigned)pack_count(r.z, r.y & 255); cost += r.w; }
+            if (mb < nmb) { const uint4 r = ldg128(&mbi[mb]); mine += (unsigned)pack_count(r.z, r.y & 0xFFFFu); cost += r.w; }
         }
     }
     cost = (unsigned)wave64_sum((int)cost); // < 2^20 * 8 * 64 per wave: fits
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(1024) void levels_scan_kernel(const mb_info_t *__re
             if (mb < nmb) {
                 off[mb] = run;
                 if (mb % mbw == 0) hdr[2 + mb / mbw] = run;
-                const uint4 r = ldg128(&mbi[mb]); run += (unsigned)pack_count(r.z, r.y & 255);
+                const uint4 r = ldg128(&mbi[mb]); run += (unsigned)pack_count(r.z, r.y & 0xFFFFu);
             }
         }
     }
@@ -82,10 +83,10 @@ __global__ __launch_bounds__(256) void levels_pack_kernel(const mb_info_t *__res
     const int mb = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = threadIdx.x & 63;
     if (mb >= nmb) return;
     const uint4 r = ldg128(&mbi[mb]);
-    const unsigned nz = r.z, type = r.y & 255;
+    const unsigned nz = r.z;
     bool present = false;
     int src = 0; // int16 offset inside the macroblock's 408 levels
-    if (c == 0) { present = type == 2; src = L_LDC; }
+    if (c == 0) { present = pack_slot(r.y & 0xFFFFu); src = L_LDC; }
     else if (c == 1) { present = (nz & NZ_LDC) != 0; src = L_LDC; }
     else if (c < 18) { present = (nz >> (c - 2)) & 1; src = L_LUMA + (c - 2) * 16; }
     else if (c == 18) { present = (nz & (NZ_CBDC | NZ_CRDC)) != 0; src = L_CDC; }

@@ -567,7 +567,19 @@ DEV void pmb_store_pred_only(const frame_ctx_t *__restrict__ ctx, int16_t *lv, i
 
 // One P macroblock on one wave (no workgroup barrier anywhere: the four waves of a workgroup are independent).
 // SC1: the reconstruction and the record are stored through to memory -- the picture's own deblocking launch reads them without a kernel boundary in between.
-template <bool SC1>
+// PART: partitions (oracle: ORC_F_PART).  A lane owns four samples of row lane >> 2, columns 4 (lane & 3) ..: its 8x8 quadrant is (lane >> 5, (lane >> 1) & 1), and a
+// quadrant's lanes differ in lane bits 0, 2, 3, 4.  Every candidate vector the refinement visits leaves the SAD of each quadrant behind (the wave-wide sum is
+// built from the quadrant sums, so they cost nothing); afterwards every partition of every shape picks the visited vector with the lowest SAD + lambda * bits,
+// the shape with the lowest total (+ lambda * header bits) against the 16x16 cost decides, and the prediction is taken again with a vector per lane.
+DEV unsigned part_gsum(unsigned v) { // sum over the lanes of this lane's quadrant (two packed 16-bit sums: a quadrant's SAD is < 2^14)
+    v += (unsigned)quad_xor<1>((int)v);
+    v += (unsigned)row_xor4((int)v);
+    v += (unsigned)row_xor8((int)v);
+    v += (unsigned)__shfl_xor((int)v, 16, 64);
+    return v;
+}
+DEV unsigned part_total(unsigned g) { g += (unsigned)quad_xor<2>((int)g); return g + (unsigned)__shfl_xor((int)g, 32, 64); } // the four quadrants' sums -> the macroblock's
+template <bool SC1, bool PART>
 DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, const int lane, const int refine) {
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = mb_qp_dev(ctx, mbn), lambda = ctx->lambda; // (quantisation only: search, refinement and decisions keep the picture's lambda)
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
@@ -648,8 +660,15 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
     int bqx = imx, bqy = imy;
     // the whole-sample winner's SAD against the REFERENCE (the surface holds its SAD against the previous source: the search runs
     // source against source)
-    unsigned best = (unsigned)wave64_sum((int)__builtin_amdgcn_sad_u8(curw, sp_sample4(L, 1 + pc, 1 + pr, 0, 0), 0u)) +
-                    (unsigned)(lambda * (mvq_bits(imx - fp.px) + mvq_bits(imy - fp.py)));
+    unsigned q0 = 0, qh[4] = {0, 0, 0, 0}, qq[4] = {0, 0, 0, 0}; // PART: this lane's quadrant's SAD of candidate 0 / the half-sample round's eight / the quarter-sample round's eight (16-bit pairs)
+    int hbx = imx, hby = imy;                                    // ... and the centre of the quarter-sample round
+    unsigned best;
+    if (PART) {
+        q0 = part_gsum(__builtin_amdgcn_sad_u8(curw, sp_sample4(L, 1 + pc, 1 + pr, 0, 0), 0u));
+        best = part_total(q0) + (unsigned)(lambda * (mvq_bits(imx - fp.px) + mvq_bits(imy - fp.py)));
+    } else
+        best = (unsigned)wave64_sum((int)__builtin_amdgcn_sad_u8(curw, sp_sample4(L, 1 + pc, 1 + pr, 0, 0), 0u)) +
+               (unsigned)(lambda * (mvq_bits(imx - fp.px) + mvq_bits(imy - fp.py)));
     if (refine) {
         sp_planes(L, lane);
         { // half-sample round: SAD, the 8 candidates scored together (two 16-bit partial sums per register)
@@ -664,7 +683,10 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
                 acc[c8 >> 1] |= sad << (16 * (c8 & 1));
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) acc[q] = (unsigned)wave64_sum((int)acc[q]);
+            for (int q = 0; q < 4; q++) {
+                if (PART) { qh[q] = part_gsum(acc[q]); acc[q] = part_total(qh[q]); }
+                else acc[q] = (unsigned)wave64_sum((int)acc[q]);
+            }
 #pragma unroll
             for (int c8 = 0; c8 < 8; c8++) {
                 const int k = c8 < 4 ? c8 : c8 + 1;
@@ -674,6 +696,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
                 if (cost < best) { best = cost; bqx = qx; bqy = qy; }
             }
         }
+        hbx = bqx; hby = bqy;
         { // quarter-sample round: SATD; the standing best is restated in the same measure first
             const int cqx = bqx, cqy = bqy;
             {
@@ -686,7 +709,13 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
                 if (k == 4) continue;
                 const int qx = cqx + (k % 3 - 1), qy = cqy + (k / 3 - 1);
                 const int ox = qx - imx, oy = qy - imy;
-                const unsigned d = pmb_satd(lane, curw, sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3)) >> 1;
+                const unsigned cw = sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3);
+                if (PART) {
+                    const int c8 = k < 4 ? k : k - 1;
+                    const unsigned g = part_gsum(__builtin_amdgcn_sad_u8(curw, cw, 0u)) << (16 * (c8 & 1));
+                    qq[0] |= (c8 >> 1) == 0 ? g : 0u; qq[1] |= (c8 >> 1) == 1 ? g : 0u; qq[2] |= (c8 >> 1) == 2 ? g : 0u; qq[3] |= (c8 >> 1) == 3 ? g : 0u;
+                }
+                const unsigned d = pmb_satd(lane, curw, cw) >> 1;
                 const unsigned cost = d + (unsigned)(lambda * (mvq_bits(qx - fp.px) + mvq_bits(qy - fp.py)));
                 if (cost < best) { best = cost; bqx = qx; bqy = qy; }
             }
@@ -694,9 +723,50 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
     }
     // ---- the final vector's prediction and its cost in the SAD domain
     const int ox = bqx - imx, oy = bqy - imy;
-    const unsigned pw = sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3);
-    const unsigned dsad = (unsigned)wave64_sum((int)__builtin_amdgcn_sad_u8(curw, pw, 0u));
-    const unsigned jinter = dsad + (unsigned)(lambda * (mvq_bits(bqx - fp.px) + mvq_bits(bqy - fp.py)));
+    unsigned pw = sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3);
+    unsigned dsad = (unsigned)wave64_sum((int)__builtin_amdgcn_sad_u8(curw, pw, 0u));
+    unsigned jinter = dsad + (unsigned)(lambda * (mvq_bits(bqx - fp.px) + mvq_bits(bqy - fp.py)));
+    // ---- 3b. partitions: every partition picks among the vectors visited above
+    int shape = 0, lvx = bqx, lvy = bqy; // the shape taken; this lane's vector
+    if (PART && refine) {
+        // key = cost << 5 | candidate (ties: the candidate visited first); per shape, this lane's partition's best
+        unsigned k8 = 0xFFFFFFFFu, k168 = 0xFFFFFFFFu, k816 = 0xFFFFFFFFu;
+#pragma unroll 1
+        for (int k = 0; k < 17; k++) {
+            const int cx = k == 0 ? imx : k < 9 ? imx + (((k - 1 < 4 ? k - 1 : k) % 3) - 1) * 2 : hbx + (((k - 9 < 4 ? k - 9 : k - 8) % 3) - 1);
+            const int cy = k == 0 ? imy : k < 9 ? imy + (((k - 1 < 4 ? k - 1 : k) / 3) - 1) * 2 : hby + (((k - 9 < 4 ? k - 9 : k - 8) / 3) - 1);
+            const unsigned bits = (unsigned)(lambda * (mvq_bits(cx - fp.px) + mvq_bits(cy - fp.py)));
+            const int c8 = k == 0 ? 0 : k < 9 ? k - 1 : k - 9;
+            const unsigned pk = k == 0 ? q0 : k < 9 ? ((c8 >> 1) == 0 ? qh[0] : (c8 >> 1) == 1 ? qh[1] : (c8 >> 1) == 2 ? qh[2] : qh[3])
+                                                    : ((c8 >> 1) == 0 ? qq[0] : (c8 >> 1) == 1 ? qq[1] : (c8 >> 1) == 2 ? qq[2] : qq[3]);
+            const unsigned sq = k == 0 ? pk : (pk >> (16 * (c8 & 1))) & 0xFFFFu;                 // this quadrant
+            const unsigned sh = sq + (unsigned)quad_xor<2>((int)sq);                              // + the quadrant beside it: the 16x8 partition
+            const unsigned sv_ = sq + (unsigned)__shfl_xor((int)sq, 32, 64);                      // + the quadrant below / above it: the 8x16 partition
+            const unsigned a = ((sq + bits) << 5) | (unsigned)k, b = ((sh + bits) << 5) | (unsigned)k, c = ((sv_ + bits) << 5) | (unsigned)k;
+            k8 = a < k8 ? a : k8; k168 = b < k168 ? b : k168; k816 = c < k816 ? c : k816;
+        }
+        // totals: one partition per group of lanes -> sum over the groups
+        const unsigned c8x8 = (k8 >> 5), c168 = (k168 >> 5), c816 = (k816 >> 5);
+        unsigned t8 = c8x8 + (unsigned)quad_xor<2>((int)c8x8); t8 += (unsigned)__shfl_xor((int)t8, 32, 64);
+        const unsigned t168 = c168 + (unsigned)__shfl_xor((int)c168, 32, 64);
+        const unsigned t816 = c816 + (unsigned)quad_xor<2>((int)c816);
+        unsigned jb = jinter + (unsigned)lambda; // header bits: 1 (16x16), 3 (16x8, 8x16), 9 (P_8x8 + four sub_mb_type)
+        unsigned key = 0;
+        const unsigned j1 = t168 + 3u * (unsigned)lambda, j2 = t816 + 3u * (unsigned)lambda, j3 = t8 + 9u * (unsigned)lambda;
+        if (j1 < jb) { jb = j1; shape = 1; key = k168; }
+        if (j2 < jb) { jb = j2; shape = 2; key = k816; }
+        if (j3 < jb) { jb = j3; shape = 3; key = k8; }
+        shape = __builtin_amdgcn_readfirstlane(shape);
+        if (shape) {
+            const int k = (int)(key & 31u);
+            lvx = k == 0 ? imx : k < 9 ? imx + (((k - 1 < 4 ? k - 1 : k) % 3) - 1) * 2 : hbx + (((k - 9 < 4 ? k - 9 : k - 8) % 3) - 1);
+            lvy = k == 0 ? imy : k < 9 ? imy + (((k - 1 < 4 ? k - 1 : k) / 3) - 1) * 2 : hby + (((k - 9 < 4 ? k - 9 : k - 8) / 3) - 1);
+            const int px_ = lvx - imx, py_ = lvy - imy;
+            pw = sp_sample4(L, 1 + (px_ >> 2) + pc, 1 + (py_ >> 2) + pr, px_ & 3, py_ & 3);
+            dsad = (unsigned)wave64_sum((int)__builtin_amdgcn_sad_u8(curw, pw, 0u));
+            jinter = jb - (unsigned)lambda; // (a partitioned macroblock pays for its longer header in the intra test too)
+        }
+    }
     // ---- 4. intra instead?
     if (ctx->intra_p && di + (unsigned)lambda * ibits >= INTRA_GATE(lambda)) {
         const uint4 dw = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES + 16); // mode16 | cmode << 8 | use_i4 << 16; cost; cost_luma; 0
@@ -714,12 +784,22 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
     }
     // ---- 5. residual
     int pd[4];
-    chroma_pred4(ctx, lane, x0, y0, W, H, bqx, bqy, pd);
+    unsigned slot = 0; // PART: this lane's dword of the luma-DC slot (lanes 0 .. 7): the vectors of partitions 1 .. 3
+    if (PART && shape) {
+        const int src = (((lane >> 4) & 1) << 5) | ((lane & 1) << 1); // a chroma lane's 4x4 block belongs to the luma quadrant (lane bit 4, lane bit 0)
+        const int cvx = __shfl(lvx, src, 64), cvy = __shfl(lvy, src, 64);
+        chroma_pred4(ctx, lane, x0, y0, W, H, cvx, cvy, pd);
+        const unsigned mine = ((unsigned)(uint16_t)lvx) | ((unsigned)(uint16_t)lvy << 16);
+        const unsigned v1 = (unsigned)__shfl((int)mine, shape == 1 ? 32 : 2, 64), v2 = (unsigned)__shfl((int)mine, 32, 64), v3 = (unsigned)__shfl((int)mine, 34, 64);
+        slot = lane == 0 ? v1 : (shape == 3 && lane == 1) ? v2 : (shape == 3 && lane == 2) ? v3 : 0u;
+        bqx = __builtin_amdgcn_readfirstlane(lvx); bqy = __builtin_amdgcn_readfirstlane(lvy); // partition 0's vector goes to the record
+    } else chroma_pred4(ctx, lane, x0, y0, W, H, bqx, bqy, pd);
     if (ctx->drop_sad && dsad < ctx->drop_sad) { // rate control's ladder below QP 51: prediction only
         pmb_store_pred_only<SC1>(ctx, lv, lane, x0, y0, pw, pd);
+        if (PART && shape && lane < 8) stx32<SC1>(lv + L_LDC + 2 * lane, slot);
         if (lane == 0) {
             mb_info_t m;
-            m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = di;
+            m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = (uint8_t)shape; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = di;
             st_mbinfo_x<SC1>(mb, m);
         }
         return;
@@ -747,10 +827,11 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
         if (dc_c & 1) nzm |= NZ_CBDC;
         if (dc_c & 2) nzm |= NZ_CRDC;
         mb_info_t m;
-        m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = nzm; m.cost = di;
+        m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = (uint8_t)shape; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = nzm; m.cost = di;
         st_mbinfo_x<SC1>(mb, m);
     }
-    if (lane < 2) stg128(lv + L_LDC + 8 * lane, make_uint4(0, 0, 0, 0)); // luma DC levels: unused by P macroblocks, kept zero
+    if (PART && shape) { if (lane < 8) stx32<SC1>(lv + L_LDC + 2 * lane, slot); } // the luma-DC slot: the vectors of partitions 1 .. 3 (the deblocker of this picture may read them behind the row counts)
+    else if (lane < 2) stg128(lv + L_LDC + 8 * lane, make_uint4(0, 0, 0, 0)); // luma DC levels: unused by P macroblocks, kept zero
 }
 
 // The launch covers macroblocks mb0 .. mb1-1, four per workgroup and turn.
@@ -771,7 +852,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
 // and resident, takes its macroblocks row by row behind them.
 // ROWS (only with GATED): the picture's deblocking launch is already on the chip and waits for this kernel's rows -- samples and records
 // are stored through to memory (sc1) and every macroblock is counted for its row.
-template <bool GATED, bool ROWS>
+template <bool GATED, bool ROWS, bool PART>
 __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine, const unsigned *__restrict__ gate_done, unsigned ref_epoch, unsigned *err, unsigned *row_done) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
@@ -809,7 +890,7 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
         tl_last(ctx, 3);
     }
     if (mbn >= mb1) return; // wave-uniform
-    pmb_mb<ROWS>(ctx, &LD[wave], mbn, lane, refine);
+    pmb_mb<ROWS, PART>(ctx, &LD[wave], mbn, lane, refine);
     if (ROWS) { // this macroblock's samples and record are in memory: count it for its row (the picture's deblocking launch, already on the chip, waits for whole rows)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(row_done + (mbn / ctx->mbw) * MI355_PROG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -869,7 +950,13 @@ void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipS
 void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, const unsigned *gate_done, unsigned ref_epoch, unsigned *d_err, unsigned *d_row_done, hipStream_t s) {
     const int n = mbw * (row1 - row0), g = (n + 3) / 4;
     if (n <= 0) return;
-    if (gate_done && d_row_done) hipLaunchKernelGGL((pmb_kernel<true, true>), dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
-    else if (gate_done) hipLaunchKernelGGL((pmb_kernel<true, false>), dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
-    else hipLaunchKernelGGL((pmb_kernel<false, false>), dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done);
+#define PMB_LAUNCH(G, R, P) hipLaunchKernelGGL((pmb_kernel<G, R, P>), dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done)
+    if (h_ctx->partitions) {
+        if (gate_done && d_row_done) PMB_LAUNCH(true, true, true);
+        else if (gate_done) PMB_LAUNCH(true, false, true);
+        else PMB_LAUNCH(false, false, true);
+    } else if (gate_done && d_row_done) PMB_LAUNCH(true, true, false);
+    else if (gate_done) PMB_LAUNCH(true, false, false);
+    else PMB_LAUNCH(false, false, false);
+#undef PMB_LAUNCH
 }

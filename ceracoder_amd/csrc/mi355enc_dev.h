@@ -87,6 +87,8 @@ typedef struct {
                                       residual is not sent */
     int32_t intra_p;               /* P macroblocks may be intra (the analysis of this picture's source is in isad / idec) */
     const int8_t *qp_off;          /* adaptive quantisation: one QP offset per macroblock (aq_kernel), or null: one QP per picture */
+    int32_t partitions;            /* P macroblocks may be split (shape in the record's i16_mode: 1 16x8, 2 8x16, 3 8x8; the vectors of partitions 1 .. 3 in the
+                                      luma-DC slot of the macroblock's levels); the deblocker then takes boundary strengths per 8x8 quadrant */
     int32_t slice_rows;            /* I pictures: a new slice every so many macroblock rows (0: one slice); the row above a slice's first row is not available (6.4.8) */
 } frame_ctx_t;
 

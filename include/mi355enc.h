@@ -104,6 +104,10 @@ typedef struct {
                                  slice boundary (6.4.8), so the slices of a picture are independent chains for the intra wavefront: an IDR picture's
                                  reconstruction takes about 1/n of the time (the deblocking filter still runs across the boundaries); the cost is the
                                  prediction lost along n - 1 rows, +0.5 % on the IDR pictures' bytes at 1080p with 4.  P pictures are one slice */
+    int partitions;           /* 0 (default): every inter macroblock is one 16x16 partition (what x264's superfast preset searches).  1: P macroblocks may be
+                                 split into 16x8, 8x16 or 8x8 partitions (x264enc: analyse / `partitions`): every partition chooses among the vectors the
+                                 macroblock's sub-sample refinement visits; rate-distortion neutral on the test clips, about 3 % fewer frames/s.  Not with
+                                 transform8x8, deblock_mode 1 or adaptive quantisation's in-order cases */
     int profile_overlap;      /* with profile_events: 0 (default) a sampled picture runs its stages strictly in order, so that every timer is one kernel
                                  alone (the picture costs the stream about two periods).  1: sampled P pictures keep the free-running schedule -- the
                                  event pairs sit on the streams the kernels are launched on, and a launch that waits on the device for another kernel's

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """dev tool: what an IDR picture costs the free-running stream, bubbles included: 600 pictures at fixed QP with key-int 60 and with key-int 600,
 same clip, pipeline_depth 2; (t60 - t600) / 9 is the wall time one IDR picture adds over a P picture.
-    python tests/devtools/gop_cost.py [qp [entropy-coding threads [aq]]]"""
+    python tests/devtools/gop_cost.py [qp [entropy-coding threads [aq] [partitions]]]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -9,14 +9,15 @@ from ceracoder_amd import enc as E, synth
 E.LIB_PATH = os.environ.get("MI355ENC_LIB", E.LIB_PATH)
 qp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # entropy-coding threads (0: the default)
-aq = len(sys.argv) > 3 and sys.argv[3] == "aq"  # adaptive quantisation
+aq = len(sys.argv) > 3 and "aq" in sys.argv[3:]  # adaptive quantisation
+parts = "partitions" in sys.argv[3:]  # inter partitions
 w, h, n = 1920, 1080, 600
 clip = list(synth.s2_frames(w, h, 16))
 bufs = [torch.from_numpy(np.concatenate([y.reshape(-1), uv.reshape(-1)])).cuda() for y, uv in clip]
 torch.cuda.synchronize()
 res = {}
 for gop in (600, 60, 600, 60, 600, 60):
-    e = E.Encoder(w, h, fps=60, gop=gop, fixed_qp=qp, pipeline_depth=2, exclusive=True, cavlc_threads=threads, aq=aq)
+    e = E.Encoder(w, h, fps=60, gop=gop, fixed_qp=qp, pipeline_depth=2, exclusive=True, cavlc_threads=threads, aq=aq, partitions=parts)
     ent = {True: [], False: []}
     def col():
         a = e.stats().ms_entropy

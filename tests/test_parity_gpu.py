@@ -695,3 +695,70 @@ def test_stage_timers_on_the_free_running_schedule_change_nothing(E):
     assert stats[0][:2] == (0, 0) and all(s[4] == 0 for s in stats)
     for n_me, n_db, ms_me, ms_db, _ in stats[1:]:
         assert n_me >= 25 and n_db >= n_me and 0.02 < ms_me / n_me < 0.5 and 0.05 < ms_db / n_db < 1.5, stats
+
+
+@pytest.mark.parametrize("w,h", SIZES + [(16, 16), (50, 34), (1920, 1088)])
+@pytest.mark.parametrize("qp,drop", [(8, 0), (20, 0), (30, 0), (40, 0), (51, 3)])
+@pytest.mark.parametrize("intra", [True, False])
+def test_fused_p_kernel_with_partitions_matches_oracle(E, oracle, w, h, qp, drop, intra):
+    """cfg.partitions: every partition of 16x8 / 8x16 / 8x8 picks among the vectors the macroblock's refinement visits (quadrant SADs left behind by the
+    same reductions that give the macroblock's), the shape with the lowest total decides, the prediction is taken with a vector per lane; shape in the
+    record's i16_mode, the vectors of partitions 1 .. 3 in the luma-DC slot of the levels -- against orc_pmb_frame with ORC_F_PART."""
+    if (w, h) == (1920, 1088) and qp != 20:
+        pytest.skip("full size: one operating point")
+    f = frames(w, h, 2)
+    (cy, cuv), (ry, ruv) = f[1][:2], f[0][:2]
+    surf, imv = _settled_field(oracle, cy, ry, qp)
+    idec = oracle.intra_decide(oracle.intra_analyse(cy, cuv), cy.shape[1] // 16, cy.shape[0] // 16, qp, False) if intra else None
+    oracle.set_features(oracle.F_ALL | oracle.F_PART)
+    try:
+        o_y, o_uv, o_mbi, o_lev, _ = oracle.pmb_frame(cy, cuv, ry, ruv, imv, surf, qp, drop=drop, refine=True, idec=idec, threads=8)
+    finally:
+        oracle.set_features(oracle.F_ALL)
+    e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp, partitions=True)
+    d_y, d_uv, d_mbi, d_lev = e.stage_pmb(cy, cuv, ry, ruv, imv, oracle.surf_to_device(surf), qp, drop=drop, refine=True, idec=idec)
+    for fld in PMB_FIELDS + ("i16_mode",):
+        assert np.array_equal(d_mbi[fld], o_mbi[fld]), (fld, first_diff(d_mbi[fld], o_mbi[fld]))
+    assert np.array_equal(d_lev, o_lev), first_diff(d_lev, o_lev)
+    assert np.array_equal(d_y, o_y), first_diff(d_y, o_y)
+    assert np.array_equal(d_uv, o_uv), first_diff(d_uv, o_uv)
+    if qp <= 30 and cy.shape[1] >= 176:
+        inter = o_mbi["mb_type"] == 1
+        assert (inter & (o_mbi["i16_mode"] != 0)).any()
+    e.close()
+
+
+@pytest.mark.parametrize("w,h,n,depth,aq", [(64, 48, 7, 0, False), (176, 144, 7, 0, False), (322, 182, 6, 1, False), (640, 368, 6, 2, True), (1280, 720, 5, 2, False), (1920, 1080, 5, 2, False),
+                                          (1920, 1080, 4, 0, True)])
+def test_partitioned_streams_equal_oracle(E, oracle, w, h, n, depth, aq):
+    """Whole path with cfg.partitions: the device's shapes and vectors, the deblocker's boundary strengths per 8x8 quadrant (vectors read from the levels'
+    luma-DC slot, behind the row counts when the stages overlap), the hand-over of that slot and the host writer's partition syntax -- access units and
+    reconstruction equal the oracle's, and the independent decoder reproduces them."""
+    qps = [24, 20, 30, 26, 34, 22, 28]
+    oracle.set_features(oracle.F_ALL | oracle.F_PART)
+    try:
+        e = E.Encoder(w, h, gop=30, fixed_qp=30, pipeline_depth=depth, exclusive=True, partitions=True, aq=aq, cavlc_threads=3)
+        oe = oracle.Encoder(w, h, gop=30, threads=8, aq=aq)
+        dec = oracle.Decoder()
+        clip = [(y, uv) for _, _, y, uv in frames(w, h, n)]
+        got = []
+        for i, (y, uv) in enumerate(clip):
+            e.set_fixed_qp(qps[i % len(qps)])
+            e.submit(y, uv, pts=i)
+            if e.pending > depth:
+                got.append(e.collect()[0])
+        while e.pending:
+            got.append(e.collect()[0])
+        split = 0
+        for i, (y, uv) in enumerate(clip):
+            ref_au, key = oe.encode(y, uv, qps[i % len(qps)])
+            assert got[i] == ref_au, ("bitstream", i, len(got[i]), len(ref_au))
+            dy, duv = dec.decode(ref_au)
+            assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv), i
+            if not key:
+                split += int(((oe.mbinfo["mb_type"] == 1) & (oe.mbinfo["i16_mode"] != 0)).sum())
+        assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y) and np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv)
+        assert split > 0 or w < 176
+        e.close()
+    finally:
+        oracle.set_features(oracle.F_ALL)
