@@ -192,7 +192,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // chain costs 10-17 us).  Not on pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
         // Every kernel-waits-for-kernel overlap below is opt-in (cfg.exclusive_device): next to another process's kernels on the same GPU a
         // kernel that waits on the device for a kernel that has not been placed yet can run into the bound of its wait.
-        const bool may_wait = overlap_allowed(h) && exclusive_device(h) && h->cfg.deblock_mode == 0 && !h->d_pre_y && !(prof && (idr || !h->cfg.profile_overlap)) && !(h->cfg.aq_mode && h->cfg.intra_in_p == 2); // (adaptive quantisation: the QP_Y chain
+        const bool may_wait = overlap_allowed(h) && exclusive_device(h) && h->cfg.deblock_mode == 0 && !h->d_pre_y && !(prof && (idr || !h->cfg.profile_overlap || !no_db2())) && !(h->cfg.aq_mode && h->cfg.intra_in_p == 2); // (adaptive quantisation: the QP_Y chain
                                                                                                                                                     // over the whole picture sits between a picture's records and its deblocking)
         const int split = !idr && fused && c->intra_p && may_wait;
         // IDR picture: the band deblocker runs on the intra stream BESIDE the intra wavefront, each of its bands waiting for the intra bands
