@@ -762,3 +762,32 @@ def test_partitioned_streams_equal_oracle(E, oracle, w, h, n, depth, aq):
         e.close()
     finally:
         oracle.set_features(oracle.F_ALL)
+
+
+@pytest.mark.parametrize("exclusive,single_stream,depth", [(False, False, 0), (False, False, 2), (True, False, 2), (False, True, 2), (True, False, 1)])
+@pytest.mark.parametrize("partitions,aq,slices", [(False, False, 0), (True, False, 3), (False, True, 2), (True, True, 0)])
+def test_schedules_and_options_give_the_oracle_stream(E, oracle, exclusive, single_stream, depth, partitions, aq, slices):
+    """The same stream whatever the schedule: kernels waiting for each other on the device (exclusive), stream order (default), one stream per
+    encoder (single_stream), one to three pictures in flight -- crossed with partitions, adaptive quantisation and sliced I pictures; 720p, so
+    that the default slice count is above one."""
+    w, h, n = 1280, 720, 5
+    qps = [26, 30, 24, 34, 28]
+    oracle.set_features(oracle.F_ALL | (oracle.F_PART if partitions else 0))
+    try:
+        e = E.Encoder(w, h, gop=3, fixed_qp=30, pipeline_depth=depth, exclusive=exclusive, single_stream=single_stream, partitions=partitions, aq=aq, intra_slices=slices)
+        oe = oracle.Encoder(w, h, gop=3, threads=8, aq=aq, intra_slices=slices)
+        clip = [(y, uv) for _, _, y, uv in frames(w, h, n)]
+        got = []
+        for i, (y, uv) in enumerate(clip):
+            e.set_fixed_qp(qps[i])
+            e.submit(y, uv, pts=i)
+            if e.pending > depth:
+                got.append(e.collect()[0])
+        while e.pending:
+            got.append(e.collect()[0])
+        for i, (y, uv) in enumerate(clip):
+            assert got[i] == oe.encode(y, uv, qps[i])[0], ("bitstream", i)
+        assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y)
+        e.close()
+    finally:
+        oracle.set_features(oracle.F_ALL)
