@@ -106,7 +106,6 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->cfg = *cfg;
     if (h->cfg.qp_min <= 0 && h->cfg.qp_max <= 0) { h->cfg.qp_min = 10; h->cfg.qp_max = 51; }
     if (h->cfg.qp_max > 51) h->cfg.qp_max = 51;
-    if (h->cfg.transform8x8) h->cfg.aq_mode = 0; // (the 8x8-transform path keeps one QP per picture)
     if (h->cfg.qp_min < 0) h->cfg.qp_min = 0;
     h->mbw = (cfg->width + 15) / 16; h->mbh = (cfg->height + 15) / 16;
     {   // slices per I picture (oracle: orc_auto_intra_slices): about 17 rows each, at most 8

@@ -89,7 +89,7 @@ void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set)
     c->iac_drop = (idr && drop > 0 && drop <= DROP_MAX) ? k_idrop_ac[drop] : 0;
     if (c->iac_drop) c->i4x4 = 0; // on the ladder: Intra_16x16 only
     c->qp_off = h->cfg.aq_mode ? h->d_qp_off[set] : nullptr;
-    c->intra_p = (h->cfg.intra_in_p && !h->cfg.transform8x8) ? (h->cfg.i4x4 && h->cfg.intra_in_p > 1 ? 2 : 1) : 0; // 2: Intra_4x4 as well
+    c->intra_p = h->cfg.intra_in_p ? (h->cfg.i4x4 && h->cfg.intra_in_p > 1 ? 2 : 1) : 0; // 2: Intra_4x4 as well
 }
 // P picture, front part (front stream): nothing here depends on the coding of the picture before
 static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof) {
@@ -99,7 +99,7 @@ static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof
     if (prof) HIPCHK(hipEventRecord(s->ev[6], st));
     k_launch_me_select_all(hc, h->mbw, 0, h->mbh, st);
     if (prof) HIPCHK(hipEventRecord(s->ev[1], st));
-    if (!h->cfg.transform8x8 && hc->intra_p) k_launch_intra_analyse(hc, h->mbw, h->mbh, 1, st);
+    if (hc->intra_p) k_launch_intra_analyse(hc, h->mbw, h->mbh, 1, st);
     if (prof) HIPCHK(hipEventRecord(s->ev[7], st));
     HIPCHK(hipGetLastError());
     return 0;
@@ -110,7 +110,7 @@ static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof
 static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split, const unsigned *gate, unsigned ref_epoch, int rows, bool fused_ip = false) {
     hipStream_t st = gate ? h->istream : h->stream;
     if (prof) HIPCHK(hipEventRecord(s->ev[8], st));
-    if (h->cfg.transform8x8) { // High profile: the two-kernel form (absolute-vector refinement, 8x8 transform), no skip / intra logic
+    if (false) { // (the two-kernel form of the High-profile path: absolute-vector refinement, 8x8 transform, no skip / intra logic -- kept for reference, reached through the stage entry points only)
         k_launch_imv_to_mbi(hc, h->mbw, 0, h->mbh, st);
         if (h->cfg.subpel) k_launch_subpel(hc, h->mbw, 0, h->mbh, st);
         if (prof) HIPCHK(hipEventRecord(s->ev[5], st));
@@ -156,7 +156,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
     // (a sampled picture runs its stages strictly in order; IDR pictures: every other one, or at the P pictures' cadence in an all-intra stream)
     const int prof = !all_skip && h->cfg.profile_events > 0 &&
                      ((idr && h->cfg.gop > 1) ? (h->idr_count & 1) == 0 : h->n_submitted % (uint64_t)h->cfg.profile_events == 0);
-    const bool fused = !h->cfg.transform8x8;
+    const bool fused = true; // (r03: the High-profile stream goes through the fused stage too; the two-kernel form remains behind the single-stage entry points)
     if (all_skip) {
         // one run of P_Skip macroblocks with the zero vector (8.4.1.1 infers it: every neighbour's vector is zero): the host
         // writes the records itself; no source sample is read, no kernel runs, the reference stays where it is

@@ -567,6 +567,114 @@ DEV void pmb_store_pred_only(const frame_ctx_t *__restrict__ ctx, int16_t *lv, i
 
 // One P macroblock on one wave (no workgroup barrier anywhere: the four waves of a workgroup are independent).
 // SC1: the reconstruction and the record are stored through to memory -- the picture's own deblocking launch reads them without a kernel boundary in between.
+// High profile: the luma residual of an inter macroblock through the 8x8 transform (oracle: tq8_block).  The wave's 256 residual samples go to an LDS tile
+// [8x8 block][row][column]; sixteen lanes -- four per block, two rows / two columns each -- run the separable passes through it (k_inter.hip has the same
+// passes for the two-kernel form); levels are stored de-interleaved the way CAVLC sends them (4x4 "block" 4 i8 + j holds scan positions 4 k + j).  Returns the
+// blkIdx mask of the sub-blocks with levels; the reconstruction is stored by all lanes.  The tile overlays the refinement's planes (dead by now).
+template <bool SC1>
+DEV unsigned pmb_luma_t8(const frame_ctx_t *__restrict__ ctx, int *tile, int lane, unsigned curw, unsigned pw, int qp, int mbn, int x0, int y0) {
+    const int pr = lane >> 2, pc = (lane & 3) * 4;
+    {
+        int *t = tile + ((pr >> 3) * 2 + (pc >> 3)) * 64 + (pr & 7) * 8 + (pc & 7);
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = byte_of(curw, i) - byte_of(pw, i);
+    }
+    WAVE_SYNC();
+    const bool act = lane < 16;
+    const int i8 = (lane >> 2) & 3, j = lane & 3;
+    int *tb = tile + i8 * 64;
+    const int m6 = qp % 6, k6 = qp / 6;
+    int rs[2][8], cw[2][8];
+    unsigned submask = 0;
+    if (act) { // rows 2j, 2j+1: first forward pass
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) rs[r][i] = tb[(2 * j + r) * 8 + i];
+            fdct8_1d(rs[r]);
+        }
+    }
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) tb[(2 * j + r) * 8 + i] = rs[r][i];
+    }
+    WAVE_SYNC();
+    if (act) { // columns 2j, 2j+1: second forward pass, quantise, scale
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) cw[c2][r] = tb[r * 8 + 2 * j + c2];
+            fdct8_1d(cw[c2]);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int xx = 2 * j + c2, cl = pos_class8(r, xx);
+                const int qbits = 16 + k6, f = (1 << qbits) / 6;
+                const int a = iabs(cw[c2][r]);
+                int l = (int)(((long long)a * g_tab.mf8[m6][cl] + f) >> qbits);
+                l = l > 2047 ? 2047 : l;
+                l = cw[c2][r] < 0 ? -l : l;
+                const int kk = g_tab.izz8[r * 8 + xx];
+                stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + (4 * i8 + (kk & 3)) * 16 + (kk >> 2)], l);
+                if (l) submask |= 1u << (kk & 3);
+                const int ls = 16 * g_tab.v8[m6][cl];
+                cw[c2][r] = qp >= 36 ? (l * ls) << (k6 - 6) : (l * ls + (1 << (5 - k6))) >> (6 - k6);
+            }
+        }
+    }
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) tb[r * 8 + 2 * j + c2] = cw[c2][r];
+    }
+    submask |= (unsigned)quad_xor<1>((int)submask); // the 8x8 block's four lanes
+    submask |= (unsigned)quad_xor<2>((int)submask);
+    WAVE_SYNC();
+    if (act) { // 8.5.13: rows first ...
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) rs[r][i] = tb[(2 * j + r) * 8 + i];
+            idct8_1d(rs[r]);
+        }
+    }
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) tb[(2 * j + r) * 8 + i] = rs[r][i];
+    }
+    WAVE_SYNC();
+    if (act) { // ... then columns, rounding
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+#pragma unroll
+            for (int r = 0; r < 8; r++) cw[c2][r] = tb[r * 8 + 2 * j + c2];
+            idct8_1d(cw[c2]);
+        }
+    }
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+            for (int r = 0; r < 8; r++) tb[r * 8 + 2 * j + c2] = (cw[c2][r] + 32) >> 6;
+    }
+    WAVE_SYNC();
+    {
+        const int *t = tile + ((pr >> 3) * 2 + (pc >> 3)) * 64 + (pr & 7) * 8 + (pc & 7);
+        int o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = clip255(byte_of(pw, i) + t[i]);
+        stx32<SC1>(ctx->rec_y + (size_t)(y0 + pr) * ctx->stride + x0 + pc, pack4(o[0], o[1], o[2], o[3]));
+    }
+    return (unsigned)(__ballot(act && ((submask >> j) & 1u)) & 0xFFFFull); // lane 4 i8 + j reports sub-block j = blkIdx 4 i8 + j
+}
 // PART: partitions (oracle: ORC_F_PART).  A lane owns four samples of row lane >> 2, columns 4 (lane & 3) ..: its 8x8 quadrant is (lane >> 5, (lane >> 1) & 1), and a
 // quadrant's lanes differ in lane bits 0, 2, 3, 4.  Every candidate vector the refinement visits leaves the SAD of each quadrant behind (the wave-wide sum is
 // built from the quadrant sums, so they cost nothing); afterwards every partition of every shape picks the visited vector with the lowest SAD + lambda * bits,
@@ -579,7 +687,7 @@ DEV unsigned part_gsum(unsigned v) { // sum over the lanes of this lane's quadra
     return v;
 }
 DEV unsigned part_total(unsigned g) { g += (unsigned)quad_xor<2>((int)g); return g + (unsigned)__shfl_xor((int)g, 32, 64); } // the four quadrants' sums -> the macroblock's
-template <bool SC1, bool PART>
+template <bool SC1, bool PART, bool T8>
 DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, const int lane, const int refine) {
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = mb_qp_dev(ctx, mbn), lambda = ctx->lambda; // (quantisation only: search, refinement and decisions keep the picture's lambda)
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
@@ -805,7 +913,10 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
         return;
     }
     unsigned nz_luma;
-    {
+    if (T8) {
+        nz_luma = pmb_luma_t8<SC1>(ctx, (int *)L, lane, curw, pw, qp, mbn, x0, y0);
+        // the sub-blocks without levels keep their zeros: the macroblock's levels are cleared first
+    } else {
         const int fy = ((py & 1) << 1) | (py >> 1);
         const col_bf cb = make_col_bf(py);
         const int kz0 = (int)((0xFEA9DB83C7426510ull >> (16 * fy)) & 0xFFFF);
@@ -826,6 +937,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
         unsigned nzm = nz_luma | (nz_c << 16);
         if (dc_c & 1) nzm |= NZ_CBDC;
         if (dc_c & 2) nzm |= NZ_CRDC;
+        if (T8 && nz_luma) nzm |= NZ_T8; // transform_size_8x8_flag: sent (and read by the deblocker) only with luma levels
         mb_info_t m;
         m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = (uint8_t)shape; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = nzm; m.cost = di;
         st_mbinfo_x<SC1>(mb, m);
@@ -852,7 +964,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
 // and resident, takes its macroblocks row by row behind them.
 // ROWS (only with GATED): the picture's deblocking launch is already on the chip and waits for this kernel's rows -- samples and records
 // are stored through to memory (sc1) and every macroblock is counted for its row.
-template <bool GATED, bool ROWS, bool PART>
+template <bool GATED, bool ROWS, bool PART, bool T8>
 __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0, int mb1, int refine, const unsigned *__restrict__ gate_done, unsigned ref_epoch, unsigned *err, unsigned *row_done) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ __attribute__((aligned(16))) sp_lds LD[4];
@@ -890,7 +1002,7 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
         tl_last(ctx, 3);
     }
     if (mbn >= mb1) return; // wave-uniform
-    pmb_mb<ROWS, PART>(ctx, &LD[wave], mbn, lane, refine);
+    pmb_mb<ROWS, PART, T8>(ctx, &LD[wave], mbn, lane, refine);
     if (ROWS) { // this macroblock's samples and record are in memory: count it for its row (the picture's deblocking launch, already on the chip, waits for whole rows)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(row_done + (mbn / ctx->mbw) * MI355_PROG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -950,13 +1062,17 @@ void k_launch_subpel(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipS
 void k_launch_pmb(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, int refine, const unsigned *gate_done, unsigned ref_epoch, unsigned *d_err, unsigned *d_row_done, hipStream_t s) {
     const int n = mbw * (row1 - row0), g = (n + 3) / 4;
     if (n <= 0) return;
-#define PMB_LAUNCH(G, R, P) hipLaunchKernelGGL((pmb_kernel<G, R, P>), dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done)
-    if (h_ctx->partitions) {
-        if (gate_done && d_row_done) PMB_LAUNCH(true, true, true);
-        else if (gate_done) PMB_LAUNCH(true, false, true);
-        else PMB_LAUNCH(false, false, true);
-    } else if (gate_done && d_row_done) PMB_LAUNCH(true, true, false);
-    else if (gate_done) PMB_LAUNCH(true, false, false);
-    else PMB_LAUNCH(false, false, false);
+#define PMB_LAUNCH(G, R, P, T) hipLaunchKernelGGL((pmb_kernel<G, R, P, T>), dim3(g), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, refine, gate_done, ref_epoch, d_err, d_row_done)
+    if (h_ctx->t8) { // High profile: 8x8 transform for the inter macroblocks' luma (no partitions on this path)
+        if (gate_done && d_row_done) PMB_LAUNCH(true, true, false, true);
+        else if (gate_done) PMB_LAUNCH(true, false, false, true);
+        else PMB_LAUNCH(false, false, false, true);
+    } else if (h_ctx->partitions) {
+        if (gate_done && d_row_done) PMB_LAUNCH(true, true, true, false);
+        else if (gate_done) PMB_LAUNCH(true, false, true, false);
+        else PMB_LAUNCH(false, false, true, false);
+    } else if (gate_done && d_row_done) PMB_LAUNCH(true, true, false, false);
+    else if (gate_done) PMB_LAUNCH(true, false, false, false);
+    else PMB_LAUNCH(false, false, false, false);
 #undef PMB_LAUNCH
 }

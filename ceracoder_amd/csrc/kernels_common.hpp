@@ -100,6 +100,33 @@ DEV int mb_qp_dev(const frame_ctx_t *ctx, int mbn) {
     return q < 0 ? 0 : (q > 51 ? 51 : q);
 }
 
+// 8-point transforms of the High-profile 8x8 residual path: forward (encoder side) and 8.5.13 inverse
+DEV void fdct8_1d(int *v) {
+    const int s07 = v[0] + v[7], s16 = v[1] + v[6], s25 = v[2] + v[5], s34 = v[3] + v[4];
+    const int a0 = s07 + s34, a1 = s16 + s25, a2 = s07 - s34, a3 = s16 - s25;
+    const int d07 = v[0] - v[7], d16 = v[1] - v[6], d25 = v[2] - v[5], d34 = v[3] - v[4];
+    const int a4 = d16 + d25 + (d07 + (d07 >> 1)), a5 = d07 - d34 - (d25 + (d25 >> 1));
+    const int a6 = d07 + d34 - (d16 + (d16 >> 1)), a7 = d16 - d25 + (d34 + (d34 >> 1));
+    v[0] = a0 + a1; v[1] = a4 + (a7 >> 2); v[2] = a2 + (a3 >> 1); v[3] = a5 + (a6 >> 2);
+    v[4] = a0 - a1; v[5] = a6 - (a5 >> 2); v[6] = (a2 >> 1) - a3; v[7] = (a4 >> 2) - a7;
+}
+DEV void idct8_1d(int *v) {
+    const int a0 = v[0] + v[4], a2 = v[0] - v[4], a4 = (v[2] >> 1) - v[6], a6 = (v[6] >> 1) + v[2];
+    const int b0 = a0 + a6, b2 = a2 + a4, b4 = a2 - a4, b6 = a0 - a6;
+    const int a1 = -v[3] + v[5] - v[7] - (v[7] >> 1), a3 = v[1] + v[7] - v[3] - (v[3] >> 1);
+    const int a5 = -v[1] + v[7] + v[5] + (v[5] >> 1), a7 = v[3] + v[5] + v[1] + (v[1] >> 1);
+    const int b1 = (a7 >> 2) + a1, b3 = a3 + (a5 >> 2), b5 = (a3 >> 2) - a5, b7 = a7 - (a1 >> 2);
+    v[0] = b0 + b7; v[1] = b2 + b5; v[2] = b4 + b3; v[3] = b6 + b1;
+    v[4] = b6 - b1; v[5] = b4 - b3; v[6] = b2 - b5; v[7] = b0 - b7;
+}
+DEV int pos_class8(int y, int x) { // 8.5.9
+    if (!(y & 3) && !(x & 3)) return 0;
+    if ((y & 1) && (x & 1)) return 1;
+    if ((y & 3) == 2 && (x & 3) == 2) return 2;
+    if ((!(y & 3) && (x & 1)) || ((y & 1) && !(x & 3))) return 3;
+    if ((!(y & 3) && (x & 3) == 2) || ((y & 3) == 2 && !(x & 3))) return 4;
+    return 5;
+}
 // 6.4.8 for the row above: another slice's macroblocks are not available (I pictures cut into slices of ctx->slice_rows rows; oracle: top_ok)
 DEV bool row_has_top(const frame_ctx_t *ctx, int my) { return my > 0 && (ctx->slice_rows <= 0 || my % ctx->slice_rows != 0); }
 // where the last of the ME_ITERS selection iterations leaves the whole-sample vector field (they walk imv_a -> imv_b -> imv_c -> imv_a ...)

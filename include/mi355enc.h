@@ -93,7 +93,7 @@ typedef struct {
                                  variance of its source samples (flat areas finer, busy texture coarser), coded with mb_qp_delta.  The QP_Y of
                                  macroblocks that send no mb_qp_delta is that of the macroblock before them (7.4.5), which the deblocker reads: a
                                  chain over the whole picture, resolved row by row by the first workgroup of the deblocking launch behind the same
-                                 progress its bands wait for (r03; about 2 % fewer frames/s).  Not with transform8x8; with intra_in_p = 2 the
+                                 progress its bands wait for (r03; about 2 % fewer frames/s).  With intra_in_p = 2 the
                                  kernels of a picture run in stream order */
     int single_stream;        /* 0 (default): four HIP streams per encoder (front / main / intra / hand-over), so that a picture's independent stages and
                                  consecutive pictures overlap.  1: everything on ONE stream, in order -- for many encoders on one GPU (several in a

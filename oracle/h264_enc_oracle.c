@@ -1367,7 +1367,8 @@ void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *r
             int ncand = 0, candx[17], candy[17];
             uint32_t candq[17][4];
 #define PART_VISIT(qx_, qy_) do { if (feat & ORC_F_PART) { candx[ncand] = (qx_); candy[ncand] = (qy_); \
-                for (int q_ = 0; q_ < 4; q_++) candq[ncand][q_] = sad_part(sy + (size_t)((q_ >> 1) * 8) * stride + (q_ & 1) * 8, stride, pred + (q_ >> 1) * 128 + (q_ & 1) * 8, 8, 8); ncand++; } } while (0)
+                for (int q_ = 0; q_ < 4; q_++) { candq[ncand][q_] = sad_part(sy + (size_t)((q_ >> 1) * 8) * stride + (q_ & 1) * 8, stride, pred + (q_ >> 1) * 128 + (q_ & 1) * 8, 8, 8); } \
+                ncand++; } } while (0)
             PART_VISIT(bx, by);
             if (refine)
                 for (int step = 2; step >= 1; step--) {
@@ -1446,12 +1447,20 @@ void orc_pmb_frame(const uint8_t *src_y, const uint8_t *src_uv, const uint8_t *r
                     if (i) { lev[ORC_L_LDC + 2 * (i - 1)] = (int16_t)pvx[i]; lev[ORC_L_LDC + 2 * (i - 1) + 1] = (int16_t)pvy[i]; }
                 }
             if (tdrop && (shape ? sad16(sy, stride, pred) : dsad) < tdrop) continue; /* rate control's ladder below QP 51: prediction only */
+            if (g_orc_t8) { /* High profile: every P_L0_16x16 macroblock through the 8x8 transform (encoder choice; no coefficient decimation on this path) */
+                for (int i8 = 0; i8 < 4; i8++) {
+                    const size_t o = (size_t)(y0 + (i8 >> 1) * 8) * stride + x0 + (i8 & 1) * 8;
+                    m->nzmask |= (uint32_t)tq8_block(src_y + o, rec_y + o, stride, mqp, lev + ORC_L_LUMA + i8 * 64) << (4 * i8);
+                }
+                if (m->nzmask & 0xFFFF) m->nzmask |= ORC_NZ_T8; /* transform_size_8x8_flag is only sent (and only matters) with luma cbp != 0 */
+            } else {
             m->nzmask = inter_luma_tq(sy, stride, pred, mqp, (feat & ORC_F_DECIMATE) != 0, lev + ORC_L_LUMA);
             for (int b = 0; b < 16; b++) {
                 if (!(m->nzmask & (1u << b))) continue;
                 int32_t d[16];
                 dq_block(lev + ORC_L_LUMA + b * 16, mqp, 0, 0, 0, d);
                 orc_idct4_add(d, rec_y + (size_t)(y0 + k_blk_y[b]) * stride + x0 + k_blk_x[b], stride);
+            }
             }
             inter_chroma_tq_recon(src_uv, rec_uv, stride, x0 / 2, y0 / 2, mqp, (feat & ORC_F_DECIMATE) != 0, lev, &m->nzmask, 0);
         }
@@ -1998,7 +2007,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
         memcpy(e->pre_uv, e->rec_uv[nxt], ysz / 2);
     } else {
         load_padded(e, y, y_stride, uv, uv_stride);
-        if (e->aq && !g_orc_t8) { orc_aq_offsets(e->src_y, e->stride, e->mbw, e->mbh, e->aq_off); g_aq = e->aq_off; }
+        if (e->aq) { orc_aq_offsets(e->src_y, e->stride, e->mbw, e->mbh, e->aq_off); g_aq = e->aq_off; }
         {
             const int ns = e->intra_slices > 0 ? e->intra_slices : orc_auto_intra_slices(e->mbh);
             g_slice_rows = (idr && ns > 1) ? (e->mbh + ns - 1) / ns : 0;
@@ -2016,16 +2025,8 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
                     orc_me_select(e->surf, e->mbw, e->mbh, e->me_range, qp, e->imv, e->imv2, e->threads);
                     orc_imv_t *t = e->imv; e->imv = e->imv2; e->imv2 = t;
                 }
-            if (g_orc_t8) { /* High-profile path: the two-stage form (refinement with absolute-vector cost, 8x8 transform), no intra / skip logic */
-                const int lam = orc_me_lambda(qp);
-                for (int i = 0; i < nmb; i++) {
-                    e->mbi[i].mvx = e->imv[i].mvx; e->mbi[i].mvy = e->imv[i].mvy;
-                    e->mbi[i].cost = e->imv[i].sad + (uint32_t)(lam * (se_bits(e->imv[i].mvx) + se_bits(e->imv[i].mvy))); /* refinement compares absolute-vector costs */
-                }
-                if (e->subpel) orc_subpel_frame(e->src_y, e->rec_y[e->cur], e->stride, e->mbw, e->mbh, qp, e->mbi, e->threads);
-                orc_inter_frame(e->src_y, e->src_uv, e->rec_y[e->cur], e->rec_uv[e->cur], e->rec_y[nxt], e->rec_uv[nxt],
-                                e->stride, e->mbw, e->mbh, qp, e->mbi, e->levels);
-            } else {
+            { /* (r03: the High-profile stream goes through the fused stage as well -- skip probe, refinement against the predictor estimates, intra macroblocks --
+               * with the 8x8 transform for the luma residual of its inter macroblocks; the two-stage form, orc_subpel_frame + orc_inter_frame, remains as stage functions) */
                 const int intra_p = (g_orc_feat & ORC_F_INTRAP) != 0;
                 if (intra_p) {
                     orc_intra_analyse(e->src_y, e->src_uv, e->stride, e->mbw, e->mbh, e->isad);

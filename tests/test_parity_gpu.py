@@ -791,3 +791,43 @@ def test_schedules_and_options_give_the_oracle_stream(E, oracle, exclusive, sing
         e.close()
     finally:
         oracle.set_features(oracle.F_ALL)
+
+
+@pytest.mark.parametrize("w,h,n,depth,aq", [(322, 182, 7, 0, False), (640, 368, 8, 1, True), (1280, 720, 6, 2, False), (1920, 1080, 6, 2, True)])
+def test_high_profile_stream_through_the_fused_stage_equals_oracle(E, oracle, w, h, n, depth, aq):
+    """transform8x8=1 since r03: the fused P stage (skip probe, refinement against the predictor estimates, intra macroblocks, the drop ladder) with the 8x8
+    transform for the luma residual of the inter macroblocks (pmb_luma_t8), overlapped like the Baseline stream; a clip with a cut, so that P pictures
+    carry intra macroblocks; with and without adaptive quantisation.  Access units, reconstruction and the independent decoder agree; 8x8-transform,
+    skipped and intra macroblocks all occur."""
+    oracle.set_transform8x8(True)
+    try:
+        from tests.util import half_static_clip
+        clip = half_static_clip(w, h, n, (h // 3) & ~15)
+        qps = [28, 24, 32, 51, 26, 30, 22, 36]
+        e = E.Encoder(w, h, gop=30, fixed_qp=30, transform8x8=True, pipeline_depth=depth, exclusive=True, scenecut=False, aq=aq)
+        oe = oracle.Encoder(w, h, gop=30, threads=8, scenecut=False, aq=aq)
+        dec = oracle.Decoder()
+        got = []
+        for i, (y, uv) in enumerate(clip):
+            e.set_fixed_qp(qps[i % 8])
+            e.submit(y, uv, pts=i)
+            if e.pending > depth:
+                got.append(e.collect()[0])
+        while e.pending:
+            got.append(e.collect()[0])
+        t8 = skip = intra = 0
+        for i, (y, uv) in enumerate(clip):
+            ref_au, key = oe.encode(y, uv, qps[i % 8])
+            assert got[i] == ref_au, ("bitstream", i, len(got[i]), len(ref_au))
+            dy, duv = dec.decode(ref_au)
+            assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv), i
+            if not key:
+                m = oe.mbinfo
+                t8 += int(((m["nzmask"] >> 27) & 1).sum())
+                intra += int((m["mb_type"] != 1).sum())
+                skip += int(((m["mb_type"] == 1) & (m["nzmask"] == 0)).sum())
+        assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y) and np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv)
+        assert t8 > 0 and skip > 0, (t8, skip, intra)
+        e.close()
+    finally:
+        oracle.set_transform8x8(False)
