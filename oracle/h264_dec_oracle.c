@@ -10,7 +10,7 @@
  * byte stream that /root/reference/src/ceracoder.c:297-339 forwards over SRT).
  *
  * Supported: Baseline-style streams -- CAVLC, frame macroblocks, I/P slices (several per
- * picture allowed), I4x4, I16x16, P_L0_16x16, P_L0_L0_16x8, P_L0_L0_8x16, P_8x8 with sub_mb_type P_L0_8x8,
+ * picture allowed), I4x4, I8x8 (transform_size_8x8_flag of an I_NxN macroblock), I16x16, P_L0_16x16, P_L0_L0_16x8, P_L0_L0_8x16, P_8x8 with sub_mb_type P_L0_8x8,
  * P_Skip, quarter-sample luma motion, one
  * reference picture, in-loop filter with all three disable_deblocking_filter_idc values.
  * Anything else sets an error string and returns < 0.
@@ -551,6 +551,82 @@ static void pred_i4(orc_dec_t *d, int X, int Y, int mode, int has_up, int has_le
         }
 }
 
+/* 8.3.2.2: Intra_8x8 prediction of the block at (X, Y); the neighbouring samples are filtered first (8.3.2.2.1) */
+static void pred_i8(orc_dec_t *d, int X, int Y, int mode, int has_up, int has_left, int has_ul, int has_ur, int *err) {
+    int raw_t[16], raw_l[8], corner = 0, pt[16], pl[8], pc = 0; /* p[x,-1], p[-1,y], p[-1,-1] and their filtered forms */
+    if (has_ul) corner = DY(d, X - 1, Y - 1);
+    for (int x = 0; x < 16; x++) raw_t[x] = has_up ? (x < 8 || has_ur ? DY(d, X + x, Y - 1) : DY(d, X + 7, Y - 1)) : 0;
+    for (int y = 0; y < 8; y++) raw_l[y] = has_left ? DY(d, X - 1, Y + y) : 0;
+    memset(pt, 0, sizeof pt); memset(pl, 0, sizeof pl);
+    if (has_up) {
+        pt[0] = has_ul ? (corner + 2 * raw_t[0] + raw_t[1] + 2) >> 2 : (3 * raw_t[0] + raw_t[1] + 2) >> 2;
+        for (int x = 1; x < 15; x++) pt[x] = (raw_t[x - 1] + 2 * raw_t[x] + raw_t[x + 1] + 2) >> 2;
+        pt[15] = (raw_t[14] + 3 * raw_t[15] + 2) >> 2;
+    }
+    if (has_left) {
+        pl[0] = has_ul ? (corner + 2 * raw_l[0] + raw_l[1] + 2) >> 2 : (3 * raw_l[0] + raw_l[1] + 2) >> 2;
+        for (int y = 1; y < 7; y++) pl[y] = (raw_l[y - 1] + 2 * raw_l[y] + raw_l[y + 1] + 2) >> 2;
+        pl[7] = (raw_l[6] + 3 * raw_l[7] + 2) >> 2;
+    }
+    if (has_ul) {
+        if (has_up && has_left) pc = (raw_t[0] + 2 * corner + raw_l[0] + 2) >> 2;
+        else if (has_up) pc = (3 * corner + raw_t[0] + 2) >> 2;
+        else if (has_left) pc = (3 * corner + raw_l[0] + 2) >> 2;
+        else pc = corner;
+    }
+    const int need_up = mode == 0 || mode == 3 || mode == 7, need_left = mode == 1 || mode == 8, need_all = mode >= 4 && mode <= 6;
+    if ((need_up && !has_up) || (need_left && !has_left) || (need_all && !(has_up && has_left && has_ul)) || mode > 8) { *err = 1; return; }
+#define PT(x) ((x) < 0 ? pc : pt[x])  /* p'[x,-1], x = -1 .. 15 */
+#define PL(y) ((y) < 0 ? pc : pl[y])  /* p'[-1,y], y = -1 .. 7 */
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) {
+            int v;
+            switch (mode) {
+            case 0: v = PT(x); break;
+            case 1: v = PL(y); break;
+            case 2: {
+                int s = 0;
+                if (has_up) for (int i = 0; i < 8; i++) s += pt[i];
+                if (has_left) for (int i = 0; i < 8; i++) s += pl[i];
+                v = has_up && has_left ? (s + 8) >> 4 : has_up || has_left ? (s + 4) >> 3 : 128;
+                break; }
+            case 3: v = x == 7 && y == 7 ? (PT(14) + 3 * PT(15) + 2) >> 2 : (PT(x + y) + 2 * PT(x + y + 1) + PT(x + y + 2) + 2) >> 2; break;
+            case 4:
+                if (x > y) v = (PT(x - y - 2) + 2 * PT(x - y - 1) + PT(x - y) + 2) >> 2;
+                else if (x < y) v = (PL(y - x - 2) + 2 * PL(y - x - 1) + PL(y - x) + 2) >> 2;
+                else v = (PT(0) + 2 * pc + PL(0) + 2) >> 2;
+                break;
+            case 5: {
+                int z = 2 * x - y;
+                if (z >= 0 && (z & 1) == 0) v = (PT(x - (y >> 1) - 1) + PT(x - (y >> 1)) + 1) >> 1;
+                else if (z >= 0) v = (PT(x - (y >> 1) - 2) + 2 * PT(x - (y >> 1) - 1) + PT(x - (y >> 1)) + 2) >> 2;
+                else if (z == -1) v = (PL(0) + 2 * pc + PT(0) + 2) >> 2;
+                else v = (PL(y - 2 * x - 1) + 2 * PL(y - 2 * x - 2) + PL(y - 2 * x - 3) + 2) >> 2;
+                break; }
+            case 6: {
+                int z = 2 * y - x;
+                if (z >= 0 && (z & 1) == 0) v = (PL(y - (x >> 1) - 1) + PL(y - (x >> 1)) + 1) >> 1;
+                else if (z >= 0) v = (PL(y - (x >> 1) - 2) + 2 * PL(y - (x >> 1) - 1) + PL(y - (x >> 1)) + 2) >> 2;
+                else if (z == -1) v = (PL(0) + 2 * pc + PT(0) + 2) >> 2;
+                else v = (PT(x - 2 * y - 1) + 2 * PT(x - 2 * y - 2) + PT(x - 2 * y - 3) + 2) >> 2;
+                break; }
+            case 7:
+                v = (y & 1) == 0 ? (PT(x + (y >> 1)) + PT(x + (y >> 1) + 1) + 1) >> 1 : (PT(x + (y >> 1)) + 2 * PT(x + (y >> 1) + 1) + PT(x + (y >> 1) + 2) + 2) >> 2;
+                break;
+            default: {
+                int z = x + 2 * y;
+                if (z > 13) v = pl[7];
+                else if (z == 13) v = (pl[6] + 3 * pl[7] + 2) >> 2;
+                else if ((z & 1) == 0) v = (PL(y + (x >> 1)) + PL(y + (x >> 1) + 1) + 1) >> 1;
+                else v = (PL(y + (x >> 1)) + 2 * PL(y + (x >> 1) + 1) + PL(y + (x >> 1) + 2) + 2) >> 2;
+                break; }
+            }
+            DY(d, X + x, Y + y) = (uint8_t)v;
+        }
+#undef PT
+#undef PL
+}
+
 /* ---------------------------------------------------------------- inter prediction (8.4.2.2) */
 static int rpx(const orc_dec_t *d, int x, int y) {
     int W = d->mbw * 16, H = d->mbh * 16;
@@ -727,10 +803,25 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
         if (d->t8_mode && (cbp & 15)) m->t8 = (int8_t)rd_bit(d);
     } else {
         m->kind = 0;
-        if (t == 0) { m->is_i4 = 1; if (d->t8_mode && rd_bit(d)) return fail(d, "Intra_8x8 unsupported"); }
+        if (t == 0) { m->is_i4 = 1; if (d->t8_mode) m->t8 = (int8_t)rd_bit(d); } /* transform_size_8x8_flag: Intra_8x8 (is_i4 with t8) or Intra_4x4 */
         else if (t <= 24) { i16 = 1; i16mode = (t - 1) & 3; cbp = (((t - 1) >> 2) % 3) << 4 | (t > 12 ? 15 : 0); }
         else return fail(d, "I_PCM / mb_type %d unsupported", t);
-        if (m->is_i4) {
+        if (m->is_i4 && m->t8) {
+            /* 8.3.2.1: the four Intra8x8PredMode, each predicted from the blocks left and above -- an Intra_4x4 neighbour contributes the mode of its 4x4
+             * block 4 n + 1 (left) / 4 n + 2 (above), an Intra_8x8 one its own (i4mode holds an 8x8 block's mode at all four of its 4x4 positions) */
+            for (int b8 = 0; b8 < 4; b8++) {
+                int ma = -1, mb_ = -1;
+                const int la = (b8 + 1) * 4 + 1, lb = (b8 + 2) * 4 + 2; /* luma4x4BlkIdx in the neighbouring macroblock */
+                if (b8 & 1) ma = m->i4mode[((b8 >> 1) * 2) * 4 + 0];
+                else if (intra_nb_ok(d, mx - 1, my, slice)) { const dmb_t *n = m - 1; ma = n->is_i4 ? n->i4mode[D_blky[la] * 4 + D_blkx[la]] : 2; }
+                if (b8 >> 1) mb_ = m->i4mode[0 * 4 + (b8 & 1) * 2];
+                else if (intra_nb_ok(d, mx, my - 1, slice)) { const dmb_t *n = m - d->mbw; mb_ = n->is_i4 ? n->i4mode[D_blky[lb] * 4 + D_blkx[lb]] : 2; }
+                int pred = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode;
+                if (rd_bit(d)) mode = pred;
+                else { int rem = (int)rd_bits(d, 3); mode = rem < pred ? rem : rem + 1; }
+                for (int j = 0; j < 4; j++) m->i4mode[((b8 >> 1) * 2 + (j >> 1)) * 4 + (b8 & 1) * 2 + (j & 1)] = (uint8_t)mode;
+            }
+        } else if (m->is_i4) {
             /* 8.3.1.1 mode prediction */
             for (int b = 0; b < 16; b++) {
                 int bx = D_blkx[b], by = D_blky[b];
@@ -788,6 +879,14 @@ static int decode_mb(orc_dec_t *d, int mx, int my, int slice, int is_p, int skip
     }
     if (m->t8) { /* 7.3.5.3.2: each 8x8 block arrives as four interleaved 4x4 CAVLC blocks; 8.5.13 reconstruction */
         for (int i8 = 0; i8 < 4; i8++) {
+            if (m->is_i4) { /* Intra_8x8: the block is predicted from what has been reconstructed so far, residual or not */
+                int err = 0;
+                const int up = i8 >= 2 || intra_nb_ok(d, mx, my - 1, slice), lf = (i8 & 1) || intra_nb_ok(d, mx - 1, my, slice);
+                const int ul = i8 == 0 ? intra_nb_ok(d, mx - 1, my - 1, slice) : i8 == 1 ? intra_nb_ok(d, mx, my - 1, slice) : i8 == 2 ? intra_nb_ok(d, mx - 1, my, slice) : 1;
+                const int ur = i8 == 0 ? intra_nb_ok(d, mx, my - 1, slice) : i8 == 1 ? intra_nb_ok(d, mx + 1, my - 1, slice) : i8 == 2;
+                pred_i8(d, mx * 16 + (i8 & 1) * 8, my * 16 + (i8 >> 1) * 8, m->i4mode[((i8 >> 1) * 2) * 4 + (i8 & 1) * 2], up, lf, ul, ur, &err);
+                if (err) return fail(d, "I8x8 mode needs an unavailable neighbour");
+            }
             if (!(cbp & (1 << i8))) continue;
             int lev8[64], any = 0;
             memset(lev8, 0, sizeof lev8);

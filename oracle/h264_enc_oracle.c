@@ -330,12 +330,12 @@ int orc_zigzag8(int k) { return k_zigzag8[k]; }
 /* One 8x8 luma block of an inter macroblock: transform, quantise, reconstruct in place over the prediction.
  * Levels are stored de-interleaved the way CAVLC transmits them (7.3.5.3.2): 4x4 "block" 4*i8+j holds
  * scan positions 4k+j, k = 0..15.  Returns the 4-bit mask of non-zero sub-blocks. */
-static int tq8_block(const uint8_t *src, uint8_t *rec, int stride, int qp, int16_t *lev4 /* 4 x 16 */) {
+static int tq8_block_i(const uint8_t *src, uint8_t *rec, int stride, int qp, int intra, int16_t *lev4 /* 4 x 16 */) {
     int res[64], co[64], dq[64], out[64], mask = 0;
     for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) res[y * 8 + x] = src[(size_t)y * stride + x] - rec[(size_t)y * stride + x];
     orc_fdct8(res, co);
     for (int k = 0; k < 64; k++) {
-        int pos = k_zigzag8[k], l = orc_quant8(co[pos], qp, pos, 0);
+        int pos = k_zigzag8[k], l = orc_quant8(co[pos], qp, pos, intra);
         lev4[(k & 3) * 16 + (k >> 2)] = (int16_t)l;
         if (l) mask |= 1 << (k & 3);
         dq[pos] = orc_dequant8(l, qp, pos);
@@ -347,6 +347,8 @@ static int tq8_block(const uint8_t *src, uint8_t *rec, int stride, int qp, int16
     }
     return mask;
 }
+
+static int tq8_block(const uint8_t *src, uint8_t *rec, int stride, int qp, int16_t *lev4) { return tq8_block_i(src, rec, stride, qp, 0, lev4); }
 
 /* residual of one 4x4 block -> levels in zig-zag order; returns 1 if any level (from `first`) != 0 */
 static int tq_block(const int16_t res[16], int qp, int intra, int first, int16_t lev_zz[16], int16_t *dc_out) {
@@ -954,6 +956,149 @@ static void intra4x4_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int
     }
 }
 
+/* ================================================================== Intra_8x8 (High profile; I pictures of a stream with transform_8x8_mode)
+ * 8.3.2: four 8x8 luma blocks per macroblock, nine modes each, predicted from reference samples that are low-pass filtered first (8.3.2.2.1).
+ * Encoder side (r03): open-loop SADs on source neighbours like Intra_4x4, decision per block = SAD + lambda * (1 when the mode is the expected one,
+ * else 4) with the expected mode taken inside the macroblock (neighbours outside count as DC), macroblock taken as Intra_8x8 when that total + 10 lambda
+ * is strictly below what Intra_16x16 / Intra_4x4 left.  The record is mb_type 2 with ORC_NZ_T8 set (whatever its levels), the four modes in
+ * lev[ORC_L_LDC + 0..3], the levels de-interleaved like the inter macroblocks' 8x8 blocks. */
+static int g_orc_i8x8 = 0; /* process-wide: try Intra_8x8 where the stream has the 8x8 transform */
+void orc_set_i8x8(int on) { g_orc_i8x8 = on; }
+int orc_get_i8x8(void) { return g_orc_i8x8; }
+/* availability of the neighbours of 8x8 block b (raster) of a macroblock with has_top / has_left / has_tr */
+static void blk8_avail(int b, int has_top, int has_left, int has_tr, int *up, int *lf, int *ul, int *ur) {
+    *up = b >= 2 || has_top; *lf = (b & 1) || has_left;
+    *ul = b == 0 ? (has_top && has_left) : b == 1 ? has_top : b == 2 ? has_left : 1;
+    *ur = b == 0 ? has_top : b == 1 ? has_tr : b == 2 ? 1 : 0;
+}
+/* the 25 reference samples of the 8x8 block at (X, Y) of plane p, filtered (8.3.2.2.1): top[0] = p'[-1,-1], top[1 + x] = p'[x,-1] (x = 0..15), left[y] = p'[-1,y] */
+static void i8_refs(const uint8_t *p, int stride, int X, int Y, int up, int lf, int ul, int ur, int top[17], int left[8]) {
+    int c = ul ? p[(size_t)(Y - 1) * stride + X - 1] : 0, t[16], l[8];
+    for (int x = 0; x < 8; x++) t[x] = up ? p[(size_t)(Y - 1) * stride + X + x] : 0;
+    for (int x = 8; x < 16; x++) t[x] = (up && ur) ? p[(size_t)(Y - 1) * stride + X + x] : t[7]; /* 8.3.2.2: not available -> p[7,-1] */
+    for (int y = 0; y < 8; y++) l[y] = lf ? p[(size_t)(Y + y) * stride + X - 1] : 0;
+    for (int i = 0; i < 17; i++) top[i] = 0;
+    for (int i = 0; i < 8; i++) left[i] = 0;
+    if (up) {
+        top[1] = ul ? (c + 2 * t[0] + t[1] + 2) >> 2 : (3 * t[0] + t[1] + 2) >> 2;
+        for (int x = 1; x < 15; x++) top[1 + x] = (t[x - 1] + 2 * t[x] + t[x + 1] + 2) >> 2;
+        top[16] = (t[14] + 3 * t[15] + 2) >> 2;
+    }
+    if (lf) {
+        left[0] = ul ? (c + 2 * l[0] + l[1] + 2) >> 2 : (3 * l[0] + l[1] + 2) >> 2;
+        for (int y = 1; y < 7; y++) left[y] = (l[y - 1] + 2 * l[y] + l[y + 1] + 2) >> 2;
+        left[7] = (l[6] + 3 * l[7] + 2) >> 2;
+    }
+    if (ul) top[0] = (up && lf) ? (t[0] + 2 * c + l[0] + 2) >> 2 : up ? (3 * c + t[0] + 2) >> 2 : lf ? (3 * c + l[0] + 2) >> 2 : c;
+}
+static int mode8_ok(int mode, int up, int lf, int ul) {
+    const int need_up = mode == 0 || mode == 3 || mode == 7, need_left = mode == 1 || mode == 8, need_all = mode >= 4 && mode <= 6;
+    return !((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul)));
+}
+/* 8.3.2.2.2 .. 8.3.2.2.10 on the filtered samples, as one edge array: E(0) = p'[-1,-1], E(k) = p'[k-1,-1] (k = 1..16), E(-k) = p'[-1,k-1] (k = 1..8) */
+static void pred8x8(const int top[17], const int left[8], int mode, int up, int lf, uint8_t out[64]) {
+    int e[25];
+    for (int k = 0; k <= 16; k++) e[8 + k] = top[k];
+    for (int k = 1; k <= 8; k++) e[8 - k] = left[k - 1];
+#define E(i) e[(i) + 8]
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) {
+            int v = 128;
+            switch (mode) {
+            case 0: v = E(x + 1); break;
+            case 1: v = E(-(y + 1)); break;
+            case 2: {
+                int s = 0;
+                if (up) for (int i = 1; i <= 8; i++) s += E(i);
+                if (lf) for (int i = 1; i <= 8; i++) s += E(-i);
+                v = (up && lf) ? (s + 8) >> 4 : (up || lf) ? (s + 4) >> 3 : 128;
+                break; }
+            case 3: v = (x == 7 && y == 7) ? (E(15) + 3 * E(16) + 2) >> 2 : (E(x + y + 1) + 2 * E(x + y + 2) + E(x + y + 3) + 2) >> 2; break;
+            case 4: { const int i = x - y; v = (E(i - 1) + 2 * E(i) + E(i + 1) + 2) >> 2; break; }
+            case 5: {
+                const int z = 2 * x - y, j = x - (y >> 1);
+                if (z >= 0 && !(z & 1)) v = (E(j) + E(j + 1) + 1) >> 1;
+                else if (z >= 0) v = (E(j - 1) + 2 * E(j) + E(j + 1) + 2) >> 2;
+                else if (z == -1) v = (E(-1) + 2 * E(0) + E(1) + 2) >> 2;
+                else { const int k = y - 2 * x - 1; v = (E(-(k + 1)) + 2 * E(-k) + E(-(k - 1)) + 2) >> 2; }
+                break; }
+            case 6: {
+                const int z = 2 * y - x, j = y - (x >> 1);
+                if (z >= 0 && !(z & 1)) v = (E(-j) + E(-(j + 1)) + 1) >> 1;
+                else if (z >= 0) v = (E(-(j - 1)) + 2 * E(-j) + E(-(j + 1)) + 2) >> 2;
+                else if (z == -1) v = (E(-1) + 2 * E(0) + E(1) + 2) >> 2;
+                else { const int k = x - 2 * y - 1; v = (E(k + 1) + 2 * E(k) + E(k - 1) + 2) >> 2; }
+                break; }
+            case 7: { const int j = x + (y >> 1); v = !(y & 1) ? (E(j + 1) + E(j + 2) + 1) >> 1 : (E(j + 1) + 2 * E(j + 2) + E(j + 3) + 2) >> 2; break; }
+            default: {
+                const int z = x + 2 * y, j = y + (x >> 1);
+                if (z > 13) v = E(-8);
+                else if (z == 13) v = (E(-7) + 3 * E(-8) + 2) >> 2;
+                else if (!(z & 1)) v = (E(-(j + 1)) + E(-(j + 2)) + 1) >> 1;
+                else v = (E(-(j + 1)) + 2 * E(-(j + 2)) + E(-(j + 3)) + 2) >> 2;
+                break; }
+            }
+            out[y * 8 + x] = (uint8_t)v;
+        }
+#undef E
+}
+/* open-loop analysis (source neighbours) and decision for one macroblock: returns cost8 = sum of the blocks' best SAD + lambda * mode bits; modes8[4] */
+static uint32_t intra8x8_choose(const uint8_t *src_y, int stride, int mbw, int mx, int my, int lambda, uint8_t modes8[4]) {
+    const int x0 = mx * 16, y0 = my * 16, has_top = top_ok(my), has_left = mx > 0, has_tr = top_ok(my) && mx + 1 < mbw;
+    uint32_t total = 0;
+    for (int b = 0; b < 4; b++) {
+        const int X = x0 + (b & 1) * 8, Y = y0 + (b >> 1) * 8;
+        int up, lf, ul, ur, top[17], left[8];
+        blk8_avail(b, has_top, has_left, has_tr, &up, &lf, &ul, &ur);
+        i8_refs(src_y, stride, X, Y, up, lf, ul, ur, top, left);
+        const int ma = (b & 1) ? modes8[b - 1] : (has_left ? 2 : -1), mb_ = (b >> 1) ? modes8[b - 2] : (has_top ? 2 : -1);
+        const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
+        uint32_t best = 0xFFFFFFFFu; int best_mode = 2;
+        for (int mode = 0; mode < 9; mode++) {
+            if (!mode8_ok(mode, up, lf, ul)) continue;
+            uint8_t p8[64];
+            pred8x8(top, left, mode, up, lf, p8);
+            uint32_t sad = 0;
+            for (int i = 0; i < 64; i++) sad += (uint32_t)iabs(src_y[(size_t)(Y + (i >> 3)) * stride + X + (i & 7)] - p8[i]);
+            const uint32_t cost = sad + (uint32_t)(lambda * (mode == pm ? 1 : 4));
+            if (cost < best) { best = cost; best_mode = mode; }
+        }
+        modes8[b] = (uint8_t)best_mode;
+        total += best;
+    }
+    return total;
+}
+/* after orc_intra_decide: Intra_8x8 where it is strictly cheaper (use_i4 = 2, the four modes in modes4[0..3]) */
+void orc_intra_decide8(const uint8_t *src_y, int stride, int mbw, int mbh, int qp, orc_idec_t *idec) {
+    const int lambda = orc_me_lambda(qp);
+    for (int my = 0; my < mbh; my++)
+        for (int mx = 0; mx < mbw; mx++) {
+            orc_idec_t *d = &idec[my * mbw + mx];
+            uint8_t m8[4];
+            const uint32_t c8 = intra8x8_choose(src_y, stride, mbw, mx, my, lambda, m8) + (uint32_t)(10 * lambda);
+            if (c8 < d->cost_luma) {
+                d->cost += c8 - d->cost_luma; d->cost_luma = c8; d->use_i4 = 2;
+                memset(d->modes4, 0, sizeof d->modes4);
+                for (int b = 0; b < 4; b++) d->modes4[b] = m8[b];
+            }
+        }
+}
+/* reconstruction of an Intra_8x8 macroblock with the modes in lev[ORC_L_LDC + 0..3] (8.3.2 + 8.5.13) */
+static void intra8x8_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int mbw, int mx, int my, int qp, int16_t *lev, uint32_t *nzmask) {
+    const int x0 = mx * 16, y0 = my * 16, has_top = top_ok(my), has_left = mx > 0, has_tr = top_ok(my) && mx + 1 < mbw;
+    for (int b = 0; b < 4; b++) {
+        const int X = x0 + (b & 1) * 8, Y = y0 + (b >> 1) * 8;
+        int up, lf, ul, ur, top[17], left[8];
+        blk8_avail(b, has_top, has_left, has_tr, &up, &lf, &ul, &ur);
+        i8_refs(rec_y, stride, X, Y, up, lf, ul, ur, top, left);
+        uint8_t p8[64];
+        pred8x8(top, left, lev[ORC_L_LDC + b], up, lf, p8);
+        for (int y = 0; y < 8; y++) memcpy(rec_y + (size_t)(Y + y) * stride + X, p8 + y * 8, 8);
+        *nzmask |= (uint32_t)tq8_block_i(src_y + (size_t)Y * stride + X, rec_y + (size_t)Y * stride + X, stride, qp, 1, lev + ORC_L_LUMA + b * 64) << (4 * b);
+    }
+    *nzmask |= ORC_NZ_T8; /* transform_size_8x8_flag of an I_NxN macroblock is sent whatever its levels */
+}
+
 /* Reconstruction of one intra macroblock with the decision `dec` (8.3 + 8.5): prediction from the reconstructed neighbours in
  * rec_y / rec_uv (whatever their type: constrained_intra_pred_flag is 0), residual, levels, record. */
 static void intra_mb(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int mx, int my, int qp,
@@ -967,9 +1112,10 @@ static void intra_mb(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
             const int best_mode = dec->mode16, best_cmode = dec->cmode, use_i4 = dec->use_i4;
             m->i16_mode = (uint8_t)(use_i4 ? 0 : best_mode);
             m->chroma_mode = (uint8_t)best_cmode;
-            if (use_i4) { m->mb_type = 2; for (int b = 0; b < 16; b++) lev[ORC_L_LDC + b] = dec->modes4[b]; }
+            if (use_i4) { m->mb_type = 2; for (int b = 0; b < 16; b++) lev[ORC_L_LDC + b] = dec->modes4[b]; } /* (Intra_8x8: four modes, the rest of the slot zero) */
             m->cost = dec->cost;
-            if (use_i4) intra4x4_recon(src_y, rec_y, stride, mbw, mx, my, qp, lev, &m->nzmask);
+            if (use_i4 == 2) intra8x8_recon(src_y, rec_y, stride, mbw, mx, my, qp, lev, &m->nzmask);
+            else if (use_i4) intra4x4_recon(src_y, rec_y, stride, mbw, mx, my, qp, lev, &m->nzmask);
             else {
             uint8_t best_pred[256];
             pred16(rec_y, stride, x0, y0, best_mode, has_top, has_left, best_pred);
@@ -1054,6 +1200,7 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
     orc_idec_t *idec = (orc_idec_t *)malloc((size_t)mbw * mbh * sizeof(orc_idec_t));
     orc_intra_analyse(src_y, src_uv, stride, mbw, mbh, isad);
     orc_intra_decide(isad, mbw, mbh, qp, drop > 0 ? 0 : g_orc_i4x4, idec); /* on the ladder: Intra_16x16 only (Intra_4x4 costs its mode bits whatever the residual) */
+    if (g_orc_t8 && g_orc_i8x8 && drop == 0) orc_intra_decide8(src_y, stride, mbw, mbh, qp, idec);
     for (int my = 0; my < mbh; my++)
         for (int mx = 0; mx < mbw; mx++) intra_mb(src_y, src_uv, rec_y, rec_uv, stride, mbw, mx, my, qp, &idec[my * mbw + mx], mbi, levels, iac);
     free(isad);
@@ -1828,20 +1975,36 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
                 int t = 1 + m->i16_mode + 4 * cbp_chroma + (cbp_luma ? 12 : 0); /* Table 7-11 */
                 bw_ue(&b, (uint32_t)(is_idr ? t : t + 5));
                 bw_ue(&b, m->chroma_mode);                                        /* intra_chroma_pred_mode */
-            } else if (intra) { /* I_NxN (Intra_4x4): 7.3.5.1 mb_pred */
+            } else if (intra) { /* I_NxN (Intra_4x4 / Intra_8x8): 7.3.5.1 mb_pred */
                 static const uint8_t rb[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* raster -> blkIdx (self-inverse) */
+                const int i8 = (m->nzmask & ORC_NZ_T8) != 0;
                 bw_ue(&b, is_idr ? 0u : 5u);
-                if (g_orc_t8) bw_put(&b, 1, 0); /* transform_size_8x8_flag: Intra_4x4, not Intra_8x8 */
+                if (g_orc_t8) bw_put(&b, 1, (uint32_t)i8); /* transform_size_8x8_flag: Intra_8x8 or Intra_4x4 */
+                /* the mode a neighbouring macroblock contributes for its 4x4 block blk (8.3.1.1 / 8.3.2.1): Intra4x4PredMode[blk], Intra8x8PredMode[blk >> 2], or DC for any other type */
+#define NXN_MODE(mm, ll, blk) ((mm)->mb_type != 2 ? 2 : ((mm)->nzmask & ORC_NZ_T8) ? (ll)[ORC_L_LDC + ((blk) >> 2)] : (ll)[ORC_L_LDC + (blk)])
+                if (i8) {
+                    for (int b8 = 0; b8 < 4; b8++) {
+                        int ma = -1, mb_ = -1;
+                        if (b8 & 1) ma = lev[ORC_L_LDC + b8 - 1];
+                        else if (mx > 0) ma = NXN_MODE(&m[-1], lev - ORC_LEVELS_PER_MB, (b8 + 1) * 4 + 1);
+                        if (b8 >> 1) mb_ = lev[ORC_L_LDC + b8 - 2];
+                        else if (top) mb_ = NXN_MODE(&m[-mbw], lev - (ptrdiff_t)mbw * ORC_LEVELS_PER_MB, (b8 + 2) * 4 + 2);
+                        const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode = lev[ORC_L_LDC + b8];
+                        if (mode == pm) bw_put(&b, 1, 1);
+                        else { bw_put(&b, 1, 0); bw_put(&b, 3, (uint32_t)(mode < pm ? mode : mode - 1)); }
+                    }
+                } else
                 for (int blk = 0; blk < 16; blk++) {
                     int bx = rb[blk] & 3, by = rb[blk] >> 2, ma = -1, mb_ = -1;
                     if (bx > 0) ma = lev[ORC_L_LDC + rb[by * 4 + bx - 1]];
-                    else if (mx > 0) ma = m[-1].mb_type == 2 ? lev[-ORC_LEVELS_PER_MB + ORC_L_LDC + rb[by * 4 + 3]] : 2;
+                    else if (mx > 0) ma = NXN_MODE(&m[-1], lev - ORC_LEVELS_PER_MB, rb[by * 4 + 3]);
                     if (by > 0) mb_ = lev[ORC_L_LDC + rb[(by - 1) * 4 + bx]];
-                    else if (top) mb_ = m[-mbw].mb_type == 2 ? lev[-(ptrdiff_t)mbw * ORC_LEVELS_PER_MB + ORC_L_LDC + rb[12 + bx]] : 2;
+                    else if (top) mb_ = NXN_MODE(&m[-mbw], lev - (ptrdiff_t)mbw * ORC_LEVELS_PER_MB, rb[12 + bx]);
                     int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode = lev[ORC_L_LDC + blk];
                     if (mode == pm) bw_put(&b, 1, 1);
                     else { bw_put(&b, 1, 0); bw_put(&b, 3, (uint32_t)(mode < pm ? mode : mode - 1)); }
                 }
+#undef NXN_MODE
                 bw_ue(&b, m->chroma_mode);
                 bw_ue(&b, k_cbp_to_codenum_intra[cbp_chroma * 16 + cbp_luma]);
             } else {

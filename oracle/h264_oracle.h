@@ -134,6 +134,9 @@ void orc_set_aq_map(const int8_t *off);          /* stage functions: the offsets
 void orc_aq_offsets(const uint8_t *src_y, int stride, int mbw, int mbh, int8_t *off);
 int orc_aq_offset_of(uint32_t sum, uint32_t sum_sq);
 void orc_qp_chain_slices(orc_mbinfo_t *mbi, int nmb, int slice_qp, int slice_mbs); /* ... with a new slice every slice_mbs macroblocks (0: one slice) */
+void orc_set_i8x8(int on);                      /* process-wide: I pictures of a stream with the 8x8 transform (orc_set_transform8x8) may use Intra_8x8 macroblocks */
+int orc_get_i8x8(void);
+void orc_intra_decide8(const uint8_t *src_y, int stride, int mbw, int mbh, int qp, orc_idec_t *idec); /* after orc_intra_decide: Intra_8x8 where strictly cheaper (use_i4 = 2, modes in modes4[0..3]) */
 void orc_set_part_levels(const int16_t *levels); /* stage functions (deblocking, slice writer): where the vectors of an inter macroblock's partitions 1 .. 3 lie (the levels of the picture; NULL: 16x16 only) */
 void orc_set_slice_rows(int rows);              /* stage functions: the I picture being coded is cut into slices of `rows` macroblock rows (0: one slice) */
 int orc_get_slice_rows(void);

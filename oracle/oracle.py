@@ -91,6 +91,8 @@ def lib():
         L.orc_qp_chain.restype = None
         L.orc_qp_chain_slices.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.orc_qp_chain_slices.restype = None
+        L.orc_set_i8x8.argtypes = [C.c_int]
+        L.orc_set_i8x8.restype = None
         L.orc_set_part_levels.argtypes = [vp]
         L.orc_set_part_levels.restype = None
         L.orc_set_slice_rows.argtypes = [C.c_int]
@@ -355,6 +357,11 @@ def set_part_levels(levels):
     global _part_levels_keep
     _part_levels_keep = None if levels is None else np.ascontiguousarray(levels, np.int16)
     lib().orc_set_part_levels(None if levels is None else _ptr(_part_levels_keep))
+
+
+def set_i8x8(on):
+    """Process-wide: Intra_8x8 macroblocks in the I pictures of a stream with the 8x8 transform."""
+    lib().orc_set_i8x8(int(on))
 
 
 def set_slice_rows(rows):
