@@ -419,7 +419,7 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
                 for (int i = 0; i < 8; i++) p_cac[i] = lv + L_CAC + i * 16;
             }
             uint8_t *im = w->i4m + (size_t)mbn * 16;
-            if (m->mb_type == 2) for (int i = 0; i < 16; i++) im[i] = (uint8_t)p_modes[i];
+            if (m->mb_type == 2) for (int i = 0; i < 16; i++) im[i] = (uint8_t)((nz & NZ_T8) ? p_modes[i >> 2] : p_modes[i]); /* (Intra_8x8: four modes, each at its block's four blkIdx) */
             int cbp_l = 0;
             if (i16) cbp_l = (nz & 0xFFFF) ? 15 : 0;
             else cbp_l = ((nz & 0x000F) ? 1 : 0) | ((nz & 0x00F0) ? 2 : 0) | ((nz & 0x0F00) ? 4 : 0) | ((nz & 0xF000) ? 8 : 0);
@@ -456,9 +456,22 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
                     int t = 1 + m->i16_mode + 4 * cbp_c + (cbp_l ? 12 : 0); /* Table 7-11 */
                     bits_ue(&b, (uint32_t)(is_idr ? t : t + 5));
                     bits_ue(&b, m->chroma_mode);
-                } else { /* I_NxN: sixteen Intra_4x4 modes, each predicted from the blocks left and above (8.3.1.1) */
+                } else { /* I_NxN: sixteen Intra_4x4 modes (8.3.1.1) or four Intra_8x8 modes (8.3.2.1), each predicted from the blocks left and above */
+                    const int i8 = (nz & NZ_T8) != 0;
                     bits_ue(&b, is_idr ? 0u : 5u);
-                    if (w->t8) bits_put(&b, 1, 0); /* transform_size_8x8_flag: Intra_4x4, not Intra_8x8 */
+                    if (w->t8) bits_put(&b, 1, (uint32_t)i8); /* transform_size_8x8_flag: Intra_8x8 or Intra_4x4 */
+                    if (i8) { /* im[] holds an 8x8 block's mode at all four of its 4x4 blkIdx, so that Intra_4x4 neighbours read it the way 8.3.1.1 says */
+                        for (int b8 = 0; b8 < 4; b8++) {
+                            int ma = -1, mb_ = -1;
+                            if (b8 & 1) ma = im[4 * (b8 - 1)];
+                            else if (mx) ma = m[-1].mb_type == 2 ? im[-16 + 4 * (b8 + 1) + 1] : 2;       /* the left macroblock's 4x4 block 4 n + 1 */
+                            if (b8 >> 1) mb_ = im[4 * (b8 - 2)];
+                            else if (top) mb_ = m[-mbw].mb_type == 2 ? im[-(ptrdiff_t)mbw * 16 + 4 * (b8 + 2) + 2] : 2; /* the macroblock above: 4 n + 2 */
+                            const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_), mode = im[4 * b8];
+                            if (mode == pm) bits_put(&b, 1, 1);
+                            else bits_put(&b, 4, (uint32_t)(mode < pm ? mode : mode - 1));
+                        }
+                    } else
                     for (int blk = 0; blk < 16; blk++) {
                         const int r = blk_to_raster[blk], bx = r & 3, by = r >> 2;
                         int ma = -1, mb_ = -1;
@@ -512,7 +525,7 @@ static void fill_ctx_row(h264_writer_t *w, int row, const mb_info_t *mbi, const 
         const uint32_t nz = m->nzmask;
         uint8_t *tl = w->tc_l + (size_t)mbn * 16, *tc = w->tc_c + (size_t)mbn * 8, *im = w->i4m + (size_t)mbn * 16;
         memset(tl, 0, 16); memset(tc, 0, 8);
-        if (m->mb_type == 2) { for (int i = 0; i < 16; i++) im[i] = (uint8_t)packed[i]; packed += 16; }
+        if (m->mb_type == 2) { for (int i = 0; i < 16; i++) im[i] = (uint8_t)((nz & NZ_T8) ? packed[i >> 2] : packed[i]); packed += 16; }
         else if (m->mb_type == 1) { const int slot = mb_shape(m) != 0; set_qmv(w->qmv + (size_t)mbn * 8, m, slot ? packed : k_zero_block); if (slot) packed += 16; }
         if (nz & NZ_LDC) packed += 16;
         const int ac_only = m->mb_type == 0; /* Intra16x16: coefficient 0 travels in the DC block */

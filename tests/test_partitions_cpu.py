@@ -96,3 +96,37 @@ def test_host_writer_codes_partitioned_macroblocks_like_the_oracle(oracle, w, h,
         assert seen > 0
     finally:
         oracle.set_features(oracle.F_ALL)
+
+
+@pytest.mark.parametrize("w,h,qp", [(64, 48, 30), (176, 144, 24), (322, 182, 34), (640, 368, 28), (1280, 720, 26)])
+def test_intra8x8_streams_decode_and_the_host_writer_codes_them(oracle, w, h, qp):
+    """Intra_8x8 (High profile; orc_set_i8x8): the oracle encoder's I pictures -- filtered-reference prediction, decision, 8x8 transform with the intra
+    rounding -- through the independent decoder (its own 8.3.2 implementation, mode prediction across Intra_4x4 / Intra_8x8 / other neighbours), and the
+    product's slice writer on the same records (transform_size_8x8_flag, prev_intra8x8_pred_mode), on one thread and on several, sliced and not."""
+    from ceracoder_amd import enc as E
+    oracle.set_transform8x8(True)
+    oracle.set_i8x8(True)
+    try:
+        for slices in (1, 0):
+            oe, dec = oracle.Encoder(w, h, gop=2, threads=8, intra_slices=slices), oracle.Decoder()
+            rows = oracle.slice_rows_for(oe.mbh, slices)
+            n8 = 0
+            try:
+                E.host_set_slice_rows(rows)
+                for i, (y, uv) in enumerate(synth.s2_frames(w, h, 4)):
+                    au, idr = oe.encode(y, uv, qp)
+                    dy, duv = dec.decode(au)
+                    assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv), i
+                    hdr = E.host_write_headers(w, h, 60, transform8x8=True) if idr else b""
+                    assert hdr + E.host_write_slice(oe.mbw, oe.mbh, idr, i % 2, i // 2, qp, oe.mbinfo, oe.levels, transform8x8=True) == au, i
+                    for thr in (2, 5):
+                        assert hdr + E.host_write_slice_packed(oe.mbw, oe.mbh, idr, i % 2, i // 2, qp, oe.mbinfo, oe.levels, threads=thr, transform8x8=True) == au, (i, thr)
+                    if idr:
+                        m = oe.mbinfo
+                        n8 += int(((m["mb_type"] == 2) & (((m["nzmask"] >> 27) & 1) == 1)).sum())
+            finally:
+                E.host_set_slice_rows(0)
+            assert n8 > 0
+    finally:
+        oracle.set_transform8x8(False)
+        oracle.set_i8x8(False)
