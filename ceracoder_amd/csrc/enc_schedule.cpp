@@ -88,6 +88,7 @@ void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set)
     c->drop_sad = (!idr && drop > 0 && drop <= DROP_MAX) ? k_drop_sad[drop] : 0;
     c->iac_drop = (idr && drop > 0 && drop <= DROP_MAX) ? k_idrop_ac[drop] : 0;
     if (c->iac_drop) c->i4x4 = 0; // on the ladder: Intra_16x16 only
+    c->i8 = (idr && h->cfg.transform8x8 && h->cfg.i8x8 && h->cfg.intra_mode == 0 && !c->iac_drop) ? 1 : 0;
     c->qp_off = h->cfg.aq_mode ? h->d_qp_off[set] : nullptr;
     c->intra_p = h->cfg.intra_in_p ? (h->cfg.i4x4 && h->cfg.intra_in_p > 1 ? 2 : 1) : 0; // 2: Intra_4x4 as well
 }

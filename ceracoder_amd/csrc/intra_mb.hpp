@@ -6,6 +6,153 @@
 #include "kernels_common.hpp"
 #include <cstddef>
 
+// =================================================================== Intra_8x8 (High profile; oracle: pred8x8 / i8_refs / intra8x8_recon)
+// The 25 reference samples of an 8x8 block, filtered (8.3.2.2.1), as one edge array in LDS: E(0) = p'[-1,-1], E(k) = p'[k-1,-1] (k = 1..16),
+// E(-k) = p'[-1,k-1] (k = 1..8), stored at e[i + 8].  rt[0..15] / rl[0..7] / rc: the raw samples above (the right half already replaced by
+// rt[7] where the block above-right is not available), to the left, and the corner; lanes 0..24 compute one entry each.
+DEV void i8_edges(int lane, const int *rt, const int *rl, int rc, bool up, bool lf, bool ul, int *e) {
+    if (lane < 25) {
+        const int i = lane - 8;
+        int v = 0;
+        if (i == 0) { if (ul) v = (up && lf) ? (rt[0] + 2 * rc + rl[0] + 2) >> 2 : up ? (3 * rc + rt[0] + 2) >> 2 : lf ? (3 * rc + rl[0] + 2) >> 2 : rc; }
+        else if (i > 0) {
+            const int x = i - 1;
+            if (up) v = x == 0 ? (ul ? (rc + 2 * rt[0] + rt[1] + 2) >> 2 : (3 * rt[0] + rt[1] + 2) >> 2) : x == 15 ? (rt[14] + 3 * rt[15] + 2) >> 2 : (rt[x - 1] + 2 * rt[x] + rt[x + 1] + 2) >> 2;
+        } else {
+            const int y = -i - 1;
+            if (lf) v = y == 0 ? (ul ? (rc + 2 * rl[0] + rl[1] + 2) >> 2 : (3 * rl[0] + rl[1] + 2) >> 2) : y == 7 ? (rl[6] + 3 * rl[7] + 2) >> 2 : (rl[y - 1] + 2 * rl[y] + rl[y + 1] + 2) >> 2;
+        }
+        e[lane] = v;
+    }
+}
+DEV bool i8_mode_ok(int mode, bool up, bool lf, bool ul) {
+    const bool need_up = mode == 0 || mode == 3 || mode == 7, need_left = mode == 1 || mode == 8, need_all = mode >= 4 && mode <= 6;
+    return !((need_up && !up) || (need_left && !lf) || (need_all && !(up && lf && ul)));
+}
+// sample (x, y) of the prediction of mode `mode` (8.3.2.2.2 .. 8.3.2.2.10); dcv: the DC value (computed once per block by the caller)
+DEV int i8_pred_px(const int *e, int mode, int x, int y, int dcv) {
+#define E(i) e[(i) + 8]
+    switch (mode) {
+    case 0: return E(x + 1);
+    case 1: return E(-(y + 1));
+    case 2: return dcv;
+    case 3: return (x == 7 && y == 7) ? (E(15) + 3 * E(16) + 2) >> 2 : (E(x + y + 1) + 2 * E(x + y + 2) + E(x + y + 3) + 2) >> 2;
+    case 4: { const int i = x - y; return (E(i - 1) + 2 * E(i) + E(i + 1) + 2) >> 2; }
+    case 5: {
+        const int z = 2 * x - y, j = x - (y >> 1);
+        if (z >= 0 && !(z & 1)) return (E(j) + E(j + 1) + 1) >> 1;
+        if (z >= 0) return (E(j - 1) + 2 * E(j) + E(j + 1) + 2) >> 2;
+        if (z == -1) return (E(-1) + 2 * E(0) + E(1) + 2) >> 2;
+        const int k = y - 2 * x - 1;
+        return (E(-(k + 1)) + 2 * E(-k) + E(-(k - 1)) + 2) >> 2; }
+    case 6: {
+        const int z = 2 * y - x, j = y - (x >> 1);
+        if (z >= 0 && !(z & 1)) return (E(-j) + E(-(j + 1)) + 1) >> 1;
+        if (z >= 0) return (E(-(j - 1)) + 2 * E(-j) + E(-(j + 1)) + 2) >> 2;
+        if (z == -1) return (E(-1) + 2 * E(0) + E(1) + 2) >> 2;
+        const int k = x - 2 * y - 1;
+        return (E(k + 1) + 2 * E(k) + E(k - 1) + 2) >> 2; }
+    case 7: { const int j = x + (y >> 1); return !(y & 1) ? (E(j + 1) + E(j + 2) + 1) >> 1 : (E(j + 1) + 2 * E(j + 2) + E(j + 3) + 2) >> 2; }
+    default: {
+        const int z = x + 2 * y, j = y + (x >> 1);
+        if (z > 13) return E(-8);
+        if (z == 13) return (E(-7) + 3 * E(-8) + 2) >> 2;
+        if (!(z & 1)) return (E(-(j + 1)) + E(-(j + 2)) + 1) >> 1;
+        return (E(-(j + 1)) + 2 * E(-(j + 2)) + E(-(j + 3)) + 2) >> 2; }
+    }
+#undef E
+}
+DEV int i8_dc(const int *e, bool up, bool lf) { // (every lane sums: 16 LDS reads; the block is a dependency chain of its own anyway)
+    int s = 0;
+    if (up) for (int i = 1; i <= 8; i++) s += e[8 + i];
+    if (lf) for (int i = 1; i <= 8; i++) s += e[8 - i];
+    return (up && lf) ? (s + 8) >> 4 : (up || lf) ? (s + 4) >> 3 : 128;
+}
+// availability of the neighbours of 8x8 block b of a macroblock (oracle: blk8_avail)
+DEV void i8_avail(int b, bool has_top, bool has_left, bool has_tr, bool &up, bool &lf, bool &ul, bool &ur) {
+    up = b >= 2 || has_top; lf = (b & 1) || has_left;
+    ul = b == 0 ? (has_top && has_left) : b == 1 ? has_top : b == 2 ? has_left : true;
+    ur = b == 0 ? has_top : b == 1 ? has_tr : b == 2;
+}
+
+// the raw neighbours of 8x8 block (bx8, by8) out of a sample tile (sample (r, c) of the macroblock, r, c >= -1, at tile[(r + 1) * stride + c + off]; the top line runs
+// to c = 23: the first eight samples of the macroblock above-right): lanes 0..15 rt[], lanes 16..23 rl[]; returns the corner (every lane)
+DEV int i8_gather(int lane, const uint8_t *tile, int stride, int off, int bx8, int by8, bool ur, int *rt, int *rl) {
+    if (lane < 16) rt[lane] = (int)tile[by8 * stride + bx8 + ((lane >= 8 && !ur) ? 7 : lane) + off];
+    else if (lane < 24) rl[lane - 16] = (int)tile[(by8 + lane - 16 + 1) * stride + bx8 - 1 + off];
+    return (int)tile[by8 * stride + bx8 - 1 + off];
+}
+// One 8x8 residual block of an Intra_8x8 macroblock through transform, quantiser (intra rounding 1/3) and back (oracle: tq8_block_i, intra = 1; the passes of
+// pmb_luma_t8 in k_motion.hip, one block): lane (x, y) hands in its residual sample and gets the reconstructed residual back; lanes 0..7 run the separable
+// passes through `tile` (64 ints of LDS).  Levels go out de-interleaved the way CAVLC sends them.  Returns the mask of the 4x4 "sub-blocks" with levels.
+DEV unsigned i8_tq8(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, int *tile, int lane, int res, int qp, int mbn, int b8, int &rres) {
+    const bool act = lane < 8;
+    const int j = lane & 7, m6 = qp % 6, k6 = qp / 6;
+    int v[8];
+    unsigned submask = 0;
+    tile[lane] = res;
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = tile[j * 8 + i];
+        fdct8_1d(v);
+    }
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) tile[j * 8 + i] = v[i];
+    }
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = tile[r * 8 + j];
+        fdct8_1d(v);
+        const int qbits = 16 + k6, f = (1 << qbits) / 3;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int cl = pos_class8(r, j), a = iabs(v[r]);
+            int l = (int)(((long long)a * T->mf8[m6][cl] + f) >> qbits);
+            l = l > 2047 ? 2047 : l;
+            l = v[r] < 0 ? -l : l;
+            const int kk = T->izz8[r * 8 + j];
+            stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + (4 * b8 + (kk & 3)) * 16 + (kk >> 2)], l);
+            if (l) submask |= 1u << (kk & 3);
+            const int ls = 16 * T->v8[m6][cl];
+            v[r] = qp >= 36 ? (l * ls) << (k6 - 6) : (l * ls + (1 << (5 - k6))) >> (6 - k6);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) tile[r * 8 + j] = v[r];
+    }
+    WAVE_SYNC();
+    if (act) { // 8.5.13: rows, then columns
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = tile[j * 8 + i];
+        idct8_1d(v);
+    }
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) tile[j * 8 + i] = v[i];
+    }
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) v[r] = tile[r * 8 + j];
+        idct8_1d(v);
+    }
+    WAVE_SYNC();
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) tile[r * 8 + j] = (v[r] + 32) >> 6;
+    }
+    WAVE_SYNC();
+    rres = tile[lane];
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (__ballot(act && ((submask >> k) & 1u))) m |= 1u << k;
+    return m;
+}
+
 // =================================================================== intra (I) macroblocks
 // Two waves per macroblock (luma, chroma), run in x + y order (left, top and top-left neighbours are then complete).
 // Per-macroblock working set of the intra reconstruction, in LDS.  Filled by the caller: top / left (reconstructed
@@ -80,7 +227,8 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
 #define LEFT(p, i) left[p][(i) + 1]
     // ---- decisions were taken by intra_analyse_kernel (oracle: orc_intra_decide)
     const int mode16 = (int)(dec1.x & 255), cmode = (int)((dec1.x >> 8) & 255);
-    const bool use_i4 = ((dec1.x >> 16) & 255) != 0;
+    const int itype = (int)((dec1.x >> 16) & 255);   // 0 Intra_16x16, 1 Intra_4x4, 2 Intra_8x8 (wave-uniform)
+    const bool use_i4 = itype == 1, use_i8 = itype == 2;
     unsigned nz4 = 0;
     WAVE_SYNC(); // S4 is in place
     unsigned nz16 = 0, ldc_any = 0, cnz8 = 0, cdc2 = 0;
@@ -201,6 +349,48 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         if (SC1) // the deblocker of the same picture follows the reconstruction while it is written: the whole tile, write-through, a word per lane
             st_sc1((unsigned *)(ry + (size_t)(y0 + (lane >> 2)) * stride + x0 + 4 * (lane & 3)), *(const unsigned *)&T4[((lane >> 2) + 1) * 24 + 4 + 4 * (lane & 3)]);
         if (OUT && lane < 16) { L->bot_y[slot][lane] = T4[16 * 24 + lane + 4]; L->right_y[lane] = T4[17 * 24 + 16 * 24 + lane + 4]; }
+    } else if (use_i8 && wave == 0) {
+        // ================================================================ Intra_8x8 reconstruction (8.3.2 + 8.5.13; oracle: intra8x8_recon)
+        // The four blocks one after another, lane = one sample.  The caller has the whole top line, the corner and the left column in L->top / L->left (as
+        // for Intra_16x16) and the first eight samples of the macroblock above-right in L->T4[20..27] (block 1 reads them; zero where that macroblock is not
+        // available).  T4 + T4t serve as one tile of stride 32 (17 rows; sample (r, c) at R[(r + 1) * 32 + c + 4]) followed by the neighbour / edge arrays;
+        // S4 becomes the transform's tile once every lane holds its four source samples.
+        uint8_t *R = L->T4;
+        int *rt = (int *)(L->T4 + 17 * 32), *rl = rt + 16, *e8 = rt + 24;
+        static_assert(17 * 32 + 4 * (24 + 25) <= 2 * 17 * 24, "tile + arrays fit T4 + T4t");
+        if (lane < 17) R[lane + 3] = (uint8_t)TOP(0, lane - 1);
+        else if (lane >= 32 && lane < 48) R[(lane - 32 + 1) * 32 + 3] = (uint8_t)LEFT(0, lane - 32);
+        const int x = lane & 7, y = lane >> 3;
+        int sv[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) sv[b] = (int)S4[((b >> 1) * 8 + y) * 16 + (b & 1) * 8 + x];
+        if (lane < 16) stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LDC + lane], lane < 4 ? (int)((dec0.x >> (8 * lane)) & 255u) : 0); // the modes, for the entropy coder
+        const bool has_tr = has_top && mx + 1 < mbw;
+#pragma unroll 1
+        for (int b = 0; b < 4; b++) {
+            const int bx8 = (b & 1) * 8, by8 = (b >> 1) * 8, mode = (int)((dec0.x >> (8 * b)) & 255u);
+            bool up, lf, ul, ur;
+            i8_avail(b, has_top, has_left, has_tr, up, lf, ul, ur);
+            WAVE_SYNC();
+            const int rc = i8_gather(lane, R, 32, 4, bx8, by8, ur, rt, rl);
+            WAVE_SYNC();
+            i8_edges(lane, rt, rl, rc, up, lf, ul, e8);
+            WAVE_SYNC();
+            const int pred = i8_pred_px(e8, mode, x, y, mode == 2 ? i8_dc(e8, up, lf) : 0);
+            int rres;
+            const unsigned m = i8_tq8(ctx, T, (int *)S4, lane, (b == 0 ? sv[0] : b == 1 ? sv[1] : b == 2 ? sv[2] : sv[3]) - pred, qp, mbn, b, rres);
+            const int recp = clip255(pred + rres);
+            R[(by8 + y + 1) * 32 + bx8 + x + 4] = (uint8_t)recp;
+            nz4 |= m << (4 * b);
+        }
+        nz4 |= NZ_T8; // transform_size_8x8_flag of an I_NxN macroblock is sent whatever its levels
+        WAVE_SYNC();
+        {
+            const unsigned rw = *(const unsigned *)&R[((lane >> 2) + 1) * 32 + 4 + 4 * (lane & 3)];
+            if (SC1) st_sc1((unsigned *)(ry + (size_t)(y0 + (lane >> 2)) * stride + x0 + 4 * (lane & 3)), rw);
+            else stg32(ry + (size_t)(y0 + (lane >> 2)) * stride + x0 + 4 * (lane & 3), rw);
+        }
+        if (OUT && lane < 16) { L->bot_y[slot][lane] = R[16 * 32 + lane + 4]; L->right_y[lane] = R[(lane + 1) * 32 + 19]; }
     } else if (wave == 0) {
         // ================================================================ Intra_16x16 reconstruction (8.3.3 + 8.5.10)
         const int bx = lane & 3, by = lane >> 4, mode = mode16, yy = 4 * by + py;
@@ -334,7 +524,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
                 }
             }
             hk.chroma_done(cnz8, cdc2);
-        } else hk.luma_done(use_i4 ? nz4 : nz16, !use_i4 && ldc_any != 0);
+        } else hk.luma_done(itype ? nz4 : nz16, !itype && ldc_any != 0);
         return;
     }
     if (wave == 1) {
@@ -353,12 +543,12 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
     } else if (lane == 0) { // the luma wave writes the record once the chroma wave's flags are in (both waves are resident: plain spin)
         while (__hip_atomic_load(&L->cseq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (unsigned)mbn + 1u) __builtin_amdgcn_s_sleep(1);
         const unsigned cany = L->cflags[0], cdc = L->cflags[1];
-        unsigned nzm = (use_i4 ? nz4 : nz16) | (cany << 16);
-        if (!use_i4 && ldc_any) nzm |= NZ_LDC;
+        unsigned nzm = (itype ? nz4 : nz16) | (cany << 16);
+        if (!itype && ldc_any) nzm |= NZ_LDC;
         if (cdc & 1) nzm |= NZ_CBDC;
         if (cdc & 2) nzm |= NZ_CRDC;
         mb_info_t mb;
-        mb.mvx = 0; mb.mvy = 0; mb.mb_type = use_i4 ? 2 : 0; mb.i16_mode = use_i4 ? 0 : (uint8_t)mode16; mb.chroma_mode = (uint8_t)cmode;
+        mb.mvx = 0; mb.mvy = 0; mb.mb_type = itype ? 2 : 0; mb.i16_mode = itype ? 0 : (uint8_t)mode16; mb.chroma_mode = (uint8_t)cmode;
         mb.qp = (uint8_t)qp; mb.nzmask = nzm; mb.cost = dec1.y;
         st_mbinfo(&ctx->mbi[mbn], mb);
     }

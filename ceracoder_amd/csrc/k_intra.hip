@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
     const frame_ctx_t *__restrict__ ctx = &cv;
     __shared__ uint16_t sh_sad[4][ISAD_PER_MB]; // this wave's macroblock: the same 152 values that go to ctx->isad
     __shared__ int sh_m4[4][16];                // Intra_4x4 modes chosen so far, raster order
+    __shared__ int sh_i8[4][16 + 8 + 8 + 32];   // Intra_8x8: raw samples above (16) / to the left (8) / above-right of the macroblock (8), the filtered edge array (25)
     __shared__ __attribute__((aligned(4))) uint8_t SL[4][17 * IA_S];
     __shared__ __attribute__((aligned(4))) uint8_t SC[4][2][9 * 12]; // [plane][row 0 = y -1][col 0 = x -1]
     const int mbw = ctx->mbw, nmb = mbw * ctx->mbh;
@@ -248,9 +249,51 @@ __global__ __launch_bounds__(256) void intra_analyse_kernel(const frame_ctx_t cv
             use_i4 = cost4 + (unsigned)(32 * lam) < cost16;
             if (use_i4) cost_luma = cost4 + (unsigned)(32 * lam);
         }
-        if (lane < 8 && ok) { // 32-byte record {u8 modes4[16] by blkIdx; u8 mode16, cmode, use_i4, 0; u32 cost, cost_luma, 0}
+        // ---- Intra_8x8 (High profile, I pictures): open loop like Intra_4x4 -- filtered SOURCE neighbours, SAD + lambda * (mode == expected ? 1 : 4) per 8x8 block,
+        // the macroblock taken when the total + 10 lambda is strictly below what stands (oracle: orc_intra_decide8)
+        unsigned m8w = 0;
+        bool use_i8 = false;
+        if (ctx->i8 && !gate_p && !ctx->iac_drop) {
+            int *rt = sh_i8[wave], *rl = rt + 16, *tr = rt + 24, *e8 = rt + 32;
+            const bool has_tr = has_top && mx + 1 < mbw;
+            if (lane < 8) { int yt = y0 - 1; yt = yt < vh ? yt : vh - 1; tr[lane] = has_tr ? (int)ldg8(sy + (size_t)yt * ss + x0 + 16 + lane) : 0; }
+            unsigned cost8 = 0;
+            int m8[4] = {2, 2, 2, 2};
+#pragma unroll 1
+            for (int b = 0; b < 4; b++) {
+                const int bx8 = (b & 1) * 8, by8 = (b >> 1) * 8;
+                bool up, lf, ul, ur;
+                i8_avail(b, has_top, has_left, has_tr, up, lf, ul, ur);
+                WAVE_SYNC();
+                if (lane < 16) { const int col = bx8 + ((lane >= 8 && !ur) ? 7 : lane); rt[lane] = col < 16 ? (int)S[by8 * IA_S + col + 1] : tr[col - 16]; }
+                else if (lane < 24) rl[lane - 16] = (int)S[(by8 + lane - 16 + 1) * IA_S + bx8];
+                const int rc = (int)S[by8 * IA_S + bx8];
+                WAVE_SYNC();
+                i8_edges(lane, rt, rl, rc, up, lf, ul, e8);
+                WAVE_SYNC();
+                const int dcv = i8_dc(e8, up, lf), x = lane & 7, y = lane >> 3;
+                const int sv = (int)S[(by8 + y + 1) * IA_S + bx8 + x + 1];
+                const int ma = (b & 1) ? m8[b - 1] : (has_left ? 2 : -1), mb_ = (b >> 1) ? m8[b - 2] : (has_top ? 2 : -1);
+                const int pm = (ma < 0 || mb_ < 0) ? 2 : (ma < mb_ ? ma : mb_);
+                unsigned best = 0xFFFFFFFFu; int bm = 2;
+#pragma unroll 1
+                for (int md = 0; md < 9; md++) {
+                    if (!i8_mode_ok(md, up, lf, ul)) continue; // (wave-uniform)
+                    const unsigned sad = (unsigned)wave64_sum(iabs(sv - i8_pred_px(e8, md, x, y, dcv)));
+                    const unsigned cost = sad + (unsigned)(lam * (md == pm ? 1 : 4));
+                    if (cost < best) { best = cost; bm = md; }
+                }
+                m8[b] = bm; cost8 += best;
+            }
+            if (cost8 + (unsigned)(10 * lam) < cost_luma) {
+                use_i8 = true; cost_luma = cost8 + (unsigned)(10 * lam);
+                m8w = (unsigned)m8[0] | ((unsigned)m8[1] << 8) | ((unsigned)m8[2] << 16) | ((unsigned)m8[3] << 24);
+            }
+        }
+        if (lane < 8 && ok) { // 32-byte record {u8 modes4[16] by blkIdx (Intra_8x8: four modes, then zeros); u8 mode16, cmode, use_i4 (2: Intra_8x8), 0; u32 cost, cost_luma, 0}
             unsigned w = 0;
-            if (lane < 4) {
+            if (use_i8 && lane < 5) w = lane == 0 ? m8w : lane == 4 ? ((unsigned)mode16 | ((unsigned)cmode << 8) | (2u << 16)) : 0u;
+            else if (lane < 4) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int bb = lane * 4 + i, r = (blky(bb) >> 2) * 4 + (blkx(bb) >> 2);
@@ -624,10 +667,16 @@ __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
             const uint4 dec0 = make_uint4(dw[0], dw[1], dw[2], dw[3]);
             const uint2 dec1 = make_uint2(dw[4], dw[5]);
             const uint2 srcc = make_uint2(SH.srcy[x & (IR_TR - 1)][lane], 0u);
-            const bool use_i4 = ((dec1.x >> 16) & 255) != 0, has_left = x > 0;
+            const int itype = (int)((dec1.x >> 16) & 255);
+            const bool use_i4 = itype == 1, has_left = x > 0;
             hk.x = x; hk.has_left = has_left; hk.nz = 0; hk.ldc = false;
-            if (!use_i4) { // Intra_16x16: the whole top line, the corner, the whole left column
+            if (!use_i4) { // Intra_16x16 / Intra_8x8: the whole top line, the corner, the whole left column
                 int tv = 0, lv = 0;
+                if (itype == 2) { // ... and the first eight samples of the macroblock above-right (its granules 0 and 1; the row above does not wait for this row)
+                    const bool has_tr = has_top && x + 1 < mbw;
+                    if (has_tr) ir_wait_lds(&SH.nly, 4u * (unsigned)(x + 1) + 2u, a.err, 14u);
+                    if (lane < 8) L->T4[20 + lane] = has_tr ? SH.topy[(x + 1) & (IR_TR - 1)][lane] : (uint8_t)0;
+                }
                 if (has_left) ir_wait_lds(&SH.prog[(x - 1) & (IR_RING - 1)], ((unsigned)(x - 1) << 4) | 10u, a.err, 18u);
                 if (has_top) {
                     ir_wait_lds(&SH.nly, 4u * (unsigned)x + 4u, a.err, 14u);

@@ -90,6 +90,7 @@ typedef struct {
     int32_t partitions;            /* P macroblocks may be split (shape in the record's i16_mode: 1 16x8, 2 8x16, 3 8x8; the vectors of partitions 1 .. 3 in the
                                       luma-DC slot of the macroblock's levels); the deblocker then takes boundary strengths per 8x8 quadrant */
     int32_t slice_rows;            /* I pictures: a new slice every so many macroblock rows (0: one slice); the row above a slice's first row is not available (6.4.8) */
+    int32_t i8;                    /* I pictures: try Intra_8x8 (High profile; intra_mode 0 only: the macroblock above-right has to be complete) */
 } frame_ctx_t;
 
 #ifdef __cplusplus

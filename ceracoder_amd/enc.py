@@ -40,7 +40,7 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
                 ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
-                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("intra_in_p", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("vbv_ms", C.c_int), ("scenecut", C.c_int), ("exclusive_device", C.c_int), ("aq_mode", C.c_int), ("single_stream", C.c_int), ("intra_slices", C.c_int), ("partitions", C.c_int), ("profile_overlap", C.c_int)]
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("intra_in_p", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("vbv_ms", C.c_int), ("scenecut", C.c_int), ("exclusive_device", C.c_int), ("aq_mode", C.c_int), ("single_stream", C.c_int), ("intra_slices", C.c_int), ("partitions", C.c_int), ("profile_overlap", C.c_int), ("i8x8", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -230,7 +230,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False, intra_slices=0, profile_overlap=False, partitions=False):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False, intra_slices=0, profile_overlap=False, partitions=False, i8x8=True):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
@@ -246,6 +246,7 @@ class Encoder:
         cfg.aq_mode = int(aq)
         cfg.single_stream = int(single_stream)
         cfg.profile_overlap = int(profile_overlap)  # sampled P pictures keep the free-running schedule (timers include device-side waits)
+        cfg.i8x8 = int(i8x8)  # with transform8x8: Intra_8x8 macroblocks in I pictures (intra_mode 0)
         cfg.partitions = int(partitions)  # P macroblocks may be split into 16x8 / 8x16 / 8x8 partitions
         cfg.intra_slices = int(intra_slices)  # 0: about 17 macroblock rows per slice (1080p: 4 slices per I picture)
         cfg.subpel = int(subpel)

@@ -962,7 +962,7 @@ static void intra4x4_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int
  * else 4) with the expected mode taken inside the macroblock (neighbours outside count as DC), macroblock taken as Intra_8x8 when that total + 10 lambda
  * is strictly below what Intra_16x16 / Intra_4x4 left.  The record is mb_type 2 with ORC_NZ_T8 set (whatever its levels), the four modes in
  * lev[ORC_L_LDC + 0..3], the levels de-interleaved like the inter macroblocks' 8x8 blocks. */
-static int g_orc_i8x8 = 0; /* process-wide: try Intra_8x8 where the stream has the 8x8 transform */
+static int g_orc_i8x8 = 1; /* process-wide (default on): try Intra_8x8 in the I pictures of a stream with the 8x8 transform (mi355enc_cfg_t.i8x8) */
 void orc_set_i8x8(int on) { g_orc_i8x8 = on; }
 int orc_get_i8x8(void) { return g_orc_i8x8; }
 /* availability of the neighbours of 8x8 block b (raster) of a macroblock with has_top / has_left / has_tr */

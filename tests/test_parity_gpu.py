@@ -207,6 +207,41 @@ def test_intra_kernel_matches_oracle(E, oracle, w, h, qp, i4, imode):
     e.close()
 
 
+@pytest.mark.parametrize("w,h", SIZES + [(48, 272), (640, 368)])
+@pytest.mark.parametrize("qp", [10, 24, 34, 46])
+@pytest.mark.parametrize("rows", [0, 3])
+def test_intra8x8_kernel_matches_oracle(E, oracle, w, h, qp, rows):
+    """High profile: I pictures may hold Intra_8x8 macroblocks (filtered reference samples, nine modes, the 8x8 transform with the intra rounding; the rows
+    kernel takes them whole, with the first eight samples of the macroblock above-right) -- decisions, records, levels and reconstruction equal the oracle's
+    (orc_intra_decide8 / intra8x8_recon), with and without slices; with i8x8 off, or with an intra schedule that cannot have the macroblock above-right
+    ready (intra_mode 1, 2), the picture is the one without them."""
+    cy, cuv = frames(w, h, 1)[0][:2]
+    oracle.set_transform8x8(True)
+    oracle.set_slice_rows(rows)
+    try:
+        o_y, o_uv, o_mbi, o_lev = oracle.intra_frame(cy, cuv, qp)
+        oracle.set_i8x8(False)
+        n_y, n_uv, n_mbi, n_lev = oracle.intra_frame(cy, cuv, qp)
+    finally:
+        oracle.set_transform8x8(False)
+        oracle.set_i8x8(True)
+        oracle.set_slice_rows(0)
+    is8 = (o_mbi["mb_type"] == 2) & ((o_mbi["nzmask"] >> 27) & 1).astype(bool)
+    assert is8.any() or (qp == 10 and w == 64)
+    for kw, (r_y, r_uv, r_mbi, r_lev) in (({}, (o_y, o_uv, o_mbi, o_lev)), ({"i8x8": False}, (n_y, n_uv, n_mbi, n_lev)), ({"intra_mode": 1}, (n_y, n_uv, n_mbi, n_lev)),
+                                          ({"intra_mode": 2}, (n_y, n_uv, n_mbi, n_lev))):
+        e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp, transform8x8=True, **kw)
+        e.stage_set_slice_rows(rows)
+        d_y, d_uv, d_mbi, d_lev = e.stage_intra(cy, cuv, qp)
+        assert mbinfo_equal(d_mbi, r_mbi, ("mb_type", "i16_mode", "chroma_mode", "cost")), \
+            (kw, [(f, first_diff(d_mbi[f], r_mbi[f])) for f in ("mb_type", "i16_mode", "chroma_mode", "cost")])
+        assert np.array_equal(d_lev, r_lev), (kw, first_diff(d_lev, r_lev))
+        assert np.array_equal(d_y, r_y), (kw, first_diff(d_y, r_y))
+        assert np.array_equal(d_uv, r_uv), (kw, first_diff(d_uv, r_uv))
+        assert mbinfo_equal(d_mbi, r_mbi, ("mb_type", "qp", "nzmask", "mvx", "mvy")), (kw, first_diff(d_mbi["nzmask"], r_mbi["nzmask"]))
+        e.close()
+
+
 @pytest.mark.parametrize("w,h,rows", [(176, 144, 3), (320, 180, 4), (640, 368, 6), (48, 272, 5), (1280, 720, 12), (1920, 1080, 17)])
 @pytest.mark.parametrize("qp", [12, 30, 44])
 @pytest.mark.parametrize("imode", [0, 1, 2])
