@@ -73,6 +73,7 @@ static int upload_done(mi355enc_t *h, slot_t *s) {
 // rate control's ladder below QP 51 (oracle: k_drop_sad): the SAD under which a P macroblock carries no residual / takes the skip vector
 static const uint32_t k_drop_sad[DROP_MAX + 1] = {0, 384, 512, 768, 1024, 1536, 2048, 3072, 4096, 6144, 8192, 12288, 0xFFFFFFFFu};
 // ... and its counterpart for I pictures (oracle: k_idrop_ac): the sum of level magnitudes up to which a macroblock's luma / chroma residual is not sent
+#define I8_QP_MAX 37 /* Intra_8x8 is tried up to this picture quantiser (oracle: ORC_I8_QP_MAX) */
 static const int32_t k_idrop_ac[DROP_MAX + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 64, 0x7FFFFFFF};
 
 void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set) {
@@ -88,7 +89,7 @@ void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set)
     c->drop_sad = (!idr && drop > 0 && drop <= DROP_MAX) ? k_drop_sad[drop] : 0;
     c->iac_drop = (idr && drop > 0 && drop <= DROP_MAX) ? k_idrop_ac[drop] : 0;
     if (c->iac_drop) c->i4x4 = 0; // on the ladder: Intra_16x16 only
-    c->i8 = (idr && h->cfg.transform8x8 && h->cfg.i8x8 && h->cfg.intra_mode == 0 && !c->iac_drop) ? 1 : 0;
+    c->i8 = (idr && h->cfg.transform8x8 && h->cfg.i8x8 && h->cfg.intra_mode == 0 && !c->iac_drop && qp <= I8_QP_MAX) ? 1 : 0;
     c->qp_off = h->cfg.aq_mode ? h->d_qp_off[set] : nullptr;
     c->intra_p = h->cfg.intra_in_p ? (h->cfg.i4x4 && h->cfg.intra_in_p > 1 ? 2 : 1) : 0; // 2: Intra_4x4 as well
 }

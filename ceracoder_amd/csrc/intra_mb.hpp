@@ -189,7 +189,7 @@ struct ic_nohook {
 static_assert(offsetof(intra_lds, T4t) == offsetof(intra_lds, T4) + 17 * 24, "the transposed tile follows the tile (addressed as one array)");
 // Reconstruction of one intra macroblock by two waves (wave 0 luma, wave 1 chroma; the planes share nothing after the
 // decisions).  Needs L->top / L->left in place and visible; dec0/dec1: the 24-byte decision of intra_analyse_kernel.
-template <bool OUT, bool SC1, class HK> // SC1: reconstruction stored write-through (sc1): intra_p_kernel, whose samples the deblocker reads while the kernel runs
+template <bool OUT, bool SC1, class HK, bool I8 = false> // I8: Intra_8x8 macroblocks may occur (the rows kernel of I pictures; everywhere else the branch is compiled out).  SC1: reconstruction stored write-through (sc1): intra_p_kernel, whose samples the deblocker reads while the kernel runs
 DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, intra_lds *L, const int mx, const int my, const int wave, const int lane,
                        const uint4 dec0, const uint2 dec1, const uint2 *presrc, HK &hk) { // presrc: this lane's source samples, loaded ahead (luma: .x, one word; chroma: the 8 interleaved bytes)
     int (*top)[17] = L->top;
@@ -228,7 +228,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
     // ---- decisions were taken by intra_analyse_kernel (oracle: orc_intra_decide)
     const int mode16 = (int)(dec1.x & 255), cmode = (int)((dec1.x >> 8) & 255);
     const int itype = (int)((dec1.x >> 16) & 255);   // 0 Intra_16x16, 1 Intra_4x4, 2 Intra_8x8 (wave-uniform)
-    const bool use_i4 = itype == 1, use_i8 = itype == 2;
+    const bool use_i4 = itype == 1, use_i8 = I8 && itype == 2;
     unsigned nz4 = 0;
     WAVE_SYNC(); // S4 is in place
     unsigned nz16 = 0, ldc_any = 0, cnz8 = 0, cdc2 = 0;

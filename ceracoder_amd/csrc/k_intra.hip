@@ -633,6 +633,7 @@ struct ir_chroma_hook {
     DEV void chroma_done(unsigned a, unsigned b) { nz8 = a; dc2 = b; }
 };
 
+template <bool IR_I8> // Intra_8x8 macroblocks may occur (ctx->i8).  A build of its own: with the branch compiled in, the Intra_4x4 chain of the default path is 9 % slower (register allocation)
 __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
     __shared__ intra_lds LD[IR_LW + 1]; // private to each compute wave
     __shared__ ir_shared SH;
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
             hk.x = x; hk.has_left = has_left; hk.nz = 0; hk.ldc = false;
             if (!use_i4) { // Intra_16x16 / Intra_8x8: the whole top line, the corner, the whole left column
                 int tv = 0, lv = 0;
-                if (itype == 2) { // ... and the first eight samples of the macroblock above-right (its granules 0 and 1; the row above does not wait for this row)
+                if (IR_I8 && itype == 2) { // ... and the first eight samples of the macroblock above-right (its granules 0 and 1; the row above does not wait for this row)
                     const bool has_tr = has_top && x + 1 < mbw;
                     if (has_tr) ir_wait_lds(&SH.nly, 4u * (unsigned)(x + 1) + 2u, a.err, 14u);
                     if (lane < 8) L->T4[20 + lane] = has_tr ? SH.topy[(x + 1) & (IR_TR - 1)][lane] : (uint8_t)0;
@@ -698,7 +699,7 @@ __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
             }
             {
                 IR_T0();
-                intra_compute<true, false, ir_luma_hook>(ctx, T, L, x, my, 0, lane, dec0, dec1, &srcc, hk);
+                intra_compute<true, false, ir_luma_hook, IR_I8>(ctx, T, L, x, my, 0, lane, dec0, dec1, &srcc, hk);
 #ifdef IR_PROF
                 if (use_i4) { IR_ACC(c_mb4); n4++; } else { IR_ACC(c_mb16); n16++; }
 #endif
@@ -856,7 +857,8 @@ __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
 void k_launch_intra_rows(const frame_ctx_t *h_ctx, int mbh, uint2 *d_gran, unsigned *d_err, unsigned *d_row_done, hipStream_t s) {
     ir_args a;
     a.ctx = *h_ctx; a.gran = d_gran; a.err = d_err; a.row_done = d_row_done;
-    hipLaunchKernelGGL(intra_rows_kernel, dim3(mbh), dim3(64 * IR_WAVES), 0, s, a);
+    if (h_ctx->i8) hipLaunchKernelGGL(intra_rows_kernel<true>, dim3(mbh), dim3(64 * IR_WAVES), 0, s, a);
+    else hipLaunchKernelGGL(intra_rows_kernel<false>, dim3(mbh), dim3(64 * IR_WAVES), 0, s, a);
 }
 
 // =================================================================== launchers

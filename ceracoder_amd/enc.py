@@ -230,7 +230,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False, intra_slices=0, profile_overlap=False, partitions=False, i8x8=True):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False, intra_slices=0, profile_overlap=False, partitions=False, i8x8=False):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)

@@ -112,8 +112,11 @@ typedef struct {
                                  alone (the picture costs the stream about two periods).  1: sampled P pictures keep the free-running schedule -- the
                                  event pairs sit on the streams the kernels are launched on, and a launch that waits on the device for another kernel's
                                  rows is timed with that wait, as a kernel trace would show it.  IDR pictures are always sampled in order */
-    int i8x8;                 /* 1 (default): with transform8x8, the macroblocks of I pictures may be Intra_8x8 (x264enc: dct8x8 brings the transform and the
-                                 intra type together); needs intra_mode 0 (the macroblock above-right has to be complete), otherwise ignored.  0: off */
+    int i8x8;                 /* 0 (default): off.  1: with transform8x8, the macroblocks of I pictures may be Intra_8x8 (x264enc: dct8x8 brings the transform
+                                 and the intra type together) at picture quantisers up to 37; needs intra_mode 0 (the macroblock above-right has to be
+                                 complete), otherwise ignored.  Measured at 1080p: IDR pictures 1.4 - 3.9 % smaller at QP 22 - 34 at equal PSNR, and an
+                                 Intra_8x8 macroblock is one step of the intra wavefront (four dependent 8x8 blocks), so a stream with key-int 60 runs
+                                 7 - 9 % slower */
 } mi355enc_cfg_t;
 
 typedef struct {

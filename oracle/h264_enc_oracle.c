@@ -962,7 +962,8 @@ static void intra4x4_recon(const uint8_t *src_y, uint8_t *rec_y, int stride, int
  * else 4) with the expected mode taken inside the macroblock (neighbours outside count as DC), macroblock taken as Intra_8x8 when that total + 10 lambda
  * is strictly below what Intra_16x16 / Intra_4x4 left.  The record is mb_type 2 with ORC_NZ_T8 set (whatever its levels), the four modes in
  * lev[ORC_L_LDC + 0..3], the levels de-interleaved like the inter macroblocks' 8x8 blocks. */
-static int g_orc_i8x8 = 1; /* process-wide (default on): try Intra_8x8 in the I pictures of a stream with the 8x8 transform (mi355enc_cfg_t.i8x8) */
+static int g_orc_i8x8 = 0; /* process-wide (default off, like mi355enc_cfg_t.i8x8): try Intra_8x8 in the I pictures of a stream with the 8x8 transform */
+#define ORC_I8_QP_MAX 37    /* ... at picture quantisers up to this one: above it the four CAVLC sub-blocks of an 8x8 block cost more than the prediction saves (measured) */
 void orc_set_i8x8(int on) { g_orc_i8x8 = on; }
 int orc_get_i8x8(void) { return g_orc_i8x8; }
 /* availability of the neighbours of 8x8 block b (raster) of a macroblock with has_top / has_left / has_tr */
@@ -1200,7 +1201,7 @@ void orc_intra_frame(const uint8_t *src_y, const uint8_t *src_uv, uint8_t *rec_y
     orc_idec_t *idec = (orc_idec_t *)malloc((size_t)mbw * mbh * sizeof(orc_idec_t));
     orc_intra_analyse(src_y, src_uv, stride, mbw, mbh, isad);
     orc_intra_decide(isad, mbw, mbh, qp, drop > 0 ? 0 : g_orc_i4x4, idec); /* on the ladder: Intra_16x16 only (Intra_4x4 costs its mode bits whatever the residual) */
-    if (g_orc_t8 && g_orc_i8x8 && drop == 0) orc_intra_decide8(src_y, stride, mbw, mbh, qp, idec);
+    if (g_orc_t8 && g_orc_i8x8 && drop == 0 && qp <= ORC_I8_QP_MAX) orc_intra_decide8(src_y, stride, mbw, mbh, qp, idec);
     for (int my = 0; my < mbh; my++)
         for (int mx = 0; mx < mbw; mx++) intra_mb(src_y, src_uv, rec_y, rec_uv, stride, mbw, mx, my, qp, &idec[my * mbw + mx], mbi, levels, iac);
     free(isad);

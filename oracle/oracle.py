@@ -360,7 +360,7 @@ def set_part_levels(levels):
 
 
 def set_i8x8(on):
-    """Process-wide (default on): Intra_8x8 macroblocks in the I pictures of a stream with the 8x8 transform (the product's cfg.i8x8; it needs intra_mode 0)."""
+    """Process-wide (default off): Intra_8x8 macroblocks in the I pictures of a stream with the 8x8 transform (the product's cfg.i8x8; it needs intra_mode 0)."""
     lib().orc_set_i8x8(int(on))
 
 

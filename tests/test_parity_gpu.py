@@ -213,23 +213,24 @@ def test_intra_kernel_matches_oracle(E, oracle, w, h, qp, i4, imode):
 def test_intra8x8_kernel_matches_oracle(E, oracle, w, h, qp, rows):
     """High profile: I pictures may hold Intra_8x8 macroblocks (filtered reference samples, nine modes, the 8x8 transform with the intra rounding; the rows
     kernel takes them whole, with the first eight samples of the macroblock above-right) -- decisions, records, levels and reconstruction equal the oracle's
-    (orc_intra_decide8 / intra8x8_recon), with and without slices; with i8x8 off, or with an intra schedule that cannot have the macroblock above-right
+    (orc_intra_decide8 / intra8x8_recon), with and without slices; not above picture QP 37; with i8x8 off (the default), or with an intra schedule that cannot have the macroblock above-right
     ready (intra_mode 1, 2), the picture is the one without them."""
     cy, cuv = frames(w, h, 1)[0][:2]
     oracle.set_transform8x8(True)
     oracle.set_slice_rows(rows)
+    oracle.set_i8x8(True)
     try:
         o_y, o_uv, o_mbi, o_lev = oracle.intra_frame(cy, cuv, qp)
         oracle.set_i8x8(False)
         n_y, n_uv, n_mbi, n_lev = oracle.intra_frame(cy, cuv, qp)
     finally:
         oracle.set_transform8x8(False)
-        oracle.set_i8x8(True)
+        oracle.set_i8x8(False)
         oracle.set_slice_rows(0)
     is8 = (o_mbi["mb_type"] == 2) & ((o_mbi["nzmask"] >> 27) & 1).astype(bool)
-    assert is8.any() or (qp == 10 and w == 64)
-    for kw, (r_y, r_uv, r_mbi, r_lev) in (({}, (o_y, o_uv, o_mbi, o_lev)), ({"i8x8": False}, (n_y, n_uv, n_mbi, n_lev)), ({"intra_mode": 1}, (n_y, n_uv, n_mbi, n_lev)),
-                                          ({"intra_mode": 2}, (n_y, n_uv, n_mbi, n_lev))):
+    assert is8.any() == (qp <= 37) or (qp == 10 and w == 64)   # (not above picture QP 37: ORC_I8_QP_MAX)
+    for kw, (r_y, r_uv, r_mbi, r_lev) in (({"i8x8": True}, (o_y, o_uv, o_mbi, o_lev)), ({}, (n_y, n_uv, n_mbi, n_lev)), ({"i8x8": True, "intra_mode": 1}, (n_y, n_uv, n_mbi, n_lev)),
+                                          ({"i8x8": True, "intra_mode": 2}, (n_y, n_uv, n_mbi, n_lev))):
         e = E.Encoder(cy.shape[1], cy.shape[0], fixed_qp=qp, transform8x8=True, **kw)
         e.stage_set_slice_rows(rows)
         d_y, d_uv, d_mbi, d_lev = e.stage_intra(cy, cuv, qp)
@@ -348,11 +349,14 @@ def test_encoder_bitstream_equals_oracle(E, oracle, w, h, n, graphs, mode, sub, 
 
 @pytest.mark.parametrize("w,h,n", [(64, 48, 6), (176, 144, 6), (322, 182, 5), (1280, 720, 3)])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_high_profile_8x8_transform_equals_oracle(E, oracle, w, h, n, mode):
-    """transform8x8=1: P macroblocks through the 8x8 transform kernel path, deblocking with 8x8 block edges."""
+@pytest.mark.parametrize("i8", [False, True])
+def test_high_profile_8x8_transform_equals_oracle(E, oracle, w, h, n, mode, i8):
+    """transform8x8=1: P macroblocks through the 8x8 transform kernel path, deblocking with 8x8 block edges; i8: Intra_8x8 macroblocks in the I pictures
+    (their inner 4-sample edges are not deblocked either)."""
     oracle.set_transform8x8(True)
+    oracle.set_i8x8(i8)
     try:
-        e = E.Encoder(w, h, gop=4, fixed_qp=30, transform8x8=True, keep_prefilter=True, deblock_mode=mode)
+        e = E.Encoder(w, h, gop=4, fixed_qp=30, transform8x8=True, keep_prefilter=True, deblock_mode=mode, i8x8=i8)
         oe = oracle.Encoder(w, h, gop=4, threads=8)
         dec = oracle.Decoder()
         for i, (_, _, y, uv) in enumerate(frames(w, h, n)):
@@ -368,6 +372,7 @@ def test_high_profile_8x8_transform_equals_oracle(E, oracle, w, h, n, mode):
             assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv)
         e.close()
     finally:
+        oracle.set_i8x8(False)
         oracle.set_transform8x8(False)
 
 
@@ -828,18 +833,20 @@ def test_schedules_and_options_give_the_oracle_stream(E, oracle, exclusive, sing
         oracle.set_features(oracle.F_ALL)
 
 
-@pytest.mark.parametrize("w,h,n,depth,aq", [(322, 182, 7, 0, False), (640, 368, 8, 1, True), (1280, 720, 6, 2, False), (1920, 1080, 6, 2, True)])
-def test_high_profile_stream_through_the_fused_stage_equals_oracle(E, oracle, w, h, n, depth, aq):
+@pytest.mark.parametrize("w,h,n,depth,aq,i8", [(322, 182, 7, 0, False, False), (640, 368, 8, 1, True, True), (1280, 720, 6, 2, False, True), (1920, 1080, 6, 2, True, False),
+                                                 (1920, 1080, 4, 2, False, True)])
+def test_high_profile_stream_through_the_fused_stage_equals_oracle(E, oracle, w, h, n, depth, aq, i8):
     """transform8x8=1 since r03: the fused P stage (skip probe, refinement against the predictor estimates, intra macroblocks, the drop ladder) with the 8x8
     transform for the luma residual of the inter macroblocks (pmb_luma_t8), overlapped like the Baseline stream; a clip with a cut, so that P pictures
     carry intra macroblocks; with and without adaptive quantisation.  Access units, reconstruction and the independent decoder agree; 8x8-transform,
     skipped and intra macroblocks all occur."""
     oracle.set_transform8x8(True)
+    oracle.set_i8x8(i8)
     try:
         from tests.util import half_static_clip
         clip = half_static_clip(w, h, n, (h // 3) & ~15)
         qps = [28, 24, 32, 51, 26, 30, 22, 36]
-        e = E.Encoder(w, h, gop=30, fixed_qp=30, transform8x8=True, pipeline_depth=depth, exclusive=True, scenecut=False, aq=aq)
+        e = E.Encoder(w, h, gop=30, fixed_qp=30, transform8x8=True, pipeline_depth=depth, exclusive=True, scenecut=False, aq=aq, i8x8=i8)
         oe = oracle.Encoder(w, h, gop=30, threads=8, scenecut=False, aq=aq)
         dec = oracle.Decoder()
         got = []
@@ -865,4 +872,5 @@ def test_high_profile_stream_through_the_fused_stage_equals_oracle(E, oracle, w,
         assert t8 > 0 and skip > 0, (t8, skip, intra)
         e.close()
     finally:
+        oracle.set_i8x8(False)
         oracle.set_transform8x8(False)

@@ -129,4 +129,4 @@ def test_intra8x8_streams_decode_and_the_host_writer_codes_them(oracle, w, h, qp
             assert n8 > 0
     finally:
         oracle.set_transform8x8(False)
-        oracle.set_i8x8(True)
+        oracle.set_i8x8(False)
