@@ -53,6 +53,7 @@ typedef struct {
     gint aq_mode;
     gint slices;
     gboolean partitions;
+    gboolean i8x8;
     gboolean single_stream;
     /* streaming state */
     mi355enc_t *enc;
@@ -68,7 +69,7 @@ typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 G_DEFINE_TYPE(GstMi355H264Enc, gst_mi355h264enc, GST_TYPE_VIDEO_ENCODER)
 
 enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME_RANGE, PROP_QP, PROP_PIPELINE_DEPTH,
-       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE, PROP_PINNED_INPUT, PROP_AQ_MODE, PROP_SINGLE_STREAM, PROP_SLICES, PROP_PARTITIONS };
+       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE, PROP_PINNED_INPUT, PROP_AQ_MODE, PROP_SINGLE_STREAM, PROP_SLICES, PROP_PARTITIONS, PROP_I8X8 };
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-raw, format=(string){ NV12, I420, YUY2, UYVY }, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
@@ -121,6 +122,7 @@ static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *
     case PROP_AQ_MODE: s->aq_mode = g_value_get_int(val); break;
     case PROP_SLICES: s->slices = g_value_get_int(val); break;
     case PROP_PARTITIONS: s->partitions = g_value_get_boolean(val); break;
+    case PROP_I8X8: s->i8x8 = g_value_get_boolean(val); break;
     case PROP_SINGLE_STREAM: s->single_stream = g_value_get_boolean(val); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
@@ -149,6 +151,7 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     case PROP_AQ_MODE: g_value_set_int(val, s->aq_mode); break;
     case PROP_SLICES: g_value_set_int(val, s->slices); break;
     case PROP_PARTITIONS: g_value_set_boolean(val, s->partitions); break;
+    case PROP_I8X8: g_value_set_boolean(val, s->i8x8); break;
     case PROP_SINGLE_STREAM: g_value_set_boolean(val, s->single_stream); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
@@ -197,7 +200,7 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     GST_OBJECT_LOCK(s);
     cfg.gop = s->key_int_max ? (int)s->key_int_max : 250;
     cfg.me_range = s->me_range; cfg.bitrate_bps = target_bps(s); cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
-    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0; cfg.scenecut = s->scenecut ? 1 : 0; cfg.exclusive_device = s->exclusive_gpu ? 1 : 0; cfg.vbv_ms = (int)s->vbv_ms; cfg.intra_in_p = s->intra_in_p ? 1 : 0; cfg.aq_mode = s->aq_mode; cfg.single_stream = s->single_stream ? 1 : 0; cfg.intra_slices = s->slices; cfg.partitions = s->partitions ? 1 : 0;
+    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0; cfg.scenecut = s->scenecut ? 1 : 0; cfg.exclusive_device = s->exclusive_gpu ? 1 : 0; cfg.vbv_ms = (int)s->vbv_ms; cfg.intra_in_p = s->intra_in_p ? 1 : 0; cfg.aq_mode = s->aq_mode; cfg.single_stream = s->single_stream ? 1 : 0; cfg.intra_slices = s->slices; cfg.partitions = s->partitions ? 1 : 0; cfg.i8x8 = s->i8x8 ? 1 : 0;
     GST_OBJECT_UNLOCK(s);
     int r = mi355enc_open(&cfg, &e);
     if (r != MI355ENC_OK) {
@@ -406,6 +409,8 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
         "Slices per IDR picture, one NAL unit each (0: about 17 macroblock rows per slice, 4 at 1080p): the slices are reconstructed side by side; P pictures are one slice", 0, 64, 0, F));
     g_object_class_install_property(g, PROP_PARTITIONS, g_param_spec_boolean("partitions", "Inter partitions",
         "P macroblocks may be split into 16x8, 8x16 or 8x8 partitions (x264enc: what speed-preset veryfast and slower analyse; superfast, the reference's preset, does not)", FALSE, F));
+    g_object_class_install_property(g, PROP_I8X8, g_param_spec_boolean("i8x8", "Intra 8x8",
+        "With dct8x8: the macroblocks of I pictures may be Intra_8x8 (x264enc: part of dct8x8; here a switch of its own: IDR pictures 1.4 - 3.9 % smaller, the stream 7 - 9 % slower)", FALSE, F));
     g_object_class_install_property(g, PROP_SINGLE_STREAM, g_param_spec_boolean("single-stream", "One HIP stream",
         "Run every stage of this encoder in order on one HIP stream (one hardware queue): for many encoders sharing a GPU", FALSE, F));
     g_object_class_install_property(g, PROP_PINNED_INPUT, g_param_spec_boolean("pinned-input", "Offer pinned input buffers",
@@ -424,7 +429,7 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->rate_raw = 2048; s->rate_is_bps = FALSE; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
-    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = TRUE; s->pinned_input = TRUE; s->aq_mode = 0; s->slices = 0; s->partitions = FALSE; s->single_stream = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
+    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = TRUE; s->pinned_input = TRUE; s->aq_mode = 0; s->slices = 0; s->partitions = FALSE; s->i8x8 = FALSE; s->single_stream = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
 }
 
 GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */
