@@ -96,41 +96,37 @@ DEV unsigned i8_tq8(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, in
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] = tile[j * 8 + i];
         fdct8_1d(v);
-    }
-    WAVE_SYNC();
-    if (act) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) tile[j * 8 + i] = v[i];
+        for (int i = 0; i < 8; i++) tile[j * 8 + i] = v[i]; // (a lane's own row: no other lane reads or writes it in this pass)
     }
     WAVE_SYNC();
     if (act) {
 #pragma unroll
         for (int r = 0; r < 8; r++) v[r] = tile[r * 8 + j];
         fdct8_1d(v);
-        const int qbits = 16 + k6, f = (1 << qbits) / 3;
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int cl = pos_class8(r, j), a = iabs(v[r]);
-            int l = (int)(((long long)a * T->mf8[m6][cl] + f) >> qbits);
-            l = l > 2047 ? 2047 : l;
-            l = v[r] < 0 ? -l : l;
-            const int kk = T->izz8[r * 8 + j];
-            stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + (4 * b8 + (kk & 3)) * 16 + (kk >> 2)], l);
-            if (l) submask |= 1u << (kk & 3);
-            const int ls = 16 * T->v8[m6][cl];
-            v[r] = qp >= 36 ? (l * ls) << (k6 - 6) : (l * ls + (1 << (5 - k6))) >> (6 - k6);
-        }
 #pragma unroll
         for (int r = 0; r < 8; r++) tile[r * 8 + j] = v[r];
+    }
+    WAVE_SYNC();
+    { // quantiser and scaling: one coefficient per lane (row lane >> 3, column lane & 7)
+        const int r = lane >> 3, c = lane & 7, cf = tile[lane];
+        const int qbits = 16 + k6, f = (1 << qbits) / 3;
+        const int cl = pos_class8(r, c), a = iabs(cf);
+        int l = (int)(((long long)a * T->mf8[m6][cl] + f) >> qbits);
+        l = l > 2047 ? 2047 : l;
+        l = cf < 0 ? -l : l;
+        const int kk = T->izz8[lane];
+        stg16(&ctx->levels[(size_t)mbn * MB_LEVELS + L_LUMA + (4 * b8 + (kk & 3)) * 16 + (kk >> 2)], l);
+        const int ls = 16 * T->v8[m6][cl];
+        tile[lane] = qp >= 36 ? (l * ls) << (k6 - 6) : (l * ls + (1 << (5 - k6))) >> (6 - k6);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (__ballot(l != 0 && (kk & 3) == k)) submask |= 1u << k;
     }
     WAVE_SYNC();
     if (act) { // 8.5.13: rows, then columns
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] = tile[j * 8 + i];
         idct8_1d(v);
-    }
-    WAVE_SYNC();
-    if (act) {
 #pragma unroll
         for (int i = 0; i < 8; i++) tile[j * 8 + i] = v[i];
     }
@@ -139,18 +135,12 @@ DEV unsigned i8_tq8(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, in
 #pragma unroll
         for (int r = 0; r < 8; r++) v[r] = tile[r * 8 + j];
         idct8_1d(v);
-    }
-    WAVE_SYNC();
-    if (act) {
 #pragma unroll
         for (int r = 0; r < 8; r++) tile[r * 8 + j] = (v[r] + 32) >> 6;
     }
     WAVE_SYNC();
     rres = tile[lane];
-    unsigned m = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) if (__ballot(act && ((submask >> k) & 1u))) m |= 1u << k;
-    return m;
+    return submask;
 }
 
 // =================================================================== intra (I) macroblocks
@@ -351,15 +341,17 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         if (OUT && lane < 16) { L->bot_y[slot][lane] = T4[16 * 24 + lane + 4]; L->right_y[lane] = T4[17 * 24 + 16 * 24 + lane + 4]; }
     } else if (use_i8 && wave == 0) {
         // ================================================================ Intra_8x8 reconstruction (8.3.2 + 8.5.13; oracle: intra8x8_recon)
-        // The four blocks one after another, lane = one sample.  The caller has the whole top line, the corner and the left column in L->top / L->left (as
-        // for Intra_16x16) and the first eight samples of the macroblock above-right in L->T4[20..27] (block 1 reads them; zero where that macroblock is not
-        // available).  T4 + T4t serve as one tile of stride 32 (17 rows; sample (r, c) at R[(r + 1) * 32 + c + 4]) followed by the neighbour / edge arrays;
-        // S4 becomes the transform's tile once every lane holds its four source samples.
+        // The four blocks one after another, lane = one sample.  The caller has the whole top line and the corner in L->top (as for Intra_16x16) and the first
+        // eight samples of the macroblock above-right in L->T4[20..27] (block 1 reads them; zero where that macroblock is not available); the left column
+        // arrives through the hook, half a macroblock at a time: hk.before8(b, R) in front of blocks 0 and 2 leaves rows 8 (b >> 1) .. + 7 of the left
+        // neighbour's right column in the tile, hk.after8(b, ...) publishes this macroblock's right column behind blocks 1 and 3 -- so macroblock x + 1
+        // runs its upper half while x runs its lower one.  T4 + T4t serve as one tile of stride 32 (17 rows; sample (r, c) at R[(r + 1) * 32 + c + 4])
+        // followed by the neighbour / edge arrays; S4 becomes the transform's tile once every lane holds its four source samples.
+      if constexpr (I8) {
         uint8_t *R = L->T4;
         int *rt = (int *)(L->T4 + 17 * 32), *rl = rt + 16, *e8 = rt + 24;
         static_assert(17 * 32 + 4 * (24 + 25) <= 2 * 17 * 24, "tile + arrays fit T4 + T4t");
         if (lane < 17) R[lane + 3] = (uint8_t)TOP(0, lane - 1);
-        else if (lane >= 32 && lane < 48) R[(lane - 32 + 1) * 32 + 3] = (uint8_t)LEFT(0, lane - 32);
         const int x = lane & 7, y = lane >> 3;
         int sv[4];
 #pragma unroll
@@ -371,6 +363,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             const int bx8 = (b & 1) * 8, by8 = (b >> 1) * 8, mode = (int)((dec0.x >> (8 * b)) & 255u);
             bool up, lf, ul, ur;
             i8_avail(b, has_top, has_left, has_tr, up, lf, ul, ur);
+            hk.before8(b, R);
             WAVE_SYNC();
             const int rc = i8_gather(lane, R, 32, 4, bx8, by8, ur, rt, rl);
             WAVE_SYNC();
@@ -381,6 +374,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             const unsigned m = i8_tq8(ctx, T, (int *)S4, lane, (b == 0 ? sv[0] : b == 1 ? sv[1] : b == 2 ? sv[2] : sv[3]) - pred, qp, mbn, b, rres);
             const int recp = clip255(pred + rres);
             R[(by8 + y + 1) * 32 + bx8 + x + 4] = (uint8_t)recp;
+            hk.after8(b, x, y, recp);
             nz4 |= m << (4 * b);
         }
         nz4 |= NZ_T8; // transform_size_8x8_flag of an I_NxN macroblock is sent whatever its levels
@@ -391,6 +385,7 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
             else stg32(ry + (size_t)(y0 + (lane >> 2)) * stride + x0 + 4 * (lane & 3), rw);
         }
         if (OUT && lane < 16) { L->bot_y[slot][lane] = R[16 * 32 + lane + 4]; L->right_y[lane] = R[(lane + 1) * 32 + 19]; }
+      }
     } else if (wave == 0) {
         // ================================================================ Intra_16x16 reconstruction (8.3.3 + 8.5.10)
         const int bx = lane & 3, by = lane >> 4, mode = mode16, yy = 4 * by + py;

@@ -621,6 +621,22 @@ struct ir_luma_hook {
         if (lane == 0) lds_st_rel(&sh->prog[x & (IR_RING - 1)], ((unsigned)x << 4) | (unsigned)(s + 1));
         IR_ACC(c_after);
     }
+    // Intra_8x8 (intra_compute<..., I8>): the left neighbour's right column half a macroblock at a time -- rows 0..7 are final once it has finished
+    // sub-step 5 / its own block 1 (progress 6), rows 8..15 with the macroblock (10) -- into column -1 of the stride-32 tile
+    DEV void before8(int b, uint8_t *R) {
+        if (has_left && !(b & 1)) {
+            { IR_T0(); ir_wait_lds(&sh->prog[(x - 1) & (IR_RING - 1)], ((unsigned)(x - 1) << 4) | (b ? 10u : 6u), err, 18u); IR_ACC(c_wait_left); }
+            if (lane < 8) R[(4 * b + lane + 1) * 32 + 3] = sh->right[(x - 1) & (IR_RING - 1)][4 * b + lane];
+        }
+    }
+    // ... and this macroblock's right column behind blocks 1 and 3, "six sub-steps done" behind block 1 (what an Intra_4x4 or Intra_8x8 macroblock to
+    // the right waits for before it reads rows 0..7); the caller publishes the bottom line and "complete"
+    DEV void after8(int b, int bx, int by, int recp) {
+        if (b & 1) {
+            if (bx == 7) sh->right[x & (IR_RING - 1)][4 * (b - 1) + by] = (uint8_t)recp;
+            if (b == 1 && lane == 0) lds_st_rel(&sh->prog[x & (IR_RING - 1)], ((unsigned)x << 4) | 6u);
+        }
+    }
     DEV void luma_done(unsigned nzb, bool dc) { nz = nzb; ldc = dc; }
     DEV void chroma_done(unsigned, unsigned) {}
 };
@@ -678,13 +694,13 @@ __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
                     if (has_tr) ir_wait_lds(&SH.nly, 4u * (unsigned)(x + 1) + 2u, a.err, 14u);
                     if (lane < 8) L->T4[20 + lane] = has_tr ? SH.topy[(x + 1) & (IR_TR - 1)][lane] : (uint8_t)0;
                 }
-                if (has_left) ir_wait_lds(&SH.prog[(x - 1) & (IR_RING - 1)], ((unsigned)(x - 1) << 4) | 10u, a.err, 18u);
+                if (has_left && itype != 2) ir_wait_lds(&SH.prog[(x - 1) & (IR_RING - 1)], ((unsigned)(x - 1) << 4) | 10u, a.err, 18u); // (Intra_8x8: the hook, per half)
                 if (has_top) {
                     ir_wait_lds(&SH.nly, 4u * (unsigned)x + 4u, a.err, 14u);
                     if (lane >= 1 && lane < 17) tv = (int)SH.topy[x & (IR_TR - 1)][lane - 1];
                     if (lane == 0 && has_left) tv = (int)SH.topy[(x - 1) & (IR_TR - 1)][15];
                 }
-                if (has_left && lane >= 1 && lane < 17) lv = (int)SH.right[(x - 1) & (IR_RING - 1)][lane - 1];
+                if (has_left && itype != 2 && lane >= 1 && lane < 17) lv = (int)SH.right[(x - 1) & (IR_RING - 1)][lane - 1];
                 if (lane == 0) lv = tv; // the corner belongs to both arrays (0 unless both neighbours exist)
                 if (lane < 17) { L->top[0][lane] = tv; L->left[0][lane] = lv; }
                 WAVE_SYNC();

@@ -114,9 +114,9 @@ typedef struct {
                                  rows is timed with that wait, as a kernel trace would show it.  IDR pictures are always sampled in order */
     int i8x8;                 /* 0 (default): off.  1: with transform8x8, the macroblocks of I pictures may be Intra_8x8 (x264enc: dct8x8 brings the transform
                                  and the intra type together) at picture quantisers up to 37; needs intra_mode 0 (the macroblock above-right has to be
-                                 complete), otherwise ignored.  Measured at 1080p: IDR pictures 1.4 - 3.9 % smaller at QP 22 - 34 at equal PSNR, and an
-                                 Intra_8x8 macroblock is one step of the intra wavefront (four dependent 8x8 blocks), so a stream with key-int 60 runs
-                                 7 - 9 % slower */
+                                 complete), otherwise ignored.  Measured at 1080p: IDR pictures 1.4 - 3.9 % smaller at QP 22 - 34 at equal PSNR; an
+                                 Intra_8x8 macroblock is four dependent 8x8 blocks on the intra wavefront (its neighbour to the right starts half a
+                                 macroblock behind), so a stream with key-int 60 runs 1 - 3 % slower, an all-intra one by a third */
 } mi355enc_cfg_t;
 
 typedef struct {
