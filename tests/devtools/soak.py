@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """dev tool: long CBR run with bitrate changes; every access unit is decoded by the independent decoder and the
-decoder's picture must equal the encoder's reconstruction every `check` pictures.  python tests/devtools/soak.py W H N"""
+decoder's picture must equal the encoder's reconstruction every `check` pictures.  python tests/devtools/soak.py W H N [t8 [i8]]
+(t8: High profile; i8: Intra_8x8 as well, key-int 15 so that I pictures are a good part of the run)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -9,7 +10,8 @@ from oracle import oracle as O
 
 w, h, n = (int(v) for v in sys.argv[1:4])
 t8 = len(sys.argv) > 4 and sys.argv[4] == "t8"
-e = E.Encoder(w, h, fps=60, gop=60, bitrate_bps=6_000_000, pipeline_depth=1, transform8x8=t8)
+i8 = t8 and len(sys.argv) > 5 and sys.argv[5] == "i8"
+e = E.Encoder(w, h, fps=60, gop=15 if i8 else 60, bitrate_bps=6_000_000, pipeline_depth=1, transform8x8=t8, i8x8=i8)
 dec = O.Decoder()
 clip = list(synth.s2_frames(w, h, 24))
 sizes, t0, pend = [], time.time(), []

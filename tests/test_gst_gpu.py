@@ -118,6 +118,30 @@ def test_element_takes_raw_formats_without_videoconvert(tmp_path, oracle, fmt):
 
 
 @pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
+def test_dct8x8_and_i8x8_properties_give_a_high_profile_stream_that_decodes(tmp_path, oracle):
+    """x264enc's `dct8x8` = High profile with the 8x8 transform; its Intra_8x8 half is the property `i8x8` here.  Both streams carry a High-profile SPS and
+    go through the independent decoder; the I pictures differ (Intra_8x8 macroblocks) and are smaller with it."""
+    streams = {}
+    for i8 in ("false", "true"):
+        pf = tmp_path / ("pipe_" + i8)
+        pf.write_text("videotestsrc num-buffers=8 pattern=zone-plate kx2=12 ky2=12 kt=2 ! video/x-raw,width=640,height=368,framerate=30/1,format=NV12 ! "
+                      "mi355h264enc key-int-max=4 qp=28 dct8x8=true i8x8=%s name=venc_bps ! appsink name=appsink sync=false\n" % i8)
+        out = tmp_path / ("out_%s.bin" % i8)
+        r = subprocess.run([HARNESS, str(pf), str(out)], env=gst_env(), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        recs = read_records(str(out))
+        assert len(recs) == 8
+        assert recs[0][1][:5] == b"\x00\x00\x00\x01\x67" and recs[0][1][5] == 100  # profile_idc of the SPS: High
+        dec = oracle.Decoder()
+        for _, au in recs:
+            y, uv = dec.decode(au)
+        assert dec.size == (640, 368)
+        streams[i8] = [au for _, au in recs]
+    assert streams["true"][0] != streams["false"][0]
+    assert len(streams["true"][0]) < len(streams["false"][0])
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
 def test_reference_x264_line_with_only_the_factory_token_changed_runs_at_the_written_rate(tmp_path):
     """The encoder hop of pipeline/mi355x/x264_superfast_camlink (the reference's file, `x264enc` -> `mi355h264enc`, still
     `name=venc_kbps`) between a test source and the appsink: the reference's encoder_control divides by 1000 for that name
