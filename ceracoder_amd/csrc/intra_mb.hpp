@@ -341,10 +341,9 @@ DEV void intra_compute(const frame_ctx_t *__restrict__ ctx, const dev_tables *T,
         if (OUT && lane < 16) { L->bot_y[slot][lane] = T4[16 * 24 + lane + 4]; L->right_y[lane] = T4[17 * 24 + 16 * 24 + lane + 4]; }
     } else if (use_i8 && wave == 0) {
         // ================================================================ Intra_8x8 reconstruction (8.3.2 + 8.5.13; oracle: intra8x8_recon)
-        // The four blocks one after another, lane = one sample.  The caller has the whole top line and the corner in L->top (as for Intra_16x16) and the first
-        // eight samples of the macroblock above-right in L->T4[20..27] (block 1 reads them; zero where that macroblock is not available); the left column
-        // arrives through the hook, half a macroblock at a time: hk.before8(b, R) in front of blocks 0 and 2 leaves rows 8 (b >> 1) .. + 7 of the left
-        // neighbour's right column in the tile, hk.after8(b, ...) publishes this macroblock's right column behind blocks 1 and 3 -- so macroblock x + 1
+        // The four blocks one after another, lane = one sample.  The caller has the whole top line and the corner in L->top (as for Intra_16x16); everything else arrives
+        // through the hook: hk.before8(b, R) in front of blocks 0 and 2 leaves rows 8 (b >> 1) .. + 7 of the left neighbour's right column in the tile, in front of
+        // block 1 the first eight samples of the macroblock above-right in R[20..27] (zero where that macroblock is not available); hk.after8(b, ...) publishes this macroblock's right column behind blocks 1 and 3 -- so macroblock x + 1
         // runs its upper half while x runs its lower one.  T4 + T4t serve as one tile of stride 32 (17 rows; sample (r, c) at R[(r + 1) * 32 + c + 4])
         // followed by the neighbour / edge arrays; S4 becomes the transform's tile once every lane holds its four source samples.
       if constexpr (I8) {

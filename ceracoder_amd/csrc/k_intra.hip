@@ -586,7 +586,7 @@ DEV void ir_deposit(ir_shared *sh, const frame_ctx_t *ctx, int mbn, int x, uint2
 #endif
 struct ir_luma_hook {
     static constexpr bool own_record = true;
-    ir_shared *sh; uint8_t *T4; uint2 *gran_my; unsigned *err; unsigned tag; int x, lane; bool has_top, has_left, feeds;
+    ir_shared *sh; uint8_t *T4; uint2 *gran_my; unsigned *err; unsigned tag; int x, lane, mbw; bool has_top, has_left, feeds;
     unsigned nz; bool ldc;
     unsigned long long c_wait_top = 0, c_wait_left = 0, c_after = 0;
     DEV void before(int s) {
@@ -624,14 +624,25 @@ struct ir_luma_hook {
     // Intra_8x8 (intra_compute<..., I8>): the left neighbour's right column half a macroblock at a time -- rows 0..7 are final once it has finished
     // sub-step 5 / its own block 1 (progress 6), rows 8..15 with the macroblock (10) -- into column -1 of the stride-32 tile
     DEV void before8(int b, uint8_t *R) {
+        if (b == 1) { // block 1 predicts from the first eight samples of the macroblock above-right: its granules 0 and 1 (the row above does not wait for this row)
+            const bool has_tr = has_top && x + 1 < mbw;
+            if (has_tr) { IR_T0(); ir_wait_lds(&sh->nly, 4u * (unsigned)(x + 1) + 2u, err, 14u); IR_ACC(c_wait_top); }
+            if (lane < 8) R[20 + lane] = has_tr ? sh->topy[(x + 1) & (IR_TR - 1)][lane] : (uint8_t)0;
+        }
         if (has_left && !(b & 1)) {
             { IR_T0(); ir_wait_lds(&sh->prog[(x - 1) & (IR_RING - 1)], ((unsigned)(x - 1) << 4) | (b ? 10u : 6u), err, 18u); IR_ACC(c_wait_left); }
             if (lane < 8) R[(4 * b + lane + 1) * 32 + 3] = sh->right[(x - 1) & (IR_RING - 1)][4 * b + lane];
         }
     }
     // ... and this macroblock's right column behind blocks 1 and 3, "six sub-steps done" behind block 1 (what an Intra_4x4 or Intra_8x8 macroblock to
-    // the right waits for before it reads rows 0..7); the caller publishes the bottom line and "complete"
+    // the right waits for before it reads rows 0..7), the bottom line of blocks 2 and 3 as two granules each for the row below; the caller publishes "complete"
     DEV void after8(int b, int bx, int by, int recp) {
+        if (feeds && b >= 2) {
+            int v = recp << (8 * (bx & 3));
+            v |= quad_xor<1>(v);
+            v |= quad_xor<2>(v);
+            if (by == 7 && !(bx & 3)) st64_sc1(gran_my + (size_t)x * 8 + 2 * (b & 1) + (bx >> 2), make_uint2((unsigned)v, tag));
+        }
         if (b & 1) {
             if (bx == 7) sh->right[x & (IR_RING - 1)][4 * (b - 1) + by] = (uint8_t)recp;
             if (b == 1 && lane == 0) lds_st_rel(&sh->prog[x & (IR_RING - 1)], ((unsigned)x << 4) | 6u);
@@ -673,7 +684,7 @@ __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
         // source samples, decisions and the row above's bottom lines come through LDS (the movers), stores are fire-and-forget.
         intra_lds *L = &LD[w];
         ir_luma_hook hk;
-        hk.sh = &SH; hk.T4 = L->T4; hk.gran_my = gran_my; hk.err = a.err; hk.tag = tag; hk.lane = lane; hk.has_top = has_top; hk.feeds = feeds;
+        hk.sh = &SH; hk.T4 = L->T4; hk.gran_my = gran_my; hk.err = a.err; hk.tag = tag; hk.lane = lane; hk.mbw = mbw; hk.has_top = has_top; hk.feeds = feeds;
 #ifdef IR_PROF
         unsigned long long c_mb4 = 0, c_mb16 = 0, c_src = 0, c_rec = 0, n4 = 0, n16 = 0;
         const unsigned long long c_start = __builtin_readcyclecounter();
@@ -687,13 +698,8 @@ __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
             const int itype = (int)((dec1.x >> 16) & 255);
             const bool use_i4 = itype == 1, has_left = x > 0;
             hk.x = x; hk.has_left = has_left; hk.nz = 0; hk.ldc = false;
-            if (!use_i4) { // Intra_16x16 / Intra_8x8: the whole top line, the corner, the whole left column
+            if (!use_i4) { // Intra_16x16: the whole top line, the corner, the whole left column; Intra_8x8: the top line and the corner (the rest through its hooks)
                 int tv = 0, lv = 0;
-                if (IR_I8 && itype == 2) { // ... and the first eight samples of the macroblock above-right (its granules 0 and 1; the row above does not wait for this row)
-                    const bool has_tr = has_top && x + 1 < mbw;
-                    if (has_tr) ir_wait_lds(&SH.nly, 4u * (unsigned)(x + 1) + 2u, a.err, 14u);
-                    if (lane < 8) L->T4[20 + lane] = has_tr ? SH.topy[(x + 1) & (IR_TR - 1)][lane] : (uint8_t)0;
-                }
                 if (has_left && itype != 2) ir_wait_lds(&SH.prog[(x - 1) & (IR_RING - 1)], ((unsigned)(x - 1) << 4) | 10u, a.err, 18u); // (Intra_8x8: the hook, per half)
                 if (has_top) {
                     ir_wait_lds(&SH.nly, 4u * (unsigned)x + 4u, a.err, 14u);
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(64 * IR_WAVES) void intra_rows_kernel(ir_args a) {
             if (!use_i4) { // published at once: right column, bottom line, "complete"
                 WAVE_SYNC();
                 if (lane < 16) SH.right[x & (IR_RING - 1)][lane] = L->right_y[lane];
-                if (feeds && lane < 4) st64_sc1(gran_my + (size_t)x * 8 + lane, make_uint2(((const unsigned *)L->bot_y[x & 3])[lane], tag));
+                if (feeds && lane < 4 && itype != 2) st64_sc1(gran_my + (size_t)x * 8 + lane, make_uint2(((const unsigned *)L->bot_y[x & 3])[lane], tag)); // (Intra_8x8: behind blocks 2 and 3)
                 if (lane == 0) lds_st_rel(&SH.prog[x & (IR_RING - 1)], ((unsigned)x << 4) | 10u);
             }
             if (lane == 0) {
