@@ -14,6 +14,9 @@ bool no_pgate() { static const bool off = getenv("MI355ENC_NO_PGATE") != nullptr
 // deblocking launch): built, bit-exact, and in round 3 SLOWER than one launch behind the other (1080p: 3100-3800 against 4990 frames/s; device
 // timeline in DESIGN.md section 5), so it is off unless MI355ENC_DB2 is set.
 bool no_db2() { static const bool on = getenv("MI355ENC_DB2") != nullptr; return !on; }
+// The intra macroblock rows of a P picture as workgroups of its deblocking launch instead of intra_p_kernel behind pmb_kernel: measured (tests/devtools/ab_env.py, alternating
+// runs in one process) +6 % at 720p, +-0 at 1080p, -3.6 % at 2160p -- so up to 720p's 3600 macroblocks.  MI355ENC_FIP / MI355ENC_NO_FIP force it (read per picture: the tool flips them).
+bool fip_on(int nmb) { return getenv("MI355ENC_NO_FIP") ? false : getenv("MI355ENC_FIP") ? true : nmb <= 3600; } // A/B switch: the intra macroblock rows of a P picture as workgroups of its (one) deblocking launch (default) / as intra_p_kernel behind pmb_kernel
 bool overlap_allowed(const mi355enc_t *h) {
     static const bool serial = getenv("MI355ENC_SERIAL") != nullptr;
     return !serial && h->safe_level == 0 && !h->cfg.single_stream && g_open_encoders.load(std::memory_order_relaxed) == 1;

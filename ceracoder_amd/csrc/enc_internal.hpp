@@ -164,6 +164,7 @@ extern std::atomic<int> g_open_encoders;
 bool exclusive_device(const mi355enc_t *h);
 bool no_pgate();
 bool no_db2();
+bool fip_on(int nmb);
 bool overlap_allowed(const mi355enc_t *h);
 int sync_compute(mi355enc_t *h);
 bool host_range_pinned(const void *p, size_t bytes); // inside memory handed out by mi355enc_host_alloc()

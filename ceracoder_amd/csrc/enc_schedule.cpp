@@ -109,7 +109,7 @@ static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof
 // ... and back part (back stream): needs the deblocked picture before it
 // gate: the reference picture's band-done words (the fused stage then runs on the intra stream, beside that picture's deblocking)
 // rows: the picture's deblocking launch will sit directly behind the previous one and wait on the device for this stage's rows (no event)
-static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split, const unsigned *gate, unsigned ref_epoch, int rows, bool fused_ip = false) {
+static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split, const unsigned *gate, unsigned ref_epoch, int rows, bool fused_ip = false, bool defer_ip = false) {
     hipStream_t st = gate ? h->istream : h->stream;
     if (prof) HIPCHK(hipEventRecord(s->ev[8], st));
     if (false) { // (the two-kernel form of the High-profile path: absolute-vector refinement, 8x8 transform, no skip / intra logic -- kept for reference, reached through the stage entry points only)
@@ -125,7 +125,7 @@ static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof,
             if (rows) h->pmb_rows_total += (uint32_t)h->mbw; // stage's rows (row counts, no event between the streams), and its movers follow intra_p_kernel
             else { HIPCHK(hipEventRecord(h->ev_pmb, st)); HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pmb, 0)); } // (fewer than three pictures in flight: by event)
             if (fused_ip) k_launch_wait_started(h->d_progress + 2, h->ip_done_total, err_word(h), st); // the intra macroblock rows ride in the deblocking launch (enqueued already): records and levels are final once they have all counted themselves
-            else if (hc->intra_p) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st);
+            else if (hc->intra_p && !defer_ip) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st); // (defer_ip: the caller enqueues the deblocking launch that carries them)
         } else if (split) { // intra_p_kernel leaves the chain: prep + the band deblocker follow the fused stage directly and overtake it row by row
             HIPCHK(hipEventRecord(h->ev_pmb, st));
             HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0));
@@ -218,7 +218,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // rows of bands b-1 .. b+1 -- by then the previous launch is through band b+2, so band b's strips and parameter table are free.
         // So consecutive such launches alternate between two streams; a picture whose stages run in order joins both.
         hipStream_t mst = h->stream;
-        bool early_db = false;
+        bool early_db = false, fip = false;
         if (prows && !no_db2() && !c->qp_off) {
             h->db_flip ^= 1;
             if (h->db_flip) {
@@ -243,7 +243,15 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
             // land on until they drain (device timeline: the launch sat there for 250 us and did its work after pmb_kernel had ended).
             early_db = prows && !no_db2() && !c->qp_off;
             if (early_db) { int r = run_deblock(h, ci, c, mst, c->intra_p ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, true, h->pmb_rows_total + (uint32_t)h->mbw, c->intra_p != 0); if (r) return r; }
-            int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur], prows, early_db && c->intra_p); if (r) return r;
+            // One launch in flight, the intra macroblock rows inside it: the rows no longer queue behind the END of pmb_kernel (stream order) -- each starts when pmb_kernel
+            // has completed its row and the row above, so the upper bands find them done when the launch starts.  Behind pmb_kernel in host order: nothing here waits for a
+            // kernel that is not on the chip or in front of it in its own stream.  Not on sampled pictures (the timers bracket the launches in stream order).
+            fip = prows && !early_db && !c->qp_off && c->intra_p && !prof && fip_on(h->nmb);
+            int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur], prows, early_db && c->intra_p, fip); if (r) return r;
+            if (fip) {
+                r = run_deblock(h, ci, c, mst, h->d_ip_progress, nullptr, h->d_db_done + (size_t)nxt * nbd, true, h->pmb_rows_total, true); if (r) return r;
+                k_launch_wait_started(h->d_progress + 2, h->ip_done_total, err_word(h), h->istream); // records and levels are final once the rows have all counted themselves
+            }
         }
         if (prof) HIPCHK(hipEventRecord(s->ev[2], h->stream));
         HIPCHK(hipGetLastError());
@@ -258,7 +266,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
             int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * h->mbh, h->d_db_done + (size_t)nxt * nbd); if (r) return r;
             HIPCHK(hipEventRecord(h->ev_dbI[nxt], h->istream));
             h->dbI_busy[nxt] = 1;
-        } else if (!early_db) { int r = run_deblock(h, ci, c, mst, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, prows != 0); if (r) return r; }
+        } else if (!early_db && !fip) { int r = run_deblock(h, ci, c, mst, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, prows != 0); if (r) return r; }
         h->rec_epoch[nxt] = h->cfg.deblock_mode == 0 ? c->epoch : 0;
         if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
         // Hand-over, enqueued after the deblocking launches so that it cannot be dispatched ahead of them: the device packs the non-zero
