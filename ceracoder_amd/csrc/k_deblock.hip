@@ -498,6 +498,9 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                 if (work) flagw[1] = 1u;
             }
         }
+#ifdef TL_PROF
+        if (!CHROMA && band == 0 && threadIdx.x == 0) *((volatile unsigned long long *)ctx->dbrec + (ctx->epoch & 63) * 16 + 14) = wall_clock64(); // band 0: its own records are on their way
+#endif
         if (!ALL_INTRA) {
             // the neighbours: "is there an intra macroblock or a coded luma block" (=> an inner edge with bS >= 2) settles it nearly always, with one load per macroblock;
             // only a band of nothing but bare vectors needs the records' own test (vector differences across edges)
@@ -525,6 +528,9 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
         if (a.band_done && threadIdx.x < DB_DONE_COPIES) st_sc1(a.band_done + DB_DONE_STRIDE * threadIdx.x + 2 * band + (CHROMA ? 1 : 0), ctx->epoch);
         return;
     }
+#ifdef TL_PROF
+    if (!CHROMA && band == 0 && threadIdx.x == 0) *((volatile unsigned long long *)ctx->dbrec + (ctx->epoch & 63) * 16 + 15) = wall_clock64(); // band 0: the prologue is over
+#endif
     const bool up_work = ALL_INTRA || flagw[0] != 0; // the band above publishes its strips
     const bool dn_work = ALL_INTRA || flagw[2] != 0; // ... and the band below reads ours
     const unsigned epoch = ctx->epoch;

@@ -33,6 +33,14 @@ for r in rows:
     us = [(int(r[k]) - int(r[7])) / 100.0 if r[k] > 0 else float('nan') for k in range(14)]
     gap = (int(r[7]) - int(prev[8])) / 100.0 if prev is not None else float("nan")
     per = (int(r[7]) - int(prev[7])) / 100.0 if prev is not None else float("nan")
-    print(" " * 73 + " ".join("%7.1f" % x for x in us) + "   %7.1f | %7.1f" % (gap, per))
+    pro = [(int(r[k]) - int(r[9])) / 100.0 for k in (14, 15)]  # band 0's prologue: its own records computed (stores under way), step loop about to start -- us after its row wait
+    print(" " * 73 + " ".join("%7.1f" % x for x in us) + "   %7.1f | %7.1f | band 0 prologue: records +%.1f, loop starts +%.1f, loop %.1f us" % (gap, per, pro[0], pro[1], (int(r[10]) - int(r[15])) / 100.0))
     prev = r
+last = rows[-1]
+e.time_stage(E.STAGE_DEBLOCK, 1)  # the last picture's launch once more, alone: its marks land in the same slots
+assert e.L.mi355enc_fetch(e.h, 100, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+t2 = buf.reshape(-1)[:64 * 16].reshape(64, 16).astype(np.int64)
+for r in t2:
+    if r[7] > last[7]:
+        print("the same launch alone: band 0 records +%.1f, loop starts +%.1f, loop %.1f us; launch %.1f us" % ((int(r[14]) - int(r[9])) / 100.0, (int(r[15]) - int(r[9])) / 100.0, (int(r[10]) - int(r[15])) / 100.0, (int(r[8]) - int(r[7])) / 100.0))
 e.close()
