@@ -7,7 +7,7 @@ import numpy as np, torch
 from ceracoder_amd import enc as E, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 for (w, h, kw) in ((1920, 1080, {}), (1920, 1080, {"aq": True}), (1920, 1080, {"partitions": True}), (1920, 1080, {"aq": True, "partitions": True, "intra_slices": 8}),
-                   (1280, 720, {}), (3840, 2160, {}), (3840, 2160, {"aq": True, "partitions": True})):
+                   (1280, 720, {}), (1280, 720, {"partitions": True}), (640, 368, {}), (1920, 1080, {"transform8x8": True, "i8x8": True}), (3840, 2160, {}), (3840, 2160, {"aq": True, "partitions": True})):  # (720p and below: the intra rows ride in the deblocking launch)
     cnt = n if w < 3000 else n // 4
     clip = list(synth.s2_frames(w, h, 16))
     bufs = [torch.from_numpy(np.concatenate([y.reshape(-1), uv.reshape(-1)])).cuda() for y, uv in clip]
