@@ -213,6 +213,7 @@ def main():
                     "(adaptive|aimd|fixed: tests/golden/balancer_<name>.txt, generated from the reference's own balancer code); auto = adaptive for 1080p_ippp "
                     "(BASELINE.json configs[2]: 'balancer driving the bitrate property'), none elsewhere")
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
+    ap.add_argument("--i8x8", type=int, default=0, help="1 (with --dct8x8 1): Intra_8x8 macroblocks in I pictures (picture QP <= 37)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         # One process per stream, as the reference runs them (bindings/typescript/src/process.ts:129-170): start the ranks ourselves, each a fresh
@@ -281,7 +282,7 @@ def main():
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                          pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                         transform8x8=bool(args.dct8x8), cavlc_threads=args.cavlc_threads, exclusive=(S == 1 and not shared_gpu), single_stream=(S > 2), profile_overlap=not args.sample_in_order)
+                         transform8x8=bool(args.dct8x8), i8x8=bool(args.i8x8), cavlc_threads=args.cavlc_threads, exclusive=(S == 1 and not shared_gpu), single_stream=(S > 2), profile_overlap=not args.sample_in_order)
 
     encs = [make_encoder() for _ in range(S)]
     e = encs[0]
@@ -539,7 +540,7 @@ def main():
                            script_name, min(b for _, b in script) // 1000, max(b for _, b in script) // 1000, script_name),
                        "me": "full search +-16 integer-pel SAD (surfaces kept) + %d median-regularised selection iterations + half-sample SAD / quarter-sample SATD refinement" % 3, "streams_per_gpu": S, "hip_streams_per_encoder": 1 if S > 2 else 4, "parallelism": "%d independent streams" % (world * S),
                        "pipeline_depth": args.depth, "exclusive_device": bool(S == 1 and not shared_gpu), "devices_on_box": n_dev, "ranks_share_devices": bool(world > n_dev),
-                       "rank0_cpus": rank_cpus if world > 1 else None, "rank0_numa_node": int(os.environ.get("MI355_BENCH_NUMA_NODE", "-1")), "dct8x8": bool(args.dct8x8), "cavlc_threads": int(st.cavlc_threads)},
+                       "rank0_cpus": rank_cpus if world > 1 else None, "rank0_numa_node": int(os.environ.get("MI355_BENCH_NUMA_NODE", "-1")), "dct8x8": bool(args.dct8x8), "i8x8": bool(args.i8x8), "cavlc_threads": int(st.cavlc_threads)},
             "roofline": roof,
             "roofline_kernels": kernels,
             "stage_timers": ("HIP events on every %d-th P picture, on the streams the kernels are launched on" % args.sample) + (
