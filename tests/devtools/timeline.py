@@ -9,11 +9,11 @@ from ceracoder_amd import enc as E, synth
 E.LIB_PATH = os.environ.get("MI355ENC_LIB", E.LIB_PATH)
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 150
-w, h = 1920, 1080
+w, h = (int(os.environ.get("TL_W", "1920")), int(os.environ.get("TL_H", "1080")))  # TL_W / TL_H: another picture size
 clip = list(synth.s2_frames(w, h, 16))
 bufs = [torch.from_numpy(np.concatenate([y.reshape(-1), uv.reshape(-1)])).cuda() for y, uv in clip]
 torch.cuda.synchronize()
-e = E.Encoder(w, h, fps=60, gop=600, bitrate_bps=6_000_000, pipeline_depth=depth, exclusive=True)
+e = E.Encoder(w, h, fps=60, gop=600, bitrate_bps=6_000_000 * (w * h) // (1920 * 1080), pipeline_depth=depth, exclusive=True)
 for i in range(n):
     k = i % 30
     p = bufs[k if k < 16 else 30 - k].data_ptr()
