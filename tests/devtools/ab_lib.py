@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """dev tool: A/B of two builds of the library (tools/build_variant.sh), alternating child processes so that minute-to-minute noise cancels: N rounds of (A, B),
 600 pictures each after a warm-up GOP, pipeline_depth 2, exclusive, CBR.  One child = one library (a process loads one build).
-    python tests/devtools/ab_lib.py LIB_A LIB_B [W H [rounds]]"""
+    python tests/devtools/ab_lib.py LIB_A LIB_B [W H [rounds]]        (LIB_x may also be VAR=value: the default build with that environment variable)"""
 import os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,7 +38,12 @@ rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 res = {la: [], lb: []}
 for rnd in range(rounds):
     for lib in (la, lb):
-        env = dict(os.environ, MI355ENC_LIB=os.path.join(ROOT, lib))
+        env = dict(os.environ)
+        if "=" in lib:  # "VAR=value" instead of a library: the default build with that variable set ("NONE=0": nothing set) -- for switches read when the encoder is opened
+            k, v = lib.split("=", 1)
+            env[k] = v
+        else:
+            env["MI355ENC_LIB"] = os.path.join(ROOT, lib)
         r = subprocess.run([sys.executable, "-c", CHILD, w, h, "2"], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
         if not line:
