@@ -10,13 +10,10 @@
 std::atomic<int> g_open_encoders{0};
 bool exclusive_device(const mi355enc_t *h) { static const bool env = getenv("MI355ENC_EXCLUSIVE") != nullptr; return h->cfg.exclusive_device != 0 || env; } // cfg.exclusive_device, or the environment for tools
 bool no_pgate() { static const bool off = getenv("MI355ENC_NO_PGATE") != nullptr; return off; } // A/B switch: the fused P stage in stream order behind the deblocking launch
-// Two deblocking launches in flight (consecutive pictures' launches on two streams, the intra macroblock rows of a P picture riding in its
-// deblocking launch): built, bit-exact, and in round 3 SLOWER than one launch behind the other (1080p: 3100-3800 against 4990 frames/s; device
-// timeline in DESIGN.md section 5), so it is off unless MI355ENC_DB2 is set.
-bool no_db2() { static const bool on = getenv("MI355ENC_DB2") != nullptr; return !on; }
 // The intra macroblock rows of a P picture as workgroups of its deblocking launch instead of intra_p_kernel behind pmb_kernel: measured (tests/devtools/ab_env.py, alternating
-// runs in one process) +6 % at 720p, +-0 at 1080p, -3.6 % at 2160p -- so up to 720p's 3600 macroblocks.  MI355ENC_FIP / MI355ENC_NO_FIP force it (read per picture: the tool flips them).
-bool fip_on(int nmb) { return getenv("MI355ENC_NO_FIP") ? false : getenv("MI355ENC_FIP") ? true : nmb <= 3600; } // A/B switch: the intra macroblock rows of a P picture as workgroups of its (one) deblocking launch (default) / as intra_p_kernel behind pmb_kernel
+// runs in one process) +6 % at 720p, +-0 at 1080p, -3.6 % at 2160p -- so up to 720p's 3600 macroblocks.  MI355ENC_FIP / MI355ENC_NO_FIP force it; latched once per encoder at
+// open() (mi355enc::fip_rows): a running encoder's schedule does not depend on a mutable environment, and getenv() is not called beside a host application's setenv().
+bool fip_on(int nmb) { return getenv("MI355ENC_NO_FIP") ? false : getenv("MI355ENC_FIP") ? true : nmb <= 3600; }
 bool overlap_allowed(const mi355enc_t *h) {
     static const bool serial = getenv("MI355ENC_SERIAL") != nullptr;
     return !serial && h->safe_level == 0 && !h->cfg.single_stream && g_open_encoders.load(std::memory_order_relaxed) == 1;
@@ -82,7 +79,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0; c->aq_mode = 0; c->single_stream = 0; c->intra_slices = 0; c->partitions = 0; c->profile_overlap = 0; c->i8x8 = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0; c->aq_mode = 0; c->single_stream = 0; c->intra_slices = 0; c->partitions = 0; c->profile_overlap = 0; c->i8x8 = 0; c->slices = 0; c->slice_deblock = 0;
 }
 
 int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
@@ -91,7 +88,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     const double t_open = now_ms();
     if (cfg->width < 16 || cfg->height < 16 || cfg->width > 8192 || cfg->height > 8192 || (cfg->width & 1) || (cfg->height & 1) ||
         cfg->fps_num <= 0 || cfg->fps_den <= 0 || cfg->gop < 1 || cfg->me_range < 1 || cfg->me_range > 16 ||
-        cfg->pipeline_depth < 0 || cfg->pipeline_depth > NSLOT - 1 || cfg->fixed_qp > 51) {
+        cfg->pipeline_depth < 0 || cfg->pipeline_depth > NSLOT - 1 || cfg->fixed_qp > 51 || cfg->slices < 0 || cfg->intra_slices < 0) {
         fprintf(stderr, "mi355enc: invalid configuration\n");
         return MI355ENC_ERR_ARG;
     }
@@ -111,11 +108,16 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     if (h->cfg.qp_max > 51) h->cfg.qp_max = 51;
     if (h->cfg.qp_min < 0) h->cfg.qp_min = 0;
     h->mbw = (cfg->width + 15) / 16; h->mbh = (cfg->height + 15) / 16;
-    {   // slices per I picture (oracle: orc_auto_intra_slices): about 17 rows each, at most 8
-        int ns = h->cfg.intra_slices > 0 ? h->cfg.intra_slices : h->mbh / 17 < 1 ? 1 : h->mbh / 17 > 8 ? 8 : h->mbh / 17;
-        if (ns > h->mbh) ns = h->mbh;
-        h->islice_rows = ns > 1 ? (h->mbh + ns - 1) / ns : 0;
-        h->stage_slice_rows = 0;
+    {   // slices (oracle: orc_auto_intra_slices, orc_slice_rows_for).  I pictures: about 17 rows each by default, at most 8; P pictures: cfg.slices (0 / 1: one slice).
+        // With slice-local deblocking every slice is a whole number of the deblocker's bands.
+        const bool local = h->cfg.slice_deblock != 0;
+        auto rows_for = [&](int n) { if (n <= 1) return 0; int rows = (h->mbh + n - 1) / n; if (local) rows = (rows + MI355_BAND_ROWS - 1) / MI355_BAND_ROWS * MI355_BAND_ROWS; return rows >= h->mbh ? 0 : rows; };
+        static_assert(MI355_BAND_ROWS == 4, "the oracle rounds slice heights to multiples of four rows (orc_slice_rows_for)");
+        const int ns = h->cfg.intra_slices > 0 ? h->cfg.intra_slices : h->mbh / 17 < 1 ? 1 : h->mbh / 17 > 8 ? 8 : h->mbh / 17;
+        h->islice_rows = rows_for(ns > h->mbh ? h->mbh : ns);
+        h->pslice_rows = rows_for(h->cfg.slices > h->mbh ? h->mbh : h->cfg.slices);
+        h->slice_dbf = local ? 2 : 0;
+        h->stage_slice_rows = 0; h->stage_slice_dbf = 0;
     }
     h->W = h->mbw * 16; h->H = h->mbh * 16; h->nmb = h->mbw * h->mbh;
     h->ysz = (size_t)h->W * h->H; h->csz = h->ysz / 2;
@@ -124,7 +126,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     for (int i = 0; i < NSET; i++) { h->g_intra[i] = h->g_deblock[i] = nullptr; h->d_ctx2[i] = nullptr; h->d_surf[i] = nullptr; h->d_idec2[i] = nullptr; h->d_mbi_set[i] = nullptr; h->d_levels_set[i] = nullptr; h->d_qp_off[i] = nullptr; }
     h->prev_slot = nullptr;
     h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->ustream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->ip_done_total = 0; h->d_row_done = nullptr; h->pmb_rows_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
-    h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr; h->ev_join = nullptr;
+    h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
     h->fixed_qp.store(cfg->fixed_qp);
@@ -132,8 +134,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     *out = h; // from here on close() cleans up partial state
     g_open_encoders.fetch_add(1, std::memory_order_relaxed);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    h->db_flip = 0; h->s2_dirty = 0; h->inorder_since_s2 = 0;
+    h->fip_rows = fip_on(h->nmb);
     for (int i = 0; i < NSET; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
     h->d_ctx = h->d_ctx2[0];
     if (h->cfg.single_stream) { // one hardware queue per encoder: every stage in order on the main stream
@@ -215,8 +216,9 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         for (int k = 0; k < 12; k++) HIPCHK(hipEventCreate(&s->ev[k]));
     }
     h->writer = h264_writer_new(h->mbw, h->mbh, h->cfg.transform8x8);
-    h264_writer_set_slice_rows(h->writer, h->islice_rows);
     if (!h->writer) return MI355ENC_ERR_NOMEM;
+    h264_writer_set_slice_rows(h->writer, h->islice_rows);
+    h264_writer_set_p_slices(h->writer, h->pslice_rows, h->slice_dbf);
     if (h->cfg.cavlc_threads <= 0) { // auto, like x264enc's threads=0
         const unsigned hw = std::thread::hardware_concurrency();
         int n = (int)(hw / 4);
@@ -314,7 +316,6 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->cstream && h->cstream != h->stream) { (void)hipStreamSynchronize(h->cstream); (void)hipStreamDestroy(h->cstream); }
     if (h->fstream && h->fstream != h->stream) (void)hipStreamDestroy(h->fstream);
     if (h->istream && h->istream != h->stream) (void)hipStreamDestroy(h->istream);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     h264_writer_free(h->writer);
     delete h;

@@ -55,6 +55,7 @@ struct slot_t {
     int all_skip;              // the picture is one run of P_Skip macroblocks: written by the host alone, no device work
     uint64_t index;            // position of the picture in the stream
     int is_idr, qp, drop, frame_num, idr_pic_id, rec_index, set;
+    int rc_picked;             // rate control booked this picture (rc_pick): its size is reported back (rc_update) or the booking taken back (rc_cancel)
     int64_t pts;
     // entropy coding on the handle's worker thread (pipeline_depth >= 1): the access unit is coded here while the caller submits the next picture
     uint8_t *au; size_t au_len; int au_state; // 0 not submitted to the worker, 1 queued / being coded, 2 coded (au_len 0: did not fit), 3 the hand-over carried an error word
@@ -74,13 +75,8 @@ struct mi355enc {
     slot_t *prev_slot;                   // slot of the picture enqueued last
     mb_info_t *d_mbi, *d_mbi_set[NSET];  // record/level sets: the hand-over of picture n overlaps the kernels of n+1 (and n+2)
     int16_t *d_levels, *d_levels_set[NSET];
-    // With three pictures in flight consecutive pictures' deblocking launches alternate between `stream` and `cstream`, so that the next
-    // picture's upper bands run beside this picture's lower ones (the hand-over kernels of such pictures go to the intra stream, behind
-    // intra_p_kernel).  No stream of its own for that: a fifth stream in the process cost a third of the frame rate (the runtime then maps
-    // two of them onto one hardware queue, and kernels meant to run beside each other take turns), whatever GPU_MAX_HW_QUEUES said.
-    hipEvent_t ev_join;                  // orders the two against each other where a picture runs its stages in order
-    int db_flip, s2_dirty, inorder_since_s2;
-    hipStream_t cstream;                 // hand-over stream (scan + pack into pinned host memory); second home of the deblocking launches
+    hipStream_t cstream;                 // hand-over stream (scan + pack into pinned host memory)
+    bool fip_rows;                       // the intra macroblock rows of a P picture ride in its deblocking launch (fip_on(), latched at open())
     uint64_t n_submitted;
     uint64_t sc_sum, sc_force_at; int sc_cnt, sc_prev_skip; // scene-cut recovery: summed cost / number of the P pictures since the last IDR; picture to force
     uint8_t *d_rec_y[2], *d_rec_uv[2], *d_pre_y, *d_pre_uv;
@@ -112,6 +108,7 @@ struct mi355enc {
     uint8_t *d_ip_strips;    // ... and the bottom lines they publish for the row below, 32 bytes per macroblock
     uint32_t epoch;
     int islice_rows, stage_slice_rows;   // rows per slice of an I picture (cfg.intra_slices; 0: one slice) / what the single-stage entry points use
+    int pslice_rows, slice_dbf, stage_slice_dbf; // ... of a P picture (cfg.slices); disable_deblocking_filter_idc of every slice (cfg.slice_deblock: 0 or 2) / of the single-stage entry points
     hipStream_t ustream;       // host-to-device copies of the source pictures (pipeline_depth >= 1): a copy engine's queue, so that a picture's transfer runs beside the
                                // previous picture's search instead of in front of this one's; nullptr: the front stream carries them
     hipStream_t istream;       // intra_p_kernel of a P picture: beside prep + the band deblocker, which follows it row by row
@@ -163,7 +160,6 @@ static inline unsigned *err_word(const mi355enc_t *h) { return h->d_progress; }
 extern std::atomic<int> g_open_encoders;
 bool exclusive_device(const mi355enc_t *h);
 bool no_pgate();
-bool no_db2();
 bool fip_on(int nmb);
 bool overlap_allowed(const mi355enc_t *h);
 int sync_compute(mi355enc_t *h);

@@ -79,7 +79,7 @@ static const int32_t k_idrop_ac[DROP_MAX + 1] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24
 void fill_ctx(mi355enc_t *h, frame_ctx_t *c, int qp, int drop, int idr, int set) {
     c->mbi = h->d_mbi; c->levels = h->d_levels; c->isad = h->d_isad; c->dbrec = h->d_dbrec; c->idec = h->d_idec2[set];
     c->stride = h->W; c->mbw = h->mbw; c->mbh = h->mbh;
-    c->slice_rows = idr ? h->islice_rows : 0;
+    c->slice_rows = idr ? h->islice_rows : h->pslice_rows; c->slice_dbf = h->slice_dbf;
     c->partitions = (!idr && h->cfg.partitions && !h->cfg.transform8x8 && h->cfg.deblock_mode == 0) ? 1 : 0;
     c->qp = qp; c->me_range = h->cfg.me_range; c->lambda = k_lambda[qp < 0 ? 0 : qp > 51 ? 51 : qp]; c->i4x4 = h->cfg.i4x4; c->t8 = h->cfg.transform8x8; c->all_intra = idr ? 1 : 0;
     c->surf = h->d_surf[set]; c->imv_a = h->d_imv[set][0]; c->imv_b = h->d_imv[set][1]; c->imv_c = h->d_imv[set][2];
@@ -109,7 +109,7 @@ static int run_p_front(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof
 // ... and back part (back stream): needs the deblocked picture before it
 // gate: the reference picture's band-done words (the fused stage then runs on the intra stream, beside that picture's deblocking)
 // rows: the picture's deblocking launch will sit directly behind the previous one and wait on the device for this stage's rows (no event)
-static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split, const unsigned *gate, unsigned ref_epoch, int rows, bool fused_ip = false, bool defer_ip = false) {
+static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof, int split, const unsigned *gate, unsigned ref_epoch, int rows, bool defer_ip = false) {
     hipStream_t st = gate ? h->istream : h->stream;
     if (prof) HIPCHK(hipEventRecord(s->ev[8], st));
     if (false) { // (the two-kernel form of the High-profile path: absolute-vector refinement, 8x8 transform, no skip / intra logic -- kept for reference, reached through the stage entry points only)
@@ -124,8 +124,7 @@ static int run_p_back(mi355enc_t *h, const frame_ctx_t *hc, slot_t *s, int prof,
         if (gate) { // the main stream carries nothing but deblocking launches, back to back: this picture's bands wait on the device for the fused
             if (rows) h->pmb_rows_total += (uint32_t)h->mbw; // stage's rows (row counts, no event between the streams), and its movers follow intra_p_kernel
             else { HIPCHK(hipEventRecord(h->ev_pmb, st)); HIPCHK(hipStreamWaitEvent(h->stream, h->ev_pmb, 0)); } // (fewer than three pictures in flight: by event)
-            if (fused_ip) k_launch_wait_started(h->d_progress + 2, h->ip_done_total, err_word(h), st); // the intra macroblock rows ride in the deblocking launch (enqueued already): records and levels are final once they have all counted themselves
-            else if (hc->intra_p && !defer_ip) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st); // (defer_ip: the caller enqueues the deblocking launch that carries them)
+            if (hc->intra_p && !defer_ip) k_launch_intra_p(hc, h->mbw, h->mbh, h->d_ip_progress, h->d_ip_strips, err_word(h), st); // (defer_ip: the caller enqueues the deblocking launch that carries them)
         } else if (split) { // intra_p_kernel leaves the chain: prep + the band deblocker follow the fused stage directly and overtake it row by row
             HIPCHK(hipEventRecord(h->ev_pmb, st));
             HIPCHK(hipStreamWaitEvent(h->istream, h->ev_pmb, 0));
@@ -147,8 +146,8 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
     rc_set_bitrate(&h->rc, h->want_bps.load(std::memory_order_relaxed));
     int fq = h->fixed_qp.load(std::memory_order_relaxed);
     int qp, drop;
-    if (fq >= 0) { qp = fq; drop = h->fixed_drop.load(std::memory_order_relaxed); }
-    else rc_pick(&h->rc, idr, &qp, &drop);
+    if (fq >= 0) { qp = fq; drop = h->fixed_drop.load(std::memory_order_relaxed); s->rc_picked = 0; } // (no pick: collect() / recover() then leave rate control alone for this picture)
+    else { rc_pick(&h->rc, idr, &qp, &drop); s->rc_picked = 1; }
     if (idr && drop == DROP_SKIP) drop = 0; // an IDR picture is never skipped; it has a ladder of its own
     const int all_skip = !idr && drop == DROP_SKIP;
     const int nxt = all_skip ? h->cur : (h->cur ^ 1); // an all-skip picture IS its reference: nothing is written
@@ -194,7 +193,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // chain costs 10-17 us).  Not on pictures whose stage timers are sampled (a gated launch's duration includes its waiting).
         // Every kernel-waits-for-kernel overlap below is opt-in (cfg.exclusive_device): next to another process's kernels on the same GPU a
         // kernel that waits on the device for a kernel that has not been placed yet can run into the bound of its wait.
-        const bool may_wait = overlap_allowed(h) && exclusive_device(h) && h->cfg.deblock_mode == 0 && !h->d_pre_y && !(prof && (idr || !h->cfg.profile_overlap || !no_db2())) && !(h->cfg.aq_mode && h->cfg.intra_in_p == 2); // (adaptive quantisation: the QP_Y chain
+        const bool may_wait = overlap_allowed(h) && exclusive_device(h) && h->cfg.deblock_mode == 0 && !h->d_pre_y && !(prof && (idr || !h->cfg.profile_overlap)) && !(h->cfg.aq_mode && h->cfg.intra_in_p == 2); // (adaptive quantisation: the QP_Y chain
                                                                                                                                                     // over the whole picture sits between a picture's records and its deblocking)
         const int split = !idr && fused && c->intra_p && may_wait;
         // IDR picture: the band deblocker runs on the intra stream BESIDE the intra wavefront, each of its bands waiting for the intra bands
@@ -211,25 +210,11 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // gets in the way (1080p depth 1: 4465 -> 3980 frames/s, 2160p: 2050 -> 1615)
         const int prows = pgate && h->cfg.pipeline_depth >= 2;
         const int isplit = idr && h->cfg.intra_mode != 1 && may_wait;
-        // Where this picture's deblocking launch goes.  A launch that waits on the device for its rows need not wait for the previous
-        // picture's launch to END: its upper bands can run beside that launch's lower ones (the bands of a launch finish staggered by the
-        // x + y order's skew, a third of the launch).  What orders the two is already on the device: pmb_kernel<GATED> of this picture reads a
-        // reference band only when the previous launch has published it, and this launch's band b starts when pmb_kernel has completed the
-        // rows of bands b-1 .. b+1 -- by then the previous launch is through band b+2, so band b's strips and parameter table are free.
-        // So consecutive such launches alternate between two streams; a picture whose stages run in order joins both.
+        // (Round 3 also built consecutive pictures' deblocking launches on two streams, the next picture's upper bands beside this one's lower
+        // ones: +2 % at 1080p, slower at 2160p, and a bounded wait that ran out in two of four runs without a cause found -- removed in round 4;
+        // what shortens the chain instead is slices with slice-local deblocking)
         hipStream_t mst = h->stream;
-        bool early_db = false, fip = false;
-        if (prows && !no_db2() && !c->qp_off) {
-            h->db_flip ^= 1;
-            if (h->db_flip) {
-                mst = h->cstream;
-                if (h->inorder_since_s2) { HIPCHK(hipEventRecord(h->ev_join, h->stream)); HIPCHK(hipStreamWaitEvent(h->cstream, h->ev_join, 0)); h->inorder_since_s2 = 0; }
-                h->s2_dirty = 1;
-            }
-        } else {
-            if (h->s2_dirty) { HIPCHK(hipEventRecord(h->ev_join, h->cstream)); HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0)); h->s2_dirty = 0; }
-            if (!prows) h->inorder_since_s2 = 1;
-        }
+        bool fip = false;
         for (int b = 0; b < 2; b++)
             if (h->dbI_busy[b] && (!idr || b == nxt)) { HIPCHK(hipStreamWaitEvent(mst, h->ev_dbI[b], 0)); h->dbI_busy[b] = 0; }
         if (idr) {
@@ -238,16 +223,11 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
             int r = run_intra(h, ci, c, isplit ? h->d_iband_done + (size_t)nxt * h->mbh : nullptr); if (r) return r;
             if (prof) HIPCHK(hipEventRecord(s->ev[1], h->stream));
         } else {
-            // Two launches in flight: this picture's deblocking launch is enqueued FIRST, and the gated P stage behind wait_started_kernel counts
-            // it in -- once pmb_kernel's waiting workgroups fill the chip, a launch of 34 workgroups of twelve 112-register waves finds no CU to
-            // land on until they drain (device timeline: the launch sat there for 250 us and did its work after pmb_kernel had ended).
-            early_db = prows && !no_db2() && !c->qp_off;
-            if (early_db) { int r = run_deblock(h, ci, c, mst, c->intra_p ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, true, h->pmb_rows_total + (uint32_t)h->mbw, c->intra_p != 0); if (r) return r; }
             // One launch in flight, the intra macroblock rows inside it: the rows no longer queue behind the END of pmb_kernel (stream order) -- each starts when pmb_kernel
             // has completed its row and the row above, so the upper bands find them done when the launch starts.  Behind pmb_kernel in host order: nothing here waits for a
             // kernel that is not on the chip or in front of it in its own stream.  Not on sampled pictures (the timers bracket the launches in stream order).
-            fip = prows && !early_db && !c->qp_off && c->intra_p && !prof && fip_on(h->nmb);
-            int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur], prows, early_db && c->intra_p, fip); if (r) return r;
+            fip = prows && !c->qp_off && c->intra_p && !prof && h->fip_rows;
+            int r = run_p_back(h, c, s, prof, split, pgate ? h->d_db_done + (size_t)h->cur * nbd : nullptr, h->rec_epoch[h->cur], prows, fip); if (r) return r;
             if (fip) {
                 r = run_deblock(h, ci, c, mst, h->d_ip_progress, nullptr, h->d_db_done + (size_t)nxt * nbd, true, h->pmb_rows_total, true); if (r) return r;
                 k_launch_wait_started(h->d_progress + 2, h->ip_done_total, err_word(h), h->istream); // records and levels are final once the rows have all counted themselves
@@ -266,14 +246,13 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
             int r = run_deblock(h, ci, c, h->istream, nullptr, h->d_iband_done + (size_t)nxt * h->mbh, h->d_db_done + (size_t)nxt * nbd); if (r) return r;
             HIPCHK(hipEventRecord(h->ev_dbI[nxt], h->istream));
             h->dbI_busy[nxt] = 1;
-        } else if (!early_db && !fip) { int r = run_deblock(h, ci, c, mst, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, prows != 0); if (r) return r; }
+        } else if (!fip) { int r = run_deblock(h, ci, c, mst, (split || (pgate && c->intra_p)) ? h->d_ip_progress : nullptr, nullptr, h->d_db_done + (size_t)nxt * nbd, prows != 0); if (r) return r; }
         h->rec_epoch[nxt] = h->cfg.deblock_mode == 0 ? c->epoch : 0;
         if (prof) { HIPCHK(hipEventRecord(s->ev[3], h->stream)); HIPCHK(hipEventRecord(s->ev[4], h->stream)); }
         // Hand-over, enqueued after the deblocking launches so that it cannot be dispatched ahead of them: the device packs the non-zero
-        // blocks straight into the pinned host buffer while the band deblocker runs.  On the hand-over stream -- or, where that stream takes
-        // every other deblocking launch, on the intra stream right behind intra_p_kernel (records and levels are final there).
-        hipStream_t pst = (prows && !no_db2() && !c->qp_off) ? h->istream : h->cstream;
-        if (pst == h->cstream) HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
+        // blocks straight into the pinned host buffer while the band deblocker runs.
+        hipStream_t pst = h->cstream;
+        HIPCHK(hipStreamWaitEvent(h->cstream, s->gpu_done, 0));
         k_launch_pack(h->d_mbi_set[set], h->d_levels_set[set], h->nmb, h->mbw, h->d_off, s->h_mbi, s->h_levels, s->h_hdr, err_word(h), pst);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->done, pst));
@@ -321,6 +300,7 @@ static size_t code_access_unit(mi355enc_t *h, slot_t *s, uint8_t *out, size_t ca
         n = h264_write_headers(out, cap, h->cfg.width, h->cfg.height, h->cfg.fps_num, h->cfg.fps_den, h->cfg.transform8x8);
         if (!n) return 0;
     }
+    h264_writer_set_p_slices(h->writer, s->all_skip ? 0 : h->pslice_rows, h->slice_dbf); // (an all-skip picture is one run of P_Skip macroblocks in one slice)
     const size_t m = h264_write_slice_packed_rows(h->writer, out + n, cap - n, s->is_idr, s->frame_num, s->idr_pic_id, s->qp, s->h_mbi, s->h_levels, s->h_hdr + 2);
     return m ? n + m : 0;
 }
@@ -405,8 +385,8 @@ static int recover(mi355enc_t *h, unsigned code) {
         again[i] = {p->src_y, p->src_uv, p->src_stride, p->force_idr, p->pts};
         if (p->is_idr) h->idr_count--;
         p->h_hdr[1] = 0;
+        if (p->rc_picked) rc_cancel(&h->rc); // their rate-control bookings (rc_cancel takes back the newest one outstanding: only the count matters)
     }
-    for (int i = 0; i < n; i++) rc_cancel(&h->rc); // their rate-control bookings, newest first
     h->n_submitted -= (uint64_t)n; h->head = h->tail; h->pending = 0; h->have_ref = 0;
     for (int i = 0; i < n; i++) {
         int r = enqueue_picture(h, &h->slot[h->head], again[i].y, again[i].uv, again[i].stride, again[i].pts, i == 0 ? 1 : again[i].force_idr);
@@ -569,7 +549,7 @@ int mi355enc_collect(mi355enc_t *h, uint8_t *out, size_t out_cap, size_t *out_le
     if (is_keyframe) *is_keyframe = s->is_idr;
     if (pts) *pts = s->pts;
     if (qp) *qp = s->qp;
-    rc_update(&h->rc, s->is_idr, s->qp, s->drop, n + m);
+    if (s->rc_picked) rc_update(&h->rc, s->is_idr, s->qp, s->drop, n + m); // picks and updates stay paired: a picture coded at a fixed QP booked nothing
     // Scene-cut recovery (cfg.scenecut; the oracle's orc_enc_frame applies the same rule): the summed cost of the picture's
     // macroblocks came with the hand-over.  The decision lands on picture index + 2, the first one not submitted yet whatever
     // the pipeline depth, and is skipped there if picture index + 1 turned out to be an IDR: the stream does not depend on

@@ -2,11 +2,15 @@
 // tests and probes) and the host-only stages (parameter sets, slice writer, rate-control model: no device needed).
 #include "enc_internal.hpp"
 
+// A single-stage call made with pictures in flight would overwrite what they use: refused BEFORE anything is uploaded (the caller collects first).
+#define STAGE_IDLE(h) do { if ((h)->pending) return MI355ENC_ERR_STATE; } while (0)
+
 extern "C" {
 
 int mi355enc_stage_csc(mi355enc_t *h, int fmt, const uint8_t *const planes[3], const int strides[3], uint8_t *out_y, uint8_t *out_uv) {
     if (!h || !out_y || !out_uv || h->pending) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
     slot_t *s = &h->slot[0];
     int r = upload_and_convert(h, s, fmt, planes, strides, h->stream);
     if (r) return r;
@@ -31,7 +35,7 @@ static int stage_ctx(mi355enc_t *h, int qp, bool src_is_staging, int drop = 0, i
     { int r = sync_compute(h); if (r) return r; }
     c->vis_h = h->H;
     fill_ctx(h, c, qp, drop, idr);
-    c->slice_rows = h->stage_slice_rows;
+    c->slice_rows = h->stage_slice_rows; c->slice_dbf = h->stage_slice_dbf;
     c->all_intra = 0; // the single-stage deblocking entry point takes records of either picture type
     c->qp_off = nullptr; // (single stages: one QP per picture)
     HIPCHK(hipMemcpyAsync(h->d_ctx, c, sizeof *c, hipMemcpyHostToDevice, h->stream));
@@ -46,6 +50,7 @@ static int upload_luma_pair(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *
 int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, uint16_t *surf_out, void *imv_out) {
     if (!h || !cur_y || !ref_y || !imv_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, cur_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_psrc[h->psrc_cur], ref_y, h->ysz, hipMemcpyHostToDevice, h->stream)); // what the search runs against (in the encoder: the previous source)
     int r = stage_ctx(h, qp, true); if (r) return r;
@@ -58,6 +63,7 @@ int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y,
 int mi355enc_stage_me_select(mi355enc_t *h, const uint16_t *surf, const void *imv_in, int qp, void *imv_out) {
     if (!h || !surf || !imv_in || !imv_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
     int r = stage_ctx(h, qp, true); if (r) return r;
     HIPCHK(hipMemcpyAsync(h->d_surf[0], surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_imv[0][0], imv_in, (size_t)h->nmb * sizeof(imv_t), hipMemcpyHostToDevice, h->stream));
@@ -69,6 +75,7 @@ int mi355enc_stage_me_select(mi355enc_t *h, const uint16_t *surf, const void *im
 int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_inout) {
     if (!h || !cur_y || !ref_y || !mbinfo_inout || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
     int r = upload_luma_pair(h, cur_y, ref_y); if (r) return r;
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
     r = stage_ctx(h, qp, true); if (r) return r;
@@ -96,6 +103,7 @@ int mi355enc_stage_inter(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
                          int qp, void *mbinfo_inout, uint8_t *rec_y, uint8_t *rec_uv, int16_t *levels) {
     if (!h || !src_y || !src_uv || !ref_y || !ref_uv || !mbinfo_inout || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
     int r = upload_planes4(h, src_y, src_uv, ref_y, ref_uv); if (r) return r;
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo_inout, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
     r = stage_ctx(h, qp, true); if (r) return r;
@@ -108,6 +116,7 @@ int mi355enc_stage_pmb(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_u
     if (!h || !src_y || !src_uv || !ref_y || !ref_uv || !imv || !surf || !mbinfo_out || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51 || drop < 0 || drop > DROP_MAX)
         return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
     int r = upload_planes4(h, src_y, src_uv, ref_y, ref_uv); if (r) return r;
     r = stage_ctx(h, qp, true, drop); if (r) return r;
     frame_ctx_t *c = h->slot[0].h_ctx;
@@ -127,6 +136,7 @@ int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
                          uint8_t *rec_uv, int16_t *levels) {
     if (!h || !src_y || !src_uv || !mbinfo_out || !rec_y || !rec_uv || !levels || qp < 0 || qp > 51 || drop < 0 || drop > DROP_MAX) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true, drop, 1); if (r) return r;
@@ -136,6 +146,7 @@ int mi355enc_stage_intra(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src
 int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint8_t *src_uv, int qp, uint16_t *isad_out, void *idec_out) {
     if (!h || !src_y || !src_uv || !isad_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_y, src_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->slot[0].d_src_uv, src_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     int r = stage_ctx(h, qp, true); if (r) return r;
@@ -148,6 +159,7 @@ int mi355enc_stage_intra_analyse(mi355enc_t *h, const uint8_t *src_y, const uint
 int mi355enc_stage_deblock(mi355enc_t *h, uint8_t *rec_y, uint8_t *rec_uv, const void *mbinfo) {
     if (!h || !rec_y || !rec_uv || !mbinfo) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
     HIPCHK(hipMemcpyAsync(h->d_rec_y[1], rec_y, h->ysz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_rec_uv[1], rec_uv, h->csz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_mbi, mbinfo, (size_t)h->nmb * sizeof(mb_info_t), hipMemcpyHostToDevice, h->stream));
@@ -221,15 +233,20 @@ int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den,
     return MI355ENC_OK;
 }
 static int g_host_slice_rows = 0;
+static int g_host_pslice_rows = 0, g_host_dbf_idc = 0;
 void mi355enc_host_set_slice_rows(int rows) { g_host_slice_rows = rows > 0 ? rows : 0; }
+void mi355enc_host_set_p_slices(int rows, int dbf_idc) { g_host_pslice_rows = rows > 0 ? rows : 0; g_host_dbf_idc = dbf_idc == 2 ? 2 : 0; }
 int mi355enc_stage_set_slice_rows(mi355enc_t *h, int rows) { if (!h || rows < 0) return MI355ENC_ERR_ARG; h->stage_slice_rows = rows; return MI355ENC_OK; }
 int mi355enc_slice_rows(const mi355enc_t *h) { return h ? h->islice_rows : 0; }
+int mi355enc_p_slice_rows(const mi355enc_t *h) { return h ? h->pslice_rows : 0; }
+int mi355enc_stage_set_slice_deblock(mi355enc_t *h, int idc) { if (!h || (idc != 0 && idc != 2)) return MI355ENC_ERR_ARG; h->stage_slice_dbf = idc; return MI355ENC_OK; }
 int mi355enc_host_write_slice(int mbw, int mbh, int is_idr, int frame_num, int idr_pic_id, int qp, int t8, const void *mbinfo,
                               const int16_t *levels, uint8_t *out, size_t cap, size_t *out_len) {
     if (!out || !out_len || !mbinfo || !levels || mbw < 1 || mbh < 1 || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     h264_writer_t *w = h264_writer_new(mbw, mbh, t8);
     if (!w) return MI355ENC_ERR_NOMEM;
     h264_writer_set_slice_rows(w, g_host_slice_rows);
+    h264_writer_set_p_slices(w, g_host_pslice_rows, g_host_dbf_idc);
     size_t n = h264_write_slice(w, out, cap, is_idr, frame_num, idr_pic_id, qp, (const mb_info_t *)mbinfo, levels);
     h264_writer_free(w);
     if (!n) return MI355ENC_ERR_OVERFLOW;
@@ -249,6 +266,7 @@ int mi355enc_host_write_slice_packed(int mbw, int mbh, int is_idr, int frame_num
     int rc = MI355ENC_ERR_NOMEM;
     if (packed && row_off && w && h264_writer_set_threads(w, threads) == 0) {
         h264_writer_set_slice_rows(w, g_host_slice_rows);
+        h264_writer_set_p_slices(w, g_host_pslice_rows, g_host_dbf_idc);
         h264_pack_levels(mbw, mbh, mbi, levels, packed, row_off);
         size_t n = h264_write_slice_packed_rows(w, out, cap, is_idr, frame_num, idr_pic_id, qp, mbi, packed, row_off);
         rc = n ? MI355ENC_OK : MI355ENC_ERR_OVERFLOW;

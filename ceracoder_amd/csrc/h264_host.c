@@ -274,25 +274,26 @@ static inline void set_qmv(int16_t *q, const mb_info_t *m, const int16_t *ldc) {
     }
 }
 /* 6.4.11.7 / 8.4.1.3.2: the 8x8 block covering luma sample (X, Y) as a neighbour of a partition of macroblock (mx, my), whose own quadrants in `done`
- * carry cur[]; one slice per P picture: a macroblock is available when it comes earlier in raster order */
-static inline void nb_blk(const int16_t *qmv, const mb_info_t *mbi, int mbw, int mx, int my, unsigned done, const int16_t *cur, int X, int Y, int *avail, int *ref, int *vx, int *vy) {
+ * carry cur[]; a macroblock is available when it comes earlier in raster order and belongs to the same slice (top: the row above does -- slices are whole rows) */
+static inline void nb_blk(const int16_t *qmv, const mb_info_t *mbi, int mbw, int mx, int my, int top, unsigned done, const int16_t *cur, int X, int Y, int *avail, int *ref, int *vx, int *vy) {
     *avail = 0; *ref = -1; *vx = *vy = 0;
     if (X < 0 || Y < 0 || X >= mbw * 16) return;
     const int nx = X >> 4, ny = Y >> 4, q = ((Y & 15) >> 3) * 2 + ((X & 15) >> 3);
     if (nx == mx && ny == my) { if ((done >> q) & 1) { *avail = 1; *ref = 0; *vx = cur[2 * q]; *vy = cur[2 * q + 1]; } return; }
     if (!(ny < my || (ny == my && nx < mx))) return;
+    if (ny < my && !top) return;
     *avail = 1;
     if (mbi[(size_t)ny * mbw + nx].mb_type == 1) { const int16_t *v = qmv + ((size_t)ny * mbw + nx) * 8 + 2 * q; *ref = 0; *vx = v[0]; *vy = v[1]; }
 }
 /* 8.4.1.3 for partition idx of shape `shape` at (x0, y0) of width wd, refIdx 0 everywhere; skip: 8.4.1.1's inference for P_Skip */
-static inline void predict_part(const int16_t *qmv, const mb_info_t *mbi, int mbw, int mx, int my, unsigned done, const int16_t *cur, int shape, int idx, int x0, int y0, int wd, int skip,
+static inline void predict_part(const int16_t *qmv, const mb_info_t *mbi, int mbw, int mx, int my, int top, unsigned done, const int16_t *cur, int shape, int idx, int x0, int y0, int wd, int skip,
                                 int *px, int *py) {
     const int X = mx * 16 + x0, Y = my * 16 + y0;
     int aA, rA, ax, ay, aB, rB, bx, by, aC, rC, cx, cy;
-    nb_blk(qmv, mbi, mbw, mx, my, done, cur, X - 1, Y, &aA, &rA, &ax, &ay);
-    nb_blk(qmv, mbi, mbw, mx, my, done, cur, X, Y - 1, &aB, &rB, &bx, &by);
-    nb_blk(qmv, mbi, mbw, mx, my, done, cur, X + wd, Y - 1, &aC, &rC, &cx, &cy);
-    if (!aC) nb_blk(qmv, mbi, mbw, mx, my, done, cur, X - 1, Y - 1, &aC, &rC, &cx, &cy);
+    nb_blk(qmv, mbi, mbw, mx, my, top, done, cur, X - 1, Y, &aA, &rA, &ax, &ay);
+    nb_blk(qmv, mbi, mbw, mx, my, top, done, cur, X, Y - 1, &aB, &rB, &bx, &by);
+    nb_blk(qmv, mbi, mbw, mx, my, top, done, cur, X + wd, Y - 1, &aC, &rC, &cx, &cy);
+    if (!aC) nb_blk(qmv, mbi, mbw, mx, my, top, done, cur, X - 1, Y - 1, &aC, &rC, &cx, &cy);
     *px = 0; *py = 0;
     if (skip && (!aA || !aB || (rA == 0 && !ax && !ay) || (rB == 0 && !bx && !by))) return;
     if (shape == 1 && idx == 0 && rB == 0) { *px = bx; *py = by; return; }
@@ -310,6 +311,8 @@ static inline void predict_part(const int16_t *qmv, const mb_info_t *mbi, int mb
 struct h264_writer {
     int mbw, mbh, t8;
     int slice_rows; /* I pictures: a new slice (own NAL unit; the row above its first row not available, 6.4.8) every so many macroblock rows; 0: one slice */
+    int pslice_rows; /* ... and P pictures (r04): there the cut also breaks the 8.4.1.3 vector predictors and the P_Skip inference */
+    int dbf_idc;     /* disable_deblocking_filter_idc of every slice header: 0 (the filter runs across slice boundaries) or 2 (it stops at them) */
     uint8_t *rbsp; size_t rbsp_cap;
     uint8_t *tc_l; /* TotalCoeff per luma 4x4 in raster order, 16 per macroblock */
     uint8_t *tc_c; /* per chroma AC block: Cb 0-3, Cr 4-7 */
@@ -333,6 +336,8 @@ h264_writer_t *h264_writer_new(int mbw, int mbh, int t8) {
     return w;
 }
 void h264_writer_set_slice_rows(h264_writer_t *w, int rows) { if (w) w->slice_rows = rows > 0 ? rows : 0; }
+void h264_writer_set_p_slices(h264_writer_t *w, int rows, int dbf_idc) { if (w) { w->pslice_rows = rows > 0 ? rows : 0; w->dbf_idc = dbf_idc == 2 ? 2 : 0; } }
+static inline int slice_rows_of(const h264_writer_t *w, int is_idr) { const int r = is_idr ? w->slice_rows : w->pslice_rows; return r > 0 && r < w->mbh ? r : 0; }
 static void cavlc_pool_free(struct cavlc_pool *p);
 void h264_writer_free(h264_writer_t *w) {
     if (!w) return;
@@ -365,7 +370,7 @@ static inline int ctx_chroma(const h264_writer_t *w, int mbn, int mx, int top, i
  * [luma block b for each set bit b][chroma DC if NZ_CBDC|NZ_CRDC][chroma AC block i for each set bit 16+i]; blocks that
  * are absent are all-zero by construction and read from k_zero_block. */
 static const int16_t k_zero_block[16] __attribute__((aligned(32))) = {0};
-static void slice_header(bits_t *bp, int first_mb, int is_idr, int frame_num, int idr_pic_id, int slice_qp) { /* 7.3.3 */
+static void slice_header(bits_t *bp, int first_mb, int is_idr, int frame_num, int idr_pic_id, int slice_qp, int dbf_idc) { /* 7.3.3 */
     bits_ue(bp, (uint32_t)first_mb);
     bits_ue(bp, is_idr ? 7 : 5);
     bits_ue(bp, 0);
@@ -375,7 +380,7 @@ static void slice_header(bits_t *bp, int first_mb, int is_idr, int frame_num, in
     if (is_idr) bits_put(bp, 2, 0);   /* no_output_of_prior_pics_flag, long_term_reference_flag */
     else bits_put(bp, 1, 0);          /* adaptive_ref_pic_marking_mode_flag */
     bits_se(bp, slice_qp - 26);
-    bits_ue(bp, 0);                   /* disable_deblocking_filter_idc */
+    bits_ue(bp, (uint32_t)dbf_idc);   /* disable_deblocking_filter_idc */
     bits_se(bp, 0); bits_se(bp, 0);
 }
 /* What a range of macroblock rows leaves open at its two ends (P slices): the mb_skip_run before its first coded
@@ -394,7 +399,7 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
     memset(w->tc_c + (size_t)row0 * mbw * 8, 0, (size_t)(row1 - row0) * mbw * 8);
     /* QP_Y,PRED of the range's first macroblock (7.4.5): the QP_Y of the last macroblock before it that sent an mb_qp_delta (Intra_16x16, or any
      * coded block), the slice's if there is none.  (One QP per picture: the slice's everywhere; adaptive quantisation: whatever that macroblock had.) */
-    const int srows = is_idr ? w->slice_rows : 0; /* (a range never straddles two slices) */
+    const int srows = slice_rows_of(w, is_idr); /* (a range never straddles two slices) */
     int skip = 0, prev_qp = slice_qp;
     for (int i = row0 * mbw - 1; i >= (srows ? row0 / srows * srows * mbw : 0); i--)
         if (mbi[i].mb_type == 0 || (mbi[i].nzmask & 0x07FFFFFFu) != 0) { prev_qp = mbi[i].qp; break; }
@@ -430,7 +435,7 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
                 set_qmv(qv, m, p_modes);
                 if (!cbp_l && !cbp_c && !shape) { /* 8.4.1.1: P_Skip when the vector equals the inferred one */
                     int sx, sy;
-                    predict_part(w->qmv, mbi, mbw, mx, my, 0, qv, 0, 0, 0, 0, 16, 1, &sx, &sy);
+                    predict_part(w->qmv, mbi, mbw, mx, my, top, 0, qv, 0, 0, 0, 0, 16, 1, &sx, &sy);
                     if (m->mvx == sx && m->mvy == sy) { skip++; continue; }
                 }
                 if (defer_first_run && !res.has_coded) res.lead_skip = skip; else bits_ue(&b, (uint32_t)skip);
@@ -442,7 +447,7 @@ static rows_result_t code_rows(h264_writer_t *w, bits_t *bp, int row0, int row1,
                     const int8_t *g = part_geo[shape][i];
                     const int q0 = (g[1] >> 3) * 2 + (g[0] >> 3);
                     int px, py;
-                    predict_part(w->qmv, mbi, mbw, mx, my, done, qv, shape, i, g[0], g[1], g[2], 0, &px, &py);
+                    predict_part(w->qmv, mbi, mbw, mx, my, top, done, qv, shape, i, g[0], g[1], g[2], 0, &px, &py);
                     bits_se(&b, qv[2 * q0] - px);
                     bits_se(&b, qv[2 * q0 + 1] - py);
                     for (int q = 0; q < 4; q++) { const int qx = (q & 1) * 8, qy = (q >> 1) * 8; if (qx >= g[0] && qx < g[0] + g[2] && qy >= g[1] && qy < g[1] + g[3]) done |= 1u << q; }
@@ -559,13 +564,13 @@ static const int16_t *skip_packed_rows(const mb_info_t *m, int n, const int16_t 
 }
 static size_t write_slice_impl(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                                int slice_qp, const mb_info_t *mbi, const int16_t *levels, const int16_t *packed) {
-    const int srows = (is_idr && w->slice_rows > 0) ? w->slice_rows : w->mbh;
+    const int srows = slice_rows_of(w, is_idr) ? slice_rows_of(w, is_idr) : w->mbh;
     size_t total = 0;
     for (int row0 = 0; row0 < w->mbh; row0 += srows) { /* one NAL unit per slice */
         const int row1 = row0 + srows < w->mbh ? row0 + srows : w->mbh;
         bits_t b;
         bits_init(&b, w->rbsp, w->rbsp_cap);
-        slice_header(&b, row0 * w->mbw, is_idr, frame_num, idr_pic_id, slice_qp);
+        slice_header(&b, row0 * w->mbw, is_idr, frame_num, idr_pic_id, slice_qp, w->dbf_idc);
         if (packed && row0 > 0) packed = skip_packed_rows(mbi + (size_t)(row0 - srows) * w->mbw, srows * w->mbw, packed);
         rows_result_t r = code_rows(w, &b, row0, row1, is_idr, slice_qp, mbi, levels, packed, 0);
         const int tail = r.has_coded ? r.trail_skip : r.lead_skip;
@@ -697,8 +702,8 @@ size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, 
     p->is_idr = is_idr; p->slice_qp = slice_qp; p->mbi = mbi; p->packed = packed; p->row_off = row_off;
     /* chunks of about four rows, at least one per thread and at most four: small enough to balance rows of unequal cost and to
      * leave late threads nothing to hold up, large enough that deriving the context of the row above stays a small share.  A chunk
-     * never straddles two slices (I pictures, slice_rows): every slice is cut into its own chunks. */
-    const int srows = (is_idr && w->slice_rows > 0) ? w->slice_rows : w->mbh;
+     * never straddles two slices: every slice is cut into its own chunks. */
+    const int srows = slice_rows_of(w, is_idr) ? slice_rows_of(w, is_idr) : w->mbh;
     const int nslice = (w->mbh + srows - 1) / srows;
     int want = w->mbh / 4;
     if (want < p->n) want = p->n;
@@ -712,7 +717,7 @@ size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, 
         const int r0 = sl * srows, r1 = r0 + srows < w->mbh ? r0 + srows : w->mbh, rows = r1 - r0, k = per < rows ? per : rows;
         for (int c = 0; c < k; c++) { p->job[nchunk].row0 = r0 + (int)((long long)rows * c / k); p->job[nchunk].row1 = r0 + (int)((long long)rows * (c + 1) / k); nchunk++; }
     }
-    for (int k = 0; k < p->n; k++) { p->cursor[k] = p->wr[k]->rbsp; p->wr[k]->slice_rows = w->slice_rows; }
+    for (int k = 0; k < p->n; k++) { p->cursor[k] = p->wr[k]->rbsp; p->wr[k]->slice_rows = w->slice_rows; p->wr[k]->pslice_rows = w->pslice_rows; p->wr[k]->dbf_idc = w->dbf_idc; }
     pthread_mutex_lock(&p->mu);
     p->nchunk = nchunk; p->next = 0; p->done = 0; p->generation++;
     pthread_cond_broadcast(&p->cv_go);
@@ -726,7 +731,7 @@ size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, 
         const int first_row = p->job[c].row0, end_row = first_row + srows < w->mbh ? first_row + srows : w->mbh;
         bits_t b;
         bits_init(&b, w->rbsp, w->rbsp_cap);
-        slice_header(&b, first_row * w->mbw, is_idr, frame_num, idr_pic_id, slice_qp);
+        slice_header(&b, first_row * w->mbw, is_idr, frame_num, idr_pic_id, slice_qp, w->dbf_idc);
         int pending = 0;
         for (; c < nchunk && p->job[c].row0 < end_row; c++) {
             const cavlc_job_t *j = &p->job[c];

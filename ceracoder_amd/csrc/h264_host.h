@@ -29,6 +29,7 @@ size_t h264_write_slice_packed(h264_writer_t *w, uint8_t *out, size_t cap, int i
 int h264_writer_set_threads(h264_writer_t *w, int threads);
 /* I pictures written from now on are cut into slices of `rows` macroblock rows, one NAL unit each (0: one slice); P pictures stay one slice */
 void h264_writer_set_slice_rows(h264_writer_t *w, int rows);
+void h264_writer_set_p_slices(h264_writer_t *w, int rows, int dbf_idc); /* P pictures: rows per slice (0: one slice); disable_deblocking_filter_idc of every slice header (I and P): 0 or 2 */
 size_t h264_write_slice_packed_rows(h264_writer_t *w, uint8_t *out, size_t cap, int is_idr, int frame_num, int idr_pic_id,
                                     int slice_qp, const mb_info_t *mbi, const int16_t *packed, const uint32_t *row_off);
 

@@ -624,7 +624,7 @@ DEV void intra_p_row(const ip_args &a, const int my, const unsigned *row_done, c
             const int mx = 32 * w + __builtin_ctz(bits);
             bits &= bits - 1;
             const int mbn = my * mbw + mx, x0 = mx * 16, y0 = my * 16, cx0 = x0 >> 1, cy0 = y0 >> 1;
-            const bool has_top = my > 0, has_left = mx > 0;
+            const bool has_top = row_has_top(ctx, my), has_left = mx > 0; // (a P slice's first row: nothing above it is available, 6.4.8)
             const bool b_intra = has_top && (ldg32(&ctx->mbi[mbn - mbw].mb_type) & 255u) != 1u;
             const bool d_intra = has_top && has_left && (ldg32(&ctx->mbi[mbn - mbw - 1].mb_type) & 255u) != 1u;
             const bool a_intra = has_left && prev_x == mx - 1;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
         const int k = lane;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            if ((e == 0 && my == 0) || ((cur.nzmask & NZ_T8) && (e & 1))) continue;
+            if ((e == 0 && !db_has_top(ctx, my)) || ((cur.nzmask & NZ_T8) && (e & 1))) continue;
             const mb_info_t &mp = e == 0 ? upp : cur;
             int bS = bs_of(mp, k >> 2, e == 0 ? 3 : e - 1, cur, k >> 2, e, e == 0);
             filter_line(T, &tl[(4 + 4 * e) * TLS + 4 + k], TLS, bS, mp.qp, cur.qp, false);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
         const int k = lane - 16;
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
-            if (e == 0 && my == 0) continue;
+            if (e == 0 && !db_has_top(ctx, my)) continue;
             const mb_info_t &mp = e == 0 ? upp : cur;
             int bS = bs_of(mp, k >> 1, e == 0 ? 3 : e - 1, cur, k >> 1, e, e == 0);
 #pragma unroll
@@ -206,6 +206,7 @@ DEV bool db_record(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, con
     const mb_info_t lft = ld_mbinfo(&ctx->mbi[mx > 0 ? i - 1 : i]);
     const mb_info_t upp = ld_mbinfo(&ctx->mbi[my > 0 ? i - mbw : i]);
     const bool t8 = (cur.nzmask & NZ_T8) != 0;
+    const bool dbtop = db_has_top(ctx, my); // the top macroblock edge is filtered (8.7: not the picture's; with slice-local deblocking not a slice's)
     const bool parts = ctx->partitions != 0; // (wave-uniform)
     unsigned vc[4], vl[4], vu[4];
     if (parts) { ld_qmv(ctx, i, cur, vc); ld_qmv(ctx, mx > 0 ? i - 1 : i, lft, vl); ld_qmv(ctx, my > 0 ? i - mbw : i, upp, vu); }
@@ -218,10 +219,10 @@ DEV bool db_record(const frame_ctx_t *__restrict__ ctx, const dev_tables *T, con
             if (!(t8 && (e & 1))) {
                 if (!parts) {
                     if (!(e == 0 && mx == 0)) v = bs_of(e == 0 ? lft : cur, e == 0 ? 3 : e - 1, sg, cur, e, sg, e == 0);
-                    if (!(e == 0 && my == 0)) h = bs_of(e == 0 ? upp : cur, sg, e == 0 ? 3 : e - 1, cur, sg, e, e == 0);
+                    if (!(e == 0 && !dbtop)) h = bs_of(e == 0 ? upp : cur, sg, e == 0 ? 3 : e - 1, cur, sg, e, e == 0);
                 } else {
                     if (!(e == 0 && mx == 0)) v = bs_of_q(e == 0 ? lft : cur, e == 0 ? vl : vc, e == 0 ? 3 : e - 1, sg, cur, vc, e, sg, e == 0);
-                    if (!(e == 0 && my == 0)) h = bs_of_q(e == 0 ? upp : cur, e == 0 ? vu : vc, sg, e == 0 ? 3 : e - 1, cur, vc, sg, e, e == 0);
+                    if (!(e == 0 && !dbtop)) h = bs_of_q(e == 0 ? upp : cur, e == 0 ? vu : vc, sg, e == 0 ? 3 : e - 1, cur, vc, sg, e, e == 0);
                 }
             }
             bv |= (unsigned long long)v << (4 * (e * 4 + sg));
@@ -390,8 +391,11 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int role = wid / ROWS, r = wid - role * ROWS; // 0: filter, 1: mover (loads), 2: storer
     const int my = band * ROWS + r;
-    const bool row_ok = my < mbh, last_row = my == mbh - 1;
-    const bool fed = row_ok && r == 0 && band > 0;
+    // Slice-local deblocking (ctx->slice_dbf == 2; slices are whole bands): a slice's first row has no top edge to filter and takes nothing from the band above
+    // (dbtop false: like the picture's first row), its last row keeps its bottom lines to itself (last_row true: like the picture's last row) -- every slice
+    // is a wavefront of its own, and the launch is as long as the longest of them.
+    const bool row_ok = my < mbh, last_row = my == mbh - 1 || db_slice_last(ctx, my), dbtop = db_has_top(ctx, my);
+    const bool fed = row_ok && r == 0 && dbtop;
     const bool feeds = row_ok && r == ROWS - 1 && !last_row;
     // ---- prologue: per macroblock of this band, the parameter word {bS, alpha, beta, tc0[bS]} of every (edge, segment) of either
     // direction -- 32 words for luma, 16 for chroma -- into a table in global memory (it stays in L2; the movers bring a
@@ -625,16 +629,16 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                         if (ALL_INTRA || work) {
                             const bool any4 = __ballot((par & 15u) == 4u) != 0;
                             edges4p_luma<ALL_INTRA>(e, par, any4, s);
-                            if (e != 0 || my > 0) { pb[2 * 16] = (uint8_t)s[2]; pb[3 * 16] = (uint8_t)s[3]; }
+                            if (e != 0 || dbtop) { pb[2 * 16] = (uint8_t)s[2]; pb[3 * 16] = (uint8_t)s[3]; }
                             qb[0] = (uint8_t)s[4]; qb[16] = (uint8_t)s[5];
-                            if ((ALL_INTRA || any4) && e == 0 && my > 0) pb[16] = (uint8_t)s[1];
+                            if ((ALL_INTRA || any4) && e == 0 && dbtop) pb[16] = (uint8_t)s[1];
                         }
                     } else if (lane < 32) {
                         const int kb = lane >> 1, ee = lane & 1; // byte column, edge
                         uint8_t *pb = (ee == 0 ? upb : tile + 2 * 16) + kb, *qb = tile + 4 * ee * 16 + kb;
                         int p1 = pb[0], p0 = pb[16], q0 = qb[0], q1 = qb[16];
                         edge_chroma_p(par, p1, p0, q0, q1);
-                        if (ee != 0 || my > 0) pb[16] = (uint8_t)p0;
+                        if (ee != 0 || dbtop) pb[16] = (uint8_t)p0;
                         qb[0] = (uint8_t)q0;
                     }
                 }
@@ -721,7 +725,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
 #else
             if (row_ok && xs2 >= 0 && xs2 < mbw) {
 #endif
-                const bool is_row = lane < keep, is_up = uplane && my > 0;
+                const bool is_row = lane < keep, is_up = uplane && dbtop;
                 const uint8_t *upb = fed ? ups + (xs2 & (DBT_NB - 1)) * UPB : tiles_up + (xs2 & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
                 const uint8_t *src = is_row ? tiles + (xs2 & (DBT_NB - 1)) * TILE + lane * 16 : upb + (lane & 3) * 16;
                 if (is_row || is_up) stg128(st_ptr + xs2 * 16, lds128(src));

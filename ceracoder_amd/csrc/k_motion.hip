@@ -37,8 +37,9 @@ DEV int med3(int a, int b, int c) {
 // 8.4.1.3 on a whole-sample vector field (every neighbour taken as inter, refIdx 0) and the 8.4.1.1 P_Skip inference on the
 // same field; quarter-sample units.  Wave-uniform inputs -> wave-uniform result.  Oracle: field_pred.
 struct fpred_t { int px, py, sx, sy; };
-DEV fpred_t field_pred(const imv_t *__restrict__ f, int mbw, int mx, int my) {
-    const bool avA = mx > 0, avB = my > 0, avC = my > 0 && mx + 1 < mbw, avD = mx > 0 && my > 0, hasC = avC || avD;
+// top: the row above is available (row_has_top: not the picture's first row, not another slice's).
+DEV fpred_t field_pred(const imv_t *__restrict__ f, int mbw, int mx, int my, bool top) {
+    const bool avA = mx > 0, avB = top, avC = top && mx + 1 < mbw, avD = mx > 0 && top, hasC = avC || avD;
     const int self = my * mbw + mx;
     const unsigned wa = avA ? ldg32(f + self - 1) : 0u, wb = avB ? ldg32(f + self - mbw) : 0u;
     const unsigned wc = avC ? ldg32(f + self - mbw + 1) : (avD ? ldg32(f + self - mbw - 1) : 0u);
@@ -213,11 +214,11 @@ __global__ __launch_bounds__(256) void me_select_kernel(const frame_ctx_t cv, in
     const int mbn = mb0 + xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
     if (mbn >= mb1) return; // wave-uniform; no workgroup barrier below
     const int my = mbn / mbw, mx = mbn - my * mbw;
-    const fpred_t fp = field_pred(in, mbw, mx, my);
+    const fpred_t fp = field_pred(in, mbw, mx, my, row_has_top(ctx, my));
     const int px = fp.px >> 2, py = fp.py >> 2, sx = fp.sx >> 2, sy = fp.sy >> 2;
     if (mode) {
         fpred_t fq = {0, 0, 0, 0};
-        if (mode == 2) fq = field_pred(prev, mbw, mx, my);
+        if (mode == 2) fq = field_pred(prev, mbw, mx, my, row_has_top(ctx, my));
         if (px == (fq.px >> 2) && py == (fq.py >> 2) && sx == (fq.sx >> 2) && sy == (fq.sy >> 2)) { // wave-uniform
             if (lane == 0) stg64(&out[mbn], ldg64(&in[mbn]));
             return;
@@ -696,7 +697,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
     const uint2 selfw = ldg64(field + mbn);
     const int imx = (int)(int16_t)(selfw.x & 0xFFFF), imy = (int)(int16_t)(selfw.x >> 16); // whole-sample winner, quarter-sample units
     const unsigned di = selfw.y & 0xFFFFu, ibits = selfw.y >> 16;
-    const fpred_t fp = field_pred(field, mbw, mx, my);
+    const fpred_t fp = field_pred(field, mbw, mx, my, row_has_top(ctx, my));
     const int pr = lane >> 2, pc = (lane & 3) * 4; // luma: lane owns row pr, columns pc .. pc+3
     const int py = (lane >> 2) & 3;
     unsigned curw;

@@ -127,8 +127,12 @@ DEV int pos_class8(int y, int x) { // 8.5.9
     if ((!(y & 3) && (x & 3) == 2) || ((y & 3) == 2 && !(x & 3))) return 4;
     return 5;
 }
-// 6.4.8 for the row above: another slice's macroblocks are not available (I pictures cut into slices of ctx->slice_rows rows; oracle: top_ok)
+// 6.4.8 for the row above: another slice's macroblocks are not available (pictures cut into slices of ctx->slice_rows rows; oracle: top_ok)
 DEV bool row_has_top(const frame_ctx_t *ctx, int my) { return my > 0 && (ctx->slice_rows <= 0 || my % ctx->slice_rows != 0); }
+// 8.7 filterTopMbEdgeFlag: the top macroblock edge is filtered unless it is the picture's, or (disable_deblocking_filter_idc 2) a slice's; and whether row my is
+// the last of its slice in that sense (nothing below it touches its bottom lines)
+DEV bool db_has_top(const frame_ctx_t *ctx, int my) { return my > 0 && !(ctx->slice_dbf == 2 && ctx->slice_rows > 0 && my % ctx->slice_rows == 0); }
+DEV bool db_slice_last(const frame_ctx_t *ctx, int my) { return ctx->slice_dbf == 2 && ctx->slice_rows > 0 && (my + 1) % ctx->slice_rows == 0; }
 // where the last of the ME_ITERS selection iterations leaves the whole-sample vector field (they walk imv_a -> imv_b -> imv_c -> imv_a ...)
 DEV const imv_t *k_final_imv_dev(const frame_ctx_t *ctx) { return ME_ITERS % 3 == 0 ? ctx->imv_a : ME_ITERS % 3 == 1 ? ctx->imv_b : ctx->imv_c; }
 

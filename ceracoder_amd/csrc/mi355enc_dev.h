@@ -89,7 +89,10 @@ typedef struct {
     const int8_t *qp_off;          /* adaptive quantisation: one QP offset per macroblock (aq_kernel), or null: one QP per picture */
     int32_t partitions;            /* P macroblocks may be split (shape in the record's i16_mode: 1 16x8, 2 8x16, 3 8x8; the vectors of partitions 1 .. 3 in the
                                       luma-DC slot of the macroblock's levels); the deblocker then takes boundary strengths per 8x8 quadrant */
-    int32_t slice_rows;            /* I pictures: a new slice every so many macroblock rows (0: one slice); the row above a slice's first row is not available (6.4.8) */
+    int32_t slice_rows;            /* a new slice every so many macroblock rows (0: one slice); the row above a slice's first row is not available (6.4.8): intra prediction,
+                                      mode and vector predictors, nC, QP_Y,PRED */
+    int32_t slice_dbf;             /* disable_deblocking_filter_idc of the picture's slices: 0 the deblocking filter runs across slice boundaries, 2 it stops at them
+                                      (slice_rows is then a multiple of MI355_BAND_ROWS: a band of the deblocker never spans two slices) */
     int32_t i8;                    /* I pictures: try Intra_8x8 (High profile; intra_mode 0 only: the macroblock above-right has to be complete) */
 } frame_ctx_t;
 

@@ -58,7 +58,7 @@ void rc_set_bitrate(rc_state_t *rc, uint32_t bps) {
         rc->target_bps = bps;
         /* pictures in flight were planned -- and will have been sized -- at the old rate: their account is settled in the new
          * rate's terms (rc_update) */
-        for (uint32_t i = rc->n_upd; i != rc->n_pick; i++) { rc->plan[i & 3] *= k; rc->plan_k[i & 3] *= k; }
+        for (uint32_t i = rc->n_upd; (int32_t)(rc->n_pick - i) > 0; i++) { rc->plan[i & 3] *= k; rc->plan_k[i & 3] *= k; } /* (wrap-safe: never more than the picks outstanding) */
         /* the bucket holds bits that are already on their way: a rate change does not change them.  After a cut they would
          * keep the stream frozen for seconds (the buffer shrinks with the rate); half the new buffer is what is kept */
         if (rc->vbv > 0.5 * bps * rc->vbv_ms / 1000.0) rc->vbv = 0.5 * bps * rc->vbv_ms / 1000.0;
@@ -151,7 +151,7 @@ void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
                 int n = room > 1.0 ? (int)floor(log(room) / log(3.3)) : 0;
                 if (n < 1 && target > 1.1 * rc->last_bits_p) { /* one step is the experiment itself: one picture takes it, and its size is waited for */
                     int out = 0;
-                    for (uint32_t i = rc->n_upd; i != rc->n_pick; i++) out |= rc->plan_vqp[i & 3] < rc->known_vqp_p;
+                    for (uint32_t i = rc->n_upd; (int32_t)(rc->n_pick - i) > 0; i++) out |= rc->plan_vqp[i & 3] < rc->known_vqp_p;
                     if (!out) n = 1;
                 }
                 if (vqp < rc->known_vqp_p - n) vqp = rc->known_vqp_p - n;
@@ -184,7 +184,7 @@ void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
 }
 /* takes the newest pick back (the picture will be picked again: a recovery re-enqueues the pictures in flight) */
 void rc_cancel(rc_state_t *rc) {
-    if (rc->n_pick == rc->n_upd) return;
+    if ((int32_t)(rc->n_pick - rc->n_upd) <= 0) return;
     rc->gop_bits += rc->plan[--rc->n_pick & 3];
     rc->gop_left++;
 }
@@ -194,6 +194,7 @@ int rc_pick_qp(rc_state_t *rc, int is_idr) {
     return qp;
 }
 void rc_update(rc_state_t *rc, int is_idr, int qp, int drop, size_t bytes) {
+    if ((int32_t)(rc->n_pick - rc->n_upd) <= 0) return; /* every update settles a pick (h264_host.h): a picture coded at a fixed QP has none */
     const double bits = 8.0 * (double)bytes;
     const int gap = rc->plan_gap[rc->n_upd & 3];
     const double kk = rc->plan_k[rc->n_upd & 3]; /* != 1: picked before the setpoint moved */

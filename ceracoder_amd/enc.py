@@ -31,7 +31,7 @@ EXPORTS = [
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
     "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_pmb", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
-    "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_host_set_slice_rows", "mi355enc_stage_set_slice_rows", "mi355enc_slice_rows", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
+    "mi355enc_host_write_headers", "mi355enc_host_write_slice", "mi355enc_host_set_slice_rows", "mi355enc_host_set_p_slices", "mi355enc_stage_set_slice_rows", "mi355enc_slice_rows", "mi355enc_p_slice_rows", "mi355enc_stage_set_slice_deblock", "mi355enc_rc_init", "mi355enc_rc_set_bitrate",
     "mi355enc_rc_pick", "mi355enc_rc_update", "mi355enc_host_cavlc_block", "mi355enc_debug_trip_wait", "mi355enc_host_alloc", "mi355enc_host_free",
 ]
 
@@ -40,7 +40,7 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("fps_num", C.c_int), ("fps_den", C.c_int), ("gop", C.c_int),
                 ("me_range", C.c_int), ("bitrate_bps", C.c_uint32), ("device_id", C.c_int), ("fixed_qp", C.c_int),
                 ("qp_min", C.c_int), ("qp_max", C.c_int), ("pipeline_depth", C.c_int), ("profile_events", C.c_int),
-                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("intra_in_p", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("vbv_ms", C.c_int), ("scenecut", C.c_int), ("exclusive_device", C.c_int), ("aq_mode", C.c_int), ("single_stream", C.c_int), ("intra_slices", C.c_int), ("partitions", C.c_int), ("profile_overlap", C.c_int), ("i8x8", C.c_int)]
+                ("use_graphs", C.c_int), ("keep_prefilter", C.c_int), ("transform8x8", C.c_int), ("i4x4", C.c_int), ("subpel", C.c_int), ("deblock_mode", C.c_int), ("intra_in_p", C.c_int), ("cavlc_threads", C.c_int), ("intra_mode", C.c_int), ("vbv_ms", C.c_int), ("scenecut", C.c_int), ("exclusive_device", C.c_int), ("aq_mode", C.c_int), ("single_stream", C.c_int), ("intra_slices", C.c_int), ("partitions", C.c_int), ("profile_overlap", C.c_int), ("i8x8", C.c_int), ("slices", C.c_int), ("slice_deblock", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -108,8 +108,12 @@ def load():
         L.mi355enc_host_write_headers.argtypes = [C.c_int] * 5 + [vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_set_slice_rows.argtypes = [C.c_int]
         L.mi355enc_host_set_slice_rows.restype = None
+        L.mi355enc_host_set_p_slices.argtypes = [C.c_int, C.c_int]
+        L.mi355enc_host_set_p_slices.restype = None
         L.mi355enc_stage_set_slice_rows.argtypes = [vp, C.c_int]
         L.mi355enc_slice_rows.argtypes = [vp]
+        L.mi355enc_p_slice_rows.argtypes = [vp]
+        L.mi355enc_stage_set_slice_deblock.argtypes = [vp, C.c_int]
         L.mi355enc_host_write_slice.argtypes = [C.c_int] * 7 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_write_slice_packed.argtypes = [C.c_int] * 8 + [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.mi355enc_host_cavlc_block.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
@@ -149,6 +153,11 @@ def host_write_headers(width, height, fps_num, fps_den=1, transform8x8=False):
 def host_set_slice_rows(rows):
     """The host stage functions write I pictures as slices of `rows` macroblock rows from now on (0: one slice)."""
     load().mi355enc_host_set_slice_rows(int(rows))
+
+
+def host_set_p_slices(rows, dbf_idc=0):
+    """... and P pictures as slices of `rows` rows (0: one slice); dbf_idc: the disable_deblocking_filter_idc of every slice header (0 or 2)."""
+    load().mi355enc_host_set_p_slices(int(rows), int(dbf_idc))
 
 
 def host_write_slice(mbw, mbh, is_idr, frame_num, idr_pic_id, qp, mbinfo, levels, transform8x8=False):
@@ -230,7 +239,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False, intra_slices=0, profile_overlap=False, partitions=False, i8x8=False):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False, intra_slices=0, profile_overlap=False, partitions=False, i8x8=False, slices=0, slice_deblock=False):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
@@ -249,6 +258,8 @@ class Encoder:
         cfg.i8x8 = int(i8x8)  # with transform8x8: Intra_8x8 macroblocks in I pictures (intra_mode 0)
         cfg.partitions = int(partitions)  # P macroblocks may be split into 16x8 / 8x16 / 8x8 partitions
         cfg.intra_slices = int(intra_slices)  # 0: about 17 macroblock rows per slice (1080p: 4 slices per I picture)
+        cfg.slices = int(slices)  # slices per P picture (0 / 1: one)
+        cfg.slice_deblock = int(slice_deblock)  # the deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2)
         cfg.subpel = int(subpel)
         cfg.i4x4 = int(i4x4)
         cfg.transform8x8 = int(transform8x8)
@@ -417,6 +428,15 @@ class Encoder:
     def slice_rows(self):
         """macroblock rows per slice of this encoder's I pictures (0: one slice)"""
         return int(self.L.mi355enc_slice_rows(self.h))
+
+    @property
+    def p_slice_rows(self):
+        """... and of its P pictures"""
+        return int(self.L.mi355enc_p_slice_rows(self.h))
+
+    def stage_set_slice_deblock(self, idc):
+        """the single-stage entry points: disable_deblocking_filter_idc of the picture's slices (0 or 2)"""
+        self._chk(self.L.mi355enc_stage_set_slice_deblock(self.h, int(idc)), "stage_set_slice_deblock")
 
     def stage_set_slice_rows(self, rows):
         """the single-stage entry points treat the picture as slices of `rows` macroblock rows (0, the default: one slice)"""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355ENC_ABI_VERSION 3
+#define MI355ENC_ABI_VERSION 4
 
 enum {
     MI355ENC_OK = 0,
@@ -117,6 +117,14 @@ typedef struct {
                                  complete), otherwise ignored.  Measured at 1080p: IDR pictures 1.4 - 3.9 % smaller at QP 22 - 34 at equal PSNR; an
                                  Intra_8x8 macroblock is four dependent 8x8 blocks on the intra wavefront (its neighbour to the right starts half a
                                  macroblock behind), so a stream with key-int 60 runs 1 - 3 % slower, an all-intra one by a third */
+    int slices;               /* slices per P picture, each its own NAL unit (r04; what x264enc's threads do to a picture behind
+                                 /root/reference/pipeline/generic/x264_superfast_camlink:5).  0 / 1 (default): one slice.  n > 1: slices of ceil(rows / n)
+                                 macroblock rows; motion-vector prediction, the P_Skip inference, intra prediction, nC and QP_Y,PRED stop at a slice's
+                                 first row (6.4.8) */
+    int slice_deblock;        /* 0 (default): the deblocking filter runs across slice boundaries (disable_deblocking_filter_idc 0).  1: it stops at them
+                                 (idc 2, in the slices of I and P pictures alike; slice heights are then multiples of four macroblock rows, the height of
+                                 the deblocker's bands): every slice is an independent dependency chain for the deblocking launch -- the launch that sets
+                                 the picture period -- so its length falls from columns + rows - 1 steps to columns + rows per slice - 1 */
 } mi355enc_cfg_t;
 
 typedef struct {
@@ -259,12 +267,16 @@ int mi355enc_host_write_headers(int width, int height, int fps_num, int fps_den,
                                 size_t *out_len);
 int mi355enc_host_write_slice(int mb_width, int mb_height, int is_idr, int frame_num, int idr_pic_id, int slice_qp, int transform8x8,
                               const void *mbinfo, const int16_t *levels, uint8_t *out, size_t out_cap, size_t *out_len);
-/* the same slice through the packed hand-over format and `threads` row-parallel host threads (bit-identical result) */
 /* process-wide, for the two host stage functions below: I pictures are written as slices of `rows` macroblock rows (0, the default: one slice) */
 void mi355enc_host_set_slice_rows(int rows);
+/* ... P pictures as slices of `rows` rows (0: one slice), and the disable_deblocking_filter_idc every slice header (I and P) carries: 0 or 2 */
+void mi355enc_host_set_p_slices(int rows, int dbf_idc);
 /* the single-stage entry points of a handle work on one-slice pictures unless told otherwise (the encoder itself follows cfg.intra_slices) */
 int mi355enc_stage_set_slice_rows(mi355enc_t *h, int rows);
 int mi355enc_slice_rows(const mi355enc_t *h); /* rows per slice of this handle's I pictures (0: one slice) */
+int mi355enc_p_slice_rows(const mi355enc_t *h); /* ... and of its P pictures */
+int mi355enc_stage_set_slice_deblock(mi355enc_t *h, int idc); /* the single-stage entry points: disable_deblocking_filter_idc of the picture's slices, 0 (default) or 2 */
+/* the same slice through the packed hand-over format and `threads` row-parallel host threads (bit-identical result) */
 int mi355enc_host_write_slice_packed(int mbw, int mbh, int is_idr, int frame_num, int idr_pic_id, int qp, int t8, int threads, const void *mbinfo,
                                      const int16_t *levels, uint8_t *out, size_t cap, size_t *out_len);
 /* One CAVLC residual block (9.2) through the slice writer's block coder, for known-answer tests: coef in scan order, maxnum 16

@@ -259,14 +259,28 @@ int orc_dequant4(int level, int qp, int pos) {
 static int g_orc_t8 = 0; /* process-wide: transform_8x8_mode (High profile stream, 8x8 transform for P macroblocks) */
 void orc_set_transform8x8(int on) { g_orc_t8 = on; }
 int orc_get_transform8x8(void) { return g_orc_t8; }
-/* Slices of an I picture: g_slice_rows > 0 cuts the picture into slices of that many macroblock rows (7.3.2.8: each its own NAL unit).  Inside the
- * encoder only the availability of the row above changes (6.4.8: a macroblock of another slice is not available for intra prediction, for the
- * Intra_4x4 mode predictor, for nC, for QP_Y,PRED); the deblocking filter runs across slice boundaries (disable_deblocking_filter_idc 0).  The
- * slices of a picture are independent chains for the intra wavefront -- that is what they are for here.  P pictures stay one slice. */
-static int g_slice_rows = 0;
+/* Slices: g_slice_rows > 0 cuts the picture being coded into slices of that many macroblock rows (7.3.2.8: each its own NAL unit).  Inside the
+ * encoder the availability of the row above changes (6.4.8: a macroblock of another slice is not available for intra prediction, for the
+ * Intra_4x4 mode predictor, for nC, for QP_Y,PRED, for the 8.4.1.3 motion vector predictors and the 8.4.1.1 P_Skip inference), and the slices of
+ * a picture become independent chains for the intra wavefront.  I pictures: since r03.  P pictures (r04; orc_enc_set_p_slices): the same cut,
+ * vector prediction included -- what x264enc's threads do behind /root/reference/pipeline/generic/x264_superfast_camlink:5.
+ * g_slice_dbf = disable_deblocking_filter_idc of the picture's slices: 0 the deblocking filter runs across slice boundaries, 2 (8.7:
+ * filterTopMbEdgeFlag = 0 where the macroblock above belongs to another slice) it stops at them -- then the slices are independent chains for
+ * the deblocking wavefront too, which is the point on the device (the picture period IS the deblocking launch). */
+static int g_slice_rows = 0, g_slice_dbf = 0;
 void orc_set_slice_rows(int rows) { g_slice_rows = rows > 0 ? rows : 0; }
 int orc_get_slice_rows(void) { return g_slice_rows; }
+void orc_set_slice_deblock(int idc) { g_slice_dbf = idc == 2 ? 2 : 0; }
+int orc_get_slice_deblock(void) { return g_slice_dbf; }
 int orc_auto_intra_slices(int mbh) { int n = mbh / 17; return n < 1 ? 1 : n > 8 ? 8 : n; } /* about 17 rows each (1080p: 4), at most 8 */
+/* rows per slice for n slices of a picture of mbh rows (0: one slice); with slice-local deblocking a multiple of four rows, the height of the
+ * device deblocker's bands (a band never spans two slices) */
+int orc_slice_rows_for(int mbh, int n, int local_deblock) {
+    if (n <= 1) return 0;
+    int rows = (mbh + n - 1) / n;
+    if (local_deblock) rows = (rows + 3) & ~3;
+    return rows >= mbh ? 0 : rows;
+}
 static int top_ok(int my) { return my > 0 && !(g_slice_rows > 0 && my % g_slice_rows == 0); }
 /* 8.5.6 8x8 zig-zag (frame) scan: scan position -> raster index y*8+x */
 static const uint8_t k_zigzag8[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -487,7 +501,8 @@ static int median3(int a, int b, int c) {
 }
 /* 8.4.1.3 on a whole-sample field (every neighbour taken as inter, refIdx 0) and the 8.4.1.1 skip inference on the same field */
 static void field_pred(const orc_imv_t *f, int mbw, int mx, int my, int *px, int *py, int *sx, int *sy) {
-    const int avA = mx > 0, avB = my > 0, avC = my > 0 && mx + 1 < mbw, avD = mx > 0 && my > 0;
+    const int top = top_ok(my); /* (the row above belongs to another slice: not available, 6.4.8) */
+    const int avA = mx > 0, avB = top, avC = top && mx + 1 < mbw, avD = mx > 0 && top;
     const orc_imv_t *A = avA ? &f[my * mbw + mx - 1] : NULL, *B = avB ? &f[(my - 1) * mbw + mx] : NULL;
     const orc_imv_t *C = avC ? &f[(my - 1) * mbw + mx + 1] : (avD ? &f[(my - 1) * mbw + mx - 1] : NULL);
     const int n = (A != NULL) + (B != NULL) + (C != NULL);
@@ -1705,7 +1720,7 @@ void orc_deblock_frame(uint8_t *rec_y, uint8_t *rec_uv, int stride, int mbw, int
             }
             /* horizontal edges, top to bottom */
             for (int e = 0; e < 4; e++) {
-                if (e == 0 && my == 0) continue;
+                if (e == 0 && (my == 0 || (g_slice_dbf == 2 && !top_ok(my)))) continue; /* 8.7: filterTopMbEdgeFlag = 0 at the picture's top, and with disable_deblocking_filter_idc 2 where the macroblock above is in another slice */
                 const orc_mbinfo_t *mp = e == 0 ? m - mbw : m;
                 int qpc_p = k_chroma_qp[mp->qp];
                 if (!(t8 && (e & 1)))
@@ -1789,13 +1804,14 @@ int orc_cavlc_block_bits(const int16_t *coef, int maxnum, int nC, uint8_t *out, 
  * are not needed: vectors are compared/added as integer-pel*4 by the caller).
  * type[] : -1 unavailable, 0 intra (refIdx -1), 1 inter (refIdx 0). */
 /* 6.4.11.7 / 8.4.1.3.2: motion data of the 8x8 block covering luma sample (X, Y) as a neighbour of a partition of macroblock (mx, my), whose own
- * quadrants in `done` carry the vectors cur[q]; macroblocks later in raster order are not available (P pictures are one slice). */
+ * quadrants in `done` carry the vectors cur[q]; macroblocks later in raster order and macroblocks of another slice are not available. */
 static void nb_blk(const orc_mbinfo_t *mbi, int mbw, int mbh, int mx, int my, unsigned done, int cur[4][2], int X, int Y, int *avail, int *ref, int *vx, int *vy) {
     *avail = 0; *ref = -1; *vx = *vy = 0;
     if (X < 0 || Y < 0 || X >= mbw * 16 || Y >= mbh * 16) return;
     const int nx = X >> 4, ny = Y >> 4, q = ((Y & 15) >> 3) * 2 + ((X & 15) >> 3);
     if (nx == mx && ny == my) { if ((done >> q) & 1) { *avail = 1; *ref = 0; *vx = cur[q][0]; *vy = cur[q][1]; } return; }
     if (!(ny < my || (ny == my && nx < mx))) return;
+    if (ny < my && !top_ok(my)) return; /* another slice (slices are whole rows: only the row above can be one) */
     *avail = 1;
     if (mbi[ny * mbw + nx].mb_type == 1) { *ref = 0; mb_qmv(mbi, ny * mbw + nx, q, vx, vy); }
 }
@@ -1920,7 +1936,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
     uint8_t *tc_l = (uint8_t *)calloc((size_t)nmb, 16); /* TotalCoeff per luma blkIdx   */
     uint8_t *tc_c = (uint8_t *)calloc((size_t)nmb, 8);  /* per chroma AC block (Cb 0-3, Cr 4-7) */
     if (!rb || !tc_l || !tc_c) { free(rb); free(tc_l); free(tc_c); return 0; }
-    const int srows = (is_idr && g_slice_rows > 0) ? g_slice_rows : 0; /* I pictures: a new slice every so many macroblock rows */
+    const int srows = g_slice_rows > 0 ? g_slice_rows : 0; /* a new slice every so many macroblock rows */
     size_t total = 0;
     bw_t b;
 #define SLICE_HEADER(first_mb)                                                                        \
@@ -1936,7 +1952,7 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
         if (is_idr) { bw_put(&b, 1, 0); bw_put(&b, 1, 0); } /* no_output_of_prior_pics, long_term_reference */ \
         else bw_put(&b, 1, 0);                        /* adaptive_ref_pic_marking_mode_flag */        \
         bw_se(&b, qp - 26);                           /* slice_qp_delta */                            \
-        bw_ue(&b, 0);                                 /* disable_deblocking_filter_idc */             \
+        bw_ue(&b, (uint32_t)g_slice_dbf);             /* disable_deblocking_filter_idc */             \
         bw_se(&b, 0);                                 /* slice_alpha_c0_offset_div2 */                \
         bw_se(&b, 0);                                 /* slice_beta_offset_div2 */                    \
     } while (0)
@@ -1946,9 +1962,10 @@ size_t orc_write_slice(uint8_t *out, size_t cap, int mbw, int mbh, int is_idr, i
     static const uint8_t raster_blk[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* by*4+bx -> blkIdx */
     int skip_run = 0, prev_qp = qp;
     for (int my = 0; my < mbh; my++) {
-        if (srows && my > 0 && my % srows == 0) { /* the slice ends (I slices: no skip run pending), the next one starts */
+        if (srows && my > 0 && my % srows == 0) { /* the slice ends (P slices: with the skip run still pending, 7.3.4), the next one starts */
+            if (!is_idr && skip_run) { bw_ue(&b, (uint32_t)skip_run); skip_run = 0; }
             bw_trailing(&b);
-            const size_t n = b.overflow ? 0 : write_nal(out + total, cap - total, 3, 5, rb, b.pos);
+            const size_t n = b.overflow ? 0 : write_nal(out + total, cap - total, is_idr ? 3 : 2, is_idr ? 5 : 1, rb, b.pos);
             if (!n) { free(rb); free(tc_l); free(tc_c); return 0; }
             total += n;
             SLICE_HEADER(my * mbw);
@@ -2084,6 +2101,7 @@ struct orc_enc {
     int width, height, mbw, mbh, stride, fps_num, fps_den, gop, me_range, threads, subpel;
     int frames_since_idr, idr_count, have_ref;
     int intra_slices;               /* slices per I picture (0: orc_auto_intra_slices) */
+    int p_slices, slice_dbf;        /* slices per P picture (0 / 1: one); disable_deblocking_filter_idc of every slice (0 or 2) */
     int aq; int8_t *aq_off;                                                    /* adaptive quantisation: per-macroblock QP offsets of the picture being coded */
     int scenecut, sc_cnt, prev_idr, sc_lag, prev_all_skip;                      /* scene-cut recovery: mirrors enc_schedule.cpp (collect / enqueue_picture) */
     unsigned long long sc_sum, sc_force_at, pic_index;
@@ -2163,6 +2181,11 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
     const int all_skip = !idr && drop == ORC_DROP_SKIP;
     int nxt = e->cur ^ 1;
     size_t ysz = (size_t)e->stride * e->mbh * 16;
+    {   /* the picture's slices (an all-skip picture stays one slice: there is nothing in it to cut) */
+        const int ns = idr ? (e->intra_slices > 0 ? e->intra_slices : orc_auto_intra_slices(e->mbh)) : e->p_slices;
+        g_slice_rows = all_skip ? 0 : orc_slice_rows_for(e->mbh, ns, e->slice_dbf == 2);
+        g_slice_dbf = e->slice_dbf;
+    }
     if (all_skip) {
         nxt = e->cur; /* the reconstruction IS the reference: every macroblock P_Skip with the zero vector, nothing to filter */
         for (int i = 0; i < nmb; i++) { memset(&e->mbi[i], 0, sizeof e->mbi[i]); e->mbi[i].mb_type = 1; e->mbi[i].qp = (uint8_t)qp; }
@@ -2172,10 +2195,6 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
     } else {
         load_padded(e, y, y_stride, uv, uv_stride);
         if (e->aq) { orc_aq_offsets(e->src_y, e->stride, e->mbw, e->mbh, e->aq_off); g_aq = e->aq_off; }
-        {
-            const int ns = e->intra_slices > 0 ? e->intra_slices : orc_auto_intra_slices(e->mbh);
-            g_slice_rows = (idr && ns > 1) ? (e->mbh + ns - 1) / ns : 0;
-        }
         if (idr)
             orc_intra_frame(e->src_y, e->src_uv, e->rec_y[nxt], e->rec_uv[nxt], e->stride, e->mbw, e->mbh, qp, drop == ORC_DROP_SKIP ? 0 : drop, e->mbi, e->levels);
         else {
@@ -2214,7 +2233,7 @@ int orc_enc_frame2(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *
     }
     size_t s = orc_write_slice(out + n, out_cap - n, e->mbw, e->mbh, idr, e->frames_since_idr, e->idr_count & 0xFFFF,
                                qp, e->mbi, e->levels);
-    g_slice_rows = 0; g_part_lev = NULL;
+    g_slice_rows = 0; g_slice_dbf = 0; g_part_lev = NULL;
     if (!s) return -2;
     *out_len = n + s;
     if (is_idr) *is_idr = idr;
@@ -2242,6 +2261,8 @@ int orc_enc_frame(orc_enc_t *e, const uint8_t *y, int y_stride, const uint8_t *u
 void orc_enc_set_subpel(orc_enc_t *e, int on) { e->subpel = on; }
 void orc_enc_set_aq(orc_enc_t *e, int on) { e->aq = on; }
 void orc_enc_set_intra_slices(orc_enc_t *e, int n) { e->intra_slices = n < 0 ? 0 : n; }
+void orc_enc_set_p_slices(orc_enc_t *e, int n) { e->p_slices = n < 0 ? 0 : n; }
+void orc_enc_set_slice_deblock(orc_enc_t *e, int local) { e->slice_dbf = local ? 2 : 0; }
 void orc_enc_set_scenecut(orc_enc_t *e, int on) { e->scenecut = on; }
 void orc_enc_set_sc_lag(orc_enc_t *e, int lag) { e->sc_lag = lag < 2 ? 2 : lag; } /* enc_schedule.cpp sc_lag(): pipeline_depth + 1 from depth 2 on */
 void orc_enc_set_me_iters(orc_enc_t *e, int n) { e->me_iters = n < 0 ? 0 : n; }

@@ -138,10 +138,15 @@ void orc_set_i8x8(int on);                      /* process-wide: I pictures of a
 int orc_get_i8x8(void);
 void orc_intra_decide8(const uint8_t *src_y, int stride, int mbw, int mbh, int qp, orc_idec_t *idec); /* after orc_intra_decide: Intra_8x8 where strictly cheaper (use_i4 = 2, modes in modes4[0..3]) */
 void orc_set_part_levels(const int16_t *levels); /* stage functions (deblocking, slice writer): where the vectors of an inter macroblock's partitions 1 .. 3 lie (the levels of the picture; NULL: 16x16 only) */
-void orc_set_slice_rows(int rows);              /* stage functions: the I picture being coded is cut into slices of `rows` macroblock rows (0: one slice) */
+void orc_set_slice_rows(int rows);              /* stage functions: the picture being coded is cut into slices of `rows` macroblock rows (0: one slice) */
+void orc_set_slice_deblock(int idc);            /* stage functions: disable_deblocking_filter_idc of the picture's slices, 0 (across slice boundaries) or 2 (slice-local) */
+int orc_get_slice_deblock(void);
+int orc_slice_rows_for(int mbh, int n, int local_deblock); /* rows per slice for n slices (0: one slice); a multiple of four with slice-local deblocking */
 int orc_get_slice_rows(void);
 int orc_auto_intra_slices(int mbh);             /* the default number of slices of an I picture: about 17 rows each, at most 8 */
 void orc_enc_set_intra_slices(orc_enc_t *e, int n); /* slices per I picture (0: the default above) */
+void orc_enc_set_p_slices(orc_enc_t *e, int n);     /* slices per P picture (0 / 1: one slice, the default) */
+void orc_enc_set_slice_deblock(orc_enc_t *e, int local); /* 1: the deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2; slice heights become multiples of four rows); default 0 */
 void orc_qp_chain(orc_mbinfo_t *mbi, int nmb, int slice_qp); /* 7.4.5: macroblocks without mb_qp_delta take the QP_Y of the one before them */
 void orc_enc_set_scenecut(orc_enc_t *e, int on); /* default on */
 void orc_enc_set_sc_lag(orc_enc_t *e, int lag);  /* scene-cut recovery lands on picture k + lag (default 2; the device: pipeline_depth + 1 from depth 2 on) */

@@ -100,6 +100,13 @@ def lib():
         L.orc_auto_intra_slices.argtypes = [C.c_int]
         L.orc_enc_set_intra_slices.argtypes = [vp, C.c_int]
         L.orc_enc_set_intra_slices.restype = None
+        L.orc_enc_set_p_slices.argtypes = [vp, C.c_int]
+        L.orc_enc_set_p_slices.restype = None
+        L.orc_enc_set_slice_deblock.argtypes = [vp, C.c_int]
+        L.orc_enc_set_slice_deblock.restype = None
+        L.orc_set_slice_deblock.argtypes = [C.c_int]
+        L.orc_set_slice_deblock.restype = None
+        L.orc_slice_rows_for.argtypes = [C.c_int, C.c_int, C.c_int]
         L.orc_enc_set_scenecut.restype = None
         L.orc_enc_set_sc_lag.argtypes = [vp, C.c_int]
         L.orc_enc_set_sc_lag.restype = None
@@ -173,7 +180,7 @@ def _view(ptr, shape, dtype):
 class Encoder:
     """Whole-encoder oracle: one NV12 frame + QP in, Annex-B access unit + stage outputs out."""
 
-    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True, scenecut=True, me_iters=None, sc_lag=2, aq=False, intra_slices=0):
+    def __init__(self, width, height, fps=60, gop=60, me_range=16, threads=1, subpel=True, scenecut=True, me_iters=None, sc_lag=2, aq=False, intra_slices=0, p_slices=0, slice_deblock_local=False):
         self.L = lib()
         self.h = self.L.orc_enc_open(width, height, fps, 1, gop, me_range, threads)
         if not self.h:
@@ -182,6 +189,8 @@ class Encoder:
         self.L.orc_enc_set_scenecut(self.h, int(scenecut))
         self.L.orc_enc_set_aq(self.h, int(aq))
         self.L.orc_enc_set_intra_slices(self.h, int(intra_slices))  # 0: the default (about 17 macroblock rows per slice)
+        self.L.orc_enc_set_p_slices(self.h, int(p_slices))          # slices per P picture (0 / 1: one slice)
+        self.L.orc_enc_set_slice_deblock(self.h, int(slice_deblock_local))  # the deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2)
         self.L.orc_enc_set_sc_lag(self.h, int(sc_lag))
         if me_iters is not None:
             self.L.orc_enc_set_me_iters(self.h, int(me_iters))
@@ -365,14 +374,20 @@ def set_i8x8(on):
 
 
 def set_slice_rows(rows):
-    """Stage functions: the I picture being coded is cut into slices of `rows` macroblock rows (0: one slice)."""
+    """Stage functions: the picture being coded is cut into slices of `rows` macroblock rows (0: one slice)."""
     lib().orc_set_slice_rows(int(rows))
 
 
-def slice_rows_for(mbh, slices=0):
-    """Rows per slice the encoders use for `slices` slices per I picture (0: the default number); 0 = one slice."""
+def set_slice_deblock(idc):
+    """Stage functions (deblock_frame, write_slice): disable_deblocking_filter_idc of the picture's slices, 0 (across boundaries) or 2 (slice-local)."""
+    lib().orc_set_slice_deblock(int(idc))
+
+
+def slice_rows_for(mbh, slices=0, local_deblock=False):
+    """Rows per slice the encoders use for `slices` slices per picture (0: the default number of an I picture); 0 = one slice.  With slice-local
+    deblocking a multiple of four rows."""
     n = slices if slices > 0 else lib().orc_auto_intra_slices(int(mbh))
-    return (mbh + n - 1) // n if n > 1 else 0
+    return lib().orc_slice_rows_for(int(mbh), int(n), int(local_deblock))
 
 
 def set_features(mask):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""dev tool: A/B of a schedule switch that the library reads from the environment per picture (e.g. MI355ENC_NO_FIP), alternating runs inside ONE process so that
+"""dev tool: A/B of a schedule switch that the library reads from the environment when an encoder is opened (e.g. MI355ENC_NO_FIP; a new encoder per configuration), alternating runs inside ONE process so that
 box-to-box and minute-to-minute noise cancels: N rounds of (unset, set), 600 pictures each, pipeline_depth 2, exclusive, CBR.
     python tests/devtools/ab_env.py VAR [W H [rounds]]"""
 import os, sys, time

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(E.EXPORTS) == declared, set(declared) ^ set(E.EXPORTS)
-    assert L.mi355enc_abi_version() == 3
+    assert L.mi355enc_abi_version() == 4
 
 
 def test_error_strings_and_defaults():
@@ -347,6 +347,32 @@ def test_rate_control_emergency_drop_lands_within_a_few_pictures(delay):
     assert all(s < 1.5 * per_frame for s in sizes[drop_at + 3 + delay:drop_at + 20]), sizes[drop_at:drop_at + 8]
     # ... and the half second after the drop carries no more than 1.3x the new rate
     assert sum(sizes[drop_at + 2:drop_at + 32]) * 8 * fps / 30 < 1.3 * 500_000
+
+
+def test_rate_control_survives_updates_without_picks():
+    """Pictures coded at a fixed QP book nothing with rate control (enqueue_picture skips rc_pick), so a stray update must not run the
+    update counter ahead of the pick counter: the loops over the picks outstanding once wrapped through 2^32 iterations there (3.5 s
+    inside set_bitrate -- past ceracoder's 1 s stall watchdog, /root/reference/src/ceracoder.c:152-200) and rc_cancel pushed the pick
+    counter further below.  Updates without a pick are ignored, the loops are wrap-safe, and rate control works as before afterwards."""
+    import time
+    rc = E.RateControl(60, 60, 6_000_000)
+    for _ in range(3):
+        rc.update(False, 30, 0, 12_000)          # no pick in front of any of them
+    t0 = time.time()
+    rc.set_bitrate(3_000_000)
+    qp, drop = rc.pick(True)
+    assert time.time() - t0 < 0.2
+    rc.update(True, qp, drop, 60_000)
+    rng = np.random.default_rng(2)
+    sizes = []
+    for i in range(1, 180):
+        idr = i % 60 == 0
+        qp, drop = rc.pick(idr)
+        n = _synthetic_bytes(rng, idr, qp, drop)
+        rc.update(idr, qp, drop, n)
+        sizes.append(n)
+    rate = sum(sizes[60:]) * 8 * 60 / len(sizes[60:])
+    assert abs(rate / 3_000_000 - 1) < 0.15, rate
 
 
 def test_device_code_avoids_miscompiled_pack_instruction(tmp_path):

@@ -1,0 +1,139 @@
+"""P pictures as slices with slice-local deblocking on the device (r04; cfg.slices / cfg.slice_deblock): the kernels whose neighbourhood stops at a
+slice's first row -- vector selection and the fused P stage (field_pred), the intra macroblock rows of P pictures, the band deblocker (a slice is a
+whole number of bands; a slice's first row has no top edge and takes no strips, its last row keeps its bottom lines) and the per-diagonal form --
+against the oracle's stage functions, then whole streams through every schedule."""
+import numpy as np
+import pytest
+
+from tests.util import first_diff, frames, mbinfo_equal
+
+pytestmark = pytest.mark.gpu
+
+IMV_FIELDS = ("mvx", "mvy", "sad", "bits")
+
+
+@pytest.mark.parametrize("w,h,rows", [(176, 144, 4), (320, 192, 4), (640, 368, 8), (1280, 720, 12), (1920, 1088, 16), (1920, 1088, 20)])
+def test_vector_selection_stops_at_slice_tops(E, oracle, w, h, rows):
+    """me_select_kernel with ctx->slice_rows: the 8.4.1.3 median and the P_Skip inference take nothing from the row above a slice's first row."""
+    e = E.Encoder(w, h, fixed_qp=30)
+    fr = frames(w, h, 2)
+    cur, ref = fr[1][0], fr[0][0]
+    o_surf, orc = oracle.me_frame(cur, ref, 16, 30, threads=8)
+    d_surf, dev = e.stage_me(cur, ref, 30)
+    assert mbinfo_equal(dev, orc, IMV_FIELDS)
+    oracle.set_slice_rows(rows)
+    try:
+        e.stage_set_slice_rows(rows)
+        mbw, mbh = w // 16, h // 16
+        for it in range(3):
+            orc2 = oracle.me_select(o_surf, orc, mbw, mbh, 16, 30, threads=8)
+            dev2 = e.stage_me_select(d_surf, dev, 30)
+            assert mbinfo_equal(dev2, orc2, IMV_FIELDS), (it, rows)
+            orc, dev = orc2, dev2
+    finally:
+        oracle.set_slice_rows(0)
+    e.close()
+
+
+@pytest.mark.parametrize("w,h,rows", [(64, 64, 4), (176, 144, 4), (320, 192, 8), (1280, 720, 12), (1920, 1088, 16), (1920, 1088, 20), (1920, 1088, 4)])
+@pytest.mark.parametrize("qp", [20, 34, 51])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_slice_local_deblocking_matches_oracle(E, oracle, w, h, rows, qp, mode):
+    """stage_deblock with disable_deblocking_filter_idc 2 on the oracle's own pre-filter pictures (one I: every edge strong; one P) and records: the band
+    kernel (slices are whole bands: 4-row slices make every band a slice) and the per-diagonal form."""
+    if rows >= (h + 15) // 16:
+        pytest.skip("one slice")
+    oe = oracle.Encoder(w, h, gop=60, threads=8)
+    e = E.Encoder((w + 15) // 16 * 16, (h + 15) // 16 * 16, fixed_qp=qp, deblock_mode=mode)
+    e.stage_set_slice_rows(rows)
+    e.stage_set_slice_deblock(2)
+    try:
+        for _, _, y, uv in frames(w, h, 2):
+            oe.encode(y, uv, qp)
+            oracle.set_slice_rows(rows)
+            oracle.set_slice_deblock(2)
+            want_y, want_uv = oracle.deblock_frame(oe.prefilter_y, oe.prefilter_uv, oe.mbinfo)
+            oracle.set_slice_rows(0)
+            oracle.set_slice_deblock(0)
+            d_y, d_uv = e.stage_deblock(oe.prefilter_y, oe.prefilter_uv, oe.mbinfo)
+            assert np.array_equal(d_y, want_y), first_diff(d_y, want_y)
+            assert np.array_equal(d_uv, want_uv), first_diff(d_uv, want_uv)
+            assert not np.array_equal(want_y, oe.recon_y)  # the seams are really left alone
+    finally:
+        oracle.set_slice_rows(0)
+        oracle.set_slice_deblock(0)
+        e.close()
+
+
+def _run_stream(E, oracle, w, h, n, qps, slices, local, depth=0, exclusive=False, single_stream=False, aq=False, partitions=False, intra_in_p=1, t8=False,
+                islices=0, clip=None, gop=4, mode=0, thr=0, check_dec=True):
+    oracle.set_features(oracle.F_ALL | (oracle.F_PART if partitions else 0) | (oracle.F_I4P if intra_in_p == 2 else 0))
+    oracle.set_transform8x8(t8)
+    try:
+        e = E.Encoder(w, h, gop=gop, fixed_qp=30, pipeline_depth=depth, exclusive=exclusive, single_stream=single_stream, partitions=partitions, aq=aq,
+                      intra_slices=islices, slices=slices, slice_deblock=local, intra_in_p=intra_in_p, transform8x8=t8, scenecut=False, deblock_mode=mode, cavlc_threads=thr)
+        oe = oracle.Encoder(w, h, gop=gop, threads=16, aq=aq, intra_slices=islices, p_slices=slices, slice_deblock_local=local, scenecut=False)
+        dec = oracle.Decoder()
+        assert e.p_slice_rows == oracle.slice_rows_for(oe.mbh, slices, local)
+        clip = clip or [(y, uv) for _, _, y, uv in frames(w, h, n)]
+        got = []
+        for i, (y, uv) in enumerate(clip):
+            e.set_fixed_qp(qps[i % len(qps)])
+            e.submit(y, uv, pts=i)
+            if e.pending > depth:
+                got.append(e.collect()[0])
+        while e.pending:
+            got.append(e.collect()[0])
+        intra = 0
+        for i, (y, uv) in enumerate(clip):
+            ref_au, key = oe.encode(y, uv, qps[i % len(qps)])
+            assert got[i] == ref_au, ("bitstream", i, len(got[i]), len(ref_au))
+            if check_dec:
+                dy, duv = dec.decode(ref_au)
+                assert np.array_equal(dy, oe.recon_y) and np.array_equal(duv, oe.recon_uv), i
+            if not key:
+                intra += int((oe.mbinfo["mb_type"] != 1).sum())
+        assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y), first_diff(e.fetch(E.FETCH_RECON_Y), oe.recon_y)
+        assert np.array_equal(e.fetch(E.FETCH_RECON_UV), oe.recon_uv)
+        st = e.stats()
+        assert st.recoveries == 0
+        e.close()
+        return intra
+    finally:
+        oracle.set_features(oracle.F_ALL)
+        oracle.set_transform8x8(False)
+
+
+@pytest.mark.parametrize("w,h,n,slices", [(176, 144, 7, 2), (322, 182, 6, 3), (640, 368, 6, 4), (1280, 720, 5, 3), (1920, 1080, 5, 4), (1920, 1080, 4, 5), (1920, 1080, 3, 17)])
+@pytest.mark.parametrize("local", [False, True])
+def test_sliced_p_pictures_equal_oracle(E, oracle, w, h, n, slices, local):
+    """Whole path at pipeline depth 0: access units, reconstruction, the independent decoder -- P pictures cut into slices, the filter across the seams
+    (idc 0) or stopping at them (idc 2)."""
+    _run_stream(E, oracle, w, h, n, [30, 28, 33, 24, 40, 26, 51], slices, local)
+
+
+@pytest.mark.parametrize("exclusive,single_stream,depth", [(False, False, 2), (True, False, 2), (False, True, 2), (True, False, 1)])
+@pytest.mark.parametrize("partitions,aq,ip,t8", [(False, False, 1, False), (True, False, 1, False), (False, True, 1, False), (False, False, 2, False), (False, True, 1, True)])
+def test_sliced_streams_through_schedules_and_options(E, oracle, exclusive, single_stream, depth, partitions, aq, ip, t8):
+    """The slice-local stream whatever the schedule (kernels waiting for each other on the device, stream order, one stream per encoder; one to three
+    pictures in flight) crossed with partitions, adaptive quantisation (the QP_Y chain starts again with every slice), Intra_4x4 in P pictures and the
+    High-profile stream; 720p with a clip that has a cut, so that P pictures carry intra macroblocks on both sides of the seams."""
+    from tests.util import cut_clip
+    w, h, n = 1280, 720, 7
+    intra = _run_stream(E, oracle, w, h, n, [26, 30, 24, 34, 28, 22, 38], 3, True, depth=depth, exclusive=exclusive, single_stream=single_stream, aq=aq, partitions=partitions,
+                        intra_in_p=ip, t8=t8, clip=cut_clip(w, h, n, 4), gop=30)
+    assert intra > 0
+
+
+@pytest.mark.parametrize("w,h,n,slices", [(1920, 1080, 40, 4), (1920, 1080, 24, 5), (3840, 2160, 8, 8), (1280, 720, 40, 3), (640, 368, 60, 2)])
+def test_three_pictures_in_flight_with_slices_equal_oracle(E, oracle, w, h, n, slices):
+    """The free-running schedule (three pictures in flight, the fused P stage beside the previous picture's deblocking launch, the launch waiting on the
+    device for its picture's rows) with every slice a wavefront of its own: the oracle's stream."""
+    _run_stream(E, oracle, w, h, n, [30, 31, 29, 32], slices, True, depth=2, exclusive=True, gop=60, check_dec=False)
+
+
+def test_per_diagonal_deblocker_and_the_writer_threads_with_slices(E, oracle):
+    """deblock_mode 1 (one launch per wavefront step: the ladder's last level) and the row-parallel writer on explicit thread counts with sliced P pictures."""
+    for thr in (1, 3, 8):
+        _run_stream(E, oracle, 640, 368, 5, [28, 32, 26], 4, True, mode=1, thr=thr)
+        _run_stream(E, oracle, 640, 368, 5, [28, 32, 26], 4, True, mode=0, thr=thr, depth=1)
