@@ -214,6 +214,9 @@ def main():
                     "(BASELINE.json configs[2]: 'balancer driving the bitrate property'), none elsewhere")
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     ap.add_argument("--i8x8", type=int, default=0, help="1 (with --dct8x8 1): Intra_8x8 macroblocks in I pictures (picture QP <= 37)")
+    ap.add_argument("--aq", type=int, default=0, help="1: adaptive quantisation (aq-mode 1)")
+    ap.add_argument("--slices", type=int, default=-1, help="slices per P picture (cfg.slices); -1: the encoder's default")
+    ap.add_argument("--slice-deblock", type=int, default=-1, help="1: the deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2); -1: the encoder's default")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         # One process per stream, as the reference runs them (bindings/typescript/src/process.ts:129-170): start the ranks ourselves, each a fresh
@@ -279,10 +282,13 @@ def main():
 
     if args.sample > 0:  # a short run (the driver's --steps 20) still gets at least four sampled pictures inside the timed region
         args.sample = max(1, min(args.sample, args.steps // 4 if args.steps >= 4 else 1))
+    # the coding tools, the same in every encoder this script opens (None: the library's default)
+    tools = dict(transform8x8=bool(args.dct8x8), i8x8=bool(args.i8x8), aq=bool(args.aq), slices=None if args.slices < 0 else args.slices,
+                 slice_deblock=None if args.slice_deblock < 0 else bool(args.slice_deblock))
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                          pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                         transform8x8=bool(args.dct8x8), i8x8=bool(args.i8x8), cavlc_threads=args.cavlc_threads, exclusive=(S == 1 and not shared_gpu), single_stream=(S > 2), profile_overlap=not args.sample_in_order)
+                         cavlc_threads=args.cavlc_threads, **tools, exclusive=(S == 1 and not shared_gpu), single_stream=(S > 2), profile_overlap=not args.sample_in_order)
 
     encs = [make_encoder() for _ in range(S)]
     e = encs[0]
@@ -332,8 +338,7 @@ def main():
         # Untimed extras.  (1) quality: a separate pass over two GOPs of the same clip with the same rate control (and the same
         # setpoint script), reconstruction fetched after every picture -- mean PSNR of Y, Cb, Cr over ALL its pictures.
         from ceracoder_amd import synth
-        q_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads,
-                          transform8x8=bool(args.dct8x8))
+        q_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads, **tools)
         nq, ps, qbytes, last_b = (2 * gop if gop > 1 else 30), [], 0, None
         for i in range(nq):
             if script:
@@ -354,7 +359,7 @@ def main():
             # (2) per-picture latency of the synchronous path an element in a live graph uses (pipeline_depth 0):
             # host NV12 in -> H2D -> kernels -> D2H -> CAVLC -> access unit out, PCIe included.
             lat_enc = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=0, cavlc_threads=args.cavlc_threads,
-                                exclusive=not shared_gpu)
+                                exclusive=not shared_gpu, **tools)
             def lat_run(n, gap_s):
                 v = []
                 for i in range(n):
@@ -379,7 +384,7 @@ def main():
             # mi355enc_host_alloc (what the element offers its upstream through the ALLOCATION query): transferred in place.  PCIe included.
             def host_run(src_frames, n):
                 he = E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp, pipeline_depth=2, cavlc_threads=args.cavlc_threads,
-                               exclusive=not shared_gpu)
+                               exclusive=not shared_gpu, **tools)
                 def go(k, first):
                     for i in range(k):
                         f = src_frames[bounce(first + i, len(src_frames))]
@@ -417,7 +422,7 @@ def main():
         idr_probe = None
         if gop > 1:
             ie = E.Encoder(width, height, fps=fps, gop=10 ** 6, bitrate_bps=bps, device_id=dev, fixed_qp=int(round(float(np.mean(qps)))), pipeline_depth=0,
-                           profile_events=1, cavlc_threads=args.cavlc_threads)
+                           profile_events=1, cavlc_threads=args.cavlc_threads, **tools)
             for i in range(3):   # cold start: code objects, first launches
                 f = frames_np[bounce(i, args.unique)]
                 ie.encode(f[:height], f[height:], pts=i)

@@ -45,15 +45,14 @@ typedef struct {
     guint key_int_max;
     gint device_id, me_range, qp, pipeline_depth, speed_preset;
     gint open_depth;  /* pipeline-depth the encoder was opened with: a write to the property in mid-stream takes effect at the next (re)negotiation */
-    gboolean stats, dct8x8;
+    gboolean stats;
     gint threads;
     gboolean scenecut, exclusive_gpu;
     guint vbv_ms;
-    gboolean intra_in_p, pinned_input;
-    gint aq_mode;
-    gint slices;
-    gboolean partitions;
-    gboolean i8x8;
+    gboolean pinned_input;
+    /* coding tools: -1 = not set on the element, i.e. what speed-preset selects (preset_tools); an explicit write wins */
+    gint dct8x8, i8x8, aq_mode, partitions, intra_in_p, slices, slice_deblock;
+    gint intra_slices;
     gboolean single_stream;
     /* streaming state */
     mi355enc_t *enc;
@@ -69,7 +68,7 @@ typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 G_DEFINE_TYPE(GstMi355H264Enc, gst_mi355h264enc, GST_TYPE_VIDEO_ENCODER)
 
 enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME_RANGE, PROP_QP, PROP_PIPELINE_DEPTH,
-       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE, PROP_PINNED_INPUT, PROP_AQ_MODE, PROP_SINGLE_STREAM, PROP_SLICES, PROP_PARTITIONS, PROP_I8X8 };
+       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE, PROP_PINNED_INPUT, PROP_AQ_MODE, PROP_SINGLE_STREAM, PROP_INTRA_SLICES, PROP_PARTITIONS, PROP_I8X8, PROP_SLICES, PROP_SLICE_DEBLOCK };
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-raw, format=(string){ NV12, I420, YUY2, UYVY }, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
@@ -86,6 +85,31 @@ static GType speed_preset_type(void) {
                                    {0, NULL, NULL}};
     if (!t) t = g_enum_register_static("GstMi355H264EncPreset", v);
     return t;
+}
+
+/* What x264enc's speed-preset selects, restated in the tools this encoder has.  The reference's pipeline files pass speed-preset=2 (superfast) and =3
+ * (veryfast) (/root/reference/pipeline/generic/x264_superfast_camlink:5, x264_veryfast_camlink:5; generator bindings/typescript/src/pipeline/generic-builder.ts:43-55),
+ * so the one-token swap has to land on a toolset and not on "ignored".  x264's own table: ultrafast = no 8x8 transform, no adaptive quantisation, no partitions;
+ * superfast and slower keep the 8x8 transform with Intra_8x8 and aq-mode 1 (partitions i8x8,i4x4); veryfast and slower analyse inter partitions and
+ * Intra_4x4 in P pictures.  Here: 0 (none) / 1: Constrained Baseline, one QP per picture -- the library's defaults; 2 and 3: dct8x8 + i8x8 + aq-mode 1 (High
+ * profile); 4 (faster) and above: + Intra_4x4 in P pictures (inter partitions exist here for the 4x4 transform only: `partitions` stays an explicit switch).
+ * Slices follow the library's default (mi355enc_default_cfg) unless `slices` / `slice-deblock` are set. */
+typedef struct { gint dct8x8, i8x8, aq_mode, partitions, intra_in_p, slices, slice_deblock; } toolset_t;
+static void preset_tools(gint preset, toolset_t *t) {
+    t->dct8x8 = t->i8x8 = t->aq_mode = preset >= 2; t->partitions = 0; t->intra_in_p = preset >= 4 ? 2 : 1;
+    t->slices = -1; t->slice_deblock = -1; /* the library's defaults (mi355enc_default_cfg) */
+}
+/* the element's effective tools: explicit properties over the preset's (object lock held) */
+static void effective_tools(GstMi355H264Enc *s, toolset_t *t) {
+    preset_tools(s->speed_preset, t);
+    if (s->dct8x8 >= 0) t->dct8x8 = s->dct8x8;
+    if (s->i8x8 >= 0) t->i8x8 = s->i8x8;
+    if (s->aq_mode >= 0) t->aq_mode = s->aq_mode;
+    if (s->partitions >= 0) t->partitions = s->partitions;
+    if (s->intra_in_p >= 0) t->intra_in_p = s->intra_in_p;
+    if (s->slices >= 0) t->slices = s->slices;
+    if (s->slice_deblock >= 0) t->slice_deblock = s->slice_deblock;
+    if (!t->dct8x8) t->i8x8 = 0; /* Intra_8x8 needs the 8x8 transform (High profile) */
 }
 
 /* The unit of "bps" follows the reference's naming rule (encoder_control.c:29-32,53): an element named venc_kbps is sent
@@ -112,17 +136,19 @@ static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *
     case PROP_PIPELINE_DEPTH: s->pipeline_depth = g_value_get_int(val); break;
     case PROP_SPEED_PRESET: s->speed_preset = g_value_get_enum(val); break;
     case PROP_STATS: s->stats = g_value_get_boolean(val); break;
-    case PROP_DCT8X8: s->dct8x8 = g_value_get_boolean(val); break;
+    case PROP_DCT8X8: s->dct8x8 = g_value_get_boolean(val) ? 1 : 0; break;
     case PROP_THREADS: s->threads = g_value_get_int(val); break;
     case PROP_SCENECUT: s->scenecut = g_value_get_boolean(val); break;
     case PROP_EXCLUSIVE: s->exclusive_gpu = g_value_get_boolean(val); break;
     case PROP_VBV: s->vbv_ms = g_value_get_uint(val); break;
-    case PROP_INTRA_IN_P: s->intra_in_p = g_value_get_boolean(val); break;
+    case PROP_INTRA_IN_P: s->intra_in_p = g_value_get_int(val); break;
     case PROP_PINNED_INPUT: s->pinned_input = g_value_get_boolean(val); break;
     case PROP_AQ_MODE: s->aq_mode = g_value_get_int(val); break;
+    case PROP_INTRA_SLICES: s->intra_slices = g_value_get_int(val); break;
     case PROP_SLICES: s->slices = g_value_get_int(val); break;
-    case PROP_PARTITIONS: s->partitions = g_value_get_boolean(val); break;
-    case PROP_I8X8: s->i8x8 = g_value_get_boolean(val); break;
+    case PROP_SLICE_DEBLOCK: s->slice_deblock = g_value_get_boolean(val) ? 1 : 0; break;
+    case PROP_PARTITIONS: s->partitions = g_value_get_boolean(val) ? 1 : 0; break;
+    case PROP_I8X8: s->i8x8 = g_value_get_boolean(val) ? 1 : 0; break;
     case PROP_SINGLE_STREAM: s->single_stream = g_value_get_boolean(val); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
@@ -130,7 +156,9 @@ static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *
 }
 static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     GstMi355H264Enc *s = GST_MI355H264ENC(obj);
+    toolset_t t;
     GST_OBJECT_LOCK(s);
+    effective_tools(s, &t); /* a tool property reads as what the encoder will use: the explicit value, or the preset's */
     switch (id) {
     case PROP_BPS: g_value_set_uint(val, s->rate_is_bps ? s->rate_raw : target_bps(s) / bps_unit(s)); break;
     case PROP_BITRATE: g_value_set_uint(val, target_bps(s) / 1000u); break;
@@ -141,17 +169,19 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     case PROP_PIPELINE_DEPTH: g_value_set_int(val, s->pipeline_depth); break;
     case PROP_SPEED_PRESET: g_value_set_enum(val, s->speed_preset); break;
     case PROP_STATS: g_value_set_boolean(val, s->stats); break;
-    case PROP_DCT8X8: g_value_set_boolean(val, s->dct8x8); break;
+    case PROP_DCT8X8: g_value_set_boolean(val, t.dct8x8 != 0); break;
     case PROP_THREADS: g_value_set_int(val, s->threads); break;
     case PROP_SCENECUT: g_value_set_boolean(val, s->scenecut); break;
     case PROP_EXCLUSIVE: g_value_set_boolean(val, s->exclusive_gpu); break;
     case PROP_VBV: g_value_set_uint(val, s->vbv_ms); break;
-    case PROP_INTRA_IN_P: g_value_set_boolean(val, s->intra_in_p); break;
+    case PROP_INTRA_IN_P: g_value_set_int(val, t.intra_in_p); break;
     case PROP_PINNED_INPUT: g_value_set_boolean(val, s->pinned_input); break;
-    case PROP_AQ_MODE: g_value_set_int(val, s->aq_mode); break;
-    case PROP_SLICES: g_value_set_int(val, s->slices); break;
-    case PROP_PARTITIONS: g_value_set_boolean(val, s->partitions); break;
-    case PROP_I8X8: g_value_set_boolean(val, s->i8x8); break;
+    case PROP_AQ_MODE: g_value_set_int(val, t.aq_mode); break;
+    case PROP_INTRA_SLICES: g_value_set_int(val, s->intra_slices); break;
+    case PROP_SLICES: g_value_set_int(val, t.slices); break;
+    case PROP_SLICE_DEBLOCK: g_value_set_boolean(val, t.slice_deblock > 0); break;
+    case PROP_PARTITIONS: g_value_set_boolean(val, t.partitions != 0); break;
+    case PROP_I8X8: g_value_set_boolean(val, t.i8x8 != 0); break;
     case PROP_SINGLE_STREAM: g_value_set_boolean(val, s->single_stream); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
     }
@@ -200,7 +230,15 @@ static gboolean enc_set_format(GstVideoEncoder *ve, GstVideoCodecState *state) {
     GST_OBJECT_LOCK(s);
     cfg.gop = s->key_int_max ? (int)s->key_int_max : 250;
     cfg.me_range = s->me_range; cfg.bitrate_bps = target_bps(s); cfg.device_id = s->device_id; cfg.fixed_qp = s->qp;
-    cfg.pipeline_depth = s->pipeline_depth; cfg.transform8x8 = s->dct8x8 ? 1 : 0; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0; cfg.scenecut = s->scenecut ? 1 : 0; cfg.exclusive_device = s->exclusive_gpu ? 1 : 0; cfg.vbv_ms = (int)s->vbv_ms; cfg.intra_in_p = s->intra_in_p ? 1 : 0; cfg.aq_mode = s->aq_mode; cfg.single_stream = s->single_stream ? 1 : 0; cfg.intra_slices = s->slices; cfg.partitions = s->partitions ? 1 : 0; cfg.i8x8 = s->i8x8 ? 1 : 0;
+    cfg.pipeline_depth = s->pipeline_depth; cfg.cavlc_threads = s->threads > 0 ? s->threads : 0; cfg.scenecut = s->scenecut ? 1 : 0; cfg.exclusive_device = s->exclusive_gpu ? 1 : 0; cfg.vbv_ms = (int)s->vbv_ms;
+    cfg.single_stream = s->single_stream ? 1 : 0; cfg.intra_slices = s->intra_slices;
+    {
+        toolset_t t;
+        effective_tools(s, &t);
+        cfg.transform8x8 = t.dct8x8; cfg.i8x8 = t.i8x8; cfg.aq_mode = t.aq_mode; cfg.partitions = t.partitions; cfg.intra_in_p = t.intra_in_p;
+        if (t.slices >= 0) cfg.slices = t.slices;               /* (-1: mi355enc_default_cfg's) */
+        if (t.slice_deblock >= 0) cfg.slice_deblock = t.slice_deblock;
+    }
     GST_OBJECT_UNLOCK(s);
     int r = mi355enc_open(&cfg, &e);
     if (r != MI355ENC_OK) {
@@ -394,19 +432,25 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
     g_object_class_install_property(g, PROP_PIPELINE_DEPTH, g_param_spec_int("pipeline-depth", "Pipeline depth",
         "0: output each picture before taking the next; 1: overlap host entropy coding with the next picture (+1 frame latency); 2: three pictures in flight (+2 frames)", 0, 2, 0, F));
     g_object_class_install_property(g, PROP_SPEED_PRESET, g_param_spec_enum("speed-preset", "Speed preset",
-        "Accepted for x264enc pipeline compatibility; ignored", speed_preset_type(), 6, F));
+        "x264enc's presets mapped onto this encoder's tools: None / ultrafast = Constrained Baseline, one quantiser per picture; superfast = dct8x8 + i8x8 + aq-mode=1 "
+        "(High profile); faster and slower = + Intra_4x4 in P pictures.  A tool property set explicitly wins over the preset", speed_preset_type(), 0, F));
     g_object_class_install_property(g, PROP_THREADS, g_param_spec_int("threads", "Entropy-coding threads",
         "Host threads that code one slice row-parallel (bit-identical output); like x264enc's property of the same name, 0 = automatic (a quarter of the CPUs, at most 8), 1 = streaming thread only", 0, 64, 0, F));
     g_object_class_install_property(g, PROP_VBV, g_param_spec_uint("vbv-buf-capacity", "VBV buffer (ms)",
         "Rate control's buffer model in milliseconds of stream at the setpoint (x264enc's property of the same name and default)", 100, 10000, 600, F));
-    g_object_class_install_property(g, PROP_INTRA_IN_P, g_param_spec_boolean("intra-in-p", "Intra macroblocks in P pictures",
-        "Macroblocks of P pictures may be coded intra (uncovered regions, partial scene changes)", TRUE, F));
+    g_object_class_install_property(g, PROP_INTRA_IN_P, g_param_spec_int("intra-in-p", "Intra macroblocks in P pictures",
+        "Macroblocks of P pictures may be coded intra (uncovered regions, partial scene changes): 0 never, 1 Intra_16x16, 2 Intra_4x4 as well (speed-preset faster and slower)", 0, 2, 1, F));
     g_object_class_install_property(g, PROP_EXCLUSIVE, g_param_spec_boolean("exclusive-gpu", "This stream has the GPU to itself",
         "One stream per GPU: kernels may wait on the device for other kernels' progress (a P picture's motion-compensation stage beside the previous picture's deblocking, the deblocker beside the intra macroblocks: about 10 % more frames/s); leave false when other processes encode on the same GPU", FALSE, F));
     g_object_class_install_property(g, PROP_AQ_MODE, g_param_spec_int("aq-mode", "Adaptive quantisation",
         "0: one quantiser per picture; 1: a QP offset per macroblock from the variance of its source samples (x264enc's aq-mode 1 in spirit), coded with mb_qp_delta", 0, 1, 0, F));
-    g_object_class_install_property(g, PROP_SLICES, g_param_spec_int("intra-slices", "Slices per I picture",
-        "Slices per IDR picture, one NAL unit each (0: about 17 macroblock rows per slice, 4 at 1080p): the slices are reconstructed side by side; P pictures are one slice", 0, 64, 0, F));
+    g_object_class_install_property(g, PROP_INTRA_SLICES, g_param_spec_int("intra-slices", "Slices per I picture",
+        "Slices per IDR picture, one NAL unit each (0: about 17 macroblock rows per slice, 4 at 1080p): the slices are reconstructed side by side", 0, 64, 0, F));
+    g_object_class_install_property(g, PROP_SLICES, g_param_spec_int("slices", "Slices per P picture",
+        "Slices per P picture, one NAL unit each (-1: the encoder's default; 0 / 1: one slice): vector and intra prediction stop at a slice's first row; with slice-deblock the "
+        "slices are independent dependency chains for the deblocking launch, which sets the picture period (x264enc: what threads / sliced-threads do to a picture)", -1, 64, -1, F));
+    g_object_class_install_property(g, PROP_SLICE_DEBLOCK, g_param_spec_boolean("slice-deblock", "Slice-local deblocking",
+        "The deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2) in I and P pictures; slice heights become multiples of four macroblock rows", FALSE, F));
     g_object_class_install_property(g, PROP_PARTITIONS, g_param_spec_boolean("partitions", "Inter partitions",
         "P macroblocks may be split into 16x8, 8x16 or 8x8 partitions (x264enc: what speed-preset veryfast and slower analyse; superfast, the reference's preset, does not)", FALSE, F));
     g_object_class_install_property(g, PROP_I8X8, g_param_spec_boolean("i8x8", "Intra 8x8",
@@ -428,8 +472,8 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
     v->finish = enc_finish; v->flush = enc_flush; v->propose_allocation = enc_propose_allocation;
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
-    s->rate_raw = 2048; s->rate_is_bps = FALSE; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 6;
-    s->stats = FALSE; s->dct8x8 = FALSE; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = TRUE; s->pinned_input = TRUE; s->aq_mode = 0; s->slices = 0; s->partitions = FALSE; s->i8x8 = FALSE; s->single_stream = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
+    s->rate_raw = 2048; s->rate_is_bps = FALSE; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 0;
+    s->stats = FALSE; s->dct8x8 = -1; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = -1; s->pinned_input = TRUE; s->aq_mode = -1; s->slices = -1; s->slice_deblock = -1; s->intra_slices = 0; s->partitions = -1; s->i8x8 = -1; s->single_stream = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
 }
 
 GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */

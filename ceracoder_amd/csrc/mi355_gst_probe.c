@@ -18,7 +18,10 @@
  * element's and not the test source's (videotestsrc paints 1080p at 300-400 pictures/s).  `pinned`: the pictures lie in
  * mi355enc_host_alloc memory, as a capture source that adopted the element's buffer pool would deliver them.
  *
- * usage: mi355_gst_probe "PIPELINE DESCRIPTION" [--no-encoder | --appsrc N W H [pinned]]
+ * With --props the description is parsed, the coding-tool properties of the encoder element (named venc_bps or venc_kbps) are printed as they will be used --
+ * an explicit property, else what speed-preset selects -- and nothing runs (no device needed).
+ *
+ * usage: mi355_gst_probe "PIPELINE DESCRIPTION" [--no-encoder | --appsrc N W H [pinned] | --props]
  */
 #include <arpa/inet.h>
 #include <gst/app/gstappsink.h>
@@ -153,6 +156,18 @@ int main(int argc, char **argv) {
     if (!pipe) { fprintf(stderr, "parse error: %s\n", err ? err->message : "?"); return 2; }
     GstElement *enc = gst_bin_get_by_name(GST_BIN(pipe), "venc_bps"), *sink = gst_bin_get_by_name(GST_BIN(pipe), "appsink");
     int no_enc = 0, use_appsrc = 0, pinned = 0, ai = 0;
+    for (int i = 2; i < argc; i++)
+        if (!strcmp(argv[i], "--props")) {
+            if (!enc) enc = gst_bin_get_by_name(GST_BIN(pipe), "venc_kbps");
+            if (!enc) { fprintf(stderr, "--props needs an element named venc_bps or venc_kbps\n"); return 2; }
+            gint preset = 0, aq = 0, iip = 0, slices = 0, islices = 0;
+            gboolean dct = FALSE, i8 = FALSE, part = FALSE, sdb = FALSE;
+            g_object_get(enc, "speed-preset", &preset, "dct8x8", &dct, "i8x8", &i8, "aq-mode", &aq, "partitions", &part, "intra-in-p", &iip, "slices", &slices, "slice-deblock", &sdb,
+                         "intra-slices", &islices, NULL);
+            printf("{\"speed_preset\":%d,\"dct8x8\":%d,\"i8x8\":%d,\"aq_mode\":%d,\"partitions\":%d,\"intra_in_p\":%d,\"slices\":%d,\"slice_deblock\":%d,\"intra_slices\":%d}\n", preset, dct, i8, aq,
+                   part, iip, slices, sdb, islices);
+            return 0;
+        }
     for (int i = 2; i < argc; i++) {
         if (!strcmp(argv[i], "--no-encoder")) no_enc = 1;
         else if (!strcmp(argv[i], "--appsrc") && i + 3 < argc) { use_appsrc = 1; ai = i; i += 3; }

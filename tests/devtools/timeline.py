@@ -13,7 +13,9 @@ w, h = (int(os.environ.get("TL_W", "1920")), int(os.environ.get("TL_H", "1080"))
 clip = list(synth.s2_frames(w, h, 16))
 bufs = [torch.from_numpy(np.concatenate([y.reshape(-1), uv.reshape(-1)])).cuda() for y, uv in clip]
 torch.cuda.synchronize()
-e = E.Encoder(w, h, fps=60, gop=600, bitrate_bps=6_000_000 * (w * h) // (1920 * 1080), pipeline_depth=depth, exclusive=True)
+slices, sdb = int(os.environ.get("TL_SLICES", "-1")), int(os.environ.get("TL_SDB", "-1"))  # TL_SLICES / TL_SDB: cfg.slices / cfg.slice_deblock (-1: the library's default)
+e = E.Encoder(w, h, fps=60, gop=600, bitrate_bps=6_000_000 * (w * h) // (1920 * 1080), pipeline_depth=depth, exclusive=True, slices=None if slices < 0 else slices,
+              slice_deblock=None if sdb < 0 else bool(sdb), intra_in_p=int(os.environ.get("TL_IP", "1")))
 for i in range(n):
     k = i % 30
     p = bufs[k if k < 16 else 30 - k].data_ptr()

@@ -98,6 +98,33 @@ def test_bps_unit_is_resolved_when_used_not_when_written(tmp_path, line, bps, kb
     assert info == {"bps_from_pipeline_text": bps, "bitrate_kbps_from_pipeline_text": kbps}
 
 
+PROBE = os.path.join(ROOT, "ceracoder_amd", "mi355_gst_probe")
+
+
+@needs_gst
+@pytest.mark.skipif(not os.path.exists(PROBE), reason="probe not built")
+@pytest.mark.parametrize("line,want", [
+    ("mi355h264enc", dict(speed_preset=0, dct8x8=0, i8x8=0, aq_mode=0, intra_in_p=1, partitions=0)),
+    ("mi355h264enc speed-preset=1", dict(dct8x8=0, i8x8=0, aq_mode=0, intra_in_p=1)),
+    ("mi355h264enc speed-preset=2 key-int-max=60", dict(speed_preset=2, dct8x8=1, i8x8=1, aq_mode=1, intra_in_p=1, partitions=0)),  # the reference's line, /root/reference/pipeline/generic/x264_superfast_camlink:5
+    ("mi355h264enc speed-preset=3 key-int-max=60", dict(speed_preset=3, dct8x8=1, i8x8=1, aq_mode=1, intra_in_p=1)),                # .../x264_veryfast_camlink:5
+    ("mi355h264enc speed-preset=veryfast", dict(speed_preset=3, dct8x8=1)),
+    ("mi355h264enc speed-preset=medium", dict(speed_preset=6, dct8x8=1, i8x8=1, aq_mode=1, intra_in_p=2)),
+    ("mi355h264enc speed-preset=2 aq-mode=0 dct8x8=false", dict(dct8x8=0, i8x8=0, aq_mode=0)),            # explicit properties win, in either order
+    ("mi355h264enc dct8x8=true speed-preset=1", dict(dct8x8=1, i8x8=0, aq_mode=0)),
+    ("mi355h264enc speed-preset=2 i8x8=false partitions=true slices=4 slice-deblock=true intra-slices=2", dict(dct8x8=1, i8x8=0, partitions=1, slices=4, slice_deblock=1, intra_slices=2)),
+])
+def test_speed_preset_selects_a_toolset_and_explicit_properties_win(line, want):
+    """The reference's pipeline files pass x264enc's speed-preset (=2 superfast, =3 veryfast: /root/reference/pipeline/generic/x264_superfast_camlink:5,
+    x264_veryfast_camlink:5; /root/reference/bindings/typescript/src/pipeline/generic-builder.ts:43-55): the element maps it onto the tools it has instead of ignoring it.
+    Read back through GObject as the encoder will use them; no device involved."""
+    r = subprocess.run([PROBE, "videotestsrc ! %s name=venc_kbps ! appsink name=appsink" % line, "--props"], env=gst_env(), capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.splitlines()[-1])
+    for k, v in want.items():
+        assert got[k] == v, (k, got)
+
+
 def test_pipeline_files_name_the_element_like_the_reference():
     """The swap point is one token: same line shape as pipeline/generic/x264_superfast_*:5-6."""
     d = os.path.join(ROOT, "pipeline", "mi355x")

@@ -58,7 +58,8 @@ def test_slice_local_deblocking_matches_oracle(E, oracle, w, h, rows, qp, mode):
             d_y, d_uv = e.stage_deblock(oe.prefilter_y, oe.prefilter_uv, oe.mbinfo)
             assert np.array_equal(d_y, want_y), first_diff(d_y, want_y)
             assert np.array_equal(d_uv, want_uv), first_diff(d_uv, want_uv)
-            assert not np.array_equal(want_y, oe.recon_y)  # the seams are really left alone
+            if qp >= 34:
+                assert not np.array_equal(want_y, oe.recon_y)  # the seams are really left alone (at QP 20 the filter does nothing there anyway)
     finally:
         oracle.set_slice_rows(0)
         oracle.set_slice_deblock(0)
