@@ -215,8 +215,8 @@ def main():
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     ap.add_argument("--i8x8", type=int, default=0, help="1 (with --dct8x8 1): Intra_8x8 macroblocks in I pictures (picture QP <= 37)")
     ap.add_argument("--aq", type=int, default=0, help="1: adaptive quantisation (aq-mode 1)")
-    ap.add_argument("--slices", type=int, default=-1, help="slices per P picture (cfg.slices); -1: the encoder's default")
-    ap.add_argument("--slice-deblock", type=int, default=-1, help="1: the deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2); -1: the encoder's default")
+    ap.add_argument("--slices", type=int, default=-1, help="slices per P picture (cfg.slices: 0 automatic, 1 one slice); -1: the library's default (automatic: 4 at 1080p)")
+    ap.add_argument("--slice-deblock", type=int, default=-1, help="1: the deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2), 0: runs across them; -1: the library's default (1)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         # One process per stream, as the reference runs them (bindings/typescript/src/process.ts:129-170): start the ranks ourselves, each a fresh
@@ -330,6 +330,7 @@ def main():
         enc.reset_stats()
     dt, (qps, nbytes) = ranks.timed(lambda: run(args.steps, args.warmup), sync=torch.cuda.synchronize)
     st = e.stats()
+    p_rows, i_rows = e.p_slice_rows, e.slice_rows  # rows per slice of P / I pictures (0: one slice)
     for enc in encs:  # (closed before the untimed extras open encoders of their own: several encoders in one process run their stages in order)
         enc.close()
 
@@ -481,7 +482,10 @@ def main():
                  FUSED: "VALU issue: one wave per macroblock (skip probe; 6-tap planes, 8 SAD + 9 SATD candidates; transforms on all 64 lanes; decimation)",
                  "intra (analyse + x+y wavefront)": "dependency chain: Intra_4x4's left-neighbour dependency lets a macroblock start 4 block sub-steps (~0.8 us each) after the one before it, "
                                                     "so a row of mbw macroblocks is ~4*mbw sub-steps however many rows run side by side; + the lag between the rows of a slice (4 slices at 1080p)",
-                 "deblock (prep + band kernel)": "dependency chain of the normative filter order: mbw+mbh dependent steps of ~0.35 us + ~2 us per band boundary inside one persistent launch (three waves per macroblock row: filter / mover / storer)"}
+                 "deblock (prep + band kernel)": "dependency chain of the normative filter order inside one persistent launch (three waves per macroblock row: filter / mover / storer): per slice "
+                                                 "%d + %d - 1 dependent steps of ~0.4-0.5 us + ~4 us per band hand-over, the slices side by side%s" % (
+                                                     coded(width) // 16, p_rows if (p_rows and args.slice_deblock != 0) else coded(height) // 16,
+                                                     " (slice-local deblocking: every slice is a wavefront of its own)" if (p_rows and args.slice_deblock != 0) else "")}
         pmc_name = {"me_kernel": "me_kernel", SEL: "me_select_kernel", FUSED: "pmb_kernel", "intra (analyse + x+y wavefront)": "intra_rows_kernel",
                     "deblock (prep + band kernel)": "deblock_rows3_kernel"}
         kernels = []
@@ -493,24 +497,44 @@ def main():
             weight["deblock (prep + band kernel)"] = n_p
         other_p = (st.ms_analyse_p + st.ms_intra_p) / max(1, st.n_inter)  # gated intra analysis + intra macroblocks of P pictures
         est_total = (sum(weight[k] * (ms / n) for k, (ms, n) in per.items() if n) + (n_idr * db_i_avg if n_p else 0.0) + n_p * other_p) or 1e-9
+        period_us = dt / (S * args.steps) * 1e6
         for name, (ms, n) in per.items():
             if not n:
                 continue
             us = ms / n * 1e3
-            ach = ALG[name] * P / (us * 1e-6) / 1e9
             pk = (prof or {}).get(pmc_name.get(name, ""), {})
-            kernels.append({"kernel": name, "launches_timed": int(n), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": int(ALG[name] * P),
-                            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                            "design_bytes_per_launch": int(DESIGN.get(name, ALG[name]) * P),
-                            "traffic": pk.get("hbm_bytes_per_launch_corrected"), "kernel_trace_avg_us": pk.get("kernel_trace_avg_us"),
-                            "time_share": round(weight[name] * (ms / n) / est_total, 4), "bounded_by": bound[name]})
+            alg_bytes, alg_note = ALG[name] * P, None
+            if name == SEL:
+                # The selection copies a macroblock whose four predictor values did not change (24 bytes instead of its 2520-byte surface), so what a launch has to
+                # read depends on the content: the upper bound (every surface, 9.97 P) is what iteration 1 reads; the mean over the three iterations is taken from
+                # the committed counter pass of this workload (profiles/*pmc_hbm_traffic*), never from bytes that were not moved.
+                if pk.get("hbm_bytes_per_launch_corrected"):
+                    alg_bytes, alg_note = float(pk["hbm_bytes_per_launch_corrected"]), "data-dependent: bytes = mean memory-side traffic per launch of the committed PMC pass (unchanged macroblocks are copied, their surfaces not read); upper bound %d B (every surface)" % int(ALG[name] * P)
+                else:
+                    alg_note = "upper bound (every surface read); no PMC pass of this workload under profiles/ to take the mean from"
+            ach = alg_bytes / (us * 1e-6) / 1e9
+            tr_us = pk.get("kernel_trace_avg_us")
+            k = {"kernel": name, "launches_timed": int(n), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": int(alg_bytes),
+                 "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                 "design_bytes_per_launch": int(DESIGN.get(name, ALG[name]) * P),
+                 "traffic": pk.get("hbm_bytes_per_launch_corrected"), "kernel_trace_avg_us": tr_us,
+                 # the same fraction from the committed kernel trace's mean launch time (profiles/*kernel_stats*: what a reader can recompute without this run)
+                 "frac_from_kernel_trace": round(alg_bytes / (tr_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if tr_us else None,
+                 "time_share": round(weight[name] * (ms / n) / est_total, 4), "bounded_by": bound[name]}
+            if alg_note:
+                k["algorithmic_bytes_note"] = alg_note
+            if us > period_us and weight[name] and name != "intra (analyse + x+y wavefront)":
+                k["avg_launch_note"] = ("longer than the picture period (%.1f us): the event pair brackets the launch on a SAMPLED picture (every %d-th), whose event records and device-side "
+                                        "waits lengthen it; the kernel trace's mean is the unperturbed figure" % (period_us, args.sample))
+            kernels.append(k)
         kernels.sort(key=lambda k: -k["time_share"])
         if not kernels:
             raise SystemExit("bench.py: no stage timers were sampled (--sample 0?): the roofline block needs them")
         dom = kernels[0]
         roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
                 "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                "launches": dom["launches_timed"], "kernel_trace_avg_us": dom["kernel_trace_avg_us"], "time_share": dom["time_share"],
+                "launches": dom["launches_timed"], "kernel_trace_avg_us": dom["kernel_trace_avg_us"], "frac_from_kernel_trace": dom["frac_from_kernel_trace"],
+                "avg_launch_note": dom.get("avg_launch_note"), "time_share": dom["time_share"],
                 "note": "dominant kernel by GPU time; " + dom["bounded_by"] + ". Every kernel of the path is listed in roofline_kernels "
                         "(the motion search north_star names is 'me_kernel'; the HBM-shaped one is the vector selection)."}
         # What the device sustains over whole GOPs, whatever share of IDR pictures the timed region happened to hold: an IDR picture's stages run
@@ -533,7 +557,10 @@ def main():
             "dtype": "u8", "data": "synthetic (S2: panning texture + 12 moving rectangles, seed 0x5EED), resident in HBM",
             "idr_in_timed_region": n_idr, "skip_pictures_in_timed_region": int(st.skip_pictures),
             "device_wait_recoveries": int(st.recoveries), "safe_level": int(st.safe_level),  # must be 0 / 0: a recovery means a bounded device-side wait ran out
-            "value_note": "pictures that went through the device per second: rate control's all-skip pictures (one P_Skip run written by the host, no kernel) are not counted",
+            "value_kind": ("P pictures only: the timed region holds no IDR picture -- gop_weighted_frames_per_s is the rate over whole GOPs" if (n_idr == 0 and gop > 1) else
+                           "whole GOPs" if gop > 1 and args.steps % gop == 0 else "all-intra" if gop == 1 else "%d IDR pictures among %d" % (n_idr, args.steps)),
+            "value_note": ("over whole GOPs the device sustains gop_weighted_frames_per_s (below); " if (n_idr == 0 and gop > 1) else "") +
+                          "value = pictures that went through the device per second: rate control's all-skip pictures (one P_Skip run written by the host, no kernel) are not counted",
             "frames_per_s_including_skip_pictures": round(world * S * args.steps / dt, 2),
             "gop_weighted_frames_per_s": round(gop_fps, 1) if gop_fps else None,
             "gop_weighted_note": "gop / ((gop-1) * t_P + t_IDR): t_IDR = an IDR picture's stage timers (its stages run in order), t_P = (wall time - IDR pictures * t_IDR) / "
@@ -545,7 +572,9 @@ def main():
                            script_name, min(b for _, b in script) // 1000, max(b for _, b in script) // 1000, script_name),
                        "me": "full search +-16 integer-pel SAD (surfaces kept) + %d median-regularised selection iterations + half-sample SAD / quarter-sample SATD refinement" % 3, "streams_per_gpu": S, "hip_streams_per_encoder": 1 if S > 2 else 4, "parallelism": "%d independent streams" % (world * S),
                        "pipeline_depth": args.depth, "exclusive_device": bool(S == 1 and not shared_gpu), "devices_on_box": n_dev, "ranks_share_devices": bool(world > n_dev),
-                       "rank0_cpus": rank_cpus if world > 1 else None, "rank0_numa_node": int(os.environ.get("MI355_BENCH_NUMA_NODE", "-1")), "dct8x8": bool(args.dct8x8), "i8x8": bool(args.i8x8), "cavlc_threads": int(st.cavlc_threads)},
+                       "rank0_cpus": rank_cpus if world > 1 else None, "rank0_numa_node": int(os.environ.get("MI355_BENCH_NUMA_NODE", "-1")), "dct8x8": bool(args.dct8x8), "i8x8": bool(args.i8x8), "aq_mode": int(args.aq), "cavlc_threads": int(st.cavlc_threads),
+                       "p_slice_rows": int(p_rows), "i_slice_rows": int(i_rows), "slices_per_p_picture": (coded(height) // 16 + p_rows - 1) // p_rows if p_rows else 1,
+                       "slice_local_deblocking": (args.slice_deblock != 0)},
             "roofline": roof,
             "roofline_kernels": kernels,
             "stage_timers": ("HIP events on every %d-th P picture, on the streams the kernels are launched on" % args.sample) + (

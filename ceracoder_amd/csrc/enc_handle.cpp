@@ -79,7 +79,7 @@ void mi355enc_default_cfg(mi355enc_cfg_t *c, int width, int height, int fps_num,
     memset(c, 0, sizeof *c);
     c->width = width; c->height = height; c->fps_num = fps_num; c->fps_den = fps_den > 0 ? fps_den : 1;
     c->gop = 60; c->me_range = 16; c->bitrate_bps = 2048000; c->device_id = 0; c->fixed_qp = -1;
-    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0; c->aq_mode = 0; c->single_stream = 0; c->intra_slices = 0; c->partitions = 0; c->profile_overlap = 0; c->i8x8 = 0; c->slices = 0; c->slice_deblock = 0;
+    c->qp_min = 10; c->qp_max = 51; c->pipeline_depth = 0; c->profile_events = 0; c->use_graphs = 1; c->keep_prefilter = 0; c->deblock_mode = 0; c->subpel = 1; c->i4x4 = 1; c->transform8x8 = 0; c->intra_in_p = 1; c->vbv_ms = 600; c->cavlc_threads = 0; c->intra_mode = 0; c->scenecut = 1; c->exclusive_device = 0; c->aq_mode = 0; c->single_stream = 0; c->intra_slices = 0; c->partitions = 0; c->profile_overlap = 0; c->i8x8 = 0; c->slices = 0; c->slice_deblock = 1;
 }
 
 int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
@@ -108,14 +108,15 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     if (h->cfg.qp_max > 51) h->cfg.qp_max = 51;
     if (h->cfg.qp_min < 0) h->cfg.qp_min = 0;
     h->mbw = (cfg->width + 15) / 16; h->mbh = (cfg->height + 15) / 16;
-    {   // slices (oracle: orc_auto_intra_slices, orc_slice_rows_for).  I pictures: about 17 rows each by default, at most 8; P pictures: cfg.slices (0 / 1: one slice).
+    {   // slices (oracle: orc_auto_intra_slices, orc_slice_rows_for).  I pictures: about 17 rows each by default, at most 8; P pictures: cfg.slices (0: the same default; 1: one slice).
         // With slice-local deblocking every slice is a whole number of the deblocker's bands.
         const bool local = h->cfg.slice_deblock != 0;
         auto rows_for = [&](int n) { if (n <= 1) return 0; int rows = (h->mbh + n - 1) / n; if (local) rows = (rows + MI355_BAND_ROWS - 1) / MI355_BAND_ROWS * MI355_BAND_ROWS; return rows >= h->mbh ? 0 : rows; };
         static_assert(MI355_BAND_ROWS == 4, "the oracle rounds slice heights to multiples of four rows (orc_slice_rows_for)");
-        const int ns = h->cfg.intra_slices > 0 ? h->cfg.intra_slices : h->mbh / 17 < 1 ? 1 : h->mbh / 17 > 8 ? 8 : h->mbh / 17;
+        const int nauto = h->mbh / 17 < 1 ? 1 : h->mbh / 17 > 8 ? 8 : h->mbh / 17;
+        const int ns = h->cfg.intra_slices > 0 ? h->cfg.intra_slices : nauto, np = h->cfg.slices > 0 ? h->cfg.slices : nauto;
         h->islice_rows = rows_for(ns > h->mbh ? h->mbh : ns);
-        h->pslice_rows = rows_for(h->cfg.slices > h->mbh ? h->mbh : h->cfg.slices);
+        h->pslice_rows = rows_for(np > h->mbh ? h->mbh : np);
         h->slice_dbf = local ? 2 : 0;
         h->stage_slice_rows = 0; h->stage_slice_dbf = 0;
     }

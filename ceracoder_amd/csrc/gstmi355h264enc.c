@@ -51,7 +51,7 @@ typedef struct {
     guint vbv_ms;
     gboolean pinned_input;
     /* coding tools: -1 = not set on the element, i.e. what speed-preset selects (preset_tools); an explicit write wins */
-    gint dct8x8, i8x8, aq_mode, partitions, intra_in_p, slices, slice_deblock;
+    gint dct8x8, i8x8, aq_mode, intra_in_p, slices, slice_deblock;
     gint intra_slices;
     gboolean single_stream;
     /* streaming state */
@@ -60,6 +60,8 @@ typedef struct {
     gsize max_au;
     guint8 *au_buf;     /* access units are coded here (worst-case size, allocated once per format) and copied into right-sized buffers */
     GstClockTime last_pts;
+    /* where the streaming thread's time goes, per stage (microseconds, summed; printed with stats=true): what separates the element's rate from the C ABI's */
+    gint64 us_map, us_submit, us_collect, us_output, us_push, us_frames;
 } GstMi355H264Enc;
 typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 
@@ -68,7 +70,7 @@ typedef struct { GstVideoEncoderClass parent_class; } GstMi355H264EncClass;
 G_DEFINE_TYPE(GstMi355H264Enc, gst_mi355h264enc, GST_TYPE_VIDEO_ENCODER)
 
 enum { PROP_0, PROP_BPS, PROP_BITRATE, PROP_KEY_INT_MAX, PROP_DEVICE_ID, PROP_ME_RANGE, PROP_QP, PROP_PIPELINE_DEPTH,
-       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE, PROP_PINNED_INPUT, PROP_AQ_MODE, PROP_SINGLE_STREAM, PROP_INTRA_SLICES, PROP_PARTITIONS, PROP_I8X8, PROP_SLICES, PROP_SLICE_DEBLOCK };
+       PROP_SPEED_PRESET, PROP_STATS, PROP_DCT8X8, PROP_THREADS, PROP_SCENECUT, PROP_VBV, PROP_INTRA_IN_P, PROP_EXCLUSIVE, PROP_PINNED_INPUT, PROP_AQ_MODE, PROP_SINGLE_STREAM, PROP_INTRA_SLICES, PROP_I8X8, PROP_SLICES, PROP_SLICE_DEBLOCK };
 
 static GstStaticPadTemplate sink_tmpl = GST_STATIC_PAD_TEMPLATE("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS("video/x-raw, format=(string){ NV12, I420, YUY2, UYVY }, width=(int)[16,8192], height=(int)[16,8192], framerate=(fraction)[0/1,MAX]"));
@@ -91,12 +93,13 @@ static GType speed_preset_type(void) {
  * (veryfast) (/root/reference/pipeline/generic/x264_superfast_camlink:5, x264_veryfast_camlink:5; generator bindings/typescript/src/pipeline/generic-builder.ts:43-55),
  * so the one-token swap has to land on a toolset and not on "ignored".  x264's own table: ultrafast = no 8x8 transform, no adaptive quantisation, no partitions;
  * superfast and slower keep the 8x8 transform with Intra_8x8 and aq-mode 1 (partitions i8x8,i4x4); veryfast and slower analyse inter partitions and
- * Intra_4x4 in P pictures.  Here: 0 (none) / 1: Constrained Baseline, one QP per picture -- the library's defaults; 2 and 3: dct8x8 + i8x8 + aq-mode 1 (High
- * profile); 4 (faster) and above: + Intra_4x4 in P pictures (inter partitions exist here for the 4x4 transform only: `partitions` stays an explicit switch).
- * Slices follow the library's default (mi355enc_default_cfg) unless `slices` / `slice-deblock` are set. */
+ * Intra_4x4 in P pictures.  Here: 0 (none) / 1: Constrained Baseline, one QP per picture -- the library's defaults; 2 (superfast) and above: dct8x8 + i8x8 +
+ * aq-mode 1 (High profile).  What the slower presets would add -- Intra_4x4 in P pictures (intra-in-p=2), inter partitions (4x4 transform only) -- measured
+ * rate-distortion neutral here and, with adaptive quantisation, Intra_4x4 in P puts a picture's stages in stream order: they stay explicit
+ * switches.  Slices follow the library's default (mi355enc_default_cfg) unless `slices` / `slice-deblock` are set. */
 typedef struct { gint dct8x8, i8x8, aq_mode, partitions, intra_in_p, slices, slice_deblock; } toolset_t;
 static void preset_tools(gint preset, toolset_t *t) {
-    t->dct8x8 = t->i8x8 = t->aq_mode = preset >= 2; t->partitions = 0; t->intra_in_p = preset >= 4 ? 2 : 1;
+    t->dct8x8 = t->i8x8 = t->aq_mode = preset >= 2; t->partitions = 0; /* (inter partitions: no property -- the search the fused stage can afford is rate-distortion neutral; cfg.partitions remains in the C ABI) */ t->intra_in_p = 1;
     t->slices = -1; t->slice_deblock = -1; /* the library's defaults (mi355enc_default_cfg) */
 }
 /* the element's effective tools: explicit properties over the preset's (object lock held) */
@@ -105,7 +108,6 @@ static void effective_tools(GstMi355H264Enc *s, toolset_t *t) {
     if (s->dct8x8 >= 0) t->dct8x8 = s->dct8x8;
     if (s->i8x8 >= 0) t->i8x8 = s->i8x8;
     if (s->aq_mode >= 0) t->aq_mode = s->aq_mode;
-    if (s->partitions >= 0) t->partitions = s->partitions;
     if (s->intra_in_p >= 0) t->intra_in_p = s->intra_in_p;
     if (s->slices >= 0) t->slices = s->slices;
     if (s->slice_deblock >= 0) t->slice_deblock = s->slice_deblock;
@@ -147,7 +149,6 @@ static void set_property(GObject *obj, guint id, const GValue *val, GParamSpec *
     case PROP_INTRA_SLICES: s->intra_slices = g_value_get_int(val); break;
     case PROP_SLICES: s->slices = g_value_get_int(val); break;
     case PROP_SLICE_DEBLOCK: s->slice_deblock = g_value_get_boolean(val) ? 1 : 0; break;
-    case PROP_PARTITIONS: s->partitions = g_value_get_boolean(val) ? 1 : 0; break;
     case PROP_I8X8: s->i8x8 = g_value_get_boolean(val) ? 1 : 0; break;
     case PROP_SINGLE_STREAM: s->single_stream = g_value_get_boolean(val); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
@@ -178,9 +179,8 @@ static void get_property(GObject *obj, guint id, GValue *val, GParamSpec *ps) {
     case PROP_PINNED_INPUT: g_value_set_boolean(val, s->pinned_input); break;
     case PROP_AQ_MODE: g_value_set_int(val, t.aq_mode); break;
     case PROP_INTRA_SLICES: g_value_set_int(val, s->intra_slices); break;
-    case PROP_SLICES: g_value_set_int(val, t.slices); break;
-    case PROP_SLICE_DEBLOCK: g_value_set_boolean(val, t.slice_deblock > 0); break;
-    case PROP_PARTITIONS: g_value_set_boolean(val, t.partitions != 0); break;
+    case PROP_SLICES: g_value_set_int(val, t.slices < 0 ? 0 : t.slices); break;
+    case PROP_SLICE_DEBLOCK: g_value_set_boolean(val, t.slice_deblock != 0); break; /* (unset: the library's default, on) */
     case PROP_I8X8: g_value_set_boolean(val, t.i8x8 != 0); break;
     case PROP_SINGLE_STREAM: g_value_set_boolean(val, s->single_stream); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID(obj, id, ps); break;
@@ -198,8 +198,11 @@ static void close_encoder(GstMi355H264Enc *s) {
             mi355enc_stats_t st;
             if (mi355enc_get_stats(e, &st) == 0)
                 g_printerr("{\"element\":\"mi355h264enc\",\"frames\":%" G_GUINT64_FORMAT ",\"idr\":%" G_GUINT64_FORMAT ",\"bytes\":%" G_GUINT64_FORMAT
-                           ",\"ms_entropy\":%.3f,\"ms_wait\":%.3f,\"last_qp\":%u,\"open_ms\":%.1f,\"target_bps\":%u}\n", st.frames, st.idr_frames, st.bytes,
-                           st.ms_entropy, st.ms_wait, st.last_qp, st.ms_open, st.target_bps);
+                           ",\"ms_entropy\":%.3f,\"ms_wait\":%.3f,\"last_qp\":%u,\"open_ms\":%.1f,\"target_bps\":%u"
+                           ",\"streaming_thread_us_per_frame\":{\"map_input\":%.1f,\"submit\":%.1f,\"collect\":%.1f,\"output_buffer\":%.1f,\"push_downstream\":%.1f}}\n", st.frames, st.idr_frames, st.bytes,
+                           st.ms_entropy, st.ms_wait, st.last_qp, st.ms_open, st.target_bps, (double)s->us_map / (double)(s->us_frames ? s->us_frames : 1),
+                           (double)s->us_submit / (double)(s->us_frames ? s->us_frames : 1), (double)s->us_collect / (double)(s->us_frames ? s->us_frames : 1),
+                           (double)s->us_output / (double)(s->us_frames ? s->us_frames : 1), (double)s->us_push / (double)(s->us_frames ? s->us_frames : 1));
         }
         mi355enc_close(e);
     }
@@ -281,7 +284,10 @@ static GstFlowReturn collect_into(GstMi355H264Enc *s, GstVideoCodecFrame *frame)
     GstVideoEncoder *ve = GST_VIDEO_ENCODER(s);
     size_t len = 0;
     int key = 0, qp = 0;
+    const gint64 t0 = g_get_monotonic_time();
     int r = mi355enc_collect(s->enc, s->au_buf, s->max_au, &len, &key, NULL, &qp);
+    const gint64 t1 = g_get_monotonic_time();
+    s->us_collect += t1 - t0;
     if (r != MI355ENC_OK) {
         GST_ELEMENT_ERROR(s, STREAM, ENCODE, ("mi355h264enc: encode failed: %s", mi355enc_strerror(r)), ("mi355enc_collect returned %d", r));
         gst_video_encoder_finish_frame(ve, frame);
@@ -299,7 +305,11 @@ static GstFlowReturn collect_into(GstMi355H264Enc *s, GstVideoCodecFrame *frame)
     if (GST_CLOCK_TIME_IS_VALID(frame->pts)) s->last_pts = frame->pts;
     frame->dts = frame->pts;
     GST_LOG_OBJECT(s, "access unit %" G_GSIZE_FORMAT " bytes, %s, qp %d, pts %" GST_TIME_FORMAT, len, key ? "IDR" : "P", qp, GST_TIME_ARGS(frame->pts));
-    return gst_video_encoder_finish_frame(ve, frame);
+    const gint64 t2 = g_get_monotonic_time();
+    s->us_output += t2 - t1;
+    fr = gst_video_encoder_finish_frame(ve, frame); /* the base class's bookkeeping and the push into whatever follows (a queue in the reference's pipelines) */
+    s->us_push += g_get_monotonic_time() - t2; s->us_frames++;
+    return fr;
 }
 
 static GstFlowReturn enc_handle_frame(GstVideoEncoder *ve, GstVideoCodecFrame *frame) {
@@ -312,6 +322,7 @@ static GstFlowReturn enc_handle_frame(GstVideoEncoder *ve, GstVideoCodecFrame *f
         GST_DEBUG_OBJECT(s, "input picture flagged DROPPABLE (pts %" GST_TIME_FORMAT "): not coded", GST_TIME_ARGS(frame->pts));
         return gst_video_encoder_finish_frame(ve, frame);
     }
+    const gint64 t0 = g_get_monotonic_time();
     if (!gst_video_frame_map(&vf, &s->input_state->info, frame->input_buffer, GST_MAP_READ)) {
         gst_video_encoder_finish_frame(ve, frame);
         return GST_FLOW_ERROR;
@@ -331,7 +342,9 @@ static GstFlowReturn enc_handle_frame(GstVideoEncoder *ve, GstVideoCodecFrame *f
         planes[i] = GST_VIDEO_FRAME_PLANE_DATA(&vf, i);
         strides[i] = GST_VIDEO_FRAME_PLANE_STRIDE(&vf, i);
     }
+    const gint64 t1 = g_get_monotonic_time();
     int r = mi355enc_submit_fmt(s->enc, fmt, planes, strides, (int64_t)frame->pts, GST_VIDEO_CODEC_FRAME_IS_FORCE_KEYFRAME(frame) ? 1 : 0);
+    s->us_map += t1 - t0; s->us_submit += g_get_monotonic_time() - t1;
     gst_video_frame_unmap(&vf); /* pageable memory: submit() has copied the picture out; pinned memory of our pool: the transfer is in flight and the
                                    codec frame keeps the buffer until the picture is collected */
     if (r != MI355ENC_OK) {
@@ -433,13 +446,13 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
         "0: output each picture before taking the next; 1: overlap host entropy coding with the next picture (+1 frame latency); 2: three pictures in flight (+2 frames)", 0, 2, 0, F));
     g_object_class_install_property(g, PROP_SPEED_PRESET, g_param_spec_enum("speed-preset", "Speed preset",
         "x264enc's presets mapped onto this encoder's tools: None / ultrafast = Constrained Baseline, one quantiser per picture; superfast = dct8x8 + i8x8 + aq-mode=1 "
-        "(High profile); faster and slower = + Intra_4x4 in P pictures.  A tool property set explicitly wins over the preset", speed_preset_type(), 0, F));
+        "(High profile), and so do the slower ones.  A tool property set explicitly wins over the preset", speed_preset_type(), 0, F));
     g_object_class_install_property(g, PROP_THREADS, g_param_spec_int("threads", "Entropy-coding threads",
         "Host threads that code one slice row-parallel (bit-identical output); like x264enc's property of the same name, 0 = automatic (a quarter of the CPUs, at most 8), 1 = streaming thread only", 0, 64, 0, F));
     g_object_class_install_property(g, PROP_VBV, g_param_spec_uint("vbv-buf-capacity", "VBV buffer (ms)",
         "Rate control's buffer model in milliseconds of stream at the setpoint (x264enc's property of the same name and default)", 100, 10000, 600, F));
     g_object_class_install_property(g, PROP_INTRA_IN_P, g_param_spec_int("intra-in-p", "Intra macroblocks in P pictures",
-        "Macroblocks of P pictures may be coded intra (uncovered regions, partial scene changes): 0 never, 1 Intra_16x16, 2 Intra_4x4 as well (speed-preset faster and slower)", 0, 2, 1, F));
+        "Macroblocks of P pictures may be coded intra (uncovered regions, partial scene changes): 0 never, 1 Intra_16x16, 2 Intra_4x4 as well", 0, 2, 1, F));
     g_object_class_install_property(g, PROP_EXCLUSIVE, g_param_spec_boolean("exclusive-gpu", "This stream has the GPU to itself",
         "One stream per GPU: kernels may wait on the device for other kernels' progress (a P picture's motion-compensation stage beside the previous picture's deblocking, the deblocker beside the intra macroblocks: about 10 % more frames/s); leave false when other processes encode on the same GPU", FALSE, F));
     g_object_class_install_property(g, PROP_AQ_MODE, g_param_spec_int("aq-mode", "Adaptive quantisation",
@@ -447,12 +460,11 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
     g_object_class_install_property(g, PROP_INTRA_SLICES, g_param_spec_int("intra-slices", "Slices per I picture",
         "Slices per IDR picture, one NAL unit each (0: about 17 macroblock rows per slice, 4 at 1080p): the slices are reconstructed side by side", 0, 64, 0, F));
     g_object_class_install_property(g, PROP_SLICES, g_param_spec_int("slices", "Slices per P picture",
-        "Slices per P picture, one NAL unit each (-1: the encoder's default; 0 / 1: one slice): vector and intra prediction stop at a slice's first row; with slice-deblock the "
-        "slices are independent dependency chains for the deblocking launch, which sets the picture period (x264enc: what threads / sliced-threads do to a picture)", -1, 64, -1, F));
+        "Slices per P picture, one NAL unit each (0: automatic, like intra-slices -- about 17 macroblock rows per slice, 4 at 1080p; 1: one slice): vector and intra prediction stop at a "
+        "slice's first row; with slice-deblock the slices are independent dependency chains for the deblocking launch, which sets the picture period (x264enc: what threads / "
+        "sliced-threads do to a picture).  Costs 2-4 % bitrate on panning content", 0, 64, 0, F));
     g_object_class_install_property(g, PROP_SLICE_DEBLOCK, g_param_spec_boolean("slice-deblock", "Slice-local deblocking",
-        "The deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2) in I and P pictures; slice heights become multiples of four macroblock rows", FALSE, F));
-    g_object_class_install_property(g, PROP_PARTITIONS, g_param_spec_boolean("partitions", "Inter partitions",
-        "P macroblocks may be split into 16x8, 8x16 or 8x8 partitions (x264enc: what speed-preset veryfast and slower analyse; superfast, the reference's preset, does not)", FALSE, F));
+        "The deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2) in I and P pictures; slice heights become multiples of four macroblock rows", TRUE, F));
     g_object_class_install_property(g, PROP_I8X8, g_param_spec_boolean("i8x8", "Intra 8x8",
         "With dct8x8: the macroblocks of I pictures may be Intra_8x8 (x264enc: part of dct8x8; here a switch of its own: IDR pictures 1.4 - 3.9 % smaller, a key-int 60 stream 1 - 3 % slower)", FALSE, F));
     g_object_class_install_property(g, PROP_SINGLE_STREAM, g_param_spec_boolean("single-stream", "One HIP stream",
@@ -473,7 +485,8 @@ static void gst_mi355h264enc_class_init(GstMi355H264EncClass *k) {
 }
 static void gst_mi355h264enc_init(GstMi355H264Enc *s) {
     s->rate_raw = 2048; s->rate_is_bps = FALSE; s->key_int_max = 60; s->device_id = 0; s->me_range = 16; s->qp = -1; s->pipeline_depth = 0; s->speed_preset = 0;
-    s->stats = FALSE; s->dct8x8 = -1; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = -1; s->pinned_input = TRUE; s->aq_mode = -1; s->slices = -1; s->slice_deblock = -1; s->intra_slices = 0; s->partitions = -1; s->i8x8 = -1; s->single_stream = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
+    s->stats = FALSE; s->dct8x8 = -1; s->threads = 0; s->scenecut = TRUE; s->exclusive_gpu = FALSE; s->vbv_ms = 600; s->intra_in_p = -1; s->pinned_input = TRUE; s->aq_mode = -1; s->slices = -1; s->slice_deblock = -1; s->intra_slices = 0; s->i8x8 = -1; s->single_stream = FALSE; s->enc = NULL; s->input_state = NULL; s->max_au = 0; s->au_buf = NULL; s->last_pts = GST_CLOCK_TIME_NONE;
+    s->us_map = s->us_submit = s->us_collect = s->us_output = s->us_push = s->us_frames = 0;
 }
 
 GType gst_mi355tsmux_get_type(void); /* gstmi355tsmux.c */

@@ -48,6 +48,7 @@ static float l_enc[MAXN], l_send[MAXN];
 static gint64 t_arr[MAXN]; /* arrival of every sample at the sink */
 static unsigned n_lat;
 static guint64 n_samples, n_bytes, n_dgrams;
+static gint64 us_in_callback; /* time the sink's streaming thread spends in on_sample (pull, map, 1316-byte regrouping, sendto) */
 static volatile gint n_out; /* samples that reached the sink (read by the feeder) */
 static int tx = -1, rx = -1, exit_code;
 static struct sockaddr_in dst;
@@ -77,6 +78,7 @@ static void send_regrouped(const unsigned char *d, size_t n) {
 }
 static GstFlowReturn on_sample(GstAppSink *sink, gpointer u) {
     (void)u;
+    const gint64 tc = g_get_monotonic_time();
     GstSample *s = gst_app_sink_pull_sample(sink);
     if (!s) return GST_FLOW_OK;
     const gint64 t1 = g_get_monotonic_time();
@@ -98,6 +100,7 @@ static GstFlowReturn on_sample(GstAppSink *sink, gpointer u) {
         gst_buffer_unmap(b, &m);
     }
     gst_sample_unref(s);
+    us_in_callback += g_get_monotonic_time() - tc;
     return GST_FLOW_OK;
 }
 static gboolean on_bus(GstBus *bus, GstMessage *msg, gpointer u) {
@@ -111,12 +114,13 @@ static gboolean on_bus(GstBus *bus, GstMessage *msg, gpointer u) {
     } else if (GST_MESSAGE_TYPE(msg) == GST_MESSAGE_EOS) g_main_loop_quit(loop);
     return TRUE;
 }
-/* ---- --appsrc: eight pictures of a texture panning by (+3, -2) per picture, pushed round-robin */
+/* ---- --appsrc: eight pictures of a texture panning by (+3, -2) per picture, pushed forwards and backwards */
 static struct { GstElement *src; int n, w, h, fps; guint8 *mem; gsize fsz; } feed;
 static gpointer feeder(gpointer u) {
     (void)u;
     for (int i = 0; i < feed.n; i++) {
-        guint8 *d = feed.mem + (gsize)(i & 7) * feed.fsz;
+        const int k = i % 14;                                    /* forwards and backwards through the eight pictures (0 1 .. 7 6 .. 1 0 1 ..), as bench.py walks its clip: */
+        guint8 *d = feed.mem + (gsize)(k < 8 ? k : 14 - k) * feed.fsz; /* wrapping 7 -> 0 would be a jump of (24, 16) samples every eighth picture -- a scene cut for the encoder, an IDR picture shortly after */
         GstBuffer *b = gst_buffer_new_wrapped_full(GST_MEMORY_FLAG_READONLY, d, feed.fsz, 0, feed.fsz, NULL, NULL);
         GST_BUFFER_PTS(b) = gst_util_uint64_scale(GST_SECOND, (guint64)i, (guint64)feed.fps);
         GST_BUFFER_DURATION(b) = gst_util_uint64_scale(GST_SECOND, 1, (guint64)feed.fps);
@@ -161,11 +165,11 @@ int main(int argc, char **argv) {
             if (!enc) enc = gst_bin_get_by_name(GST_BIN(pipe), "venc_kbps");
             if (!enc) { fprintf(stderr, "--props needs an element named venc_bps or venc_kbps\n"); return 2; }
             gint preset = 0, aq = 0, iip = 0, slices = 0, islices = 0;
-            gboolean dct = FALSE, i8 = FALSE, part = FALSE, sdb = FALSE;
-            g_object_get(enc, "speed-preset", &preset, "dct8x8", &dct, "i8x8", &i8, "aq-mode", &aq, "partitions", &part, "intra-in-p", &iip, "slices", &slices, "slice-deblock", &sdb,
+            gboolean dct = FALSE, i8 = FALSE, sdb = FALSE;
+            g_object_get(enc, "speed-preset", &preset, "dct8x8", &dct, "i8x8", &i8, "aq-mode", &aq, "intra-in-p", &iip, "slices", &slices, "slice-deblock", &sdb,
                          "intra-slices", &islices, NULL);
-            printf("{\"speed_preset\":%d,\"dct8x8\":%d,\"i8x8\":%d,\"aq_mode\":%d,\"partitions\":%d,\"intra_in_p\":%d,\"slices\":%d,\"slice_deblock\":%d,\"intra_slices\":%d}\n", preset, dct, i8, aq,
-                   part, iip, slices, sdb, islices);
+            printf("{\"speed_preset\":%d,\"dct8x8\":%d,\"i8x8\":%d,\"aq_mode\":%d,\"intra_in_p\":%d,\"slices\":%d,\"slice_deblock\":%d,\"intra_slices\":%d,\"has_partitions_property\":%d}\n", preset, dct, i8, aq,
+                   iip, slices, sdb, islices, g_object_class_find_property(G_OBJECT_GET_CLASS(enc), "partitions") != NULL);
             return 0;
         }
     for (int i = 2; i < argc; i++) {
@@ -226,6 +230,7 @@ int main(int argc, char **argv) {
         if (n > 120 && t_arr[n - 1] > t_arr[60]) printf(",\"fps_after_first_gop\":%.1f,\"buffers_timed\":%" G_GUINT64_FORMAT, (double)(n - 1 - 60) * 1e6 / (double)(t_arr[n - 1] - t_arr[60]), n - 1 - 60);
         else printf(",\"fps_after_first_gop\":null");
     }
+    printf(",\"us_sink_callback_per_sample\":%.1f", n_samples ? (double)us_in_callback / (double)n_samples : 0.0);
     const unsigned skip = n_lat > 90 ? 60 : 0; /* discard the first GOP (warm-up) */
     pct("ms_encoder_sink_to_appsink", l_enc + skip, n_lat - skip);
     pct("ms_appsink_to_last_udp_send", l_send + skip, n_lat - skip);

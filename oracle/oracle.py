@@ -390,6 +390,11 @@ def slice_rows_for(mbh, slices=0, local_deblock=False):
     return lib().orc_slice_rows_for(int(mbh), int(n), int(local_deblock))
 
 
+def auto_slices(mbh):
+    """The default number of slices per picture (about 17 macroblock rows each, at most 8): what the product uses for I pictures, and since r04 for P pictures."""
+    return int(lib().orc_auto_intra_slices(int(mbh)))
+
+
 def set_features(mask):
     """Process-wide ablation switches of the P-macroblock stage (default F_ALL)."""
     lib().orc_set_features(int(mask))

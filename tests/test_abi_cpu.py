@@ -349,6 +349,15 @@ def test_rate_control_emergency_drop_lands_within_a_few_pictures(delay):
     assert sum(sizes[drop_at + 2:drop_at + 32]) * 8 * fps / 30 < 1.3 * 500_000
 
 
+def test_default_cfg_cuts_p_pictures_into_slices_with_local_deblocking():
+    """r04: the library's default stream has P pictures sliced like I pictures (cfg.slices 0 = automatic) and the deblocking filter stopping at the seams
+    (cfg.slice_deblock 1); everything else as before."""
+    L = E.load()
+    cfg = E.Cfg()
+    L.mi355enc_default_cfg(C.byref(cfg), 1920, 1080, 60, 1)
+    assert (cfg.slices, cfg.slice_deblock, cfg.intra_slices, cfg.gop, cfg.fixed_qp, cfg.transform8x8, cfg.aq_mode) == (0, 1, 0, 60, -1, 0, 0)
+
+
 def test_rate_control_survives_updates_without_picks():
     """Pictures coded at a fixed QP book nothing with rate control (enqueue_picture skips rc_pick), so a stray update must not run the
     update counter ahead of the pick counter: the loops over the picks outstanding once wrapped through 2^32 iterations there (3.5 s

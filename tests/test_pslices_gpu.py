@@ -138,3 +138,26 @@ def test_per_diagonal_deblocker_and_the_writer_threads_with_slices(E, oracle):
     for thr in (1, 3, 8):
         _run_stream(E, oracle, 640, 368, 5, [28, 32, 26], 4, True, mode=1, thr=thr)
         _run_stream(E, oracle, 640, 368, 5, [28, 32, 26], 4, True, mode=0, thr=thr, depth=1)
+
+
+@pytest.mark.parametrize("w,h,n,depth", [(1280, 720, 5, 0), (1920, 1080, 5, 2), (3840, 2160, 3, 2), (640, 368, 5, 1)])
+def test_library_defaults_are_sliced_and_equal_oracle(E, oracle, w, h, n, depth):
+    """mi355enc_default_cfg (what the element and bench.py get; this mirror's own defaults keep the one-slice P pictures of rounds 1-3): P pictures cut like I
+    pictures -- about 17 macroblock rows per slice, rounded up to whole deblocking bands -- with slice-local deblocking.  Same stream as the oracle told the same."""
+    e = E.Encoder(w, h, gop=3, fixed_qp=30, pipeline_depth=depth, exclusive=True, slices=None, slice_deblock=None, scenecut=False)
+    mbh = (h + 15) // 16
+    ns = oracle.auto_slices(mbh)
+    oe = oracle.Encoder(w, h, gop=3, threads=16, intra_slices=0, p_slices=ns, slice_deblock_local=True, scenecut=False)
+    assert e.p_slice_rows == e.slice_rows == oracle.slice_rows_for(mbh, ns, True)
+    clip = [(y, uv) for _, _, y, uv in frames(w, h, n)]
+    got = []
+    for i, (y, uv) in enumerate(clip):
+        e.submit(y, uv, pts=i)
+        if e.pending > depth:
+            got.append(e.collect()[0])
+    while e.pending:
+        got.append(e.collect()[0])
+    for i, (y, uv) in enumerate(clip):
+        assert got[i] == oe.encode(y, uv, 30)[0], i
+    assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y)
+    e.close()
