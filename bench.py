@@ -95,7 +95,7 @@ def gst_latency(width, height, fps, gop, bps, dev, seconds=4):
     return out
 
 
-def gst_throughput(width, height, fps, gop, bps, dev, depth, buffers=660):
+def gst_throughput(width, height, fps, gop, bps, dev, depth, buffers=660, clip=None):
     """M1 through the element (SURVEY 8d "Timing method"): a NON-live source, the element instantiated by gst_parse_launch the way
     /root/reference/src/io/pipeline_loader.c:59 does, wall-clock between buffers arriving at the sink behind it, first GOP discarded.
     The source is videotestsrc (what the reference's own test pipelines use); its own ceiling -- the same source into the same sink
@@ -122,16 +122,23 @@ def gst_throughput(width, height, fps, gop, bps, dev, depth, buffers=660):
             out[key] = {"unavailable": "probe failed: %s" % e}
     # ... and with the probe feeding pre-rendered pictures through appsrc (no copy, no painting): what the element itself sustains
     asrc = "appsrc name=src ! video/x-raw,width=%d,height=%d,framerate=%d/1,format=NV12" % (width & ~3, height, fps)
+    clip_args = []
+    if clip is not None and (width & 3) == 0:  # the same pictures the C-ABI legs code (the first 16 of the clip, walked forwards and backwards), as one raw NV12 file
+        path = "/tmp/mi355_bench_clip_%dx%d.nv12" % (width, height)
+        with open(path, "wb") as f:
+            f.write(np.ascontiguousarray(clip[:16]).tobytes())  # (n, height * 3 / 2, width): NV12 pictures one after the other
+        clip_args = ["--clip", path]
     # (each twice, the better run reported and both listed: a 0.4 s run now and then lands on a box hiccup -- one r03 run measured 541 where every other gave 3700-3850)
     for key, extra in (("element_appsrc_pageable", []), ("element_appsrc_pinned", ["pinned"])):
         try:
             runs = []
             for _ in range(2):
-                r = subprocess.run([probe, "%s ! queue ! %s ! appsink name=appsink sync=false" % (asrc, encoder), "--appsrc", str(2 * buffers), str(width), str(height)] + extra,
+                r = subprocess.run([probe, "%s ! queue ! %s ! appsink name=appsink sync=false" % (asrc, encoder), "--appsrc", str(2 * buffers), str(width), str(height)] + extra + clip_args,
                                    env=env, capture_output=True, text=True, timeout=180)
                 runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
             j = max(runs, key=lambda x: x.get("fps_after_first_gop") or 0.0)
-            out[key] = {"frames_per_s": j.get("fps_after_first_gop"), "buffers_timed": j.get("buffers_timed"), "samples": j.get("samples"), "runs": [x.get("fps_after_first_gop") for x in runs]}
+            out[key] = {"frames_per_s": j.get("fps_after_first_gop"), "buffers_timed": j.get("buffers_timed"), "samples": j.get("samples"), "runs": [x.get("fps_after_first_gop") for x in runs],
+                        "content": "the bench's own clip (first 16 pictures, forwards and backwards)" if clip_args else "the probe's panning texture"}
         except Exception as e:
             out[key] = {"unavailable": "probe failed: %s" % e}
     out["pipeline"] = "%s ! queue ! %s ! appsink sync=false (non-live; wall-clock between buffers at the sink, first 60 discarded)" % (src, encoder)
@@ -440,7 +447,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_gst_latency:
         extra["latency_gst_ms"] = gst_latency(width, height, fps, gop, bps, dev)
-        g = gst_throughput(width, height, fps, gop, bps, dev, args.depth)
+        g = gst_throughput(width, height, fps, gop, bps, dev, args.depth, clip=frames_np)
         extra["gst_throughput"] = g
         extra["gst_frames_per_s"] = (g.get("element") or {}).get("frames_per_s")                     # videotestsrc in front: the source's own painting rate bounds it
         extra["gst_appsrc_frames_per_s"] = (g.get("element_appsrc_pinned") or {}).get("frames_per_s")  # pre-rendered pictures in pinned memory through appsrc

@@ -16,7 +16,9 @@
  * With --appsrc N W H [pinned] the description starts with `appsrc name=src`: the probe feeds N NV12 pictures itself (eight
  * pre-rendered pictures of a panning texture, wrapped without a copy, as fast as the pipeline takes them), so that the figure is the
  * element's and not the test source's (videotestsrc paints 1080p at 300-400 pictures/s).  `pinned`: the pictures lie in
- * mi355enc_host_alloc memory, as a capture source that adopted the element's buffer pool would deliver them.
+ * mi355enc_host_alloc memory, as a capture source that adopted the element's buffer pool would deliver them.  `--clip FILE`: the pictures come from FILE (raw NV12
+ * pictures of W x H one after the other, at most 32) instead of being rendered here -- bench.py passes the pictures of its own clip, so that this leg and the C-ABI legs
+ * code the same content.
  *
  * With --props the description is parsed, the coding-tool properties of the encoder element (named venc_bps or venc_kbps) are printed as they will be used --
  * an explicit property, else what speed-preset selects -- and nothing runs (no device needed).
@@ -115,12 +117,12 @@ static gboolean on_bus(GstBus *bus, GstMessage *msg, gpointer u) {
     return TRUE;
 }
 /* ---- --appsrc: eight pictures of a texture panning by (+3, -2) per picture, pushed forwards and backwards */
-static struct { GstElement *src; int n, w, h, fps; guint8 *mem; gsize fsz; } feed;
+static struct { GstElement *src; int n, w, h, fps, npic; guint8 *mem; gsize fsz; const char *clip; } feed;
 static gpointer feeder(gpointer u) {
     (void)u;
     for (int i = 0; i < feed.n; i++) {
-        const int k = i % 14;                                    /* forwards and backwards through the eight pictures (0 1 .. 7 6 .. 1 0 1 ..), as bench.py walks its clip: */
-        guint8 *d = feed.mem + (gsize)(k < 8 ? k : 14 - k) * feed.fsz; /* wrapping 7 -> 0 would be a jump of (24, 16) samples every eighth picture -- a scene cut for the encoder, an IDR picture shortly after */
+        const int np = feed.npic, k = np > 1 ? i % (2 * np - 2) : 0;  /* forwards and backwards through the pictures (0 1 .. 7 6 .. 1 0 1 ..), as bench.py walks its clip: */
+        guint8 *d = feed.mem + (gsize)(k < np ? k : 2 * np - 2 - k) * feed.fsz; /* wrapping 7 -> 0 would be a jump of (24, 16) samples every eighth picture -- a scene cut for the encoder, an IDR picture shortly after */
         GstBuffer *b = gst_buffer_new_wrapped_full(GST_MEMORY_FLAG_READONLY, d, feed.fsz, 0, feed.fsz, NULL, NULL);
         GST_BUFFER_PTS(b) = gst_util_uint64_scale(GST_SECOND, (guint64)i, (guint64)feed.fps);
         GST_BUFFER_DURATION(b) = gst_util_uint64_scale(GST_SECOND, 1, (guint64)feed.fps);
@@ -176,12 +178,17 @@ int main(int argc, char **argv) {
         if (!strcmp(argv[i], "--no-encoder")) no_enc = 1;
         else if (!strcmp(argv[i], "--appsrc") && i + 3 < argc) { use_appsrc = 1; ai = i; i += 3; }
         else if (!strcmp(argv[i], "pinned")) pinned = 1;
+        else if (!strcmp(argv[i], "--clip") && i + 1 < argc) feed.clip = argv[++i];
     }
     if (use_appsrc) {
         feed.src = gst_bin_get_by_name(GST_BIN(pipe), "src");
         feed.n = atoi(argv[ai + 1]); feed.w = atoi(argv[ai + 2]) & ~3; feed.h = atoi(argv[ai + 3]) & ~1; feed.fps = 60;
         if (!feed.src || feed.n < 1 || feed.w < 16 || feed.h < 16) { fprintf(stderr, "--appsrc needs `appsrc name=src` in the description and N W H\n"); return 2; }
         feed.fsz = (gsize)feed.w * feed.h * 3 / 2;
+        feed.npic = 8;
+        FILE *cf = feed.clip ? fopen(feed.clip, "rb") : NULL;
+        if (feed.clip && !cf) { fprintf(stderr, "cannot open %s\n", feed.clip); return 2; }
+        if (cf) { fseek(cf, 0, SEEK_END); const long sz = ftell(cf); fseek(cf, 0, SEEK_SET); feed.npic = (int)(sz / (long)feed.fsz); if (feed.npic > 32) feed.npic = 32; if (feed.npic < 1) { fprintf(stderr, "%s holds no %dx%d NV12 picture\n", feed.clip, feed.w, feed.h); return 2; } }
         if (pinned) { /* libmi355enc.so sits beside this program; loaded here rather than linked (this image's GStreamer brings an older libstdc++ than HIP's) */
             char exe[4096];
             ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 32);
@@ -191,13 +198,14 @@ int main(int argc, char **argv) {
                 snprintf(lib, sizeof lib, "%s/libmi355enc.so", dirname(exe));
                 void *dl = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
                 void *(*alloc)(size_t) = dl ? (void *(*)(size_t))dlsym(dl, "mi355enc_host_alloc") : NULL;
-                if (alloc) feed.mem = (guint8 *)alloc(8 * feed.fsz);
+                if (alloc) feed.mem = (guint8 *)alloc((gsize)feed.npic * feed.fsz);
                 else fprintf(stderr, "cannot load %s: %s\n", lib, dlerror());
             }
         }
         if (pinned && !feed.mem) fprintf(stderr, "mi355enc_host_alloc unavailable: pageable pictures instead\n");
-        if (!feed.mem) feed.mem = (guint8 *)g_malloc(8 * feed.fsz);
-        render_pictures();
+        if (!feed.mem) feed.mem = (guint8 *)g_malloc((gsize)feed.npic * feed.fsz);
+        if (cf) { if (fread(feed.mem, feed.fsz, (size_t)feed.npic, cf) != (size_t)feed.npic) { fprintf(stderr, "short read from %s\n", feed.clip); return 2; } fclose(cf); }
+        else render_pictures();
         g_object_set(feed.src, "format", GST_FORMAT_TIME, NULL);
     }
     if ((!enc && !no_enc) || !sink) { fprintf(stderr, "the description needs elements named venc_bps and appsink\n"); return 2; }

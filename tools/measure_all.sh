@@ -5,7 +5,7 @@
 #   afterwards: cp gpurun_out/final/profiles/* profiles/
 set -e
 R=$PWD
-RND=${1:-3}
+RND=${1:-4}
 PART=${2:-bench}
 mkdir -p gpurun_out/final/profiles
 prof() { # workload, extra bench args
