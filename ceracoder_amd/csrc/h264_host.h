@@ -66,6 +66,10 @@ typedef struct {
     int upd_drop_p, catchup;   /* ladder level of the last P picture whose size is known; pictures still to come whose size is a catch-up transient */
     int known_vqp_p;           /* the virtual quantiser of the last P picture whose size is known */
     unsigned n_pick, n_upd;
+    unsigned char plan_reg[4], regime; /* the tracker's regime when a picture was picked: a rise out of the ladder starts a new one, and the sizes of pictures picked before it
+                                        * (still on the ladder) no longer move the tracker */
+    double cplx_q; int have_q; /* the P tracker's last value while the stream lived on real quantisers (no ladder level, no all-skip cadence): what a rise of the setpoint out of
+                                * the ladder starts from -- on the ladder bits * qstep(virtual QP) says little about what a quantiser below 51 will cost */
 } rc_state_t;
 void rc_init(rc_state_t *rc, double fps, int gop, uint32_t bps, int qp_min, int qp_max);
 void rc_set_vbv(rc_state_t *rc, int vbv_ms);

@@ -67,7 +67,20 @@ void rc_set_bitrate(rc_state_t *rc, uint32_t bps) {
          * rate rises it is moved at most two octaves, the rest it walks (see the note on cliffs above) */
         int d = (int)lround(-6.0 * log2(k));
         if (d < -12) d = -12;
-        rc->last_vqp_p += d; rc->last_vqp_i += d;
+        /* A rise that starts at the coarse end of the scale -- on the ladder below the last quantiser, or within a few steps of it: there bits * qstep(virtual QP) says little
+         * about what a real quantiser will cost (a ladder level is worth far less than the RC_DROP_DQ steps it is booked as; at QP 46+ a picture is headers and vectors), so the
+         * tracker predicts QP 51 for a target that QP 30 would meet, "two octaves, then walk" is pulled back up by it, and the GOP that starts with the step ends short (measured:
+         * 300 kbit/s -> 1 Mbit/s at 1080p60 0.87, 2160p60 0.89, the still scene 0.85; 1.5 -> 20 Mbit/s with three pictures in flight 0.77 in tools/rc_sim_oracle.py).  The tracker's
+         * value from the last time the stream lived on real quantisers (QP <= 45: cplx_q) says where to go: the quantiser it predicts for a picture's share at the new rate, two
+         * steps on the safe side, is taken at once when it lies below the bounded move, the tracker continues from that value, and the sizes of the pictures still in flight --
+         * picked in the old regime -- no longer move it (rc_update: stale). */
+        if (k > 1.0 && rc->have_q && rc->last_vqp_p > rc->qp_max - 6) {
+            const double per = (double)bps / rc->fps;
+            int vq = (int)lround(4.0 + 6.0 * log2(rc->cplx_q / (per > 1 ? per : 1))) + 2;
+            if (vq < rc->qp_min) vq = rc->qp_min;
+            if (vq < rc->last_vqp_p + d) { d = vq - rc->last_vqp_p; rc->cplx_p = rc->cplx_q; rc->cliff_age = 0; rc->regime++; rc->known_vqp_p = 0; } /* (the model continues from the same value: the ladder's samples would pull the next pick back up) */
+        }
+        rc->last_vqp_p += d; rc->last_vqp_i += d > -12 ? d : -12;
         if (rc->last_vqp_p > RC_VQP_MAX(rc)) rc->last_vqp_p = RC_VQP_MAX(rc);
         if (rc->last_vqp_i > RC_VQP_MAX(rc)) rc->last_vqp_i = RC_VQP_MAX(rc);
         if (rc->last_vqp_p < rc->qp_min) rc->last_vqp_p = rc->qp_min;
@@ -178,6 +191,7 @@ void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
     rc->plan_gop[rc->n_pick & 3] = rc->gop_serial;
     rc->plan_gap[rc->n_pick & 3] = (short)(is_idr ? 0 : gap_before);
     rc->plan_k[rc->n_pick & 3] = 1.0;
+    rc->plan_reg[rc->n_pick & 3] = rc->regime;
     rc->plan[rc->n_pick++ & 3] = target; /* booked now, corrected when the picture's size is known */
     rc->gop_bits -= target;
     rc->gop_left--;
@@ -198,8 +212,9 @@ void rc_update(rc_state_t *rc, int is_idr, int qp, int drop, size_t bytes) {
     const double bits = 8.0 * (double)bytes;
     const int gap = rc->plan_gap[rc->n_upd & 3];
     const double kk = rc->plan_k[rc->n_upd & 3]; /* != 1: picked before the setpoint moved */
+    const int stale = rc->plan_reg[rc->n_upd & 3] != rc->regime; /* picked on the ladder, before a rise that left it: says nothing about the quantisers now in use */
     const double planned = rc->plan[rc->n_upd++ & 3];
-    if (drop != DROP_SKIP) {
+    if (drop != DROP_SKIP && !(stale && !is_idr)) {
         const double vqp = is_idr ? qp + RC_DROP_DQ_I * drop : qp + RC_DROP_DQ * drop;
         const double c = bits * qstep(vqp);
         if (is_idr) {
@@ -218,6 +233,7 @@ void rc_update(rc_state_t *rc, int is_idr, int qp, int drop, size_t bytes) {
             rc->cplx_gap = rc->have_p ? (1 - a) * rc->cplx_gap + a * gap : gap;
             rc->cplx_p = rc->have_p ? (1 - a) * rc->cplx_p + a * c : c;
             rc->have_p = 1; rc->last_bits_p = bits; rc->last_target_p = planned; rc->known_vqp_p = (int)vqp;
+            if (drop == 0 && gap == 0 && !transient && vqp <= rc->qp_max - 6) { rc->cplx_q = rc->have_q ? 0.5 * rc->cplx_q + 0.5 * c : c; rc->have_q = 1; } /* (a picture coded on a real quantiser, well inside the scale, right behind another coded one) */
             if (transient) { /* not a cliff either */ }
             else if (bits > 3.0 * planned && planned > 4 * RC_SKIP_BITS && vqp <= rc->qp_max && vqp < rc->last_vqp_p + 2) { rc->cliff_vqp = (int)vqp; rc->cliff_bits = bits; rc->cliff_age = (int)rc->fps; }
             else if (rc->cliff_age > 0) rc->cliff_age--;
