@@ -78,7 +78,7 @@ void rc_set_bitrate(rc_state_t *rc, uint32_t bps) {
             const double per = (double)bps / rc->fps;
             int vq = (int)lround(4.0 + 6.0 * log2(rc->cplx_q / (per > 1 ? per : 1))) + 2;
             if (vq < rc->qp_min) vq = rc->qp_min;
-            if (vq < rc->last_vqp_p + d) { d = vq - rc->last_vqp_p; rc->cplx_p = rc->cplx_q; rc->cliff_age = 0; rc->regime++; rc->known_vqp_p = 0; } /* (the model continues from the same value: the ladder's samples would pull the next pick back up) */
+            if (vq < rc->last_vqp_p + d) { d = vq - rc->last_vqp_p; rc->cplx_p = rc->cplx_q; rc->cliff_age = 0; rc->regime++; rc->known_vqp_p = 0; rc->catchup = 3; } /* (catchup: the first pictures coded down here also pay for what the ladder and its skip runs left uncoded -- transients, not a cliff) */ /* (the model continues from the same value: the ladder's samples would pull the next pick back up) */
         }
         rc->last_vqp_p += d; rc->last_vqp_i += d > -12 ? d : -12;
         if (rc->last_vqp_p > RC_VQP_MAX(rc)) rc->last_vqp_p = RC_VQP_MAX(rc);
@@ -235,7 +235,7 @@ void rc_update(rc_state_t *rc, int is_idr, int qp, int drop, size_t bytes) {
             rc->have_p = 1; rc->last_bits_p = bits; rc->last_target_p = planned; rc->known_vqp_p = (int)vqp;
             if (drop == 0 && gap == 0 && !transient && vqp <= rc->qp_max - 6) { rc->cplx_q = rc->have_q ? 0.5 * rc->cplx_q + 0.5 * c : c; rc->have_q = 1; } /* (a picture coded on a real quantiser, well inside the scale, right behind another coded one) */
             if (transient) { /* not a cliff either */ }
-            else if (bits > 3.0 * planned && planned > 4 * RC_SKIP_BITS && vqp <= rc->qp_max && vqp < rc->last_vqp_p + 2) { rc->cliff_vqp = (int)vqp; rc->cliff_bits = bits; rc->cliff_age = (int)rc->fps; }
+            else if (bits > 3.0 * planned && planned > 4 * RC_SKIP_BITS && vqp <= rc->qp_max && vqp < rc->last_vqp_p + 2 && gap == 0) { /* (gap: a picture behind a run of all-skip pictures carries their changes too) */ rc->cliff_vqp = (int)vqp; rc->cliff_bits = bits; rc->cliff_age = (int)rc->fps; }
             else if (rc->cliff_age > 0) rc->cliff_age--;
         }
     }

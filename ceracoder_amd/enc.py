@@ -239,7 +239,7 @@ class Encoder:
     (bitrate in bits/s as written through `bps`, key-int-max -> gop)."""
 
     def __init__(self, width, height, fps=60, gop=60, bitrate_bps=6_000_000, device_id=0, fixed_qp=-1, me_range=16,
-                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False, intra_slices=0, profile_overlap=False, partitions=False, i8x8=False, slices=1, slice_deblock=False):
+                 pipeline_depth=0, profile_events=False, use_graphs=True, keep_prefilter=False, fps_den=1, deblock_mode=0, subpel=True, i4x4=True, transform8x8=False, intra_in_p=True, cavlc_threads=0, intra_mode=0, scenecut=True, exclusive=False, aq=False, single_stream=False, intra_slices=0, profile_overlap=False, partitions=False, i8x8=False, slices="mirror", slice_deblock="mirror"):
         self.L = load()
         cfg = Cfg()
         self.L.mi355enc_default_cfg(C.byref(cfg), width, height, fps, fps_den)
@@ -260,6 +260,12 @@ class Encoder:
         cfg.intra_slices = int(intra_slices)  # 0: about 17 macroblock rows per slice (1080p: 4 slices per I picture)
         # slices / slice_deblock: this mirror defaults to the one-slice P pictures and the filter across slice boundaries of rounds 1-3 (what the stage-by-stage parity
         # suite was written against); None = the library's own default (mi355enc_default_cfg: P pictures sliced like I pictures, slice-local deblocking)
+        # (dev tools: MI355ENC_MIRROR_DEFAULTS=library makes the mirror's default the library's)
+        lib_defaults = os.environ.get("MI355ENC_MIRROR_DEFAULTS") == "library"
+        if isinstance(slices, str):
+            slices = None if lib_defaults else 1
+        if isinstance(slice_deblock, str):
+            slice_deblock = None if lib_defaults else False
         if slices is not None:
             cfg.slices = int(slices)  # slices per P picture (0: automatic, 1: one)
         if slice_deblock is not None:

@@ -1,7 +1,7 @@
 # Refreshes everything under profiles/ on a GPU box: per workload the rocprofv3 kernel trace and the two PMC passes (MI355ENC_SERIAL=1 there:
 # counter collection serialises kernel dispatches, and a kernel that follows another kernel's progress cannot wait for one that is not
 # allowed to run beside it), then the bench lines of the workloads and the multi-stream runs.
-#   gpurun --timeout 1200 -- bash tools/measure_all.sh ROUND part      part: prof1 (1080p_ippp) | prof2 (2160p_ippp, 1080p_intra) | bench
+#   gpurun --timeout 1200 -- bash tools/measure_all.sh ROUND part      part: prof1 (1080p_ippp) | prof2 (2160p_ippp, 1080p_intra) | bench | price
 #   afterwards: cp gpurun_out/final/profiles/* profiles/
 set -e
 R=$PWD
@@ -40,5 +40,8 @@ bench)
   timeout -k 10 300 python bench.py --gpus 2 --no-gst-latency --no-cpu-baseline > gpurun_out/final/bench_1080p_ippp_ranks2_shared.log 2>&1
   grep '^{' gpurun_out/final/bench_1080p_ippp_ranks2_shared.log | tail -1 > profiles/r0${RND}_bench_1080p_ippp_ranks2_shared_gpu.json
   cp profiles/r0${RND}_bench_* gpurun_out/final/profiles/ ;;
+price)  # what the toolsets and the slices cost and buy (tools/toolset_price.py)
+  timeout -k 10 900 python tools/toolset_price.py profiles/r0${RND}_toolset_price.md > gpurun_out/final/toolset_price.log 2>&1
+  cp profiles/r0${RND}_toolset_price.md gpurun_out/final/profiles/ ;;
 esac
 ls -la gpurun_out/final/profiles
