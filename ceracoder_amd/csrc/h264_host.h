@@ -68,6 +68,7 @@ typedef struct {
     unsigned n_pick, n_upd;
     unsigned char plan_reg[4], regime; /* the tracker's regime when a picture was picked: a rise out of the ladder starts a new one, and the sizes of pictures picked before it
                                         * (still on the ladder) no longer move the tracker */
+    int cliff_doubt;           /* pictures in a row, coded one step above a remembered cliff, that came out far below their target: the cliff is tried again after eight */
     double cplx_q; int have_q; /* the P tracker's last value while the stream lived on real quantisers (no ladder level, no all-skip cadence): what a rise of the setpoint out of
                                 * the ladder starts from -- on the ladder bits * qstep(virtual QP) says little about what a quantiser below 51 will cost */
 } rc_state_t;

@@ -114,6 +114,7 @@ void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
         if (target < per) target = per;
     } else target = rc->gop_bits / (rc->gop_left > 0 ? rc->gop_left : 1);
     const int vmax = RC_VQP_MAX(rc);
+    const int exhausted = !is_idr && target < 0.25 * per; /* the GOP's grant is (nearly) used up: what such a picture is given says something about the books, nothing about the content */
     const double cplx = is_idr ? rc->cplx_i : rc->cplx_p;
     const int have = is_idr ? rc->have_i : rc->have_p;
     int skip = 0, vqp, idrop = 0;
@@ -173,7 +174,7 @@ void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
     }
     static int trace = -1; /* dev aid: MI355ENC_RC_TRACE=1 prints every decision */
     if (trace < 0) trace = getenv("MI355ENC_RC_TRACE") != NULL;
-    if (trace) fprintf(stderr, "rc idr=%d tgt=%.0f cplx=%.3g have=%d vqp=%d skip=%d since=%d vbv=%.0f known=%d lastb=%.0f lastv=%d gopb=%.0f left=%d np=%u nu=%u\n", is_idr, target, cplx, have, have ? vqp : -1, skip, rc->since_real, rc->vbv, rc->known_vqp_p, rc->last_bits_p, rc->last_vqp_p, rc->gop_bits, rc->gop_left, rc->n_pick, rc->n_upd);
+    if (trace) fprintf(stderr, "rc idr=%d tgt=%.0f cplx=%.3g have=%d vqp=%d skip=%d since=%d vbv=%.0f known=%d lastb=%.0f lastv=%d gopb=%.0f left=%d np=%u nu=%u cliff=%d/%.0f/%d catchup=%d\n", is_idr, target, cplx, have, have ? vqp : -1, skip, rc->since_real, rc->vbv, rc->known_vqp_p, rc->last_bits_p, rc->last_vqp_p, rc->gop_bits, rc->gop_left, rc->n_pick, rc->n_upd, rc->cliff_vqp, rc->cliff_bits, rc->cliff_age, rc->catchup);
     const int gap_before = rc->since_real > 0x7FFF ? 0x7FFF : rc->since_real;
     if (!is_idr) rc->since_real = skip ? rc->since_real + 1 : 0;
     if (skip) {
@@ -185,7 +186,10 @@ void rc_pick(rc_state_t *rc, int is_idr, int *qp, int *drop) {
         if (is_idr) { if (vqp > rc->qp_max) vqp = rc->qp_max; *qp = vqp; *drop = idrop; }
         else if (vqp <= rc->qp_max) *qp = vqp;
         else { *qp = rc->qp_max; *drop = (vqp - rc->qp_max + RC_DROP_DQ - 1) / RC_DROP_DQ; vqp = rc->qp_max + RC_DROP_DQ * *drop; }
-        if (is_idr) rc->last_vqp_i = vqp; else rc->last_vqp_p = vqp; /* remembered when chosen: the picture's size arrives a picture later, after the next choice */
+        if (is_idr) rc->last_vqp_i = vqp;
+        else if (!exhausted) rc->last_vqp_p = vqp; /* remembered when chosen: the picture's size arrives a picture later, after the next choice.  (Not the quantiser of a picture at the end
+                                                     * of an exhausted GOP: it is driven to the ladder's last level by the books, and the next GOP would start its walk from there -- a dozen pictures
+                                                     * at a level a picture: 1 Mbit/s at 1080p60, second GOP 0.93) */
     }
     rc->plan_vqp[rc->n_pick & 3] = (short)((is_idr || skip) ? 0x7FFF : vqp);
     rc->plan_gop[rc->n_pick & 3] = rc->gop_serial;
@@ -236,7 +240,15 @@ void rc_update(rc_state_t *rc, int is_idr, int qp, int drop, size_t bytes) {
             if (drop == 0 && gap == 0 && !transient && vqp <= rc->qp_max - 6) { rc->cplx_q = rc->have_q ? 0.5 * rc->cplx_q + 0.5 * c : c; rc->have_q = 1; } /* (a picture coded on a real quantiser, well inside the scale, right behind another coded one) */
             if (transient) { /* not a cliff either */ }
             else if (bits > 3.0 * planned && planned > 4 * RC_SKIP_BITS && vqp <= rc->qp_max && vqp < rc->last_vqp_p + 2 && gap == 0) { /* (gap: a picture behind a run of all-skip pictures carries their changes too) */ rc->cliff_vqp = (int)vqp; rc->cliff_bits = bits; rc->cliff_age = (int)rc->fps; }
-            else if (rc->cliff_age > 0) rc->cliff_age--;
+            else if (rc->cliff_age > 0) {
+                rc->cliff_age--;
+                /* A remembered cliff keeps the quantiser one step above it while the target could not pay what the edge cost.  What is taken for an edge can be a transient (the
+                 * first picture on a finer quantiser after the ladder also pays for the reference the ladder left: 59 kbit at QP 49 between pictures of 10-15 kbit at QP 50 and,
+                 * later, at QP 49 as well -- the GOP that starts with 1 -> 1.5 Mbit/s then sat at QP 50 for 38 pictures at half its target: 0.79): eight pictures in a row right
+                 * above the edge at under 60 % of their target and the edge is tried again (a real one is remembered again at the cost of one picture). */
+                rc->cliff_doubt = ((int)vqp == rc->cliff_vqp + 1 && bits < 0.6 * planned) ? rc->cliff_doubt + 1 : 0;
+                if (rc->cliff_doubt >= 8) { rc->cliff_age = 0; rc->cliff_doubt = 0; }
+            }
         }
     }
     if (rc->plan_gop[(rc->n_upd - 1) & 3] == rc->gop_serial) rc->gop_bits += planned - bits * kk;

@@ -142,6 +142,31 @@ def test_dct8x8_and_i8x8_properties_give_a_high_profile_stream_that_decodes(tmp_
 
 
 @pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
+@pytest.mark.parametrize("props,profile_idc,p_slices", [("speed-preset=3 key-int-max=60", 100, 2), ("speed-preset=2 key-int-max=60", 100, 2), ("speed-preset=1 key-int-max=60", 66, 2),
+                                                         ("key-int-max=60", 66, 2), ("speed-preset=3 dct8x8=false key-int-max=60", 66, 2),
+                                                         ("speed-preset=veryfast slices=1 slice-deblock=false key-int-max=60", 100, 1), ("speed-preset=2 slices=3 key-int-max=60", 100, 3)])
+def test_speed_preset_and_slices_reach_the_stream(tmp_path, oracle, props, profile_idc, p_slices):
+    """What the reference's files pass (`speed-preset=2` / `=3`: /root/reference/pipeline/generic/x264_superfast_camlink:5, x264_veryfast_camlink:5) lands on the High-profile
+    toolset (SPS profile_idc 100), ultrafast / none on Constrained Baseline (66), an explicit `dct8x8=false` wins; P pictures are cut into slices by default (720p: two,
+    disable_deblocking_filter_idc 2) unless told otherwise.  Every stream decodes with the independent decoder."""
+    pf = tmp_path / "pipe"
+    pf.write_text("videotestsrc num-buffers=6 pattern=zone-plate kx2=12 ky2=12 kt=2 ! video/x-raw,width=1280,height=720,framerate=30/1,format=NV12 ! "
+                  "mi355h264enc %s qp=30 name=venc_kbps ! appsink name=appsink sync=false\n" % props)
+    out = tmp_path / "out.bin"
+    r = subprocess.run([HARNESS, str(pf), str(out)], env=gst_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = read_records(str(out))
+    assert len(recs) == 6
+    assert recs[0][1][:5] == b"\x00\x00\x00\x01\x67" and recs[0][1][5] == profile_idc
+    dec = oracle.Decoder()
+    for i, (_, au) in enumerate(recs):
+        dec.decode(au)
+        if i:
+            assert au.count(b"\x00\x00\x01\x41") == p_slices, (i, au.count(b"\x00\x00\x01\x41"))  # P slices: nal_ref_idc 2, type 1
+    assert dec.size == (1280, 720)
+
+
+@pytest.mark.skipif(not os.path.exists(HARNESS), reason="oracle/_ref/ref_harness not shipped")
 def test_reference_x264_line_with_only_the_factory_token_changed_runs_at_the_written_rate(tmp_path):
     """The encoder hop of pipeline/mi355x/x264_superfast_camlink (the reference's file, `x264enc` -> `mi355h264enc`, still
     `name=venc_kbps`) between a test source and the appsink: the reference's encoder_control divides by 1000 for that name
