@@ -9,7 +9,15 @@
 // MI355ENC_SERIAL is set (tools/measure_all.sh sets it for the counter passes).  Every wait is bounded and reported anyway.
 std::atomic<int> g_open_encoders{0};
 bool exclusive_device(const mi355enc_t *h) { static const bool env = getenv("MI355ENC_EXCLUSIVE") != nullptr; return h->cfg.exclusive_device != 0 || env; } // cfg.exclusive_device, or the environment for tools
-bool no_pgate() { static const bool off = getenv("MI355ENC_NO_PGATE") != nullptr; return off; } // A/B switch: the fused P stage in stream order behind the deblocking launch
+// The fused P stage of picture n + 1 beside the deblocking launch of picture n, its workgroups waiting on the device for the bands they read (pmb_kernel<GATED>): worth 8 % at 1080p,
+// where the P period is a dependency chain with most of the chip idle -- and a LOSS where the flat kernels' chip time is the period (r04: 2160p 2 573 -> 2 757 frames/s without it;
+// tests/devtools/ab_lib.py, alternating processes): tens of thousands of waiting waves take issue slots from the kernels the picture is actually waiting for.  So: up to
+// MI355ENC_PGATE_MAX macroblocks per picture (default 16 384: 1080p and 1440p yes, 2160p no); MI355ENC_NO_PGATE=1 switches it off everywhere (A/B).  Latched at open().
+bool pgate_on(int nmb) {
+    if (getenv("MI355ENC_NO_PGATE")) return false;
+    const char *m = getenv("MI355ENC_PGATE_MAX");
+    return nmb <= (m ? atoi(m) : 16384);
+}
 // The intra macroblock rows of a P picture as workgroups of its deblocking launch instead of intra_p_kernel behind pmb_kernel: measured (tests/devtools/ab_env.py, alternating
 // runs in one process) +6 % at 720p, +-0 at 1080p, -3.6 % at 2160p -- so up to 720p's 3600 macroblocks.  MI355ENC_FIP / MI355ENC_NO_FIP force it; latched once per encoder at
 // open() (mi355enc::fip_rows): a running encoder's schedule does not depend on a mutable environment, and getenv() is not called beside a host application's setenv().
@@ -136,6 +144,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     g_open_encoders.fetch_add(1, std::memory_order_relaxed);
     HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->fip_rows = fip_on(h->nmb);
+    h->pgate = pgate_on(h->nmb);
     for (int i = 0; i < NSET; i++) HIPCHK(hipMalloc((void **)&h->d_ctx2[i], sizeof(frame_ctx_t)));
     h->d_ctx = h->d_ctx2[0];
     if (h->cfg.single_stream) { // one hardware queue per encoder: every stage in order on the main stream

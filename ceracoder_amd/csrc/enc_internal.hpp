@@ -76,6 +76,7 @@ struct mi355enc {
     mb_info_t *d_mbi, *d_mbi_set[NSET];  // record/level sets: the hand-over of picture n overlaps the kernels of n+1 (and n+2)
     int16_t *d_levels, *d_levels_set[NSET];
     hipStream_t cstream;                 // hand-over stream (scan + pack into pinned host memory)
+    bool pgate;                          // the fused P stage runs beside the previous picture's deblocking launch, gated per band (pgate_on(), latched at open())
     bool fip_rows;                       // the intra macroblock rows of a P picture ride in its deblocking launch (fip_on(), latched at open())
     uint64_t n_submitted;
     uint64_t sc_sum, sc_force_at; int sc_cnt, sc_prev_skip; // scene-cut recovery: summed cost / number of the P pictures since the last IDR; picture to force
@@ -159,7 +160,7 @@ static inline unsigned *err_word(const mi355enc_t *h) { return h->d_progress; }
 // enc_handle.cpp
 extern std::atomic<int> g_open_encoders;
 bool exclusive_device(const mi355enc_t *h);
-bool no_pgate();
+bool pgate_on(int nmb);
 bool fip_on(int nmb);
 bool overlap_allowed(const mi355enc_t *h);
 int sync_compute(mi355enc_t *h);

@@ -203,7 +203,7 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // P picture whose reference is still being deblocked: the fused stage leaves the chain too.  It runs on the intra stream, each of
         // its waves waiting for the reference's bands it reads (pmb_kernel<GATED>), so it is all but done when that deblocking ends.
         const size_t nbd = k_deblock_done_bytes() / sizeof(unsigned); // words per reconstruction buffer
-        const int pgate = !idr && fused && may_wait && h->rec_epoch[h->cur] != 0 && !no_pgate();
+        const int pgate = !idr && fused && may_wait && h->rec_epoch[h->cur] != 0 && h->pgate;
         HIPCHK(hipStreamWaitEvent(pgate ? h->istream : h->stream, s->ev_front, 0));
         // ... and with three pictures in flight (the next picture's front stages are done long before this launch ends) the deblocking launches go back
         // to back, each waiting on the device for its picture's rows; with fewer the host sits on the chain and a launch waiting on the chip only

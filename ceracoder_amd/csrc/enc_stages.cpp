@@ -72,6 +72,21 @@ int mi355enc_stage_me_select(mi355enc_t *h, const uint16_t *surf, const void *im
     HIPCHK(hipStreamSynchronize(h->stream));
     return MI355ENC_OK;
 }
+// ... and the form the encoder's later iterations use (me_select_sparse_kernel): imv_prev is the field imv_in was selected from -- a macroblock whose predictors are
+// the same in both copies its entry of imv_in.  Must equal mi355enc_stage_me_select(surf, imv_in) whenever imv_in really is the selection over imv_prev.
+int mi355enc_stage_me_select_next(mi355enc_t *h, const uint16_t *surf, const void *imv_in, const void *imv_prev, int qp, void *imv_out) {
+    if (!h || !surf || !imv_in || !imv_prev || !imv_out || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device_id));
+    STAGE_IDLE(h);
+    int r = stage_ctx(h, qp, true); if (r) return r;
+    HIPCHK(hipMemcpyAsync(h->d_surf[0], surf, (size_t)h->nmb * SURF_U16 * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_imv[0][0], imv_in, (size_t)h->nmb * sizeof(imv_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_imv[0][2], imv_prev, (size_t)h->nmb * sizeof(imv_t), hipMemcpyHostToDevice, h->stream));
+    k_launch_me_select(h->slot[0].h_ctx, h->mbw, 0, h->mbh, h->d_imv[0][0], h->d_imv[0][1], h->d_imv[0][2], 2, h->stream);
+    HIPCHK(hipMemcpyAsync(imv_out, h->d_imv[0][1], (size_t)h->nmb * sizeof(imv_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MI355ENC_OK;
+}
 int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_inout) {
     if (!h || !cur_y || !ref_y || !mbinfo_inout || qp < 0 || qp > 51) return MI355ENC_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device_id));

@@ -234,6 +234,42 @@ __global__ __launch_bounds__(256) void me_select_kernel(const frame_ctx_t cv, in
     if (lane == 0) store_imv(&out[mbn], best, ctx->lambda, px, py, sx, sy);
 }
 
+// The same iteration for the later passes (mode 2), where nine macroblocks in ten only copy their previous result: one wave per macroblock then spends a launch of
+// 8 160 waves (32 400 at 2160p) on reading predictors.  Here a wave takes SEL_SPW consecutive macroblocks: lanes 0 .. SEL_SPW-1 each check one (both fields' predictors,
+// per-lane addresses), copy the unchanged ones, and the wave then walks the changed ones with all 64 lanes on the surface as above.  Same result bit for bit (the test
+// is the same, the selection is the same function); an eighth of the waves, and almost none of them long.
+#define SEL_SPW 8
+__global__ __launch_bounds__(256) void me_select_sparse_kernel(const frame_ctx_t cv, int mb0, int mb1, const imv_t *__restrict__ in, imv_t *__restrict__ out, const imv_t *__restrict__ prev) {
+    const frame_ctx_t *__restrict__ ctx = &cv;
+    const int mbw = ctx->mbw;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int base = mb0 + ((int)blockIdx.x * 4 + wave) * SEL_SPW;
+    if (base >= mb1) return; // wave-uniform; no workgroup barrier below
+    const int mine = base + (lane < SEL_SPW ? lane : 0);
+    const bool have = lane < SEL_SPW && mine < mb1;
+    const int mbn_l = have ? mine : base, my_l = mbn_l / mbw, mx_l = mbn_l - my_l * mbw;
+    const bool top_l = row_has_top(ctx, my_l);
+    const fpred_t fp = field_pred(in, mbw, mx_l, my_l, top_l), fq = field_pred(prev, mbw, mx_l, my_l, top_l);
+    const int px = fp.px >> 2, py = fp.py >> 2, sx = fp.sx >> 2, sy = fp.sy >> 2;
+    const bool same = px == (fq.px >> 2) && py == (fq.py >> 2) && sx == (fq.sx >> 2) && sy == (fq.sy >> 2);
+    if (have && same) stg64(&out[mbn_l], ldg64(&in[mbn_l]));
+    unsigned todo = (unsigned)(__ballot(have && !same) & ((1ull << SEL_SPW) - 1ull));
+    const bool active = lane < 63;
+    const int g = active ? lane / 9 : 0, dxg = active ? lane % 9 : 0;
+    while (todo) { // wave-uniform
+        const int j = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int mbn = base + j;
+        const int jpx = __builtin_amdgcn_readlane(px, j), jpy = __builtin_amdgcn_readlane(py, j), jsx = __builtin_amdgcn_readlane(sx, j), jsy = __builtin_amdgcn_readlane(sy, j);
+        unsigned long long acc[ME_K];
+        const uint16_t *sf = ctx->surf + (size_t)mbn * SURF_U16 + 4 * dxg;
+#pragma unroll
+        for (int d = 0; d < ME_K; d++) { const uint2 v = ldg64(sf + (ME_K * g + d) * SURF_COLS); acc[d] = ((unsigned long long)v.y << 32) | v.x; }
+        const unsigned best = select_min(acc, g, dxg, active, ctx->me_range, ctx->lambda, jpx, jpy, jsx, jsy);
+        if (lane == 0) store_imv(&out[mbn], best, ctx->lambda, jpx, jpy, jsx, jsy);
+    }
+}
+
 // =================================================================== sub-sample refinement
 // One wave per macroblock.  Around the integer winner (ix, iy) the wave builds, in LDS, the
 // integer samples G and the three half-sample planes of 8.4.2.2.1 (b: horizontal 6-tap,
@@ -1045,7 +1081,14 @@ void k_launch_me(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStrea
 }
 void k_launch_me_select(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, const imv_t *in, imv_t *out, const imv_t *prev, int mode, hipStream_t s) {
     int n = mbw * (row1 - row0);
-    if (n > 0) hipLaunchKernelGGL(me_select_kernel, dim3((n + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, in, out, prev, mode);
+    if (n <= 0) return;
+#ifdef NO_SPARSE_SELECT /* A/B build (tools/build_variant.sh): the dense kernel for every pass */
+    if (false) hipLaunchKernelGGL(me_select_sparse_kernel,
+#else
+    if (mode == 2) hipLaunchKernelGGL(me_select_sparse_kernel,
+#endif
+  dim3((n + 4 * SEL_SPW - 1) / (4 * SEL_SPW)), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, in, out, prev); // later passes: mostly copies
+    else hipLaunchKernelGGL(me_select_kernel, dim3((n + 3) / 4), dim3(256), 0, s, *h_ctx, row0 * mbw, row1 * mbw, in, out, prev, mode);
 }
 // The ME_ITERS iterations walk a -> b -> c -> a ...: iteration k reads field k % 3, writes (k + 1) % 3 and compares with what iteration k - 1 read.
 void k_launch_me_select_all(const frame_ctx_t *h_ctx, int mbw, int row0, int row1, hipStream_t s) {

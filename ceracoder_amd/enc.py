@@ -27,7 +27,7 @@ STAGE_ME, STAGE_INTER, STAGE_INTRA, STAGE_DEBLOCK, STAGE_SUBPEL, STAGE_CSC_I420,
 
 EXPORTS = [
     "mi355enc_abi_version", "mi355enc_strerror", "mi355enc_default_cfg", "mi355enc_open", "mi355enc_close",
-    "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_set_fixed_drop", "mi355enc_stage_me_select", "mi355enc_encode", "mi355enc_submit",
+    "mi355enc_set_bitrate", "mi355enc_get_bitrate", "mi355enc_set_fixed_qp", "mi355enc_set_fixed_drop", "mi355enc_stage_me_select", "mi355enc_stage_me_select_next", "mi355enc_encode", "mi355enc_submit",
     "mi355enc_submit_device", "mi355enc_pending", "mi355enc_collect", "mi355enc_get_stats", "mi355enc_reset_stats",
     "mi355enc_max_au_bytes", "mi355enc_fetch", "mi355enc_mb_width", "mi355enc_mb_height", "mi355enc_stage_me",
     "mi355enc_stage_subpel", "mi355enc_stage_inter", "mi355enc_stage_pmb", "mi355enc_stage_intra", "mi355enc_stage_intra_analyse", "mi355enc_stage_csc", "mi355enc_submit_fmt", "mi355enc_host_write_slice_packed", "mi355enc_stage_deblock", "mi355enc_time_stage",
@@ -386,6 +386,12 @@ class Encoder:
     def stage_me_select(self, surf, imv, qp):
         out = np.zeros(imv.size, IMV_DTYPE)
         self._chk(self.L.mi355enc_stage_me_select(self.h, _p(np.ascontiguousarray(surf, np.uint16)), _p(np.ascontiguousarray(imv)), qp, _p(out)), "stage_me_select")
+        return out
+
+    def stage_me_select_next(self, surf, imv, prev, qp):
+        """the same iteration as the encoder's later passes run it: macroblocks whose predictors are unchanged against `prev` (the field `imv` was selected from) are copied"""
+        out = np.zeros(imv.size, IMV_DTYPE)
+        self._chk(self.L.mi355enc_stage_me_select_next(self.h, _p(np.ascontiguousarray(surf, np.uint16)), _p(np.ascontiguousarray(imv)), _p(np.ascontiguousarray(prev)), qp, _p(out)), "stage_me_select_next")
         return out
 
     def stage_subpel(self, cur_y, ref_y, mbi, qp):

@@ -235,6 +235,8 @@ int mi355enc_mb_height(const mi355enc_t *h);
 int mi355enc_stage_me(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, uint16_t *surf_out, void *imv_out);
 /* One more selection over the surfaces, bits charged against the median of the neighbours' vectors in imv_in. */
 int mi355enc_stage_me_select(mi355enc_t *h, const uint16_t *surf, const void *imv_in, int qp, void *imv_out);
+/* the same iteration in the form the encoder's later passes use (macroblocks whose predictors are unchanged against imv_prev -- the field imv_in was selected from -- are copied) */
+int mi355enc_stage_me_select_next(mi355enc_t *h, const uint16_t *surf, const void *imv_in, const void *imv_prev, int qp, void *imv_out);
 /* Two-kernel form of the P stage (High-profile path): refine the vectors in mbinfo (mvx, mvy in quarter-sample units, cost) in place ... */
 int mi355enc_stage_subpel(mi355enc_t *h, const uint8_t *cur_y, const uint8_t *ref_y, int qp, void *mbinfo_inout);
 /* ... and prediction, residual (4x4 or 8x8 transform), reconstruction for the vectors in mbinfo */

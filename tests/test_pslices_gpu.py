@@ -35,6 +35,36 @@ def test_vector_selection_stops_at_slice_tops(E, oracle, w, h, rows):
     e.close()
 
 
+@pytest.mark.parametrize("w,h,rows", [(64, 48, 0), (176, 144, 0), (330, 182, 0), (320, 192, 4), (1280, 720, 12), (1920, 1088, 0), (1920, 1088, 20), (3840, 2160, 0)])
+def test_later_selection_passes_copy_what_did_not_change(E, oracle, w, h, rows):
+    """me_select_sparse_kernel (r04: the encoder's second and third selection pass -- a wave checks eight macroblocks' predictors and only walks the surfaces of those
+    that changed): the same field as the dense pass and as the oracle, three passes in a row, with and without slices, down to pictures narrower than a wave's eight."""
+    W, H = (w + 15) // 16 * 16, (h + 15) // 16 * 16
+    e = E.Encoder(W, H, fixed_qp=30)
+    fr = frames(w, h, 2)
+    cur, ref = fr[1][0], fr[0][0]
+    o_surf, orc = oracle.me_frame(cur, ref, 16, 30, threads=8)
+    d_surf, dev = e.stage_me(cur, ref, 30)
+    assert mbinfo_equal(dev, orc, IMV_FIELDS)
+    oracle.set_slice_rows(rows)
+    try:
+        e.stage_set_slice_rows(rows)
+        prev = dev
+        cur_f = e.stage_me_select(d_surf, dev, 30)  # first pass: dense
+        copied = 0
+        for it in range(3):
+            dense = e.stage_me_select(d_surf, cur_f, 30)
+            sparse = e.stage_me_select_next(d_surf, cur_f, prev, 30)
+            want = oracle.me_select(o_surf, cur_f, W // 16, H // 16, 16, 30, threads=8)
+            assert mbinfo_equal(sparse, dense, IMV_FIELDS) and mbinfo_equal(sparse, want, IMV_FIELDS), (it, rows)
+            copied += int((sparse == cur_f).sum())
+            prev, cur_f = cur_f, sparse
+        assert copied > 0
+    finally:
+        oracle.set_slice_rows(0)
+    e.close()
+
+
 @pytest.mark.parametrize("w,h,rows", [(64, 64, 4), (176, 144, 4), (320, 192, 8), (1280, 720, 12), (1920, 1088, 16), (1920, 1088, 20), (1920, 1088, 4)])
 @pytest.mark.parametrize("qp", [20, 34, 51])
 @pytest.mark.parametrize("mode", [0, 1])
