@@ -219,7 +219,10 @@ int mi355enc_abi_version(void);
 
 /* ---- inspection of the last collected picture (parity tests) ----------------------
  * Copies device state to host: coded-size planes (stride = 16*mb_width), the 16-byte
- * per-macroblock records and the 408 int16 levels per macroblock (layout: DESIGN.md). */
+ * per-macroblock records and the 408 int16 levels per macroblock (layout: DESIGN.md).
+ * MI355ENC_FETCH_MBINFO returns the records as they were handed to the entropy coder.  With adaptive quantisation (aq_mode 1) the `qp` byte of a macroblock that sends
+ * no mb_qp_delta (P_Skip, or no coded block and not Intra_16x16) is NOT defined there: the deblocking launch's QP_Y chain rewrites it on the device (7.4.5: the QP_Y of the
+ * macroblock before it) while the hand-over copies the records, and the entropy coder never reads it -- take `qp` only from macroblocks that send a delta. */
 enum { MI355ENC_FETCH_RECON_Y = 0, MI355ENC_FETCH_RECON_UV = 1, MI355ENC_FETCH_PREFILTER_Y = 2,
        MI355ENC_FETCH_PREFILTER_UV = 3, MI355ENC_FETCH_MBINFO = 4, MI355ENC_FETCH_LEVELS = 5 };
 int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t dst_bytes);
