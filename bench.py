@@ -469,9 +469,9 @@ def main():
         # refinement = cur luma P + reference window P + 16 B/MB record read and written = 2.125 P; one vector-selection
         # iteration = the macroblock's SAD surface read once (35 x 36 uint16) + the three neighbours' vectors + its own 8-byte
         # result = 2552 B/MB = 9.97 P (the stage this design adds to make the motion search's HBM output do the regularising).
-        ALG = {"me_kernel": 2.03125, "me_select_kernel (one of %d iterations)" % 3: 2552.0 / 256, "subpel_kernel": 2.125, "inter_kernel": 7.5625,
+        SEL = "vector selection: me_select_kernel (first pass, every surface) + 2 x me_select_sparse_kernel (later passes: changed macroblocks only)"
+        ALG = {"me_kernel": 2.03125, SEL: 2552.0 / 256, "subpel_kernel": 2.125, "inter_kernel": 7.5625,
                "intra (analyse + x+y wavefront)": 6.0625, "deblock (prep + band kernel)": 3.0625}
-        SEL = "me_select_kernel (one of %d iterations)" % 3
         # what THIS design moves per launch where that differs from the survey's figure: me_kernel also writes the SAD surfaces (2520 B/MB) and the
         # source copy the next picture searches against -- traffic is to be compared with this one
         DESIGN = {"me_kernel": 3.0 + 2528.0 / 256}
@@ -480,12 +480,13 @@ def main():
         fused = not args.dct8x8  # the 8x8-transform path keeps subpel_kernel + inter_kernel
         ALG[FUSED] = 7.5625      # the inter stage's bytes; probe and refinement re-read the same reference window
         pmb_ms = st.ms_inter - st.ms_analyse_p - st.ms_intra_p if fused else st.ms_inter
-        per = {"me_kernel": (st.ms_me, st.n_me), SEL: (st.ms_select / 3.0, st.n_me), "subpel_kernel": (st.ms_subpel, 0 if fused else st.n_me),
+        # (the selection's three passes are bracketed by one event pair: one entry for the three launches of a picture)
+        per = {"me_kernel": (st.ms_me, st.n_me), SEL: (st.ms_select, st.n_me), "subpel_kernel": (st.ms_subpel, 0 if fused else st.n_me),
                ("inter_kernel" if not fused else FUSED): (pmb_ms, st.n_inter),
                "intra (analyse + x+y wavefront)": (st.ms_intra, st.n_intra), "deblock (prep + band kernel)": db_p}
         bound = {"me_kernel": "VALU SAD issue rate (~142 T abs-diff/s chip-wide, tools/ubench_sad.hip): 1089*P abs-diffs -> >=17.6 us @1080p; besides the survey's "
                               "2.03 P it writes the 9.84 P of SAD surfaces (2520 B per macroblock) that the selection iterations and the fused stage read",
-                 SEL: "HBM / Infinity Cache: streams every macroblock's SAD surface once per iteration",
+                 SEL: "first pass: HBM / Infinity Cache (streams every macroblock's SAD surface once); later passes: latency of the few changed macroblocks' surface reads (a wave checks eight macroblocks and walks the changed ones)",
                  "subpel_kernel": "LDS-staged 6-tap planes, latency/LDS", "inter_kernel": "launch + byte stores of interleaved chroma",
                  FUSED: "VALU issue: one wave per macroblock (skip probe; 6-tap planes, 8 SAD + 9 SATD candidates; transforms on all 64 lanes; decimation)",
                  "intra (analyse + x+y wavefront)": "dependency chain: Intra_4x4's left-neighbour dependency lets a macroblock start 4 block sub-steps (~0.8 us each) after the one before it, "
@@ -498,7 +499,7 @@ def main():
                     "deblock (prep + band kernel)": "deblock_rows3_kernel"}
         kernels = []
         n_idr, n_p = int(st.idr_frames), int(st.frames - st.idr_frames - st.skip_pictures)
-        weight = {"me_kernel": n_p, SEL: 3 * n_p, "subpel_kernel": n_p, "inter_kernel": n_p, FUSED: n_p, "intra (analyse + x+y wavefront)": n_idr,
+        weight = {"me_kernel": n_p, SEL: n_p, "subpel_kernel": n_p, "inter_kernel": n_p, FUSED: n_p, "intra (analyse + x+y wavefront)": n_idr,
                   "deblock (prep + band kernel)": n_idr + n_p}  # launches in the timed region (timers are sampled)
         db_i_avg = st.ms_deblock_idr / st.n_deblock_idr if st.n_deblock_idr else 0.0
         if n_p and st.n_deblock_idr:  # deblocking of P pictures is the roofline entry; IDR pictures are added to the total separately
@@ -512,12 +513,17 @@ def main():
             us = ms / n * 1e3
             pk = (prof or {}).get(pmc_name.get(name, ""), {})
             alg_bytes, alg_note = ALG[name] * P, None
+            if name == SEL and prof:  # the three launches of a picture together: the dense first pass + two sparse ones
+                d_, s_ = prof.get("me_select_kernel", {}), prof.get("me_select_sparse_kernel", {})
+                if d_.get("hbm_bytes_per_launch_corrected") and s_.get("hbm_bytes_per_launch_corrected"):
+                    pk = {"hbm_bytes_per_launch_corrected": d_["hbm_bytes_per_launch_corrected"] + 2 * s_["hbm_bytes_per_launch_corrected"],
+                          "kernel_trace_avg_us": round(d_.get("kernel_trace_avg_us", 0) + 2 * s_.get("kernel_trace_avg_us", 0), 3) if d_.get("kernel_trace_avg_us") and s_.get("kernel_trace_avg_us") else None}
             if name == SEL:
                 # The selection copies a macroblock whose four predictor values did not change (24 bytes instead of its 2520-byte surface), so what a launch has to
                 # read depends on the content: the upper bound (every surface, 9.97 P) is what iteration 1 reads; the mean over the three iterations is taken from
                 # the committed counter pass of this workload (profiles/*pmc_hbm_traffic*), never from bytes that were not moved.
                 if pk.get("hbm_bytes_per_launch_corrected"):
-                    alg_bytes, alg_note = float(pk["hbm_bytes_per_launch_corrected"]), "data-dependent: bytes = mean memory-side traffic per launch of the committed PMC pass (unchanged macroblocks are copied, their surfaces not read); upper bound %d B (every surface)" % int(ALG[name] * P)
+                    alg_bytes, alg_note = float(pk["hbm_bytes_per_launch_corrected"]), "data-dependent: bytes = memory-side traffic of a picture's three selection launches in the committed PMC pass (first pass + 2 x later pass: unchanged macroblocks are copied, their surfaces not read); the first pass alone reads every surface: %d B" % int(ALG[name] * P)
                 else:
                     alg_note = "upper bound (every surface read); no PMC pass of this workload under profiles/ to take the mean from"
             ach = alg_bytes / (us * 1e-6) / 1e9
@@ -578,7 +584,7 @@ def main():
                        "rate_control": ("fixed qp %d" % args.fixed_qp) if args.fixed_qp >= 0 else ("cbr %d bit/s" % bps) if not script else
                        "cbr, setpoint driven by the reference's '%s' balancer script (%d..%d kbit/s, tests/golden/balancer_%s.txt)" % (
                            script_name, min(b for _, b in script) // 1000, max(b for _, b in script) // 1000, script_name),
-                       "me": "full search +-16 integer-pel SAD (surfaces kept) + %d median-regularised selection iterations + half-sample SAD / quarter-sample SATD refinement" % 3, "streams_per_gpu": S, "hip_streams_per_encoder": 1 if ((S >= 2) if args.single_stream < 0 else bool(args.single_stream)) else 4, "parallelism": "%d independent streams" % (world * S),
+                       "me": "full search +-16 integer-pel SAD (surfaces kept) + 3 median-regularised selection iterations + half-sample SAD / quarter-sample SATD refinement", "streams_per_gpu": S, "hip_streams_per_encoder": 1 if ((S >= 2) if args.single_stream < 0 else bool(args.single_stream)) else 4, "parallelism": "%d independent streams" % (world * S),
                        "pipeline_depth": args.depth, "exclusive_device": bool(S == 1 and not shared_gpu), "devices_on_box": n_dev, "ranks_share_devices": bool(world > n_dev),
                        "rank0_cpus": rank_cpus if world > 1 else None, "rank0_numa_node": int(os.environ.get("MI355_BENCH_NUMA_NODE", "-1")), "dct8x8": bool(args.dct8x8), "i8x8": bool(args.i8x8), "aq_mode": int(args.aq), "cavlc_threads": int(st.cavlc_threads),
                        "p_slice_rows": int(p_rows), "i_slice_rows": int(i_rows), "slices_per_p_picture": (coded(height) // 16 + p_rows - 1) // p_rows if p_rows else 1,

@@ -98,6 +98,8 @@ DEV void store_imv(imv_t *dst, unsigned best, int lambda, int px, int py, int sx
     stg64(dst, make_uint2(((unsigned)(uint16_t)(4 * bx)) | ((unsigned)(uint16_t)(4 * by) << 16), sad | (bits << 16))); // quarter-sample units
 }
 
+// (r04 A/B: capping the resident waves per SIMD at 6 / 4 / 2 -- so that workgroups start staggered and the staging and surface stores of some run beside the SAD loop of
+// others -- gave 34.9 / 36.3 / 40.6 us alone against 34.8, and -2 ... +3 % frames/s in the stream, inside the noise: the loop is at the issue ceiling either way.)
 __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, int row0) { // context by value: lives in the kernarg segment, no per-picture upload
     const frame_ctx_t *__restrict__ ctx = &cv;
     if (blockIdx.x == 0) tl_first(ctx, 0);
