@@ -464,6 +464,20 @@ def main():
                 prof = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["kernels"]
         except Exception:
             prof = None
+        # ... and the kernel trace itself (profiles/*kernel_stats_<workload>.csv: one row per template instantiation).  A kernel's launch time is compared with the instantiation
+        # that ran most often in the traced command -- for the fused P stage and the deblocking launch that is the free-running one, which waits on the device for the rows /
+        # bands it follows and is what the stage timers of a free-running sampled picture bracket as well.
+        trace_rows = {}
+        try:
+            import csv as _csv, re as _re
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("kernel_stats_%s.csv" % args.workload))
+            if cands:
+                for row in _csv.DictReader(open(os.path.join(ROOT, "profiles", cands[-1]))):
+                    m = _re.match(r"^_Z(\d+)", row["Name"])
+                    short = row["Name"][m.end():m.end() + int(m.group(1))] if m else row["Name"]
+                    trace_rows.setdefault(short, []).append((int(row["Calls"]), float(row["TotalDurationNs"]) / int(row["Calls"]) / 1e3, row["Name"].replace(".kd", "")))
+        except Exception:
+            trace_rows = {}
         P = coded(width) * coded(height)
         # SURVEY.md 8(d) algorithmic bytes per launch (P = coded luma pixels).  Kernels the survey has no line for: sub-pel
         # refinement = cur luma P + reference window P + 16 B/MB record read and written = 2.125 P; one vector-selection
@@ -527,11 +541,15 @@ def main():
                 else:
                     alg_note = "upper bound (every surface read); no PMC pass of this workload under profiles/ to take the mean from"
             ach = alg_bytes / (us * 1e-6) / 1e9
-            tr_us = pk.get("kernel_trace_avg_us")
+            tr_us, tr_inst = pk.get("kernel_trace_avg_us"), None
+            rows_ = trace_rows.get(pmc_name.get(name, ""), [])
+            if rows_ and name != SEL:  # the instantiation launched most often in the traced command
+                calls_, tr_us, tr_inst = max(rows_)
+                tr_us = round(tr_us, 3)
             k = {"kernel": name, "launches_timed": int(n), "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": int(alg_bytes),
                  "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                  "design_bytes_per_launch": int(DESIGN.get(name, ALG[name]) * P),
-                 "traffic": pk.get("hbm_bytes_per_launch_corrected"), "kernel_trace_avg_us": tr_us,
+                 "traffic": pk.get("hbm_bytes_per_launch_corrected"), "kernel_trace_avg_us": tr_us, "kernel_trace_instantiation": tr_inst,
                  # the same fraction from the committed kernel trace's mean launch time (profiles/*kernel_stats*: what a reader can recompute without this run)
                  "frac_from_kernel_trace": round(alg_bytes / (tr_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if tr_us else None,
                  "time_share": round(weight[name] * (ms / n) / est_total, 4), "bounded_by": bound[name]}

@@ -183,6 +183,8 @@ int enqueue_picture(mi355enc_t *h, slot_t *s, const uint8_t *src_y, const uint8_
         // front stream: the source is in place (upload / conversion were enqueued there); P pictures: search, selection, gated intra
         // analysis; I pictures: only the padded source copy the next picture's search will run against
         if (c->qp_off) k_launch_aq(c, h->d_qp_off[set], h->fstream); // adaptive quantisation: the offsets of this picture's macroblocks
+        // (r04 tried the IDR picture's open-loop analysis on the front stream as well -- it needs nothing but the source: all-intra 3 469 -> 3 463 frames/s, the flat analysis
+        // launch beside the previous picture's rows kernel slows that kernel by what it saves; not kept.)
         if (idr) k_launch_copy_luma(c, h->fstream);
         else { int r = run_p_front(h, c, s, prof); if (r) return r; }
         HIPCHK(hipEventRecord(s->ev_front, h->fstream));
