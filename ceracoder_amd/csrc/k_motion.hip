@@ -240,7 +240,9 @@ __global__ __launch_bounds__(256) void me_select_kernel(const frame_ctx_t cv, in
 // 8 160 waves (32 400 at 2160p) on reading predictors.  Here a wave takes SEL_SPW consecutive macroblocks: lanes 0 .. SEL_SPW-1 each check one (both fields' predictors,
 // per-lane addresses), copy the unchanged ones, and the wave then walks the changed ones with all 64 lanes on the surface as above.  Same result bit for bit (the test
 // is the same, the selection is the same function); an eighth of the waves, and almost none of them long.
+#ifndef SEL_SPW /* (A/B on hardware, alternating processes: 4 per wave 0.99 x, 16 per wave 1.06 x in one noisy pair at 1080p and 1.00 x at 2160p: 8 stays) */
 #define SEL_SPW 8
+#endif
 __global__ __launch_bounds__(256) void me_select_sparse_kernel(const frame_ctx_t cv, int mb0, int mb1, const imv_t *__restrict__ in, imv_t *__restrict__ out, const imv_t *__restrict__ prev) {
     const frame_ctx_t *__restrict__ ctx = &cv;
     const int mbw = ctx->mbw;
@@ -1031,7 +1033,10 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
             for (;;) {
                 const uint2 f = ld64_sc1(flags + b);
                 if (f.x == ref_epoch && f.y == ref_epoch) { if (++b > b_hi) break; continue; }
-                __builtin_amdgcn_s_sleep(64);
+#ifndef PMB_POLL_SLEEP /* (A/B: 16 and 127 give 1.00 x at 1080p, 127 gives 1.01 x at 2160p: the back-off between polls is not where the time goes) */
+#define PMB_POLL_SLEEP 64
+#endif
+                __builtin_amdgcn_s_sleep(PMB_POLL_SLEEP);
                 if (++spins > DB_SPIN_MAX) { st_sc1(err, 3u); break; }
                 if ((spins & 255) == 0 && ld_sc1(err)) break; // somebody else gave up: nobody waits again // bounded; the host reports the picture as failed
             }

@@ -32,6 +32,15 @@ bench)
     grep '^{' gpurun_out/final/bench_$wl.log | tail -1 > profiles/r0${RND}_bench_$wl.json
     echo "bench $wl done"
   done
+  # the toolset the reference's own files select (speed-preset=2: dct8x8 + i8x8 + aq-mode 1), and the all-intra workload at the headline's quantiser instead of the ladder's floor
+  for wl in 1080p_ippp 2160p_ippp; do
+    timeout -k 10 300 python bench.py --workload $wl --dct8x8 1 --i8x8 1 --aq 1 --no-gst-latency --no-cpu-baseline > gpurun_out/final/bench_${wl}_preset2.log 2>&1
+    grep '^{' gpurun_out/final/bench_${wl}_preset2.log | tail -1 > profiles/r0${RND}_bench_${wl}_preset2.json
+    echo "bench $wl preset2 done"
+  done
+  timeout -k 10 300 python bench.py --workload 1080p_intra --fixed-qp 31 --no-gst-latency --no-cpu-baseline > gpurun_out/final/bench_1080p_intra_qp31.log 2>&1
+  grep '^{' gpurun_out/final/bench_1080p_intra_qp31.log | tail -1 > profiles/r0${RND}_bench_1080p_intra_qp31.json
+  echo "bench 1080p_intra qp31 done"
   for s in 2 4 8; do
     timeout -k 10 300 python bench.py --streams-per-gpu $s --no-gst-latency --no-cpu-baseline > gpurun_out/final/bench_1080p_ippp_streams$s.log 2>&1
     grep '^{' gpurun_out/final/bench_1080p_ippp_streams$s.log | tail -1 > profiles/r0${RND}_bench_1080p_ippp_streams$s.json
