@@ -222,7 +222,7 @@ def main():
     ap.add_argument("--dct8x8", type=int, default=0, help="1: High profile, 8x8 transform for P macroblocks (x264enc dct8x8)")
     ap.add_argument("--i8x8", type=int, default=0, help="1 (with --dct8x8 1): Intra_8x8 macroblocks in I pictures (picture QP <= 37)")
     ap.add_argument("--aq", type=int, default=0, help="1: adaptive quantisation (aq-mode 1)")
-    ap.add_argument("--single-stream", type=int, default=-1, help="1: every encoder runs its stages in order on ONE HIP stream (cfg.single_stream); -1: automatic (two or more streams per GPU: 2 streams 4 170 -> 4 840 frames/s in r04)")
+    ap.add_argument("--single-stream", type=int, default=-1, help="1: every encoder runs its stages in order on ONE HIP stream (cfg.single_stream); -1: automatic (two or more streams per GPU: 2 streams 4 170 -> 4 840 frames/s in r04; ranks sharing a GPU: two ranks 5 771 -> 6 282)")
     ap.add_argument("--slices", type=int, default=-1, help="slices per P picture (cfg.slices: 0 automatic, 1 one slice); -1: the library's default (automatic: 4 at 1080p)")
     ap.add_argument("--slice-deblock", type=int, default=-1, help="1: the deblocking filter stops at slice boundaries (disable_deblocking_filter_idc 2), 0: runs across them; -1: the library's default (1)")
     args = ap.parse_args()
@@ -296,7 +296,7 @@ def main():
     def make_encoder():
         return E.Encoder(width, height, fps=fps, gop=gop, bitrate_bps=bps, device_id=dev, fixed_qp=args.fixed_qp,
                          pipeline_depth=args.depth, profile_events=args.sample, use_graphs=not args.no_graphs, deblock_mode=args.deblock_mode,
-                         cavlc_threads=args.cavlc_threads, **tools, exclusive=(S == 1 and not shared_gpu), single_stream=(S >= 2) if args.single_stream < 0 else bool(args.single_stream), profile_overlap=not args.sample_in_order)
+                         cavlc_threads=args.cavlc_threads, **tools, exclusive=(S == 1 and not shared_gpu), single_stream=(S >= 2 or shared_gpu) if args.single_stream < 0 else bool(args.single_stream), profile_overlap=not args.sample_in_order)
 
     encs = [make_encoder() for _ in range(S)]
     e = encs[0]
@@ -602,7 +602,7 @@ def main():
                        "rate_control": ("fixed qp %d" % args.fixed_qp) if args.fixed_qp >= 0 else ("cbr %d bit/s" % bps) if not script else
                        "cbr, setpoint driven by the reference's '%s' balancer script (%d..%d kbit/s, tests/golden/balancer_%s.txt)" % (
                            script_name, min(b for _, b in script) // 1000, max(b for _, b in script) // 1000, script_name),
-                       "me": "full search +-16 integer-pel SAD (surfaces kept) + 3 median-regularised selection iterations + half-sample SAD / quarter-sample SATD refinement", "streams_per_gpu": S, "hip_streams_per_encoder": 1 if ((S >= 2) if args.single_stream < 0 else bool(args.single_stream)) else 4, "parallelism": "%d independent streams" % (world * S),
+                       "me": "full search +-16 integer-pel SAD (surfaces kept) + 3 median-regularised selection iterations + half-sample SAD / quarter-sample SATD refinement", "streams_per_gpu": S, "hip_streams_per_encoder": 1 if ((S >= 2 or shared_gpu) if args.single_stream < 0 else bool(args.single_stream)) else 4, "parallelism": "%d independent streams" % (world * S),
                        "pipeline_depth": args.depth, "exclusive_device": bool(S == 1 and not shared_gpu), "devices_on_box": n_dev, "ranks_share_devices": bool(world > n_dev),
                        "rank0_cpus": rank_cpus if world > 1 else None, "rank0_numa_node": int(os.environ.get("MI355_BENCH_NUMA_NODE", "-1")), "dct8x8": bool(args.dct8x8), "i8x8": bool(args.i8x8), "aq_mode": int(args.aq), "cavlc_threads": int(st.cavlc_threads),
                        "p_slice_rows": int(p_rows), "i_slice_rows": int(i_rows), "slices_per_p_picture": (coded(height) // 16 + p_rows - 1) // p_rows if p_rows else 1,

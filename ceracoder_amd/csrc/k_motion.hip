@@ -57,6 +57,9 @@ DEV fpred_t field_pred(const imv_t *__restrict__ f, int mbw, int mx, int my, boo
 // key = cost << 12 | (dy+16) << 6 | (dx+16), cost = SAD + lambda * (bits(dx - px) + bits(dy - py) + SEL_BONUS) -- the candidate
 // equal to the skip inference (sx, sy) is charged nothing; ties resolve to the first candidate in (dy, dx) raster order.
 // px .. sy in whole samples.
+// ZERO (the search's own first selection: all four predictors are zero): the skip candidate is handled once, by the one lane that holds (0, 0), behind the loop --
+// charged nothing it can only lower that candidate's key, so the minimum is the one the replacement inside the loop gives.
+template <bool ZERO = false>
 DEV unsigned select_min(const unsigned long long *acc, int g, int dxg, bool active, int R, int lambda, int px, int py, int sx, int sy) {
     const unsigned INVALID = 0x40000000u;
     unsigned bo[4];
@@ -77,19 +80,19 @@ DEV unsigned select_min(const unsigned long long *acc, int g, int dxg, bool acti
         unsigned k[4];
 #pragma unroll
         for (int o = 0; o < 4; o++) {
-            const bool is_skip = dy == sy && so == o && active; // in range by construction: a median of in-range vectors
+            const bool is_skip = !ZERO && dy == sy && so == o && active; // in range by construction: a median of in-range vectors
             k[o] = is_skip ? (s[o] | pos | (unsigned)(sx + 16)) : s[o] + bd + bo[o];
         }
         unsigned ka = k[0] < k[1] ? k[0] : k[1], kb = k[2] < k[3] ? k[2] : k[3];
         ka = ka < kb ? ka : kb;
         best = best < ka ? best : ka;
     }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-        unsigned o = (unsigned)__shfl_xor((int)best, sft, 64);
-        best = best < o ? best : o;
+    if (ZERO && active && ME_K * g <= 16 && 16 < ME_K * g + ME_K && dxg == 4) { // dy = -16 + ME_K g + d = 0, dx = -16 + 4 dxg + 0 = 0
+        const unsigned long long a = acc[16 - ME_K * (16 / ME_K)];
+        const unsigned k0 = (((unsigned)a << 16) >> 4) | (16u << 6) | 16u;
+        best = best < k0 ? best : k0;
     }
-    return best;
+    return wave64_umin(best);
 }
 DEV void store_imv(imv_t *dst, unsigned best, int lambda, int px, int py, int sx, int sy) {
     const int bx = (int)(best & 63) - 16, by = (int)((best >> 6) & 63) - 16;
@@ -117,7 +120,12 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
         int row = i / ME_WQ, q = i - row * ME_WQ;
         const int gy = clip3(0, H - 1, my * 16 - 16 + row), gx = sx * (ME_MBS * 16) - 16 + 16 * q;
         uint4 v;
+#ifdef ME_DBG_NOSTAGE
+        v = make_uint4(i, i, i, i);
+        if (gx != -12345) {}
+#else
         if (gx >= 0 && gx < W) v = ldg128(ref + (size_t)gy * stride + gx);
+#endif
         else { const unsigned e = ldg8(ref + (size_t)gy * stride + (gx < 0 ? 0 : W - 1)) * 0x01010101u; v = make_uint4(e, e, e, e); }
         unsigned *d = &win[row * ME_STRIDE + 4 * q];
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -138,15 +146,25 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
         const int ss = ctx->src_stride, vh = ctx->vis_h;
         // wave-uniform, so they live in SGPRs (v_qsad takes one scalar source): 64 VGPRs less, 8 waves per SIMD instead of 5 -- every workgroup of a
         // 1080p picture is resident at once (36.1 -> 35.2 us alone, 2160p 130 -> 123)
+        // ... and arrive there through the scalar cache: 16 s_load_dwordx4 instead of 16 vector loads of one address and 64 v_readfirstlane (r04: 118 -> ... us at 2160p)
         const int mu = __builtin_amdgcn_readfirstlane(mxc);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             int sy = my * 16 + r;
             sy = sy < vh ? sy : vh - 1;
-            const uint4 v = ldg128(src + (size_t)sy * ss + mu * 16);
-            if (lane == r && mx < mbw) stg128(ctx->psrc_out + (size_t)(my * 16 + r) * stride + mu * 16, v); // the next picture searches against this
+#ifdef ME_DBG_NOCUR
+            const uint4 v = make_uint4(sy, mu, r, sy ^ mu);
+#else
+            const uint4 v = ldc128(src + (size_t)sy * ss + mu * 16);
+#endif
             c[r][0] = __builtin_amdgcn_readfirstlane(v.x); c[r][1] = __builtin_amdgcn_readfirstlane(v.y);
             c[r][2] = __builtin_amdgcn_readfirstlane(v.z); c[r][3] = __builtin_amdgcn_readfirstlane(v.w);
+        }
+        // (behind the scalar loads: in front of them the compiler merges their address terms with this branch's through VGPRs and the loads turn into vector loads)
+        if (lane < 16 && mx < mbw) { // the next picture searches against this: lane r copies row r
+            int sy = my * 16 + lane;
+            sy = sy < vh ? sy : vh - 1;
+            stg128(ctx->psrc_out + (size_t)(my * 16 + lane) * stride + mu * 16, ldg128(src + (size_t)sy * ss + mu * 16));
         }
     }
     __syncthreads();
@@ -197,7 +215,11 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
         for (int d = 0; d < ME_K; d++) stg64(sf + (ME_K * g + d) * SURF_COLS, make_uint2((unsigned)acc[d], (unsigned)(acc[d] >> 32)));
     }
     // ---- first selection: bits against the zero vector
-    const unsigned best = select_min(acc, g, dxg, active, ctx->me_range, ctx->lambda, 0, 0, 0, 0);
+#ifdef ME_DBG_NOSEL
+    const unsigned best = ((((unsigned)acc[0] ^ (unsigned)acc[4]) & 0x0FFFu) << 12) | 0x410u; // (the zero vector: nothing downstream leaves its window)
+#else
+    const unsigned best = select_min<true>(acc, g, dxg, active, ctx->me_range, ctx->lambda, 0, 0, 0, 0);
+#endif
     if (lane == 0 && mx < mbw) store_imv(&ctx->imv_a[my * mbw + mx], best, ctx->lambda, 0, 0, 0, 0);
     tl_last(ctx, 1);
 }

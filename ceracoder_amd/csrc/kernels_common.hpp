@@ -71,6 +71,8 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 DEV uint2 ldg64(const void *p) { const v2u v = *(const GAS v2u *)p; return make_uint2(v.x, v.y); }
 DEV uint2 ldg64x(const void *p) { return make_uint2(*(const GAS unsigned *)p, *((const GAS unsigned *)p + 1)); } // 4-byte aligned pair
 DEV uint4 ldg128(const void *p) { const v4u v = *(const GAS v4u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+// 16 bytes at a wave-uniform address of memory nothing writes while the kernel runs, through the scalar cache (s_load_dwordx4: the result is in SGPRs, no VMEM, no VALU)
+DEV uint4 ldc128(const void *p) { const v4u v = *(const __attribute__((address_space(4))) v4u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
 DEV int ldg16(const void *p) { return *(const GAS int16_t *)p; }
 DEV void stg8(void *p, unsigned v) { *(GAS uint8_t *)p = (uint8_t)v; }
 DEV void stg16(void *p, int v) { *(GAS int16_t *)p = (int16_t)v; }
@@ -291,6 +293,16 @@ DEV int wave64_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast:15 into rows 1 and 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast:31 into rows 2 and 3
     return __builtin_amdgcn_readlane(v, 63);
+}
+// minimum over the whole wave, returned uniformly: the same DPP ladder (six v_min_u32_dpp and a readlane instead of six LDS-crossbar shuffles)
+DEV unsigned wave64_umin(unsigned v) {
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x128, 0xF, 0xF, false)); // row_ror:8
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x124, 0xF, 0xF, false)); // row_ror:4
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xF, 0xF, false));  // quad_perm:[2,3,0,1]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xF, 0xF, false));  // quad_perm:[1,0,3,2]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xA, 0xF, false)); // row_bcast:15 into rows 1 and 3
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xC, 0xF, false)); // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 // lane ^ 4 / lane ^ 12 inside a row of 16 lanes, two DPP moves each: quad reversal (lane ^ 3) followed by the half-row mirror
 // (lane ^ 7) or the row mirror (lane ^ 15)

@@ -170,7 +170,8 @@ def test_per_diagonal_deblocker_and_the_writer_threads_with_slices(E, oracle):
         _run_stream(E, oracle, 640, 368, 5, [28, 32, 26], 4, True, mode=0, thr=thr, depth=1)
 
 
-@pytest.mark.parametrize("w,h,n,depth", [(1280, 720, 5, 0), (1920, 1080, 5, 2), (3840, 2160, 3, 2), (640, 368, 5, 1)])
+@pytest.mark.parametrize("w,h,n,depth", [(1280, 720, 5, 0), (1920, 1080, 5, 2), (3840, 2160, 3, 2), (640, 368, 5, 1), (16, 16, 4, 2), (48, 32, 4, 0), (176, 144, 5, 2), (352, 288, 5, 2), (720, 576, 5, 1),
+                                       (1920, 1200, 4, 2), (2560, 1440, 4, 2), (854, 480, 5, 2), (4096, 2304, 3, 2)])
 def test_library_defaults_are_sliced_and_equal_oracle(E, oracle, w, h, n, depth):
     """mi355enc_default_cfg (what the element and bench.py get; this mirror's own defaults keep the one-slice P pictures of rounds 1-3): P pictures cut like I
     pictures -- about 17 macroblock rows per slice, rounded up to whole deblocking bands -- with slice-local deblocking.  Same stream as the oracle told the same."""
