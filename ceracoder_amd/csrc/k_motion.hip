@@ -750,11 +750,23 @@ DEV unsigned part_gsum(unsigned v) { // sum over the lanes of this lane's quadra
     return v;
 }
 DEV unsigned part_total(unsigned g) { g += (unsigned)quad_xor<2>((int)g); return g + (unsigned)__shfl_xor((int)g, 32, 64); } // the four quadrants' sums -> the macroblock's
+// development builds (-DPMB_PROF, tests/devtools/pmb_phases.py): cycles a wave spends between the marks below, left per macroblock in ctx->dbrec (word 16 mbn + k; 0: the wave never reached mark k)
+#ifdef PMB_PROF
+#define PMB_NPH 11
+#define PMB_MARK(k) do { const unsigned long long t1_ = __builtin_readcyclecounter(); ph_[k] = t1_ - t0_; t0_ = t1_; } while (0)
+#define PMB_MARK0() unsigned long long ph_[PMB_NPH] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long t0_ = __builtin_readcyclecounter()
+#define PMB_FLUSH() do { if (lane == 0) for (int k_ = 0; k_ < PMB_NPH; k_++) stg32((unsigned *)ctx->dbrec + (size_t)mbn * 16 + k_, (unsigned)ph_[k_]); } while (0)
+#else
+#define PMB_MARK(k) ((void)0)
+#define PMB_MARK0() ((void)0)
+#define PMB_FLUSH() ((void)0)
+#endif
 template <bool SC1, bool PART, bool T8>
 DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, const int lane, const int refine) {
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = mb_qp_dev(ctx, mbn), lambda = ctx->lambda; // (quantisation only: search, refinement and decisions keep the picture's lambda)
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
     const dev_tables *T = &g_tab;
+    PMB_MARK0();
     const imv_t *__restrict__ field = k_final_imv_dev(ctx);
     const uint2 selfw = ldg64(field + mbn);
     const int imx = (int)(int16_t)(selfw.x & 0xFFFF), imy = (int)(int16_t)(selfw.x >> 16); // whole-sample winner, quarter-sample units
@@ -785,6 +797,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
         const unsigned ds = (unsigned)*(const GAS uint16_t *)(ctx->surf + (size_t)mbn * SURF_U16 + ((fp.sy >> 2) + 16) * SURF_COLS + (fp.sx >> 2) + 16);
         bool pass = ctx->drop_sad && ds < ctx->drop_sad;
         const bool worth = ds <= di + (unsigned)(lambda * SKIP_MARGIN_BITS);
+        PMB_MARK(0); // the field, the predictors and the skip candidate's SAD have arrived
         if (pass || worth) {
             const int X = x0 + (fp.sx >> 2), Y = y0 + (fp.sy >> 2);
             const bool inside = X >= 0 && Y >= 0 && X + 16 <= W && Y + 16 <= H;
@@ -799,6 +812,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
                     pass = (nz_c | dc_c) == 0;
                 }
             }
+            PMB_MARK(1); // skip probe: prediction loaded, transformed, decided
             if (pass) {
                 pmb_store_pred_only<SC1>(ctx, lv, lane, x0, y0, pw, pd);
                 if (lane == 0) {
@@ -806,6 +820,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
                     m.mvx = (int16_t)fp.sx; m.mvy = (int16_t)fp.sy; m.mb_type = 1; m.i16_mode = 0; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = di;
                     st_mbinfo_x<SC1>(mb, m);
                 }
+                PMB_FLUSH();
                 return;
             }
         }
@@ -828,6 +843,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
             L->G[r * SP_GS + c] = (uint8_t)ldg8(ref + (size_t)yy * stride + xx);
         }
     WAVE_SYNC();
+    PMB_MARK(2); // the refinement's window is in LDS
     int bqx = imx, bqy = imy;
     // the whole-sample winner's SAD against the REFERENCE (the surface holds its SAD against the previous source: the search runs
     // source against source)
@@ -840,8 +856,10 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
     } else
         best = (unsigned)wave64_sum((int)__builtin_amdgcn_sad_u8(curw, sp_sample4(L, 1 + pc, 1 + pr, 0, 0), 0u)) +
                (unsigned)(lambda * (mvq_bits(imx - fp.px) + mvq_bits(imy - fp.py)));
+    PMB_MARK(3); // the whole-sample winner's SAD against the reference
     if (refine) {
         sp_planes(L, lane);
+        PMB_MARK(4); // half-sample planes
         { // half-sample round: SAD, the 8 candidates scored together (two 16-bit partial sums per register)
             const int cqx = bqx, cqy = bqy;
             unsigned acc[4] = {0, 0, 0, 0};
@@ -868,6 +886,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
             }
         }
         hbx = bqx; hby = bqy;
+        PMB_MARK(5); // half-sample round
         { // quarter-sample round: SATD; the standing best is restated in the same measure first
             const int cqx = bqx, cqy = bqy;
             {
@@ -892,6 +911,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
             }
         }
     }
+    PMB_MARK(6); // quarter-sample round
     // ---- the final vector's prediction and its cost in the SAD domain
     const int ox = bqx - imx, oy = bqy - imy;
     unsigned pw = sp_sample4(L, 1 + (ox >> 2) + pc, 1 + (oy >> 2) + pr, ox & 3, oy & 3);
@@ -950,9 +970,11 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
                 m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = dw.y;
                 st_mbinfo_x<SC1>(mb, m);
             }
+            PMB_FLUSH();
             return;
         }
     }
+    PMB_MARK(7); // final cost, intra test
     // ---- 5. residual
     int pd[4];
     unsigned slot = 0; // PART: this lane's dword of the luma-DC slot (lanes 0 .. 7): the vectors of partitions 1 .. 3
@@ -973,8 +995,10 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
             m.mvx = (int16_t)bqx; m.mvy = (int16_t)bqy; m.mb_type = 1; m.i16_mode = (uint8_t)shape; m.chroma_mode = 0; m.qp = (uint8_t)qp; m.nzmask = 0; m.cost = di;
             st_mbinfo_x<SC1>(mb, m);
         }
+        PMB_FLUSH();
         return;
     }
+    PMB_MARK(8); // chroma prediction loaded
     unsigned nz_luma;
     if (T8) {
         nz_luma = pmb_luma_t8<SC1>(ctx, (int *)L, lane, curw, pw, qp, mbn, x0, y0);
@@ -994,8 +1018,10 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
         for (int i = 0; i < 4; i++) o[i] = clip255(byte_of(pw, i) + ((inv_col(x[i], cb) + 32) >> 6));
         stx32<SC1>(ctx->rec_y + (size_t)(y0 + pr) * stride + x0 + pc, pack4(o[0], o[1], o[2], o[3]));
     }
+    PMB_MARK(9); // luma residual
     unsigned nz_c = 0, dc_c = 0;
     chroma_rows4(ctx, T, lv, x0 >> 1, y0 >> 1, lane, pd, sv, qp, false, true, nullptr, nz_c, dc_c, true, 0, SC1);
+    PMB_MARK(10); // chroma residual
     if (lane == 0) {
         unsigned nzm = nz_luma | (nz_c << 16);
         if (dc_c & 1) nzm |= NZ_CBDC;
@@ -1007,6 +1033,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
     }
     if (PART && shape) { if (lane < 8) stx32<SC1>(lv + L_LDC + 2 * lane, slot); } // the luma-DC slot: the vectors of partitions 1 .. 3 (the deblocker of this picture may read them behind the row counts)
     else if (lane < 2) stg128(lv + L_LDC + 8 * lane, make_uint4(0, 0, 0, 0)); // luma DC levels: unused by P macroblocks, kept zero
+    PMB_FLUSH();
 }
 
 // The launch covers macroblocks mb0 .. mb1-1, four per workgroup and turn.
