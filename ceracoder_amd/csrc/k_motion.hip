@@ -761,32 +761,50 @@ DEV unsigned part_total(unsigned g) { g += (unsigned)quad_xor<2>((int)g); return
 #define PMB_MARK0() ((void)0)
 #define PMB_FLUSH() ((void)0)
 #endif
+// What a macroblock of the fused stage reads that does NOT depend on the reference picture: its vector and its neighbours' (hence the predictors), its source
+// samples, the skip candidate's SAD from the surface and the intra decision.  A gated launch loads these BEFORE its workgroup waits for the reference's bands, so
+// that the two dependent round trips (field -> surface) are over when the gate opens -- they were the first 11 000 of a wave's ~45 000 cycles behind the gate
+// (profiles/r04_pmb_phases.txt), i.e. of the stretch by which a picture's fused stage trails the previous deblocking launch.
+struct pmb_pre_t { uint2 selfw; fpred_t fp; unsigned curw; uint2 sw; unsigned ds; uint4 dw; };
+DEV pmb_pre_t pmb_preload(const frame_ctx_t *__restrict__ ctx, const int mbn, const int lane) {
+    const int mbw = ctx->mbw, my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
+    pmb_pre_t p;
+    const imv_t *__restrict__ field = k_final_imv_dev(ctx);
+    p.selfw = ldg64(field + mbn);
+    {
+        int sy = y0 + (lane >> 2);
+        sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
+        p.curw = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + x0 + (lane & 3) * 4);
+    }
+    {
+        const int cby = (lane >> 4) & 1, cbx = lane & 1;
+        int sy = (y0 >> 1) + cby * 4 + ((lane >> 2) & 3);
+        const int vh2 = ctx->vis_h >> 1;
+        sy = sy < vh2 ? sy : vh2 - 1;
+        p.sw = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * ((x0 >> 1) + cbx * 4));
+    }
+    p.dw = ctx->intra_p ? ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES + 16) : make_uint4(0, 0, 0, 0); // mode16 | cmode << 8 | use_i4 << 16; cost; cost_luma; 0
+    p.fp = field_pred(field, mbw, mx, my, row_has_top(ctx, my));
+    p.ds = (unsigned)*(const GAS uint16_t *)(ctx->surf + (size_t)mbn * SURF_U16 + ((p.fp.sy >> 2) + 16) * SURF_COLS + (p.fp.sx >> 2) + 16);
+    return p;
+}
 template <bool SC1, bool PART, bool T8>
-DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, const int lane, const int refine) {
+DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, const int lane, const int refine, const pmb_pre_t &pre) {
     const int mbw = ctx->mbw, mbh = ctx->mbh, stride = ctx->stride, W = mbw * 16, H = mbh * 16, qp = mb_qp_dev(ctx, mbn), lambda = ctx->lambda; // (quantisation only: search, refinement and decisions keep the picture's lambda)
     const int my = mbn / mbw, mx = mbn - my * mbw, x0 = mx * 16, y0 = my * 16;
     const dev_tables *T = &g_tab;
     PMB_MARK0();
-    const imv_t *__restrict__ field = k_final_imv_dev(ctx);
-    const uint2 selfw = ldg64(field + mbn);
+    const uint2 selfw = pre.selfw;
     const int imx = (int)(int16_t)(selfw.x & 0xFFFF), imy = (int)(int16_t)(selfw.x >> 16); // whole-sample winner, quarter-sample units
     const unsigned di = selfw.y & 0xFFFFu, ibits = selfw.y >> 16;
-    const fpred_t fp = field_pred(field, mbw, mx, my, row_has_top(ctx, my));
+    const fpred_t fp = pre.fp;
     const int pr = lane >> 2, pc = (lane & 3) * 4; // luma: lane owns row pr, columns pc .. pc+3
     const int py = (lane >> 2) & 3;
-    unsigned curw;
-    {
-        int sy = y0 + pr;
-        sy = sy < ctx->vis_h ? sy : ctx->vis_h - 1;
-        curw = ldg32(ctx->src_y + (size_t)sy * ctx->src_stride + x0 + pc);
-    }
+    const unsigned curw = pre.curw;
     int sv[4]; // chroma source samples of this lane (lanes 0..31)
     {
-        const int cby = (lane >> 4) & 1, c = (lane >> 1) & 1, cbx = lane & 1;
-        int sy = (y0 >> 1) + cby * 4 + py;
-        const int vh2 = ctx->vis_h >> 1;
-        sy = sy < vh2 ? sy : vh2 - 1;
-        const uint2 sw = ldg64(ctx->src_uv + (size_t)sy * ctx->src_stride + 2 * ((x0 >> 1) + cbx * 4));
+        const int c = (lane >> 1) & 1;
+        const uint2 sw = pre.sw;
         const unsigned slo = c ? (sw.x >> 8) : sw.x, shi = c ? (sw.y >> 8) : sw.y;
         sv[0] = (int)(slo & 255); sv[1] = (int)((slo >> 16) & 255); sv[2] = (int)(shi & 255); sv[3] = (int)((shi >> 16) & 255);
     }
@@ -794,7 +812,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
     mb_info_t *mb = &ctx->mbi[mbn];
     // ---- 2. skip probe
     {
-        const unsigned ds = (unsigned)*(const GAS uint16_t *)(ctx->surf + (size_t)mbn * SURF_U16 + ((fp.sy >> 2) + 16) * SURF_COLS + (fp.sx >> 2) + 16);
+        const unsigned ds = pre.ds;
         bool pass = ctx->drop_sad && ds < ctx->drop_sad;
         const bool worth = ds <= di + (unsigned)(lambda * SKIP_MARGIN_BITS);
         PMB_MARK(0); // the field, the predictors and the skip candidate's SAD have arrived
@@ -960,7 +978,7 @@ DEV void pmb_mb(const frame_ctx_t *__restrict__ ctx, sp_lds *L, const int mbn, c
     }
     // ---- 4. intra instead?
     if (ctx->intra_p && di + (unsigned)lambda * ibits >= INTRA_GATE(lambda)) {
-        const uint4 dw = ldg128(ctx->idec + (size_t)mbn * IDEC_BYTES + 16); // mode16 | cmode << 8 | use_i4 << 16; cost; cost_luma; 0
+        const uint4 dw = pre.dw;
         const unsigned jintra = dw.z + (dw.z >> 3) + (unsigned)(lambda * 12);
         if (jintra < jinter) {
             if (lane == 0) {
@@ -1061,6 +1079,8 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // an SGPR: what is derived from it is scalar control flow
     const int mbn = mb0 + 4 * (int)blockIdx.x + wave;
     if (mb0 == 0 && blockIdx.x == 0) tl_first(ctx, 2);
+    pmb_pre_t pre;
+    if (mbn < mb1) pre = pmb_preload(ctx, mbn, lane); // (wave-uniform) nothing here reads the reference: issued in front of the gate
     if (GATED) { // wave 0 waits for the bands the workgroup's macroblocks read, the others for wave 0
         if (wave == 0) {
             // EVERY band the window touches, not only the lowest: a band's word says that ITS lines are in memory -- the band above it has
@@ -1095,7 +1115,7 @@ __global__ __launch_bounds__(256) void pmb_kernel(const frame_ctx_t cv, int mb0,
         tl_last(ctx, 3);
     }
     if (mbn >= mb1) return; // wave-uniform
-    pmb_mb<ROWS, PART, T8>(ctx, &LD[wave], mbn, lane, refine);
+    pmb_mb<ROWS, PART, T8>(ctx, &LD[wave], mbn, lane, refine, pre);
     if (ROWS) { // this macroblock's samples and record are in memory: count it for its row (the picture's deblocking launch, already on the chip, waits for whole rows)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(row_done + (mbn / ctx->mbw) * MI355_PROG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
