@@ -155,8 +155,26 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->cstream, hipStreamNonBlocking, hi));
+        // MI355ENC_RESERVE_CUS=n[,mode] (development): the front and the intra stream -- the search, the selection, the fused stage, intra_p_kernel: thousands of
+        // four-wave workgroups that fill every slot that frees up -- stay off n compute units, so that a deblocking launch (34 workgroups of twelve waves at 1080p, each
+        // of which needs an all but empty compute unit) finds room when the launch before it ends instead of when the fused stage has drained.
+        // mode 0: the mask's first n bits, 1: every (256 / n)-th bit.
+        const char *rs = getenv("MI355ENC_RESERVE_CUS");
+        const int nres = rs ? atoi(rs) : 0, rmode = (rs && strchr(rs, ',')) ? atoi(strchr(rs, ',') + 1) : 0;
+        if (nres > 0 && nres < 200) {
+            hipDeviceProp_t pr;
+            HIPCHK(hipGetDeviceProperties(&pr, h->cfg.device_id));
+            const int ncu = pr.multiProcessorCount;
+            uint32_t mask[16];
+            memset(mask, 0, sizeof mask);
+            for (int i = 0; i < ncu && i < 512; i++) mask[i >> 5] |= 1u << (i & 31);
+            for (int k = 0; k < nres; k++) { const int i = rmode == 1 ? (int)((long long)k * ncu / nres) : k; mask[i >> 5] &= ~(1u << (i & 31)); }
+            HIPCHK(hipExtStreamCreateWithCUMask(&h->fstream, (uint32_t)((ncu + 31) / 32), mask));
+            HIPCHK(hipExtStreamCreateWithCUMask(&h->istream, (uint32_t)((ncu + 31) / 32), mask));
+        } else {
         HIPCHK(hipStreamCreateWithPriority(&h->fstream, hipStreamNonBlocking, getenv("MI355ENC_FPRIO") ? atoi(getenv("MI355ENC_FPRIO")) : lo));
         HIPCHK(hipStreamCreateWithPriority(&h->istream, hipStreamNonBlocking, 0));
+        }
         if (h->cfg.pipeline_depth >= 1 && !getenv("MI355ENC_NO_UPSTREAM")) HIPCHK(hipStreamCreateWithFlags(&h->ustream, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&h->ev_pmb, hipEventDisableTiming));
     }
