@@ -522,7 +522,7 @@ def main():
         est_total = (sum(weight[k] * (ms / n) for k, (ms, n) in per.items() if n) + (n_idr * db_i_avg if n_p else 0.0) + n_p * other_p) or 1e-9
         period_us = dt / (S * args.steps) * 1e6
         for name, (ms, n) in per.items():
-            if not n:
+            if not n or ms <= 0:  # (a stage whose timer pair bracketed nothing on the sampled pictures: e.g. the stand-alone selection timer when adaptive quantisation reorders the front stream's records)
                 continue
             us = ms / n * 1e3
             pk = (prof or {}).get(pmc_name.get(name, ""), {})

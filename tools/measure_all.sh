@@ -1,7 +1,7 @@
 # Refreshes everything under profiles/ on a GPU box: per workload the rocprofv3 kernel trace and the two PMC passes (MI355ENC_SERIAL=1 there:
 # counter collection serialises kernel dispatches, and a kernel that follows another kernel's progress cannot wait for one that is not
 # allowed to run beside it), then the bench lines of the workloads and the multi-stream runs.
-#   gpurun --timeout 1200 -- bash tools/measure_all.sh ROUND part      part: prof1 (1080p_ippp) | prof2 (2160p_ippp, 1080p_intra) | bench | price
+#   gpurun --timeout 1200 -- bash tools/measure_all.sh ROUND part      part: prof1 (1080p_ippp) | prof2 (2160p_ippp, 1080p_intra) | bench (the four workloads, then bench2) | bench2 (preset 2, QP-31 all-intra, several streams, two ranks) | price
 #   afterwards: cp gpurun_out/final/profiles/* profiles/
 set -e
 R=$PWD
@@ -32,6 +32,8 @@ bench)
     grep '^{' gpurun_out/final/bench_$wl.log | tail -1 > profiles/r0${RND}_bench_$wl.json
     echo "bench $wl done"
   done
+  bash tools/measure_all.sh $RND bench2 ;;
+bench2)
   # the toolset the reference's own files select (speed-preset=2: dct8x8 + i8x8 + aq-mode 1), and the all-intra workload at the headline's quantiser instead of the ladder's floor
   for wl in 1080p_ippp 2160p_ippp; do
     timeout -k 10 300 python bench.py --workload $wl --dct8x8 1 --i8x8 1 --aq 1 --no-gst-latency --no-cpu-baseline > gpurun_out/final/bench_${wl}_preset2.log 2>&1
