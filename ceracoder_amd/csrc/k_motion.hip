@@ -230,6 +230,8 @@ __global__ __launch_bounds__(64 * ME_MBS) void me_kernel(const frame_ctx_t cv, i
 // (px, py, sx, sy) alone, so where the field `prev` the previous iteration read gives the same four numbers (mode 2; mode 1: the
 // search's own selection, which used zeros) the previous result is copied and the surface is not read (on the S2 clip 9 of 10
 // macroblocks from the second iteration on).  mode 0: always recompute.
+// (r04 A/B: asking for the surface before the predictors -- one memory round trip a wave instead of two, the loads wasted where the macroblock copies -- gave 0.945 x at 1080p
+// and 0.99 x at 2160p, alternating processes: not kept.)
 __global__ __launch_bounds__(256) void me_select_kernel(const frame_ctx_t cv, int mb0, int mb1, const imv_t *__restrict__ in, imv_t *__restrict__ out,
                                                         const imv_t *__restrict__ prev, int mode) {
     const frame_ctx_t *__restrict__ ctx = &cv;
