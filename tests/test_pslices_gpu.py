@@ -192,3 +192,11 @@ def test_library_defaults_are_sliced_and_equal_oracle(E, oracle, w, h, n, depth)
         assert got[i] == oe.encode(y, uv, 30)[0], i
     assert np.array_equal(e.fetch(E.FETCH_RECON_Y), oe.recon_y)
     e.close()
+
+
+@pytest.mark.parametrize("reserve", ["40", "24,1"])
+def test_reserved_compute_units_switch_keeps_the_stream(E, oracle, monkeypatch, reserve):
+    """MI355ENC_RESERVE_CUS (development switch, read when an encoder is opened): the front and the intra stream are created with a compute-unit mask.  Placement
+    only -- the stream is the oracle's."""
+    monkeypatch.setenv("MI355ENC_RESERVE_CUS", reserve)
+    _run_stream(E, oracle, 1280, 720, 6, [30, 28, 33], 3, True, depth=2, exclusive=True, gop=30, check_dec=False)
