@@ -134,7 +134,7 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     h->cur = 0; h->have_ref = 0; h->frames_since_idr = 0; h->idr_count = 0; h->last_collected_rec = 0; h->last_slot = nullptr;
     for (int i = 0; i < NSET; i++) { h->g_intra[i] = h->g_deblock[i] = nullptr; h->d_ctx2[i] = nullptr; h->d_surf[i] = nullptr; h->d_idec2[i] = nullptr; h->d_mbi_set[i] = nullptr; h->d_levels_set[i] = nullptr; h->d_qp_off[i] = nullptr; }
     h->prev_slot = nullptr;
-    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->ustream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->ip_done_total = 0; h->d_row_done = nullptr; h->pmb_rows_total = 0; h->d_db_par = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
+    h->d_ctx = nullptr; h->d_pre_y = h->d_pre_uv = nullptr; memset(h->d_imv, 0, sizeof h->d_imv); h->d_psrc[0] = h->d_psrc[1] = nullptr; h->psrc_cur = 0; h->fstream = nullptr; h->ustream = nullptr; h->d_ip_progress = nullptr; h->d_ip_strips = nullptr; h->epoch = 0; h->istream = nullptr; h->ev_pmb = nullptr; h->d_db_gran = nullptr; h->d_db_done = nullptr; h->rec_epoch[0] = h->rec_epoch[1] = 0; h->db_started_total = 0; h->ip_done_total = 0; h->d_row_done = nullptr; h->pmb_rows_total = 0; h->d_db_par = nullptr; h->d_db_part = nullptr; h->d_ib_gran = nullptr; h->d_iband_done = nullptr; h->ev_dbI[0] = h->ev_dbI[1] = nullptr; h->dbI_busy[0] = h->dbI_busy[1] = 0; h->d_progress = nullptr; h->d_off = nullptr; h->d_isad = nullptr; h->d_dbrec = nullptr; h->d_idec = nullptr;
     h->cstream = nullptr; h->d_mbi = nullptr; h->d_levels = nullptr;
     memset(&h->st, 0, sizeof h->st);
     h->want_bps.store(cfg->bitrate_bps ? cfg->bitrate_bps : 2048000);
@@ -198,6 +198,10 @@ int mi355enc_open(const mi355enc_cfg_t *cfg, mi355enc_t **out) {
     HIPCHK(hipMalloc((void **)&h->d_progress, 4 * sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream)); // the error word is sticky: only cleared here
     HIPCHK(hipMalloc((void **)&h->d_db_par, k_deblock_partab_bytes(h->mbw, h->mbh)));
+    if (!getenv("MI355ENC_NO_SPLIT")) { // (A/B switch, read once per encoder)
+        HIPCHK(hipMalloc((void **)&h->d_db_part, 6 * (size_t)k_deblock_bands16(h->mbh) * sizeof(unsigned))); // two counters and two {cut, epoch} granules per band
+        HIPCHK(hipMemsetAsync(h->d_db_part, 0, 6 * (size_t)k_deblock_bands16(h->mbh) * sizeof(unsigned), h->stream));
+    }
     HIPCHK(hipMalloc((void **)&h->d_ib_gran, (size_t)h->mbh * h->mbw * 8 * sizeof(uint2)));
     HIPCHK(hipMemsetAsync(h->d_ib_gran, 0, (size_t)h->mbh * h->mbw * 8 * sizeof(uint2), h->stream));
     HIPCHK(hipMalloc((void **)&h->d_iband_done, 2 * (size_t)h->mbh * sizeof(unsigned))); // one word per macroblock row (intra_mode 2: per band), one set per reconstruction buffer: the next picture's wavefront runs beside this one's deblocking
@@ -326,6 +330,7 @@ void mi355enc_close(mi355enc_t *h) {
     if (h->d_db_done) (void)hipFree(h->d_db_done);
     if (h->d_row_done) (void)hipFree(h->d_row_done);
     if (h->d_db_par) (void)hipFree(h->d_db_par);
+    if (h->d_db_part) (void)hipFree(h->d_db_part);
     if (h->d_ib_gran) (void)hipFree(h->d_ib_gran);
     if (h->d_iband_done) (void)hipFree(h->d_iband_done);
     for (int i = 0; i < 2; i++) if (h->ev_dbI[i]) (void)hipEventDestroy(h->ev_dbI[i]);
@@ -392,6 +397,7 @@ int mi355enc_fetch(mi355enc_t *h, int what, void *dst, size_t n) {
     case MI355ENC_FETCH_PREFILTER_UV: src = h->d_pre_uv; need = h->csz; break;
     case MI355ENC_FETCH_MBINFO: src = h->last_slot ? h->last_slot->h_mbi : nullptr; need = (size_t)h->nmb * sizeof(mb_info_t); host = true; break;
     case MI355ENC_FETCH_LEVELS: src = h->last_slot ? h->d_levels_set[h->last_slot->set] : nullptr; need = (size_t)h->nmb * MB_LEVELS * 2; break; // dense, from HBM
+    case 102: src = h->d_db_part; need = h->d_db_part ? 6 * (size_t)k_deblock_bands16(h->mbh) * sizeof(unsigned) : 0; break; /* development: per band and plane the parts' counter, then {cut column, epoch} of the last launch */
     case 100: src = h->d_dbrec; need = (size_t)h->nmb * 64; break; /* development: deblocking records (cycle counters in -DD3_PROF builds) */
     case 101: src = h->d_isad; need = 1024; break;                 /* development: cycle counters of -DIB_PROF builds */
     default: return MI355ENC_ERR_ARG;

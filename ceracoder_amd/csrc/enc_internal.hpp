@@ -89,6 +89,7 @@ struct mi355enc {
     hipEvent_t ev_dbI[2];  // [reconstruction buffer]: the deblocking of an IDR picture that ran beside its intra wavefront on the intra stream has finished
     int dbI_busy[2];
     unsigned *d_db_par;   // the band deblocker's table of per-edge parameter words (written by its prologue, read by its movers)
+    unsigned *d_db_part;  // ... and, per band and plane, the count of band parts that have finished (P pictures walk every band as two workgroups: k_deblock.hip, "the cut"); null: bands are walked whole (MI355ENC_NO_SPLIT)
     unsigned *d_db_done;  // per reconstruction buffer: one word per band and plane, = the epoch of the picture whose deblocking of that band is complete
     unsigned *d_row_done;      // per macroblock row: macroblocks the gated P-stage launches have completed so far (the picture's deblocking launch waits for its rows)
     uint32_t pmb_rows_total;   // ... and what each of those counts reaches with the last gated launch enqueued

@@ -46,11 +46,11 @@ int run_intra(mi355enc_t *h, int ci, const frame_ctx_t *hc, unsigned *band_done)
 // whole picture on the main stream; hc: host copy of the context (by-value kernels), ci: which device copy holds the same (graph kernels)
 int run_deblock(mi355enc_t *h, int ci, const frame_ctx_t *hc, hipStream_t st, const unsigned *ip_progress, const unsigned *iband_done, unsigned *band_done, bool after_gated_pmb, unsigned row_need, bool fused_ip) {
     if (h->cfg.deblock_mode == 0) { // the persistent band kernel (its prologue derives the boundary strengths from the records)
-        k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, h->cfg.intra_mode == 2 ? k_intra_band_rows() : 1, band_done, h->d_progress + 1, after_gated_pmb ? h->d_row_done : nullptr, row_need ? row_need : h->pmb_rows_total,
-                               fused_ip ? h->d_ip_strips : nullptr, fused_ip ? h->d_progress + 2 : nullptr, h->d_progress + 3, h->qpc_total, st);
+        const int wgs = k_launch_deblock_bands(hc, h->mbh, 0, k_deblock_bands16(h->mbh), err_word(h), h->d_db_gran, h->d_db_par, ip_progress, iband_done, h->cfg.intra_mode == 2 ? k_intra_band_rows() : 1, band_done, h->d_progress + 1, after_gated_pmb ? h->d_row_done : nullptr, row_need ? row_need : h->pmb_rows_total,
+                                               fused_ip ? h->d_ip_strips : nullptr, fused_ip ? h->d_progress + 2 : nullptr, h->d_progress + 3, h->qpc_total, h->d_db_part, st);
         if (hc->qp_off) h->qpc_total += (uint32_t)h->mbh; // the QP_Y chain rides in the launch and counts the rows it has resolved
         if (fused_ip) h->ip_done_total += (uint32_t)h->mbh;
-        h->db_started_total += 2u * (unsigned)k_deblock_bands16(h->mbh);
+        h->db_started_total += (unsigned)wgs; // (two per band, or four where every band is walked as two parts)
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -375,6 +375,7 @@ static int recover(mi355enc_t *h, unsigned code) {
     { int r = sync_compute(h); if (r) return r; }
     HIPCHK(hipMemsetAsync(h->d_progress, 0, 4 * sizeof(unsigned), h->stream));
     HIPCHK(hipMemsetAsync(h->d_row_done, 0, (size_t)h->mbh * MI355_PROG_STRIDE * sizeof(unsigned), h->stream));
+    if (h->d_db_part) HIPCHK(hipMemsetAsync(h->d_db_part, 0, 6 * (size_t)k_deblock_bands16(h->mbh) * sizeof(unsigned), h->stream));
     HIPCHK(hipMemsetAsync(h->d_db_done, 0, 2 * k_deblock_done_bytes(), h->stream));
     HIPCHK(hipMemsetAsync(h->d_iband_done, 0, 2 * (size_t)h->mbh * sizeof(unsigned), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

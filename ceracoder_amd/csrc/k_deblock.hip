@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void deblock_kernel(const frame_ctx_t *__restri
 
 // ------------------------------------------------------------------ shared by the persistent band kernel
 struct edge_par { int alpha, beta; unsigned tc0; }; // tc0: three bytes, bS 1..3 (kept packed: an indexable array would live in scratch)
-struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; unsigned *band_done; unsigned *started; const unsigned *row_done; unsigned row_need; int nip; unsigned *ip_progress_w; uint8_t *ip_strips; unsigned *ip_done; unsigned *qpc; unsigned qpc_base; }; // qpc (adaptive quantisation): the launch's first workgroup resolves the QP_Y chain row by row and counts the rows there (qp_chain_rows) // nip > 0: the launch's first nip workgroups are the picture's intra macroblock rows (intra_p_row) // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
+struct db_args { frame_ctx_t ctx; unsigned *err; int band0, nb_total; uint2 *gran; const unsigned *ip_progress; unsigned *partab; const unsigned *iband_done; int ib_rows; unsigned *band_done; unsigned *started; const unsigned *row_done; unsigned row_need; int nip; unsigned *ip_progress_w; uint8_t *ip_strips; unsigned *ip_done; unsigned *qpc; unsigned qpc_base; unsigned *part_cnt; }; // qpc (adaptive quantisation): the launch's first workgroup resolves the QP_Y chain row by row and counts the rows there (qp_chain_rows) // nip > 0: the launch's first nip workgroups are the picture's intra macroblock rows (intra_p_row) // ip_progress: see GATED; partab: see the prologue // a launch covers bands band0 .. band0 + gridDim.x/2 - 1
 
 // =================================================================== deblocking, persistent: bands of rows in x + y order
 // One launch per picture instead of one per wavefront.  Two observations shorten the dependency chain:
@@ -382,7 +382,8 @@ DEV unsigned par_word(unsigned nib, unsigned ab, unsigned tcw) { return nib | (a
 // picture, and this kernel writes a macroblock's lines 0..11 once its row is three macroblocks further, its bottom lines
 // once the ROW BELOW is -- by which time the marks say that the intra macroblocks that read them are done.
 template <bool CHROMA, bool ALL_INTRA, int ROWS, bool GATED>
-DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds) {
+// part: -1 the band whole; 0 / 1 (a.part_cnt set): the band's left / right part, cut at a column where the filter does nothing (see "the cut" below)
+DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds, const int part) {
     constexpr int rows_mb = CHROMA ? 8 : 16, strip = CHROMA ? 2 : 4, ring_n = CHROMA ? 8 : 16;
     constexpr int ROW_LDS = CHROMA ? (int)sizeof(dbt_chroma) : (int)sizeof(dbt_luma);
     constexpr int TILE = rows_mb * 16, UPB = strip * 16;
@@ -469,8 +470,15 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     unsigned *partab = a.partab + (CHROMA ? (size_t)nb * ROWS * mbw * 32 : 0) + (size_t)band * ROWS * mbw * PARW;
     unsigned *flagw = (unsigned *)(lds + ROWS * ROW_LDS);   // [3]: band - 1, band, band + 1
     unsigned *firsti = flagw + 4;                           // [ROWS] (GATED): the first intra macroblock of each row of this band
+    unsigned *busyw = firsti + ROWS;                        // [2]: columns around the middle whose left macroblock edge has something to filter in some row of this band
     if (threadIdx.x < 3) flagw[threadIdx.x] = 0;
+    if (threadIdx.x < 2) busyw[threadIdx.x] = 0;
     if (GATED && threadIdx.x < ROWS) firsti[threadIdx.x] = (unsigned)mbw;
+    // The cut: every edge of a row reads what the edge before it wrote -- except across a vertical macroblock edge with bS = 0 in every row of the band; there the left and
+    // the right part share no filtered sample (column x0 behaves like a picture's first column, column x1 - 1 like its last), so two workgroups walk them side by side,
+    // each against the band above's strips of its own columns.  Both evaluate the same records and choose the same column: the one nearest the middle, within a quarter
+    // of the row; without one the left part walks the whole row and the right part has nothing to do.
+    const int cut_mid = mbw >> 1, cut_w = (mbw >> 2) < 31 ? (mbw >> 2) : 31;
     __syncthreads();
     {
         const dev_tables *T = &g_tab;
@@ -500,6 +508,10 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
 #pragma unroll
                 for (int q = 0; q < PARW / 4; q++) stg128(partab + (size_t)j * PARW + 4 * q, make_uint4(pw[4 * q], pw[4 * q + 1], pw[4 * q + 2], pw[4 * q + 3]));
                 if (work) flagw[1] = 1u;
+                if (part >= 0) {
+                    const int kc = j % mbw - (cut_mid - cut_w);
+                    if (kc >= 0 && kc <= 2 * cut_w && ((pw[0] | pw[1] | pw[2] | pw[3]) & 15u) != 0) atomicOr(&busyw[kc >> 5], 1u << (kc & 31)); // (vertical, edge 0, the four segments)
+                }
             }
         }
 #ifdef TL_PROF
@@ -528,9 +540,71 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the table's stores have left this CU before its movers load them
     __syncthreads();
+    // This band's lines are final in memory: tell the next picture's P stage, which may be running already (pmb_kernel's gate).  Release pattern: every storing wave
+    // drains, the workgroup meets, one lane writes this XCD's L2 back and publishes the epoch.  A band walked in two parts is done when both are: each part counts itself
+    // (an agent-scope add BEHIND its own release), and the one that finds the count odd -- the other part's add, hence its release, came first -- publishes for both.
+    auto publish = [&](const bool drained) {
+        if (!a.band_done) return;
+        if (!drained) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        if (part >= 0) {
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                flagw[3] = __hip_atomic_fetch_add(a.part_cnt + 2 * band + (CHROMA ? 1 : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u;
+            }
+            __syncthreads();
+            if (flagw[3] == 0) return; // (workgroup-uniform) the other part is still at work: it will publish
+        }
+        if (threadIdx.x < DB_DONE_COPIES) { // (one copy per poller group: a few thousand waves reading one word would make its memory channel a hot spot)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_sc1(a.band_done + DB_DONE_STRIDE * threadIdx.x + 2 * band + (CHROMA ? 1 : 0), ctx->epoch);
+        }
+    };
+    // (the cut of every band is left for the band below: {column, picture epoch}, one granule per band and plane behind the parts' counters)
+    uint2 *cutg = part >= 0 ? (uint2 *)(a.part_cnt + 2 * nb) + 2 * band + (CHROMA ? 1 : 0) : nullptr;
     if (!ALL_INTRA && flagw[1] == 0) { // nothing written here: the samples were final at the previous kernel boundary
-        if (a.band_done && threadIdx.x < DB_DONE_COPIES) st_sc1(a.band_done + DB_DONE_STRIDE * threadIdx.x + 2 * band + (CHROMA ? 1 : 0), ctx->epoch);
+        if (cutg && threadIdx.x == 0) st64_sc1(cutg, make_uint2(0u, ctx->epoch)); // (nobody below waits for this band's strips: no constraint)
+        publish(true);
         return;
+    }
+    int x0 = 0, x1 = mbw; // the columns this workgroup walks
+    if (part >= 0) {
+        int cut = mbw; // (workgroup-uniform: every thread reads the same words)
+        // The band above's cut: this band's must not lie to the left of it (below).  It is there as soon as that band's prologue is over -- the two run side by side.
+        int cut_up = 0;
+        if (!ALL_INTRA && db_has_top(ctx, band * ROWS) && flagw[0] != 0) {
+            if (threadIdx.x == 0) {
+                uint2 g;
+                int spins = 0;
+                while ((g = ld64_sc1(cutg - 2)).y != ctx->epoch) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > DB_SPIN_MAX) { st_sc1(a.err, 24u | ((unsigned)band << 8) | (CHROMA ? 0x8000u : 0u)); g.x = 0; break; } // bounded; the host reports the picture as failed
+                    if ((spins & 1023) == 0 && ld_sc1(a.err)) { g.x = 0; break; }
+                }
+                flagw[3] = g.x;
+            }
+            __syncthreads();
+            cut_up = (int)flagw[3];
+            __syncthreads(); // (flagw[3] is used again by publish)
+        }
+        if (!ALL_INTRA && mbw >= 16) {
+            // The free column nearest to the middle that is not to the LEFT of the band above's cut: the right part of a band can only start where the band above has
+            // published its strips, and a cut to the left of that band's leaves its first columns to that band's left part -- which reaches them last.  With cuts
+            // that never step left the left parts follow each other and the right parts follow each other at the usual distance.
+            int tgt = cut_w - (cut_w >> 3); // bit position in the window: a little left of the middle for a band that has nothing to keep to (the cuts below it can only step right)
+            const int lo = (cut_up > 0 && cut_up < mbw) ? cut_up - (cut_mid - cut_w) : 0; // (the band above walked whole, or idle: nothing to keep to)
+            tgt = tgt > lo ? tgt : lo;
+            const unsigned long long busy = (unsigned long long)busyw[0] | ((unsigned long long)busyw[1] << 32);
+            for (int d = 0; d <= 2 * cut_w && cut == mbw; d++) {
+                if (tgt + d <= 2 * cut_w && !((busy >> (tgt + d)) & 1ull)) cut = cut_mid - cut_w + tgt + d;
+                else if (tgt - d >= lo && tgt - d >= 0 && !((busy >> (tgt - d)) & 1ull)) cut = cut_mid - cut_w + tgt - d;
+            }
+        }
+        cut = __builtin_amdgcn_readfirstlane(cut); // an SGPR: read out of LDS the column is a vector value to the compiler, and every test against it in the step loops below a vector compare with exec-mask control flow (measured: the steps twice as long)
+        if (threadIdx.x == 0) st64_sc1(cutg, make_uint2((unsigned)cut, ctx->epoch)); // (both parts write the same granule)
+        if (part == 0) x1 = cut; else x0 = cut;
+        if (x0 >= x1) { publish(true); return; } // (the right part of a band without a cut)
     }
 #ifdef TL_PROF
     if (!CHROMA && band == 0 && threadIdx.x == 0) *((volatile unsigned long long *)ctx->dbrec + (ctx->epoch & 63) * 16 + 15) = wall_clock64(); // band 0: the prologue is over
@@ -548,7 +622,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     unsigned *pars = (unsigned *)(rowl + DBT_NB * (TILE + UPB));  // [4][PARW]: the parameter words of the macroblocks in flight
     uint8_t *tiles_up = lds + (r > 0 ? r - 1 : 0) * ROW_LDS;      // the row above's tiles
     const int keep = last_row ? rows_mb : rows_mb - strip;
-    const int t_end = mbw + ROWS + 1;
+    const int t_end = (x1 - x0) + ROWS + 1;
     // ---- per-role state
     const int k = lane >> 2, e = lane & 3;                        // filter lanes (luma): line / column k, edge e
     uint4 preA, preB; // mover: two macroblock loads in flight.  Deliberately not initialised: a phi with a constant at the loop header
@@ -583,8 +657,8 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     if (role == 0) {
         for (int t = -2; t <= t_last; t++) {
             DBT_T0();
-            const int x = t - 1 - r;
-            const bool act = row_ok && x >= 0 && x < mbw;
+            const int x = x0 + t - 1 - r;
+            const bool act = row_ok && x >= x0 && x < x1;
             // =========================================================== F: vertical edges | barrier | horizontal edges
                 uint8_t *tile = tiles + (x & (DBT_NB - 1)) * TILE;
                 if (act) {
@@ -602,7 +676,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                             const int nx = quad_next(s[2] | (s[3] << 8));
                             const unsigned hi = e == 3 ? (unsigned)(s[6] | (s[7] << 8)) : (unsigned)nx;
                             *qw = (unsigned)s[4] | ((unsigned)s[5] << 8) | (hi << 16);
-                            if (e == 0 && x > 0) *pw = pack4(s[0], s[1], s[2], s[3]);
+                            if (e == 0 && x > x0) *pw = pack4(s[0], s[1], s[2], s[3]);
                         }
                     } else if (lane < 32) {
                         const int kk = lane >> 2, c = (lane >> 1) & 1, ee = lane & 1; // line, plane, edge (luma edges 0 and 2)
@@ -610,7 +684,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                         uint8_t *pb = ee == 0 ? tl + kk * 16 + 12 + c : tile + kk * 16 + 4 + c, *qb = tile + kk * 16 + 8 * ee + c;
                         int p1 = pb[0], p0 = pb[2], q0 = qb[0], q1 = qb[2];
                         edge_chroma_p(par, p1, p0, q0, q1);
-                        if (ee != 0 || x > 0) pb[2] = (uint8_t)p0;
+                        if (ee != 0 || x > x0) pb[2] = (uint8_t)p0;
                         qb[0] = (uint8_t)q0;
                     }
                 }
@@ -652,11 +726,11 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
         int fin = GATED ? (int)firsti[r] : 0x7FFF;
         auto mstep = [&](const int t, uint4 &cur, uint2 &gpre) __attribute__((always_inline)) {
             DBT_T0();
-            const int x = t - 1 - r;
-            const bool act = row_ok && x >= 0 && x < mbw;
+            const int x = x0 + t - 1 - r;
+            const bool act = row_ok && x >= x0 && x < x1;
             // =========================================================== M: land macroblock x+1 | barrier | load macroblock x+3 (and the strip above x+1)
                 const int xm = x + 1, xl = x + 3;
-                const bool lands = row_ok && xm >= 0 && xm < mbw;
+                const bool lands = row_ok && xm >= x0 && xm < x1;
                 if (lands) {
                     if (rlane) *(uint4 *)(tiles + (xm & (DBT_NB - 1)) * TILE + lane * 16) = cur;
                     if (plane_l) *(uint4 *)(pars + (xm & 3) * PARW + 4 * (lane - 16)) = cur; // ... and its parameter words
@@ -694,7 +768,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                     // edges changes its right column, and its top edge the sample above that column's top -- the left column and the corner an intra
                     // macroblock at xl + 1 predicts from.  (The first form of the test was `> xl`: safe only as long as intra_p_kernel has a head start.)
                     const int need = xl + 2 < mbw ? xl + 2 : mbw;
-                    if (GATED && row_ok && xl >= 0 && xl < mbw && fin < need) {
+                    if (GATED && row_ok && xl >= x0 && xl < x1 && fin < need) {
                         const unsigned tag = (epoch & 0xFFFFFu) << 12; // IP_EPOCH of k_intra.hip
                         int spins = 0;
                         for (;;) {
@@ -714,16 +788,16 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
     } else {
         for (int t = -2; t <= t_last; t++) {
             DBT_T0();
-            const int x = t - 1 - r;
+            const int x = x0 + t - 1 - r;
             // =========================================================== S: store macroblock x-2 | barrier | publish the strip of macroblock x-1
             // Lines 0 .. keep-1 of macroblock x-2 and the strip above it became final with the barrier of the step before (this row's
             // vertical phase of x-1 patched its columns 12..15; the horizontal phase of x-2 finished the strip above): one LDS read
             // and one 16-byte store per lane, per-lane addresses.
             const int xs2 = x - 2;
 #ifdef DBG_DELAY_BAND /* adversarial-schedule build: the band's last four macroblocks of every row are written back long after its loop has ended (below) */
-            if (row_ok && xs2 >= 0 && xs2 < mbw && !(band == DBG_DELAY_BAND && xs2 >= mbw - 4 && lane < keep)) {
+            if (row_ok && xs2 >= x0 && xs2 < x1 && !(band == DBG_DELAY_BAND && xs2 >= mbw - 4 && lane < keep)) {
 #else
-            if (row_ok && xs2 >= 0 && xs2 < mbw) {
+            if (row_ok && xs2 >= x0 && xs2 < x1) {
 #endif
                 const bool is_row = lane < keep, is_up = uplane && dbtop;
                 const uint8_t *upb = fed ? ups + (xs2 & (DBT_NB - 1)) * UPB : tiles_up + (xs2 & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16;
@@ -734,7 +808,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
             BAND_BARRIER();
             DBT_TICK(1);
             const int xs = x - 1; // its bottom strip is final within this band now: the band below waits for it
-            if (feeds && xs >= 0 && xs < mbw && glane) {
+            if (feeds && xs >= x0 && xs < x1 && glane) {
                 const int j = lane - 32;
                 const unsigned w = *(const unsigned *)(tiles + (xs & (DBT_NB - 1)) * TILE + (rows_mb - strip) * 16 + 4 * j);
                 if (dn_work) st64_sc1(gran_my + (size_t)xs * ring_n + j, make_uint2(w, epoch));
@@ -743,8 +817,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
             DBT_TICK(2);
         }
     }
-    // ---- this band's lines are final in memory: tell the next picture's P stage, which may be running already (pmb_kernel's gate).
-    // Release pattern: every storing wave drains, the workgroup meets, one lane writes this XCD's L2 back and publishes the epoch.
+    // ---- this band's lines are final in memory (see publish above)
     if (a.band_done) {
 #ifdef DBG_DELAY_BAND /* adversarial-schedule build (tests/test_adversarial_gpu.py): this band's last macroblocks reach memory ~0.3 ms after its loop has
                          ended -- long after the bands below it, which only needed its strips, have published: a reader of the next picture that
@@ -755,13 +828,7 @@ DEV void rows3_body(const db_args &a, const int band, const int nb, uint8_t *lds
                 for (int xs2 = mbw - 4 > 0 ? mbw - 4 : 0; xs2 < mbw; xs2++) stg128(st_ptr + xs2 * 16, lds128(tiles + (xs2 & (DBT_NB - 1)) * TILE + lane * 16));
         }
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x < DB_DONE_COPIES) { // (one copy per poller group: a few thousand waves reading one word would make its memory channel a hot spot)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            st_sc1(a.band_done + DB_DONE_STRIDE * threadIdx.x + 2 * band + (CHROMA ? 1 : 0), epoch);
-        }
+        publish(false);
     }
     tl_last(ctx, 8);
 #ifdef TL_PROF
@@ -896,11 +963,13 @@ __global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a) {
         }
         bi -= a.nip; nwg -= a.nip;
     }
-    const int nl = nwg >> 1;
     if (bi == 0) tl_first(&a.ctx, 7);
     if (a.started && threadIdx.x == 0) __hip_atomic_fetch_add(a.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this workgroup holds its place on a CU (wait_started_kernel)
-    if (bi < nl) rows3_body<false, ALL_INTRA, ROWS, GATED>(a, a.band0 + bi, a.nb_total, lds);
-    else rows3_body<true, ALL_INTRA, ROWS, GATED>(a, a.band0 + bi - nl, a.nb_total, lds);
+    int part = -1;
+    if (!ALL_INTRA && !FUSED_IP && a.part_cnt) { part = bi & 1; bi >>= 1; nwg >>= 1; } // two workgroups per band: its left and its right part (rows3_body: the cut)
+    const int nl = nwg >> 1;
+    if (bi < nl) rows3_body<false, ALL_INTRA, ROWS, GATED>(a, a.band0 + bi, a.nb_total, lds, part);
+    else rows3_body<true, ALL_INTRA, ROWS, GATED>(a, a.band0 + bi - nl, a.nb_total, lds, part);
 }
 
 // =================================================================== launchers
@@ -920,10 +989,12 @@ size_t k_deblock_gran_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16
 // The band kernel may be launched in several pieces (bands [band0, band1)): a band only ever waits for the band above it.
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the movers follow its per-row progress words.
 template <typename K>
-static void launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStream_t s) {
-    constexpr size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + 16 + 4 * DB_ROWS; // the rows' tile rings + three work flags + the rows' first intra macroblocks: ~12.5 KB
+static int launch_bands(K kernel, const db_args &a, int nbands, int mbw, hipStream_t s) {
+    constexpr size_t lds = (size_t)DB_ROWS * sizeof(dbt_luma) + 16 + 4 * DB_ROWS + 8; // the rows' tile rings + three work flags (and the parts' hand-shake word) + the rows' first intra macroblocks + the cut's column mask: ~12.5 KB
     static_assert(lds <= 48 * 1024, "above 48 KB of dynamic LDS every instantiation launched here would need hipFuncAttributeMaxDynamicSharedMemorySize");
-    hipLaunchKernelGGL(kernel, dim3(2 * nbands + (a.nip > 0 ? a.nip : 0) + (a.qpc && a.nip <= 0 ? 1 : 0)), dim3(192 * DB_ROWS), lds, s, a);
+    const int wgs = (a.part_cnt ? 4 : 2) * nbands;
+    hipLaunchKernelGGL(kernel, dim3(wgs + (a.nip > 0 ? a.nip : 0) + (a.qpc && a.nip <= 0 ? 1 : 0)), dim3(192 * DB_ROWS), lds, s, a);
+    return wgs; // the workgroups that count themselves in a.started
 }
 // One wave that ends once `count` workgroups of band-deblocking launches have been placed since the encoder was opened (the count only
 // grows; the comparison is wrap-safe).  On a stream in front of a kernel whose workgroups wait for the deblocker's flags, it keeps
@@ -940,18 +1011,23 @@ __global__ __launch_bounds__(64) void wait_started_kernel(const unsigned *starte
 void k_launch_wait_started(const unsigned *d_started, unsigned count, unsigned *d_err, hipStream_t s) { hipLaunchKernelGGL(wait_started_kernel, dim3(1), dim3(64), 0, s, d_started, count, d_err); }
 size_t k_deblock_done_bytes(void) { return (size_t)DB_DONE_COPIES * DB_DONE_STRIDE * sizeof(unsigned); } // 2 words per band: up to 512 bands
 size_t k_deblock_partab_bytes(int mbw, int mbh) { return (size_t)k_deblock_bands16(mbh) * DB_ROWS * mbw * 48 * sizeof(unsigned); } // 32 luma + 16 chroma words per macroblock
-void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
-                            const unsigned *d_iband_done, int ib_rows, unsigned *d_band_done, unsigned *d_started, const unsigned *d_row_done, unsigned row_need,
-                            uint8_t *d_ip_strips, unsigned *d_ip_done, unsigned *d_qpc, unsigned qpc_base, hipStream_t s) {
+int k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
+                           const unsigned *d_iband_done, int ib_rows, unsigned *d_band_done, unsigned *d_started, const unsigned *d_row_done, unsigned row_need,
+                           uint8_t *d_ip_strips, unsigned *d_ip_done, unsigned *d_qpc, unsigned qpc_base, unsigned *d_part_cnt, hipStream_t s) {
     db_args a;
+    a.part_cnt = nullptr;
     a.ctx = *h_ctx; a.err = d_err; a.band0 = band0; a.nb_total = k_deblock_bands16(mbh); a.gran = d_gran; a.ip_progress = d_ip_progress; a.partab = d_partab; a.iband_done = d_iband_done; a.ib_rows = ib_rows > 0 ? ib_rows : DB_ROWS; a.band_done = d_band_done; a.started = d_started; a.row_done = d_row_done; a.row_need = row_need;
     a.nip = 0; a.ip_progress_w = nullptr; a.ip_strips = nullptr; a.ip_done = nullptr;
     a.qpc = (h_ctx->qp_off && band0 == 0) ? d_qpc : nullptr; a.qpc_base = qpc_base; // (a launch of all the picture's bands)
-    if (band1 <= band0) return;
-    if (h_ctx->all_intra) launch_bands(deblock_rows3_kernel<DB_ROWS, true, false, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
-    else if (d_ip_progress && d_ip_done && d_row_done && band0 == 0) { // the picture's intra macroblock rows lead the launch (pmb_kernel<GATED, ROWS> of the same picture still runs)
+    if (band1 <= band0) return 0;
+    if (h_ctx->all_intra) return launch_bands(deblock_rows3_kernel<DB_ROWS, true, false, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
+    if (d_ip_progress && d_ip_done && d_row_done && band0 == 0) { // the picture's intra macroblock rows lead the launch (pmb_kernel<GATED, ROWS> of the same picture still runs)
         a.nip = mbh; a.ip_progress_w = const_cast<unsigned *>(d_ip_progress); a.ip_strips = d_ip_strips; a.ip_done = d_ip_done;
-        launch_bands(deblock_rows3_kernel<DB_ROWS, false, true, true>, a, band1 - band0, h_ctx->mbw, s);
-    } else if (d_ip_progress) launch_bands(deblock_rows3_kernel<DB_ROWS, false, true, false>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel
-    else launch_bands(deblock_rows3_kernel<DB_ROWS, false, false, false>, a, band1 - band0, h_ctx->mbw, s);
+        return launch_bands(deblock_rows3_kernel<DB_ROWS, false, true, true>, a, band1 - band0, h_ctx->mbw, s);
+    }
+#ifndef DBG_DELAY_BAND /* (the adversarial-schedule build delays a band's last columns by their position in the whole row) */
+    if (band0 == 0 && band1 == a.nb_total && h_ctx->mbw >= 16) a.part_cnt = d_part_cnt; // P pictures, the whole picture in one launch: every band as two workgroups (rows3_body: the cut)
+#endif
+    if (d_ip_progress) return launch_bands(deblock_rows3_kernel<DB_ROWS, false, true, false>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel
+    return launch_bands(deblock_rows3_kernel<DB_ROWS, false, false, false>, a, band1 - band0, h_ctx->mbw, s);
 }

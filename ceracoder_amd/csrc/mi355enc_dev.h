@@ -124,14 +124,17 @@ int k_deblock_bands16(int mbh);
  // flags: per-band "has work" words of this picture's set
 // d_ip_progress (may be null): intra_p_kernel of the same picture is still running; the band kernel follows its per-row progress words
 // d_iband_done (may be null; all-intra pictures): the intra band kernel of the same picture is still running; a band waits for its flags
-void k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
+/* returns the number of workgroups that will count themselves in *d_started */
+int k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int band1, unsigned *d_err, uint2 *d_gran, unsigned *d_partab, const unsigned *d_ip_progress,
                             const unsigned *d_iband_done, int ib_rows /* rows per intra band */,
                             unsigned *d_band_done /* may be null: DB_DONE_COPIES x {luma, chroma} per band = the picture's epoch once the band is final in memory */,
                             unsigned *d_started /* may be null: counts the workgroups placed */,
                             const unsigned *d_row_done /* may be null: pmb_kernel<GATED> of this picture is still running; per macroblock row, it counts up to row_need */, unsigned row_need,
                             uint8_t *d_ip_strips, unsigned *d_ip_done /* both non-null (with d_ip_progress and d_row_done): the picture's intra macroblock rows run as the launch's
                                                                             leading workgroups; each counts itself in d_ip_done when its records and levels are in memory */,
-                            unsigned *d_qpc, unsigned qpc_base /* adaptive quantisation (h_ctx->qp_off): the launch's first workgroup resolves the QP_Y chain and counts the rows in *d_qpc from qpc_base */, hipStream_t s);
+                            unsigned *d_qpc, unsigned qpc_base /* adaptive quantisation (h_ctx->qp_off): the launch's first workgroup resolves the QP_Y chain and counts the rows in *d_qpc from qpc_base */,
+                            unsigned *d_part_cnt /* may be null; 2 words per band, zeroed once: P pictures walk every band as two workgroups, cut at a column where the filter does nothing;
+                                                    each part adds one when its lines are in memory (the counts only grow: two per band, plane and launch) */, hipStream_t s);
 int k_intra_band_rows(void);
 size_t k_deblock_partab_bytes(int mbw, int mbh); // scratch of the band kernel: one parameter word per (edge, segment) of every macroblock
 size_t k_deblock_gran_bytes(int mbw, int mbh);
