@@ -200,3 +200,36 @@ def test_reserved_compute_units_switch_keeps_the_stream(E, oracle, monkeypatch, 
     only -- the stream is the oracle's."""
     monkeypatch.setenv("MI355ENC_RESERVE_CUS", reserve)
     _run_stream(E, oracle, 1280, 720, 6, [30, 28, 33], 3, True, depth=2, exclusive=True, gop=30, check_dec=False)
+
+
+def test_bands_walked_whole_keep_the_stream(E, oracle, monkeypatch):
+    """MI355ENC_NO_SPLIT (A/B switch, read when an encoder is opened): every deblocking band as one workgroup per plane, the round-3 form.  Same stream."""
+    monkeypatch.setenv("MI355ENC_NO_SPLIT", "1")
+    _run_stream(E, oracle, 1920, 1080, 5, [30, 28, 33], 4, True, depth=2, exclusive=True, gop=30, check_dec=False)
+
+
+def test_bands_are_cut_where_the_filter_does_nothing(E):
+    """The default: a P picture's deblocking bands are walked as two workgroups, cut at a column with bS = 0 in every row of the band (k_deblock.hip, "the cut").  After a few
+    P pictures of the S2 clip most bands of the last launch carry a cut inside the row, tagged with that picture's epoch, and no cut lies left of the band above's
+    in the same slice.  (That the result is the oracle's is what every other test here checks; this one checks that the feature is at work.)"""
+    import ctypes as C
+    from ceracoder_amd import synth
+    w, h = 1920, 1080
+    e = E.Encoder(w, h, gop=60, fixed_qp=31, pipeline_depth=0, slices=None, slice_deblock=None, scenecut=False)
+    for y, uv in synth.s2_frames(w, h, 4):
+        e.submit(y, uv, pts=0)
+        e.collect(copy=False)
+    nb = (e.mbh + 3) // 4
+    buf = np.zeros(6 * nb, np.uint32)
+    assert e.L.mi355enc_fetch(e.h, 102, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == 0
+    rows = e.p_slice_rows
+    e.close()
+    cuts = buf[2 * nb:].reshape(nb, 2, 2)
+    assert len(set(cuts[:, :, 1].reshape(-1).tolist())) == 1, "every band of the last launch left its cut"
+    assert (buf[:2 * nb] % 2 == 0).all(), "both parts of every band have counted themselves"
+    for plane in range(2):
+        c = cuts[:, plane, 0].astype(int)
+        assert ((c >= e.mbw // 4) & (c < e.mbw)).sum() >= nb // 2, c
+        for b in range(1, nb):
+            if rows and (b * 4) % rows != 0 and c[b - 1] < e.mbw and c[b] < e.mbw:
+                assert c[b] >= c[b - 1], (b, c)
