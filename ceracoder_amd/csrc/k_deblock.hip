@@ -966,7 +966,7 @@ __global__ __launch_bounds__(192 * ROWS) void deblock_rows3_kernel(db_args a) {
     if (bi == 0) tl_first(&a.ctx, 7);
     if (a.started && threadIdx.x == 0) __hip_atomic_fetch_add(a.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // this workgroup holds its place on a CU (wait_started_kernel)
     int part = -1;
-    if (!ALL_INTRA && !FUSED_IP && a.part_cnt) { part = bi & 1; bi >>= 1; nwg >>= 1; } // two workgroups per band: its left and its right part (rows3_body: the cut)
+    if (!ALL_INTRA && a.part_cnt) { part = bi & 1; bi >>= 1; nwg >>= 1; } // two workgroups per band: its left and its right part (rows3_body: the cut)
     const int nl = nwg >> 1;
     if (bi < nl) rows3_body<false, ALL_INTRA, ROWS, GATED>(a, a.band0 + bi, a.nb_total, lds, part);
     else rows3_body<true, ALL_INTRA, ROWS, GATED>(a, a.band0 + bi - nl, a.nb_total, lds, part);
@@ -981,6 +981,9 @@ void k_launch_deblock_diag(const frame_ctx_t *d_ctx, int mbw, int mbh, int diag,
     if (y_hi < y_lo) return;
     hipLaunchKernelGGL(deblock_kernel, dim3(y_hi - y_lo + 1), dim3(64), 0, s, d_ctx, diag);
 }
+#ifndef DB_CUT_MIN_MBW
+#define DB_CUT_MIN_MBW 60 /* rows at least this long are walked in two parts (A/B, alternating processes: 2160p +6...9 %, 1080p +2 %, 720p +5 %, 640 x 368 -3 %: two workgroups' prologues cost more than twenty columns save) */
+#endif
 #ifndef DB_ROWS
 #define DB_ROWS MI355_BAND_ROWS /* rows per band: three waves per row, one row per SIMD (5 rows = 15 waves is equal on P pictures, a third slower on I pictures) */
 #endif
@@ -1021,13 +1024,13 @@ int k_launch_deblock_bands(const frame_ctx_t *h_ctx, int mbh, int band0, int ban
     a.qpc = (h_ctx->qp_off && band0 == 0) ? d_qpc : nullptr; a.qpc_base = qpc_base; // (a launch of all the picture's bands)
     if (band1 <= band0) return 0;
     if (h_ctx->all_intra) return launch_bands(deblock_rows3_kernel<DB_ROWS, true, false, false>, a, band1 - band0, h_ctx->mbw, s); // IDR pictures: every edge has work
+#ifndef DBG_DELAY_BAND /* (the adversarial-schedule build delays a band's last columns by their position in the whole row) */
+    if (band0 == 0 && band1 == a.nb_total && h_ctx->mbw >= DB_CUT_MIN_MBW) a.part_cnt = d_part_cnt; // P pictures, the whole picture in one launch: every band as two workgroups (rows3_body: the cut)
+#endif
     if (d_ip_progress && d_ip_done && d_row_done && band0 == 0) { // the picture's intra macroblock rows lead the launch (pmb_kernel<GATED, ROWS> of the same picture still runs)
         a.nip = mbh; a.ip_progress_w = const_cast<unsigned *>(d_ip_progress); a.ip_strips = d_ip_strips; a.ip_done = d_ip_done;
         return launch_bands(deblock_rows3_kernel<DB_ROWS, false, true, true>, a, band1 - band0, h_ctx->mbw, s);
     }
-#ifndef DBG_DELAY_BAND /* (the adversarial-schedule build delays a band's last columns by their position in the whole row) */
-    if (band0 == 0 && band1 == a.nb_total && h_ctx->mbw >= 16) a.part_cnt = d_part_cnt; // P pictures, the whole picture in one launch: every band as two workgroups (rows3_body: the cut)
-#endif
     if (d_ip_progress) return launch_bands(deblock_rows3_kernel<DB_ROWS, false, true, false>, a, band1 - band0, h_ctx->mbw, s); // beside intra_p_kernel
     return launch_bands(deblock_rows3_kernel<DB_ROWS, false, false, false>, a, band1 - band0, h_ctx->mbw, s);
 }
